@@ -1,0 +1,171 @@
+"""Workload generators for the BASELINE.json configs.
+
+`make_render_tree_100` restates examples/renderlist_100_common.nim:11-251 (the
+"300 boxes with shadows" demo): per copy one red elliptical-corner rect with a
+stroke, one green rect with a drop shadow (3-stop gradient on even copies) and
+one blue rect with a stroke and an inset shadow; then an elliptical orange
+pill, a 360x240 backdrop-blur node and a yellow overlay.
+
+The reference draws the two per-copy base positions from Nim's
+`initRand(12345)` (xoroshiro128+), which is not reproducible without a Nim
+runtime; they are drawn from PCG32(seed 12345) instead.  All
+other parameters are the closed-form float32 expressions of the reference.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+from .scene import (Fig, FigFlags, FigKind, FillGradientAxis, RenderList, Renders, RenderShadow, RenderStroke,
+                    ShadowStyle, fill, linear, rect, rgba)
+
+f32 = np.float32
+
+
+class PCG32:
+    """Minimal PCG-XSH-RR 64/32 (O'Neill 2014), used only to place the copies."""
+
+    def __init__(self, seed: int, seq: int = 54):
+        self.state = 0
+        self.inc = ((seq << 1) | 1) & 0xFFFFFFFFFFFFFFFF
+        self.next_u32()
+        self.state = (self.state + seed) & 0xFFFFFFFFFFFFFFFF
+        self.next_u32()
+
+    def next_u32(self) -> int:
+        old = self.state
+        self.state = (old * 6364136223846793005 + self.inc) & 0xFFFFFFFFFFFFFFFF
+        xorshifted = (((old >> 18) ^ old) >> 27) & 0xFFFFFFFF
+        rot = old >> 59
+        return ((xorshifted >> rot) | (xorshifted << ((-rot) & 31))) & 0xFFFFFFFF
+
+    def uniform(self, hi: float) -> np.float32:
+        return f32(f32(self.next_u32() >> 8) * f32(1.0 / 16777216.0) * f32(hi))
+
+
+def _sin(x):
+    return f32(math.sin(float(f32(x))))
+
+
+def _cos(x):
+    return f32(math.cos(float(f32(x))))
+
+
+def _u16(x) -> int:  # Nim uint16(float) truncates
+    return int(f32(x)) & 0xFFFF
+
+
+def make_render_tree_100(w: float, h: float, frame: int = 0, copies: int = 100, full_frame_blur: bool = False,
+                         seed: int = 12345) -> Renders:
+    w, h = f32(w), f32(h)
+    lst = RenderList()
+    t = f32(f32(frame) * f32(0.02))
+    lst.addRoot(Fig(kind=FigKind.nkRectangle, screenBox=rect(0, 0, w, h), fill=rgba(255, 255, 255, 155)))
+
+    redStartX, redStartY = f32(60), f32(60)
+    greenStartX, greenStartY = f32(320), f32(120)
+    blueStartX, blueStartY = f32(180), f32(300)
+    maxW, maxH = f32(260), f32(180)
+    maxX = max(f32(0), f32(w - (greenStartX + maxW)))
+    maxY = max(f32(0), f32(h - (blueStartY + maxH)))
+    rng = PCG32(seed)
+
+    for i in range(copies):
+        fi = f32(i)
+        baseX = rng.uniform(maxX)
+        baseY = rng.uniform(maxY)
+        jitterX = f32(_sin(t + fi * f32(0.15)) * f32(20))
+        jitterY = f32(_cos(t * f32(0.9) + fi * f32(0.2)) * f32(20))
+        offsetX = min(max(f32(baseX + jitterX), f32(0)), maxX)
+        offsetY = min(max(f32(baseY + jitterY), f32(0)), maxY)
+        sizePulseW = f32(f32(0.5) + f32(0.5) * _sin(t * f32(0.8) + fi * f32(0.07)))
+        sizePulseH = f32(f32(0.5) + f32(0.5) * _cos(t * f32(0.65) + fi * f32(0.09)))
+        redW = f32(f32(160) + f32(100) * sizePulseW)
+        redH = f32(f32(110) + f32(70) * sizePulseH)
+        greenW = f32(f32(160) + f32(100) * sizePulseH)
+        greenH = f32(f32(110) + f32(70) * sizePulseW)
+        blueW = f32(f32(160) + f32(100) * (f32(1) - sizePulseW))
+        blueH = f32(f32(110) + f32(70) * (f32(1) - sizePulseH))
+        cornerPulse = f32(f32(0.5) + f32(0.5) * _sin(t * f32(1.25) + fi * f32(0.11)))
+        c0 = f32(f32(4) + f32(26) * cornerPulse)
+        c1 = f32(f32(6) + f32(22) * (f32(1) - cornerPulse))
+        c2 = f32(f32(8) + f32(18) * (f32(0.5) + f32(0.5) * _sin(t * f32(0.7) + fi * f32(0.05))))
+        c3 = f32(f32(10) + f32(16) * (f32(0.5) + f32(0.5) * _cos(t * f32(0.8) + fi * f32(0.06))))
+        greenCornerPulse = f32(f32(0.5) + f32(0.5) * _cos(t * f32(0.95) + fi * f32(0.08)))
+        g0 = f32(f32(6) + f32(22) * greenCornerPulse)
+        g1 = f32(f32(8) + f32(18) * (f32(1) - greenCornerPulse))
+        g2 = f32(f32(10) + f32(16) * (f32(0.5) + f32(0.5) * _cos(t * f32(0.75) + fi * f32(0.04))))
+        g3 = f32(f32(12) + f32(14) * (f32(0.5) + f32(0.5) * _sin(t * f32(0.85) + fi * f32(0.05))))
+        shadowPulse = f32(f32(0.5) + f32(0.5) * _sin(t * f32(1.1) + fi * f32(0.05)))
+        shadowBlur = max(f32(0), f32(f32(6) + f32(18) * shadowPulse))
+        shadowSpread = max(f32(0), f32(f32(4) + f32(20) * (f32(1) - shadowPulse)))
+        shadowX = f32(f32(6) + f32(10) * _sin(t * f32(0.9) + fi * f32(0.03)))
+        shadowY = f32(f32(6) + f32(10) * _cos(t * f32(0.9) + fi * f32(0.03)))
+        insetPulse = f32(f32(0.5) + f32(0.5) * _sin(t * f32(1.05) + fi * f32(0.06)))
+        insetBlur = max(f32(0), f32(f32(8) + f32(10) * insetPulse))
+        insetSpread = max(f32(0), f32(f32(2) + f32(10) * (f32(1) - insetPulse)))
+        insetX = f32(f32(6) * _sin(t * f32(0.85) + fi * f32(0.04)))
+        insetY = f32(f32(6) * _cos(t * f32(0.8) + fi * f32(0.04)))
+        useGreenGradient = (i % 2) == 0
+        useBlueGradient = (i % 3) == 0
+
+        lst.addRoot(Fig(
+            kind=FigKind.nkRectangle,
+            corners=[_u16(c0), _u16(c1), _u16(c2), _u16(c3)],
+            cornerRadiiY=[_u16(c0), _u16(f32(c1 * f32(2))), _u16(c2), _u16(f32(c3 * f32(2)))],
+            flags=FigFlags.NfEllipticalCorners,
+            screenBox=rect(f32(redStartX + offsetX), f32(redStartY + offsetY), redW, redH),
+            fill=rgba(220, 40, 40, 155),
+            stroke=RenderStroke(weight=5.0, fill=fill(rgba(0, 0, 0, 155))),
+        ))
+        lst.addRoot(Fig(
+            kind=FigKind.nkRectangle,
+            screenBox=rect(f32(greenStartX + offsetX), f32(greenStartY + offsetY), greenW, greenH),
+            corners=[_u16(g0), _u16(g1), _u16(g2), _u16(g3)],
+            fill=(linear(rgba(18, 112, 64, 255), rgba(40, 180, 90, 255), rgba(78, 224, 188, 255),
+                         axis=FillGradientAxis.fgaX if (i % 4) < 2 else FillGradientAxis.fgaDiagTLBR, midPos=128)
+                  if useGreenGradient else fill(rgba(40, 180, 90, 155))),
+            shadows=[RenderShadow(style=ShadowStyle.DropShadow, blur=shadowBlur, spread=shadowSpread, x=shadowX,
+                                  y=shadowY, fill=fill(rgba(0, 0, 0, 155)))],
+        ))
+        lst.addRoot(Fig(
+            kind=FigKind.nkRectangle,
+            screenBox=rect(f32(blueStartX + offsetX), f32(blueStartY + offsetY), blueW, blueH),
+            fill=(linear(rgba(44, 72, 186, 255), rgba(60, 90, 220, 255), rgba(118, 168, 255, 255),
+                         axis=FillGradientAxis.fgaY if (i % 2) == 0 else FillGradientAxis.fgaDiagBLTR, midPos=132)
+                  if useBlueGradient else fill(rgba(60, 90, 220, 155))),
+            stroke=RenderStroke(weight=4.0, fill=fill(rgba(255, 255, 255, 210))),
+            shadows=[RenderShadow(
+                style=ShadowStyle.InnerShadow, blur=insetBlur, spread=insetSpread, x=insetX, y=insetY,
+                fill=(linear(rgba(25, 25, 40, 100), rgba(65, 65, 95, 180), axis=FillGradientAxis.fgaDiagBLTR)
+                      if useBlueGradient else fill(rgba(40, 40, 60, 150))))],
+        ))
+
+    lst.addRoot(Fig(
+        kind=FigKind.nkRectangle,
+        screenBox=rect(max(f32(20), f32(w - f32(200))), 20, 180, 100),
+        fill=rgba(238, 140, 30, 220),
+        corners=[90, 90, 90, 90], cornerRadiiY=[50, 50, 50, 50], flags=FigFlags.NfEllipticalCorners,
+        stroke=RenderStroke(weight=4.0, fill=fill(rgba(90, 45, 0, 220))),
+    ))
+
+    if full_frame_blur:
+        # one full-frame nkBackdropBlur(18) after the rects, before the overlay
+        lst.addRoot(Fig(kind=FigKind.nkBackdropBlur, screenBox=rect(0, 0, w, h), fill=rgba(0, 0, 0, 0), blur=18.0))
+
+    yellowW, yellowH, yellowMargin = f32(360), f32(240), f32(20)
+    yellowTravelX = max(f32(0), f32(w - yellowW - yellowMargin * f32(2)))
+    yellowTravelY = max(f32(0), f32(h - yellowH - yellowMargin * f32(2)))
+    yellowX = f32(yellowMargin + yellowTravelX * (f32(0.5) + f32(0.5) * _sin(t * f32(0.33))))
+    yellowY = f32(yellowMargin + yellowTravelY * (f32(0.5) + f32(0.5) * _cos(t * f32(0.41))))
+    yellowCorner = f32(f32(20) + f32(12) * (f32(0.5) + f32(0.5) * _sin(t * f32(0.7))))
+    yc = _u16(yellowCorner)
+    lst.addRoot(Fig(kind=FigKind.nkBackdropBlur, corners=[yc] * 4, screenBox=rect(yellowX, yellowY, yellowW, yellowH),
+                    fill=rgba(0, 0, 0, 0), blur=18.0))
+    lst.addRoot(Fig(kind=FigKind.nkRectangle, corners=[yc] * 4, screenBox=rect(yellowX, yellowY, yellowW, yellowH),
+                    fill=rgba(255, 225, 55, 120), stroke=RenderStroke(weight=6.0, fill=fill(rgba(95, 72, 0, 185)))))
+
+    out = Renders()
+    out.setLayer(0, lst)
+    return out

@@ -1,0 +1,1147 @@
+/* figdraw_oracle.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE (see figdraw_oracle.h).
+ *
+ * CPU restatement (plain C, float32, IEEE, no FMA contraction) of figdraw's
+ * node-list -> RGBA8 path.  Citations are relative to /root/reference/.
+ *
+ * Structure mirrors the GL implementation on purpose (one full-frame pass per
+ * draw, real R8 mask planes per nesting level, real full-frame blur textures,
+ * RGBA8 store after every draw) -- it is NOT structured like the HIP product
+ * (tile-binned, masks analytic, blur restricted to footprints), which is what
+ * makes HIP-vs-oracle parity meaningful.
+ *
+ * Third-party arithmetic that is not under /root/reference and is restated from
+ * its published definition ("parity unpinned" for these two items only):
+ *   - vmath (any version, figdraw.nimble:20): Mat4 column-major, rotateZ(a) =
+ *     [[cos,-sin],[sin,cos]] (vmath >= 2.0), translate/scale/ortho/inverse.
+ *   - pixie >= 5.0.1 Image.minifyBy2 used for atlas mip levels
+ *     (opengl/textures.nim:106-119): 2x2 box average, (sum+2) div 4.
+ */
+#include "figdraw_oracle.h"
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ------------------------------------------------------------------ small helpers */
+typedef struct { float x, y; } v2;
+typedef struct { float x, y, z, w; } v4;
+
+static inline float clampf(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); }
+static inline float minf(float a, float b) { return a < b ? a : b; }
+static inline float maxf(float a, float b) { return a > b ? a : b; }
+static inline float mixf(float a, float b, float t) { return a * (1.0f - t) + b * t; } /* GLSL mix */
+/* Nim math.round: half away from zero */
+static inline float nim_round(float x) { return x >= 0.0f ? floorf(x + 0.5f) : -floorf(-x + 0.5f); }
+/* GL unorm8 store: round to nearest */
+static inline uint8_t to_unorm8(float x) { return (uint8_t)floorf(clampf(x, 0.0f, 1.0f) * 255.0f + 0.5f); }
+static inline float from_unorm8(uint8_t v) { return (float)v / 255.0f; }
+
+/* 2D affine part of the vmath Mat4 transform stack: [a c tx; b d ty] acting on column vectors */
+typedef struct { float a, b, c, d, tx, ty; } Aff;
+static Aff aff_identity(void) { Aff m = {1, 0, 0, 1, 0, 0}; return m; }
+static Aff aff_mul(Aff m, Aff n) { /* m * n */
+  Aff r;
+  r.a = m.a * n.a + m.c * n.b;
+  r.b = m.b * n.a + m.d * n.b;
+  r.c = m.a * n.c + m.c * n.d;
+  r.d = m.b * n.c + m.d * n.d;
+  r.tx = m.a * n.tx + m.c * n.ty + m.tx;
+  r.ty = m.b * n.tx + m.d * n.ty + m.ty;
+  return r;
+}
+static v2 aff_apply(Aff m, float x, float y) { v2 r = {m.a * x + m.c * y + m.tx, m.b * x + m.d * y + m.ty}; return r; }
+static Aff aff_inverse(Aff m) {
+  float det = m.a * m.d - m.b * m.c;
+  float id = 1.0f / det;
+  Aff r;
+  r.a = m.d * id;
+  r.b = -m.b * id;
+  r.c = -m.c * id;
+  r.d = m.a * id;
+  r.tx = -(r.a * m.tx + r.c * m.ty);
+  r.ty = -(r.b * m.tx + r.d * m.ty);
+  return r;
+}
+
+/* ------------------------------------------------------------------ L5: glsl/atlas.frag restated */
+/* atlas.frag:51-69 */
+static float sd_rounded_box(float px, float py, float bx, float by, v4 r) {
+  float rr;
+  if (px > 0.0f) rr = (py > 0.0f) ? r.x : r.y;
+  else rr = (py > 0.0f) ? r.z : r.w;
+  float qx = fabsf(px) - bx + rr, qy = fabsf(py) - by + rr;
+  float mx = maxf(qx, 0.0f), my = maxf(qy, 0.0f);
+  return minf(maxf(qx, qy), 0.0f) + sqrtf(mx * mx + my * my) - rr;
+}
+/* atlas.frag:71-79 */
+static float sd_ellipse(float px, float py, float rx, float ry) {
+  float sx = maxf(rx, 0.000001f), sy = maxf(ry, 0.000001f);
+  float ax = px / sx, ay = py / sy;
+  float k0 = sqrtf(ax * ax + ay * ay);
+  if (k0 <= 0.000001f) return -minf(sx, sy);
+  float bx = px / (sx * sx), by = py / (sy * sy);
+  float k1 = sqrtf(bx * bx + by * by);
+  return k0 * (k0 - 1.0f) / maxf(k1, 0.000001f);
+}
+/* atlas.frag:81-86 */
+static float select_corner_radius(v4 r, float px, float py) {
+  if (px > 0.0f) return (py > 0.0f) ? r.x : r.y;
+  return (py > 0.0f) ? r.z : r.w;
+}
+/* atlas.frag:88-115 */
+static float sd_elliptical_rounded_box(float px, float py, float bx, float by, v4 packed) {
+  float sel = select_corner_radius(packed, px, py);
+  if (sel < 0.0f) {
+    float r = -sel - 1.0f;
+    v4 rr = {r, r, r, r};
+    return sd_rounded_box(px, py, bx, by, rr);
+  }
+  float pv = floorf(sel + 0.5f);
+  float rx = (pv - 4096.0f * floorf(pv / 4096.0f)) * bx / 4095.0f; /* mod(pv, 4096) */
+  float ry = floorf(pv / 4096.0f) * by / 4095.0f;
+  if (rx <= 0.0f || ry <= 0.0f) {
+    float qx = fabsf(px) - bx, qy = fabsf(py) - by;
+    float mx = maxf(qx, 0.0f), my = maxf(qy, 0.0f);
+    return minf(maxf(qx, qy), 0.0f) + sqrtf(mx * mx + my * my);
+  }
+  if (rx == ry) {
+    v4 rr = {rx, rx, rx, rx};
+    return sd_rounded_box(px, py, bx, by, rr);
+  }
+  float qx = fabsf(px) - bx + rx, qy = fabsf(py) - by + ry;
+  if (qx > 0.0f && qy > 0.0f) return sd_ellipse(qx, qy, rx, ry);
+  return maxf(qx - rx, qy - ry);
+}
+/* atlas.frag:211-216 */
+static float shadow_profile(float sd, float blur_radius) {
+  float sigma = maxf(0.5f * blur_radius, 0.5f);
+  float z = sd / sigma;
+  return expf(-0.5f * z * z);
+}
+/* atlas.frag:218-231 */
+static float linear3_t(int fill_mode, float u, float v) {
+  switch (fill_mode) {
+    case 1: return u;
+    case 2: return v;
+    case 3: return 0.5f * (u + v);
+    case 4: return 0.5f * (u + (1.0f - v));
+    default: return 0.0f;
+  }
+}
+static float median3(float a, float b, float c) { return maxf(minf(a, b), minf(maxf(a, b), c)); } /* atlas.frag:41-43 */
+
+/* ------------------------------------------------------------------ L4 state */
+#define FO_MAX_MASKS 16
+#define FO_MAX_MATS 256
+#define FO_MAX_MIPS 14
+
+typedef struct { int64_t key; float x, y, w, h; /* UV units */ int used; } AtlasEntry;
+
+typedef struct {
+  int kind; /* 1 = fast (analytic), 2 = mask texture */
+  v4 params, radii, matx, maty;
+} RectMask;
+
+typedef struct {
+  char* buf;
+  size_t len, cap;
+  int on, first;
+} Recorder;
+
+struct FoCtx {
+  int W, H;
+  uint8_t* fb;                    /* RGBA8 top-down */
+  uint8_t* mask[FO_MAX_MASKS];    /* R8 planes, index 0 unused ("white", never sampled) */
+  uint8_t *backdrop, *backdrop_tmp;
+  int mask_write, mask_begun, frame_begun;
+  RectMask rect_masks[FO_MAX_MASKS];
+  int n_rect_masks;
+  Aff mat, mats[FO_MAX_MATS];
+  int n_mats;
+  float aa, pixel_scale, ui_scale;
+  int subpixel_enabled;
+  float subpixel_shift;
+  /* atlas */
+  int atlas_size, atlas_margin, n_mips;
+  uint8_t* atlas[FO_MAX_MIPS];
+  uint16_t* heights;
+  AtlasEntry* entries;
+  int n_entries, cap_entries;
+  Recorder rec;
+};
+
+static int g_threads = 1;
+void fo_set_threads(int n) { g_threads = n < 1 ? 1 : n; }
+void fo_set_ui_scale(FoCtx* c, float s) { c->ui_scale = s; }
+int fo_sizeof_fig(void) { return (int)sizeof(FoFig); }
+int fo_sizeof_glyph(void) { return (int)sizeof(FoGlyph); }
+
+/* ------------------------------------------------------------------ recorder */
+static void rec_printf(FoCtx* c, const char* fmt, ...) {
+  Recorder* r = &c->rec;
+  if (!r->on) return;
+  for (;;) {
+    va_list ap;
+    va_start(ap, fmt);
+    int n = vsnprintf(r->buf + r->len, r->cap - r->len, fmt, ap);
+    va_end(ap);
+    if (n >= 0 && (size_t)n < r->cap - r->len) { r->len += (size_t)n; return; }
+    r->cap = r->cap ? r->cap * 2 : 4096;
+    r->buf = (char*)realloc(r->buf, r->cap);
+  }
+}
+static void rec_open(FoCtx* c, const char* name) {
+  if (!c->rec.on) return;
+  rec_printf(c, "%s[\"%s\"", c->rec.first ? "" : ",\n", name);
+  c->rec.first = 0;
+}
+static void rec_f(FoCtx* c, double v) { rec_printf(c, ",%.9g", v); }
+static void rec_i(FoCtx* c, long long v) { rec_printf(c, ",%lld", v); }
+static void rec_fv(FoCtx* c, const float* v, int n) {
+  rec_printf(c, ",[");
+  for (int i = 0; i < n; i++) rec_printf(c, "%s%.9g", i ? "," : "", (double)v[i]);
+  rec_printf(c, "]");
+}
+static void rec_col(FoCtx* c, FoColor k) { rec_printf(c, ",[%d,%d,%d,%d]", k.r, k.g, k.b, k.a); }
+static void rec_cols(FoCtx* c, const FoColor k[4]) {
+  rec_printf(c, ",[");
+  for (int i = 0; i < 4; i++) rec_printf(c, "%s[%d,%d,%d,%d]", i ? "," : "", k[i].r, k[i].g, k[i].b, k[i].a);
+  rec_printf(c, "]");
+}
+static void rec_close(FoCtx* c) { rec_printf(c, "]"); }
+void fo_record_begin(FoCtx* c) {
+  c->rec.on = 1;
+  c->rec.first = 1;
+  c->rec.len = 0;
+  rec_printf(c, "[");
+}
+const char* fo_record_json(FoCtx* c) {
+  if (!c->rec.on) return "[]";
+  rec_printf(c, "\n]");
+  c->rec.on = 0;
+  return c->rec.buf;
+}
+
+/* ------------------------------------------------------------------ context */
+FoCtx* fo_create(int atlas_size, float pixel_scale) {
+  FoCtx* c = (FoCtx*)calloc(1, sizeof(FoCtx));
+  c->atlas_size = atlas_size > 0 ? atlas_size : 1024; /* newContext defaults glcontext.nim:255-261 */
+  c->atlas_margin = 4;
+  c->pixel_scale = pixel_scale;
+  c->ui_scale = 1.0f;
+  c->aa = 1.2f; /* DefaultSdfAaFactor figbackend.nim:34 */
+  c->mat = aff_identity();
+  c->heights = (uint16_t*)calloc((size_t)c->atlas_size, sizeof(uint16_t));
+  int s = c->atlas_size, l = 0;
+  while (s >= 1 && l < FO_MAX_MIPS) {
+    c->atlas[l] = (uint8_t*)calloc((size_t)s * s * 4, 1);
+    l++;
+    if (s == 1) break;
+    s /= 2;
+  }
+  c->n_mips = l;
+  return c;
+}
+static void free_frame(FoCtx* c) {
+  free(c->fb);
+  free(c->backdrop);
+  free(c->backdrop_tmp);
+  c->fb = c->backdrop = c->backdrop_tmp = NULL;
+  for (int i = 0; i < FO_MAX_MASKS; i++) { free(c->mask[i]); c->mask[i] = NULL; }
+}
+void fo_destroy(FoCtx* c) {
+  if (!c) return;
+  free_frame(c);
+  for (int i = 0; i < FO_MAX_MIPS; i++) free(c->atlas[i]);
+  free(c->heights);
+  free(c->entries);
+  free(c->rec.buf);
+  free(c);
+}
+
+/* transforms: glcontext.nim:1991-2017 */
+void fo_save_transform(FoCtx* c) { rec_open(c, "save_transform"); rec_close(c); if (c->n_mats < FO_MAX_MATS) c->mats[c->n_mats++] = c->mat; }
+void fo_restore_transform(FoCtx* c) { rec_open(c, "restore_transform"); rec_close(c); if (c->n_mats > 0) c->mat = c->mats[--c->n_mats]; }
+void fo_translate(FoCtx* c, float x, float y) {
+  rec_open(c, "translate"); rec_f(c, x); rec_f(c, y); rec_close(c);
+  Aff t = {1, 0, 0, 1, x, y};
+  c->mat = aff_mul(c->mat, t);
+}
+void fo_rotate(FoCtx* c, float a) {
+  rec_open(c, "rotate"); rec_f(c, a); rec_close(c);
+  float cs = cosf(a), sn = sinf(a);
+  Aff r = {cs, sn, -sn, cs, 0, 0}; /* vmath rotateZ: col0=(cos,sin) col1=(-sin,cos) */
+  c->mat = aff_mul(c->mat, r);
+}
+void fo_scale(FoCtx* c, float sx, float sy) {
+  rec_open(c, "scale"); rec_f(c, sx); rec_f(c, sy); rec_close(c);
+  Aff s = {sx, 0, 0, sy, 0, 0};
+  c->mat = aff_mul(c->mat, s);
+}
+void fo_apply_transform(FoCtx* c, const float m[16]) {
+  rec_open(c, "apply_transform"); rec_fv(c, m, 16); rec_close(c);
+  /* column-major Mat4; `ctx.mat * vec3(x, y, 0)` (glcontext.nim:905-906) only uses the 2D affine part */
+  Aff n = {m[0], m[1], m[4], m[5], m[12], m[13]};
+  c->mat = aff_mul(c->mat, n);
+}
+void fo_set_aa_factor(FoCtx* c, float aa) { rec_open(c, "set_aa_factor"); rec_f(c, aa); rec_close(c); c->aa = aa; }
+void fo_set_text_subpixel(FoCtx* c, int enabled, float shift) { c->subpixel_enabled = enabled; c->subpixel_shift = shift; }
+
+/* beginFrame: glcontext.nim:2080-2092, 1951-1980 */
+void fo_begin_frame(FoCtx* c, int w, int h, int clear, const float rgba[4]) {
+  rec_open(c, "begin_frame"); rec_i(c, clear); rec_fv(c, rgba, 4); rec_close(c);
+  if (w != c->W || h != c->H || !c->fb) {
+    free_frame(c);
+    c->W = w;
+    c->H = h;
+    c->fb = (uint8_t*)calloc((size_t)w * h * 4, 1);
+    c->backdrop = (uint8_t*)calloc((size_t)w * h * 4, 1);
+    c->backdrop_tmp = (uint8_t*)calloc((size_t)w * h * 4, 1);
+  }
+  if (clear) {
+    uint8_t k[4] = {to_unorm8(rgba[0]), to_unorm8(rgba[1]), to_unorm8(rgba[2]), to_unorm8(rgba[3])};
+    for (size_t i = 0; i < (size_t)w * h; i++) memcpy(c->fb + i * 4, k, 4);
+  }
+  c->frame_begun = 1;
+  c->n_rect_masks = 0;
+  c->mask_write = 0;
+  c->mask_begun = 0;
+}
+void fo_end_frame(FoCtx* c) { rec_open(c, "end_frame"); rec_close(c); c->frame_begun = 0; }
+
+/* ------------------------------------------------------------------ radii packing: glcontext.nim:745-817 */
+static float clamp_radius(float r, float m) { return r <= 0.0f ? 0.0f : nim_round(maxf(1.0f, minf(r, m))); }
+void fo_rounded_radii_vec(const float rx[4], const float ry[4], float hx, float hy, float out[4], int* elliptical) {
+  enum { TL = 0, TR = 1, BL = 2, BR = 3 };
+  int circular = 1;
+  for (int i = 0; i < 4; i++) if (rx[i] != ry[i]) circular = 0;
+  if (circular) {
+    float m = minf(hx, hy);
+    out[0] = clamp_radius(rx[TR], m);
+    out[1] = clamp_radius(rx[BR], m);
+    out[2] = clamp_radius(rx[TL], m);
+    out[3] = clamp_radius(rx[BL], m);
+    *elliptical = 0;
+    return;
+  }
+  float cm = minf(hx, hy);
+  static const int order[4] = {TR, BR, TL, BL};
+  for (int k = 0; k < 4; k++) {
+    int i = order[k];
+    float cx = clamp_radius(rx[i], hx), cy = clamp_radius(ry[i], hy);
+    float v;
+    if (rx[i] == ry[i]) v = -(clamp_radius(rx[i], cm) + 1.0f);
+    else if (cx == cy) v = -(cx + 1.0f);
+    else {
+      float qx = nim_round(clampf(cx / maxf(hx, 0.000001f), 0.0f, 1.0f) * 4095.0f);
+      float qy = nim_round(clampf(cy / maxf(hy, 0.000001f), 0.0f, 1.0f) * 4095.0f);
+      v = qx + qy * 4096.0f;
+    }
+    out[k] = v;
+  }
+  *elliptical = 1;
+}
+
+/* ------------------------------------------------------------------ fills: figbackend.nim:96-183 */
+static FoColor lerp_color(FoColor a, FoColor b, float t) { /* figbackend.nim:129-136 */
+  float ct = clampf(t, 0.0f, 1.0f), it = 1.0f - ct;
+  FoColor r;
+  r.r = (uint8_t)nim_round((float)a.r * it + (float)b.r * ct);
+  r.g = (uint8_t)nim_round((float)a.g * it + (float)b.g * ct);
+  r.b = (uint8_t)nim_round((float)a.b * it + (float)b.b * ct);
+  r.a = (uint8_t)nim_round((float)a.a * it + (float)b.a * ct);
+  return r;
+}
+static float fill_mid_pos01(const FoFill* f) { return clampf((float)f->mid_pos / 255.0f, 0.01f, 0.99f); } /* figbackend.nim:125 */
+static FoColor sample_color(const FoFill* f, float t) { /* figbackend.nim:138-153 */
+  if (f->kind == FO_FILL_COLOR) return f->start;
+  if (f->kind == FO_FILL_LINEAR2) return lerp_color(f->start, f->stop, t);
+  float ct = clampf(t, 0.0f, 1.0f), mid = fill_mid_pos01(f);
+  if (ct <= mid) return lerp_color(f->start, f->mid, ct / mid);
+  return lerp_color(f->mid, f->stop, (ct - mid) / (1.0f - mid));
+}
+void fo_gradient_colors(const FoFill* f, FoColor out[4]) { /* figbackend.nim:161-183; order BL,BR,TR,TL */
+  int axis = f->kind == FO_FILL_COLOR ? FO_AXIS_X : f->axis;
+  static const float T[4][4] = {{0, 1, 1, 0}, {1, 1, 0, 0}, {0.5f, 1, 0.5f, 0}, {0, 0.5f, 1, 0.5f}};
+  for (int i = 0; i < 4; i++) out[i] = sample_color(f, T[axis][i]);
+}
+static uint8_t fill_alpha_max(const FoFill* f) { /* figrender.nim:587-594 */
+  if (f->kind == FO_FILL_COLOR) return f->start.a;
+  if (f->kind == FO_FILL_LINEAR2) return f->start.a > f->stop.a ? f->start.a : f->stop.a;
+  uint8_t m = f->start.a > f->mid.a ? f->start.a : f->mid.a;
+  return m > f->stop.a ? m : f->stop.a;
+}
+
+/* ------------------------------------------------------------------ texture sampling */
+/* GL_LINEAR, clamp-to-edge RGBA8 fetch at texel-space coordinate (x,y) = s*W-0.5 */
+static void bilinear_rgba8_clamp(const uint8_t* tex, int W, int H, float x, float y, float out[4]) {
+  float fx = floorf(x), fy = floorf(y);
+  float ax = x - fx, ay = y - fy;
+  int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
+  if (x0 < 0) x0 = 0; if (x0 > W - 1) x0 = W - 1;
+  if (x1 < 0) x1 = 0; if (x1 > W - 1) x1 = W - 1;
+  if (y0 < 0) y0 = 0; if (y0 > H - 1) y0 = H - 1;
+  if (y1 < 0) y1 = 0; if (y1 > H - 1) y1 = H - 1;
+  const uint8_t *p00 = tex + ((size_t)y0 * W + x0) * 4, *p10 = tex + ((size_t)y0 * W + x1) * 4;
+  const uint8_t *p01 = tex + ((size_t)y1 * W + x0) * 4, *p11 = tex + ((size_t)y1 * W + x1) * 4;
+  for (int k = 0; k < 4; k++) {
+    float top = from_unorm8(p00[k]) * (1.0f - ax) + from_unorm8(p10[k]) * ax;
+    float bot = from_unorm8(p01[k]) * (1.0f - ax) + from_unorm8(p11[k]) * ax;
+    out[k] = top * (1.0f - ay) + bot * ay;
+  }
+}
+/* GL_LINEAR, GL_REPEAT (atlas default wrap, glcontext.nim:157-169) */
+static void bilinear_rgba8_repeat(const uint8_t* tex, int S, float x, float y, float out[4]) {
+  float fx = floorf(x), fy = floorf(y);
+  float ax = x - fx, ay = y - fy;
+  int x0 = ((int)fx % S + S) % S, y0 = ((int)fy % S + S) % S;
+  int x1 = (x0 + 1) % S, y1 = (y0 + 1) % S;
+  const uint8_t *p00 = tex + ((size_t)y0 * S + x0) * 4, *p10 = tex + ((size_t)y0 * S + x1) * 4;
+  const uint8_t *p01 = tex + ((size_t)y1 * S + x0) * 4, *p11 = tex + ((size_t)y1 * S + x1) * 4;
+  for (int k = 0; k < 4; k++) {
+    float top = from_unorm8(p00[k]) * (1.0f - ax) + from_unorm8(p10[k]) * ax;
+    float bot = from_unorm8(p01[k]) * (1.0f - ax) + from_unorm8(p11[k]) * ax;
+    out[k] = top * (1.0f - ay) + bot * ay;
+  }
+}
+/* texture(atlasTex, uv): LINEAR_MIPMAP_LINEAR min / LINEAR mag; rho from the quad's
+ * (per-triangle constant) uv derivatives, in level-0 texels per pixel. */
+static void sample_atlas(const FoCtx* c, float u, float v, float rho, int lod0_only, float out[4]) {
+  int S = c->atlas_size;
+  float lambda = (lod0_only || rho <= 0.0f) ? 0.0f : log2f(rho);
+  if (lambda <= 0.0f || c->n_mips < 2) {
+    bilinear_rgba8_repeat(c->atlas[0], S, u * (float)S - 0.5f, v * (float)S - 0.5f, out);
+    return;
+  }
+  float maxl = (float)(c->n_mips - 1);
+  if (lambda > maxl) lambda = maxl;
+  int l0 = (int)floorf(lambda);
+  int l1 = l0 + 1 > c->n_mips - 1 ? c->n_mips - 1 : l0 + 1;
+  float f = lambda - (float)l0;
+  float a[4], b[4];
+  int S0 = S >> l0, S1 = S >> l1;
+  bilinear_rgba8_repeat(c->atlas[l0], S0, u * (float)S0 - 0.5f, v * (float)S0 - 0.5f, a);
+  bilinear_rgba8_repeat(c->atlas[l1], S1, u * (float)S1 - 0.5f, v * (float)S1 - 0.5f, b);
+  for (int k = 0; k < 4; k++) out[k] = a[k] * (1.0f - f) + b[k] * f;
+}
+
+/* ------------------------------------------------------------------ one quad through the pipeline */
+typedef struct {
+  v2 pos[4], uv[4];  /* vertex order BL,BR,TR,TL (glcontext.nim:1498-1509) */
+  v4 col[4];         /* unorm8 -> float */
+  v4 mid, stop;
+  v4 params, radii;
+  int mode_word;
+  float factor0, factor1;
+  float subpixel_shift;
+} Quad;
+
+typedef struct { float u, v; v4 col; float rho; float fw_u, fw_v; } Frag;
+
+/* atlas_rect_mask.frag:222-237 */
+static float rect_mask_alpha(const RectMask* rm, float aa, float px, float py) {
+  if (rm->params.z < 0.0f || rm->params.w < 0.0f) return 1.0f;
+  float lx = (rm->matx.x * px + rm->matx.y * py) + rm->matx.z;
+  float ly = (rm->maty.x * px + rm->maty.y * py) + rm->maty.z;
+  float qx = lx - rm->params.x, qy = ly - rm->params.y;
+  float dist = rm->maty.w > 0.5f ? sd_elliptical_rounded_box(qx, -qy, rm->params.z, rm->params.w, rm->radii)
+                                 : sd_rounded_box(qx, -qy, rm->params.z, rm->params.w, rm->radii);
+  return 1.0f - clampf(aa * dist + 0.5f, 0.0f, 1.0f);
+}
+
+/* mask.frag:186-234 -> scalar alpha (fragColor = vec4(alpha)) */
+static float shade_mask(const FoCtx* c, const Quad* q, const Frag* f) {
+  int word = q->mode_word;
+  int fill_mode = word / 256;
+  int mode = word - fill_mode * 256;
+  int ellip = mode >= 128;
+  if (ellip) mode -= 128;
+  float alpha;
+  if (mode == 0) {
+    float t[4];
+    sample_atlas(c, f->u, f->v, f->rho, 0, t);
+    alpha = t[3] * f->col.w;
+  } else {
+    float px = (f->u - 0.5f) * 2.0f * q->params.x, py = (f->v - 0.5f) * 2.0f * q->params.y;
+    float dist = ellip ? sd_elliptical_rounded_box(px, -py, q->params.z, q->params.w, q->radii)
+                       : sd_rounded_box(px, -py, q->params.z, q->params.w, q->radii);
+    if (mode == 12) {
+      float hw = maxf(q->factor0, 0.0f) * 0.5f;
+      dist = fabsf(dist + hw) - hw;
+    }
+    float cl = clampf(c->aa * dist + 0.5f, 0.0f, 1.0f);
+    alpha = (1.0f - cl) * f->col.w;
+  }
+  return alpha;
+}
+
+/* atlas.frag:252-399 -> fragColor before the mask multiply.  (x,y) = integer pixel (for mode 17) */
+static v4 shade_main(const FoCtx* c, const Quad* q, const Frag* f, int x, int y) {
+  int word = q->mode_word;
+  int fill_mode = word / 256;
+  int mode = word - fill_mode * 256;
+  int ellip = mode >= 128;
+  if (ellip) mode -= 128;
+  float qhx = q->params.x, qhy = q->params.y;
+  int inset = mode == 9;
+  float shx = inset ? qhx : q->params.z, shy = inset ? qhy : q->params.w;
+  float px = (f->u - 0.5f) * 2.0f * qhx, py = (f->v - 0.5f) * 2.0f * qhy;
+  float dist = ellip ? sd_elliptical_rounded_box(px, -py, shx, shy, q->radii) : sd_rounded_box(px, -py, shx, shy, q->radii);
+  float sdf_factor = q->factor0;
+  float sdf_spread = fill_mode == 0 ? q->factor1 : 0.0f;
+  /* evalFillColor atlas.frag:233-250 */
+  v4 fc = f->col;
+  if (fill_mode != 0) {
+    float t = clampf(linear3_t(fill_mode, f->u, f->v), 0.0f, 1.0f);
+    float mid = clampf(q->factor1, 0.01f, 0.99f);
+    if (t <= mid) {
+      float k = t / mid;
+      fc.x = mixf(f->col.x, q->mid.x, k); fc.y = mixf(f->col.y, q->mid.y, k);
+      fc.z = mixf(f->col.z, q->mid.z, k); fc.w = mixf(f->col.w, q->mid.w, k);
+    } else {
+      float k = (t - mid) / (1.0f - mid);
+      fc.x = mixf(q->mid.x, q->stop.x, k); fc.y = mixf(q->mid.y, q->stop.y, k);
+      fc.z = mixf(q->mid.z, q->stop.z, k); fc.w = mixf(q->mid.w, q->stop.w, k);
+    }
+  }
+  float alpha = 0.0f;
+  v4 out;
+  if (mode == 0) { /* atlas.frag:284-295 */
+    float u = f->u;
+    if (c->subpixel_enabled) u -= q->subpixel_shift * (1.0f / maxf((float)c->atlas_size, 1.0f));
+    float t[4];
+    sample_atlas(c, u, f->v, f->rho, 0, t);
+    out.x = t[0] * f->col.x; out.y = t[1] * f->col.y; out.z = t[2] * f->col.z; out.w = t[3] * f->col.w;
+    return out;
+  }
+  if (mode >= 13 && mode <= 16) { /* atlas.frag:296-318 */
+    float t[4];
+    sample_atlas(c, f->u, f->v, 0.0f, 1, t); /* textureLod(atlasTex, uv, 0.0) */
+    int is_mtsdf = (mode == 14 || mode == 16), is_stroke = (mode == 15 || mode == 16);
+    float sd = is_mtsdf ? t[3] : median3(t[0], t[1], t[2]);
+    /* msdfScreenPxRange atlas.frag:45-49 */
+    float unit = q->factor0 / (float)c->atlas_size;
+    float spr = maxf(0.5f * (unit * (1.0f / f->fw_u) + unit * (1.0f / f->fw_v)), 1.0f);
+    float spd = spr * (sd - q->factor1);
+    if (is_stroke) {
+      float hw = maxf(q->params.y, 0.0f) * 0.5f;
+      alpha = clampf(hw - fabsf(spd) + 0.5f, 0.0f, 1.0f);
+    } else {
+      alpha = clampf(spd + 0.5f, 0.0f, 1.0f);
+    }
+    out.x = fc.x; out.y = fc.y; out.z = fc.z; out.w = fc.w * alpha;
+    return out;
+  }
+  switch (mode) {
+    case 11: { float h = sdf_factor * 0.5f; float sd = fabsf(dist + h) - h; alpha = sd < 0.0f ? 1.0f : 0.0f; break; }
+    case 12: { float h = sdf_factor * 0.5f; float sd = fabsf(dist + h) - h; alpha = 1.0f - clampf(c->aa * sd + 0.5f, 0.0f, 1.0f); break; }
+    case 7: { float sd = dist - sdf_spread; float a = shadow_profile(sd, sdf_factor); alpha = sd > 0.0f ? minf(a, 1.0f) : 1.0f; break; }
+    case 8: {
+      float inside = 1.0f - clampf(c->aa * dist + 0.5f, 0.0f, 1.0f);
+      float sd = dist - sdf_spread; float a = shadow_profile(sd, sdf_factor);
+      alpha = sd >= 0.0f ? minf(a, 1.0f) : inside; break;
+    }
+    case 9: { /* atlas.frag:364-380 */
+      float qx = px, qy = -py;
+      float sx = qx - q->params.z, sy = qy - (-q->params.w);
+      float clip_d = ellip ? sd_elliptical_rounded_box(qx, qy, qhx, qhy, q->radii) : sd_rounded_box(qx, qy, qhx, qhy, q->radii);
+      float clip_a = 1.0f - clampf(c->aa * clip_d + 0.5f, 0.0f, 1.0f);
+      float sh_d = ellip ? sd_elliptical_rounded_box(sx, sy, qhx, qhy, q->radii) : sd_rounded_box(sx, sy, qhx, qhy, q->radii);
+      float sd = sh_d + sdf_spread; float a = shadow_profile(sd, sdf_factor);
+      float inset_a = sd < 0.0f ? minf(a, 1.0f) : 1.0f;
+      alpha = clip_a * inset_a; break;
+    }
+    case 17: { /* atlas.frag:381-388: blurred backdrop at the fragment's own pixel */
+      alpha = 1.0f - clampf(c->aa * dist + 0.5f, 0.0f, 1.0f);
+      const uint8_t* b = c->backdrop + ((size_t)y * c->W + x) * 4;
+      out.x = from_unorm8(b[0]); out.y = from_unorm8(b[1]); out.z = from_unorm8(b[2]); out.w = from_unorm8(b[3]) * alpha;
+      return out;
+    }
+    default: alpha = 1.0f - clampf(c->aa * dist + 0.5f, 0.0f, 1.0f); break; /* ClipAA & others atlas.frag:389-393 */
+  }
+  out.x = fc.x; out.y = fc.y; out.z = fc.z; out.w = fc.w * alpha;
+  return out;
+}
+
+/* edge function helpers for the two triangles (3,0,1) and (2,3,1): glcontext.nim:418-429 */
+static inline double edge_fn(v2 a, v2 b, double px, double py) { return ((double)b.x - a.x) * (py - a.y) - ((double)b.y - a.y) * (px - a.x); }
+/* top-left rule in the final image orientation (y down): an edge a->b of a triangle whose
+ * interior is on the positive side of edge_fn owns the pixels lying exactly on it iff it is a
+ * top edge (horizontal, interior below) or a left edge (interior to the right). */
+static int edge_owns(v2 a, v2 b, v2 opp) {
+  if (a.y == b.y) return opp.y > a.y;
+  /* x of the edge at the opposite vertex's y */
+  double t = ((double)opp.y - a.y) / ((double)b.y - a.y);
+  double ex = a.x + t * ((double)b.x - a.x);
+  return opp.x > ex;
+}
+
+static void draw_quad(FoCtx* c, const Quad* q) {
+  int W = c->W, H = c->H;
+  float minx = q->pos[0].x, maxx = minx, miny = q->pos[0].y, maxy = miny;
+  for (int i = 1; i < 4; i++) {
+    minx = minf(minx, q->pos[i].x); maxx = maxf(maxx, q->pos[i].x);
+    miny = minf(miny, q->pos[i].y); maxy = maxf(maxy, q->pos[i].y);
+  }
+  int x0 = (int)floorf(minx), x1 = (int)ceilf(maxx), y0 = (int)floorf(miny), y1 = (int)ceilf(maxy);
+  if (x0 < 0) x0 = 0; if (y0 < 0) y0 = 0; if (x1 > W) x1 = W; if (y1 > H) y1 = H;
+  if (x0 >= x1 || y0 >= y1) return;
+  static const int TRI[2][3] = {{3, 0, 1}, {2, 3, 1}};
+  /* per-triangle setup */
+  double area[2];
+  int own[2][3];
+  float rho[2], fwu[2], fwv[2];
+  for (int t = 0; t < 2; t++) {
+    v2 a = q->pos[TRI[t][0]], b = q->pos[TRI[t][1]], d = q->pos[TRI[t][2]];
+    area[t] = edge_fn(a, b, d.x, d.y);
+    /* edge k is opposite vertex k: e0 = (b->d), e1 = (d->a), e2 = (a->b) */
+    own[t][0] = edge_owns(b, d, a);
+    own[t][1] = edge_owns(d, a, b);
+    own[t][2] = edge_owns(a, b, d);
+    /* uv derivatives of this triangle's affine map (for LOD / fwidth) */
+    v2 ua = q->uv[TRI[t][0]], ub = q->uv[TRI[t][1]], ud = q->uv[TRI[t][2]];
+    double e1x = (double)b.x - a.x, e1y = (double)b.y - a.y, e2x = (double)d.x - a.x, e2y = (double)d.y - a.y;
+    double det = e1x * e2y - e1y * e2x;
+    if (det != 0.0) {
+      double du1 = (double)ub.x - ua.x, du2 = (double)ud.x - ua.x, dv1 = (double)ub.y - ua.y, dv2 = (double)ud.y - ua.y;
+      double dudx = (du1 * e2y - du2 * e1y) / det, dudy = (du2 * e1x - du1 * e2x) / det;
+      double dvdx = (dv1 * e2y - dv2 * e1y) / det, dvdy = (dv2 * e1x - dv1 * e2x) / det;
+      double S = (double)c->atlas_size;
+      double rx = sqrt(dudx * dudx + dvdx * dvdx) * S, ry = sqrt(dudy * dudy + dvdy * dvdy) * S;
+      rho[t] = (float)(rx > ry ? rx : ry);
+      fwu[t] = (float)(fabs(dudx) + fabs(dudy));
+      fwv[t] = (float)(fabs(dvdx) + fabs(dvdy));
+    } else {
+      rho[t] = 0.0f; fwu[t] = fwv[t] = 1.0f;
+    }
+  }
+  const RectMask* fast = NULL;
+  if (!c->mask_begun)
+    for (int i = c->n_rect_masks - 1; i >= 0; i--)
+      if (c->rect_masks[i].kind == 1) { fast = &c->rect_masks[i]; break; }
+  int mask_read = c->mask_begun ? c->mask_write - 1 : c->mask_write; /* flush(maskTextureRead) glcontext.nim:643,1891,1920 */
+  const uint8_t* mask_tex = mask_read != 0 ? c->mask[mask_read] : NULL;
+  uint8_t* mask_dst = c->mask_begun ? c->mask[c->mask_write] : NULL;
+
+#pragma omp parallel for schedule(static) num_threads(g_threads) if (g_threads > 1)
+  for (int y = y0; y < y1; y++) {
+    for (int x = x0; x < x1; x++) {
+      double cx = x + 0.5, cy = y + 0.5;
+      int hit = -1;
+      double w0 = 0, w1 = 0, w2 = 0;
+      for (int t = 0; t < 2 && hit < 0; t++) {
+        if (area[t] == 0.0) continue;
+        v2 a = q->pos[TRI[t][0]], b = q->pos[TRI[t][1]], d = q->pos[TRI[t][2]];
+        double sgn = area[t] > 0 ? 1.0 : -1.0;
+        double e0 = sgn * edge_fn(b, d, cx, cy), e1 = sgn * edge_fn(d, a, cx, cy), e2 = sgn * edge_fn(a, b, cx, cy);
+        if (e0 < 0 || e1 < 0 || e2 < 0) continue;
+        if ((e0 == 0 && !own[t][0]) || (e1 == 0 && !own[t][1]) || (e2 == 0 && !own[t][2])) continue;
+        hit = t; w0 = e0; w1 = e1; w2 = e2;
+      }
+      if (hit < 0) continue;
+      double inv = 1.0 / (w0 + w1 + w2);
+      float l0 = (float)(w0 * inv), l1 = (float)(w1 * inv), l2 = (float)(w2 * inv);
+      const int* T = TRI[hit];
+      Frag f;
+      f.u = l0 * q->uv[T[0]].x + l1 * q->uv[T[1]].x + l2 * q->uv[T[2]].x;
+      f.v = l0 * q->uv[T[0]].y + l1 * q->uv[T[1]].y + l2 * q->uv[T[2]].y;
+      f.col.x = l0 * q->col[T[0]].x + l1 * q->col[T[1]].x + l2 * q->col[T[2]].x;
+      f.col.y = l0 * q->col[T[0]].y + l1 * q->col[T[1]].y + l2 * q->col[T[2]].y;
+      f.col.z = l0 * q->col[T[0]].z + l1 * q->col[T[1]].z + l2 * q->col[T[2]].z;
+      f.col.w = l0 * q->col[T[0]].w + l1 * q->col[T[1]].w + l2 * q->col[T[2]].w;
+      f.rho = rho[hit]; f.fw_u = fwu[hit]; f.fw_v = fwv[hit];
+      size_t pi = (size_t)y * W + x;
+      if (mask_dst) {
+        /* mask.frag + blend into the R8 plane: r = a*a + dst*(1-a)  (utils/glutils.nim:150-154) */
+        float a = shade_mask(c, q, &f);
+        if (mask_tex) a *= from_unorm8(mask_tex[pi]);
+        float d = from_unorm8(mask_dst[pi]);
+        mask_dst[pi] = to_unorm8(a * a + d * (1.0f - a));
+      } else {
+        v4 s = shade_main(c, q, &f, x, y);
+        if (mask_tex) s.w *= from_unorm8(mask_tex[pi]); /* atlas.frag:401-404 */
+        if (fast) s.w *= rect_mask_alpha(fast, c->aa, (float)cx, (float)cy); /* atlas_rect_mask.frag:425 */
+        uint8_t* d = c->fb + pi * 4;
+        float dr = from_unorm8(d[0]), dg = from_unorm8(d[1]), db = from_unorm8(d[2]), da = from_unorm8(d[3]);
+        float sa = s.w, ia = 1.0f - sa;
+        d[0] = to_unorm8(s.x * sa + dr * ia);
+        d[1] = to_unorm8(s.y * sa + dg * ia);
+        d[2] = to_unorm8(s.z * sa + db * ia);
+        d[3] = to_unorm8(sa + da * ia);
+      }
+    }
+  }
+}
+
+static v4 col_to_v4(FoColor k) { v4 r = {from_unorm8(k.r), from_unorm8(k.g), from_unorm8(k.b), from_unorm8(k.a)}; return r; }
+static v2 ceil_xf(const FoCtx* c, float x, float y) { v2 p = aff_apply(c->mat, x, y); p.x = ceilf(p.x); p.y = ceilf(p.y); return p; }
+static float active_subpixel_shift(const FoCtx* c) { /* glcontext.nim:819-822 */
+  if (!c->subpixel_enabled) return 0.0f;
+  return maxf(0.0f, minf(c->subpixel_shift, 0.999f));
+}
+
+/* drawRoundedRectSdfOpenGl: glcontext.nim:1449-1559 */
+void fo_draw_rounded_rect_sdf(FoCtx* c, const float rect[4], const FoColor colors[4], const float radii_x[4],
+                              const float radii_y[4], int mode, float factor, float spread, const float shape[2],
+                              int fill_mode, FoColor mid, FoColor stop, float mid_pos) {
+  rec_open(c, "draw_rounded_rect_sdf");
+  rec_fv(c, rect, 4); rec_cols(c, colors); rec_fv(c, radii_x, 4); rec_fv(c, radii_y, 4); rec_i(c, mode);
+  rec_f(c, factor); rec_f(c, spread); rec_fv(c, shape, 2); rec_i(c, fill_mode); rec_col(c, mid); rec_col(c, stop); rec_f(c, mid_pos);
+  rec_close(c);
+  float x = rect[0], y = rect[1], w = rect[2], h = rect[3];
+  if (w <= 0 || h <= 0) return;
+  Quad q;
+  memset(&q, 0, sizeof q);
+  float qhx = w * 0.5f, qhy = h * 0.5f;
+  int inset = mode == 9;
+  float rsx = (shape[0] > 0.0f && shape[1] > 0.0f) ? shape[0] : w;
+  float rsy = (shape[0] > 0.0f && shape[1] > 0.0f) ? shape[1] : h;
+  float shx = inset ? qhx : rsx * 0.5f, shy = inset ? qhy : rsy * 0.5f;
+  q.params.x = qhx; q.params.y = qhy;
+  if (inset) { q.params.z = shape[0]; q.params.w = shape[1]; } else { q.params.z = shx; q.params.w = shy; }
+  float r4[4];
+  int ellip;
+  fo_rounded_radii_vec(radii_x, radii_y, shx, shy, r4, &ellip);
+  q.radii.x = r4[0]; q.radii.y = r4[1]; q.radii.z = r4[2]; q.radii.w = r4[3];
+  q.pos[0] = ceil_xf(c, x, y + h); q.pos[1] = ceil_xf(c, x + w, y + h);
+  q.pos[2] = ceil_xf(c, x + w, y); q.pos[3] = ceil_xf(c, x, y);
+  q.uv[0].x = 0; q.uv[0].y = 1; q.uv[1].x = 1; q.uv[1].y = 1; q.uv[2].x = 1; q.uv[2].y = 0; q.uv[3].x = 0; q.uv[3].y = 0;
+  for (int i = 0; i < 4; i++) q.col[i] = col_to_v4(colors[i]);
+  q.mid = col_to_v4(mid); q.stop = col_to_v4(stop);
+  q.factor0 = factor;
+  q.factor1 = fill_mode == 0 ? spread : clampf(mid_pos, 0.01f, 0.99f);
+  q.mode_word = mode + (ellip ? 128 : 0) + fill_mode * 256; /* encodeSdfMode glcontext.nim:1002-1008 */
+  q.subpixel_shift = active_subpixel_shift(c);
+  draw_quad(c, &q);
+}
+
+/* drawRoundedRectSdf(fill: BackendFill): glcontext.nim:1581-1617 */
+void fo_draw_rounded_rect_fill(FoCtx* c, const float rect[4], const FoFill* fill, const float radii_x[4],
+                               const float radii_y[4], int mode, float factor, float spread, const float shape[2]) {
+  FoColor zero = {0, 0, 0, 0};
+  if (fill->kind == FO_FILL_LINEAR3 && (mode == 3 || mode == 11 || mode == 12)) {
+    FoColor cols[4] = {fill->start, fill->start, fill->start, fill->start};
+    fo_draw_rounded_rect_sdf(c, rect, cols, radii_x, radii_y, mode, factor, spread, shape, 1 + fill->axis, fill->mid,
+                             fill->stop, fill_mid_pos01(fill));
+  } else {
+    FoColor cols[4];
+    fo_gradient_colors(fill, cols);
+    fo_draw_rounded_rect_sdf(c, rect, cols, radii_x, radii_y, mode, factor, spread, shape, 0, zero, zero, 0.5f);
+  }
+}
+
+/* ------------------------------------------------------------------ atlas: glcontext.nim:541-586 */
+static AtlasEntry* find_entry(FoCtx* c, int64_t key) {
+  for (int i = 0; i < c->n_entries; i++) if (c->entries[i].used && c->entries[i].key == key) return &c->entries[i];
+  return NULL;
+}
+int fo_put_image(FoCtx* c, int64_t key, int w, int h, const uint8_t* rgba, int out_rect[4]) {
+  int S = c->atlas_size, M = c->atlas_margin;
+  int iw = w + M * 2, ih = h + M * 2;
+  int lowest = S, at = 0;
+  for (int i = 0; i < S; i++) {
+    int v = c->heights[i];
+    if (v < lowest) {
+      int fit = 1;
+      for (int j = 0; j <= iw; j++) {
+        if (i + j >= S) { fit = 0; break; }
+        if ((int)c->heights[i + j] > v) { fit = 0; break; }
+      }
+      if (fit) { lowest = v; at = i; }
+    }
+  }
+  if (lowest + ih > S) return -1; /* reference grows the atlas (glcontext.nim:536-539,564-567); callers size it up front */
+  for (int j = at; j < at + iw; j++) c->heights[j] = (uint16_t)(lowest + ih + M * 2);
+  int rx = at + M, ry = lowest + M;
+  AtlasEntry* e = find_entry(c, key);
+  if (!e) {
+    if (c->n_entries == c->cap_entries) {
+      c->cap_entries = c->cap_entries ? c->cap_entries * 2 : 64;
+      c->entries = (AtlasEntry*)realloc(c->entries, (size_t)c->cap_entries * sizeof(AtlasEntry));
+    }
+    e = &c->entries[c->n_entries++];
+  }
+  e->key = key; e->used = 1;
+  e->x = (float)rx / (float)S; e->y = (float)ry / (float)S; e->w = (float)w / (float)S; e->h = (float)h / (float)S;
+  if (out_rect) { out_rect[0] = rx; out_rect[1] = ry; out_rect[2] = w; out_rect[3] = h; }
+  /* updateSubImage with the minifyBy2 mip chain: textures.nim:106-119 */
+  int cw = w, ch = h, lx = rx, ly = ry, level = 0;
+  uint8_t* cur = (uint8_t*)malloc((size_t)w * h * 4);
+  memcpy(cur, rgba, (size_t)w * h * 4);
+  while (cw > 1 && ch > 1 && level < c->n_mips) {
+    int LS = S >> level;
+    for (int yy = 0; yy < ch; yy++)
+      for (int xx = 0; xx < cw; xx++) {
+        int tx = lx + xx, ty = ly + yy;
+        if (tx >= 0 && ty >= 0 && tx < LS && ty < LS) memcpy(c->atlas[level] + ((size_t)ty * LS + tx) * 4, cur + ((size_t)yy * cw + xx) * 4, 4);
+      }
+    int nw = cw / 2, nh = ch / 2;
+    uint8_t* nxt = (uint8_t*)malloc((size_t)(nw > 0 ? nw : 1) * (nh > 0 ? nh : 1) * 4);
+    for (int yy = 0; yy < nh; yy++)
+      for (int xx = 0; xx < nw; xx++)
+        for (int k = 0; k < 4; k++) {
+          unsigned s = cur[((size_t)(2 * yy) * cw + 2 * xx) * 4 + k] + cur[((size_t)(2 * yy) * cw + 2 * xx + 1) * 4 + k] +
+                       cur[((size_t)(2 * yy + 1) * cw + 2 * xx) * 4 + k] + cur[((size_t)(2 * yy + 1) * cw + 2 * xx + 1) * 4 + k];
+          nxt[((size_t)yy * nw + xx) * 4 + k] = (uint8_t)((s + 2) / 4);
+        }
+    free(cur);
+    cur = nxt; cw = nw; ch = nh; lx /= 2; ly /= 2; level++;
+  }
+  free(cur);
+  return 0;
+}
+
+static void draw_uv_quad(FoCtx* c, float ax, float ay, float tx, float ty, v2 uv_at, v2 uv_to, const FoColor colors[4],
+                         int mode_word, v4 params, float f0, float f1) {
+  Quad q;
+  memset(&q, 0, sizeof q);
+  q.pos[0] = ceil_xf(c, ax, ty); q.pos[1] = ceil_xf(c, tx, ty); q.pos[2] = ceil_xf(c, tx, ay); q.pos[3] = ceil_xf(c, ax, ay);
+  q.uv[0].x = uv_at.x; q.uv[0].y = uv_to.y; q.uv[1].x = uv_to.x; q.uv[1].y = uv_to.y;
+  q.uv[2].x = uv_to.x; q.uv[2].y = uv_at.y; q.uv[3].x = uv_at.x; q.uv[3].y = uv_at.y;
+  for (int i = 0; i < 4; i++) q.col[i] = col_to_v4(colors[i]);
+  q.params = params;
+  q.mode_word = mode_word;
+  q.factor0 = f0; q.factor1 = f1;
+  q.subpixel_shift = active_subpixel_shift(c);
+  draw_quad(c, &q);
+}
+
+/* drawImage(imageId, pos, colors, size, flipY): glcontext.nim:1350-1367, drawUvRect :1236-1302 */
+void fo_draw_image(FoCtx* c, int64_t key, const float pos[2], const FoColor colors[4], const float size[2], int flip_y) {
+  rec_open(c, "draw_image"); rec_i(c, key); rec_fv(c, pos, 2); rec_cols(c, colors); rec_fv(c, size, 2); rec_i(c, flip_y); rec_close(c);
+  AtlasEntry* e = find_entry(c, key);
+  if (!e) return; /* "missing image in context": warn + no-op glcontext.nim:1310-1315 */
+  float S = (float)c->atlas_size;
+  float dw = (size[0] > 0.0f && size[1] > 0.0f) ? size[0] : e->w * S;
+  float dh = (size[0] > 0.0f && size[1] > 0.0f) ? size[1] : e->h * S;
+  v2 at, to;
+  if (flip_y) { at.x = e->x; at.y = e->y + e->h; to.x = e->x + e->w; to.y = e->y; }
+  else { at.x = e->x; at.y = e->y; to.x = e->x + e->w; to.y = e->y + e->h; }
+  v4 z = {0, 0, 0, 0};
+  draw_uv_quad(c, pos[0], pos[1], pos[0] + dw, pos[1] + dh, at, to, colors, 0, z, 0.0f, 0.0f);
+}
+
+/* drawMsdfImage / drawMtsdfImage: glcontext.nim:1097-1155, drawUvRectAtlasSdf :1022-1093 */
+void fo_draw_msdf(FoCtx* c, int64_t key, const float pos[2], FoColor color, const float size[2], float px_range,
+                  float sd_threshold, float stroke_weight, int mtsdf, int flip_y) {
+  rec_open(c, "draw_msdf"); rec_i(c, key); rec_fv(c, pos, 2); rec_col(c, color); rec_fv(c, size, 2); rec_f(c, px_range);
+  rec_f(c, sd_threshold); rec_f(c, stroke_weight); rec_i(c, mtsdf); rec_i(c, flip_y); rec_close(c);
+  AtlasEntry* e = find_entry(c, key);
+  if (!e) return;
+  v2 at, to;
+  if (flip_y) { at.x = e->x; at.y = e->y + e->h; to.x = e->x + e->w; to.y = e->y; }
+  else { at.x = e->x; at.y = e->y; to.x = e->x + e->w; to.y = e->y + e->h; }
+  float sw = maxf(0.0f, stroke_weight);
+  v4 params = {(float)c->atlas_size, sw, 0, 0};
+  int mode = mtsdf ? (sw > 0.0f ? 16 : 14) : (sw > 0.0f ? 15 : 13);
+  FoColor cols[4] = {color, color, color, color};
+  draw_uv_quad(c, pos[0], pos[1], pos[0] + size[0], pos[1] + size[1], at, to, cols, mode, params, px_range, sd_threshold);
+}
+
+/* ------------------------------------------------------------------ masks: glcontext.nim:1873-1949 */
+void fo_begin_mask(FoCtx* c, const float rect[4], const float rx[4], const float ry[4]) {
+  rec_open(c, "begin_mask"); rec_fv(c, rect, 4); rec_fv(c, rx, 4); rec_fv(c, ry, 4); rec_close(c);
+  int was = c->rec.on;
+  c->rec.on = 0;
+  c->mask_begun = 1;
+  c->mask_write++;
+  if (c->mask_write >= FO_MAX_MASKS) { fprintf(stderr, "figdraw_oracle: mask stack overflow\n"); abort(); }
+  if (!c->mask[c->mask_write]) c->mask[c->mask_write] = (uint8_t*)malloc((size_t)c->W * c->H);
+  memset(c->mask[c->mask_write], 0, (size_t)c->W * c->H);
+  FoColor red = {255, 0, 0, 255}, zero = {0, 0, 0, 0};
+  FoColor cols[4] = {red, red, red, red};
+  float shape[2] = {0, 0};
+  fo_draw_rounded_rect_sdf(c, rect, cols, rx, ry, 3, 4.0f, 0.0f, shape, 0, zero, zero, 0.5f);
+  c->rec.on = was;
+}
+void fo_end_mask(FoCtx* c) { rec_open(c, "end_mask"); rec_close(c); c->mask_begun = 0; }
+void fo_pop_mask(FoCtx* c) { rec_open(c, "pop_mask"); rec_close(c); c->mask_write--; }
+
+/* makeRectMask glcontext.nim:831-850, beginRectMask :1932-1943 */
+void fo_begin_rect_mask(FoCtx* c, const float rect[4], const float rx[4], const float ry[4]) {
+  rec_open(c, "begin_rect_mask"); rec_fv(c, rect, 4); rec_fv(c, rx, 4); rec_fv(c, ry, 4); rec_close(c);
+  int was = c->rec.on;
+  c->rec.on = 0;
+  RectMask* rm = &c->rect_masks[c->n_rect_masks];
+  if (c->n_rect_masks == 0 && rect[2] > 0.0f && rect[3] > 0.0f) {
+    float hx = rect[2] * 0.5f, hy = rect[3] * 0.5f;
+    float r4[4];
+    int ellip;
+    fo_rounded_radii_vec(rx, ry, hx, hy, r4, &ellip);
+    Aff inv = aff_inverse(c->mat);
+    rm->kind = 1;
+    rm->params.x = rect[0] + hx; rm->params.y = rect[1] + hy; rm->params.z = hx; rm->params.w = hy;
+    rm->radii.x = r4[0]; rm->radii.y = r4[1]; rm->radii.z = r4[2]; rm->radii.w = r4[3];
+    rm->matx.x = inv.a; rm->matx.y = inv.c; rm->matx.z = inv.tx; rm->matx.w = 1.0f;
+    rm->maty.x = inv.b; rm->maty.y = inv.d; rm->maty.z = inv.ty; rm->maty.w = ellip ? 1.0f : 0.0f;
+  } else {
+    fo_begin_mask(c, rect, rx, ry);
+    fo_end_mask(c);
+    rm->kind = 2;
+  }
+  c->n_rect_masks++;
+  c->rec.on = was;
+}
+void fo_pop_rect_mask(FoCtx* c) {
+  rec_open(c, "pop_rect_mask"); rec_close(c);
+  int was = c->rec.on;
+  c->rec.on = 0;
+  if (c->n_rect_masks > 0) {
+    RectMask rm = c->rect_masks[--c->n_rect_masks];
+    if (rm.kind == 2) fo_pop_mask(c);
+  }
+  c->rec.on = was;
+}
+
+/* ------------------------------------------------------------------ blur: blur.frag:11-32, glcontext.nim:1743-1786 */
+static void blur_pass(int W, int H, const uint8_t* src, uint8_t* dst, float blur_radius, int vertical) {
+  float radius = clampf(blur_radius, 0.0f, 64.0f);
+  float sigma = maxf(0.5f * radius, 0.5f);
+  float step_px = maxf(radius / 8.0f, 1.0f);
+  float tsx = vertical ? 0.0f : 1.0f / (float)W, tsy = vertical ? 1.0f / (float)H : 0.0f;
+#pragma omp parallel for schedule(static) num_threads(g_threads) if (g_threads > 1)
+  for (int y = 0; y < H; y++)
+    for (int x = 0; x < W; x++) {
+      /* uv of the full-screen triangle at the fragment centre */
+      float u = ((float)x + 0.5f) / (float)W, v = ((float)y + 0.5f) / (float)H;
+      float acc[4] = {0, 0, 0, 0}, wsum = 0.0f;
+      if (radius <= 0.5f) {
+        memcpy(dst + ((size_t)y * W + x) * 4, src + ((size_t)y * W + x) * 4, 4);
+        continue;
+      }
+      for (int i = -8; i <= 8; i++) {
+        float xx = (float)i * step_px;
+        float w = expf(-0.5f * (xx * xx) / (sigma * sigma));
+        float su = u + tsx * xx, sv = v + tsy * xx;
+        float t[4];
+        bilinear_rgba8_clamp(src, W, H, su * (float)W - 0.5f, sv * (float)H - 0.5f, t);
+        for (int k = 0; k < 4; k++) acc[k] += t[k] * w;
+        wsum += w;
+      }
+      float d = maxf(wsum, 1e-5f);
+      uint8_t* o = dst + ((size_t)y * W + x) * 4;
+      for (int k = 0; k < 4; k++) o[k] = to_unorm8(acc[k] / d);
+    }
+}
+void fo_blur_image(int w, int h, const uint8_t* src, uint8_t* dst, float radius) {
+  if (radius <= 0.5f) { memcpy(dst, src, (size_t)w * h * 4); return; }
+  uint8_t* tmp = (uint8_t*)malloc((size_t)w * h * 4);
+  blur_pass(w, h, src, tmp, radius, 0);
+  blur_pass(w, h, tmp, dst, radius, 1);
+  free(tmp);
+}
+
+/* drawBackdropBlur: glcontext.nim:1788-1841 */
+void fo_draw_backdrop_blur(FoCtx* c, const float rect[4], const float rx[4], const float ry[4], float blur_radius) {
+  rec_open(c, "draw_backdrop_blur"); rec_fv(c, rect, 4); rec_fv(c, rx, 4); rec_fv(c, ry, 4); rec_f(c, blur_radius); rec_close(c);
+  if (blur_radius <= 0.0f || rect[2] <= 0.0f || rect[3] <= 0.0f) return;
+  int was = c->rec.on;
+  c->rec.on = 0;
+  memcpy(c->backdrop, c->fb, (size_t)c->W * c->H * 4); /* glCopyTexSubImage2D of the whole frame */
+  if (blur_radius > 0.5f) {
+    blur_pass(c->W, c->H, c->backdrop, c->backdrop_tmp, blur_radius, 0);
+    blur_pass(c->W, c->H, c->backdrop_tmp, c->backdrop, blur_radius, 1);
+  }
+  FoColor white = {255, 255, 255, 255}, zero = {0, 0, 0, 0};
+  FoColor cols[4] = {white, white, white, white};
+  float shape[2] = {0, 0};
+  fo_draw_rounded_rect_sdf(c, rect, cols, rx, ry, 17, blur_radius, 0.0f, shape, 0, zero, zero, 0.5f);
+  c->rec.on = was;
+}
+
+/* readPixels + flipVertical: glcontext.nim:2094-2135 (top-down result) */
+int fo_read_pixels(FoCtx* c, int x, int y, int w, int h, uint8_t* out) {
+  if (!c->fb) return -1;
+  if (w <= 0 || h <= 0) { x = 0; y = 0; w = c->W; h = c->H; }
+  if (x < 0 || y < 0 || x + w > c->W || y + h > c->H) return -1;
+  for (int r = 0; r < h; r++) memcpy(out + (size_t)r * w * 4, c->fb + ((size_t)(y + r) * c->W + x) * 4, (size_t)w * 4);
+  return 0;
+}
+int fo_read_mask(FoCtx* c, int level, uint8_t* out) {
+  if (level <= 0 || level >= FO_MAX_MASKS || !c->mask[level]) return -1;
+  memcpy(out, c->mask[level], (size_t)c->W * c->H);
+  return 0;
+}
+
+/* ================================================================== L2: figrender.nim */
+static float scaled(const FoCtx* c, float v) { return v * c->ui_scale; } /* common/shared.nim:94-95 */
+
+static void node_radii(const FoCtx* c, const FoFig* n, float rx[4], float ry[4]) { /* resolvedCorners+scaledCorners figrender.nim:549-571 */
+  for (int i = 0; i < 4; i++) {
+    rx[i] = scaled(c, (float)n->corners[i]);
+    ry[i] = (n->flags & FO_NF_ELLIPTICAL_CORNERS) ? scaled(c, (float)n->corner_radii_y[i]) : rx[i];
+  }
+}
+static void node_box(const FoCtx* c, const FoFig* n, float b[4]) { for (int i = 0; i < 4; i++) b[i] = n->box[i] * c->ui_scale; }
+
+/* renderDropShadows figrender.nim:654-689 */
+static void render_drop_shadows(FoCtx* c, const FoFig* n) {
+  for (int s = 0; s < 4; s++) {
+    const FoShadow* sh = &n->shadows[s];
+    if (sh->style != FO_SHADOW_DROP) continue;
+    if (sh->blur <= 0.0f && sh->spread <= 0.0f) continue;
+    if (fill_alpha_max(&sh->fill) == 0) continue;
+    float box[4];
+    node_box(c, n, box);
+    float sx = scaled(c, sh->x), sy = scaled(c, sh->y), sb = scaled(c, sh->blur), ss = scaled(c, sh->spread);
+    float blur_pad = nim_round(1.5f * sb);
+    float pad = maxf(nim_round(ss) + blur_pad, 0.0f);
+    float srx = box[0] + sx, sry = box[1] + sy, srw = box[2], srh = box[3];
+    float quad[4] = {srx - pad, sry - pad, srw + 2.0f * pad, srh + 2.0f * pad};
+    float shape[2] = {srw, srh};
+    float rx[4], ry[4];
+    node_radii(c, n, rx, ry);
+    fo_draw_rounded_rect_fill(c, quad, &sh->fill, rx, ry, 7, sb, ss, shape);
+  }
+}
+/* renderInnerShadows figrender.nim:716-744 */
+static void render_inner_shadows(FoCtx* c, const FoFig* n) {
+  for (int s = 0; s < 4; s++) {
+    const FoShadow* sh = &n->shadows[s];
+    if (sh->style != FO_SHADOW_INNER) continue;
+    if (sh->blur <= 0.0f && sh->spread <= 0.0f) continue;
+    if (fill_alpha_max(&sh->fill) == 0) continue;
+    float box[4];
+    node_box(c, n, box);
+    float off[2] = {scaled(c, sh->x), scaled(c, sh->y)};
+    float rx[4], ry[4];
+    node_radii(c, n, rx, ry);
+    fo_draw_rounded_rect_fill(c, box, &sh->fill, rx, ry, 9, scaled(c, sh->blur), scaled(c, sh->spread), off);
+  }
+}
+/* renderRoundedShapeScaledCorners figrender.nim:806-873 */
+static void render_rounded_shape(FoCtx* c, const float box_unscaled[4], const FoFill* fill, const FoStroke* stroke,
+                                 const float rx[4], const float ry[4]) {
+  float box[4];
+  for (int i = 0; i < 4; i++) box[i] = box_unscaled[i] * c->ui_scale;
+  float shape[2] = {0, 0};
+  int has_gradient = (fill->kind == FO_FILL_LINEAR2 || fill->kind == FO_FILL_LINEAR3) && fill_alpha_max(fill) > 0;
+  if (has_gradient) {
+    fo_draw_rounded_rect_fill(c, box, fill, rx, ry, 3, 4.0f, 0.0f, shape);
+  } else if (fill_alpha_max(fill) > 0) {
+    /* fillCenterColor -> Color -> rgba(): an RGBA8 round trip, identity for flColor */
+    FoFill solid = *fill;
+    solid.kind = FO_FILL_COLOR;
+    solid.start = sample_color(fill, 0.5f);
+    fo_draw_rounded_rect_fill(c, box, &solid, rx, ry, 3, 4.0f, 0.0f, shape);
+  }
+  if (stroke && fill_alpha_max(&stroke->fill) > 0 && stroke->weight > 0.0f)
+    fo_draw_rounded_rect_fill(c, box, &stroke->fill, rx, ry, 12, scaled(c, stroke->weight), 0.0f, shape);
+}
+
+static void render_node(FoCtx* c, const FoScene* sc, const FoLayer* L, int idx);
+
+static void render_text(FoCtx* c, const FoScene* sc, const FoFig* n) { /* renderText figrender.nim:417-497 (glyph loop) */
+  fo_save_transform(c);
+  fo_translate(c, scaled(c, n->box[0]), scaled(c, n->box[1]));
+  if (n->flags & FO_NF_INVERT_Y) {
+    fo_translate(c, 0.0f, scaled(c, n->box[3]));
+    fo_scale(c, 1.0f, -1.0f);
+  }
+  for (int g = n->glyph_first; g < n->glyph_first + n->glyph_count && g < sc->n_glyphs; g++) {
+    const FoGlyph* gl = &sc->glyphs[g];
+    float pos[2] = {gl->x, gl->y}, size[2] = {0, 0};
+    c->subpixel_shift = gl->subpixel_shift;
+    fo_draw_image(c, gl->image_id, pos, gl->colors, size, 0);
+  }
+  c->subpixel_shift = 0.0f;
+  fo_restore_transform(c);
+}
+
+/* render figrender.nim:1756-1839 (stage order fixed by renderStages :501-547) */
+static void render_node(FoCtx* c, const FoScene* sc, const FoLayer* L, int idx) {
+  const FoFig* n = &L->nodes[idx];
+  if (n->flags & FO_NF_DISABLE_RENDER) return;
+  float box[4];
+  node_box(c, n, box);
+  float rx[4], ry[4];
+  node_radii(c, n, rx, ry);
+  int did_rot = 0, did_xf = 0, did_clip = 0, did_rmask = 0;
+  if (n->rotation != 0.0f) {
+    did_rot = 1;
+    fo_save_transform(c);
+    float cx = box[0] + box[2] / 2.0f, cy = box[1] + box[3] / 2.0f;
+    fo_translate(c, cx, cy);
+    fo_rotate(c, n->rotation / 180.0f * 3.14159265358979323846f); /* node.rotation / 180 * PI in float32 */
+    fo_translate(c, -cx, -cy);
+  }
+  if (n->kind == FO_NK_TRANSFORM) {
+    did_xf = 1;
+    fo_save_transform(c);
+    if (n->translation[0] != 0.0f || n->translation[1] != 0.0f) fo_translate(c, scaled(c, n->translation[0]), scaled(c, n->translation[1]));
+    if (n->use_matrix) fo_apply_transform(c, n->matrix);
+  }
+  if (n->kind == FO_NK_RECTANGLE) render_drop_shadows(c, n);
+  if (n->flags & FO_NF_CLIP_CONTENT) {
+    did_clip = 1;
+    fo_begin_mask(c, box, rx, ry);
+    fo_end_mask(c);
+  }
+  if (n->flags & FO_NF_RECT_MASK_CONTENT) {
+    did_rmask = 1;
+    fo_begin_rect_mask(c, box, rx, ry);
+  }
+  switch (n->kind) {
+    case FO_NK_TEXT: render_text(c, sc, n); break;
+    case FO_NK_RECTANGLE: render_rounded_shape(c, n->box, &n->fill, &n->stroke, rx, ry); break; /* renderBoxes :1669-1671 */
+    case FO_NK_IMAGE: { /* renderImage :1673-1684 */
+      if (n->image_id == 0) break;
+      FoColor k = sample_color(&n->image_fill, 0.5f);
+      FoColor cols[4] = {k, k, k, k};
+      float pos[2] = {box[0], box[1]}, size[2] = {box[2], box[3]};
+      fo_draw_image(c, n->image_id, pos, cols, size, (n->flags & FO_NF_INVERT_Y) != 0);
+      break;
+    }
+    case FO_NK_MSDF_IMAGE:
+    case FO_NK_MTSDF_IMAGE: { /* renderMsdfImage / renderMtsdfImage :1686-1732 */
+      if (n->image_id == 0) break;
+      float pr = n->px_range > 0.0f ? n->px_range : 4.0f;
+      float th = (n->sd_threshold > 0.0f && n->sd_threshold < 1.0f) ? n->sd_threshold : 0.5f;
+      float sw = scaled(c, maxf(0.0f, n->stroke_weight));
+      float pos[2] = {box[0], box[1]}, size[2] = {box[2], box[3]};
+      fo_draw_msdf(c, n->image_id, pos, sample_color(&n->image_fill, 0.5f), size, pr, th, sw, n->kind == FO_NK_MTSDF_IMAGE,
+                   (n->flags & FO_NF_INVERT_Y) != 0);
+      break;
+    }
+    case FO_NK_BACKDROP_BLUR: { /* renderBackdropBlur :1734-1754 */
+      if (n->blur > 0.0f) fo_draw_backdrop_blur(c, box, rx, ry, scaled(c, n->blur));
+      if (fill_alpha_max(&n->fill) != 0) {
+        FoStroke none;
+        memset(&none, 0, sizeof none);
+        render_rounded_shape(c, n->box, &n->fill, &none, rx, ry);
+      }
+      break;
+    }
+    default: break; /* nkFrame/nkScrollBar draw nothing; nkDrawable is a SURVEY 8(f) "next" row */
+  }
+  if (n->kind == FO_NK_RECTANGLE) render_inner_shadows(c, n); /* hasActiveInnerShadow :778-789 folded into the loop's skip rules */
+  /* children: childIndex fignodes.nim:165-177 */
+  int cnt = 0;
+  for (int i = idx + 1; i < L->n_nodes && cnt < n->child_count; i++)
+    if (L->nodes[i].parent == idx) { cnt++; render_node(c, sc, L, i); }
+  /* postRender: cleanups in reverse stage order */
+  if (did_rmask) fo_pop_rect_mask(c);
+  if (did_clip) fo_pop_mask(c);
+  if (did_xf) fo_restore_transform(c);
+  if (did_rot) fo_restore_transform(c);
+}
+
+/* renderFrame figrender.nim:1960-1995, renderRoot :1946-1955 */
+void fo_render_frame(FoCtx* c, const FoScene* sc, float frame_w, float frame_h, int clear, const float rgba[4]) {
+  float fw = frame_w * c->ui_scale, fh = frame_h * c->ui_scale;
+  if (fw <= 0.0f || fh <= 0.0f) return;
+  fo_begin_frame(c, (int)fw, (int)fh, clear, rgba);
+  fo_save_transform(c);
+  fo_scale(c, c->pixel_scale, c->pixel_scale);
+  for (int l = 0; l < sc->n_layers; l++) {
+    const FoLayer* L = &sc->layers[l];
+    for (int r = 0; r < L->n_roots; r++) render_node(c, sc, L, L->root_ids[r]);
+  }
+  fo_restore_transform(c);
+  fo_end_frame(c);
+}

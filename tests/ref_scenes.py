@@ -1,0 +1,266 @@
+"""Scenes of the reference's own pixel tests, restated with the reference's names,
+plus extra scenes that exercise the rest of SURVEY.md §8(a) (no reference PNG
+exists for those; their goldens come from the reference shaders on SwiftShader).
+
+Coordinates are written as explicit numbers (the
+reference's `w * 0.30'f32`-style expressions only reproduce its golden PNG when
+evaluated in float64).
+"""
+from __future__ import annotations
+
+from figdraw_amd.scene import (Fig, FigFlags, FigKind, FillGradientAxis, RenderList, Renders, RenderShadow,
+                               RenderStroke, ShadowStyle, fill, linear, rect, rgba)
+
+DROP, INNER = ShadowStyle.DropShadow, ShadowStyle.InnerShadow
+RECT = FigKind.nkRectangle
+
+
+def rgb_boxes_sdf(w=800.0, h=600.0) -> Renders:
+    """tests/trender_rgb_boxes_sdf.nim:13-101 (golden: tests/expected/render_rgb_boxes_sdf.png)."""
+    lst = RenderList()
+    root = lst.addRoot(Fig(kind=RECT, screenBox=rect(0, 0, w, h), fill=rgba(255, 255, 255, 255)))
+    lst.addChild(root, Fig(kind=RECT, corners=[10, 20, 30, 40], screenBox=rect(60, 60, 220, 140),
+                           fill=rgba(220, 40, 40, 255), stroke=RenderStroke(weight=5.0, fill=fill(rgba(0, 0, 0, 255)))))
+    lst.addChild(root, Fig(
+        kind=RECT, screenBox=rect(320, 120, 220, 140),
+        fill=linear(rgba(24, 128, 72, 255), rgba(40, 180, 90, 255), rgba(54, 206, 170, 255),
+                    axis=FillGradientAxis.fgaX, midPos=140),
+        shadows=[RenderShadow(style=DROP, blur=10, spread=10, x=10, y=10, fill=fill(rgba(0, 0, 0, 55)))]))
+    lst.addChild(root, Fig(
+        kind=RECT, screenBox=rect(180, 300, 220, 140), fill=rgba(60, 90, 220, 255),
+        shadows=[
+            RenderShadow(style=INNER, blur=12, spread=0, x=-6, y=-6,
+                         fill=linear(rgba(25, 25, 25, 90), rgba(65, 65, 65, 175), axis=FillGradientAxis.fgaDiagTLBR)),
+            RenderShadow(style=INNER, blur=12, spread=0, x=6, y=6,
+                         fill=linear(rgba(255, 255, 255, 255), rgba(205, 205, 205, 115), axis=FillGradientAxis.fgaDiagTLBR)),
+        ]))
+    out = Renders()
+    out.layers[0] = lst
+    return out
+
+
+def oneframe(w=240.0, h=160.0) -> Renders:
+    """tests/tfigrender_oneframe_screenshot.nim:20-42."""
+    lst = RenderList()
+    lst.addRoot(Fig(kind=RECT, screenBox=rect(0, 0, w, h), fill=rgba(255, 255, 255, 255)))
+    lst.addRoot(Fig(kind=RECT, screenBox=rect(32, 24, 120, 80), fill=rgba(220, 40, 40, 255)))
+    out = Renders()
+    out.layers[0] = lst
+    return out
+
+
+def linear_gradient(w=800.0, h=600.0) -> Renders:
+    """tests/trender_linear_gradient.nim:13-99 (golden: tests/expected/render_linear_gradient.png)."""
+    lst = RenderList()
+    root = lst.addRoot(Fig(kind=RECT, screenBox=rect(0, 0, w, h), fill=rgba(255, 255, 255, 255)))
+    lst.addChild(root, Fig(kind=RECT, screenBox=rect(80, 80, 440, 120), corners=[12] * 4,
+                           fill=linear(rgba(220, 40, 40, 255), rgba(40, 200, 90, 255), rgba(50, 90, 225, 255),
+                                       axis=FillGradientAxis.fgaX, midPos=128)))
+    lst.addChild(root, Fig(kind=RECT, screenBox=rect(80, 240, 220, 220), corners=[10] * 4,
+                           fill=linear(rgba(240, 210, 40, 255), rgba(110, 60, 210, 255), axis=FillGradientAxis.fgaY)))
+    lst.addChild(root, Fig(kind=RECT, screenBox=rect(340, 250, 240, 180), fill=rgba(0, 0, 0, 0),
+                           stroke=RenderStroke(weight=20, fill=linear(rgba(245, 70, 70, 255), rgba(70, 115, 245, 255),
+                                                                      axis=FillGradientAxis.fgaX))))
+    lst.addChild(root, Fig(kind=RECT, screenBox=rect(610, 300, 150, 200), fill=rgba(245, 245, 245, 255),
+                           shadows=[RenderShadow(style=DROP, blur=6, spread=14, x=0, y=0,
+                                                 fill=linear(rgba(255, 70, 70, 170), rgba(70, 110, 255, 170),
+                                                             axis=FillGradientAxis.fgaX))]))
+    out = Renders()
+    out.layers[0] = lst
+    return out
+
+
+def _add_root_rect(lst, box, color, z, clip=False, rectMask=False, corners=10):
+    flags = FigFlags(0)
+    if clip:
+        flags |= FigFlags.NfClipContent
+    if rectMask:
+        flags |= FigFlags.NfRectMaskContent
+    return lst.addRoot(Fig(kind=RECT, zlevel=z, screenBox=box, fill=color, corners=[corners] * 4, flags=flags))
+
+
+def _add_rect(lst, parent, box, color, z, clip=False, rectMask=False, corners=10):
+    flags = FigFlags(0)
+    if clip:
+        flags |= FigFlags.NfClipContent
+    if rectMask:
+        flags |= FigFlags.NfRectMaskContent
+    lst.addChild(parent, Fig(kind=RECT, zlevel=z, screenBox=box, fill=color, corners=[corners] * 4, flags=flags))
+
+
+def layers_clip(w=800.0, h=375.0, rectMask=False) -> Renders:
+    """tests/trender_layers_clip.nim:76-171 (golden: tests/expected/render_layers_clip.png, both variants)."""
+    bg, container, button = rgba(255, 255, 255, 255), rgba(208, 208, 208, 255), rgba(43, 159, 234, 255)
+    containerW, containerH, containerY = w * 0.30, w * 0.40, h * 0.10
+    containerLeftX, containerRightX = w * 0.03, w * 0.50
+    buttonX, buttonW, buttonH = containerW * 0.10, containerW * 1.30, containerH * 0.20
+    buttonY1, buttonY2, buttonY3 = containerH * 0.15, containerH * 0.45, containerH * 0.75
+    bgList, layer0, low, top = RenderList(), RenderList(), RenderList(), RenderList()
+    bgList.addRoot(Fig(kind=RECT, zlevel=-20, screenBox=rect(0, 0, w, h), fill=bg))
+    left = _add_root_rect(layer0, rect(containerLeftX, containerY, containerW, containerH), container, 0)
+    right = _add_root_rect(layer0, rect(containerRightX, containerY, containerW, containerH), container, 0,
+                           clip=not rectMask, rectMask=rectMask)
+    _add_rect(layer0, left, rect(containerLeftX + buttonX, containerY + buttonY2, buttonW, buttonH), button, 0)
+    _add_rect(layer0, right, rect(containerRightX + buttonX, containerY + buttonY2, buttonW, buttonH), button, 0)
+    _add_root_rect(low, rect(containerLeftX + buttonX, containerY + buttonY3, buttonW, buttonH), button, -5)
+    _add_root_rect(top, rect(containerLeftX + buttonX, containerY + buttonY1, buttonW, buttonH), button, 20)
+    _add_root_rect(low, rect(containerRightX + buttonX, containerY + buttonY3, buttonW, buttonH), button, -5)
+    _add_root_rect(top, rect(containerRightX + buttonX, containerY + buttonY1, buttonW, buttonH), button, 20)
+    out = Renders()
+    out.layers[-20] = bgList
+    out.layers[0] = layer0
+    out.layers[-5] = low
+    out.layers[20] = top
+    out.sort()
+    return out
+
+
+def rect_mask_mixed_batch(w=480.0, h=180.0) -> Renders:
+    """tests/trender_layers_clip.nim:179-221."""
+    lst = RenderList()
+    _add_root_rect(lst, rect(0, 0, w, h), rgba(255, 255, 255, 255), 0, corners=0)
+    _add_root_rect(lst, rect(32, 48, 96, 80), rgba(230, 70, 52, 255), 0, corners=0)
+    m = _add_root_rect(lst, rect(180, 48, 80, 80), rgba(218, 218, 218, 255), 0, rectMask=True, corners=0)
+    _add_rect(lst, m, rect(150, 72, 150, 34), rgba(56, 168, 88, 255), 0, corners=0)
+    _add_root_rect(lst, rect(310, 48, 96, 80), rgba(54, 118, 230, 255), 0, corners=0)
+    out = Renders()
+    out.layers[0] = lst
+    return out
+
+
+# ----------------------------------------------------------------------- extra coverage (SwiftShader goldens)
+def elliptical_and_fractional(w=320.0, h=240.0) -> Renders:
+    """Elliptical corners, fractional rects (ceil-snapped quad with un-snapped half extents),
+    translucent fills and strokes, spread-only and blur-only shadows."""
+    lst = RenderList()
+    lst.addRoot(Fig(kind=RECT, screenBox=rect(0, 0, w, h), fill=rgba(250, 250, 245, 255)))
+    lst.addRoot(Fig(kind=RECT, screenBox=rect(20.3, 15.6, 120.5, 70.25), fill=rgba(30, 120, 220, 155),
+                    corners=[30, 10, 8, 40], cornerRadiiY=[30, 20, 8, 80], flags=FigFlags.NfEllipticalCorners,
+                    stroke=RenderStroke(weight=5.0, fill=fill(rgba(10, 10, 10, 200)))))
+    lst.addRoot(Fig(kind=RECT, screenBox=rect(170.5, 20.5, 110.0, 60.0), fill=rgba(240, 200, 40, 255),
+                    corners=[90, 90, 90, 90], cornerRadiiY=[50, 50, 50, 50], flags=FigFlags.NfEllipticalCorners,
+                    stroke=RenderStroke(weight=4.0, fill=fill(rgba(90, 45, 0, 220))),
+                    shadows=[RenderShadow(style=DROP, blur=0, spread=6, x=3, y=4, fill=fill(rgba(0, 0, 0, 120))),
+                             RenderShadow(style=DROP, blur=9, spread=0, x=-6, y=5, fill=fill(rgba(200, 0, 0, 90)))]))
+    lst.addRoot(Fig(kind=RECT, screenBox=rect(30.75, 120.2, 130.3, 90.9), corners=[16, 0, 24, 7],
+                    fill=linear(rgba(44, 72, 186, 255), rgba(60, 90, 220, 200), rgba(118, 168, 255, 255),
+                                axis=FillGradientAxis.fgaDiagBLTR, midPos=132),
+                    stroke=RenderStroke(weight=3.5, fill=linear(rgba(255, 255, 255, 210), rgba(0, 0, 0, 210),
+                                                                axis=FillGradientAxis.fgaY)),
+                    shadows=[RenderShadow(style=INNER, blur=11, spread=5, x=4.5, y=-3.5,
+                                          fill=linear(rgba(25, 25, 40, 100), rgba(65, 65, 95, 180),
+                                                      axis=FillGradientAxis.fgaDiagBLTR)),
+                             RenderShadow(style=INNER, blur=0, spread=3, x=0, y=0, fill=fill(rgba(255, 0, 255, 80)))]))
+    lst.addRoot(Fig(kind=RECT, screenBox=rect(190.2, 110.7, 100.6, 100.1), corners=[50, 50, 50, 50],
+                    fill=linear(rgba(18, 112, 64, 255), rgba(40, 180, 90, 120), rgba(78, 224, 188, 255),
+                                axis=FillGradientAxis.fgaDiagTLBR, midPos=60),
+                    shadows=[RenderShadow(style=DROP, blur=14, spread=3, x=5, y=7,
+                                          fill=linear(rgba(255, 70, 70, 170), rgba(70, 110, 255, 170),
+                                                      axis=FillGradientAxis.fgaY))]))
+    out = Renders()
+    out.layers[0] = lst
+    return out
+
+
+def nested_clips(w=320.0, h=240.0) -> Renders:
+    """NfClipContent nested two deep (mask = (alpha*parent)^2 per level), a clipped node with its own
+    shadow (drawn unclipped, before beginMask) and children overflowing both clips."""
+    lst = RenderList()
+    lst.addRoot(Fig(kind=RECT, screenBox=rect(0, 0, w, h), fill=rgba(255, 255, 255, 255)))
+    outer = lst.addRoot(Fig(kind=RECT, screenBox=rect(30.5, 20.25, 220, 170), fill=rgba(220, 220, 230, 255),
+                            corners=[40, 12, 25, 60], flags=FigFlags.NfClipContent,
+                            shadows=[RenderShadow(style=DROP, blur=8, spread=2, x=4, y=4, fill=fill(rgba(0, 0, 0, 90)))]))
+    lst.addChild(outer, Fig(kind=RECT, screenBox=rect(10, 100, 300, 60), fill=rgba(43, 159, 234, 200), corners=[10] * 4))
+    inner = lst.addChild(outer, Fig(kind=RECT, screenBox=rect(120.75, 40.5, 180, 120), fill=rgba(250, 180, 60, 255),
+                                    corners=[30] * 4, flags=FigFlags.NfClipContent,
+                                    stroke=RenderStroke(weight=3, fill=fill(rgba(120, 60, 0, 255)))))
+    lst.addChild(inner, Fig(kind=RECT, screenBox=rect(100, 30, 250, 50), fill=rgba(200, 30, 60, 230), corners=[20] * 4))
+    lst.addChild(inner, Fig(kind=RECT, screenBox=rect(150, 90, 60, 120), fill=rgba(20, 160, 70, 255)))
+    lst.addRoot(Fig(kind=RECT, screenBox=rect(5, 200, 120, 30), fill=rgba(90, 20, 160, 255), corners=[8] * 4))
+    out = Renders()
+    out.layers[0] = lst
+    return out
+
+
+def rect_mask_nested(w=320.0, h=240.0) -> Renders:
+    """NfRectMaskContent with rounded corners; a second rect mask nested inside falls back to a real mask
+    (glcontext.nim:1932-1943); plus a NfClipContent child inside a rect mask."""
+    lst = RenderList()
+    lst.addRoot(Fig(kind=RECT, screenBox=rect(0, 0, w, h), fill=rgba(255, 255, 255, 255)))
+    a = lst.addRoot(Fig(kind=RECT, screenBox=rect(20.5, 20.5, 200, 150), fill=rgba(225, 225, 225, 255),
+                        corners=[30, 8, 16, 44], flags=FigFlags.NfRectMaskContent))
+    lst.addChild(a, Fig(kind=RECT, screenBox=rect(0, 60, 320, 40), fill=rgba(56, 168, 88, 220)))
+    b = lst.addChild(a, Fig(kind=RECT, screenBox=rect(100, 30, 160, 110), fill=rgba(54, 118, 230, 255),
+                            corners=[25] * 4, flags=FigFlags.NfRectMaskContent))
+    lst.addChild(b, Fig(kind=RECT, screenBox=rect(80, 100, 220, 30), fill=rgba(230, 70, 52, 255), corners=[6] * 4))
+    c = lst.addChild(a, Fig(kind=RECT, screenBox=rect(30, 110, 90, 50), fill=rgba(250, 210, 80, 255),
+                            corners=[14] * 4, flags=FigFlags.NfClipContent))
+    lst.addChild(c, Fig(kind=RECT, screenBox=rect(10, 130, 140, 20), fill=rgba(30, 30, 30, 255)))
+    lst.addRoot(Fig(kind=RECT, screenBox=rect(230, 180, 70, 40), fill=rgba(120, 20, 160, 255), corners=[8] * 4))
+    out = Renders()
+    out.layers[0] = lst
+    return out
+
+
+def backdrop_blur(w=320.0, h=240.0) -> Renders:
+    """nkBackdropBlur nodes (a rounded one with a tint overlay and a later, overlapping one: each is a global
+    barrier in painter's order) over a busy background; radius 18 -> step 2.25 px."""
+    lst = RenderList()
+    lst.addRoot(Fig(kind=RECT, screenBox=rect(0, 0, w, h), fill=rgba(255, 255, 255, 255)))
+    cols = [rgba(220, 40, 40, 255), rgba(40, 180, 90, 255), rgba(60, 90, 220, 255), rgba(240, 200, 40, 255)]
+    for i in range(12):
+        lst.addRoot(Fig(kind=RECT, screenBox=rect(10 + 25 * i, 10 + 17 * (i % 5), 40, 170 - 9 * i), fill=cols[i % 4],
+                        corners=[6 + i] * 4, stroke=RenderStroke(weight=2, fill=fill(rgba(0, 0, 0, 255)))))
+    lst.addRoot(Fig(kind=FigKind.nkBackdropBlur, screenBox=rect(40.5, 50.25, 180, 120), corners=[28] * 4,
+                    fill=rgba(255, 255, 255, 60), blur=18.0))
+    lst.addRoot(Fig(kind=RECT, screenBox=rect(60, 70, 60, 30), fill=rgba(0, 0, 0, 255), corners=[5] * 4))
+    lst.addRoot(Fig(kind=FigKind.nkBackdropBlur, screenBox=rect(150, 20, 150, 200), corners=[10, 40, 10, 40],
+                    cornerRadiiY=[20, 40, 5, 70], flags=FigFlags.NfEllipticalCorners, fill=rgba(0, 0, 0, 0), blur=5.0))
+    lst.addRoot(Fig(kind=RECT, screenBox=rect(250, 190, 60, 40), fill=rgba(255, 225, 55, 120), corners=[10] * 4,
+                    stroke=RenderStroke(weight=6.0, fill=fill(rgba(95, 72, 0, 185)))))
+    out = Renders()
+    out.layers[0] = lst
+    return out
+
+
+def rotation_and_transform(w=320.0, h=240.0) -> Renders:
+    """Rotated nodes (two-triangle rasterisation of per-vertex ceil'd quads),
+    nkTransform translation + matrix, and a rect mask created under a rotated transform."""
+    lst = RenderList()
+    lst.addRoot(Fig(kind=RECT, screenBox=rect(0, 0, w, h), fill=rgba(255, 255, 255, 255)))
+    lst.addRoot(Fig(kind=RECT, screenBox=rect(30, 30, 120, 70), rotation=17.0, fill=rgba(220, 40, 40, 200),
+                    corners=[10, 20, 30, 5], stroke=RenderStroke(weight=4, fill=fill(rgba(0, 0, 0, 255))),
+                    shadows=[RenderShadow(style=DROP, blur=8, spread=4, x=6, y=6, fill=fill(rgba(0, 0, 0, 100)))]))
+    t = lst.addRoot(Fig(kind=FigKind.nkTransform, translation=(150.0, 20.0), useMatrix=True,
+                        matrix=[1.2, 0.25, 0, 0, -0.3, 0.9, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1]))
+    lst.addChild(t, Fig(kind=RECT, screenBox=rect(10, 10, 100, 60),
+                        fill=linear(rgba(24, 128, 72, 255), rgba(40, 180, 90, 255), rgba(54, 206, 170, 255),
+                                    axis=FillGradientAxis.fgaX, midPos=140), corners=[14] * 4,
+                        shadows=[RenderShadow(style=INNER, blur=8, spread=1, x=3, y=3, fill=fill(rgba(0, 0, 0, 160)))]))
+    m = lst.addRoot(Fig(kind=RECT, screenBox=rect(40, 130, 140, 80), rotation=-25.0, fill=rgba(210, 210, 225, 255),
+                        corners=[20] * 4, flags=FigFlags.NfRectMaskContent))
+    lst.addChild(m, Fig(kind=RECT, screenBox=rect(20, 150, 200, 30), fill=rgba(43, 159, 234, 255), corners=[8] * 4))
+    lst.addRoot(Fig(kind=RECT, screenBox=rect(210, 140, 80, 60), rotation=45.0,
+                    fill=linear(rgba(240, 210, 40, 255), rgba(110, 60, 210, 255), axis=FillGradientAxis.fgaDiagTLBR)))
+    out = Renders()
+    out.layers[0] = lst
+    return out
+
+
+REFERENCE_PNG_SCENES = {
+    # name: (builder, width, height, reference golden png under tests/expected/)
+    "rgb_boxes_sdf": (rgb_boxes_sdf, 800, 600, "render_rgb_boxes_sdf.png"),
+    "linear_gradient": (linear_gradient, 800, 600, "render_linear_gradient.png"),
+    "layers_clip": (lambda w, h: layers_clip(w, h, False), 800, 375, "render_layers_clip.png"),
+    "layers_rect_mask": (lambda w, h: layers_clip(w, h, True), 800, 375, "render_layers_clip.png"),
+}
+
+SWIFTSHADER_SCENES = {
+    "oneframe": (oneframe, 240, 160),
+    "rect_mask_mixed_batch": (rect_mask_mixed_batch, 480, 180),
+    "elliptical_and_fractional": (elliptical_and_fractional, 320, 240),
+    "nested_clips": (nested_clips, 320, 240),
+    "rect_mask_nested": (rect_mask_nested, 320, 240),
+    "backdrop_blur": (backdrop_blur, 320, 240),
+    "rotation_and_transform": (rotation_and_transform, 320, 240),
+}

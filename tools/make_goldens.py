@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Regenerates tests/golden/ (run in the build container only; needs /root/reference + SwiftShader).
+
+  ref_<name>.png   byte-for-byte image content of the reference's own test fixtures
+                   (tests/expected/*.png in the reference): data the reference's tests hold.
+  ss_<name>.png    the reference's GLSL shaders run on SwiftShader (oracle/ref_swiftshader.py)
+                   over the BackendContext call stream the scene decomposes into.
+  manifest.json    sizes, provenance and the measured oracle-vs-golden agreement at generation time.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+from PIL import Image
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import ref_scenes as RS  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+from oracle import ref_swiftshader as R  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+REF_EXPECTED = "/root/reference/tests/expected"
+
+
+def stats(a, b):
+    d = np.abs(a.astype(int) - b.astype(int)).max(axis=2)
+    return {"max": int(d.max()), "n_gt0": int((d > 0).sum()), "n_gt1": int((d > 1).sum())}
+
+
+def main():
+    assert R.available(), "needs /root/reference and SwiftShader"
+    os.makedirs(GOLD, exist_ok=True)
+    manifest = {}
+    scenes = {k: v[:3] for k, v in RS.REFERENCE_PNG_SCENES.items()}
+    scenes.update(RS.SWIFTSHADER_SCENES)
+    for name, (fn, w, h) in scenes.items():
+        o = O.Oracle(threads=8)
+        o.record_begin()
+        o.render_frame(fn(float(w), float(h)), w, h)
+        calls = o.record_calls()
+        img = o.read_pixels()
+        ss = R.replay(calls, w, h)
+        Image.fromarray(ss).save(os.path.join(GOLD, f"ss_{name}.png"), optimize=True)
+        entry = {"width": w, "height": h, "n_calls": len(calls), "oracle_vs_swiftshader": stats(img, ss)}
+        if name in RS.REFERENCE_PNG_SCENES:
+            png = RS.REFERENCE_PNG_SCENES[name][3]
+            exp = np.array(Image.open(os.path.join(REF_EXPECTED, png)).convert("RGBA"))
+            Image.fromarray(exp).save(os.path.join(GOLD, f"ref_{png}"), optimize=True)
+            entry["reference_png"] = png
+            entry["oracle_vs_reference_png"] = stats(img, exp)
+            entry["swiftshader_vs_reference_png"] = stats(ss, exp)
+        manifest[name] = entry
+        print(name, entry)
+    # blur-only vectors: random RGBA8 through blur.frag H+V at several radii
+    rng = np.random.default_rng(7)
+    src = rng.integers(0, 256, size=(64, 96, 4), dtype=np.uint8)
+    Image.fromarray(src).save(os.path.join(GOLD, "blur_src.png"))
+    for radius in (0.4, 1.0, 5.0, 18.0, 64.0, 100.0):
+        gl = R.RefGL(96, 64)
+        out = gl.blur_only(src, radius)
+        gl.close()
+        Image.fromarray(out).save(os.path.join(GOLD, f"ss_blur_r{radius:g}.png"))
+        manifest[f"blur_r{radius:g}"] = {"oracle_vs_swiftshader": stats(O.blur_image(src, radius), out)}
+        print("blur", radius, manifest[f"blur_r{radius:g}"])
+    with open(os.path.join(GOLD, "manifest.json"), "w") as f:
+        json.dump(manifest, f, indent=1, sort_keys=True)
+
+
+if __name__ == "__main__":
+    main()
