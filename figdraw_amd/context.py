@@ -1,0 +1,291 @@
+"""HipContext: the BackendContext-shaped Python binding over libfigdraw_hip.so.
+
+Method names follow the reference's `BackendContext` (src/figdraw/figbackend.nim:245-705) in
+snake_case; `render_frame` is `renderFrame` (figrender.nim:1960-1995).  There is no fallback: if
+the shared library is missing or no gfx950 GPU is usable, construction raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import Optional
+
+import numpy as np
+
+from . import scene as S
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfigdraw_hip.so")
+_lib = None
+
+_F4 = C.c_float * 4
+_F2 = C.c_float * 2
+_COL4 = S.CColor * 4
+
+
+class FigdrawHipError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"[{code}] {msg}")
+        self.code = code
+
+
+class FrameStats(C.Structure):
+    _fields_ = [("n_draws", C.c_int32), ("n_phases", C.c_int32), ("n_blurs", C.c_int32), ("n_bins", C.c_int32),
+                ("ms_total", C.c_float), ("ms_bin", C.c_float), ("ms_composite", C.c_float), ("ms_blur", C.c_float),
+                ("bytes_algorithmic", C.c_int64), ("fragments", C.c_int64)]
+
+
+def build(force: bool = False) -> str:
+    """hipcc --offload-arch=gfx950 the C-ABI library in-tree (cross-compiles without a GPU)."""
+    csrc = os.path.join(_HERE, "csrc")
+    args = ["make", "-C", csrc, "-s"]
+    if force:
+        args.append("-B")
+    subprocess.check_call(args)
+    return LIB_PATH
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FigdrawHipError(-2, f"{LIB_PATH} is missing: run __graft_entry__.build() (there is no CPU fallback)")
+    L = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    L.fdh_last_error.restype = C.c_char_p
+    L.fdh_version.restype = C.c_char_p
+    L.fdh_create.argtypes = [C.POINTER(vp), C.c_int, C.c_float, C.c_int, C.c_uint32]
+    L.fdh_destroy.argtypes = [vp]
+    L.fdh_set_stream.argtypes = [vp, vp]
+    L.fdh_begin_frame.argtypes = [vp, C.c_int, C.c_int, C.c_int, _F4]
+    L.fdh_end_frame.argtypes = [vp]
+    L.fdh_save_transform.argtypes = [vp]
+    L.fdh_restore_transform.argtypes = [vp]
+    L.fdh_translate.argtypes = [vp, C.c_float, C.c_float]
+    L.fdh_rotate.argtypes = [vp, C.c_float]
+    L.fdh_scale.argtypes = [vp, C.c_float, C.c_float]
+    L.fdh_apply_transform.argtypes = [vp, C.c_float * 16]
+    L.fdh_transform_mirrors_y.argtypes = [vp, C.POINTER(C.c_int)]
+    L.fdh_set_aa_factor.argtypes = [vp, C.c_float]
+    L.fdh_get_aa_factor.argtypes = [vp, C.POINTER(C.c_float)]
+    L.fdh_get_pixel_scale.argtypes = [vp, C.POINTER(C.c_float)]
+    L.fdh_draw_rounded_rect_sdf.argtypes = [vp, _F4, _COL4, _F4, _F4, C.c_int, C.c_float, C.c_float, _F2, C.c_int,
+                                            S.CColor, S.CColor, C.c_float]
+    L.fdh_draw_rounded_rect_fill.argtypes = [vp, _F4, C.POINTER(S.CFill), _F4, _F4, C.c_int, C.c_float, C.c_float, _F2]
+    L.fdh_draw_image.argtypes = [vp, C.c_int64, _F2, _COL4, _F2, C.c_int]
+    L.fdh_draw_msdf.argtypes = [vp, C.c_int64, _F2, S.CColor, _F2, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int]
+    L.fdh_draw_backdrop_blur.argtypes = [vp, _F4, _F4, _F4, C.c_float]
+    L.fdh_begin_mask.argtypes = [vp, _F4, _F4, _F4]
+    L.fdh_end_mask.argtypes = [vp]
+    L.fdh_pop_mask.argtypes = [vp]
+    L.fdh_begin_rect_mask.argtypes = [vp, _F4, _F4, _F4]
+    L.fdh_pop_rect_mask.argtypes = [vp]
+    L.fdh_set_text_subpixel_positioning.argtypes = [vp, C.c_int]
+    L.fdh_set_text_subpixel_shift.argtypes = [vp, C.c_float]
+    L.fdh_put_image.argtypes = [vp, C.c_int64, C.c_int, C.c_int, vp, C.c_int * 4]
+    L.fdh_update_image.argtypes = [vp, C.c_int64, C.c_int, C.c_int, vp]
+    L.fdh_remove_image.argtypes = [vp, C.c_int64]
+    L.fdh_has_image.argtypes = [vp, C.c_int64, C.POINTER(C.c_int)]
+    L.fdh_reset_atlas.argtypes = [vp, C.c_int]
+    L.fdh_atlas_size.argtypes = [vp, C.POINTER(C.c_int)]
+    L.fdh_atlas_packed_area.argtypes = [vp, C.POINTER(C.c_int64)]
+    L.fdh_read_pixels.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]
+    L.fdh_frame_device_ptr.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int64)]
+    L.fdh_sync.argtypes = [vp]
+    L.fdh_set_ui_scale.argtypes = [vp, C.c_float]
+    L.fdh_render_frame.argtypes = [vp, vp, C.c_float, C.c_float, C.c_int, _F4]
+    L.fdh_set_stripe.argtypes = [vp, C.c_int, C.c_int]
+    L.fdh_replay.argtypes = [vp, C.c_int]
+    L.fdh_get_frame_stats.argtypes = [vp, C.POINTER(FrameStats)]
+    assert L.fdh_sizeof_fig() == C.sizeof(S.CFig), (L.fdh_sizeof_fig(), C.sizeof(S.CFig))
+    assert L.fdh_sizeof_glyph() == C.sizeof(S.CGlyph)
+    _lib = L
+    return L
+
+
+def _cols(colors):
+    return _COL4(*[S.CColor(*[int(v) for v in c]) for c in colors])
+
+
+class HipContext:
+    """One GPU, one HIP stream, one RGBA8 surface (newContext, glcontext.nim:255-261)."""
+
+    def __init__(self, atlas_size: int = 1024, pixel_scale: float = 1.0, device: int = 0):
+        self.L = load()
+        h = C.c_void_p()
+        rc = self.L.fdh_create(C.byref(h), atlas_size, pixel_scale, device, 0)
+        if rc != 0:
+            raise FigdrawHipError(rc, self.L.fdh_last_error().decode())
+        self.h = h
+        self.W = self.H = 0
+        self.device = device
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise FigdrawHipError(rc, self.L.fdh_last_error().decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.fdh_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- BackendContext surface
+    def begin_frame(self, w, h, clear=True, color=(1.0, 1.0, 1.0, 1.0)):
+        self.W, self.H = int(w), int(h)
+        self._ck(self.L.fdh_begin_frame(self.h, int(w), int(h), int(bool(clear)), _F4(*color)))
+
+    def end_frame(self):
+        self._ck(self.L.fdh_end_frame(self.h))
+
+    def save_transform(self):
+        self._ck(self.L.fdh_save_transform(self.h))
+
+    def restore_transform(self):
+        self._ck(self.L.fdh_restore_transform(self.h))
+
+    def translate(self, x, y):
+        self._ck(self.L.fdh_translate(self.h, x, y))
+
+    def rotate(self, a):
+        self._ck(self.L.fdh_rotate(self.h, a))
+
+    def scale(self, sx, sy=None):
+        self._ck(self.L.fdh_scale(self.h, sx, sx if sy is None else sy))
+
+    def apply_transform(self, m16):
+        self._ck(self.L.fdh_apply_transform(self.h, (C.c_float * 16)(*m16)))
+
+    def transform_mirrors_y(self) -> bool:
+        out = C.c_int()
+        self._ck(self.L.fdh_transform_mirrors_y(self.h, C.byref(out)))
+        return bool(out.value)
+
+    def set_aa_factor(self, aa):
+        self._ck(self.L.fdh_set_aa_factor(self.h, aa))
+
+    def sdf_aa_factor(self) -> float:
+        out = C.c_float()
+        self._ck(self.L.fdh_get_aa_factor(self.h, C.byref(out)))
+        return out.value
+
+    def draw_rounded_rect_sdf(self, rect, colors, radii_x, radii_y, mode, factor=4.0, spread=0.0, shape=(0.0, 0.0),
+                              fill_mode=0, mid=(0, 0, 0, 0), stop=(0, 0, 0, 0), mid_pos=0.5):
+        self._ck(self.L.fdh_draw_rounded_rect_sdf(self.h, _F4(*rect), _cols(colors), _F4(*radii_x), _F4(*radii_y), int(mode),
+                                                  factor, spread, _F2(*shape), int(fill_mode), S.CColor(*mid),
+                                                  S.CColor(*stop), mid_pos))
+
+    def draw_rounded_rect_fill(self, rect, fill: S.Fill, radii_x, radii_y, mode, factor=4.0, spread=0.0, shape=(0.0, 0.0)):
+        cf = S.cfill(fill)
+        self._ck(self.L.fdh_draw_rounded_rect_fill(self.h, _F4(*rect), C.byref(cf), _F4(*radii_x), _F4(*radii_y), int(mode),
+                                                   factor, spread, _F2(*shape)))
+
+    def draw_image(self, key, pos, colors, size=(0.0, 0.0), flip_y=False):
+        self._ck(self.L.fdh_draw_image(self.h, int(key), _F2(*pos), _cols(colors), _F2(*size), int(bool(flip_y))))
+
+    def draw_msdf(self, key, pos, color, size, px_range, sd_threshold=0.5, stroke_weight=0.0, mtsdf=False, flip_y=False):
+        self._ck(self.L.fdh_draw_msdf(self.h, int(key), _F2(*pos), S.CColor(*color), _F2(*size), px_range, sd_threshold,
+                                      stroke_weight, int(bool(mtsdf)), int(bool(flip_y))))
+
+    def draw_backdrop_blur(self, rect, radii_x, radii_y, blur_radius):
+        self._ck(self.L.fdh_draw_backdrop_blur(self.h, _F4(*rect), _F4(*radii_x), _F4(*radii_y), blur_radius))
+
+    def begin_mask(self, rect, radii_x, radii_y):
+        self._ck(self.L.fdh_begin_mask(self.h, _F4(*rect), _F4(*radii_x), _F4(*radii_y)))
+
+    def end_mask(self):
+        self._ck(self.L.fdh_end_mask(self.h))
+
+    def pop_mask(self):
+        self._ck(self.L.fdh_pop_mask(self.h))
+
+    def begin_rect_mask(self, rect, radii_x, radii_y):
+        self._ck(self.L.fdh_begin_rect_mask(self.h, _F4(*rect), _F4(*radii_x), _F4(*radii_y)))
+
+    def pop_rect_mask(self):
+        self._ck(self.L.fdh_pop_rect_mask(self.h))
+
+    def set_text_subpixel(self, enabled: bool, shift: float = 0.0):
+        self._ck(self.L.fdh_set_text_subpixel_positioning(self.h, int(bool(enabled))))
+        self._ck(self.L.fdh_set_text_subpixel_shift(self.h, shift))
+
+    # ---- atlas
+    def put_image(self, key, rgba: np.ndarray):
+        rgba = np.ascontiguousarray(rgba, dtype=np.uint8)
+        out = (C.c_int * 4)()
+        self._ck(self.L.fdh_put_image(self.h, int(key), rgba.shape[1], rgba.shape[0], rgba.ctypes.data, out))
+        return tuple(out)
+
+    def update_image(self, key, rgba: np.ndarray):
+        rgba = np.ascontiguousarray(rgba, dtype=np.uint8)
+        self._ck(self.L.fdh_update_image(self.h, int(key), rgba.shape[1], rgba.shape[0], rgba.ctypes.data))
+
+    def has_image(self, key) -> bool:
+        out = C.c_int()
+        self._ck(self.L.fdh_has_image(self.h, int(key), C.byref(out)))
+        return bool(out.value)
+
+    def remove_image(self, key):
+        self._ck(self.L.fdh_remove_image(self.h, int(key)))
+
+    def reset_atlas(self, minimum_size=0):
+        self._ck(self.L.fdh_reset_atlas(self.h, int(minimum_size)))
+
+    def atlas_size(self) -> int:
+        out = C.c_int()
+        self._ck(self.L.fdh_atlas_size(self.h, C.byref(out)))
+        return out.value
+
+    # ---- readback
+    def read_pixels(self, x=0, y=0, w=0, h=0) -> np.ndarray:
+        if w <= 0 or h <= 0:
+            x, y, w, h = 0, 0, self.W, self.H
+        out = np.zeros((h, w, 4), dtype=np.uint8)
+        self._ck(self.L.fdh_read_pixels(self.h, x, y, w, h, out.ctypes.data))
+        return out
+
+    def frame_device_ptr(self):
+        p, w, h, pitch = C.c_void_p(), C.c_int(), C.c_int(), C.c_int64()
+        self._ck(self.L.fdh_frame_device_ptr(self.h, C.byref(p), C.byref(w), C.byref(h), C.byref(pitch)))
+        return p.value, w.value, h.value, pitch.value
+
+    def sync(self):
+        self._ck(self.L.fdh_sync(self.h))
+
+    def set_stream(self, stream_ptr: Optional[int]):
+        self._ck(self.L.fdh_set_stream(self.h, C.c_void_p(stream_ptr or 0)))
+
+    # ---- whole scenes
+    def render_frame(self, renders: S.Renders, w, h, clear=True, color=(1.0, 1.0, 1.0, 1.0), ui_scale=1.0):
+        cs = renders.to_c()
+        self._ck(self.L.fdh_set_ui_scale(self.h, ui_scale))
+        self.W, self.H = int(w * ui_scale), int(h * ui_scale)
+        self._ck(self.L.fdh_render_frame(self.h, cs.byref(), float(w), float(h), int(bool(clear)), _F4(*color)))
+
+    def replay_calls(self, calls):
+        """Replay a recorded BackendContext call stream (same format as the test harnesses use)."""
+        for call in calls:
+            name, args = call[0], call[1:]
+            if name == "begin_frame":
+                self.begin_frame(self.W, self.H, *args)
+            else:
+                getattr(self, name)(*args)
+
+    # ---- multi-GPU / measurement
+    def set_stripe(self, y0: int, y1: int):
+        self._ck(self.L.fdh_set_stripe(self.h, int(y0), int(y1)))
+
+    def replay(self, times: int = 1):
+        self._ck(self.L.fdh_replay(self.h, int(times)))
+
+    def frame_stats(self) -> FrameStats:
+        st = FrameStats()
+        self._ck(self.L.fdh_get_frame_stats(self.h, C.byref(st)))
+        return st

@@ -1,0 +1,149 @@
+// fdh_capi.cpp -- extern "C" surface of libfigdraw_hip.so (include/figdraw_hip.h).  Every entry point
+// converts C++ exceptions into a negative FdhStatus + a thread-local message: nothing throws across the ABI.
+#include <string>
+
+#include "fdh_context.h"
+
+using fdh::Context;
+
+namespace {
+thread_local std::string g_last_error;
+
+template <typename F>
+int guard(F&& f) {
+  try {
+    f();
+    return FDH_OK;
+  } catch (const fdh::Error& e) {
+    g_last_error = e.what();
+    return e.code;
+  } catch (const std::exception& e) {
+    g_last_error = e.what();
+    return FDH_ERR_INVALID;
+  } catch (...) {
+    g_last_error = "unknown error";
+    return FDH_ERR_INVALID;
+  }
+}
+inline Context* C(FdhContext* c) {
+  if (!c) throw fdh::Error(FDH_ERR_INVALID, "null FdhContext");
+  return reinterpret_cast<Context*>(c);
+}
+}  // namespace
+
+extern "C" {
+
+const char* fdh_last_error(void) { return g_last_error.c_str(); }
+const char* fdh_version(void) { return "figdraw_hip 0.1.0 (gfx950)"; }
+int fdh_sizeof_fig(void) { return (int)sizeof(FdhFig); }
+int fdh_sizeof_glyph(void) { return (int)sizeof(FdhGlyph); }
+
+int fdh_create(FdhContext** out, int atlas_size, float pixel_scale, int device, uint32_t flags) {
+  return guard([&] {
+    if (!out) throw fdh::Error(FDH_ERR_INVALID, "fdh_create: null out pointer");
+    *out = nullptr;
+    *out = reinterpret_cast<FdhContext*>(new Context(atlas_size, pixel_scale, device, flags));
+  });
+}
+int fdh_destroy(FdhContext* c) { return guard([&] { delete C(c); }); }
+int fdh_set_stream(FdhContext* c, void* s) { return guard([&] { C(c)->set_stream(s); }); }
+
+int fdh_begin_frame(FdhContext* c, int w, int h, int clear, const float rgba[4]) {
+  return guard([&] {
+    const float white[4] = {1, 1, 1, 1};
+    C(c)->begin_frame(w, h, clear != 0, rgba ? rgba : white);
+  });
+}
+int fdh_end_frame(FdhContext* c) { return guard([&] { C(c)->end_frame(); }); }
+int fdh_save_transform(FdhContext* c) { return guard([&] { C(c)->save_transform(); }); }
+int fdh_restore_transform(FdhContext* c) { return guard([&] { C(c)->restore_transform(); }); }
+int fdh_translate(FdhContext* c, float x, float y) { return guard([&] { C(c)->translate(x, y); }); }
+int fdh_rotate(FdhContext* c, float a) { return guard([&] { C(c)->rotate(a); }); }
+int fdh_scale(FdhContext* c, float sx, float sy) { return guard([&] { C(c)->scale(sx, sy); }); }
+int fdh_apply_transform(FdhContext* c, const float m[16]) { return guard([&] { C(c)->apply_transform(m); }); }
+int fdh_transform_mirrors_y(FdhContext* c, int* out) { return guard([&] { *out = C(c)->transform_mirrors_y() ? 1 : 0; }); }
+int fdh_set_aa_factor(FdhContext* c, float aa) { return guard([&] { C(c)->set_aa(aa); }); }
+int fdh_get_aa_factor(FdhContext* c, float* out) { return guard([&] { *out = C(c)->aa(); }); }
+int fdh_get_pixel_scale(FdhContext* c, float* out) { return guard([&] { *out = C(c)->pixel_scale(); }); }
+
+int fdh_draw_rounded_rect_sdf(FdhContext* c, const float rect[4], const FdhColor colors[4], const float rx[4], const float ry[4],
+                              int mode, float factor, float spread, const float shape[2], int fill_mode, FdhColor mid,
+                              FdhColor stop, float mid_pos) {
+  return guard([&] {
+    const float zero2[2] = {0, 0};
+    C(c)->draw_rounded_rect_sdf(rect, colors, rx, ry ? ry : rx, mode, factor, spread, shape ? shape : zero2, fill_mode, mid, stop, mid_pos);
+  });
+}
+int fdh_draw_rounded_rect_fill(FdhContext* c, const float rect[4], const FdhFill* fill, const float rx[4], const float ry[4],
+                               int mode, float factor, float spread, const float shape[2]) {
+  return guard([&] {
+    if (!fill) throw fdh::Error(FDH_ERR_INVALID, "null fill");
+    const float zero2[2] = {0, 0};
+    C(c)->draw_rounded_rect_fill(rect, *fill, rx, ry ? ry : rx, mode, factor, spread, shape ? shape : zero2);
+  });
+}
+int fdh_draw_image(FdhContext* c, int64_t key, const float pos[2], const FdhColor colors[4], const float size[2], int flip_y) {
+  return guard([&] {
+    const float zero2[2] = {0, 0};
+    C(c)->draw_image(key, pos, colors, size ? size : zero2, flip_y != 0);
+  });
+}
+int fdh_draw_msdf(FdhContext* c, int64_t key, const float pos[2], FdhColor color, const float size[2], float px_range,
+                  float sd_threshold, float stroke_weight, int mtsdf, int flip_y) {
+  return guard([&] { C(c)->draw_msdf(key, pos, color, size, px_range, sd_threshold, stroke_weight, mtsdf != 0, flip_y != 0); });
+}
+int fdh_draw_backdrop_blur(FdhContext* c, const float rect[4], const float rx[4], const float ry[4], float blur_radius) {
+  return guard([&] { C(c)->draw_backdrop_blur(rect, rx, ry ? ry : rx, blur_radius); });
+}
+int fdh_begin_mask(FdhContext* c, const float rect[4], const float rx[4], const float ry[4]) {
+  return guard([&] { C(c)->begin_mask(rect, rx, ry ? ry : rx); });
+}
+int fdh_end_mask(FdhContext* c) { return guard([&] { C(c)->end_mask(); }); }
+int fdh_pop_mask(FdhContext* c) { return guard([&] { C(c)->pop_mask(); }); }
+int fdh_begin_rect_mask(FdhContext* c, const float rect[4], const float rx[4], const float ry[4]) {
+  return guard([&] { C(c)->begin_rect_mask(rect, rx, ry ? ry : rx); });
+}
+int fdh_pop_rect_mask(FdhContext* c) { return guard([&] { C(c)->pop_rect_mask(); }); }
+int fdh_draw_quadratic_bezier_sdf(FdhContext* c, const float*, const FdhFill*, const float*, const float*, const float*, float, int) {
+  return guard([&] { (void)C(c); throw fdh::Error(FDH_ERR_UNSUPPORTED, "Backend drawQuadraticBezierSdf unavailable"); });
+}
+int fdh_draw_filled_quad(FdhContext* c, const float*, const FdhColor*) {
+  return guard([&] { (void)C(c); throw fdh::Error(FDH_ERR_UNSUPPORTED, "Backend drawFilledQuad unavailable"); });
+}
+int fdh_set_text_subpixel_positioning(FdhContext* c, int e) { return guard([&] { C(c)->set_subpixel_enabled(e != 0); }); }
+int fdh_set_text_subpixel_shift(FdhContext* c, float s) { return guard([&] { C(c)->set_subpixel_shift(s); }); }
+
+int fdh_put_image(FdhContext* c, int64_t key, int w, int h, const uint8_t* rgba, int out_rect[4]) {
+  return guard([&] { C(c)->put_image(key, w, h, rgba, out_rect); });
+}
+int fdh_update_image(FdhContext* c, int64_t key, int w, int h, const uint8_t* rgba) {
+  return guard([&] { C(c)->update_image(key, w, h, rgba); });
+}
+int fdh_remove_image(FdhContext* c, int64_t key) { return guard([&] { C(c)->remove_image(key); }); }
+int fdh_has_image(FdhContext* c, int64_t key, int* out) { return guard([&] { *out = C(c)->has_image(key) ? 1 : 0; }); }
+int fdh_reset_atlas(FdhContext* c, int minimum_size) { return guard([&] { C(c)->reset_atlas(minimum_size); }); }
+int fdh_atlas_size(FdhContext* c, int* out) { return guard([&] { *out = C(c)->atlas_size(); }); }
+int fdh_atlas_packed_area(FdhContext* c, int64_t* out) { return guard([&] { *out = C(c)->atlas_packed_area(); }); }
+
+int fdh_read_pixels(FdhContext* c, int x, int y, int w, int h, uint8_t* out) {
+  return guard([&] {
+    if (!out) throw fdh::Error(FDH_ERR_INVALID, "null output buffer");
+    C(c)->read_pixels(x, y, w, h, out);
+  });
+}
+int fdh_frame_device_ptr(FdhContext* c, void** p, int* w, int* h, int64_t* pitch) {
+  return guard([&] { C(c)->frame_device_ptr(p, w, h, pitch); });
+}
+int fdh_sync(FdhContext* c) { return guard([&] { C(c)->sync(); }); }
+int fdh_set_ui_scale(FdhContext* c, float s) { return guard([&] { C(c)->set_ui_scale(s); }); }
+int fdh_render_frame(FdhContext* c, const FdhScene* scene, float fw, float fh, int clear, const float rgba[4]) {
+  return guard([&] {
+    const float white[4] = {1, 1, 1, 1};
+    C(c)->render_frame(scene, fw, fh, clear != 0, rgba ? rgba : white);
+  });
+}
+int fdh_set_stripe(FdhContext* c, int y0, int y1) { return guard([&] { C(c)->set_stripe(y0, y1); }); }
+int fdh_replay(FdhContext* c, int times) { return guard([&] { C(c)->replay(times); }); }
+int fdh_get_frame_stats(FdhContext* c, FdhFrameStats* out) { return guard([&] { C(c)->frame_stats(out); }); }
+
+}  // extern "C"

@@ -1,0 +1,804 @@
+// fdh_context.cpp -- host side: BackendContext calls -> draw records -> GPU submission.
+//
+// What glcontext.nim does with ten vertex streams and a batch flush, this does with one 128-byte record
+// per call.  The record carries exactly what the reference's vertex attributes carry (ceil-snapped quad,
+// un-snapped half extents, packed radii, mode word, factors, colours) so the kernels can restate the
+// fragment shaders.  Clip masks become push/pop records evaluated analytically per pixel, backdrop
+// blurs split the list into phases (a blur is a global barrier in painter's order, glcontext.nim:1788-1841).
+#include "fdh_context.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace fdh {
+
+void hip_check(hipError_t e, const char* what) {
+  if (e != hipSuccess) throw Error(FDH_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+static inline float nim_round(float x) { return x >= 0.0f ? std::floor(x + 0.5f) : -std::floor(-x + 0.5f); }  // Nim math.round
+static inline float clampf(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); }
+static inline uint32_t pack_color(FdhColor c) { return (uint32_t)c.r | ((uint32_t)c.g << 8) | ((uint32_t)c.b << 16) | ((uint32_t)c.a << 24); }
+
+static Aff aff_mul(const Aff& m, const Aff& n) {
+  Aff r;
+  r.a = m.a * n.a + m.c * n.b;
+  r.b = m.b * n.a + m.d * n.b;
+  r.c = m.a * n.c + m.c * n.d;
+  r.d = m.b * n.c + m.d * n.d;
+  r.tx = m.a * n.tx + m.c * n.ty + m.tx;
+  r.ty = m.b * n.tx + m.d * n.ty + m.ty;
+  return r;
+}
+
+// ------------------------------------------------------------------ lifetime
+Context::Context(int atlas_size, float pixel_scale, int device, uint32_t flags) : device_(device), flags_(flags), pixel_scale_(pixel_scale) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) throw Error(FDH_ERR_NO_DEVICE, "no HIP device visible (libfigdraw_hip has no CPU fallback)");
+  if (device < 0 || device >= n) throw Error(FDH_ERR_NO_DEVICE, "HIP device ordinal out of range");
+  FDH_HIP(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  FDH_HIP(hipGetDeviceProperties(&prop, device));
+  if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+    throw Error(FDH_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library carries gfx950 code only");
+  FDH_HIP(hipStreamCreateWithFlags(&own_stream_, hipStreamNonBlocking));
+  stream_ = own_stream_;
+  for (auto& e : ev_) FDH_HIP(hipEventCreate(&e));
+  initial_atlas_size_ = atlas_size > 0 ? atlas_size : 1024;  // newContext default, glcontext.nim:255-261
+  alloc_atlas(initial_atlas_size_);
+}
+
+Context::~Context() {
+  (void)hipSetDevice(device_);
+  if (stream_) (void)hipStreamSynchronize(stream_);
+  for (auto& e : ev_) if (e) (void)hipEventDestroy(e);
+  for (auto& l : atlas_levels_) if (l) (void)hipFree(l);
+  if (fb_) (void)hipFree(fb_);
+  if (backdrop_) (void)hipFree(backdrop_);
+  if (blur_tmp_) (void)hipFree(blur_tmp_);
+  d_recs_.release(); d_bboxes_.release(); d_exts_.release(); d_lists_.release(); d_counts_.release(); d_phase_first_.release();
+  staging_.release();
+  if (own_stream_) (void)hipStreamDestroy(own_stream_);
+}
+
+void Context::set_stream(void* s) {
+  FDH_HIP(hipStreamSynchronize(stream_));
+  stream_ = s ? (hipStream_t)s : own_stream_;
+}
+void Context::sync() {
+  FDH_HIP(hipSetDevice(device_));
+  FDH_HIP(hipStreamSynchronize(stream_));
+}
+
+// ------------------------------------------------------------------ atlas (glcontext.nim:536-641, textures.nim:88-119)
+void Context::alloc_atlas(int size) {
+  int s = 1;
+  while (s < size) s <<= 1;  // the samplers mask coordinates: keep the atlas a power of two
+  for (auto& l : atlas_levels_) { if (l) (void)hipFree(l); l = nullptr; }
+  atlas_size_ = s;
+  n_levels_ = 0;
+  for (int ls = s; ls >= 1 && n_levels_ < kMaxMips; ls >>= 1) {
+    FDH_HIP(hipMalloc((void**)&atlas_levels_[n_levels_], (size_t)ls * ls * 4));
+    FDH_HIP(hipMemsetAsync(atlas_levels_[n_levels_], 0, (size_t)ls * ls * 4, stream_));
+    n_levels_++;
+    if (ls == 1) break;
+  }
+  heights_.assign((size_t)s, 0);
+  entries_.clear();
+}
+void Context::reset_atlas(int minimum_size) {
+  sync();
+  int s = initial_atlas_size_;
+  while (s < minimum_size) s *= 2;  // plannedAtlasSize
+  alloc_atlas(s);
+}
+int64_t Context::atlas_packed_area() const {
+  int64_t a = 0;
+  for (auto h : heights_) a += h;
+  return a;
+}
+void Context::find_empty_rect(int w, int h, int* ox, int* oy) {  // glcontext.nim:541-579
+  for (;;) {
+    const int S = atlas_size_, M = atlas_margin_;
+    const int iw = w + M * 2, ih = h + M * 2;
+    int lowest = S, at = 0;
+    for (int i = 0; i < S; i++) {
+      int v = heights_[i];
+      if (v < lowest) {
+        bool fit = true;
+        for (int j = 0; j <= iw; j++) {
+          if (i + j >= S) { fit = false; break; }
+          if ((int)heights_[i + j] > v) { fit = false; break; }
+        }
+        if (fit) { lowest = v; at = i; }
+      }
+    }
+    if (lowest + ih > S) {
+      if (S >= 16384) throw Error(FDH_ERR_ATLAS_FULL, "atlas full at 16384^2");
+      sync();
+      alloc_atlas(S * 2);  // grow(): resetImageAtlas(atlasSize * 2) drops every entry (glcontext.nim:536-539)
+      continue;
+    }
+    for (int j = at; j < at + iw; j++) heights_[j] = (uint16_t)(lowest + ih + M * 2);
+    *ox = at + M;
+    *oy = lowest + M;
+    return;
+  }
+}
+void Context::upload_atlas_rect(int level, int x, int y, int w, int h, const uint8_t* rgba) {
+  const int LS = atlas_size_ >> level;
+  if (x < 0 || y < 0 || x + w > LS || y + h > LS || w <= 0 || h <= 0) return;
+  FDH_HIP(hipMemcpy2D(atlas_levels_[level] + (size_t)y * LS + x, (size_t)LS * 4, rgba, (size_t)w * 4, (size_t)w * 4, h,
+                      hipMemcpyHostToDevice));  // synchronous: image uploads are rare and the source is pageable
+}
+void Context::put_levels(int x, int y, int w, int h, const uint8_t* rgba) {
+  // updateSubImage: level chain by repeated minifyBy2 while width > 1 and height > 1 (textures.nim:106-119);
+  // pixie's minifyBy2 is a 2x2 box average with round-half-up: (a+b+c+d+2) div 4.
+  std::vector<uint8_t> cur(rgba, rgba + (size_t)w * h * 4), nxt;
+  int cw = w, ch = h, lx = x, ly = y, level = 0;
+  while (cw > 1 && ch > 1 && level < n_levels_) {
+    upload_atlas_rect(level, lx, ly, cw, ch, cur.data());
+    const int nw = cw / 2, nh = ch / 2;
+    nxt.assign((size_t)std::max(nw, 1) * std::max(nh, 1) * 4, 0);
+    for (int yy = 0; yy < nh; yy++)
+      for (int xx = 0; xx < nw; xx++)
+        for (int k = 0; k < 4; k++) {
+          unsigned s = cur[((size_t)(2 * yy) * cw + 2 * xx) * 4 + k] + cur[((size_t)(2 * yy) * cw + 2 * xx + 1) * 4 + k] +
+                       cur[((size_t)(2 * yy + 1) * cw + 2 * xx) * 4 + k] + cur[((size_t)(2 * yy + 1) * cw + 2 * xx + 1) * 4 + k];
+          nxt[((size_t)yy * nw + xx) * 4 + k] = (uint8_t)((s + 2) / 4);
+        }
+    cur.swap(nxt);
+    cw = nw; ch = nh; lx /= 2; ly /= 2; level++;
+  }
+}
+void Context::put_image(int64_t key, int w, int h, const uint8_t* rgba, int out_rect[4]) {
+  if (w <= 0 || h <= 0 || !rgba) throw Error(FDH_ERR_INVALID, "put_image: empty image");
+  FDH_HIP(hipSetDevice(device_));
+  int x, y;
+  find_empty_rect(w, h, &x, &y);
+  entries_[key] = AtlasEntry{x, y, w, h};
+  FDH_HIP(hipStreamSynchronize(stream_));  // a frame in flight may still sample the atlas
+  put_levels(x, y, w, h, rgba);
+  if (out_rect) { out_rect[0] = x; out_rect[1] = y; out_rect[2] = w; out_rect[3] = h; }
+}
+void Context::update_image(int64_t key, int w, int h, const uint8_t* rgba) {  // glcontext.nim:591-604
+  auto it = entries_.find(key);
+  if (it == entries_.end()) throw Error(FDH_ERR_INVALID, "update_image: unknown key");
+  if (it->second.w != w || it->second.h != h) throw Error(FDH_ERR_INVALID, "update_image: size mismatch");
+  FDH_HIP(hipSetDevice(device_));
+  FDH_HIP(hipStreamSynchronize(stream_));
+  put_levels(it->second.x, it->second.y, w, h, rgba);
+}
+
+// ------------------------------------------------------------------ transforms (glcontext.nim:1991-2024)
+void Context::save_transform() { mats_.push_back(mat_); }
+void Context::restore_transform() {
+  if (mats_.empty()) throw Error(FDH_ERR_INVALID, "restoreTransform: empty transform stack");
+  mat_ = mats_.back();
+  mats_.pop_back();
+}
+void Context::translate(float x, float y) { Aff t; t.tx = x; t.ty = y; mat_ = aff_mul(mat_, t); }
+void Context::rotate(float a) {
+  Aff r;  // vmath rotateZ: column 0 = (cos, sin), column 1 = (-sin, cos)
+  r.a = std::cos(a); r.b = std::sin(a); r.c = -r.b; r.d = r.a;
+  mat_ = aff_mul(mat_, r);
+}
+void Context::scale(float sx, float sy) { Aff s; s.a = sx; s.d = sy; mat_ = aff_mul(mat_, s); }
+void Context::apply_transform(const float m[16]) {  // column-major Mat4; `mat * vec3(x, y, 0)` uses its 2D affine part
+  Aff n;
+  n.a = m[0]; n.b = m[1]; n.c = m[4]; n.d = m[5]; n.tx = m[12]; n.ty = m[13];
+  mat_ = aff_mul(mat_, n);
+}
+bool Context::transform_mirrors_y() const { return mat_.a * mat_.d - mat_.b * mat_.c < 0.0f; }
+
+// ------------------------------------------------------------------ frame
+void Context::ensure_surfaces() {
+  if (surf_w_ == W_ && surf_h_ == H_ && fb_) return;
+  FDH_HIP(hipStreamSynchronize(stream_));
+  if (fb_) FDH_HIP(hipFree(fb_));
+  if (backdrop_) FDH_HIP(hipFree(backdrop_));
+  if (blur_tmp_) FDH_HIP(hipFree(blur_tmp_));
+  const size_t n = (size_t)W_ * H_;
+  FDH_HIP(hipMalloc((void**)&fb_, n * 4));
+  FDH_HIP(hipMalloc((void**)&backdrop_, n * 4));
+  FDH_HIP(hipMalloc((void**)&blur_tmp_, n * 4));
+  FDH_HIP(hipMemsetAsync(fb_, 0, n * 4, stream_));
+  surf_w_ = W_;
+  surf_h_ = H_;
+}
+
+void Context::begin_frame(int w, int h, bool clear, const float rgba[4]) {  // glcontext.nim:2080-2092, 1951-1980
+  if (frame_begun_) throw Error(FDH_ERR_INVALID, "ctx.beginFrame has already been called.");
+  if (w <= 0 || h <= 0 || w > 16384 || h > 16384) throw Error(FDH_ERR_INVALID, "beginFrame: frame size must be in 1..16384");
+  FDH_HIP(hipSetDevice(device_));
+  W_ = w;
+  H_ = h;
+  ensure_surfaces();
+  clear_ = clear;
+  if (clear) {
+    auto q = [](float v) { return (uint32_t)std::floor(clampf(v, 0.0f, 1.0f) * 255.0f + 0.5f); };
+    clear_rgba8_ = q(rgba[0]) | (q(rgba[1]) << 8) | (q(rgba[2]) << 16) | (q(rgba[3]) << 24);
+  }
+  frame_begun_ = true;
+  mask_begun_ = false;
+  mask_depth_ = 0;
+  rect_masks_.clear();
+  open_ops_.clear();
+  recs_.clear();
+  bboxes_.clear();
+  exts_.clear();
+  phases_.clear();
+  blurs_.clear();
+  fragments_ = 0;
+  phases_.push_back(Phase{});
+}
+
+void Context::push_rec(const DrawRec& r, const BBox& b) {
+  recs_.push_back(r);
+  bboxes_.push_back(b);
+  phases_.back().count++;
+}
+
+static inline bool bbox_empty(const BBox& b) { return b.x1 <= b.x0 || b.y1 <= b.y0; }
+static inline void bbox_union(BBox& a, const BBox& b) {
+  if (bbox_empty(b)) return;
+  if (bbox_empty(a)) { a = b; return; }
+  a.x0 = std::min(a.x0, b.x0); a.y0 = std::min(a.y0, b.y0); a.x1 = std::max(a.x1, b.x1); a.y1 = std::max(a.y1, b.y1);
+}
+
+// Quad emission: ceil(ctx.mat * corner) per vertex, order BL,BR,TR,TL (glcontext.nim:1498-1509), then either the
+// axis-aligned fast form or the two-triangle general form.
+void Context::emit_quad(DrawRec& r, float x0, float y0, float x1, float y1, int64_t* fragments) {
+  auto xf = [&](float x, float y, float* ox, float* oy) {
+    *ox = std::ceil(mat_.a * x + mat_.c * y + mat_.tx);
+    *oy = std::ceil(mat_.b * x + mat_.d * y + mat_.ty);
+  };
+  float px[4], py[4];
+  xf(x0, y1, &px[0], &py[0]);
+  xf(x1, y1, &px[1], &py[1]);
+  xf(x1, y0, &px[2], &py[2]);
+  xf(x0, y0, &px[3], &py[3]);
+  float minx = px[0], maxx = px[0], miny = py[0], maxy = py[0];
+  for (int i = 1; i < 4; i++) {
+    minx = std::min(minx, px[i]); maxx = std::max(maxx, px[i]);
+    miny = std::min(miny, py[i]); maxy = std::max(maxy, py[i]);
+  }
+  const float lim = 1.0e6f;  // keep the integer edge functions far from overflow
+  BBox b{0, 0, 0, 0};
+  if (!(minx > -lim && maxx < lim && miny > -lim && maxy < lim)) { r.bx0 = r.by0 = r.bx1 = r.by1 = 0; push_rec(r, b); return; }
+  b.x0 = (int16_t)clampf(minx, 0.0f, (float)W_); b.x1 = (int16_t)clampf(maxx, 0.0f, (float)W_);
+  b.y0 = (int16_t)clampf(miny, 0.0f, (float)H_); b.y1 = (int16_t)clampf(maxy, 0.0f, (float)H_);
+  r.bx0 = b.x0; r.by0 = b.y0; r.bx1 = b.x1; r.by1 = b.y1;
+  const bool aligned = px[3] == px[0] && px[2] == px[1] && py[3] == py[2] && py[0] == py[1] && px[1] > px[0] && py[0] > py[3];
+  if (aligned) {
+    r.ox = px[3];
+    r.oy = py[3];
+    r.inv_w = 1.0f / (px[1] - px[0]);
+    r.inv_h = 1.0f / (py[0] - py[3]);
+  } else {
+    QuadExt q;
+    std::memset(&q, 0, sizeof q);
+    static const int TRI[2][3] = {{3, 0, 1}, {2, 3, 1}};  // glcontext.nim:418-429
+    const uint32_t mode = r.op_mode & 255u;
+    const bool atlas_mode = mode == 0u || (mode >= 13u && mode <= 16u);
+    const float uax = atlas_mode ? r.r[0] : 0.0f, uay = atlas_mode ? r.r[1] : 0.0f, utx = atlas_mode ? r.r[2] : 1.0f, uty = atlas_mode ? r.r[3] : 1.0f;
+    const float vu[4] = {uax, utx, utx, uax}, vv[4] = {uty, uty, uay, uay};
+    float lod = -1.0e30f;
+    for (int t = 0; t < 2; t++) {
+      long long X[3], Y[3];
+      for (int k = 0; k < 3; k++) { X[k] = 2 * (long long)px[TRI[t][k]]; Y[k] = 2 * (long long)py[TRI[t][k]]; }
+      // edge k is opposite vertex k: from vertex (k+1)%3 to vertex (k+2)%3
+      long long area2 = (X[1] - X[0]) * (Y[2] - Y[0]) - (Y[1] - Y[0]) * (X[2] - X[0]);
+      const long long sgn = area2 >= 0 ? 1 : -1;
+      for (int k = 0; k < 3; k++) {
+        const int i0 = (k + 1) % 3, i1 = (k + 2) % 3;
+        long long A = -(Y[i1] - Y[i0]) * sgn, B = (X[i1] - X[i0]) * sgn;
+        long long C = -(B * Y[i0]) - (A * X[i0]);
+        q.e[t][k].a = (int32_t)A; q.e[t][k].b = (int32_t)B; q.e[t][k].c = C;
+        // top-left rule in image orientation (y down): owns iff top edge (horizontal, interior below) or left edge
+        bool own;
+        if (Y[i0] == Y[i1]) own = Y[k] > Y[i0];
+        else {
+          double tt = (double)(Y[k] - Y[i0]) / (double)(Y[i1] - Y[i0]);
+          double ex = (double)X[i0] + tt * (double)(X[i1] - X[i0]);
+          own = (double)X[k] > ex;
+        }
+        if (own) q.own |= 1u << (t * 3 + k);
+      }
+      if (area2 != 0) {
+        // E0+E1+E2 is the same at every point: |area2| (each E_k equals it at vertex k, where the other two vanish)
+        q.inv_sum[t] = (float)(1.0 / (double)(area2 * sgn));
+        const double e1x = (double)(px[TRI[t][1]] - px[TRI[t][0]]), e1y = (double)(py[TRI[t][1]] - py[TRI[t][0]]);
+        const double e2x = (double)(px[TRI[t][2]] - px[TRI[t][0]]), e2y = (double)(py[TRI[t][2]] - py[TRI[t][0]]);
+        const double det = e1x * e2y - e1y * e2x;
+        const double du1 = vu[TRI[t][1]] - vu[TRI[t][0]], du2 = vu[TRI[t][2]] - vu[TRI[t][0]];
+        const double dv1 = vv[TRI[t][1]] - vv[TRI[t][0]], dv2 = vv[TRI[t][2]] - vv[TRI[t][0]];
+        const double dudx = (du1 * e2y - du2 * e1y) / det, dudy = (du2 * e1x - du1 * e2x) / det;
+        const double dvdx = (dv1 * e2y - dv2 * e1y) / det, dvdy = (dv2 * e1x - dv1 * e2x) / det;
+        q.fw_u[t] = (float)(std::fabs(dudx) + std::fabs(dudy));
+        q.fw_v[t] = (float)(std::fabs(dvdx) + std::fabs(dvdy));
+        const double S = (double)atlas_size_;
+        const double rho = std::max(std::sqrt(dudx * dudx + dvdx * dvdx), std::sqrt(dudy * dudy + dvdy * dvdy)) * S;
+        if (rho > 0.0) lod = std::max(lod, (float)std::log2(rho));
+      } else {
+        q.fw_u[t] = q.fw_v[t] = 1.0f;
+      }
+    }
+    q.lod = lod < -1.0e29f ? 0.0f : lod;
+    r.op_mode |= F_GENERAL;
+    r.ext = (uint32_t)exts_.size();
+    exts_.push_back(q);
+  }
+  if (fragments) *fragments += (int64_t)(b.x1 - b.x0) * (b.y1 - b.y0);
+  for (auto idx : open_ops_) bbox_union(bboxes_[idx], b);  // clip pushes only need to reach tiles their content touches
+  push_rec(r, b);
+}
+
+// radii packing: glcontext.nim:745-817
+static float clamp_radius(float r, float m) { return r <= 0.0f ? 0.0f : nim_round(std::max(1.0f, std::min(r, m))); }
+static bool rounded_radii_vec(const float rx[4], const float ry[4], float hx, float hy, float out[4]) {
+  enum { TL = 0, TR = 1, BL = 2, BR = 3 };
+  bool circular = true;
+  for (int i = 0; i < 4; i++) circular = circular && rx[i] == ry[i];
+  static const int order[4] = {TR, BR, TL, BL};
+  if (circular) {
+    const float m = std::min(hx, hy);
+    for (int k = 0; k < 4; k++) out[k] = clamp_radius(rx[order[k]], m);
+    return false;
+  }
+  const float cm = std::min(hx, hy);
+  for (int k = 0; k < 4; k++) {
+    const int i = order[k];
+    const float cx = clamp_radius(rx[i], hx), cy = clamp_radius(ry[i], hy);
+    if (rx[i] == ry[i]) out[k] = -(clamp_radius(rx[i], cm) + 1.0f);
+    else if (cx == cy) out[k] = -(cx + 1.0f);
+    else {
+      const float qx = nim_round(clampf(cx / std::max(hx, 0.000001f), 0.0f, 1.0f) * 4095.0f);
+      const float qy = nim_round(clampf(cy / std::max(hy, 0.000001f), 0.0f, 1.0f) * 4095.0f);
+      out[k] = qx + qy * 4096.0f;
+    }
+  }
+  return true;
+}
+
+static void fill_sdf_rec(DrawRec& r, const float rect[4], const FdhColor colors[4], const float rx[4], const float ry[4], int mode,
+                         float factor, float spread, const float shape[2], int fill_mode, FdhColor mid, FdhColor stop, float mid_pos,
+                         float aa) {
+  std::memset(&r, 0, sizeof r);
+  const float w = rect[2], h = rect[3];
+  const float qhx = w * 0.5f, qhy = h * 0.5f;
+  const bool inset = mode == FDH_SDF_INSET_SHADOW;
+  const bool has_shape = shape[0] > 0.0f && shape[1] > 0.0f;
+  const float shx = inset ? qhx : (has_shape ? shape[0] : w) * 0.5f;
+  const float shy = inset ? qhy : (has_shape ? shape[1] : h) * 0.5f;
+  r.p0 = qhx; r.p1 = qhy;
+  if (inset) { r.p2 = shape[0]; r.p3 = shape[1]; } else { r.p2 = shx; r.p3 = shy; }
+  const bool ellip = rounded_radii_vec(rx, ry, shx, shy, r.r);
+  r.f0 = factor;
+  r.f1 = fill_mode == 0 ? spread : clampf(mid_pos, 0.01f, 0.99f);
+  for (int i = 0; i < 4; i++) r.col[i] = pack_color(colors[i]);
+  r.mid = pack_color(mid);
+  r.stop = pack_color(stop);
+  r.aa = aa;
+  r.op_mode = (uint32_t)mode | (ellip ? F_ELLIP : 0u) | ((uint32_t)fill_mode << 9);
+  if (r.col[0] == r.col[1] && r.col[1] == r.col[2] && r.col[2] == r.col[3]) r.op_mode |= F_SOLID;
+}
+
+// drawRoundedRectSdfOpenGl: glcontext.nim:1449-1559
+void Context::draw_rounded_rect_sdf(const float rect[4], const FdhColor colors[4], const float rx[4], const float ry[4], int mode,
+                                    float factor, float spread, const float shape[2], int fill_mode, FdhColor mid, FdhColor stop,
+                                    float mid_pos) {
+  if (!frame_begun_) throw Error(FDH_ERR_INVALID, "ctx.beginFrame has not been called.");
+  if (rect[2] <= 0.0f || rect[3] <= 0.0f) return;
+  if (mode >= FDH_SDF_BEZIER_STROKE_AA) throw Error(FDH_ERR_UNSUPPORTED, "Backend drawQuadraticBezierSdf unavailable");
+  DrawRec r;
+  fill_sdf_rec(r, rect, colors, rx, ry, mode, factor, spread, shape, fill_mode, mid, stop, mid_pos, aa_);
+  if (mode == FDH_SDF_BACKDROP_BLUR) r.op_mode |= F_SELF_BACKDROP;  // a bare mode-17 call has no snapshot of its own
+  emit_quad(r, rect[0], rect[1], rect[0] + rect[2], rect[1] + rect[3], &fragments_);
+}
+
+// fills: figbackend.nim:129-183
+static FdhColor lerp_color(FdhColor a, FdhColor b, float t) {
+  const float ct = clampf(t, 0.0f, 1.0f), it = 1.0f - ct;
+  FdhColor r;
+  r.r = (uint8_t)nim_round((float)a.r * it + (float)b.r * ct);
+  r.g = (uint8_t)nim_round((float)a.g * it + (float)b.g * ct);
+  r.b = (uint8_t)nim_round((float)a.b * it + (float)b.b * ct);
+  r.a = (uint8_t)nim_round((float)a.a * it + (float)b.a * ct);
+  return r;
+}
+static float mid_pos01(const FdhFill& f) { return clampf((float)f.mid_pos / 255.0f, 0.01f, 0.99f); }
+FdhColor sample_fill(const FdhFill& f, float t) {
+  if (f.kind == FDH_FILL_COLOR) return f.start;
+  if (f.kind == FDH_FILL_LINEAR2) return lerp_color(f.start, f.stop, t);
+  const float ct = clampf(t, 0.0f, 1.0f), mid = mid_pos01(f);
+  if (ct <= mid) return lerp_color(f.start, f.mid, ct / mid);
+  return lerp_color(f.mid, f.stop, (ct - mid) / (1.0f - mid));
+}
+void gradient_colors(const FdhFill& f, FdhColor out[4]) {  // vertex order BL,BR,TR,TL
+  const int axis = f.kind == FDH_FILL_COLOR ? FDH_AXIS_X : f.axis;
+  static const float T[4][4] = {{0, 1, 1, 0}, {1, 1, 0, 0}, {0.5f, 1, 0.5f, 0}, {0, 0.5f, 1, 0.5f}};
+  for (int i = 0; i < 4; i++) out[i] = sample_fill(f, T[axis & 3][i]);
+}
+
+// drawRoundedRectSdf(fill: BackendFill): glcontext.nim:1581-1617
+void Context::draw_rounded_rect_fill(const float rect[4], const FdhFill& fill, const float rx[4], const float ry[4], int mode,
+                                     float factor, float spread, const float shape[2]) {
+  const FdhColor zero{0, 0, 0, 0};
+  if (fill.kind == FDH_FILL_LINEAR3 && (mode == FDH_SDF_CLIP_AA || mode == FDH_SDF_ANNULAR || mode == FDH_SDF_ANNULAR_AA)) {
+    const FdhColor cols[4] = {fill.start, fill.start, fill.start, fill.start};
+    draw_rounded_rect_sdf(rect, cols, rx, ry, mode, factor, spread, shape, 1 + (fill.axis & 3), fill.mid, fill.stop, mid_pos01(fill));
+  } else {
+    FdhColor cols[4];
+    gradient_colors(fill, cols);
+    draw_rounded_rect_sdf(rect, cols, rx, ry, mode, factor, spread, shape, 0, zero, zero, 0.5f);
+  }
+}
+
+// drawImage / drawUvRect: glcontext.nim:1236-1302, 1350-1367
+void Context::draw_image(int64_t key, const float pos[2], const FdhColor colors[4], const float size[2], bool flip_y) {
+  if (!frame_begun_) throw Error(FDH_ERR_INVALID, "ctx.beginFrame has not been called.");
+  auto it = entries_.find(key);
+  if (it == entries_.end()) return;  // "missing image in context": warn + no-op (glcontext.nim:1310-1315)
+  const AtlasEntry& e = it->second;
+  const float S = (float)atlas_size_;
+  const float ex = (float)e.x / S, ey = (float)e.y / S, ew = (float)e.w / S, eh = (float)e.h / S;  // entries = rect / atlasSize
+  const bool sized = size[0] > 0.0f && size[1] > 0.0f;
+  const float dw = sized ? size[0] : ew * S, dh = sized ? size[1] : eh * S;
+  DrawRec r;
+  std::memset(&r, 0, sizeof r);
+  r.op_mode = FDH_SDF_ATLAS;
+  if (flip_y) { r.r[0] = ex; r.r[1] = ey + eh; r.r[2] = ex + ew; r.r[3] = ey; }
+  else { r.r[0] = ex; r.r[1] = ey; r.r[2] = ex + ew; r.r[3] = ey + eh; }
+  for (int i = 0; i < 4; i++) r.col[i] = pack_color(colors[i]);
+  if (r.col[0] == r.col[1] && r.col[1] == r.col[2] && r.col[2] == r.col[3]) r.op_mode |= F_SOLID;
+  r.aa = aa_;
+  if (subpixel_enabled_) {
+    r.op_mode |= F_SUBPIXEL;
+    r.aux = std::max(0.0f, std::min(subpixel_shift_, 0.999f));  // activeSubpixelShift glcontext.nim:819-822
+  }
+  // LOD for the axis-aligned form: rho = max(|du/dx|, |dv/dy|) in level-0 texels per pixel
+  const float x0 = pos[0], y0 = pos[1], x1 = pos[0] + dw, y1 = pos[1] + dh;
+  {
+    const float qx0 = std::ceil(mat_.a * x0 + mat_.tx), qx1 = std::ceil(mat_.a * x1 + mat_.tx);
+    const float qy0 = std::ceil(mat_.d * y0 + mat_.ty), qy1 = std::ceil(mat_.d * y1 + mat_.ty);
+    const float rw = std::fabs(qx1 - qx0), rh = std::fabs(qy1 - qy0);
+    if (rw > 0.0f && rh > 0.0f) {
+      const float rho = std::max(std::fabs(r.r[2] - r.r[0]) * S / rw, std::fabs(r.r[3] - r.r[1]) * S / rh);
+      r.aux2 = rho > 0.0f ? std::log2(rho) : 0.0f;
+    }
+  }
+  emit_quad(r, x0, y0, x1, y1, &fragments_);
+}
+
+// drawMsdfImage / drawMtsdfImage: glcontext.nim:1097-1155, drawUvRectAtlasSdf :1022-1093
+void Context::draw_msdf(int64_t key, const float pos[2], FdhColor color, const float size[2], float px_range, float sd_threshold,
+                        float stroke_weight, bool mtsdf, bool flip_y) {
+  if (!frame_begun_) throw Error(FDH_ERR_INVALID, "ctx.beginFrame has not been called.");
+  auto it = entries_.find(key);
+  if (it == entries_.end()) return;
+  const AtlasEntry& e = it->second;
+  const float S = (float)atlas_size_;
+  const float ex = (float)e.x / S, ey = (float)e.y / S, ew = (float)e.w / S, eh = (float)e.h / S;
+  const float sw = std::max(0.0f, stroke_weight);
+  DrawRec r;
+  std::memset(&r, 0, sizeof r);
+  r.op_mode = (uint32_t)(mtsdf ? (sw > 0.0f ? FDH_SDF_MTSDF_ANNULAR : FDH_SDF_MTSDF) : (sw > 0.0f ? FDH_SDF_MSDF_ANNULAR : FDH_SDF_MSDF)) | F_SOLID;
+  if (flip_y) { r.r[0] = ex; r.r[1] = ey + eh; r.r[2] = ex + ew; r.r[3] = ey; }
+  else { r.r[0] = ex; r.r[1] = ey; r.r[2] = ex + ew; r.r[3] = ey + eh; }
+  r.p0 = S; r.p1 = sw;
+  r.f0 = px_range; r.f1 = sd_threshold;
+  for (int i = 0; i < 4; i++) r.col[i] = pack_color(color);
+  r.aa = aa_;
+  emit_quad(r, pos[0], pos[1], pos[0] + size[0], pos[1] + size[1], &fragments_);
+}
+
+// ------------------------------------------------------------------ masks (glcontext.nim:1873-1949)
+void Context::begin_mask(const float rect[4], const float rx[4], const float ry[4]) {
+  if (!frame_begun_) throw Error(FDH_ERR_INVALID, "ctx.beginFrame has not been called.");
+  if (mask_begun_) throw Error(FDH_ERR_INVALID, "ctx.beginMask has already been called.");
+  if (mask_depth_ >= kMaskDepth) throw Error(FDH_ERR_UNSUPPORTED, "clip masks nested deeper than 8");
+  mask_begun_ = true;
+  mask_depth_++;
+  const FdhColor red{255, 0, 0, 255}, zero{0, 0, 0, 0};
+  const FdhColor cols[4] = {red, red, red, red};
+  const float shape[2] = {0, 0};
+  DrawRec r;
+  fill_sdf_rec(r, rect, cols, rx, ry, FDH_SDF_CLIP_AA, 4.0f, 0.0f, shape, 0, zero, zero, 0.5f, aa_);
+  r.op_mode |= OP_MASK_PUSH << 12;
+  const size_t before = recs_.size();
+  if (rect[2] > 0.0f && rect[3] > 0.0f) {
+    emit_quad(r, rect[0], rect[1], rect[0] + rect[2], rect[1] + rect[3], nullptr);
+  } else {  // drawRoundedRectSdf returns early: the mask plane stays cleared to 0
+    r.bx0 = r.by0 = r.bx1 = r.by1 = 0;
+    push_rec(r, BBox{0, 0, 0, 0});
+  }
+  bboxes_[before] = BBox{0, 0, 0, 0};  // grows to the union of the content drawn under it
+  open_ops_.push_back((uint32_t)before);
+}
+void Context::end_mask() {
+  if (!mask_begun_) throw Error(FDH_ERR_INVALID, "ctx.maskBegun has not been called.");
+  mask_begun_ = false;
+}
+void Context::pop_mask() {
+  if (mask_depth_ <= 0 || open_ops_.empty()) throw Error(FDH_ERR_INVALID, "popMask without beginMask");
+  const uint32_t push_idx = open_ops_.back();
+  open_ops_.pop_back();
+  mask_depth_--;
+  DrawRec r;
+  std::memset(&r, 0, sizeof r);
+  r.op_mode = OP_MASK_POP << 12;
+  push_rec(r, bboxes_[push_idx]);
+}
+// makeRectMask glcontext.nim:831-850; beginRectMask :1932-1943
+void Context::begin_rect_mask(const float rect[4], const float rx[4], const float ry[4]) {
+  if (!frame_begun_) throw Error(FDH_ERR_INVALID, "ctx.beginFrame has not been called.");
+  if (mask_begun_) throw Error(FDH_ERR_INVALID, "ctx.beginRectMask cannot start inside a mask.");
+  if (rect_masks_.empty() && rect[2] > 0.0f && rect[3] > 0.0f) {
+    const float hx = rect[2] * 0.5f, hy = rect[3] * 0.5f;
+    DrawRec r;
+    std::memset(&r, 0, sizeof r);
+    const bool ellip = rounded_radii_vec(rx, ry, hx, hy, r.r);
+    const float det = mat_.a * mat_.d - mat_.b * mat_.c, id = 1.0f / det;
+    const float ia = mat_.d * id, ib = -mat_.b * id, ic = -mat_.c * id, idd = mat_.a * id;
+    const float itx = -(ia * mat_.tx + ic * mat_.ty), ity = -(ib * mat_.tx + idd * mat_.ty);
+    r.ox = ia; r.oy = ic; r.inv_w = itx;   // matX
+    r.inv_h = ib; r.f0 = idd; r.f1 = ity;  // matY
+    r.p0 = rect[0] + hx; r.p1 = rect[1] + hy; r.p2 = hx; r.p3 = hy;
+    r.aa = aa_;
+    r.op_mode = (OP_RMASK_BEGIN << 12) | (ellip ? F_ELLIP : 0u);
+    open_ops_.push_back((uint32_t)recs_.size());
+    push_rec(r, BBox{0, 0, 0, 0});
+    rect_masks_.push_back(RectMaskEntry{1});
+  } else {
+    begin_mask(rect, rx, ry);
+    end_mask();
+    rect_masks_.push_back(RectMaskEntry{2});
+  }
+}
+void Context::pop_rect_mask() {
+  if (rect_masks_.empty()) throw Error(FDH_ERR_INVALID, "No rect mask has been pushed.");
+  const RectMaskEntry e = rect_masks_.back();
+  rect_masks_.pop_back();
+  if (e.kind == 2) { pop_mask(); return; }
+  const uint32_t begin_idx = open_ops_.back();
+  open_ops_.pop_back();
+  DrawRec r;
+  std::memset(&r, 0, sizeof r);
+  r.op_mode = OP_RMASK_END << 12;
+  push_rec(r, bboxes_[begin_idx]);
+}
+
+// ------------------------------------------------------------------ backdrop blur (glcontext.nim:1743-1841, blur.frag:11-32)
+static BlurTaps make_taps(float blur_radius) {
+  BlurTaps t;
+  std::memset(&t, 0, sizeof t);
+  const float radius = clampf(blur_radius, 0.0f, 64.0f);
+  const float sigma = std::max(0.5f * radius, 0.5f);
+  const float step = std::max(radius / 8.0f, 1.0f);
+  float w[17], wsum = 0.0f;
+  for (int i = -8; i <= 8; i++) {
+    const float x = (float)i * step;
+    w[i + 8] = std::exp(-0.5f * (x * x) / (sigma * sigma));
+    wsum += w[i + 8];
+  }
+  const float inv = 1.0f / std::max(wsum, 1e-5f);
+  auto add = [&](int off, float c) {
+    if (c == 0.0f) return;
+    for (int k = 0; k < t.n; k++) if (t.off[k] == off) { t.coef[k] += c; return; }
+    t.off[t.n] = off; t.coef[t.n] = c; t.n++;
+  };
+  for (int i = -8; i <= 8; i++) {
+    const float x = (float)i * step;
+    const float fl = std::floor(x), a = x - fl;
+    add((int)fl, w[i + 8] * (1.0f - a) * inv);
+    add((int)fl + 1, w[i + 8] * a * inv);
+  }
+  for (int k = 0; k < t.n; k++) t.reach = std::max(t.reach, std::abs(t.off[k]));
+  return t;
+}
+
+void Context::draw_backdrop_blur(const float rect[4], const float rx[4], const float ry[4], float blur_radius) {
+  if (!frame_begun_) throw Error(FDH_ERR_INVALID, "ctx.beginFrame has not been called.");
+  if (blur_radius <= 0.0f || rect[2] <= 0.0f || rect[3] <= 0.0f) return;
+  const FdhColor white{255, 255, 255, 255}, zero{0, 0, 0, 0};
+  const FdhColor cols[4] = {white, white, white, white};
+  const float shape[2] = {0, 0};
+  DrawRec r;
+  fill_sdf_rec(r, rect, cols, rx, ry, FDH_SDF_BACKDROP_BLUR, blur_radius, 0.0f, shape, 0, zero, zero, 0.5f, aa_);
+  if (blur_radius <= 0.5f) {  // runBackdropSeparableBlur returns early: the snapshot is the live frame
+    r.op_mode |= F_SELF_BACKDROP;
+    emit_quad(r, rect[0], rect[1], rect[0] + rect[2], rect[1] + rect[3], &fragments_);
+    return;
+  }
+  // A blurred snapshot is a barrier in painter's order: close the phase, blur, continue in a new phase.
+  std::vector<DrawRec> reopen;
+  for (auto idx : open_ops_) reopen.push_back(recs_[idx]);
+  Phase next;
+  next.first = (int)recs_.size();
+  next.blur = (int)blurs_.size();
+  phases_.push_back(next);
+  for (size_t i = 0; i < reopen.size(); i++) {  // re-establish the open clip stack for the new phase
+    open_ops_[i] = (uint32_t)recs_.size();
+    push_rec(reopen[i], BBox{0, 0, 0, 0});
+  }
+  emit_quad(r, rect[0], rect[1], rect[0] + rect[2], rect[1] + rect[3], &fragments_);
+  const BBox fb = bboxes_.back();
+  BlurJob job;
+  job.radius = blur_radius;
+  job.x0 = fb.x0; job.y0 = fb.y0; job.x1 = fb.x1; job.y1 = fb.y1;
+  job.taps = make_taps(blur_radius);
+  blurs_.push_back(job);
+}
+
+// ------------------------------------------------------------------ submission
+void Context::end_frame() {  // glcontext.nim:1982-1989
+  if (!frame_begun_) throw Error(FDH_ERR_INVALID, "ctx.beginFrame was not called first.");
+  if (mask_depth_ != 0) throw Error(FDH_ERR_INVALID, "Not all masks have been popped.");
+  if (!rect_masks_.empty()) throw Error(FDH_ERR_INVALID, "Not all rect masks have been popped.");
+  frame_begun_ = false;
+  have_frame_ = true;
+  submit(true);
+}
+
+void Context::submit(bool upload) {
+  FDH_HIP(hipSetDevice(device_));
+  const size_t n = recs_.size();
+  bins_x_ = (W_ + kBin - 1) / kBin;
+  bins_y_ = (H_ + kBin - 1) / kBin;
+  const int nb = bins_x_ * bins_y_;
+  int max_count = 1;
+  for (auto& p : phases_) {
+    max_count = std::max(max_count, p.count);
+    BBox u{0, 0, 0, 0};
+    for (int i = p.first; i < p.first + p.count; i++) bbox_union(u, bboxes_[i]);
+    p.bin_x0 = u.x0 / kBin; p.bin_y0 = u.y0 / kBin;
+    p.bin_x1 = bbox_empty(u) ? p.bin_x0 : (u.x1 + kBin - 1) / kBin;
+    p.bin_y1 = bbox_empty(u) ? p.bin_y0 : (u.y1 + kBin - 1) / kBin;
+  }
+  list_stride_ = max_count;
+  if (upload) {
+    d_recs_.reserve(std::max<size_t>(n, 1));
+    d_bboxes_.reserve(std::max<size_t>(n, 1));
+    d_exts_.reserve(std::max<size_t>(exts_.size(), 1));
+    d_phase_first_.reserve(phases_.size() + 1);
+    d_lists_.reserve((size_t)phases_.size() * nb * list_stride_);
+    d_counts_.reserve((size_t)phases_.size() * nb);
+    std::vector<int> pf(phases_.size() + 1);
+    for (size_t i = 0; i < phases_.size(); i++) pf[i] = phases_[i].first;
+    pf[phases_.size()] = (int)n;
+    const size_t b_recs = n * sizeof(DrawRec), b_bb = n * sizeof(BBox), b_ext = exts_.size() * sizeof(QuadExt), b_pf = pf.size() * sizeof(int);
+    FDH_HIP(hipStreamSynchronize(stream_));  // the staging buffer may still feed the previous frame's copies
+    staging_.reserve(b_recs + b_bb + b_ext + b_pf + 64);
+    uint8_t* s = staging_.ptr;
+    if (b_recs) { std::memcpy(s, recs_.data(), b_recs); FDH_HIP(hipMemcpyAsync(d_recs_.ptr, s, b_recs, hipMemcpyHostToDevice, stream_)); s += b_recs; }
+    if (b_bb) { std::memcpy(s, bboxes_.data(), b_bb); FDH_HIP(hipMemcpyAsync(d_bboxes_.ptr, s, b_bb, hipMemcpyHostToDevice, stream_)); s += b_bb; }
+    if (b_ext) { std::memcpy(s, exts_.data(), b_ext); FDH_HIP(hipMemcpyAsync(d_exts_.ptr, s, b_ext, hipMemcpyHostToDevice, stream_)); s += b_ext; }
+    std::memcpy(s, pf.data(), b_pf);
+    FDH_HIP(hipMemcpyAsync(d_phase_first_.ptr, s, b_pf, hipMemcpyHostToDevice, stream_));
+  }
+  // algorithmic bytes of this frame: final store + per blur (pre-blur store is the store above for
+  // a full-frame node; H read + H write + V read + V write + composite read) + records once
+  int64_t bytes = 4LL * W_ * H_ + (int64_t)n * (int64_t)sizeof(DrawRec);
+  for (auto& j : blurs_) {
+    const int ylo = std::max(0, j.y0 - j.taps.reach), yhi = std::min(H_, j.y1 + j.taps.reach);
+    const int64_t a_h = (int64_t)(j.x1 - j.x0) * (yhi - ylo), a_v = (int64_t)(j.x1 - j.x0) * (j.y1 - j.y0);
+    bytes += 4 * a_h + 4 * a_h + 4 * a_h + 4 * a_v + 4 * a_v;
+  }
+  stats_.n_draws = (int32_t)n;
+  stats_.n_phases = (int32_t)phases_.size();
+  stats_.n_blurs = (int32_t)blurs_.size();
+  stats_.n_bins = nb;
+  stats_.bytes_algorithmic = bytes;
+  stats_.fragments = fragments_;
+  launch_frame(false);
+}
+
+void Context::launch_frame(bool profile) {
+  const int nb = bins_x_ * bins_y_;
+  const int np = (int)phases_.size();
+  // rows each phase has to produce: the stripe, widened by the vertical reach of every later blur
+  int s0 = 0, s1 = H_;
+  if (stripe_y1_ > stripe_y0_) { s0 = std::max(0, stripe_y0_); s1 = std::min(H_, stripe_y1_); }
+  std::vector<int> lo(np), hi(np);
+  {
+    int l = s0, h = s1;
+    for (int p = np - 1; p >= 0; p--) {
+      lo[p] = l; hi[p] = h;
+      if (phases_[p].blur >= 0) {
+        const int reach = blurs_[phases_[p].blur].taps.reach;
+        l = std::max(0, l - reach);
+        h = std::min(H_, h + reach);
+      }
+    }
+  }
+  if (profile) FDH_HIP(hipEventRecord(ev_[2], stream_));
+  BinParams B;
+  B.bbox = d_bboxes_.ptr; B.lists = d_lists_.ptr; B.counts = d_counts_.ptr; B.phase_first = d_phase_first_.ptr;
+  B.n_phases = np; B.bins_x = bins_x_; B.bins_y = bins_y_; B.stride = list_stride_;
+  launch_bin(stream_, B);
+  if (profile) FDH_HIP(hipEventRecord(ev_[3], stream_));
+  for (int p = 0; p < np; p++) {
+    const Phase& ph = phases_[p];
+    if (ph.blur >= 0) {
+      const BlurJob& j = blurs_[ph.blur];
+      // V output: footprint rows this phase must produce; H output: those rows widened by the tap reach
+      const int vy0 = std::max(j.y0, lo[p]), vy1 = std::min(j.y1, hi[p]);
+      if (vy1 > vy0 && j.x1 > j.x0) {
+        BlurParams bp;
+        bp.W = W_; bp.H = H_; bp.pitch = W_;
+        bp.taps = j.taps;
+        bp.src = fb_; bp.dst = blur_tmp_;
+        bp.x0 = j.x0; bp.x1 = j.x1; bp.y0 = std::max(0, vy0 - j.taps.reach); bp.y1 = std::min(H_, vy1 + j.taps.reach);
+        if (profile) FDH_HIP(hipEventRecord(ev_[6], stream_));
+        launch_blur_h(stream_, bp);
+        bp.src = blur_tmp_; bp.dst = backdrop_;
+        bp.y0 = vy0; bp.y1 = vy1;
+        launch_blur_v(stream_, bp);
+        if (profile) FDH_HIP(hipEventRecord(ev_[7], stream_));
+      }
+    }
+    CompositeParams C;
+    C.lists = d_lists_.ptr + (size_t)p * nb * list_stride_;
+    C.counts = d_counts_.ptr + (size_t)p * nb;
+    C.backdrop = backdrop_;
+    C.fb = fb_;
+    for (int l = 0; l < kMaxMips; l++) C.atlas.level[l] = atlas_levels_[l];
+    C.atlas.size = atlas_size_; C.atlas.n_levels = n_levels_;
+    C.W = W_; C.H = H_; C.pitch = W_;
+    C.bins_x = bins_x_; C.stride = list_stride_;
+    const bool full = (p == 0 && clear_);
+    C.bin_x0 = full ? 0 : ph.bin_x0; C.bin_y0 = full ? 0 : ph.bin_y0;
+    C.bin_nx = full ? bins_x_ : ph.bin_x1 - ph.bin_x0; C.bin_ny = full ? bins_y_ : ph.bin_y1 - ph.bin_y0;
+    C.row_lo = lo[p]; C.row_hi = hi[p];
+    C.load_fb = full ? 0 : 1;
+    C.clear_rgba8 = clear_rgba8_;
+    C.n_wg = 0;
+    if (profile && p == 0) FDH_HIP(hipEventRecord(ev_[4], stream_));
+    launch_composite(stream_, d_recs_.ptr, d_bboxes_.ptr, d_exts_.ptr, C);
+    if (profile && p == 0) FDH_HIP(hipEventRecord(ev_[5], stream_));
+  }
+  FDH_HIP(hipGetLastError());
+}
+
+void Context::replay(int times) {
+  if (!have_frame_) throw Error(FDH_ERR_INVALID, "replay: no frame has been submitted");
+  FDH_HIP(hipSetDevice(device_));
+  if (times <= 0) return;
+  FDH_HIP(hipEventRecord(ev_[0], stream_));
+  for (int i = 0; i < times; i++) launch_frame(false);
+  FDH_HIP(hipEventRecord(ev_[1], stream_));
+  FDH_HIP(hipEventSynchronize(ev_[1]));
+  float ms = 0.0f;
+  FDH_HIP(hipEventElapsedTime(&ms, ev_[0], ev_[1]));
+  stats_.ms_total = ms / (float)times;
+  // one more, instrumented frame for the per-kernel split (events between launches perturb the total slightly,
+  // so it is never part of ms_total)
+  launch_frame(true);
+  FDH_HIP(hipStreamSynchronize(stream_));
+  float t = 0.0f;
+  FDH_HIP(hipEventElapsedTime(&t, ev_[2], ev_[3])); stats_.ms_bin = t;
+  FDH_HIP(hipEventElapsedTime(&t, ev_[4], ev_[5])); stats_.ms_composite = t;
+  stats_.ms_blur = 0.0f;
+  if (!blurs_.empty()) {
+    // ev_[6]/ev_[7] bracket the LAST blur of the frame; good enough for the split, bench.py times kernels itself
+    if (hipEventElapsedTime(&t, ev_[6], ev_[7]) == hipSuccess) stats_.ms_blur = t;
+  }
+}
+
+// ------------------------------------------------------------------ readback (glcontext.nim:2094-2135)
+void Context::read_pixels(int x, int y, int w, int h, uint8_t* out) {
+  if (!fb_) throw Error(FDH_ERR_INVALID, "readPixels before the first frame");
+  FDH_HIP(hipSetDevice(device_));
+  if (w <= 0 || h <= 0) { x = 0; y = 0; w = W_; h = H_; }
+  if (x < 0 || y < 0 || x + w > W_ || y + h > H_) throw Error(FDH_ERR_INVALID, "readPixels: rectangle outside the frame");
+  FDH_HIP(hipStreamSynchronize(stream_));
+  FDH_HIP(hipMemcpy2D(out, (size_t)w * 4, fb_ + (size_t)y * W_ + x, (size_t)W_ * 4, (size_t)w * 4, h, hipMemcpyDeviceToHost));
+}
+void Context::frame_device_ptr(void** p, int* w, int* h, int64_t* pitch_bytes) {
+  if (!fb_) throw Error(FDH_ERR_INVALID, "no frame surface yet");
+  *p = fb_; *w = W_; *h = H_; *pitch_bytes = (int64_t)W_ * 4;
+}
+
+}  // namespace fdh

@@ -1,0 +1,203 @@
+// fdh_context.h -- host side of libfigdraw_hip.so: the BackendContext-shaped state machine that turns
+// backend calls into draw records (what glcontext.nim does into vertex streams) and submits them.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/figdraw_hip.h"
+#include "fdh_kernels.h"
+
+namespace fdh {
+
+struct Error : std::runtime_error {
+  int code;
+  Error(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+void hip_check(hipError_t e, const char* what);
+#define FDH_HIP(x) ::fdh::hip_check((x), #x)
+
+// 2D affine part of the vmath Mat4 stack: [a c tx; b d ty]
+struct Aff {
+  float a = 1, b = 0, c = 0, d = 1, tx = 0, ty = 0;
+};
+
+template <typename T>
+struct DeviceBuf {
+  T* ptr = nullptr;
+  size_t cap = 0;
+  void reserve(size_t n) {
+    if (n <= cap) return;
+    if (ptr) FDH_HIP(hipFree(ptr));
+    size_t want = cap ? cap : 256;
+    while (want < n) want *= 2;
+    FDH_HIP(hipMalloc((void**)&ptr, want * sizeof(T)));
+    cap = want;
+  }
+  void release() {
+    if (ptr) (void)hipFree(ptr);
+    ptr = nullptr;
+    cap = 0;
+  }
+};
+
+template <typename T>
+struct PinnedBuf {
+  T* ptr = nullptr;
+  size_t cap = 0;
+  void reserve(size_t n) {
+    if (n <= cap) return;
+    if (ptr) FDH_HIP(hipHostFree(ptr));
+    size_t want = cap ? cap : 256;
+    while (want < n) want *= 2;
+    FDH_HIP(hipHostMalloc((void**)&ptr, want * sizeof(T), hipHostMallocDefault));
+    cap = want;
+  }
+  void release() {
+    if (ptr) (void)hipHostFree(ptr);
+    ptr = nullptr;
+    cap = 0;
+  }
+};
+
+struct AtlasEntry { int x, y, w, h; };
+
+struct Phase {
+  int first = 0, count = 0;
+  int blur = -1;  // index into blurs: executed before this phase's composite
+  int bin_x0 = 0, bin_y0 = 0, bin_x1 = 0, bin_y1 = 0;  // bins touched by the phase's draws
+};
+struct BlurJob {
+  float radius;
+  int x0, y0, x1, y1;  // footprint: the mode-17 quad's pixel bounds
+  BlurTaps taps;
+};
+
+struct RectMaskEntry { int kind; };  // 1 = fast analytic, 2 = real mask (glcontext.nim:36-44)
+
+class Context {
+ public:
+  Context(int atlas_size, float pixel_scale, int device, uint32_t flags);
+  ~Context();
+
+  // BackendContext surface
+  void begin_frame(int w, int h, bool clear, const float rgba[4]);
+  void end_frame();
+  void save_transform();
+  void restore_transform();
+  void translate(float x, float y);
+  void rotate(float a);
+  void scale(float sx, float sy);
+  void apply_transform(const float m[16]);
+  bool transform_mirrors_y() const;
+  void set_aa(float aa) { aa_ = aa; }
+  float aa() const { return aa_; }
+  float pixel_scale() const { return pixel_scale_; }
+  void draw_rounded_rect_sdf(const float rect[4], const FdhColor colors[4], const float rx[4], const float ry[4], int mode,
+                             float factor, float spread, const float shape[2], int fill_mode, FdhColor mid, FdhColor stop,
+                             float mid_pos);
+  void draw_rounded_rect_fill(const float rect[4], const FdhFill& fill, const float rx[4], const float ry[4], int mode,
+                              float factor, float spread, const float shape[2]);
+  void draw_image(int64_t key, const float pos[2], const FdhColor colors[4], const float size[2], bool flip_y);
+  void draw_msdf(int64_t key, const float pos[2], FdhColor color, const float size[2], float px_range, float sd_threshold,
+                 float stroke_weight, bool mtsdf, bool flip_y);
+  void draw_backdrop_blur(const float rect[4], const float rx[4], const float ry[4], float blur_radius);
+  void begin_mask(const float rect[4], const float rx[4], const float ry[4]);
+  void end_mask();
+  void pop_mask();
+  void begin_rect_mask(const float rect[4], const float rx[4], const float ry[4]);
+  void pop_rect_mask();
+  void set_subpixel_enabled(bool e) { subpixel_enabled_ = e; }
+  void set_subpixel_shift(float s) { subpixel_shift_ = s; }
+
+  // atlas
+  void put_image(int64_t key, int w, int h, const uint8_t* rgba, int out_rect[4]);
+  void update_image(int64_t key, int w, int h, const uint8_t* rgba);
+  void remove_image(int64_t key) { entries_.erase(key); }
+  bool has_image(int64_t key) const { return entries_.count(key) != 0; }
+  void reset_atlas(int minimum_size);
+  int atlas_size() const { return atlas_size_; }
+  int64_t atlas_packed_area() const;
+
+  // readback / interop
+  void read_pixels(int x, int y, int w, int h, uint8_t* out);
+  void frame_device_ptr(void** p, int* w, int* h, int64_t* pitch_bytes);
+  void sync();
+  void set_stream(void* s);
+
+  // scene front-end (fdh_frontend.cpp)
+  void set_ui_scale(float s) { ui_scale_ = s; }
+  float ui_scale() const { return ui_scale_; }
+  void render_frame(const FdhScene* scene, float fw, float fh, bool clear, const float rgba[4]);
+
+  // multi-GPU / measurement
+  void set_stripe(int y0, int y1) { stripe_y0_ = y0; stripe_y1_ = y1; }
+  void replay(int times);
+  void frame_stats(FdhFrameStats* out) const { *out = stats_; }
+
+ private:
+  void push_rec(const DrawRec& r, const BBox& b);
+  void emit_quad(DrawRec& r, float x0, float y0, float x1, float y1, int64_t* fragments);
+  void upload_atlas_rect(int level, int x, int y, int w, int h, const uint8_t* rgba);
+  void put_levels(int x, int y, int w, int h, const uint8_t* rgba);
+  void alloc_atlas(int size);
+  void find_empty_rect(int w, int h, int* ox, int* oy);
+  void submit(bool upload);
+  void launch_frame(bool profile);
+  void ensure_surfaces();
+
+  int device_ = 0;
+  uint32_t flags_ = 0;
+  hipStream_t own_stream_ = nullptr, stream_ = nullptr;
+  hipEvent_t ev_[10] = {};
+
+  // frame state
+  int W_ = 0, H_ = 0;
+  bool frame_begun_ = false, mask_begun_ = false;
+  bool clear_ = true;
+  uint32_t clear_rgba8_ = 0xFFFFFFFFu;
+  int mask_depth_ = 0;
+  std::vector<RectMaskEntry> rect_masks_;
+  std::vector<uint32_t> open_ops_;  // indices of currently open MASK_PUSH / RMASK_BEGIN records (re-emitted after a blur)
+  Aff mat_;
+  std::vector<Aff> mats_;
+  float aa_ = 1.2f, pixel_scale_ = 1.0f, ui_scale_ = 1.0f;
+  bool subpixel_enabled_ = false;
+  float subpixel_shift_ = 0.0f;
+  int stripe_y0_ = 0, stripe_y1_ = 0;
+
+  // recorded frame
+  std::vector<DrawRec> recs_;
+  std::vector<BBox> bboxes_;
+  std::vector<QuadExt> exts_;
+  std::vector<Phase> phases_;
+  std::vector<BlurJob> blurs_;
+  int64_t fragments_ = 0;
+  bool have_frame_ = false;
+
+  // device state
+  uint32_t *fb_ = nullptr, *backdrop_ = nullptr, *blur_tmp_ = nullptr;
+  int surf_w_ = 0, surf_h_ = 0;
+  DeviceBuf<DrawRec> d_recs_;
+  DeviceBuf<BBox> d_bboxes_;
+  DeviceBuf<QuadExt> d_exts_;
+  DeviceBuf<uint32_t> d_lists_, d_counts_;
+  DeviceBuf<int> d_phase_first_;
+  PinnedBuf<uint8_t> staging_;
+  int bins_x_ = 0, bins_y_ = 0, list_stride_ = 0;
+
+  // atlas
+  int atlas_size_ = 0, initial_atlas_size_ = 0, atlas_margin_ = 4, n_levels_ = 0;
+  uint32_t* atlas_levels_[kMaxMips] = {};
+  std::vector<uint16_t> heights_;
+  std::unordered_map<int64_t, AtlasEntry> entries_;
+
+  FdhFrameStats stats_ = {};
+};
+
+}  // namespace fdh

@@ -1,0 +1,46 @@
+// fdh_kernels.h -- kernel parameter blocks and launchers shared by fdh_kernels.hip and the host context.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "fdh_types.h"
+
+namespace fdh {
+
+struct BinParams {
+  const BBox* bbox;     // per draw, clipped pixel bounds (ops that must reach every tile carry the frame)
+  uint32_t* lists;      // [phase][bin][stride]
+  uint32_t* counts;     // [phase][bin]
+  const int* phase_first;  // [n_phases + 1]
+  int n_phases, bins_x, bins_y, stride;
+};
+
+struct CompositeParams {
+  const uint32_t* lists;   // this phase's [bin][stride]
+  const uint32_t* counts;  // this phase's [bin]
+  const uint32_t* backdrop;  // blurred snapshot sampled by mode 17
+  uint32_t* fb;
+  AtlasView atlas;
+  int W, H, pitch;          // pitch in pixels
+  int bins_x, stride;
+  int bin_x0, bin_y0, bin_nx, bin_ny;  // sub-grid of bins this launch covers
+  int row_lo, row_hi;       // stripe: only rows in [row_lo,row_hi) are produced
+  int load_fb;              // 0: start from clear_rgba8
+  uint32_t clear_rgba8;
+  int n_wg;                 // total workgroups (for the XCD remap)
+};
+
+struct BlurParams {
+  const uint32_t* src;
+  uint32_t* dst;
+  int W, H, pitch;
+  int x0, y0, x1, y1;  // output region
+  BlurTaps taps;
+};
+
+void launch_bin(hipStream_t s, const BinParams& P);
+void launch_composite(hipStream_t s, const DrawRec* draws, const BBox* bboxes, const QuadExt* exts, CompositeParams P);
+void launch_blur_h(hipStream_t s, const BlurParams& P);
+void launch_blur_v(hipStream_t s, const BlurParams& P);
+void launch_fill(hipStream_t s, uint32_t* p, uint32_t v, size_t n);
+
+}  // namespace fdh

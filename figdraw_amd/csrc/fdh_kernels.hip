@@ -1,0 +1,538 @@
+// fdh_kernels.hip -- hand-written gfx950 (CDNA4) kernels for figdraw's per-pixel SDF path.
+//
+//   k_bin_draws        coarse binning: ordered per-bin draw lists (64x64-pixel bins)
+//   k_composite_tiles  one wavefront per 8x8 tile walks its draws in painter's order keeping RGBA in
+//                      registers, re-quantising to RGBA8 after every draw like the GL framebuffer does
+//                      (utils/glutils.nim:150-154 blend + RGBA8 target), and stores the tile once
+//   k_blur_h/k_blur_v  the separable backdrop blur of glsl/blur.frag as a merged FIR, LDS line staging
+//
+// The per-pixel math restates src/figdraw/opengl/glsl/{atlas,atlas_rect_mask,mask}.frag; every device
+// function cites the lines it follows.  No MFMA: this is VALU + transcendental work.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "fdh_kernels.h"
+
+namespace fdh {
+
+// ------------------------------------------------------------------ small device helpers
+__device__ __forceinline__ float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ float fexp2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float clamp01(float x) { return __builtin_fminf(__builtin_fmaxf(x, 0.0f), 1.0f); }
+__device__ __forceinline__ float mixf(float a, float b, float t) { return a * (1.0f - t) + b * t; }
+
+struct F4 { float x, y, z, w; };
+
+__device__ __forceinline__ F4 unpack255(uint32_t c) {  // RGBA8 -> floats in 0..255
+  F4 r;
+  r.x = (float)(c & 255u);
+  r.y = (float)((c >> 8) & 255u);
+  r.z = (float)((c >> 16) & 255u);
+  r.w = (float)(c >> 24);
+  return r;
+}
+__device__ __forceinline__ uint32_t pack255(F4 f) {
+  return (uint32_t)f.x | ((uint32_t)f.y << 8) | ((uint32_t)f.z << 16) | ((uint32_t)f.w << 24);
+}
+
+// atlas.frag:51-69
+__device__ __forceinline__ float sd_rounded_box(float px, float py, float bx, float by, float r0, float r1, float r2, float r3) {
+  float rr = (px > 0.0f) ? ((py > 0.0f) ? r0 : r1) : ((py > 0.0f) ? r2 : r3);
+  float qx = __builtin_fabsf(px) - bx + rr, qy = __builtin_fabsf(py) - by + rr;
+  float mx = __builtin_fmaxf(qx, 0.0f), my = __builtin_fmaxf(qy, 0.0f);
+  return __builtin_fminf(__builtin_fmaxf(qx, qy), 0.0f) + fsqrt(mx * mx + my * my) - rr;
+}
+// atlas.frag:71-79
+__device__ __forceinline__ float sd_ellipse(float px, float py, float rx, float ry) {
+  float sx = __builtin_fmaxf(rx, 0.000001f), sy = __builtin_fmaxf(ry, 0.000001f);
+  float isx = frcp(sx), isy = frcp(sy);
+  float ax = px * isx, ay = py * isy;
+  float k0 = fsqrt(ax * ax + ay * ay);
+  if (k0 <= 0.000001f) return -__builtin_fminf(sx, sy);
+  float bx = ax * isx, by = ay * isy;
+  float k1 = fsqrt(bx * bx + by * by);
+  return k0 * (k0 - 1.0f) * frcp(__builtin_fmaxf(k1, 0.000001f));
+}
+// atlas.frag:88-115
+__device__ __forceinline__ float sd_elliptical_rounded_box(float px, float py, float bx, float by, float r0, float r1, float r2, float r3) {
+  float sel = (px > 0.0f) ? ((py > 0.0f) ? r0 : r1) : ((py > 0.0f) ? r2 : r3);
+  if (sel < 0.0f) {
+    float r = -sel - 1.0f;
+    return sd_rounded_box(px, py, bx, by, r, r, r, r);
+  }
+  float pv = __builtin_floorf(sel + 0.5f);
+  float hi = __builtin_floorf(pv * (1.0f / 4096.0f));
+  float rx = (pv - 4096.0f * hi) * bx * (1.0f / 4095.0f);
+  float ry = hi * by * (1.0f / 4095.0f);
+  float ax = __builtin_fabsf(px), ay = __builtin_fabsf(py);
+  if (rx <= 0.0f || ry <= 0.0f) {
+    float qx = ax - bx, qy = ay - by;
+    float mx = __builtin_fmaxf(qx, 0.0f), my = __builtin_fmaxf(qy, 0.0f);
+    return __builtin_fminf(__builtin_fmaxf(qx, qy), 0.0f) + fsqrt(mx * mx + my * my);
+  }
+  if (rx == ry) return sd_rounded_box(px, py, bx, by, rx, rx, rx, rx);
+  float qx = ax - bx + rx, qy = ay - by + ry;
+  if (qx > 0.0f && qy > 0.0f) return sd_ellipse(qx, qy, rx, ry);
+  return __builtin_fmaxf(qx - rx, qy - ry);
+}
+__device__ __forceinline__ float shape_dist(bool ellip, float px, float py, float bx, float by, float r0, float r1, float r2, float r3) {
+  return ellip ? sd_elliptical_rounded_box(px, py, bx, by, r0, r1, r2, r3) : sd_rounded_box(px, py, bx, by, r0, r1, r2, r3);
+}
+// atlas.frag:211-216 -- exp(-0.5 z^2) as exp2
+__device__ __forceinline__ float shadow_profile(float sd, float blur_radius) {
+  float sigma = __builtin_fmaxf(0.5f * blur_radius, 0.5f);
+  float z = sd * frcp(sigma);
+  return fexp2(-0.72134752044f * z * z);
+}
+__device__ __forceinline__ float median3(float a, float b, float c) {  // atlas.frag:41-43
+  return __builtin_fmaxf(__builtin_fminf(a, b), __builtin_fminf(__builtin_fmaxf(a, b), c));
+}
+
+// GL_LINEAR + GL_REPEAT fetch from one atlas level, texel-space coords (s*S - 0.5); returns 0..1 floats
+__device__ __forceinline__ F4 atlas_bilinear(const uint32_t* __restrict__ tex, int S, float x, float y) {
+  float fx = __builtin_floorf(x), fy = __builtin_floorf(y);
+  float ax = x - fx, ay = y - fy;
+  int m = S - 1;  // S is a power of two
+  int x0 = (int)fx & m, y0 = (int)fy & m, x1 = (x0 + 1) & m, y1 = (y0 + 1) & m;
+  F4 a = unpack255(tex[(size_t)y0 * S + x0]), b = unpack255(tex[(size_t)y0 * S + x1]);
+  F4 c = unpack255(tex[(size_t)y1 * S + x0]), d = unpack255(tex[(size_t)y1 * S + x1]);
+  const float k = 1.0f / 255.0f;
+  F4 o;
+  o.x = (mixf(a.x, b.x, ax) * (1.0f - ay) + mixf(c.x, d.x, ax) * ay) * k;
+  o.y = (mixf(a.y, b.y, ax) * (1.0f - ay) + mixf(c.y, d.y, ax) * ay) * k;
+  o.z = (mixf(a.z, b.z, ax) * (1.0f - ay) + mixf(c.z, d.z, ax) * ay) * k;
+  o.w = (mixf(a.w, b.w, ax) * (1.0f - ay) + mixf(c.w, d.w, ax) * ay) * k;
+  return o;
+}
+// texture(atlasTex, uv) with LINEAR_MIPMAP_LINEAR min / LINEAR mag (glcontext.nim:157-169); lod = log2(rho)
+__device__ __forceinline__ F4 atlas_sample(const AtlasView& A, float u, float v, float lod) {
+  int S = A.size;
+  if (!(lod > 0.0f) || A.n_levels < 2) return atlas_bilinear(A.level[0], S, u * (float)S - 0.5f, v * (float)S - 0.5f);
+  float maxl = (float)(A.n_levels - 1);
+  lod = __builtin_fminf(lod, maxl);
+  int l0 = (int)__builtin_floorf(lod);
+  int l1 = l0 + 1 > A.n_levels - 1 ? A.n_levels - 1 : l0 + 1;
+  float f = lod - (float)l0;
+  int S0 = S >> l0, S1 = S >> l1;
+  F4 a = atlas_bilinear(A.level[l0], S0, u * (float)S0 - 0.5f, v * (float)S0 - 0.5f);
+  F4 b = atlas_bilinear(A.level[l1], S1, u * (float)S1 - 0.5f, v * (float)S1 - 0.5f);
+  F4 o = {mixf(a.x, b.x, f), mixf(a.y, b.y, f), mixf(a.z, b.z, f), mixf(a.w, b.w, f)};
+  return o;
+}
+
+// ------------------------------------------------------------------ binning
+
+// One workgroup per (phase, bin): ordered stream compaction of the phase's draws that touch the bin.
+__global__ __launch_bounds__(256) void k_bin_draws(BinParams P) {
+  __shared__ uint32_t wave_cnt[4];
+  __shared__ uint32_t base_sh;
+  const int nb = P.bins_x * P.bins_y;
+  const int phase = blockIdx.x / nb, bin = blockIdx.x - phase * nb;
+  const int by = bin / P.bins_x, bx = bin - by * P.bins_x;
+  const int x0 = bx * kBin, y0 = by * kBin, x1 = x0 + kBin, y1 = y0 + kBin;
+  const int first = P.phase_first[phase], last = P.phase_first[phase + 1];
+  uint32_t* out = P.lists + ((size_t)phase * nb + bin) * P.stride;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) base_sh = 0;
+  __syncthreads();
+  for (int i0 = first; i0 < last; i0 += 256) {
+    int i = i0 + threadIdx.x;
+    bool hit = false;
+    if (i < last) {
+      BBox b = P.bbox[i];
+      hit = b.x0 < x1 && b.x1 > x0 && b.y0 < y1 && b.y1 > y0;
+    }
+    unsigned long long m = __ballot(hit);
+    uint32_t before = __builtin_popcountll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) wave_cnt[wave] = __builtin_popcountll(m);
+    __syncthreads();
+    uint32_t base = base_sh, woff = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+      uint32_t c = wave_cnt[w];
+      if (w < wave) woff += c;
+      total += c;
+    }
+    if (hit) out[base + woff + before] = (uint32_t)i;
+    __syncthreads();
+    if (threadIdx.x == 0) base_sh = base + total;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) P.counts[(size_t)phase * nb + bin] = base_sh;
+}
+
+// ------------------------------------------------------------------ compositing
+
+struct Frag {
+  float u, v;     // interpolated quad uv
+  F4 col;         // interpolated vertex colour, 0..1
+  float fw_u, fw_v, lod;
+  bool covered;
+};
+
+// per-triangle affine interpolation of the four vertex colours on an axis-aligned quad:
+// triangles (TL,BL,BR) and (TR,TL,BR) (glcontext.nim:418-429); s,t = quad-normalised x, y-down
+__device__ __forceinline__ float tri_lerp(float tl, float bl, float br, float tr, float s, float t) {
+  return (s > t) ? (tl + (tr - tl) * s + (br - tr) * t) : (tl + (bl - tl) * t + (br - bl) * s);
+}
+
+__device__ __forceinline__ Frag make_frag(const DrawRec& r, const QuadExt* __restrict__ exts, int px, int py) {
+  Frag f;
+  const uint32_t om = r.op_mode;
+  const uint32_t mode = om & 255u;
+  const bool atlas_mode = (mode == 0u) || (mode >= 13u && mode <= 16u);
+  // vertex uvs: BL=(at.x,to.y) BR=(to.x,to.y) TR=(to.x,at.y) TL=(at.x,at.y); SDF quads use (0,0)-(1,1)
+  const float uax = atlas_mode ? r.r[0] : 0.0f, uay = atlas_mode ? r.r[1] : 0.0f;
+  const float utx = atlas_mode ? r.r[2] : 1.0f, uty = atlas_mode ? r.r[3] : 1.0f;
+  f.covered = px >= r.bx0 && px < r.bx1 && py >= r.by0 && py < r.by1;
+  if (!(om & F_GENERAL)) {
+    float s = ((float)px + 0.5f - r.ox) * r.inv_w;
+    float t = ((float)py + 0.5f - r.oy) * r.inv_h;
+    f.u = uax + (utx - uax) * s;
+    f.v = uay + (uty - uay) * t;
+    if (om & F_SOLID) {
+      F4 c = unpack255(r.col[0]);
+      const float k = 1.0f / 255.0f;
+      f.col = {c.x * k, c.y * k, c.z * k, c.w * k};
+    } else {
+      F4 bl = unpack255(r.col[0]), br = unpack255(r.col[1]), tr = unpack255(r.col[2]), tl = unpack255(r.col[3]);
+      const float k = 1.0f / 255.0f;
+      f.col.x = tri_lerp(tl.x, bl.x, br.x, tr.x, s, t) * k;
+      f.col.y = tri_lerp(tl.y, bl.y, br.y, tr.y, s, t) * k;
+      f.col.z = tri_lerp(tl.z, bl.z, br.z, tr.z, s, t) * k;
+      f.col.w = tri_lerp(tl.w, bl.w, br.w, tr.w, s, t) * k;
+    }
+    f.fw_u = __builtin_fabsf((utx - uax) * r.inv_w);
+    f.fw_v = __builtin_fabsf((uty - uay) * r.inv_h);
+    f.lod = r.aux2;
+    return f;
+  }
+  // general quad: exact integer edge functions in half-pixel units, top-left rule
+  const QuadExt& q = exts[r.ext];
+  const int X = 2 * px + 1, Y = 2 * py + 1;
+  int hit = -1;
+  long long e0 = 0, e1 = 0, e2 = 0;
+#pragma unroll
+  for (int t = 0; t < 2; t++) {
+    if (hit >= 0 || q.inv_sum[t] == 0.0f) continue;
+    long long a0 = (long long)q.e[t][0].a * X + (long long)q.e[t][0].b * Y + q.e[t][0].c;
+    long long a1 = (long long)q.e[t][1].a * X + (long long)q.e[t][1].b * Y + q.e[t][1].c;
+    long long a2 = (long long)q.e[t][2].a * X + (long long)q.e[t][2].b * Y + q.e[t][2].c;
+    bool in = a0 >= 0 && a1 >= 0 && a2 >= 0;
+    uint32_t own = q.own >> (t * 3);
+    if (a0 == 0 && !(own & 1u)) in = false;
+    if (a1 == 0 && !(own & 2u)) in = false;
+    if (a2 == 0 && !(own & 4u)) in = false;
+    if (in) { hit = t; e0 = a0; e1 = a1; e2 = a2; }
+  }
+  f.covered = f.covered && hit >= 0;
+  const int t = hit < 0 ? 0 : hit;
+  const float is = q.inv_sum[t];
+  const float l0 = (float)e0 * is, l1 = (float)e1 * is, l2 = (float)e2 * is;
+  // triangle 0 = vertices (3,0,1) = (TL,BL,BR); triangle 1 = (2,3,1) = (TR,TL,BR)
+  const float u0 = t == 0 ? uax : utx, v0 = t == 0 ? uay : uay;   // TL | TR
+  const float u1 = t == 0 ? uax : uax, v1 = t == 0 ? uty : uay;   // BL | TL
+  const float u2 = utx, v2 = uty;                                 // BR | BR
+  f.u = l0 * u0 + l1 * u1 + l2 * u2;
+  f.v = l0 * v0 + l1 * v1 + l2 * v2;
+  F4 c0 = unpack255(t == 0 ? r.col[3] : r.col[2]);
+  F4 c1 = unpack255(t == 0 ? r.col[0] : r.col[3]);
+  F4 c2 = unpack255(r.col[1]);
+  const float k = 1.0f / 255.0f;
+  f.col.x = (l0 * c0.x + l1 * c1.x + l2 * c2.x) * k;
+  f.col.y = (l0 * c0.y + l1 * c1.y + l2 * c2.y) * k;
+  f.col.z = (l0 * c0.z + l1 * c1.z + l2 * c2.z) * k;
+  f.col.w = (l0 * c0.w + l1 * c1.w + l2 * c2.w) * k;
+  f.fw_u = q.fw_u[t];
+  f.fw_v = q.fw_v[t];
+  f.lod = q.lod;
+  return f;
+}
+
+// evalFillColor atlas.frag:233-250
+__device__ __forceinline__ F4 eval_fill(const DrawRec& r, const Frag& f, uint32_t fill_mode) {
+  if (fill_mode == 0u) return f.col;
+  float t;
+  switch (fill_mode) {
+    case 1u: t = f.u; break;
+    case 2u: t = f.v; break;
+    case 3u: t = 0.5f * (f.u + f.v); break;
+    default: t = 0.5f * (f.u + (1.0f - f.v)); break;
+  }
+  t = clamp01(t);
+  const float mid = __builtin_fminf(__builtin_fmaxf(r.f1, 0.01f), 0.99f);
+  const float k = 1.0f / 255.0f;
+  F4 m = unpack255(r.mid), s = unpack255(r.stop), o;
+  if (t <= mid) {
+    float w = t * frcp(mid);
+    o.x = mixf(f.col.x, m.x * k, w); o.y = mixf(f.col.y, m.y * k, w); o.z = mixf(f.col.z, m.z * k, w); o.w = mixf(f.col.w, m.w * k, w);
+  } else {
+    float w = (t - mid) * frcp(1.0f - mid);
+    o.x = mixf(m.x * k, s.x * k, w); o.y = mixf(m.y * k, s.y * k, w); o.z = mixf(m.z * k, s.z * k, w); o.w = mixf(m.w * k, s.w * k, w);
+  }
+  return o;
+}
+
+// fixed-function blend SRC_ALPHA/ONE_MINUS_SRC_ALPHA (rgb), ONE/ONE_MINUS_SRC_ALPHA (alpha), then the RGBA8
+// store (utils/glutils.nim:150-154).  F holds the framebuffer texel as 0..255 integers in floats.
+__device__ __forceinline__ void blend(F4& F, float r, float g, float b, float sa) {
+  const float ia = 1.0f - sa;
+  F.x = __builtin_rintf(r * (255.0f * sa) + F.x * ia);
+  F.y = __builtin_rintf(g * (255.0f * sa) + F.y * ia);
+  F.z = __builtin_rintf(b * (255.0f * sa) + F.z * ia);
+  F.w = __builtin_rintf(255.0f * sa + F.w * ia);
+}
+
+// atlas_rect_mask.frag:222-237
+__device__ __forceinline__ float rect_mask_alpha(const DrawRec& r, float cx, float cy) {
+  float lx = (r.ox * cx + r.oy * cy) + r.inv_w;
+  float ly = (r.inv_h * cx + r.f0 * cy) + r.f1;
+  float qx = lx - r.p0, qy = ly - r.p1;
+  float dist = shape_dist((r.op_mode & F_ELLIP) != 0u, qx, -qy, r.p2, r.p3, r.r[0], r.r[1], r.r[2], r.r[3]);
+  return 1.0f - clamp01(r.aa * dist + 0.5f);
+}
+
+__global__ __launch_bounds__(256) void k_composite_tiles(const DrawRec* __restrict__ draws, const BBox* __restrict__ bboxes,
+                                                         const QuadExt* __restrict__ exts, CompositeParams P) {
+  __shared__ float mask_stack[kWavesPerWg][kMaskDepth][64];
+  // XCD-aware remap: the dispatcher places workgroup b on XCD b % 8; give every XCD a contiguous run of
+  // logical workgroups so the 16 workgroups of a bin (same draw list, adjacent framebuffer lines) share an L2.
+  int wg = blockIdx.x;
+  {
+    const int n = P.n_wg, per = (n + 7) >> 3;
+    int logical = (wg & 7) * per + (wg >> 3);
+    if (logical >= n) return;  // padded tail of the remap (grid is rounded up to a multiple of 8)
+    wg = logical;
+  }
+  const int bin_local = wg / kWgsPerBin, j = wg - bin_local * kWgsPerBin;
+  const int bly = bin_local / P.bin_nx, blx = bin_local - bly * P.bin_nx;
+  const int bin_x = P.bin_x0 + blx, bin_y = P.bin_y0 + bly;
+  const int bin = bin_y * P.bins_x + bin_x;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int tx0 = bin_x * kBin + (j & 1) * kWgW + wave * kTile;
+  const int ty0 = bin_y * kBin + (j >> 1) * kWgH;
+  if (tx0 >= P.W || ty0 >= P.H) return;
+  if (ty0 + kTile <= P.row_lo || ty0 >= P.row_hi) return;
+  const int tx1 = tx0 + kTile, ty1 = ty0 + kTile;
+  const int px = tx0 + (lane & 7), py = ty0 + (lane >> 3);
+  const bool in_frame = px < P.W && py < P.H;
+  const size_t pix = (size_t)py * P.pitch + px;
+
+  float mask_cur = 1.0f;   // product state of the NfClipContent stack (1 = no mask bound: maskTexEnabled false)
+  float rmask_cur = 1.0f;  // fast rect mask (atlas_rect_mask.frag), 1 when none
+  int mask_depth = 0;
+  bool touched = false;
+
+  const uint32_t cnt = P.counts[bin];
+  if (cnt == 0 && P.load_fb) return;  // nothing lands in this bin: the surface already holds the result
+  F4 F = unpack255(P.clear_rgba8);
+  if (P.load_fb && in_frame) F = unpack255(P.fb[pix]);
+  const uint32_t* __restrict__ list = P.lists + (size_t)bin * P.stride;
+  const float cx = (float)px + 0.5f, cy = (float)py + 0.5f;
+
+  for (uint32_t base = 0; base < cnt; base += 64) {
+    const uint32_t i = base + lane;
+    uint32_t idx = 0;
+    bool hit = false;
+    if (i < cnt) {
+      idx = list[i];
+      BBox b = bboxes[idx];
+      hit = b.x0 < tx1 && b.x1 > tx0 && b.y0 < ty1 && b.y1 > ty0;
+    }
+    unsigned long long m = __ballot(hit);
+    while (m) {
+      const int bsel = __builtin_ctzll(m);
+      m &= m - 1;
+      const uint32_t d = __builtin_amdgcn_readlane(idx, bsel);
+      const DrawRec& r = draws[d];
+      const uint32_t om = r.op_mode;
+      const uint32_t op = (om >> 12) & 15u;
+      const uint32_t mode = om & 255u;
+      const bool ellip = (om & F_ELLIP) != 0u;
+      touched = true;
+      if (op == OP_MASK_POP) {
+        mask_depth--;
+        mask_cur = mask_depth > 0 ? mask_stack[wave][mask_depth - 1][lane] : 1.0f;
+        continue;
+      }
+      if (op == OP_RMASK_END) { rmask_cur = 1.0f; continue; }
+      if (op == OP_RMASK_BEGIN) { rmask_cur = rect_mask_alpha(r, cx, cy); continue; }
+
+      Frag f = make_frag(r, exts, px, py);
+      if (op == OP_MASK_PUSH) {
+        // mask.frag:186-234 drawn through the blender into a cleared R8 plane: stored = q8(a*a), a = shape*parent
+        float a = 0.0f;
+        if (f.covered) {
+          float lx = (f.u - 0.5f) * 2.0f * r.p0, ly = (f.v - 0.5f) * 2.0f * r.p1;
+          float dist = shape_dist(ellip, lx, -ly, r.p2, r.p3, r.r[0], r.r[1], r.r[2], r.r[3]);
+          a = (1.0f - clamp01(r.aa * dist + 0.5f)) * f.col.w * mask_cur;
+        }
+        float stored = __builtin_rintf(a * a * 255.0f) * (1.0f / 255.0f);
+        mask_stack[wave][mask_depth][lane] = stored;
+        mask_depth++;
+        mask_cur = stored;
+        continue;
+      }
+      // ---- OP_DRAW: atlas.frag main():252-405
+      const uint32_t fill_mode = (om >> 9) & 7u;
+      float sr, sg, sb, sa;
+      if (mode == 0u) {  // atlas.frag:284-295
+        float u = f.u;
+        if (om & F_SUBPIXEL) u -= r.aux * frcp(__builtin_fmaxf((float)P.atlas.size, 1.0f));
+        F4 t = atlas_sample(P.atlas, u, f.v, f.lod);
+        sr = t.x * f.col.x; sg = t.y * f.col.y; sb = t.z * f.col.z; sa = t.w * f.col.w;
+      } else if (mode >= 13u && mode <= 16u) {  // atlas.frag:296-318
+        F4 fc = eval_fill(r, f, fill_mode);
+        F4 t = atlas_sample(P.atlas, f.u, f.v, 0.0f);  // textureLod(atlasTex, uv, 0.0)
+        const bool is_mtsdf = (mode == 14u || mode == 16u), is_stroke = (mode == 15u || mode == 16u);
+        float sd = is_mtsdf ? t.w : median3(t.x, t.y, t.z);
+        float unit = r.f0 * frcp(r.p0);  // pxRange / atlas size (atlas.frag:45-49)
+        float spr = __builtin_fmaxf(0.5f * (unit * frcp(f.fw_u) + unit * frcp(f.fw_v)), 1.0f);
+        float spd = spr * (sd - r.f1);
+        float alpha = is_stroke ? clamp01(__builtin_fmaxf(r.p1, 0.0f) * 0.5f - __builtin_fabsf(spd) + 0.5f) : clamp01(spd + 0.5f);
+        sr = fc.x; sg = fc.y; sb = fc.z; sa = fc.w * alpha;
+      } else {
+        const float qhx = r.p0, qhy = r.p1;
+        const bool inset = mode == 9u;
+        const float shx = inset ? qhx : r.p2, shy = inset ? qhy : r.p3;
+        const float lx = (f.u - 0.5f) * 2.0f * qhx, ly = (f.v - 0.5f) * 2.0f * qhy;
+        const float dist = shape_dist(ellip, lx, -ly, shx, shy, r.r[0], r.r[1], r.r[2], r.r[3]);
+        const float spread = fill_mode == 0u ? r.f1 : 0.0f;
+        float alpha;
+        switch (mode) {
+          case 11u: { float h = r.f0 * 0.5f; float sd = __builtin_fabsf(dist + h) - h; alpha = sd < 0.0f ? 1.0f : 0.0f; break; }
+          case 12u: { float h = r.f0 * 0.5f; float sd = __builtin_fabsf(dist + h) - h; alpha = 1.0f - clamp01(r.aa * sd + 0.5f); break; }
+          case 7u: { float sd = dist - spread; alpha = sd > 0.0f ? __builtin_fminf(shadow_profile(sd, r.f0), 1.0f) : 1.0f; break; }
+          case 8u: {
+            float inside = 1.0f - clamp01(r.aa * dist + 0.5f);
+            float sd = dist - spread;
+            alpha = sd >= 0.0f ? __builtin_fminf(shadow_profile(sd, r.f0), 1.0f) : inside;
+            break;
+          }
+          case 9u: {  // atlas.frag:364-380
+            float clip_a = 1.0f - clamp01(r.aa * dist + 0.5f);
+            float sx = lx - r.p2, sy = -ly + r.p3;
+            float shd = shape_dist(ellip, sx, sy, qhx, qhy, r.r[0], r.r[1], r.r[2], r.r[3]);
+            float sd = shd + spread;
+            float ia = sd < 0.0f ? __builtin_fminf(shadow_profile(sd, r.f0), 1.0f) : 1.0f;
+            alpha = clip_a * ia;
+            break;
+          }
+          default: alpha = 1.0f - clamp01(r.aa * dist + 0.5f); break;  // ClipAA / BackdropBlur / others
+        }
+        if (mode == 17u) {  // atlas.frag:381-388: the blurred backdrop at this fragment's own pixel
+          F4 b = F;
+          if (!(om & F_SELF_BACKDROP) && in_frame) b = unpack255(P.backdrop[pix]);
+          const float k = 1.0f / 255.0f;
+          sr = b.x * k; sg = b.y * k; sb = b.z * k; sa = b.w * k * alpha;
+        } else {
+          F4 fc = eval_fill(r, f, fill_mode);
+          sr = fc.x; sg = fc.y; sb = fc.z; sa = fc.w * alpha;
+        }
+      }
+      sa *= mask_cur;   // atlas.frag:401-404
+      sa *= rmask_cur;  // atlas_rect_mask.frag:425
+      if (f.covered) blend(F, sr, sg, sb, sa);
+    }
+  }
+  if (in_frame && py >= P.row_lo && py < P.row_hi && (touched || !P.load_fb)) P.fb[pix] = pack255(F);
+}
+
+// ------------------------------------------------------------------ blur (blur.frag:11-32 as a merged FIR)
+
+constexpr int kBlurHW = 256;  // horizontal pass: one workgroup = 256 consecutive pixels of one row
+__global__ __launch_bounds__(256) void k_blur_h(BlurParams P) {
+  __shared__ uint32_t line[kBlurHW + 2 * 66];
+  const int y = P.y0 + blockIdx.y;
+  const int xs = P.x0 + blockIdx.x * kBlurHW;
+  const int reach = P.taps.reach;
+  const uint32_t* __restrict__ row = P.src + (size_t)y * P.pitch;
+  for (int i = threadIdx.x; i < kBlurHW + 2 * reach; i += 256) {
+    int x = xs - reach + i;
+    x = x < 0 ? 0 : (x > P.W - 1 ? P.W - 1 : x);  // clamp-to-edge (glcontext.nim:214-215)
+    line[i] = row[x];
+  }
+  __syncthreads();
+  const int x = xs + threadIdx.x;
+  if (x >= P.x1) return;
+  float ar = 0.f, ag = 0.f, ab = 0.f, aa = 0.f;
+  const int n = P.taps.n;
+  for (int k = 0; k < n; k++) {
+    F4 t = unpack255(line[threadIdx.x + reach + P.taps.off[k]]);
+    const float c = P.taps.coef[k];
+    ar += t.x * c; ag += t.y * c; ab += t.z * c; aa += t.w * c;
+  }
+  F4 o = {__builtin_rintf(ar), __builtin_rintf(ag), __builtin_rintf(ab), __builtin_rintf(aa)};
+  P.dst[(size_t)y * P.pitch + x] = pack255(o);
+}
+
+constexpr int kBlurVW = 64, kBlurVH = 32;  // vertical pass: one workgroup = 64 columns x 32 rows
+__global__ __launch_bounds__(256) void k_blur_v(BlurParams P) {
+  extern __shared__ uint32_t tile[];  // (kBlurVH + 2*reach) rows x 64 columns
+  const int xs = P.x0 + blockIdx.x * kBlurVW;
+  const int ys = P.y0 + blockIdx.y * kBlurVH;
+  const int reach = P.taps.reach;
+  const int rows = kBlurVH + 2 * reach;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int x = xs + lane;
+  const int xc = x > P.W - 1 ? P.W - 1 : x;
+  for (int rr = wave; rr < rows; rr += 4) {
+    int y = ys - reach + rr;
+    y = y < 0 ? 0 : (y > P.H - 1 ? P.H - 1 : y);
+    tile[rr * kBlurVW + lane] = P.src[(size_t)y * P.pitch + xc];
+  }
+  __syncthreads();
+  if (x >= P.x1) return;
+  const int n = P.taps.n;
+#pragma unroll 1
+  for (int q = 0; q < kBlurVH / 4; q++) {
+    const int ry = wave * (kBlurVH / 4) + q;
+    const int y = ys + ry;
+    if (y >= P.y1) break;
+    float ar = 0.f, ag = 0.f, ab = 0.f, aa = 0.f;
+    for (int k = 0; k < n; k++) {
+      F4 t = unpack255(tile[(ry + reach + P.taps.off[k]) * kBlurVW + lane]);
+      const float c = P.taps.coef[k];
+      ar += t.x * c; ag += t.y * c; ab += t.z * c; aa += t.w * c;
+    }
+    F4 o = {__builtin_rintf(ar), __builtin_rintf(ag), __builtin_rintf(ab), __builtin_rintf(aa)};
+    P.dst[(size_t)y * P.pitch + x] = pack255(o);
+  }
+}
+
+__global__ void k_fill_u32(uint32_t* p, uint32_t v, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) p[i] = v;
+}
+
+// ------------------------------------------------------------------ launch wrappers (called from fdh_context.cpp)
+void launch_bin(hipStream_t s, const BinParams& P) {
+  const int n = P.n_phases * P.bins_x * P.bins_y;
+  if (n > 0) hipLaunchKernelGGL(k_bin_draws, dim3(n), dim3(256), 0, s, P);
+}
+void launch_composite(hipStream_t s, const DrawRec* draws, const BBox* bboxes, const QuadExt* exts, CompositeParams P) {
+  const int n = P.bin_nx * P.bin_ny * kWgsPerBin;
+  if (n <= 0) return;
+  P.n_wg = n;
+  const int grid = ((n + 7) / 8) * 8;
+  hipLaunchKernelGGL(k_composite_tiles, dim3(grid), dim3(256), 0, s, draws, bboxes, exts, P);
+}
+void launch_blur_h(hipStream_t s, const BlurParams& P) {
+  if (P.x1 <= P.x0 || P.y1 <= P.y0) return;
+  dim3 grid((P.x1 - P.x0 + kBlurHW - 1) / kBlurHW, P.y1 - P.y0);
+  hipLaunchKernelGGL(k_blur_h, grid, dim3(256), 0, s, P);
+}
+void launch_blur_v(hipStream_t s, const BlurParams& P) {
+  if (P.x1 <= P.x0 || P.y1 <= P.y0) return;
+  dim3 grid((P.x1 - P.x0 + kBlurVW - 1) / kBlurVW, (P.y1 - P.y0 + kBlurVH - 1) / kBlurVH);
+  const size_t lds = (size_t)(kBlurVH + 2 * P.taps.reach) * kBlurVW * sizeof(uint32_t);
+  hipLaunchKernelGGL(k_blur_v, grid, dim3(256), lds, s, P);
+}
+void launch_fill(hipStream_t s, uint32_t* p, uint32_t v, size_t n) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(k_fill_u32, dim3(1024), dim3(256), 0, s, p, v, n);
+}
+
+}  // namespace fdh

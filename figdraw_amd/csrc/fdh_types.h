@@ -1,0 +1,85 @@
+// fdh_types.h -- records shared by the host-side context and the gfx950 kernels.
+#pragma once
+#include <stdint.h>
+
+namespace fdh {
+
+// Tile geometry: one wavefront (64 lanes) = one 8x8 pixel tile, lane <-> pixel (row-major inside the
+// tile).  A workgroup is 4 waves = 4 tiles side by side = a 32x8 strip, so a row of the strip is one
+// 128-byte line of the RGBA8 surface.  A coarse bin is 64x64 pixels = 16 workgroups.
+constexpr int kTile = 8;
+constexpr int kWavesPerWg = 4;
+constexpr int kWgW = kTile * kWavesPerWg;  // 32
+constexpr int kWgH = kTile;                // 8
+constexpr int kBin = 64;
+constexpr int kWgsPerBin = (kBin / kWgW) * (kBin / kWgH);  // 16
+constexpr int kMaskDepth = 8;                              // per-lane clip stack depth kept in LDS
+constexpr int kMaxMips = 14;
+constexpr int kMaxBlurTaps = 36;
+
+// op codes (DrawRec::op_mode bits 12..15)
+enum : uint32_t { OP_DRAW = 0, OP_MASK_PUSH = 1, OP_MASK_POP = 2, OP_RMASK_BEGIN = 3, OP_RMASK_END = 4 };
+
+// DrawRec::op_mode layout
+//   bits 0..7   SdfMode (figbackend.nim:36-52)
+//   bit  8      elliptical radii (SdfEllipticalRadiiFlag, glcontext.nim:992)
+//   bits 9..11  fill mode 0..4 (glcontext.nim:987-991)
+//   bits 12..15 op
+//   bit  16     general quad: `ext` indexes a QuadExt (rotated / mirrored / skewed transforms)
+//   bit  17     all four vertex colours equal
+//   bit  18     mode 17 samples the live framebuffer (blur radius <= 0.5: the snapshot is unblurred)
+//   bit  19     subpixel positioning enabled (mode 0)
+constexpr uint32_t F_ELLIP = 1u << 8;
+constexpr uint32_t F_GENERAL = 1u << 16;
+constexpr uint32_t F_SOLID = 1u << 17;
+constexpr uint32_t F_SELF_BACKDROP = 1u << 18;
+constexpr uint32_t F_SUBPIXEL = 1u << 19;
+
+// One BackendContext draw call, 128 bytes, read with wave-uniform (scalar) loads.
+struct alignas(16) DrawRec {
+  uint32_t op_mode;
+  uint32_t ext;        // QuadExt index when F_GENERAL
+  float ox, oy;        // ceil'd quad origin (axis-aligned path)      | RMASK: matX.xy
+  float inv_w, inv_h;  // 1 / ceil'd quad extent                      | RMASK: matX.z, matY.x
+  float p0, p1;        // sdfParams.xy (quad half extents; msdf: atlas size, stroke width) | RMASK: centre
+  float p2, p3;        // sdfParams.zw (shape half extents; inset: shadow offset)           | RMASK: half extents
+  float f0, f1;        // sdfFactors (factor, spread | midPos | msdf pxRange, threshold)     | RMASK: matY.yz
+  float r[4];          // sdfRadii (TR,BR,TL,BL) -- atlas modes: uvAt.xy, uvTo.xy
+  uint32_t col[4];     // vertex colours BL,BR,TR,TL, RGBA8 little-endian (r in the low byte)
+  uint32_t mid, stop;  // 3-stop gradient colours
+  float aa;            // SDF AA factor in effect for this draw
+  float aux;           // mode 0: subpixel shift ; atlas modes: texture LOD (log2 rho) in aux2
+  float aux2;
+  int16_t bx0, by0, bx1, by1;  // covered pixel bounds, clipped to the frame: [bx0,bx1) x [by0,by1)
+  uint32_t _pad[5];
+};
+static_assert(sizeof(DrawRec) == 128, "DrawRec must be 128 bytes");
+
+// Extension for non-axis-aligned quads: the two triangles (3,0,1) and (2,3,1) of glcontext.nim:418-429
+// over the four per-vertex ceil'd positions.  Edge functions are exact integers in half-pixel units.
+struct alignas(16) QuadExt {
+  struct Edge { int32_t a, b; int64_t c; };  // E = a*X + b*Y + c with X = 2*px+1, Y = 2*py+1 (64-bit accumulate)
+  Edge e[2][3];            // [tri][edge]; edge k is opposite vertex k; interior is E >= 0
+  float inv_sum[2];        // 1 / (E0+E1+E2)  (0 => degenerate triangle)
+  uint32_t own;            // bit (tri*3+edge): edge owns pixel centres lying exactly on it (top-left rule)
+  float fw_u[2], fw_v[2];  // |du/dx|+|du/dy|, |dv/dx|+|dv/dy| per triangle (msdf fwidth)
+  float lod;               // log2(rho) (atlas mip selection), max over the two triangles
+};
+static_assert(sizeof(QuadExt) == 128, "QuadExt must be 128 bytes");
+
+struct alignas(8) BBox { int16_t x0, y0, x1, y1; };
+
+struct BlurTaps {  // merged FIR of blur.frag:19-29 for one radius: out = sum coef[k] * src[x + off[k]]
+  int n;
+  int reach;  // max |off|
+  int off[kMaxBlurTaps];
+  float coef[kMaxBlurTaps];
+};
+
+struct AtlasView {
+  const uint32_t* level[kMaxMips];
+  int size;
+  int n_levels;
+};
+
+}  // namespace fdh

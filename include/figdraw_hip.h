@@ -1,0 +1,222 @@
+/* figdraw_hip.h -- C ABI of libfigdraw_hip.so: an MI355X (gfx950) offscreen
+ * rasteriser for figdraw's per-pixel SDF path ("node list -> RGBA8 framebuffer").
+ *
+ * The drop-in seam in the reference is the Nim `BackendContext` plug-in object
+ * (src/figdraw/figbackend.nim:185-190 type, :245-705 methods; implemented today by
+ * `OpenGlContext`, src/figdraw/opengl/glcontext.nim:46).  Every entry point below
+ * names the reference method it replaces; INTEGRATION.md shows the Nim shim
+ * (`HipContext = ref object of BackendContext`) that binds them with `importc`.
+ *
+ * Conventions
+ *   - plain C, opaque handle, no HIP/torch types in any signature
+ *   - every call returns 0 on success or a negative FdhStatus; fdh_last_error()
+ *     returns a human-readable message for the calling thread's last failure
+ *   - one handle = one GPU + one HIP stream; a handle is single-threaded, exactly
+ *     like a BackendContext (all reference call sites are on the render thread:
+ *     figrender.nim `{.forbids: [AppMainThreadEff].}`)
+ *   - coordinates are the same pre-transform pixel units the reference hands to its
+ *     backend (already multiplied by uiScale by the front-end); radii arrays are
+ *     in DirectionCorners order TL,TR,BL,BR (figbasics.nim:25-29); colour arrays
+ *     are in vertex order BL,BR,TR,TL (figbackend.nim:162)
+ *   - there is NO CPU fallback: if no gfx950 device is usable the create call fails
+ */
+#ifndef FIGDRAW_HIP_H
+#define FIGDRAW_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__GNUC__)
+#define FDH_API __attribute__((visibility("default")))
+#else
+#define FDH_API
+#endif
+
+typedef struct FdhContext FdhContext;
+
+typedef enum {
+  FDH_OK = 0,
+  FDH_ERR_INVALID = -1,    /* bad argument / call out of order (the reference asserts: glcontext.nim:1888-1889,1984-1986) */
+  FDH_ERR_NO_DEVICE = -2,  /* no usable gfx950 device: the library never falls back to the CPU */
+  FDH_ERR_HIP = -3,        /* a HIP runtime call failed */
+  FDH_ERR_ATLAS_FULL = -4, /* atlas cannot hold the image even after growing */
+  FDH_ERR_UNSUPPORTED = -5 /* the reference's "Backend ... unavailable" ValueError (figbackend.nim:468-705 base methods) */
+} FdhStatus;
+
+/* ------------------------------------------------------------------ scene model
+ * POD mirror of Fig / RenderList / Renders (src/figdraw/fignodes.nim:44-92,
+ * figbasics.nim:31-113, common/filltypes.nim:11-42).  The Nim `Fig` is a variant
+ * object and not C-stable, so the shim copies nodes into these. */
+typedef struct { uint8_t r, g, b, a; } FdhColor;
+
+enum { FDH_FILL_COLOR = 0, FDH_FILL_LINEAR2 = 1, FDH_FILL_LINEAR3 = 2 };                  /* FillKind filltypes.nim:18-21 */
+enum { FDH_AXIS_X = 0, FDH_AXIS_Y = 1, FDH_AXIS_DIAG_TLBR = 2, FDH_AXIS_DIAG_BLTR = 3 }; /* FillGradientAxis :12-16 */
+
+typedef struct {
+  int32_t kind;
+  int32_t axis;
+  FdhColor start; /* flColor: the colour */
+  FdhColor mid;
+  FdhColor stop;
+  uint8_t mid_pos; /* 0..255 (Linear3.midPos) */
+  uint8_t _pad[3];
+} FdhFill;
+
+enum { FDH_SHADOW_NONE = 0, FDH_SHADOW_DROP = 1, FDH_SHADOW_INNER = 2 }; /* ShadowStyle figbasics.nim:60-64 */
+typedef struct { int32_t style; FdhFill fill; float blur, spread, x, y; } FdhShadow; /* RenderShadow :78-84 */
+typedef struct { float weight; FdhFill fill; int32_t cap, join; } FdhStroke;         /* RenderStroke :86-90 */
+
+enum { /* FigKind figbasics.nim:37-48 */
+  FDH_NK_FRAME = 0, FDH_NK_TEXT = 1, FDH_NK_RECTANGLE = 2, FDH_NK_DRAWABLE = 3, FDH_NK_SCROLLBAR = 4,
+  FDH_NK_IMAGE = 5, FDH_NK_MSDF_IMAGE = 6, FDH_NK_MTSDF_IMAGE = 7, FDH_NK_BACKDROP_BLUR = 8, FDH_NK_TRANSFORM = 9
+};
+enum { /* FigFlags figbasics.nim:50-58, bit = enum ordinal */
+  FDH_NF_CLIP_CONTENT = 1 << 0, FDH_NF_DISABLE_RENDER = 1 << 1, FDH_NF_ROOT_WINDOW = 1 << 2, FDH_NF_INACTIVE = 1 << 3,
+  FDH_NF_SELECT_TEXT = 1 << 4, FDH_NF_INVERT_Y = 1 << 5, FDH_NF_RECT_MASK_CONTENT = 1 << 6, FDH_NF_ELLIPTICAL_CORNERS = 1 << 7
+};
+enum { /* SdfMode figbackend.nim:36-52 */
+  FDH_SDF_ATLAS = 0, FDH_SDF_CLIP_AA = 3, FDH_SDF_DROP_SHADOW = 7, FDH_SDF_DROP_SHADOW_AA = 8, FDH_SDF_INSET_SHADOW = 9,
+  FDH_SDF_INSET_SHADOW_ANNULAR = 10, FDH_SDF_ANNULAR = 11, FDH_SDF_ANNULAR_AA = 12, FDH_SDF_MSDF = 13, FDH_SDF_MTSDF = 14,
+  FDH_SDF_MSDF_ANNULAR = 15, FDH_SDF_MTSDF_ANNULAR = 16, FDH_SDF_BACKDROP_BLUR = 17, FDH_SDF_BEZIER_STROKE_AA = 18,
+  FDH_SDF_BEZIER_STROKE_BUTT_AA = 19, FDH_SDF_BEZIER_STROKE_SQUARE_AA = 20
+};
+
+typedef struct {
+  int32_t kind;
+  uint32_t flags;
+  int32_t parent; /* FigIdx, -1 = root */
+  int32_t child_count;
+  int32_t zlevel;
+  float box[4];   /* screenBox x,y,w,h in UI units */
+  float rotation; /* degrees about the box centre */
+  FdhFill fill;
+  uint16_t corners[4];        /* TL,TR,BL,BR */
+  uint16_t corner_radii_y[4]; /* when NfEllipticalCorners */
+  FdhShadow shadows[4];       /* nkRectangle (ShadowCount = 4, figbasics.nim:12) */
+  FdhStroke stroke;           /* nkRectangle */
+  int64_t image_id;           /* nkImage / nkMsdfImage / nkMtsdfImage (ImageId = distinct Hash) */
+  FdhFill image_fill;
+  float px_range, sd_threshold, stroke_weight; /* MsdfImageStyle figbasics.nim:96-105 */
+  float blur;                 /* BackdropBlurStyle */
+  float translation[2];       /* TransformStyle */
+  float matrix[16];           /* column-major (vmath Mat4 memory order) */
+  int32_t use_matrix;
+  int32_t glyph_first, glyph_count; /* nkText: range into FdhScene.glyphs */
+} FdhFig;
+
+/* One positioned glyph quad: what figrender.nim:456-496 hands to drawImage after typesetting
+ * (typesetting / glyph rasterisation are CPU pre-processing done by the caller). */
+typedef struct {
+  int64_t image_id;
+  float x, y;         /* local top-left, UI-scaled (glyphLocalPos + imageOffset) */
+  FdhColor colors[4]; /* BL,BR,TR,TL */
+  float subpixel_shift;
+} FdhGlyph;
+
+typedef struct { int32_t zlevel; int32_t n_nodes; int32_t n_roots; int32_t _pad; const FdhFig* nodes; const int32_t* root_ids; } FdhLayer;
+typedef struct { const FdhLayer* layers; const FdhGlyph* glyphs; int32_t n_layers; int32_t n_glyphs; } FdhScene;
+
+/* ------------------------------------------------------------------ lifetime */
+/* newContext(atlasSize, ..., pixelScale): glcontext.nim:255-261.  device = HIP ordinal. */
+FDH_API int fdh_create(FdhContext** out, int atlas_size, float pixel_scale, int device, uint32_t flags);
+FDH_API int fdh_destroy(FdhContext*);
+FDH_API const char* fdh_last_error(void);
+/* Use a caller-owned hipStream_t (passed as void*) instead of the context's own stream; NULL restores it. */
+FDH_API int fdh_set_stream(FdhContext*, void* hip_stream);
+
+/* ------------------------------------------------------------------ BackendContext methods on the path */
+FDH_API int fdh_begin_frame(FdhContext*, int width, int height, int clear_main, const float clear_rgba[4]); /* beginFrame figbackend.nim:628-631, glcontext.nim:2080-2092 */
+FDH_API int fdh_end_frame(FdhContext*);      /* endFrame :633-634, glcontext.nim:1982-1989: submits the frame to the GPU */
+FDH_API int fdh_save_transform(FdhContext*);                   /* :654 */
+FDH_API int fdh_restore_transform(FdhContext*);                /* :657 */
+FDH_API int fdh_translate(FdhContext*, float x, float y);      /* :636 */
+FDH_API int fdh_rotate(FdhContext*, float radians);            /* :639 */
+FDH_API int fdh_scale(FdhContext*, float sx, float sy);        /* :642-646 */
+FDH_API int fdh_apply_transform(FdhContext*, const float m16[16]); /* :648 */
+FDH_API int fdh_transform_mirrors_y(FdhContext*, int* out);    /* :659, glcontext.nim:2019-2024 */
+FDH_API int fdh_set_aa_factor(FdhContext*, float aa);          /* setSdfAaFactor :277-279 */
+FDH_API int fdh_get_aa_factor(FdhContext*, float* out);        /* sdfAaFactor :274 */
+FDH_API int fdh_get_pixel_scale(FdhContext*, float* out);      /* pixelScale :271 */
+
+/* drawRoundedRectSdf(rect, colors, radii, mode, factor, spread, shapeSize) figbackend.nim:522-532;
+ * fill_mode/mid/stop/mid_pos carry the in-shader 3-stop gradient of glcontext.nim:1591-1607 (0 = vertex colours). */
+FDH_API int fdh_draw_rounded_rect_sdf(FdhContext*, const float rect[4], const FdhColor colors[4], const float radii_x[4],
+                                      const float radii_y[4], int mode, float factor, float spread, const float shape_size[2],
+                                      int fill_mode, FdhColor mid, FdhColor stop, float mid_pos);
+/* drawRoundedRectSdf(rect, fill: BackendFill, ...) figbackend.nim:534-552, glcontext.nim:1581-1617 */
+FDH_API int fdh_draw_rounded_rect_fill(FdhContext*, const float rect[4], const FdhFill* fill, const float radii_x[4],
+                                       const float radii_y[4], int mode, float factor, float spread, const float shape_size[2]);
+/* drawImage(path, pos, colors, size, flipY) figbackend.nim:468-475, glcontext.nim:1350-1367 */
+FDH_API int fdh_draw_image(FdhContext*, int64_t key, const float pos[2], const FdhColor colors[4], const float size[2], int flip_y);
+/* drawMsdfImage / drawMtsdfImage figbackend.nim:575-601, glcontext.nim:1097-1155 */
+FDH_API int fdh_draw_msdf(FdhContext*, int64_t key, const float pos[2], FdhColor color, const float size[2], float px_range,
+                          float sd_threshold, float stroke_weight, int mtsdf, int flip_y);
+/* drawBackdropBlur(rect, radii, blurRadius) figbackend.nim:603-606, glcontext.nim:1788-1841 */
+FDH_API int fdh_draw_backdrop_blur(FdhContext*, const float rect[4], const float radii_x[4], const float radii_y[4], float blur_radius);
+FDH_API int fdh_begin_mask(FdhContext*, const float rect[4], const float radii_x[4], const float radii_y[4]); /* beginMask :608-611, glcontext.nim:1886-1914 */
+FDH_API int fdh_end_mask(FdhContext*);                                                                         /* endMask :613, glcontext.nim:1916-1925 */
+FDH_API int fdh_pop_mask(FdhContext*);                                                                         /* popMask :616, glcontext.nim:1927-1930 */
+FDH_API int fdh_begin_rect_mask(FdhContext*, const float rect[4], const float radii_x[4], const float radii_y[4]); /* :619-623, glcontext.nim:1932-1943 */
+FDH_API int fdh_pop_rect_mask(FdhContext*);                                                                     /* :625, glcontext.nim:1945-1949 */
+/* drawQuadraticBezierSdf / drawFilledQuad / drawRect / drawImageAdj (figbackend.nim:499-520) belong to the
+ * drawable path, a SURVEY.md 8(f) "next" row: they report FDH_ERR_UNSUPPORTED like the reference's base methods. */
+FDH_API int fdh_draw_quadratic_bezier_sdf(FdhContext*, const float rect[4], const FdhFill* fill, const float p0[2],
+                                          const float p1[2], const float p2[2], float stroke_weight, int cap);
+FDH_API int fdh_draw_filled_quad(FdhContext*, const float verts[8], const FdhColor colors[4]);
+
+/* text flags: figbackend.nim:663-686 */
+FDH_API int fdh_set_text_subpixel_positioning(FdhContext*, int enabled);
+FDH_API int fdh_set_text_subpixel_shift(FdhContext*, float shift);
+
+/* ------------------------------------------------------------------ atlas (hasImage/putImage/updateImage/removeImage/... figbackend.nim:281-294,400-432) */
+/* putImage: skyline packer with margin 4 (glcontext.nim:541-586); out_rect = packed pixel rect x,y,w,h.
+ * The shim derives the UV entry as rect / atlasSize (glcontext.nim:584).  The atlas doubles when full (:536-539),
+ * which invalidates every earlier entry exactly as in the reference (resetImageAtlas :634-641). */
+FDH_API int fdh_put_image(FdhContext*, int64_t key, int width, int height, const uint8_t* rgba8, int out_rect[4]);
+FDH_API int fdh_update_image(FdhContext*, int64_t key, int width, int height, const uint8_t* rgba8); /* glcontext.nim:591-604 */
+FDH_API int fdh_remove_image(FdhContext*, int64_t key);
+FDH_API int fdh_has_image(FdhContext*, int64_t key, int* out);
+FDH_API int fdh_reset_atlas(FdhContext*, int minimum_size); /* resetImageAtlas / clearImageAtlas */
+FDH_API int fdh_atlas_size(FdhContext*, int* out);
+FDH_API int fdh_atlas_packed_area(FdhContext*, int64_t* out); /* atlasPackedArea glcontext.nim:2052-2054 */
+
+/* ------------------------------------------------------------------ readback */
+/* readPixels(frame, readFront) figbackend.nim:660-661, glcontext.nim:2094-2135: RGBA8, top-down rows.
+ * (x, y, w, h) is in top-down pixel coordinates; w <= 0 or h <= 0 reads the whole frame. Blocks until the frame is done. */
+FDH_API int fdh_read_pixels(FdhContext*, int x, int y, int w, int h, uint8_t* out_rgba8);
+/* Device pointer (hipDeviceptr_t as void*) + pitch of the RGBA8 surface, for zero-copy consumers
+ * (RCCL gather of stripes / frames, torch.from_blob).  Valid until the next begin_frame with another size. */
+FDH_API int fdh_frame_device_ptr(FdhContext*, void** out_ptr, int* out_width, int* out_height, int64_t* out_pitch_bytes);
+FDH_API int fdh_sync(FdhContext*);
+
+/* ------------------------------------------------------------------ whole-scene entry (renderFrame figrender.nim:1960-1995) */
+FDH_API int fdh_set_ui_scale(FdhContext*, float s); /* common/shared.nim:69-98 */
+FDH_API int fdh_render_frame(FdhContext*, const FdhScene*, float frame_w, float frame_h, int clear_main, const float clear_rgba[4]);
+
+/* ------------------------------------------------------------------ multi-GPU / measurement hooks (no reference counterpart) */
+/* Restrict rasterisation to rows [y0, y1) of the frame (row-stripe sharding).  Rows outside the
+ * stripe are left untouched; blur halos are rendered redundantly so no exchange is needed.  y1 <= y0 disables it. */
+FDH_API int fdh_set_stripe(FdhContext*, int y0, int y1);
+/* Re-run the GPU work of the last submitted frame `times` times from the draw records already resident in HBM
+ * (the host-side decomposition and the upload are not repeated). */
+FDH_API int fdh_replay(FdhContext*, int times);
+typedef struct {
+  int32_t n_draws, n_phases, n_blurs, n_bins;
+  float ms_total;      /* hipEvent time of the last submit/replay batch, all kernels, per frame */
+  float ms_bin;        /* binning kernel, per frame */
+  float ms_composite;  /* composite kernel(s), per frame */
+  float ms_blur;       /* blur H+V kernels, per frame */
+  int64_t bytes_algorithmic; /* SURVEY.md 8(d) B_frame for the last frame */
+  int64_t fragments;         /* sum of covered fragments over all draws (GL-equivalent work unit) */
+} FdhFrameStats;
+FDH_API int fdh_get_frame_stats(FdhContext*, FdhFrameStats* out);
+FDH_API int fdh_sizeof_fig(void);
+FDH_API int fdh_sizeof_glyph(void);
+FDH_API const char* fdh_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
