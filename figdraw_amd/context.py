@@ -32,8 +32,10 @@ class FigdrawHipError(RuntimeError):
 
 class FrameStats(C.Structure):
     _fields_ = [("n_draws", C.c_int32), ("n_phases", C.c_int32), ("n_blurs", C.c_int32), ("n_bins", C.c_int32),
-                ("ms_total", C.c_float), ("ms_bin", C.c_float), ("ms_composite", C.c_float), ("ms_blur", C.c_float),
-                ("bytes_algorithmic", C.c_int64), ("fragments", C.c_int64)]
+                ("ms_total", C.c_float), ("ms_bin", C.c_float), ("ms_composite", C.c_float),
+                ("ms_composite_main", C.c_float), ("ms_blur_h", C.c_float), ("ms_blur_v", C.c_float),
+                ("bytes_algorithmic", C.c_int64), ("bytes_composite_main", C.c_int64), ("bytes_blur", C.c_int64),
+                ("fragments", C.c_int64)]
 
 
 def build(force: bool = False) -> str:
@@ -98,6 +100,7 @@ def load():
     L.fdh_render_frame.argtypes = [vp, vp, C.c_float, C.c_float, C.c_int, _F4]
     L.fdh_set_stripe.argtypes = [vp, C.c_int, C.c_int]
     L.fdh_replay.argtypes = [vp, C.c_int]
+    L.fdh_profile.argtypes = [vp, C.c_int]
     L.fdh_get_frame_stats.argtypes = [vp, C.POINTER(FrameStats)]
     assert L.fdh_sizeof_fig() == C.sizeof(S.CFig), (L.fdh_sizeof_fig(), C.sizeof(S.CFig))
     assert L.fdh_sizeof_glyph() == C.sizeof(S.CGlyph)
@@ -284,6 +287,9 @@ class HipContext:
 
     def replay(self, times: int = 1):
         self._ck(self.L.fdh_replay(self.h, int(times)))
+
+    def profile(self, times: int = 1):
+        self._ck(self.L.fdh_profile(self.h, int(times)))
 
     def frame_stats(self) -> FrameStats:
         st = FrameStats()

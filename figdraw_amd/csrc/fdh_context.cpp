@@ -53,6 +53,7 @@ Context::~Context() {
   (void)hipSetDevice(device_);
   if (stream_) (void)hipStreamSynchronize(stream_);
   for (auto& e : ev_) if (e) (void)hipEventDestroy(e);
+  for (auto& e : ev_pool_) (void)hipEventDestroy(e);
   for (auto& l : atlas_levels_) if (l) (void)hipFree(l);
   if (fb_) (void)hipFree(fb_);
   if (backdrop_) (void)hipFree(backdrop_);
@@ -680,12 +681,16 @@ void Context::submit(bool upload) {
   }
   // algorithmic bytes of this frame: final store + per blur (pre-blur store is the store above for
   // a full-frame node; H read + H write + V read + V write + composite read) + records once
-  int64_t bytes = 4LL * W_ * H_ + (int64_t)n * (int64_t)sizeof(DrawRec);
+  int64_t bytes = 4LL * W_ * H_ + (int64_t)n * (int64_t)sizeof(DrawRec), bytes_blur = 0;
   for (auto& j : blurs_) {
     const int ylo = std::max(0, j.y0 - j.taps.reach), yhi = std::min(H_, j.y1 + j.taps.reach);
     const int64_t a_h = (int64_t)(j.x1 - j.x0) * (yhi - ylo), a_v = (int64_t)(j.x1 - j.x0) * (j.y1 - j.y0);
-    bytes += 4 * a_h + 4 * a_h + 4 * a_h + 4 * a_v + 4 * a_v;
+    bytes_blur += 4 * a_h + 4 * a_h + 4 * a_h + 4 * a_v;  // H read, H write, V read, V write
+    bytes += 4 * a_v;                                     // the composite's read of the blurred footprint
   }
+  bytes += bytes_blur;
+  stats_.bytes_blur = bytes_blur;
+  stats_.bytes_composite_main = 4LL * W_ * H_ * (clear_ ? 1 : 2) + (int64_t)phases_[0].count * (int64_t)sizeof(DrawRec);
   stats_.n_draws = (int32_t)n;
   stats_.n_phases = (int32_t)phases_.size();
   stats_.n_blurs = (int32_t)blurs_.size();
@@ -713,12 +718,14 @@ void Context::launch_frame(bool profile) {
       }
     }
   }
-  if (profile) FDH_HIP(hipEventRecord(ev_[2], stream_));
+  auto span_begin = [&](int kind) { if (profile) { Span sp{kind, next_event(), next_event()}; FDH_HIP(hipEventRecord(sp.a, stream_)); spans_.push_back(sp); } };
+  auto span_end = [&]() { if (profile) FDH_HIP(hipEventRecord(spans_.back().b, stream_)); };
+  span_begin(0);
   BinParams B;
   B.bbox = d_bboxes_.ptr; B.lists = d_lists_.ptr; B.counts = d_counts_.ptr; B.phase_first = d_phase_first_.ptr;
   B.n_phases = np; B.bins_x = bins_x_; B.bins_y = bins_y_; B.stride = list_stride_;
   launch_bin(stream_, B);
-  if (profile) FDH_HIP(hipEventRecord(ev_[3], stream_));
+  span_end();
   for (int p = 0; p < np; p++) {
     const Phase& ph = phases_[p];
     if (ph.blur >= 0) {
@@ -731,12 +738,14 @@ void Context::launch_frame(bool profile) {
         bp.taps = j.taps;
         bp.src = fb_; bp.dst = blur_tmp_;
         bp.x0 = j.x0; bp.x1 = j.x1; bp.y0 = std::max(0, vy0 - j.taps.reach); bp.y1 = std::min(H_, vy1 + j.taps.reach);
-        if (profile) FDH_HIP(hipEventRecord(ev_[6], stream_));
+        span_begin(3);
         launch_blur_h(stream_, bp);
+        span_end();
         bp.src = blur_tmp_; bp.dst = backdrop_;
         bp.y0 = vy0; bp.y1 = vy1;
+        span_begin(4);
         launch_blur_v(stream_, bp);
-        if (profile) FDH_HIP(hipEventRecord(ev_[7], stream_));
+        span_end();
       }
     }
     CompositeParams C;
@@ -755,9 +764,9 @@ void Context::launch_frame(bool profile) {
     C.load_fb = full ? 0 : 1;
     C.clear_rgba8 = clear_rgba8_;
     C.n_wg = 0;
-    if (profile && p == 0) FDH_HIP(hipEventRecord(ev_[4], stream_));
+    span_begin(p == 0 ? 1 : 2);
     launch_composite(stream_, d_recs_.ptr, d_bboxes_.ptr, d_exts_.ptr, C);
-    if (profile && p == 0) FDH_HIP(hipEventRecord(ev_[5], stream_));
+    span_end();
   }
   FDH_HIP(hipGetLastError());
 }
@@ -773,18 +782,39 @@ void Context::replay(int times) {
   float ms = 0.0f;
   FDH_HIP(hipEventElapsedTime(&ms, ev_[0], ev_[1]));
   stats_.ms_total = ms / (float)times;
-  // one more, instrumented frame for the per-kernel split (events between launches perturb the total slightly,
-  // so it is never part of ms_total)
-  launch_frame(true);
-  FDH_HIP(hipStreamSynchronize(stream_));
-  float t = 0.0f;
-  FDH_HIP(hipEventElapsedTime(&t, ev_[2], ev_[3])); stats_.ms_bin = t;
-  FDH_HIP(hipEventElapsedTime(&t, ev_[4], ev_[5])); stats_.ms_composite = t;
-  stats_.ms_blur = 0.0f;
-  if (!blurs_.empty()) {
-    // ev_[6]/ev_[7] bracket the LAST blur of the frame; good enough for the split, bench.py times kernels itself
-    if (hipEventElapsedTime(&t, ev_[6], ev_[7]) == hipSuccess) stats_.ms_blur = t;
+}
+
+hipEvent_t Context::next_event() {
+  if (ev_used_ == ev_pool_.size()) {
+    hipEvent_t e;
+    FDH_HIP(hipEventCreate(&e));
+    ev_pool_.push_back(e);
   }
+  return ev_pool_[ev_used_++];
+}
+
+// Per-kernel timing: events bracket every launch, so this is kept apart from replay()'s batch timing.
+void Context::profile(int times) {
+  if (!have_frame_) throw Error(FDH_ERR_INVALID, "profile: no frame has been submitted");
+  FDH_HIP(hipSetDevice(device_));
+  if (times <= 0) return;
+  double acc[5] = {0, 0, 0, 0, 0};
+  for (int i = 0; i < times; i++) {
+    ev_used_ = 0;
+    spans_.clear();
+    launch_frame(true);
+    FDH_HIP(hipStreamSynchronize(stream_));
+    for (auto& sp : spans_) {
+      float t = 0.0f;
+      FDH_HIP(hipEventElapsedTime(&t, sp.a, sp.b));
+      acc[sp.kind] += t;
+    }
+  }
+  stats_.ms_bin = (float)(acc[0] / times);
+  stats_.ms_composite_main = (float)(acc[1] / times);
+  stats_.ms_composite = (float)((acc[1] + acc[2]) / times);
+  stats_.ms_blur_h = (float)(acc[3] / times);
+  stats_.ms_blur_v = (float)(acc[4] / times);
 }
 
 // ------------------------------------------------------------------ readback (glcontext.nim:2094-2135)

@@ -138,6 +138,7 @@ class Context {
   // multi-GPU / measurement
   void set_stripe(int y0, int y1) { stripe_y0_ = y0; stripe_y1_ = y1; }
   void replay(int times);
+  void profile(int times);
   void frame_stats(FdhFrameStats* out) const { *out = stats_; }
 
  private:
@@ -149,12 +150,17 @@ class Context {
   void find_empty_rect(int w, int h, int* ox, int* oy);
   void submit(bool upload);
   void launch_frame(bool profile);
+  hipEvent_t next_event();
   void ensure_surfaces();
 
   int device_ = 0;
   uint32_t flags_ = 0;
   hipStream_t own_stream_ = nullptr, stream_ = nullptr;
-  hipEvent_t ev_[10] = {};
+  hipEvent_t ev_[2] = {};
+  std::vector<hipEvent_t> ev_pool_;
+  size_t ev_used_ = 0;
+  struct Span { int kind; hipEvent_t a, b; };  // kind: 0 bin, 1 composite main, 2 composite later, 3 blur h, 4 blur v
+  std::vector<Span> spans_;
 
   // frame state
   int W_ = 0, H_ = 0;

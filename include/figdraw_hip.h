@@ -204,13 +204,19 @@ FDH_API int fdh_set_stripe(FdhContext*, int y0, int y1);
 FDH_API int fdh_replay(FdhContext*, int times);
 typedef struct {
   int32_t n_draws, n_phases, n_blurs, n_bins;
-  float ms_total;      /* hipEvent time of the last submit/replay batch, all kernels, per frame */
-  float ms_bin;        /* binning kernel, per frame */
-  float ms_composite;  /* composite kernel(s), per frame */
-  float ms_blur;       /* blur H+V kernels, per frame */
+  float ms_total;          /* fdh_replay: hipEvent time per frame over the whole batch (no per-kernel events in it) */
+  float ms_bin;            /* fdh_profile: binning kernel, per frame */
+  float ms_composite;      /* fdh_profile: all composite launches of a frame */
+  float ms_composite_main; /* fdh_profile: the phase-0 composite launch (the dominant kernel) */
+  float ms_blur_h;         /* fdh_profile: all horizontal blur launches of a frame */
+  float ms_blur_v;         /* fdh_profile: all vertical blur launches of a frame */
   int64_t bytes_algorithmic; /* SURVEY.md 8(d) B_frame for the last frame */
+  int64_t bytes_composite_main; /* algorithmic bytes of the phase-0 composite launch: surface store (+load) + records */
+  int64_t bytes_blur;        /* algorithmic bytes of all blur launches: H read + H write + V read + V write */
   int64_t fragments;         /* sum of covered fragments over all draws (GL-equivalent work unit) */
 } FdhFrameStats;
+/* Run `times` more frames with hipEvents around every kernel launch and fill the per-kernel averages. */
+FDH_API int fdh_profile(FdhContext*, int times);
 FDH_API int fdh_get_frame_stats(FdhContext*, FdhFrameStats* out);
 FDH_API int fdh_sizeof_fig(void);
 FDH_API int fdh_sizeof_glyph(void);
