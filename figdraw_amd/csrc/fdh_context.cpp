@@ -597,6 +597,7 @@ static BlurTaps make_taps(float blur_radius) {
     add((int)fl + 1, w[i + 8] * a * inv);
   }
   for (int k = 0; k < t.n; k++) t.reach = std::max(t.reach, std::abs(t.off[k]));
+  for (int k = 0; k < t.n; k++) t.dense[3 + t.reach + t.off[k]] = t.coef[k];
   return t;
 }
 
@@ -624,9 +625,15 @@ void Context::draw_backdrop_blur(const float rect[4], const float rx[4], const f
     open_ops_[i] = (uint32_t)recs_.size();
     push_rec(reopen[i], BBox{0, 0, 0, 0});
   }
+  const bool fuse = open_ops_.empty();  // no clip state to carry: the V pass can composite the quad itself
   emit_quad(r, rect[0], rect[1], rect[0] + rect[2], rect[1] + rect[3], &fragments_);
   const BBox fb = bboxes_.back();
   BlurJob job;
+  job.fuse_draw = -1;
+  if (fuse) {
+    job.fuse_draw = (int)recs_.size() - 1;
+    bboxes_.back() = BBox{0, 0, 0, 0};  // never binned: k_blur_v blends it
+  }
   job.radius = blur_radius;
   job.x0 = fb.x0; job.y0 = fb.y0; job.x1 = fb.x1; job.y1 = fb.y1;
   job.taps = make_taps(blur_radius);
@@ -736,15 +743,17 @@ void Context::launch_frame(bool profile) {
         BlurParams bp;
         bp.W = W_; bp.H = H_; bp.pitch = W_;
         bp.taps = j.taps;
+        bp.fuse_draw = -1;
         bp.src = fb_; bp.dst = blur_tmp_;
         bp.x0 = j.x0; bp.x1 = j.x1; bp.y0 = std::max(0, vy0 - j.taps.reach); bp.y1 = std::min(H_, vy1 + j.taps.reach);
         span_begin(3);
         launch_blur_h(stream_, bp);
         span_end();
-        bp.src = blur_tmp_; bp.dst = backdrop_;
+        bp.src = blur_tmp_; bp.dst = j.fuse_draw >= 0 ? fb_ : backdrop_;
+        bp.fuse_draw = j.fuse_draw;
         bp.y0 = vy0; bp.y1 = vy1;
         span_begin(4);
-        launch_blur_v(stream_, bp);
+        launch_blur_v(stream_, bp, d_recs_.ptr, d_exts_.ptr);
         span_end();
       }
     }

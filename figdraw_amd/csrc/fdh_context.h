@@ -75,6 +75,7 @@ struct Phase {
 struct BlurJob {
   float radius;
   int x0, y0, x1, y1;  // footprint: the mode-17 quad's pixel bounds
+  int fuse_draw;       // record index of the consuming mode-17 quad when k_blur_v composites it, else -1
   BlurTaps taps;
 };
 

@@ -34,13 +34,16 @@ struct BlurParams {
   uint32_t* dst;
   int W, H, pitch;
   int x0, y0, x1, y1;  // output region
+  // V pass only: when fuse_draw >= 0 the mode-17 quad that consumes this blur is composited straight into
+  // `dst` (the live surface) instead of writing the blurred snapshot out and reading it back
+  int fuse_draw;
   BlurTaps taps;
 };
 
 void launch_bin(hipStream_t s, const BinParams& P);
 void launch_composite(hipStream_t s, const DrawRec* draws, const BBox* bboxes, const QuadExt* exts, CompositeParams P);
 void launch_blur_h(hipStream_t s, const BlurParams& P);
-void launch_blur_v(hipStream_t s, const BlurParams& P);
+void launch_blur_v(hipStream_t s, const BlurParams& P, const DrawRec* draws, const QuadExt* exts);
 void launch_fill(hipStream_t s, uint32_t* p, uint32_t v, size_t n);
 
 }  // namespace fdh

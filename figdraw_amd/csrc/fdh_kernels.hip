@@ -293,6 +293,16 @@ __device__ __forceinline__ float rect_mask_alpha(const DrawRec& r, float cx, flo
   return 1.0f - clamp01(r.aa * dist + 0.5f);
 }
 
+// Wave-uniform record fetch: 8 x 16-byte scalar loads issued together so one s_waitcnt covers them all.
+__device__ __forceinline__ DrawRec load_rec(const DrawRec* __restrict__ p) {
+  DrawRec r;
+  const uint4* __restrict__ src = reinterpret_cast<const uint4*>(p);
+  uint4* dst = reinterpret_cast<uint4*>(&r);
+#pragma unroll
+  for (int i = 0; i < 8; i++) dst[i] = src[i];
+  return r;
+}
+
 __global__ __launch_bounds__(256) void k_composite_tiles(const DrawRec* __restrict__ draws, const BBox* __restrict__ bboxes,
                                                          const QuadExt* __restrict__ exts, CompositeParams P) {
   __shared__ float mask_stack[kWavesPerWg][kMaskDepth][64];
@@ -345,7 +355,8 @@ __global__ __launch_bounds__(256) void k_composite_tiles(const DrawRec* __restri
       const int bsel = __builtin_ctzll(m);
       m &= m - 1;
       const uint32_t d = __builtin_amdgcn_readlane(idx, bsel);
-      const DrawRec& r = draws[d];
+      // the whole 128-byte record in one go (two s_load_dwordx16 into SGPRs), not field by field inside the branches
+      const DrawRec r = load_rec(draws + d);
       const uint32_t om = r.op_mode;
       const uint32_t op = (om >> 12) & 15u;
       const uint32_t mode = om & 255u;
@@ -440,42 +451,88 @@ __global__ __launch_bounds__(256) void k_composite_tiles(const DrawRec* __restri
 }
 
 // ------------------------------------------------------------------ blur (blur.frag:11-32 as a merged FIR)
+// blur.frag takes 17 bilinear taps at i*step px.  The step is constant, so tap i has the same bilinear fraction at
+// every pixel and the pass is a fixed FIR over integer offsets (BlurTaps, built on the host).  Each thread produces
+// FOUR consecutive outputs along the filter direction: every staged texel is unpacked once (4 x v_cvt_f32_ubyte)
+// and feeds up to four accumulators with packed FMAs, instead of being re-read and re-unpacked per tap.
+typedef float f2 __attribute__((ext_vector_type(2)));
 
-constexpr int kBlurHW = 256;  // horizontal pass: one workgroup = 256 consecutive pixels of one row
-__global__ __launch_bounds__(256) void k_blur_h(BlurParams P) {
-  __shared__ uint32_t line[kBlurHW + 2 * 66];
-  const int y = P.y0 + blockIdx.y;
-  const int xs = P.x0 + blockIdx.x * kBlurHW;
-  const int reach = P.taps.reach;
-  const uint32_t* __restrict__ row = P.src + (size_t)y * P.pitch;
-  for (int i = threadIdx.x; i < kBlurHW + 2 * reach; i += 256) {
-    int x = xs - reach + i;
-    x = x < 0 ? 0 : (x > P.W - 1 ? P.W - 1 : x);  // clamp-to-edge (glcontext.nim:214-215)
-    line[i] = row[x];
-  }
-  __syncthreads();
-  const int x = xs + threadIdx.x;
-  if (x >= P.x1) return;
-  float ar = 0.f, ag = 0.f, ab = 0.f, aa = 0.f;
-  const int n = P.taps.n;
-  for (int k = 0; k < n; k++) {
-    F4 t = unpack255(line[threadIdx.x + reach + P.taps.off[k]]);
-    const float c = P.taps.coef[k];
-    ar += t.x * c; ag += t.y * c; ab += t.z * c; aa += t.w * c;
-  }
-  F4 o = {__builtin_rintf(ar), __builtin_rintf(ag), __builtin_rintf(ab), __builtin_rintf(aa)};
-  P.dst[(size_t)y * P.pitch + x] = pack255(o);
+__device__ __forceinline__ void unpack2(uint32_t c, f2& rg, f2& ba) {
+  rg.x = (float)(c & 255u);
+  rg.y = (float)((c >> 8) & 255u);
+  ba.x = (float)((c >> 16) & 255u);
+  ba.y = (float)(c >> 24);
+}
+__device__ __forceinline__ uint32_t pack2(f2 rg, f2 ba) {
+  return (uint32_t)__builtin_rintf(rg.x) | ((uint32_t)__builtin_rintf(rg.y) << 8) | ((uint32_t)__builtin_rintf(ba.x) << 16) |
+         ((uint32_t)__builtin_rintf(ba.y) << 24);
 }
 
-constexpr int kBlurVW = 64, kBlurVH = 32;  // vertical pass: one workgroup = 64 columns x 32 rows
-__global__ __launch_bounds__(256) void k_blur_v(BlurParams P) {
-  extern __shared__ uint32_t tile[];  // (kBlurVH + 2*reach) rows x 64 columns
+constexpr int kBlurHW = 256;  // horizontal pass: one wave = 256 consecutive pixels of one row (4 per lane), 4 rows per workgroup
+constexpr int kBlurHLine = kBlurHW + 2 * kMaxBlurReach + 4;
+__global__ __launch_bounds__(256) void k_blur_h(BlurParams P) {
+  __shared__ __attribute__((aligned(16))) uint32_t lines[4][kBlurHLine];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int y = P.y0 + blockIdx.y * 4 + wave;
+  const int xs = P.x0 + blockIdx.x * kBlurHW;
+  const int reach = P.taps.reach;
+  const int span = kBlurHW + 2 * reach;
+  uint32_t* line = lines[wave];
+  if (y < P.y1) {
+    const uint32_t* __restrict__ row = P.src + (size_t)y * P.pitch;
+    for (int i = lane; i < span + 4; i += 64) {
+      int x = xs - reach + i;
+      x = x < 0 ? 0 : (x > P.W - 1 ? P.W - 1 : x);  // clamp-to-edge (glcontext.nim:214-215)
+      line[i] = row[x];
+    }
+  }
+  __syncthreads();
+  const int x = xs + lane * 4;
+  if (y >= P.y1 || x >= P.x1) return;
+  f2 rg[4], ba[4];
+#pragma unroll
+  for (int p = 0; p < 4; p++) { rg[p] = 0.0f; ba[p] = 0.0f; }
+  const float* __restrict__ d = P.taps.dense;  // d[3 + reach + off]
+  const int nwin = 4 + 2 * reach;              // window texels: outputs p..p+2*reach for p = 0..3
+  const uint4* __restrict__ win = reinterpret_cast<const uint4*>(line + lane * 4);
+  for (int jj = 0; jj < nwin; jj += 4) {
+    const uint4 q = win[jj >> 2];
+    const uint32_t tx[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+      f2 trg, tba;
+      unpack2(tx[s], trg, tba);
+      const int j = jj + s;  // window index: output p sees it at offset j - p - reach -> dense index j - p + 3
+#pragma unroll
+      for (int p = 0; p < 4; p++) {
+        const float c = d[j - p + 3];
+        rg[p] += trg * c;
+        ba[p] += tba * c;
+      }
+    }
+  }
+  uint4 o = {pack2(rg[0], ba[0]), pack2(rg[1], ba[1]), pack2(rg[2], ba[2]), pack2(rg[3], ba[3])};
+  uint32_t* out = P.dst + (size_t)y * P.pitch + x;
+  if (x + 3 < P.x1 && ((reinterpret_cast<uintptr_t>(out) & 15) == 0)) {
+    *reinterpret_cast<uint4*>(out) = o;
+  } else {
+    const uint32_t ov[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+    for (int p = 0; p < 4; p++) if (x + p < P.x1) out[p] = ov[p];
+  }
+}
+
+// vertical pass: one workgroup = 64 columns x 32 rows; a lane owns a column, each wave produces 8 rows as two
+// groups of 4 consecutive outputs.  With fuse_draw >= 0 the consuming mode-17 quad is blended in place.
+constexpr int kBlurVW = 64, kBlurVH = 32;
+__global__ __launch_bounds__(256) void k_blur_v(BlurParams P, const DrawRec* __restrict__ draws, const QuadExt* __restrict__ exts) {
+  extern __shared__ uint32_t tile[];  // (kBlurVH + 2*reach + 4) rows x 64 columns
   const int xs = P.x0 + blockIdx.x * kBlurVW;
   const int ys = P.y0 + blockIdx.y * kBlurVH;
   const int reach = P.taps.reach;
   const int rows = kBlurVH + 2 * reach;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  int x = xs + lane;
+  const int x = xs + lane;
   const int xc = x > P.W - 1 ? P.W - 1 : x;
   for (int rr = wave; rr < rows; rr += 4) {
     int y = ys - reach + rr;
@@ -484,20 +541,48 @@ __global__ __launch_bounds__(256) void k_blur_v(BlurParams P) {
   }
   __syncthreads();
   if (x >= P.x1) return;
-  const int n = P.taps.n;
+  const float* __restrict__ d = P.taps.dense;
+  const int nwin = 4 + 2 * reach;
 #pragma unroll 1
-  for (int q = 0; q < kBlurVH / 4; q++) {
-    const int ry = wave * (kBlurVH / 4) + q;
+  for (int g = 0; g < 2; g++) {
+    const int ry = wave * 8 + g * 4;  // first of the four output rows, relative to ys
     const int y = ys + ry;
     if (y >= P.y1) break;
-    float ar = 0.f, ag = 0.f, ab = 0.f, aa = 0.f;
-    for (int k = 0; k < n; k++) {
-      F4 t = unpack255(tile[(ry + reach + P.taps.off[k]) * kBlurVW + lane]);
-      const float c = P.taps.coef[k];
-      ar += t.x * c; ag += t.y * c; ab += t.z * c; aa += t.w * c;
+    f2 rg[4], ba[4];
+#pragma unroll
+    for (int p = 0; p < 4; p++) { rg[p] = 0.0f; ba[p] = 0.0f; }
+    const uint32_t* __restrict__ col = tile + ry * kBlurVW + lane;  // window row j is tile row ry + j
+    for (int j = 0; j < nwin; j++) {
+      f2 trg, tba;
+      unpack2(col[j * kBlurVW], trg, tba);
+#pragma unroll
+      for (int p = 0; p < 4; p++) {
+        const float c = d[j - p + 3];
+        rg[p] += trg * c;
+        ba[p] += tba * c;
+      }
     }
-    F4 o = {__builtin_rintf(ar), __builtin_rintf(ag), __builtin_rintf(ab), __builtin_rintf(aa)};
-    P.dst[(size_t)y * P.pitch + x] = pack255(o);
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+      if (y + p >= P.y1) break;
+      const size_t pix = (size_t)(y + p) * P.pitch + x;
+      F4 b = {__builtin_rintf(rg[p].x), __builtin_rintf(rg[p].y), __builtin_rintf(ba[p].x), __builtin_rintf(ba[p].y)};
+      if (P.fuse_draw < 0) {
+        P.dst[pix] = pack255(b);
+      } else {
+        // atlas.frag:381-388 on the blurred texel just produced, blended over the live surface (first draw of the phase)
+        const DrawRec r = load_rec(draws + P.fuse_draw);
+        const Frag f = make_frag(r, exts, x, y + p);
+        if (!f.covered) continue;
+        const float lx = (f.u - 0.5f) * 2.0f * r.p0, ly = (f.v - 0.5f) * 2.0f * r.p1;
+        const float dist = shape_dist((r.op_mode & F_ELLIP) != 0u, lx, -ly, r.p2, r.p3, r.r[0], r.r[1], r.r[2], r.r[3]);
+        const float alpha = 1.0f - clamp01(r.aa * dist + 0.5f);
+        const float k = 1.0f / 255.0f;
+        F4 F = unpack255(P.dst[pix]);
+        blend(F, b.x * k, b.y * k, b.z * k, b.w * k * alpha);
+        P.dst[pix] = pack255(F);
+      }
+    }
   }
 }
 
@@ -521,14 +606,14 @@ void launch_composite(hipStream_t s, const DrawRec* draws, const BBox* bboxes, c
 }
 void launch_blur_h(hipStream_t s, const BlurParams& P) {
   if (P.x1 <= P.x0 || P.y1 <= P.y0) return;
-  dim3 grid((P.x1 - P.x0 + kBlurHW - 1) / kBlurHW, P.y1 - P.y0);
+  dim3 grid((P.x1 - P.x0 + kBlurHW - 1) / kBlurHW, (P.y1 - P.y0 + 3) / 4);
   hipLaunchKernelGGL(k_blur_h, grid, dim3(256), 0, s, P);
 }
-void launch_blur_v(hipStream_t s, const BlurParams& P) {
+void launch_blur_v(hipStream_t s, const BlurParams& P, const DrawRec* draws, const QuadExt* exts) {
   if (P.x1 <= P.x0 || P.y1 <= P.y0) return;
   dim3 grid((P.x1 - P.x0 + kBlurVW - 1) / kBlurVW, (P.y1 - P.y0 + kBlurVH - 1) / kBlurVH);
   const size_t lds = (size_t)(kBlurVH + 2 * P.taps.reach) * kBlurVW * sizeof(uint32_t);
-  hipLaunchKernelGGL(k_blur_v, grid, dim3(256), lds, s, P);
+  hipLaunchKernelGGL(k_blur_v, grid, dim3(256), lds, s, P, draws, exts);
 }
 void launch_fill(hipStream_t s, uint32_t* p, uint32_t v, size_t n) {
   if (n == 0) return;
