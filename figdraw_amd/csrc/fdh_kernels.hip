@@ -250,30 +250,6 @@ __device__ __forceinline__ Frag make_frag(const DrawRec& r, const QuadExt* __res
   return f;
 }
 
-// evalFillColor atlas.frag:233-250
-__device__ __forceinline__ F4 eval_fill(const DrawRec& r, const Frag& f, uint32_t fill_mode) {
-  if (fill_mode == 0u) return f.col;
-  float t;
-  switch (fill_mode) {
-    case 1u: t = f.u; break;
-    case 2u: t = f.v; break;
-    case 3u: t = 0.5f * (f.u + f.v); break;
-    default: t = 0.5f * (f.u + (1.0f - f.v)); break;
-  }
-  t = clamp01(t);
-  const float mid = __builtin_fminf(__builtin_fmaxf(r.f1, 0.01f), 0.99f);
-  const float k = 1.0f / 255.0f;
-  F4 m = unpack255(r.mid), s = unpack255(r.stop), o;
-  if (t <= mid) {
-    float w = t * frcp(mid);
-    o.x = mixf(f.col.x, m.x * k, w); o.y = mixf(f.col.y, m.y * k, w); o.z = mixf(f.col.z, m.z * k, w); o.w = mixf(f.col.w, m.w * k, w);
-  } else {
-    float w = (t - mid) * frcp(1.0f - mid);
-    o.x = mixf(m.x * k, s.x * k, w); o.y = mixf(m.y * k, s.y * k, w); o.z = mixf(m.z * k, s.z * k, w); o.w = mixf(m.w * k, s.w * k, w);
-  }
-  return o;
-}
-
 // fixed-function blend SRC_ALPHA/ONE_MINUS_SRC_ALPHA (rgb), ONE/ONE_MINUS_SRC_ALPHA (alpha), then the RGBA8
 // store (utils/glutils.nim:150-154).  F holds the framebuffer texel as 0..255 integers in floats.
 __device__ __forceinline__ void blend(F4& F, float r, float g, float b, float sa) {
@@ -303,15 +279,193 @@ __device__ __forceinline__ DrawRec load_rec(const DrawRec* __restrict__ p) {
   return r;
 }
 
-__global__ __launch_bounds__(256) void k_composite_tiles(const DrawRec* __restrict__ draws, const BBox* __restrict__ bboxes,
+// ---- branch-free shape distance: no per-lane exec juggling (divergent control flow is paid in
+// s_and_saveexec/s_or sequences on the CU's single scalar unit).  The two-sqrt ellipse evaluation is skipped with
+// ONE wave-uniform branch when no lane of the wave sits in an elliptical corner region.
+struct Corner { float rx, ry; bool same; };
+__device__ __forceinline__ Corner pick_corner(bool ellip, float px, float py, float bx, float by, float r0, float r1, float r2, float r3) {
+  const float sel = (px > 0.0f) ? ((py > 0.0f) ? r0 : r1) : ((py > 0.0f) ? r2 : r3);
+  Corner c;
+  if (!ellip) { c.rx = sel; c.ry = sel; c.same = true; return c; }  // wave-uniform
+  // decodeEllipticalCornerRadii atlas.frag:88-94; negative = circular corner of radius -v-1 (:98-100)
+  const float pv = __builtin_floorf(sel + 0.5f);
+  const float hi = __builtin_floorf(pv * (1.0f / 4096.0f));
+  float rx = (pv - 4096.0f * hi) * bx * (1.0f / 4095.0f);
+  float ry = hi * by * (1.0f / 4095.0f);
+  const bool circle = sel < 0.0f;
+  const float rc = -sel - 1.0f;
+  rx = circle ? rc : rx;
+  ry = circle ? rc : ry;
+  const bool zero = rx <= 0.0f || ry <= 0.0f;  // :102-105 -> plain box, i.e. the rounded-box formula with r = 0
+  c.rx = zero ? 0.0f : rx;
+  c.ry = zero ? 0.0f : ry;
+  c.same = c.rx == c.ry;
+  return c;
+}
+__device__ __forceinline__ float sd_ellipse_nb(float px, float py, float rx, float ry) {  // atlas.frag:71-79 without branches
+  const float sx = __builtin_fmaxf(rx, 0.000001f), sy = __builtin_fmaxf(ry, 0.000001f);
+  const float isx = frcp(sx), isy = frcp(sy);
+  const float ax = px * isx, ay = py * isy;
+  const float k0 = fsqrt(ax * ax + ay * ay);
+  const float bx = ax * isx, by = ay * isy;
+  const float k1 = fsqrt(bx * bx + by * by);
+  const float d = k0 * (k0 - 1.0f) * frcp(__builtin_fmaxf(k1, 0.000001f));
+  return k0 <= 0.000001f ? -__builtin_fminf(sx, sy) : d;
+}
+// distance of 4 pixels of one row at once (sdRoundedBox :51-69 / sdEllipticalRoundedBox :96-115)
+__device__ __forceinline__ void shape_dist4(bool ellip, const float px[4], float py, float bx, float by, float r0, float r1, float r2,
+                                            float r3, float out[4]) {
+  Corner c[4];
+  float qx[4], qy[4];
+  bool need = false;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    c[k] = pick_corner(ellip, px[k], py, bx, by, r0, r1, r2, r3);
+    qx[k] = __builtin_fabsf(px[k]) - bx + c[k].rx;
+    qy[k] = __builtin_fabsf(py) - by + c[k].ry;
+    const float mx = __builtin_fmaxf(qx[k], 0.0f), my = __builtin_fmaxf(qy[k], 0.0f);
+    out[k] = __builtin_fminf(__builtin_fmaxf(qx[k], qy[k]), 0.0f) + fsqrt(mx * mx + my * my) - c[k].rx;
+    need = need || (!c[k].same && qx[k] > 0.0f && qy[k] > 0.0f);
+  }
+  if (!ellip) return;  // wave-uniform
+  const bool any_ellipse = __any(need);
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const bool corner = qx[k] > 0.0f && qy[k] > 0.0f;
+    float de = __builtin_fmaxf(qx[k] - c[k].rx, qy[k] - c[k].ry);
+    if (any_ellipse) {  // wave-uniform
+      const float e = sd_ellipse_nb(qx[k], qy[k], c[k].rx, c[k].ry);
+      de = corner ? e : de;
+    }
+    out[k] = c[k].same ? out[k] : de;
+  }
+}
+
+// evalFillColor atlas.frag:233-250, select-based.  Everything is passed BY VALUE: `c ? a.x : b.x` on lvalues is an
+// lvalue conditional (pointer select, then a load), which pins arrays of F4 in scratch.
+__device__ __forceinline__ float selectf(bool c, float a, float b) { return c ? a : b; }
+__device__ __forceinline__ F4 eval_fill_nb(F4 col, F4 m, F4 s, uint32_t fill_mode, float mid, float u, float v) {
+  float t;
+  switch (fill_mode) {  // wave-uniform
+    case 1u: t = u; break;
+    case 2u: t = v; break;
+    case 3u: t = 0.5f * (u + v); break;
+    default: t = 0.5f * (u + (1.0f - v)); break;
+  }
+  t = clamp01(t);
+  const bool lo = t <= mid;
+  const float w = selectf(lo, t * frcp(mid), (t - mid) * frcp(1.0f - mid));
+  F4 o;
+  o.x = mixf(selectf(lo, col.x, m.x), selectf(lo, m.x, s.x), w);
+  o.y = mixf(selectf(lo, col.y, m.y), selectf(lo, m.y, s.y), w);
+  o.z = mixf(selectf(lo, col.z, m.z), selectf(lo, m.z, s.z), w);
+  o.w = mixf(selectf(lo, col.w, m.w), selectf(lo, m.w, s.w), w);
+  return o;
+}
+
+__device__ __forceinline__ F4 eval_fill_rec(const DrawRec& r, F4 col, uint32_t fill_mode, float u, float v) {
+  if (fill_mode == 0u) return col;
+  const float k = 1.0f / 255.0f;
+  const F4 mc = unpack255(r.mid), sc = unpack255(r.stop);
+  const F4 m01 = {mc.x * k, mc.y * k, mc.z * k, mc.w * k}, s01 = {sc.x * k, sc.y * k, sc.z * k, sc.w * k};
+  return eval_fill_nb(col, m01, s01, fill_mode, __builtin_fminf(__builtin_fmaxf(r.f1, 0.01f), 0.99f), u, v);
+}
+
+// ---- generic one-pixel shading (atlas / MSDF sampling, rotated or skewed quads, rect-mask setup): the rare draws.
+// Reads the record through the global pointer (dynamic field selection must not force a local copy into scratch).
+struct Src { float r, g, b, a; bool covered; };
+__device__ __forceinline__ Src shade_one(const DrawRec* __restrict__ rp, const QuadExt* __restrict__ exts, const AtlasView* __restrict__ atlas,
+                                      const uint32_t* __restrict__ backdrop, size_t pix, bool in_frame, int px, int py, F4 F) {
+  const DrawRec& r = *rp;
+  const uint32_t om = r.op_mode;
+  const uint32_t mode = om & 255u;
+  const bool ellip = (om & F_ELLIP) != 0u;
+  const uint32_t fill_mode = (om >> 9) & 7u;
+  const Frag f = make_frag(r, exts, px, py);
+  Src s;
+  s.covered = f.covered;
+  if (((om >> 12) & 15u) == OP_MASK_PUSH) {  // mask.frag:186-234: returns the shape alpha (x colour alpha) in .a
+    const float lx = (f.u - 0.5f) * 2.0f * r.p0, ly = (f.v - 0.5f) * 2.0f * r.p1;
+    const float dist = shape_dist(ellip, lx, -ly, r.p2, r.p3, r.r[0], r.r[1], r.r[2], r.r[3]);
+    s.r = s.g = s.b = 0.0f;
+    s.a = (1.0f - clamp01(r.aa * dist + 0.5f)) * f.col.w;
+    return s;
+  }
+  if (mode == 0u) {  // atlas.frag:284-295
+    float u = f.u;
+    if (om & F_SUBPIXEL) u -= r.aux * frcp(__builtin_fmaxf((float)atlas->size, 1.0f));
+    const F4 t = atlas_sample(*atlas, u, f.v, f.lod);
+    s.r = t.x * f.col.x; s.g = t.y * f.col.y; s.b = t.z * f.col.z; s.a = t.w * f.col.w;
+    return s;
+  }
+  if (mode >= 13u && mode <= 16u) {  // atlas.frag:296-318
+    const F4 fc = eval_fill_rec(r, f.col, fill_mode, f.u, f.v);
+    const F4 t = atlas_sample(*atlas, f.u, f.v, 0.0f);  // textureLod(atlasTex, uv, 0.0)
+    const bool is_mtsdf = (mode == 14u || mode == 16u), is_stroke = (mode == 15u || mode == 16u);
+    const float sd = is_mtsdf ? t.w : median3(t.x, t.y, t.z);
+    const float unit = r.f0 * frcp(r.p0);  // pxRange / atlas size (atlas.frag:45-49)
+    const float spr = __builtin_fmaxf(0.5f * (unit * frcp(f.fw_u) + unit * frcp(f.fw_v)), 1.0f);
+    const float spd = spr * (sd - r.f1);
+    const float alpha = is_stroke ? clamp01(__builtin_fmaxf(r.p1, 0.0f) * 0.5f - __builtin_fabsf(spd) + 0.5f) : clamp01(spd + 0.5f);
+    s.r = fc.x; s.g = fc.y; s.b = fc.z; s.a = fc.w * alpha;
+    return s;
+  }
+  const float qhx = r.p0, qhy = r.p1;
+  const bool inset = mode == 9u;
+  const float shx = inset ? qhx : r.p2, shy = inset ? qhy : r.p3;
+  const float lx = (f.u - 0.5f) * 2.0f * qhx, ly = (f.v - 0.5f) * 2.0f * qhy;
+  const float dist = shape_dist(ellip, lx, -ly, shx, shy, r.r[0], r.r[1], r.r[2], r.r[3]);
+  const float spread = fill_mode == 0u ? r.f1 : 0.0f;
+  float alpha;
+  switch (mode) {
+    case 11u: { float h = r.f0 * 0.5f; float sd = __builtin_fabsf(dist + h) - h; alpha = sd < 0.0f ? 1.0f : 0.0f; break; }
+    case 12u: { float h = r.f0 * 0.5f; float sd = __builtin_fabsf(dist + h) - h; alpha = 1.0f - clamp01(r.aa * sd + 0.5f); break; }
+    case 7u: { float sd = dist - spread; alpha = sd > 0.0f ? __builtin_fminf(shadow_profile(sd, r.f0), 1.0f) : 1.0f; break; }
+    case 8u: {
+      float inside = 1.0f - clamp01(r.aa * dist + 0.5f);
+      float sd = dist - spread;
+      alpha = sd >= 0.0f ? __builtin_fminf(shadow_profile(sd, r.f0), 1.0f) : inside;
+      break;
+    }
+    case 9u: {  // atlas.frag:364-380
+      float clip_a = 1.0f - clamp01(r.aa * dist + 0.5f);
+      float shd = shape_dist(ellip, lx - r.p2, -ly + r.p3, qhx, qhy, r.r[0], r.r[1], r.r[2], r.r[3]);
+      float sd = shd + spread;
+      float ia = sd < 0.0f ? __builtin_fminf(shadow_profile(sd, r.f0), 1.0f) : 1.0f;
+      alpha = clip_a * ia;
+      break;
+    }
+    default: alpha = 1.0f - clamp01(r.aa * dist + 0.5f); break;
+  }
+  if (mode == 17u) {  // atlas.frag:381-388
+    F4 b = F;
+    if (!(om & F_SELF_BACKDROP) && in_frame) b = unpack255(backdrop[pix]);
+    const float k = 1.0f / 255.0f;
+    s.r = b.x * k; s.g = b.y * k; s.b = b.z * k; s.a = b.w * k * alpha;
+  } else {
+    const F4 fc = eval_fill_rec(r, f.col, fill_mode, f.u, f.v);
+    s.r = fc.x; s.g = fc.y; s.b = fc.z; s.a = fc.w * alpha;
+  }
+  return s;
+}
+
+// One wavefront = one 32x8 pixel tile: lane l owns the 4 horizontally adjacent pixels x = tx0 + 4*(l&7) .. +3 of
+// row ty0 + (l>>3) -- i.e. four side-by-side 8x8 sub-tiles shaded in lock-step, so every record fetch, mode
+// dispatch and loop step is paid once per 256 pixels, loads/stores of the surface are 16 B per lane and a wave
+// reads or writes 8 full 128-byte lines.  A workgroup stacks 4 waves (32x32); 4 workgroups tile a 64x64 bin.
+//
+// Axis-aligned SDF draws (fills, strokes, shadows, clip pushes, blur composites -- all but a handful of calls in
+// real scenes) take the 4-wide straight-line path.  Everything else goes through shade_one() one pixel slot at a
+// time; the per-lane state arrays are rotated between slots so they are only ever indexed statically.
+__global__ __launch_bounds__(256, 4) void k_composite_tiles(const DrawRec* __restrict__ draws, const BBox* __restrict__ bboxes,
                                                          const QuadExt* __restrict__ exts, CompositeParams P) {
-  __shared__ float mask_stack[kWavesPerWg][kMaskDepth][64];
+  __shared__ uint32_t mask_stack[kWavesPerWg][kMaskDepth][64];  // 4 pixels' q8 mask values packed per lane
   // XCD-aware remap: the dispatcher places workgroup b on XCD b % 8; give every XCD a contiguous run of
-  // logical workgroups so the 16 workgroups of a bin (same draw list, adjacent framebuffer lines) share an L2.
+  // logical workgroups so the workgroups of a bin (same draw list, adjacent surface lines) share an L2.
   int wg = blockIdx.x;
   {
     const int n = P.n_wg, per = (n + 7) >> 3;
-    int logical = (wg & 7) * per + (wg >> 3);
+    const int logical = (wg & 7) * per + (wg >> 3);
     if (logical >= n) return;  // padded tail of the remap (grid is rounded up to a multiple of 8)
     wg = logical;
   }
@@ -320,26 +474,39 @@ __global__ __launch_bounds__(256) void k_composite_tiles(const DrawRec* __restri
   const int bin_x = P.bin_x0 + blx, bin_y = P.bin_y0 + bly;
   const int bin = bin_y * P.bins_x + bin_x;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int tx0 = bin_x * kBin + (j & 1) * kWgW + wave * kTile;
-  const int ty0 = bin_y * kBin + (j >> 1) * kWgH;
+  const int tx0 = bin_x * kBin + (j & 1) * kWgW;
+  const int ty0 = bin_y * kBin + (j >> 1) * kWgH + wave * kTileH;
   if (tx0 >= P.W || ty0 >= P.H) return;
-  if (ty0 + kTile <= P.row_lo || ty0 >= P.row_hi) return;
-  const int tx1 = tx0 + kTile, ty1 = ty0 + kTile;
-  const int px = tx0 + (lane & 7), py = ty0 + (lane >> 3);
-  const bool in_frame = px < P.W && py < P.H;
-  const size_t pix = (size_t)py * P.pitch + px;
-
-  float mask_cur = 1.0f;   // product state of the NfClipContent stack (1 = no mask bound: maskTexEnabled false)
-  float rmask_cur = 1.0f;  // fast rect mask (atlas_rect_mask.frag), 1 when none
-  int mask_depth = 0;
-  bool touched = false;
-
+  if (ty0 + kTileH <= P.row_lo || ty0 >= P.row_hi) return;
+  const int tx1 = tx0 + kTileW, ty1 = ty0 + kTileH;
+  const int px0 = tx0 + (lane & 7) * 4, py = ty0 + (lane >> 3);
   const uint32_t cnt = P.counts[bin];
   if (cnt == 0 && P.load_fb) return;  // nothing lands in this bin: the surface already holds the result
-  F4 F = unpack255(P.clear_rgba8);
-  if (P.load_fb && in_frame) F = unpack255(P.fb[pix]);
+
+  const bool row_ok = py < P.H;
+  const bool vec_ok = row_ok && px0 + 3 < P.W && (P.pitch & 3) == 0;  // whole 16-byte group inside the frame
+  const size_t pix = (size_t)py * P.pitch + px0;
+  F4 F0, F1, F2, F3;
+  F0 = F1 = F2 = F3 = unpack255(P.clear_rgba8);
+  if (P.load_fb) {
+    if (vec_ok) {
+      const uint4 q = *reinterpret_cast<const uint4*>(P.fb + pix);
+      F0 = unpack255(q.x); F1 = unpack255(q.y); F2 = unpack255(q.z); F3 = unpack255(q.w);
+    } else if (row_ok) {
+      if (px0 + 0 < P.W) F0 = unpack255(P.fb[pix + 0]);
+      if (px0 + 1 < P.W) F1 = unpack255(P.fb[pix + 1]);
+      if (px0 + 2 < P.W) F2 = unpack255(P.fb[pix + 2]);
+      if (px0 + 3 < P.W) F3 = unpack255(P.fb[pix + 3]);
+    }
+  }
+  float mk0 = 1.0f, mk1 = 1.0f, mk2 = 1.0f, mk3 = 1.0f;  // NfClipContent stack product (1 = maskTexEnabled false)
+  float rm0 = 1.0f, rm1 = 1.0f, rm2 = 1.0f, rm3 = 1.0f;  // fast rect mask (atlas_rect_mask.frag), 1 when none
+  int mask_depth = 0;
+  bool touched = false;
   const uint32_t* __restrict__ list = P.lists + (size_t)bin * P.stride;
-  const float cx = (float)px + 0.5f, cy = (float)py + 0.5f;
+  const float cy = (float)py + 0.5f;
+  const float cx0 = (float)px0 + 0.5f;
+  const float inv255 = 1.0f / 255.0f;
 
   for (uint32_t base = 0; base < cnt; base += 64) {
     const uint32_t i = base + lane;
@@ -347,7 +514,7 @@ __global__ __launch_bounds__(256) void k_composite_tiles(const DrawRec* __restri
     bool hit = false;
     if (i < cnt) {
       idx = list[i];
-      BBox b = bboxes[idx];
+      const BBox b = bboxes[idx];
       hit = b.x0 < tx1 && b.x1 > tx0 && b.y0 < ty1 && b.y1 > ty0;
     }
     unsigned long long m = __ballot(hit);
@@ -355,99 +522,209 @@ __global__ __launch_bounds__(256) void k_composite_tiles(const DrawRec* __restri
       const int bsel = __builtin_ctzll(m);
       m &= m - 1;
       const uint32_t d = __builtin_amdgcn_readlane(idx, bsel);
-      // the whole 128-byte record in one go (two s_load_dwordx16 into SGPRs), not field by field inside the branches
-      const DrawRec r = load_rec(draws + d);
-      const uint32_t om = r.op_mode;
+      const uint32_t om = draws[d].op_mode;
       const uint32_t op = (om >> 12) & 15u;
       const uint32_t mode = om & 255u;
-      const bool ellip = (om & F_ELLIP) != 0u;
       touched = true;
       if (op == OP_MASK_POP) {
         mask_depth--;
-        mask_cur = mask_depth > 0 ? mask_stack[wave][mask_depth - 1][lane] : 1.0f;
+        if (mask_depth > 0) {
+          const uint32_t w = mask_stack[wave][mask_depth - 1][lane];
+          mk0 = (float)(w & 255u) * inv255; mk1 = (float)((w >> 8) & 255u) * inv255;
+          mk2 = (float)((w >> 16) & 255u) * inv255; mk3 = (float)(w >> 24) * inv255;
+        } else {
+          mk0 = mk1 = mk2 = mk3 = 1.0f;
+        }
         continue;
       }
-      if (op == OP_RMASK_END) { rmask_cur = 1.0f; continue; }
-      if (op == OP_RMASK_BEGIN) { rmask_cur = rect_mask_alpha(r, cx, cy); continue; }
+      if (op == OP_RMASK_END) { rm0 = rm1 = rm2 = rm3 = 1.0f; continue; }
+      const bool atlas_mode = (mode == 0u) || (mode >= 13u && mode <= 16u);
+      const bool fast = !(om & F_GENERAL) && !atlas_mode && (op == OP_DRAW || op == OP_MASK_PUSH);
+      if (!fast) {
+        // ---- one pixel slot at a time, state rotated so slot 0 is always the live one
+        uint32_t packed = 0;
+#pragma unroll 1
+        for (int k = 0; k < 4; k++) {
+          const int px = px0 + k;
+          if (op == OP_RMASK_BEGIN) {
+            rm0 = rect_mask_alpha(draws[d], (float)px + 0.5f, cy);
+          } else {
+            const bool in_frame = row_ok && px < P.W;
+            const Src s = shade_one(draws + d, exts, &P.atlas, P.backdrop, pix + k, in_frame, px, py, F0);
+            if (op == OP_MASK_PUSH) {
+              float a = s.covered ? s.a * mk0 : 0.0f;
+              const float q = __builtin_rintf(a * a * 255.0f);
+              packed |= (uint32_t)q << (8 * k);
+              mk0 = q * inv255;
+            } else {
+              float a = s.a * mk0 * rm0;
+              a = s.covered ? a : 0.0f;
+              blend(F0, s.r, s.g, s.b, a);
+            }
+          }
+          { const F4 t = F0; F0 = F1; F1 = F2; F2 = F3; F3 = t; }
+          { const float t = mk0; mk0 = mk1; mk1 = mk2; mk2 = mk3; mk3 = t; }
+          { const float t = rm0; rm0 = rm1; rm1 = rm2; rm2 = rm3; rm3 = t; }
+        }
+        if (op == OP_MASK_PUSH) { mask_stack[wave][mask_depth][lane] = packed; mask_depth++; }
+        continue;
+      }
 
-      Frag f = make_frag(r, exts, px, py);
+      // ---- fast path: axis-aligned SDF draw / clip push, 4 pixels per lane in lock-step
+      const DrawRec r = load_rec(draws + d);  // whole record, wave-uniform scalar loads
+      const bool ellip = (om & F_ELLIP) != 0u;
+      const uint32_t fill_mode = (om >> 9) & 7u;
+      const float t = (cy - r.oy) * r.inv_h;  // v of the quad (uv = (0,0)-(1,1) for SDF quads)
+      const bool rowc = py >= r.by0 && py < r.by1;
+      float u[4];
+      bool cov[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        u[k] = (cx0 + (float)k - r.ox) * r.inv_w;
+        cov[k] = rowc && px0 + k >= r.bx0 && px0 + k < r.bx1;
+      }
+      F4 col[4];
+      {
+        const F4 c0 = unpack255(r.col[0]);
+        if (om & F_SOLID) {
+#pragma unroll
+          for (int k = 0; k < 4; k++) col[k] = {c0.x * inv255, c0.y * inv255, c0.z * inv255, c0.w * inv255};
+        } else {
+          const F4 br = unpack255(r.col[1]), tr = unpack255(r.col[2]), tl = unpack255(r.col[3]);
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            col[k].x = tri_lerp(tl.x, c0.x, br.x, tr.x, u[k], t) * inv255;
+            col[k].y = tri_lerp(tl.y, c0.y, br.y, tr.y, u[k], t) * inv255;
+            col[k].z = tri_lerp(tl.z, c0.z, br.z, tr.z, u[k], t) * inv255;
+            col[k].w = tri_lerp(tl.w, c0.w, br.w, tr.w, u[k], t) * inv255;
+          }
+        }
+      }
+      const float qhx = r.p0, qhy = r.p1;
+      const bool inset = mode == 9u && op == OP_DRAW;
+      const float shx = inset ? qhx : r.p2, shy = inset ? qhy : r.p3;
+      float lx[4], dist[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) lx[k] = (u[k] - 0.5f) * 2.0f * qhx;
+      const float ly = (t - 0.5f) * 2.0f * qhy;
+      shape_dist4(ellip, lx, -ly, shx, shy, r.r[0], r.r[1], r.r[2], r.r[3], dist);
+
       if (op == OP_MASK_PUSH) {
         // mask.frag:186-234 drawn through the blender into a cleared R8 plane: stored = q8(a*a), a = shape*parent
-        float a = 0.0f;
-        if (f.covered) {
-          float lx = (f.u - 0.5f) * 2.0f * r.p0, ly = (f.v - 0.5f) * 2.0f * r.p1;
-          float dist = shape_dist(ellip, lx, -ly, r.p2, r.p3, r.r[0], r.r[1], r.r[2], r.r[3]);
-          a = (1.0f - clamp01(r.aa * dist + 0.5f)) * f.col.w * mask_cur;
+        float mk[4] = {mk0, mk1, mk2, mk3};
+        uint32_t packed = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          float a = (1.0f - clamp01(r.aa * dist[k] + 0.5f)) * col[k].w * mk[k];
+          a = cov[k] ? a : 0.0f;
+          const float q = __builtin_rintf(a * a * 255.0f);
+          packed |= (uint32_t)q << (8 * k);
+          mk[k] = q * inv255;
         }
-        float stored = __builtin_rintf(a * a * 255.0f) * (1.0f / 255.0f);
-        mask_stack[wave][mask_depth][lane] = stored;
+        mk0 = mk[0]; mk1 = mk[1]; mk2 = mk[2]; mk3 = mk[3];
+        mask_stack[wave][mask_depth][lane] = packed;
         mask_depth++;
-        mask_cur = stored;
         continue;
       }
+
       // ---- OP_DRAW: atlas.frag main():252-405
-      const uint32_t fill_mode = (om >> 9) & 7u;
-      float sr, sg, sb, sa;
-      if (mode == 0u) {  // atlas.frag:284-295
-        float u = f.u;
-        if (om & F_SUBPIXEL) u -= r.aux * frcp(__builtin_fmaxf((float)P.atlas.size, 1.0f));
-        F4 t = atlas_sample(P.atlas, u, f.v, f.lod);
-        sr = t.x * f.col.x; sg = t.y * f.col.y; sb = t.z * f.col.z; sa = t.w * f.col.w;
-      } else if (mode >= 13u && mode <= 16u) {  // atlas.frag:296-318
-        F4 fc = eval_fill(r, f, fill_mode);
-        F4 t = atlas_sample(P.atlas, f.u, f.v, 0.0f);  // textureLod(atlasTex, uv, 0.0)
-        const bool is_mtsdf = (mode == 14u || mode == 16u), is_stroke = (mode == 15u || mode == 16u);
-        float sd = is_mtsdf ? t.w : median3(t.x, t.y, t.z);
-        float unit = r.f0 * frcp(r.p0);  // pxRange / atlas size (atlas.frag:45-49)
-        float spr = __builtin_fmaxf(0.5f * (unit * frcp(f.fw_u) + unit * frcp(f.fw_v)), 1.0f);
-        float spd = spr * (sd - r.f1);
-        float alpha = is_stroke ? clamp01(__builtin_fmaxf(r.p1, 0.0f) * 0.5f - __builtin_fabsf(spd) + 0.5f) : clamp01(spd + 0.5f);
-        sr = fc.x; sg = fc.y; sb = fc.z; sa = fc.w * alpha;
-      } else {
-        const float qhx = r.p0, qhy = r.p1;
-        const bool inset = mode == 9u;
-        const float shx = inset ? qhx : r.p2, shy = inset ? qhy : r.p3;
-        const float lx = (f.u - 0.5f) * 2.0f * qhx, ly = (f.v - 0.5f) * 2.0f * qhy;
-        const float dist = shape_dist(ellip, lx, -ly, shx, shy, r.r[0], r.r[1], r.r[2], r.r[3]);
-        const float spread = fill_mode == 0u ? r.f1 : 0.0f;
-        float alpha;
-        switch (mode) {
-          case 11u: { float h = r.f0 * 0.5f; float sd = __builtin_fabsf(dist + h) - h; alpha = sd < 0.0f ? 1.0f : 0.0f; break; }
-          case 12u: { float h = r.f0 * 0.5f; float sd = __builtin_fabsf(dist + h) - h; alpha = 1.0f - clamp01(r.aa * sd + 0.5f); break; }
-          case 7u: { float sd = dist - spread; alpha = sd > 0.0f ? __builtin_fminf(shadow_profile(sd, r.f0), 1.0f) : 1.0f; break; }
-          case 8u: {
-            float inside = 1.0f - clamp01(r.aa * dist + 0.5f);
-            float sd = dist - spread;
-            alpha = sd >= 0.0f ? __builtin_fminf(shadow_profile(sd, r.f0), 1.0f) : inside;
-            break;
-          }
-          case 9u: {  // atlas.frag:364-380
-            float clip_a = 1.0f - clamp01(r.aa * dist + 0.5f);
-            float sx = lx - r.p2, sy = -ly + r.p3;
-            float shd = shape_dist(ellip, sx, sy, qhx, qhy, r.r[0], r.r[1], r.r[2], r.r[3]);
-            float sd = shd + spread;
-            float ia = sd < 0.0f ? __builtin_fminf(shadow_profile(sd, r.f0), 1.0f) : 1.0f;
-            alpha = clip_a * ia;
-            break;
-          }
-          default: alpha = 1.0f - clamp01(r.aa * dist + 0.5f); break;  // ClipAA / BackdropBlur / others
+      const float spread = fill_mode == 0u ? r.f1 : 0.0f;
+      float alpha[4];
+      switch (mode) {  // wave-uniform
+        case 11u: {
+          const float h = r.f0 * 0.5f;
+#pragma unroll
+          for (int k = 0; k < 4; k++) alpha[k] = (__builtin_fabsf(dist[k] + h) - h) < 0.0f ? 1.0f : 0.0f;
+          break;
         }
-        if (mode == 17u) {  // atlas.frag:381-388: the blurred backdrop at this fragment's own pixel
-          F4 b = F;
-          if (!(om & F_SELF_BACKDROP) && in_frame) b = unpack255(P.backdrop[pix]);
-          const float k = 1.0f / 255.0f;
-          sr = b.x * k; sg = b.y * k; sb = b.z * k; sa = b.w * k * alpha;
-        } else {
-          F4 fc = eval_fill(r, f, fill_mode);
-          sr = fc.x; sg = fc.y; sb = fc.z; sa = fc.w * alpha;
+        case 12u: {
+          const float h = r.f0 * 0.5f;
+#pragma unroll
+          for (int k = 0; k < 4; k++) alpha[k] = 1.0f - clamp01(r.aa * (__builtin_fabsf(dist[k] + h) - h) + 0.5f);
+          break;
+        }
+        case 7u: {
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            const float sd = dist[k] - spread;
+            alpha[k] = sd > 0.0f ? __builtin_fminf(shadow_profile(sd, r.f0), 1.0f) : 1.0f;
+          }
+          break;
+        }
+        case 8u: {
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            const float inside = 1.0f - clamp01(r.aa * dist[k] + 0.5f);
+            const float sd = dist[k] - spread;
+            alpha[k] = sd >= 0.0f ? __builtin_fminf(shadow_profile(sd, r.f0), 1.0f) : inside;
+          }
+          break;
+        }
+        case 9u: {  // atlas.frag:364-380
+          float sx[4], shd[4];
+#pragma unroll
+          for (int k = 0; k < 4; k++) sx[k] = lx[k] - r.p2;
+          shape_dist4(ellip, sx, -ly + r.p3, qhx, qhy, r.r[0], r.r[1], r.r[2], r.r[3], shd);
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            const float clip_a = 1.0f - clamp01(r.aa * dist[k] + 0.5f);
+            const float sd = shd[k] + spread;
+            const float ia = sd < 0.0f ? __builtin_fminf(shadow_profile(sd, r.f0), 1.0f) : 1.0f;
+            alpha[k] = clip_a * ia;
+          }
+          break;
+        }
+        default: {  // ClipAA / BackdropBlur / others: atlas.frag:389-393
+#pragma unroll
+          for (int k = 0; k < 4; k++) alpha[k] = 1.0f - clamp01(r.aa * dist[k] + 0.5f);
+          break;
         }
       }
-      sa *= mask_cur;   // atlas.frag:401-404
-      sa *= rmask_cur;  // atlas_rect_mask.frag:425
-      if (f.covered) blend(F, sr, sg, sb, sa);
+      float sr[4], sg[4], sb[4], sa[4];
+      if (mode == 17u) {  // atlas.frag:381-388: the blurred backdrop at this fragment's own pixel
+        F4 b[4] = {F0, F1, F2, F3};
+        if (!(om & F_SELF_BACKDROP)) {
+          if (vec_ok) {
+            const uint4 q = *reinterpret_cast<const uint4*>(P.backdrop + pix);
+            b[0] = unpack255(q.x); b[1] = unpack255(q.y); b[2] = unpack255(q.z); b[3] = unpack255(q.w);
+          } else if (row_ok) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) if (px0 + k < P.W) b[k] = unpack255(P.backdrop[pix + k]);
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) { sr[k] = b[k].x * inv255; sg[k] = b[k].y * inv255; sb[k] = b[k].z * inv255; sa[k] = b[k].w * inv255 * alpha[k]; }
+      } else if (fill_mode == 0u) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) { sr[k] = col[k].x; sg[k] = col[k].y; sb[k] = col[k].z; sa[k] = col[k].w * alpha[k]; }
+      } else {
+        const F4 mc = unpack255(r.mid), sc = unpack255(r.stop);
+        const F4 m01 = {mc.x * inv255, mc.y * inv255, mc.z * inv255, mc.w * inv255}, s01 = {sc.x * inv255, sc.y * inv255, sc.z * inv255, sc.w * inv255};
+        const float mid = __builtin_fminf(__builtin_fmaxf(r.f1, 0.01f), 0.99f);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const F4 fc = eval_fill_nb(col[k], m01, s01, fill_mode, mid, u[k], t);
+          sr[k] = fc.x; sg[k] = fc.y; sb[k] = fc.z; sa[k] = fc.w * alpha[k];
+        }
+      }
+      // mask multiply (atlas.frag:401-404), rect mask (atlas_rect_mask.frag:425); outside the quad alpha is forced
+      // to 0: blending with alpha 0 leaves the integer texel exactly as it is
+      blend(F0, sr[0], sg[0], sb[0], cov[0] ? sa[0] * mk0 * rm0 : 0.0f);
+      blend(F1, sr[1], sg[1], sb[1], cov[1] ? sa[1] * mk1 * rm1 : 0.0f);
+      blend(F2, sr[2], sg[2], sb[2], cov[2] ? sa[2] * mk2 * rm2 : 0.0f);
+      blend(F3, sr[3], sg[3], sb[3], cov[3] ? sa[3] * mk3 * rm3 : 0.0f);
     }
   }
-  if (in_frame && py >= P.row_lo && py < P.row_hi && (touched || !P.load_fb)) P.fb[pix] = pack255(F);
+  if (!(touched || !P.load_fb) || py < P.row_lo || py >= P.row_hi) return;
+  if (vec_ok) {
+    uint4 o = {pack255(F0), pack255(F1), pack255(F2), pack255(F3)};
+    *reinterpret_cast<uint4*>(P.fb + pix) = o;
+  } else if (row_ok) {
+    if (px0 + 0 < P.W) P.fb[pix + 0] = pack255(F0);
+    if (px0 + 1 < P.W) P.fb[pix + 1] = pack255(F1);
+    if (px0 + 2 < P.W) P.fb[pix + 2] = pack255(F2);
+    if (px0 + 3 < P.W) P.fb[pix + 3] = pack255(F3);
+  }
 }
 
 // ------------------------------------------------------------------ blur (blur.frag:11-32 as a merged FIR)

@@ -4,15 +4,17 @@
 
 namespace fdh {
 
-// Tile geometry: one wavefront (64 lanes) = one 8x8 pixel tile, lane <-> pixel (row-major inside the
-// tile).  A workgroup is 4 waves = 4 tiles side by side = a 32x8 strip, so a row of the strip is one
-// 128-byte line of the RGBA8 surface.  A coarse bin is 64x64 pixels = 16 workgroups.
+// Tile geometry: the shading unit is the 8x8 pixel tile; one wavefront (64 lanes) shades four of them side by
+// side in lock-step (a 32x8 strip, lane <-> 4 adjacent pixels of one row), so a row of the strip is one 128-byte
+// line of the RGBA8 surface.  A workgroup stacks 4 waves (32x32 pixels); a coarse bin is 64x64 pixels = 4 workgroups.
 constexpr int kTile = 8;
+constexpr int kTileW = 4 * kTile;  // a wavefront covers four side-by-side 8x8 sub-tiles: 32 x 8 pixels, 4 pixels per lane
+constexpr int kTileH = kTile;
 constexpr int kWavesPerWg = 4;
-constexpr int kWgW = kTile * kWavesPerWg;  // 32
-constexpr int kWgH = kTile;                // 8
+constexpr int kWgW = kTileW;                // 32
+constexpr int kWgH = kTileH * kWavesPerWg;  // 32: the four waves of a workgroup are stacked vertically
 constexpr int kBin = 64;
-constexpr int kWgsPerBin = (kBin / kWgW) * (kBin / kWgH);  // 16
+constexpr int kWgsPerBin = (kBin / kWgW) * (kBin / kWgH);  // 4
 constexpr int kMaskDepth = 8;                              // per-lane clip stack depth kept in LDS
 constexpr int kMaxMips = 14;
 constexpr int kMaxBlurTaps = 36;
