@@ -15,6 +15,15 @@
 
 namespace fdh {
 
+// A/B switches (measured on MI355X, S300@4K): record prefetch costs SGPR spills and loses ~5 %, the exact
+// tile classification wins 2-10 % depending on how many shapes have small radii.
+#ifndef FDH_PREFETCH
+#define FDH_PREFETCH 0
+#endif
+#ifndef FDH_CLASSIFY
+#define FDH_CLASSIFY 1
+#endif
+
 // ------------------------------------------------------------------ small device helpers
 __device__ __forceinline__ float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ float fsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
@@ -312,14 +321,15 @@ __device__ __forceinline__ float sd_ellipse_nb(float px, float py, float rx, flo
   const float d = k0 * (k0 - 1.0f) * frcp(__builtin_fmaxf(k1, 0.000001f));
   return k0 <= 0.000001f ? -__builtin_fminf(sx, sy) : d;
 }
-// distance of 4 pixels of one row at once (sdRoundedBox :51-69 / sdEllipticalRoundedBox :96-115)
-__device__ __forceinline__ void shape_dist4(bool ellip, const float px[4], float py, float bx, float by, float r0, float r1, float r2,
-                                            float r3, float out[4]) {
-  Corner c[4];
-  float qx[4], qy[4];
+// distance of N pixels of one row at once (sdRoundedBox :51-69 / sdEllipticalRoundedBox :96-115)
+template <int N>
+__device__ __forceinline__ void shape_distN(bool ellip, const float* px, float py, float bx, float by, float r0, float r1, float r2,
+                                            float r3, float* out) {
+  Corner c[N];
+  float qx[N], qy[N];
   bool need = false;
 #pragma unroll
-  for (int k = 0; k < 4; k++) {
+  for (int k = 0; k < N; k++) {
     c[k] = pick_corner(ellip, px[k], py, bx, by, r0, r1, r2, r3);
     qx[k] = __builtin_fabsf(px[k]) - bx + c[k].rx;
     qy[k] = __builtin_fabsf(py) - by + c[k].ry;
@@ -330,7 +340,7 @@ __device__ __forceinline__ void shape_dist4(bool ellip, const float px[4], float
   if (!ellip) return;  // wave-uniform
   const bool any_ellipse = __any(need);
 #pragma unroll
-  for (int k = 0; k < 4; k++) {
+  for (int k = 0; k < N; k++) {
     const bool corner = qx[k] > 0.0f && qy[k] > 0.0f;
     float de = __builtin_fmaxf(qx[k] - c[k].rx, qy[k] - c[k].ry);
     if (any_ellipse) {  // wave-uniform
@@ -518,11 +528,11 @@ __global__ __launch_bounds__(256, 4) void k_composite_tiles(const DrawRec* __res
       hit = b.x0 < tx1 && b.x1 > tx0 && b.y0 < ty1 && b.y1 > ty0;
     }
     unsigned long long m = __ballot(hit);
-    while (m) {
-      const int bsel = __builtin_ctzll(m);
-      m &= m - 1;
-      const uint32_t d = __builtin_amdgcn_readlane(idx, bsel);
-      const uint32_t om = draws[d].op_mode;
+    if (m == 0) continue;
+    // One draw = one lambda call.  The record of the NEXT surviving draw is fetched (scalar loads) before the
+    // current one is shaded, so the ~L2-latency of the fetch overlaps the shading arithmetic.
+    auto shade = [&](const uint32_t d, const DrawRec& r) {
+      const uint32_t om = r.op_mode;
       const uint32_t op = (om >> 12) & 15u;
       const uint32_t mode = om & 255u;
       touched = true;
@@ -535,9 +545,9 @@ __global__ __launch_bounds__(256, 4) void k_composite_tiles(const DrawRec* __res
         } else {
           mk0 = mk1 = mk2 = mk3 = 1.0f;
         }
-        continue;
+        return;
       }
-      if (op == OP_RMASK_END) { rm0 = rm1 = rm2 = rm3 = 1.0f; continue; }
+      if (op == OP_RMASK_END) { rm0 = rm1 = rm2 = rm3 = 1.0f; return; }
       const bool atlas_mode = (mode == 0u) || (mode >= 13u && mode <= 16u);
       const bool fast = !(om & F_GENERAL) && !atlas_mode && (op == OP_DRAW || op == OP_MASK_PUSH);
       if (!fast) {
@@ -567,11 +577,10 @@ __global__ __launch_bounds__(256, 4) void k_composite_tiles(const DrawRec* __res
           { const float t = rm0; rm0 = rm1; rm1 = rm2; rm2 = rm3; rm3 = t; }
         }
         if (op == OP_MASK_PUSH) { mask_stack[wave][mask_depth][lane] = packed; mask_depth++; }
-        continue;
+        return;
       }
 
       // ---- fast path: axis-aligned SDF draw / clip push, 4 pixels per lane in lock-step
-      const DrawRec r = load_rec(draws + d);  // whole record, wave-uniform scalar loads
       const bool ellip = (om & F_ELLIP) != 0u;
       const uint32_t fill_mode = (om >> 9) & 7u;
       const float t = (cy - r.oy) * r.inv_h;  // v of the quad (uv = (0,0)-(1,1) for SDF quads)
@@ -607,7 +616,37 @@ __global__ __launch_bounds__(256, 4) void k_composite_tiles(const DrawRec* __res
 #pragma unroll
       for (int k = 0; k < 4; k++) lx[k] = (u[k] - 0.5f) * 2.0f * qhx;
       const float ly = (t - 0.5f) * 2.0f * qhy;
-      shape_dist4(ellip, lx, -ly, shx, shy, r.r[0], r.r[1], r.r[2], r.r[3], dist);
+      const float spread = fill_mode == 0u ? r.f1 : 0.0f;
+      // Tile classification.  Along a row the rounded-box distance is quasi-convex (its sub-level sets are
+      // intervals), so if the two OUTER pixels of every lane's 4-pixel run give the same saturated alpha, the two
+      // inner ones do too -- exactly, not approximately.  cls 1: alpha == 1 on the whole 32x8 strip (shape interior);
+      // cls 2: alpha == 0 (deep inside a stroke): the draw is a no-op for this strip.
+      int cls = 0;
+      if (FDH_CLASSIFY && !ellip) {
+        const float lxo[2] = {lx[0], lx[3]};
+        float d2[2];
+        shape_distN<2>(false, lxo, -ly, shx, shy, r.r[0], r.r[1], r.r[2], r.r[3], d2);
+        dist[0] = d2[0];
+        dist[3] = d2[1];
+        const float dm = __builtin_fmaxf(d2[0], d2[1]);
+        bool one = false, zero = false;
+        if (op == OP_MASK_PUSH || mode == 3u || mode == 17u) one = r.aa * dm + 0.5f <= 0.0f;
+        else if (mode == 7u) one = dm - spread <= 0.0f;
+        else if (mode == 12u) { const float h = r.f0 * 0.5f; zero = (dm + h < 0.0f) && (r.aa * (-(dm + h) - h) + 0.5f >= 1.0f); }
+        if (__all(one)) cls = 1;
+        else if (__all(zero)) cls = 2;
+        if (cls == 2) return;
+        if (cls == 0) {
+          const float lxi[2] = {lx[1], lx[2]};
+          shape_distN<2>(false, lxi, -ly, shx, shy, r.r[0], r.r[1], r.r[2], r.r[3], d2);
+          dist[1] = d2[0];
+          dist[2] = d2[1];
+        } else {
+          dist[1] = dist[2] = dm;
+        }
+      } else {
+        shape_distN<4>(true, lx, -ly, shx, shy, r.r[0], r.r[1], r.r[2], r.r[3], dist);
+      }
 
       if (op == OP_MASK_PUSH) {
         // mask.frag:186-234 drawn through the blender into a cleared R8 plane: stored = q8(a*a), a = shape*parent
@@ -624,11 +663,10 @@ __global__ __launch_bounds__(256, 4) void k_composite_tiles(const DrawRec* __res
         mk0 = mk[0]; mk1 = mk[1]; mk2 = mk[2]; mk3 = mk[3];
         mask_stack[wave][mask_depth][lane] = packed;
         mask_depth++;
-        continue;
+        return;
       }
 
       // ---- OP_DRAW: atlas.frag main():252-405
-      const float spread = fill_mode == 0u ? r.f1 : 0.0f;
       float alpha[4];
       switch (mode) {  // wave-uniform
         case 11u: {
@@ -664,7 +702,7 @@ __global__ __launch_bounds__(256, 4) void k_composite_tiles(const DrawRec* __res
           float sx[4], shd[4];
 #pragma unroll
           for (int k = 0; k < 4; k++) sx[k] = lx[k] - r.p2;
-          shape_dist4(ellip, sx, -ly + r.p3, qhx, qhy, r.r[0], r.r[1], r.r[2], r.r[3], shd);
+          shape_distN<4>(ellip, sx, -ly + r.p3, qhx, qhy, r.r[0], r.r[1], r.r[2], r.r[3], shd);
 #pragma unroll
           for (int k = 0; k < 4; k++) {
             const float clip_a = 1.0f - clamp01(r.aa * dist[k] + 0.5f);
@@ -713,6 +751,24 @@ __global__ __launch_bounds__(256, 4) void k_composite_tiles(const DrawRec* __res
       blend(F1, sr[1], sg[1], sb[1], cov[1] ? sa[1] * mk1 * rm1 : 0.0f);
       blend(F2, sr[2], sg[2], sb[2], cov[2] ? sa[2] * mk2 * rm2 : 0.0f);
       blend(F3, sr[3], sg[3], sb[3], cov[3] ? sa[3] * mk3 * rm3 : 0.0f);
+    };
+    uint32_t d = __builtin_amdgcn_readlane(idx, __builtin_ctzll(m));
+    m &= m - 1;
+    DrawRec r = load_rec(draws + d);
+    for (;;) {
+      const bool more = m != 0;
+      uint32_t d_next = d;
+      if (more) { d_next = __builtin_amdgcn_readlane(idx, __builtin_ctzll(m)); m &= m - 1; }
+#if FDH_PREFETCH
+      const DrawRec r_next = load_rec(draws + d_next);  // issued now, consumed after shade(): latency hidden
+      shade(d, r);
+#else
+      shade(d, r);
+      const DrawRec r_next = load_rec(draws + d_next);
+#endif
+      if (!more) break;
+      d = d_next;
+      r = r_next;
     }
   }
   if (!(touched || !P.load_fb) || py < P.row_lo || py >= P.row_hi) return;
@@ -799,8 +855,8 @@ __global__ __launch_bounds__(256) void k_blur_h(BlurParams P) {
   }
 }
 
-// vertical pass: one workgroup = 64 columns x 32 rows; a lane owns a column, each wave produces 8 rows as two
-// groups of 4 consecutive outputs.  With fuse_draw >= 0 the consuming mode-17 quad is blended in place.
+// vertical pass: one workgroup = 64 columns x 32 rows (taller tiles cut the halo re-read but cost LDS occupancy: measured slower); a lane owns a column, each wave
+// produces 8 rows as two groups of 4 consecutive outputs.  With fuse_draw >= 0 the consuming mode-17 quad is blended in place.
 constexpr int kBlurVW = 64, kBlurVH = 32;
 __global__ __launch_bounds__(256) void k_blur_v(BlurParams P, const DrawRec* __restrict__ draws, const QuadExt* __restrict__ exts) {
   extern __shared__ uint32_t tile[];  // (kBlurVH + 2*reach + 4) rows x 64 columns
@@ -820,9 +876,11 @@ __global__ __launch_bounds__(256) void k_blur_v(BlurParams P, const DrawRec* __r
   if (x >= P.x1) return;
   const float* __restrict__ d = P.taps.dense;
   const int nwin = 4 + 2 * reach;
+  DrawRec r;
+  if (P.fuse_draw >= 0) r = load_rec(draws + P.fuse_draw);
 #pragma unroll 1
-  for (int g = 0; g < 2; g++) {
-    const int ry = wave * 8 + g * 4;  // first of the four output rows, relative to ys
+  for (int g = 0; g < kBlurVH / 16; g++) {
+    const int ry = wave * (kBlurVH / 4) + g * 4;  // first of the four output rows, relative to ys
     const int y = ys + ry;
     if (y >= P.y1) break;
     f2 rg[4], ba[4];
@@ -848,7 +906,6 @@ __global__ __launch_bounds__(256) void k_blur_v(BlurParams P, const DrawRec* __r
         P.dst[pix] = pack255(b);
       } else {
         // atlas.frag:381-388 on the blurred texel just produced, blended over the live surface (first draw of the phase)
-        const DrawRec r = load_rec(draws + P.fuse_draw);
         const Frag f = make_frag(r, exts, x, y + p);
         if (!f.covered) continue;
         const float lx = (f.u - 0.5f) * 2.0f * r.p0, ly = (f.v - 0.5f) * 2.0f * r.p1;
