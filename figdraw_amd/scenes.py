@@ -169,3 +169,53 @@ def make_render_tree_100(w: float, h: float, frame: int = 0, copies: int = 100, 
     out = Renders()
     out.setLayer(0, lst)
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def load_glyph_fixture(path):
+    """tests/golden/glyphs_ubuntu20.npz -> {image_id: (h, w, 4) uint8}.  Ids: 1000+code = coverage glyph (20 px
+    Ubuntu, premultiplied white), 2000+code = 32x32 MSDF/MTSDF texture, 3000 = the reference's data/img1.png."""
+    z = np.load(path)
+    images = {}
+    for code in range(33, 127):
+        images[1000 + code] = z[f"cov_{code}"]
+        images[2000 + code] = z[f"msdf_{code}"]
+    images[3000] = z["img1_premul"]
+    return images
+
+
+def make_glyph_scene(w: float, h: float, images, cols: int = 100, rows: int = 100, pitch=(38.0, 21.0), origin=(8.0, 6.0),
+                     msdf_size: float = 48.0) -> Renders:
+    """BASELINE.json configs[3] "T10k@4K" (SURVEY.md 8d #4): cols x rows glyph quads (ASCII 33..126 cycling) over a
+    3-stop gradient background; even cells are coverage glyphs from the atlas drawn 1:1 at integer positions with a
+    2-stop vertical tint (mode 0, what renderText emits: figrender.nim:456-496), odd cells are MSDF images drawn
+    magnified (mode 13, pxRange 4, threshold 0.5: renderMsdfImage figrender.nim:1686-1708)."""
+    from .scene import Glyph
+
+    lst = RenderList()
+    lst.addRoot(Fig(kind=FigKind.nkRectangle, screenBox=rect(0, 0, w, h),
+                    fill=linear(rgba(250, 250, 255, 255), rgba(225, 235, 250, 255), rgba(255, 240, 225, 255),
+                                axis=FillGradientAxis.fgaDiagTLBR, midPos=110)))
+    top, bottom = rgba(20, 30, 120, 255), rgba(160, 20, 40, 255)
+    tint = [bottom, bottom, top, top]  # BL, BR, TR, TL of a Y gradient (gradientColors figbackend.nim:169-173)
+    for r in range(rows):
+        y = origin[1] + r * pitch[1]
+        glyphs = []
+        for c in range(cols):
+            i = r * cols + c
+            code = 33 + i % 94
+            x = origin[0] + c * pitch[0]
+            if i % 2 == 0:
+                gh = images[1000 + code].shape[0]
+                glyphs.append(Glyph(image_id=1000 + code, x=float(x), y=float(20 - gh), colors=tint))
+        lst.addRoot(Fig(kind=FigKind.nkText, screenBox=rect(0, y, w, pitch[1]), glyphs=glyphs))
+        for c in range(cols):
+            i = r * cols + c
+            if i % 2 == 1:
+                code = 33 + i % 94
+                x = origin[0] + c * pitch[0]
+                lst.addRoot(Fig(kind=FigKind.nkMsdfImage, screenBox=rect(x - 6.0, y - 14.0, msdf_size, msdf_size),
+                                image_id=2000 + code, image_fill=fill(rgba(10, 90, 40, 230)), pxRange=4.0, sdThreshold=0.5))
+    out = Renders()
+    out.setLayer(0, lst)
+    return out

@@ -264,3 +264,65 @@ SWIFTSHADER_SCENES = {
     "backdrop_blur": (backdrop_blur, 320, 240),
     "rotation_and_transform": (rotation_and_transform, 320, 240),
 }
+
+
+# ----------------------------------------------------------------------- atlas scenes (need images: see ATLAS_SCENES)
+def glyphs_small(w=330.0, h=90.0, images=None) -> Renders:
+    """An 8x3 corner of the T10k glyph workload: coverage glyphs 1:1 (mode 0, gradient tint) + magnified MSDF (mode 13)."""
+    from figdraw_amd.scenes import make_glyph_scene
+
+    return make_glyph_scene(w, h, images, cols=8, rows=3)
+
+
+def images_and_msdf_variants(w=360.0, h=260.0, images=None) -> Renders:
+    """nkImage magnified / 1:1 / minified (mip chain, LINEAR_MIPMAP_LINEAR) with tints and NfInvertY, MTSDF, annular
+    MSDF stroke, a rotated MSDF image, glyphs under NfInvertY text, and an image inside a clip."""
+    from figdraw_amd.scene import Glyph
+
+    lst = RenderList()
+    lst.addRoot(Fig(kind=RECT, screenBox=rect(0, 0, w, h), fill=rgba(160, 160, 160, 255)))
+    # tests/trender_image.nim:13-97 draws data/img1.png (100x100) at 160x160 on grey 160
+    lst.addRoot(Fig(kind=FigKind.nkImage, screenBox=rect(10, 10, 160, 160), image_id=3000))
+    lst.addRoot(Fig(kind=FigKind.nkImage, screenBox=rect(180, 10, 100, 100), image_id=3000, image_fill=fill(rgba(255, 200, 200, 200))))
+    lst.addRoot(Fig(kind=FigKind.nkImage, screenBox=rect(290, 10, 60, 60), image_id=3000))                     # minified 0.6x
+    lst.addRoot(Fig(kind=FigKind.nkImage, screenBox=rect(290, 80, 27, 31), image_id=3000, flags=FigFlags.NfInvertY))  # ~0.29x, flipped
+    lst.addRoot(Fig(kind=FigKind.nkMtsdfImage, screenBox=rect(180, 120, 96, 96), image_id=2000 + ord("R"),
+                    image_fill=fill(rgba(20, 20, 160, 255)), pxRange=4.0, sdThreshold=0.5))
+    lst.addRoot(Fig(kind=FigKind.nkMsdfImage, screenBox=rect(20, 175, 80, 80), image_id=2000 + ord("g"),
+                    image_fill=fill(rgba(200, 40, 20, 255)), pxRange=4.0, sdThreshold=0.45, strokeWeight=3.0))
+    lst.addRoot(Fig(kind=FigKind.nkMsdfImage, screenBox=rect(110, 180, 64, 64), rotation=30.0, image_id=2000 + ord("&"),
+                    image_fill=fill(rgba(0, 0, 0, 255)), pxRange=4.0, sdThreshold=0.5))
+    tint = [rgba(255, 255, 0, 255), rgba(0, 255, 255, 255), rgba(255, 0, 255, 255), rgba(255, 255, 255, 255)]
+    glyphs = [Glyph(image_id=1000 + ord(ch), x=float(4 + 13 * i), y=float(20 - images[1000 + ord(ch)].shape[0]), colors=tint)
+              for i, ch in enumerate("figdraw!")]
+    lst.addRoot(Fig(kind=FigKind.nkText, screenBox=rect(285, 130, 120, 24), glyphs=glyphs))
+    lst.addRoot(Fig(kind=FigKind.nkText, screenBox=rect(285, 160, 120, 24), glyphs=glyphs, flags=FigFlags.NfInvertY))
+    c = lst.addRoot(Fig(kind=RECT, screenBox=rect(285, 195, 70, 55), fill=rgba(255, 255, 255, 255), corners=[18] * 4,
+                        flags=FigFlags.NfClipContent))
+    lst.addChild(c, Fig(kind=FigKind.nkImage, screenBox=rect(270, 185, 100, 100), image_id=3000))
+    out = Renders()
+    out.layers[0] = lst
+    return out
+
+
+# Atlas size used for the goldens: 256.  SwiftShader samples with 16-bit NORMALISED texture coordinates, i.e. only
+# 65536/atlasSize sub-texel steps; on a 1024 atlas that is 6 bits and MSDF edges (alpha slope = screenPxRange)
+# land up to 7 LSB away from exact bilinear filtering, at 256 the same scenes agree within 2 LSB (measured, see
+# DESIGN.md).  Texture-filter precision is implementation-defined in GL; the oracle and the HIP path filter in float.
+ATLAS_GOLDEN_SIZE = 256
+ATLAS_SCENES = {
+    "glyphs_small": (glyphs_small, 330, 90),
+    "images_and_msdf_variants": (images_and_msdf_variants, 360, 260),
+}
+
+
+def used_images(renders, images):
+    """The subset of `images` a scene references, in sorted-key order (the upload order every backend uses)."""
+    ids = set()
+    for lst in renders.layers.values():
+        for n in lst.nodes:
+            if n.image_id:
+                ids.add(n.image_id)
+            for g in n.glyphs:
+                ids.add(g.image_id)
+    return {k: images[k] for k in sorted(ids)}

@@ -145,3 +145,74 @@ def test_error_behaviour(hip):
     hip.draw_image(12345, (0, 0), [(255, 255, 255, 255)] * 4)
     hip.end_frame()
     assert (hip.read_pixels() == 255).all()
+
+
+def _atlas_ctx_pair(sc, images, atlas_size):
+    from figdraw_amd.context import HipContext
+    from oracle import oracle as O
+
+    ctx = HipContext(atlas_size=atlas_size, device=0)
+    o = O.Oracle(atlas_size=atlas_size, threads=8)
+    for k, img in images.items():
+        assert ctx.put_image(k, img) == o.put_image(k, img)  # same skyline packer, same rects
+    return ctx, o
+
+
+@pytest.mark.parametrize("name", sorted(RS.ATLAS_SCENES))
+def test_atlas_scenes_match_oracle_and_goldens(name):
+    import os
+
+    from conftest import GOLDEN
+    from figdraw_amd.scenes import load_glyph_fixture
+
+    fn, w, h = RS.ATLAS_SCENES[name]
+    all_images = load_glyph_fixture(os.path.join(GOLDEN, "glyphs_ubuntu20.npz"))
+    sc = fn(float(w), float(h), all_images)
+    ctx, o = _atlas_ctx_pair(sc, RS.used_images(sc, all_images), RS.ATLAS_GOLDEN_SIZE)
+    ctx.render_frame(sc, w, h)
+    o.render_frame(sc, w, h)
+    got = ctx.read_pixels()
+    mx, n0, n1 = diff_stats(got, o.read_pixels())
+    assert mx <= 1 and n0 <= 0.005 * w * h, (name, "vs oracle", mx, n0, n1)
+    mx, n0, n1 = diff_stats(got, load_png(f"ss_{name}.png"))
+    assert mx <= 3, (name, "vs reference GLSL on SwiftShader", mx, n0, n1)
+    ctx.close()
+
+
+def test_t10k_glyph_config_4k_matches_oracle():
+    """BASELINE config 4: 10 000 glyph quads (5 000 coverage glyphs 1:1 + 5 000 magnified MSDF) at 3840x2160."""
+    import os
+
+    from conftest import GOLDEN
+    from figdraw_amd.scenes import load_glyph_fixture, make_glyph_scene
+
+    w, h = 3840, 2160
+    all_images = load_glyph_fixture(os.path.join(GOLDEN, "glyphs_ubuntu20.npz"))
+    sc = make_glyph_scene(w, h, all_images)
+    ctx, o = _atlas_ctx_pair(sc, RS.used_images(sc, all_images), 1024)
+    ctx.render_frame(sc, w, h)
+    st = ctx.frame_stats()
+    assert st.n_draws == 10001
+    o.render_frame(sc, w, h)
+    mx, n0, n1 = diff_stats(ctx.read_pixels(), o.read_pixels())
+    assert mx <= 1 and n0 <= 0.005 * w * h, (mx, n0, n1)
+    ctx.close()
+
+
+def test_atlas_grow_and_update(hip):
+    """The atlas doubles when full (glcontext.nim:536-539) and drops its entries, like resetImageAtlas."""
+    from figdraw_amd.context import HipContext
+
+    ctx = HipContext(atlas_size=64, device=0)
+    assert ctx.atlas_size() == 64
+    ctx.put_image(1, np.full((20, 20, 4), 255, np.uint8))
+    assert ctx.has_image(1)
+    ctx.put_image(2, np.full((60, 60, 4), 128, np.uint8))  # needs 68 px: grows to 128
+    assert ctx.atlas_size() == 128 and ctx.has_image(2) and not ctx.has_image(1)
+    ctx.update_image(2, np.full((60, 60, 4), 255, np.uint8))
+    ctx.begin_frame(64, 64, True, (0, 0, 0, 1))
+    ctx.draw_image(2, (2, 2), [(255, 255, 255, 255)] * 4)
+    ctx.end_frame()
+    img = ctx.read_pixels()
+    assert (img[2:62, 2:62] == 255).all() and (img[0, 0] == [0, 0, 0, 255]).all()
+    ctx.close()

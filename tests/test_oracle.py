@@ -189,3 +189,36 @@ def test_gradient_colors_and_radii_packing():
     # elliptical: x=30,10,8,40 / y=30,20,8,80 on half extents (100.25, 60.125)
     r4, e = O.rounded_radii_vec([30, 10, 8, 40], [30, 20, 8, 80], 100.25, 60.125)
     assert e and r4 == [5579160.0, 16737890.0, -31.0, -9.0]
+
+
+@pytest.mark.parametrize("name", sorted(RS.ATLAS_SCENES))
+def test_oracle_atlas_sampling_matches_reference_shaders(name):
+    """Mode 0 (1:1 glyphs, magnified / minified / flipped images through the mip chain), MSDF / MTSDF / annular MSDF.
+    Tolerance 2 LSB: SwiftShader quantises texture coordinates to 16 normalised bits (ref_scenes.ATLAS_GOLDEN_SIZE)."""
+    import os
+
+    from conftest import GOLDEN
+    from figdraw_amd.scenes import load_glyph_fixture
+
+    fn, w, h = RS.ATLAS_SCENES[name]
+    all_images = load_glyph_fixture(os.path.join(GOLDEN, "glyphs_ubuntu20.npz"))
+    sc = fn(float(w), float(h), all_images)
+    o = O.Oracle(atlas_size=RS.ATLAS_GOLDEN_SIZE, threads=4)
+    for k, img in RS.used_images(sc, all_images).items():
+        o.put_image(k, img)
+    o.render_frame(sc, w, h)
+    mx, n0, n1 = diff_stats(o.read_pixels(), load_png(f"ss_{name}.png"))
+    assert mx <= 2 and n1 <= 0.001 * w * h, (name, mx, n0, n1)
+
+
+def test_atlas_packer_known_answers():
+    """findEmptyRect (glcontext.nim:541-579): skyline with margin 4; entries are packed pixel rects."""
+    o = O.Oracle(atlas_size=256)
+    a = o.put_image(1, np.zeros((10, 20, 4), np.uint8))   # first image lands at (margin, margin)
+    b = o.put_image(2, np.zeros((10, 20, 4), np.uint8))   # next free column run: x = 20 + 2*4 + 4
+    c = o.put_image(3, np.zeros((30, 200, 4), np.uint8))  # does not fit beside them: goes where the skyline is lowest
+    assert a == (4, 4, 20, 10)
+    assert b == (32, 4, 20, 10)
+    assert c[2:] == (200, 30) and c[0] >= 4 and c[1] >= 4
+    with pytest.raises(RuntimeError):
+        o.put_image(4, np.zeros((300, 300, 4), np.uint8))

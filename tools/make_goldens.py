@@ -55,6 +55,25 @@ def main():
             entry["swiftshader_vs_reference_png"] = stats(ss, exp)
         manifest[name] = entry
         print(name, entry)
+    # atlas scenes: images uploaded in sorted-key order into a 256^2 atlas (see ref_scenes.ATLAS_GOLDEN_SIZE)
+    from figdraw_amd.scenes import load_glyph_fixture
+
+    all_images = load_glyph_fixture(os.path.join(GOLD, "glyphs_ubuntu20.npz"))
+    for name, (fn, w, h) in RS.ATLAS_SCENES.items():
+        sc = fn(float(w), float(h), all_images)
+        images = RS.used_images(sc, all_images)
+        o = O.Oracle(atlas_size=RS.ATLAS_GOLDEN_SIZE, threads=8)
+        for k in sorted(images):
+            o.put_image(k, images[k])
+        o.record_begin()
+        o.render_frame(sc, w, h)
+        calls = o.record_calls()
+        img = o.read_pixels()
+        ss = R.replay(calls, w, h, atlas_size=RS.ATLAS_GOLDEN_SIZE, images=images)
+        Image.fromarray(ss).save(os.path.join(GOLD, f"ss_{name}.png"), optimize=True)
+        manifest[name] = {"width": w, "height": h, "n_calls": len(calls), "atlas_size": RS.ATLAS_GOLDEN_SIZE,
+                          "n_images": len(images), "oracle_vs_swiftshader": stats(img, ss)}
+        print(name, manifest[name])
     # blur-only vectors: random RGBA8 through blur.frag H+V at several radii
     rng = np.random.default_rng(7)
     src = rng.integers(0, 256, size=(64, 96, 4), dtype=np.uint8)
