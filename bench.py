@@ -141,6 +141,20 @@ def main():
         roofline_blur["ms_per_frame"] = round(blur_ms, 4)
         roofline_blur["algorithmic_bytes_per_frame"] = int(st.bytes_blur)
     frame_gbs = st.bytes_algorithmic / (ms_step * 1e-3) / 1e9
+    # HBM traffic per launch from PMC counters cannot be collected inside this process; it comes from the committed
+    # rocprofv3 --pmc passes over this very command (profiles/*_pmc_traffic.json, corrected as MI355X_MICROARCH.md
+    # prescribes) and is attached only when the workload is the one those passes profiled.
+    try:
+        import glob
+
+        pmc = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[-1]))["kernels"]
+        if (w, h) == (W, H) and 700 <= st.n_draws <= 715:
+            if roofline is not None:
+                roofline["traffic"] = pmc["k_composite_tiles.phase0"]["hbm_bytes"]
+            if roofline_blur is not None:
+                roofline_blur["traffic"] = sum(pmc[k]["hbm_bytes"] for k in pmc if k.startswith("k_blur_"))
+    except Exception:
+        pass
 
     cpu_baseline = None
     if world == 1 and not args.no_cpu_baseline:
