@@ -46,6 +46,8 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for the 1-GPU self-test)")
+    ap.add_argument("--all-ranks-on-device0", action="store_true", help="self-test of the N>1 code path on a 1-GPU box")
     ap.add_argument("--width", type=int, default=W)
     ap.add_argument("--height", type=int, default=H)
     args = ap.parse_args()
@@ -56,14 +58,20 @@ def main():
     import torch
 
     dist = None
+    if args.all_ranks_on_device0:
+        local_rank = 0
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
     else:
         torch.cuda.set_device(local_rank)
+    on_host = dist is not None and args.backend != "nccl"  # gloo moves tensors through host memory
 
     from figdraw_amd.context import HipContext
     from figdraw_amd.scenes import make_render_tree_100
@@ -93,7 +101,7 @@ def main():
         dist.barrier()
     elapsed = t1 - t0
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if on_host else f"cuda:{local_rank}")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     st_batch = ctx.frame_stats()
@@ -106,6 +114,8 @@ def main():
     gather_ms = None
     if dist is not None:
         mine = frame_tensor(ctx).contiguous()
+        if on_host:
+            mine = mine.cpu()
         outs = [torch.empty_like(mine) for _ in range(world)] if rank == 0 else None
         barrier()
         g0 = time.perf_counter()
