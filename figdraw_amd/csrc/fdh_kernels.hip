@@ -327,15 +327,28 @@ __device__ __forceinline__ void shape_distN(bool ellip, const float* px, float p
                                             float r3, float* out) {
   Corner c[N];
   float qx[N], qy[N];
-  bool need = false;
+  bool need = false, diag = false;
 #pragma unroll
   for (int k = 0; k < N; k++) {
     c[k] = pick_corner(ellip, px[k], py, bx, by, r0, r1, r2, r3);
     qx[k] = __builtin_fabsf(px[k]) - bx + c[k].rx;
     qy[k] = __builtin_fabsf(py) - by + c[k].ry;
+    const bool corner = qx[k] > 0.0f && qy[k] > 0.0f;
+    diag = diag || corner;
+    need = need || (!c[k].same && corner);
+  }
+  // length(max(q, 0)) only needs the (quarter-rate) sqrt where BOTH components are positive, i.e. in the corner
+  // arcs; elsewhere it is max(qx, qy, 0).  One wave-uniform branch skips the sqrt for every strip without an arc.
+  const bool any_diag = __any(diag);
+#pragma unroll
+  for (int k = 0; k < N; k++) {
     const float mx = __builtin_fmaxf(qx[k], 0.0f), my = __builtin_fmaxf(qy[k], 0.0f);
-    out[k] = __builtin_fminf(__builtin_fmaxf(qx[k], qy[k]), 0.0f) + fsqrt(mx * mx + my * my) - c[k].rx;
-    need = need || (!c[k].same && qx[k] > 0.0f && qy[k] > 0.0f);
+    float len = __builtin_fmaxf(mx, my);
+    if (any_diag) {  // wave-uniform
+      const float e = fsqrt(mx * mx + my * my);
+      len = (mx > 0.0f && my > 0.0f) ? e : len;
+    }
+    out[k] = __builtin_fminf(__builtin_fmaxf(qx[k], qy[k]), 0.0f) + len - c[k].rx;
   }
   if (!ellip) return;  // wave-uniform
   const bool any_ellipse = __any(need);
