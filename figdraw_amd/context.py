@@ -78,6 +78,9 @@ def load():
     L.fdh_draw_rounded_rect_fill.argtypes = [vp, _F4, C.POINTER(S.CFill), _F4, _F4, C.c_int, C.c_float, C.c_float, _F2]
     L.fdh_draw_image.argtypes = [vp, C.c_int64, _F2, _COL4, _F2, C.c_int]
     L.fdh_draw_msdf.argtypes = [vp, C.c_int64, _F2, S.CColor, _F2, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int]
+    L.fdh_draw_quadratic_bezier_sdf.argtypes = [vp, _F4, C.POINTER(S.CFill), _F2, _F2, _F2, C.c_float, C.c_int]
+    L.fdh_draw_filled_quad.argtypes = [vp, C.c_float * 8, _COL4]
+    L.fdh_draw_rect.argtypes = [vp, _F4, S.CColor]
     L.fdh_draw_backdrop_blur.argtypes = [vp, _F4, _F4, _F4, C.c_float]
     L.fdh_begin_mask.argtypes = [vp, _F4, _F4, _F4]
     L.fdh_end_mask.argtypes = [vp]
@@ -104,6 +107,7 @@ def load():
     L.fdh_get_frame_stats.argtypes = [vp, C.POINTER(FrameStats)]
     assert L.fdh_sizeof_fig() == C.sizeof(S.CFig), (L.fdh_sizeof_fig(), C.sizeof(S.CFig))
     assert L.fdh_sizeof_glyph() == C.sizeof(S.CGlyph)
+    assert L.fdh_sizeof_draw_op() == C.sizeof(S.CDrawOp)
     _lib = L
     return L
 
@@ -196,6 +200,17 @@ class HipContext:
     def draw_msdf(self, key, pos, color, size, px_range, sd_threshold=0.5, stroke_weight=0.0, mtsdf=False, flip_y=False):
         self._ck(self.L.fdh_draw_msdf(self.h, int(key), _F2(*pos), S.CColor(*color), _F2(*size), px_range, sd_threshold,
                                       stroke_weight, int(bool(mtsdf)), int(bool(flip_y))))
+
+    def draw_quadratic_bezier_sdf(self, rect, fill, p0, p1, p2, stroke_weight, cap):
+        cf = S.cfill(S.fill_from_json(fill))
+        self._ck(self.L.fdh_draw_quadratic_bezier_sdf(self.h, _F4(*rect), C.byref(cf), _F2(*p0), _F2(*p1), _F2(*p2),
+                                                      stroke_weight, int(cap)))
+
+    def draw_filled_quad(self, verts, colors):
+        self._ck(self.L.fdh_draw_filled_quad(self.h, (C.c_float * 8)(*verts), _cols(colors)))
+
+    def draw_rect(self, rect, color):
+        self._ck(self.L.fdh_draw_rect(self.h, _F4(*rect), S.CColor(*color)))
 
     def draw_backdrop_blur(self, rect, radii_x, radii_y, blur_radius):
         self._ck(self.L.fdh_draw_backdrop_blur(self.h, _F4(*rect), _F4(*radii_x), _F4(*radii_y), blur_radius))

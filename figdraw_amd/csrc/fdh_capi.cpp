@@ -37,6 +37,7 @@ const char* fdh_last_error(void) { return g_last_error.c_str(); }
 const char* fdh_version(void) { return "figdraw_hip 0.1.0 (gfx950)"; }
 int fdh_sizeof_fig(void) { return (int)sizeof(FdhFig); }
 int fdh_sizeof_glyph(void) { return (int)sizeof(FdhGlyph); }
+int fdh_sizeof_draw_op(void) { return (int)sizeof(FdhDrawOp); }
 
 int fdh_create(FdhContext** out, int atlas_size, float pixel_scale, int device, uint32_t flags) {
   return guard([&] {
@@ -104,12 +105,17 @@ int fdh_begin_rect_mask(FdhContext* c, const float rect[4], const float rx[4], c
   return guard([&] { C(c)->begin_rect_mask(rect, rx, ry ? ry : rx); });
 }
 int fdh_pop_rect_mask(FdhContext* c) { return guard([&] { C(c)->pop_rect_mask(); }); }
-int fdh_draw_quadratic_bezier_sdf(FdhContext* c, const float*, const FdhFill*, const float*, const float*, const float*, float, int) {
-  return guard([&] { (void)C(c); throw fdh::Error(FDH_ERR_UNSUPPORTED, "Backend drawQuadraticBezierSdf unavailable"); });
+int fdh_draw_quadratic_bezier_sdf(FdhContext* c, const float rect[4], const FdhFill* fill, const float p0[2], const float p1[2],
+                                  const float p2[2], float stroke_weight, int cap) {
+  return guard([&] {
+    if (!fill) throw fdh::Error(FDH_ERR_INVALID, "null fill");
+    C(c)->draw_quadratic_bezier_sdf(rect, *fill, p0, p1, p2, stroke_weight, cap);
+  });
 }
-int fdh_draw_filled_quad(FdhContext* c, const float*, const FdhColor*) {
-  return guard([&] { (void)C(c); throw fdh::Error(FDH_ERR_UNSUPPORTED, "Backend drawFilledQuad unavailable"); });
+int fdh_draw_filled_quad(FdhContext* c, const float verts[8], const FdhColor colors[4]) {
+  return guard([&] { C(c)->draw_filled_quad(verts, colors); });
 }
+int fdh_draw_rect(FdhContext* c, const float rect[4], FdhColor color) { return guard([&] { C(c)->draw_rect(rect, color); }); }
 int fdh_set_text_subpixel_positioning(FdhContext* c, int e) { return guard([&] { C(c)->set_subpixel_enabled(e != 0); }); }
 int fdh_set_text_subpixel_shift(FdhContext* c, float s) { return guard([&] { C(c)->set_subpixel_shift(s); }); }
 

@@ -181,8 +181,8 @@ void Context::restore_transform() {
 }
 void Context::translate(float x, float y) { Aff t; t.tx = x; t.ty = y; mat_ = aff_mul(mat_, t); }
 void Context::rotate(float a) {
-  Aff r;  // vmath rotateZ: column 0 = (cos, sin), column 1 = (-sin, cos)
-  r.a = std::cos(a); r.b = std::sin(a); r.c = -r.b; r.d = r.a;
+  Aff r;  // vmath rotateZ: column 0 = (cos, -sin), column 1 = (sin, cos); pinned by tests/expected/render_line_rect.png
+  r.a = std::cos(a); r.b = -std::sin(a); r.c = -r.b; r.d = r.a;
   mat_ = aff_mul(mat_, r);
 }
 void Context::scale(float sx, float sy) { Aff s; s.a = sx; s.d = sy; mat_ = aff_mul(mat_, s); }
@@ -251,15 +251,17 @@ static inline void bbox_union(BBox& a, const BBox& b) {
 // Quad emission: ceil(ctx.mat * corner) per vertex, order BL,BR,TR,TL (glcontext.nim:1498-1509), then either the
 // axis-aligned fast form or the two-triangle general form.
 void Context::emit_quad(DrawRec& r, float x0, float y0, float x1, float y1, int64_t* fragments) {
-  auto xf = [&](float x, float y, float* ox, float* oy) {
-    *ox = std::ceil(mat_.a * x + mat_.c * y + mat_.tx);
-    *oy = std::ceil(mat_.b * x + mat_.d * y + mat_.ty);
-  };
+  const float vx[4] = {x0, x1, x1, x0}, vy[4] = {y1, y1, y0, y0};  // BL, BR, TR, TL
+  emit_quad_pts(r, vx, vy, fragments);
+}
+
+// Four pre-transform vertices in the reference's vertex order 0..3 (triangles (3,0,1) and (2,3,1), glcontext.nim:418-429).
+void Context::emit_quad_pts(DrawRec& r, const float vx[4], const float vy[4], int64_t* fragments) {
   float px[4], py[4];
-  xf(x0, y1, &px[0], &py[0]);
-  xf(x1, y1, &px[1], &py[1]);
-  xf(x1, y0, &px[2], &py[2]);
-  xf(x0, y0, &px[3], &py[3]);
+  for (int i = 0; i < 4; i++) {
+    px[i] = std::ceil(mat_.a * vx[i] + mat_.c * vy[i] + mat_.tx);
+    py[i] = std::ceil(mat_.b * vx[i] + mat_.d * vy[i] + mat_.ty);
+  }
   float minx = px[0], maxx = px[0], miny = py[0], maxy = py[0];
   for (int i = 1; i < 4; i++) {
     minx = std::min(minx, px[i]); maxx = std::max(maxx, px[i]);
@@ -392,7 +394,7 @@ void Context::draw_rounded_rect_sdf(const float rect[4], const FdhColor colors[4
                                     float mid_pos) {
   if (!frame_begun_) throw Error(FDH_ERR_INVALID, "ctx.beginFrame has not been called.");
   if (rect[2] <= 0.0f || rect[3] <= 0.0f) return;
-  if (mode >= FDH_SDF_BEZIER_STROKE_AA) throw Error(FDH_ERR_UNSUPPORTED, "Backend drawQuadraticBezierSdf unavailable");
+  if (mode >= FDH_SDF_BEZIER_STROKE_AA) throw Error(FDH_ERR_INVALID, "bezier stroke modes go through drawQuadraticBezierSdf");
   DrawRec r;
   fill_sdf_rec(r, rect, colors, rx, ry, mode, factor, spread, shape, fill_mode, mid, stop, mid_pos, aa_);
   if (mode == FDH_SDF_BACKDROP_BLUR) r.op_mode |= F_SELF_BACKDROP;  // a bare mode-17 call has no snapshot of its own
@@ -493,6 +495,80 @@ void Context::draw_msdf(int64_t key, const float pos[2], FdhColor color, const f
   for (int i = 0; i < 4; i++) r.col[i] = pack_color(color);
   r.aa = aa_;
   emit_quad(r, pos[0], pos[1], pos[0] + size[0], pos[1] + size[1], &fragments_);
+}
+
+// drawQuadraticBezierSdf: glcontext.nim:1619-1741
+void Context::draw_quadratic_bezier_sdf(const float rect[4], const FdhFill& fill, const float p0[2], const float p1[2],
+                                        const float p2[2], float stroke_weight, int cap) {
+  if (!frame_begun_) throw Error(FDH_ERR_INVALID, "ctx.beginFrame has not been called.");
+  if (rect[2] <= 0.0f || rect[3] <= 0.0f || stroke_weight <= 0.0f) return;
+  DrawRec r;
+  std::memset(&r, 0, sizeof r);
+  r.p0 = rect[2] * 0.5f; r.p1 = rect[3] * 0.5f; r.p2 = p0[0]; r.p3 = p0[1];  // params = (quadHalf, p0)
+  r.r[0] = p1[0]; r.r[1] = p1[1]; r.r[2] = p2[0]; r.r[3] = p2[1];             // "radii" slot = (p1, p2)
+  FdhColor cols[4];
+  uint32_t fill_mode = 0;
+  if (fill.kind == FDH_FILL_LINEAR3) {
+    fill_mode = 1u + (uint32_t)(fill.axis & 3);
+    cols[0] = cols[1] = cols[2] = cols[3] = fill.start;
+    r.mid = pack_color(fill.mid);
+    r.stop = pack_color(fill.stop);
+  } else {
+    gradient_colors(fill, cols);
+  }
+  for (int i = 0; i < 4; i++) r.col[i] = pack_color(cols[i]);
+  r.f0 = stroke_weight;
+  r.f1 = fill_mode == 0 ? 0.0f : clampf(mid_pos01(fill), 0.01f, 0.99f);
+  r.aa = aa_;
+  const uint32_t mode = cap == FDH_CAP_BUTT ? FDH_SDF_BEZIER_STROKE_BUTT_AA
+                                            : (cap == FDH_CAP_SQUARE ? FDH_SDF_BEZIER_STROKE_SQUARE_AA : FDH_SDF_BEZIER_STROKE_AA);
+  r.op_mode = mode | (fill_mode << 9);
+  if (r.col[0] == r.col[1] && r.col[1] == r.col[2] && r.col[2] == r.col[3]) r.op_mode |= F_SOLID;
+  emit_quad(r, rect[0], rect[1], rect[0] + rect[2], rect[1] + rect[3], &fragments_);
+}
+
+// The 4x4 white "rect" atlas image drawRect / drawFilledQuad sample (glcontext.nim:966-970, 1411-1415); it takes
+// atlas space on first use exactly like the reference's.
+static constexpr int64_t kRectImageKey = 0x7265637452454354LL;
+const AtlasEntry& Context::rect_entry() {
+  auto it = entries_.find(kRectImageKey);
+  if (it == entries_.end()) {
+    uint8_t white[4 * 4 * 4];
+    std::memset(white, 255, sizeof white);
+    put_image(kRectImageKey, 4, 4, white, nullptr);
+    it = entries_.find(kRectImageKey);
+  }
+  return it->second;
+}
+static void white_texel_uv(const AtlasEntry& e, int atlas_size, DrawRec& r) {
+  const float S = (float)atlas_size;
+  const float ex = (float)e.x / S, ey = (float)e.y / S, ew = (float)e.w / S, eh = (float)e.h / S;
+  r.r[0] = r.r[2] = ex + ew / 2.0f;  // uvAt = uvTo = the image centre
+  r.r[1] = r.r[3] = ey + eh / 2.0f;
+}
+// drawFilledQuad: glcontext.nim:963-982 (+ drawQuad :908-961): an arbitrary quad textured with one white texel
+void Context::draw_filled_quad(const float verts[8], const FdhColor colors[4]) {
+  if (!frame_begun_) throw Error(FDH_ERR_INVALID, "ctx.beginFrame has not been called.");
+  DrawRec r;
+  std::memset(&r, 0, sizeof r);
+  r.op_mode = FDH_SDF_ATLAS;
+  white_texel_uv(rect_entry(), atlas_size_, r);
+  for (int i = 0; i < 4; i++) r.col[i] = pack_color(colors[i]);
+  if (r.col[0] == r.col[1] && r.col[1] == r.col[2] && r.col[2] == r.col[3]) r.op_mode |= F_SOLID;
+  r.aa = aa_;
+  const float vx[4] = {verts[0], verts[2], verts[4], verts[6]}, vy[4] = {verts[1], verts[3], verts[5], verts[7]};
+  emit_quad_pts(r, vx, vy, &fragments_);
+}
+// drawRect: glcontext.nim:1410-1426
+void Context::draw_rect(const float rect[4], FdhColor color) {
+  if (!frame_begun_) throw Error(FDH_ERR_INVALID, "ctx.beginFrame has not been called.");
+  DrawRec r;
+  std::memset(&r, 0, sizeof r);
+  r.op_mode = FDH_SDF_ATLAS | F_SOLID;
+  white_texel_uv(rect_entry(), atlas_size_, r);
+  for (int i = 0; i < 4; i++) r.col[i] = pack_color(color);
+  r.aa = aa_;
+  emit_quad(r, rect[0], rect[1], rect[0] + rect[2], rect[1] + rect[3], &fragments_);
 }
 
 // ------------------------------------------------------------------ masks (glcontext.nim:1873-1949)

@@ -107,6 +107,10 @@ class Context {
   void draw_image(int64_t key, const float pos[2], const FdhColor colors[4], const float size[2], bool flip_y);
   void draw_msdf(int64_t key, const float pos[2], FdhColor color, const float size[2], float px_range, float sd_threshold,
                  float stroke_weight, bool mtsdf, bool flip_y);
+  void draw_quadratic_bezier_sdf(const float rect[4], const FdhFill& fill, const float p0[2], const float p1[2], const float p2[2],
+                                 float stroke_weight, int cap);
+  void draw_filled_quad(const float verts[8], const FdhColor colors[4]);
+  void draw_rect(const float rect[4], FdhColor color);
   void draw_backdrop_blur(const float rect[4], const float rx[4], const float ry[4], float blur_radius);
   void begin_mask(const float rect[4], const float rx[4], const float ry[4]);
   void end_mask();
@@ -145,6 +149,8 @@ class Context {
  private:
   void push_rec(const DrawRec& r, const BBox& b);
   void emit_quad(DrawRec& r, float x0, float y0, float x1, float y1, int64_t* fragments);
+  void emit_quad_pts(DrawRec& r, const float vx[4], const float vy[4], int64_t* fragments);
+  const AtlasEntry& rect_entry();
   void upload_atlas_rect(int level, int x, int y, int w, int h, const uint8_t* rgba);
   void put_levels(int x, int y, int w, int h, const uint8_t* rgba);
   void alloc_atlas(int size);

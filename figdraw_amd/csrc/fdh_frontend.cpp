@@ -3,8 +3,10 @@
 // Restates figrender.nim's `renderFrame` (:1960-1995), `renderRoot` (:1946-1955) and the recursive
 // `render` (:1756-1839) whose stage order is fixed by the `renderStages` macro (:501-547): stages run
 // top-down, their `finally` blocks run in reverse after the children.
+#include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <vector>
 
 #include "fdh_context.h"
 
@@ -81,6 +83,338 @@ struct Walker {
       ctx.draw_rounded_rect_fill(box, stroke->fill, rx, ry, FDH_SDF_ANNULAR_AA, scaled(stroke->weight), 0.0f, shape);
   }
 
+
+  // ------------------------------------------------------------------ nkDrawable (figrender.nim:910-1667)
+  struct V2 { float x, y; };
+  struct Span { V2 p0, p1, p2; };
+  static V2 add(V2 a, V2 b) { return {a.x + b.x, a.y + b.y}; }
+  static V2 sub(V2 a, V2 b) { return {a.x - b.x, a.y - b.y}; }
+  static V2 mul(V2 a, float k) { return {a.x * k, a.y * k}; }
+  static float len(V2 v) { return std::sqrt(v.x * v.x + v.y * v.y); }
+  static V2 normalized_or(V2 v, V2 fb) { const float l = len(v); return l <= 0.000001f ? fb : V2{v.x / l, v.y / l}; }
+  static V2 normal_left(V2 d) { return {-d.y, d.x}; }
+  static float cross2(V2 a, V2 b) { return a.x * b.y - a.y * b.x; }
+  static float nround(float x) { return x >= 0.0f ? std::floor(x + 0.5f) : -std::floor(-x + 0.5f); }
+  static uint16_t radius_corner(float r) {  // :797-802
+    if (r <= 0.0f) return 0;
+    if (r >= 65535.0f) return 65535;
+    return (uint16_t)nround(r);
+  }
+  static constexpr int kMaxAdaptiveSteps = 192;  // max(DefaultDrawableBezierSteps * 4, 64)
+  static constexpr int kMaxCurveDepth = 8;
+
+  // renderRoundedShape on an explicit (unscaled) box: fill + optional stroke
+  void shape(const float box_unscaled[4], const FdhFill& fill, const FdhStroke* stroke, const float rx[4], const float ry[4]) {
+    float box[4];
+    for (int i = 0; i < 4; i++) box[i] = box_unscaled[i] * ui;
+    const float shp[2] = {0, 0};
+    const bool gradient = (fill.kind == FDH_FILL_LINEAR2 || fill.kind == FDH_FILL_LINEAR3) && fill_alpha_max(fill) > 0;
+    if (gradient) {
+      ctx.draw_rounded_rect_fill(box, fill, rx, ry, FDH_SDF_CLIP_AA, 4.0f, 0.0f, shp);
+    } else if (fill_alpha_max(fill) > 0) {
+      FdhFill solid = fill;
+      solid.kind = FDH_FILL_COLOR;
+      solid.start = sample_fill(fill, 0.5f);
+      ctx.draw_rounded_rect_fill(box, solid, rx, ry, FDH_SDF_CLIP_AA, 4.0f, 0.0f, shp);
+    }
+    if (stroke && fill_alpha_max(stroke->fill) > 0 && stroke->weight > 0.0f)
+      ctx.draw_rounded_rect_fill(box, stroke->fill, rx, ry, FDH_SDF_ANNULAR_AA, scaled(stroke->weight), 0.0f, shp);
+  }
+  void shape_u16(const float box[4], const FdhFill& fill, const FdhStroke* stroke, const uint16_t corners[4]) {
+    float rx[4];
+    for (int i = 0; i < 4; i++) rx[i] = scaled((float)corners[i]);
+    shape(box, fill, stroke, rx, rx);
+  }
+  void stroke_cap(V2 center, float radius, const FdhFill& fill) {  // renderDrawableStrokeCap :993-1005
+    if (radius <= 0.0f || fill_alpha_max(fill) == 0) return;
+    const float box[4] = {center.x - radius, center.y - radius, radius * 2.0f, radius * 2.0f};
+    const uint16_t rc = radius_corner(radius);
+    const uint16_t corners[4] = {rc, rc, rc, rc};
+    shape_u16(box, fill, nullptr, corners);
+  }
+  void line(V2 origin, V2 pa, V2 pb, const FdhStroke& stroke) {  // renderDrawableLine :943-991
+    const float weight = std::max(0.0f, stroke.weight);
+    if (weight <= 0.0f || fill_alpha_max(stroke.fill) == 0) return;
+    const V2 a = add(origin, pa), b = add(origin, pb), delta = sub(b, a);
+    const float length = len(delta);
+    if (length <= 0.0f) return;
+    const int cap = stroke.cap == FDH_CAP_AUTO ? FDH_CAP_BUTT : stroke.cap;
+    const float cap_radius = weight * 0.5f;
+    const V2 dir{delta.x / length, delta.y / length};
+    V2 da = a, db = b;
+    float dl = length;
+    if (cap == FDH_CAP_SQUARE) { da = sub(a, mul(dir, cap_radius)); db = add(b, mul(dir, cap_radius)); dl = length + weight; }
+    const V2 center{(da.x + db.x) / 2.0f, (da.y + db.y) / 2.0f};
+    const float box[4] = {center.x - dl / 2.0f, center.y - weight / 2.0f, dl, weight};
+    const float pvx = box[0] * ui + box[2] * ui / 2.0f, pvy = box[1] * ui + box[3] * ui / 2.0f;
+    ctx.save_transform();
+    ctx.translate(pvx, pvy);
+    ctx.rotate(std::atan2(delta.y, delta.x));
+    ctx.translate(-pvx, -pvy);
+    const uint16_t zero[4] = {0, 0, 0, 0};
+    shape_u16(box, stroke.fill, nullptr, zero);
+    ctx.restore_transform();
+    if (cap == FDH_CAP_ROUND) { stroke_cap(a, cap_radius, stroke.fill); stroke_cap(b, cap_radius, stroke.fill); }
+  }
+  void endpoint_cap(V2 origin, V2 point, V2 tangent, float radius, const FdhStroke& stroke, int cap, bool is_start) {  // :1007-1040
+    if (radius <= 0.0f || fill_alpha_max(stroke.fill) == 0) return;
+    if (cap == FDH_CAP_ROUND) { stroke_cap(add(origin, point), radius, stroke.fill); return; }
+    if (cap == FDH_CAP_SQUARE) {
+      const V2 dir = normalized_or(tangent, {1.0f, 0.0f});
+      const V2 a = is_start ? sub(point, mul(dir, radius)) : point;
+      const V2 b = is_start ? point : add(point, mul(dir, radius));
+      FdhStroke s2 = stroke;
+      s2.cap = FDH_CAP_BUTT;
+      line(origin, a, b, s2);
+    }
+  }
+  void filled_quad(const V2 v[4], const FdhFill& fill) {  // renderDrawableFilledQuad :1050-1058
+    if (fill_alpha_max(fill) == 0) return;
+    const FdhColor k = sample_fill(fill, 0.5f);
+    const FdhColor cols[4] = {k, k, k, k};
+    float vv[8];
+    for (int i = 0; i < 4; i++) { vv[2 * i] = v[i].x * ui; vv[2 * i + 1] = v[i].y * ui; }
+    ctx.draw_filled_quad(vv, cols);
+  }
+  void stroke_join(V2 origin, V2 point, V2 in_t, V2 out_t, float radius, const FdhFill& fill, int join) {  // :1060-1109
+    if (radius <= 0.0f || fill_alpha_max(fill) == 0) return;
+    if (join == FDH_JOIN_ROUND) { stroke_cap(add(origin, point), radius, fill); return; }
+    if (join != FDH_JOIN_BEVEL && join != FDH_JOIN_MITER) return;
+    const V2 incoming = normalized_or(in_t, {1.0f, 0.0f});
+    const V2 outgoing = normalized_or(out_t, incoming);
+    const float turn = cross2(incoming, outgoing);
+    if (std::fabs(turn) <= 0.0001f) return;
+    const float side = turn > 0.0f ? -1.0f : 1.0f;
+    const V2 in_outer = add(point, mul(normal_left(incoming), radius * side));
+    const V2 out_outer = add(point, mul(normal_left(outgoing), radius * side));
+    if (join == FDH_JOIN_MITER) {
+      const float denom = cross2(incoming, outgoing);  // lineIntersection :1042-1048
+      if (std::fabs(denom) > 0.000001f) {
+        const float t = cross2(sub(out_outer, in_outer), outgoing) / denom;
+        const V2 miter = add(in_outer, mul(incoming, t));
+        if (len(sub(miter, point)) <= radius * 4.0f) {
+          const V2 q[4] = {add(origin, point), add(origin, in_outer), add(origin, miter), add(origin, out_outer)};
+          filled_quad(q, fill);
+          return;
+        }
+      }
+    }
+    const V2 q[4] = {add(origin, point), add(origin, in_outer), add(origin, out_outer), add(origin, out_outer)};
+    filled_quad(q, fill);
+  }
+  static V2 bezier_point(const float* ctrl, int n, float t) {  // de Casteljau, bezierPoint :1139-1153
+    V2 work[32];
+    if (n <= 0) return {0, 0};
+    n = std::min(n, 32);
+    for (int i = 0; i < n; i++) work[i] = {ctrl[2 * i], ctrl[2 * i + 1]};
+    for (int count = n; count > 1; count--)
+      for (int i = 0; i < count - 1; i++) work[i] = add(mul(work[i], 1.0f - t), mul(work[i + 1], t));
+    return work[0];
+  }
+  static V2 quadratic_point(V2 p0, V2 p1, V2 p2, float t) {
+    const float it = 1.0f - t;
+    return add(add(mul(p0, it * it), mul(p1, 2.0f * it * t)), mul(p2, t * t));
+  }
+  static void quadratic_bounds(V2 p0, V2 p1, V2 p2, float pad, float out[4]) {  // :1177-1202
+    V2 mn{std::min(p0.x, p2.x), std::min(p0.y, p2.y)}, mx{std::max(p0.x, p2.x), std::max(p0.y, p2.y)};
+    auto include = [&](V2 q) { mn.x = std::min(mn.x, q.x); mn.y = std::min(mn.y, q.y); mx.x = std::max(mx.x, q.x); mx.y = std::max(mx.y, q.y); };
+    const float dx = p0.x - 2.0f * p1.x + p2.x;
+    if (std::fabs(dx) > 0.000001f) { const float t = (p0.x - p1.x) / dx; if (t > 0.0f && t < 1.0f) include(quadratic_point(p0, p1, p2, t)); }
+    const float dy = p0.y - 2.0f * p1.y + p2.y;
+    if (std::fabs(dy) > 0.000001f) { const float t = (p0.y - p1.y) / dy; if (t > 0.0f && t < 1.0f) include(quadratic_point(p0, p1, p2, t)); }
+    out[0] = mn.x - pad; out[1] = mn.y - pad; out[2] = mx.x - mn.x + pad * 2.0f; out[3] = mx.y - mn.y + pad * 2.0f;
+  }
+  static V2 start_tangent(const Span& s) { return normalized_or(sub(s.p1, s.p0), normalized_or(sub(s.p2, s.p0), {1.0f, 0.0f})); }
+  static V2 end_tangent(const Span& s) { return normalized_or(sub(s.p2, s.p1), normalized_or(sub(s.p2, s.p0), {1.0f, 0.0f})); }
+  static Span bezier_span(const float* ctrl, int n, float t0, float t2) {  // bezierQuadraticSpan :1238-1247
+    const float tm = (t0 + t2) * 0.5f;
+    Span s;
+    s.p0 = bezier_point(ctrl, n, t0);
+    const V2 pm = bezier_point(ctrl, n, tm);
+    s.p2 = bezier_point(ctrl, n, t2);
+    s.p1 = sub(mul(pm, 2.0f), mul(add(s.p0, s.p2), 0.5f));
+    return s;
+  }
+  void adaptive_spans(const float* ctrl, int n, float t0, float t2, int depth, std::vector<Span>& spans) {  // :1267-1282
+    const Span s = bezier_span(ctrl, n, t0, t2);
+    float err = 0.0f;
+    for (float lt : {0.25f, 0.75f}) {  // quadraticApproxErrorPx :1256-1265
+      const float t = t0 + (t2 - t0) * lt;
+      err = std::max(err, len(mul(sub(bezier_point(ctrl, n, t), quadratic_point(s.p0, s.p1, s.p2, lt)), ui)));
+    }
+    if (err <= 0.5f || depth >= kMaxCurveDepth || (int)spans.size() >= kMaxAdaptiveSteps - 1) { spans.push_back(s); return; }
+    const float tm = (t0 + t2) * 0.5f;
+    adaptive_spans(ctrl, n, t0, tm, depth + 1, spans);
+    adaptive_spans(ctrl, n, tm, t2, depth + 1, spans);
+  }
+  void quadratic_sdf(V2 origin, V2 p0, V2 p1, V2 p2, const FdhStroke& stroke, int cap) {  // renderDrawableQuadraticBezierSdf :1335-1376
+    const int rcap = cap == FDH_CAP_AUTO ? (stroke.cap == FDH_CAP_AUTO ? FDH_CAP_ROUND : stroke.cap) : cap;
+    if (std::fabs(cross2(sub(p1, p0), sub(p2, p1))) <= 0.0001f) {  // isFlatQuadratic
+      FdhStroke s2 = stroke;
+      s2.cap = rcap;
+      line(origin, p0, p2, s2);
+      return;
+    }
+    const float sw = std::max(0.0f, stroke.weight);
+    const float padding = sw * 0.5f + 2.0f / ui;  // DrawableSdfPaddingPx.descaled()
+    const V2 a = add(origin, p0), b = add(origin, p1), c = add(origin, p2);
+    float box[4];
+    quadratic_bounds(a, b, c, padding, box);
+    if (box[2] <= 0.0f || box[3] <= 0.0f) return;
+    const V2 center{box[0] + box[2] * 0.5f, box[1] + box[3] * 0.5f};
+    const float la[2] = {(a.x - center.x) * ui, (a.y - center.y) * ui}, lb[2] = {(b.x - center.x) * ui, (b.y - center.y) * ui};
+    const float lc[2] = {(c.x - center.x) * ui, (c.y - center.y) * ui};
+    const float sbox[4] = {box[0] * ui, box[1] * ui, box[2] * ui, box[3] * ui};
+    ctx.draw_quadratic_bezier_sdf(sbox, stroke.fill, la, lb, lc, sw * ui, rcap);
+  }
+  void draw_spans(V2 origin, const std::vector<Span>& spans, const FdhStroke& stroke) {  // :1412-1455, :1548-1604
+    const int cap = stroke.cap == FDH_CAP_AUTO ? FDH_CAP_ROUND : stroke.cap;
+    const int join = stroke.join == FDH_JOIN_AUTO ? FDH_JOIN_ROUND : stroke.join;
+    const bool simple = cap == FDH_CAP_ROUND && join == FDH_JOIN_ROUND;
+    const int span_cap = simple ? FDH_CAP_ROUND : FDH_CAP_BUTT;
+    const float cap_radius = std::max(0.0f, stroke.weight) / 2.0f;
+    const int n = (int)spans.size();
+    for (int i = 0; i < n; i++) {
+      quadratic_sdf(origin, spans[i].p0, spans[i].p1, spans[i].p2, stroke, span_cap);
+      if (simple) continue;
+      if (i == 0) endpoint_cap(origin, spans[i].p0, start_tangent(spans[i]), cap_radius, stroke, cap, true);
+      else stroke_join(origin, spans[i].p0, end_tangent(spans[i - 1]), start_tangent(spans[i]), cap_radius, stroke.fill, join);
+      if (i == n - 1) endpoint_cap(origin, spans[i].p2, end_tangent(spans[i]), cap_radius, stroke, cap, false);
+    }
+  }
+  static int explicit_steps(uint16_t steps, uint16_t node_steps) {  // :1204-1210
+    if (steps != 0) return std::max<int>(1, steps);
+    if (node_steps != 0) return std::max<int>(1, node_steps);
+    return 0;
+  }
+  void segment_points(const float* ctrl, int n, float t0, float t2, int depth, std::vector<V2>& pts) {  // :1297-1313
+    const V2 p0 = bezier_point(ctrl, n, t0), p2 = bezier_point(ctrl, n, t2);
+    const float tm = (t0 + t2) * 0.5f;
+    const V2 P = mul(bezier_point(ctrl, n, tm), ui), A = mul(p0, ui), B = mul(p2, ui), ab = sub(B, A);
+    const float denom = ab.x * ab.x + ab.y * ab.y;
+    float err;
+    if (denom <= 0.000001f) err = len(sub(P, A));
+    else {
+      const float h = std::min(std::max(((P.x - A.x) * ab.x + (P.y - A.y) * ab.y) / denom, 0.0f), 1.0f);
+      err = len(sub(P, add(A, mul(ab, h))));
+    }
+    if (err <= 0.5f || depth >= kMaxCurveDepth || (int)pts.size() >= kMaxAdaptiveSteps) { pts.push_back(p2); return; }
+    segment_points(ctrl, n, t0, tm, depth + 1, pts);
+    segment_points(ctrl, n, tm, t2, depth + 1, pts);
+  }
+  void bezier_segments(V2 origin, const float* ctrl, int n, uint16_t steps, const FdhStroke& stroke, uint16_t node_steps) {  // :1378-1410
+    if (n < 2 || stroke.weight <= 0.0f || fill_alpha_max(stroke.fill) == 0) return;
+    std::vector<V2> pts;
+    const int fixed = explicit_steps(steps, node_steps);
+    pts.push_back(bezier_point(ctrl, n, 0.0f));
+    if (fixed > 0) for (int s = 1; s <= fixed; s++) pts.push_back(bezier_point(ctrl, n, (float)s / (float)fixed));
+    else segment_points(ctrl, n, 0.0f, 1.0f, 0, pts);
+    if (pts.size() < 2) return;
+    const int cap = stroke.cap == FDH_CAP_AUTO ? FDH_CAP_ROUND : stroke.cap;
+    const int join = stroke.join == FDH_JOIN_AUTO ? FDH_JOIN_ROUND : stroke.join;
+    const float cap_radius = std::max(0.0f, stroke.weight) / 2.0f;
+    FdhStroke seg = stroke;
+    seg.cap = FDH_CAP_BUTT;
+    V2 prev = pts[0], prev_t{1.0f, 0.0f};
+    for (size_t s = 1; s < pts.size(); s++) {
+      const V2 cur = pts[s], tan = sub(cur, prev);
+      line(origin, prev, cur, seg);
+      if (s == 1) endpoint_cap(origin, prev, tan, cap_radius, stroke, cap, true);
+      else stroke_join(origin, prev, prev_t, tan, cap_radius, stroke.fill, join);
+      if (s == pts.size() - 1) endpoint_cap(origin, cur, tan, cap_radius, stroke, cap, false);
+      prev = cur;
+      prev_t = tan;
+    }
+  }
+  void drawable_ops(const FdhFig& n) {  // renderDrawableOps :1627-1645
+    const V2 origin{n.box[0], n.box[1]};
+    const FdhStroke& stroke = n.draw_stroke;
+    for (int oi = n.op_first; oi < n.op_first + n.op_count && oi < scene.n_ops; oi++) {
+      const FdhDrawOp& op = scene.ops[oi];
+      switch (op.kind) {
+        case FDH_DK_LINE: line(origin, {op.v[0], op.v[1]}, {op.v[2], op.v[3]}, stroke); break;
+        case FDH_DK_CIRCLE: {  // :1111-1125
+          const float r = std::max(0.0f, op.v[2]);
+          if (r <= 0.0f) break;
+          const float box[4] = {origin.x + op.v[0] - r, origin.y + op.v[1] - r, r * 2.0f, r * 2.0f};
+          const uint16_t rc = radius_corner(r);
+          const uint16_t corners[4] = {rc, rc, rc, rc};
+          shape_u16(box, n.fill, &stroke, corners);
+          break;
+        }
+        case FDH_DK_RECTANGLE: {  // :1127-1131
+          const float box[4] = {origin.x + op.v[0], origin.y + op.v[1], op.v[2], op.v[3]};
+          shape_u16(box, n.fill, &stroke, op.corners);
+          break;
+        }
+        case FDH_DK_ELLIPSE: {  // :1606-1625
+          const float rx0 = std::max(0.0f, op.v[2]), ry0 = std::max(0.0f, op.v[3]);
+          if (rx0 <= 0.0f || ry0 <= 0.0f) break;
+          const float box[4] = {origin.x + op.v[0] - rx0, origin.y + op.v[1] - ry0, rx0 * 2.0f, ry0 * 2.0f};
+          float rx[4], ry[4];
+          for (int i = 0; i < 4; i++) { rx[i] = scaled(rx0); ry[i] = scaled(ry0); }
+          shape(box, n.fill, &stroke, rx, ry);
+          break;
+        }
+        case FDH_DK_BEZIER: {  // renderDrawableBezier :1457-1486
+          const int nc = op.ctrl_count;
+          if (nc < 2 || op.ctrl_first < 0 || op.ctrl_first + nc > scene.n_controls) break;
+          const float* ctrl = scene.controls + 2 * op.ctrl_first;
+          if (stroke.weight <= 0.0f || fill_alpha_max(stroke.fill) == 0) break;
+          if (nc == 3) {
+            quadratic_sdf(origin, {ctrl[0], ctrl[1]}, {ctrl[2], ctrl[3]}, {ctrl[4], ctrl[5]}, stroke,
+                          stroke.cap == FDH_CAP_AUTO ? FDH_CAP_ROUND : stroke.cap);
+          } else if (nc > 3) {
+            std::vector<Span> spans;
+            const int fixed = explicit_steps(op.steps, n.draw_steps);
+            if (fixed > 0) for (int st = 0; st < fixed; st++) spans.push_back(bezier_span(ctrl, nc, (float)st / (float)fixed, (float)(st + 1) / (float)fixed));
+            else adaptive_spans(ctrl, nc, 0.0f, 1.0f, 0, spans);
+            draw_spans(origin, spans, stroke);
+          } else {
+            bezier_segments(origin, ctrl, nc, op.steps, stroke, n.draw_steps);
+          }
+          break;
+        }
+        case FDH_DK_ARC: {  // renderDrawableArc :1606-1625, arcQuadraticSpan :1531-1546, adaptiveArcStepCount :1315-1333
+          const float radius = std::max(0.0f, op.v[2]), start = op.v[3], sweep = op.v[4];
+          if (radius <= 0.0f || sweep == 0.0f || stroke.weight <= 0.0f || fill_alpha_max(stroke.fill) == 0) break;
+          int steps = explicit_steps(op.steps, n.draw_steps);
+          if (steps <= 0) {
+            const float rpx = std::max(0.0f, scaled(radius)), asw = std::fabs(sweep);
+            if (rpx <= 0.0f || asw <= 0.0f) steps = 1;
+            else {
+              const float cl = std::min(std::max(1.0f - 0.5f / rpx, -1.0f), 1.0f);
+              const float max_angle = std::max(0.01f, 2.0f * std::acos(cl));
+              steps = std::min(std::max((int)std::ceil(asw / max_angle), 1), kMaxAdaptiveSteps);
+            }
+          }
+          std::vector<Span> spans;
+          const V2 cen{op.v[0], op.v[1]};
+          for (int st = 0; st < steps; st++) {
+            const float t0 = (float)st / (float)steps, t2 = (float)(st + 1) / (float)steps, tm = (t0 + t2) * 0.5f;
+            const float a0 = start + sweep * t0, a2 = start + sweep * t2, am = start + sweep * tm;
+            Span sp;
+            sp.p0 = add(cen, {std::cos(a0) * radius, std::sin(a0) * radius});
+            const V2 pm = add(cen, {std::cos(am) * radius, std::sin(am) * radius});
+            sp.p2 = add(cen, {std::cos(a2) * radius, std::sin(a2) * radius});
+            sp.p1 = sub(mul(pm, 2.0f), mul(add(sp.p0, sp.p2), 0.5f));
+            spans.push_back(sp);
+          }
+          draw_spans(origin, spans, stroke);
+          break;
+        }
+        default: break;
+      }
+    }
+  }
+  void drawable(const FdhFig& n) {  // renderDrawable :1647-1667
+    if (n.draw_aa <= 0.0f || ctx.aa() == n.draw_aa) { drawable_ops(n); return; }
+    const float old = ctx.aa();
+    ctx.set_aa(n.draw_aa);
+    drawable_ops(n);
+    ctx.set_aa(old);
+  }
+
   void text(const FdhFig& n) {  // renderText :417-497, glyph loop (layout happened on the caller's side)
     ctx.save_transform();
     ctx.translate(scaled(n.box[0]), scaled(n.box[1]));
@@ -151,8 +485,7 @@ struct Walker {
         if (fill_alpha_max(n.fill) != 0) rounded_shape(n, n.fill, nullptr);
         break;
       }
-      case FDH_NK_DRAWABLE:
-        throw Error(FDH_ERR_UNSUPPORTED, "nkDrawable (lines / circles / beziers) is not on the implemented path yet");
+      case FDH_NK_DRAWABLE: drawable(n); break;
       default: break;  // nkFrame / nkScrollBar / nkTransform draw nothing themselves
     }
     if (n.kind == FDH_NK_RECTANGLE) inner_shadows(n);

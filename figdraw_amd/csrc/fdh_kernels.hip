@@ -94,6 +94,72 @@ __device__ __forceinline__ float shadow_profile(float sd, float blur_radius) {
   float z = sd * frcp(sigma);
   return fexp2(-0.72134752044f * z * z);
 }
+// sdBezier atlas.frag:121-160 (exact quadratic-Bezier distance: cubic solve).  Rare path: libm-quality functions.
+__device__ __forceinline__ float sd_bezier(float px, float py, float Ax, float Ay, float Bx, float By, float Cx, float Cy) {
+  const float ax = Bx - Ax, ay = By - Ay;
+  const float bx = Ax - 2.0f * Bx + Cx, by = Ay - 2.0f * By + Cy;
+  const float bb = bx * bx + by * by;
+  if (bb <= 0.000001f) {
+    const float bax = Cx - Ax, bay = Cy - Ay;
+    const float h = clamp01(((px - Ax) * bax + (py - Ay) * bay) / __builtin_fmaxf(bax * bax + bay * bay, 0.000001f));
+    const float dx = px - (Ax + bax * h), dy = py - (Ay + bay * h);
+    return __builtin_sqrtf(dx * dx + dy * dy);
+  }
+  const float cx = ax * 2.0f, cy = ay * 2.0f;
+  const float dx = Ax - px, dy = Ay - py;
+  const float kk = 1.0f / bb;
+  const float kx = kk * (ax * bx + ay * by);
+  const float ky = kk * (2.0f * (ax * ax + ay * ay) + (dx * bx + dy * by)) / 3.0f;
+  const float kz = kk * (dx * ax + dy * ay);
+  const float p = ky - kx * kx;
+  const float p3 = p * p * p;
+  const float q = kx * (2.0f * kx * kx - 3.0f * ky) + kz;
+  float h = q * q + 4.0f * p3;
+  float res;
+  if (h >= 0.0f) {
+    h = __builtin_sqrtf(h);
+    const float x0 = (h - q) / 2.0f, x1 = (-h - q) / 2.0f;
+    const float r0 = __builtin_copysignf(powf(__builtin_fabsf(x0), 1.0f / 3.0f), x0) * (x0 == 0.0f ? 0.0f : 1.0f);
+    const float r1 = __builtin_copysignf(powf(__builtin_fabsf(x1), 1.0f / 3.0f), x1) * (x1 == 0.0f ? 0.0f : 1.0f);
+    const float t = clamp01(r0 + r1 - kx);
+    const float ex = dx + (cx + bx * t) * t, ey = dy + (cy + by * t) * t;
+    res = ex * ex + ey * ey;
+  } else {
+    const float z = __builtin_sqrtf(-p);
+    const float v = acosf(__builtin_fminf(__builtin_fmaxf(q / (p * z * 2.0f), -1.0f), 1.0f)) / 3.0f;
+    const float m = cosf(v);
+    const float n = sinf(v) * 1.732050808f;
+    const float t1 = clamp01((m + m) * z - kx);
+    const float t2 = clamp01((-n - m) * z - kx);
+    const float e1x = dx + (cx + bx * t1) * t1, e1y = dy + (cy + by * t1) * t1;
+    const float e2x = dx + (cx + bx * t2) * t2, e2y = dy + (cy + by * t2) * t2;
+    res = __builtin_fminf(e1x * e1x + e1y * e1y, e2x * e2x + e2y * e2y);
+  }
+  return __builtin_sqrtf(res);
+}
+__device__ __forceinline__ void safe_normalize(float x, float y, float fx, float fy, float& ox, float& oy) {  // atlas.frag:174-177
+  const float len = __builtin_sqrtf(x * x + y * y);
+  if (len <= 0.000001f) { ox = fx; oy = fy; } else { ox = x / len; oy = y / len; }
+}
+// bezierStrokeSd atlas.frag:179-209
+__device__ __forceinline__ float bezier_stroke_sd(float dist, float px, float py, float Ax, float Ay, float Bx, float By, float Cx, float Cy,
+                                                  float half_w, uint32_t mode) {
+  if (mode == 18u) return dist - half_w;
+  float fx, fy, sx, sy, ex, ey;
+  safe_normalize(Cx - Ax, Cy - Ay, 1.0f, 0.0f, fx, fy);
+  safe_normalize(Bx - Ax, By - Ay, fx, fy, sx, sy);
+  safe_normalize(Cx - Bx, Cy - By, fx, fy, ex, ey);
+  const float start_proj = (px - Ax) * sx + (py - Ay) * sy;
+  const float end_proj = (px - Cx) * ex + (py - Cy) * ey;
+  const float trim = mode == 20u ? half_w : 0.0f;
+  float tube = dist;
+  if (mode == 20u) {
+    if (start_proj < 0.0f) tube = __builtin_fminf(tube, __builtin_fabsf((px - Ax) * sy - (py - Ay) * sx));
+    if (end_proj > 0.0f) tube = __builtin_fminf(tube, __builtin_fabsf((px - Cx) * ey - (py - Cy) * ex));
+  }
+  const float cap = __builtin_fmaxf(-start_proj - trim, end_proj - trim);
+  return __builtin_fmaxf(tube - half_w, cap);
+}
 __device__ __forceinline__ float median3(float a, float b, float c) {  // atlas.frag:41-43
   return __builtin_fmaxf(__builtin_fminf(a, b), __builtin_fminf(__builtin_fmaxf(a, b), c));
 }
@@ -437,10 +503,17 @@ __device__ __forceinline__ Src shade_one(const DrawRec* __restrict__ rp, const Q
   const bool inset = mode == 9u;
   const float shx = inset ? qhx : r.p2, shy = inset ? qhy : r.p3;
   const float lx = (f.u - 0.5f) * 2.0f * qhx, ly = (f.v - 0.5f) * 2.0f * qhy;
-  const float dist = shape_dist(ellip, lx, -ly, shx, shy, r.r[0], r.r[1], r.r[2], r.r[3]);
+  const bool bezier = mode >= 18u && mode <= 20u;  // isBezierStrokeMode atlas.frag:162-168 (p is NOT y-flipped here)
+  const float dist = bezier ? sd_bezier(lx, ly, r.p2, r.p3, r.r[0], r.r[1], r.r[2], r.r[3])
+                            : shape_dist(ellip, lx, -ly, shx, shy, r.r[0], r.r[1], r.r[2], r.r[3]);
   const float spread = fill_mode == 0u ? r.f1 : 0.0f;
   float alpha;
   switch (mode) {
+    case 18u: case 19u: case 20u: {  // atlas.frag:321-336
+      const float sd = bezier_stroke_sd(dist, lx, ly, r.p2, r.p3, r.r[0], r.r[1], r.r[2], r.r[3], __builtin_fmaxf(r.f0, 0.0f) * 0.5f, mode);
+      alpha = 1.0f - clamp01(r.aa * sd + 0.5f);
+      break;
+    }
     case 11u: { float h = r.f0 * 0.5f; float sd = __builtin_fabsf(dist + h) - h; alpha = sd < 0.0f ? 1.0f : 0.0f; break; }
     case 12u: { float h = r.f0 * 0.5f; float sd = __builtin_fabsf(dist + h) - h; alpha = 1.0f - clamp01(r.aa * sd + 0.5f); break; }
     case 7u: { float sd = dist - spread; alpha = sd > 0.0f ? __builtin_fminf(shadow_profile(sd, r.f0), 1.0f) : 1.0f; break; }
@@ -562,7 +635,7 @@ __global__ __launch_bounds__(256, 4) void k_composite_tiles(const DrawRec* __res
       }
       if (op == OP_RMASK_END) { rm0 = rm1 = rm2 = rm3 = 1.0f; return; }
       const bool atlas_mode = (mode == 0u) || (mode >= 13u && mode <= 16u);
-      const bool fast = !(om & F_GENERAL) && !atlas_mode && (op == OP_DRAW || op == OP_MASK_PUSH);
+      const bool fast = !(om & F_GENERAL) && !atlas_mode && mode < 18u && (op == OP_DRAW || op == OP_MASK_PUSH);
       if (!fast) {
         // ---- one pixel slot at a time, state rotated so slot 0 is always the live one
         uint32_t packed = 0;

@@ -64,6 +64,29 @@ class FillGradientAxis(enum.IntEnum):  # filltypes.nim:12-16
     fgaDiagBLTR = 3
 
 
+class DrawableKind(enum.IntEnum):  # fignodes.nim:13-19
+    dkLine = 0
+    dkCircle = 1
+    dkRectangle = 2
+    dkBezier = 3
+    dkArc = 4
+    dkEllipse = 5
+
+
+class StrokeCap(enum.IntEnum):  # figbasics.nim:66-70
+    scAuto = 0
+    scRound = 1
+    scButt = 2
+    scSquare = 3
+
+
+class StrokeJoin(enum.IntEnum):  # figbasics.nim:72-76
+    sjAuto = 0
+    sjRound = 1
+    sjBevel = 2
+    sjMiter = 3
+
+
 class SdfMode(enum.IntEnum):  # figbackend.nim:36-52
     sdfModeAtlas = 0
     sdfModeClipAA = 3
@@ -113,6 +136,13 @@ def linear(start: RGBA, *rest, axis: FillGradientAxis = FillGradientAxis.fgaX, m
     raise TypeError("linear(start, stop) or linear(start, mid, stop)")
 
 
+def fill_from_json(d) -> Fill:
+    """A Fill from the dict form used in recorded call streams ({kind, axis, start, mid, stop, mid_pos})."""
+    if isinstance(d, Fill):
+        return d
+    return Fill(FillKind(d["kind"]), FillGradientAxis(d["axis"]), tuple(d["start"]), tuple(d["mid"]), tuple(d["stop"]), int(d["mid_pos"]))
+
+
 def _as_fill(v) -> Fill:
     if isinstance(v, Fill):
         return v
@@ -149,6 +179,39 @@ class Glyph:
 
 
 @dataclass
+class DrawableOp:  # fignodes.nim:21-42
+    kind: DrawableKind
+    v: Sequence[float] = ()
+    corners: Sequence[int] = (0, 0, 0, 0)
+    controls: Sequence[Tuple[float, float]] = ()
+    steps: int = 0
+
+
+def drawableLine(a, b) -> DrawableOp:  # fignodes.nim:234-238
+    return DrawableOp(DrawableKind.dkLine, (a[0], a[1], b[0], b[1]))
+
+
+def drawableCircle(center, radius) -> DrawableOp:
+    return DrawableOp(DrawableKind.dkCircle, (center[0], center[1], radius))
+
+
+def drawableEllipse(center, radii) -> DrawableOp:
+    return DrawableOp(DrawableKind.dkEllipse, (center[0], center[1], radii[0], radii[1]))
+
+
+def drawableRect(box, corners=(0, 0, 0, 0)) -> DrawableOp:
+    return DrawableOp(DrawableKind.dkRectangle, tuple(box), corners=tuple(corners))
+
+
+def drawableBezier(controls, steps: int = 0) -> DrawableOp:  # `steps = 0` inherits drawSteps or is adaptive
+    return DrawableOp(DrawableKind.dkBezier, controls=[tuple(c) for c in controls], steps=steps)
+
+
+def drawableArc(center, radius, startAngle, sweepAngle, steps: int = 0) -> DrawableOp:
+    return DrawableOp(DrawableKind.dkArc, (center[0], center[1], radius, startAngle, sweepAngle), steps=steps)
+
+
+@dataclass
 class Fig:  # fignodes.nim:54-92
     kind: FigKind = FigKind.nkFrame
     zlevel: int = 0
@@ -172,10 +235,15 @@ class Fig:  # fignodes.nim:54-92
     matrix: Optional[Sequence[float]] = None  # 16 floats, column-major
     useMatrix: bool = False
     glyphs: List[Glyph] = field(default_factory=list)
+    drawStroke: RenderStroke = field(default_factory=RenderStroke)
+    drawSteps: int = 0
+    drawAa: float = 0.0
+    drawOps: List[DrawableOp] = field(default_factory=list)
 
     def __post_init__(self):
         self.fill = _as_fill(self.fill)
         self.stroke.fill = _as_fill(self.stroke.fill)
+        self.drawStroke.fill = _as_fill(self.drawStroke.fill)
         for s in self.shadows:
             s.fill = _as_fill(s.fill)
 
@@ -263,7 +331,14 @@ class CFig(C.Structure):
         ("sd_threshold", C.c_float), ("stroke_weight", C.c_float), ("blur", C.c_float),
         ("translation", C.c_float * 2), ("matrix", C.c_float * 16), ("use_matrix", C.c_int32),
         ("glyph_first", C.c_int32), ("glyph_count", C.c_int32),
+        ("draw_stroke", CStroke), ("draw_steps", C.c_uint16), ("_pad0", C.c_uint16), ("draw_aa", C.c_float),
+        ("op_first", C.c_int32), ("op_count", C.c_int32),
     ]
+
+
+class CDrawOp(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("steps", C.c_uint16), ("corners", C.c_uint16 * 4), ("_pad", C.c_uint16),
+                ("v", C.c_float * 6), ("ctrl_first", C.c_int32), ("ctrl_count", C.c_int32)]
 
 
 class CGlyph(C.Structure):
@@ -278,7 +353,8 @@ class CLayer(C.Structure):
 
 class CSceneStruct(C.Structure):
     _fields_ = [("layers", C.POINTER(CLayer)), ("glyphs", C.POINTER(CGlyph)), ("n_layers", C.c_int32),
-                ("n_glyphs", C.c_int32)]
+                ("n_glyphs", C.c_int32), ("ops", C.POINTER(CDrawOp)), ("controls", C.POINTER(C.c_float)),
+                ("n_ops", C.c_int32), ("n_controls", C.c_int32)]
 
 
 def _ccolor(c: RGBA) -> CColor:
@@ -304,6 +380,7 @@ class CScene:
 
     def __init__(self, renders: Renders):
         glyphs: List[Glyph] = []
+        ops: List[DrawableOp] = []
         self._keep = []
         layers = (CLayer * max(1, len(renders.layers)))()
         for li, (z, lst) in enumerate(renders.layers.items()):
@@ -341,6 +418,15 @@ class CScene:
                 cn.glyph_first = len(glyphs)
                 cn.glyph_count = len(n.glyphs)
                 glyphs.extend(n.glyphs)
+                cn.draw_stroke.weight = float(n.drawStroke.weight)
+                cn.draw_stroke.fill = cfill(n.drawStroke.fill)
+                cn.draw_stroke.cap = int(n.drawStroke.cap)
+                cn.draw_stroke.join = int(n.drawStroke.join)
+                cn.draw_steps = int(n.drawSteps)
+                cn.draw_aa = float(n.drawAa)
+                cn.op_first = len(ops)
+                cn.op_count = len(n.drawOps)
+                ops.extend(n.drawOps)
             roots = (C.c_int32 * max(1, len(lst.rootIds)))(*lst.rootIds)
             self._keep += [nodes, roots]
             L = layers[li]
@@ -356,12 +442,48 @@ class CScene:
             for k in range(4):
                 cg[i].colors[k] = _ccolor(g.colors[k])
             cg[i].subpixel_shift = float(g.subpixel_shift)
-        self._keep += [layers, cg]
+        cops = (CDrawOp * max(1, len(ops)))()
+        ctrl: List[float] = []
+        for i, op in enumerate(ops):
+            cops[i].kind = int(op.kind)
+            cops[i].steps = int(op.steps)
+            cops[i].corners = (C.c_uint16 * 4)(*[int(v) for v in op.corners])
+            vv = [float(x) for x in op.v] + [0.0] * (6 - len(op.v))
+            cops[i].v = (C.c_float * 6)(*vv)
+            cops[i].ctrl_first = len(ctrl) // 2
+            cops[i].ctrl_count = len(op.controls)
+            for (x, y) in op.controls:
+                ctrl += [float(x), float(y)]
+        cctrl = (C.c_float * max(1, len(ctrl)))(*ctrl)
+        self._keep += [layers, cg, cops, cctrl]
         self.struct = CSceneStruct()
         self.struct.layers = C.cast(layers, C.POINTER(CLayer))
         self.struct.glyphs = C.cast(cg, C.POINTER(CGlyph))
         self.struct.n_layers = len(renders.layers)
         self.struct.n_glyphs = len(glyphs)
+        self.struct.ops = C.cast(cops, C.POINTER(CDrawOp))
+        self.struct.controls = C.cast(cctrl, C.POINTER(C.c_float))
+        self.struct.n_ops = len(ops)
+        self.struct.n_controls = len(ctrl) // 2
 
     def byref(self):
         return C.byref(self.struct)
+
+
+def figLine(a, b, fill_, weight: float, zlevel: int = 0) -> Fig:
+    """figextras.nim:3-19: a stroked line as an nkDrawable whose box bounds the segment + half the weight."""
+    hw = max(0.0, float(weight)) / 2.0
+    x, y = min(a[0], b[0]) - hw, min(a[1], b[1]) - hw
+    box = (x, y, abs(b[0] - a[0]) + hw * 2.0, abs(b[1] - a[1]) + hw * 2.0)
+    f = Fig(kind=FigKind.nkDrawable, zlevel=zlevel, screenBox=box, fill=_as_fill(fill_),
+            drawStroke=RenderStroke(weight=float(weight), fill=_as_fill(fill_)))
+    f.drawOps.append(drawableLine((a[0] - x, a[1] - y), (b[0] - x, b[1] - y)))
+    return f
+
+
+def figCircle(center, fill_, radius: float, zlevel: int = 0) -> Fig:
+    """figextras.nim:32-44."""
+    r = max(0.0, float(radius))
+    f = Fig(kind=FigKind.nkDrawable, zlevel=zlevel, fill=_as_fill(fill_), screenBox=(center[0] - r, center[1] - r, 2 * r, 2 * r))
+    f.drawOps.append(drawableCircle((r, r), r))
+    return f

@@ -104,7 +104,27 @@ typedef struct {
   float matrix[16];           /* column-major (vmath Mat4 memory order) */
   int32_t use_matrix;
   int32_t glyph_first, glyph_count; /* nkText: range into FdhScene.glyphs */
+  FdhStroke draw_stroke;            /* nkDrawable: drawStroke (fignodes.nim:78-82) */
+  uint16_t draw_steps;              /*             drawSteps: default step count for curve ops, 0 = adaptive */
+  uint16_t _pad0;
+  float draw_aa;                    /*             drawAa: SDF AA factor override, <= 0 = keep the backend's */
+  int32_t op_first, op_count;       /*             drawOps: range into FdhScene.ops */
 } FdhFig;
+
+/* DrawableOp (fignodes.nim:13-42).  `v` holds, by kind: line a.xy b.xy | circle center.xy radius | rectangle
+ * box x,y,w,h | arc center.xy radius startAngle sweepAngle | ellipse center.xy radii.xy.  Bezier control points
+ * are pairs of floats in FdhScene.controls[ctrl_first .. ctrl_first + ctrl_count). */
+enum { FDH_DK_LINE = 0, FDH_DK_CIRCLE = 1, FDH_DK_RECTANGLE = 2, FDH_DK_BEZIER = 3, FDH_DK_ARC = 4, FDH_DK_ELLIPSE = 5 };
+enum { FDH_CAP_AUTO = 0, FDH_CAP_ROUND = 1, FDH_CAP_BUTT = 2, FDH_CAP_SQUARE = 3 };    /* StrokeCap figbasics.nim:66-70 */
+enum { FDH_JOIN_AUTO = 0, FDH_JOIN_ROUND = 1, FDH_JOIN_BEVEL = 2, FDH_JOIN_MITER = 3 }; /* StrokeJoin :72-76 */
+typedef struct {
+  int32_t kind;
+  uint16_t steps;      /* dkBezier.steps / dkArc.arcSteps */
+  uint16_t corners[4]; /* dkRectangle.corners TL,TR,BL,BR */
+  uint16_t _pad;
+  float v[6];
+  int32_t ctrl_first, ctrl_count;
+} FdhDrawOp;
 
 /* One positioned glyph quad: what figrender.nim:456-496 hands to drawImage after typesetting
  * (typesetting / glyph rasterisation are CPU pre-processing done by the caller). */
@@ -116,7 +136,16 @@ typedef struct {
 } FdhGlyph;
 
 typedef struct { int32_t zlevel; int32_t n_nodes; int32_t n_roots; int32_t _pad; const FdhFig* nodes; const int32_t* root_ids; } FdhLayer;
-typedef struct { const FdhLayer* layers; const FdhGlyph* glyphs; int32_t n_layers; int32_t n_glyphs; } FdhScene;
+typedef struct {
+  const FdhLayer* layers;
+  const FdhGlyph* glyphs;
+  int32_t n_layers;
+  int32_t n_glyphs;
+  const FdhDrawOp* ops;  /* nkDrawable ops of all nodes */
+  const float* controls; /* x,y pairs of all bezier ops */
+  int32_t n_ops;
+  int32_t n_controls;    /* number of POINTS */
+} FdhScene;
 
 /* ------------------------------------------------------------------ lifetime */
 /* newContext(atlasSize, ..., pixelScale): glcontext.nim:255-261.  device = HIP ordinal. */
@@ -160,11 +189,14 @@ FDH_API int fdh_end_mask(FdhContext*);                                          
 FDH_API int fdh_pop_mask(FdhContext*);                                                                         /* popMask :616, glcontext.nim:1927-1930 */
 FDH_API int fdh_begin_rect_mask(FdhContext*, const float rect[4], const float radii_x[4], const float radii_y[4]); /* :619-623, glcontext.nim:1932-1943 */
 FDH_API int fdh_pop_rect_mask(FdhContext*);                                                                     /* :625, glcontext.nim:1945-1949 */
-/* drawQuadraticBezierSdf / drawFilledQuad / drawRect / drawImageAdj (figbackend.nim:499-520) belong to the
- * drawable path, a SURVEY.md 8(f) "next" row: they report FDH_ERR_UNSUPPORTED like the reference's base methods. */
+/* drawQuadraticBezierSdf(rect, fill, p0, p1, p2, strokeWeight, cap) figbackend.nim:512-520, glcontext.nim:1619-1741;
+ * p0..p2 are relative to the rect centre. */
 FDH_API int fdh_draw_quadratic_bezier_sdf(FdhContext*, const float rect[4], const FdhFill* fill, const float p0[2],
                                           const float p1[2], const float p2[2], float stroke_weight, int cap);
+/* drawFilledQuad(verts, colors) figbackend.nim:507, glcontext.nim:963-982; verts = x0,y0 .. x3,y3 */
 FDH_API int fdh_draw_filled_quad(FdhContext*, const float verts[8], const FdhColor colors[4]);
+/* drawRect(rect, color) figbackend.nim:504, glcontext.nim:1410-1426 */
+FDH_API int fdh_draw_rect(FdhContext*, const float rect[4], FdhColor color);
 
 /* text flags: figbackend.nim:663-686 */
 FDH_API int fdh_set_text_subpixel_positioning(FdhContext*, int enabled);
@@ -220,6 +252,7 @@ FDH_API int fdh_profile(FdhContext*, int times);
 FDH_API int fdh_get_frame_stats(FdhContext*, FdhFrameStats* out);
 FDH_API int fdh_sizeof_fig(void);
 FDH_API int fdh_sizeof_glyph(void);
+FDH_API int fdh_sizeof_draw_op(void);
 FDH_API const char* fdh_version(void);
 
 #ifdef __cplusplus

@@ -11,8 +11,8 @@
  *
  * Third-party arithmetic that is not under /root/reference and is restated from
  * its published definition ("parity unpinned" for these two items only):
- *   - vmath (any version, figdraw.nimble:20): Mat4 column-major, rotateZ(a) =
- *     [[cos,-sin],[sin,cos]] (vmath >= 2.0), translate/scale/ortho/inverse.
+ *   - vmath (any version, figdraw.nimble:20): Mat4 column-major, translate/scale/ortho/inverse; rotateZ(a) maps
+ *     (x, y) to (cos x + sin y, -sin x + cos y) -- this one IS pinned, by tests/expected/render_line_rect.png.
  *   - pixie >= 5.0.1 Image.minifyBy2 used for atlas mip levels
  *     (opengl/textures.nim:106-119): 2x2 box average, (sum+2) div 4.
  */
@@ -133,6 +133,74 @@ static float linear3_t(int fill_mode, float u, float v) {
     default: return 0.0f;
   }
 }
+/* atlas.frag:121-160 */
+static float sd_bezier(float px, float py, v2 A, v2 B, v2 C) {
+  float ax = B.x - A.x, ay = B.y - A.y;
+  float bx = A.x - 2.0f * B.x + C.x, by = A.y - 2.0f * B.y + C.y;
+  float bb = bx * bx + by * by;
+  if (bb <= 0.000001f) {
+    float bax = C.x - A.x, bay = C.y - A.y;
+    float h = clampf(((px - A.x) * bax + (py - A.y) * bay) / maxf(bax * bax + bay * bay, 0.000001f), 0.0f, 1.0f);
+    float dx = px - (A.x + bax * h), dy = py - (A.y + bay * h);
+    return sqrtf(dx * dx + dy * dy);
+  }
+  float cx = ax * 2.0f, cy = ay * 2.0f;
+  float dx = A.x - px, dy = A.y - py;
+  float kk = 1.0f / bb;
+  float kx = kk * (ax * bx + ay * by);
+  float ky = kk * (2.0f * (ax * ax + ay * ay) + (dx * bx + dy * by)) / 3.0f;
+  float kz = kk * (dx * ax + dy * ay);
+  float p = ky - kx * kx;
+  float p3 = p * p * p;
+  float q = kx * (2.0f * kx * kx - 3.0f * ky) + kz;
+  float h = q * q + 4.0f * p3;
+  float res;
+  if (h >= 0.0f) {
+    h = sqrtf(h);
+    float x0 = (h - q) / 2.0f, x1 = (-h - q) / 2.0f;
+    float r0 = (x0 > 0.0f ? 1.0f : (x0 < 0.0f ? -1.0f : 0.0f)) * powf(fabsf(x0), 1.0f / 3.0f);
+    float r1 = (x1 > 0.0f ? 1.0f : (x1 < 0.0f ? -1.0f : 0.0f)) * powf(fabsf(x1), 1.0f / 3.0f);
+    float t = clampf(r0 + r1 - kx, 0.0f, 1.0f);
+    float ex = dx + (cx + bx * t) * t, ey = dy + (cy + by * t) * t;
+    res = ex * ex + ey * ey;
+  } else {
+    float z = sqrtf(-p);
+    float v = acosf(clampf(q / (p * z * 2.0f), -1.0f, 1.0f)) / 3.0f;
+    float m = cosf(v);
+    float n = sinf(v) * 1.732050808f;
+    float t1 = clampf((m + m) * z - kx, 0.0f, 1.0f);
+    float t2 = clampf((-n - m) * z - kx, 0.0f, 1.0f);
+    float e1x = dx + (cx + bx * t1) * t1, e1y = dy + (cy + by * t1) * t1;
+    float e2x = dx + (cx + bx * t2) * t2, e2y = dy + (cy + by * t2) * t2;
+    res = minf(e1x * e1x + e1y * e1y, e2x * e2x + e2y * e2y);
+  }
+  return sqrtf(res);
+}
+static v2 safe_normalize(float x, float y, v2 fallback) { /* atlas.frag:174-177 */
+  float len = sqrtf(x * x + y * y);
+  v2 r;
+  if (len <= 0.000001f) return fallback;
+  r.x = x / len; r.y = y / len;
+  return r;
+}
+/* atlas.frag:179-209 */
+static float bezier_stroke_sd(float dist, float px, float py, v2 A, v2 B, v2 C, float half_w, int mode) {
+  if (mode == 18) return dist - half_w;
+  v2 one = {1.0f, 0.0f};
+  v2 fallback = safe_normalize(C.x - A.x, C.y - A.y, one);
+  v2 st = safe_normalize(B.x - A.x, B.y - A.y, fallback);
+  v2 et = safe_normalize(C.x - B.x, C.y - B.y, fallback);
+  float start_proj = (px - A.x) * st.x + (py - A.y) * st.y;
+  float end_proj = (px - C.x) * et.x + (py - C.y) * et.y;
+  float trim = mode == 20 ? half_w : 0.0f;
+  float tube = dist;
+  if (mode == 20) {
+    if (start_proj < 0.0f) tube = minf(tube, fabsf((px - A.x) * st.y - (py - A.y) * st.x));
+    if (end_proj > 0.0f) tube = minf(tube, fabsf((px - C.x) * et.y - (py - C.y) * et.x));
+  }
+  float cap = maxf(-start_proj - trim, end_proj - trim);
+  return maxf(tube - half_w, cap);
+}
 static float median3(float a, float b, float c) { return maxf(minf(a, b), minf(maxf(a, b), c)); } /* atlas.frag:41-43 */
 
 /* ------------------------------------------------------------------ L4 state */
@@ -180,6 +248,7 @@ void fo_set_threads(int n) { g_threads = n < 1 ? 1 : n; }
 void fo_set_ui_scale(FoCtx* c, float s) { c->ui_scale = s; }
 int fo_sizeof_fig(void) { return (int)sizeof(FoFig); }
 int fo_sizeof_glyph(void) { return (int)sizeof(FoGlyph); }
+int fo_sizeof_draw_op(void) { return (int)sizeof(FoDrawOp); }
 
 /* ------------------------------------------------------------------ recorder */
 static void rec_printf(FoCtx* c, const char* fmt, ...) {
@@ -275,7 +344,9 @@ void fo_translate(FoCtx* c, float x, float y) {
 void fo_rotate(FoCtx* c, float a) {
   rec_open(c, "rotate"); rec_f(c, a); rec_close(c);
   float cs = cosf(a), sn = sinf(a);
-  Aff r = {cs, sn, -sn, cs, 0, 0}; /* vmath rotateZ: col0=(cos,sin) col1=(-sin,cos) */
+  /* vmath rotateZ: m[0,1] = -sin, m[1,0] = sin, i.e. column 0 = (cos, -sin), column 1 = (sin, cos): x' = cos x + sin y,
+   * y' = -sin x + cos y.  Pinned by the reference golden tests/expected/render_line_rect.png (a line drawn as a rotated box). */
+  Aff r = {cs, -sn, sn, cs, 0, 0};
   c->mat = aff_mul(c->mat, r);
 }
 void fo_scale(FoCtx* c, float sx, float sy) {
@@ -491,7 +562,10 @@ static v4 shade_main(const FoCtx* c, const Quad* q, const Frag* f, int x, int y)
   int inset = mode == 9;
   float shx = inset ? qhx : q->params.z, shy = inset ? qhy : q->params.w;
   float px = (f->u - 0.5f) * 2.0f * qhx, py = (f->v - 0.5f) * 2.0f * qhy;
-  float dist = ellip ? sd_elliptical_rounded_box(px, -py, shx, shy, q->radii) : sd_rounded_box(px, -py, shx, shy, q->radii);
+  int bezier = mode >= 18 && mode <= 20; /* isBezierStrokeMode atlas.frag:162-168 */
+  v2 bA = {q->params.z, q->params.w}, bB = {q->radii.x, q->radii.y}, bC = {q->radii.z, q->radii.w};
+  float dist = bezier ? sd_bezier(px, py, bA, bB, bC)
+                      : (ellip ? sd_elliptical_rounded_box(px, -py, shx, shy, q->radii) : sd_rounded_box(px, -py, shx, shy, q->radii));
   float sdf_factor = q->factor0;
   float sdf_spread = fill_mode == 0 ? q->factor1 : 0.0f;
   /* evalFillColor atlas.frag:233-250 */
@@ -538,6 +612,11 @@ static v4 shade_main(const FoCtx* c, const Quad* q, const Frag* f, int x, int y)
     return out;
   }
   switch (mode) {
+    case 18: case 19: case 20: { /* atlas.frag:321-336 */
+      float sd = bezier_stroke_sd(dist, px, py, bA, bB, bC, maxf(sdf_factor, 0.0f) * 0.5f, mode);
+      alpha = 1.0f - clampf(c->aa * sd + 0.5f, 0.0f, 1.0f);
+      break;
+    }
     case 11: { float h = sdf_factor * 0.5f; float sd = fabsf(dist + h) - h; alpha = sd < 0.0f ? 1.0f : 0.0f; break; }
     case 12: { float h = sdf_factor * 0.5f; float sd = fabsf(dist + h) - h; alpha = 1.0f - clampf(c->aa * sd + 0.5f, 0.0f, 1.0f); break; }
     case 7: { float sd = dist - sdf_spread; float a = shadow_profile(sd, sdf_factor); alpha = sd > 0.0f ? minf(a, 1.0f) : 1.0f; break; }
@@ -843,6 +922,83 @@ void fo_draw_msdf(FoCtx* c, int64_t key, const float pos[2], FoColor color, cons
   draw_uv_quad(c, pos[0], pos[1], pos[0] + size[0], pos[1] + size[1], at, to, cols, mode, params, px_range, sd_threshold);
 }
 
+/* drawQuadraticBezierSdf: glcontext.nim:1619-1741 */
+void fo_draw_quadratic_bezier_sdf(FoCtx* c, const float rect[4], const FoFill* fill, const float p0[2], const float p1[2],
+                                  const float p2[2], float stroke_weight, int cap) {
+  rec_open(c, "draw_quadratic_bezier_sdf");
+  rec_fv(c, rect, 4);
+  rec_printf(c, ",{\"kind\":%d,\"axis\":%d,\"start\":[%d,%d,%d,%d],\"mid\":[%d,%d,%d,%d],\"stop\":[%d,%d,%d,%d],\"mid_pos\":%d}", fill->kind,
+             fill->axis, fill->start.r, fill->start.g, fill->start.b, fill->start.a, fill->mid.r, fill->mid.g, fill->mid.b, fill->mid.a,
+             fill->stop.r, fill->stop.g, fill->stop.b, fill->stop.a, fill->mid_pos);
+  rec_fv(c, p0, 2); rec_fv(c, p1, 2); rec_fv(c, p2, 2); rec_f(c, stroke_weight); rec_i(c, cap);
+  rec_close(c);
+  if (rect[2] <= 0.0f || rect[3] <= 0.0f || stroke_weight <= 0.0f) return;
+  Quad q;
+  memset(&q, 0, sizeof q);
+  float x = rect[0], y = rect[1], w = rect[2], h = rect[3];
+  q.params.x = w * 0.5f; q.params.y = h * 0.5f; q.params.z = p0[0]; q.params.w = p0[1];
+  q.radii.x = p1[0]; q.radii.y = p1[1]; q.radii.z = p2[0]; q.radii.w = p2[1];
+  q.pos[0] = ceil_xf(c, x, y + h); q.pos[1] = ceil_xf(c, x + w, y + h);
+  q.pos[2] = ceil_xf(c, x + w, y); q.pos[3] = ceil_xf(c, x, y);
+  q.uv[0].x = 0; q.uv[0].y = 1; q.uv[1].x = 1; q.uv[1].y = 1; q.uv[2].x = 1; q.uv[2].y = 0; q.uv[3].x = 0; q.uv[3].y = 0;
+  int fill_mode = 0;
+  FoColor cols[4];
+  if (fill->kind == FO_FILL_LINEAR3) {
+    fill_mode = 1 + fill->axis;
+    cols[0] = cols[1] = cols[2] = cols[3] = fill->start;
+    q.mid = col_to_v4(fill->mid); q.stop = col_to_v4(fill->stop);
+  } else {
+    fo_gradient_colors(fill, cols);
+  }
+  for (int i = 0; i < 4; i++) q.col[i] = col_to_v4(cols[i]);
+  q.factor0 = stroke_weight;
+  q.factor1 = fill_mode == 0 ? 0.0f : clampf(fill_mid_pos01(fill), 0.01f, 0.99f);
+  int mode = cap == FO_CAP_BUTT ? 19 : (cap == FO_CAP_SQUARE ? 20 : 18); /* bezierStrokeSdfMode figbackend.nim:54-58 */
+  q.mode_word = mode + fill_mode * 256;
+  q.subpixel_shift = active_subpixel_shift(c);
+  draw_quad(c, &q);
+}
+
+/* the 4x4 white "rect" atlas image both drawRect and drawFilledQuad sample (glcontext.nim:966-970,1411-1415) */
+#define FO_RECT_IMAGE_KEY 0x7265637452454354LL
+static AtlasEntry* rect_entry(FoCtx* c) {
+  AtlasEntry* e = find_entry(c, FO_RECT_IMAGE_KEY);
+  if (!e) {
+    uint8_t white[4 * 4 * 4];
+    memset(white, 255, sizeof white);
+    fo_put_image(c, FO_RECT_IMAGE_KEY, 4, 4, white, NULL);
+    e = find_entry(c, FO_RECT_IMAGE_KEY);
+  }
+  return e;
+}
+/* drawFilledQuad: glcontext.nim:963-982 + drawQuad :908-961 */
+void fo_draw_filled_quad(FoCtx* c, const float verts[8], const FoColor colors[4]) {
+  rec_open(c, "draw_filled_quad"); rec_fv(c, verts, 8); rec_cols(c, colors); rec_close(c);
+  AtlasEntry* e = rect_entry(c);
+  if (!e) return;
+  Quad q;
+  memset(&q, 0, sizeof q);
+  float u = e->x + e->w / 2.0f, v = e->y + e->h / 2.0f;
+  for (int i = 0; i < 4; i++) {
+    q.pos[i] = ceil_xf(c, verts[2 * i], verts[2 * i + 1]);
+    q.uv[i].x = u; q.uv[i].y = v;
+    q.col[i] = col_to_v4(colors[i]);
+  }
+  q.mode_word = 0;
+  q.subpixel_shift = active_subpixel_shift(c);
+  draw_quad(c, &q);
+}
+/* drawRect: glcontext.nim:1410-1426 */
+void fo_draw_rect(FoCtx* c, const float rect[4], FoColor color) {
+  rec_open(c, "draw_rect"); rec_fv(c, rect, 4); rec_col(c, color); rec_close(c);
+  AtlasEntry* e = rect_entry(c);
+  if (!e) return;
+  v2 uvc = {e->x + e->w / 2.0f, e->y + e->h / 2.0f};
+  FoColor cols[4] = {color, color, color, color};
+  v4 z = {0, 0, 0, 0};
+  draw_uv_quad(c, rect[0], rect[1], rect[0] + rect[2], rect[1] + rect[3], uvc, uvc, cols, 0, z, 0.0f, 0.0f);
+}
+
 /* ------------------------------------------------------------------ masks: glcontext.nim:1873-1949 */
 void fo_begin_mask(FoCtx* c, const float rect[4], const float rx[4], const float ry[4]) {
   rec_open(c, "begin_mask"); rec_fv(c, rect, 4); rec_fv(c, rx, 4); rec_fv(c, ry, 4); rec_close(c);
@@ -1034,6 +1190,334 @@ static void render_rounded_shape(FoCtx* c, const float box_unscaled[4], const Fo
     fo_draw_rounded_rect_fill(c, box, &stroke->fill, rx, ry, 12, scaled(c, stroke->weight), 0.0f, shape);
 }
 
+
+/* ------------------------------------------------------------------ L2: nkDrawable (figrender.nim:910-1667) */
+typedef struct { v2 p0, p1, p2; } QSpan;
+static v2 v2mk(float x, float y) { v2 r = {x, y}; return r; }
+static v2 v2add(v2 a, v2 b) { return v2mk(a.x + b.x, a.y + b.y); }
+static v2 v2sub(v2 a, v2 b) { return v2mk(a.x - b.x, a.y - b.y); }
+static v2 v2mul(v2 a, float s) { return v2mk(a.x * s, a.y * s); }
+static float v2len(v2 v) { return sqrtf(v.x * v.x + v.y * v.y); }                  /* vectorLength :910-911 */
+static v2 normalized_or(v2 v, v2 fb) { float l = v2len(v); return l <= 0.000001f ? fb : v2mk(v.x / l, v.y / l); } /* :913-918 */
+static v2 normal_left(v2 d) { return v2mk(-d.y, d.x); }
+static float cross2f(v2 a, v2 b) { return a.x * b.y - a.y * b.x; }
+static float descaled(const FoCtx* c, float v) { return v / c->ui_scale; }
+static uint16_t radius_corner(float r) { /* :797-802 */
+  if (r <= 0.0f) return 0;
+  if (r >= 65535.0f) return 65535;
+  return (uint16_t)nim_round(r);
+}
+
+typedef struct { FoCtx* c; const FoScene* sc; } DrawEnv;
+
+static void shape_u16(FoCtx* c, const float box[4], const FoFill* fill, const FoStroke* stroke, const uint16_t corners[4]) {
+  float rx[4];
+  for (int i = 0; i < 4; i++) rx[i] = scaled(c, (float)corners[i]);
+  render_rounded_shape(c, box, fill, stroke, rx, rx);
+}
+static void draw_stroke_cap(FoCtx* c, v2 center, float radius, const FoFill* fill) { /* renderDrawableStrokeCap :993-1005 */
+  if (radius <= 0.0f || fill_alpha_max(fill) == 0) return;
+  float d = radius * 2.0f;
+  float box[4] = {center.x - radius, center.y - radius, d, d};
+  uint16_t rc = radius_corner(radius);
+  uint16_t corners[4] = {rc, rc, rc, rc};
+  shape_u16(c, box, fill, NULL, corners);
+}
+static void draw_line(FoCtx* c, v2 origin, v2 pa, v2 pb, const FoStroke* stroke) { /* renderDrawableLine :943-991 */
+  float weight = maxf(0.0f, stroke->weight);
+  if (weight <= 0.0f || fill_alpha_max(&stroke->fill) == 0) return;
+  v2 a = v2add(origin, pa), b = v2add(origin, pb), delta = v2sub(b, a);
+  float length = v2len(delta);
+  if (length <= 0.0f) return;
+  int cap = stroke->cap == FO_CAP_AUTO ? FO_CAP_BUTT : stroke->cap; /* resolveLineCap */
+  float cap_radius = weight * 0.5f;
+  v2 dir = v2mk(delta.x / length, delta.y / length);
+  v2 da = a, db = b;
+  float dl = length;
+  if (cap == FO_CAP_SQUARE) { da = v2sub(a, v2mul(dir, cap_radius)); db = v2add(b, v2mul(dir, cap_radius)); dl = length + weight; }
+  v2 center = v2mk((da.x + db.x) / 2.0f, (da.y + db.y) / 2.0f);
+  float box[4] = {center.x - dl / 2.0f, center.y - weight / 2.0f, dl, weight};
+  float sb[4] = {box[0] * c->ui_scale, box[1] * c->ui_scale, box[2] * c->ui_scale, box[3] * c->ui_scale};
+  float pvx = sb[0] + sb[2] / 2.0f, pvy = sb[1] + sb[3] / 2.0f;
+  float angle = atan2f(delta.y, delta.x);
+  fo_save_transform(c);
+  fo_translate(c, pvx, pvy);
+  fo_rotate(c, angle);
+  fo_translate(c, -pvx, -pvy);
+  uint16_t zero[4] = {0, 0, 0, 0};
+  shape_u16(c, box, &stroke->fill, NULL, zero);
+  fo_restore_transform(c);
+  if (cap == FO_CAP_ROUND) { draw_stroke_cap(c, a, cap_radius, &stroke->fill); draw_stroke_cap(c, b, cap_radius, &stroke->fill); }
+}
+static void draw_endpoint_cap(FoCtx* c, v2 origin, v2 point, v2 tangent, float radius, const FoStroke* stroke, int cap, int is_start) { /* :1007-1040 */
+  if (radius <= 0.0f || fill_alpha_max(&stroke->fill) == 0) return;
+  if (cap == FO_CAP_ROUND) { draw_stroke_cap(c, v2add(origin, point), radius, &stroke->fill); return; }
+  if (cap == FO_CAP_SQUARE) {
+    v2 dir = normalized_or(tangent, v2mk(1.0f, 0.0f));
+    v2 a = is_start ? v2sub(point, v2mul(dir, radius)) : point;
+    v2 b = is_start ? point : v2add(point, v2mul(dir, radius));
+    FoStroke s2 = *stroke;
+    s2.cap = FO_CAP_BUTT;
+    draw_line(c, origin, a, b, &s2);
+  }
+}
+static void draw_filled_quad_l2(FoCtx* c, const v2 verts[4], const FoFill* fill) { /* renderDrawableFilledQuad :1050-1058 */
+  if (fill_alpha_max(fill) == 0) return;
+  FoColor k = sample_color(fill, 0.5f);
+  FoColor cols[4] = {k, k, k, k};
+  float vv[8];
+  for (int i = 0; i < 4; i++) { vv[2 * i] = verts[i].x * c->ui_scale; vv[2 * i + 1] = verts[i].y * c->ui_scale; }
+  fo_draw_filled_quad(c, vv, cols);
+}
+static void draw_stroke_join(FoCtx* c, v2 origin, v2 point, v2 in_t, v2 out_t, float radius, const FoFill* fill, int join) { /* :1060-1109 */
+  if (radius <= 0.0f || fill_alpha_max(fill) == 0) return;
+  if (join == FO_JOIN_ROUND) { draw_stroke_cap(c, v2add(origin, point), radius, fill); return; }
+  if (join != FO_JOIN_BEVEL && join != FO_JOIN_MITER) return;
+  v2 incoming = normalized_or(in_t, v2mk(1.0f, 0.0f));
+  v2 outgoing = normalized_or(out_t, incoming);
+  float turn = cross2f(incoming, outgoing);
+  if (fabsf(turn) <= 0.0001f) return;
+  float side = turn > 0.0f ? -1.0f : 1.0f;
+  v2 in_outer = v2add(point, v2mul(normal_left(incoming), radius * side));
+  v2 out_outer = v2add(point, v2mul(normal_left(outgoing), radius * side));
+  if (join == FO_JOIN_MITER) {
+    float denom = cross2f(incoming, outgoing); /* lineIntersection :1042-1048 */
+    if (fabsf(denom) > 0.000001f) {
+      float t = cross2f(v2sub(out_outer, in_outer), outgoing) / denom;
+      v2 miter = v2add(in_outer, v2mul(incoming, t));
+      if (v2len(v2sub(miter, point)) <= radius * 4.0f) {
+        v2 q[4] = {v2add(origin, point), v2add(origin, in_outer), v2add(origin, miter), v2add(origin, out_outer)};
+        draw_filled_quad_l2(c, q, fill);
+        return;
+      }
+    }
+  }
+  v2 q[4] = {v2add(origin, point), v2add(origin, in_outer), v2add(origin, out_outer), v2add(origin, out_outer)};
+  draw_filled_quad_l2(c, q, fill);
+}
+static v2 bezier_point(const float* ctrl, int n, float t) { /* bezierPoint :1139-1153 */
+  v2 work[32];
+  if (n <= 0) return v2mk(0, 0);
+  if (n > 32) n = 32;
+  for (int i = 0; i < n; i++) work[i] = v2mk(ctrl[2 * i], ctrl[2 * i + 1]);
+  for (int count = n; count > 1; count--)
+    for (int i = 0; i < count - 1; i++) work[i] = v2add(v2mul(work[i], 1.0f - t), v2mul(work[i + 1], t));
+  return work[0];
+}
+static v2 quadratic_point(v2 p0, v2 p1, v2 p2, float t) { /* :1155-1157 */
+  float it = 1.0f - t;
+  return v2add(v2add(v2mul(p0, it * it), v2mul(p1, 2.0f * it * t)), v2mul(p2, t * t));
+}
+static void quadratic_bounds(v2 p0, v2 p1, v2 p2, float pad, float out[4]) { /* :1177-1202 */
+  v2 mn = v2mk(minf(p0.x, p2.x), minf(p0.y, p2.y)), mx = v2mk(maxf(p0.x, p2.x), maxf(p0.y, p2.y));
+  float dx = p0.x - 2.0f * p1.x + p2.x;
+  if (fabsf(dx) > 0.000001f) {
+    float t = (p0.x - p1.x) / dx;
+    if (t > 0.0f && t < 1.0f) { v2 q = quadratic_point(p0, p1, p2, t); mn.x = minf(mn.x, q.x); mn.y = minf(mn.y, q.y); mx.x = maxf(mx.x, q.x); mx.y = maxf(mx.y, q.y); }
+  }
+  float dy = p0.y - 2.0f * p1.y + p2.y;
+  if (fabsf(dy) > 0.000001f) {
+    float t = (p0.y - p1.y) / dy;
+    if (t > 0.0f && t < 1.0f) { v2 q = quadratic_point(p0, p1, p2, t); mn.x = minf(mn.x, q.x); mn.y = minf(mn.y, q.y); mx.x = maxf(mx.x, q.x); mx.y = maxf(mx.y, q.y); }
+  }
+  out[0] = mn.x - pad; out[1] = mn.y - pad; out[2] = mx.x - mn.x + pad * 2.0f; out[3] = mx.y - mn.y + pad * 2.0f;
+}
+static v2 span_start_tangent(const QSpan* s) { return normalized_or(v2sub(s->p1, s->p0), normalized_or(v2sub(s->p2, s->p0), v2mk(1.0f, 0.0f))); }
+static v2 span_end_tangent(const QSpan* s) { return normalized_or(v2sub(s->p2, s->p1), normalized_or(v2sub(s->p2, s->p0), v2mk(1.0f, 0.0f))); }
+static QSpan bezier_span(const float* ctrl, int n, float t0, float t2) { /* bezierQuadraticSpan :1238-1247 */
+  float tm = (t0 + t2) * 0.5f;
+  QSpan s;
+  s.p0 = bezier_point(ctrl, n, t0);
+  v2 pm = bezier_point(ctrl, n, tm);
+  s.p2 = bezier_point(ctrl, n, t2);
+  s.p1 = v2sub(v2mul(pm, 2.0f), v2mul(v2add(s.p0, s.p2), 0.5f));
+  return s;
+}
+#define FO_MAX_ADAPTIVE_STEPS 192 /* max(DefaultDrawableBezierSteps*4, 64) :1171 */
+#define FO_MAX_CURVE_DEPTH 8
+static void adaptive_spans(const FoCtx* c, const float* ctrl, int n, float t0, float t2, int depth, QSpan* spans, int* ns) { /* :1267-1282 */
+  QSpan s = bezier_span(ctrl, n, t0, t2);
+  float err = 0.0f;
+  const float lt[2] = {0.25f, 0.75f};
+  for (int i = 0; i < 2; i++) { /* quadraticApproxErrorPx :1256-1265 */
+    float t = t0 + (t2 - t0) * lt[i];
+    v2 actual = bezier_point(ctrl, n, t), approx = quadratic_point(s.p0, s.p1, s.p2, lt[i]);
+    err = maxf(err, v2len(v2mul(v2sub(actual, approx), c->ui_scale)));
+  }
+  if (err <= 0.5f || depth >= FO_MAX_CURVE_DEPTH || *ns >= FO_MAX_ADAPTIVE_STEPS - 1) { spans[(*ns)++] = s; return; }
+  float tm = (t0 + t2) * 0.5f;
+  adaptive_spans(c, ctrl, n, t0, tm, depth + 1, spans, ns);
+  adaptive_spans(c, ctrl, n, tm, t2, depth + 1, spans, ns);
+}
+static void draw_quadratic_sdf(FoCtx* c, v2 origin, v2 p0, v2 p1, v2 p2, const FoStroke* stroke, int cap) { /* renderDrawableQuadraticBezierSdf :1335-1376 */
+  int rcap = cap == FO_CAP_AUTO ? (stroke->cap == FO_CAP_AUTO ? FO_CAP_ROUND : stroke->cap) : cap;
+  if (fabsf(cross2f(v2sub(p1, p0), v2sub(p2, p1))) <= 0.0001f) { /* isFlatQuadratic :1165-1166 */
+    FoStroke s2 = *stroke;
+    s2.cap = rcap;
+    draw_line(c, origin, p0, p2, &s2);
+    return;
+  }
+  float sw = maxf(0.0f, stroke->weight);
+  float padding = sw * 0.5f + descaled(c, 2.0f); /* DrawableSdfPaddingPx */
+  v2 a = v2add(origin, p0), b = v2add(origin, p1), cc = v2add(origin, p2);
+  float box[4];
+  quadratic_bounds(a, b, cc, padding, box);
+  if (box[2] <= 0.0f || box[3] <= 0.0f) return;
+  v2 center = v2mk(box[0] + box[2] * 0.5f, box[1] + box[3] * 0.5f);
+  float us = c->ui_scale;
+  float la[2] = {(a.x - center.x) * us, (a.y - center.y) * us}, lb[2] = {(b.x - center.x) * us, (b.y - center.y) * us};
+  float lc[2] = {(cc.x - center.x) * us, (cc.y - center.y) * us};
+  float sbox[4] = {box[0] * us, box[1] * us, box[2] * us, box[3] * us};
+  fo_draw_quadratic_bezier_sdf(c, sbox, &stroke->fill, la, lb, lc, sw * us, rcap);
+}
+static void draw_spans(FoCtx* c, v2 origin, const QSpan* spans, int n, const FoStroke* stroke) { /* :1412-1455, :1569-1604 */
+  int cap = stroke->cap == FO_CAP_AUTO ? FO_CAP_ROUND : stroke->cap;
+  int join = stroke->join == FO_JOIN_AUTO ? FO_JOIN_ROUND : stroke->join;
+  int simple = cap == FO_CAP_ROUND && join == FO_JOIN_ROUND;
+  int span_cap = simple ? FO_CAP_ROUND : FO_CAP_BUTT;
+  float cap_radius = maxf(0.0f, stroke->weight) / 2.0f;
+  for (int i = 0; i < n; i++) {
+    draw_quadratic_sdf(c, origin, spans[i].p0, spans[i].p1, spans[i].p2, stroke, span_cap);
+    if (!simple) {
+      if (i == 0) draw_endpoint_cap(c, origin, spans[i].p0, span_start_tangent(&spans[i]), cap_radius, stroke, cap, 1);
+      else draw_stroke_join(c, origin, spans[i].p0, span_end_tangent(&spans[i - 1]), span_start_tangent(&spans[i]), cap_radius, &stroke->fill, join);
+      if (i == n - 1) draw_endpoint_cap(c, origin, spans[i].p2, span_end_tangent(&spans[i]), cap_radius, stroke, cap, 0);
+    }
+  }
+}
+static int explicit_steps(uint16_t steps, uint16_t node_steps) { /* :1204-1210 */
+  if (steps != 0) return steps > 1 ? steps : 1;
+  if (node_steps != 0) return node_steps > 1 ? node_steps : 1;
+  return 0;
+}
+static void seg_points(const FoCtx* c, const float* ctrl, int n, float t0, float t2, int depth, v2* pts, int* np) { /* :1297-1313 */
+  v2 p0 = bezier_point(ctrl, n, t0), p2 = bezier_point(ctrl, n, t2);
+  float tm = (t0 + t2) * 0.5f;
+  v2 pm = bezier_point(ctrl, n, tm);
+  v2 P = v2mul(pm, c->ui_scale), A = v2mul(p0, c->ui_scale), B = v2mul(p2, c->ui_scale), ab = v2sub(B, A); /* distanceToLinePx */
+  float denom = ab.x * ab.x + ab.y * ab.y, err;
+  if (denom <= 0.000001f) err = v2len(v2sub(P, A));
+  else {
+    float h = clampf(((P.x - A.x) * ab.x + (P.y - A.y) * ab.y) / denom, 0.0f, 1.0f);
+    err = v2len(v2sub(P, v2add(A, v2mul(ab, h))));
+  }
+  if (err <= 0.5f || depth >= FO_MAX_CURVE_DEPTH || *np >= FO_MAX_ADAPTIVE_STEPS) { pts[(*np)++] = p2; return; }
+  seg_points(c, ctrl, n, t0, tm, depth + 1, pts, np);
+  seg_points(c, ctrl, n, tm, t2, depth + 1, pts, np);
+}
+static void draw_bezier_segments(FoCtx* c, v2 origin, const float* ctrl, int n, uint16_t steps, const FoStroke* stroke, uint16_t node_steps) { /* :1378-1410 */
+  if (n < 2 || stroke->weight <= 0.0f || fill_alpha_max(&stroke->fill) == 0) return;
+  static v2 pts[FO_MAX_ADAPTIVE_STEPS + 70000];
+  int np = 0, fixed = explicit_steps(steps, node_steps);
+  pts[np++] = bezier_point(ctrl, n, 0.0f);
+  if (fixed > 0) for (int s = 1; s <= fixed; s++) pts[np++] = bezier_point(ctrl, n, (float)s / (float)fixed);
+  else seg_points(c, ctrl, n, 0.0f, 1.0f, 0, pts, &np);
+  if (np < 2) return;
+  int cap = stroke->cap == FO_CAP_AUTO ? FO_CAP_ROUND : stroke->cap;
+  int join = stroke->join == FO_JOIN_AUTO ? FO_JOIN_ROUND : stroke->join;
+  float cap_radius = maxf(0.0f, stroke->weight) / 2.0f;
+  FoStroke seg = *stroke;
+  seg.cap = FO_CAP_BUTT;
+  v2 prev = pts[0], prev_t = v2mk(1.0f, 0.0f);
+  for (int s = 1; s < np; s++) {
+    v2 cur = pts[s], tan = v2sub(cur, prev);
+    draw_line(c, origin, prev, cur, &seg);
+    if (s == 1) draw_endpoint_cap(c, origin, prev, tan, cap_radius, stroke, cap, 1);
+    else draw_stroke_join(c, origin, prev, prev_t, tan, cap_radius, &stroke->fill, join);
+    if (s == np - 1) draw_endpoint_cap(c, origin, cur, tan, cap_radius, stroke, cap, 0);
+    prev = cur;
+    prev_t = tan;
+  }
+}
+static void render_drawable_ops(FoCtx* c, const FoScene* sc, const FoFig* n) { /* renderDrawableOps :1627-1645 */
+  v2 origin = v2mk(n->box[0], n->box[1]);
+  const FoStroke* stroke = &n->draw_stroke;
+  for (int oi = n->op_first; oi < n->op_first + n->op_count && oi < sc->n_ops; oi++) {
+    const FoDrawOp* op = &sc->ops[oi];
+    switch (op->kind) {
+      case FO_DK_LINE: draw_line(c, origin, v2mk(op->v[0], op->v[1]), v2mk(op->v[2], op->v[3]), stroke); break;
+      case FO_DK_CIRCLE: { /* :1111-1125 */
+        float r = maxf(0.0f, op->v[2]);
+        if (r <= 0.0f) break;
+        float box[4] = {origin.x + op->v[0] - r, origin.y + op->v[1] - r, r * 2.0f, r * 2.0f};
+        uint16_t rc = radius_corner(r);
+        uint16_t corners[4] = {rc, rc, rc, rc};
+        shape_u16(c, box, &n->fill, stroke, corners);
+        break;
+      }
+      case FO_DK_RECTANGLE: { /* :1127-1131 */
+        float box[4] = {origin.x + op->v[0], origin.y + op->v[1], op->v[2], op->v[3]};
+        shape_u16(c, box, &n->fill, stroke, op->corners);
+        break;
+      }
+      case FO_DK_ELLIPSE: { /* :1606-1625 */
+        float rx0 = maxf(0.0f, op->v[2]), ry0 = maxf(0.0f, op->v[3]);
+        if (rx0 <= 0.0f || ry0 <= 0.0f) break;
+        float box[4] = {origin.x + op->v[0] - rx0, origin.y + op->v[1] - ry0, rx0 * 2.0f, ry0 * 2.0f};
+        float rx[4], ry[4];
+        for (int i = 0; i < 4; i++) { rx[i] = scaled(c, rx0); ry[i] = scaled(c, ry0); }
+        render_rounded_shape(c, box, &n->fill, stroke, rx, ry);
+        break;
+      }
+      case FO_DK_BEZIER: { /* renderDrawableBezier :1457-1486 */
+        int nc = op->ctrl_count;
+        const float* ctrl = sc->controls + 2 * op->ctrl_first;
+        if (nc < 2 || stroke->weight <= 0.0f || fill_alpha_max(&stroke->fill) == 0) break;
+        if (nc == 3) {
+          draw_quadratic_sdf(c, origin, v2mk(ctrl[0], ctrl[1]), v2mk(ctrl[2], ctrl[3]), v2mk(ctrl[4], ctrl[5]), stroke,
+                             stroke->cap == FO_CAP_AUTO ? FO_CAP_ROUND : stroke->cap);
+        } else if (nc > 3) {
+          static QSpan spans[70000];
+          int ns = 0, fixed = explicit_steps(op->steps, n->draw_steps);
+          if (fixed > 0) for (int st = 0; st < fixed; st++) spans[ns++] = bezier_span(ctrl, nc, (float)st / (float)fixed, (float)(st + 1) / (float)fixed);
+          else adaptive_spans(c, ctrl, nc, 0.0f, 1.0f, 0, spans, &ns);
+          draw_spans(c, origin, spans, ns, stroke);
+        } else {
+          draw_bezier_segments(c, origin, ctrl, nc, op->steps, stroke, n->draw_steps);
+        }
+        break;
+      }
+      case FO_DK_ARC: { /* renderDrawableArc :1606-1625, arcQuadraticSpan :1531-1546, adaptiveArcStepCount :1315-1328 */
+        float radius = maxf(0.0f, op->v[2]), start = op->v[3], sweep = op->v[4];
+        if (radius <= 0.0f || sweep == 0.0f || stroke->weight <= 0.0f || fill_alpha_max(&stroke->fill) == 0) break;
+        int steps = explicit_steps(op->steps, n->draw_steps);
+        if (steps <= 0) {
+          float rpx = maxf(0.0f, scaled(c, radius)), asw = fabsf(sweep);
+          if (rpx <= 0.0f || asw <= 0.0f) steps = 1;
+          else {
+            float cl = clampf(1.0f - 0.5f / rpx, -1.0f, 1.0f);
+            float max_angle = maxf(0.01f, 2.0f * acosf(cl));
+            int k = (int)ceilf(asw / max_angle);
+            steps = k < 1 ? 1 : (k > FO_MAX_ADAPTIVE_STEPS ? FO_MAX_ADAPTIVE_STEPS : k);
+          }
+        }
+        static QSpan spans[70000];
+        v2 cen = v2mk(op->v[0], op->v[1]);
+        for (int st = 0; st < steps; st++) {
+          float t0 = (float)st / (float)steps, t2 = (float)(st + 1) / (float)steps, tm = (t0 + t2) * 0.5f;
+          float a0 = start + sweep * t0, a2 = start + sweep * t2, am = start + sweep * tm;
+          QSpan sp;
+          sp.p0 = v2add(cen, v2mk(cosf(a0) * radius, sinf(a0) * radius));
+          v2 pm = v2add(cen, v2mk(cosf(am) * radius, sinf(am) * radius));
+          sp.p2 = v2add(cen, v2mk(cosf(a2) * radius, sinf(a2) * radius));
+          sp.p1 = v2sub(v2mul(pm, 2.0f), v2mul(v2add(sp.p0, sp.p2), 0.5f));
+          spans[st] = sp;
+        }
+        draw_spans(c, origin, spans, steps, stroke);
+        break;
+      }
+      default: break;
+    }
+  }
+}
+static void render_drawable(FoCtx* c, const FoScene* sc, const FoFig* n) { /* renderDrawable :1647-1667 */
+  if (n->draw_aa <= 0.0f || c->aa == n->draw_aa) { render_drawable_ops(c, sc, n); return; }
+  float old = c->aa;
+  fo_set_aa_factor(c, n->draw_aa);
+  render_drawable_ops(c, sc, n);
+  fo_set_aa_factor(c, old);
+}
+
 static void render_node(FoCtx* c, const FoScene* sc, const FoLayer* L, int idx);
 
 static void render_text(FoCtx* c, const FoScene* sc, const FoFig* n) { /* renderText figrender.nim:417-497 (glyph loop) */
@@ -1088,6 +1572,7 @@ static void render_node(FoCtx* c, const FoScene* sc, const FoLayer* L, int idx) 
   }
   switch (n->kind) {
     case FO_NK_TEXT: render_text(c, sc, n); break;
+    case FO_NK_DRAWABLE: render_drawable(c, sc, n); break;
     case FO_NK_RECTANGLE: render_rounded_shape(c, n->box, &n->fill, &n->stroke, rx, ry); break; /* renderBoxes :1669-1671 */
     case FO_NK_IMAGE: { /* renderImage :1673-1684 */
       if (n->image_id == 0) break;
@@ -1117,7 +1602,7 @@ static void render_node(FoCtx* c, const FoScene* sc, const FoLayer* L, int idx) 
       }
       break;
     }
-    default: break; /* nkFrame/nkScrollBar draw nothing; nkDrawable is a SURVEY 8(f) "next" row */
+    default: break; /* nkFrame / nkScrollBar / nkTransform draw nothing themselves */
   }
   if (n->kind == FO_NK_RECTANGLE) render_inner_shadows(c, n); /* hasActiveInnerShadow :778-789 folded into the loop's skip rules */
   /* children: childIndex fignodes.nim:165-177 */

@@ -75,7 +75,25 @@ typedef struct {
   float matrix[16];           /* column-major, vmath Mat4 memory order */
   int32_t use_matrix;
   int32_t glyph_first, glyph_count; /* nkText: range into FoScene.glyphs */
+  FoStroke draw_stroke;             /* nkDrawable (fignodes.nim:78-82) */
+  uint16_t draw_steps;
+  uint16_t _pad0;
+  float draw_aa;
+  int32_t op_first, op_count;       /* range into FoScene.ops */
 } FoFig;
+
+/* DrawableOp (fignodes.nim:13-42); v by kind: line a.xy b.xy | circle c.xy r | rectangle x,y,w,h | arc c.xy r start sweep | ellipse c.xy radii.xy */
+enum { FO_DK_LINE = 0, FO_DK_CIRCLE = 1, FO_DK_RECTANGLE = 2, FO_DK_BEZIER = 3, FO_DK_ARC = 4, FO_DK_ELLIPSE = 5 };
+enum { FO_CAP_AUTO = 0, FO_CAP_ROUND = 1, FO_CAP_BUTT = 2, FO_CAP_SQUARE = 3 };
+enum { FO_JOIN_AUTO = 0, FO_JOIN_ROUND = 1, FO_JOIN_BEVEL = 2, FO_JOIN_MITER = 3 };
+typedef struct {
+  int32_t kind;
+  uint16_t steps;
+  uint16_t corners[4];
+  uint16_t _pad;
+  float v[6];
+  int32_t ctrl_first, ctrl_count;
+} FoDrawOp;
 
 /* A pre-shaped glyph quad: typesetting and glyph rasterisation are third-party
  * (pixie) CPU pre-processing in the reference; the path only consumes
@@ -88,7 +106,16 @@ typedef struct {
 } FoGlyph;
 
 typedef struct { int32_t zlevel; int32_t n_nodes; int32_t n_roots; int32_t _pad; const FoFig* nodes; const int32_t* root_ids; } FoLayer;
-typedef struct { const FoLayer* layers; const FoGlyph* glyphs; int32_t n_layers; int32_t n_glyphs; } FoScene;
+typedef struct {
+  const FoLayer* layers;
+  const FoGlyph* glyphs;
+  int32_t n_layers;
+  int32_t n_glyphs;
+  const FoDrawOp* ops;
+  const float* controls;
+  int32_t n_ops;
+  int32_t n_controls;
+} FoScene;
 
 /* ---- the CPU backend (restates glcontext.nim) */
 typedef struct FoCtx FoCtx;
@@ -116,6 +143,10 @@ void fo_draw_rounded_rect_fill(FoCtx*, const float rect[4], const FoFill* fill, 
 void fo_draw_image(FoCtx*, int64_t key, const float pos[2], const FoColor colors[4], const float size[2], int flip_y);
 void fo_draw_msdf(FoCtx*, int64_t key, const float pos[2], FoColor color, const float size[2], float px_range,
                   float sd_threshold, float stroke_weight, int mtsdf, int flip_y);
+void fo_draw_quadratic_bezier_sdf(FoCtx*, const float rect[4], const FoFill* fill, const float p0[2], const float p1[2],
+                                  const float p2[2], float stroke_weight, int cap);
+void fo_draw_filled_quad(FoCtx*, const float verts[8], const FoColor colors[4]);
+void fo_draw_rect(FoCtx*, const float rect[4], FoColor color);
 void fo_draw_backdrop_blur(FoCtx*, const float rect[4], const float radii_x[4], const float radii_y[4], float blur_radius);
 void fo_begin_mask(FoCtx*, const float rect[4], const float radii_x[4], const float radii_y[4]);
 void fo_end_mask(FoCtx*);
@@ -143,6 +174,7 @@ void fo_gradient_colors(const FoFill* fill, FoColor out[4]);
 void fo_blur_image(int w, int h, const uint8_t* src, uint8_t* dst, float radius); /* H then V, RGBA8 between */
 int fo_sizeof_fig(void);
 int fo_sizeof_glyph(void);
+int fo_sizeof_draw_op(void);
 
 #ifdef __cplusplus
 }

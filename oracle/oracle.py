@@ -56,6 +56,9 @@ def lib():
                                                 C.c_float, _F2]
         L.fo_draw_image.argtypes = [C.c_void_p, C.c_int64, _F2, _COL4, _F2, C.c_int]
         L.fo_draw_msdf.argtypes = [C.c_void_p, C.c_int64, _F2, S.CColor, _F2, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int]
+        L.fo_draw_quadratic_bezier_sdf.argtypes = [C.c_void_p, _F4, C.POINTER(S.CFill), _F2, _F2, _F2, C.c_float, C.c_int]
+        L.fo_draw_filled_quad.argtypes = [C.c_void_p, C.c_float * 8, _COL4]
+        L.fo_draw_rect.argtypes = [C.c_void_p, _F4, S.CColor]
         L.fo_draw_backdrop_blur.argtypes = [C.c_void_p, _F4, _F4, _F4, C.c_float]
         L.fo_begin_mask.argtypes = [C.c_void_p, _F4, _F4, _F4]
         L.fo_end_mask.argtypes = [C.c_void_p]
@@ -80,6 +83,8 @@ def lib():
         L.fo_sizeof_glyph.restype = C.c_int
         assert L.fo_sizeof_fig() == C.sizeof(S.CFig), (L.fo_sizeof_fig(), C.sizeof(S.CFig))
         assert L.fo_sizeof_glyph() == C.sizeof(S.CGlyph)
+        L.fo_sizeof_draw_op.restype = C.c_int
+        assert L.fo_sizeof_draw_op() == C.sizeof(S.CDrawOp)
         _lib = L
     return _lib
 
@@ -148,6 +153,16 @@ class Oracle:
     def draw_msdf(self, key, pos, color, size, px_range, sd_threshold=0.5, stroke_weight=0.0, mtsdf=False, flip_y=False):
         self.L.fo_draw_msdf(self.h, int(key), _F2(*pos), S.CColor(*color), _F2(*size), px_range, sd_threshold,
                             stroke_weight, int(bool(mtsdf)), int(bool(flip_y)))
+
+    def draw_quadratic_bezier_sdf(self, rect, fill, p0, p1, p2, stroke_weight, cap):
+        cf = S.cfill(S.fill_from_json(fill))
+        self.L.fo_draw_quadratic_bezier_sdf(self.h, _F4(*rect), C.byref(cf), _F2(*p0), _F2(*p1), _F2(*p2), stroke_weight, int(cap))
+
+    def draw_filled_quad(self, verts, colors):
+        self.L.fo_draw_filled_quad(self.h, (C.c_float * 8)(*verts), _cols(colors))
+
+    def draw_rect(self, rect, color):
+        self.L.fo_draw_rect(self.h, _F4(*rect), S.CColor(*color))
 
     def draw_backdrop_blur(self, rect, radii_x, radii_y, blur_radius):
         self.L.fo_draw_backdrop_blur(self.h, _F4(*rect), _F4(*radii_x), _F4(*radii_y), blur_radius)

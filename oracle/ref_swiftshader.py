@@ -208,15 +208,14 @@ def _mat_scale(x, y):
 
 
 def _mat_rotate_z(angle):
-    # vmath rotateZ(angle): [[cos, -sin],[sin, cos]] acting on column vectors
-    # (glcontext.nim:1995-1997).  In the y-down pixel space this turns +x
-    # towards +y for positive angles.
+    # vmath rotateZ(angle) (glcontext.nim:1995-1997): m[0,1] = -sin, m[1,0] = sin in vmath's [column, row]
+    # indexing, i.e. x' = cos x + sin y, y' = -sin x + cos y.  Pinned by tests/expected/render_line_rect.png.
     c = f32(math.cos(float(f32(angle))))
     s = f32(math.sin(float(f32(angle))))
     m = np.eye(4, dtype=f32)
     m[0, 0] = c
-    m[0, 1] = -s
-    m[1, 0] = s
+    m[0, 1] = s
+    m[1, 0] = -s
     m[1, 1] = c
     return m
 
@@ -644,6 +643,76 @@ class RefGL:
         uv = [(uv_at[0], uv_to[1]), (uv_to[0], uv_to[1]), (uv_to[0], uv_at[1]), (uv_at[0], uv_at[1])]
         z4 = (0, 0, 0, 0)
         self._draw_quad(p4, uv, [color] * 4, z4, z4, params, z4, mode, (f32(px_range), f32(sd_threshold)))
+
+    # ---- drawable path: drawQuadraticBezierSdf (glcontext.nim:1619-1741), drawFilledQuad (:963-982), drawRect (:1410-1426)
+    RECT_IMAGE_KEY = 0x7265637452454354
+
+    @staticmethod
+    def _lerp_color(a, b, t):
+        ct = min(max(f32(t), f32(0)), f32(1))
+        it = f32(1) - ct
+        return tuple(int(_round_half_away(f32(a[i]) * it + f32(b[i]) * ct)) for i in range(4))
+
+    def _gradient_colors(self, fill):
+        """figbackend.nim:129-183 (vertex order BL, BR, TR, TL)."""
+        kind, axis = fill["kind"], fill["axis"]
+        if kind == 0:
+            return [tuple(fill["start"])] * 4, 0.5
+
+        mid = min(max(f32(fill["mid_pos"]) / f32(255), f32(0.01)), f32(0.99))
+
+        def sample(t):
+            if kind == 1:
+                return self._lerp_color(fill["start"], fill["stop"], t)
+            ct = min(max(f32(t), f32(0)), f32(1))
+            if ct <= mid:
+                return self._lerp_color(fill["start"], fill["mid"], ct / mid)
+            return self._lerp_color(fill["mid"], fill["stop"], (ct - mid) / (f32(1) - mid))
+
+        T = {0: (0, 1, 1, 0), 1: (1, 1, 0, 0), 2: (0.5, 1, 0.5, 0), 3: (0, 0.5, 1, 0.5)}[axis]
+        return [sample(t) for t in T], mid
+
+    def draw_quadratic_bezier_sdf(self, rect, fill, p0, p1, p2, stroke_weight, cap):
+        x, y, w, h = [f32(v) for v in rect]
+        if w <= 0 or h <= 0 or f32(stroke_weight) <= 0:
+            return
+        params = (f32(w * f32(0.5)), f32(h * f32(0.5)), f32(p0[0]), f32(p0[1]))
+        curve = (f32(p1[0]), f32(p1[1]), f32(p2[0]), f32(p2[1]))
+        pos = self._quad_pos(x, y, f32(x + w), f32(y + h))
+        uv = [(0, 1), (1, 1), (1, 0), (0, 0)]
+        mode = {2: 19, 3: 20}.get(int(cap), 18)
+        z4 = (0, 0, 0, 0)
+        if fill["kind"] == 2:
+            mid = min(max(f32(fill["mid_pos"]) / f32(255), f32(0.01)), f32(0.99))
+            fm = 1 + int(fill["axis"])
+            self._draw_quad(pos, uv, [tuple(fill["start"])] * 4, tuple(fill["mid"]), tuple(fill["stop"]), params, curve,
+                            mode + 256 * fm, (f32(stroke_weight), mid))
+        else:
+            cols, _ = self._gradient_colors(fill)
+            self._draw_quad(pos, uv, cols, z4, z4, params, curve, mode, (f32(stroke_weight), f32(0)))
+
+    def _rect_entry(self):
+        if self.RECT_IMAGE_KEY not in self.entries:
+            self.put_image(self.RECT_IMAGE_KEY, np.full((4, 4, 4), 255, dtype=np.uint8))
+        return self.entries[self.RECT_IMAGE_KEY]
+
+    def draw_filled_quad(self, verts, colors):
+        ex, ey, ew, eh = self._rect_entry()
+        u, v = f32(ex + ew / f32(2)), f32(ey + eh / f32(2))
+        pos = []
+        for i in range(4):
+            a, b = self._xf(verts[2 * i], verts[2 * i + 1])
+            pos.append((f32(math.ceil(float(a))), f32(math.ceil(float(b)))))
+        z4 = (0, 0, 0, 0)
+        self._draw_quad(pos, [(u, v)] * 4, colors, z4, z4, z4, z4, 0, (0, 0))
+
+    def draw_rect(self, rect, color):
+        ex, ey, ew, eh = self._rect_entry()
+        u, v = f32(ex + ew / f32(2)), f32(ey + eh / f32(2))
+        x, y, w, h = [f32(t) for t in rect]
+        pos = self._quad_pos(x, y, f32(x + w), f32(y + h))
+        z4 = (0, 0, 0, 0)
+        self._draw_quad(pos, [(u, v)] * 4, [color] * 4, z4, z4, z4, z4, 0, (0, 0))
 
     # ---- masks (glcontext.nim:1873-1949)
     def begin_mask(self, rect, radii_x, radii_y):

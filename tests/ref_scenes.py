@@ -9,7 +9,9 @@ evaluated in float64).
 from __future__ import annotations
 
 from figdraw_amd.scene import (Fig, FigFlags, FigKind, FillGradientAxis, RenderList, Renders, RenderShadow,
-                               RenderStroke, ShadowStyle, fill, linear, rect, rgba)
+                               RenderStroke, ShadowStyle, StrokeCap, StrokeJoin, drawableArc, drawableBezier,
+                               drawableCircle, drawableEllipse, drawableLine, drawableRect, figCircle, figLine, fill,
+                               linear, rect, rgba)
 
 DROP, INNER = ShadowStyle.DropShadow, ShadowStyle.InnerShadow
 RECT = FigKind.nkRectangle
@@ -128,7 +130,64 @@ def rect_mask_mixed_batch(w=480.0, h=180.0) -> Renders:
     return out
 
 
+def line_rect(w=800.0, h=600.0) -> Renders:
+    """tests/trender_extras.nim:17-37 (golden: tests/expected/render_line_rect.png): a line is a rotated box, so this
+    PNG also pins the direction of vmath's rotateZ."""
+    lst = RenderList()
+    root = lst.addRoot(Fig(kind=RECT, screenBox=rect(0, 0, w, h), fill=rgba(255, 255, 255, 255)))
+    lst.addChild(root, figLine((90.0, 120.0), (710.0, 470.0), rgba(0, 0, 0, 255), 48.0))
+    out = Renders()
+    out.layers[0] = lst
+    return out
+
+
+def circle_rect(w=800.0, h=600.0) -> Renders:
+    """tests/trender_extras.nim:39-58 (golden: tests/expected/render_circle_rect.png)."""
+    lst = RenderList()
+    root = lst.addRoot(Fig(kind=RECT, screenBox=rect(0, 0, w, h), fill=rgba(255, 255, 255, 255)))
+    lst.addChild(root, figCircle((400.0, 300.0), rgba(0, 0, 0, 255), 110.0))
+    out = Renders()
+    out.layers[0] = lst
+    return out
+
+
 # ----------------------------------------------------------------------- extra coverage (SwiftShader goldens)
+def drawables(w=420.0, h=300.0) -> Renders:
+    """nkDrawable ops: lines with butt / round / square caps, a quadratic bezier (one SDF op, modes 18-20), an adaptive
+    cubic, fixed-step arcs with bevel and miter joins (drawFilledQuad), an ellipse, a rounded rect with drawAa, and a
+    3-stop gradient stroke on a curve."""
+    lst = RenderList()
+    lst.addRoot(Fig(kind=RECT, screenBox=rect(0, 0, w, h), fill=rgba(252, 252, 248, 255)))
+    D = FigKind.nkDrawable
+    black = fill(rgba(20, 20, 20, 255))
+    lst.addRoot(Fig(kind=D, screenBox=rect(10, 10, 130, 80), drawStroke=RenderStroke(weight=9.0, fill=black),
+                    drawOps=[drawableLine((5, 10), (120, 30))]))
+    lst.addRoot(Fig(kind=D, screenBox=rect(10, 40, 130, 80), drawStroke=RenderStroke(weight=9.0, fill=fill(rgba(200, 30, 30, 200)), cap=StrokeCap.scRound),
+                    drawOps=[drawableLine((5, 10), (120, 30))]))
+    lst.addRoot(Fig(kind=D, screenBox=rect(10, 70, 130, 80), drawStroke=RenderStroke(weight=9.0, fill=fill(rgba(30, 30, 200, 255)), cap=StrokeCap.scSquare),
+                    drawOps=[drawableLine((15, 10), (110, 30))]))
+    lst.addRoot(Fig(kind=D, screenBox=rect(150, 10, 120, 90), drawStroke=RenderStroke(weight=6.0, fill=fill(rgba(10, 120, 60, 255))),
+                    drawOps=[drawableBezier([(5, 5), (60, 110), (115, 10)])]))
+    lst.addRoot(Fig(kind=D, screenBox=rect(150, 60, 120, 90), drawStroke=RenderStroke(weight=5.0, fill=fill(rgba(150, 20, 160, 255)), cap=StrokeCap.scButt),
+                    drawOps=[drawableBezier([(5, 5), (60, 80), (115, 10)])]))
+    lst.addRoot(Fig(kind=D, screenBox=rect(280, 10, 130, 120), drawStroke=RenderStroke(weight=4.0, fill=linear(rgba(240, 120, 20, 255), rgba(30, 160, 220, 255), rgba(90, 20, 180, 255), axis=FillGradientAxis.fgaX, midPos=100)),
+                    drawOps=[drawableBezier([(5, 60), (40, -60), (80, 180), (125, 50)])]))
+    lst.addRoot(Fig(kind=D, screenBox=rect(10, 150, 130, 130), drawStroke=RenderStroke(weight=10.0, fill=fill(rgba(0, 90, 160, 230)), cap=StrokeCap.scButt, join=StrokeJoin.sjBevel),
+                    drawOps=[drawableArc((65, 65), 50.0, 0.3, 3.6, steps=5)]))
+    lst.addRoot(Fig(kind=D, screenBox=rect(150, 160, 120, 120), drawStroke=RenderStroke(weight=8.0, fill=fill(rgba(160, 90, 0, 255)), cap=StrokeCap.scSquare, join=StrokeJoin.sjMiter),
+                    drawOps=[drawableArc((60, 60), 45.0, 3.4, -2.6, steps=3)]))
+    lst.addRoot(Fig(kind=D, screenBox=rect(280, 140, 130, 70), fill=fill(rgba(20, 40, 80, 200)), drawStroke=RenderStroke(weight=3.0, fill=fill(rgba(255, 60, 0, 255))),
+                    drawOps=[drawableEllipse((65, 35), (56.25, 28.5)), drawableCircle((20, 20), 11.0)]))
+    lst.addRoot(Fig(kind=D, screenBox=rect(280, 220, 130, 70), fill=fill(rgba(250, 200, 40, 255)), drawAa=0.6,
+                    drawStroke=RenderStroke(weight=2.0, fill=black), drawOps=[drawableRect((6.5, 8.25, 110, 50), (14, 0, 22, 6))]))
+    lst.addRoot(Fig(kind=D, screenBox=rect(150, 230, 120, 60), drawStroke=RenderStroke(weight=3.0, fill=black, cap=StrokeCap.scButt, join=StrokeJoin.sjMiter),
+                    drawOps=[drawableBezier([(5, 50), (60, 5)], steps=0), drawableBezier([(60, 5), (115, 50)])]))
+    out = Renders()
+    out.layers[0] = lst
+    return out
+
+
+
 def elliptical_and_fractional(w=320.0, h=240.0) -> Renders:
     """Elliptical corners, fractional rects (ceil-snapped quad with un-snapped half extents),
     translucent fills and strokes, spread-only and blur-only shadows."""
@@ -253,6 +312,8 @@ REFERENCE_PNG_SCENES = {
     "linear_gradient": (linear_gradient, 800, 600, "render_linear_gradient.png"),
     "layers_clip": (lambda w, h: layers_clip(w, h, False), 800, 375, "render_layers_clip.png"),
     "layers_rect_mask": (lambda w, h: layers_clip(w, h, True), 800, 375, "render_layers_clip.png"),
+    "line_rect": (line_rect, 800, 600, "render_line_rect.png"),
+    "circle_rect": (circle_rect, 800, 600, "render_circle_rect.png"),
 }
 
 SWIFTSHADER_SCENES = {
@@ -263,6 +324,7 @@ SWIFTSHADER_SCENES = {
     "rect_mask_nested": (rect_mask_nested, 320, 240),
     "backdrop_blur": (backdrop_blur, 320, 240),
     "rotation_and_transform": (rotation_and_transform, 320, 240),
+    "drawables": (drawables, 420, 300),
 }
 
 

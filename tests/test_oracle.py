@@ -20,7 +20,7 @@ def _render(fn, w, h, threads=4):
     return o.read_pixels()
 
 
-@pytest.mark.parametrize("name", ["rgb_boxes_sdf", "linear_gradient", "layers_clip"])
+@pytest.mark.parametrize("name", ["rgb_boxes_sdf", "linear_gradient", "layers_clip", "line_rect", "circle_rect"])
 def test_oracle_matches_reference_pngs(name):
     fn, w, h, png = RS.REFERENCE_PNG_SCENES[name]
     img = _render(fn, w, h)
@@ -104,7 +104,7 @@ def _xf_point(calls, upto, x, y):
         elif c[0] == "scale":
             m = m @ np.diag([c[1], c[2], 1])
         elif c[0] == "rotate":
-            m = m @ np.array([[math.cos(c[1]), -math.sin(c[1]), 0], [math.sin(c[1]), math.cos(c[1]), 0], [0, 0, 1]])
+            m = m @ np.array([[math.cos(c[1]), math.sin(c[1]), 0], [-math.sin(c[1]), math.cos(c[1]), 0], [0, 0, 1]])
         elif c[0] == "apply_transform":
             a = np.array(c[1]).reshape(4, 4).T
             m = m @ np.array([[a[0, 0], a[0, 1], a[0, 3]], [a[1, 0], a[1, 1], a[1, 3]], [0, 0, 1]])
@@ -222,3 +222,89 @@ def test_atlas_packer_known_answers():
     assert c[2:] == (200, 30) and c[0] >= 4 and c[1] >= 4
     with pytest.raises(RuntimeError):
         o.put_image(4, np.zeros((300, 300, 4), np.uint8))
+
+
+# ----------------------------------------------------------------------------------------------- drawable path
+def _drawable_draws(op=None, ops=None, box=(0.0, 0.0, 300.0, 300.0), stroke=None, draw_steps=0, ui_scale=1.0, fill_=None, draw_aa=0.0):
+    """tests/ttransform.nim:127-144 `renderedDrawableDraws`: the backend calls one nkDrawable node decomposes into."""
+    from figdraw_amd.scene import RenderStroke
+
+    r = Renders()
+    f = Fig(kind=FigKind.nkDrawable, screenBox=box, drawSteps=draw_steps, drawAa=draw_aa,
+            drawStroke=stroke if stroke is not None else RenderStroke(weight=2.0, fill=fill(rgba(255, 0, 0, 255))), drawOps=ops or [op])
+    if fill_ is not None:
+        f.fill = fill_
+    r.addRoot(0, f)
+    o = O.Oracle()
+    o.record_begin()
+    o.render_frame(r, 64, 64, ui_scale=ui_scale)
+    calls = o.record_calls()
+    return [c for c in calls if c[0].startswith("draw_")], calls
+
+
+def test_drawable_known_answers_from_ttransform():
+    """tests/ttransform.nim:269-547 restated against the recorded backend-call stream."""
+    from figdraw_amd.scene import (RenderStroke, StrokeCap, StrokeJoin, drawableArc, drawableBezier, drawableEllipse,
+                                   drawableLine, drawableRect)
+
+    red = fill(rgba(255, 0, 0, 255))
+    box = (5.0, 7.0, 30.0, 20.0)
+    # quadratic bezier = ONE sdf op (:269-292)
+    d, _ = _drawable_draws(drawableBezier([(0, 0), (10, 20), (20, 0)], steps=4), box=box)
+    assert [c[0] for c in d] == ["draw_quadratic_bezier_sdf"]
+    # round-capped line = body + 2 caps (:294-312); square cap = one extended segment (:314-332)
+    d, _ = _drawable_draws(drawableLine((0, 0), (10, 0)), box=box, stroke=RenderStroke(weight=2.0, fill=red, cap=StrokeCap.scRound))
+    assert len(d) == 3
+    d, _ = _drawable_draws(drawableLine((0, 0), (10, 0)), box=box, stroke=RenderStroke(weight=2.0, fill=red, cap=StrokeCap.scSquare))
+    assert len(d) == 1 and d[0][1][2] == pytest.approx(12.0)  # length + weight
+    # cubic with steps=4 -> 4 quadratic spans (:334-360)
+    d, _ = _drawable_draws(drawableBezier([(0, 0), (10, 20), (20, -10), (30, 0)], steps=4), box=box)
+    assert len(d) == 4 and all(c[0] == "draw_quadratic_bezier_sdf" for c in d)
+    # adaptive decomposition grows with screen size (:362-386)
+    small, _ = _drawable_draws(drawableBezier([(0, 0), (4, 20), (8, -20), (12, 0)]))
+    large, _ = _drawable_draws(drawableBezier([(0, 0), (40, 200), (80, -200), (120, 0)]))
+    assert 0 < len(small) < len(large)
+    # arc with steps=4 -> 4 spans (:388-410); adaptive arcs grow with radius (:412-422)
+    d, _ = _drawable_draws(drawableArc((10, 10), 8.0, 0.0, 1.5707964, steps=4), box=box)
+    assert len(d) == 4
+    small, _ = _drawable_draws(drawableArc((16, 16), 8.0, 0.0, 3.1415927))
+    large, _ = _drawable_draws(drawableArc((90, 90), 80.0, 0.0, 3.1415927))
+    assert 0 < len(small) < len(large)
+    # ellipse: fill (ClipAA) + stroke (AnnularAA) with elliptical radii, box = centre -/+ radii (:424-452)
+    d, _ = _drawable_draws(drawableEllipse((10, 8), (6.25, 3.5)), box=box, fill_=fill(rgba(20, 40, 80, 255)))
+    assert [c[5] for c in d] == [3, 12]
+    for c in d:
+        assert c[3] == [6.25] * 4 and c[4] == [3.5] * 4
+    assert d[0][1] == pytest.approx([8.75, 11.5, 12.5, 7.0])
+    # zero radius ellipse draws nothing (:454-457)
+    d, _ = _drawable_draws(drawableEllipse((10, 10), (8, 0)))
+    assert d == []
+    # butt caps + bevel joins on a 4-span arc: 4 spans + 3 joins = 7 draws (:459-487)
+    d, _ = _drawable_draws(drawableArc((10, 10), 8.0, 0.0, 1.5707964, steps=4), box=box,
+                           stroke=RenderStroke(weight=2.0, fill=red, cap=StrokeCap.scButt, join=StrokeJoin.sjBevel))
+    assert len(d) == 7 and sum(c[0] == "draw_filled_quad" for c in d) == 3
+    # node drawSteps are the default for curve ops: quadratic (1) + arc with its own steps=2 (:489-521)
+    d, _ = _drawable_draws(ops=[drawableBezier([(0, 0), (10, 20), (20, 0)]), drawableArc((20, 10), 8.0, 0.0, 1.5707964, steps=2)],
+                           box=(5.0, 7.0, 40.0, 30.0), draw_steps=4)
+    assert len(d) == 3
+    # SDF padding stays 2 PHYSICAL px under uiScale 2: 20x5 curve box -> (20+2*(1+1))*2 = 48 x (5+4)*2 = 18 (:523-537)
+    d, _ = _drawable_draws(drawableBezier([(0, 0), (10, 10), (20, 0)]), ui_scale=2.0)
+    assert len(d) == 1 and d[0][1][2] == pytest.approx(48.0) and d[0][1][3] == pytest.approx(18.0)
+    # drawAa overrides the backend AA factor and restores it (:539-566)
+    d, calls = _drawable_draws(drawableRect((2, 3, 10, 8)), box=(5.0, 7.0, 40.0, 30.0), fill_=red, draw_aa=0.75, stroke=RenderStroke())
+    aa = [c[1] for c in calls if c[0] == "set_aa_factor"]
+    assert len(d) == 1 and aa == [pytest.approx(0.75), pytest.approx(1.2)]
+
+
+def test_fig_line_and_circle_helpers():
+    """tests/trender_extras.nim:84-140 (figextras.nim math)."""
+    from figdraw_amd.scene import DrawableKind, figCircle, figLine
+
+    c = figCircle((80.0, 50.0), rgba(0, 0, 0, 255), 24.0)
+    assert c.kind == FigKind.nkDrawable and c.screenBox == pytest.approx((56.0, 26.0, 48.0, 48.0))
+    assert c.drawOps[0].kind == DrawableKind.dkCircle and tuple(c.drawOps[0].v) == pytest.approx((24.0, 24.0, 24.0))
+    ln = figLine((10.0, 20.0), (110.0, 20.0), rgba(0, 0, 0, 255), 8.0)
+    assert ln.screenBox == pytest.approx((6.0, 16.0, 108.0, 8.0)) and tuple(ln.drawOps[0].v) == pytest.approx((4.0, 4.0, 104.0, 4.0))
+    assert ln.drawStroke.weight == 8.0 and ln.drawStroke.fill.start == (0, 0, 0, 255)
+    ln = figLine((40.0, 25.0), (40.0, 145.0), rgba(0, 0, 0, 255), 12.0)
+    assert ln.screenBox == pytest.approx((34.0, 19.0, 12.0, 132.0)) and tuple(ln.drawOps[0].v) == pytest.approx((6.0, 6.0, 6.0, 126.0))
