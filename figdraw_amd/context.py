@@ -91,6 +91,8 @@ def load():
     L.fdh_set_text_subpixel_shift.argtypes = [vp, C.c_float]
     L.fdh_put_image.argtypes = [vp, C.c_int64, C.c_int, C.c_int, vp, C.c_int * 4]
     L.fdh_update_image.argtypes = [vp, C.c_int64, C.c_int, C.c_int, vp]
+    L.fdh_put_image_mips.argtypes = [vp, C.c_int64, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_void_p), C.c_int * 4]
+    L.fdh_put_flippy.argtypes = [vp, C.c_int64, C.c_char_p, C.c_size_t, C.c_int * 4]
     L.fdh_remove_image.argtypes = [vp, C.c_int64]
     L.fdh_has_image.argtypes = [vp, C.c_int64, C.POINTER(C.c_int)]
     L.fdh_reset_atlas.argtypes = [vp, C.c_int]
@@ -239,6 +241,22 @@ class HipContext:
         rgba = np.ascontiguousarray(rgba, dtype=np.uint8)
         out = (C.c_int * 4)()
         self._ck(self.L.fdh_put_image(self.h, int(key), rgba.shape[1], rgba.shape[0], rgba.ctypes.data, out))
+        return tuple(out)
+
+    def put_image_mips(self, key, mips):
+        """Upload an explicit mip chain (premultiplied RGBA8 arrays, level 0 first), as putFlippy does."""
+        mips = [np.ascontiguousarray(m, dtype=np.uint8) for m in mips]
+        n = len(mips)
+        ws = (C.c_int * n)(*[m.shape[1] for m in mips])
+        hs = (C.c_int * n)(*[m.shape[0] for m in mips])
+        ptrs = (C.c_void_p * n)(*[m.ctypes.data for m in mips])
+        out = (C.c_int * 4)()
+        self._ck(self.L.fdh_put_image_mips(self.h, int(key), n, ws, hs, ptrs, out))
+        return tuple(out)
+
+    def put_flippy(self, key, file_bytes: bytes):
+        out = (C.c_int * 4)()
+        self._ck(self.L.fdh_put_flippy(self.h, int(key), file_bytes, len(file_bytes), out))
         return tuple(out)
 
     def update_image(self, key, rgba: np.ndarray):

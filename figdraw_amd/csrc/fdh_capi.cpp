@@ -122,6 +122,13 @@ int fdh_set_text_subpixel_shift(FdhContext* c, float s) { return guard([&] { C(c
 int fdh_put_image(FdhContext* c, int64_t key, int w, int h, const uint8_t* rgba, int out_rect[4]) {
   return guard([&] { C(c)->put_image(key, w, h, rgba, out_rect); });
 }
+int fdh_put_image_mips(FdhContext* c, int64_t key, int n_levels, const int* widths, const int* heights,
+                       const uint8_t* const* premul_rgba8, int out_rect[4]) {
+  return guard([&] { C(c)->put_mips(key, n_levels, widths, heights, premul_rgba8, out_rect); });
+}
+int fdh_put_flippy(FdhContext* c, int64_t key, const uint8_t* bytes, size_t n, int out_rect[4]) {
+  return guard([&] { C(c)->put_flippy(key, bytes, n, out_rect); });
+}
 int fdh_update_image(FdhContext* c, int64_t key, int w, int h, const uint8_t* rgba) {
   return guard([&] { C(c)->update_image(key, w, h, rgba); });
 }

@@ -163,6 +163,94 @@ void Context::put_image(int64_t key, int w, int h, const uint8_t* rgba, int out_
   put_levels(x, y, w, h, rgba);
   if (out_rect) { out_rect[0] = x; out_rect[1] = y; out_rect[2] = w; out_rect[3] = h; }
 }
+// Flippy: figdraw's mip-mapped image container (common/formatflippy.nim:77-149).  Layout: "flip", u32 version (1), then per
+// mip level "mip!", u32 width, u32 height, u32 zlen, and a raw-snappy block holding straight RGBA8.  The reference
+// converts every texel to pixie's premultiplied ColorRGBX on load and uploads level l at (x >> l, y >> l)
+// (putFlippy glcontext.nim:610-620) instead of rebuilding the chain with minifyBy2.
+static std::vector<uint8_t> snappy_uncompress(const uint8_t* in, size_t n) {
+  size_t i = 0, len = 0;
+  for (int shift = 0;; shift += 7) {
+    if (i >= n || shift > 35) throw Error(FDH_ERR_INVALID, "flippy: bad snappy length");
+    const uint8_t c = in[i++];
+    len |= (size_t)(c & 0x7f) << shift;
+    if (c < 0x80) break;
+  }
+  std::vector<uint8_t> out;
+  out.reserve(len);
+  auto need = [&](size_t k) { if (i + k > n) throw Error(FDH_ERR_INVALID, "flippy: truncated snappy block"); };
+  while (i < n) {
+    const uint8_t tag = in[i++];
+    const int t = tag & 3;
+    if (t == 0) {  // literal
+      size_t l = tag >> 2;
+      if (l < 60) l += 1;
+      else {
+        const int nb = (int)l - 59;
+        need(nb);
+        l = 0;
+        for (int k = 0; k < nb; k++) l |= (size_t)in[i + k] << (8 * k);
+        l += 1;
+        i += nb;
+      }
+      need(l);
+      out.insert(out.end(), in + i, in + i + l);
+      i += l;
+    } else {  // copy with 1-, 2- or 4-byte offset
+      size_t l, off;
+      if (t == 1) { need(1); l = ((tag >> 2) & 7) + 4; off = ((size_t)(tag >> 5) << 8) | in[i]; i += 1; }
+      else if (t == 2) { need(2); l = (tag >> 2) + 1; off = in[i] | ((size_t)in[i + 1] << 8); i += 2; }
+      else { need(4); l = (tag >> 2) + 1; off = in[i] | ((size_t)in[i + 1] << 8) | ((size_t)in[i + 2] << 16) | ((size_t)in[i + 3] << 24); i += 4; }
+      if (off == 0 || off > out.size()) throw Error(FDH_ERR_INVALID, "flippy: bad snappy copy offset");
+      for (size_t k = 0; k < l; k++) out.push_back(out[out.size() - off]);
+    }
+  }
+  if (out.size() != len) throw Error(FDH_ERR_INVALID, "flippy: snappy length mismatch");
+  return out;
+}
+void Context::put_mips(int64_t key, int n, const int* ws, const int* hs, const uint8_t* const* premul_rgba, int out_rect[4]) {
+  // putFlippy glcontext.nim:610-620: level l goes to (x >> l, y >> l) with the size the container stored for it
+  if (n <= 0 || !ws || !hs || !premul_rgba) throw Error(FDH_ERR_INVALID, "put_mips: no mip levels");
+  for (int l = 0; l < n; l++)
+    if (ws[l] <= 0 || hs[l] <= 0 || !premul_rgba[l]) throw Error(FDH_ERR_INVALID, "put_mips: bad mip level");
+  FDH_HIP(hipSetDevice(device_));
+  int rx = 0, ry = 0;
+  find_empty_rect(ws[0], hs[0], &rx, &ry);
+  entries_[key] = AtlasEntry{rx, ry, ws[0], hs[0]};
+  if (out_rect) { out_rect[0] = rx; out_rect[1] = ry; out_rect[2] = ws[0]; out_rect[3] = hs[0]; }
+  FDH_HIP(hipStreamSynchronize(stream_));
+  for (int l = 0; l < n && l < n_levels_; l++) upload_atlas_rect(l, rx >> l, ry >> l, ws[l], hs[l], premul_rgba[l]);
+}
+void Context::put_flippy(int64_t key, const uint8_t* data, size_t n, int out_rect[4]) {
+  auto u32 = [&](size_t at) { return (uint32_t)data[at] | ((uint32_t)data[at + 1] << 8) | ((uint32_t)data[at + 2] << 16) | ((uint32_t)data[at + 3] << 24); };
+  if (!data || n < 8 || std::memcmp(data, "flip", 4) != 0) throw Error(FDH_ERR_INVALID, "Invalid Flippy header");
+  if (u32(4) != 1) throw Error(FDH_ERR_INVALID, "Invalid Flippy version");
+  std::vector<std::vector<uint8_t>> mips;
+  std::vector<int> ws, hs;
+  size_t i = 8;
+  while (i < n) {
+    if (i + 16 > n || std::memcmp(data + i, "mip!", 4) != 0) throw Error(FDH_ERR_INVALID, "Invalid Flippy sub header");
+    const int w = (int)u32(i + 4), h = (int)u32(i + 8);
+    const size_t z = u32(i + 12);
+    i += 16;
+    if (i + z > n || w <= 0 || h <= 0) throw Error(FDH_ERR_INVALID, "Flippy read error");
+    std::vector<uint8_t> px = snappy_uncompress(data + i, z);
+    i += z;
+    if (px.size() != (size_t)w * h * 4) throw Error(FDH_ERR_INVALID, "Flippy mip size mismatch");
+    for (size_t k = 0; k < (size_t)w * h; k++) {  // ColorRGBA -> premultiplied ColorRGBX
+      const unsigned a = px[4 * k + 3];
+      px[4 * k + 0] = (uint8_t)((px[4 * k + 0] * a) / 255);
+      px[4 * k + 1] = (uint8_t)((px[4 * k + 1] * a) / 255);
+      px[4 * k + 2] = (uint8_t)((px[4 * k + 2] * a) / 255);
+    }
+    mips.push_back(std::move(px));
+    ws.push_back(w);
+    hs.push_back(h);
+  }
+  if (mips.empty()) throw Error(FDH_ERR_INVALID, "Flippy has no mip levels");
+  std::vector<const uint8_t*> ptrs;
+  for (auto& m : mips) ptrs.push_back(m.data());
+  put_mips(key, (int)mips.size(), ws.data(), hs.data(), ptrs.data(), out_rect);
+}
 void Context::update_image(int64_t key, int w, int h, const uint8_t* rgba) {  // glcontext.nim:591-604
   auto it = entries_.find(key);
   if (it == entries_.end()) throw Error(FDH_ERR_INVALID, "update_image: unknown key");

@@ -123,6 +123,8 @@ class Context {
   // atlas
   void put_image(int64_t key, int w, int h, const uint8_t* rgba, int out_rect[4]);
   void update_image(int64_t key, int w, int h, const uint8_t* rgba);
+  void put_mips(int64_t key, int n, const int* ws, const int* hs, const uint8_t* const* premul_rgba, int out_rect[4]);
+  void put_flippy(int64_t key, const uint8_t* data, size_t n, int out_rect[4]);
   void remove_image(int64_t key) { entries_.erase(key); }
   bool has_image(int64_t key) const { return entries_.count(key) != 0; }
   void reset_atlas(int minimum_size);

@@ -22,6 +22,7 @@
  */
 #ifndef FIGDRAW_HIP_H
 #define FIGDRAW_HIP_H
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -207,6 +208,11 @@ FDH_API int fdh_set_text_subpixel_shift(FdhContext*, float shift);
  * The shim derives the UV entry as rect / atlasSize (glcontext.nim:584).  The atlas doubles when full (:536-539),
  * which invalidates every earlier entry exactly as in the reference (resetImageAtlas :634-641). */
 FDH_API int fdh_put_image(FdhContext*, int64_t key, int width, int height, const uint8_t* rgba8, int out_rect[4]);
+/* putFlippy (glcontext.nim:610-620): `bytes` is a whole .flippy file (common/formatflippy.nim:77-149: "flip", version 1, then per
+ * mip "mip!", w, h, zlen, raw-snappy straight RGBA8); every stored level is uploaded as is at (x >> l, y >> l). */
+FDH_API int fdh_put_image_mips(FdhContext*, int64_t key, int n_levels, const int* widths, const int* heights,
+                               const uint8_t* const* premul_rgba8, int out_rect[4]); /* an already decoded Flippy (flippy.mipmaps) */
+FDH_API int fdh_put_flippy(FdhContext*, int64_t key, const uint8_t* bytes, size_t n_bytes, int out_rect[4]);
 FDH_API int fdh_update_image(FdhContext*, int64_t key, int width, int height, const uint8_t* rgba8); /* glcontext.nim:591-604 */
 FDH_API int fdh_remove_image(FdhContext*, int64_t key);
 FDH_API int fdh_has_image(FdhContext*, int64_t key, int* out);

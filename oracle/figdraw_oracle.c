@@ -819,7 +819,7 @@ static AtlasEntry* find_entry(FoCtx* c, int64_t key) {
   for (int i = 0; i < c->n_entries; i++) if (c->entries[i].used && c->entries[i].key == key) return &c->entries[i];
   return NULL;
 }
-int fo_put_image(FoCtx* c, int64_t key, int w, int h, const uint8_t* rgba, int out_rect[4]) {
+static int place_rect(FoCtx* c, int64_t key, int w, int h, int* ox, int* oy) { /* findEmptyRect + entry bookkeeping */
   int S = c->atlas_size, M = c->atlas_margin;
   int iw = w + M * 2, ih = h + M * 2;
   int lowest = S, at = 0;
@@ -847,6 +847,12 @@ int fo_put_image(FoCtx* c, int64_t key, int w, int h, const uint8_t* rgba, int o
   }
   e->key = key; e->used = 1;
   e->x = (float)rx / (float)S; e->y = (float)ry / (float)S; e->w = (float)w / (float)S; e->h = (float)h / (float)S;
+  *ox = rx; *oy = ry;
+  return 0;
+}
+int fo_put_image(FoCtx* c, int64_t key, int w, int h, const uint8_t* rgba, int out_rect[4]) {
+  int S = c->atlas_size, rx, ry;
+  if (place_rect(c, key, w, h, &rx, &ry) != 0) return -1;
   if (out_rect) { out_rect[0] = rx; out_rect[1] = ry; out_rect[2] = w; out_rect[3] = h; }
   /* updateSubImage with the minifyBy2 mip chain: textures.nim:106-119 */
   int cw = w, ch = h, lx = rx, ly = ry, level = 0;
@@ -873,6 +879,92 @@ int fo_put_image(FoCtx* c, int64_t key, int w, int h, const uint8_t* rgba, int o
   }
   free(cur);
   return 0;
+}
+
+/* Flippy container (common/formatflippy.nim:77-149): "flip", u32 version 1, then per mip "mip!", u32 w, u32 h, u32 zlen and a
+ * snappy block (third-party supersnappy; the raw-snappy format is public: varint length, then literal / copy tags) of straight
+ * RGBA8; on load every texel is converted to pixie's premultiplied ColorRGBX.  putFlippy (glcontext.nim:610-620) uploads mip l
+ * at (x >> l, y >> l).  The premultiply rounding is pixie's (floor(c*a/255)); parity unpinned for 0 < a < 255. */
+static int snappy_uncompress(const uint8_t* in, size_t n, uint8_t** out, size_t* out_n) {
+  size_t i = 0, len = 0;
+  int shift = 0;
+  for (;;) {
+    if (i >= n) return -1;
+    uint8_t c = in[i++];
+    len |= (size_t)(c & 0x7f) << shift;
+    if (c < 0x80) break;
+    shift += 7;
+    if (shift > 35) return -1;
+  }
+  uint8_t* o = (uint8_t*)malloc(len ? len : 1);
+  size_t w = 0;
+  while (i < n) {
+    uint8_t tag = in[i++];
+    int t = tag & 3;
+    if (t == 0) {
+      size_t l = tag >> 2;
+      if (l < 60) l += 1;
+      else {
+        int nb = (int)l - 59;
+        if (i + nb > n) { free(o); return -1; }
+        l = 0;
+        for (int k = 0; k < nb; k++) l |= (size_t)in[i + k] << (8 * k);
+        l += 1;
+        i += nb;
+      }
+      if (i + l > n || w + l > len) { free(o); return -1; }
+      memcpy(o + w, in + i, l);
+      w += l; i += l;
+    } else {
+      size_t l, off;
+      if (t == 1) { if (i + 1 > n) { free(o); return -1; } l = ((tag >> 2) & 7) + 4; off = ((size_t)(tag >> 5) << 8) | in[i]; i += 1; }
+      else if (t == 2) { if (i + 2 > n) { free(o); return -1; } l = (tag >> 2) + 1; off = in[i] | ((size_t)in[i + 1] << 8); i += 2; }
+      else { if (i + 4 > n) { free(o); return -1; } l = (tag >> 2) + 1; off = in[i] | ((size_t)in[i + 1] << 8) | ((size_t)in[i + 2] << 16) | ((size_t)in[i + 3] << 24); i += 4; }
+      if (off == 0 || off > w || w + l > len) { free(o); return -1; }
+      for (size_t k = 0; k < l; k++) { o[w] = o[w - off]; w++; }
+    }
+  }
+  if (w != len) { free(o); return -1; }
+  *out = o; *out_n = len;
+  return 0;
+}
+static uint32_t rd_u32(const uint8_t* p) { return p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+static int place_rect(FoCtx* c, int64_t key, int w, int h, int* ox, int* oy);
+int fo_put_flippy(FoCtx* c, int64_t key, const uint8_t* data, size_t n, int out_rect[4]) {
+  if (n < 8 || memcmp(data, "flip", 4) != 0 || rd_u32(data + 4) != 1) return -2;
+  size_t i = 8;
+  int level = 0, rx = 0, ry = 0, S = c->atlas_size;
+  while (i < n) {
+    if (i + 16 > n || memcmp(data + i, "mip!", 4) != 0) return -2;
+    int w = (int)rd_u32(data + i + 4), h = (int)rd_u32(data + i + 8);
+    size_t z = rd_u32(data + i + 12);
+    i += 16;
+    if (i + z > n) return -2;
+    uint8_t* px; size_t pn;
+    if (snappy_uncompress(data + i, z, &px, &pn) != 0 || pn != (size_t)w * h * 4) return -2;
+    i += z;
+    for (size_t k = 0; k < (size_t)w * h; k++) { /* ColorRGBA -> ColorRGBX */
+      unsigned a = px[4 * k + 3];
+      px[4 * k + 0] = (uint8_t)((px[4 * k + 0] * a) / 255);
+      px[4 * k + 1] = (uint8_t)((px[4 * k + 1] * a) / 255);
+      px[4 * k + 2] = (uint8_t)((px[4 * k + 2] * a) / 255);
+    }
+    if (level == 0) {
+      if (place_rect(c, key, w, h, &rx, &ry) != 0) { free(px); return -1; }
+      if (out_rect) { out_rect[0] = rx; out_rect[1] = ry; out_rect[2] = w; out_rect[3] = h; }
+    }
+    if (level < c->n_mips) {
+      int LS = S >> level, lx = rx >> level, ly = ry >> level;
+      for (int yy = 0; yy < h; yy++)
+        for (int xx = 0; xx < w; xx++) {
+          int tx = lx + xx, ty = ly + yy;
+          if (tx >= 0 && ty >= 0 && tx < LS && ty < LS) memcpy(c->atlas[level] + ((size_t)ty * LS + tx) * 4, px + ((size_t)yy * w + xx) * 4, 4);
+        }
+    }
+    free(px);
+    level++;
+  }
+  return level > 0 ? 0 : -2;
 }
 
 static void draw_uv_quad(FoCtx* c, float ax, float ay, float tx, float ty, v2 uv_at, v2 uv_to, const FoColor colors[4],

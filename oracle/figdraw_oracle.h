@@ -17,6 +17,7 @@
  */
 #ifndef FIGDRAW_ORACLE_H
 #define FIGDRAW_ORACLE_H
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -154,6 +155,7 @@ void fo_pop_mask(FoCtx*);
 void fo_begin_rect_mask(FoCtx*, const float rect[4], const float radii_x[4], const float radii_y[4]);
 void fo_pop_rect_mask(FoCtx*);
 int fo_put_image(FoCtx*, int64_t key, int w, int h, const uint8_t* rgba, int out_rect[4]);
+int fo_put_flippy(FoCtx*, int64_t key, const uint8_t* file_bytes, size_t n, int out_rect[4]); /* putFlippy glcontext.nim:610-620 */
 void fo_set_text_subpixel(FoCtx*, int enabled, float shift);
 /* readPixels: top-down RGBA8, (x,y,w,h) in top-down pixel coordinates; w<=0 -> whole frame */
 int fo_read_pixels(FoCtx*, int x, int y, int w, int h, uint8_t* out);

@@ -67,6 +67,8 @@ def lib():
         L.fo_pop_rect_mask.argtypes = [C.c_void_p]
         L.fo_put_image.restype = C.c_int
         L.fo_put_image.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_int * 4]
+        L.fo_put_flippy.restype = C.c_int
+        L.fo_put_flippy.argtypes = [C.c_void_p, C.c_int64, C.c_char_p, C.c_size_t, C.c_int * 4]
         L.fo_set_text_subpixel.argtypes = [C.c_void_p, C.c_int, C.c_float]
         L.fo_read_pixels.restype = C.c_int
         L.fo_read_pixels.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
@@ -188,6 +190,12 @@ class Oracle:
         rc = self.L.fo_put_image(self.h, int(key), rgba.shape[1], rgba.shape[0], rgba.ctypes.data, out)
         if rc != 0:
             raise RuntimeError("oracle atlas full")
+        return tuple(out)
+
+    def put_flippy(self, key, file_bytes: bytes):
+        out = (C.c_int * 4)()
+        if self.L.fo_put_flippy(self.h, int(key), file_bytes, len(file_bytes), out) != 0:
+            raise RuntimeError("bad flippy / atlas full")
         return tuple(out)
 
     def read_pixels(self, x=0, y=0, w=0, h=0) -> np.ndarray:

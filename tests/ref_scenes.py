@@ -378,6 +378,20 @@ ATLAS_SCENES = {
 }
 
 
+FLIPPY_IMAGE_KEY = 0x696D6731  # any key: the reference hashes the file name (figbasics.nim imgId)
+
+
+def image_flippy(w=800.0, h=600.0) -> Renders:
+    """tests/trender_image.nim:13-38: grey 160 background + nkImage rect(60,60,160,160) showing data/img1.flippy
+    (100x100, 8 stored mips).  Reference output: tests/expected/render_image.png (atlas 2048)."""
+    lst = RenderList()
+    root = lst.addRoot(Fig(kind=RECT, screenBox=rect(0, 0, w, h), fill=rgba(160, 160, 160, 255)))
+    lst.addChild(root, Fig(kind=FigKind.nkImage, screenBox=rect(60, 60, 160, 160), image_id=FLIPPY_IMAGE_KEY))
+    out = Renders()
+    out.layers[0] = lst
+    return out
+
+
 def used_images(renders, images):
     """The subset of `images` a scene references, in sorted-key order (the upload order every backend uses)."""
     ids = set()

@@ -179,6 +179,33 @@ def test_atlas_scenes_match_oracle_and_goldens(name):
     ctx.close()
 
 
+def test_flippy_image_matches_oracle_and_reference_png():
+    """tests/trender_image.nim with data/img1.flippy through fdh_put_flippy; bad containers raise (formatflippy.nim:120-147)."""
+    import os
+
+    from conftest import GOLDEN
+
+    from figdraw_amd.context import HipContext
+    from oracle import oracle as O
+
+    data = open(os.path.join(GOLDEN, "img1.flippy"), "rb").read()
+    ctx = HipContext(atlas_size=2048, device=0)
+    o = O.Oracle(atlas_size=2048, threads=8)
+    assert ctx.put_flippy(RS.FLIPPY_IMAGE_KEY, data) == o.put_flippy(RS.FLIPPY_IMAGE_KEY, data) == (4, 4, 100, 100)
+    sc = RS.image_flippy()
+    ctx.render_frame(sc, 800, 600)
+    o.render_frame(sc, 800, 600)
+    got = ctx.read_pixels()
+    mx, n0, n1 = diff_stats(got, o.read_pixels())
+    assert mx <= 1 and n0 <= 0.005 * 800 * 600, ("vs oracle", mx, n0, n1)
+    mx, n0, n1 = diff_stats(got, load_png("ref_render_image.png"))
+    assert mx <= 2, ("vs reference PNG", mx, n0, n1)
+    for bad in (b"", b"flop" + data[4:], data[:4] + b"\x02\0\0\0" + data[8:], data[:40]):
+        with pytest.raises(Exception, match="[Ff]lippy"):
+            ctx.put_flippy(99, bad)
+    ctx.close()
+
+
 def test_t10k_glyph_config_4k_matches_oracle():
     """BASELINE config 4: 10 000 glyph quads (5 000 coverage glyphs 1:1 + 5 000 magnified MSDF) at 3840x2160."""
     import os

@@ -211,6 +211,24 @@ def test_oracle_atlas_sampling_matches_reference_shaders(name):
     assert mx <= 2 and n1 <= 0.001 * w * h, (name, mx, n0, n1)
 
 
+def test_oracle_flippy_image_matches_reference_png():
+    """putFlippy (glcontext.nim:610-620, formatflippy.nim:114-149) + nkImage: the reference's own tests/trender_image.nim
+    scene with its own data/img1.flippy, against its own tests/expected/render_image.png."""
+    import os
+
+    from conftest import GOLDEN
+
+    data = open(os.path.join(GOLDEN, "img1.flippy"), "rb").read()
+    o = O.Oracle(atlas_size=2048, threads=4)
+    assert o.put_flippy(RS.FLIPPY_IMAGE_KEY, data) == (4, 4, 100, 100)
+    o.render_frame(RS.image_flippy(), 800, 600)
+    mx, n0, n1 = diff_stats(o.read_pixels(), load_png("ref_render_image.png"))
+    assert mx <= 1 and n0 <= 0.01 * 800 * 600, (mx, n0, n1)
+    for bad in (b"", b"flop" + data[4:], data[:4] + b"\x02\0\0\0" + data[8:], data[:40]):
+        with pytest.raises(RuntimeError):
+            O.Oracle(atlas_size=256).put_flippy(1, bad)
+
+
 def test_atlas_packer_known_answers():
     """findEmptyRect (glcontext.nim:541-579): skyline with margin 4; entries are packed pixel rects."""
     o = O.Oracle(atlas_size=256)

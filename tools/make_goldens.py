@@ -55,6 +55,17 @@ def main():
             entry["swiftshader_vs_reference_png"] = stats(ss, exp)
         manifest[name] = entry
         print(name, entry)
+    # the reference's Flippy fixture and the PNG its own test expects for it (tests/trender_image.nim:13-38)
+    import shutil
+
+    shutil.copyfile("/root/reference/data/img1.flippy", os.path.join(GOLD, "img1.flippy"))
+    exp = np.array(Image.open(os.path.join(REF_EXPECTED, "render_image.png")).convert("RGBA"))
+    Image.fromarray(exp).save(os.path.join(GOLD, "ref_render_image.png"), optimize=True)
+    o = O.Oracle(atlas_size=2048, threads=8)
+    o.put_flippy(RS.FLIPPY_IMAGE_KEY, open(os.path.join(GOLD, "img1.flippy"), "rb").read())
+    o.render_frame(RS.image_flippy(), 800, 600)
+    manifest["image_flippy"] = {"width": 800, "height": 600, "oracle_vs_reference_png": stats(o.read_pixels(), exp)}
+    print("image_flippy", manifest["image_flippy"])
     # atlas scenes: images uploaded in sorted-key order into a 256^2 atlas (see ref_scenes.ATLAS_GOLDEN_SIZE)
     from figdraw_amd.scenes import load_glyph_fixture
 
