@@ -52,9 +52,10 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
-        raise FigdrawHipError(-2, f"{LIB_PATH} is missing: run __graft_entry__.build() (there is no CPU fallback)")
-    L = C.CDLL(LIB_PATH)
+    path = os.environ.get("FIGDRAW_HIP_LIB", LIB_PATH)  # override: instrumented builds (csrc/Makefile `stats`)
+    if not os.path.exists(path):
+        raise FigdrawHipError(-2, f"{path} is missing: run __graft_entry__.build() (there is no CPU fallback)")
+    L = C.CDLL(path)
     vp = C.c_void_p
     L.fdh_last_error.restype = C.c_char_p
     L.fdh_version.restype = C.c_char_p

@@ -34,6 +34,10 @@ inline Context* C(FdhContext* c) {
 extern "C" {
 
 const char* fdh_last_error(void) { return g_last_error.c_str(); }
+#if FDH_STATS
+extern "C++" { namespace fdh { void debug_counters(unsigned long long out[64], bool reset); } }
+__attribute__((visibility("default"))) int fdh_debug_counters(unsigned long long out[64], int reset) { fdh::debug_counters(out, reset != 0); return 0; }
+#endif
 const char* fdh_version(void) { return "figdraw_hip 0.1.0 (gfx950)"; }
 int fdh_sizeof_fig(void) { return (int)sizeof(FdhFig); }
 int fdh_sizeof_glyph(void) { return (int)sizeof(FdhGlyph); }

@@ -336,6 +336,64 @@ static inline void bbox_union(BBox& a, const BBox& b) {
   a.x0 = std::min(a.x0, b.x0); a.y0 = std::min(a.y0, b.y0); a.x1 = std::max(a.x1, b.x1); a.y1 = std::max(a.y1, b.y1);
 }
 
+// The part of an axis-aligned SDF quad where the coverage term is saturated (DrawRec::ix0..iy1).  Works in the
+// shader's local frame (atlas.frag:252-262: p = (uv - 0.5) * 2 * quadHalfExtents, y up) and maps back to pixels.
+// {dist <= -e} of sdRoundedBox(b, r) is the rounded box (b - e, max(r - e, 0)); an axis-aligned rectangle whose
+// corners are pulled in by (1 - 1/sqrt 2) r per corner lies inside it.  Elliptical corners use an approximate
+// distance (atlas.frag:71-79), so there the core stays out of the corner cells, where the distance is the plain
+// box distance max(|p| - b).  One pixel of slack on every side absorbs all float rounding.
+static void set_saturated_core(DrawRec& r, float w_px, float h_px) {
+  r.ix0 = r.iy0 = r.ix1 = r.iy1 = 0;
+  const uint32_t mode = r.op_mode & 255u, op = (r.op_mode >> 12) & 15u;
+  const uint32_t fill_mode = (r.op_mode >> 9) & 7u;
+  if (!(op == OP_DRAW || op == OP_MASK_PUSH) || !(r.aa > 0.0f)) return;
+  double e;  // core = {dist <= -e}
+  if (op == OP_MASK_PUSH || mode == FDH_SDF_CLIP_AA || mode == FDH_SDF_BACKDROP_BLUR) e = 0.5 / r.aa;
+  else if (mode == FDH_SDF_DROP_SHADOW) e = std::max(0.0, -(double)(fill_mode == 0u ? r.f1 : 0.0f));
+  else if (mode == FDH_SDF_ANNULAR || mode == FDH_SDF_ANNULAR_AA) e = std::max(0.0, (double)r.f0) + 0.5 / r.aa;
+  else return;
+  const double qhx = r.p0, qhy = r.p1, bx = r.p2, by = r.p3;
+  if (!(qhx > 0.0 && qhy > 0.0 && bx > 0.0 && by > 0.0)) return;
+  double crx[4], cry[4];  // TR, BR, TL, BL as in DrawRec::r
+  for (int k = 0; k < 4; k++) {
+    const double sel = r.r[k];
+    if (!(r.op_mode & F_ELLIP)) { crx[k] = cry[k] = std::max(sel, 0.0); continue; }
+    if (sel < 0.0) { crx[k] = cry[k] = -sel - 1.0; continue; }
+    const double pv = std::floor(sel + 0.5), hi = std::floor(pv / 4096.0);
+    crx[k] = (pv - 4096.0 * hi) * bx / 4095.0;
+    cry[k] = hi * by / 4095.0;
+  }
+  enum { TR = 0, BR = 1, TL = 2, BL = 3 };
+  double xl, xr, yb, yt;  // local frame, y up
+  if (!(r.op_mode & F_ELLIP)) {
+    const double k = 0.2929;
+    auto rr = [&](int i) { return std::max(crx[i] - e, 0.0); };
+    xr = (bx - e) - k * std::max(rr(TR), rr(BR));
+    xl = -(bx - e) + k * std::max(rr(TL), rr(BL));
+    yt = (by - e) - k * std::max(rr(TR), rr(TL));
+    yb = -(by - e) + k * std::max(rr(BR), rr(BL));
+  } else {
+    // horizontal band (full width, between the corner cells) or vertical band, whichever is larger
+    const double hx0 = -(bx - e), hx1 = bx - e;
+    const double hy1 = std::min(by - e, by - std::max(cry[TR], cry[TL])), hy0 = -std::min(by - e, by - std::max(cry[BR], cry[BL]));
+    const double vy0 = -(by - e), vy1 = by - e;
+    const double vx1 = std::min(bx - e, bx - std::max(crx[TR], crx[BR])), vx0 = -std::min(bx - e, bx - std::max(crx[TL], crx[BL]));
+    const double ah = std::max(hx1 - hx0, 0.0) * std::max(hy1 - hy0, 0.0), av = std::max(vx1 - vx0, 0.0) * std::max(vy1 - vy0, 0.0);
+    if (ah >= av) { xl = hx0; xr = hx1; yb = hy0; yt = hy1; } else { xl = vx0; xr = vx1; yb = vy0; yt = vy1; }
+  }
+  if (!(xr > xl && yt > yb)) return;
+  // local -> pixel centres: cx = ox + w_px * (x / (2 qhx) + 0.5), cy = oy + h_px * (0.5 - y / (2 qhy))
+  const double slack = 1.0;
+  const double cxl = r.ox + w_px * (xl / (2.0 * qhx) + 0.5) + slack, cxr = r.ox + w_px * (xr / (2.0 * qhx) + 0.5) - slack;
+  const double cyt = r.oy + h_px * (0.5 - yt / (2.0 * qhy)) + slack, cyb = r.oy + h_px * (0.5 - yb / (2.0 * qhy)) - slack;
+  double ix0 = std::ceil(cxl - 0.5), ix1 = std::floor(cxr - 0.5) + 1.0, iy0 = std::ceil(cyt - 0.5), iy1 = std::floor(cyb - 0.5) + 1.0;
+  ix0 = std::max(ix0, (double)r.ox); ix1 = std::min(ix1, (double)r.ox + w_px);  // stay inside the quad (coverage)
+  iy0 = std::max(iy0, (double)r.oy); iy1 = std::min(iy1, (double)r.oy + h_px);
+  auto c16 = [](double v) { return (int16_t)std::min(std::max(v, -32768.0), 32767.0); };
+  if (!(ix1 > ix0 && iy1 > iy0)) return;
+  r.ix0 = c16(ix0); r.iy0 = c16(iy0); r.ix1 = c16(ix1); r.iy1 = c16(iy1);
+}
+
 // Quad emission: ceil(ctx.mat * corner) per vertex, order BL,BR,TR,TL (glcontext.nim:1498-1509), then either the
 // axis-aligned fast form or the two-triangle general form.
 void Context::emit_quad(DrawRec& r, float x0, float y0, float x1, float y1, int64_t* fragments) {
@@ -367,6 +425,7 @@ void Context::emit_quad_pts(DrawRec& r, const float vx[4], const float vy[4], in
     r.oy = py[3];
     r.inv_w = 1.0f / (px[1] - px[0]);
     r.inv_h = 1.0f / (py[0] - py[3]);
+    set_saturated_core(r, px[1] - px[0], py[0] - py[3]);
   } else {
     QuadExt q;
     std::memset(&q, 0, sizeof q);
@@ -824,7 +883,14 @@ void Context::submit(bool upload) {
   for (auto& p : phases_) {
     max_count = std::max(max_count, p.count);
     BBox u{0, 0, 0, 0};
-    for (int i = p.first; i < p.first + p.count; i++) bbox_union(u, bboxes_[i]);
+    p.has_slow = false;
+    for (int i = p.first; i < p.first + p.count; i++) {
+      bbox_union(u, bboxes_[i]);
+      // mirrors the `fast` predicate of k_composite_tiles
+      const uint32_t om = recs_[i].op_mode, op = (om >> 12) & 15u, mode = om & 255u;
+      const bool atlas_mode = mode == 0u || (mode >= 13u && mode <= 16u);
+      if (op == OP_RMASK_BEGIN || ((op == OP_DRAW || op == OP_MASK_PUSH) && ((om & F_GENERAL) || atlas_mode || mode >= 18u))) p.has_slow = true;
+    }
     p.bin_x0 = u.x0 / kBin; p.bin_y0 = u.y0 / kBin;
     p.bin_x1 = bbox_empty(u) ? p.bin_x0 : (u.x1 + kBin - 1) / kBin;
     p.bin_y1 = bbox_empty(u) ? p.bin_y0 : (u.y1 + kBin - 1) / kBin;
@@ -937,6 +1003,7 @@ void Context::launch_frame(bool profile) {
     C.load_fb = full ? 0 : 1;
     C.clear_rgba8 = clear_rgba8_;
     C.n_wg = 0;
+    C.has_slow = ph.has_slow ? 1 : 0;
     span_begin(p == 0 ? 1 : 2);
     launch_composite(stream_, d_recs_.ptr, d_bboxes_.ptr, d_exts_.ptr, C);
     span_end();

@@ -22,6 +22,9 @@ namespace fdh {
 #endif
 #ifndef FDH_CLASSIFY
 #define FDH_CLASSIFY 1
+#ifndef FDH_STATS
+#define FDH_STATS 0  // `make stats`: per-strip draw classification counters (tools/strip_stats.py); never in the product build
+#endif
 #endif
 
 // ------------------------------------------------------------------ small device helpers
@@ -327,12 +330,21 @@ __device__ __forceinline__ Frag make_frag(const DrawRec& r, const QuadExt* __res
 
 // fixed-function blend SRC_ALPHA/ONE_MINUS_SRC_ALPHA (rgb), ONE/ONE_MINUS_SRC_ALPHA (alpha), then the RGBA8
 // store (utils/glutils.nim:150-154).  F holds the framebuffer texel as 0..255 integers in floats.
+typedef float f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void blend(F4& F, float r, float g, float b, float sa) {
-  const float ia = 1.0f - sa;
-  F.x = __builtin_rintf(r * (255.0f * sa) + F.x * ia);
-  F.y = __builtin_rintf(g * (255.0f * sa) + F.y * ia);
-  F.z = __builtin_rintf(b * (255.0f * sa) + F.z * ia);
-  F.w = __builtin_rintf(255.0f * sa + F.w * ia);
+  const float ia = 1.0f - sa, A = 255.0f * sa;
+  F.x = __builtin_rintf(__builtin_fmaf(F.x, ia, r * A));
+  F.y = __builtin_rintf(__builtin_fmaf(F.y, ia, g * A));
+  F.z = __builtin_rintf(__builtin_fmaf(F.z, ia, b * A));
+  F.w = __builtin_rintf(__builtin_fmaf(F.w, ia, A));
+}
+// the same blend with the source term (rgb * 255 sa, 255 sa) and 1 - sa already formed: two packed FMAs per pixel
+__device__ __forceinline__ void blend_pre(F4& F, f2 c_rg, f2 c_ba, float ia) {
+  f2 xy = {F.x, F.y}, zw = {F.z, F.w};
+  const f2 ia2 = {ia, ia};
+  xy = __builtin_elementwise_fma(xy, ia2, c_rg);
+  zw = __builtin_elementwise_fma(zw, ia2, c_ba);
+  F.x = __builtin_rintf(xy.x); F.y = __builtin_rintf(xy.y); F.z = __builtin_rintf(zw.x); F.w = __builtin_rintf(zw.y);
 }
 
 // atlas_rect_mask.frag:222-237
@@ -553,23 +565,40 @@ __device__ __forceinline__ Src shade_one(const DrawRec* __restrict__ rp, const Q
 // Axis-aligned SDF draws (fills, strokes, shadows, clip pushes, blur composites -- all but a handful of calls in
 // real scenes) take the 4-wide straight-line path.  Everything else goes through shade_one() one pixel slot at a
 // time; the per-lane state arrays are rotated between slots so they are only ever indexed statically.
-__global__ __launch_bounds__(256, 4) void k_composite_tiles(const DrawRec* __restrict__ draws, const BBox* __restrict__ bboxes,
+#if FDH_STATS
+__device__ unsigned long long g_counters[64];
+#define FDH_COUNT(i) do { if (lane == 0) atomicAdd(&g_counters[(i)], 1ull); } while (0)
+#else
+#define FDH_COUNT(i) do { } while (0)
+#endif
+#ifndef FDH_WAVE_WG
+#define FDH_WAVE_WG 1  // 1: a workgroup is ONE wavefront (the dispatcher refills wave slots one at a time)
+#endif
+// kSlow = false is the build for phases made only of axis-aligned SDF draws, clips and rect masks (no atlas sampling,
+// no rotated quads, no bezier strokes): without the one-pixel-slot path the kernel needs no scratch and fits 5 waves/SIMD.
+template <bool kSlow>
+__global__ __launch_bounds__(FDH_WAVE_WG ? 64 : 256, kSlow ? 4 : 5) void k_composite_tiles(const DrawRec* __restrict__ draws, const BBox* __restrict__ bboxes,
                                                          const QuadExt* __restrict__ exts, CompositeParams P) {
-  __shared__ uint32_t mask_stack[kWavesPerWg][kMaskDepth][64];  // 4 pixels' q8 mask values packed per lane
+  __shared__ uint32_t mask_stack[FDH_WAVE_WG ? 1 : kWavesPerWg][kMaskDepth][64];  // 4 pixels' q8 mask values packed per lane
   // XCD-aware remap: the dispatcher places workgroup b on XCD b % 8; give every XCD a contiguous run of
   // logical workgroups so the workgroups of a bin (same draw list, adjacent surface lines) share an L2.
   int wg = blockIdx.x;
   {
-    const int n = P.n_wg, per = (n + 7) >> 3;
+    const int n = FDH_WAVE_WG ? P.n_wg * kWavesPerWg : P.n_wg, per = (n + 7) >> 3;
     const int logical = (wg & 7) * per + (wg >> 3);
     if (logical >= n) return;  // padded tail of the remap (grid is rounded up to a multiple of 8)
     wg = logical;
   }
+#if FDH_WAVE_WG
+  const int wave = wg & (kWavesPerWg - 1), lane = threadIdx.x & 63, mslot = 0;
+  wg >>= 2;
+#else
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, mslot = wave;
+#endif
   const int bin_local = wg / kWgsPerBin, j = wg - bin_local * kWgsPerBin;
   const int bly = bin_local / P.bin_nx, blx = bin_local - bly * P.bin_nx;
   const int bin_x = P.bin_x0 + blx, bin_y = P.bin_y0 + bly;
   const int bin = bin_y * P.bins_x + bin_x;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int tx0 = bin_x * kBin + (j & 1) * kWgW;
   const int ty0 = bin_y * kBin + (j >> 1) * kWgH + wave * kTileH;
   if (tx0 >= P.W || ty0 >= P.H) return;
@@ -598,6 +627,7 @@ __global__ __launch_bounds__(256, 4) void k_composite_tiles(const DrawRec* __res
   float mk0 = 1.0f, mk1 = 1.0f, mk2 = 1.0f, mk3 = 1.0f;  // NfClipContent stack product (1 = maskTexEnabled false)
   float rm0 = 1.0f, rm1 = 1.0f, rm2 = 1.0f, rm3 = 1.0f;  // fast rect mask (atlas_rect_mask.frag), 1 when none
   int mask_depth = 0;
+  bool rmask_on = false;  // wave-uniform: rm0..3 may differ from 1
   bool touched = false;
   const uint32_t* __restrict__ list = P.lists + (size_t)bin * P.stride;
   const float cy = (float)py + 0.5f;
@@ -614,6 +644,10 @@ __global__ __launch_bounds__(256, 4) void k_composite_tiles(const DrawRec* __res
       hit = b.x0 < tx1 && b.x1 > tx0 && b.y0 < ty1 && b.y1 > ty0;
     }
     unsigned long long m = __ballot(hit);
+#ifdef FDH_EXPERIMENT_CULL_ONLY
+    touched = touched || m != 0;
+    continue;
+#endif
     if (m == 0) continue;
     // One draw = one lambda call.  The record of the NEXT surviving draw is fetched (scalar loads) before the
     // current one is shaded, so the ~L2-latency of the fetch overlaps the shading arithmetic.
@@ -622,10 +656,11 @@ __global__ __launch_bounds__(256, 4) void k_composite_tiles(const DrawRec* __res
       const uint32_t op = (om >> 12) & 15u;
       const uint32_t mode = om & 255u;
       touched = true;
+      FDH_COUNT(0);
       if (op == OP_MASK_POP) {
         mask_depth--;
         if (mask_depth > 0) {
-          const uint32_t w = mask_stack[wave][mask_depth - 1][lane];
+          const uint32_t w = mask_stack[mslot][mask_depth - 1][lane];
           mk0 = (float)(w & 255u) * inv255; mk1 = (float)((w >> 8) & 255u) * inv255;
           mk2 = (float)((w >> 16) & 255u) * inv255; mk3 = (float)(w >> 24) * inv255;
         } else {
@@ -633,16 +668,19 @@ __global__ __launch_bounds__(256, 4) void k_composite_tiles(const DrawRec* __res
         }
         return;
       }
-      if (op == OP_RMASK_END) { rm0 = rm1 = rm2 = rm3 = 1.0f; return; }
+      if (op == OP_RMASK_END) { rm0 = rm1 = rm2 = rm3 = 1.0f; rmask_on = false; return; }
       const bool atlas_mode = (mode == 0u) || (mode >= 13u && mode <= 16u);
       const bool fast = !(om & F_GENERAL) && !atlas_mode && mode < 18u && (op == OP_DRAW || op == OP_MASK_PUSH);
-      if (!fast) {
+      if (!kSlow && !fast) return;  // unreachable: the host picks kSlow = true for any phase holding such a draw
+      if (kSlow && !fast) {
+        FDH_COUNT(1);
         // ---- one pixel slot at a time, state rotated so slot 0 is always the live one
         uint32_t packed = 0;
 #pragma unroll 1
         for (int k = 0; k < 4; k++) {
           const int px = px0 + k;
           if (op == OP_RMASK_BEGIN) {
+            rmask_on = true;
             rm0 = rect_mask_alpha(draws[d], (float)px + 0.5f, cy);
           } else {
             const bool in_frame = row_ok && px < P.W;
@@ -662,13 +700,39 @@ __global__ __launch_bounds__(256, 4) void k_composite_tiles(const DrawRec* __res
           { const float t = mk0; mk0 = mk1; mk1 = mk2; mk2 = mk3; mk3 = t; }
           { const float t = rm0; rm0 = rm1; rm1 = rm2; rm2 = rm3; rm3 = t; }
         }
-        if (op == OP_MASK_PUSH) { mask_stack[wave][mask_depth][lane] = packed; mask_depth++; }
+        if (op == OP_MASK_PUSH) { mask_stack[mslot][mask_depth][lane] = packed; mask_depth++; }
         return;
       }
 
       // ---- fast path: axis-aligned SDF draw / clip push, 4 pixels per lane in lock-step
       const bool ellip = (om & F_ELLIP) != 0u;
       const uint32_t fill_mode = (om >> 9) & 7u;
+      // Saturated core (DrawRec::ix0..iy1), decided on the scalar unit: the whole strip has coverage alpha 1 -- or, for
+      // the annular stroke modes, alpha 0 and the draw is a no-op here.
+      const bool core = tx0 >= r.ix0 && tx1 <= r.ix1 && ty0 >= r.iy0 && ty1 <= r.iy1;
+      if (core) {
+        if (mode == 11u || mode == 12u) { FDH_COUNT(32); return; }
+        if (op == OP_DRAW && (om & F_SOLID) && fill_mode == 0u && mode != 17u) {
+          FDH_COUNT(33);
+          const F4 c0 = unpack255(r.col[0]);
+          const float sa = c0.w * inv255;
+          if (mask_depth == 0 && !rmask_on) {  // one source term for the whole strip
+            const float A = 255.0f * sa, ia = 1.0f - sa;
+            const f2 c_rg = {c0.x * inv255 * A, c0.y * inv255 * A}, c_ba = {c0.z * inv255 * A, A};
+            blend_pre(F0, c_rg, c_ba, ia); blend_pre(F1, c_rg, c_ba, ia); blend_pre(F2, c_rg, c_ba, ia); blend_pre(F3, c_rg, c_ba, ia);
+          } else {
+            const float cr = c0.x * inv255, cg = c0.y * inv255, cb = c0.z * inv255;
+            blend(F0, cr, cg, cb, sa * mk0 * rm0); blend(F1, cr, cg, cb, sa * mk1 * rm1);
+            blend(F2, cr, cg, cb, sa * mk2 * rm2); blend(F3, cr, cg, cb, sa * mk3 * rm3);
+          }
+          return;
+        }
+        FDH_COUNT(34);
+      }
+      FDH_COUNT(8 + (mode & 31u));
+      if (ellip) FDH_COUNT(2);
+      if (!(om & F_SOLID)) FDH_COUNT(3);
+      if (fill_mode != 0u) FDH_COUNT(4);
       const float t = (cy - r.oy) * r.inv_h;  // v of the quad (uv = (0,0)-(1,1) for SDF quads)
       const bool rowc = py >= r.by0 && py < r.by1;
       float u[4];
@@ -708,7 +772,11 @@ __global__ __launch_bounds__(256, 4) void k_composite_tiles(const DrawRec* __res
       // inner ones do too -- exactly, not approximately.  cls 1: alpha == 1 on the whole 32x8 strip (shape interior);
       // cls 2: alpha == 0 (deep inside a stroke): the draw is a no-op for this strip.
       int cls = 0;
-      if (FDH_CLASSIFY && !ellip) {
+      if (core) {
+        cls = 1;
+#pragma unroll
+        for (int k = 0; k < 4; k++) dist[k] = -1.0e30f;
+      } else if (FDH_CLASSIFY && !ellip) {
         const float lxo[2] = {lx[0], lx[3]};
         float d2[2];
         shape_distN<2>(false, lxo, -ly, shx, shy, r.r[0], r.r[1], r.r[2], r.r[3], d2);
@@ -721,6 +789,10 @@ __global__ __launch_bounds__(256, 4) void k_composite_tiles(const DrawRec* __res
         else if (mode == 12u) { const float h = r.f0 * 0.5f; zero = (dm + h < 0.0f) && (r.aa * (-(dm + h) - h) + 0.5f >= 1.0f); }
         if (__all(one)) cls = 1;
         else if (__all(zero)) cls = 2;
+        if (cls == 1) FDH_COUNT(5);
+        if (cls == 2) FDH_COUNT(6);
+        if (cls == 1 && r.bx0 <= tx0 && r.bx1 >= tx1 && r.by0 <= ty0 && r.by1 >= ty1) FDH_COUNT(7);
+        if (cls == 1) FDH_COUNT(40 + (mode & 15u));
         if (cls == 2) return;
         if (cls == 0) {
           const float lxi[2] = {lx[1], lx[2]};
@@ -747,14 +819,17 @@ __global__ __launch_bounds__(256, 4) void k_composite_tiles(const DrawRec* __res
           mk[k] = q * inv255;
         }
         mk0 = mk[0]; mk1 = mk[1]; mk2 = mk[2]; mk3 = mk[3];
-        mask_stack[wave][mask_depth][lane] = packed;
+        mask_stack[mslot][mask_depth][lane] = packed;
         mask_depth++;
         return;
       }
 
       // ---- OP_DRAW: atlas.frag main():252-405
       float alpha[4];
-      switch (mode) {  // wave-uniform
+      if (cls == 1) {  // wave-uniform: saturated coverage
+#pragma unroll
+        for (int k = 0; k < 4; k++) alpha[k] = 1.0f;
+      } else switch (mode) {  // wave-uniform
         case 11u: {
           const float h = r.f0 * 0.5f;
 #pragma unroll
@@ -874,8 +949,6 @@ __global__ __launch_bounds__(256, 4) void k_composite_tiles(const DrawRec* __res
 // every pixel and the pass is a fixed FIR over integer offsets (BlurTaps, built on the host).  Each thread produces
 // FOUR consecutive outputs along the filter direction: every staged texel is unpacked once (4 x v_cvt_f32_ubyte)
 // and feeds up to four accumulators with packed FMAs, instead of being re-read and re-unpacked per tap.
-typedef float f2 __attribute__((ext_vector_type(2)));
-
 __device__ __forceinline__ void unpack2(uint32_t c, f2& rg, f2& ba) {
   rg.x = (float)(c & 255u);
   rg.y = (float)((c >> 8) & 255u);
@@ -1021,8 +1094,10 @@ void launch_composite(hipStream_t s, const DrawRec* draws, const BBox* bboxes, c
   const int n = P.bin_nx * P.bin_ny * kWgsPerBin;
   if (n <= 0) return;
   P.n_wg = n;
-  const int grid = ((n + 7) / 8) * 8;
-  hipLaunchKernelGGL(k_composite_tiles, dim3(grid), dim3(256), 0, s, draws, bboxes, exts, P);
+  const int units = FDH_WAVE_WG ? n * kWavesPerWg : n;
+  const int grid = ((units + 7) / 8) * 8;
+  if (P.has_slow) hipLaunchKernelGGL(k_composite_tiles<true>, dim3(grid), dim3(FDH_WAVE_WG ? 64 : 256), 0, s, draws, bboxes, exts, P);
+  else hipLaunchKernelGGL(k_composite_tiles<false>, dim3(grid), dim3(FDH_WAVE_WG ? 64 : 256), 0, s, draws, bboxes, exts, P);
 }
 void launch_blur_h(hipStream_t s, const BlurParams& P) {
   if (P.x1 <= P.x0 || P.y1 <= P.y0) return;
@@ -1039,5 +1114,12 @@ void launch_fill(hipStream_t s, uint32_t* p, uint32_t v, size_t n) {
   if (n == 0) return;
   hipLaunchKernelGGL(k_fill_u32, dim3(1024), dim3(256), 0, s, p, v, n);
 }
+
+#if FDH_STATS
+void debug_counters(unsigned long long out[64], bool reset) {
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_counters), 64 * sizeof(unsigned long long));
+  if (reset) { unsigned long long z[64] = {}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_counters), z, sizeof z); }
+}
+#endif
 
 }  // namespace fdh

@@ -53,7 +53,11 @@ struct alignas(16) DrawRec {
   float aux;           // mode 0: subpixel shift ; atlas modes: texture LOD (log2 rho) in aux2
   float aux2;
   int16_t bx0, by0, bx1, by1;  // covered pixel bounds, clipped to the frame: [bx0,bx1) x [by0,by1)
-  uint32_t _pad[5];
+  // Saturated core of an axis-aligned SDF draw, in (unclipped) pixel bounds, empty when unknown: every pixel centre in
+  // [ix0,ix1) x [iy0,iy1) has coverage alpha == 1 (fills, clip pushes, drop-shadow bodies, blur composites) or, for
+  // the annular stroke modes 11/12, alpha == 0.  Conservative by a pixel; lets a strip be classified on the scalar unit.
+  int16_t ix0, iy0, ix1, iy1;
+  uint32_t _pad[3];
 };
 static_assert(sizeof(DrawRec) == 128, "DrawRec must be 128 bytes");
 
