@@ -35,7 +35,8 @@ extern "C" {
 
 const char* fdh_last_error(void) { return g_last_error.c_str(); }
 #if FDH_STATS
-extern "C++" { namespace fdh { void debug_counters(unsigned long long out[64], bool reset); } }
+extern "C++" { namespace fdh { void debug_counters(unsigned long long out[64], bool reset); void debug_wave_times(unsigned long long* out); } }
+__attribute__((visibility("default"))) int fdh_debug_wave_times(unsigned long long* out) { fdh::debug_wave_times(out); return 0; }
 __attribute__((visibility("default"))) int fdh_debug_counters(unsigned long long out[64], int reset) { fdh::debug_counters(out, reset != 0); return 0; }
 #endif
 const char* fdh_version(void) { return "figdraw_hip 0.1.0 (gfx950)"; }

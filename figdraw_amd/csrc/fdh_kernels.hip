@@ -18,7 +18,9 @@ namespace fdh {
 // A/B switches (measured on MI355X, S300@4K): record prefetch costs SGPR spills and loses ~5 %, the exact
 // tile classification wins 2-10 % depending on how many shapes have small radii.
 #ifndef FDH_PREFETCH
+#ifndef FDH_PREFETCH
 #define FDH_PREFETCH 0
+#endif
 #endif
 #ifndef FDH_CLASSIFY
 #define FDH_CLASSIFY 1
@@ -565,9 +567,20 @@ __device__ __forceinline__ Src shade_one(const DrawRec* __restrict__ rp, const Q
 // Axis-aligned SDF draws (fills, strokes, shadows, clip pushes, blur composites -- all but a handful of calls in
 // real scenes) take the 4-wide straight-line path.  Everything else goes through shade_one() one pixel slot at a
 // time; the per-lane state arrays are rotated between slots so they are only ever indexed statically.
+#ifndef FDH_TIMING
+#define FDH_TIMING 0  // `make variant DEFS="-DFDH_STATS=1 -DFDH_TIMING=1"`: per-wave phase times (100 MHz ticks) instead of counts
+#endif
+#if FDH_TIMING
+#define FDH_NOW() clock64()
+#endif
 #if FDH_STATS
+__device__ unsigned long long g_wave_times[8 * 65536];  // FDH_TIMING: one row per wave (no atomics: they would serialise)
 __device__ unsigned long long g_counters[64];
+#if FDH_TIMING
+#define FDH_COUNT(i) do { } while (0)
+#else
 #define FDH_COUNT(i) do { if (lane == 0) atomicAdd(&g_counters[(i)], 1ull); } while (0)
+#endif
 #else
 #define FDH_COUNT(i) do { } while (0)
 #endif
@@ -576,26 +589,29 @@ __device__ unsigned long long g_counters[64];
 #endif
 // kSlow = false is the build for phases made only of axis-aligned SDF draws, clips and rect masks (no atlas sampling,
 // no rotated quads, no bezier strokes): without the one-pixel-slot path the kernel needs no scratch and fits 5 waves/SIMD.
+#ifndef FDH_FAST_WAVES
+#define FDH_FAST_WAVES 5
+#endif
 template <bool kSlow>
-__global__ __launch_bounds__(FDH_WAVE_WG ? 64 : 256, kSlow ? 4 : 5) void k_composite_tiles(const DrawRec* __restrict__ draws, const BBox* __restrict__ bboxes,
+__global__ __launch_bounds__(FDH_WAVE_WG ? 64 : 256, kSlow ? 4 : FDH_FAST_WAVES) void k_composite_tiles(const DrawRec* __restrict__ draws, const BBox* __restrict__ bboxes,
                                                          const QuadExt* __restrict__ exts, CompositeParams P) {
   __shared__ uint32_t mask_stack[FDH_WAVE_WG ? 1 : kWavesPerWg][kMaskDepth][64];  // 4 pixels' q8 mask values packed per lane
-  // XCD-aware remap: the dispatcher places workgroup b on XCD b % 8; give every XCD a contiguous run of
-  // logical workgroups so the workgroups of a bin (same draw list, adjacent surface lines) share an L2.
-  int wg = blockIdx.x;
-  {
-    const int n = FDH_WAVE_WG ? P.n_wg * kWavesPerWg : P.n_wg, per = (n + 7) >> 3;
-    const int logical = (wg & 7) * per + (wg >> 3);
-    if (logical >= n) return;  // padded tail of the remap (grid is rounded up to a multiple of 8)
-    wg = logical;
-  }
+  // XCD-aware mapping: the dispatcher places workgroup b on XCD b % 8.  XCD x takes the bins x, x+8, x+16, ... of this
+  // launch (row-major), all 16 strips of a bin back to back: a bin's draw list and records stay in ONE L2, and every
+  // XCD gets an even sample of the frame -- contiguous bands per XCD left the XCDs holding the busy rows 3x the work
+  // of the ones holding the emptier top and bottom of the frame.
+  constexpr int kStripsPerBin = kWgsPerBin * kWavesPerWg;  // 16
 #if FDH_WAVE_WG
-  const int wave = wg & (kWavesPerWg - 1), lane = threadIdx.x & 63, mslot = 0;
-  wg >>= 2;
+  const int q = blockIdx.x >> 3, xcd = blockIdx.x & 7;
+  const int bin_local = xcd + 8 * (q / kStripsPerBin), sidx = q % kStripsPerBin;
+  if (bin_local >= P.bin_nx * P.bin_ny) return;
+  const int j = sidx >> 2, wave = sidx & 3, lane = threadIdx.x & 63, mslot = 0;
 #else
+  const int q = blockIdx.x >> 3, xcd = blockIdx.x & 7;
+  const int bin_local = xcd + 8 * (q / kWgsPerBin), j = q % kWgsPerBin;
+  if (bin_local >= P.bin_nx * P.bin_ny) return;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, mslot = wave;
 #endif
-  const int bin_local = wg / kWgsPerBin, j = wg - bin_local * kWgsPerBin;
   const int bly = bin_local / P.bin_nx, blx = bin_local - bly * P.bin_nx;
   const int bin_x = P.bin_x0 + blx, bin_y = P.bin_y0 + bly;
   const int bin = bin_y * P.bins_x + bin_x;
@@ -605,7 +621,14 @@ __global__ __launch_bounds__(FDH_WAVE_WG ? 64 : 256, kSlow ? 4 : 5) void k_compo
   if (ty0 + kTileH <= P.row_lo || ty0 >= P.row_hi) return;
   const int tx1 = tx0 + kTileW, ty1 = ty0 + kTileH;
   const int px0 = tx0 + (lane & 7) * 4, py = ty0 + (lane >> 3);
+#if FDH_TIMING
+  const unsigned long long T0 = FDH_NOW();
+  unsigned long long T_cull = 0, T_rec = 0, T_shade = 0, T_cnt = 0, n_draws_t = 0;
+#endif
   const uint32_t cnt = P.counts[bin];
+#if FDH_TIMING
+  T_cnt = FDH_NOW() - T0 + (cnt & 0u);
+#endif
   if (cnt == 0 && P.load_fb) return;  // nothing lands in this bin: the surface already holds the result
 
   const bool row_ok = py < P.H;
@@ -635,6 +658,9 @@ __global__ __launch_bounds__(FDH_WAVE_WG ? 64 : 256, kSlow ? 4 : 5) void k_compo
   const float inv255 = 1.0f / 255.0f;
 
   for (uint32_t base = 0; base < cnt; base += 64) {
+#if FDH_TIMING
+    const unsigned long long Tc0 = FDH_NOW();
+#endif
     const uint32_t i = base + lane;
     uint32_t idx = 0;
     bool hit = false;
@@ -644,6 +670,9 @@ __global__ __launch_bounds__(FDH_WAVE_WG ? 64 : 256, kSlow ? 4 : 5) void k_compo
       hit = b.x0 < tx1 && b.x1 > tx0 && b.y0 < ty1 && b.y1 > ty0;
     }
     unsigned long long m = __ballot(hit);
+#if FDH_TIMING
+    T_cull += FDH_NOW() - Tc0 + (m & 0ull);
+#endif
 #ifdef FDH_EXPERIMENT_CULL_ONLY
     touched = touched || m != 0;
     continue;
@@ -657,6 +686,9 @@ __global__ __launch_bounds__(FDH_WAVE_WG ? 64 : 256, kSlow ? 4 : 5) void k_compo
       const uint32_t mode = om & 255u;
       touched = true;
       FDH_COUNT(0);
+#ifdef FDH_X5
+      if (om != 0x12345u) return;
+#endif
       if (op == OP_MASK_POP) {
         mask_depth--;
         if (mask_depth > 0) {
@@ -710,12 +742,18 @@ __global__ __launch_bounds__(FDH_WAVE_WG ? 64 : 256, kSlow ? 4 : 5) void k_compo
       // Saturated core (DrawRec::ix0..iy1), decided on the scalar unit: the whole strip has coverage alpha 1 -- or, for
       // the annular stroke modes, alpha 0 and the draw is a no-op here.
       const bool core = tx0 >= r.ix0 && tx1 <= r.ix1 && ty0 >= r.iy0 && ty1 <= r.iy1;
+#ifdef FDH_X9
+      if (core || !core) { F0.x += core ? 1e-30f : 0.0f; return; }
+#endif
       if (core) {
         if (mode == 11u || mode == 12u) { FDH_COUNT(32); return; }
         if (op == OP_DRAW && (om & F_SOLID) && fill_mode == 0u && mode != 17u) {
           FDH_COUNT(33);
           const F4 c0 = unpack255(r.col[0]);
           const float sa = c0.w * inv255;
+#ifdef FDH_X10
+          if (mask_depth == 0 && !rmask_on) { F0.x += sa * 1e-30f; return; }
+#endif
           if (mask_depth == 0 && !rmask_on) {  // one source term for the whole strip
             const float A = 255.0f * sa, ia = 1.0f - sa;
             const f2 c_rg = {c0.x * inv255 * A, c0.y * inv255 * A}, c_ba = {c0.z * inv255 * A, A};
@@ -826,6 +864,12 @@ __global__ __launch_bounds__(FDH_WAVE_WG ? 64 : 256, kSlow ? 4 : 5) void k_compo
 
       // ---- OP_DRAW: atlas.frag main():252-405
       float alpha[4];
+#ifdef FDH_X1
+      if (cls != 1) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) alpha[k] = 1.0f - clamp01(r.aa * dist[k] + 0.5f);
+      } else
+#endif
       if (cls == 1) {  // wave-uniform: saturated coverage
 #pragma unroll
         for (int k = 0; k < 4; k++) alpha[k] = 1.0f;
@@ -879,6 +923,10 @@ __global__ __launch_bounds__(FDH_WAVE_WG ? 64 : 256, kSlow ? 4 : 5) void k_compo
           break;
         }
       }
+#ifdef FDH_X2
+      F0.x += alpha[0] * 1e-30f; F1.x += alpha[1] * 1e-30f; F2.x += alpha[2] * 1e-30f; F3.x += alpha[3] * 1e-30f;
+      return;
+#endif
       float sr[4], sg[4], sb[4], sa[4];
       if (mode == 17u) {  // atlas.frag:381-388: the blurred backdrop at this fragment's own pixel
         F4 b[4] = {F0, F1, F2, F3};
@@ -915,8 +963,16 @@ __global__ __launch_bounds__(FDH_WAVE_WG ? 64 : 256, kSlow ? 4 : 5) void k_compo
     };
     uint32_t d = __builtin_amdgcn_readlane(idx, __builtin_ctzll(m));
     m &= m - 1;
+#if FDH_TIMING
+    unsigned long long Tr0 = FDH_NOW();
+#endif
     DrawRec r = load_rec(draws + d);
     for (;;) {
+#if FDH_TIMING
+      const unsigned long long Tr1 = FDH_NOW() + (r.op_mode & 0u);
+      T_rec += Tr1 - Tr0;
+      n_draws_t++;
+#endif
       const bool more = m != 0;
       uint32_t d_next = d;
       if (more) { d_next = __builtin_amdgcn_readlane(idx, __builtin_ctzll(m)); m &= m - 1; }
@@ -925,6 +981,10 @@ __global__ __launch_bounds__(FDH_WAVE_WG ? 64 : 256, kSlow ? 4 : 5) void k_compo
       shade(d, r);
 #else
       shade(d, r);
+#if FDH_TIMING
+      Tr0 = FDH_NOW() + (__builtin_amdgcn_readfirstlane(__float_as_uint(F0.x + F1.x + F2.x + F3.x)) & 0u);
+      T_shade += Tr0 - Tr1;
+#endif
       const DrawRec r_next = load_rec(draws + d_next);
 #endif
       if (!more) break;
@@ -932,6 +992,13 @@ __global__ __launch_bounds__(FDH_WAVE_WG ? 64 : 256, kSlow ? 4 : 5) void k_compo
       r = r_next;
     }
   }
+#if FDH_TIMING
+  if (lane == 0 && blockIdx.x < 65536) {
+    const unsigned long long T1 = FDH_NOW();
+    unsigned long long* row = g_wave_times + 8 * (size_t)blockIdx.x;
+    row[0] = T1 - T0; row[1] = T_cnt; row[2] = T_cull; row[3] = T_rec; row[4] = T_shade; row[5] = n_draws_t; row[6] = 1; row[7] = T0;
+  }
+#endif
   if (!(touched || !P.load_fb) || py < P.row_lo || py >= P.row_hi) return;
   if (vec_ok) {
     uint4 o = {pack255(F0), pack255(F1), pack255(F2), pack255(F3)};
@@ -1094,8 +1161,8 @@ void launch_composite(hipStream_t s, const DrawRec* draws, const BBox* bboxes, c
   const int n = P.bin_nx * P.bin_ny * kWgsPerBin;
   if (n <= 0) return;
   P.n_wg = n;
-  const int units = FDH_WAVE_WG ? n * kWavesPerWg : n;
-  const int grid = ((units + 7) / 8) * 8;
+  const int bins8 = (P.bin_nx * P.bin_ny + 7) / 8;  // bins per XCD
+  const int grid = 8 * bins8 * (FDH_WAVE_WG ? kWgsPerBin * kWavesPerWg : kWgsPerBin);
   if (P.has_slow) hipLaunchKernelGGL(k_composite_tiles<true>, dim3(grid), dim3(FDH_WAVE_WG ? 64 : 256), 0, s, draws, bboxes, exts, P);
   else hipLaunchKernelGGL(k_composite_tiles<false>, dim3(grid), dim3(FDH_WAVE_WG ? 64 : 256), 0, s, draws, bboxes, exts, P);
 }
@@ -1116,6 +1183,10 @@ void launch_fill(hipStream_t s, uint32_t* p, uint32_t v, size_t n) {
 }
 
 #if FDH_STATS
+void debug_wave_times(unsigned long long* out) {
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_times), sizeof(unsigned long long) * 8 * 65536);
+  (void)hipMemset((void*)nullptr, 0, 0);
+}
 void debug_counters(unsigned long long out[64], bool reset) {
   (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_counters), 64 * sizeof(unsigned long long));
   if (reset) { unsigned long long z[64] = {}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_counters), z, sizeof z); }

@@ -13,8 +13,14 @@ w, h = 3840, 2160
 ctx = ctx_mod.HipContext(device=0)
 L = ctx_mod.load()
 buf = (C.c_ulonglong * 64)()
-L.fdh_debug_counters(buf, 1)
 ctx.render_frame(make_render_tree_100(w, h, frame=0, full_frame_blur=True), w, h)
+ctx.replay(5)
+ctx.sync()
+ctx.profile(5)
+st = ctx.frame_stats()
+print(f"this build: composite_main {st.ms_composite_main * 1000:.1f} us, frame {st.ms_total * 1000:.1f} us")
+L.fdh_debug_counters(buf, 1)  # reset after warm-up
+ctx.replay(1)
 ctx.sync()
 L.fdh_debug_counters(buf, 1)
 c = list(buf)
@@ -27,4 +33,28 @@ for m in range(32):
         print(f"fast mode {m:2d}: {c[8 + m]:10d}   of which cls1 {c[40 + (m & 15)] if m < 16 else 0:10d}")
 for i, n in ((32, "core: stroke no-op"), (33, "core: solid uniform blend"), (34, "core: other (gradient / push / blur)")):
     print(f"{n:34s} {c[i]:10d}")
+if hasattr(L, "fdh_debug_wave_times") and os.environ.get("FDH_TIMING"):
+    import numpy as np
+    wt = np.zeros((65536, 8), dtype=np.uint64)
+    L.fdh_debug_wave_times(wt.ctypes.data_as(C.c_void_p))
+    ids = np.nonzero(wt[:, 6] == 1)[0]
+    wt = wt[wt[:, 6] == 1].astype(np.float64)
+    per_xcd = [wt[(ids & 7) == x, 0].sum() / 1000 for x in range(8)]
+    print("sum of wave durations per XCD (kcycles):", [round(v) for v in per_xcd], " balanced kernel = sum/5120 slots =",
+          round(wt[:, 0].sum() / 5120 / 1000, 1), "kcycles;  worst XCD / 640 slots =", round(max(per_xcd) / 640, 1))
+    for x in range(8):
+        sel = (ids & 7) == x
+        tt = wt[sel, 7]
+        print("  xcd", x, "span kcycles", round(((tt - tt.min()) + wt[sel, 0]).max() / 1000, 1), "waves", int(sel.sum()))
+    n = len(wt)
+    for i in range(6):
+        c[50 + i] = wt[:, i].sum()
+    c[56] = n
+    t0 = wt[:, 7] - wt[:, 7].min()
+    print("kernel span (kcycles): first start -> last end", (t0 + wt[:, 0]).max() / 1000, " wave duration p50/p90/max",
+          np.percentile(wt[:, 0], 50) / 1000, np.percentile(wt[:, 0], 90) / 1000, wt[:, 0].max() / 1000)
+if c[56]:
+    n = c[56]
+    print(f"timing build: {n} waves, mean per wave in kilo-cycles (s_memtime): total {c[50] / n / 1000:.2f}  counts-load {c[51] / n / 1000:.2f}  "
+          f"cull {c[52] / n / 1000:.2f}  record-wait {c[53] / n / 1000:.2f}  shade {c[54] / n / 1000:.2f}  draws/wave {c[55] / n:.2f}")
 print("strips:", (w // 32) * (h // 8))
