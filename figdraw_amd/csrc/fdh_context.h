@@ -202,7 +202,8 @@ class Context {
   DeviceBuf<DrawRec> d_recs_;
   DeviceBuf<BBox> d_bboxes_;
   DeviceBuf<QuadExt> d_exts_;
-  DeviceBuf<uint32_t> d_lists_, d_counts_;
+  DeviceBuf<uint2> d_lists_;
+  DeviceBuf<uint32_t> d_counts_;
   DeviceBuf<int> d_phase_first_;
   PinnedBuf<uint8_t> staging_;
   int bins_x_ = 0, bins_y_ = 0, list_stride_ = 0;

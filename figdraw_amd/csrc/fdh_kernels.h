@@ -8,14 +8,14 @@ namespace fdh {
 
 struct BinParams {
   const BBox* bbox;     // per draw, clipped pixel bounds (ops that must reach every tile carry the frame)
-  uint32_t* lists;      // [phase][bin][stride]
+  uint2* lists;         // [phase][bin][stride] entries {draw index, 16-bit strip mask}
   uint32_t* counts;     // [phase][bin]
   const int* phase_first;  // [n_phases + 1]
   int n_phases, bins_x, bins_y, stride;
 };
 
 struct CompositeParams {
-  const uint32_t* lists;   // this phase's [bin][stride]
+  const uint2* lists;      // this phase's [bin][stride]
   const uint32_t* counts;  // this phase's [bin]
   const uint32_t* backdrop;  // blurred snapshot sampled by mode 17
   uint32_t* fb;

@@ -203,6 +203,27 @@ __device__ __forceinline__ F4 atlas_sample(const AtlasView& A, float u, float v,
 
 // ------------------------------------------------------------------ binning
 
+// Which of a bin's 16 strips (32x8 px; strip s = (jy*2 + jx)*4 + w sits at column jx, row jy*4 + w) a bin-relative
+// pixel box [x0,x1) x [y0,y1) touches.  The compositor's per-strip culling is then one bit test on the list entry
+// instead of a dependent bounding-box fetch.
+__device__ __forceinline__ uint32_t strip_mask(int x0, int y0, int x1, int y1) {
+  x0 = x0 < 0 ? 0 : x0; y0 = y0 < 0 ? 0 : y0;
+  x1 = x1 > kBin ? kBin : x1; y1 = y1 > kBin ? kBin : y1;
+  const int r0 = y0 >> 3, r1 = (y1 + 7) >> 3;                   // strip rows [r0, r1) of 8
+  const uint32_t rows = ((1u << r1) - 1u) & ~((1u << r0) - 1u);  // 8 bits
+  const uint32_t cols = (x0 < kTileW ? 1u : 0u) | (x1 > kTileW ? 2u : 0u);
+  uint32_t m = 0;
+#pragma unroll
+  for (int r = 0; r < 8; r++) {
+    if (rows & (1u << r)) {
+      const int jy = r >> 2, w = r & 3;
+      if (cols & 1u) m |= 1u << ((jy * 2 + 0) * 4 + w);
+      if (cols & 2u) m |= 1u << ((jy * 2 + 1) * 4 + w);
+    }
+  }
+  return m;
+}
+
 // One workgroup per (phase, bin): ordered stream compaction of the phase's draws that touch the bin.
 __global__ __launch_bounds__(256) void k_bin_draws(BinParams P) {
   __shared__ uint32_t wave_cnt[4];
@@ -212,16 +233,18 @@ __global__ __launch_bounds__(256) void k_bin_draws(BinParams P) {
   const int by = bin / P.bins_x, bx = bin - by * P.bins_x;
   const int x0 = bx * kBin, y0 = by * kBin, x1 = x0 + kBin, y1 = y0 + kBin;
   const int first = P.phase_first[phase], last = P.phase_first[phase + 1];
-  uint32_t* out = P.lists + ((size_t)phase * nb + bin) * P.stride;
+  uint2* out = P.lists + ((size_t)phase * nb + bin) * P.stride;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (threadIdx.x == 0) base_sh = 0;
   __syncthreads();
   for (int i0 = first; i0 < last; i0 += 256) {
     int i = i0 + threadIdx.x;
     bool hit = false;
+    uint32_t strips = 0;
     if (i < last) {
       BBox b = P.bbox[i];
       hit = b.x0 < x1 && b.x1 > x0 && b.y0 < y1 && b.y1 > y0;
+      if (hit) strips = strip_mask(b.x0 - x0, b.y0 - y0, b.x1 - x0, b.y1 - y0);
     }
     unsigned long long m = __ballot(hit);
     uint32_t before = __builtin_popcountll(m & ((1ull << lane) - 1ull));
@@ -234,7 +257,7 @@ __global__ __launch_bounds__(256) void k_bin_draws(BinParams P) {
       if (w < wave) woff += c;
       total += c;
     }
-    if (hit) out[base + woff + before] = (uint32_t)i;
+    if (hit) out[base + woff + before] = make_uint2((uint32_t)i, strips);
     __syncthreads();
     if (threadIdx.x == 0) base_sh = base + total;
     __syncthreads();
@@ -612,6 +635,7 @@ __global__ __launch_bounds__(FDH_WAVE_WG ? 64 : 256, kSlow ? 4 : FDH_FAST_WAVES)
   if (bin_local >= P.bin_nx * P.bin_ny) return;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, mslot = wave;
 #endif
+  const int sbit = j * 4 + wave;  // this strip's bit in the list entries' strip masks
   const int bly = bin_local / P.bin_nx, blx = bin_local - bly * P.bin_nx;
   const int bin_x = P.bin_x0 + blx, bin_y = P.bin_y0 + bly;
   const int bin = bin_y * P.bins_x + bin_x;
@@ -623,7 +647,7 @@ __global__ __launch_bounds__(FDH_WAVE_WG ? 64 : 256, kSlow ? 4 : FDH_FAST_WAVES)
   const int px0 = tx0 + (lane & 7) * 4, py = ty0 + (lane >> 3);
 #if FDH_TIMING
   const unsigned long long T0 = FDH_NOW();
-  unsigned long long T_cull = 0, T_rec = 0, T_shade = 0, T_cnt = 0, n_draws_t = 0;
+  unsigned long long T_cull = 0, T_rec = 0, T_shade = 0, T_cnt = 0, n_draws_t = 0, T_cull_core = 0, n_core_t = 0;
 #endif
   const uint32_t cnt = P.counts[bin];
 #if FDH_TIMING
@@ -652,7 +676,7 @@ __global__ __launch_bounds__(FDH_WAVE_WG ? 64 : 256, kSlow ? 4 : FDH_FAST_WAVES)
   int mask_depth = 0;
   bool rmask_on = false;  // wave-uniform: rm0..3 may differ from 1
   bool touched = false;
-  const uint32_t* __restrict__ list = P.lists + (size_t)bin * P.stride;
+  const uint2* __restrict__ list = P.lists + (size_t)bin * P.stride;
   const float cy = (float)py + 0.5f;
   const float cx0 = (float)px0 + 0.5f;
   const float inv255 = 1.0f / 255.0f;
@@ -665,9 +689,9 @@ __global__ __launch_bounds__(FDH_WAVE_WG ? 64 : 256, kSlow ? 4 : FDH_FAST_WAVES)
     uint32_t idx = 0;
     bool hit = false;
     if (i < cnt) {
-      idx = list[i];
-      const BBox b = bboxes[idx];
-      hit = b.x0 < tx1 && b.x1 > tx0 && b.y0 < ty1 && b.y1 > ty0;
+      const uint2 e = list[i];  // {draw index, strips of this bin the draw's bounds touch}
+      idx = e.x;
+      hit = (e.y >> sbit) & 1u;
     }
     unsigned long long m = __ballot(hit);
 #if FDH_TIMING
@@ -767,6 +791,9 @@ __global__ __launch_bounds__(FDH_WAVE_WG ? 64 : 256, kSlow ? 4 : FDH_FAST_WAVES)
         }
         FDH_COUNT(34);
       }
+#ifdef FDH_X3
+      if (!core) return;
+#endif
       FDH_COUNT(8 + (mode & 31u));
       if (ellip) FDH_COUNT(2);
       if (!(om & F_SOLID)) FDH_COUNT(3);
@@ -984,6 +1011,7 @@ __global__ __launch_bounds__(FDH_WAVE_WG ? 64 : 256, kSlow ? 4 : FDH_FAST_WAVES)
 #if FDH_TIMING
       Tr0 = FDH_NOW() + (__builtin_amdgcn_readfirstlane(__float_as_uint(F0.x + F1.x + F2.x + F3.x)) & 0u);
       T_shade += Tr0 - Tr1;
+      if (tx0 >= r.ix0 && tx1 <= r.ix1 && ty0 >= r.iy0 && ty1 <= r.iy1) { T_cull_core += Tr0 - Tr1; n_core_t++; }
 #endif
       const DrawRec r_next = load_rec(draws + d_next);
 #endif
@@ -996,7 +1024,7 @@ __global__ __launch_bounds__(FDH_WAVE_WG ? 64 : 256, kSlow ? 4 : FDH_FAST_WAVES)
   if (lane == 0 && blockIdx.x < 65536) {
     const unsigned long long T1 = FDH_NOW();
     unsigned long long* row = g_wave_times + 8 * (size_t)blockIdx.x;
-    row[0] = T1 - T0; row[1] = T_cnt; row[2] = T_cull; row[3] = T_rec; row[4] = T_shade; row[5] = n_draws_t; row[6] = 1; row[7] = T0;
+    row[0] = T1 - T0; row[1] = T_cnt; row[2] = T_cull; row[3] = T_rec; row[4] = T_shade; row[5] = n_draws_t; row[6] = 1; row[7] = T_cull_core * 1024 + n_core_t;
   }
 #endif
   if (!(touched || !P.load_fb) || py < P.row_lo || py >= P.row_hi) return;

@@ -4,7 +4,7 @@ import collections, csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in rows:
-    k = r['Kernel_Name'].split('(')[0]
+    k = r['Kernel_Name'].split('(')[0].replace('void ', '')
     if not k.startswith('fdh::'):
         continue
     agg[(k, r.get('Grid_Size'), r.get('VGPR_Count'), r.get('SGPR_Count'))][r['Counter_Name']].append(float(r['Counter_Value']))

@@ -42,16 +42,15 @@ if hasattr(L, "fdh_debug_wave_times") and os.environ.get("FDH_TIMING"):
     per_xcd = [wt[(ids & 7) == x, 0].sum() / 1000 for x in range(8)]
     print("sum of wave durations per XCD (kcycles):", [round(v) for v in per_xcd], " balanced kernel = sum/5120 slots =",
           round(wt[:, 0].sum() / 5120 / 1000, 1), "kcycles;  worst XCD / 640 slots =", round(max(per_xcd) / 640, 1))
-    for x in range(8):
-        sel = (ids & 7) == x
-        tt = wt[sel, 7]
-        print("  xcd", x, "span kcycles", round(((tt - tt.min()) + wt[sel, 0]).max() / 1000, 1), "waves", int(sel.sum()))
+
     n = len(wt)
     for i in range(6):
         c[50 + i] = wt[:, i].sum()
+    core_t = np.floor(wt[:, 7] / 1024).sum(); core_n = (wt[:, 7] % 1024).sum()
+    print(f"shade: core draws {int(core_n)} mean {core_t / max(core_n, 1):.0f} cycles; other draws {int(c[55] - core_n)} mean "
+          f"{(c[54] - core_t) / max(c[55] - core_n, 1):.0f} cycles")
     c[56] = n
-    t0 = wt[:, 7] - wt[:, 7].min()
-    print("kernel span (kcycles): first start -> last end", (t0 + wt[:, 0]).max() / 1000, " wave duration p50/p90/max",
+    print("wave duration p50/p90/max",
           np.percentile(wt[:, 0], 50) / 1000, np.percentile(wt[:, 0], 90) / 1000, wt[:, 0].max() / 1000)
 if c[56]:
     n = c[56]
