@@ -820,7 +820,7 @@ static BlurTaps make_taps(float blur_radius) {
     add((int)fl + 1, w[i + 8] * a * inv);
   }
   for (int k = 0; k < t.n; k++) t.reach = std::max(t.reach, std::abs(t.off[k]));
-  for (int k = 0; k < t.n; k++) t.dense[3 + t.reach + t.off[k]] = t.coef[k];
+  for (int k = 0; k < t.n; k++) t.dense[kBlurPad + t.reach + t.off[k]] = t.coef[k];
   return t;
 }
 

@@ -1055,65 +1055,99 @@ __device__ __forceinline__ uint32_t pack2(f2 rg, f2 ba) {
          ((uint32_t)__builtin_rintf(ba.y) << 24);
 }
 
-constexpr int kBlurHW = 256;  // horizontal pass: one wave = 256 consecutive pixels of one row (4 per lane), 4 rows per workgroup
-constexpr int kBlurHLine = kBlurHW + 2 * kMaxBlurReach + 4;
+constexpr int kBlurOut = 8;             // consecutive outputs per thread along the filter direction
+constexpr int kBlurHW = 64 * kBlurOut;  // horizontal pass: one wave = 512 consecutive pixels of one row, 4 rows per workgroup
+constexpr int kBlurHLine = kBlurHW + 2 * kMaxBlurReach + 8;
+
+// One thread's kBlurOut consecutive outputs of the merged FIR.  `tex(j)` returns window texel j (output p sees it at
+// offset j - p - reach); every texel is unpacked once and feeds the accumulators with packed FMAs.  The first and last
+// kBlurOut - 1 window texels reach only some of the outputs (the rest would multiply the zero padding of `dense`):
+// those two triangles are peeled with the in-range (p, j) pairs spelled out at compile time.
+template <typename Tex>
+__device__ __forceinline__ void fir_outputs(const float* __restrict__ d, int reach, Tex tex, f2 (&rg)[kBlurOut], f2 (&ba)[kBlurOut]) {
+#pragma unroll
+  for (int p = 0; p < kBlurOut; p++) { rg[p] = 0.0f; ba[p] = 0.0f; }
+  const int nwin = kBlurOut + 2 * reach;
+  // head: window texels 0 .. kBlurOut-2, texel j reaches outputs p <= j
+#pragma unroll
+  for (int j = 0; j < kBlurOut - 1; j++) {
+    f2 trg, tba;
+    unpack2(tex(j), trg, tba);
+#pragma unroll
+    for (int p = 0; p <= j; p++) {
+      const float c = d[j - p + kBlurPad];
+      rg[p] += trg * c;
+      ba[p] += tba * c;
+    }
+  }
+  // body: every output is in range
+  for (int j = kBlurOut - 1; j < nwin - (kBlurOut - 1); j++) {
+    f2 trg, tba;
+    unpack2(tex(j), trg, tba);
+#pragma unroll
+    for (int p = 0; p < kBlurOut; p++) {
+      const float c = d[j - p + kBlurPad];
+      rg[p] += trg * c;
+      ba[p] += tba * c;
+    }
+  }
+  // tail: window texel nwin-1-i (i = kBlurOut-2 .. 0) reaches outputs p >= kBlurOut-1-i
+#pragma unroll
+  for (int i = kBlurOut - 2; i >= 0; i--) {
+    const int j = nwin - 1 - i;
+    f2 trg, tba;
+    unpack2(tex(j), trg, tba);
+#pragma unroll
+    for (int p = kBlurOut - 1 - i; p < kBlurOut; p++) {
+      const float c = d[j - p + kBlurPad];
+      rg[p] += trg * c;
+      ba[p] += tba * c;
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void k_blur_h(BlurParams P) {
   __shared__ __attribute__((aligned(16))) uint32_t lines[4][kBlurHLine];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int y = P.y0 + blockIdx.y * 4 + wave;
   const int xs = P.x0 + blockIdx.x * kBlurHW;
   const int reach = P.taps.reach;
-  const int span = kBlurHW + 2 * reach;
+  const int wpx = min(kBlurHW, P.x1 - xs);  // pixels this block produces
+  const int span = wpx + 2 * reach;
   uint32_t* line = lines[wave];
   if (y < P.y1) {
     const uint32_t* __restrict__ row = P.src + (size_t)y * P.pitch;
-    for (int i = lane; i < span + 4; i += 64) {
+    for (int i = lane; i < span + kBlurOut; i += 64) {
       int x = xs - reach + i;
       x = x < 0 ? 0 : (x > P.W - 1 ? P.W - 1 : x);  // clamp-to-edge (glcontext.nim:214-215)
       line[i] = row[x];
     }
   }
-  __syncthreads();
-  const int x = xs + lane * 4;
+  __builtin_amdgcn_wave_barrier();  // a wave reads back only the line it staged itself: no workgroup barrier
+  const int x = xs + lane * kBlurOut;
   if (y >= P.y1 || x >= P.x1) return;
-  f2 rg[4], ba[4];
+  f2 rg[kBlurOut], ba[kBlurOut];
+  const uint32_t* __restrict__ win = line + lane * kBlurOut;
+  fir_outputs(P.taps.dense, reach, [&](int j) { return win[j]; }, rg, ba);
+  uint32_t ov[kBlurOut];
 #pragma unroll
-  for (int p = 0; p < 4; p++) { rg[p] = 0.0f; ba[p] = 0.0f; }
-  const float* __restrict__ d = P.taps.dense;  // d[3 + reach + off]
-  const int nwin = 4 + 2 * reach;              // window texels: outputs p..p+2*reach for p = 0..3
-  const uint4* __restrict__ win = reinterpret_cast<const uint4*>(line + lane * 4);
-  for (int jj = 0; jj < nwin; jj += 4) {
-    const uint4 q = win[jj >> 2];
-    const uint32_t tx[4] = {q.x, q.y, q.z, q.w};
-#pragma unroll
-    for (int s = 0; s < 4; s++) {
-      f2 trg, tba;
-      unpack2(tx[s], trg, tba);
-      const int j = jj + s;  // window index: output p sees it at offset j - p - reach -> dense index j - p + 3
-#pragma unroll
-      for (int p = 0; p < 4; p++) {
-        const float c = d[j - p + 3];
-        rg[p] += trg * c;
-        ba[p] += tba * c;
-      }
-    }
-  }
-  uint4 o = {pack2(rg[0], ba[0]), pack2(rg[1], ba[1]), pack2(rg[2], ba[2]), pack2(rg[3], ba[3])};
+  for (int p = 0; p < kBlurOut; p++) ov[p] = pack2(rg[p], ba[p]);
   uint32_t* out = P.dst + (size_t)y * P.pitch + x;
-  if (x + 3 < P.x1 && ((reinterpret_cast<uintptr_t>(out) & 15) == 0)) {
-    *reinterpret_cast<uint4*>(out) = o;
+  if (x + kBlurOut - 1 < P.x1 && ((reinterpret_cast<uintptr_t>(out) & 15) == 0)) {
+    reinterpret_cast<uint4*>(out)[0] = make_uint4(ov[0], ov[1], ov[2], ov[3]);
+    reinterpret_cast<uint4*>(out)[1] = make_uint4(ov[4], ov[5], ov[6], ov[7]);
   } else {
-    const uint32_t ov[4] = {o.x, o.y, o.z, o.w};
 #pragma unroll
-    for (int p = 0; p < 4; p++) if (x + p < P.x1) out[p] = ov[p];
+    for (int p = 0; p < kBlurOut; p++) if (x + p < P.x1) out[p] = ov[p];
   }
 }
 
-// vertical pass: one workgroup = 64 columns x 32 rows (taller tiles cut the halo re-read but cost LDS occupancy: measured slower); a lane owns a column, each wave
-// produces 8 rows as two groups of 4 consecutive outputs.  With fuse_draw >= 0 the consuming mode-17 quad is blended in place.
-constexpr int kBlurVW = 64, kBlurVH = 32;
+// vertical pass: one workgroup = 64 columns x 32 rows (taller tiles cut the halo re-read but cost LDS occupancy: measured
+// slower); a lane owns a column, each wave produces 8 consecutive rows.  With fuse_draw >= 0 the consuming mode-17 quad
+// is blended in place; tiles inside the quad's saturated core (DrawRec::ix0..iy1) skip the coverage evaluation.
+constexpr int kBlurVW = 64, kBlurVH = 4 * kBlurOut;
 __global__ __launch_bounds__(256) void k_blur_v(BlurParams P, const DrawRec* __restrict__ draws, const QuadExt* __restrict__ exts) {
-  extern __shared__ uint32_t tile[];  // (kBlurVH + 2*reach + 4) rows x 64 columns
+  extern __shared__ uint32_t tile[];  // (kBlurVH + 2*reach) rows x 64 columns
   const int xs = P.x0 + blockIdx.x * kBlurVW;
   const int ys = P.y0 + blockIdx.y * kBlurVH;
   const int reach = P.taps.reach;
@@ -1127,50 +1161,38 @@ __global__ __launch_bounds__(256) void k_blur_v(BlurParams P, const DrawRec* __r
     tile[rr * kBlurVW + lane] = P.src[(size_t)y * P.pitch + xc];
   }
   __syncthreads();
-  if (x >= P.x1) return;
-  const float* __restrict__ d = P.taps.dense;
-  const int nwin = 4 + 2 * reach;
-  DrawRec r;
-  if (P.fuse_draw >= 0) r = load_rec(draws + P.fuse_draw);
-#pragma unroll 1
-  for (int g = 0; g < kBlurVH / 16; g++) {
-    const int ry = wave * (kBlurVH / 4) + g * 4;  // first of the four output rows, relative to ys
-    const int y = ys + ry;
-    if (y >= P.y1) break;
-    f2 rg[4], ba[4];
+  const int ry = wave * kBlurOut;  // first of this wave's output rows, relative to ys
+  const int y = ys + ry;
+  if (x >= P.x1 || y >= P.y1) return;
+  f2 rg[kBlurOut], ba[kBlurOut];
+  const uint32_t* __restrict__ col = tile + ry * kBlurVW + lane;  // window row j is tile row ry + j
+  fir_outputs(P.taps.dense, reach, [&](int j) { return col[j * kBlurVW]; }, rg, ba);
+  if (P.fuse_draw < 0) {
 #pragma unroll
-    for (int p = 0; p < 4; p++) { rg[p] = 0.0f; ba[p] = 0.0f; }
-    const uint32_t* __restrict__ col = tile + ry * kBlurVW + lane;  // window row j is tile row ry + j
-    for (int j = 0; j < nwin; j++) {
-      f2 trg, tba;
-      unpack2(col[j * kBlurVW], trg, tba);
+    for (int p = 0; p < kBlurOut; p++)
+      if (y + p < P.y1) P.dst[(size_t)(y + p) * P.pitch + x] = pack2(rg[p], ba[p]);
+    return;
+  }
+  // atlas.frag:381-388 on the blurred texel just produced, blended over the live surface (first draw of the phase)
+  const DrawRec r = load_rec(draws + P.fuse_draw);
+  const bool core = xs >= r.ix0 && xs + kBlurVW <= r.ix1 && ys >= r.iy0 && ys + kBlurVH <= r.iy1;  // coverage alpha == 1
+  const float k = 1.0f / 255.0f;
 #pragma unroll
-      for (int p = 0; p < 4; p++) {
-        const float c = d[j - p + 3];
-        rg[p] += trg * c;
-        ba[p] += tba * c;
-      }
+  for (int p = 0; p < kBlurOut; p++) {
+    if (y + p >= P.y1) break;
+    const size_t pix = (size_t)(y + p) * P.pitch + x;
+    const F4 b = {__builtin_rintf(rg[p].x), __builtin_rintf(rg[p].y), __builtin_rintf(ba[p].x), __builtin_rintf(ba[p].y)};
+    float alpha = 1.0f;
+    if (!core) {  // workgroup-uniform
+      const Frag f = make_frag(r, exts, x, y + p);
+      if (!f.covered) continue;
+      const float lx = (f.u - 0.5f) * 2.0f * r.p0, ly = (f.v - 0.5f) * 2.0f * r.p1;
+      const float dist = shape_dist((r.op_mode & F_ELLIP) != 0u, lx, -ly, r.p2, r.p3, r.r[0], r.r[1], r.r[2], r.r[3]);
+      alpha = 1.0f - clamp01(r.aa * dist + 0.5f);
     }
-#pragma unroll
-    for (int p = 0; p < 4; p++) {
-      if (y + p >= P.y1) break;
-      const size_t pix = (size_t)(y + p) * P.pitch + x;
-      F4 b = {__builtin_rintf(rg[p].x), __builtin_rintf(rg[p].y), __builtin_rintf(ba[p].x), __builtin_rintf(ba[p].y)};
-      if (P.fuse_draw < 0) {
-        P.dst[pix] = pack255(b);
-      } else {
-        // atlas.frag:381-388 on the blurred texel just produced, blended over the live surface (first draw of the phase)
-        const Frag f = make_frag(r, exts, x, y + p);
-        if (!f.covered) continue;
-        const float lx = (f.u - 0.5f) * 2.0f * r.p0, ly = (f.v - 0.5f) * 2.0f * r.p1;
-        const float dist = shape_dist((r.op_mode & F_ELLIP) != 0u, lx, -ly, r.p2, r.p3, r.r[0], r.r[1], r.r[2], r.r[3]);
-        const float alpha = 1.0f - clamp01(r.aa * dist + 0.5f);
-        const float k = 1.0f / 255.0f;
-        F4 F = unpack255(P.dst[pix]);
-        blend(F, b.x * k, b.y * k, b.z * k, b.w * k * alpha);
-        P.dst[pix] = pack255(F);
-      }
-    }
+    F4 F = unpack255(P.dst[pix]);
+    blend(F, b.x * k, b.y * k, b.z * k, b.w * k * alpha);
+    P.dst[pix] = pack255(F);
   }
 }
 

@@ -76,15 +76,16 @@ static_assert(sizeof(QuadExt) == 128, "QuadExt must be 128 bytes");
 struct alignas(8) BBox { int16_t x0, y0, x1, y1; };
 
 constexpr int kMaxBlurReach = 66;
+constexpr int kBlurPad = 7;
 struct BlurTaps {  // merged FIR of blur.frag:19-29 for one radius: out = sum coef[k] * src[x + off[k]]
   int n;
   int reach;  // max |off|
   int off[kMaxBlurTaps];
   float coef[kMaxBlurTaps];
-  // the same filter as a dense coefficient array over offsets -reach..+reach, padded with 3 zeros on both
-  // sides: dense[3 + reach + off].  Used by the 4-outputs-per-thread kernels (every staged texel is unpacked
-  // once and feeds up to four outputs).
-  float dense[2 * kMaxBlurReach + 1 + 6];
+  // the same filter as a dense coefficient array over offsets -reach..+reach, padded with kBlurPad zeros on both
+  // sides: dense[kBlurPad + reach + off].  Used by the 8-outputs-per-thread kernels (every staged texel is
+  // unpacked once and feeds up to eight accumulators).
+  float dense[2 * kMaxBlurReach + 1 + 2 * kBlurPad + 16];  // + slack read (never used) by the pipelined loops
 };
 
 struct AtlasView {
