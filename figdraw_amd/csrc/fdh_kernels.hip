@@ -1055,15 +1055,15 @@ __device__ __forceinline__ uint32_t pack2(f2 rg, f2 ba) {
          ((uint32_t)__builtin_rintf(ba.y) << 24);
 }
 
-constexpr int kBlurOut = 8;             // consecutive outputs per thread along the filter direction
-constexpr int kBlurHW = 64 * kBlurOut;  // horizontal pass: one wave = 512 consecutive pixels of one row, 4 rows per workgroup
-constexpr int kBlurHLine = kBlurHW + 2 * kMaxBlurReach + 8;
+// NOUT = consecutive outputs per thread along the filter direction: 8 for large regions (every staged texel is unpacked
+// once per 8 outputs), 2 for small ones (a 360x240 backdrop is ~50 workgroups at NOUT = 8: a few long serial waves on an
+// empty machine; at NOUT = 2 four times as many waves each run a four times shorter chain).
 
 // One thread's kBlurOut consecutive outputs of the merged FIR.  `tex(j)` returns window texel j (output p sees it at
 // offset j - p - reach); every texel is unpacked once and feeds the accumulators with packed FMAs.  The first and last
 // kBlurOut - 1 window texels reach only some of the outputs (the rest would multiply the zero padding of `dense`):
 // those two triangles are peeled with the in-range (p, j) pairs spelled out at compile time.
-template <typename Tex>
+template <int kBlurOut, typename Tex>
 __device__ __forceinline__ void fir_outputs(const float* __restrict__ d, int reach, Tex tex, f2 (&rg)[kBlurOut], f2 (&ba)[kBlurOut]) {
 #pragma unroll
   for (int p = 0; p < kBlurOut; p++) { rg[p] = 0.0f; ba[p] = 0.0f; }
@@ -1106,7 +1106,10 @@ __device__ __forceinline__ void fir_outputs(const float* __restrict__ d, int rea
   }
 }
 
+template <int kBlurOut>
 __global__ __launch_bounds__(256) void k_blur_h(BlurParams P) {
+  constexpr int kBlurHW = 64 * kBlurOut;  // one wave = 64 * NOUT consecutive pixels of one row, 4 rows per workgroup
+  constexpr int kBlurHLine = kBlurHW + 2 * kMaxBlurReach + 8;
   __shared__ __attribute__((aligned(16))) uint32_t lines[4][kBlurHLine];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int y = P.y0 + blockIdx.y * 4 + wave;
@@ -1128,14 +1131,14 @@ __global__ __launch_bounds__(256) void k_blur_h(BlurParams P) {
   if (y >= P.y1 || x >= P.x1) return;
   f2 rg[kBlurOut], ba[kBlurOut];
   const uint32_t* __restrict__ win = line + lane * kBlurOut;
-  fir_outputs(P.taps.dense, reach, [&](int j) { return win[j]; }, rg, ba);
+  fir_outputs<kBlurOut>(P.taps.dense, reach, [&](int j) { return win[j]; }, rg, ba);
   uint32_t ov[kBlurOut];
 #pragma unroll
   for (int p = 0; p < kBlurOut; p++) ov[p] = pack2(rg[p], ba[p]);
   uint32_t* out = P.dst + (size_t)y * P.pitch + x;
-  if (x + kBlurOut - 1 < P.x1 && ((reinterpret_cast<uintptr_t>(out) & 15) == 0)) {
+  if (kBlurOut == 8 && x + kBlurOut - 1 < P.x1 && ((reinterpret_cast<uintptr_t>(out) & 15) == 0)) {
     reinterpret_cast<uint4*>(out)[0] = make_uint4(ov[0], ov[1], ov[2], ov[3]);
-    reinterpret_cast<uint4*>(out)[1] = make_uint4(ov[4], ov[5], ov[6], ov[7]);
+    reinterpret_cast<uint4*>(out)[1] = make_uint4(ov[4 % kBlurOut], ov[5 % kBlurOut], ov[6 % kBlurOut], ov[7 % kBlurOut]);
   } else {
 #pragma unroll
     for (int p = 0; p < kBlurOut; p++) if (x + p < P.x1) out[p] = ov[p];
@@ -1145,8 +1148,10 @@ __global__ __launch_bounds__(256) void k_blur_h(BlurParams P) {
 // vertical pass: one workgroup = 64 columns x 32 rows (taller tiles cut the halo re-read but cost LDS occupancy: measured
 // slower); a lane owns a column, each wave produces 8 consecutive rows.  With fuse_draw >= 0 the consuming mode-17 quad
 // is blended in place; tiles inside the quad's saturated core (DrawRec::ix0..iy1) skip the coverage evaluation.
-constexpr int kBlurVW = 64, kBlurVH = 4 * kBlurOut;
+constexpr int kBlurVW = 64;
+template <int kBlurOut>
 __global__ __launch_bounds__(256) void k_blur_v(BlurParams P, const DrawRec* __restrict__ draws, const QuadExt* __restrict__ exts) {
+  constexpr int kBlurVH = 4 * kBlurOut;
   extern __shared__ uint32_t tile[];  // (kBlurVH + 2*reach) rows x 64 columns
   const int xs = P.x0 + blockIdx.x * kBlurVW;
   const int ys = P.y0 + blockIdx.y * kBlurVH;
@@ -1166,7 +1171,7 @@ __global__ __launch_bounds__(256) void k_blur_v(BlurParams P, const DrawRec* __r
   if (x >= P.x1 || y >= P.y1) return;
   f2 rg[kBlurOut], ba[kBlurOut];
   const uint32_t* __restrict__ col = tile + ry * kBlurVW + lane;  // window row j is tile row ry + j
-  fir_outputs(P.taps.dense, reach, [&](int j) { return col[j * kBlurVW]; }, rg, ba);
+  fir_outputs<kBlurOut>(P.taps.dense, reach, [&](int j) { return col[j * kBlurVW]; }, rg, ba);
   if (P.fuse_draw < 0) {
 #pragma unroll
     for (int p = 0; p < kBlurOut; p++)
@@ -1216,16 +1221,24 @@ void launch_composite(hipStream_t s, const DrawRec* draws, const BBox* bboxes, c
   if (P.has_slow) hipLaunchKernelGGL(k_composite_tiles<true>, dim3(grid), dim3(FDH_WAVE_WG ? 64 : 256), 0, s, draws, bboxes, exts, P);
   else hipLaunchKernelGGL(k_composite_tiles<false>, dim3(grid), dim3(FDH_WAVE_WG ? 64 : 256), 0, s, draws, bboxes, exts, P);
 }
+// small regions: fewer outputs per thread -> more, shorter waves (see NOUT above)
+static bool blur_small(const BlurParams& P) { return (long long)(P.x1 - P.x0) * (P.y1 - P.y0) < 1024 * 1024; }
+template <int NOUT> static void launch_blur_h_n(hipStream_t s, const BlurParams& P) {
+  dim3 grid((P.x1 - P.x0 + 64 * NOUT - 1) / (64 * NOUT), (P.y1 - P.y0 + 3) / 4);
+  hipLaunchKernelGGL(k_blur_h<NOUT>, grid, dim3(256), 0, s, P);
+}
+template <int NOUT> static void launch_blur_v_n(hipStream_t s, const BlurParams& P, const DrawRec* draws, const QuadExt* exts) {
+  dim3 grid((P.x1 - P.x0 + kBlurVW - 1) / kBlurVW, (P.y1 - P.y0 + 4 * NOUT - 1) / (4 * NOUT));
+  const size_t lds = (size_t)(4 * NOUT + 2 * P.taps.reach) * kBlurVW * sizeof(uint32_t);
+  hipLaunchKernelGGL(k_blur_v<NOUT>, grid, dim3(256), lds, s, P, draws, exts);
+}
 void launch_blur_h(hipStream_t s, const BlurParams& P) {
   if (P.x1 <= P.x0 || P.y1 <= P.y0) return;
-  dim3 grid((P.x1 - P.x0 + kBlurHW - 1) / kBlurHW, (P.y1 - P.y0 + 3) / 4);
-  hipLaunchKernelGGL(k_blur_h, grid, dim3(256), 0, s, P);
+  if (blur_small(P)) launch_blur_h_n<2>(s, P); else launch_blur_h_n<8>(s, P);
 }
 void launch_blur_v(hipStream_t s, const BlurParams& P, const DrawRec* draws, const QuadExt* exts) {
   if (P.x1 <= P.x0 || P.y1 <= P.y0) return;
-  dim3 grid((P.x1 - P.x0 + kBlurVW - 1) / kBlurVW, (P.y1 - P.y0 + kBlurVH - 1) / kBlurVH);
-  const size_t lds = (size_t)(kBlurVH + 2 * P.taps.reach) * kBlurVW * sizeof(uint32_t);
-  hipLaunchKernelGGL(k_blur_v, grid, dim3(256), lds, s, P, draws, exts);
+  if (blur_small(P)) launch_blur_v_n<2>(s, P, draws, exts); else launch_blur_v_n<8>(s, P, draws, exts);
 }
 void launch_fill(hipStream_t s, uint32_t* p, uint32_t v, size_t n) {
   if (n == 0) return;
