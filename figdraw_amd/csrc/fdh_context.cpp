@@ -959,7 +959,7 @@ void Context::launch_frame(bool profile) {
   auto span_end = [&]() { if (profile) FDH_HIP(hipEventRecord(spans_.back().b, stream_)); };
   span_begin(0);
   BinParams B;
-  B.bbox = d_bboxes_.ptr; B.lists = d_lists_.ptr; B.counts = d_counts_.ptr; B.phase_first = d_phase_first_.ptr;
+  B.bbox = d_bboxes_.ptr; B.draws = d_recs_.ptr; B.lists = d_lists_.ptr; B.counts = d_counts_.ptr; B.phase_first = d_phase_first_.ptr;
   B.n_phases = np; B.bins_x = bins_x_; B.bins_y = bins_y_; B.stride = list_stride_;
   launch_bin(stream_, B);
   span_end();

@@ -8,6 +8,7 @@ namespace fdh {
 
 struct BinParams {
   const BBox* bbox;     // per draw, clipped pixel bounds (ops that must reach every tile carry the frame)
+  const DrawRec* draws; // op_mode and the saturated core of the draws that hit a bin
   uint2* lists;         // [phase][bin][stride] entries {draw index, 16-bit strip mask}
   uint32_t* counts;     // [phase][bin]
   const int* phase_first;  // [n_phases + 1]

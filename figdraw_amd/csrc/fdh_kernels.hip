@@ -224,7 +224,33 @@ __device__ __forceinline__ uint32_t strip_mask(int x0, int y0, int x1, int y1) {
   return m;
 }
 
-// One workgroup per (phase, bin): ordered stream compaction of the phase's draws that touch the bin.
+// the strips of a bin that lie entirely inside a bin-relative pixel box (the draw's saturated core)
+__device__ __forceinline__ uint32_t strip_mask_inside(int x0, int y0, int x1, int y1) {
+  if (x1 <= x0 || y1 <= y0) return 0u;
+  int r0 = (y0 + 7) >> 3, r1 = y1 >> 3;  // strip rows [r0, r1) fully inside
+  r0 = r0 < 0 ? 0 : r0; r1 = r1 > 8 ? 8 : r1;
+  if (r1 <= r0) return 0u;
+  const uint32_t rows = ((1u << r1) - 1u) & ~((1u << r0) - 1u);
+  const uint32_t cols = ((x0 <= 0 && x1 >= kTileW) ? 1u : 0u) | ((x0 <= kTileW && x1 >= 2 * kTileW) ? 2u : 0u);
+  uint32_t m = 0;
+#pragma unroll
+  for (int r = 0; r < 8; r++) {
+    if (rows & (1u << r)) {
+      const int jy = r >> 2, w = r & 3;
+      if (cols & 1u) m |= 1u << ((jy * 2 + 0) * 4 + w);
+      if (cols & 2u) m |= 1u << ((jy * 2 + 1) * 4 + w);
+    }
+  }
+  return m;
+}
+
+// List entry flags (uint2.x high bits; the low 30 bits are the draw index)
+constexpr uint32_t LE_PLAIN = 1u << 31;  // axis-aligned SDF draw with ONE colour: on its core strips it is a uniform blend
+constexpr uint32_t LE_INDEX = (1u << 30) - 1u;
+
+// One workgroup per (phase, bin): ordered stream compaction of the phase's draws that touch the bin.  An entry is
+// {draw index | flags, strips touched (16 bits) | strips inside the draw's saturated core (16 bits)}; strips where an
+// annular stroke is provably invisible (its core) are dropped from the entry, and the entry with them if none is left.
 __global__ __launch_bounds__(256) void k_bin_draws(BinParams P) {
   __shared__ uint32_t wave_cnt[4];
   __shared__ uint32_t base_sh;
@@ -240,11 +266,27 @@ __global__ __launch_bounds__(256) void k_bin_draws(BinParams P) {
   for (int i0 = first; i0 < last; i0 += 256) {
     int i = i0 + threadIdx.x;
     bool hit = false;
-    uint32_t strips = 0;
+    uint32_t strips = 0, flags = 0;
     if (i < last) {
       BBox b = P.bbox[i];
       hit = b.x0 < x1 && b.x1 > x0 && b.y0 < y1 && b.y1 > y0;
-      if (hit) strips = strip_mask(b.x0 - x0, b.y0 - y0, b.x1 - x0, b.y1 - y0);
+      if (hit) {
+        strips = strip_mask(b.x0 - x0, b.y0 - y0, b.x1 - x0, b.y1 - y0);
+        const DrawRec* r = P.draws + i;
+        const uint32_t om = r->op_mode, op = (om >> 12) & 15u, mode = om & 255u;
+        const bool atlas_mode = mode == 0u || (mode >= 13u && mode <= 16u);
+        const bool sdf = !(om & F_GENERAL) && !atlas_mode && mode < 18u && (op == OP_DRAW || op == OP_MASK_PUSH);
+        if (sdf) {
+          const uint32_t core = strip_mask_inside(r->ix0 - x0, r->iy0 - y0, r->ix1 - x0, r->iy1 - y0) & strips;
+          if (op == OP_DRAW && (mode == 11u || mode == 12u)) {
+            strips &= ~core;  // alpha == 0 there
+            hit = strips != 0u;
+          } else {
+            strips |= core << 16;
+            if (op == OP_DRAW && (om & F_SOLID) && ((om >> 9) & 7u) == 0u && mode != 17u) flags = LE_PLAIN;
+          }
+        }
+      }
     }
     unsigned long long m = __ballot(hit);
     uint32_t before = __builtin_popcountll(m & ((1ull << lane) - 1ull));
@@ -257,7 +299,7 @@ __global__ __launch_bounds__(256) void k_bin_draws(BinParams P) {
       if (w < wave) woff += c;
       total += c;
     }
-    if (hit) out[base + woff + before] = make_uint2((uint32_t)i, strips);
+    if (hit) out[base + woff + before] = make_uint2((uint32_t)i | flags, strips);
     __syncthreads();
     if (threadIdx.x == 0) base_sh = base + total;
     __syncthreads();
@@ -687,13 +729,15 @@ __global__ __launch_bounds__(FDH_WAVE_WG ? 64 : 256, kSlow ? 4 : FDH_FAST_WAVES)
 #endif
     const uint32_t i = base + lane;
     uint32_t idx = 0;
-    bool hit = false;
+    bool hit = false, in_core = false;
     if (i < cnt) {
-      const uint2 e = list[i];  // {draw index, strips of this bin the draw's bounds touch}
+      const uint2 e = list[i];  // {draw index | flags, strips touched | strips inside the saturated core << 16}
       idx = e.x;
       hit = (e.y >> sbit) & 1u;
+      in_core = (e.y >> (16 + sbit)) & 1u;
     }
     unsigned long long m = __ballot(hit);
+    const unsigned long long m_core = __ballot(hit && in_core);
 #if FDH_TIMING
     T_cull += FDH_NOW() - Tc0 + (m & 0ull);
 #endif
@@ -704,7 +748,7 @@ __global__ __launch_bounds__(FDH_WAVE_WG ? 64 : 256, kSlow ? 4 : FDH_FAST_WAVES)
     if (m == 0) continue;
     // One draw = one lambda call.  The record of the NEXT surviving draw is fetched (scalar loads) before the
     // current one is shaded, so the ~L2-latency of the fetch overlaps the shading arithmetic.
-    auto shade = [&](const uint32_t d, const DrawRec& r) {
+    auto shade = [&](const uint32_t d, const DrawRec& r, const bool core) {
       const uint32_t om = r.op_mode;
       const uint32_t op = (om >> 12) & 15u;
       const uint32_t mode = om & 255u;
@@ -763,9 +807,8 @@ __global__ __launch_bounds__(FDH_WAVE_WG ? 64 : 256, kSlow ? 4 : FDH_FAST_WAVES)
       // ---- fast path: axis-aligned SDF draw / clip push, 4 pixels per lane in lock-step
       const bool ellip = (om & F_ELLIP) != 0u;
       const uint32_t fill_mode = (om >> 9) & 7u;
-      // Saturated core (DrawRec::ix0..iy1), decided on the scalar unit: the whole strip has coverage alpha 1 -- or, for
-      // the annular stroke modes, alpha 0 and the draw is a no-op here.
-      const bool core = tx0 >= r.ix0 && tx1 <= r.ix1 && ty0 >= r.iy0 && ty1 <= r.iy1;
+      // `core`: the strip lies in the draw's saturated core (DrawRec::ix0..iy1, decided per strip by k_bin_draws): the
+      // whole strip has coverage alpha 1 (annular strokes, alpha 0 there, never get this far).
 #ifdef FDH_X9
       if (core || !core) { F0.x += core ? 1e-30f : 0.0f; return; }
 #endif
@@ -988,36 +1031,24 @@ __global__ __launch_bounds__(FDH_WAVE_WG ? 64 : 256, kSlow ? 4 : FDH_FAST_WAVES)
       blend(F2, sr[2], sg[2], sb[2], cov[2] ? sa[2] * mk2 * rm2 : 0.0f);
       blend(F3, sr[3], sg[3], sb[3], cov[3] ? sa[3] * mk3 * rm3 : 0.0f);
     };
-    uint32_t d = __builtin_amdgcn_readlane(idx, __builtin_ctzll(m));
-    m &= m - 1;
-#if FDH_TIMING
-    unsigned long long Tr0 = FDH_NOW();
-#endif
-    DrawRec r = load_rec(draws + d);
-    for (;;) {
-#if FDH_TIMING
-      const unsigned long long Tr1 = FDH_NOW() + (r.op_mode & 0u);
-      T_rec += Tr1 - Tr0;
-      n_draws_t++;
-#endif
-      const bool more = m != 0;
-      uint32_t d_next = d;
-      if (more) { d_next = __builtin_amdgcn_readlane(idx, __builtin_ctzll(m)); m &= m - 1; }
-#if FDH_PREFETCH
-      const DrawRec r_next = load_rec(draws + d_next);  // issued now, consumed after shade(): latency hidden
-      shade(d, r);
-#else
-      shade(d, r);
-#if FDH_TIMING
-      Tr0 = FDH_NOW() + (__builtin_amdgcn_readfirstlane(__float_as_uint(F0.x + F1.x + F2.x + F3.x)) & 0u);
-      T_shade += Tr0 - Tr1;
-      if (tx0 >= r.ix0 && tx1 <= r.ix1 && ty0 >= r.iy0 && ty1 <= r.iy1) { T_cull_core += Tr0 - Tr1; n_core_t++; }
-#endif
-      const DrawRec r_next = load_rec(draws + d_next);
-#endif
-      if (!more) break;
-      d = d_next;
-      r = r_next;
+    while (m != 0) {
+      const int bit = __builtin_ctzll(m);
+      m &= m - 1;
+      const uint32_t word = __builtin_amdgcn_readlane(idx, bit);
+      const uint32_t d = word & LE_INDEX;
+      const bool core = (m_core >> bit) & 1ull;
+      if (core && (word & LE_PLAIN) && mask_depth == 0 && !rmask_on) {
+        // One colour, coverage 1, nothing clipping: the whole strip gets the same source term.  Only the colour is
+        // fetched (4 bytes instead of the 128-byte record) and nothing of the record is decoded.
+        const F4 c0 = unpack255(draws[d].col[0]);
+        const float sa = c0.w * inv255, A = 255.0f * sa, ia = 1.0f - sa;
+        const f2 c_rg = {c0.x * inv255 * A, c0.y * inv255 * A}, c_ba = {c0.z * inv255 * A, A};
+        blend_pre(F0, c_rg, c_ba, ia); blend_pre(F1, c_rg, c_ba, ia); blend_pre(F2, c_rg, c_ba, ia); blend_pre(F3, c_rg, c_ba, ia);
+        touched = true;
+        continue;
+      }
+      const DrawRec r = load_rec(draws + d);
+      shade(d, r, core);
     }
   }
 #if FDH_TIMING
