@@ -884,11 +884,13 @@ void Context::submit(bool upload) {
     max_count = std::max(max_count, p.count);
     BBox u{0, 0, 0, 0};
     p.has_slow = false;
+    p.has_masks = false;
     for (int i = p.first; i < p.first + p.count; i++) {
       bbox_union(u, bboxes_[i]);
       // mirrors the `fast` predicate of k_composite_tiles
       const uint32_t om = recs_[i].op_mode, op = (om >> 12) & 15u, mode = om & 255u;
       const bool atlas_mode = mode == 0u || (mode >= 13u && mode <= 16u);
+      if (op != OP_DRAW) p.has_masks = true;
       if (op == OP_RMASK_BEGIN || ((op == OP_DRAW || op == OP_MASK_PUSH) && ((om & F_GENERAL) || atlas_mode || mode >= 18u))) p.has_slow = true;
     }
     p.bin_x0 = u.x0 / kBin; p.bin_y0 = u.y0 / kBin;
@@ -1004,6 +1006,7 @@ void Context::launch_frame(bool profile) {
     C.clear_rgba8 = clear_rgba8_;
     C.n_wg = 0;
     C.has_slow = ph.has_slow ? 1 : 0;
+    C.has_masks = ph.has_masks ? 1 : 0;
     span_begin(p == 0 ? 1 : 2);
     launch_composite(stream_, d_recs_.ptr, d_bboxes_.ptr, d_exts_.ptr, C);
     span_end();

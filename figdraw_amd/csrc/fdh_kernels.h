@@ -28,6 +28,7 @@ struct CompositeParams {
   int load_fb;              // 0: start from clear_rgba8
   uint32_t clear_rgba8;
   int n_wg;                 // total workgroups (for the XCD remap)
+  int has_masks;            // the phase holds clip / rect-mask ops (disables per-strip occlusion culling)
   int has_slow;             // the phase holds draws that need the one-pixel-slot path (k_composite_tiles<true>)
 };
 

@@ -246,6 +246,7 @@ __device__ __forceinline__ uint32_t strip_mask_inside(int x0, int y0, int x1, in
 
 // List entry flags (uint2.x high bits; the low 30 bits are the draw index)
 constexpr uint32_t LE_PLAIN = 1u << 31;  // axis-aligned SDF draw with ONE colour: on its core strips it is a uniform blend
+constexpr uint32_t LE_OPAQUE = 1u << 30;  // a fill whose source alpha is 255 everywhere: on its core strips it REPLACES the surface
 constexpr uint32_t LE_INDEX = (1u << 30) - 1u;
 
 // One workgroup per (phase, bin): ordered stream compaction of the phase's draws that touch the bin.  An entry is
@@ -283,7 +284,13 @@ __global__ __launch_bounds__(256) void k_bin_draws(BinParams P) {
             hit = strips != 0u;
           } else {
             strips |= core << 16;
-            if (op == OP_DRAW && (om & F_SOLID) && ((om >> 9) & 7u) == 0u && mode != 17u) flags = LE_PLAIN;
+            const uint32_t fill_mode = (om >> 9) & 7u;
+            if (op == OP_DRAW && (om & F_SOLID) && fill_mode == 0u && mode != 17u) flags = LE_PLAIN;
+            if (op == OP_DRAW && mode == 3u) {
+              uint32_t a = r->col[0] & r->col[1] & r->col[2] & r->col[3];
+              if (fill_mode != 0u) a &= r->mid & r->stop;
+              if ((a >> 24) == 255u) flags |= LE_OPAQUE;
+            }
           }
         }
       }
@@ -738,6 +745,12 @@ __global__ __launch_bounds__(FDH_WAVE_WG ? 64 : 256, kSlow ? 4 : FDH_FAST_WAVES)
     }
     unsigned long long m = __ballot(hit);
     const unsigned long long m_core = __ballot(hit && in_core);
+    if (!P.has_masks) {
+      // Occlusion: an opaque fill that covers the whole strip makes every earlier draw of the strip invisible.  (Only in
+      // phases without clip / rect masks: a skipped push or pop would derail the mask stack.)
+      const unsigned long long m_opaque = __ballot(hit && in_core && (idx & LE_OPAQUE) != 0u);
+      if (m_opaque != 0) m &= ~((1ull << (63 - __builtin_clzll(m_opaque))) - 1ull);
+    }
 #if FDH_TIMING
     T_cull += FDH_NOW() - Tc0 + (m & 0ull);
 #endif
