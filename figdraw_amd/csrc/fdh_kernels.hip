@@ -1197,8 +1197,22 @@ template <int kBlurOut>
 __global__ __launch_bounds__(256) void k_blur_v(BlurParams P, const DrawRec* __restrict__ draws, const QuadExt* __restrict__ exts) {
   constexpr int kBlurVH = 4 * kBlurOut;
   extern __shared__ uint32_t tile[];  // (kBlurVH + 2*reach) rows x 64 columns
-  const int xs = P.x0 + blockIdx.x * kBlurVW;
-  const int ys = P.y0 + blockIdx.y * kBlurVH;
+  // XCD-aware tile order: workgroup b runs on XCD b % 8.  Tiles are sequenced band by band (a band = 8 tile columns,
+  // walked row by row) and every XCD takes one contiguous eighth of that sequence, so the 2*reach halo rows a tile
+  // shares with the tiles above and below it are still in THAT XCD's L2 (row-major order put vertical neighbours on
+  // different XCDs: every halo row was fetched from HBM twice) and all XCDs get the same number of tiles.
+  const int ntx = (P.x1 - P.x0 + kBlurVW - 1) / kBlurVW, nty = (P.y1 - P.y0 + kBlurVH - 1) / kBlurVH;
+  const int total = ntx * nty, per = (total + 7) >> 3;
+  const int q = blockIdx.x >> 3;
+  const int item = (blockIdx.x & 7) * per + q;
+  if (q >= per || item >= total) return;
+  const int full = ntx >> 3, in_full = full * 8 * nty;
+  int band, rem, bw;
+  if (item < in_full) { band = item / (8 * nty); rem = item - band * 8 * nty; bw = 8; }
+  else { band = full; rem = item - in_full; bw = ntx - full * 8; }
+  const int tyi = rem / bw, txi = band * 8 + rem - tyi * bw;
+  const int xs = P.x0 + txi * kBlurVW;
+  const int ys = P.y0 + tyi * kBlurVH;
   const int reach = P.taps.reach;
   const int rows = kBlurVH + 2 * reach;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1272,7 +1286,8 @@ template <int NOUT> static void launch_blur_h_n(hipStream_t s, const BlurParams&
   hipLaunchKernelGGL(k_blur_h<NOUT>, grid, dim3(256), 0, s, P);
 }
 template <int NOUT> static void launch_blur_v_n(hipStream_t s, const BlurParams& P, const DrawRec* draws, const QuadExt* exts) {
-  dim3 grid((P.x1 - P.x0 + kBlurVW - 1) / kBlurVW, (P.y1 - P.y0 + 4 * NOUT - 1) / (4 * NOUT));
+  const int ntx = (P.x1 - P.x0 + kBlurVW - 1) / kBlurVW, nty = (P.y1 - P.y0 + 4 * NOUT - 1) / (4 * NOUT);
+  dim3 grid(8 * ((ntx * nty + 7) / 8));  // 8 XCDs x an eighth of the tile sequence each
   const size_t lds = (size_t)(4 * NOUT + 2 * P.taps.reach) * kBlurVW * sizeof(uint32_t);
   hipLaunchKernelGGL(k_blur_v<NOUT>, grid, dim3(256), lds, s, P, draws, exts);
 }

@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Assemble profiles/<tag>_pmc_traffic.json from rocprofv3 counter_collection CSVs (see tools/pmc_traffic.sh)."""
+import collections, csv, json, sys
+
+tag, files = sys.argv[1], sys.argv[2:]
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in files:
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        if not k.startswith("fdh::"):
+            continue
+        agg[(k[5:], int(r["Grid_Size"]))][r["Counter_Name"]].append(float(r["Counter_Value"]))
+# name the launches of a frame: the largest grid of each kernel is the full-frame / phase-0 launch
+by_kernel = collections.defaultdict(list)
+for (k, g) in agg:
+    by_kernel[k.split("<")[0]].append((g, k))
+kernels = {}
+for base, lst in by_kernel.items():
+    lst.sort(reverse=True)
+    for i, (g, k) in enumerate(lst):
+        c = {n: sum(v) / len(v) for n, v in agg[(k, g)].items()}
+        if base == "k_composite_tiles":
+            label = "k_composite_tiles.phase0" if i == 0 else f"k_composite_tiles.later{i}"
+        elif base in ("k_blur_h", "k_blur_v"):
+            label = f"{base}.fullframe" if i == 0 else f"{base}.small{i}"
+        else:
+            label = base if i == 0 else f"{base}.{i}"
+        e = {"kernel": k, "grid": g}
+        e.update({n: round(v, 1) for n, v in c.items()})
+        if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            e["hbm_bytes"] = int((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024)
+        if "TCC_HIT_sum" in c and "TCC_MISS_sum" in c and c["TCC_HIT_sum"] + c["TCC_MISS_sum"] > 0:
+            e["l2_hit_rate"] = round(c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"]), 3)
+        kernels[label] = e
+print(json.dumps({"_about": "rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE / TCC_HIT_sum TCC_MISS_sum in separate runs, each with "
+                  "--kernel-trace only) over `python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline`, MI355X, S300@4K frame. Means per "
+                  "dispatch in the counters' native unit (KB for *_SIZE). hbm_bytes applies MI355X_MICROARCH.md's gfx950 correction: "
+                  "FETCH_SIZE counts 128-B requests as 64 B, so reads are doubled: (2*FETCH_SIZE + WRITE_SIZE) * 1024.",
+                  "tag": tag, "kernels": kernels}, indent=1))
