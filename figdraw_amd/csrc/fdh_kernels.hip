@@ -1153,7 +1153,7 @@ __device__ __forceinline__ void fir_outputs(const float* __restrict__ d, int rea
 template <int kBlurOut>
 __global__ __launch_bounds__(256) void k_blur_h(BlurParams P) {
   constexpr int kBlurHW = 64 * kBlurOut;  // one wave = 64 * NOUT consecutive pixels of one row, 4 rows per workgroup
-  constexpr int kBlurHLine = kBlurHW + 2 * kMaxBlurReach + 8;
+  constexpr int kBlurHLine = kBlurHW + 2 * kMaxBlurReach + kBlurOut;
   __shared__ __attribute__((aligned(16))) uint32_t lines[4][kBlurHLine];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int y = P.y0 + blockIdx.y * 4 + wave;
@@ -1180,9 +1180,10 @@ __global__ __launch_bounds__(256) void k_blur_h(BlurParams P) {
 #pragma unroll
   for (int p = 0; p < kBlurOut; p++) ov[p] = pack2(rg[p], ba[p]);
   uint32_t* out = P.dst + (size_t)y * P.pitch + x;
-  if (kBlurOut == 8 && x + kBlurOut - 1 < P.x1 && ((reinterpret_cast<uintptr_t>(out) & 15) == 0)) {
-    reinterpret_cast<uint4*>(out)[0] = make_uint4(ov[0], ov[1], ov[2], ov[3]);
-    reinterpret_cast<uint4*>(out)[1] = make_uint4(ov[4 % kBlurOut], ov[5 % kBlurOut], ov[6 % kBlurOut], ov[7 % kBlurOut]);
+  if (kBlurOut >= 4 && x + kBlurOut - 1 < P.x1 && ((reinterpret_cast<uintptr_t>(out) & 15) == 0)) {
+#pragma unroll
+    for (int g = 0; g < kBlurOut / 4; g++)
+      reinterpret_cast<uint4*>(out)[g] = make_uint4(ov[(4 * g) % kBlurOut], ov[(4 * g + 1) % kBlurOut], ov[(4 * g + 2) % kBlurOut], ov[(4 * g + 3) % kBlurOut]);
   } else {
 #pragma unroll
     for (int p = 0; p < kBlurOut; p++) if (x + p < P.x1) out[p] = ov[p];
@@ -1280,6 +1281,9 @@ void launch_composite(hipStream_t s, const DrawRec* draws, const BBox* bboxes, c
   else hipLaunchKernelGGL(k_composite_tiles<false>, dim3(grid), dim3(FDH_WAVE_WG ? 64 : 256), 0, s, draws, bboxes, exts, P);
 }
 // small regions: fewer outputs per thread -> more, shorter waves (see NOUT above)
+#ifndef FDH_BLUR_NOUT
+#define FDH_BLUR_NOUT 8
+#endif
 static bool blur_small(const BlurParams& P) { return (long long)(P.x1 - P.x0) * (P.y1 - P.y0) < 1024 * 1024; }
 template <int NOUT> static void launch_blur_h_n(hipStream_t s, const BlurParams& P) {
   dim3 grid((P.x1 - P.x0 + 64 * NOUT - 1) / (64 * NOUT), (P.y1 - P.y0 + 3) / 4);
@@ -1293,11 +1297,11 @@ template <int NOUT> static void launch_blur_v_n(hipStream_t s, const BlurParams&
 }
 void launch_blur_h(hipStream_t s, const BlurParams& P) {
   if (P.x1 <= P.x0 || P.y1 <= P.y0) return;
-  if (blur_small(P)) launch_blur_h_n<2>(s, P); else launch_blur_h_n<8>(s, P);
+  if (blur_small(P)) launch_blur_h_n<2>(s, P); else launch_blur_h_n<FDH_BLUR_NOUT>(s, P);
 }
 void launch_blur_v(hipStream_t s, const BlurParams& P, const DrawRec* draws, const QuadExt* exts) {
   if (P.x1 <= P.x0 || P.y1 <= P.y0) return;
-  if (blur_small(P)) launch_blur_v_n<2>(s, P, draws, exts); else launch_blur_v_n<8>(s, P, draws, exts);
+  if (blur_small(P)) launch_blur_v_n<2>(s, P, draws, exts); else launch_blur_v_n<FDH_BLUR_NOUT>(s, P, draws, exts);
 }
 void launch_fill(hipStream_t s, uint32_t* p, uint32_t v, size_t n) {
   if (n == 0) return;

@@ -76,7 +76,7 @@ static_assert(sizeof(QuadExt) == 128, "QuadExt must be 128 bytes");
 struct alignas(8) BBox { int16_t x0, y0, x1, y1; };
 
 constexpr int kMaxBlurReach = 66;
-constexpr int kBlurPad = 7;
+constexpr int kBlurPad = 15;  // >= (largest outputs-per-thread) - 1
 struct BlurTaps {  // merged FIR of blur.frag:19-29 for one radius: out = sum coef[k] * src[x + off[k]]
   int n;
   int reach;  // max |off|
