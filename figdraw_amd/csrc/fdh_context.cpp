@@ -925,7 +925,9 @@ void Context::submit(bool upload) {
     const int ylo = std::max(0, j.y0 - j.taps.reach), yhi = std::min(H_, j.y1 + j.taps.reach);
     const int64_t a_h = (int64_t)(j.x1 - j.x0) * (yhi - ylo), a_v = (int64_t)(j.x1 - j.x0) * (j.y1 - j.y0);
     bytes_blur += 4 * a_h + 4 * a_h + 4 * a_h + 4 * a_v;  // H read, H write, V read, V write
-    bytes += 4 * a_v;                                     // the composite's read of the blurred footprint
+    // the consuming composite: fused into the V pass it reads the live surface there; otherwise a composite launch
+    // reads the blurred snapshot
+    if (j.fuse_draw >= 0) bytes_blur += 4 * a_v; else bytes += 4 * a_v;
   }
   bytes += bytes_blur;
   stats_.bytes_blur = bytes_blur;
