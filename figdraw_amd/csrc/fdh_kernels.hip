@@ -22,6 +22,9 @@ namespace fdh {
 #define FDH_PREFETCH 0
 #endif
 #endif
+#ifndef FDH_SIMPLE_EDGE
+#define FDH_SIMPLE_EDGE 1
+#endif
 #ifndef FDH_CLASSIFY
 #define FDH_CLASSIFY 1
 #ifndef FDH_STATS
@@ -646,7 +649,7 @@ __device__ __forceinline__ Src shade_one(const DrawRec* __restrict__ rp, const Q
 #define FDH_NOW() clock64()
 #endif
 #if FDH_STATS
-__device__ unsigned long long g_wave_times[8 * 65536];  // FDH_TIMING: one row per wave (no atomics: they would serialise)
+__device__ unsigned long long g_wave_times[16 * 65536];  // FDH_TIMING: one row per wave (no atomics: they would serialise)
 __device__ unsigned long long g_counters[64];
 #if FDH_TIMING
 #define FDH_COUNT(i) do { } while (0)
@@ -697,6 +700,7 @@ __global__ __launch_bounds__(FDH_WAVE_WG ? 64 : 256, kSlow ? 4 : FDH_FAST_WAVES)
 #if FDH_TIMING
   const unsigned long long T0 = FDH_NOW();
   unsigned long long T_cull = 0, T_rec = 0, T_shade = 0, T_cnt = 0, n_draws_t = 0, T_cull_core = 0, n_core_t = 0;
+  unsigned long long T_mode[4] = {0, 0, 0, 0}, N_mode[4] = {0, 0, 0, 0};  // edge draws by mode: 3, 7, 9, 12
 #endif
   const uint32_t cnt = P.counts[bin];
 #if FDH_TIMING
@@ -849,6 +853,80 @@ __global__ __launch_bounds__(FDH_WAVE_WG ? 64 : 256, kSlow ? 4 : FDH_FAST_WAVES)
       }
 #ifdef FDH_X3
       if (!core) return;
+#endif
+#if FDH_SIMPLE_EDGE
+      // ---- the common edge strip, written out in packed pairs: circular corners, ONE colour, nothing clipping, mode
+      // fill / drop shadow / AA stroke.  Pixels (0,1) and (2,3) of the lane share every add / mul / fma
+      // (v_pk_*_f32); only compares, selects, min/max and the transcendentals stay per pixel.  Same formulas, same
+      // order of operations as the generic path below.
+      if (!core && !ellip && (om & F_SOLID) && fill_mode == 0u && op == OP_DRAW && mask_depth == 0 && !rmask_on &&
+          (mode == 3u || mode == 7u || mode == 12u)) {
+        const float shx = r.p2, shy = r.p3;
+        const float tq = (cy - r.oy) * r.inv_h;
+        const float pyy = -((tq - 0.5f) * 2.0f * r.p1);
+        const bool top = pyy > 0.0f;
+        const float rR = top ? r.r[0] : r.r[1], rL = top ? r.r[2] : r.r[3];
+        const float ay = __builtin_fabsf(pyy) - shy;
+        const f2 cxa = {cx0, cx0 + 1.0f}, cxb = {cx0 + 2.0f, cx0 + 3.0f};
+        const f2 ua = (cxa - r.ox) * r.inv_w, ub = (cxb - r.ox) * r.inv_w;
+        const float qh2 = 2.0f * r.p0;
+        f2 lxa = (ua - 0.5f) * 2.0f * r.p0, lxb = (ub - 0.5f) * 2.0f * r.p0;
+        (void)qh2;
+        const f2 rra = {lxa.x > 0.0f ? rR : rL, lxa.y > 0.0f ? rR : rL}, rrb = {lxb.x > 0.0f ? rR : rL, lxb.y > 0.0f ? rR : rL};
+        const f2 axa = {__builtin_fabsf(lxa.x), __builtin_fabsf(lxa.y)}, axb = {__builtin_fabsf(lxb.x), __builtin_fabsf(lxb.y)};
+        const f2 qxa = axa - shx + rra, qxb = axb - shx + rrb;
+        const f2 qya = ay + rra, qyb = ay + rrb;
+        const f2 mxa = {__builtin_fmaxf(qxa.x, 0.0f), __builtin_fmaxf(qxa.y, 0.0f)}, mxb = {__builtin_fmaxf(qxb.x, 0.0f), __builtin_fmaxf(qxb.y, 0.0f)};
+        const f2 mya = {__builtin_fmaxf(qya.x, 0.0f), __builtin_fmaxf(qya.y, 0.0f)}, myb = {__builtin_fmaxf(qyb.x, 0.0f), __builtin_fmaxf(qyb.y, 0.0f)};
+        f2 lena = {__builtin_fmaxf(mxa.x, mya.x), __builtin_fmaxf(mxa.y, mya.y)}, lenb = {__builtin_fmaxf(mxb.x, myb.x), __builtin_fmaxf(mxb.y, myb.y)};
+        const f2 lowa = {__builtin_fminf(qxa.x, qya.x), __builtin_fminf(qxa.y, qya.y)}, lowb = {__builtin_fminf(qxb.x, qyb.x), __builtin_fminf(qxb.y, qyb.y)};
+        if (__any(lowa.x > 0.0f || lowa.y > 0.0f || lowb.x > 0.0f || lowb.y > 0.0f)) {  // some lane sits in a corner cell
+          const f2 sa2 = mxa * mxa + mya * mya, sb2 = mxb * mxb + myb * myb;
+          lena.x = lowa.x > 0.0f ? fsqrt(sa2.x) : lena.x; lena.y = lowa.y > 0.0f ? fsqrt(sa2.y) : lena.y;
+          lenb.x = lowb.x > 0.0f ? fsqrt(sb2.x) : lenb.x; lenb.y = lowb.y > 0.0f ? fsqrt(sb2.y) : lenb.y;
+        }
+        const f2 ina = {__builtin_fminf(__builtin_fmaxf(qxa.x, qya.x), 0.0f), __builtin_fminf(__builtin_fmaxf(qxa.y, qya.y), 0.0f)};
+        const f2 inb = {__builtin_fminf(__builtin_fmaxf(qxb.x, qyb.x), 0.0f), __builtin_fminf(__builtin_fmaxf(qxb.y, qyb.y), 0.0f)};
+        const f2 da = ina + lena - rra, db = inb + lenb - rrb;
+        f2 ala, alb;  // coverage
+        if (mode == 3u) {
+          const f2 ta = da * r.aa + 0.5f, tb = db * r.aa + 0.5f;
+          ala = {1.0f - clamp01(ta.x), 1.0f - clamp01(ta.y)}; alb = {1.0f - clamp01(tb.x), 1.0f - clamp01(tb.y)};
+        } else if (mode == 12u) {
+          const float h = r.f0 * 0.5f;
+          const f2 ea = da + h, eb = db + h;
+          const f2 ga = {__builtin_fabsf(ea.x), __builtin_fabsf(ea.y)}, gb = {__builtin_fabsf(eb.x), __builtin_fabsf(eb.y)};
+          const f2 ta = (ga - h) * r.aa + 0.5f, tb = (gb - h) * r.aa + 0.5f;
+          ala = {1.0f - clamp01(ta.x), 1.0f - clamp01(ta.y)}; alb = {1.0f - clamp01(tb.x), 1.0f - clamp01(tb.y)};
+          if (__all(ala.x == 0.0f && ala.y == 0.0f && alb.x == 0.0f && alb.y == 0.0f)) return;  // inside the stroke: no-op
+        } else {  // 7: atlas.frag:330-343
+          const float spread = r.f1;
+          const f2 sda = da - spread, sdb = db - spread;
+          if (__all(sda.x <= 0.0f && sda.y <= 0.0f && sdb.x <= 0.0f && sdb.y <= 0.0f)) {
+            ala = 1.0f; alb = 1.0f;
+          } else {
+            const float rs = frcp(__builtin_fmaxf(0.5f * r.f0, 0.5f));
+            const f2 za = sda * rs, zb = sdb * rs;
+            const f2 ea = -0.72134752044f * za * za, eb = -0.72134752044f * zb * zb;
+            ala = {sda.x > 0.0f ? __builtin_fminf(fexp2(ea.x), 1.0f) : 1.0f, sda.y > 0.0f ? __builtin_fminf(fexp2(ea.y), 1.0f) : 1.0f};
+            alb = {sdb.x > 0.0f ? __builtin_fminf(fexp2(eb.x), 1.0f) : 1.0f, sdb.y > 0.0f ? __builtin_fminf(fexp2(eb.y), 1.0f) : 1.0f};
+          }
+        }
+        // coverage of the quad: unsigned (x - bx0) < width, width 0 on rows outside it
+        const uint32_t xrel = (uint32_t)(px0 - (int)r.bx0);
+        const uint32_t wcov = (py >= r.by0 && py < r.by1) ? (uint32_t)((int)r.bx1 - (int)r.bx0) : 0u;
+        const F4 c0u = unpack255(r.col[0]);
+        const float cw = c0u.w * inv255;
+        f2 saa = ala * cw, sab = alb * cw;
+        saa.x = xrel < wcov ? saa.x : 0.0f; saa.y = xrel + 1u < wcov ? saa.y : 0.0f;
+        sab.x = xrel + 2u < wcov ? sab.x : 0.0f; sab.y = xrel + 3u < wcov ? sab.y : 0.0f;
+        const f2 Aa = saa * 255.0f, Ab = sab * 255.0f, iaa = 1.0f - saa, iab = 1.0f - sab;
+        const f2 crg = {c0u.x * inv255, c0u.y * inv255};
+        const float cb = c0u.z * inv255;
+        { const f2 b1 = {cb, 1.0f}; blend_pre(F0, crg * Aa.x, b1 * Aa.x, iaa.x); blend_pre(F1, crg * Aa.y, b1 * Aa.y, iaa.y);
+          blend_pre(F2, crg * Ab.x, b1 * Ab.x, iab.x); blend_pre(F3, crg * Ab.y, b1 * Ab.y, iab.y); }
+        return;
+      }
 #endif
       FDH_COUNT(8 + (mode & 31u));
       if (ellip) FDH_COUNT(2);
@@ -1061,14 +1139,27 @@ __global__ __launch_bounds__(FDH_WAVE_WG ? 64 : 256, kSlow ? 4 : FDH_FAST_WAVES)
         continue;
       }
       const DrawRec r = load_rec(draws + d);
+#if FDH_TIMING
+      const unsigned long long Ts0 = FDH_NOW() + (r.op_mode & 0u);
+#endif
       shade(d, r, core);
+#if FDH_TIMING
+      {
+        const unsigned long long Ts1 = FDH_NOW() + (__builtin_amdgcn_readfirstlane(__float_as_uint(F0.x + F1.x + F2.x + F3.x)) & 0u);
+        const uint32_t md = r.op_mode & 255u;
+        const int slot = md == 3u ? 0 : md == 7u ? 1 : md == 9u ? 2 : 3;
+        if (!core) { T_mode[slot] += Ts1 - Ts0; N_mode[slot]++; }
+        T_shade += Ts1 - Ts0; n_draws_t++;
+      }
+#endif
     }
   }
 #if FDH_TIMING
   if (lane == 0 && blockIdx.x < 65536) {
     const unsigned long long T1 = FDH_NOW();
-    unsigned long long* row = g_wave_times + 8 * (size_t)blockIdx.x;
+    unsigned long long* row = g_wave_times + 16 * (size_t)blockIdx.x;
     row[0] = T1 - T0; row[1] = T_cnt; row[2] = T_cull; row[3] = T_rec; row[4] = T_shade; row[5] = n_draws_t; row[6] = 1; row[7] = T_cull_core * 1024 + n_core_t;
+    for (int i = 0; i < 4; i++) { row[8 + i] = T_mode[i]; row[12 + i] = N_mode[i]; }
   }
 #endif
   if (!(touched || !P.load_fb) || py < P.row_lo || py >= P.row_hi) return;
@@ -1310,7 +1401,7 @@ void launch_fill(hipStream_t s, uint32_t* p, uint32_t v, size_t n) {
 
 #if FDH_STATS
 void debug_wave_times(unsigned long long* out) {
-  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_times), sizeof(unsigned long long) * 8 * 65536);
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_times), sizeof(unsigned long long) * 16 * 65536);
   (void)hipMemset((void*)nullptr, 0, 0);
 }
 void debug_counters(unsigned long long out[64], bool reset) {

@@ -35,7 +35,7 @@ for i, n in ((32, "core: stroke no-op"), (33, "core: solid uniform blend"), (34,
     print(f"{n:34s} {c[i]:10d}")
 if hasattr(L, "fdh_debug_wave_times") and os.environ.get("FDH_TIMING"):
     import numpy as np
-    wt = np.zeros((65536, 8), dtype=np.uint64)
+    wt = np.zeros((65536, 16), dtype=np.uint64)
     L.fdh_debug_wave_times(wt.ctypes.data_as(C.c_void_p))
     ids = np.nonzero(wt[:, 6] == 1)[0]
     wt = wt[wt[:, 6] == 1].astype(np.float64)
@@ -46,6 +46,8 @@ if hasattr(L, "fdh_debug_wave_times") and os.environ.get("FDH_TIMING"):
     n = len(wt)
     for i in range(6):
         c[50 + i] = wt[:, i].sum()
+    for i, nm in enumerate(("mode 3 fill", "mode 7 drop shadow", "mode 9 inset shadow", "mode 12 stroke / other")):
+        print(f"edge draws {nm:24s} n={int(wt[:, 12 + i].sum()):7d}  mean {wt[:, 8 + i].sum() / max(wt[:, 12 + i].sum(), 1):7.0f} cycles  total {wt[:, 8 + i].sum() / 1e6:7.1f} Mcycles")
     core_t = np.floor(wt[:, 7] / 1024).sum(); core_n = (wt[:, 7] % 1024).sum()
     print(f"shade: core draws {int(core_n)} mean {core_t / max(core_n, 1):.0f} cycles; other draws {int(c[55] - core_n)} mean "
           f"{(c[54] - core_t) / max(c[55] - core_n, 1):.0f} cycles")
