@@ -378,6 +378,69 @@ ATLAS_SCENES = {
 }
 
 
+def random_scene(seed: int, w: float, h: float, n: int = 40, clips: bool = True, blur: bool = True) -> Renders:
+    """Seeded random mix of everything the SDF path has: opaque and translucent fills (solid, 2- and 3-stop on all
+    axes), circular and elliptical corners, strokes, drop and inner shadows, nested NfClipContent / NfRectMaskContent
+    containers, rotations and a backdrop blur -- at whatever (odd) frame size the caller picks.  Used to compare the
+    HIP path with the oracle where no golden exists (strip masks, saturated cores, occlusion culling, edge tiles)."""
+    import random
+
+    rnd = random.Random(seed)
+    lst = RenderList()
+
+    def col(opaque=None):
+        a = 255 if (opaque if opaque is not None else rnd.random() < 0.4) else rnd.randrange(20, 255)
+        return rgba(rnd.randrange(256), rnd.randrange(256), rnd.randrange(256), a)
+
+    def some_fill():
+        k = rnd.random()
+        if k < 0.55:
+            return fill(col())
+        opaque = rnd.random() < 0.5
+        axis = rnd.choice(list(FillGradientAxis))
+        if k < 0.8:
+            return linear(col(opaque), col(opaque), axis=axis)
+        return linear(col(opaque), col(opaque), col(opaque), axis=axis, midPos=rnd.randrange(20, 236))
+
+    def some_rect(parent=None, depth=0):
+        bw, bh = rnd.uniform(8, 0.7 * w), rnd.uniform(8, 0.7 * h)
+        x, y = rnd.uniform(-0.1 * w, w - 0.5 * bw), rnd.uniform(-0.1 * h, h - 0.5 * bh)
+        if rnd.random() < 0.5:  # fractional boxes exercise the ceil snapping
+            x, y, bw, bh = round(x), round(y), round(bw), round(bh)
+        mr = int(min(bw, bh) / 2)
+        corners = [rnd.randrange(0, max(mr, 1)) if rnd.random() < 0.7 else 0 for _ in range(4)]
+        f = Fig(kind=RECT, screenBox=rect(x, y, bw, bh), fill=some_fill(), corners=corners)
+        if rnd.random() < 0.25:
+            f.cornerRadiiY = [rnd.randrange(0, max(mr, 1)) for _ in range(4)]
+            f.flags |= FigFlags.NfEllipticalCorners
+        if rnd.random() < 0.4:
+            f.stroke = RenderStroke(weight=rnd.choice([1.0, 2.5, 6.0, 14.0]), fill=some_fill())
+        if rnd.random() < 0.35:
+            st = rnd.choice([ShadowStyle.DropShadow, ShadowStyle.InnerShadow])
+            f.shadows = [RenderShadow(style=st, blur=rnd.uniform(0, 24), spread=rnd.uniform(0, 12), x=rnd.uniform(-12, 12),
+                                      y=rnd.uniform(-12, 12), fill=some_fill())]
+        if rnd.random() < 0.1:
+            f.rotation = rnd.uniform(-40, 40)
+        idx = lst.addRoot(f) if parent is None else lst.addChild(parent, f)
+        if clips and depth < 2 and rnd.random() < 0.2:
+            f.flags |= rnd.choice([FigFlags.NfClipContent, FigFlags.NfRectMaskContent])
+            for _ in range(rnd.randrange(1, 4)):
+                some_rect(idx, depth + 1)
+        return idx
+
+    lst.addRoot(Fig(kind=RECT, screenBox=rect(0, 0, w, h), fill=fill(col(rnd.random() < 0.5))))
+    for i in range(n):
+        some_rect()
+        if blur and i == n // 2:
+            bw, bh = rnd.uniform(0.2 * w, 0.8 * w), rnd.uniform(0.2 * h, 0.8 * h)
+            c = rnd.randrange(0, 30)
+            lst.addRoot(Fig(kind=FigKind.nkBackdropBlur, screenBox=rect(rnd.uniform(0, w - bw), rnd.uniform(0, h - bh), bw, bh),
+                            corners=[c] * 4, fill=rgba(0, 0, 0, 0), blur=rnd.choice([3.0, 9.0, 18.0, 40.0])))
+    out = Renders()
+    out.layers[0] = lst
+    return out
+
+
 FLIPPY_IMAGE_KEY = 0x696D6731  # any key: the reference hashes the file name (figbasics.nim imgId)
 
 

@@ -51,6 +51,23 @@ def test_scene_matches_oracle_and_goldens(hip, name):
         assert mx <= 2, (name, "vs reference golden PNG", mx, n0, n1)
 
 
+FUZZ = [(1, 333, 217, True, True), (2, 640, 480, True, False), (3, 257, 129, False, True), (4, 1000, 70, True, True),
+        (5, 65, 600, False, False), (6, 512, 512, False, False), (7, 799, 601, True, True), (8, 1283, 721, False, True)]
+
+
+@pytest.mark.parametrize("seed,w,h,clips,blur", FUZZ)
+def test_random_scenes_match_oracle(hip, seed, w, h, clips, blur):
+    """Seeded random scenes at odd frame sizes: the bin kernel's strip masks, saturated cores, bin-time stroke removal
+    and occlusion culling (only legal in phases without mask ops: `clips` toggles that) must not change a pixel."""
+    sc = RS.random_scene(seed, float(w), float(h), n=60, clips=clips, blur=blur)
+    hip.render_frame(sc, w, h)
+    got = hip.read_pixels()
+    want = _oracle(lambda *_: sc, w, h)
+    mx, n0, n1 = diff_stats(got, want)
+    assert mx <= 1, (seed, "vs oracle", mx, n0, n1)
+    assert n0 <= 0.005 * w * h, (seed, "vs oracle: too many 1-LSB pixels", n0)
+
+
 def test_render_is_deterministic_and_replay_is_idempotent(hip):
     fn, w, h = RS.SWIFTSHADER_SCENES["backdrop_blur"]
     hip.render_frame(fn(float(w), float(h)), w, h)
