@@ -884,6 +884,7 @@ void Context::submit(bool upload) {
     max_count = std::max(max_count, p.count);
     BBox u{0, 0, 0, 0};
     p.has_slow = false;
+    p.has_atlas = false;
     p.has_masks = false;
     for (int i = p.first; i < p.first + p.count; i++) {
       bbox_union(u, bboxes_[i]);
@@ -891,7 +892,10 @@ void Context::submit(bool upload) {
       const uint32_t om = recs_[i].op_mode, op = (om >> 12) & 15u, mode = om & 255u;
       const bool atlas_mode = mode == 0u || (mode >= 13u && mode <= 16u);
       if (op != OP_DRAW) p.has_masks = true;
-      if (op == OP_RMASK_BEGIN || ((op == OP_DRAW || op == OP_MASK_PUSH) && ((om & F_GENERAL) || atlas_mode || mode >= 18u))) p.has_slow = true;
+      // mirrors the path selection of k_composite_tiles: 4-wide atlas path for axis-aligned atlas quads sampled from level 0
+      const bool atlas4 = atlas_mode && !(om & F_GENERAL) && op == OP_DRAW && !(mode == 0u && recs_[i].aux2 > 0.0f && n_levels_ >= 2);
+      if (atlas4) p.has_atlas = true;
+      else if (op == OP_RMASK_BEGIN || ((op == OP_DRAW || op == OP_MASK_PUSH) && ((om & F_GENERAL) || atlas_mode || mode >= 18u))) p.has_slow = true;
     }
     p.bin_x0 = u.x0 / kBin; p.bin_y0 = u.y0 / kBin;
     p.bin_x1 = bbox_empty(u) ? p.bin_x0 : (u.x1 + kBin - 1) / kBin;
@@ -1008,6 +1012,7 @@ void Context::launch_frame(bool profile) {
     C.clear_rgba8 = clear_rgba8_;
     C.n_wg = 0;
     C.has_slow = ph.has_slow ? 1 : 0;
+    C.has_atlas = ph.has_atlas ? 1 : 0;
     C.has_masks = ph.has_masks ? 1 : 0;
     span_begin(p == 0 ? 1 : 2);
     launch_composite(stream_, d_recs_.ptr, d_bboxes_.ptr, d_exts_.ptr, C);

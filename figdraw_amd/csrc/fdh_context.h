@@ -72,6 +72,7 @@ struct Phase {
   int blur = -1;  // index into blurs: executed before this phase's composite
   int bin_x0 = 0, bin_y0 = 0, bin_x1 = 0, bin_y1 = 0;  // bins touched by the phase's draws
   bool has_masks = false; // clip / rect-mask ops present
+  bool has_atlas = false; // axis-aligned atlas quads at >= 1:1 present (k_composite_tiles<2> unless has_slow)
   bool has_slow = false;  // some draw needs k_composite_tiles<true> (atlas / rotated quad / bezier / rect-mask setup)
 };
 struct BlurJob {

@@ -29,7 +29,8 @@ struct CompositeParams {
   uint32_t clear_rgba8;
   int n_wg;                 // total workgroups (for the XCD remap)
   int has_masks;            // the phase holds clip / rect-mask ops (disables per-strip occlusion culling)
-  int has_slow;             // the phase holds draws that need the one-pixel-slot path (k_composite_tiles<true>)
+  int has_slow;             // the phase holds draws that need the one-pixel-slot path (k_composite_tiles<3>)
+  int has_atlas;            // ... or axis-aligned atlas quads at >= 1:1 (k_composite_tiles<2>)
 };
 
 struct BlurParams {

@@ -667,8 +667,10 @@ __device__ unsigned long long g_counters[64];
 #ifndef FDH_FAST_WAVES
 #define FDH_FAST_WAVES 5
 #endif
-template <bool kSlow>
-__global__ __launch_bounds__(FDH_WAVE_WG ? 64 : 256, kSlow ? 4 : FDH_FAST_WAVES) void k_composite_tiles(const DrawRec* __restrict__ draws, const BBox* __restrict__ bboxes,
+// kPaths: bit 0 = the one-pixel-slot path (rotated / skewed quads, bezier strokes, rect-mask setup, minified images),
+// bit 1 = the 4-wide atlas path (axis-aligned glyphs, images at >= 1:1, MSDF).  0: SDF draws, clips and rect masks only.
+template <int kPaths>
+__global__ __launch_bounds__(FDH_WAVE_WG ? 64 : 256, (kPaths & 1) ? 4 : FDH_FAST_WAVES) void k_composite_tiles(const DrawRec* __restrict__ draws, const BBox* __restrict__ bboxes,
                                                          const QuadExt* __restrict__ exts, CompositeParams P) {
   __shared__ uint32_t mask_stack[FDH_WAVE_WG ? 1 : kWavesPerWg][kMaskDepth][64];  // 4 pixels' q8 mask values packed per lane
   // XCD-aware mapping: the dispatcher places workgroup b on XCD b % 8.  XCD x takes the bins x, x+8, x+16, ... of this
@@ -788,6 +790,75 @@ __global__ __launch_bounds__(FDH_WAVE_WG ? 64 : 256, kSlow ? 4 : FDH_FAST_WAVES)
       if (op == OP_RMASK_END) { rm0 = rm1 = rm2 = rm3 = 1.0f; rmask_on = false; return; }
       const bool atlas_mode = (mode == 0u) || (mode >= 13u && mode <= 16u);
       const bool fast = !(om & F_GENERAL) && !atlas_mode && mode < 18u && (op == OP_DRAW || op == OP_MASK_PUSH);
+      // ---- axis-aligned atlas quads (glyphs, images at >= 1:1, MSDF / MTSDF): 4 pixels per lane in lock-step.  All
+      // sixteen bilinear texel fetches of the lane are issued before any of them is used, so the wave pays the atlas
+      // latency once per draw instead of once per pixel slot.  (Minified images, lod > 0, keep the trilinear slot path.)
+      constexpr bool kSlow = (kPaths & 1) != 0, kAtlas = (kPaths & 2) != 0;
+      if (kAtlas && atlas_mode && !(om & F_GENERAL) && op == OP_DRAW && !(mode == 0u && r.aux2 > 0.0f && P.atlas.n_levels >= 2)) {
+        const uint32_t fill_mode = (om >> 9) & 7u;
+        const int S = P.atlas.size, msk = S - 1;
+        const float fS = (float)S;
+        const uint32_t* __restrict__ tex = P.atlas.level[0];
+        const float uax = r.r[0], uay = r.r[1], utx = r.r[2], uty = r.r[3];
+        const float t = (cy - r.oy) * r.inv_h;
+        const float v = uay + (uty - uay) * t;
+        const float ty_ = v * fS - 0.5f, fy = __builtin_floorf(ty_), ayf = ty_ - fy;
+        const int y0 = (int)fy & msk, y1 = (y0 + 1) & msk;
+        const uint32_t xrel = (uint32_t)(px0 - (int)r.bx0);
+        const uint32_t wcov = (py >= r.by0 && py < r.by1) ? (uint32_t)((int)r.bx1 - (int)r.bx0) : 0u;
+        const float ushift = (mode == 0u && (om & F_SUBPIXEL)) ? r.aux * frcp(__builtin_fmaxf(fS, 1.0f)) : 0.0f;
+        float sK[4], uK[4], axK[4];
+        uint32_t q00[4], q01[4], q10[4], q11[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          sK[k] = (cx0 + (float)k - r.ox) * r.inv_w;
+          uK[k] = uax + (utx - uax) * sK[k];
+          const float tx_ = (uK[k] - ushift) * fS - 0.5f, fx = __builtin_floorf(tx_);
+          axK[k] = tx_ - fx;
+          const int x0 = (int)fx & msk, x1 = (x0 + 1) & msk;
+          q00[k] = tex[(size_t)y0 * S + x0]; q01[k] = tex[(size_t)y0 * S + x1];
+          q10[k] = tex[(size_t)y1 * S + x0]; q11[k] = tex[(size_t)y1 * S + x1];
+        }
+        const bool solid = (om & F_SOLID) != 0u;
+        const bool masked = mask_depth > 0 || rmask_on;
+        const bool msdf = mode != 0u;
+        const bool is_mtsdf = (mode == 14u || mode == 16u), is_stroke = (mode == 15u || mode == 16u);
+        const float unit = r.f0 * frcp(r.p0);  // pxRange / atlas size (atlas.frag:45-49)
+        const float fw_u = __builtin_fabsf((utx - uax) * r.inv_w), fw_v = __builtin_fabsf((uty - uay) * r.inv_h);
+        const float spr = __builtin_fmaxf(0.5f * (unit * frcp(fw_u) + unit * frcp(fw_v)), 1.0f);
+        const F4 c0u = unpack255(r.col[0]);
+        auto pixel = [&](const int k, F4& F, const float mk, const float rm) __attribute__((always_inline)) {
+          const F4 a = unpack255(q00[k]), b = unpack255(q01[k]), c = unpack255(q10[k]), d = unpack255(q11[k]);
+          const float ax = axK[k];
+          F4 tx;  // GL_LINEAR, 0..1
+          tx.x = (mixf(a.x, b.x, ax) * (1.0f - ayf) + mixf(c.x, d.x, ax) * ayf) * inv255;
+          tx.y = (mixf(a.y, b.y, ax) * (1.0f - ayf) + mixf(c.y, d.y, ax) * ayf) * inv255;
+          tx.z = (mixf(a.z, b.z, ax) * (1.0f - ayf) + mixf(c.z, d.z, ax) * ayf) * inv255;
+          tx.w = (mixf(a.w, b.w, ax) * (1.0f - ayf) + mixf(c.w, d.w, ax) * ayf) * inv255;
+          F4 col = {c0u.x * inv255, c0u.y * inv255, c0u.z * inv255, c0u.w * inv255};
+          if (!solid) {  // wave-uniform
+            const F4 br = unpack255(r.col[1]), tr = unpack255(r.col[2]), tl = unpack255(r.col[3]);
+            col.x = tri_lerp(tl.x, c0u.x, br.x, tr.x, sK[k], t) * inv255;
+            col.y = tri_lerp(tl.y, c0u.y, br.y, tr.y, sK[k], t) * inv255;
+            col.z = tri_lerp(tl.z, c0u.z, br.z, tr.z, sK[k], t) * inv255;
+            col.w = tri_lerp(tl.w, c0u.w, br.w, tr.w, sK[k], t) * inv255;
+          }
+          float sr, sg, sb, sa;
+          if (!msdf) {  // atlas.frag:284-295
+            sr = tx.x * col.x; sg = tx.y * col.y; sb = tx.z * col.z; sa = tx.w * col.w;
+          } else {  // atlas.frag:296-318
+            const F4 fc = eval_fill_rec(r, col, fill_mode, uK[k], v);
+            const float sd = is_mtsdf ? tx.w : median3(tx.x, tx.y, tx.z);
+            const float spd = spr * (sd - r.f1);
+            const float alpha = is_stroke ? clamp01(__builtin_fmaxf(r.p1, 0.0f) * 0.5f - __builtin_fabsf(spd) + 0.5f) : clamp01(spd + 0.5f);
+            sr = fc.x; sg = fc.y; sb = fc.z; sa = fc.w * alpha;
+          }
+          if (masked) sa = sa * mk * rm;
+          blend(F, sr, sg, sb, (xrel + (uint32_t)k) < wcov ? sa : 0.0f);
+        };
+        pixel(0, F0, mk0, rm0); pixel(1, F1, mk1, rm1); pixel(2, F2, mk2, rm2); pixel(3, F3, mk3, rm3);
+        return;
+      }
       if (!kSlow && !fast) return;  // unreachable: the host picks kSlow = true for any phase holding such a draw
       if (kSlow && !fast) {
         FDH_COUNT(1);
@@ -1368,8 +1439,10 @@ void launch_composite(hipStream_t s, const DrawRec* draws, const BBox* bboxes, c
   P.n_wg = n;
   const int bins8 = (P.bin_nx * P.bin_ny + 7) / 8;  // bins per XCD
   const int grid = 8 * bins8 * (FDH_WAVE_WG ? kWgsPerBin * kWavesPerWg : kWgsPerBin);
-  if (P.has_slow) hipLaunchKernelGGL(k_composite_tiles<true>, dim3(grid), dim3(FDH_WAVE_WG ? 64 : 256), 0, s, draws, bboxes, exts, P);
-  else hipLaunchKernelGGL(k_composite_tiles<false>, dim3(grid), dim3(FDH_WAVE_WG ? 64 : 256), 0, s, draws, bboxes, exts, P);
+  const dim3 blk(FDH_WAVE_WG ? 64 : 256);
+  if (P.has_slow) hipLaunchKernelGGL(k_composite_tiles<3>, dim3(grid), blk, 0, s, draws, bboxes, exts, P);
+  else if (P.has_atlas) hipLaunchKernelGGL(k_composite_tiles<2>, dim3(grid), blk, 0, s, draws, bboxes, exts, P);
+  else hipLaunchKernelGGL(k_composite_tiles<0>, dim3(grid), blk, 0, s, draws, bboxes, exts, P);
 }
 // small regions: fewer outputs per thread -> more, shorter waves (see NOUT above)
 #ifndef FDH_BLUR_NOUT
