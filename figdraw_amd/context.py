@@ -35,7 +35,8 @@ class FrameStats(C.Structure):
                 ("ms_total", C.c_float), ("ms_bin", C.c_float), ("ms_composite", C.c_float),
                 ("ms_composite_main", C.c_float), ("ms_blur_h", C.c_float), ("ms_blur_v", C.c_float),
                 ("bytes_algorithmic", C.c_int64), ("bytes_composite_main", C.c_int64), ("bytes_blur", C.c_int64),
-                ("fragments", C.c_int64)]
+                ("fragments", C.c_int64), ("ms_host_record", C.c_float), ("ms_host_upload", C.c_float),
+                ("ms_host_launch", C.c_float), ("_reserved", C.c_float)]
 
 
 def build(force: bool = False) -> str:

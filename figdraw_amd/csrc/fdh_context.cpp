@@ -7,6 +7,8 @@
 // blurs split the list into phases (a blur is a global barrier in painter's order, glcontext.nim:1788-1841).
 #include "fdh_context.h"
 
+#include <chrono>
+
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -45,6 +47,7 @@ Context::Context(int atlas_size, float pixel_scale, int device, uint32_t flags) 
   FDH_HIP(hipStreamCreateWithFlags(&own_stream_, hipStreamNonBlocking));
   stream_ = own_stream_;
   for (auto& e : ev_) FDH_HIP(hipEventCreate(&e));
+  for (auto& e : staging_ev_) FDH_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   initial_atlas_size_ = atlas_size > 0 ? atlas_size : 1024;  // newContext default, glcontext.nim:255-261
   alloc_atlas(initial_atlas_size_);
 }
@@ -58,8 +61,9 @@ Context::~Context() {
   if (fb_) (void)hipFree(fb_);
   if (backdrop_) (void)hipFree(backdrop_);
   if (blur_tmp_) (void)hipFree(blur_tmp_);
-  d_recs_.release(); d_bboxes_.release(); d_exts_.release(); d_lists_.release(); d_counts_.release(); d_phase_first_.release();
-  staging_.release();
+  d_frame_.release(); d_lists_.release(); d_counts_.release();
+  for (auto& b : staging_) b.release();
+  for (auto& e : staging_ev_) if (e) (void)hipEventDestroy(e);
   if (own_stream_) (void)hipStreamDestroy(own_stream_);
 }
 
@@ -300,6 +304,7 @@ void Context::ensure_surfaces() {
 void Context::begin_frame(int w, int h, bool clear, const float rgba[4]) {  // glcontext.nim:2080-2092, 1951-1980
   if (frame_begun_) throw Error(FDH_ERR_INVALID, "ctx.beginFrame has already been called.");
   if (w <= 0 || h <= 0 || w > 16384 || h > 16384) throw Error(FDH_ERR_INVALID, "beginFrame: frame size must be in 1..16384");
+  t_begin_frame_ = std::chrono::steady_clock::now();
   FDH_HIP(hipSetDevice(device_));
   W_ = w;
   H_ = h;
@@ -870,10 +875,13 @@ void Context::end_frame() {  // glcontext.nim:1982-1989
   if (!rect_masks_.empty()) throw Error(FDH_ERR_INVALID, "Not all rect masks have been popped.");
   frame_begun_ = false;
   have_frame_ = true;
+  const auto t1 = std::chrono::steady_clock::now();
+  host_record_ms_ = std::chrono::duration<float, std::milli>(t1 - t_begin_frame_).count();
   submit(true);
 }
 
 void Context::submit(bool upload) {
+  const auto t_s0 = std::chrono::steady_clock::now();
   FDH_HIP(hipSetDevice(device_));
   const size_t n = recs_.size();
   bins_x_ = (W_ + kBin - 1) / kBin;
@@ -903,24 +911,33 @@ void Context::submit(bool upload) {
   }
   list_stride_ = max_count;
   if (upload) {
-    d_recs_.reserve(std::max<size_t>(n, 1));
-    d_bboxes_.reserve(std::max<size_t>(n, 1));
-    d_exts_.reserve(std::max<size_t>(exts_.size(), 1));
-    d_phase_first_.reserve(phases_.size() + 1);
     d_lists_.reserve((size_t)phases_.size() * nb * list_stride_);
     d_counts_.reserve((size_t)phases_.size() * nb);
     std::vector<int> pf(phases_.size() + 1);
     for (size_t i = 0; i < phases_.size(); i++) pf[i] = phases_[i].first;
     pf[phases_.size()] = (int)n;
-    const size_t b_recs = n * sizeof(DrawRec), b_bb = n * sizeof(BBox), b_ext = exts_.size() * sizeof(QuadExt), b_pf = pf.size() * sizeof(int);
-    FDH_HIP(hipStreamSynchronize(stream_));  // the staging buffer may still feed the previous frame's copies
-    staging_.reserve(b_recs + b_bb + b_ext + b_pf + 64);
-    uint8_t* s = staging_.ptr;
-    if (b_recs) { std::memcpy(s, recs_.data(), b_recs); FDH_HIP(hipMemcpyAsync(d_recs_.ptr, s, b_recs, hipMemcpyHostToDevice, stream_)); s += b_recs; }
-    if (b_bb) { std::memcpy(s, bboxes_.data(), b_bb); FDH_HIP(hipMemcpyAsync(d_bboxes_.ptr, s, b_bb, hipMemcpyHostToDevice, stream_)); s += b_bb; }
-    if (b_ext) { std::memcpy(s, exts_.data(), b_ext); FDH_HIP(hipMemcpyAsync(d_exts_.ptr, s, b_ext, hipMemcpyHostToDevice, stream_)); s += b_ext; }
-    std::memcpy(s, pf.data(), b_pf);
-    FDH_HIP(hipMemcpyAsync(d_phase_first_.ptr, s, b_pf, hipMemcpyHostToDevice, stream_));
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t b_recs = n * sizeof(DrawRec), b_ext = exts_.size() * sizeof(QuadExt), b_bb = n * sizeof(BBox), b_pf = pf.size() * sizeof(int);
+    const size_t o_recs = 0, o_ext = up(o_recs + b_recs), o_bb = up(o_ext + b_ext), o_pf = up(o_bb + b_bb), total = up(o_pf + b_pf);
+    d_frame_.reserve(total);
+    dv_.recs = reinterpret_cast<DrawRec*>(d_frame_.ptr + o_recs);
+    dv_.exts = reinterpret_cast<QuadExt*>(d_frame_.ptr + o_ext);
+    dv_.bboxes = reinterpret_cast<BBox*>(d_frame_.ptr + o_bb);
+    dv_.phase_first = reinterpret_cast<int*>(d_frame_.ptr + o_pf);
+    const int slot = staging_i_;
+    staging_i_ = (staging_i_ + 1) % kStaging;
+    if (staging_busy_[slot]) FDH_HIP(hipEventSynchronize(staging_ev_[slot]));  // its copy of three frames ago
+    staging_[slot].reserve(total);
+    uint8_t* s = staging_[slot].ptr;
+    if (b_recs) std::memcpy(s + o_recs, recs_.data(), b_recs);
+    if (b_ext) std::memcpy(s + o_ext, exts_.data(), b_ext);
+    if (b_bb) std::memcpy(s + o_bb, bboxes_.data(), b_bb);
+    std::memcpy(s + o_pf, pf.data(), b_pf);
+    void* s_dev = nullptr;
+    FDH_HIP(hipHostGetDevicePointer(&s_dev, s, 0));
+    launch_upload(stream_, d_frame_.ptr, s_dev, total);  // whole 16-byte groups: both sides are padded to 256 B
+    FDH_HIP(hipEventRecord(staging_ev_[slot], stream_));
+    staging_busy_[slot] = true;
   }
   // algorithmic bytes of this frame: final store + per blur (pre-blur store is the store above for
   // a full-frame node; H read + H write + V read + V write + composite read) + records once
@@ -942,7 +959,12 @@ void Context::submit(bool upload) {
   stats_.n_bins = nb;
   stats_.bytes_algorithmic = bytes;
   stats_.fragments = fragments_;
+  const auto t_l0 = std::chrono::steady_clock::now();
   launch_frame(false);
+  const auto t_l1 = std::chrono::steady_clock::now();
+  stats_.ms_host_record = host_record_ms_;
+  stats_.ms_host_upload = std::chrono::duration<float, std::milli>(t_l0 - t_s0).count();
+  stats_.ms_host_launch = std::chrono::duration<float, std::milli>(t_l1 - t_l0).count();
 }
 
 void Context::launch_frame(bool profile) {
@@ -967,7 +989,7 @@ void Context::launch_frame(bool profile) {
   auto span_end = [&]() { if (profile) FDH_HIP(hipEventRecord(spans_.back().b, stream_)); };
   span_begin(0);
   BinParams B;
-  B.bbox = d_bboxes_.ptr; B.draws = d_recs_.ptr; B.lists = d_lists_.ptr; B.counts = d_counts_.ptr; B.phase_first = d_phase_first_.ptr;
+  B.bbox = dv_.bboxes; B.draws = dv_.recs; B.lists = d_lists_.ptr; B.counts = d_counts_.ptr; B.phase_first = dv_.phase_first;
   B.n_phases = np; B.bins_x = bins_x_; B.bins_y = bins_y_; B.stride = list_stride_;
   launch_bin(stream_, B);
   span_end();
@@ -991,7 +1013,7 @@ void Context::launch_frame(bool profile) {
         bp.fuse_draw = j.fuse_draw;
         bp.y0 = vy0; bp.y1 = vy1;
         span_begin(4);
-        launch_blur_v(stream_, bp, d_recs_.ptr, d_exts_.ptr);
+        launch_blur_v(stream_, bp, dv_.recs, dv_.exts);
         span_end();
       }
     }
@@ -1015,7 +1037,7 @@ void Context::launch_frame(bool profile) {
     C.has_atlas = ph.has_atlas ? 1 : 0;
     C.has_masks = ph.has_masks ? 1 : 0;
     span_begin(p == 0 ? 1 : 2);
-    launch_composite(stream_, d_recs_.ptr, d_bboxes_.ptr, d_exts_.ptr, C);
+    launch_composite(stream_, dv_.recs, dv_.bboxes, dv_.exts, C);
     span_end();
   }
   FDH_HIP(hipGetLastError());

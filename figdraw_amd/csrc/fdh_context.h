@@ -2,6 +2,7 @@
 // backend calls into draw records (what glcontext.nim does into vertex streams) and submits them.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <chrono>
 
 #include <cstdint>
 #include <stdexcept>
@@ -201,13 +202,19 @@ class Context {
   // device state
   uint32_t *fb_ = nullptr, *backdrop_ = nullptr, *blur_tmp_ = nullptr;
   int surf_w_ = 0, surf_h_ = 0;
-  DeviceBuf<DrawRec> d_recs_;
-  DeviceBuf<BBox> d_bboxes_;
-  DeviceBuf<QuadExt> d_exts_;
+  // records, quad extensions, bounding boxes and phase offsets of a frame live in ONE device block and arrive with ONE
+  // copy (four small hipMemcpyAsync calls cost the host ~100 us per frame); the typed views point into it
+  DeviceBuf<uint8_t> d_frame_;
+  struct View { DrawRec* recs = nullptr; QuadExt* exts = nullptr; BBox* bboxes = nullptr; int* phase_first = nullptr; } dv_;
   DeviceBuf<uint2> d_lists_;
   DeviceBuf<uint32_t> d_counts_;
-  DeviceBuf<int> d_phase_first_;
-  PinnedBuf<uint8_t> staging_;
+  // three pinned staging buffers in rotation, each guarded by an event recorded after its copies: the host builds
+  // frame N+1 and N+2 while frame N still runs (a single buffer forced a stream sync per frame)
+  static constexpr int kStaging = 3;
+  PinnedBuf<uint8_t> staging_[kStaging];
+  hipEvent_t staging_ev_[kStaging] = {};
+  bool staging_busy_[kStaging] = {};
+  int staging_i_ = 0;
   int bins_x_ = 0, bins_y_ = 0, list_stride_ = 0;
 
   // atlas
@@ -217,6 +224,8 @@ class Context {
   std::unordered_map<int64_t, AtlasEntry> entries_;
 
   FdhFrameStats stats_ = {};
+  std::chrono::steady_clock::time_point t_begin_frame_;
+  float host_record_ms_ = 0.0f;
 };
 
 }  // namespace fdh

@@ -49,5 +49,6 @@ void launch_composite(hipStream_t s, const DrawRec* draws, const BBox* bboxes, c
 void launch_blur_h(hipStream_t s, const BlurParams& P);
 void launch_blur_v(hipStream_t s, const BlurParams& P, const DrawRec* draws, const QuadExt* exts);
 void launch_fill(hipStream_t s, uint32_t* p, uint32_t v, size_t n);
+void launch_upload(hipStream_t s, void* dst, const void* src_mapped, size_t bytes);  // src: device view of pinned host memory
 
 }  // namespace fdh

@@ -1467,6 +1467,19 @@ void launch_blur_v(hipStream_t s, const BlurParams& P, const DrawRec* draws, con
   if (P.x1 <= P.x0 || P.y1 <= P.y0) return;
   if (blur_small(P)) launch_blur_v_n<2>(s, P, draws, exts); else launch_blur_v_n<FDH_BLUR_NOUT>(s, P, draws, exts);
 }
+// Frame upload as a kernel on the render stream: the source is pinned host memory mapped into the device's address
+// space, read over the host link 16 bytes per lane.  (hipMemcpyAsync hands the copy to another engine; the round trip
+// of dependencies between that engine and the compute queue cost ~60 us of idle GPU per frame.)
+__global__ void k_upload(uint4* __restrict__ dst, const uint4* __restrict__ src, size_t n16) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n16) dst[i] = src[i];
+}
+void launch_upload(hipStream_t s, void* dst, const void* src_mapped, size_t bytes) {
+  const size_t n16 = (bytes + 15) / 16;
+  if (n16 == 0) return;
+  hipLaunchKernelGGL(k_upload, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, s, reinterpret_cast<uint4*>(dst),
+                     reinterpret_cast<const uint4*>(src_mapped), n16);
+}
 void launch_fill(hipStream_t s, uint32_t* p, uint32_t v, size_t n) {
   if (n == 0) return;
   hipLaunchKernelGGL(k_fill_u32, dim3(1024), dim3(256), 0, s, p, v, n);

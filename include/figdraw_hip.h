@@ -252,6 +252,10 @@ typedef struct {
   int64_t bytes_composite_main; /* algorithmic bytes of the phase-0 composite launch: surface store (+load) + records */
   int64_t bytes_blur;        /* algorithmic bytes of all blur launches: H read + H write + V read + V write */
   int64_t fragments;         /* sum of covered fragments over all draws (GL-equivalent work unit) */
+  /* host-side cost of the last begin_frame .. end_frame: recording the calls (tree walk for fdh_render_frame), building
+   * the upload, and issuing the copies + kernel launches; all asynchronous to the GPU */
+  float ms_host_record, ms_host_upload, ms_host_launch;
+  float _reserved;
 } FdhFrameStats;
 /* Run `times` more frames with hipEvents around every kernel launch and fill the per-kernel averages. */
 FDH_API int fdh_profile(FdhContext*, int times);
