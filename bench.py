@@ -111,6 +111,30 @@ def main():
     ctx.profile(min(args.steps, 50))
     st = ctx.frame_stats()
 
+    # the DYNAMIC path next to it (not `value`): fdh_render_frame every frame = C++ tree walk + record upload + kernels,
+    # four different frames of the animation in rotation, scenes marshalled to the C structs beforehand
+    dynamic = None
+    if rank == 0:
+        from figdraw_amd import context as C_
+
+        cs = [make_render_tree_100(w, h, frame=f, full_frame_blur=True).to_c() for f in range(4)]
+        col = C_._F4(1.0, 1.0, 1.0, 1.0)
+        n_dyn = min(args.steps, 100)
+        for i in range(8):
+            ctx._ck(ctx.L.fdh_render_frame(ctx.h, cs[i & 3].byref(), float(w), float(h), 1, col))
+        ctx.sync()
+        td = time.perf_counter()
+        for i in range(n_dyn):
+            ctx._ck(ctx.L.fdh_render_frame(ctx.h, cs[i & 3].byref(), float(w), float(h), 1, col))
+        ctx.sync()
+        td = time.perf_counter() - td
+        sd = ctx.frame_stats()
+        dynamic = {"ms_per_frame": round(1e3 * td / n_dyn, 4), "mpixels_per_s": round(w * h * n_dyn / td / 1e6, 1),
+                   "host_record_us": round(1e3 * sd.ms_host_record, 1), "host_launch_us": round(1e3 * sd.ms_host_launch, 1),
+                   "note": "scene tree walked, decomposed and uploaded every frame (the drop-in's per-frame cost); `value` replays resident records"}
+        ctx.render_frame(scene, w, h)  # back to the benchmark frame for the gather / parity legs below
+        ctx.sync()
+
     gather_ms = None
     if dist is not None:
         mine = frame_tensor(ctx).contiguous()
@@ -220,6 +244,7 @@ def main():
                                 "composite_main": round(st.ms_composite_main, 4), "blur_h": round(st.ms_blur_h, 4),
                                 "blur_v": round(st.ms_blur_v, 4)},
                   "host_decompose_upload_first_frame_ms": round(1e3 * (t_host1 - t_host0), 2)},
+        "dynamic_path": dynamic,
         "cpu_baseline": cpu_baseline,
     }
     if gather_ms is not None:
