@@ -91,6 +91,7 @@ def load():
     L.fdh_pop_rect_mask.argtypes = [vp]
     L.fdh_set_text_subpixel_positioning.argtypes = [vp, C.c_int]
     L.fdh_set_text_subpixel_shift.argtypes = [vp, C.c_float]
+    L.fdh_set_text_subpixel_glyph_variants.argtypes = [vp, C.c_int]
     L.fdh_put_image.argtypes = [vp, C.c_int64, C.c_int, C.c_int, vp, C.c_int * 4]
     L.fdh_update_image.argtypes = [vp, C.c_int64, C.c_int, C.c_int, vp]
     L.fdh_put_image_mips.argtypes = [vp, C.c_int64, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_void_p), C.c_int * 4]
@@ -112,6 +113,7 @@ def load():
     assert L.fdh_sizeof_fig() == C.sizeof(S.CFig), (L.fdh_sizeof_fig(), C.sizeof(S.CFig))
     assert L.fdh_sizeof_glyph() == C.sizeof(S.CGlyph)
     assert L.fdh_sizeof_draw_op() == C.sizeof(S.CDrawOp)
+    assert L.fdh_sizeof_text_rect() == C.sizeof(S.CTextRect)
     _lib = L
     return L
 
@@ -234,8 +236,9 @@ class HipContext:
     def pop_rect_mask(self):
         self._ck(self.L.fdh_pop_rect_mask(self.h))
 
-    def set_text_subpixel(self, enabled: bool, shift: float = 0.0):
+    def set_text_subpixel(self, enabled: bool, shift: float = 0.0, glyph_variants: bool = False):
         self._ck(self.L.fdh_set_text_subpixel_positioning(self.h, int(bool(enabled))))
+        self._ck(self.L.fdh_set_text_subpixel_glyph_variants(self.h, int(bool(glyph_variants))))
         self._ck(self.L.fdh_set_text_subpixel_shift(self.h, shift))
 
     # ---- atlas

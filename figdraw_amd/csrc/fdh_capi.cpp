@@ -43,6 +43,7 @@ const char* fdh_version(void) { return "figdraw_hip 0.1.0 (gfx950)"; }
 int fdh_sizeof_fig(void) { return (int)sizeof(FdhFig); }
 int fdh_sizeof_glyph(void) { return (int)sizeof(FdhGlyph); }
 int fdh_sizeof_draw_op(void) { return (int)sizeof(FdhDrawOp); }
+int fdh_sizeof_text_rect(void) { return (int)sizeof(FdhTextRect); }
 
 int fdh_create(FdhContext** out, int atlas_size, float pixel_scale, int device, uint32_t flags) {
   return guard([&] {
@@ -122,6 +123,7 @@ int fdh_draw_filled_quad(FdhContext* c, const float verts[8], const FdhColor col
 }
 int fdh_draw_rect(FdhContext* c, const float rect[4], FdhColor color) { return guard([&] { C(c)->draw_rect(rect, color); }); }
 int fdh_set_text_subpixel_positioning(FdhContext* c, int e) { return guard([&] { C(c)->set_subpixel_enabled(e != 0); }); }
+int fdh_set_text_subpixel_glyph_variants(FdhContext* c, int e) { return guard([&] { C(c)->set_subpixel_variants(e != 0); }); }
 int fdh_set_text_subpixel_shift(FdhContext* c, float s) { return guard([&] { C(c)->set_subpixel_shift(s); }); }
 
 int fdh_put_image(FdhContext* c, int64_t key, int w, int h, const uint8_t* rgba, int out_rect[4]) {

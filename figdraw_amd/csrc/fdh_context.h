@@ -122,6 +122,9 @@ class Context {
   void begin_rect_mask(const float rect[4], const float rx[4], const float ry[4]);
   void pop_rect_mask();
   void set_subpixel_enabled(bool e) { subpixel_enabled_ = e; }
+  bool subpixel_enabled() const { return subpixel_enabled_; }
+  void set_subpixel_variants(bool e) { subpixel_variants_ = e; }
+  bool subpixel_variants() const { return subpixel_variants_; }
   void set_subpixel_shift(float s) { subpixel_shift_ = s; }
 
   // atlas
@@ -186,7 +189,7 @@ class Context {
   Aff mat_;
   std::vector<Aff> mats_;
   float aa_ = 1.2f, pixel_scale_ = 1.0f, ui_scale_ = 1.0f;
-  bool subpixel_enabled_ = false;
+  bool subpixel_enabled_ = false, subpixel_variants_ = false;
   float subpixel_shift_ = 0.0f;
   int stripe_y0_ = 0, stripe_y1_ = 0;
 

@@ -415,18 +415,54 @@ struct Walker {
     ctx.set_aa(old);
   }
 
-  void text(const FdhFig& n) {  // renderText :417-497, glyph loop (layout happened on the caller's side)
+  void text_rect(float x, float y, float w, float h, const FdhFill& f) {  // figrender.nim:355-369, 444-452
+    const float rect[4] = {scaled(x), scaled(y), scaled(w), scaled(h)};
+    const float zero[4] = {0, 0, 0, 0}, shape[2] = {0, 0};
+    ctx.draw_rounded_rect_fill(rect, f, zero, zero, FDH_SDF_CLIP_AA, 4.0f, 0.0f, shape);
+  }
+  void text(const FdhFig& n) {  // renderText :417-497 (typesetting happened on the caller's side)
     ctx.save_transform();
     ctx.translate(scaled(n.box[0]), scaled(n.box[1]));
     if (n.flags & FDH_NF_INVERT_Y) {
       ctx.translate(0.0f, scaled(n.box[3]));
       ctx.scale(1.0f, -1.0f);
     }
+    // selection rectangles first (:435-452), then underline / strikethrough (:371-415), then the glyphs
+    for (int pass = 0; pass < 2; pass++) {
+      for (int k = n.text_rect_first; k < n.text_rect_first + n.text_rect_count && k < scene.n_text_rects; k++) {
+        const FdhTextRect& tr = scene.text_rects[k];
+        if (tr.kind != pass) continue;
+        if (pass == 0) {
+          if (!(n.flags & FDH_NF_SELECT_TEXT) || fill_alpha_max(n.fill) == 0 || !(tr.h > 0.0f)) continue;
+          text_rect(tr.x, tr.y, std::max(tr.w, 1.0f), tr.h, n.fill);
+        } else {
+          if (tr.w <= 0.0f || tr.h <= 0.0f) continue;
+          text_rect(tr.x, tr.y, tr.w, tr.h, tr.fill);
+        }
+      }
+    }
     for (int g = n.glyph_first; g < n.glyph_first + n.glyph_count && g < scene.n_glyphs; g++) {
       const FdhGlyph& gl = scene.glyphs[g];
-      const float pos[2] = {gl.x, gl.y}, size[2] = {0, 0};
-      ctx.set_subpixel_shift(gl.subpixel_shift);
-      ctx.draw_image(gl.image_id, pos, gl.colors, size, false);
+      float pos[2] = {gl.x, gl.y};
+      const float size[2] = {0, 0};
+      int64_t key = gl.image_id;
+      float shift = gl.subpixel_shift;
+      if (shift < 0.0f) {  // figrender.nim:464-471
+        shift = 0.0f;
+        if (ctx.subpixel_enabled()) {
+          const float snapped = std::floor(pos[0]);
+          const float frac = std::max(0.0f, std::min(pos[0] - snapped, 0.999f));
+          pos[0] = snapped;
+          if (ctx.subpixel_variants() && scene.glyph_variant_ids) {  // toGlyphVariantSubpixelStep common/fontglyphs.nim:50-52
+            const int step = std::min((int)(frac * (float)FDH_GLYPH_VARIANT_STEPS), FDH_GLYPH_VARIANT_STEPS - 1);
+            key = scene.glyph_variant_ids[(size_t)g * FDH_GLYPH_VARIANT_STEPS + step];
+          } else {
+            shift = frac;
+          }
+        }
+      }
+      ctx.set_subpixel_shift(shift);
+      ctx.draw_image(key, pos, gl.colors, size, false);
     }
     ctx.set_subpixel_shift(0.0f);
     ctx.restore_transform();

@@ -175,7 +175,43 @@ class Glyph:
     x: float
     y: float
     colors: Sequence[RGBA] = ((0, 0, 0, 255),) * 4  # BL, BR, TR, TL
-    subpixel_shift: float = 0.0
+    subpixel_shift: float = 0.0  # >= 0 explicit; < 0: derived from x by the renderer (figrender.nim:464-471)
+    variant_ids: Optional[Sequence[int]] = None  # GLYPH_VARIANT_STEPS atlas keys (sub-pixel glyph variants), optional
+
+
+GLYPH_VARIANT_STEPS = 10  # common/fontglyphs.nim:43
+
+
+@dataclass
+class TextRect:
+    """A rectangle renderText draws before the glyphs (figrender.nim:355-452), text-local UI units.
+    kind 0 = selection (node fill, needs NfSelectText), kind 1 = underline / strikethrough (own fill)."""
+    x: float
+    y: float
+    w: float
+    h: float
+    kind: int = 0
+    fill: Fill = field(default_factory=Fill)
+
+    def __post_init__(self):
+        self.fill = _as_fill(self.fill)
+
+
+def text_decoration_rects(min_x, max_x, min_y, max_y, font_size, underline=False, strikethrough=False, color=None):
+    """renderTextDecorations (figrender.nim:371-415) for one (span, line) run whose glyph rectangles span
+    [min_x,max_x] x [min_y,max_y]: thickness = max(round(size/16), 1)."""
+    import math
+
+    out = []
+    if not (min_x < max_x and min_y < max_y):
+        return out
+    t = max(math.floor(font_size / 16.0 + 0.5), 1.0)
+    f = color if color is not None else fill((0, 0, 0, 255))
+    if underline:
+        out.append(TextRect(min_x, max_y - t * 1.5, max_x - min_x, t, kind=1, fill=f))
+    if strikethrough:
+        out.append(TextRect(min_x, min_y + (max_y - min_y) * 0.5 - t * 0.5, max_x - min_x, t, kind=1, fill=f))
+    return out
 
 
 @dataclass
@@ -235,6 +271,7 @@ class Fig:  # fignodes.nim:54-92
     matrix: Optional[Sequence[float]] = None  # 16 floats, column-major
     useMatrix: bool = False
     glyphs: List[Glyph] = field(default_factory=list)
+    textRects: List[TextRect] = field(default_factory=list)
     drawStroke: RenderStroke = field(default_factory=RenderStroke)
     drawSteps: int = 0
     drawAa: float = 0.0
@@ -333,6 +370,7 @@ class CFig(C.Structure):
         ("glyph_first", C.c_int32), ("glyph_count", C.c_int32),
         ("draw_stroke", CStroke), ("draw_steps", C.c_uint16), ("_pad0", C.c_uint16), ("draw_aa", C.c_float),
         ("op_first", C.c_int32), ("op_count", C.c_int32),
+        ("text_rect_first", C.c_int32), ("text_rect_count", C.c_int32),
     ]
 
 
@@ -346,6 +384,10 @@ class CGlyph(C.Structure):
                 ("subpixel_shift", C.c_float)]
 
 
+class CTextRect(C.Structure):
+    _fields_ = [("x", C.c_float), ("y", C.c_float), ("w", C.c_float), ("h", C.c_float), ("fill", CFill), ("kind", C.c_int32)]
+
+
 class CLayer(C.Structure):
     _fields_ = [("zlevel", C.c_int32), ("n_nodes", C.c_int32), ("n_roots", C.c_int32), ("_pad", C.c_int32),
                 ("nodes", C.POINTER(CFig)), ("root_ids", C.POINTER(C.c_int32))]
@@ -354,7 +396,8 @@ class CLayer(C.Structure):
 class CSceneStruct(C.Structure):
     _fields_ = [("layers", C.POINTER(CLayer)), ("glyphs", C.POINTER(CGlyph)), ("n_layers", C.c_int32),
                 ("n_glyphs", C.c_int32), ("ops", C.POINTER(CDrawOp)), ("controls", C.POINTER(C.c_float)),
-                ("n_ops", C.c_int32), ("n_controls", C.c_int32)]
+                ("n_ops", C.c_int32), ("n_controls", C.c_int32), ("text_rects", C.POINTER(CTextRect)),
+                ("n_text_rects", C.c_int32), ("_pad", C.c_int32), ("glyph_variant_ids", C.POINTER(C.c_int64))]
 
 
 def _ccolor(c: RGBA) -> CColor:
@@ -380,6 +423,7 @@ class CScene:
 
     def __init__(self, renders: Renders):
         glyphs: List[Glyph] = []
+        trects: List[TextRect] = []
         ops: List[DrawableOp] = []
         self._keep = []
         layers = (CLayer * max(1, len(renders.layers)))()
@@ -418,6 +462,9 @@ class CScene:
                 cn.glyph_first = len(glyphs)
                 cn.glyph_count = len(n.glyphs)
                 glyphs.extend(n.glyphs)
+                cn.text_rect_first = len(trects)
+                cn.text_rect_count = len(n.textRects)
+                trects.extend(n.textRects)
                 cn.draw_stroke.weight = float(n.drawStroke.weight)
                 cn.draw_stroke.fill = cfill(n.drawStroke.fill)
                 cn.draw_stroke.cap = int(n.drawStroke.cap)
@@ -442,6 +489,18 @@ class CScene:
             for k in range(4):
                 cg[i].colors[k] = _ccolor(g.colors[k])
             cg[i].subpixel_shift = float(g.subpixel_shift)
+        ctr = (CTextRect * max(1, len(trects)))()
+        for i, t in enumerate(trects):
+            ctr[i].x, ctr[i].y, ctr[i].w, ctr[i].h = float(t.x), float(t.y), float(t.w), float(t.h)
+            ctr[i].fill = cfill(t.fill)
+            ctr[i].kind = int(t.kind)
+        cvar = None
+        if any(g.variant_ids is not None for g in glyphs):
+            cvar = (C.c_int64 * (GLYPH_VARIANT_STEPS * max(1, len(glyphs))))()
+            for i, g in enumerate(glyphs):
+                ids = list(g.variant_ids) if g.variant_ids is not None else [g.image_id] * GLYPH_VARIANT_STEPS
+                for k in range(GLYPH_VARIANT_STEPS):
+                    cvar[i * GLYPH_VARIANT_STEPS + k] = int(ids[k])
         cops = (CDrawOp * max(1, len(ops)))()
         ctrl: List[float] = []
         for i, op in enumerate(ops):
@@ -455,7 +514,7 @@ class CScene:
             for (x, y) in op.controls:
                 ctrl += [float(x), float(y)]
         cctrl = (C.c_float * max(1, len(ctrl)))(*ctrl)
-        self._keep += [layers, cg, cops, cctrl]
+        self._keep += [layers, cg, cops, cctrl, ctr, cvar]
         self.struct = CSceneStruct()
         self.struct.layers = C.cast(layers, C.POINTER(CLayer))
         self.struct.glyphs = C.cast(cg, C.POINTER(CGlyph))
@@ -465,6 +524,9 @@ class CScene:
         self.struct.controls = C.cast(cctrl, C.POINTER(C.c_float))
         self.struct.n_ops = len(ops)
         self.struct.n_controls = len(ctrl) // 2
+        self.struct.text_rects = C.cast(ctr, C.POINTER(CTextRect))
+        self.struct.n_text_rects = len(trects)
+        self.struct.glyph_variant_ids = C.cast(cvar, C.POINTER(C.c_int64)) if cvar is not None else None
 
     def byref(self):
         return C.byref(self.struct)

@@ -110,6 +110,7 @@ typedef struct {
   uint16_t _pad0;
   float draw_aa;                    /*             drawAa: SDF AA factor override, <= 0 = keep the backend's */
   int32_t op_first, op_count;       /*             drawOps: range into FdhScene.ops */
+  int32_t text_rect_first, text_rect_count; /* nkText: selection / decoration rectangles, range into FdhScene.text_rects */
 } FdhFig;
 
 /* DrawableOp (fignodes.nim:13-42).  `v` holds, by kind: line a.xy b.xy | circle center.xy radius | rectangle
@@ -133,8 +134,18 @@ typedef struct {
   int64_t image_id;
   float x, y;         /* local top-left, UI-scaled (glyphLocalPos + imageOffset) */
   FdhColor colors[4]; /* BL,BR,TR,TL */
-  float subpixel_shift;
+  float subpixel_shift; /* >= 0: the shift to use (setTextSubpixelShift).  < 0: derive it from x the way renderText does when
+                         * sub-pixel positioning is on: x snaps to floor(x), the fraction becomes the shift -- or, with glyph
+                         * variants enabled, selects FdhScene.glyph_variant_ids[glyph][step] (figrender.nim:464-476) */
 } FdhGlyph;
+
+/* The rectangles renderText draws before the glyphs (figrender.nim:435-452, 355-415), in the text node's local
+ * UI units; typesetting (selectionRectsFor, glyphRect) is the caller's.  kind 0 = selection rectangle: drawn with the
+ * NODE's fill, only when NfSelectText is set and that fill is not fully transparent, width forced to >= 1, skipped when
+ * h <= 0.  kind 1 = underline / strikethrough: drawn with `fill`, skipped when w <= 0 or h <= 0. */
+enum { FDH_TEXT_RECT_SELECTION = 0, FDH_TEXT_RECT_DECORATION = 1 };
+typedef struct { float x, y, w, h; FdhFill fill; int32_t kind; } FdhTextRect;
+#define FDH_GLYPH_VARIANT_STEPS 10 /* glyphVariantSubpixelSteps, common/fontglyphs.nim:43 */
 
 typedef struct { int32_t zlevel; int32_t n_nodes; int32_t n_roots; int32_t _pad; const FdhFig* nodes; const int32_t* root_ids; } FdhLayer;
 typedef struct {
@@ -146,6 +157,10 @@ typedef struct {
   const float* controls; /* x,y pairs of all bezier ops */
   int32_t n_ops;
   int32_t n_controls;    /* number of POINTS */
+  const FdhTextRect* text_rects;
+  int32_t n_text_rects;
+  int32_t _pad;
+  const int64_t* glyph_variant_ids; /* optional: [n_glyphs][FDH_GLYPH_VARIANT_STEPS] atlas keys of the sub-pixel variants */
 } FdhScene;
 
 /* ------------------------------------------------------------------ lifetime */
@@ -202,6 +217,7 @@ FDH_API int fdh_draw_rect(FdhContext*, const float rect[4], FdhColor color);
 /* text flags: figbackend.nim:663-686 */
 FDH_API int fdh_set_text_subpixel_positioning(FdhContext*, int enabled);
 FDH_API int fdh_set_text_subpixel_shift(FdhContext*, float shift);
+FDH_API int fdh_set_text_subpixel_glyph_variants(FdhContext*, int enabled); /* textSubpixelGlyphVariantsEnabled (figbackend.nim) */
 
 /* ------------------------------------------------------------------ atlas (hasImage/putImage/updateImage/removeImage/... figbackend.nim:281-294,400-432) */
 /* putImage: skyline packer with margin 4 (glcontext.nim:541-586); out_rect = packed pixel rect x,y,w,h.
@@ -263,6 +279,7 @@ FDH_API int fdh_get_frame_stats(FdhContext*, FdhFrameStats* out);
 FDH_API int fdh_sizeof_fig(void);
 FDH_API int fdh_sizeof_glyph(void);
 FDH_API int fdh_sizeof_draw_op(void);
+FDH_API int fdh_sizeof_text_rect(void);
 FDH_API const char* fdh_version(void);
 
 #ifdef __cplusplus

@@ -233,6 +233,7 @@ struct FoCtx {
   int n_mats;
   float aa, pixel_scale, ui_scale;
   int subpixel_enabled;
+  int subpixel_variants;
   float subpixel_shift;
   /* atlas */
   int atlas_size, atlas_margin, n_mips;
@@ -249,6 +250,7 @@ void fo_set_ui_scale(FoCtx* c, float s) { c->ui_scale = s; }
 int fo_sizeof_fig(void) { return (int)sizeof(FoFig); }
 int fo_sizeof_glyph(void) { return (int)sizeof(FoGlyph); }
 int fo_sizeof_draw_op(void) { return (int)sizeof(FoDrawOp); }
+int fo_sizeof_text_rect(void) { return (int)sizeof(FoTextRect); }
 
 /* ------------------------------------------------------------------ recorder */
 static void rec_printf(FoCtx* c, const char* fmt, ...) {
@@ -362,6 +364,7 @@ void fo_apply_transform(FoCtx* c, const float m[16]) {
 }
 void fo_set_aa_factor(FoCtx* c, float aa) { rec_open(c, "set_aa_factor"); rec_f(c, aa); rec_close(c); c->aa = aa; }
 void fo_set_text_subpixel(FoCtx* c, int enabled, float shift) { c->subpixel_enabled = enabled; c->subpixel_shift = shift; }
+void fo_set_text_subpixel_glyph_variants(FoCtx* c, int enabled) { c->subpixel_variants = enabled; }
 
 /* beginFrame: glcontext.nim:2080-2092, 1951-1980 */
 void fo_begin_frame(FoCtx* c, int w, int h, int clear, const float rgba[4]) {
@@ -1612,18 +1615,54 @@ static void render_drawable(FoCtx* c, const FoScene* sc, const FoFig* n) { /* re
 
 static void render_node(FoCtx* c, const FoScene* sc, const FoLayer* L, int idx);
 
-static void render_text(FoCtx* c, const FoScene* sc, const FoFig* n) { /* renderText figrender.nim:417-497 (glyph loop) */
+static void draw_text_rect(FoCtx* c, float x, float y, float w, float h, const FoFill* fill) { /* figrender.nim:355-369, 444-452 */
+  const float rect[4] = {scaled(c, x), scaled(c, y), scaled(c, w), scaled(c, h)};
+  const float zero[4] = {0, 0, 0, 0}, shape[2] = {0, 0};
+  fo_draw_rounded_rect_fill(c, rect, fill, zero, zero, 3 /* sdfModeClipAA */, 4.0f, 0.0f, shape);
+}
+static void render_text(FoCtx* c, const FoScene* sc, const FoFig* n) { /* renderText figrender.nim:417-497 */
   fo_save_transform(c);
   fo_translate(c, scaled(c, n->box[0]), scaled(c, n->box[1]));
   if (n->flags & FO_NF_INVERT_Y) {
     fo_translate(c, 0.0f, scaled(c, n->box[3]));
     fo_scale(c, 1.0f, -1.0f);
   }
+  /* selection rectangles first (:435-452), then underline / strikethrough (:371-415), then the glyphs */
+  for (int pass = 0; pass < 2; pass++) {
+    for (int k = n->text_rect_first; k < n->text_rect_first + n->text_rect_count && k < sc->n_text_rects; k++) {
+      const FoTextRect* tr = &sc->text_rects[k];
+      if (tr->kind != pass) continue;
+      if (pass == 0) {
+        if (!(n->flags & FO_NF_SELECT_TEXT) || fill_alpha_max(&n->fill) == 0 || !(tr->h > 0.0f)) continue;
+        draw_text_rect(c, tr->x, tr->y, maxf(tr->w, 1.0f), tr->h, &n->fill);
+      } else {
+        if (tr->w <= 0.0f || tr->h <= 0.0f) continue;
+        draw_text_rect(c, tr->x, tr->y, tr->w, tr->h, &tr->fill);
+      }
+    }
+  }
   for (int g = n->glyph_first; g < n->glyph_first + n->glyph_count && g < sc->n_glyphs; g++) {
     const FoGlyph* gl = &sc->glyphs[g];
     float pos[2] = {gl->x, gl->y}, size[2] = {0, 0};
-    c->subpixel_shift = gl->subpixel_shift;
-    fo_draw_image(c, gl->image_id, pos, gl->colors, size, 0);
+    int64_t key = gl->image_id;
+    float shift = gl->subpixel_shift;
+    if (shift < 0.0f) { /* figrender.nim:464-471 */
+      shift = 0.0f;
+      if (c->subpixel_enabled) {
+        const float snapped = floorf(pos[0]);
+        const float frac = maxf(0.0f, minf(pos[0] - snapped, 0.999f));
+        pos[0] = snapped;
+        if (c->subpixel_variants && sc->glyph_variant_ids) { /* toGlyphVariantSubpixelStep common/fontglyphs.nim:50-52 */
+          int step = (int)(frac * (float)FO_GLYPH_VARIANT_STEPS);
+          if (step > FO_GLYPH_VARIANT_STEPS - 1) step = FO_GLYPH_VARIANT_STEPS - 1;
+          key = sc->glyph_variant_ids[(size_t)g * FO_GLYPH_VARIANT_STEPS + step];
+        } else {
+          shift = frac;
+        }
+      }
+    }
+    c->subpixel_shift = shift;
+    fo_draw_image(c, key, pos, gl->colors, size, 0);
   }
   c->subpixel_shift = 0.0f;
   fo_restore_transform(c);

@@ -81,6 +81,7 @@ typedef struct {
   uint16_t _pad0;
   float draw_aa;
   int32_t op_first, op_count;       /* range into FoScene.ops */
+  int32_t text_rect_first, text_rect_count; /* nkText: range into FoScene.text_rects */
 } FoFig;
 
 /* DrawableOp (fignodes.nim:13-42); v by kind: line a.xy b.xy | circle c.xy r | rectangle x,y,w,h | arc c.xy r start sweep | ellipse c.xy radii.xy */
@@ -106,6 +107,10 @@ typedef struct {
   float subpixel_shift;
 } FoGlyph;
 
+/* selection (kind 0, node fill) and decoration (kind 1, own fill) rectangles of renderText, figrender.nim:355-452 */
+typedef struct { float x, y, w, h; FoFill fill; int32_t kind; } FoTextRect;
+#define FO_GLYPH_VARIANT_STEPS 10 /* common/fontglyphs.nim:43 */
+
 typedef struct { int32_t zlevel; int32_t n_nodes; int32_t n_roots; int32_t _pad; const FoFig* nodes; const int32_t* root_ids; } FoLayer;
 typedef struct {
   const FoLayer* layers;
@@ -116,6 +121,10 @@ typedef struct {
   const float* controls;
   int32_t n_ops;
   int32_t n_controls;
+  const FoTextRect* text_rects;
+  int32_t n_text_rects;
+  int32_t _pad;
+  const int64_t* glyph_variant_ids; /* optional [n_glyphs][FO_GLYPH_VARIANT_STEPS] */
 } FoScene;
 
 /* ---- the CPU backend (restates glcontext.nim) */
@@ -157,6 +166,7 @@ void fo_pop_rect_mask(FoCtx*);
 int fo_put_image(FoCtx*, int64_t key, int w, int h, const uint8_t* rgba, int out_rect[4]);
 int fo_put_flippy(FoCtx*, int64_t key, const uint8_t* file_bytes, size_t n, int out_rect[4]); /* putFlippy glcontext.nim:610-620 */
 void fo_set_text_subpixel(FoCtx*, int enabled, float shift);
+void fo_set_text_subpixel_glyph_variants(FoCtx*, int enabled);
 /* readPixels: top-down RGBA8, (x,y,w,h) in top-down pixel coordinates; w<=0 -> whole frame */
 int fo_read_pixels(FoCtx*, int x, int y, int w, int h, uint8_t* out);
 int fo_read_mask(FoCtx*, int level, uint8_t* out_r8);
@@ -177,6 +187,7 @@ void fo_blur_image(int w, int h, const uint8_t* src, uint8_t* dst, float radius)
 int fo_sizeof_fig(void);
 int fo_sizeof_glyph(void);
 int fo_sizeof_draw_op(void);
+int fo_sizeof_text_rect(void);
 
 #ifdef __cplusplus
 }

@@ -70,6 +70,7 @@ def lib():
         L.fo_put_flippy.restype = C.c_int
         L.fo_put_flippy.argtypes = [C.c_void_p, C.c_int64, C.c_char_p, C.c_size_t, C.c_int * 4]
         L.fo_set_text_subpixel.argtypes = [C.c_void_p, C.c_int, C.c_float]
+        L.fo_set_text_subpixel_glyph_variants.argtypes = [C.c_void_p, C.c_int]
         L.fo_read_pixels.restype = C.c_int
         L.fo_read_pixels.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.fo_read_mask.restype = C.c_int
@@ -87,6 +88,8 @@ def lib():
         assert L.fo_sizeof_glyph() == C.sizeof(S.CGlyph)
         L.fo_sizeof_draw_op.restype = C.c_int
         assert L.fo_sizeof_draw_op() == C.sizeof(S.CDrawOp)
+        L.fo_sizeof_text_rect.restype = C.c_int
+        assert L.fo_sizeof_text_rect() == C.sizeof(S.CTextRect)
         _lib = L
     return _lib
 
@@ -191,6 +194,10 @@ class Oracle:
         if rc != 0:
             raise RuntimeError("oracle atlas full")
         return tuple(out)
+
+    def set_text_subpixel(self, enabled: bool, shift: float = 0.0, glyph_variants: bool = False):
+        self.L.fo_set_text_subpixel(self.h, int(bool(enabled)), float(shift))
+        self.L.fo_set_text_subpixel_glyph_variants(self.h, int(bool(glyph_variants)))
 
     def put_flippy(self, key, file_bytes: bytes):
         out = (C.c_int * 4)()

@@ -378,6 +378,34 @@ ATLAS_SCENES = {
 }
 
 
+def text_frontend(w=300.0, h=120.0, images=None) -> Renders:
+    """renderText beyond the glyph loop (figrender.nim:417-497): selection rectangles (NfSelectText, node fill, width
+    forced to >= 1, h <= 0 skipped), underline / strikethrough runs, glyph x positions the RENDERER snaps (sub-pixel
+    shift, or one of the ten glyph variants when those are enabled -- here the variants are other letters so the
+    choice is visible), under NfInvertY as well."""
+    from figdraw_amd.scene import GLYPH_VARIANT_STEPS, Glyph, TextRect, text_decoration_rects
+
+    lst = RenderList()
+    lst.addRoot(Fig(kind=RECT, screenBox=rect(0, 0, w, h), fill=rgba(250, 250, 245, 255)))
+    word = "figdraw"
+    black = [rgba(20, 20, 20, 255)] * 4
+    variants = [1000 + ord(c) for c in "abcdefghij"]
+    for row, (flags, y0) in enumerate(((FigFlags.NfSelectText, 8.0), (FigFlags.NfSelectText | FigFlags.NfInvertY, 62.0))):
+        glyphs, x = [], 6.3
+        for ch in word:
+            gh = images[1000 + ord(ch)].shape[0]
+            glyphs.append(Glyph(image_id=1000 + ord(ch), x=x, y=24.0 - gh, colors=black, subpixel_shift=-1.0,
+                                variant_ids=variants if row == 1 else None))
+            x += 13.37
+        rects = [TextRect(20.25, 2.0, 55.5, 26.0), TextRect(90.0, 2.0, 0.2, 26.0), TextRect(120.0, 2.0, 30.0, 0.0)]
+        rects += text_decoration_rects(6.0, x, 4.0, 26.0, 20.0, underline=True, strikethrough=(row == 1), color=fill(rgba(200, 30, 30, 255)))
+        lst.addRoot(Fig(kind=FigKind.nkText, screenBox=rect(10.5, y0, 200, 40), flags=flags, fill=rgba(90, 140, 255, 120), glyphs=glyphs,
+                        textRects=rects))
+    out = Renders()
+    out.layers[0] = lst
+    return out
+
+
 def random_scene(seed: int, w: float, h: float, n: int = 40, clips: bool = True, blur: bool = True) -> Renders:
     """Seeded random mix of everything the SDF path has: opaque and translucent fills (solid, 2- and 3-stop on all
     axes), circular and elliptical corners, strokes, drop and inner shadows, nested NfClipContent / NfRectMaskContent

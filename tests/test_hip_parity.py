@@ -223,6 +223,30 @@ def test_flippy_image_matches_oracle_and_reference_png():
     ctx.close()
 
 
+@pytest.mark.parametrize("subpixel,variants", [(False, False), (True, False), (True, True)])
+def test_text_frontend_matches_oracle(subpixel, variants):
+    """Selection rectangles, underline / strikethrough and renderer-side glyph snapping (shift or glyph variants)."""
+    import os
+
+    from conftest import GOLDEN
+    from figdraw_amd.scenes import load_glyph_fixture
+
+    w, h = 300, 120
+    all_images = load_glyph_fixture(os.path.join(GOLDEN, "glyphs_ubuntu20.npz"))
+    sc = RS.text_frontend(float(w), float(h), all_images)
+    used = {k: all_images[k] for k in sorted({1000 + ord(c) for c in "figdrawabcdefghij"})}
+    ctx, o = _atlas_ctx_pair(sc, used, 256)
+    ctx.set_text_subpixel(subpixel, 0.0, glyph_variants=variants)
+    o.set_text_subpixel(subpixel, 0.0, glyph_variants=variants)
+    ctx.render_frame(sc, w, h)
+    o.render_frame(sc, w, h)
+    got, want = ctx.read_pixels(), o.read_pixels()
+    mx, n0, n1 = diff_stats(got, want)
+    assert mx <= 1 and n0 <= 0.005 * w * h, (subpixel, variants, mx, n0, n1)
+    assert (got[..., :3] != got[0, 0, :3]).any()
+    ctx.close()
+
+
 def test_t10k_glyph_config_4k_matches_oracle():
     """BASELINE config 4: 10 000 glyph quads (5 000 coverage glyphs 1:1 + 5 000 magnified MSDF) at 3840x2160."""
     import os

@@ -229,6 +229,45 @@ def test_oracle_flippy_image_matches_reference_png():
             O.Oracle(atlas_size=256).put_flippy(1, bad)
 
 
+def test_text_frontend_known_answers():
+    """renderText's selection / decoration rectangles and renderer-side glyph snapping (figrender.nim:417-497)."""
+    from figdraw_amd.scene import Glyph, TextRect, text_decoration_rects
+
+    img = np.zeros((10, 8, 4), np.uint8)
+    sel = [TextRect(5.0, 2.0, 0.25, 10.0), TextRect(9.0, 2.0, 4.0, 0.0), TextRect(20.0, 3.0, 6.0, 11.0)]
+    dec = text_decoration_rects(1.0, 41.0, 2.0, 22.0, 40.0, underline=True, strikethrough=True, color=fill(rgba(9, 8, 7, 255)))
+    assert [(d.x, d.y, d.w, d.h) for d in dec] == [(1.0, 22.0 - 3.0 * 1.5, 40.0, 3.0), (1.0, 2.0 + 10.0 - 1.5, 40.0, 3.0)]  # thickness round(40/16)=3
+    glyphs = [Glyph(image_id=7, x=10.3, y=1.0, subpixel_shift=-1.0, variant_ids=[100 + k for k in range(10)]),
+              Glyph(image_id=7, x=20.75, y=1.0, subpixel_shift=0.5)]
+
+    def calls(flags, node_fill, subpixel, variants, ui_scale=1.0):
+        r = Renders()
+        r.addRoot(0, Fig(kind=FigKind.nkText, screenBox=rect(100, 50, 80, 30), flags=flags, fill=node_fill, glyphs=glyphs, textRects=sel + dec))
+        o = O.Oracle(atlas_size=256)
+        for k in [7] + [100 + k for k in range(10)]:
+            o.put_image(k, img)
+        o.set_text_subpixel(subpixel, 0.0, glyph_variants=variants)
+        o.record_begin()
+        o.render_frame(r, 256, 128, ui_scale=ui_scale)
+        return [c for c in o.record_calls() if c[0].startswith("draw_")]
+
+    c = calls(FigFlags.NfSelectText, fill(rgba(1, 2, 3, 200)), True, False, ui_scale=2.0)
+    rects = [x for x in c if x[0] == "draw_rounded_rect_sdf"]
+    # two live selection rectangles (the h = 0 one is skipped, the narrow one is widened to 1), then the two decorations
+    assert [tuple(x[1]) for x in rects] == [(10.0, 4.0, 2.0, 20.0), (40.0, 6.0, 12.0, 22.0), (2.0, 35.0, 80.0, 6.0), (2.0, 21.0, 80.0, 6.0)]
+    assert all(x[5] == 3 and x[6] == 4.0 for x in rects)  # sdfModeClipAA, factor 4
+    assert rects[0][2][0] == [1, 2, 3, 200] and rects[2][2][0] == [9, 8, 7, 255]
+    imgs = [x for x in c if x[0] == "draw_image"]
+    assert [x[1] for x in imgs] == [7, 7] and imgs[0][2] == [10.0, 1.0] and imgs[1][2] == [20.75, 1.0]  # snapped | explicit shift keeps x
+    # glyph variants: step = int(0.3 * 10) = 3 replaces the atlas key; no selection without NfSelectText or with a transparent fill
+    c = calls(FigFlags(0), fill(rgba(1, 2, 3, 200)), True, True)
+    assert [x[1] for x in c if x[0] == "draw_image"] == [103, 7]
+    assert len([x for x in c if x[0] == "draw_rounded_rect_sdf"]) == 2
+    c = calls(FigFlags.NfSelectText, fill(rgba(1, 2, 3, 0)), False, False)
+    assert len([x for x in c if x[0] == "draw_rounded_rect_sdf"]) == 2
+    assert [x[2] for x in c if x[0] == "draw_image"][0] == [pytest.approx(10.3), 1.0]  # positioning off: x untouched
+
+
 def test_atlas_packer_known_answers():
     """findEmptyRect (glcontext.nim:541-579): skyline with margin 4; entries are packed pixel rects."""
     o = O.Oracle(atlas_size=256)
