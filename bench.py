@@ -20,6 +20,8 @@ import os
 import sys
 import time
 
+import numpy as np
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -107,6 +109,10 @@ def main():
     st_batch = ctx.frame_stats()
     ms_step = 1e3 * elapsed / args.steps
 
+    # per-frame distribution (SURVEY.md 8d timing protocol): one event between consecutive frames
+    ft = ctx.replay_timed(min(args.steps, 120))
+    frame_dist = {"n": int(len(ft)), "min": round(float(ft.min()), 4), "p50": round(float(np.percentile(ft, 50)), 4),
+                  "p95": round(float(np.percentile(ft, 95)), 4), "max": round(float(ft.max()), 4)}
     # per-kernel durations, HIP events on the context's stream around every launch (same frames, same records)
     ctx.profile(min(args.steps, 50))
     st = ctx.frame_stats()
@@ -210,7 +216,6 @@ def main():
                                   f"oracle/figdraw_oracle.c, OpenMP over rows, {dt:.1f} s"}
         if n_frames > 1:  # parity check below compares frame 0
             orc.render_frame(scene, w, h)
-        import numpy as np
 
         got = ctx.read_pixels()
         d = np.abs(got.astype(int) - orc.read_pixels().astype(int))
@@ -239,7 +244,9 @@ def main():
         "frame": {"algorithmic_bytes": int(st.bytes_algorithmic), "achieved_GBs": round(frame_gbs, 1),
                   "frac_of_hbm_peak": round(frame_gbs / HBM_PEAK_GBS, 5),
                   "gfragments_per_s": round(world * st.fragments * args.steps / elapsed / 1e9, 2),
-                  "ms_event_timed": round(st_batch.ms_total, 4),
+                  "ms_event_timed": round(st_batch.ms_total, 4), "ms_per_frame_dist": frame_dist,
+                  "gl_equivalent_bytes": int(8 * st.fragments),  # 8 B x fragments: what a GL rasteriser's blend RMW moves; context only
+
                   "kernel_ms": {"bin": round(st.ms_bin, 4), "composite_all": round(st.ms_composite, 4),
                                 "composite_main": round(st.ms_composite_main, 4), "blur_h": round(st.ms_blur_h, 4),
                                 "blur_v": round(st.ms_blur_v, 4)},

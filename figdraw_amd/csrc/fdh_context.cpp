@@ -1056,6 +1056,24 @@ void Context::replay(int times) {
   stats_.ms_total = ms / (float)times;
 }
 
+// `times` frames back to back with one event between consecutive frames: ms_out[i] = duration of frame i on the stream
+void Context::replay_timed(int times, float* ms_out) {
+  if (!have_frame_) throw Error(FDH_ERR_INVALID, "replay: no frame has been submitted");
+  if (times <= 0 || !ms_out) return;
+  FDH_HIP(hipSetDevice(device_));
+  ev_used_ = 0;
+  std::vector<hipEvent_t> marks;
+  marks.push_back(next_event());
+  FDH_HIP(hipEventRecord(marks.back(), stream_));
+  for (int i = 0; i < times; i++) {
+    launch_frame(false);
+    marks.push_back(next_event());
+    FDH_HIP(hipEventRecord(marks.back(), stream_));
+  }
+  FDH_HIP(hipEventSynchronize(marks.back()));
+  for (int i = 0; i < times; i++) FDH_HIP(hipEventElapsedTime(&ms_out[i], marks[i], marks[i + 1]));
+}
+
 hipEvent_t Context::next_event() {
   if (ev_used_ == ev_pool_.size()) {
     hipEvent_t e;
