@@ -108,6 +108,7 @@ def load():
     L.fdh_render_frame.argtypes = [vp, vp, C.c_float, C.c_float, C.c_int, _F4]
     L.fdh_set_stripe.argtypes = [vp, C.c_int, C.c_int]
     L.fdh_replay.argtypes = [vp, C.c_int]
+    L.fdh_replay_async.argtypes = [vp, C.c_int]
     L.fdh_replay_timed.argtypes = [vp, C.c_int, C.POINTER(C.c_float)]
     L.fdh_profile.argtypes = [vp, C.c_int]
     L.fdh_get_frame_stats.argtypes = [vp, C.POINTER(FrameStats)]
@@ -326,6 +327,9 @@ class HipContext:
 
     def replay(self, times: int = 1):
         self._ck(self.L.fdh_replay(self.h, int(times)))
+
+    def replay_async(self, times: int = 1):
+        self._ck(self.L.fdh_replay_async(self.h, int(times)))
 
     def replay_timed(self, times: int):
         """Per-frame stream times (ms) of `times` back-to-back frames."""

@@ -164,6 +164,7 @@ int fdh_render_frame(FdhContext* c, const FdhScene* scene, float fw, float fh, i
 }
 int fdh_set_stripe(FdhContext* c, int y0, int y1) { return guard([&] { C(c)->set_stripe(y0, y1); }); }
 int fdh_replay(FdhContext* c, int times) { return guard([&] { C(c)->replay(times); }); }
+int fdh_replay_async(FdhContext* c, int times) { return guard([&] { C(c)->replay_async(times); }); }
 int fdh_replay_timed(FdhContext* c, int times, float* ms_out) { return guard([&] { C(c)->replay_timed(times, ms_out); }); }
 int fdh_profile(FdhContext* c, int times) { return guard([&] { C(c)->profile(times); }); }
 int fdh_get_frame_stats(FdhContext* c, FdhFrameStats* out) { return guard([&] { C(c)->frame_stats(out); }); }

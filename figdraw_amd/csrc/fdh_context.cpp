@@ -1056,6 +1056,13 @@ void Context::replay(int times) {
   stats_.ms_total = ms / (float)times;
 }
 
+// enqueue only: several contexts (own streams, own surfaces) can then have frames in flight on one GPU at once
+void Context::replay_async(int times) {
+  if (!have_frame_) throw Error(FDH_ERR_INVALID, "replay: no frame has been submitted");
+  FDH_HIP(hipSetDevice(device_));
+  for (int i = 0; i < times; i++) launch_frame(false);
+}
+
 // `times` frames back to back with one event between consecutive frames: ms_out[i] = duration of frame i on the stream
 void Context::replay_timed(int times, float* ms_out) {
   if (!have_frame_) throw Error(FDH_ERR_INVALID, "replay: no frame has been submitted");

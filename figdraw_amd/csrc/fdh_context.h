@@ -153,6 +153,7 @@ class Context {
   void set_stripe(int y0, int y1) { stripe_y0_ = y0; stripe_y1_ = y1; }
   void replay(int times);
   void replay_timed(int times, float* ms_out);
+  void replay_async(int times);
   void profile(int times);
   void frame_stats(FdhFrameStats* out) const { *out = stats_; }
 

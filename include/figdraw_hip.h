@@ -256,6 +256,8 @@ FDH_API int fdh_set_stripe(FdhContext*, int y0, int y1);
 /* Re-run the GPU work of the last submitted frame `times` times from the draw records already resident in HBM
  * (the host-side decomposition and the upload are not repeated). */
 FDH_API int fdh_replay(FdhContext*, int times);
+/* enqueue `times` frames and return without waiting (fdh_sync waits): lets several contexts overlap on one GPU */
+FDH_API int fdh_replay_async(FdhContext*, int times);
 /* the same with a hipEvent between consecutive frames: ms_out[i] = stream time of frame i (min / p50 / p95 reporting) */
 FDH_API int fdh_replay_timed(FdhContext*, int times, float* ms_out);
 typedef struct {
