@@ -1416,8 +1416,14 @@ __global__ __launch_bounds__(256) void k_blur_v(BlurParams P, const DrawRec* __r
       const float dist = shape_dist((r.op_mode & F_ELLIP) != 0u, lx, -ly, r.p2, r.p3, r.r[0], r.r[1], r.r[2], r.r[3]);
       alpha = 1.0f - clamp01(r.aa * dist + 0.5f);
     }
+    if (__all(b.w == 255.0f && alpha == 1.0f)) {  // opaque backdrop under full coverage: the blend is a replacement
+      P.dst[pix] = pack255(b);                    // (bit-identical: 1 - sa is 0 to 1e-7 and every term an integer <= 255)
+      continue;
+    }
     F4 F = unpack255(P.dst[pix]);
-    blend(F, b.x * k, b.y * k, b.z * k, b.w * k * alpha);
+    const float sa = b.w * k * alpha, A = 255.0f * sa;
+    const f2 brg = {b.x, b.y};
+    blend_pre(F, brg * k * A, f2{b.z * k * A, A}, 1.0f - sa);  // = blend(F, b.rgb / 255, sa), two packed FMAs
     P.dst[pix] = pack255(F);
   }
 }
