@@ -763,10 +763,6 @@ __global__ __launch_bounds__(FDH_WAVE_WG ? 64 : 256, (kPaths & 1) ? 4 : FDH_FAST
 #if FDH_TIMING
     T_cull += FDH_NOW() - Tc0 + (m & 0ull);
 #endif
-#ifdef FDH_EXPERIMENT_CULL_ONLY
-    touched = touched || m != 0;
-    continue;
-#endif
     if (m == 0) continue;
     // One draw = one lambda call.  The record of the NEXT surviving draw is fetched (scalar loads) before the
     // current one is shaded, so the ~L2-latency of the fetch overlaps the shading arithmetic.
@@ -776,9 +772,6 @@ __global__ __launch_bounds__(FDH_WAVE_WG ? 64 : 256, (kPaths & 1) ? 4 : FDH_FAST
       const uint32_t mode = om & 255u;
       touched = true;
       FDH_COUNT(0);
-#ifdef FDH_X5
-      if (om != 0x12345u) return;
-#endif
       if (op == OP_MASK_POP) {
         mask_depth--;
         if (mask_depth > 0) {
@@ -900,8 +893,8 @@ __global__ __launch_bounds__(FDH_WAVE_WG ? 64 : 256, (kPaths & 1) ? 4 : FDH_FAST
       const uint32_t fill_mode = (om >> 9) & 7u;
       // `core`: the strip lies in the draw's saturated core (DrawRec::ix0..iy1, decided per strip by k_bin_draws): the
       // whole strip has coverage alpha 1 (annular strokes, alpha 0 there, never get this far).
-#ifdef FDH_X9
-      if (core || !core) { F0.x += core ? 1e-30f : 0.0f; return; }
+#ifdef FDH_ABLATE_SHADING  // ablation build (make variant): records are fetched, nothing is shaded
+      { F0.x += core ? 1e-30f : 0.0f; return; }
 #endif
       if (core) {
         if (mode == 11u || mode == 12u) { FDH_COUNT(32); return; }
@@ -909,9 +902,6 @@ __global__ __launch_bounds__(FDH_WAVE_WG ? 64 : 256, (kPaths & 1) ? 4 : FDH_FAST
           FDH_COUNT(33);
           const F4 c0 = unpack255(r.col[0]);
           const float sa = c0.w * inv255;
-#ifdef FDH_X10
-          if (mask_depth == 0 && !rmask_on) { F0.x += sa * 1e-30f; return; }
-#endif
           if (mask_depth == 0 && !rmask_on) {  // one source term for the whole strip
             const float A = 255.0f * sa, ia = 1.0f - sa;
             const f2 c_rg = {c0.x * inv255 * A, c0.y * inv255 * A}, c_ba = {c0.z * inv255 * A, A};
@@ -925,7 +915,7 @@ __global__ __launch_bounds__(FDH_WAVE_WG ? 64 : 256, (kPaths & 1) ? 4 : FDH_FAST
         }
         FDH_COUNT(34);
       }
-#ifdef FDH_X3
+#ifdef FDH_ABLATE_EDGE  // ablation build (make variant): edge strips are skipped, core strips shaded
       if (!core) return;
 #endif
 #if FDH_SIMPLE_EDGE
@@ -1099,12 +1089,6 @@ __global__ __launch_bounds__(FDH_WAVE_WG ? 64 : 256, (kPaths & 1) ? 4 : FDH_FAST
 
       // ---- OP_DRAW: atlas.frag main():252-405
       float alpha[4];
-#ifdef FDH_X1
-      if (cls != 1) {
-#pragma unroll
-        for (int k = 0; k < 4; k++) alpha[k] = 1.0f - clamp01(r.aa * dist[k] + 0.5f);
-      } else
-#endif
       if (cls == 1) {  // wave-uniform: saturated coverage
 #pragma unroll
         for (int k = 0; k < 4; k++) alpha[k] = 1.0f;
@@ -1158,10 +1142,6 @@ __global__ __launch_bounds__(FDH_WAVE_WG ? 64 : 256, (kPaths & 1) ? 4 : FDH_FAST
           break;
         }
       }
-#ifdef FDH_X2
-      F0.x += alpha[0] * 1e-30f; F1.x += alpha[1] * 1e-30f; F2.x += alpha[2] * 1e-30f; F3.x += alpha[3] * 1e-30f;
-      return;
-#endif
       float sr[4], sg[4], sb[4], sa[4];
       if (mode == 17u) {  // atlas.frag:381-388: the blurred backdrop at this fragment's own pixel
         F4 b[4] = {F0, F1, F2, F3};
