@@ -918,12 +918,15 @@ void Context::submit(bool upload) {
     pf[phases_.size()] = (int)n;
     auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
     const size_t b_recs = n * sizeof(DrawRec), b_ext = exts_.size() * sizeof(QuadExt), b_bb = n * sizeof(BBox), b_pf = pf.size() * sizeof(int);
-    const size_t o_recs = 0, o_ext = up(o_recs + b_recs), o_bb = up(o_ext + b_ext), o_pf = up(o_bb + b_bb), total = up(o_pf + b_pf);
+    const size_t b_box = ((n + 3) & ~(size_t)3) * sizeof(uint32_t);
+    const size_t o_recs = 0, o_ext = up(o_recs + b_recs), o_bb = up(o_ext + b_ext), o_box = up(o_bb + b_bb), o_pf = up(o_box + b_box),
+                 total = up(o_pf + b_pf);
     d_frame_.reserve(total);
     dv_.recs = reinterpret_cast<DrawRec*>(d_frame_.ptr + o_recs);
     dv_.exts = reinterpret_cast<QuadExt*>(d_frame_.ptr + o_ext);
     dv_.bboxes = reinterpret_cast<BBox*>(d_frame_.ptr + o_bb);
     dv_.phase_first = reinterpret_cast<int*>(d_frame_.ptr + o_pf);
+    dv_.binbox = reinterpret_cast<uint32_t*>(d_frame_.ptr + o_box);
     const int slot = staging_i_;
     staging_i_ = (staging_i_ + 1) % kStaging;
     if (staging_busy_[slot]) FDH_HIP(hipEventSynchronize(staging_ev_[slot]));  // its copy of three frames ago
@@ -932,6 +935,20 @@ void Context::submit(bool upload) {
     if (b_recs) std::memcpy(s + o_recs, recs_.data(), b_recs);
     if (b_ext) std::memcpy(s + o_ext, exts_.data(), b_ext);
     if (b_bb) std::memcpy(s + o_bb, bboxes_.data(), b_bb);
+    {  // bin boxes (what k_bin_draws scans): 7-bit inclusive bounds in bin units, upper bounds complemented
+      uint32_t* bxp = reinterpret_cast<uint32_t*>(s + o_box);
+      binbox_shift_ = (bins_x_ > 128 || bins_y_ > 128) ? 1 : 0;
+      const int unit = kBin << binbox_shift_;
+      for (size_t i = 0; i < b_box / sizeof(uint32_t); i++) {
+        uint32_t v = 0x7f7f7f7fu;  // x0 = y0 = 127, x1 = y1 = 0: never hits
+        if (i < n && !bbox_empty(bboxes_[i])) {
+          const BBox& b = bboxes_[i];
+          v = (uint32_t)(b.x0 / unit) | ((uint32_t)(b.y0 / unit) << 8) | ((127u - (uint32_t)((b.x1 - 1) / unit)) << 16) |
+              ((127u - (uint32_t)((b.y1 - 1) / unit)) << 24);
+        }
+        bxp[i] = v;
+      }
+    }
     std::memcpy(s + o_pf, pf.data(), b_pf);
     void* s_dev = nullptr;
     FDH_HIP(hipHostGetDevicePointer(&s_dev, s, 0));
@@ -989,7 +1006,7 @@ void Context::launch_frame(bool profile) {
   auto span_end = [&]() { if (profile) FDH_HIP(hipEventRecord(spans_.back().b, stream_)); };
   span_begin(0);
   BinParams B;
-  B.bbox = dv_.bboxes; B.draws = dv_.recs; B.lists = d_lists_.ptr; B.counts = d_counts_.ptr; B.phase_first = dv_.phase_first;
+  B.bbox = dv_.bboxes; B.draws = dv_.recs; B.binbox = dv_.binbox; B.n_draws = (int)recs_.size(); B.binbox_shift = binbox_shift_; B.lists = d_lists_.ptr; B.counts = d_counts_.ptr; B.phase_first = dv_.phase_first;
   B.n_phases = np; B.bins_x = bins_x_; B.bins_y = bins_y_; B.stride = list_stride_;
   launch_bin(stream_, B);
   span_end();

@@ -210,7 +210,7 @@ class Context {
   // records, quad extensions, bounding boxes and phase offsets of a frame live in ONE device block and arrive with ONE
   // copy (four small hipMemcpyAsync calls cost the host ~100 us per frame); the typed views point into it
   DeviceBuf<uint8_t> d_frame_;
-  struct View { DrawRec* recs = nullptr; QuadExt* exts = nullptr; BBox* bboxes = nullptr; int* phase_first = nullptr; } dv_;
+  struct View { DrawRec* recs = nullptr; QuadExt* exts = nullptr; BBox* bboxes = nullptr; int* phase_first = nullptr; uint32_t* binbox = nullptr; } dv_;
   DeviceBuf<uint2> d_lists_;
   DeviceBuf<uint32_t> d_counts_;
   // three pinned staging buffers in rotation, each guarded by an event recorded after its copies: the host builds
@@ -220,7 +220,7 @@ class Context {
   hipEvent_t staging_ev_[kStaging] = {};
   bool staging_busy_[kStaging] = {};
   int staging_i_ = 0;
-  int bins_x_ = 0, bins_y_ = 0, list_stride_ = 0;
+  int bins_x_ = 0, bins_y_ = 0, list_stride_ = 0, binbox_shift_ = 0;
 
   // atlas
   int atlas_size_ = 0, initial_atlas_size_ = 0, atlas_margin_ = 4, n_levels_ = 0;
