@@ -439,7 +439,6 @@ void Context::emit_quad_pts(DrawRec& r, const float vx[4], const float vy[4], in
     const bool atlas_mode = mode == 0u || (mode >= 13u && mode <= 16u);
     const float uax = atlas_mode ? r.r[0] : 0.0f, uay = atlas_mode ? r.r[1] : 0.0f, utx = atlas_mode ? r.r[2] : 1.0f, uty = atlas_mode ? r.r[3] : 1.0f;
     const float vu[4] = {uax, utx, utx, uax}, vv[4] = {uty, uty, uay, uay};
-    float lod = -1.0e30f;
     for (int t = 0; t < 2; t++) {
       long long X[3], Y[3];
       for (int k = 0; k < 3; k++) { X[k] = 2 * (long long)px[TRI[t][k]]; Y[k] = 2 * (long long)py[TRI[t][k]]; }
@@ -475,12 +474,11 @@ void Context::emit_quad_pts(DrawRec& r, const float vx[4], const float vy[4], in
         q.fw_v[t] = (float)(std::fabs(dvdx) + std::fabs(dvdy));
         const double S = (double)atlas_size_;
         const double rho = std::max(std::sqrt(dudx * dudx + dvdx * dvdx), std::sqrt(dudy * dudy + dvdy * dvdy)) * S;
-        if (rho > 0.0) lod = std::max(lod, (float)std::log2(rho));
+        q.lod[t] = rho > 0.0 ? (float)std::log2(rho) : 0.0f;
       } else {
         q.fw_u[t] = q.fw_v[t] = 1.0f;
       }
     }
-    q.lod = lod < -1.0e29f ? 0.0f : lod;
     r.op_mode |= F_GENERAL;
     r.ext = (uint32_t)exts_.size();
     exts_.push_back(q);

@@ -456,7 +456,7 @@ __device__ __forceinline__ Frag make_frag(const DrawRec& r, const QuadExt* __res
   f.col.w = (l0 * c0.w + l1 * c1.w + l2 * c2.w) * k;
   f.fw_u = q.fw_u[t];
   f.fw_v = q.fw_v[t];
-  f.lod = q.lod;
+  f.lod = q.lod[t];
   return f;
 }
 

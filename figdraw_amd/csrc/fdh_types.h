@@ -69,9 +69,11 @@ struct alignas(16) QuadExt {
   float inv_sum[2];        // 1 / (E0+E1+E2)  (0 => degenerate triangle)
   uint32_t own;            // bit (tri*3+edge): edge owns pixel centres lying exactly on it (top-left rule)
   float fw_u[2], fw_v[2];  // |du/dx|+|du/dy|, |dv/dx|+|dv/dy| per triangle (msdf fwidth)
-  float lod;               // log2(rho) (atlas mip selection), max over the two triangles
+  float lod[2];            // log2(rho) per triangle (atlas mip selection: GL derives rho from per-fragment derivatives,
+                           // which are constant on a triangle)
+  float _pad[3];
 };
-static_assert(sizeof(QuadExt) == 128, "QuadExt must be 128 bytes");
+static_assert(sizeof(QuadExt) == 144, "QuadExt must be 144 bytes");
 
 struct alignas(8) BBox { int16_t x0, y0, x1, y1; };
 

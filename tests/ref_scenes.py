@@ -406,7 +406,7 @@ def text_frontend(w=300.0, h=120.0, images=None) -> Renders:
     return out
 
 
-def random_scene(seed: int, w: float, h: float, n: int = 40, clips: bool = True, blur: bool = True) -> Renders:
+def random_scene(seed: int, w: float, h: float, n: int = 40, clips: bool = True, blur: bool = True, images=None) -> Renders:
     """Seeded random mix of everything the SDF path has: opaque and translucent fills (solid, 2- and 3-stop on all
     axes), circular and elliptical corners, strokes, drop and inner shadows, nested NfClipContent / NfRectMaskContent
     containers, rotations and a backdrop blur -- at whatever (odd) frame size the caller picks.  Used to compare the
@@ -429,6 +429,34 @@ def random_scene(seed: int, w: float, h: float, n: int = 40, clips: bool = True,
         if k < 0.8:
             return linear(col(opaque), col(opaque), axis=axis)
         return linear(col(opaque), col(opaque), col(opaque), axis=axis, midPos=rnd.randrange(20, 236))
+
+    def some_atlas_node(parent=None):
+        """coverage glyphs (1:1, tinted), images magnified / minified / flipped, MSDF / MTSDF incl. annular, some rotated"""
+        from figdraw_amd.scene import Glyph
+
+        k = rnd.random()
+        x, y = rnd.uniform(0, 0.8 * w), rnd.uniform(0, 0.8 * h)
+        if k < 0.35:
+            word = "".join(rnd.choice("figdrawABC&!?gjpq") for _ in range(rnd.randrange(2, 9)))
+            tint = [col(True) for _ in range(4)] if rnd.random() < 0.5 else [col(True)] * 4
+            gl = [Glyph(image_id=1000 + ord(c), x=float(round(13.2 * i)) + (0.0 if rnd.random() < 0.7 else 0.37),
+                        y=float(20 - images[1000 + ord(c)].shape[0]), colors=tint) for i, c in enumerate(word)]
+            f = Fig(kind=FigKind.nkText, screenBox=rect(round(x), round(y), 120, 24), glyphs=gl,
+                    flags=FigFlags.NfInvertY if rnd.random() < 0.2 else FigFlags(0))
+        elif k < 0.6:
+            sz = rnd.choice([100.0, 160.0, 230.5, 60.0, 33.0])
+            f = Fig(kind=FigKind.nkImage, screenBox=rect(x, y, sz, sz * rnd.choice([1.0, 0.8])), image_id=3000,
+                    image_fill=fill(col()) if rnd.random() < 0.5 else fill(rgba(255, 255, 255, 255)),
+                    flags=FigFlags.NfInvertY if rnd.random() < 0.3 else FigFlags(0))
+        else:
+            ch = rnd.choice("R&gA?")
+            sz = rnd.uniform(24, 140)
+            f = Fig(kind=rnd.choice([FigKind.nkMsdfImage, FigKind.nkMtsdfImage]), screenBox=rect(x, y, sz, sz), image_id=2000 + ord(ch),
+                    image_fill=some_fill(), pxRange=4.0, sdThreshold=rnd.choice([0.5, 0.45]),
+                    strokeWeight=rnd.choice([0.0, 0.0, 2.5]))
+        if rnd.random() < 0.15:
+            f.rotation = rnd.uniform(-50, 50)
+        return lst.addRoot(f) if parent is None else lst.addChild(parent, f)
 
     def some_rect(parent=None, depth=0):
         bw, bh = rnd.uniform(8, 0.7 * w), rnd.uniform(8, 0.7 * h)
@@ -453,12 +481,18 @@ def random_scene(seed: int, w: float, h: float, n: int = 40, clips: bool = True,
         if clips and depth < 2 and rnd.random() < 0.2:
             f.flags |= rnd.choice([FigFlags.NfClipContent, FigFlags.NfRectMaskContent])
             for _ in range(rnd.randrange(1, 4)):
-                some_rect(idx, depth + 1)
+                if images is not None and rnd.random() < 0.4:
+                    some_atlas_node(idx)
+                else:
+                    some_rect(idx, depth + 1)
         return idx
 
     lst.addRoot(Fig(kind=RECT, screenBox=rect(0, 0, w, h), fill=fill(col(rnd.random() < 0.5))))
     for i in range(n):
-        some_rect()
+        if images is not None and rnd.random() < 0.45:
+            some_atlas_node()
+        else:
+            some_rect()
         if blur and i == n // 2:
             bw, bh = rnd.uniform(0.2 * w, 0.8 * w), rnd.uniform(0.2 * h, 0.8 * h)
             c = rnd.randrange(0, 30)

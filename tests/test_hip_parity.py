@@ -223,6 +223,25 @@ def test_flippy_image_matches_oracle_and_reference_png():
     ctx.close()
 
 
+@pytest.mark.parametrize("seed,w,h,clips", [(11, 400, 300, True), (12, 777, 333, False), (13, 1024, 512, True), (14, 250, 640, False)])
+def test_random_atlas_scenes_match_oracle(seed, w, h, clips):
+    """Random scenes mixing SDF rects with glyph runs, scaled / flipped images and (M)(T)SDF quads, some rotated, some
+    under clips: the 4-wide atlas path, the one-pixel-slot path (rotated, minified) and the kernel-variant selection."""
+    import os
+
+    from conftest import GOLDEN
+    from figdraw_amd.scenes import load_glyph_fixture
+
+    all_images = load_glyph_fixture(os.path.join(GOLDEN, "glyphs_ubuntu20.npz"))
+    sc = RS.random_scene(seed, float(w), float(h), n=50, clips=clips, blur=(seed % 2 == 1), images=all_images)
+    ctx, o = _atlas_ctx_pair(sc, RS.used_images(sc, all_images), 1024)
+    ctx.render_frame(sc, w, h)
+    o.render_frame(sc, w, h)
+    mx, n0, n1 = diff_stats(ctx.read_pixels(), o.read_pixels())
+    assert mx <= 1 and n0 <= 0.005 * w * h, (seed, mx, n0, n1)
+    ctx.close()
+
+
 @pytest.mark.parametrize("subpixel,variants", [(False, False), (True, False), (True, True)])
 def test_text_frontend_matches_oracle(subpixel, variants):
     """Selection rectangles, underline / strikethrough and renderer-side glyph snapping (shift or glyph variants)."""
