@@ -312,6 +312,55 @@ class RenderList:  # fignodes.nim:44-46
         return idx
 
 
+    # ---- physical inserts: nodes are shifted, parent / root indexes rewritten, child counts recomputed
+    def child_indices(self, parentIdx: int):  # iterator childIndex fignodes.nim:165-177
+        out, idx = [], parentIdx + 1
+        cnt = self.nodes[parentIdx].childCount
+        while len(out) < cnt and idx < len(self.nodes):
+            if self.nodes[idx].parent == parentIdx:
+                out.append(idx)
+            idx += 1
+        return out
+
+    def _child_insert_index(self, parentIdx: int, childPos: int) -> int:  # fignodes.nim:179-193
+        cc = self.nodes[parentIdx].childCount
+        assert 0 <= childPos <= cc
+        if childPos == cc:
+            return len(self.nodes)
+        return self.child_indices(parentIdx)[childPos]
+
+    def _shift_indexes(self, insertIdx: int, count: int):  # fignodes.nim:134-144
+        for n in self.nodes:
+            if n.parent >= insertIdx:
+                n.parent += count
+        self.rootIds = [r + count if r >= insertIdx else r for r in self.rootIds]
+
+    def _recompute_child_counts(self):
+        for n in self.nodes:
+            n.childCount = 0
+        for n in self.nodes:
+            if n.parent >= 0:
+                self.nodes[n.parent].childCount += 1
+
+    def insertRoot(self, root: Fig, rootPos: int) -> int:  # fignodes.nim:332-350
+        assert 0 <= rootPos <= len(self.rootIds)
+        insertIdx = len(self.nodes) if rootPos == len(self.rootIds) else self.rootIds[rootPos]
+        self._shift_indexes(insertIdx, 1)
+        root.parent = -1
+        self.nodes.insert(insertIdx, root)
+        self.rootIds.insert(rootPos, insertIdx)
+        self._recompute_child_counts()
+        return insertIdx
+
+    def insertChild(self, parentIdx: int, child: Fig, childPos: int) -> int:  # fignodes.nim:376-400
+        insertIdx = self._child_insert_index(parentIdx, childPos)
+        self._shift_indexes(insertIdx, 1)
+        child.parent = parentIdx + 1 if parentIdx >= insertIdx else parentIdx
+        self.nodes.insert(insertIdx, child)
+        self._recompute_child_counts()
+        return insertIdx
+
+
 class Renders:  # fignodes.nim:48-49 -- OrderedTable[ZLevel, RenderList]; insertion order is render order
     def __init__(self):
         self.layers: Dict[int, RenderList] = {}
