@@ -1395,9 +1395,9 @@ __global__ __launch_bounds__(256) void k_blur_h(BlurParams P) {
 // slower); a lane owns a column, each wave produces 8 consecutive rows.  With fuse_draw >= 0 the consuming mode-17 quad
 // is blended in place; tiles inside the quad's saturated core (DrawRec::ix0..iy1) skip the coverage evaluation.
 constexpr int kBlurVW = 64;
-template <int kBlurOut>
-__global__ __launch_bounds__(256) void k_blur_v(BlurParams P, const DrawRec* __restrict__ draws, const QuadExt* __restrict__ exts) {
-  constexpr int kBlurVH = 4 * kBlurOut;
+template <int kBlurOut, int kVWaves>
+__global__ __launch_bounds__(64 * kVWaves) void k_blur_v(BlurParams P, const DrawRec* __restrict__ draws, const QuadExt* __restrict__ exts) {
+  constexpr int kBlurVH = kVWaves * kBlurOut;  // rows per workgroup: each wave produces kBlurOut of them
   extern __shared__ uint32_t tile[];  // (kBlurVH + 2*reach) rows x 64 columns
   // XCD-aware tile order: workgroup b runs on XCD b % 8.  Tiles are sequenced band by band (a band = 8 tile columns,
   // walked row by row) and every XCD takes one contiguous eighth of that sequence, so the 2*reach halo rows a tile
@@ -1420,7 +1420,7 @@ __global__ __launch_bounds__(256) void k_blur_v(BlurParams P, const DrawRec* __r
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int x = xs + lane;
   const int xc = x > P.W - 1 ? P.W - 1 : x;
-  for (int rr = wave; rr < rows; rr += 4) {
+  for (int rr = wave; rr < rows; rr += kVWaves) {
     int y = ys - reach + rr;
     y = y < 0 ? 0 : (y > P.H - 1 ? P.H - 1 : y);
     tile[rr * kBlurVW + lane] = P.src[(size_t)y * P.pitch + xc];
@@ -1493,16 +1493,19 @@ void launch_composite(hipStream_t s, const DrawRec* draws, const BBox* bboxes, c
 #ifndef FDH_BLUR_NOUT
 #define FDH_BLUR_NOUT 8
 #endif
+#ifndef FDH_BLUR_VWAVES
+#define FDH_BLUR_VWAVES 4  // waves per V-pass workgroup: the tile is 64 columns x (waves * outputs) rows
+#endif
 static bool blur_small(const BlurParams& P) { return (long long)(P.x1 - P.x0) * (P.y1 - P.y0) < 1024 * 1024; }
 template <int NOUT> static void launch_blur_h_n(hipStream_t s, const BlurParams& P) {
   dim3 grid((P.x1 - P.x0 + 64 * NOUT - 1) / (64 * NOUT), (P.y1 - P.y0 + 3) / 4);
   hipLaunchKernelGGL(k_blur_h<NOUT>, grid, dim3(256), 0, s, P);
 }
-template <int NOUT> static void launch_blur_v_n(hipStream_t s, const BlurParams& P, const DrawRec* draws, const QuadExt* exts) {
-  const int ntx = (P.x1 - P.x0 + kBlurVW - 1) / kBlurVW, nty = (P.y1 - P.y0 + 4 * NOUT - 1) / (4 * NOUT);
+template <int NOUT, int WAVES> static void launch_blur_v_n(hipStream_t s, const BlurParams& P, const DrawRec* draws, const QuadExt* exts) {
+  const int ntx = (P.x1 - P.x0 + kBlurVW - 1) / kBlurVW, nty = (P.y1 - P.y0 + WAVES * NOUT - 1) / (WAVES * NOUT);
   dim3 grid(8 * ((ntx * nty + 7) / 8));  // 8 XCDs x an eighth of the tile sequence each
-  const size_t lds = (size_t)(4 * NOUT + 2 * P.taps.reach) * kBlurVW * sizeof(uint32_t);
-  hipLaunchKernelGGL(k_blur_v<NOUT>, grid, dim3(256), lds, s, P, draws, exts);
+  const size_t lds = (size_t)(WAVES * NOUT + 2 * P.taps.reach) * kBlurVW * sizeof(uint32_t);
+  hipLaunchKernelGGL((k_blur_v<NOUT, WAVES>), grid, dim3(64 * WAVES), lds, s, P, draws, exts);
 }
 void launch_blur_h(hipStream_t s, const BlurParams& P) {
   if (P.x1 <= P.x0 || P.y1 <= P.y0) return;
@@ -1510,7 +1513,7 @@ void launch_blur_h(hipStream_t s, const BlurParams& P) {
 }
 void launch_blur_v(hipStream_t s, const BlurParams& P, const DrawRec* draws, const QuadExt* exts) {
   if (P.x1 <= P.x0 || P.y1 <= P.y0) return;
-  if (blur_small(P)) launch_blur_v_n<2>(s, P, draws, exts); else launch_blur_v_n<FDH_BLUR_NOUT>(s, P, draws, exts);
+  if (blur_small(P)) launch_blur_v_n<2, 4>(s, P, draws, exts); else launch_blur_v_n<FDH_BLUR_NOUT, FDH_BLUR_VWAVES>(s, P, draws, exts);
 }
 // Frame upload as a kernel on the render stream: the source is pinned host memory mapped into the device's address
 // space, read over the host link 16 bytes per lane.  (hipMemcpyAsync hands the copy to another engine; the round trip
