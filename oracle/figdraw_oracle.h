@@ -11,7 +11,7 @@
  * this library, and only as the checker / the timed CPU baseline.  The product
  * (libfigdraw_hip.so) never links, loads or calls it.
  *
- * Pinning: see oracle/README.md -- checked against the reference's own golden
+ * Pinning: checked against the reference's own golden
  * PNGs (tests/expected/render_{rgb_boxes_sdf,linear_gradient,layers_clip}.png)
  * and against the reference's GLSL run on SwiftShader (oracle/ref_swiftshader.py).
  */
