@@ -356,8 +356,15 @@ static void set_saturated_core(DrawRec& r, float w_px, float h_px) {
   if (op == OP_MASK_PUSH || mode == FDH_SDF_CLIP_AA || mode == FDH_SDF_BACKDROP_BLUR) e = 0.5 / r.aa;
   else if (mode == FDH_SDF_DROP_SHADOW) e = std::max(0.0, -(double)(fill_mode == 0u ? r.f1 : 0.0f));
   else if (mode == FDH_SDF_ANNULAR || mode == FDH_SDF_ANNULAR_AA) e = std::max(0.0, (double)r.f0) + 0.5 / r.aa;
-  else return;
-  const double qhx = r.p0, qhy = r.p1, bx = r.p2, by = r.p3;
+  else if (mode == FDH_SDF_INSET_SHADOW && op == OP_DRAW) {
+    // Inner shadow: far enough inside the (offset) shape the profile exp(-z^2/2) is below 0.49/255, so the blend cannot
+    // move any 8-bit channel whatever the colours are (|sa (255 c - F)| < 0.5): the draw is a no-op there, like the
+    // inside of a stroke.  z > 3.7 leaves a margin over the exact 3.54.
+    const double sigma = std::max(0.5 * (double)r.f0, 0.5);
+    e = std::max(0.0, 3.7 * sigma + (double)(fill_mode == 0u ? r.f1 : 0.0f));
+  } else return;
+  const bool inset = mode == FDH_SDF_INSET_SHADOW;
+  const double qhx = r.p0, qhy = r.p1, bx = inset ? qhx : (double)r.p2, by = inset ? qhy : (double)r.p3;
   if (!(qhx > 0.0 && qhy > 0.0 && bx > 0.0 && by > 0.0)) return;
   double crx[4], cry[4];  // TR, BR, TL, BL as in DrawRec::r
   for (int k = 0; k < 4; k++) {
@@ -386,6 +393,7 @@ static void set_saturated_core(DrawRec& r, float w_px, float h_px) {
     const double ah = std::max(hx1 - hx0, 0.0) * std::max(hy1 - hy0, 0.0), av = std::max(vx1 - vx0, 0.0) * std::max(vy1 - vy0, 0.0);
     if (ah >= av) { xl = hx0; xr = hx1; yb = hy0; yt = hy1; } else { xl = vx0; xr = vx1; yb = vy0; yt = vy1; }
   }
+  if (inset) { xl += r.p2; xr += r.p2; yb -= r.p3; yt -= r.p3; }  // the shadow shape sits at (p2, -p3) in the quad's frame
   if (!(xr > xl && yt > yb)) return;
   // local -> pixel centres: cx = ox + w_px * (x / (2 qhx) + 0.5), cy = oy + h_px * (0.5 - y / (2 qhy))
   const double slack = 1.0;

@@ -279,8 +279,8 @@ __device__ __forceinline__ void bin_entry(const BinParams& P, int i, int x0, int
   const bool sdf = !(om & F_GENERAL) && !atlas_mode && mode < 18u && (op == OP_DRAW || op == OP_MASK_PUSH);
   if (!sdf) return;
   const uint32_t core = strip_mask_inside(r->ix0 - x0, r->iy0 - y0, r->ix1 - x0, r->iy1 - y0) & strips;
-  if (op == OP_DRAW && (mode == 11u || mode == 12u)) {
-    strips &= ~core;  // alpha == 0 there
+  if (op == OP_DRAW && (mode == 9u || mode == 11u || mode == 12u)) {
+    strips &= ~core;  // alpha == 0 there (stroke interior) or too small to change an 8-bit channel (deep inside an inner shadow)
     hit = strips != 0u;
     return;
   }
@@ -949,7 +949,7 @@ __global__ __launch_bounds__(FDH_WAVE_WG ? 64 : 256, (kPaths & 1) ? 4 : FDH_FAST
       { F0.x += core ? 1e-30f : 0.0f; return; }
 #endif
       if (core) {
-        if (mode == 11u || mode == 12u) { FDH_COUNT(32); return; }
+        if (mode == 9u || mode == 11u || mode == 12u) { FDH_COUNT(32); return; }
         if (op == OP_DRAW && (om & F_SOLID) && fill_mode == 0u && mode != 17u) {
           FDH_COUNT(33);
           const F4 c0 = unpack255(r.col[0]);

@@ -55,7 +55,8 @@ struct alignas(16) DrawRec {
   int16_t bx0, by0, bx1, by1;  // covered pixel bounds, clipped to the frame: [bx0,bx1) x [by0,by1)
   // Saturated core of an axis-aligned SDF draw, in (unclipped) pixel bounds, empty when unknown: every pixel centre in
   // [ix0,ix1) x [iy0,iy1) has coverage alpha == 1 (fills, clip pushes, drop-shadow bodies, blur composites) or, for
-  // the annular stroke modes 11/12, alpha == 0.  Conservative by a pixel; lets a strip be classified on the scalar unit.
+  // the annular stroke modes 11/12, alpha == 0 -- or, for an inner shadow (mode 9), alpha too small to change any 8-bit
+  // channel.  Conservative by a pixel; lets a strip be classified by a bit test.
   int16_t ix0, iy0, ix1, iy1;
   uint32_t _pad[3];
 };
