@@ -1080,7 +1080,7 @@ void Context::launch_frame(bool profile) {
     C.has_atlas = ph.has_atlas ? 1 : 0;
     C.has_masks = ph.has_masks ? 1 : 0;
     span_begin(p == 0 ? 1 : 2);
-    launch_composite(stream_, dv_.recs, dv_.bboxes, dv_.exts, C);
+    launch_composite(stream_, dv_.recs, dv_.exts, C);
     span_end();
   }
   FDH_HIP(hipGetLastError());

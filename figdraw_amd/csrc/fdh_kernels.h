@@ -47,7 +47,7 @@ struct BlurParams {
 };
 
 void launch_bin(hipStream_t s, const BinParams& P);
-void launch_composite(hipStream_t s, const DrawRec* draws, const BBox* bboxes, const QuadExt* exts, CompositeParams P);
+void launch_composite(hipStream_t s, const DrawRec* draws, const QuadExt* exts, CompositeParams P);
 void launch_blur_h(hipStream_t s, const BlurParams& P);
 void launch_blur_v(hipStream_t s, const BlurParams& P, const DrawRec* draws, const QuadExt* exts);
 void launch_fill(hipStream_t s, uint32_t* p, uint32_t v, size_t n);

@@ -15,21 +15,13 @@
 
 namespace fdh {
 
-// A/B switches (measured on MI355X, S300@4K): record prefetch costs SGPR spills and loses ~5 %, the exact
-// tile classification wins 2-10 % depending on how many shapes have small radii.
-#ifndef FDH_PREFETCH
-#ifndef FDH_PREFETCH
-#define FDH_PREFETCH 0
-#endif
-#endif
+// Build switches.  What was tried and dropped is in DESIGN.md section 4 (register prefetch of the next record, 4-wave
+// workgroups, several strips per wave, sequential per-pixel shading, ...).
 #ifndef FDH_SIMPLE_EDGE
-#define FDH_SIMPLE_EDGE 1
+#define FDH_SIMPLE_EDGE 1  // hand-packed path for the commonest edge strips (-4 % VALU instructions)
 #endif
-#ifndef FDH_CLASSIFY
-#define FDH_CLASSIFY 1
 #ifndef FDH_STATS
 #define FDH_STATS 0  // `make stats`: per-strip draw classification counters (tools/strip_stats.py); never in the product build
-#endif
 #endif
 
 // ------------------------------------------------------------------ small device helpers
@@ -714,9 +706,6 @@ __device__ unsigned long long g_counters[64];
 #else
 #define FDH_COUNT(i) do { } while (0)
 #endif
-#ifndef FDH_WAVE_WG
-#define FDH_WAVE_WG 1  // 1: a workgroup is ONE wavefront (the dispatcher refills wave slots one at a time)
-#endif
 // kSlow = false is the build for phases made only of axis-aligned SDF draws, clips and rect masks (no atlas sampling,
 // no rotated quads, no bezier strokes): without the one-pixel-slot path the kernel needs no scratch and fits 5 waves/SIMD.
 #ifndef FDH_FAST_WAVES
@@ -725,25 +714,19 @@ __device__ unsigned long long g_counters[64];
 // kPaths: bit 0 = the one-pixel-slot path (rotated / skewed quads, bezier strokes, rect-mask setup, minified images),
 // bit 1 = the 4-wide atlas path (axis-aligned glyphs, images at >= 1:1, MSDF).  0: SDF draws, clips and rect masks only.
 template <int kPaths>
-__global__ __launch_bounds__(FDH_WAVE_WG ? 64 : 256, (kPaths & 1) ? 4 : FDH_FAST_WAVES) void k_composite_tiles(const DrawRec* __restrict__ draws, const BBox* __restrict__ bboxes,
+__global__ __launch_bounds__(64, (kPaths & 1) ? 4 : FDH_FAST_WAVES) void k_composite_tiles(const DrawRec* __restrict__ draws,
                                                          const QuadExt* __restrict__ exts, CompositeParams P) {
-  __shared__ uint32_t mask_stack[FDH_WAVE_WG ? 1 : kWavesPerWg][kMaskDepth][64];  // 4 pixels' q8 mask values packed per lane
+  __shared__ uint32_t mask_stack[1][kMaskDepth][64];  // clip stack: 4 pixels' q8 mask values packed per lane and level
   // XCD-aware mapping: the dispatcher places workgroup b on XCD b % 8.  XCD x takes the bins x, x+8, x+16, ... of this
   // launch (row-major), all 16 strips of a bin back to back: a bin's draw list and records stay in ONE L2, and every
   // XCD gets an even sample of the frame -- contiguous bands per XCD left the XCDs holding the busy rows 3x the work
   // of the ones holding the emptier top and bottom of the frame.
   constexpr int kStripsPerBin = kWgsPerBin * kWavesPerWg;  // 16
-#if FDH_WAVE_WG
+  // (a workgroup is ONE wavefront: nothing is shared between strips, and the dispatcher refills wave slots one at a time)
   const int q = blockIdx.x >> 3, xcd = blockIdx.x & 7;
   const int bin_local = xcd + 8 * (q / kStripsPerBin), sidx = q % kStripsPerBin;
   if (bin_local >= P.bin_nx * P.bin_ny) return;
   const int j = sidx >> 2, wave = sidx & 3, lane = threadIdx.x & 63, mslot = 0;
-#else
-  const int q = blockIdx.x >> 3, xcd = blockIdx.x & 7;
-  const int bin_local = xcd + 8 * (q / kWgsPerBin), j = q % kWgsPerBin;
-  if (bin_local >= P.bin_nx * P.bin_ny) return;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, mslot = wave;
-#endif
   const int sbit = j * 4 + wave;  // this strip's bit in the list entries' strip masks
   const int bly = bin_local / P.bin_nx, blx = bin_local - bly * P.bin_nx;
   const int bin_x = P.bin_x0 + blx, bin_y = P.bin_y0 + bly;
@@ -1091,7 +1074,7 @@ __global__ __launch_bounds__(FDH_WAVE_WG ? 64 : 256, (kPaths & 1) ? 4 : FDH_FAST
         cls = 1;
 #pragma unroll
         for (int k = 0; k < 4; k++) dist[k] = -1.0e30f;
-      } else if (FDH_CLASSIFY && !ellip) {
+      } else if (!ellip) {
         const float lxo[2] = {lx[0], lx[3]};
         float d2[2];
         shape_distN<2>(false, lxo, -ly, shx, shy, r.r[0], r.r[1], r.r[2], r.r[3], d2);
@@ -1478,16 +1461,16 @@ void launch_bin(hipStream_t s, const BinParams& P) {
   const int n = P.n_phases * P.bins_x * P.bins_y;
   if (n > 0) hipLaunchKernelGGL(k_bin_draws, dim3(n), dim3(64), 0, s, P);
 }
-void launch_composite(hipStream_t s, const DrawRec* draws, const BBox* bboxes, const QuadExt* exts, CompositeParams P) {
+void launch_composite(hipStream_t s, const DrawRec* draws, const QuadExt* exts, CompositeParams P) {
   const int n = P.bin_nx * P.bin_ny * kWgsPerBin;
   if (n <= 0) return;
   P.n_wg = n;
   const int bins8 = (P.bin_nx * P.bin_ny + 7) / 8;  // bins per XCD
-  const int grid = 8 * bins8 * (FDH_WAVE_WG ? kWgsPerBin * kWavesPerWg : kWgsPerBin);
-  const dim3 blk(FDH_WAVE_WG ? 64 : 256);
-  if (P.has_slow) hipLaunchKernelGGL(k_composite_tiles<3>, dim3(grid), blk, 0, s, draws, bboxes, exts, P);
-  else if (P.has_atlas) hipLaunchKernelGGL(k_composite_tiles<2>, dim3(grid), blk, 0, s, draws, bboxes, exts, P);
-  else hipLaunchKernelGGL(k_composite_tiles<0>, dim3(grid), blk, 0, s, draws, bboxes, exts, P);
+  const int grid = 8 * bins8 * kWgsPerBin * kWavesPerWg;  // 16 strips per bin, one wavefront each
+  const dim3 blk(64);
+  if (P.has_slow) hipLaunchKernelGGL(k_composite_tiles<3>, dim3(grid), blk, 0, s, draws, exts, P);
+  else if (P.has_atlas) hipLaunchKernelGGL(k_composite_tiles<2>, dim3(grid), blk, 0, s, draws, exts, P);
+  else hipLaunchKernelGGL(k_composite_tiles<0>, dim3(grid), blk, 0, s, draws, exts, P);
 }
 // small regions: fewer outputs per thread -> more, shorter waves (see NOUT above)
 #ifndef FDH_BLUR_NOUT
