@@ -1348,10 +1348,15 @@ __global__ __launch_bounds__(256) void k_blur_h(BlurParams P) {
   uint32_t* line = lines[wave];
   if (y < P.y1) {
     const uint32_t* __restrict__ row = P.src + (size_t)y * P.pitch;
-    for (int i = lane; i < span + kBlurOut; i += 64) {
-      int x = xs - reach + i;
-      x = x < 0 ? 0 : (x > P.W - 1 ? P.W - 1 : x);  // clamp-to-edge (glcontext.nim:214-215)
-      line[i] = row[x];
+    if (xs - reach >= 0 && xs - reach + span + kBlurOut <= P.W) {  // wave-uniform: nothing to clamp
+      const uint32_t* __restrict__ p = row + (xs - reach);
+      for (int i = lane; i < span + kBlurOut; i += 64) line[i] = p[i];
+    } else {
+      for (int i = lane; i < span + kBlurOut; i += 64) {
+        int x = xs - reach + i;
+        x = x < 0 ? 0 : (x > P.W - 1 ? P.W - 1 : x);  // clamp-to-edge (glcontext.nim:214-215)
+        line[i] = row[x];
+      }
     }
   }
   __builtin_amdgcn_wave_barrier();  // a wave reads back only the line it staged itself: no workgroup barrier
@@ -1403,10 +1408,17 @@ __global__ __launch_bounds__(64 * kVWaves) void k_blur_v(BlurParams P, const Dra
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int x = xs + lane;
   const int xc = x > P.W - 1 ? P.W - 1 : x;
-  for (int rr = wave; rr < rows; rr += kVWaves) {
-    int y = ys - reach + rr;
-    y = y < 0 ? 0 : (y > P.H - 1 ? P.H - 1 : y);
-    tile[rr * kBlurVW + lane] = P.src[(size_t)y * P.pitch + xc];
+  if (ys - reach >= 0 && ys - reach + rows <= P.H) {  // workgroup-uniform: no row to clamp, the row pointer just advances
+    const uint32_t* __restrict__ p = P.src + (size_t)(ys - reach + wave) * P.pitch + xc;
+    const size_t step = (size_t)kVWaves * P.pitch;
+#pragma unroll 6
+    for (int rr = wave; rr < rows; rr += kVWaves) tile[rr * kBlurVW + lane] = p[(size_t)((rr - wave) / kVWaves) * step];
+  } else {
+    for (int rr = wave; rr < rows; rr += kVWaves) {
+      int y = ys - reach + rr;
+      y = y < 0 ? 0 : (y > P.H - 1 ? P.H - 1 : y);  // clamp-to-edge
+      tile[rr * kBlurVW + lane] = P.src[(size_t)y * P.pitch + xc];
+    }
   }
   __syncthreads();
   const int ry = wave * kBlurOut;  // first of this wave's output rows, relative to ys
