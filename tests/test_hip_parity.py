@@ -52,7 +52,8 @@ def test_scene_matches_oracle_and_goldens(hip, name):
 
 
 FUZZ = [(1, 333, 217, True, True), (2, 640, 480, True, False), (3, 257, 129, False, True), (4, 1000, 70, True, True),
-        (5, 65, 600, False, False), (6, 512, 512, False, False), (7, 799, 601, True, True), (8, 1283, 721, False, True)]
+        (5, 65, 600, False, False), (6, 512, 512, False, False), (7, 799, 601, True, True), (8, 1283, 721, False, True),
+        (9, 9000, 90, True, True), (10, 70, 8400, False, True)]  # > 128 bins along an axis: bin boxes in 128-px units
 
 
 @pytest.mark.parametrize("seed,w,h,clips,blur", FUZZ)
