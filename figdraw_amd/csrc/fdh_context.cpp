@@ -733,7 +733,7 @@ void Context::draw_rect(const float rect[4], FdhColor color) {
 void Context::begin_mask(const float rect[4], const float rx[4], const float ry[4]) {
   if (!frame_begun_) throw Error(FDH_ERR_INVALID, "ctx.beginFrame has not been called.");
   if (mask_begun_) throw Error(FDH_ERR_INVALID, "ctx.beginMask has already been called.");
-  if (mask_depth_ >= kMaskDepth) throw Error(FDH_ERR_UNSUPPORTED, "clip masks nested deeper than 8");
+  if (mask_depth_ >= kMaskDepth) throw Error(FDH_ERR_UNSUPPORTED, "clip masks nested deeper than 16");
   mask_begun_ = true;
   mask_depth_++;
   const FdhColor red{255, 0, 0, 255}, zero{0, 0, 0, 0};

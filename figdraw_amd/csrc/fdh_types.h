@@ -15,7 +15,7 @@ constexpr int kWgW = kTileW;                // 32
 constexpr int kWgH = kTileH * kWavesPerWg;  // 32: the four waves of a workgroup are stacked vertically
 constexpr int kBin = 64;
 constexpr int kWgsPerBin = (kBin / kWgW) * (kBin / kWgH);  // 4
-constexpr int kMaskDepth = 8;                              // per-lane clip stack depth kept in LDS
+constexpr int kMaskDepth = 16;                             // per-lane clip stack depth kept in LDS (4 KB per wavefront)
 constexpr int kMaxMips = 14;
 constexpr int kMaxBlurTaps = 36;
 
