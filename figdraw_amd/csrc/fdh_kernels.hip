@@ -1369,10 +1369,13 @@ __global__ __launch_bounds__(256) void k_blur_h(BlurParams P) {
 #pragma unroll
   for (int p = 0; p < kBlurOut; p++) ov[p] = pack2(rg[p], ba[p]);
   uint32_t* out = P.dst + (size_t)y * P.pitch + x;
-  if (kBlurOut >= 4 && x + kBlurOut - 1 < P.x1 && ((reinterpret_cast<uintptr_t>(out) & 15) == 0)) {
+  if (kBlurOut % 4 == 0 && x + kBlurOut - 1 < P.x1 && ((reinterpret_cast<uintptr_t>(out) & 15) == 0)) {
 #pragma unroll
     for (int g = 0; g < kBlurOut / 4; g++)
       reinterpret_cast<uint4*>(out)[g] = make_uint4(ov[(4 * g) % kBlurOut], ov[(4 * g + 1) % kBlurOut], ov[(4 * g + 2) % kBlurOut], ov[(4 * g + 3) % kBlurOut]);
+  } else if (kBlurOut % 2 == 0 && x + kBlurOut - 1 < P.x1 && ((reinterpret_cast<uintptr_t>(out) & 7) == 0)) {
+#pragma unroll
+    for (int g = 0; g < kBlurOut / 2; g++) reinterpret_cast<uint2*>(out)[g] = make_uint2(ov[(2 * g) % kBlurOut], ov[(2 * g + 1) % kBlurOut]);
   } else {
 #pragma unroll
     for (int p = 0; p < kBlurOut; p++) if (x + p < P.x1) out[p] = ov[p];
@@ -1486,12 +1489,29 @@ void launch_composite(hipStream_t s, const DrawRec* draws, const QuadExt* exts, 
 }
 // small regions: fewer outputs per thread -> more, shorter waves (see NOUT above)
 #ifndef FDH_BLUR_NOUT
-#define FDH_BLUR_NOUT 8
+#define FDH_BLUR_NOUT 0  // 0: pick 8, 10 or 12 outputs per thread per launch (blur_pick_nout); otherwise that value everywhere
 #endif
 #ifndef FDH_BLUR_VWAVES
 #define FDH_BLUR_VWAVES 4  // waves per V-pass workgroup: the tile is 64 columns x (waves * outputs) rows
 #endif
 static bool blur_small(const BlurParams& P) { return (long long)(P.x1 - P.x0) * (P.y1 - P.y0) < 1024 * 1024; }
+// Outputs per thread for a large region: more outputs share each unpacked texel (4 converts per texel and n outputs
+// against the 2 * taps packed FMAs every output needs anyway), but the extent along the pass is cut into units of
+// `quantum * n` and the last unit of every row / column runs with idle lanes.  3840 px in 512-px waves is 7.5 waves per row
+// (1/16 of the pass wasted); in 768-px waves it is exactly 5.  Cost model = padded extent x instructions per output.
+static int blur_pick_nout(int extent, int quantum, int reach) {
+  if (FDH_BLUR_NOUT) return FDH_BLUR_NOUT;
+  int best = 8;
+  double best_cost = 1e300;
+  for (int n : {8, 10, 12}) {
+    const int unit = quantum * n;
+    const double padded = (double)((extent + unit - 1) / unit) * unit;
+    const double per_output = 2.0 * (2 * reach + 1) + 4.0 * (n + 2 * reach) / n + 6.0;
+    const double cost = padded * per_output;
+    if (cost < best_cost) { best_cost = cost; best = n; }
+  }
+  return best;
+}
 template <int NOUT> static void launch_blur_h_n(hipStream_t s, const BlurParams& P) {
   dim3 grid((P.x1 - P.x0 + 64 * NOUT - 1) / (64 * NOUT), (P.y1 - P.y0 + 3) / 4);
   hipLaunchKernelGGL(k_blur_h<NOUT>, grid, dim3(256), 0, s, P);
@@ -1504,11 +1524,23 @@ template <int NOUT, int WAVES> static void launch_blur_v_n(hipStream_t s, const 
 }
 void launch_blur_h(hipStream_t s, const BlurParams& P) {
   if (P.x1 <= P.x0 || P.y1 <= P.y0) return;
-  if (blur_small(P)) launch_blur_h_n<2>(s, P); else launch_blur_h_n<FDH_BLUR_NOUT>(s, P);
+  if (blur_small(P)) { launch_blur_h_n<2>(s, P); return; }
+  switch (blur_pick_nout(P.x1 - P.x0, 64, P.taps.reach)) {
+    case 12: launch_blur_h_n<12>(s, P); break;
+    case 10: launch_blur_h_n<10>(s, P); break;
+    case 16: launch_blur_h_n<16>(s, P); break;
+    default: launch_blur_h_n<8>(s, P); break;
+  }
 }
 void launch_blur_v(hipStream_t s, const BlurParams& P, const DrawRec* draws, const QuadExt* exts) {
   if (P.x1 <= P.x0 || P.y1 <= P.y0) return;
-  if (blur_small(P)) launch_blur_v_n<2, 4>(s, P, draws, exts); else launch_blur_v_n<FDH_BLUR_NOUT, FDH_BLUR_VWAVES>(s, P, draws, exts);
+  if (blur_small(P)) { launch_blur_v_n<2, 4>(s, P, draws, exts); return; }
+  switch (blur_pick_nout(P.y1 - P.y0, FDH_BLUR_VWAVES, P.taps.reach)) {
+    case 12: launch_blur_v_n<12, FDH_BLUR_VWAVES>(s, P, draws, exts); break;
+    case 10: launch_blur_v_n<10, FDH_BLUR_VWAVES>(s, P, draws, exts); break;
+    case 16: launch_blur_v_n<16, FDH_BLUR_VWAVES>(s, P, draws, exts); break;
+    default: launch_blur_v_n<8, FDH_BLUR_VWAVES>(s, P, draws, exts); break;
+  }
 }
 // Frame upload as a kernel on the render stream: the source is pinned host memory mapped into the device's address
 // space, read over the host link 16 bytes per lane.  (hipMemcpyAsync hands the copy to another engine; the round trip
