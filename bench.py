@@ -50,7 +50,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for the 1-GPU self-test)")
     ap.add_argument("--all-ranks-on-device0", action="store_true", help="self-test of the N>1 code path on a 1-GPU box")
-    ap.add_argument("--frames-in-flight", type=int, default=3,
+    ap.add_argument("--frames-in-flight", type=int, default=4,
                     help="independent render contexts per GPU (own stream + surfaces) whose frames overlap; 1 = strictly one frame at a time")
     ap.add_argument("--width", type=int, default=W)
     ap.add_argument("--height", type=int, default=H)
@@ -90,7 +90,7 @@ def main():
 
     # Frames are independent, so a GPU keeps F of them in flight: F contexts, each with its own stream and surfaces,
     # rendering different frames of the animation.  One frame at a time leaves the machine idle in every kernel's ramp
-    # and tail and in the small dependent launches of a frame (measured: 49 -> 68 Gpixel/s from F = 1 -> 3).
+    # and tail and in the small dependent launches of a frame (measured: 53 -> 81 / 82 Gpixel/s from F = 1 -> 3 / 4; a fifth stream has no hardware queue of its own and loses).
     F = max(1, min(args.frames_in_flight, args.steps))
     ctxs = [ctx]
     for i in range(1, F):
