@@ -39,6 +39,10 @@ extern "C++" { namespace fdh { void debug_counters(unsigned long long out[64], b
 __attribute__((visibility("default"))) int fdh_debug_wave_times(unsigned long long* out) { fdh::debug_wave_times(out); return 0; }
 __attribute__((visibility("default"))) int fdh_debug_counters(unsigned long long out[64], int reset) { fdh::debug_counters(out, reset != 0); return 0; }
 #endif
+int fdh_saturated_core(const float rect[4], const float rx[4], const float ry[4], int mode, float factor, float spread,
+                       const float shape[2], float aa, int out_px[4]) {
+  return guard([&] { fdh::saturated_core_of(rect, rx, ry, mode, factor, spread, shape, aa, out_px); });
+}
 const char* fdh_version(void) { return "figdraw_hip 0.1.0 (gfx950)"; }
 int fdh_sizeof_fig(void) { return (int)sizeof(FdhFig); }
 int fdh_sizeof_glyph(void) { return (int)sizeof(FdhGlyph); }

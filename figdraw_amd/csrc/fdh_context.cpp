@@ -546,6 +546,23 @@ static void fill_sdf_rec(DrawRec& r, const float rect[4], const FdhColor colors[
   if (r.col[0] == r.col[1] && r.col[1] == r.col[2] && r.col[2] == r.col[3]) r.op_mode |= F_SOLID;
 }
 
+// Host-only (no device is touched): the saturated core the submission path would attach to this draw under the identity
+// transform.  Lets the CPU test-suite check the derivation against the oracle's pixels.
+void saturated_core_of(const float rect[4], const float rx[4], const float ry[4], int mode, float factor, float spread,
+                       const float shape[2], float aa, int out[4]) {
+  const FdhColor white{255, 255, 255, 255}, zero{0, 0, 0, 0};
+  const FdhColor cols[4] = {white, white, white, white};
+  DrawRec r;
+  fill_sdf_rec(r, rect, cols, rx, ry, mode, factor, spread, shape, 0, zero, zero, 0.5f, aa);
+  const float x0 = std::ceil(rect[0]), y0 = std::ceil(rect[1]), x1 = std::ceil(rect[0] + rect[2]), y1 = std::ceil(rect[1] + rect[3]);
+  out[0] = out[1] = out[2] = out[3] = 0;
+  if (!(x1 > x0 && y1 > y0)) return;
+  r.ox = x0; r.oy = y0;
+  r.inv_w = 1.0f / (x1 - x0); r.inv_h = 1.0f / (y1 - y0);
+  set_saturated_core(r, x1 - x0, y1 - y0);
+  out[0] = r.ix0; out[1] = r.iy0; out[2] = r.ix1; out[3] = r.iy1;
+}
+
 // drawRoundedRectSdfOpenGl: glcontext.nim:1449-1559
 void Context::draw_rounded_rect_sdf(const float rect[4], const FdhColor colors[4], const float rx[4], const float ry[4], int mode,
                                     float factor, float spread, const float shape[2], int fill_mode, FdhColor mid, FdhColor stop,

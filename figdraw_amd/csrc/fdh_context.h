@@ -233,4 +233,7 @@ class Context {
   float host_record_ms_ = 0.0f;
 };
 
+void saturated_core_of(const float rect[4], const float rx[4], const float ry[4], int mode, float factor, float spread,
+                       const float shape[2], float aa, int out[4]);
+
 }  // namespace fdh

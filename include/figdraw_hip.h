@@ -284,6 +284,11 @@ FDH_API int fdh_sizeof_fig(void);
 FDH_API int fdh_sizeof_glyph(void);
 FDH_API int fdh_sizeof_draw_op(void);
 FDH_API int fdh_sizeof_text_rect(void);
+/* Diagnostic, host-only (no device, no context): the pixel rectangle [x0,x1) x [y0,y1) the submission path marks as the
+ * draw's saturated core (coverage exactly 1, or a provable no-op for strokes / inner shadows) under the identity
+ * transform; all zeros when there is none.  Arguments as fdh_draw_rounded_rect_sdf. */
+FDH_API int fdh_saturated_core(const float rect[4], const float radii_x[4], const float radii_y[4], int mode, float factor,
+                               float spread, const float shape[2], float aa, int out_px[4]);
 FDH_API const char* fdh_version(void);
 
 #ifdef __cplusplus

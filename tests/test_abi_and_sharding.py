@@ -105,3 +105,57 @@ def test_two_rank_gloo_stripe_gather(tmp_path):
     outs = [p.communicate(timeout=240)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert "GATHER_OK" in outs[0]
+
+
+def test_saturated_core_is_conservative_against_the_oracle():
+    """Host logic, no GPU: the pixel rectangle the submission path marks as a draw's saturated core (fdh_saturated_core)
+    must hold what the kernels assume there -- coverage exactly 1 for fills / drop-shadow bodies, exactly no effect for
+    strokes and inner shadows -- checked on the oracle's pixels for random shapes with circular and elliptical corners at
+    fractional positions."""
+    import ctypes as C
+    import random
+
+    import numpy as np
+
+    from figdraw_amd import context
+    from oracle import oracle as O
+
+    L = context.load()
+    F4, F2, I4 = C.c_float * 4, C.c_float * 2, C.c_int * 4
+    L.fdh_saturated_core.argtypes = [F4, F4, F4, C.c_int, C.c_float, C.c_float, F2, C.c_float, I4]
+    rnd = random.Random(5)
+    W, H, aa = 160, 120, 1.2
+    bg = (0.2, 0.4, 0.6, 1.0)
+    bg8 = np.array([51, 102, 153, 255], np.uint8)
+    col = (250, 10, 30, 255)
+    found = 0
+    for it in range(120):
+        w, h = rnd.uniform(20, 130), rnd.uniform(20, 100)
+        x, y = rnd.uniform(2, W - w - 2), rnd.uniform(2, H - h - 2)
+        m = min(w, h) / 2
+        rx = [rnd.uniform(0, m) if rnd.random() < 0.7 else 0.0 for _ in range(4)]
+        ry = list(rx) if rnd.random() < 0.6 else [rnd.uniform(0, m) for _ in range(4)]
+        mode = rnd.choice([3, 3, 12, 11, 9, 7])
+        factor = {3: 4.0, 12: rnd.choice([1.5, 4.0, 9.0]), 11: 3.0, 9: rnd.uniform(1, 12), 7: rnd.uniform(2, 16)}[mode]
+        spread = rnd.uniform(0, 6) if mode in (7, 9) else 0.0
+        rect, shape = (x, y, w, h), (0.0, 0.0)
+        if mode == 7:  # drop shadow: padded quad around the shape (figrender.nim:654-689)
+            pad = 1.5 * factor + spread + 1.0
+            rect, shape = (x - pad, y - pad, w + 2 * pad, h + 2 * pad), (w, h)
+        if mode == 9:
+            shape = (rnd.uniform(-5, 5), rnd.uniform(-5, 5))  # inset: the shadow offset travels in shapeSize
+        out = I4()
+        assert L.fdh_saturated_core(F4(*rect), F4(*rx), F4(*ry), mode, factor, spread, F2(*shape), aa, out) == 0
+        x0, y0, x1, y1 = out
+        if x1 <= x0 or y1 <= y0:
+            continue
+        found += 1
+        o = O.Oracle(threads=2)
+        o.set_aa_factor(aa)
+        o.begin_frame(W, H, True, bg)
+        o.draw_rounded_rect_sdf(rect, [col] * 4, rx, ry, mode, factor, spread, shape)
+        o.end_frame()
+        core = o.read_pixels()[max(y0, 0):y1, max(x0, 0):x1]
+        want = np.array(col, np.uint8) if mode in (3, 7) else bg8
+        assert (core == want).all(), (it, mode, rect, rx, ry, factor, spread, shape, tuple(out))
+    assert found > 60
