@@ -955,38 +955,42 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? 4 : FDH_FAST_WAVES) void k_compo
 #endif
 #if FDH_SIMPLE_EDGE
       // ---- the common edge strip, written out in packed pairs: circular corners, ONE colour, nothing clipping, mode
-      // fill / drop shadow / AA stroke.  Pixels (0,1) and (2,3) of the lane share every add / mul / fma
+      // fill / drop shadow / inner shadow / AA stroke.  Pixels (0,1) and (2,3) of the lane share every add / mul / fma
       // (v_pk_*_f32); only compares, selects, min/max and the transcendentals stay per pixel.  Same formulas, same
       // order of operations as the generic path below.
       if (!core && !ellip && (om & F_SOLID) && fill_mode == 0u && op == OP_DRAW && mask_depth == 0 && !rmask_on &&
-          (mode == 3u || mode == 7u || mode == 12u)) {
-        const float shx = r.p2, shy = r.p3;
+          (mode == 3u || mode == 7u || mode == 9u || mode == 12u)) {
+        const bool inset = mode == 9u;
+        const float shx = inset ? r.p0 : r.p2, shy = inset ? r.p1 : r.p3;
         const float tq = (cy - r.oy) * r.inv_h;
         const float pyy = -((tq - 0.5f) * 2.0f * r.p1);
-        const bool top = pyy > 0.0f;
-        const float rR = top ? r.r[0] : r.r[1], rL = top ? r.r[2] : r.r[3];
-        const float ay = __builtin_fabsf(pyy) - shy;
         const f2 cxa = {cx0, cx0 + 1.0f}, cxb = {cx0 + 2.0f, cx0 + 3.0f};
         const f2 ua = (cxa - r.ox) * r.inv_w, ub = (cxb - r.ox) * r.inv_w;
-        const float qh2 = 2.0f * r.p0;
-        f2 lxa = (ua - 0.5f) * 2.0f * r.p0, lxb = (ub - 0.5f) * 2.0f * r.p0;
-        (void)qh2;
-        const f2 rra = {lxa.x > 0.0f ? rR : rL, lxa.y > 0.0f ? rR : rL}, rrb = {lxb.x > 0.0f ? rR : rL, lxb.y > 0.0f ? rR : rL};
-        const f2 axa = {__builtin_fabsf(lxa.x), __builtin_fabsf(lxa.y)}, axb = {__builtin_fabsf(lxb.x), __builtin_fabsf(lxb.y)};
-        const f2 qxa = axa - shx + rra, qxb = axb - shx + rrb;
-        const f2 qya = ay + rra, qyb = ay + rrb;
-        const f2 mxa = {__builtin_fmaxf(qxa.x, 0.0f), __builtin_fmaxf(qxa.y, 0.0f)}, mxb = {__builtin_fmaxf(qxb.x, 0.0f), __builtin_fmaxf(qxb.y, 0.0f)};
-        const f2 mya = {__builtin_fmaxf(qya.x, 0.0f), __builtin_fmaxf(qya.y, 0.0f)}, myb = {__builtin_fmaxf(qyb.x, 0.0f), __builtin_fmaxf(qyb.y, 0.0f)};
-        f2 lena = {__builtin_fmaxf(mxa.x, mya.x), __builtin_fmaxf(mxa.y, mya.y)}, lenb = {__builtin_fmaxf(mxb.x, myb.x), __builtin_fmaxf(mxb.y, myb.y)};
-        const f2 lowa = {__builtin_fminf(qxa.x, qya.x), __builtin_fminf(qxa.y, qya.y)}, lowb = {__builtin_fminf(qxb.x, qyb.x), __builtin_fminf(qxb.y, qyb.y)};
-        if (__any(lowa.x > 0.0f || lowa.y > 0.0f || lowb.x > 0.0f || lowb.y > 0.0f)) {  // some lane sits in a corner cell
-          const f2 sa2 = mxa * mxa + mya * mya, sb2 = mxb * mxb + myb * myb;
-          lena.x = lowa.x > 0.0f ? fsqrt(sa2.x) : lena.x; lena.y = lowa.y > 0.0f ? fsqrt(sa2.y) : lena.y;
-          lenb.x = lowb.x > 0.0f ? fsqrt(sb2.x) : lenb.x; lenb.y = lowb.y > 0.0f ? fsqrt(sb2.y) : lenb.y;
-        }
-        const f2 ina = {__builtin_fminf(__builtin_fmaxf(qxa.x, qya.x), 0.0f), __builtin_fminf(__builtin_fmaxf(qxa.y, qya.y), 0.0f)};
-        const f2 inb = {__builtin_fminf(__builtin_fmaxf(qxb.x, qyb.x), 0.0f), __builtin_fminf(__builtin_fmaxf(qxb.y, qyb.y), 0.0f)};
-        const f2 da = ina + lena - rra, db = inb + lenb - rrb;
+        const f2 lxa = (ua - 0.5f) * 2.0f * r.p0, lxb = (ub - 0.5f) * 2.0f * r.p0;
+        // sdRoundedBox (atlas.frag:51-69) of the lane's four pixels at height py for half extents (bx, by)
+        auto dist4 = [&](const f2 pxa, const f2 pxb, const float py_, const float bx, const float by, f2& da, f2& db) __attribute__((always_inline)) {
+          const bool top = py_ > 0.0f;
+          const float rR = top ? r.r[0] : r.r[1], rL = top ? r.r[2] : r.r[3];
+          const float ay = __builtin_fabsf(py_) - by;
+          const f2 rra = {pxa.x > 0.0f ? rR : rL, pxa.y > 0.0f ? rR : rL}, rrb = {pxb.x > 0.0f ? rR : rL, pxb.y > 0.0f ? rR : rL};
+          const f2 axa = {__builtin_fabsf(pxa.x), __builtin_fabsf(pxa.y)}, axb = {__builtin_fabsf(pxb.x), __builtin_fabsf(pxb.y)};
+          const f2 qxa = axa - bx + rra, qxb = axb - bx + rrb;
+          const f2 qya = ay + rra, qyb = ay + rrb;
+          const f2 mxa = {__builtin_fmaxf(qxa.x, 0.0f), __builtin_fmaxf(qxa.y, 0.0f)}, mxb = {__builtin_fmaxf(qxb.x, 0.0f), __builtin_fmaxf(qxb.y, 0.0f)};
+          const f2 mya = {__builtin_fmaxf(qya.x, 0.0f), __builtin_fmaxf(qya.y, 0.0f)}, myb = {__builtin_fmaxf(qyb.x, 0.0f), __builtin_fmaxf(qyb.y, 0.0f)};
+          f2 lena = {__builtin_fmaxf(mxa.x, mya.x), __builtin_fmaxf(mxa.y, mya.y)}, lenb = {__builtin_fmaxf(mxb.x, myb.x), __builtin_fmaxf(mxb.y, myb.y)};
+          const f2 lowa = {__builtin_fminf(qxa.x, qya.x), __builtin_fminf(qxa.y, qya.y)}, lowb = {__builtin_fminf(qxb.x, qyb.x), __builtin_fminf(qxb.y, qyb.y)};
+          if (__any(lowa.x > 0.0f || lowa.y > 0.0f || lowb.x > 0.0f || lowb.y > 0.0f)) {  // some lane sits in a corner cell
+            const f2 sa2 = mxa * mxa + mya * mya, sb2 = mxb * mxb + myb * myb;
+            lena.x = lowa.x > 0.0f ? fsqrt(sa2.x) : lena.x; lena.y = lowa.y > 0.0f ? fsqrt(sa2.y) : lena.y;
+            lenb.x = lowb.x > 0.0f ? fsqrt(sb2.x) : lenb.x; lenb.y = lowb.y > 0.0f ? fsqrt(sb2.y) : lenb.y;
+          }
+          const f2 ina = {__builtin_fminf(__builtin_fmaxf(qxa.x, qya.x), 0.0f), __builtin_fminf(__builtin_fmaxf(qxa.y, qya.y), 0.0f)};
+          const f2 inb = {__builtin_fminf(__builtin_fmaxf(qxb.x, qyb.x), 0.0f), __builtin_fminf(__builtin_fmaxf(qxb.y, qyb.y), 0.0f)};
+          da = ina + lena - rra; db = inb + lenb - rrb;
+        };
+        f2 da, db;
+        dist4(lxa, lxb, pyy, shx, shy, da, db);
         f2 ala, alb;  // coverage
         if (mode == 3u) {
           const f2 ta = da * r.aa + 0.5f, tb = db * r.aa + 0.5f;
@@ -998,6 +1002,19 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? 4 : FDH_FAST_WAVES) void k_compo
           const f2 ta = (ga - h) * r.aa + 0.5f, tb = (gb - h) * r.aa + 0.5f;
           ala = {1.0f - clamp01(ta.x), 1.0f - clamp01(ta.y)}; alb = {1.0f - clamp01(tb.x), 1.0f - clamp01(tb.y)};
           if (__all(ala.x == 0.0f && ala.y == 0.0f && alb.x == 0.0f && alb.y == 0.0f)) return;  // inside the stroke: no-op
+        } else if (inset) {  // 9: atlas.frag:364-380 -- clip alpha of the node's own shape x the falloff inside the offset shape
+          f2 sha, shb;
+          dist4(lxa - r.p2, lxb - r.p2, pyy + r.p3, r.p0, r.p1, sha, shb);
+          const float spread = r.f1;
+          const f2 sda = sha + spread, sdb = shb + spread;
+          const float rs = frcp(__builtin_fmaxf(0.5f * r.f0, 0.5f));
+          const f2 za = sda * rs, zb = sdb * rs;
+          const f2 ea = -0.72134752044f * za * za, eb = -0.72134752044f * zb * zb;
+          const f2 ta = da * r.aa + 0.5f, tb = db * r.aa + 0.5f;
+          ala = {(1.0f - clamp01(ta.x)) * (sda.x < 0.0f ? __builtin_fminf(fexp2(ea.x), 1.0f) : 1.0f),
+                 (1.0f - clamp01(ta.y)) * (sda.y < 0.0f ? __builtin_fminf(fexp2(ea.y), 1.0f) : 1.0f)};
+          alb = {(1.0f - clamp01(tb.x)) * (sdb.x < 0.0f ? __builtin_fminf(fexp2(eb.x), 1.0f) : 1.0f),
+                 (1.0f - clamp01(tb.y)) * (sdb.y < 0.0f ? __builtin_fminf(fexp2(eb.y), 1.0f) : 1.0f)};
         } else {  // 7: atlas.frag:330-343
           const float spread = r.f1;
           const f2 sda = da - spread, sdb = db - spread;
