@@ -61,7 +61,7 @@ Context::~Context() {
   if (fb_) (void)hipFree(fb_);
   if (backdrop_) (void)hipFree(backdrop_);
   if (blur_tmp_) (void)hipFree(blur_tmp_);
-  d_frame_.release(); d_lists_.release(); d_counts_.release();
+  d_frame_.release(); d_lists_.release(); d_counts_.release(); d_order_.release();
   for (auto& b : staging_) b.release();
   for (auto& e : staging_ev_) if (e) (void)hipEventDestroy(e);
   if (own_stream_) (void)hipStreamDestroy(own_stream_);
@@ -1052,6 +1052,10 @@ void Context::launch_frame(bool profile) {
   B.bbox = dv_.bboxes; B.draws = dv_.recs; B.binbox = dv_.binbox; B.n_draws = (int)recs_.size(); B.binbox_shift = binbox_shift_; B.lists = d_lists_.ptr; B.counts = d_counts_.ptr; B.phase_first = dv_.phase_first;
   B.n_phases = np; B.bins_x = bins_x_; B.bins_y = bins_y_; B.stride = list_stride_;
   launch_bin(stream_, B);
+  if (clear_ && np > 0) {  // the full-grid composite of phase 0 takes its bins longest-list first
+    d_order_.reserve(nb);
+    launch_order_bins(stream_, d_counts_.ptr, d_order_.ptr, nb);
+  }
   span_end();
   for (int p = 0; p < np; p++) {
     const Phase& ph = phases_[p];
@@ -1093,6 +1097,7 @@ void Context::launch_frame(bool profile) {
     C.load_fb = full ? 0 : 1;
     C.clear_rgba8 = clear_rgba8_;
     C.n_wg = 0;
+    C.order = full ? d_order_.ptr : nullptr;  // phase 0 covers the whole bin grid: longest lists first
     C.has_slow = ph.has_slow ? 1 : 0;
     C.has_atlas = ph.has_atlas ? 1 : 0;
     C.has_masks = ph.has_masks ? 1 : 0;
