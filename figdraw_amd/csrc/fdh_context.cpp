@@ -1052,7 +1052,8 @@ void Context::launch_frame(bool profile) {
   B.bbox = dv_.bboxes; B.draws = dv_.recs; B.binbox = dv_.binbox; B.n_draws = (int)recs_.size(); B.binbox_shift = binbox_shift_; B.lists = d_lists_.ptr; B.counts = d_counts_.ptr; B.phase_first = dv_.phase_first;
   B.n_phases = np; B.bins_x = bins_x_; B.bins_y = bins_y_; B.stride = list_stride_;
   launch_bin(stream_, B);
-  if (clear_ && np > 0) {  // the full-grid composite of phase 0 takes its bins longest-list first
+  const bool ordered = clear_ && np > 0 && order_bins_supported(nb);
+  if (ordered) {  // the full-grid composite of phase 0 takes its bins longest-list first
     d_order_.reserve(nb);
     launch_order_bins(stream_, d_counts_.ptr, d_order_.ptr, nb);
   }
@@ -1097,7 +1098,7 @@ void Context::launch_frame(bool profile) {
     C.load_fb = full ? 0 : 1;
     C.clear_rgba8 = clear_rgba8_;
     C.n_wg = 0;
-    C.order = full ? d_order_.ptr : nullptr;  // phase 0 covers the whole bin grid: longest lists first
+    C.order = (full && ordered) ? d_order_.ptr : nullptr;  // phase 0 covers the whole bin grid: longest lists first
     C.has_slow = ph.has_slow ? 1 : 0;
     C.has_atlas = ph.has_atlas ? 1 : 0;
     C.has_masks = ph.has_masks ? 1 : 0;

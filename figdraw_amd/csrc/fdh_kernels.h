@@ -51,6 +51,7 @@ void launch_bin(hipStream_t s, const BinParams& P);
 void launch_composite(hipStream_t s, const DrawRec* draws, const QuadExt* exts, CompositeParams P);
 void launch_blur_h(hipStream_t s, const BlurParams& P);
 void launch_blur_v(hipStream_t s, const BlurParams& P, const DrawRec* draws, const QuadExt* exts);
+bool order_bins_supported(int nb);  // one workgroup sorts up to 8192 bins
 void launch_order_bins(hipStream_t s, const uint32_t* counts, int* order, int nb);
 void launch_fill(hipStream_t s, uint32_t* p, uint32_t v, size_t n);
 void launch_upload(hipStream_t s, void* dst, const void* src_mapped, size_t bytes);  // src: device view of pinned host memory

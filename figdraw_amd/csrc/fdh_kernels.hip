@@ -368,18 +368,20 @@ __global__ __launch_bounds__(64) void k_bin_draws(BinParams P) {
 // min(count, 255); the order among equal keys is whatever the LDS atomics give -- bins are independent, only the
 // schedule changes).  A strip's cost is roughly its list length, and a launch ends when its last wave does: started in
 // frame order, a 60-entry strip picked up near the end ran on alone for a fifth of the kernel (58 -> 48 us).
-__global__ __launch_bounds__(256) void k_order_bins(const uint32_t* __restrict__ counts, int* __restrict__ order, int nb) {
+constexpr int kOrderThreads = 1024, kOrderPer = 8;  // one workgroup sorts up to 8192 bins with every count in a register
+__global__ __launch_bounds__(kOrderThreads) void k_order_bins(const uint32_t* __restrict__ counts, int* __restrict__ order, int nb) {
   __shared__ uint32_t offs[256];
-  offs[threadIdx.x] = 0;
-  __syncthreads();
-  constexpr int kPer = 8;  // bins per thread and pass: their counts are fetched together
-  for (int i0 = threadIdx.x; i0 < nb; i0 += 256 * kPer) {
-    uint32_t c[kPer];
+  if (threadIdx.x < 256) offs[threadIdx.x] = 0;
+  // all loads first (one latency), keys kept in registers for the scatter
+  uint32_t key[kOrderPer];
 #pragma unroll
-    for (int k = 0; k < kPer; k++) c[k] = i0 + 256 * k < nb ? counts[i0 + 256 * k] : 0xffffffffu;
-#pragma unroll
-    for (int k = 0; k < kPer; k++) if (c[k] != 0xffffffffu) atomicAdd(&offs[255u - min(c[k], 255u)], 1u);
+  for (int k = 0; k < kOrderPer; k++) {
+    const int i = threadIdx.x + kOrderThreads * k;
+    key[k] = i < nb ? 255u - min(counts[i], 255u) : 0xffffffffu;
   }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < kOrderPer; k++) if (key[k] != 0xffffffffu) atomicAdd(&offs[key[k]], 1u);
   __syncthreads();
   if (threadIdx.x < 64) {  // exclusive prefix over the 256 buckets: 4 per lane, then a wave scan
     const int l = threadIdx.x;
@@ -394,13 +396,9 @@ __global__ __launch_bounds__(256) void k_order_bins(const uint32_t* __restrict__
     offs[4 * l] = base; offs[4 * l + 1] = base + a; offs[4 * l + 2] = base + a + b; offs[4 * l + 3] = base + a + b + c2;
   }
   __syncthreads();
-  for (int i0 = threadIdx.x; i0 < nb; i0 += 256 * kPer) {
-    uint32_t c[kPer];
 #pragma unroll
-    for (int k = 0; k < kPer; k++) c[k] = i0 + 256 * k < nb ? counts[i0 + 256 * k] : 0xffffffffu;
-#pragma unroll
-    for (int k = 0; k < kPer; k++) if (c[k] != 0xffffffffu) order[atomicAdd(&offs[255u - min(c[k], 255u)], 1u)] = i0 + 256 * k;
-  }
+  for (int k = 0; k < kOrderPer; k++)
+    if (key[k] != 0xffffffffu) order[atomicAdd(&offs[key[k]], 1u)] = threadIdx.x + kOrderThreads * k;
 }
 
 // ------------------------------------------------------------------ compositing
@@ -1613,8 +1611,9 @@ void launch_upload(hipStream_t s, void* dst, const void* src_mapped, size_t byte
   hipLaunchKernelGGL(k_upload, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, s, reinterpret_cast<uint4*>(dst),
                      reinterpret_cast<const uint4*>(src_mapped), n16);
 }
+bool order_bins_supported(int nb) { return nb > 0 && nb <= kOrderThreads * kOrderPer; }
 void launch_order_bins(hipStream_t s, const uint32_t* counts, int* order, int nb) {
-  if (nb > 0) hipLaunchKernelGGL(k_order_bins, dim3(1), dim3(256), 0, s, counts, order, nb);
+  if (nb > 0 && nb <= kOrderThreads * kOrderPer) hipLaunchKernelGGL(k_order_bins, dim3(1), dim3(kOrderThreads), 0, s, counts, order, nb);
 }
 void launch_fill(hipStream_t s, uint32_t* p, uint32_t v, size_t n) {
   if (n == 0) return;
