@@ -80,6 +80,30 @@ def test_render_is_deterministic_and_replay_is_idempotent(hip):
     assert (a == b).all() and (a == c).all()
 
 
+def test_contexts_in_flight_do_not_disturb_each_other(hip):
+    """bench.py keeps several frames in flight on one GPU (one context = one stream + surface set each): every context
+    must end up with exactly the frame it renders alone."""
+    from figdraw_amd.context import HipContext
+    from figdraw_amd.scenes import make_render_tree_100
+
+    w, h = 1280, 720
+    scenes = [make_render_tree_100(w, h, frame=f, copies=40, full_frame_blur=True) for f in range(3)]
+    alone = []
+    for sc in scenes:
+        hip.render_frame(sc, w, h)
+        alone.append(hip.read_pixels())
+    ctxs = [HipContext(device=0) for _ in scenes]
+    for c, sc in zip(ctxs, scenes):
+        c.render_frame(sc, w, h)
+    for _ in range(6):  # interleaved enqueues, no waiting in between
+        for c in ctxs:
+            c.replay_async(3)
+    for c, want in zip(ctxs, alone):
+        c.sync()
+        assert np.array_equal(c.read_pixels(), want)
+        c.close()
+
+
 def test_workload_scene_1080p_matches_oracle(hip):
     """BASELINE config 2: renderlist_100 at 1920x1080 (304 nodes / 706 draws)."""
     from figdraw_amd.scenes import make_render_tree_100
