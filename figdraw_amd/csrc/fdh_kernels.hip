@@ -13,6 +13,8 @@
 
 #include "fdh_kernels.h"
 
+#include <cstdlib>
+
 namespace fdh {
 
 // Build switches.  What was tried and dropped is in DESIGN.md section 4 (register prefetch of the next record, 4-wave
@@ -1539,6 +1541,11 @@ void launch_composite(hipStream_t s, const DrawRec* draws, const QuadExt* exts, 
   const int bins8 = (P.bin_nx * P.bin_ny + 7) / 8;  // bins per XCD
   const int grid = 8 * bins8 * kWgsPerBin * kWavesPerWg;  // 16 strips per bin, one wavefront each
   const dim3 blk(64);
+  // FDH_FORCE_KERNEL_PATHS=3 (or 2): run a more general build than the phase needs -- a test hook: every build must give
+  // the same pixels (tests/test_hip_parity.py)
+  static const int force = [] { const char* e = std::getenv("FDH_FORCE_KERNEL_PATHS"); return e ? std::atoi(e) : 0; }();
+  if (force == 3) P.has_slow = 1;
+  if (force == 2) P.has_atlas = 1;
   if (P.has_slow) hipLaunchKernelGGL(k_composite_tiles<3>, dim3(grid), blk, 0, s, draws, exts, P);
   else if (P.has_atlas) hipLaunchKernelGGL(k_composite_tiles<2>, dim3(grid), blk, 0, s, draws, exts, P);
   else hipLaunchKernelGGL(k_composite_tiles<0>, dim3(grid), blk, 0, s, draws, exts, P);

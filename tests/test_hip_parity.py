@@ -80,6 +80,41 @@ def test_render_is_deterministic_and_replay_is_idempotent(hip):
     assert (a == b).all() and (a == c).all()
 
 
+@pytest.mark.parametrize("paths", [2, 3])
+def test_every_kernel_build_gives_the_same_pixels(hip, paths):
+    """k_composite_tiles comes in three builds (SDF only / + 4-wide atlas path / + one-pixel-slot path) picked per phase.
+    Forcing the more general builds onto SDF-only scenes (a child process with FDH_FORCE_KERNEL_PATHS) must not change a
+    pixel."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+
+    names = ["oneframe", "nested_clips", "elliptical_and_fractional", "backdrop_blur"]
+    code = (
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import ref_scenes as RS\n"
+        "from figdraw_amd.context import HipContext\n"
+        "ctx = HipContext(device=0)\n"
+        "out = {}\n"
+        "for n in %r:\n"
+        "    fn, w, h = RS.SWIFTSHADER_SCENES[n]\n"
+        "    ctx.render_frame(fn(float(w), float(h)), w, h); out[n] = ctx.read_pixels()\n"
+        "sc = RS.random_scene(21, 700.0, 500.0, n=70)\n"
+        "ctx.render_frame(sc, 700, 500); out['fuzz'] = ctx.read_pixels()\n"
+        "np.savez(sys.argv[1], **out)\n"
+    ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)), names)
+    with tempfile.TemporaryDirectory() as td:
+        res = {}
+        for tag, env in (("default", {}), ("forced", {"FDH_FORCE_KERNEL_PATHS": str(paths)})):
+            path = os.path.join(td, tag + ".npz")
+            subprocess.check_call([sys.executable, "-c", code, path], env={**os.environ, **env})
+            res[tag] = dict(np.load(path))
+        for k in res["default"]:
+            assert np.array_equal(res["default"][k], res["forced"][k]), (paths, k)
+
+
 def test_contexts_in_flight_do_not_disturb_each_other(hip):
     """bench.py keeps several frames in flight on one GPU (one context = one stream + surface set each): every context
     must end up with exactly the frame it renders alone."""
