@@ -61,7 +61,7 @@ Context::~Context() {
   if (fb_) (void)hipFree(fb_);
   if (backdrop_) (void)hipFree(backdrop_);
   if (blur_tmp_) (void)hipFree(blur_tmp_);
-  d_frame_.release(); d_lists_.release(); d_counts_.release(); d_order_.release();
+  d_frame_.release(); d_lists_.release(); d_counts_.release(); d_order_[0].release(); d_order_[1].release();
   for (auto& b : staging_) b.release();
   for (auto& e : staging_ev_) if (e) (void)hipEventDestroy(e);
   if (own_stream_) (void)hipStreamDestroy(own_stream_);
@@ -1052,12 +1052,21 @@ void Context::launch_frame(bool profile) {
   B.bbox = dv_.bboxes; B.draws = dv_.recs; B.binbox = dv_.binbox; B.n_draws = (int)recs_.size(); B.binbox_shift = binbox_shift_; B.lists = d_lists_.ptr; B.counts = d_counts_.ptr; B.phase_first = dv_.phase_first;
   B.n_phases = np; B.bins_x = bins_x_; B.bins_y = bins_y_; B.stride = list_stride_;
   launch_bin(stream_, B);
-  const bool ordered = clear_ && np > 0 && order_bins_supported(nb);
-  if (ordered) {  // the full-grid composite of phase 0 takes its bins longest-list first
-    d_order_.reserve(nb);
-    launch_order_bins(stream_, d_counts_.ptr, d_order_.ptr, nb);
-  }
   span_end();
+  // Phase 0's full-grid composite takes its bins longest-list first, in the order its predecessor sorted (an extra
+  // wavefront of that launch); it sorts this frame's counts for its successor.  Any permutation is a correct schedule.
+  if (order_valid_ && order_nb_ != nb) order_valid_ = false;  // frame size changed
+  const bool sorting = clear_ && np > 0 && nb <= 8192 && phases_[0].count > 0;
+  const int* order_now = (sorting && order_valid_) ? d_order_[order_read_].ptr : nullptr;
+  int* order_next = nullptr;
+  if (sorting) {
+    const int wr = order_valid_ ? 1 - order_read_ : order_read_;
+    d_order_[wr].reserve(nb);
+    order_next = d_order_[wr].ptr;
+    order_read_ = wr;
+    order_nb_ = nb;
+    order_valid_ = true;
+  }
   for (int p = 0; p < np; p++) {
     const Phase& ph = phases_[p];
     if (ph.blur >= 0) {
@@ -1098,7 +1107,8 @@ void Context::launch_frame(bool profile) {
     C.load_fb = full ? 0 : 1;
     C.clear_rgba8 = clear_rgba8_;
     C.n_wg = 0;
-    C.order = (full && ordered) ? d_order_.ptr : nullptr;  // phase 0 covers the whole bin grid: longest lists first
+    C.order = full ? order_now : nullptr;
+    C.order_next = full ? order_next : nullptr;
     C.has_slow = ph.has_slow ? 1 : 0;
     C.has_atlas = ph.has_atlas ? 1 : 0;
     C.has_masks = ph.has_masks ? 1 : 0;

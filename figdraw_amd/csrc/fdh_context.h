@@ -213,7 +213,9 @@ class Context {
   struct View { DrawRec* recs = nullptr; QuadExt* exts = nullptr; BBox* bboxes = nullptr; int* phase_first = nullptr; uint32_t* binbox = nullptr; } dv_;
   DeviceBuf<uint2> d_lists_;
   DeviceBuf<uint32_t> d_counts_;
-  DeviceBuf<int> d_order_;  // phase 0's bins, longest list first (k_order_bins)
+  DeviceBuf<int> d_order_[2];  // phase 0's bins, longest list first: read by this frame's launch / written for the next
+  int order_read_ = 0, order_nb_ = 0;
+  bool order_valid_ = false;
   // three pinned staging buffers in rotation, each guarded by an event recorded after its copies: the host builds
   // frame N+1 and N+2 while frame N still runs (a single buffer forced a stream sync per frame)
   static constexpr int kStaging = 3;

@@ -30,7 +30,9 @@ struct CompositeParams {
   int load_fb;              // 0: start from clear_rgba8
   uint32_t clear_rgba8;
   int n_wg;                 // total workgroups (for the XCD remap)
-  const int* order;         // bins of a full-grid launch sorted by list length, longest first (k_order_bins), or null
+  const int* order;         // bins of a full-grid launch sorted by list length, longest first, or null (built by the
+                            // previous frame's launch)
+  int* order_next;          // if set, one extra wavefront of this launch sorts this frame's counts into it
   int has_masks;            // the phase holds clip / rect-mask ops (disables per-strip occlusion culling)
   int has_slow;             // the phase holds draws that need the one-pixel-slot path (k_composite_tiles<3>)
   int has_atlas;            // ... or axis-aligned atlas quads at >= 1:1 (k_composite_tiles<2>)
@@ -51,8 +53,6 @@ void launch_bin(hipStream_t s, const BinParams& P);
 void launch_composite(hipStream_t s, const DrawRec* draws, const QuadExt* exts, CompositeParams P);
 void launch_blur_h(hipStream_t s, const BlurParams& P);
 void launch_blur_v(hipStream_t s, const BlurParams& P, const DrawRec* draws, const QuadExt* exts);
-bool order_bins_supported(int nb);  // one workgroup sorts up to 8192 bins
-void launch_order_bins(hipStream_t s, const uint32_t* counts, int* order, int nb);
 void launch_fill(hipStream_t s, uint32_t* p, uint32_t v, size_t n);
 void launch_upload(hipStream_t s, void* dst, const void* src_mapped, size_t bytes);  // src: device view of pinned host memory
 

@@ -369,38 +369,41 @@ __global__ __launch_bounds__(64) void k_bin_draws(BinParams P) {
 // Longest-processing-time-first order for the compositor: bins sorted by list length, descending (counting sort on
 // min(count, 255); the order among equal keys is whatever the LDS atomics give -- bins are independent, only the
 // schedule changes).  A strip's cost is roughly its list length, and a launch ends when its last wave does: started in
-// frame order, a 60-entry strip picked up near the end ran on alone for a fifth of the kernel (58 -> 48 us).
-constexpr int kOrderThreads = 1024, kOrderPer = 8;  // one workgroup sorts up to 8192 bins with every count in a register
-__global__ __launch_bounds__(kOrderThreads) void k_order_bins(const uint32_t* __restrict__ counts, int* __restrict__ order, int nb) {
-  __shared__ uint32_t offs[256];
-  if (threadIdx.x < 256) offs[threadIdx.x] = 0;
-  // all loads first (one latency), keys kept in registers for the scatter
-  uint32_t key[kOrderPer];
+// frame order, a 60-entry strip picked up near the end ran on alone for a fifth of the kernel (58 -> 48 us).  The sort is
+// done by ONE wavefront with 256 words of LDS, from inside k_composite_tiles (see there)
+__device__ __forceinline__ void order_bins_wave(const uint32_t* __restrict__ counts, int* __restrict__ order, int nb, uint32_t* offs, int lane) {
 #pragma unroll
-  for (int k = 0; k < kOrderPer; k++) {
-    const int i = threadIdx.x + kOrderThreads * k;
-    key[k] = i < nb ? 255u - min(counts[i], 255u) : 0xffffffffu;
+  for (int k = 0; k < 4; k++) offs[lane + 64 * k] = 0;
+  __builtin_amdgcn_wave_barrier();
+  constexpr int kU = 8;
+  for (int i0 = lane; i0 < nb; i0 += 64 * kU) {
+    uint32_t c[kU];
+#pragma unroll
+    for (int k = 0; k < kU; k++) c[k] = i0 + 64 * k < nb ? counts[i0 + 64 * k] : 0xffffffffu;
+#pragma unroll
+    for (int k = 0; k < kU; k++) if (c[k] != 0xffffffffu) atomicAdd(&offs[255u - min(c[k], 255u)], 1u);
   }
-  __syncthreads();
-#pragma unroll
-  for (int k = 0; k < kOrderPer; k++) if (key[k] != 0xffffffffu) atomicAdd(&offs[key[k]], 1u);
-  __syncthreads();
-  if (threadIdx.x < 64) {  // exclusive prefix over the 256 buckets: 4 per lane, then a wave scan
-    const int l = threadIdx.x;
-    const uint32_t a = offs[4 * l], b = offs[4 * l + 1], c2 = offs[4 * l + 2], d = offs[4 * l + 3];
+  __builtin_amdgcn_wave_barrier();
+  {
+    const uint32_t a = offs[4 * lane], b = offs[4 * lane + 1], c2 = offs[4 * lane + 2], d = offs[4 * lane + 3];
     uint32_t incl = a + b + c2 + d;
 #pragma unroll
     for (int sh = 1; sh < 64; sh <<= 1) {
       const uint32_t up = __shfl_up(incl, sh, 64);
-      if (l >= sh) incl += up;
+      if (lane >= sh) incl += up;
     }
     const uint32_t base = incl - (a + b + c2 + d);
-    offs[4 * l] = base; offs[4 * l + 1] = base + a; offs[4 * l + 2] = base + a + b; offs[4 * l + 3] = base + a + b + c2;
+    __builtin_amdgcn_wave_barrier();
+    offs[4 * lane] = base; offs[4 * lane + 1] = base + a; offs[4 * lane + 2] = base + a + b; offs[4 * lane + 3] = base + a + b + c2;
   }
-  __syncthreads();
+  __builtin_amdgcn_wave_barrier();
+  for (int i0 = lane; i0 < nb; i0 += 64 * kU) {
+    uint32_t c[kU];
 #pragma unroll
-  for (int k = 0; k < kOrderPer; k++)
-    if (key[k] != 0xffffffffu) order[atomicAdd(&offs[key[k]], 1u)] = threadIdx.x + kOrderThreads * k;
+    for (int k = 0; k < kU; k++) c[k] = i0 + 64 * k < nb ? counts[i0 + 64 * k] : 0xffffffffu;
+#pragma unroll
+    for (int k = 0; k < kU; k++) if (c[k] != 0xffffffffu) order[atomicAdd(&offs[255u - min(c[k], 255u)], 1u)] = i0 + 64 * k;
+  }
 }
 
 // ------------------------------------------------------------------ compositing
@@ -762,7 +765,18 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? 4 : FDH_FAST_WAVES) void k_compo
   // of the ones holding the emptier top and bottom of the frame.
   constexpr int kStripsPerBin = kWgsPerBin * kWavesPerWg;  // 16
   // (a workgroup is ONE wavefront: nothing is shared between strips, and the dispatcher refills wave slots one at a time)
-  const int q = blockIdx.x >> 3, xcd = blockIdx.x & 7;
+  // (with a sort riding along, the first eight workgroups are its: one sorts, dispatched first so it is done long before
+  // the launch ends; the numbering of the rest shifts by eight and keeps its XCD phase)
+  const int blk = P.order_next ? (int)blockIdx.x - 8 : (int)blockIdx.x;
+  if (blk < 0 && blockIdx.x != 0) return;
+  const int q = blk >> 3, xcd = blk & 7;
+  if (blk < 0) {
+    // One extra wavefront per full-frame launch sorts THIS frame's bin counts for the NEXT frame's launch (any
+    // permutation is a correct schedule, and list lengths barely change from frame to frame).  As a kernel of its own the
+    // sort was a ~6 us serial step of every frame; here it runs beside 32 000 compositing waves.
+    order_bins_wave(P.counts, P.order_next, P.bin_nx * P.bin_ny, &mask_stack[0][0][0], threadIdx.x);
+    return;
+  }
   int bin_local = xcd + 8 * (q / kStripsPerBin);
   const int sidx = q % kStripsPerBin;
   if (bin_local >= P.bin_nx * P.bin_ny) return;
@@ -1539,7 +1553,7 @@ void launch_composite(hipStream_t s, const DrawRec* draws, const QuadExt* exts, 
   if (n <= 0) return;
   P.n_wg = n;
   const int bins8 = (P.bin_nx * P.bin_ny + 7) / 8;  // bins per XCD
-  const int grid = 8 * bins8 * kWgsPerBin * kWavesPerWg;  // 16 strips per bin, one wavefront each
+  const int grid = 8 * bins8 * kWgsPerBin * kWavesPerWg + (P.order_next ? 8 : 0);  // 16 strips per bin, one wavefront each (+ the sorting one)
   const dim3 blk(64);
   // FDH_FORCE_KERNEL_PATHS=3 (or 2): run a more general build than the phase needs -- a test hook: every build must give
   // the same pixels (tests/test_hip_parity.py)
@@ -1617,10 +1631,6 @@ void launch_upload(hipStream_t s, void* dst, const void* src_mapped, size_t byte
   if (n16 == 0) return;
   hipLaunchKernelGGL(k_upload, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, s, reinterpret_cast<uint4*>(dst),
                      reinterpret_cast<const uint4*>(src_mapped), n16);
-}
-bool order_bins_supported(int nb) { return nb > 0 && nb <= kOrderThreads * kOrderPer; }
-void launch_order_bins(hipStream_t s, const uint32_t* counts, int* order, int nb) {
-  if (nb > 0 && nb <= kOrderThreads * kOrderPer) hipLaunchKernelGGL(k_order_bins, dim3(1), dim3(kOrderThreads), 0, s, counts, order, nb);
 }
 void launch_fill(hipStream_t s, uint32_t* p, uint32_t v, size_t n) {
   if (n == 0) return;
