@@ -962,14 +962,16 @@ void Context::submit(bool upload) {
     auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
     const size_t b_recs = n * sizeof(DrawRec), b_ext = exts_.size() * sizeof(QuadExt), b_bb = n * sizeof(BBox), b_pf = pf.size() * sizeof(int);
     const size_t b_box = ((n + 3) & ~(size_t)3) * sizeof(uint32_t);
-    const size_t o_recs = 0, o_ext = up(o_recs + b_recs), o_bb = up(o_ext + b_ext), o_box = up(o_bb + b_bb), o_pf = up(o_box + b_box),
-                 total = up(o_pf + b_pf);
+    const size_t n_chunks = (n + 255) / 256, b_chunk = std::max<size_t>(n_chunks, 1) * sizeof(uint32_t);
+    const size_t o_recs = 0, o_ext = up(o_recs + b_recs), o_bb = up(o_ext + b_ext), o_box = up(o_bb + b_bb), o_chunk = up(o_box + b_box),
+                 o_pf = up(o_chunk + b_chunk), total = up(o_pf + b_pf);
     d_frame_.reserve(total);
     dv_.recs = reinterpret_cast<DrawRec*>(d_frame_.ptr + o_recs);
     dv_.exts = reinterpret_cast<QuadExt*>(d_frame_.ptr + o_ext);
     dv_.bboxes = reinterpret_cast<BBox*>(d_frame_.ptr + o_bb);
     dv_.phase_first = reinterpret_cast<int*>(d_frame_.ptr + o_pf);
     dv_.binbox = reinterpret_cast<uint32_t*>(d_frame_.ptr + o_box);
+    dv_.chunkbox = reinterpret_cast<uint32_t*>(d_frame_.ptr + o_chunk);
     const int slot = staging_i_;
     staging_i_ = (staging_i_ + 1) % kStaging;
     if (staging_busy_[slot]) FDH_HIP(hipEventSynchronize(staging_ev_[slot]));  // its copy of three frames ago
@@ -990,6 +992,18 @@ void Context::submit(bool upload) {
               ((127u - (uint32_t)((b.y1 - 1) / unit)) << 24);
         }
         bxp[i] = v;
+      }
+      // second level: the union box of every 256 draws = byte-wise min (x0, y0 min; 127 - x1, 127 - y1 min)
+      uint32_t* cb = reinterpret_cast<uint32_t*>(s + o_chunk);
+      for (size_t c = 0; c < std::max<size_t>(n_chunks, 1); c++) {
+        uint32_t m = 0x7f7f7f7fu;
+        for (size_t i = c * 256; i < std::min((c + 1) * 256, n); i++) {
+          const uint32_t v = bxp[i];
+          uint32_t o = 0;
+          for (int sh = 0; sh < 32; sh += 8) o |= std::min((m >> sh) & 255u, (v >> sh) & 255u) << sh;
+          m = o;
+        }
+        cb[c] = m;
       }
     }
     std::memcpy(s + o_pf, pf.data(), b_pf);
@@ -1049,7 +1063,7 @@ void Context::launch_frame(bool profile) {
   auto span_end = [&]() { if (profile) FDH_HIP(hipEventRecord(spans_.back().b, stream_)); };
   span_begin(0);
   BinParams B;
-  B.bbox = dv_.bboxes; B.draws = dv_.recs; B.binbox = dv_.binbox; B.n_draws = (int)recs_.size(); B.binbox_shift = binbox_shift_; B.lists = d_lists_.ptr; B.counts = d_counts_.ptr; B.phase_first = dv_.phase_first;
+  B.bbox = dv_.bboxes; B.draws = dv_.recs; B.binbox = dv_.binbox; B.chunkbox = dv_.chunkbox; B.n_draws = (int)recs_.size(); B.binbox_shift = binbox_shift_; B.lists = d_lists_.ptr; B.counts = d_counts_.ptr; B.phase_first = dv_.phase_first;
   B.n_phases = np; B.bins_x = bins_x_; B.bins_y = bins_y_; B.stride = list_stride_;
   launch_bin(stream_, B);
   span_end();

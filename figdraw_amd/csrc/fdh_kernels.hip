@@ -315,27 +315,35 @@ __global__ __launch_bounds__(64) void k_bin_draws(BinParams P) {
     queued = 0;
     __builtin_amdgcn_wave_barrier();
   };
-  auto fetch = [&](int base) {
-    const int g = (base >> 2) + lane;
-    return g < ngroups ? boxes4[g] : make_uint4(0x7f7f7f7fu, 0x7f7f7f7fu, 0x7f7f7f7fu, 0x7f7f7f7fu);  // never hits
-  };
   const uint32_t cbx = (uint32_t)bx >> P.binbox_shift, cby = (uint32_t)by >> P.binbox_shift;
   const uint32_t U = (cbx | (cby << 8) | ((127u - cbx) << 16) | ((127u - cby) << 24)) | 0x80808080u;
-  // four steps (1024 draws) of boxes are fetched together and the next four are in flight while these are tested: with two
-  // waves per SIMD nothing else hides the L2 latency of a dependent load per step
+  // Two levels: P.chunkbox[c] is the union box of draws [256 c, 256 c + 256) (byte-wise min of their bin boxes).  The wave
+  // tests 64 chunks at once (one box per lane) and then walks only the chunks that can reach this bin -- draws arrive in
+  // layout order, so a run of 256 glyphs touches a handful of bins and most (bin, chunk) pairs end at the ballot.
+  // The boxes of up to four live chunks are fetched together: with two waves per SIMD nothing else hides the L2 latency
+  // of a dependent load per step.
   constexpr int kAhead = 4;
-  uint4 qn[kAhead];
-  const int base0 = first & ~3;
-#pragma unroll
-  for (int a = 0; a < kAhead; a++) qn[a] = fetch(base0 + 256 * a);
-  for (int blk = base0; blk < last; blk += 256 * kAhead) {
+  const int c_last = (last - 1) >> 8;
+  for (int c0 = first >> 8; c0 <= c_last && first < last; c0 += 64) {
+    const int cl = c0 + lane;
+    unsigned long long live = __ballot(cl <= c_last && binbox_hits(P.chunkbox[min(cl, c_last)], U));
+    while (live) {
+    int cs[kAhead];
     uint4 qc[kAhead];
 #pragma unroll
-    for (int a = 0; a < kAhead; a++) { qc[a] = qn[a]; qn[a] = fetch(blk + 256 * (kAhead + a)); }
+    for (int a = 0; a < kAhead; a++) {
+      cs[a] = -1;
+      if (live) {
+        cs[a] = c0 + __builtin_ctzll(live);
+        live &= live - 1ull;
+        const int g = cs[a] * 64 + lane;
+        qc[a] = g < ngroups ? boxes4[g] : make_uint4(0x7f7f7f7fu, 0x7f7f7f7fu, 0x7f7f7f7fu, 0x7f7f7f7fu);  // never hits
+      }
+    }
 #pragma unroll
     for (int a = 0; a < kAhead; a++) {  // (body kept at one indent level)
-    const int base = blk + 256 * a;
-    if (base >= last) break;
+    if (cs[a] < 0) break;
+    const int base = cs[a] << 8;
     const uint4 q = qc[a];
     const uint32_t qq[4] = {q.x, q.y, q.z, q.w};
     const int i4 = base + lane * 4;
@@ -360,6 +368,7 @@ __global__ __launch_bounds__(64) void k_bin_draws(BinParams P) {
     }
     queued += total;
     if (queued > kQueue - 256) flush();  // the next step can add up to 256
+    }
     }
   }
   flush();
