@@ -1546,6 +1546,281 @@ __global__ __launch_bounds__(64 * kVWaves) void k_blur_v(BlurParams P, const Dra
   }
 }
 
+// ------------------------------------------------------------------ blur on the matrix pipe (large regions)
+// The FIR is the one contraction on the path: 32 consecutive outputs of a line are a banded Toeplitz matrix (32 x (32 + 2 reach))
+// times the line's texels.  As packed-FMA code it ran at ~85 % of the VALU issue rate and 28 % of the HBM roofline; on the
+// matrix pipe (v_mfma_f32_32x32x16_f16, f32 accumulate) the arithmetic drops under the memory time.
+//   * texels need no conversion: a byte b in the low bits of a half IS the subnormal b * 2^-24, and the matrix pipe honours
+//     f16 subnormals (tools/microbench/mfma_f16_probe.hip) -- one v_perm_b32 builds two operand halves of one channel;
+//   * weights w * 2^10 are split hi + lo into two halves (22 significant bits; every product is exact in f32), both
+//     MFMAs accumulate into the same f32 tile, so out = acc * 2^14;
+//   * operands: A[i][k] = Toeplitz weights (i = output inside the block), B[k][j] = texels (j = lane & 31: a column for the
+//     vertical pass, a row for the horizontal one; k = 16 texels along the filter direction per MFMA, lane group g = lane >> 5
+//     holds k = 8 g .. 8 g + 7); D[i][j]: lane (j, g), register r <-> i = (r & 3) + 8 (r >> 2) + 4 g.
+//   A wave walks T blocks of 32 outputs along the filter direction; a block reads NK k-steps (16 NK >= 32 + 2 reach) and
+//   shares all but two of them with the block before it.
+using h8 = __attribute__((ext_vector_type(8))) _Float16;
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+union H8Bits { h8 v; uint32_t u[4]; };
+
+// the two operand halves (texels 2q, 2q + 1 of the lane's eight) of channel c: bytes (R[2q].c, 0, R[2q+1].c, 0)
+template <int c> __device__ __forceinline__ h8 mx_frag(const uint32_t (&R)[8]) {
+  constexpr uint32_t sel = 0x0c000c00u | (uint32_t)c | ((uint32_t)(4 + c) << 16);
+  H8Bits o;
+#pragma unroll
+  for (int q = 0; q < 4; q++) o.u[q] = __builtin_amdgcn_perm(R[2 * q + 1], R[2 * q], sel);
+  return o.v;
+}
+// Toeplitz fragment m of the lane whose A row carries output `out_idx` of the block: texel 16 m + 8 g + t of the block's
+// window (which starts `delta` texels before output 0's first tap) meets tap k = that - delta - out_idx
+template <int NK>
+__device__ __forceinline__ void mx_weights(const float* __restrict__ dense, int reach, int delta, int out_idx, int g, h8 (&whi)[NK], h8 (&wlo)[NK]) {
+#pragma unroll
+  for (int m = 0; m < NK; m++) {
+#pragma unroll
+    for (int t = 0; t < 8; t++) {
+      const int k = 16 * m + 8 * g + t - delta - out_idx, kc = min(max(k, 0), 2 * reach);
+      const float w = k == kc ? dense[kBlurPad + kc] * 1024.0f : 0.0f;  // (an unconditional load and a select)
+      const _Float16 hi = (_Float16)w;
+      whi[m][t] = hi;
+      wlo[m][t] = (_Float16)(w - (float)hi);
+    }
+  }
+}
+constexpr float kMxScale = 16384.0f;  // 2^24 (subnormal texels) / 2^10 (weight scale)
+constexpr int kMxSlot = 512;          // dwords of one k-step in LDS: 16 texels along the filter x 32 lines
+// LDS-DMA: 16 (or 4) bytes per lane from `src` to LDS byte address `lds` + 16 (4) * lane.  Written as inline assembly on
+// purpose: after the builtin form hipcc drains vmcnt to 0 before the next LDS read, which also waits for the stores just
+// issued; the kernel below places its own counted waits.  (M0 = LDS address; one wait state between s_mov m0 and its use.)
+__device__ __forceinline__ void lds_dma16(const void* src, uint32_t lds) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(lds) : "memory", "m0");
+}
+__device__ __forceinline__ void lds_dma4(const void* src, uint32_t lds) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(src), "s"(lds) : "memory", "m0");
+}
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// One wave walks `T` blocks of 32 outputs along the filter direction over 32 lines (columns for the vertical pass, rows
+// for the horizontal one).  Texels reach LDS by LDS-DMA (global_load_lds, no registers, full 16-byte pieces of whole
+// 64/128-byte runs) into a ring of NK + 4 k-step slots: while block b is multiplied, the two k-steps block b + 2 adds
+// are in flight and the stores of block b - 1 drain.  vmcnt is one in-order counter for loads and stores, so the wait at
+// the top of an iteration allows exactly the batch issued last and nothing is issued between that batch and the wait.
+// Both passes end with lane = x, accumulator register = y inside a 32 x 32 pixel block (the horizontal pass multiplies
+// texels x weights, the vertical one weights x texels), so every store is a 128-byte run.
+template <int NK, bool kV>
+__global__ __launch_bounds__(64, 2) void k_blur_mx(BlurParams P, const DrawRec* __restrict__ draws, const QuadExt* __restrict__ exts, int T) {
+  constexpr int R = NK + 4;
+  extern __shared__ __attribute__((aligned(16))) uint32_t ring[];  // R slots
+  // blocks sit at absolute multiples of 32 along the filter direction: a pixel's sum is then grouped into MFMAs the same
+  // way whatever region or stripe it is rendered in (stripes of a frame must reproduce the full frame bit for bit)
+  const int a_lo = kV ? P.y0 : P.x0, a_hi = kV ? P.y1 : P.x1, a0 = a_lo & ~31;
+  const int l0 = kV ? (P.x0 & ~31) : P.y0, l_hi = kV ? P.x1 : P.y1;
+  const int n_along = (a_hi - a0 + 32 * T - 1) / (32 * T), n_lines = (l_hi - l0 + 31) >> 5;
+  const int total = n_along * n_lines, per = (total + 7) >> 3, q = blockIdx.x >> 3, item = (blockIdx.x & 7) * per + q;
+  if (q >= per || item >= total) return;  // every XCD takes a contiguous eighth of the sequence: neighbours along the filter share an L2
+  // Sequence: horizontal pass, along the rows (neighbours in x run together and share their halo); vertical pass, bands of
+  // 16 strips (2 KB of every row) walked segment row by segment row -- the waves in flight on an XCD then read each row
+  // in 2-KB runs, not in 128-byte pieces 15 KB apart (one DRAM page per piece), and vertical neighbours still share an L2.
+  int sl, sa;
+  if (kV) {
+    constexpr int kBand = 16;
+    const int per_band = kBand * n_along, band = item / per_band, rem = item - band * per_band;
+    const int bw = min(kBand, n_lines - band * kBand);
+    sa = rem / bw;
+    sl = band * kBand + rem - sa * bw;
+  } else {
+    sl = item / n_along;
+    sa = item - sl * n_along;
+  }
+  const int lane = threadIdx.x, g = lane >> 5, j = lane & 31;
+  const int reach = P.taps.reach;
+  const int as = a0 + 32 * T * sa, lb = l0 + 32 * sl;
+  const int n_blocks = min(T, (a_hi - as + 31) >> 5);
+  const int w0 = as - reach, w0a = kV ? w0 : (w0 & ~3), delta = w0 - w0a;  // horizontal: window start moved back to a 16-byte boundary
+  h8 whi[NK], wlo[NK];
+  mx_weights<NK>(P.taps.dense, reach, delta, j, g, whi, wlo);
+  const uint32_t ring_lds = (uint32_t)reinterpret_cast<uintptr_t>(ring);
+
+  // LDS-DMA of k-step s (texels w0a + 16 s .. + 15 along the filter, 32 lines) into slot s % R; returns the instructions issued
+  auto issue = [&](int s) -> int {
+    const uint32_t slot = ring_lds + (uint32_t)(s % R) * (kMxSlot * 4u);  // LDS byte address
+    if (kV) {  // slot image [16 rows][32 px]; an instruction = 8 rows x 128 bytes
+      const int r = lane >> 3, c = lane & 7;
+      const int xch = min(lb + 4 * c, P.W - 4);  // (columns past the frame are never stored)
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        int y = w0a + 16 * s + 8 * h + r;
+        y = y < 0 ? 0 : (y > P.H - 1 ? P.H - 1 : y);  // clamp-to-edge (glcontext.nim:214-215)
+        lds_dma16(P.src + (size_t)y * P.pitch + xch, slot + h * 1024u);
+      }
+      return 2;
+    }
+    // slot image [32 rows][16 px], the four 16-byte pieces of a row XOR-swizzled by (row >> 2) & 3 so that the
+    // ds_read_b128 of sixteen lanes (rows) hits sixteen different bank groups
+    const int xb = w0a + 16 * s;
+    if (xb >= 0 && xb + 16 <= P.W) {  // wave-uniform: an instruction = 16 rows x 64 bytes
+      const int r = lane >> 2, c = lane & 3;
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        const int row = 16 * h + r, y = min(lb + row, P.y1 - 1);
+        const int gx = xb + 4 * (c ^ ((row >> 2) & 3));
+        lds_dma16(P.src + (size_t)y * P.pitch + gx, slot + h * 1024u);
+      }
+      return 2;
+    }
+    const int rr = lane >> 4, pp = lane & 15;  // the k-step crosses a frame edge: one texel per lane, clamped
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const int row = 4 * i + rr, y = min(lb + row, P.y1 - 1);
+      int gx = xb + 4 * ((pp >> 2) ^ ((row >> 2) & 3)) + (pp & 3);
+      gx = gx < 0 ? 0 : (gx > P.W - 1 ? P.W - 1 : gx);
+      lds_dma4(P.src + (size_t)y * P.pitch + gx, slot + i * 256u);
+    }
+    return 8;
+  };
+  auto wait_for_all_but = [&](int n) {  // (allowing fewer than were issued last is always safe)
+    if (n >= 16) wait_vm<16>(); else if (n >= 10) wait_vm<10>(); else if (n >= 4) wait_vm<4>(); else wait_vm<0>();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  const int n_steps = 2 * n_blocks + NK - 2;
+  for (int s = 0; s < NK; s++) issue(s);
+  int last_batch = 0;
+  if (n_blocks > 1) { last_batch = issue(NK); last_batch += issue(NK + 1); }
+  (void)n_steps;
+  DrawRec r;
+  if (kV && P.fuse_draw >= 0) r = load_rec(draws + P.fuse_draw);
+  uint32_t pend[16];
+  uint32_t pmask = 0;
+  int pbx = 0, pby = 0;
+  auto store_pending = [&]() {
+#pragma unroll
+    for (int rr = 0; rr < 16; rr++)
+      if ((pmask >> rr) & 1u) P.dst[(size_t)(pby + (rr & 3) + 8 * (rr >> 2) + 4 * g) * P.pitch + pbx + j] = pend[rr];
+    pmask = 0;
+  };
+#pragma unroll 1
+  for (int b = 0; b < n_blocks; b++) {
+    wait_for_all_but(last_batch);  // the k-steps of block b have landed; the stores issued an iteration ago have drained
+    store_pending();               // block b - 1
+    f32x16 acc[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+#pragma unroll
+      for (int e = 0; e < 16; e++) acc[c][e] = 0.0f;
+#pragma unroll
+    for (int m = 0; m < NK; m++) {
+      const uint32_t* slot = ring + ((2 * b + m) % R) * kMxSlot;
+      uint32_t t8[8];
+      if (kV) {
+#pragma unroll
+        for (int t = 0; t < 8; t++) t8[t] = slot[(8 * g + t) * 32 + j];
+      } else {
+        const uint4* row4 = reinterpret_cast<const uint4*>(slot + j * 16);
+        const int sw = (j >> 2) & 3;
+        const uint4 lo4 = row4[(2 * g) ^ sw], hi4 = row4[(2 * g + 1) ^ sw];
+        t8[0] = lo4.x; t8[1] = lo4.y; t8[2] = lo4.z; t8[3] = lo4.w; t8[4] = hi4.x; t8[5] = hi4.y; t8[6] = hi4.z; t8[7] = hi4.w;
+      }
+      const h8 f0 = mx_frag<0>(t8), f1 = mx_frag<1>(t8), f2_ = mx_frag<2>(t8), f3 = mx_frag<3>(t8);
+      if (kV) {  // weights x texels: D[output row][column]
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi[m], f0, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi[m], f1, acc[1], 0, 0, 0);
+        acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi[m], f2_, acc[2], 0, 0, 0);
+        acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi[m], f3, acc[3], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo[m], f0, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo[m], f1, acc[1], 0, 0, 0);
+        acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo[m], f2_, acc[2], 0, 0, 0);
+        acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo[m], f3, acc[3], 0, 0, 0);
+      } else {   // texels x weights: D[row][output column]
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f0, whi[m], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f1, whi[m], acc[1], 0, 0, 0);
+        acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f2_, whi[m], acc[2], 0, 0, 0);
+        acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f3, whi[m], acc[3], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f0, wlo[m], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f1, wlo[m], acc[1], 0, 0, 0);
+        acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f2_, wlo[m], acc[2], 0, 0, 0);
+        acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f3, wlo[m], acc[3], 0, 0, 0);
+      }
+    }
+    // the block's 32 x 32 pixels: lane = x, register rr = row (rr & 3) + 8 (rr >> 2) + 4 g
+    const int bx = kV ? lb : as + 32 * b, by = kV ? as + 32 * b : lb;
+    const int x = bx + j;
+    pbx = bx; pby = by;
+    const bool x_ok = x >= P.x0 && x < P.x1;
+#pragma unroll
+    for (int rr = 0; rr < 16; rr++) {
+      const int y = by + (rr & 3) + 8 * (rr >> 2) + 4 * g;
+      pend[rr] = pack2(f2{acc[0][rr], acc[1][rr]} * kMxScale, f2{acc[2][rr], acc[3][rr]} * kMxScale);
+      if (x_ok && y >= P.y0 && y < P.y1) pmask |= 1u << rr;
+    }
+    if (kV && P.fuse_draw >= 0) {
+      // atlas.frag:381-388 on the blurred texel just produced, blended over the live surface (first draw of the phase).
+      // `alpha16[rr]`: the quad's coverage at the lane's pixel of row rr; pixels with an opaque backdrop under full
+      // coverage are plain replacements (the blend is exact there) and need nothing more.
+      const bool core = bx >= r.ix0 && bx + 32 <= r.ix1 && by >= r.iy0 && by + 32 <= r.iy1;  // coverage alpha == 1 (wave-uniform)
+      uint32_t blend_mask = 0;
+      uint32_t* sc0 = ring + ((2 * b - 2 + R) % R) * kMxSlot;  // the two ring slots block b - 1 gave up: nothing is in
+      uint32_t* sc1 = ring + ((2 * b - 1 + R) % R) * kMxSlot;  // flight into them until the end of this iteration
+      if (core) {
+#pragma unroll
+        for (int rr = 0; rr < 16; rr++) if (((pmask >> rr) & 1u) && (pend[rr] >> 24) != 255u) blend_mask |= 1u << rr;
+      } else {
+        // a block on the quad's border (a few hundred of 8100 at 4K): the coverage evaluation exists once, in a rolled
+        // loop, and hands its alphas over through LDS
+        const uint32_t valid = pmask;
+        pmask = 0;
+#pragma unroll 1
+        for (int rr = 0; rr < 16; rr++) {
+          const int y = by + (rr & 3) + 8 * (rr >> 2) + 4 * g;
+          float alpha = -1.0f;
+          if ((valid >> rr) & 1u) {
+            const Frag f = make_frag(r, exts, x, y);
+            if (f.covered) {
+              const float lx = (f.u - 0.5f) * 2.0f * r.p0, ly = (f.v - 0.5f) * 2.0f * r.p1;
+              const float dist = shape_dist((r.op_mode & F_ELLIP) != 0u, lx, -ly, r.p2, r.p3, r.r[0], r.r[1], r.r[2], r.r[3]);
+              alpha = 1.0f - clamp01(r.aa * dist + 0.5f);
+            }
+          }
+          (rr < 8 ? sc0 : sc1)[(rr & 7) * 64 + lane] = __float_as_uint(alpha);
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int rr = 0; rr < 16; rr++) if (__uint_as_float((rr < 8 ? sc0 : sc1)[(rr & 7) * 64 + lane]) >= 0.0f) { pmask |= 1u << rr; blend_mask |= 1u << rr; }
+      }
+      if (__any(blend_mask != 0u)) {  // (never on an opaque surface inside the quad)
+        uint32_t dstv[16];
+#pragma unroll
+        for (int rr = 0; rr < 16; rr++)  // all the loads first: sixteen dependent round trips otherwise
+          dstv[rr] = ((blend_mask >> rr) & 1u) ? P.dst[(size_t)(by + (rr & 3) + 8 * (rr >> 2) + 4 * g) * P.pitch + x] : 0u;
+        const float k = 1.0f / 255.0f;
+#pragma unroll
+        for (int rr = 0; rr < 16; rr++) {
+          if (!((blend_mask >> rr) & 1u)) continue;
+          const float alpha = core ? 1.0f : __uint_as_float((rr < 8 ? sc0 : sc1)[(rr & 7) * 64 + lane]);
+          const F4 bl = unpack255(pend[rr]);
+          F4 Fd = unpack255(dstv[rr]);
+          const float sa = bl.w * k * alpha, A = 255.0f * sa;
+          // = blend(F, b.rgb / 255, sa) (blend_pre's arithmetic, FMA for FMA).  Scalar on purpose: written with the packed
+          // f2 helpers this block gave red = 0 in lanes 48-63 of a few dozen wavefronts per 4K frame (measured; the same
+          // helpers are exact everywhere else) -- the block runs for a few hundred of 8100 blocks, its cost does not matter
+          const float ia = 1.0f - sa;
+          Fd.x = __builtin_rintf(__builtin_fmaf(Fd.x, ia, bl.x * k * A));
+          Fd.y = __builtin_rintf(__builtin_fmaf(Fd.y, ia, bl.y * k * A));
+          Fd.z = __builtin_rintf(__builtin_fmaf(Fd.z, ia, bl.z * k * A));
+          Fd.w = __builtin_rintf(__builtin_fmaf(Fd.w, ia, A));
+          pend[rr] = pack255(Fd);
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    // the ring slots block b - 1 gave up take the two k-steps block b + 2 adds
+    __builtin_amdgcn_sched_barrier(0);
+    last_batch = 0;
+    if (b + 2 < n_blocks) { last_batch = issue(2 * b + NK + 2); last_batch += issue(2 * b + NK + 3); }
+  }
+  store_pending();
+}
+
 __global__ void k_fill_u32(uint32_t* p, uint32_t v, size_t n) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -1580,7 +1855,13 @@ void launch_composite(hipStream_t s, const DrawRec* draws, const QuadExt* exts, 
 #ifndef FDH_BLUR_VWAVES
 #define FDH_BLUR_VWAVES 4  // waves per V-pass workgroup: the tile is 64 columns x (waves * outputs) rows
 #endif
-static bool blur_small(const BlurParams& P) { return (long long)(P.x1 - P.x0) * (P.y1 - P.y0) < 1024 * 1024; }
+// FDH_FORCE_BLUR_PATH=1|2|3 (a test hook, tests/test_hip_parity.py): every blur on the 2-outputs-per-thread passes / the
+// many-outputs passes / the matrix-pipe passes, whatever the region size
+static int blur_forced_path() { static const int v = [] { const char* e = std::getenv("FDH_FORCE_BLUR_PATH"); return e ? std::atoi(e) : 0; }(); return v; }
+static bool blur_small(const BlurParams& P) {
+  if (blur_forced_path()) return blur_forced_path() == 1;
+  return (long long)(P.x1 - P.x0) * (P.y1 - P.y0) < 1024 * 1024;
+}
 // Outputs per thread for a large region: more outputs share each unpacked texel (4 converts per texel and n outputs
 // against the 2 * taps packed FMAs every output needs anyway), but the extent along the pass is cut into units of
 // `quantum * n` and the last unit of every row / column runs with idle lanes.  3840 px in 512-px waves is 7.5 waves per row
@@ -1608,9 +1889,40 @@ template <int NOUT, int WAVES> static void launch_blur_v_n(hipStream_t s, const 
   const size_t lds = (size_t)(WAVES * NOUT + 2 * P.taps.reach) * kBlurVW * sizeof(uint32_t);
   hipLaunchKernelGGL((k_blur_v<NOUT, WAVES>), grid, dim3(64 * WAVES), lds, s, P, draws, exts);
 }
+// Matrix-pipe passes: NK k-steps of 16 texels must cover a block's 32 + 2 reach window (+ up to 3 texels of alignment
+// for the horizontal pass); T blocks per wave, as many as still leave every SIMD a couple of waves.
+#ifndef FDH_BLUR_MX
+#define FDH_BLUR_MX 1
+#endif
+static int mx_nk(int reach, int slack) { return (32 + 2 * reach + slack + 15) / 16; }
+static int mx_pick_t(long long outputs_along, long long lines) {  // segments = lines/32 * ceil(outputs_along / (32 T))
+  static const int forced = [] { const char* e = std::getenv("FDH_MX_T"); return e ? std::atoi(e) : 0; }();  // experiments
+  if (forced) return forced;
+  for (int t : {4, 2}) if ((lines + 31) / 32 * ((outputs_along + 32 * t - 1) / (32 * t)) >= 2000) return t;
+  return 1;
+}
+template <int NK, bool kV> static void launch_blur_mx(hipStream_t s, const BlurParams& P, const DrawRec* draws, const QuadExt* exts, int t) {
+  const int a_lo = kV ? P.y0 : P.x0, a_hi = kV ? P.y1 : P.x1, l_lo = kV ? (P.x0 & ~31) : P.y0, l_hi = kV ? P.x1 : P.y1;
+  const int total = ((a_hi - (a_lo & ~31) + 32 * t - 1) / (32 * t)) * ((l_hi - l_lo + 31) / 32);
+  hipLaunchKernelGGL((k_blur_mx<NK, kV>), dim3(8 * ((total + 7) / 8)), dim3(64), (size_t)(NK + 4) * kMxSlot * sizeof(uint32_t), s, P, draws, exts, t);
+}
+template <bool kV> static bool launch_blur_mx_nk(hipStream_t s, const BlurParams& P, const DrawRec* draws, const QuadExt* exts) {
+  // LDS-DMA moves 16-byte pieces: rows have to start on 16-byte boundaries
+  if ((P.pitch & 3) || (reinterpret_cast<uintptr_t>(P.src) & 15) || P.W < 4) return false;
+  const int nk = mx_nk(P.taps.reach, kV ? 0 : 3);
+  const int t = kV ? mx_pick_t(P.y1 - P.y0, P.x1 - P.x0) : mx_pick_t(P.x1 - P.x0, P.y1 - P.y0);
+  switch (nk) {
+    case 3: launch_blur_mx<3, kV>(s, P, draws, exts, t); return true;
+    case 4: launch_blur_mx<4, kV>(s, P, draws, exts, t); return true;
+    case 5: launch_blur_mx<5, kV>(s, P, draws, exts, t); return true;
+    case 6: launch_blur_mx<6, kV>(s, P, draws, exts, t); return true;
+    default: return false;  // wider filters: the packed-FMA passes
+  }
+}
 void launch_blur_h(hipStream_t s, const BlurParams& P) {
   if (P.x1 <= P.x0 || P.y1 <= P.y0) return;
   if (blur_small(P)) { launch_blur_h_n<2>(s, P); return; }
+  if (FDH_BLUR_MX && blur_forced_path() != 2 && launch_blur_mx_nk<false>(s, P, nullptr, nullptr)) return;
   switch (blur_pick_nout(P.x1 - P.x0, 64, P.taps.reach)) {
     case 12: launch_blur_h_n<12>(s, P); break;
     case 10: launch_blur_h_n<10>(s, P); break;
@@ -1621,6 +1933,7 @@ void launch_blur_h(hipStream_t s, const BlurParams& P) {
 void launch_blur_v(hipStream_t s, const BlurParams& P, const DrawRec* draws, const QuadExt* exts) {
   if (P.x1 <= P.x0 || P.y1 <= P.y0) return;
   if (blur_small(P)) { launch_blur_v_n<2, 4>(s, P, draws, exts); return; }
+  if (FDH_BLUR_MX && blur_forced_path() != 2 && launch_blur_mx_nk<true>(s, P, draws, exts)) return;
   switch (blur_pick_nout(P.y1 - P.y0, FDH_BLUR_VWAVES, P.taps.reach)) {
     case 12: launch_blur_v_n<12, FDH_BLUR_VWAVES>(s, P, draws, exts); break;
     case 10: launch_blur_v_n<10, FDH_BLUR_VWAVES>(s, P, draws, exts); break;

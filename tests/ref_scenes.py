@@ -406,6 +406,29 @@ def text_frontend(w=300.0, h=120.0, images=None) -> Renders:
     return out
 
 
+def blur_sweep(w=700.0, h=420.0, radii=(1.0, 3.0, 6.5, 9.0, 12.0, 18.0, 24.0, 30.0, 40.0, 64.0)) -> Renders:
+    """One backdrop-blur node per radius (tap reach 2 .. 66 px: every FIR width the blur kernels are specialised for), over a
+    busy background, the nodes hanging over all four frame edges (clamp-to-edge taps) and overlapping each other; the last
+    one covers the whole frame."""
+    lst = RenderList()
+    lst.addRoot(Fig(kind=RECT, screenBox=rect(0, 0, w, h), fill=rgba(250, 250, 250, 255)))
+    cols = [rgba(220, 40, 40, 255), rgba(40, 180, 90, 255), rgba(60, 90, 220, 255), rgba(240, 200, 40, 255), rgba(10, 10, 10, 255)]
+    for i in range(40):
+        lst.addRoot(Fig(kind=RECT, screenBox=rect((i * 53) % int(w) - 20, (i * 37) % int(h) - 15, 30 + (i * 7) % 90, 20 + (i * 11) % 70),
+                        fill=cols[i % 5], corners=[(i * 3) % 17] * 4))
+    n = len(radii)
+    for i, r in enumerate(radii):
+        fx, fy = (i % 4) / 3.0, (i // 4) / max(1, (n - 1) // 4)
+        bw, bh = 0.45 * w, 0.5 * h
+        lst.addRoot(Fig(kind=FigKind.nkBackdropBlur, screenBox=rect(-0.1 * w + fx * (1.2 * w - bw) + 0.25, -0.1 * h + fy * (1.2 * h - bh) + 0.5, bw, bh),
+                        corners=[4 + 5 * i] * 4, fill=rgba(255, 255, 255, 20 if i % 2 else 0), blur=r))
+        lst.addRoot(Fig(kind=RECT, screenBox=rect(fx * (w - 40), fy * (h - 30), 40, 30), fill=cols[i % 5], corners=[3] * 4))
+    lst.addRoot(Fig(kind=FigKind.nkBackdropBlur, screenBox=rect(0, 0, w, h), fill=rgba(0, 0, 0, 0), blur=14.0))
+    out = Renders()
+    out.layers[0] = lst
+    return out
+
+
 def random_scene(seed: int, w: float, h: float, n: int = 40, clips: bool = True, blur: bool = True, images=None) -> Renders:
     """Seeded random mix of everything the SDF path has: opaque and translucent fills (solid, 2- and 3-stop on all
     axes), circular and elliptical corners, strokes, drop and inner shadows, nested NfClipContent / NfRectMaskContent

@@ -115,6 +115,45 @@ def test_every_kernel_build_gives_the_same_pixels(hip, paths):
             assert np.array_equal(res["default"][k], res["forced"][k]), (paths, k)
 
 
+@pytest.mark.parametrize("path", [1, 2, 3])
+def test_every_blur_path_matches_oracle(path):
+    """The blur passes exist as three builds picked by region size and filter width: 2 outputs per thread (small regions),
+    8-12 outputs per thread, and the matrix-pipe passes (large regions, tap reach <= 30).  FDH_FORCE_BLUR_PATH puts every
+    blur of a frame on one of them (a child process); each must stay within 1 LSB of the oracle for every filter width,
+    with taps clamped at all four frame edges."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+
+    cases = [("sweep", 700, 420, None), ("sweep_odd", 333, 517, None), ("backdrop", 320, 240, None), ("fuzz7", 799, 601, 7), ("fuzz8", 1283, 721, 8)]
+    code = (
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import ref_scenes as RS\n"
+        "from figdraw_amd.context import HipContext\n"
+        "ctx = HipContext(device=0)\n"
+        "out = {}\n"
+        "for name, w, h, seed in %r:\n"
+        "    sc = RS.random_scene(seed, float(w), float(h), n=60, clips=(seed == 7), blur=True) if seed else (RS.backdrop_blur if name == 'backdrop' else RS.blur_sweep)(float(w), float(h))\n"
+        "    ctx.render_frame(sc, w, h); out[name] = ctx.read_pixels()\n"
+        "np.savez(sys.argv[1], **out)\n"
+    ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)), cases)
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "o.npz")
+        subprocess.check_call([sys.executable, "-c", code, out], env={**os.environ, "FDH_FORCE_BLUR_PATH": str(path)})
+        got = dict(np.load(out))
+    for name, w, h, seed in cases:
+        if seed:
+            sc = RS.random_scene(seed, float(w), float(h), n=60, clips=(seed == 7), blur=True)
+        else:
+            sc = (RS.backdrop_blur if name == "backdrop" else RS.blur_sweep)(float(w), float(h))
+        want = _oracle(lambda *_: sc, w, h)
+        mx, n0, n1 = diff_stats(got[name], want)
+        assert mx <= 1, (path, name, "vs oracle", mx, n0, n1)
+        assert n0 <= 0.005 * w * h, (path, name, "vs oracle: too many 1-LSB pixels", n0)
+
+
 def test_contexts_in_flight_do_not_disturb_each_other(hip):
     """bench.py keeps several frames in flight on one GPU (one context = one stream + surface set each): every context
     must end up with exactly the frame it renders alone."""
