@@ -1694,11 +1694,22 @@ __global__ __launch_bounds__(64, 2) void k_blur_mx(BlurParams P, const DrawRec* 
   uint32_t pmask = 0;
   int pbx = 0, pby = 0;
   auto store_pending = [&]() {
+    // a row's address = uniform row pointer (scalar arithmetic) + one 32-bit per-lane byte offset: no vector address
+    // arithmetic per store; a block with every pixel live (wave-uniform test) stores without execution masks
+    const uint32_t lane_off = ((uint32_t)(4 * g) * (uint32_t)P.pitch + (uint32_t)j) * 4u;
+    char* base = reinterpret_cast<char*>(P.dst + (size_t)pby * P.pitch + pbx);
+    if (__all(pmask == 0xffffu)) {
 #pragma unroll
-    for (int rr = 0; rr < 16; rr++)
-      if ((pmask >> rr) & 1u) P.dst[(size_t)(pby + (rr & 3) + 8 * (rr >> 2) + 4 * g) * P.pitch + pbx + j] = pend[rr];
+      for (int rr = 0; rr < 16; rr++)
+        *reinterpret_cast<uint32_t*>(base + (size_t)((rr & 3) + 8 * (rr >> 2)) * P.pitch * 4u + lane_off) = pend[rr];
+    } else if (__any(pmask != 0u)) {
+#pragma unroll
+      for (int rr = 0; rr < 16; rr++)
+        if ((pmask >> rr) & 1u) *reinterpret_cast<uint32_t*>(base + (size_t)((rr & 3) + 8 * (rr >> 2)) * P.pitch * 4u + lane_off) = pend[rr];
+    }
     pmask = 0;
   };
+  int slot0 = 0;  // (2 b) % R
 #pragma unroll 1
   for (int b = 0; b < n_blocks; b++) {
     wait_for_all_but(last_batch);  // the k-steps of block b have landed; the stores issued an iteration ago have drained
@@ -1710,7 +1721,7 @@ __global__ __launch_bounds__(64, 2) void k_blur_mx(BlurParams P, const DrawRec* 
       for (int e = 0; e < 16; e++) acc[c][e] = 0.0f;
 #pragma unroll
     for (int m = 0; m < NK; m++) {
-      const uint32_t* slot = ring + ((2 * b + m) % R) * kMxSlot;
+      const uint32_t* slot = ring + (slot0 + m >= R ? slot0 + m - R : slot0 + m) * kMxSlot;
       uint32_t t8[8];
       if (kV) {
 #pragma unroll
@@ -1748,10 +1759,15 @@ __global__ __launch_bounds__(64, 2) void k_blur_mx(BlurParams P, const DrawRec* 
     pbx = bx; pby = by;
     const bool x_ok = x >= P.x0 && x < P.x1;
 #pragma unroll
-    for (int rr = 0; rr < 16; rr++) {
-      const int y = by + (rr & 3) + 8 * (rr >> 2) + 4 * g;
-      pend[rr] = pack2(f2{acc[0][rr], acc[1][rr]} * kMxScale, f2{acc[2][rr], acc[3][rr]} * kMxScale);
-      if (x_ok && y >= P.y0 && y < P.y1) pmask |= 1u << rr;
+    for (int rr = 0; rr < 16; rr++) pend[rr] = pack2(f2{acc[0][rr], acc[1][rr]} * kMxScale, f2{acc[2][rr], acc[3][rr]} * kMxScale);
+    if (bx >= P.x0 && bx + 32 <= P.x1 && by >= P.y0 && by + 32 <= P.y1) {  // wave-uniform: the whole block lies in the region
+      pmask = 0xffffu;
+    } else {
+#pragma unroll
+      for (int rr = 0; rr < 16; rr++) {
+        const int y = by + (rr & 3) + 8 * (rr >> 2) + 4 * g;
+        if (x_ok && y >= P.y0 && y < P.y1) pmask |= 1u << rr;
+      }
     }
     if (kV && P.fuse_draw >= 0) {
       // atlas.frag:381-388 on the blurred texel just produced, blended over the live surface (first draw of the phase).
@@ -1759,33 +1775,53 @@ __global__ __launch_bounds__(64, 2) void k_blur_mx(BlurParams P, const DrawRec* 
       // coverage are plain replacements (the blend is exact there) and need nothing more.
       const bool core = bx >= r.ix0 && bx + 32 <= r.ix1 && by >= r.iy0 && by + 32 <= r.iy1;  // coverage alpha == 1 (wave-uniform)
       uint32_t blend_mask = 0;
-      uint32_t* sc0 = ring + ((2 * b - 2 + R) % R) * kMxSlot;  // the two ring slots block b - 1 gave up: nothing is in
-      uint32_t* sc1 = ring + ((2 * b - 1 + R) % R) * kMxSlot;  // flight into them until the end of this iteration
+      uint32_t* sc0 = ring + (slot0 >= 2 ? slot0 - 2 : slot0 - 2 + R) * kMxSlot;  // the two ring slots block b - 1 gave up: nothing is in
+      uint32_t* sc1 = ring + (slot0 >= 1 ? slot0 - 1 : slot0 - 1 + R) * kMxSlot;  // flight into them until the end of this iteration
       if (core) {
 #pragma unroll
         for (int rr = 0; rr < 16; rr++) if (((pmask >> rr) & 1u) && (pend[rr] >> 24) != 255u) blend_mask |= 1u << rr;
       } else {
-        // a block on the quad's border (a few hundred of 8100 at 4K): the coverage evaluation exists once, in a rolled
-        // loop, and hands its alphas over through LDS
+        // A block on the quad's border (a few hundred of 8100 at 4K).  Its rows and columns inside the core have
+        // alpha == 1; the others are evaluated densely, one row (lane = x) or one column (lane = y) per lane group and
+        // step, and reach the accumulator layout (lane = x, register = row) through LDS.  (Evaluating in the accumulator
+        // layout costs 16 sparse steps per block: the two border strips then ran 2.5x longer than every other wave.)
         const uint32_t valid = pmask;
         pmask = 0;
+#pragma unroll
+        for (int rr = 0; rr < 16; rr++) (rr < 8 ? sc0 : sc1)[(rr & 7) * 64 + lane] = __float_as_uint(((valid >> rr) & 1u) ? 1.0f : -1.0f);
+        __builtin_amdgcn_wave_barrier();
+        const int ra = min(max(r.iy0 - by, 0), 32), rb = max(ra, min(max(r.iy1 - by, 0), 32));  // rows [ra, rb) lie in the core's rows
+        const int ca = min(max(r.ix0 - bx, 0), 32), cb = max(ca, min(max(r.ix1 - bx, 0), 32));
+        const int nr = ra + 32 - rb, nc = ca + 32 - cb;
 #pragma unroll 1
-        for (int rr = 0; rr < 16; rr++) {
-          const int y = by + (rr & 3) + 8 * (rr >> 2) + 4 * g;
+        for (int u0 = 0; u0 < nr + nc; u0 += 2) {
+          const int u = u0 + g;
+          int dx, dy;
+          if (u < nr) { dy = u < ra ? u : rb + (u - ra); dx = j; }
+          else { const int v = u - nr; dx = v < ca ? v : cb + (v - ca); dy = j; }
+          if (u >= nr + nc) continue;
+          const int ex = bx + dx, ey = by + dy;
           float alpha = -1.0f;
-          if ((valid >> rr) & 1u) {
-            const Frag f = make_frag(r, exts, x, y);
+          if (ex >= P.x0 && ex < P.x1 && ey >= P.y0 && ey < P.y1) {
+            const Frag f = make_frag(r, exts, ex, ey);
             if (f.covered) {
               const float lx = (f.u - 0.5f) * 2.0f * r.p0, ly = (f.v - 0.5f) * 2.0f * r.p1;
               const float dist = shape_dist((r.op_mode & F_ELLIP) != 0u, lx, -ly, r.p2, r.p3, r.r[0], r.r[1], r.r[2], r.r[3]);
               alpha = 1.0f - clamp01(r.aa * dist + 0.5f);
             }
           }
-          (rr < 8 ? sc0 : sc1)[(rr & 7) * 64 + lane] = __float_as_uint(alpha);
+          const int er = (dy & 3) + 4 * (dy >> 3), el = dx + 32 * ((dy >> 2) & 1);  // accumulator register and lane of (dx, dy)
+          (er < 8 ? sc0 : sc1)[(er & 7) * 64 + el] = __float_as_uint(alpha);
         }
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int rr = 0; rr < 16; rr++) if (__uint_as_float((rr < 8 ? sc0 : sc1)[(rr & 7) * 64 + lane]) >= 0.0f) { pmask |= 1u << rr; blend_mask |= 1u << rr; }
+        for (int rr = 0; rr < 16; rr++) {
+          const float al = __uint_as_float((rr < 8 ? sc0 : sc1)[(rr & 7) * 64 + lane]);
+          if (al >= 0.0f) {
+            pmask |= 1u << rr;
+            if (al != 1.0f || (pend[rr] >> 24) != 255u) blend_mask |= 1u << rr;
+          }
+        }
       }
       if (__any(blend_mask != 0u)) {  // (never on an opaque surface inside the quad)
         uint32_t dstv[16];
@@ -1817,6 +1853,7 @@ __global__ __launch_bounds__(64, 2) void k_blur_mx(BlurParams P, const DrawRec* 
     __builtin_amdgcn_sched_barrier(0);
     last_batch = 0;
     if (b + 2 < n_blocks) { last_batch = issue(2 * b + NK + 2); last_batch += issue(2 * b + NK + 3); }
+    slot0 = slot0 + 2 >= R ? slot0 + 2 - R : slot0 + 2;
   }
   store_pending();
 }
