@@ -206,11 +206,11 @@ def main():
         roofline["ms_per_launch"] = round(st.ms_composite_main, 4)
         roofline["algorithmic_bytes_per_launch"] = int(st.bytes_composite_main)
         roofline["note"] = ("fused tile compositor: VALU/transcendental-bound by construction, it moves 4 B/pixel out + "
-                            "128 B/draw in; the HBM-bound kernels are k_blur_h/k_blur_v (roofline_blur)")
+                            "128 B/draw in; the HBM-bound kernels are the blur passes (roofline_blur)")
     blur_ms = st.ms_blur_h + st.ms_blur_v
     roofline_blur = roof(st.bytes_blur, blur_ms)
     if roofline_blur is not None:
-        roofline_blur["kernel"] = "k_blur_h + k_blur_v (all blur nodes of a frame)"
+        roofline_blur["kernel"] = "blur passes of a frame: k_blur_mx<.., false|true> (full-frame node, matrix pipe) + k_blur_h / k_blur_v (360x240 node)"
         roofline_blur["ms_per_frame"] = round(blur_ms, 4)
         roofline_blur["algorithmic_bytes_per_frame"] = int(st.bytes_blur)
     frame_gbs = st.bytes_algorithmic / (ms_step * 1e-3) / 1e9

@@ -126,7 +126,11 @@ def test_every_blur_path_matches_oracle(path):
     import sys
     import tempfile
 
-    cases = [("sweep", 700, 420, None), ("sweep_odd", 333, 517, None), ("backdrop", 320, 240, None), ("fuzz7", 799, 601, 7), ("fuzz8", 1283, 721, 8)]
+    # (the matrix-pipe passes need rows on 16-byte boundaries: widths that are not multiples of 4 fall back to path 2)
+    white, glass = (1.0, 1.0, 1.0, 1.0), (0.2, 0.3, 0.4, 0.5)  # a translucent clear colour: the fused composite has to blend
+    cases = [("sweep", 700, 420, None, white), ("sweep_odd", 333, 517, None, white), ("sweep_glass", 644, 388, None, glass),
+             ("backdrop", 320, 240, None, white), ("backdrop_glass", 320, 240, None, glass), ("fuzz7", 799, 601, 7, white),
+             ("fuzz8", 1284, 720, 8, glass)]
     code = (
         "import sys, numpy as np\n"
         "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
@@ -134,21 +138,25 @@ def test_every_blur_path_matches_oracle(path):
         "from figdraw_amd.context import HipContext\n"
         "ctx = HipContext(device=0)\n"
         "out = {}\n"
-        "for name, w, h, seed in %r:\n"
-        "    sc = RS.random_scene(seed, float(w), float(h), n=60, clips=(seed == 7), blur=True) if seed else (RS.backdrop_blur if name == 'backdrop' else RS.blur_sweep)(float(w), float(h))\n"
-        "    ctx.render_frame(sc, w, h); out[name] = ctx.read_pixels()\n"
+        "for name, w, h, seed, color in %r:\n"
+        "    sc = RS.random_scene(seed, float(w), float(h), n=60, clips=(seed == 7), blur=True) if seed else (RS.backdrop_blur if name.startswith('backdrop') else RS.blur_sweep)(float(w), float(h))\n"
+        "    ctx.render_frame(sc, w, h, color=color); out[name] = ctx.read_pixels()\n"
         "np.savez(sys.argv[1], **out)\n"
     ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)), cases)
     with tempfile.TemporaryDirectory() as td:
         out = os.path.join(td, "o.npz")
         subprocess.check_call([sys.executable, "-c", code, out], env={**os.environ, "FDH_FORCE_BLUR_PATH": str(path)})
         got = dict(np.load(out))
-    for name, w, h, seed in cases:
+    from oracle import oracle as O
+
+    for name, w, h, seed, color in cases:
         if seed:
             sc = RS.random_scene(seed, float(w), float(h), n=60, clips=(seed == 7), blur=True)
         else:
-            sc = (RS.backdrop_blur if name == "backdrop" else RS.blur_sweep)(float(w), float(h))
-        want = _oracle(lambda *_: sc, w, h)
+            sc = (RS.backdrop_blur if name.startswith("backdrop") else RS.blur_sweep)(float(w), float(h))
+        o = O.Oracle(threads=8)
+        o.render_frame(sc, w, h, color=color)
+        want = o.read_pixels()
         mx, n0, n1 = diff_stats(got[name], want)
         assert mx <= 1, (path, name, "vs oracle", mx, n0, n1)
         assert n0 <= 0.005 * w * h, (path, name, "vs oracle: too many 1-LSB pixels", n0)

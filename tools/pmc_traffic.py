@@ -21,8 +21,11 @@ for base, lst in by_kernel.items():
         c = {n: sum(v) / len(v) for n, v in agg[(k, g)].items()}
         if base == "k_composite_tiles":
             label = "k_composite_tiles.phase0" if i == 0 else f"k_composite_tiles.later{i}"
+        elif base == "k_blur_mx":  # template arguments <NK, vertical>
+            label = "k_blur_mx.vertical" if "true" in k else "k_blur_mx.horizontal"
+            label += "" if not any(kk.startswith(label) for kk in kernels) else f".{i}"
         elif base in ("k_blur_h", "k_blur_v"):
-            label = f"{base}.fullframe" if i == 0 else f"{base}.small{i}"
+            label = f"{base}.largest" if i == 0 else f"{base}.{i}"
         else:
             label = base if i == 0 else f"{base}.{i}"
         e = {"kernel": k, "grid": g}
