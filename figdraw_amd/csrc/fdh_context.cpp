@@ -903,6 +903,45 @@ void Context::end_frame() {  // glcontext.nim:1982-1989
   submit(true);
 }
 
+// Weight fragments of a matrix-pipe blur pass (k_blur_mx, fdh_kernels.hip).  Lane (j, g) of fragment m holds, for the window
+// texels 16 m + 8 g + t (t = 0..7) of a 32-output block, the tap each meets at output j: k = texel - delta - j, weight
+// dense[k] * 2^10 when 0 <= k <= 2 reach, else 0 -- split into two halves hi + lo (hi = RNE(w), lo = RNE(w - hi): 22
+// significant bits, every product with an 8-bit texel is exact in f32).
+static uint16_t half_bits_rne(float f) {  // |f| < 65504
+  uint32_t u;
+  std::memcpy(&u, &f, 4);
+  const uint16_t sign = (uint16_t)((u >> 16) & 0x8000u);
+  const float a = std::fabs(f);
+  if (a == 0.0f) return sign;
+  std::memcpy(&u, &a, 4);
+  const int e = (int)(u >> 23) - 127;
+  if (e < -14) return sign | (uint16_t)std::nearbyint(a * 16777216.0f);  // subnormal half: units of 2^-24 (1024 = the smallest normal)
+  const uint32_t mant = u & 0x7fffffu, m = mant >> 13, rem = mant & 0x1fffu;
+  uint32_t h = ((uint32_t)(e + 15) << 10) | m;
+  if (rem > 0x1000u || (rem == 0x1000u && (m & 1u))) h++;  // round to nearest even; a carry moves into the exponent
+  return sign | (uint16_t)h;
+}
+static float half_value(uint16_t h) {
+  const int e = (h >> 10) & 31, m = h & 1023;
+  const float v = e == 0 ? std::ldexp((float)m, -24) : std::ldexp((float)(m + 1024), e - 25);
+  return (h & 0x8000u) ? -v : v;
+}
+static void build_mx_weights(const BlurTaps& t, bool vertical, uint8_t* out) {
+  const int nk = mx_nk(t.reach, vertical), delta = mx_delta(t.reach, vertical);
+  uint16_t* o = reinterpret_cast<uint16_t*>(out);
+  for (int m = 0; m < nk; m++)
+    for (int lane = 0; lane < 64; lane++) {
+      const int j = lane & 31, g = lane >> 5;
+      for (int e = 0; e < 8; e++) {
+        const int k = 16 * m + 8 * g + e - delta - j;
+        const float w = (k >= 0 && k <= 2 * t.reach) ? t.dense[kBlurPad + k] * 1024.0f : 0.0f;
+        const uint16_t hi = half_bits_rne(w), lo = half_bits_rne(w - half_value(hi));
+        o[(((size_t)(2 * m) * 64 + lane) * 8) + e] = hi;
+        o[(((size_t)(2 * m + 1) * 64 + lane) * 8) + e] = lo;
+      }
+    }
+}
+
 void Context::submit(bool upload) {
   const auto t_s0 = std::chrono::steady_clock::now();
   FDH_HIP(hipSetDevice(device_));
@@ -964,7 +1003,16 @@ void Context::submit(bool upload) {
     const size_t b_box = ((n + 3) & ~(size_t)3) * sizeof(uint32_t);
     const size_t n_chunks = (n + 255) / 256, b_chunk = std::max<size_t>(n_chunks, 1) * sizeof(uint32_t);
     const size_t o_recs = 0, o_ext = up(o_recs + b_recs), o_bb = up(o_ext + b_ext), o_box = up(o_bb + b_bb), o_chunk = up(o_box + b_box),
-                 o_pf = up(o_chunk + b_chunk), total = up(o_pf + b_pf);
+                 o_pf = up(o_chunk + b_chunk);
+    // weight fragments of the matrix-pipe blur passes, two tables (H, V) per blur job
+    std::vector<size_t> o_mxh(blurs_.size(), 0), o_mxv(blurs_.size(), 0);
+    size_t total = up(o_pf + b_pf);
+    for (size_t i = 0; i < blurs_.size(); i++) {
+      const int nkh = mx_nk(blurs_[i].taps.reach, false), nkv = mx_nk(blurs_[i].taps.reach, true);
+      if (nkh > kMxMaxNK || nkv > kMxMaxNK) continue;
+      o_mxh[i] = total; total = up(total + mx_table_bytes(nkh));
+      o_mxv[i] = total; total = up(total + mx_table_bytes(nkv));
+    }
     d_frame_.reserve(total);
     dv_.recs = reinterpret_cast<DrawRec*>(d_frame_.ptr + o_recs);
     dv_.exts = reinterpret_cast<QuadExt*>(d_frame_.ptr + o_ext);
@@ -972,6 +1020,10 @@ void Context::submit(bool upload) {
     dv_.phase_first = reinterpret_cast<int*>(d_frame_.ptr + o_pf);
     dv_.binbox = reinterpret_cast<uint32_t*>(d_frame_.ptr + o_box);
     dv_.chunkbox = reinterpret_cast<uint32_t*>(d_frame_.ptr + o_chunk);
+    mx_w_h_.assign(blurs_.size(), nullptr);
+    mx_w_v_.assign(blurs_.size(), nullptr);
+    for (size_t i = 0; i < blurs_.size(); i++)
+      if (o_mxh[i]) { mx_w_h_[i] = reinterpret_cast<const uint4*>(d_frame_.ptr + o_mxh[i]); mx_w_v_[i] = reinterpret_cast<const uint4*>(d_frame_.ptr + o_mxv[i]); }
     const int slot = staging_i_;
     staging_i_ = (staging_i_ + 1) % kStaging;
     if (staging_busy_[slot]) FDH_HIP(hipEventSynchronize(staging_ev_[slot]));  // its copy of three frames ago
@@ -1007,6 +1059,8 @@ void Context::submit(bool upload) {
       }
     }
     std::memcpy(s + o_pf, pf.data(), b_pf);
+    for (size_t i = 0; i < blurs_.size(); i++)
+      if (o_mxh[i]) { build_mx_weights(blurs_[i].taps, false, s + o_mxh[i]); build_mx_weights(blurs_[i].taps, true, s + o_mxv[i]); }
     void* s_dev = nullptr;
     FDH_HIP(hipHostGetDevicePointer(&s_dev, s, 0));
     launch_upload(stream_, d_frame_.ptr, s_dev, total);  // whole 16-byte groups: both sides are padded to 256 B
@@ -1092,12 +1146,14 @@ void Context::launch_frame(bool profile) {
         bp.W = W_; bp.H = H_; bp.pitch = W_;
         bp.taps = j.taps;
         bp.fuse_draw = -1;
+        bp.mx_w = (size_t)ph.blur < mx_w_h_.size() ? mx_w_h_[ph.blur] : nullptr;
         bp.src = fb_; bp.dst = blur_tmp_;
         bp.x0 = j.x0; bp.x1 = j.x1; bp.y0 = std::max(0, vy0 - j.taps.reach); bp.y1 = std::min(H_, vy1 + j.taps.reach);
         span_begin(3);
         launch_blur_h(stream_, bp);
         span_end();
         bp.src = blur_tmp_; bp.dst = j.fuse_draw >= 0 ? fb_ : backdrop_;
+        bp.mx_w = (size_t)ph.blur < mx_w_v_.size() ? mx_w_v_[ph.blur] : nullptr;
         bp.fuse_draw = j.fuse_draw;
         bp.y0 = vy0; bp.y1 = vy1;
         span_begin(4);

@@ -201,6 +201,7 @@ class Context {
   std::vector<QuadExt> exts_;
   std::vector<Phase> phases_;
   std::vector<BlurJob> blurs_;
+  std::vector<const uint4*> mx_w_h_, mx_w_v_;  // per blur job: weight fragments of the matrix-pipe passes (in d_frame_), or null
   int64_t fragments_ = 0;
   bool have_frame_ = false;
 

@@ -47,6 +47,9 @@ struct BlurParams {
   // V pass only: when fuse_draw >= 0 the mode-17 quad that consumes this blur is composited straight into
   // `dst` (the live surface) instead of writing the blurred snapshot out and reading it back
   int fuse_draw;
+  // Toeplitz weight fragments of this pass for k_blur_mx (Context::submit builds them: [k-step][hi, lo][lane] x 8 halves),
+  // or null: the packed-FMA passes then take the launch
+  const uint4* mx_w;
   BlurTaps taps;
 };
 

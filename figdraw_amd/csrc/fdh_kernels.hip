@@ -1571,22 +1571,6 @@ template <int c> __device__ __forceinline__ h8 mx_frag(const uint32_t (&R)[8]) {
   for (int q = 0; q < 4; q++) o.u[q] = __builtin_amdgcn_perm(R[2 * q + 1], R[2 * q], sel);
   return o.v;
 }
-// Toeplitz fragment m of the lane whose A row carries output `out_idx` of the block: texel 16 m + 8 g + t of the block's
-// window (which starts `delta` texels before output 0's first tap) meets tap k = that - delta - out_idx
-template <int NK>
-__device__ __forceinline__ void mx_weights(const float* __restrict__ dense, int reach, int delta, int out_idx, int g, h8 (&whi)[NK], h8 (&wlo)[NK]) {
-#pragma unroll
-  for (int m = 0; m < NK; m++) {
-#pragma unroll
-    for (int t = 0; t < 8; t++) {
-      const int k = 16 * m + 8 * g + t - delta - out_idx, kc = min(max(k, 0), 2 * reach);
-      const float w = k == kc ? dense[kBlurPad + kc] * 1024.0f : 0.0f;  // (an unconditional load and a select)
-      const _Float16 hi = (_Float16)w;
-      whi[m][t] = hi;
-      wlo[m][t] = (_Float16)(w - (float)hi);
-    }
-  }
-}
 constexpr float kMxScale = 16384.0f;  // 2^24 (subnormal texels) / 2^10 (weight scale)
 constexpr int kMxSlot = 512;          // dwords of one k-step in LDS: 16 texels along the filter x 32 lines
 // LDS-DMA: 16 (or 4) bytes per lane from `src` to LDS byte address `lds` + 16 (4) * lane.  Written as inline assembly on
@@ -1637,8 +1621,17 @@ __global__ __launch_bounds__(64, 2) void k_blur_mx(BlurParams P, const DrawRec* 
   const int as = a0 + 32 * T * sa, lb = l0 + 32 * sl;
   const int n_blocks = min(T, (a_hi - as + 31) >> 5);
   const int w0 = as - reach, w0a = kV ? w0 : (w0 & ~3), delta = w0 - w0a;  // horizontal: window start moved back to a 16-byte boundary
+  // Toeplitz weight fragments (fdh_context.cpp, build_mx_weights): fragment m of the lane that carries output j of a block
+  // holds, for texel 16 m + 8 g + t of the block's window, the tap that texel meets at that output -- the same for every
+  // wave of the launch, so it is built once on the host and fetched here as 2 NK coalesced 16-byte loads
   h8 whi[NK], wlo[NK];
-  mx_weights<NK>(P.taps.dense, reach, delta, j, g, whi, wlo);
+#pragma unroll
+  for (int m = 0; m < NK; m++) {
+    H8Bits a, b;
+    const uint4 va = P.mx_w[(2 * m) * 64 + lane], vb = P.mx_w[(2 * m + 1) * 64 + lane];
+    a.u[0] = va.x; a.u[1] = va.y; a.u[2] = va.z; a.u[3] = va.w; b.u[0] = vb.x; b.u[1] = vb.y; b.u[2] = vb.z; b.u[3] = vb.w;
+    whi[m] = a.v; wlo[m] = b.v;
+  }
   const uint32_t ring_lds = (uint32_t)reinterpret_cast<uintptr_t>(ring);
 
   // LDS-DMA of k-step s (texels w0a + 16 s .. + 15 along the filter, 32 lines) into slot s % R; returns the instructions issued
@@ -1931,7 +1924,6 @@ template <int NOUT, int WAVES> static void launch_blur_v_n(hipStream_t s, const 
 #ifndef FDH_BLUR_MX
 #define FDH_BLUR_MX 1
 #endif
-static int mx_nk(int reach, int slack) { return (32 + 2 * reach + slack + 15) / 16; }
 static int mx_pick_t(long long outputs_along, long long lines) {  // segments = lines/32 * ceil(outputs_along / (32 T))
   static const int forced = [] { const char* e = std::getenv("FDH_MX_T"); return e ? std::atoi(e) : 0; }();  // experiments
   if (forced) return forced;
@@ -1945,15 +1937,20 @@ template <int NK, bool kV> static void launch_blur_mx(hipStream_t s, const BlurP
 }
 template <bool kV> static bool launch_blur_mx_nk(hipStream_t s, const BlurParams& P, const DrawRec* draws, const QuadExt* exts) {
   // LDS-DMA moves 16-byte pieces: rows have to start on 16-byte boundaries
-  if ((P.pitch & 3) || (reinterpret_cast<uintptr_t>(P.src) & 15) || P.W < 4) return false;
-  const int nk = mx_nk(P.taps.reach, kV ? 0 : 3);
+  if (!P.mx_w || (P.pitch & 3) || (reinterpret_cast<uintptr_t>(P.src) & 15) || P.W < 4) return false;
+  const int nk = mx_nk(P.taps.reach, kV);
   const int t = kV ? mx_pick_t(P.y1 - P.y0, P.x1 - P.x0) : mx_pick_t(P.x1 - P.x0, P.y1 - P.y0);
   switch (nk) {
     case 3: launch_blur_mx<3, kV>(s, P, draws, exts, t); return true;
     case 4: launch_blur_mx<4, kV>(s, P, draws, exts, t); return true;
     case 5: launch_blur_mx<5, kV>(s, P, draws, exts, t); return true;
     case 6: launch_blur_mx<6, kV>(s, P, draws, exts, t); return true;
-    default: return false;  // wider filters: the packed-FMA passes
+    case 7: launch_blur_mx<7, kV>(s, P, draws, exts, t); return true;
+    case 8: launch_blur_mx<8, kV>(s, P, draws, exts, t); return true;
+    case 9: launch_blur_mx<9, kV>(s, P, draws, exts, t); return true;
+    case 10: launch_blur_mx<10, kV>(s, P, draws, exts, t); return true;
+    case 11: launch_blur_mx<11, kV>(s, P, draws, exts, t); return true;  // reach 66 = the widest filter (radius clamp 64)
+    default: return false;
   }
 }
 void launch_blur_h(hipStream_t s, const BlurParams& P) {

@@ -91,6 +91,13 @@ struct BlurTaps {  // merged FIR of blur.frag:19-29 for one radius: out = sum co
   float dense[2 * kMaxBlurReach + 1 + 2 * kBlurPad + 16];  // + slack read (never used) by the pipelined loops
 };
 
+// Matrix-pipe blur passes (k_blur_mx): a block of 32 outputs reads NK k-steps of 16 texels; they must cover its
+// 32 + 2 reach window (+ up to 3 texels of alignment slack for the horizontal pass)
+constexpr int kMxMaxNK = 11;  // reach 66 = the widest filter (radius clamp 64)
+inline int mx_nk(int reach, bool vertical) { return (32 + 2 * reach + (vertical ? 0 : 3) + 15) / 16; }
+inline int mx_delta(int reach, bool vertical) { return vertical ? 0 : ((-reach) % 4 + 4) % 4; }  // window start -> 16-byte boundary
+constexpr size_t mx_table_bytes(int nk) { return (size_t)nk * 2 * 64 * 16; }  // [k-step][hi, lo][lane] x 8 halves
+
 struct AtlasView {
   const uint32_t* level[kMaxMips];
   int size;

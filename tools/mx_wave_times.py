@@ -1,0 +1,21 @@
+#!/usr/bin/env python3
+"""GPU-box helper: per-wave phase times of the matrix-pipe blur passes from an instrumented build
+(make -C figdraw_amd/csrc variant NAME=timing DEFS="-DFDH_STATS=1 -DFDH_TIMING=1" with the k_blur_mx probes applied)."""
+import ctypes as C, os, sys
+import numpy as np
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from figdraw_amd import context as ctx_mod
+from figdraw_amd.scenes import make_render_tree_100
+w, h = 3840, 2160
+ctx = ctx_mod.HipContext(device=0); L = ctx_mod.load()
+ctx.render_frame(make_render_tree_100(w, h, frame=0, full_frame_blur=True), w, h); ctx.replay(3); ctx.sync()
+wt = np.zeros((65536, 16), dtype=np.uint64)
+L.fdh_debug_wave_times(wt.ctypes.data_as(C.c_void_p))
+for mark, name in ((2, "horizontal"), (3, "vertical")):
+    r = wt[wt[:, 6] == mark].astype(np.float64)
+    if not len(r): continue
+    tick = 10.0  # s_memtime: 100 MHz
+    print(f"{name}: {len(r)} waves; per wave (ns): total {r[:,0].mean()*tick:.0f} (p10 {np.percentile(r[:,0],10)*tick:.0f}, p90 {np.percentile(r[:,0],90)*tick:.0f}, max {r[:,0].max()*tick:.0f}) "
+          f"prologue {r[:,1].mean()*tick:.0f}; per block: wait {(r[:,2]/r[:,8]).mean()*tick:.0f} stores {(r[:,3]/r[:,8]).mean()*tick:.0f} "
+          f"lds+mfma {(r[:,4]/r[:,8]).mean()*tick:.0f} epilogue {(r[:,5]/r[:,8]).mean()*tick:.0f} issue {(r[:,7]/r[:,8]).mean()*tick:.0f}; "
+          f"launch span {(r[:,9].max() + r[r[:,9].argmax(),0] - r[:,9].min())*tick/1000:.1f} us, start spread {(r[:,9].max()-r[:,9].min())*tick/1000:.1f} us")
