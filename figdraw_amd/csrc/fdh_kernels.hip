@@ -1624,6 +1624,10 @@ __global__ __launch_bounds__(64, 2) void k_blur_mx(BlurParams P, const DrawRec* 
   // Toeplitz weight fragments (fdh_context.cpp, build_mx_weights): fragment m of the lane that carries output j of a block
   // holds, for texel 16 m + 8 g + t of the block's window, the tap that texel meets at that output -- the same for every
   // wave of the launch, so it is built once on the host and fetched here as 2 NK coalesced 16-byte loads
+#if FDH_TIMING  // per-wave phase times in shader cycles (tools/mx_wave_times.py)
+  const unsigned long long T0 = FDH_NOW();
+  unsigned long long T_wait = 0, T_st = 0, T_mma = 0, T_epi = 0, T_iss = 0;
+#endif
   h8 whi[NK], wlo[NK];
 #pragma unroll
   for (int m = 0; m < NK; m++) {
@@ -1635,16 +1639,30 @@ __global__ __launch_bounds__(64, 2) void k_blur_mx(BlurParams P, const DrawRec* 
   const uint32_t ring_lds = (uint32_t)reinterpret_cast<uintptr_t>(ring);
 
   // LDS-DMA of k-step s (texels w0a + 16 s .. + 15 along the filter, 32 lines) into slot s % R; returns the instructions issued
+  // Per-lane source pointers of the two DMA instructions of a k-step, without the k-step's own (uniform) offset:
+  // computed once, a k-step adds a scalar.  V: (column piece, row 8 h + r) -- the row is clamped per k-step instead.
+  // H: row 16 h + r of the block's 32 rows, 16-byte piece c ^ swizzle.
+  const uint32_t* hsrc[2];
+  if (!kV) {
+    const int r = lane >> 2, c = lane & 3;
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const int row = 16 * h + r, y = min(lb + row, P.y1 - 1);  // rows past the region read a valid row and store nothing
+      hsrc[h] = P.src + (size_t)y * P.pitch + 4 * (c ^ ((row >> 2) & 3));
+    }
+  }
+  const int vxch = kV ? min(lb + 4 * (lane & 7), P.W - 4) : 0;  // (columns past the frame are never stored)
+  int issue_slot = 0;  // ring slot of the next k-step to be issued
   auto issue = [&](int s) -> int {
-    const uint32_t slot = ring_lds + (uint32_t)(s % R) * (kMxSlot * 4u);  // LDS byte address
+    const uint32_t slot = ring_lds + (uint32_t)issue_slot * (kMxSlot * 4u);  // LDS byte address
+    issue_slot = issue_slot + 1 == R ? 0 : issue_slot + 1;
     if (kV) {  // slot image [16 rows][32 px]; an instruction = 8 rows x 128 bytes
-      const int r = lane >> 3, c = lane & 7;
-      const int xch = min(lb + 4 * c, P.W - 4);  // (columns past the frame are never stored)
+      const int r = lane >> 3;
 #pragma unroll
       for (int h = 0; h < 2; h++) {
         int y = w0a + 16 * s + 8 * h + r;
         y = y < 0 ? 0 : (y > P.H - 1 ? P.H - 1 : y);  // clamp-to-edge (glcontext.nim:214-215)
-        lds_dma16(P.src + (size_t)y * P.pitch + xch, slot + h * 1024u);
+        lds_dma16(P.src + (size_t)y * P.pitch + vxch, slot + h * 1024u);
       }
       return 2;
     }
@@ -1652,13 +1670,8 @@ __global__ __launch_bounds__(64, 2) void k_blur_mx(BlurParams P, const DrawRec* 
     // ds_read_b128 of sixteen lanes (rows) hits sixteen different bank groups
     const int xb = w0a + 16 * s;
     if (xb >= 0 && xb + 16 <= P.W) {  // wave-uniform: an instruction = 16 rows x 64 bytes
-      const int r = lane >> 2, c = lane & 3;
-#pragma unroll
-      for (int h = 0; h < 2; h++) {
-        const int row = 16 * h + r, y = min(lb + row, P.y1 - 1);
-        const int gx = xb + 4 * (c ^ ((row >> 2) & 3));
-        lds_dma16(P.src + (size_t)y * P.pitch + gx, slot + h * 1024u);
-      }
+      lds_dma16(hsrc[0] + xb, slot);
+      lds_dma16(hsrc[1] + xb, slot + 1024u);
       return 2;
     }
     const int rr = lane >> 4, pp = lane & 15;  // the k-step crosses a frame edge: one texel per lane, clamped
@@ -1676,13 +1689,14 @@ __global__ __launch_bounds__(64, 2) void k_blur_mx(BlurParams P, const DrawRec* 
     __builtin_amdgcn_sched_barrier(0);
   };
 
-  const int n_steps = 2 * n_blocks + NK - 2;
   for (int s = 0; s < NK; s++) issue(s);
   int last_batch = 0;
   if (n_blocks > 1) { last_batch = issue(NK); last_batch += issue(NK + 1); }
-  (void)n_steps;
   DrawRec r;
   if (kV && P.fuse_draw >= 0) r = load_rec(draws + P.fuse_draw);
+#if FDH_TIMING
+  const unsigned long long T_pro = FDH_NOW() - T0 + (__builtin_amdgcn_readfirstlane(whi[0][0] != whi[0][1]) & 0u);
+#endif
   uint32_t pend[16];
   uint32_t pmask = 0;
   int pbx = 0, pby = 0;
@@ -1705,8 +1719,17 @@ __global__ __launch_bounds__(64, 2) void k_blur_mx(BlurParams P, const DrawRec* 
   int slot0 = 0;  // (2 b) % R
 #pragma unroll 1
   for (int b = 0; b < n_blocks; b++) {
+#if FDH_TIMING
+    const unsigned long long Ta = FDH_NOW();
+#endif
     wait_for_all_but(last_batch);  // the k-steps of block b have landed; the stores issued an iteration ago have drained
+#if FDH_TIMING
+    const unsigned long long Tb = FDH_NOW();
+#endif
     store_pending();               // block b - 1
+#if FDH_TIMING
+    const unsigned long long Tc = FDH_NOW();
+#endif
     f32x16 acc[4];
 #pragma unroll
     for (int c = 0; c < 4; c++)
@@ -1746,13 +1769,17 @@ __global__ __launch_bounds__(64, 2) void k_blur_mx(BlurParams P, const DrawRec* 
         acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f3, wlo[m], acc[3], 0, 0, 0);
       }
     }
+#if FDH_TIMING
+    const unsigned long long Td = FDH_NOW() + (__builtin_amdgcn_readfirstlane(__float_as_uint(acc[0][0] + acc[1][0] + acc[2][0] + acc[3][0])) & 0u);
+#endif
     // the block's 32 x 32 pixels: lane = x, register rr = row (rr & 3) + 8 (rr >> 2) + 4 g
     const int bx = kV ? lb : as + 32 * b, by = kV ? as + 32 * b : lb;
     const int x = bx + j;
     pbx = bx; pby = by;
     const bool x_ok = x >= P.x0 && x < P.x1;
 #pragma unroll
-    for (int rr = 0; rr < 16; rr++) pend[rr] = pack2(f2{acc[0][rr], acc[1][rr]} * kMxScale, f2{acc[2][rr], acc[3][rr]} * kMxScale);
+    for (int rr = 0; rr < 16; rr++)  // (scalar multiplies: the four channels sit in four accumulator tiles, a packed multiply would need two moves first)
+      pend[rr] = pack2(f2{acc[0][rr] * kMxScale, acc[1][rr] * kMxScale}, f2{acc[2][rr] * kMxScale, acc[3][rr] * kMxScale});
     if (bx >= P.x0 && bx + 32 <= P.x1 && by >= P.y0 && by + 32 <= P.y1) {  // wave-uniform: the whole block lies in the region
       pmask = 0xffffu;
     } else {
@@ -1842,13 +1869,26 @@ __global__ __launch_bounds__(64, 2) void k_blur_mx(BlurParams P, const DrawRec* 
       }
       __builtin_amdgcn_wave_barrier();
     }
+#if FDH_TIMING
+    const unsigned long long Te = FDH_NOW() + (__builtin_amdgcn_readfirstlane(pend[0] + pend[15]) & 0u);
+#endif
     // the ring slots block b - 1 gave up take the two k-steps block b + 2 adds
     __builtin_amdgcn_sched_barrier(0);
     last_batch = 0;
     if (b + 2 < n_blocks) { last_batch = issue(2 * b + NK + 2); last_batch += issue(2 * b + NK + 3); }
     slot0 = slot0 + 2 >= R ? slot0 + 2 - R : slot0 + 2;
+#if FDH_TIMING
+    const unsigned long long Tf = FDH_NOW();
+    T_wait += Tb - Ta; T_st += Tc - Tb; T_mma += Td - Tc; T_epi += Te - Td; T_iss += Tf - Te;
+#endif
   }
   store_pending();
+#if FDH_TIMING
+  if (lane == 0 && blockIdx.x < 32768) {  // rows 0.. : horizontal pass, rows 32768.. : vertical pass (the compositor's rows are overwritten)
+    unsigned long long* row = g_wave_times + 16 * ((size_t)blockIdx.x + (kV ? 32768 : 0));
+    row[0] = FDH_NOW() - T0; row[1] = T_pro; row[2] = T_wait; row[3] = T_st; row[4] = T_mma; row[5] = T_epi; row[6] = kV ? 3 : 2; row[7] = T_iss; row[8] = n_blocks; row[9] = T0;
+  }
+#endif
 }
 
 __global__ void k_fill_u32(uint32_t* p, uint32_t v, size_t n) {
@@ -1924,11 +1964,17 @@ template <int NOUT, int WAVES> static void launch_blur_v_n(hipStream_t s, const 
 #ifndef FDH_BLUR_MX
 #define FDH_BLUR_MX 1
 #endif
-static int mx_pick_t(long long outputs_along, long long lines) {  // segments = lines/32 * ceil(outputs_along / (32 T))
+// Blocks per wave: the smallest T for which every wave of the launch is resident at once.  A wave lives for the whole pass
+// (prologue + T blocks), so a second, partly filled round of waves costs a whole wave lifetime.  Slots per CU = LDS (a
+// ring of NK + 4 slots of 2 KB per wave) and at most 3 waves per SIMD (168 registers).  (4K, NK = 5: T = 4, 2040 waves for
+// 2048 slots; leaving a tenth of the slots free, T = 5, measured 1 us slower on the vertical pass.)
+static int mx_pick_t(int nk, long long outputs_along, long long lines) {
   static const int forced = [] { const char* e = std::getenv("FDH_MX_T"); return e ? std::atoi(e) : 0; }();  // experiments
   if (forced) return forced;
-  for (int t : {4, 2}) if ((lines + 31) / 32 * ((outputs_along + 32 * t - 1) / (32 * t)) >= 2000) return t;
-  return 1;
+  const long long per_cu = std::min<long long>(12, 160 / ((nk + 4) * 2)), slots = 256 * per_cu;
+  const long long along_blocks = (outputs_along + 31) / 32, line_groups = (lines + 31) / 32;
+  for (int t = 1; t < 64; t++) if (line_groups * ((along_blocks + t - 1) / t) <= slots) return t;
+  return 64;
 }
 template <int NK, bool kV> static void launch_blur_mx(hipStream_t s, const BlurParams& P, const DrawRec* draws, const QuadExt* exts, int t) {
   const int a_lo = kV ? P.y0 : P.x0, a_hi = kV ? P.y1 : P.x1, l_lo = kV ? (P.x0 & ~31) : P.y0, l_hi = kV ? P.x1 : P.y1;
@@ -1939,7 +1985,7 @@ template <bool kV> static bool launch_blur_mx_nk(hipStream_t s, const BlurParams
   // LDS-DMA moves 16-byte pieces: rows have to start on 16-byte boundaries
   if (!P.mx_w || (P.pitch & 3) || (reinterpret_cast<uintptr_t>(P.src) & 15) || P.W < 4) return false;
   const int nk = mx_nk(P.taps.reach, kV);
-  const int t = kV ? mx_pick_t(P.y1 - P.y0, P.x1 - P.x0) : mx_pick_t(P.x1 - P.x0, P.y1 - P.y0);
+  const int t = kV ? mx_pick_t(nk, P.y1 - P.y0, P.x1 - P.x0) : mx_pick_t(nk, P.x1 - P.x0, P.y1 - P.y0);
   switch (nk) {
     case 3: launch_blur_mx<3, kV>(s, P, draws, exts, t); return true;
     case 4: launch_blur_mx<4, kV>(s, P, draws, exts, t); return true;

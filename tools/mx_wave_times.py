@@ -8,13 +8,19 @@ from figdraw_amd import context as ctx_mod
 from figdraw_amd.scenes import make_render_tree_100
 w, h = 3840, 2160
 ctx = ctx_mod.HipContext(device=0); L = ctx_mod.load()
-ctx.render_frame(make_render_tree_100(w, h, frame=0, full_frame_blur=True), w, h); ctx.replay(3); ctx.sync()
+ctx.render_frame(make_render_tree_100(w, h, frame=0, full_frame_blur=True), w, h); ctx.sync()  # (one frame: the compositor's later launches overwrite only their own rows' share)
 wt = np.zeros((65536, 16), dtype=np.uint64)
 L.fdh_debug_wave_times(wt.ctypes.data_as(C.c_void_p))
 for mark, name in ((2, "horizontal"), (3, "vertical")):
-    r = wt[wt[:, 6] == mark].astype(np.float64)
+    sel = np.nonzero(wt[:, 6] == mark)[0]
+    r = wt[sel].astype(np.float64)
+    spans = []
+    for x in range(8):  # s_memtime is per XCD: compare start times only inside one
+        q = wt[sel[(sel % 8) == x]].astype(np.float64)
+        if len(q): spans.append(((q[:, 9] + q[:, 0]).max() - q[:, 9].min(), q[:, 9].max() - q[:, 9].min(), len(q)))
+    print(name, "per XCD: (kernel span, spread of wave start times, waves) in us:", [(round(a / 2100, 1), round(b / 2100, 1), n) for a, b, n in spans])
     if not len(r): continue
-    tick = 10.0  # s_memtime: 100 MHz
+    tick = 1.0 / 2.1  # s_memtime ticks are shader cycles here; ~2.1 GHz under this load -> ns
     print(f"{name}: {len(r)} waves; per wave (ns): total {r[:,0].mean()*tick:.0f} (p10 {np.percentile(r[:,0],10)*tick:.0f}, p90 {np.percentile(r[:,0],90)*tick:.0f}, max {r[:,0].max()*tick:.0f}) "
           f"prologue {r[:,1].mean()*tick:.0f}; per block: wait {(r[:,2]/r[:,8]).mean()*tick:.0f} stores {(r[:,3]/r[:,8]).mean()*tick:.0f} "
           f"lds+mfma {(r[:,4]/r[:,8]).mean()*tick:.0f} epilogue {(r[:,5]/r[:,8]).mean()*tick:.0f} issue {(r[:,7]/r[:,8]).mean()*tick:.0f}; "
