@@ -2042,7 +2042,8 @@ void launch_fill(hipStream_t s, uint32_t* p, uint32_t v, size_t n) {
 #if FDH_STATS
 void debug_wave_times(unsigned long long* out) {
   (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_times), sizeof(unsigned long long) * 16 * 65536);
-  (void)hipMemset((void*)nullptr, 0, 0);
+  void* p = nullptr;  // cleared after every read: the next read then holds exactly the launches in between
+  if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_wave_times)) == hipSuccess) (void)hipMemset(p, 0, sizeof(unsigned long long) * 16 * 65536);
 }
 void debug_counters(unsigned long long out[64], bool reset) {
   (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_counters), 64 * sizeof(unsigned long long));

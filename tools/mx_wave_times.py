@@ -8,9 +8,11 @@ from figdraw_amd import context as ctx_mod
 from figdraw_amd.scenes import make_render_tree_100
 w, h = 3840, 2160
 ctx = ctx_mod.HipContext(device=0); L = ctx_mod.load()
-ctx.render_frame(make_render_tree_100(w, h, frame=0, full_frame_blur=True), w, h); ctx.sync()  # (one frame: the compositor's later launches overwrite only their own rows' share)
+ctx.render_frame(make_render_tree_100(w, h, frame=0, full_frame_blur=True), w, h); ctx.sync()
 wt = np.zeros((65536, 16), dtype=np.uint64)
-L.fdh_debug_wave_times(wt.ctypes.data_as(C.c_void_p))
+L.fdh_debug_wave_times(wt.ctypes.data_as(C.c_void_p))  # (reading clears the rows)
+ctx.replay(1); ctx.sync()
+L.fdh_debug_wave_times(wt.ctypes.data_as(C.c_void_p))  # exactly one frame
 for mark, name in ((2, "horizontal"), (3, "vertical")):
     sel = np.nonzero(wt[:, 6] == mark)[0]
     r = wt[sel].astype(np.float64)
