@@ -43,6 +43,12 @@ int fdh_saturated_core(const float rect[4], const float rx[4], const float ry[4]
                        const float shape[2], float aa, int out_px[4]) {
   return guard([&] { fdh::saturated_core_of(rect, rx, ry, mode, factor, spread, shape, aa, out_px); });
 }
+int fdh_blur_weight_fragments(float blur_radius, int vertical, float* dense, uint16_t* frag_bits, int* reach, int* k_steps) {
+  return guard([&] {
+    if (!dense || !frag_bits || !reach || !k_steps) throw fdh::Error(FDH_ERR_INVALID, "fdh_blur_weight_fragments: null pointer");
+    fdh::blur_weight_fragments(blur_radius, vertical != 0, dense, frag_bits, reach, k_steps);
+  });
+}
 const char* fdh_version(void) { return "figdraw_hip 0.1.0 (gfx950)"; }
 int fdh_sizeof_fig(void) { return (int)sizeof(FdhFig); }
 int fdh_sizeof_glyph(void) { return (int)sizeof(FdhGlyph); }

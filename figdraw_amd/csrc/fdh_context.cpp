@@ -942,6 +942,15 @@ static void build_mx_weights(const BlurTaps& t, bool vertical, uint8_t* out) {
     }
 }
 
+void blur_weight_fragments(float blur_radius, bool vertical, float* dense, uint16_t* frag_bits, int* reach, int* k_steps) {
+  const BlurTaps t = make_taps(blur_radius);
+  for (int k = 0; k <= 2 * t.reach; k++) dense[k] = t.dense[kBlurPad + k];
+  *reach = t.reach;
+  *k_steps = mx_nk(t.reach, vertical);
+  if (*k_steps > kMxMaxNK) throw Error(FDH_ERR_INVALID, "blur_weight_fragments: filter too wide");
+  build_mx_weights(t, vertical, reinterpret_cast<uint8_t*>(frag_bits));
+}
+
 void Context::submit(bool upload) {
   const auto t_s0 = std::chrono::steady_clock::now();
   FDH_HIP(hipSetDevice(device_));

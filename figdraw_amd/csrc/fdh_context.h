@@ -237,6 +237,7 @@ class Context {
   float host_record_ms_ = 0.0f;
 };
 
+void blur_weight_fragments(float blur_radius, bool vertical, float* dense, uint16_t* frag_bits, int* reach, int* k_steps);
 void saturated_core_of(const float rect[4], const float rx[4], const float ry[4], int mode, float factor, float spread,
                        const float shape[2], float aa, int out[4]);
 

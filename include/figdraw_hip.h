@@ -289,6 +289,11 @@ FDH_API int fdh_sizeof_text_rect(void);
  * transform; all zeros when there is none.  Arguments as fdh_draw_rounded_rect_sdf. */
 FDH_API int fdh_saturated_core(const float rect[4], const float radii_x[4], const float radii_y[4], int mode, float factor,
                                float spread, const float shape[2], float aa, int out_px[4]);
+/* Diagnostic, host-only: the tap table of a backdrop blur of `blur_radius` (the merged FIR of blur.frag:11-32, glcontext.nim
+ * :1743-1786: dense weights over offsets -reach..+reach into `dense`, capacity >= 133) and the weight fragments the
+ * matrix-pipe pass (vertical != 0: vertical pass) multiplies with: k-steps x {hi, lo} x 64 lanes x 8 binary16 values into
+ * `frag_bits` (capacity >= 11 * 2 * 64 * 8).  Returns the tap reach in *reach and the number of k-steps in *k_steps. */
+FDH_API int fdh_blur_weight_fragments(float blur_radius, int vertical, float* dense, uint16_t* frag_bits, int* reach, int* k_steps);
 FDH_API const char* fdh_version(void);
 
 #ifdef __cplusplus

@@ -159,3 +159,39 @@ def test_saturated_core_is_conservative_against_the_oracle():
         want = np.array(col, np.uint8) if mode in (3, 7) else bg8
         assert (core == want).all(), (it, mode, rect, rx, ry, factor, spread, shape, tuple(out))
     assert found > 60
+
+
+def test_blur_weight_fragments_reproduce_the_fir():
+    """Host logic, no GPU: the weight fragments of the matrix-pipe blur passes (fdh_blur_weight_fragments) are the banded
+    Toeplitz form of the merged FIR: lane (j, g) of k-step m holds, for window texels 16 m + 8 g + t, the tap that texel
+    meets at output j (hi + lo halves = tap * 2^10 to 2^-21 relative), zeros outside the band; every output's weights sum
+    to 2^10 (the taps are normalised)."""
+    import ctypes as C
+
+    from figdraw_amd import context as ctx_mod
+
+    L = ctx_mod.load()
+    L.fdh_blur_weight_fragments.argtypes = [C.c_float, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_uint16), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    for radius in (0.8, 3.0, 9.0, 18.0, 27.5, 40.0, 64.0, 100.0):
+        for vertical in (0, 1):
+            dense = (C.c_float * 160)()
+            bits = (C.c_uint16 * (11 * 2 * 64 * 8))()
+            reach, nk = C.c_int(), C.c_int()
+            assert L.fdh_blur_weight_fragments(radius, vertical, dense, bits, C.byref(reach), C.byref(nk)) == 0
+            r, n = reach.value, nk.value
+            taps = np.array(dense[: 2 * r + 1], dtype=np.float64)
+            assert abs(taps.sum() - 1.0) < 1e-5 and (taps >= 0).all() and np.allclose(taps, taps[::-1], atol=1e-7)
+            delta = 0 if vertical else (-r) % 4
+            assert 16 * n >= 32 + 2 * r + delta and n <= 11
+            frag = np.frombuffer(bits, dtype=np.float16)[: n * 2 * 64 * 8].astype(np.float64).reshape(n, 2, 64, 8)
+            w = frag[:, 0] + frag[:, 1]  # [k-step][lane][t]
+            per_output = np.zeros(32)
+            for m in range(n):
+                for lane in range(64):
+                    j, g = lane & 31, lane >> 5
+                    for t in range(8):
+                        k = 16 * m + 8 * g + t - delta - j
+                        want = taps[k] * 1024.0 if 0 <= k <= 2 * r else 0.0
+                        assert abs(w[m, lane, t] - want) <= 1024.0 * 2.0 ** -21 * max(want / 1024.0, 2.0 ** -14), (radius, vertical, m, lane, t)
+                        per_output[j] += w[m, lane, t]
+            assert np.allclose(per_output, 1024.0, atol=2e-2), (radius, vertical)

@@ -118,7 +118,7 @@ def test_every_kernel_build_gives_the_same_pixels(hip, paths):
 @pytest.mark.parametrize("path", [1, 2, 3])
 def test_every_blur_path_matches_oracle(path):
     """The blur passes exist as three builds picked by region size and filter width: 2 outputs per thread (small regions),
-    8-12 outputs per thread, and the matrix-pipe passes (large regions, tap reach <= 30).  FDH_FORCE_BLUR_PATH puts every
+    8-12 outputs per thread, and the matrix-pipe passes (large regions).  FDH_FORCE_BLUR_PATH puts every
     blur of a frame on one of them (a child process); each must stay within 1 LSB of the oracle for every filter width,
     with taps clamped at all four frame edges."""
     import os
