@@ -222,6 +222,28 @@ def test_4k_config_properties(hip):
     assert full[..., 3].min() == 255
 
 
+def test_8k_full_frame_blur_matches_oracle(hip):
+    """BASELINE config 5's frame size with a wide full-frame blur: the matrix-pipe passes walk 16+ blocks per wave here (the 4K
+    frame: 4) with 6 k-steps per block; the whole frame against the oracle."""
+    from figdraw_amd.scene import Fig, FigKind, RenderList, Renders, rect, rgba
+
+    w, h = 7680, 4320
+    lst = RenderList()
+    lst.addRoot(Fig(kind=FigKind.nkRectangle, screenBox=rect(0, 0, w, h), fill=rgba(245, 245, 250, 255)))
+    for i in range(48):
+        lst.addRoot(Fig(kind=FigKind.nkRectangle, screenBox=rect((i * 1531) % w - 100, (i * 977) % h - 80, 500 + 37 * (i % 7), 300 + 29 * (i % 5)),
+                        fill=rgba(40 * (i % 6), 200 - 30 * (i % 5), 90 + 20 * (i % 8), 255), corners=[(i * 5) % 40] * 4))
+    lst.addRoot(Fig(kind=FigKind.nkBackdropBlur, screenBox=rect(0, 0, w, h), fill=rgba(255, 255, 255, 30), blur=28.0))
+    sc = Renders()
+    sc.setLayer(0, lst)
+    hip.render_frame(sc, w, h)
+    got = hip.read_pixels()
+    want = _oracle(lambda *_: sc, w, h)
+    mx, n0, n1 = diff_stats(got, want)
+    assert mx <= 1, (mx, n0, n1)
+    assert n0 <= 0.005 * w * h
+
+
 def test_backend_level_calls_match_oracle(hip):
     """Drive the BackendContext surface directly (no scene front-end), incl. set_aa_factor and mode 8/11."""
     from oracle import oracle as O
