@@ -1794,6 +1794,15 @@ __global__ __launch_bounds__(64, 2) void k_blur_mx(BlurParams P, const DrawRec* 
       // `alpha16[rr]`: the quad's coverage at the lane's pixel of row rr; pixels with an opaque backdrop under full
       // coverage are plain replacements (the blend is exact there) and need nothing more.
       const bool core = bx >= r.ix0 && bx + 32 <= r.ix1 && by >= r.iy0 && by + 32 <= r.iy1;  // coverage alpha == 1 (wave-uniform)
+      // the common block -- inside the core, every blurred texel opaque -- is done: one AND chain and one ballot decide it
+      bool replace_all = false;
+      if (core) {
+        uint32_t conj = pend[0];
+#pragma unroll
+        for (int rr = 1; rr < 16; rr++) conj &= pend[rr];
+        replace_all = __all((conj >> 24) == 255u);
+      }
+      if (!replace_all) {
       uint32_t blend_mask = 0;
       uint32_t* sc0 = ring + (slot0 >= 2 ? slot0 - 2 : slot0 - 2 + R) * kMxSlot;  // the two ring slots block b - 1 gave up: nothing is in
       uint32_t* sc1 = ring + (slot0 >= 1 ? slot0 - 1 : slot0 - 1 + R) * kMxSlot;  // flight into them until the end of this iteration
@@ -1868,6 +1877,7 @@ __global__ __launch_bounds__(64, 2) void k_blur_mx(BlurParams P, const DrawRec* 
         }
       }
       __builtin_amdgcn_wave_barrier();
+      }
     }
 #if FDH_TIMING
     const unsigned long long Te = FDH_NOW() + (__builtin_amdgcn_readfirstlane(pend[0] + pend[15]) & 0u);
