@@ -767,7 +767,11 @@ __device__ unsigned long long g_counters[64];
 template <int kPaths>
 __global__ __launch_bounds__(64, (kPaths & 1) ? 4 : FDH_FAST_WAVES) void k_composite_tiles(const DrawRec* __restrict__ draws,
                                                          const QuadExt* __restrict__ exts, CompositeParams P) {
-  __shared__ uint32_t mask_stack[1][kMaskDepth][64];  // clip stack: 4 pixels' q8 mask values packed per lane and level
+  // clip stack: 4 pixels' q8 mask values packed per lane and level.  Dynamic LDS: 4 KB when the phase has clip operations,
+  // 1 KB (what the bin-ordering wavefront needs) when it has none -- a phase's waves then fit beside the 18-KB rings of
+  // another frame's blur pass on the same CU (20 x 4 KB + 8 x 18 KB do not)
+  extern __shared__ uint32_t composite_lds[];
+  uint32_t (*mask_stack)[kMaskDepth][64] = reinterpret_cast<uint32_t (*)[kMaskDepth][64]>(composite_lds);
   // XCD-aware mapping: the dispatcher places workgroup b on XCD b % 8.  XCD x takes the bins x, x+8, x+16, ... of this
   // launch (row-major), all 16 strips of a bin back to back: a bin's draw list and records stay in ONE L2, and every
   // XCD gets an even sample of the frame -- contiguous bands per XCD left the XCDs holding the busy rows 3x the work
@@ -1924,9 +1928,10 @@ void launch_composite(hipStream_t s, const DrawRec* draws, const QuadExt* exts, 
   static const int force = [] { const char* e = std::getenv("FDH_FORCE_KERNEL_PATHS"); return e ? std::atoi(e) : 0; }();
   if (force == 3) P.has_slow = 1;
   if (force == 2) P.has_atlas = 1;
-  if (P.has_slow) hipLaunchKernelGGL(k_composite_tiles<3>, dim3(grid), blk, 0, s, draws, exts, P);
-  else if (P.has_atlas) hipLaunchKernelGGL(k_composite_tiles<2>, dim3(grid), blk, 0, s, draws, exts, P);
-  else hipLaunchKernelGGL(k_composite_tiles<0>, dim3(grid), blk, 0, s, draws, exts, P);
+  const size_t lds = P.has_masks ? sizeof(uint32_t) * kMaskDepth * 64 : sizeof(uint32_t) * 256;
+  if (P.has_slow) hipLaunchKernelGGL(k_composite_tiles<3>, dim3(grid), blk, lds, s, draws, exts, P);
+  else if (P.has_atlas) hipLaunchKernelGGL(k_composite_tiles<2>, dim3(grid), blk, lds, s, draws, exts, P);
+  else hipLaunchKernelGGL(k_composite_tiles<0>, dim3(grid), blk, lds, s, draws, exts, P);
 }
 // small regions: fewer outputs per thread -> more, shorter waves (see NOUT above)
 #ifndef FDH_BLUR_NOUT

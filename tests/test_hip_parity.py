@@ -130,6 +130,7 @@ def test_every_blur_path_matches_oracle(path):
     white, glass = (1.0, 1.0, 1.0, 1.0), (0.2, 0.3, 0.4, 0.5)  # a translucent clear colour: the fused composite has to blend
     cases = [("sweep", 700, 420, None, white), ("sweep_odd", 333, 517, None, white), ("sweep_glass", 644, 388, None, glass),
              ("backdrop", 320, 240, None, white), ("backdrop_glass", 320, 240, None, glass), ("fuzz7", 799, 601, 7, white),
+             ("fuzz7_clips", 800, 600, 7, white),  # a blur inside an open clip: the vertical pass writes the snapshot, unfused
              ("fuzz8", 1284, 720, 8, glass)]
     code = (
         "import sys, numpy as np\n"
