@@ -1624,7 +1624,7 @@ __global__ __launch_bounds__(64, 2) void k_blur_mx(BlurParams P, const DrawRec* 
   const int reach = P.taps.reach;
   const int as = a0 + 32 * T * sa, lb = l0 + 32 * sl;
   const int n_blocks = min(T, (a_hi - as + 31) >> 5);
-  const int w0 = as - reach, w0a = kV ? w0 : (w0 & ~3), delta = w0 - w0a;  // horizontal: window start moved back to a 16-byte boundary
+  const int w0 = as - reach, w0a = kV ? w0 : (w0 & ~3);  // horizontal: window start moved back to a 16-byte boundary (mx_delta)
   // Toeplitz weight fragments (fdh_context.cpp, build_mx_weights): fragment m of the lane that carries output j of a block
   // holds, for texel 16 m + 8 g + t of the block's window, the tap that texel meets at that output -- the same for every
   // wave of the launch, so it is built once on the host and fetched here as 2 NK coalesced 16-byte loads
