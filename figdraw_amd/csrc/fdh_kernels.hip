@@ -1580,11 +1580,16 @@ constexpr int kMxSlot = 512;          // dwords of one k-step in LDS: 16 texels 
 // LDS-DMA: 16 (or 4) bytes per lane from `src` to LDS byte address `lds` + 16 (4) * lane.  Written as inline assembly on
 // purpose: after the builtin form hipcc drains vmcnt to 0 before the next LDS read, which also waits for the stores just
 // issued; the kernel below places its own counted waits.  (M0 = LDS address; one wait state between s_mov m0 and its use.)
+// M0 is a reserved register for hipcc (a clobber on it is ignored, -Winline-asm): the block saves and restores it.
 __device__ __forceinline__ void lds_dma16(const void* src, uint32_t lds) {
-  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(lds) : "memory", "m0");
+  uint32_t m0_saved;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(m0_saved) : "v"(src), "s"(lds) : "memory");
 }
 __device__ __forceinline__ void lds_dma4(const void* src, uint32_t lds) {
-  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(src), "s"(lds) : "memory", "m0");
+  uint32_t m0_saved;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(m0_saved) : "v"(src), "s"(lds) : "memory");
 }
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
