@@ -195,3 +195,51 @@ def test_blur_weight_fragments_reproduce_the_fir():
                         assert abs(w[m, lane, t] - want) <= 1024.0 * 2.0 ** -21 * max(want / 1024.0, 2.0 ** -14), (radius, vertical, m, lane, t)
                         per_output[j] += w[m, lane, t]
             assert np.allclose(per_output, 1024.0, atol=2e-2), (radius, vertical)
+
+
+@pytest.mark.parametrize("radius", [1.0, 5.0, 18.0, 64.0])
+def test_blur_weight_fragments_blur_like_the_reference(radius):
+    """Host logic, no GPU: a numpy restatement of what the matrix-pipe passes compute -- (hi + lo) * texel products summed,
+    scaled by 2^-10, rounded to nearest even, RGBA8 between the passes, clamp-to-edge taps -- with the weight fragments the
+    library builds, against the oracle's blur (max 1 LSB) and the reference's blur.frag on SwiftShader (max 2 LSB)."""
+    import ctypes as C
+
+    from conftest import diff_stats, load_png
+    from figdraw_amd import context as ctx_mod
+    from oracle import oracle as O
+
+    L = ctx_mod.load()
+    L.fdh_blur_weight_fragments.argtypes = [C.c_float, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_uint16), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    src = load_png("blur_src.png")
+    img = src.astype(np.float64)
+    for vertical in (0, 1):
+        dense = (C.c_float * 160)()
+        bits = (C.c_uint16 * (11 * 2 * 64 * 8))()
+        reach, nk = C.c_int(), C.c_int()
+        assert L.fdh_blur_weight_fragments(radius, vertical, dense, bits, C.byref(reach), C.byref(nk)) == 0
+        r, n = reach.value, nk.value
+        frag = np.frombuffer(bits, dtype=np.float16)[: n * 2 * 64 * 8].astype(np.float64).reshape(n, 2, 64, 8)
+        delta = 0 if vertical else (-r) % 4
+        # output 0 of a block (lane j = 0) meets window texel 16 m + 8 g + t with tap k = that - delta
+        taps = np.zeros(2 * r + 1)
+        for m in range(n):
+            for g in range(2):
+                for t in range(8):
+                    k = 16 * m + 8 * g + t - delta
+                    if 0 <= k <= 2 * r:
+                        taps[k] = frag[m, 0, 32 * g, t] + frag[m, 1, 32 * g, t]
+        axis = 0 if vertical else 1
+        pad = [(0, 0)] * 3
+        pad[axis] = (r, r)
+        ext = np.pad(img, pad, mode="edge")
+        acc = np.zeros_like(img)
+        for k in range(2 * r + 1):
+            sl = [slice(None)] * 3
+            sl[axis] = slice(k, k + img.shape[axis])
+            acc += taps[k] * ext[tuple(sl)]
+        img = np.rint(acc / 1024.0)  # numpy rounds half to even, like v_cvt_pk_u8_f32
+    got = img.astype(np.uint8)
+    mx, n0, n1 = diff_stats(got, O.blur_image(src, radius))
+    assert mx <= 1 and n0 <= 0.005 * src.shape[0] * src.shape[1], (radius, "vs oracle", mx, n0)
+    mx, n0, n1 = diff_stats(got, load_png(f"ss_blur_r{radius:g}.png"))
+    assert mx <= 2, (radius, "vs blur.frag on SwiftShader", mx, n0)
