@@ -1701,8 +1701,10 @@ __global__ __launch_bounds__(64, 2) void k_blur_mx(BlurParams P, const DrawRec* 
   for (int s = 0; s < NK; s++) issue(s);
   int last_batch = 0;
   if (n_blocks > 1) { last_batch = issue(NK); last_batch += issue(NK + 1); }
-  DrawRec r;
-  if (kV && P.fuse_draw >= 0) r = load_rec(draws + P.fuse_draw);
+  // the consuming quad's saturated core; the rest of its record is fetched by the few blocks on its border (32 fewer
+  // SGPRs held through the walk: the vertical pass was spilling them into VGPR lanes)
+  int core_x0 = 0, core_y0 = 0, core_x1 = 0, core_y1 = 0;
+  if (kV && P.fuse_draw >= 0) { const DrawRec* q = draws + P.fuse_draw; core_x0 = q->ix0; core_y0 = q->iy0; core_x1 = q->ix1; core_y1 = q->iy1; }
 #if FDH_TIMING
   const unsigned long long T_pro = FDH_NOW() - T0 + (__builtin_amdgcn_readfirstlane(whi[0][0] != whi[0][1]) & 0u);
 #endif
@@ -1802,7 +1804,7 @@ __global__ __launch_bounds__(64, 2) void k_blur_mx(BlurParams P, const DrawRec* 
       // atlas.frag:381-388 on the blurred texel just produced, blended over the live surface (first draw of the phase).
       // `alpha16[rr]`: the quad's coverage at the lane's pixel of row rr; pixels with an opaque backdrop under full
       // coverage are plain replacements (the blend is exact there) and need nothing more.
-      const bool core = bx >= r.ix0 && bx + 32 <= r.ix1 && by >= r.iy0 && by + 32 <= r.iy1;  // coverage alpha == 1 (wave-uniform)
+      const bool core = bx >= core_x0 && bx + 32 <= core_x1 && by >= core_y0 && by + 32 <= core_y1;  // coverage alpha == 1 (wave-uniform)
       // the common block -- inside the core, every blurred texel opaque -- is done: one AND chain and one ballot decide it
       bool replace_all = false;
       if (core) {
@@ -1828,8 +1830,9 @@ __global__ __launch_bounds__(64, 2) void k_blur_mx(BlurParams P, const DrawRec* 
 #pragma unroll
         for (int rr = 0; rr < 16; rr++) (rr < 8 ? sc0 : sc1)[(rr & 7) * 64 + lane] = __float_as_uint(((valid >> rr) & 1u) ? 1.0f : -1.0f);
         __builtin_amdgcn_wave_barrier();
-        const int ra = min(max(r.iy0 - by, 0), 32), rb = max(ra, min(max(r.iy1 - by, 0), 32));  // rows [ra, rb) lie in the core's rows
-        const int ca = min(max(r.ix0 - bx, 0), 32), cb = max(ca, min(max(r.ix1 - bx, 0), 32));
+        const DrawRec r = load_rec(draws + P.fuse_draw);
+        const int ra = min(max(core_y0 - by, 0), 32), rb = max(ra, min(max(core_y1 - by, 0), 32));  // rows [ra, rb) lie in the core's rows
+        const int ca = min(max(core_x0 - bx, 0), 32), cb = max(ca, min(max(core_x1 - bx, 0), 32));
         const int nr = ra + 32 - rb, nc = ca + 32 - cb;
 #pragma unroll 1
         for (int u0 = 0; u0 < nr + nc; u0 += 2) {
