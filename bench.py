@@ -212,6 +212,8 @@ def main():
     if roofline_blur is not None:
         roofline_blur["kernel"] = "blur passes of a frame: k_blur_mx<.., false|true> (full-frame node, matrix pipe) + k_blur_h / k_blur_v (360x240 node)"
         roofline_blur["ms_per_frame"] = round(blur_ms, 4)
+        roofline_blur["arithmetic"] = ("v_mfma_f32_32x32x16_f16, f32 accumulate: RGBA8 texels as exact f16 subnormals x weights split into "
+                                       "two f16 halves (22 bits), every product exact; <= 1 LSB from the f32 FIR")
         roofline_blur["algorithmic_bytes_per_frame"] = int(st.bytes_blur)
     frame_gbs = st.bytes_algorithmic / (ms_step * 1e-3) / 1e9
     # HBM traffic per launch from PMC counters cannot be collected inside this process; it comes from the committed
