@@ -1877,9 +1877,10 @@ __global__ __launch_bounds__(64, 2) void k_blur_mx(BlurParams P, const DrawRec* 
           const F4 bl = unpack255(pend[rr]);
           F4 Fd = unpack255(dstv[rr]);
           const float sa = bl.w * k * alpha, A = 255.0f * sa;
-          // = blend(F, b.rgb / 255, sa) (blend_pre's arithmetic, FMA for FMA).  Scalar on purpose: written with the packed
-          // f2 helpers this block gave red = 0 in lanes 48-63 of a few dozen wavefronts per 4K frame (measured; the same
-          // helpers are exact everywhere else) -- the block runs for a few hundred of 8100 blocks, its cost does not matter
+          // = blend(F, b.rgb / 255, sa) (blend_pre's arithmetic, FMA for FMA), kept scalar: in an earlier arrangement of this
+          // block (coverage evaluated in a rolled 16-step loop) the packed f2 form gave red = 0 in lanes 48-63 of a few dozen
+          // wavefronts per 4K frame while the scalar form was exact; the cause was never found and the current arrangement
+          // is exact either way.  The block runs for a few hundred of 8100 blocks: its cost does not matter.
           const float ia = 1.0f - sa;
           Fd.x = __builtin_rintf(__builtin_fmaf(Fd.x, ia, bl.x * k * A));
           Fd.y = __builtin_rintf(__builtin_fmaf(Fd.y, ia, bl.y * k * A));
