@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
-"""One-off sweep of RS.random_scene seeds: HIP vs oracle, report every seed that exceeds the parity bar."""
+"""One-off sweep of RS.random_scene seeds: HIP vs oracle, report every seed that exceeds the parity bar.
+usage: fuzz_sweep.py LO HI [mx]   (mx: frame widths are multiples of 4 and every blur runs on the matrix-pipe passes)"""
 import os, sys
+MX = len(sys.argv) > 3 and sys.argv[3] == "mx"
+if MX: os.environ.setdefault("FDH_FORCE_BLUR_PATH", "3")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np, random
 import ref_scenes as RS
@@ -13,8 +16,9 @@ bad = 0
 for seed in range(lo, hi):
     rnd = random.Random(seed * 7919)
     w, h = rnd.randrange(40, 1400), rnd.randrange(40, 900)
+    if MX: w = (w + 3) & ~3
     atlas = seed % 2 == 0
-    sc = RS.random_scene(seed, float(w), float(h), n=rnd.randrange(5, 90), clips=rnd.random() < 0.6, blur=rnd.random() < 0.5, images=imgs if atlas else None)
+    sc = RS.random_scene(seed, float(w), float(h), n=rnd.randrange(5, 90), clips=rnd.random() < 0.6, blur=MX or rnd.random() < 0.5, images=imgs if atlas else None)
     ctx = HipContext(atlas_size=1024, device=0); orc = O.Oracle(atlas_size=1024, threads=16)
     if atlas:
         for k, v in RS.used_images(sc, imgs).items():
