@@ -1022,11 +1022,11 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? 4 : FDH_FAST_WAVES) void k_compo
       if (!core) return;
 #endif
 #if FDH_SIMPLE_EDGE
-      // ---- the common edge strip, written out in packed pairs: circular corners, ONE colour, nothing clipping, mode
+      // ---- the common edge strip, written out in packed pairs: ONE colour, nothing clipping, mode
       // fill / drop shadow / inner shadow / AA stroke.  Pixels (0,1) and (2,3) of the lane share every add / mul / fma
       // (v_pk_*_f32); only compares, selects, min/max and the transcendentals stay per pixel.  Same formulas, same
       // order of operations as the generic path below.
-      if (!core && !ellip && (om & F_SOLID) && fill_mode == 0u && op == OP_DRAW && mask_depth == 0 && !rmask_on &&
+      if (!core && (om & F_SOLID) && fill_mode == 0u && op == OP_DRAW && mask_depth == 0 && !rmask_on &&
           (mode == 3u || mode == 7u || mode == 9u || mode == 12u)) {
         const bool inset = mode == 9u;
         const float shx = inset ? r.p0 : r.p2, shy = inset ? r.p1 : r.p3;
@@ -1057,8 +1057,16 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? 4 : FDH_FAST_WAVES) void k_compo
           const f2 inb = {__builtin_fminf(__builtin_fmaxf(qxb.x, qyb.x), 0.0f), __builtin_fminf(__builtin_fmaxf(qxb.y, qyb.y), 0.0f)};
           da = ina + lena - rra; db = inb + lenb - rrb;
         };
+        // elliptical corners (atlas.frag:96-115): the distance itself comes from the general routine, four pixels
+        // unpacked; coverage and blend below stay packed
+        auto dist4e = [&](const f2 pxa, const f2 pxb, const float py_, const float bx, const float by, f2& oa, f2& ob) __attribute__((always_inline)) {
+          const float px4[4] = {pxa.x, pxa.y, pxb.x, pxb.y};
+          float d4[4];
+          shape_distN<4>(true, px4, py_, bx, by, r.r[0], r.r[1], r.r[2], r.r[3], d4);
+          oa = {d4[0], d4[1]}; ob = {d4[2], d4[3]};
+        };
         f2 da, db;
-        dist4(lxa, lxb, pyy, shx, shy, da, db);
+        if (ellip) dist4e(lxa, lxb, pyy, shx, shy, da, db); else dist4(lxa, lxb, pyy, shx, shy, da, db);
         f2 ala, alb;  // coverage
         if (mode == 3u) {
           const f2 ta = da * r.aa + 0.5f, tb = db * r.aa + 0.5f;
@@ -1072,7 +1080,7 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? 4 : FDH_FAST_WAVES) void k_compo
           if (__all(ala.x == 0.0f && ala.y == 0.0f && alb.x == 0.0f && alb.y == 0.0f)) return;  // inside the stroke: no-op
         } else if (inset) {  // 9: atlas.frag:364-380 -- clip alpha of the node's own shape x the falloff inside the offset shape
           f2 sha, shb;
-          dist4(lxa - r.p2, lxb - r.p2, pyy + r.p3, r.p0, r.p1, sha, shb);
+          if (ellip) dist4e(lxa - r.p2, lxb - r.p2, pyy + r.p3, r.p0, r.p1, sha, shb); else dist4(lxa - r.p2, lxb - r.p2, pyy + r.p3, r.p0, r.p1, sha, shb);
           const float spread = r.f1;
           const f2 sda = sha + spread, sdb = shb + spread;
           const float rs = frcp(__builtin_fmaxf(0.5f * r.f0, 0.5f));
@@ -1600,8 +1608,9 @@ template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_wai
 // the top of an iteration allows exactly the batch issued last and nothing is issued between that batch and the wait.
 // Both passes end with lane = x, accumulator register = y inside a 32 x 32 pixel block (the horizontal pass multiplies
 // texels x weights, the vertical one weights x texels), so every store is a 128-byte run.
-template <int NK, bool kV>
-__global__ __launch_bounds__(64, 2) void k_blur_mx(BlurParams P, const DrawRec* __restrict__ draws, const QuadExt* __restrict__ exts, int T) {
+template <int NK>
+__global__ __launch_bounds__(64, 2) void k_blur_mx(BlurParams P, const DrawRec* __restrict__ draws, const QuadExt* __restrict__ exts, int T, int vertical) {
+  const bool kV = vertical != 0;
   constexpr int R = NK + 4;
   extern __shared__ __attribute__((aligned(16))) uint32_t ring[];  // R slots
   // blocks sit at absolute multiples of 32 along the filter direction: a pixel's sum is then grouped into MFMAs the same
@@ -2005,7 +2014,7 @@ static int mx_pick_t(int nk, long long outputs_along, long long lines) {
 template <int NK, bool kV> static void launch_blur_mx(hipStream_t s, const BlurParams& P, const DrawRec* draws, const QuadExt* exts, int t) {
   const int a_lo = kV ? P.y0 : P.x0, a_hi = kV ? P.y1 : P.x1, l_lo = kV ? (P.x0 & ~31) : P.y0, l_hi = kV ? P.x1 : P.y1;
   const int total = ((a_hi - (a_lo & ~31) + 32 * t - 1) / (32 * t)) * ((l_hi - l_lo + 31) / 32);
-  hipLaunchKernelGGL((k_blur_mx<NK, kV>), dim3(8 * ((total + 7) / 8)), dim3(64), (size_t)(NK + 4) * kMxSlot * sizeof(uint32_t), s, P, draws, exts, t);
+  hipLaunchKernelGGL((k_blur_mx<NK>), dim3(8 * ((total + 7) / 8)), dim3(64), (size_t)(NK + 4) * kMxSlot * sizeof(uint32_t), s, P, draws, exts, t, kV ? 1 : 0);
 }
 template <bool kV> static bool launch_blur_mx_nk(hipStream_t s, const BlurParams& P, const DrawRec* draws, const QuadExt* exts) {
   // LDS-DMA moves 16-byte pieces: rows have to start on 16-byte boundaries
