@@ -57,7 +57,7 @@ def _u16(x) -> int:  # Nim uint16(float) truncates
 
 
 def make_render_tree_100(w: float, h: float, frame: int = 0, copies: int = 100, full_frame_blur: bool = False,
-                         seed: int = 12345) -> Renders:
+                         seed: int = 12345, full_frame_blur_radius: float = 18.0) -> Renders:
     w, h = f32(w), f32(h)
     lst = RenderList()
     t = f32(f32(frame) * f32(0.02))
@@ -152,7 +152,7 @@ def make_render_tree_100(w: float, h: float, frame: int = 0, copies: int = 100, 
 
     if full_frame_blur:
         # one full-frame nkBackdropBlur(18) after the rects, before the overlay
-        lst.addRoot(Fig(kind=FigKind.nkBackdropBlur, screenBox=rect(0, 0, w, h), fill=rgba(0, 0, 0, 0), blur=18.0))
+        lst.addRoot(Fig(kind=FigKind.nkBackdropBlur, screenBox=rect(0, 0, w, h), fill=rgba(0, 0, 0, 0), blur=full_frame_blur_radius))
 
     yellowW, yellowH, yellowMargin = f32(360), f32(240), f32(20)
     yellowTravelX = max(f32(0), f32(w - yellowW - yellowMargin * f32(2)))

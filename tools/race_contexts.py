@@ -6,10 +6,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.ins
 import numpy as np
 from figdraw_amd.context import HipContext
 from figdraw_amd.scenes import make_render_tree_100
-w, h = 1280, 720
+w, h = [int(v) for v in os.environ.get('SIZE', '1280x720').split('x')]
+COPIES = int(os.environ.get('COPIES', '40'))
 NC = int(os.environ.get('NC', '3'))
 ONLY1 = os.environ.get('ONLY1')
-scenes = [make_render_tree_100(w, h, frame=f, copies=40, full_frame_blur=(not ONLY1 or f == 1)) for f in range(NC)]
+RADII = [float(v) for v in os.environ.get('RADII', '18').split(',')]  # per context, cycled: different radii = different kernel instantiations
+scenes = [make_render_tree_100(w, h, frame=f, copies=COPIES, full_frame_blur=(not ONLY1 or f == 1), full_frame_blur_radius=RADII[f % len(RADII)]) for f in range(NC)]
 hip = HipContext(device=0)
 alone = []
 for sc in scenes:
