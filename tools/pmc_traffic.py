@@ -21,9 +21,8 @@ for base, lst in by_kernel.items():
         c = {n: sum(v) / len(v) for n, v in agg[(k, g)].items()}
         if base == "k_composite_tiles":
             label = "k_composite_tiles.phase0" if i == 0 else f"k_composite_tiles.later{i}"
-        elif base == "k_blur_mx":  # template arguments <NK, vertical>
-            label = "k_blur_mx.vertical" if "true" in k else "k_blur_mx.horizontal"
-            label += "" if not any(kk.startswith(label) for kk in kernels) else f".{i}"
+        elif base == "k_blur_mx":  # one kernel function for both passes: the horizontal and the vertical launch share name and grid
+            label = "k_blur_mx.both_passes" if i == 0 else f"k_blur_mx.{i}"
         elif base in ("k_blur_h", "k_blur_v"):
             label = f"{base}.largest" if i == 0 else f"{base}.{i}"
         else:
@@ -32,6 +31,9 @@ for base, lst in by_kernel.items():
         e.update({n: round(v, 1) for n, v in c.items()})
         if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
             e["hbm_bytes"] = int((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024)
+            if label == "k_blur_mx.both_passes":  # the counters are means per launch; a frame has the two launches
+                e["hbm_bytes_per_launch"] = e["hbm_bytes"]
+                e["hbm_bytes"] *= 2
         if "TCC_HIT_sum" in c and "TCC_MISS_sum" in c and c["TCC_HIT_sum"] + c["TCC_MISS_sum"] > 0:
             e["l2_hit_rate"] = round(c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"]), 3)
         kernels[label] = e
