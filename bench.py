@@ -136,6 +136,14 @@ def main():
     if dist is not None:
         dist.barrier()
     elapsed = t1 - t0
+    # Integrity of the frames-in-flight mode (outside the timed region): every context must hold exactly the frame it
+    # renders with the GPU to itself.  (The blur passes once failed this as two kernels: DESIGN.md section 4.)
+    in_flight_differing = 0
+    for c in ctxs:
+        got_in_flight = c.read_pixels()
+        c.replay(1)
+        c.sync()
+        in_flight_differing += int((got_in_flight != c.read_pixels()).any(axis=2).sum())
     if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if on_host else f"cuda:{local_rank}")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -274,6 +282,8 @@ def main():
                                f"2-pass Gaussian backdrop blur(18) (BASELINE.json configs[2])",
                    "draws": st.n_draws, "phases": st.n_phases, "blur_nodes": st.n_blurs, "fragments": int(st.fragments),
                    "parallelism": f"frame-parallel x{world}" if world > 1 else "single GPU", "frames_in_flight_per_gpu": F},
+        "frames_in_flight_check": {"contexts": F, "identical_to_each_frame_rendered_alone": in_flight_differing == 0,
+                                   "pixels_differing": in_flight_differing},
         "one_frame_at_a_time": {"value": round(w * h * args.steps / single_elapsed / 1e6, 1), "unit": "Mpixels/s (this rank)",
                                 "ms_per_step": round(1e3 * single_elapsed / args.steps, 4)},
         "roofline": roofline,
