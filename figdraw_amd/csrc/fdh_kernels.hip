@@ -1026,7 +1026,7 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? 4 : FDH_FAST_WAVES) void k_compo
       // fill / drop shadow / inner shadow / AA stroke.  Pixels (0,1) and (2,3) of the lane share every add / mul / fma
       // (v_pk_*_f32); only compares, selects, min/max and the transcendentals stay per pixel.  Same formulas, same
       // order of operations as the generic path below.
-      if (!core && (om & F_SOLID) && fill_mode == 0u && op == OP_DRAW && mask_depth == 0 && !rmask_on &&
+      if (!core && (kPaths == 0 || !ellip) && (om & F_SOLID) && fill_mode == 0u && op == OP_DRAW && mask_depth == 0 && !rmask_on &&
           (mode == 3u || mode == 7u || mode == 9u || mode == 12u)) {
         const bool inset = mode == 9u;
         const float shx = inset ? r.p0 : r.p2, shy = inset ? r.p1 : r.p3;
@@ -1066,7 +1066,7 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? 4 : FDH_FAST_WAVES) void k_compo
           oa = {d4[0], d4[1]}; ob = {d4[2], d4[3]};
         };
         f2 da, db;
-        if (ellip) dist4e(lxa, lxb, pyy, shx, shy, da, db); else dist4(lxa, lxb, pyy, shx, shy, da, db);
+        if (kPaths == 0 && ellip) dist4e(lxa, lxb, pyy, shx, shy, da, db); else dist4(lxa, lxb, pyy, shx, shy, da, db);
         f2 ala, alb;  // coverage
         if (mode == 3u) {
           const f2 ta = da * r.aa + 0.5f, tb = db * r.aa + 0.5f;
@@ -1080,7 +1080,7 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? 4 : FDH_FAST_WAVES) void k_compo
           if (__all(ala.x == 0.0f && ala.y == 0.0f && alb.x == 0.0f && alb.y == 0.0f)) return;  // inside the stroke: no-op
         } else if (inset) {  // 9: atlas.frag:364-380 -- clip alpha of the node's own shape x the falloff inside the offset shape
           f2 sha, shb;
-          if (ellip) dist4e(lxa - r.p2, lxb - r.p2, pyy + r.p3, r.p0, r.p1, sha, shb); else dist4(lxa - r.p2, lxb - r.p2, pyy + r.p3, r.p0, r.p1, sha, shb);
+          if (kPaths == 0 && ellip) dist4e(lxa - r.p2, lxb - r.p2, pyy + r.p3, r.p0, r.p1, sha, shb); else dist4(lxa - r.p2, lxb - r.p2, pyy + r.p3, r.p0, r.p1, sha, shb);
           const float spread = r.f1;
           const f2 sda = sha + spread, sdb = shb + spread;
           const float rs = frcp(__builtin_fmaxf(0.5f * r.f0, 0.5f));
