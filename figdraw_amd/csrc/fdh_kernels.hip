@@ -1608,6 +1608,11 @@ template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_wai
 // the top of an iteration allows exactly the batch issued last and nothing is issued between that batch and the wait.
 // Both passes end with lane = x, accumulator register = y inside a 32 x 32 pixel block (the horizontal pass multiplies
 // texels x weights, the vertical one weights x texels), so every store is a 128-byte run.
+//
+// ONE kernel function with ONE body for both passes: `kV` is a wave-uniform run-time flag tested where the passes differ.
+// Do not specialise it (two kernels, or two bodies under a branch): that form is 4 us per pass faster and exact alone,
+// but with several contexts replaying on their own streams it corrupted texels in 10-60 % of the runs; this form has
+// not in 13 000 (tools/race_contexts.py has to stay clean after any change here).
 template <int NK>
 __global__ __launch_bounds__(64, 2) void k_blur_mx(BlurParams P, const DrawRec* __restrict__ draws, const QuadExt* __restrict__ exts, int T, int vertical) {
   const bool kV = vertical != 0;

@@ -176,7 +176,7 @@ def test_contexts_in_flight_do_not_disturb_each_other(hip):
         hip.render_frame(sc, w, h)
         alone.append(hip.read_pixels())
     # Repeated: with the blur passes as two different LDS-DMA kernels (horizontal, vertical) roughly one run in eight came
-    # out with a few hundred wrong pixels in one context; as one kernel function: none in 600 (tools/race_contexts.py).
+    # out with a few hundred wrong pixels in one context; as one kernel function with one merged body: none in 13 000 (tools/race_contexts.py).
     for _ in range(8):
         ctxs = [HipContext(device=0) for _ in scenes]
         for c, sc in zip(ctxs, scenes):
