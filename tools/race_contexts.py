@@ -27,6 +27,8 @@ for it in range(int(sys.argv[1]) if len(sys.argv) > 1 else 20):
         if not np.array_equal(got, want):
             bad += 1
             d = np.abs(got.astype(int) - want.astype(int)).max(axis=2); ys, xs = np.nonzero(d)
+            if os.environ.get('SAMPLES') and bad <= 3:
+                for k in range(0, len(ys), max(1, len(ys) // 6)): print("   px", xs[k], ys[k], "got", got[ys[k], xs[k]], "want", want[ys[k], xs[k]])
             if bad < 100: print("iter", it, "ctx", i, "differing", len(ys), "max", d.max(), "bbox x", xs.min(), xs.max(), "y", ys.min(), ys.max(),
                   "\n", (got.astype(int) - want.astype(int))[ys.min():ys.max() + 1:4, xs.min():xs.max() + 1:4, 0] if len(ys) < 3000 and bad <= 2 else "",
                   "x%32", np.unique(xs % 32)[:8], "y%32", np.unique(ys % 32)[:8], "blocks", sorted(set(zip((xs // 32).tolist(), (ys // 32).tolist())))[:6])
