@@ -102,6 +102,7 @@ def load():
     L.fdh_atlas_size.argtypes = [vp, C.POINTER(C.c_int)]
     L.fdh_atlas_packed_area.argtypes = [vp, C.POINTER(C.c_int64)]
     L.fdh_read_pixels.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]
+    L.fdh_debug_read_surface.argtypes = [vp, C.c_int, vp]
     L.fdh_frame_device_ptr.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int64)]
     L.fdh_sync.argtypes = [vp]
     L.fdh_set_ui_scale.argtypes = [vp, C.c_float]
@@ -292,6 +293,12 @@ class HipContext:
             x, y, w, h = 0, 0, self.W, self.H
         out = np.zeros((h, w, 4), dtype=np.uint8)
         self._ck(self.L.fdh_read_pixels(self.h, x, y, w, h, out.ctypes.data))
+        return out
+
+    def debug_read_surface(self, which: int) -> np.ndarray:
+        """0: frame, 1: horizontal blur pass output, 2: blurred snapshot (diagnostic)"""
+        out = np.zeros((self.H, self.W, 4), dtype=np.uint8)
+        self._ck(self.L.fdh_debug_read_surface(self.h, which, out.ctypes.data))
         return out
 
     def frame_device_ptr(self):

@@ -34,6 +34,14 @@ inline Context* C(FdhContext* c) {
 extern "C" {
 
 const char* fdh_last_error(void) { return g_last_error.c_str(); }
+#if defined(FDH_EDGE_CHECK) && FDH_EDGE_CHECK
+extern "C++" { namespace fdh { void debug_edge_bad(unsigned int* n, unsigned int* out, bool reset); } }
+__attribute__((visibility("default"))) int fdh_debug_edge_bad(unsigned int* n, unsigned int* out, int reset) { fdh::debug_edge_bad(n, out, reset != 0); return 0; }
+#endif
+#if defined(FDH_MX_CHECK) && FDH_MX_CHECK
+extern "C++" { namespace fdh { void debug_mx_bad(unsigned int* n, unsigned int* out, bool reset); } }
+__attribute__((visibility("default"))) int fdh_debug_mx_bad(unsigned int* n, unsigned int* out, int reset) { fdh::debug_mx_bad(n, out, reset != 0); return 0; }
+#endif
 #if FDH_STATS
 extern "C++" { namespace fdh { void debug_counters(unsigned long long out[64], bool reset); void debug_wave_times(unsigned long long* out); } }
 __attribute__((visibility("default"))) int fdh_debug_wave_times(unsigned long long* out) { fdh::debug_wave_times(out); return 0; }
@@ -163,6 +171,12 @@ int fdh_read_pixels(FdhContext* c, int x, int y, int w, int h, uint8_t* out) {
 }
 int fdh_frame_device_ptr(FdhContext* c, void** p, int* w, int* h, int64_t* pitch) {
   return guard([&] { C(c)->frame_device_ptr(p, w, h, pitch); });
+}
+int fdh_debug_read_surface(FdhContext* c, int which, uint8_t* out) {
+  return guard([&] {
+    if (!out) throw fdh::Error(FDH_ERR_INVALID, "null output buffer");
+    C(c)->debug_read_surface(which, out);
+  });
 }
 int fdh_sync(FdhContext* c) { return guard([&] { C(c)->sync(); }); }
 int fdh_set_ui_scale(FdhContext* c, float s) { return guard([&] { C(c)->set_ui_scale(s); }); }

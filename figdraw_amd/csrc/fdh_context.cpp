@@ -61,6 +61,7 @@ Context::~Context() {
   if (fb_) (void)hipFree(fb_);
   if (backdrop_) (void)hipFree(backdrop_);
   if (blur_tmp_) (void)hipFree(blur_tmp_);
+  if (dbg_snap_) (void)hipFree(dbg_snap_);
   d_frame_.release(); d_lists_.release(); d_counts_.release(); d_order_[0].release(); d_order_[1].release();
   for (auto& b : staging_) b.release();
   for (auto& e : staging_ev_) if (e) (void)hipEventDestroy(e);
@@ -292,6 +293,7 @@ void Context::ensure_surfaces() {
   if (fb_) FDH_HIP(hipFree(fb_));
   if (backdrop_) FDH_HIP(hipFree(backdrop_));
   if (blur_tmp_) FDH_HIP(hipFree(blur_tmp_));
+  if (dbg_snap_) { FDH_HIP(hipFree(dbg_snap_)); dbg_snap_ = nullptr; }
   const size_t n = (size_t)W_ * H_;
   FDH_HIP(hipMalloc((void**)&fb_, n * 4));
   FDH_HIP(hipMalloc((void**)&backdrop_, n * 4));
@@ -1194,6 +1196,11 @@ void Context::launch_frame(bool profile) {
     span_begin(p == 0 ? 1 : 2);
     launch_composite(stream_, dv_.recs, dv_.exts, C);
     span_end();
+    static const bool snap = [] { const char* e = std::getenv("FDH_DEBUG_SNAP"); return e && std::atoi(e) != 0; }();
+    if (snap && p == 0) {  // diagnostic only (tools/race_probe.py): what the first blur pass is about to read
+      if (!dbg_snap_) FDH_HIP(hipMalloc((void**)&dbg_snap_, (size_t)W_ * H_ * 4));
+      FDH_HIP(hipMemcpyAsync(dbg_snap_, fb_, (size_t)W_ * H_ * 4, hipMemcpyDeviceToDevice, stream_));
+    }
   }
   FDH_HIP(hipGetLastError());
 }
@@ -1277,6 +1284,13 @@ void Context::read_pixels(int x, int y, int w, int h, uint8_t* out) {
   if (x < 0 || y < 0 || x + w > W_ || y + h > H_) throw Error(FDH_ERR_INVALID, "readPixels: rectangle outside the frame");
   FDH_HIP(hipStreamSynchronize(stream_));
   FDH_HIP(hipMemcpy2D(out, (size_t)w * 4, fb_ + (size_t)y * W_ + x, (size_t)W_ * 4, (size_t)w * 4, h, hipMemcpyDeviceToHost));
+}
+void Context::debug_read_surface(int which, uint8_t* out) {
+  const uint32_t* src = which == 0 ? fb_ : which == 1 ? blur_tmp_ : which == 2 ? backdrop_ : which == 3 ? dbg_snap_ : nullptr;
+  if (!src) throw Error(FDH_ERR_INVALID, "debug_read_surface: no such surface (or no frame yet)");
+  FDH_HIP(hipSetDevice(device_));
+  FDH_HIP(hipStreamSynchronize(stream_));
+  FDH_HIP(hipMemcpy(out, src, (size_t)W_ * H_ * 4, hipMemcpyDeviceToHost));
 }
 void Context::frame_device_ptr(void** p, int* w, int* h, int64_t* pitch_bytes) {
   if (!fb_) throw Error(FDH_ERR_INVALID, "no frame surface yet");

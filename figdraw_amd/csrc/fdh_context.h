@@ -141,6 +141,7 @@ class Context {
   // readback / interop
   void read_pixels(int x, int y, int w, int h, uint8_t* out);
   void frame_device_ptr(void** p, int* w, int* h, int64_t* pitch_bytes);
+  void debug_read_surface(int which, uint8_t* out);
   void sync();
   void set_stream(void* s);
 
@@ -207,6 +208,7 @@ class Context {
 
   // device state
   uint32_t *fb_ = nullptr, *backdrop_ = nullptr, *blur_tmp_ = nullptr;
+  uint32_t* dbg_snap_ = nullptr;  // FDH_DEBUG_SNAP=1 (diagnostic): the surface as phase 0 left it, copied in-stream
   int surf_w_ = 0, surf_h_ = 0;
   // records, quad extensions, bounding boxes and phase offsets of a frame live in ONE device block and arrive with ONE
   // copy (four small hipMemcpyAsync calls cost the host ~100 us per frame); the typed views point into it

@@ -1,13 +1,18 @@
 // fdh_kernels.hip -- hand-written gfx950 (CDNA4) kernels for figdraw's per-pixel SDF path.
 //
-//   k_bin_draws        coarse binning: ordered per-bin draw lists (64x64-pixel bins)
-//   k_composite_tiles  one wavefront per 8x8 tile walks its draws in painter's order keeping RGBA in
-//                      registers, re-quantising to RGBA8 after every draw like the GL framebuffer does
-//                      (utils/glutils.nim:150-154 blend + RGBA8 target), and stores the tile once
-//   k_blur_h/k_blur_v  the separable backdrop blur of glsl/blur.frag as a merged FIR, LDS line staging
+//   k_bin_draws        coarse binning: one wavefront per (phase, 64x64-pixel bin) builds the bin's draw list in painter's
+//                      order; an entry carries the draw index, flags and two 16-bit strip masks (touched / inside the core)
+//   k_composite_tiles  one single-wave workgroup per 32x8-pixel strip (four 8x8 tiles side by side, four pixels per lane)
+//                      walks the bin's list in painter's order keeping RGBA in registers, re-quantising to RGBA8 after every
+//                      draw like the GL framebuffer does (utils/glutils.nim:150-154 blend + RGBA8 target), and stores the
+//                      strip once.  Three builds <0|2|3> picked per phase (SDF only / + 4-wide atlas path / + general quads)
+//   k_blur_mx<NK,kV>   the separable backdrop blur of glsl/blur.frag for regions of 0.4 Mpx and more: the merged FIR as a banded
+//                      Toeplitz product on the matrix pipe (v_mfma_f32_32x32x16_f16), texels staged by LDS-DMA into a per-wave ring
+//   k_blur_h/k_blur_v  the same FIR with VALU FMAs for small regions and unaligned pitches, LDS line staging
 //
-// The per-pixel math restates src/figdraw/opengl/glsl/{atlas,atlas_rect_mask,mask}.frag; every device
-// function cites the lines it follows.  No MFMA: this is VALU + transcendental work.
+// The per-pixel math restates src/figdraw/opengl/glsl/{atlas,atlas_rect_mask,mask,blur}.frag; every device function cites
+// the lines it follows.  Only the blur FIR is a contraction and runs on MFMA; everything else is VALU + transcendental work
+// (SURVEY.md 8d).  The translation unit is compiled WITHOUT packed-FP32 instructions (csrc/Makefile): DESIGN.md section 4.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -759,6 +764,13 @@ __device__ unsigned long long g_counters[64];
 #endif
 // kSlow = false is the build for phases made only of axis-aligned SDF draws, clips and rect masks (no atlas sampling,
 // no rotated quads, no bezier strokes): without the one-pixel-slot path the kernel needs no scratch and fits 5 waves/SIMD.
+#ifndef FDH_EDGE_CHECK
+#define FDH_EDGE_CHECK 0  // experiment builds only: every packed edge strip is also shaded by the generic path and compared
+#endif
+#if FDH_EDGE_CHECK
+__device__ unsigned int g_edge_bad_n;
+__device__ unsigned int g_edge_bad[4096 * 8];
+#endif
 #ifndef FDH_FAST_WAVES
 #define FDH_FAST_WAVES 5
 #endif
@@ -1026,6 +1038,10 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? 4 : FDH_FAST_WAVES) void k_compo
       // fill / drop shadow / inner shadow / AA stroke.  Pixels (0,1) and (2,3) of the lane share every add / mul / fma
       // (v_pk_*_f32); only compares, selects, min/max and the transcendentals stay per pixel.  Same formulas, same
       // order of operations as the generic path below.
+#if FDH_EDGE_CHECK
+      F4 S0 = F0, S1 = F1, S2 = F2, S3 = F3;
+      bool did_simple = false;
+#endif
       if (!core && (kPaths == 0 || !ellip) && (om & F_SOLID) && fill_mode == 0u && op == OP_DRAW && mask_depth == 0 && !rmask_on &&
           (mode == 3u || mode == 7u || mode == 9u || mode == 12u)) {
         const bool inset = mode == 9u;
@@ -1115,9 +1131,17 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? 4 : FDH_FAST_WAVES) void k_compo
         const f2 Aa = saa * 255.0f, Ab = sab * 255.0f, iaa = 1.0f - saa, iab = 1.0f - sab;
         const f2 crg = {c0u.x * inv255, c0u.y * inv255};
         const float cb = c0u.z * inv255;
+#if FDH_EDGE_CHECK
+        { const f2 b1 = {cb, 1.0f}; blend_pre(S0, crg * Aa.x, b1 * Aa.x, iaa.x); blend_pre(S1, crg * Aa.y, b1 * Aa.y, iaa.y);
+          blend_pre(S2, crg * Ab.x, b1 * Ab.x, iab.x); blend_pre(S3, crg * Ab.y, b1 * Ab.y, iab.y); }
+        did_simple = true;
+#else
         { const f2 b1 = {cb, 1.0f}; blend_pre(F0, crg * Aa.x, b1 * Aa.x, iaa.x); blend_pre(F1, crg * Aa.y, b1 * Aa.y, iaa.y);
           blend_pre(F2, crg * Ab.x, b1 * Ab.x, iab.x); blend_pre(F3, crg * Ab.y, b1 * Ab.y, iab.y); }
+#endif
+#if !FDH_EDGE_CHECK
         return;
+#endif
       }
 #endif
       FDH_COUNT(8 + (mode & 31u));
@@ -1303,6 +1327,18 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? 4 : FDH_FAST_WAVES) void k_compo
       blend(F1, sr[1], sg[1], sb[1], cov[1] ? sa[1] * mk1 * rm1 : 0.0f);
       blend(F2, sr[2], sg[2], sb[2], cov[2] ? sa[2] * mk2 * rm2 : 0.0f);
       blend(F3, sr[3], sg[3], sb[3], cov[3] ? sa[3] * mk3 * rm3 : 0.0f);
+#if FDH_EDGE_CHECK
+      if (did_simple) {
+        const float gS[16] = {S0.x, S0.y, S0.z, S0.w, S1.x, S1.y, S1.z, S1.w, S2.x, S2.y, S2.z, S2.w, S3.x, S3.y, S3.z, S3.w};
+        const float gF[16] = {F0.x, F0.y, F0.z, F0.w, F1.x, F1.y, F1.z, F1.w, F2.x, F2.y, F2.z, F2.w, F3.x, F3.y, F3.z, F3.w};
+#pragma unroll
+        for (int e = 0; e < 16; e++)
+          if (__float_as_uint(gS[e]) != __float_as_uint(gF[e])) {
+            const unsigned int i = atomicAdd(&g_edge_bad_n, 1u);
+            if (i < 4096u) { unsigned int* o = g_edge_bad + 8 * i; o[0] = mode; o[1] = blockIdx.x; o[2] = d; o[3] = (unsigned)e; o[4] = (unsigned)lane; o[5] = (ellip ? 1u : 0u) | ((unsigned)(reinterpret_cast<uintptr_t>(P.fb) >> 12) << 1); o[6] = __float_as_uint(gS[e]); o[7] = __float_as_uint(gF[e]); }
+          }
+      }
+#endif
     };
     while (m != 0) {
       const int bit = __builtin_ctzll(m);
@@ -1609,13 +1645,20 @@ template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_wai
 // Both passes end with lane = x, accumulator register = y inside a 32 x 32 pixel block (the horizontal pass multiplies
 // texels x weights, the vertical one weights x texels), so every store is a 128-byte run.
 //
-// ONE kernel function with ONE body for both passes: `kV` is a wave-uniform run-time flag tested where the passes differ.
-// Do not specialise it (two kernels, or two bodies under a branch): that form is 4 us per pass faster and exact alone,
-// but with several contexts replaying on their own streams it corrupted texels in 10-60 % of the runs; this form has
-// not in 13 000 (tools/race_contexts.py has to stay clean after any change here).
-template <int NK>
-__global__ __launch_bounds__(64, 2) void k_blur_mx(BlurParams P, const DrawRec* __restrict__ draws, const QuadExt* __restrict__ exts, int T, int vertical) {
-  const bool kV = vertical != 0;
+// Two specialisations (horizontal, vertical).  Round 1 shipped ONE merged body with a run-time direction flag because, with
+// several contexts in flight, frames came out with wrong texels when the passes were two kernels.  The wrong texels were
+// never produced here: they were compositor pixels misread by packed-FP32 instructions while these kernels' v_mfma shared
+// the SIMD (tools/microbench/pk_vs_mfma.hip); the merged body merely ran slowly enough to hide it.
+// The library is now built without packed-FP32 instructions (csrc/Makefile, tools/lint_isa.py).
+#ifndef FDH_MX_CHECK
+#define FDH_MX_CHECK 0  // experiment builds only: every texel a wave reads from its LDS ring is compared with global memory
+#endif
+#if FDH_MX_CHECK
+__device__ unsigned int g_mx_bad_n;
+__device__ unsigned int g_mx_bad[4096 * 8];
+#endif
+template <int NK, bool kV>
+__global__ __launch_bounds__(64, 2) void k_blur_mx(BlurParams P, const DrawRec* __restrict__ draws, const QuadExt* __restrict__ exts, int T) {
   constexpr int R = NK + 4;
   extern __shared__ __attribute__((aligned(16))) uint32_t ring[];  // R slots
   // blocks sit at absolute multiples of 32 along the filter direction: a pixel's sum is then grouped into MFMAs the same
@@ -1773,6 +1816,27 @@ __global__ __launch_bounds__(64, 2) void k_blur_mx(BlurParams P, const DrawRec* 
         const uint4 lo4 = row4[(2 * g) ^ sw], hi4 = row4[(2 * g + 1) ^ sw];
         t8[0] = lo4.x; t8[1] = lo4.y; t8[2] = lo4.z; t8[3] = lo4.w; t8[4] = hi4.x; t8[5] = hi4.y; t8[6] = hi4.z; t8[7] = hi4.w;
       }
+#if FDH_MX_CHECK
+#pragma unroll
+      for (int t = 0; t < 8; t++) {
+        const int pos = w0a + 16 * (2 * b + m) + 8 * g + t;
+        uint32_t want;
+        if (kV) {
+          const int yy = pos < 0 ? 0 : (pos > P.H - 1 ? P.H - 1 : pos);
+          want = P.src[(size_t)yy * P.pitch + min(lb + 4 * (j >> 2), P.W - 4) + (j & 3)];
+        } else {
+          const int xx = pos < 0 ? 0 : (pos > P.W - 1 ? P.W - 1 : pos);
+          want = P.src[(size_t)min(lb + j, P.y1 - 1) * P.pitch + xx];
+        }
+        if (want != t8[t]) {
+          const unsigned int i = atomicAdd(&g_mx_bad_n, 1u);
+          if (i < 4096u) {
+            unsigned int* o = g_mx_bad + 8 * i;
+            o[0] = kV ? 1u : 0u; o[1] = blockIdx.x; o[2] = (unsigned)b | ((unsigned)n_blocks << 16); o[3] = (unsigned)m; o[4] = (unsigned)lane; o[5] = (unsigned)t; o[6] = t8[t]; o[7] = want;
+          }
+        }
+      }
+#endif
       const h8 f0 = mx_frag<0>(t8), f1 = mx_frag<1>(t8), f2_ = mx_frag<2>(t8), f3 = mx_frag<3>(t8);
       if (kV) {  // weights x texels: D[output row][column]
         acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi[m], f0, acc[0], 0, 0, 0);
@@ -2019,7 +2083,7 @@ static int mx_pick_t(int nk, long long outputs_along, long long lines) {
 template <int NK, bool kV> static void launch_blur_mx(hipStream_t s, const BlurParams& P, const DrawRec* draws, const QuadExt* exts, int t) {
   const int a_lo = kV ? P.y0 : P.x0, a_hi = kV ? P.y1 : P.x1, l_lo = kV ? (P.x0 & ~31) : P.y0, l_hi = kV ? P.x1 : P.y1;
   const int total = ((a_hi - (a_lo & ~31) + 32 * t - 1) / (32 * t)) * ((l_hi - l_lo + 31) / 32);
-  hipLaunchKernelGGL((k_blur_mx<NK>), dim3(8 * ((total + 7) / 8)), dim3(64), (size_t)(NK + 4) * kMxSlot * sizeof(uint32_t), s, P, draws, exts, t, kV ? 1 : 0);
+  hipLaunchKernelGGL((k_blur_mx<NK, kV>), dim3(8 * ((total + 7) / 8)), dim3(64), (size_t)(NK + 4) * kMxSlot * sizeof(uint32_t), s, P, draws, exts, t);
 }
 template <bool kV> static bool launch_blur_mx_nk(hipStream_t s, const BlurParams& P, const DrawRec* draws, const QuadExt* exts) {
   // LDS-DMA moves 16-byte pieces: rows have to start on 16-byte boundaries
@@ -2079,6 +2143,22 @@ void launch_fill(hipStream_t s, uint32_t* p, uint32_t v, size_t n) {
   hipLaunchKernelGGL(k_fill_u32, dim3(1024), dim3(256), 0, s, p, v, n);
 }
 
+#if FDH_EDGE_CHECK
+void debug_edge_bad(unsigned int* n, unsigned int* out, bool reset) {
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(n, HIP_SYMBOL(g_edge_bad_n), sizeof(unsigned int));
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_edge_bad), sizeof(unsigned int) * 4096 * 8);
+  if (reset) { const unsigned int z = 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_edge_bad_n), &z, sizeof z); }
+}
+#endif
+#if FDH_MX_CHECK
+void debug_mx_bad(unsigned int* n, unsigned int* out, bool reset) {
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(n, HIP_SYMBOL(g_mx_bad_n), sizeof(unsigned int));
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mx_bad), sizeof(unsigned int) * 4096 * 8);
+  if (reset) { const unsigned int z = 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_mx_bad_n), &z, sizeof z); }
+}
+#endif
 #if FDH_STATS
 void debug_wave_times(unsigned long long* out) {
   (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_times), sizeof(unsigned long long) * 16 * 65536);

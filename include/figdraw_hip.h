@@ -284,6 +284,11 @@ FDH_API int fdh_sizeof_fig(void);
 FDH_API int fdh_sizeof_glyph(void);
 FDH_API int fdh_sizeof_draw_op(void);
 FDH_API int fdh_sizeof_text_rect(void);
+/* Diagnostic: copy one of the context's working surfaces to the host (W x H RGBA8, tightly packed) after waiting for its
+ * stream.  which = 0: the frame (= fdh_read_pixels), 1: the horizontal blur pass's output (the reference's intermediate blur
+ * texture, glcontext.nim:1743-1786) as the last blur node left it, 2: the blurred snapshot of the last unfused blur node.
+ * tools/race_contexts.py uses it to tell which pass a wrong pixel came from. */
+FDH_API int fdh_debug_read_surface(FdhContext*, int which, uint8_t* out_rgba8);
 /* Diagnostic, host-only (no device, no context): the pixel rectangle [x0,x1) x [y0,y1) the submission path marks as the
  * draw's saturated core (coverage exactly 1, or a provable no-op for strokes / inner shadows) under the identity
  * transform; all zeros when there is none.  Arguments as fdh_draw_rounded_rect_sdf. */
