@@ -103,6 +103,9 @@ def load():
     L.fdh_atlas_packed_area.argtypes = [vp, C.POINTER(C.c_int64)]
     L.fdh_read_pixels.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]
     L.fdh_debug_read_surface.argtypes = [vp, C.c_int, vp]
+    L.fdh_record_begin.argtypes = [vp]
+    L.fdh_record_json.argtypes = [vp]
+    L.fdh_record_json.restype = C.c_char_p
     L.fdh_frame_device_ptr.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int64)]
     L.fdh_sync.argtypes = [vp]
     L.fdh_set_ui_scale.argtypes = [vp, C.c_float]
@@ -128,10 +131,14 @@ def _cols(colors):
 class HipContext:
     """One GPU, one HIP stream, one RGBA8 surface (newContext, glcontext.nim:255-261)."""
 
-    def __init__(self, atlas_size: int = 1024, pixel_scale: float = 1.0, device: int = 0):
+    RECORD_ONLY = 1  # FDH_CREATE_RECORD_ONLY
+
+    def __init__(self, atlas_size: int = 1024, pixel_scale: float = 1.0, device: int = 0, record_only: bool = False):
+        """record_only: a call recorder -- the scene front-end and the atlas packer run, nothing is drawn and no GPU is
+        needed (the RecordingBackend of the reference's tests/ttransform.nim); see record_begin / record_calls."""
         self.L = load()
         h = C.c_void_p()
-        rc = self.L.fdh_create(C.byref(h), atlas_size, pixel_scale, device, 0)
+        rc = self.L.fdh_create(C.byref(h), atlas_size, pixel_scale, device, self.RECORD_ONLY if record_only else 0)
         if rc != 0:
             raise FigdrawHipError(rc, self.L.fdh_last_error().decode())
         self.h = h
@@ -294,6 +301,15 @@ class HipContext:
         out = np.zeros((h, w, 4), dtype=np.uint8)
         self._ck(self.L.fdh_read_pixels(self.h, x, y, w, h, out.ctypes.data))
         return out
+
+    def record_begin(self):
+        """start recording the backend-level calls this context receives (tests/ttransform.nim's RecordingBackend)"""
+        self._ck(self.L.fdh_record_begin(self.h))
+
+    def record_calls(self):
+        import json
+
+        return json.loads(self.L.fdh_record_json(self.h).decode())
 
     def debug_read_surface(self, which: int) -> np.ndarray:
         """0: frame, 1: horizontal blur pass output, 2: blurred snapshot (diagnostic)"""

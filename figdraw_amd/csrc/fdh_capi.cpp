@@ -172,6 +172,12 @@ int fdh_read_pixels(FdhContext* c, int x, int y, int w, int h, uint8_t* out) {
 int fdh_frame_device_ptr(FdhContext* c, void** p, int* w, int* h, int64_t* pitch) {
   return guard([&] { C(c)->frame_device_ptr(p, w, h, pitch); });
 }
+int fdh_record_begin(FdhContext* c) { return guard([&] { C(c)->record_begin(); }); }
+const char* fdh_record_json(FdhContext* c) {
+  const char* out = "[]";
+  guard([&] { out = C(c)->record_json(); });
+  return out;
+}
 int fdh_debug_read_surface(FdhContext* c, int which, uint8_t* out) {
   return guard([&] {
     if (!out) throw fdh::Error(FDH_ERR_INVALID, "null output buffer");

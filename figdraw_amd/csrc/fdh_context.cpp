@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstring>
 
 namespace fdh {
@@ -36,6 +37,12 @@ static Aff aff_mul(const Aff& m, const Aff& n) {
 
 // ------------------------------------------------------------------ lifetime
 Context::Context(int atlas_size, float pixel_scale, int device, uint32_t flags) : device_(device), flags_(flags), pixel_scale_(pixel_scale) {
+  host_only_ = (flags & FDH_CREATE_RECORD_ONLY) != 0;
+  if (host_only_) {  // a call recorder: the front-end and the atlas packer run, nothing is drawn, no device is touched
+    initial_atlas_size_ = atlas_size > 0 ? atlas_size : 1024;
+    alloc_atlas(initial_atlas_size_);
+    return;
+  }
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) throw Error(FDH_ERR_NO_DEVICE, "no HIP device visible (libfigdraw_hip has no CPU fallback)");
   if (device < 0 || device >= n) throw Error(FDH_ERR_NO_DEVICE, "HIP device ordinal out of range");
@@ -53,6 +60,7 @@ Context::Context(int atlas_size, float pixel_scale, int device, uint32_t flags) 
 }
 
 Context::~Context() {
+  if (host_only_) return;
   (void)hipSetDevice(device_);
   if (stream_) (void)hipStreamSynchronize(stream_);
   for (auto& e : ev_) if (e) (void)hipEventDestroy(e);
@@ -69,10 +77,15 @@ Context::~Context() {
 }
 
 void Context::set_stream(void* s) {
+  need_device("set_stream");
   FDH_HIP(hipStreamSynchronize(stream_));
   stream_ = s ? (hipStream_t)s : own_stream_;
 }
+void Context::need_device(const char* what) const {
+  if (host_only_) throw Error(FDH_ERR_NO_DEVICE, std::string(what) + ": this context was created with FDH_CREATE_RECORD_ONLY (it records calls, it draws nothing)");
+}
 void Context::sync() {
+  if (host_only_) return;
   FDH_HIP(hipSetDevice(device_));
   FDH_HIP(hipStreamSynchronize(stream_));
 }
@@ -85,8 +98,10 @@ void Context::alloc_atlas(int size) {
   atlas_size_ = s;
   n_levels_ = 0;
   for (int ls = s; ls >= 1 && n_levels_ < kMaxMips; ls >>= 1) {
-    FDH_HIP(hipMalloc((void**)&atlas_levels_[n_levels_], (size_t)ls * ls * 4));
-    FDH_HIP(hipMemsetAsync(atlas_levels_[n_levels_], 0, (size_t)ls * ls * 4, stream_));
+    if (!host_only_) {
+      FDH_HIP(hipMalloc((void**)&atlas_levels_[n_levels_], (size_t)ls * ls * 4));
+      FDH_HIP(hipMemsetAsync(atlas_levels_[n_levels_], 0, (size_t)ls * ls * 4, stream_));
+    }
     n_levels_++;
     if (ls == 1) break;
   }
@@ -134,7 +149,7 @@ void Context::find_empty_rect(int w, int h, int* ox, int* oy) {  // glcontext.ni
 }
 void Context::upload_atlas_rect(int level, int x, int y, int w, int h, const uint8_t* rgba) {
   const int LS = atlas_size_ >> level;
-  if (x < 0 || y < 0 || x + w > LS || y + h > LS || w <= 0 || h <= 0) return;
+  if (x < 0 || y < 0 || x + w > LS || y + h > LS || w <= 0 || h <= 0 || host_only_) return;
   FDH_HIP(hipMemcpy2D(atlas_levels_[level] + (size_t)y * LS + x, (size_t)LS * 4, rgba, (size_t)w * 4, (size_t)w * 4, h,
                       hipMemcpyHostToDevice));  // synchronous: image uploads are rare and the source is pageable
 }
@@ -160,11 +175,11 @@ void Context::put_levels(int x, int y, int w, int h, const uint8_t* rgba) {
 }
 void Context::put_image(int64_t key, int w, int h, const uint8_t* rgba, int out_rect[4]) {
   if (w <= 0 || h <= 0 || !rgba) throw Error(FDH_ERR_INVALID, "put_image: empty image");
-  FDH_HIP(hipSetDevice(device_));
+  if (!host_only_) FDH_HIP(hipSetDevice(device_));
   int x, y;
   find_empty_rect(w, h, &x, &y);
   entries_[key] = AtlasEntry{x, y, w, h};
-  FDH_HIP(hipStreamSynchronize(stream_));  // a frame in flight may still sample the atlas
+  sync();  // a frame in flight may still sample the atlas
   put_levels(x, y, w, h, rgba);
   if (out_rect) { out_rect[0] = x; out_rect[1] = y; out_rect[2] = w; out_rect[3] = h; }
 }
@@ -217,12 +232,12 @@ void Context::put_mips(int64_t key, int n, const int* ws, const int* hs, const u
   if (n <= 0 || !ws || !hs || !premul_rgba) throw Error(FDH_ERR_INVALID, "put_mips: no mip levels");
   for (int l = 0; l < n; l++)
     if (ws[l] <= 0 || hs[l] <= 0 || !premul_rgba[l]) throw Error(FDH_ERR_INVALID, "put_mips: bad mip level");
-  FDH_HIP(hipSetDevice(device_));
+  if (!host_only_) FDH_HIP(hipSetDevice(device_));
   int rx = 0, ry = 0;
   find_empty_rect(ws[0], hs[0], &rx, &ry);
   entries_[key] = AtlasEntry{rx, ry, ws[0], hs[0]};
   if (out_rect) { out_rect[0] = rx; out_rect[1] = ry; out_rect[2] = ws[0]; out_rect[3] = hs[0]; }
-  FDH_HIP(hipStreamSynchronize(stream_));
+  sync();
   for (int l = 0; l < n && l < n_levels_; l++) upload_atlas_rect(l, rx >> l, ry >> l, ws[l], hs[l], premul_rgba[l]);
 }
 void Context::put_flippy(int64_t key, const uint8_t* data, size_t n, int out_rect[4]) {
@@ -260,26 +275,79 @@ void Context::update_image(int64_t key, int w, int h, const uint8_t* rgba) {  //
   auto it = entries_.find(key);
   if (it == entries_.end()) throw Error(FDH_ERR_INVALID, "update_image: unknown key");
   if (it->second.w != w || it->second.h != h) throw Error(FDH_ERR_INVALID, "update_image: size mismatch");
-  FDH_HIP(hipSetDevice(device_));
-  FDH_HIP(hipStreamSynchronize(stream_));
+  sync();
   put_levels(it->second.x, it->second.y, w, h, rgba);
 }
 
 // ------------------------------------------------------------------ transforms (glcontext.nim:1991-2024)
-void Context::save_transform() { mats_.push_back(mat_); }
+
+// ------------------------------------------------------------------ call recorder
+// The reference's own front-end tests (tests/ttransform.nim, tests/trenderfragments.nim) hand the renderer a RecordingBackend
+// and assert on the calls it receives.  fdh_record_begin / fdh_record_json give the same view of THIS library's front-end
+// (fdh_frontend.cpp): every BackendContext-level call between the two, as a JSON array of [name, args...] -- the format
+// oracle/figdraw_oracle.c records and oracle/ref_swiftshader.py replays.
+namespace {
+struct Rec {
+  std::string& s; bool& first; const bool on;
+  Rec(std::string& s_, bool& first_, bool on_, const char* name) : s(s_), first(first_), on(on_) {
+    if (!on) return;
+    s += first ? "[\"" : ",\n[\""; s += name; s += "\""; first = false;
+  }
+  ~Rec() { if (on) s += "]"; }
+  Rec& f(double v) { if (on) { char b[40]; std::snprintf(b, sizeof b, ",%.9g", v); s += b; } return *this; }
+  Rec& i(long long v) { if (on) { char b[32]; std::snprintf(b, sizeof b, ",%lld", v); s += b; } return *this; }
+  Rec& fv(const float* v, int n) {
+    if (on) { s += ",["; for (int k = 0; k < n; k++) { char b[40]; std::snprintf(b, sizeof b, "%s%.9g", k ? "," : "", (double)v[k]); s += b; } s += "]"; }
+    return *this;
+  }
+  Rec& col(FdhColor c) { if (on) { char b[48]; std::snprintf(b, sizeof b, ",[%d,%d,%d,%d]", c.r, c.g, c.b, c.a); s += b; } return *this; }
+  Rec& cols(const FdhColor c[4]) {
+    if (on) { s += ",["; for (int k = 0; k < 4; k++) { char b[48]; std::snprintf(b, sizeof b, "%s[%d,%d,%d,%d]", k ? "," : "", c[k].r, c[k].g, c[k].b, c[k].a); s += b; } s += "]"; }
+    return *this;
+  }
+  Rec& fill(const FdhFill& fl) {
+    if (on) {
+      char b[200];
+      std::snprintf(b, sizeof b, ",{\"kind\":%d,\"axis\":%d,\"start\":[%d,%d,%d,%d],\"mid\":[%d,%d,%d,%d],\"stop\":[%d,%d,%d,%d],\"mid_pos\":%d}", fl.kind, fl.axis,
+                    fl.start.r, fl.start.g, fl.start.b, fl.start.a, fl.mid.r, fl.mid.g, fl.mid.b, fl.mid.a, fl.stop.r, fl.stop.g, fl.stop.b, fl.stop.a, fl.mid_pos);
+      s += b;
+    }
+    return *this;
+  }
+};
+}  // namespace
+struct RecPause {  // a backend method that calls other backend methods records only itself
+  bool& on; const bool was;
+  explicit RecPause(bool& o) : on(o), was(o) { on = false; }
+  ~RecPause() { on = was; }
+};
+#define FDH_REC(name) Rec rec_scope_(rec_, rec_first_, rec_on_, name); rec_scope_
+void Context::record_begin() { rec_on_ = true; rec_first_ = true; rec_ = "["; }
+const char* Context::record_json() {
+  if (!rec_on_) return "[]";
+  rec_ += "\n]";
+  rec_on_ = false;
+  return rec_.c_str();
+}
+void Context::set_aa(float aa) { { FDH_REC("set_aa_factor").f(aa); } aa_ = aa; }
+
+void Context::save_transform() { { FDH_REC("save_transform"); } mats_.push_back(mat_); }
 void Context::restore_transform() {
+  { FDH_REC("restore_transform"); }
   if (mats_.empty()) throw Error(FDH_ERR_INVALID, "restoreTransform: empty transform stack");
   mat_ = mats_.back();
   mats_.pop_back();
 }
-void Context::translate(float x, float y) { Aff t; t.tx = x; t.ty = y; mat_ = aff_mul(mat_, t); }
+void Context::translate(float x, float y) { { FDH_REC("translate").f(x).f(y); } Aff t; t.tx = x; t.ty = y; mat_ = aff_mul(mat_, t); }
 void Context::rotate(float a) {
+  { FDH_REC("rotate").f(a); }
   Aff r;  // vmath rotateZ: column 0 = (cos, -sin), column 1 = (sin, cos); pinned by tests/expected/render_line_rect.png
   r.a = std::cos(a); r.b = -std::sin(a); r.c = -r.b; r.d = r.a;
   mat_ = aff_mul(mat_, r);
 }
-void Context::scale(float sx, float sy) { Aff s; s.a = sx; s.d = sy; mat_ = aff_mul(mat_, s); }
+void Context::scale(float sx, float sy) { { FDH_REC("scale").f(sx).f(sy); } Aff s; s.a = sx; s.d = sy; mat_ = aff_mul(mat_, s); }
 void Context::apply_transform(const float m[16]) {  // column-major Mat4; `mat * vec3(x, y, 0)` uses its 2D affine part
+  { FDH_REC("apply_transform").fv(m, 16); }
   Aff n;
   n.a = m[0]; n.b = m[1]; n.c = m[4]; n.d = m[5]; n.tx = m[12]; n.ty = m[13];
   mat_ = aff_mul(mat_, n);
@@ -288,7 +356,7 @@ bool Context::transform_mirrors_y() const { return mat_.a * mat_.d - mat_.b * ma
 
 // ------------------------------------------------------------------ frame
 void Context::ensure_surfaces() {
-  if (surf_w_ == W_ && surf_h_ == H_ && fb_) return;
+  if (host_only_ || (surf_w_ == W_ && surf_h_ == H_ && fb_)) return;
   FDH_HIP(hipStreamSynchronize(stream_));
   if (fb_) FDH_HIP(hipFree(fb_));
   if (backdrop_) FDH_HIP(hipFree(backdrop_));
@@ -304,10 +372,11 @@ void Context::ensure_surfaces() {
 }
 
 void Context::begin_frame(int w, int h, bool clear, const float rgba[4]) {  // glcontext.nim:2080-2092, 1951-1980
+  { FDH_REC("begin_frame").i(clear ? 1 : 0).fv(rgba, 4); }
   if (frame_begun_) throw Error(FDH_ERR_INVALID, "ctx.beginFrame has already been called.");
   if (w <= 0 || h <= 0 || w > 16384 || h > 16384) throw Error(FDH_ERR_INVALID, "beginFrame: frame size must be in 1..16384");
   t_begin_frame_ = std::chrono::steady_clock::now();
-  FDH_HIP(hipSetDevice(device_));
+  if (!host_only_) FDH_HIP(hipSetDevice(device_));
   W_ = w;
   H_ = h;
   ensure_surfaces();
@@ -569,6 +638,7 @@ void saturated_core_of(const float rect[4], const float rx[4], const float ry[4]
 void Context::draw_rounded_rect_sdf(const float rect[4], const FdhColor colors[4], const float rx[4], const float ry[4], int mode,
                                     float factor, float spread, const float shape[2], int fill_mode, FdhColor mid, FdhColor stop,
                                     float mid_pos) {
+  { FDH_REC("draw_rounded_rect_sdf").fv(rect, 4).cols(colors).fv(rx, 4).fv(ry, 4).i(mode).f(factor).f(spread).fv(shape, 2).i(fill_mode).col(mid).col(stop).f(mid_pos); }
   if (!frame_begun_) throw Error(FDH_ERR_INVALID, "ctx.beginFrame has not been called.");
   if (rect[2] <= 0.0f || rect[3] <= 0.0f) return;
   if (mode >= FDH_SDF_BEZIER_STROKE_AA) throw Error(FDH_ERR_INVALID, "bezier stroke modes go through drawQuadraticBezierSdf");
@@ -618,6 +688,7 @@ void Context::draw_rounded_rect_fill(const float rect[4], const FdhFill& fill, c
 
 // drawImage / drawUvRect: glcontext.nim:1236-1302, 1350-1367
 void Context::draw_image(int64_t key, const float pos[2], const FdhColor colors[4], const float size[2], bool flip_y) {
+  { FDH_REC("draw_image").i(key).fv(pos, 2).cols(colors).fv(size, 2).i(flip_y ? 1 : 0); }
   if (!frame_begun_) throw Error(FDH_ERR_INVALID, "ctx.beginFrame has not been called.");
   auto it = entries_.find(key);
   if (it == entries_.end()) return;  // "missing image in context": warn + no-op (glcontext.nim:1310-1315)
@@ -655,6 +726,7 @@ void Context::draw_image(int64_t key, const float pos[2], const FdhColor colors[
 // drawMsdfImage / drawMtsdfImage: glcontext.nim:1097-1155, drawUvRectAtlasSdf :1022-1093
 void Context::draw_msdf(int64_t key, const float pos[2], FdhColor color, const float size[2], float px_range, float sd_threshold,
                         float stroke_weight, bool mtsdf, bool flip_y) {
+  { FDH_REC("draw_msdf").i(key).fv(pos, 2).col(color).fv(size, 2).f(px_range).f(sd_threshold).f(stroke_weight).i(mtsdf ? 1 : 0).i(flip_y ? 1 : 0); }
   if (!frame_begun_) throw Error(FDH_ERR_INVALID, "ctx.beginFrame has not been called.");
   auto it = entries_.find(key);
   if (it == entries_.end()) return;
@@ -677,6 +749,7 @@ void Context::draw_msdf(int64_t key, const float pos[2], FdhColor color, const f
 // drawQuadraticBezierSdf: glcontext.nim:1619-1741
 void Context::draw_quadratic_bezier_sdf(const float rect[4], const FdhFill& fill, const float p0[2], const float p1[2],
                                         const float p2[2], float stroke_weight, int cap) {
+  { FDH_REC("draw_quadratic_bezier_sdf").fv(rect, 4).fill(fill).fv(p0, 2).fv(p1, 2).fv(p2, 2).f(stroke_weight).i(cap); }
   if (!frame_begun_) throw Error(FDH_ERR_INVALID, "ctx.beginFrame has not been called.");
   if (rect[2] <= 0.0f || rect[3] <= 0.0f || stroke_weight <= 0.0f) return;
   DrawRec r;
@@ -725,6 +798,7 @@ static void white_texel_uv(const AtlasEntry& e, int atlas_size, DrawRec& r) {
 }
 // drawFilledQuad: glcontext.nim:963-982 (+ drawQuad :908-961): an arbitrary quad textured with one white texel
 void Context::draw_filled_quad(const float verts[8], const FdhColor colors[4]) {
+  { FDH_REC("draw_filled_quad").fv(verts, 8).cols(colors); }
   if (!frame_begun_) throw Error(FDH_ERR_INVALID, "ctx.beginFrame has not been called.");
   DrawRec r;
   std::memset(&r, 0, sizeof r);
@@ -738,6 +812,7 @@ void Context::draw_filled_quad(const float verts[8], const FdhColor colors[4]) {
 }
 // drawRect: glcontext.nim:1410-1426
 void Context::draw_rect(const float rect[4], FdhColor color) {
+  { FDH_REC("draw_rect").fv(rect, 4).col(color); }
   if (!frame_begun_) throw Error(FDH_ERR_INVALID, "ctx.beginFrame has not been called.");
   DrawRec r;
   std::memset(&r, 0, sizeof r);
@@ -750,6 +825,7 @@ void Context::draw_rect(const float rect[4], FdhColor color) {
 
 // ------------------------------------------------------------------ masks (glcontext.nim:1873-1949)
 void Context::begin_mask(const float rect[4], const float rx[4], const float ry[4]) {
+  { FDH_REC("begin_mask").fv(rect, 4).fv(rx, 4).fv(ry, 4); }
   if (!frame_begun_) throw Error(FDH_ERR_INVALID, "ctx.beginFrame has not been called.");
   if (mask_begun_) throw Error(FDH_ERR_INVALID, "ctx.beginMask has already been called.");
   if (mask_depth_ >= kMaskDepth) throw Error(FDH_ERR_UNSUPPORTED, "clip masks nested deeper than 16");
@@ -772,10 +848,12 @@ void Context::begin_mask(const float rect[4], const float rx[4], const float ry[
   open_ops_.push_back((uint32_t)before);
 }
 void Context::end_mask() {
+  { FDH_REC("end_mask"); }
   if (!mask_begun_) throw Error(FDH_ERR_INVALID, "ctx.maskBegun has not been called.");
   mask_begun_ = false;
 }
 void Context::pop_mask() {
+  { FDH_REC("pop_mask"); }
   if (mask_depth_ <= 0 || open_ops_.empty()) throw Error(FDH_ERR_INVALID, "popMask without beginMask");
   const uint32_t push_idx = open_ops_.back();
   open_ops_.pop_back();
@@ -787,6 +865,7 @@ void Context::pop_mask() {
 }
 // makeRectMask glcontext.nim:831-850; beginRectMask :1932-1943
 void Context::begin_rect_mask(const float rect[4], const float rx[4], const float ry[4]) {
+  { FDH_REC("begin_rect_mask").fv(rect, 4).fv(rx, 4).fv(ry, 4); }
   if (!frame_begun_) throw Error(FDH_ERR_INVALID, "ctx.beginFrame has not been called.");
   if (mask_begun_) throw Error(FDH_ERR_INVALID, "ctx.beginRectMask cannot start inside a mask.");
   if (rect_masks_.empty() && rect[2] > 0.0f && rect[3] > 0.0f) {
@@ -806,16 +885,18 @@ void Context::begin_rect_mask(const float rect[4], const float rx[4], const floa
     push_rec(r, BBox{0, 0, 0, 0});
     rect_masks_.push_back(RectMaskEntry{1});
   } else {
-    begin_mask(rect, rx, ry);
-    end_mask();
+    { const RecPause quiet(rec_on_);  // the fallback's own begin/end are this backend's business, not the caller's
+      begin_mask(rect, rx, ry);
+      end_mask(); }
     rect_masks_.push_back(RectMaskEntry{2});
   }
 }
 void Context::pop_rect_mask() {
+  { FDH_REC("pop_rect_mask"); }
   if (rect_masks_.empty()) throw Error(FDH_ERR_INVALID, "No rect mask has been pushed.");
   const RectMaskEntry e = rect_masks_.back();
   rect_masks_.pop_back();
-  if (e.kind == 2) { pop_mask(); return; }
+  if (e.kind == 2) { const RecPause quiet(rec_on_); pop_mask(); return; }
   const uint32_t begin_idx = open_ops_.back();
   open_ops_.pop_back();
   DrawRec r;
@@ -855,6 +936,7 @@ static BlurTaps make_taps(float blur_radius) {
 }
 
 void Context::draw_backdrop_blur(const float rect[4], const float rx[4], const float ry[4], float blur_radius) {
+  { FDH_REC("draw_backdrop_blur").fv(rect, 4).fv(rx, 4).fv(ry, 4).f(blur_radius); }
   if (!frame_begun_) throw Error(FDH_ERR_INVALID, "ctx.beginFrame has not been called.");
   if (blur_radius <= 0.0f || rect[2] <= 0.0f || rect[3] <= 0.0f) return;
   const FdhColor white{255, 255, 255, 255}, zero{0, 0, 0, 0};
@@ -895,6 +977,7 @@ void Context::draw_backdrop_blur(const float rect[4], const float rx[4], const f
 
 // ------------------------------------------------------------------ submission
 void Context::end_frame() {  // glcontext.nim:1982-1989
+  { FDH_REC("end_frame"); }
   if (!frame_begun_) throw Error(FDH_ERR_INVALID, "ctx.beginFrame was not called first.");
   if (mask_depth_ != 0) throw Error(FDH_ERR_INVALID, "Not all masks have been popped.");
   if (!rect_masks_.empty()) throw Error(FDH_ERR_INVALID, "Not all rect masks have been popped.");
@@ -902,6 +985,7 @@ void Context::end_frame() {  // glcontext.nim:1982-1989
   have_frame_ = true;
   const auto t1 = std::chrono::steady_clock::now();
   host_record_ms_ = std::chrono::duration<float, std::milli>(t1 - t_begin_frame_).count();
+  if (host_only_) { have_frame_ = false; return; }
   submit(true);
 }
 
@@ -1206,6 +1290,7 @@ void Context::launch_frame(bool profile) {
 }
 
 void Context::replay(int times) {
+  need_device("replay");
   if (!have_frame_) throw Error(FDH_ERR_INVALID, "replay: no frame has been submitted");
   FDH_HIP(hipSetDevice(device_));
   if (times <= 0) return;
@@ -1220,6 +1305,7 @@ void Context::replay(int times) {
 
 // enqueue only: several contexts (own streams, own surfaces) can then have frames in flight on one GPU at once
 void Context::replay_async(int times) {
+  need_device("replay_async");
   if (!have_frame_) throw Error(FDH_ERR_INVALID, "replay: no frame has been submitted");
   FDH_HIP(hipSetDevice(device_));
   for (int i = 0; i < times; i++) launch_frame(false);
@@ -1227,6 +1313,7 @@ void Context::replay_async(int times) {
 
 // `times` frames back to back with one event between consecutive frames: ms_out[i] = duration of frame i on the stream
 void Context::replay_timed(int times, float* ms_out) {
+  need_device("replay_timed");
   if (!have_frame_) throw Error(FDH_ERR_INVALID, "replay: no frame has been submitted");
   if (times <= 0 || !ms_out) return;
   FDH_HIP(hipSetDevice(device_));
@@ -1254,6 +1341,7 @@ hipEvent_t Context::next_event() {
 
 // Per-kernel timing: events bracket every launch, so this is kept apart from replay()'s batch timing.
 void Context::profile(int times) {
+  need_device("profile");
   if (!have_frame_) throw Error(FDH_ERR_INVALID, "profile: no frame has been submitted");
   FDH_HIP(hipSetDevice(device_));
   if (times <= 0) return;
@@ -1278,6 +1366,7 @@ void Context::profile(int times) {
 
 // ------------------------------------------------------------------ readback (glcontext.nim:2094-2135)
 void Context::read_pixels(int x, int y, int w, int h, uint8_t* out) {
+  need_device("read_pixels");
   if (!fb_) throw Error(FDH_ERR_INVALID, "readPixels before the first frame");
   FDH_HIP(hipSetDevice(device_));
   if (w <= 0 || h <= 0) { x = 0; y = 0; w = W_; h = H_; }
@@ -1286,6 +1375,7 @@ void Context::read_pixels(int x, int y, int w, int h, uint8_t* out) {
   FDH_HIP(hipMemcpy2D(out, (size_t)w * 4, fb_ + (size_t)y * W_ + x, (size_t)W_ * 4, (size_t)w * 4, h, hipMemcpyDeviceToHost));
 }
 void Context::debug_read_surface(int which, uint8_t* out) {
+  need_device("debug_read_surface");
   const uint32_t* src = which == 0 ? fb_ : which == 1 ? blur_tmp_ : which == 2 ? backdrop_ : which == 3 ? dbg_snap_ : nullptr;
   if (!src) throw Error(FDH_ERR_INVALID, "debug_read_surface: no such surface (or no frame yet)");
   FDH_HIP(hipSetDevice(device_));
@@ -1293,6 +1383,7 @@ void Context::debug_read_surface(int which, uint8_t* out) {
   FDH_HIP(hipMemcpy(out, src, (size_t)W_ * H_ * 4, hipMemcpyDeviceToHost));
 }
 void Context::frame_device_ptr(void** p, int* w, int* h, int64_t* pitch_bytes) {
+  need_device("frame_device_ptr");
   if (!fb_) throw Error(FDH_ERR_INVALID, "no frame surface yet");
   *p = fb_; *w = W_; *h = H_; *pitch_bytes = (int64_t)W_ * 4;
 }

@@ -100,7 +100,7 @@ class Context {
   void scale(float sx, float sy);
   void apply_transform(const float m[16]);
   bool transform_mirrors_y() const;
-  void set_aa(float aa) { aa_ = aa; }
+  void set_aa(float aa);
   float aa() const { return aa_; }
   float pixel_scale() const { return pixel_scale_; }
   void draw_rounded_rect_sdf(const float rect[4], const FdhColor colors[4], const float rx[4], const float ry[4], int mode,
@@ -142,6 +142,9 @@ class Context {
   void read_pixels(int x, int y, int w, int h, uint8_t* out);
   void frame_device_ptr(void** p, int* w, int* h, int64_t* pitch_bytes);
   void debug_read_surface(int which, uint8_t* out);
+  // call recorder (fdh_record_begin / fdh_record_json): the backend-level calls the scene front-end makes, as JSON
+  void record_begin();
+  const char* record_json();
   void sync();
   void set_stream(void* s);
 
@@ -171,6 +174,7 @@ class Context {
   void launch_frame(bool profile);
   hipEvent_t next_event();
   void ensure_surfaces();
+  void need_device(const char* what) const;
 
   int device_ = 0;
   uint32_t flags_ = 0;
@@ -208,7 +212,10 @@ class Context {
 
   // device state
   uint32_t *fb_ = nullptr, *backdrop_ = nullptr, *blur_tmp_ = nullptr;
-  uint32_t* dbg_snap_ = nullptr;  // FDH_DEBUG_SNAP=1 (diagnostic): the surface as phase 0 left it, copied in-stream
+  uint32_t* dbg_snap_ = nullptr;
+  bool host_only_ = false;  // FDH_CREATE_RECORD_ONLY
+  bool rec_on_ = false, rec_first_ = true;
+  std::string rec_;  // FDH_DEBUG_SNAP=1 (diagnostic): the surface as phase 0 left it, copied in-stream
   int surf_w_ = 0, surf_h_ = 0;
   // records, quad extensions, bounding boxes and phase offsets of a frame live in ONE device block and arrive with ONE
   // copy (four small hipMemcpyAsync calls cost the host ~100 us per frame); the typed views point into it

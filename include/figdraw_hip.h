@@ -165,6 +165,11 @@ typedef struct {
 
 /* ------------------------------------------------------------------ lifetime */
 /* newContext(atlasSize, ..., pixelScale): glcontext.nim:255-261.  device = HIP ordinal. */
+/* fdh_create flags.  FDH_CREATE_RECORD_ONLY: a context that records the calls it receives (fdh_record_begin / fdh_record_json)
+ * and runs the scene front-end and the atlas packer, but draws nothing and touches no device: the counterpart of the
+ * RecordingBackend in the reference's tests/ttransform.nim.  Every entry point that needs pixels (read_pixels, replay, ...)
+ * fails with FDH_ERR_NO_DEVICE on such a context. */
+enum { FDH_CREATE_RECORD_ONLY = 1 };
 FDH_API int fdh_create(FdhContext** out, int atlas_size, float pixel_scale, int device, uint32_t flags);
 FDH_API int fdh_destroy(FdhContext*);
 FDH_API const char* fdh_last_error(void);
@@ -284,6 +289,14 @@ FDH_API int fdh_sizeof_fig(void);
 FDH_API int fdh_sizeof_glyph(void);
 FDH_API int fdh_sizeof_draw_op(void);
 FDH_API int fdh_sizeof_text_rect(void);
+/* Call recorder -- the library-side counterpart of the RecordingBackend the reference's front-end tests use
+ * (tests/ttransform.nim:19-144, tests/trenderfragments.nim): between fdh_record_begin and fdh_record_json every
+ * BackendContext-level call this context receives -- from the caller or from its own scene front-end (fdh_render_frame) -- is
+ * appended to a JSON array of ["name", args...] entries (same names and argument order as the entry points above; colours as
+ * [r,g,b,a]).  fdh_record_json ends the recording and returns the text (valid until the next fdh_record_begin). */
+FDH_API int fdh_record_begin(FdhContext*);
+FDH_API const char* fdh_record_json(FdhContext*);
+
 /* Diagnostic: copy one of the context's working surfaces to the host (W x H RGBA8, tightly packed) after waiting for its
  * stream.  which = 0: the frame (= fdh_read_pixels), 1: the horizontal blur pass's output (the reference's intermediate blur
  * texture, glcontext.nim:1743-1786) as the last blur node left it, 2: the blurred snapshot of the last unfused blur node.

@@ -1,0 +1,90 @@
+"""CPU suite: the HIP library's scene front-end (figdraw_amd/csrc/fdh_frontend.cpp, driven through the C ABI on a
+FDH_CREATE_RECORD_ONLY context -- no GPU) against the oracle's, call for call.
+
+The reference pins its front-end with a RecordingBackend (tests/ttransform.nim:19-144); tests/test_oracle.py asserts the
+reference's known answers on both restatements.  Here the two recorded BackendContext call streams are compared entry by
+entry for every test scene, the BASELINE workload scenes and seeded random scenes (clips, rect masks, rotations, matrix
+transforms, drawables, shadows, gradients, blur nodes): names, order and every argument."""
+import math
+
+import pytest
+
+import ref_scenes as RS
+from figdraw_amd.context import HipContext
+from figdraw_amd.scenes import make_render_tree_100
+from oracle import oracle as O
+
+
+def _streams(scene, w, h, ui_scale=1.0):
+    out = []
+    for be in (O.Oracle(threads=8), HipContext(record_only=True)):  # (the oracle has no record-only mode: it also renders)
+        be.record_begin()
+        be.render_frame(scene, w, h, ui_scale=ui_scale)
+        out.append(be.record_calls())
+    return out
+
+
+def _same(a, b, path=""):
+    if isinstance(a, (list, tuple)):
+        assert isinstance(b, (list, tuple)) and len(a) == len(b), (path, a, b)
+        for i, (x, y) in enumerate(zip(a, b)):
+            _same(x, y, f"{path}[{i}]")
+    elif isinstance(a, dict):
+        assert a.keys() == b.keys(), (path, a, b)
+        for k in a:
+            _same(a[k], b[k], f"{path}.{k}")
+    elif isinstance(a, float) or isinstance(b, float):
+        # both sides print float32 values with %.9g; the two front-ends evaluate a few expressions in another order
+        assert math.isclose(a, b, rel_tol=2e-6, abs_tol=2e-5), (path, a, b)
+    else:
+        assert a == b, (path, a, b)
+
+
+SCENES = {k: v[:3] for k, v in RS.REFERENCE_PNG_SCENES.items()}
+SCENES.update(RS.SWIFTSHADER_SCENES)
+
+
+@pytest.mark.parametrize("name", sorted(SCENES))
+def test_call_stream_of_every_test_scene(name):
+    fn, w, h = SCENES[name]
+    want, got = _streams(fn(float(w), float(h)), w, h)
+    assert [c[0] for c in got] == [c[0] for c in want]
+    _same(want, got)
+
+
+@pytest.mark.parametrize("seed,w,h,clips,blur", [(1, 333, 217, True, True), (2, 640, 480, True, False), (7, 799, 601, True, True),
+                                                  (8, 1283, 721, False, True), (21, 700, 500, False, False), (33, 512, 512, True, True)])
+def test_call_stream_of_random_scenes(seed, w, h, clips, blur):
+    sc = RS.random_scene(seed, float(w), float(h), n=60, clips=clips, blur=blur)
+    want, got = _streams(sc, w, h)
+    assert len(got) > 60
+    _same(want, got)
+
+
+@pytest.mark.parametrize("w,h,frame,ffb", [(1920, 1080, 0, False), (3840, 2160, 3, True)])
+def test_call_stream_of_the_baseline_workloads(w, h, frame, ffb):
+    """BASELINE configs 2 and 3 (config 5 is config 3's tree at twice the size): 304 (305) nodes -> 706 (707) SDF draws, in the reference's stage order."""
+    sc = make_render_tree_100(w, h, frame=frame, full_frame_blur=ffb)
+    want, got = _streams(sc, w, h)
+    draws = [c for c in got if c[0] == "draw_rounded_rect_sdf"]
+    blurs = [c for c in got if c[0] == "draw_backdrop_blur"]
+    assert len(draws) == 705 and len(blurs) == (2 if ffb else 1)  # + the blur nodes' own mode-17 draws = 706 / 707 records
+    _same(want, got)
+
+
+def test_ui_scale_reaches_every_coordinate():
+    fn, w, h = RS.SWIFTSHADER_SCENES["drawables"]
+    want, got = _streams(fn(float(w), float(h)), w, h, ui_scale=2.0)
+    _same(want, got)
+
+
+def test_record_only_context_draws_nothing():
+    from figdraw_amd.context import FigdrawHipError
+
+    ctx = HipContext(record_only=True)
+    fn, w, h = RS.SWIFTSHADER_SCENES["oneframe"]
+    ctx.render_frame(fn(float(w), float(h)), w, h)
+    with pytest.raises(FigdrawHipError):
+        ctx.read_pixels()
+    with pytest.raises(FigdrawHipError):
+        ctx.replay(1)

@@ -175,8 +175,8 @@ def test_contexts_in_flight_do_not_disturb_each_other(hip):
     for sc in scenes:
         hip.render_frame(sc, w, h)
         alone.append(hip.read_pixels())
-    # Repeated: with the blur passes as two different LDS-DMA kernels (horizontal, vertical) roughly one run in eight came
-    # out with a few hundred wrong pixels in one context; as one kernel function with one merged body: none in 13 000 (tools/race_contexts.py).
+    # Repeated: a library WITH packed-FP32 instructions fails here in roughly half the context-runs (the compositor's
+    # v_pk_* misread an operand while another context's v_mfma shares the SIMD: DESIGN.md section 4, tools/race_probe.py).
     for _ in range(8):
         ctxs = [HipContext(device=0) for _ in scenes]
         for c, sc in zip(ctxs, scenes):
@@ -204,10 +204,11 @@ def test_workload_scene_1080p_matches_oracle(hip):
     assert n0 <= 0.005 * w * h
 
 
-def test_4k_config_properties(hip):
-    """BASELINE config 3 at full size: size-independent properties instead of a full oracle pass.
-    (a) a horizontal band rendered as its own stripe equals the same rows of the full render,
-    (b) a 512x512 crop window agrees with the oracle run on a translated copy of the scene."""
+def test_4k_config_matches_oracle_and_stripes(hip):
+    """BASELINE config 3 at full size (S300@4K + full-frame blur, the bench frame):
+    (a) the whole 3840x2160 frame against the oracle (<= 1 LSB, <= 0.5 % of the pixels differing),
+    (b) a horizontal band rendered as its own stripe equals the same rows of the full render,
+    (c) every row was written (alpha 255 everywhere: no stale rows from an earlier frame)."""
     from figdraw_amd.scenes import make_render_tree_100
 
     w, h = 3840, 2160
@@ -217,13 +218,73 @@ def test_4k_config_properties(hip):
     assert full.shape == (h, w, 4)
     st = hip.frame_stats()
     assert st.n_draws >= 700 and st.n_blurs == 2
+    want = _oracle(lambda *_: sc, w, h)
+    mx, n0, n1 = diff_stats(full, want)
+    assert mx <= 1, ("4K frame vs oracle", mx, n0, n1)
+    assert n0 <= 0.005 * w * h, ("4K frame vs oracle: too many 1-LSB pixels", n0)
     hip.set_stripe(1000, 1300)
     hip.render_frame(sc, w, h)
     band = hip.read_pixels(0, 1000, w, 300)
     hip.set_stripe(0, 0)
     assert (band == full[1000:1300]).all()
-    # checksum of checksums: every row must have been written (no stale rows from an earlier frame)
     assert full[..., 3].min() == 255
+
+
+def test_8k_config5_row_stripes_match_full_frame_and_oracle(hip):
+    """BASELINE config 5 on one GPU: a frame of S300 at 7680x4320 rendered as the eight row stripes the 8-GPU run gives its
+    ranks (`stripe_rows(4320, 8, r)`, each with its redundant blur halo), stitched: equal to the full render bit for bit, and
+    the full render within 1 LSB of the oracle."""
+    from figdraw_amd.scenes import make_render_tree_100
+    from figdraw_amd.sharding import stripe_rows
+
+    w, h = 7680, 4320
+    sc = make_render_tree_100(w, h, frame=5, full_frame_blur=True)
+    hip.render_frame(sc, w, h)
+    full = hip.read_pixels()
+    stitched = np.zeros_like(full)
+    for r in range(8):
+        y0, y1 = stripe_rows(h, 8, r)
+        hip.set_stripe(y0, y1)
+        hip.render_frame(sc, w, h)
+        stitched[y0:y1] = hip.read_pixels(0, y0, w, y1 - y0)
+    hip.set_stripe(0, 0)
+    assert np.array_equal(stitched, full)
+    want = _oracle(lambda *_: sc, w, h)
+    mx, n0, n1 = diff_stats(full, want)
+    assert mx <= 1, ("8K frame vs oracle", mx, n0, n1)
+    assert n0 <= 0.005 * w * h
+
+
+def test_contexts_in_flight_at_4k_match_the_oracle(hip):
+    """The bench's mode at the bench's size: four contexts replay different 4K frames on their own streams (matrix-pipe blur
+    passes of one beside the compositor waves of the others).  Each context must end with the frame it renders alone, and one
+    of them is also held against the oracle.  (With packed-FP32 instructions in the library this fails within a few rounds:
+    DESIGN.md section 4.)"""
+    from figdraw_amd.context import HipContext
+    from figdraw_amd.scenes import make_render_tree_100
+
+    w, h = 3840, 2160
+    scenes = [make_render_tree_100(w, h, frame=f, full_frame_blur=True) for f in range(4)]
+    alone = []
+    for sc in scenes:
+        hip.render_frame(sc, w, h)
+        alone.append(hip.read_pixels())
+    ctxs = [HipContext(device=0) for _ in scenes]
+    try:
+        for c, sc in zip(ctxs, scenes):
+            c.render_frame(sc, w, h)
+        for _ in range(6):
+            for _ in range(6):
+                for c in ctxs:
+                    c.replay_async(3)
+            for c, want in zip(ctxs, alone):
+                c.sync()
+                assert np.array_equal(c.read_pixels(), want)
+        mx, n0, n1 = diff_stats(ctxs[2].read_pixels(), _oracle(lambda *_: scenes[2], w, h))
+        assert mx <= 1 and n0 <= 0.005 * w * h, (mx, n0, n1)
+    finally:
+        for c in ctxs:
+            c.close()
 
 
 def test_8k_full_frame_blur_matches_oracle(hip):

@@ -81,8 +81,29 @@ def test_blur_matches_reference_blur_frag(radius):
     assert mx <= 1
 
 
+# The call-stream tests below run twice: on the oracle's front-end and on the HIP library's own front-end
+# (figdraw_amd/csrc/fdh_frontend.cpp behind the C ABI, a FDH_CREATE_RECORD_ONLY context: no GPU needed).  The known answers
+# are the reference's (tests/ttransform.nim, tests/trender_rgb_boxes_sdf.nim); both restatements have to give them.
+_BACKEND = ["oracle"]
+
+
+@pytest.fixture(params=["oracle", "hip"])
+def frontend(request):
+    _BACKEND[0] = request.param
+    yield request.param
+    _BACKEND[0] = "oracle"
+
+
+def _recorder():
+    if _BACKEND[0] == "hip":
+        from figdraw_amd.context import HipContext
+
+        return HipContext(record_only=True)
+    return O.Oracle()
+
+
 def _record(renders, w=64, h=64):
-    o = O.Oracle()
+    o = _recorder()
     o.record_begin()
     o.render_frame(renders, w, h)
     return o.record_calls()
@@ -112,7 +133,7 @@ def _xf_point(calls, upto, x, y):
     return p[0], p[1]
 
 
-def test_known_answers_from_ttransform():
+def test_known_answers_from_ttransform(frontend):
     """tests/ttransform.nim:146-267 restated with rectangle children (nkDrawable is a 'next' row)."""
     K = FigKind
     # elliptical radii passthrough (:147-166)
@@ -151,7 +172,7 @@ def test_known_answers_from_ttransform():
     assert abs(x - 14.0) < 1e-4 and abs(y - 26.0) < 1e-4
 
 
-def test_decomposition_order_and_skip_rules():
+def test_decomposition_order_and_skip_rules(frontend):
     """figrender.nim:1756-1839 stage order; :659-663,721-724,837,855 skip rules."""
     sc = RS.rgb_boxes_sdf()
     modes = [c[5] for c in _record(sc, 800, 600) if c[0] == "draw_rounded_rect_sdf"]
@@ -292,14 +313,14 @@ def _drawable_draws(op=None, ops=None, box=(0.0, 0.0, 300.0, 300.0), stroke=None
     if fill_ is not None:
         f.fill = fill_
     r.addRoot(0, f)
-    o = O.Oracle()
+    o = _recorder()
     o.record_begin()
     o.render_frame(r, 64, 64, ui_scale=ui_scale)
     calls = o.record_calls()
     return [c for c in calls if c[0].startswith("draw_")], calls
 
 
-def test_drawable_known_answers_from_ttransform():
+def test_drawable_known_answers_from_ttransform(frontend):
     """tests/ttransform.nim:269-547 restated against the recorded backend-call stream."""
     from figdraw_amd.scene import (RenderStroke, StrokeCap, StrokeJoin, drawableArc, drawableBezier, drawableEllipse,
                                    drawableLine, drawableRect)

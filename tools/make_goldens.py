@@ -3,8 +3,11 @@
 
   ref_<name>.png   byte-for-byte image content of the reference's own test fixtures
                    (tests/expected/*.png in the reference): data the reference's tests hold.
-  ss_<name>.png    the reference's GLSL shaders run on SwiftShader (oracle/ref_swiftshader.py)
-                   over the BackendContext call stream the scene decomposes into.
+  ss_<name>.png    the reference's GLSL shaders run on SwiftShader (oracle/ref_swiftshader.py) over the
+                   BackendContext call stream the scene decomposes into -- the stream recorded from the HIP
+                   library's OWN front-end (fdh_record_begin / fdh_record_json on a FDH_CREATE_RECORD_ONLY
+                   context), checked here to equal the oracle's: the goldens pin the product's decomposition,
+                   not only the oracle's.
   manifest.json    sizes, provenance and the measured oracle-vs-golden agreement at generation time.
 """
 import json
@@ -21,6 +24,20 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import ref_scenes as RS  # noqa: E402
 from oracle import oracle as O  # noqa: E402
 from oracle import ref_swiftshader as R  # noqa: E402
+from figdraw_amd.context import HipContext  # noqa: E402
+from test_frontend_calls import _same  # noqa: E402
+
+
+def hip_calls(scene, w, h, atlas_size=1024, images=None):
+    """the call stream of the HIP library's front-end for `scene` (no GPU: a record-only context)"""
+    ctx = HipContext(atlas_size=atlas_size, record_only=True)
+    for k in sorted(images or {}):
+        ctx.put_image(k, images[k])
+    ctx.record_begin()
+    ctx.render_frame(scene, w, h)
+    calls = ctx.record_calls()
+    ctx.close()
+    return calls
 
 GOLD = os.path.join(ROOT, "tests", "golden")
 REF_EXPECTED = "/root/reference/tests/expected"
@@ -41,11 +58,13 @@ def main():
         o = O.Oracle(threads=8)
         o.record_begin()
         o.render_frame(fn(float(w), float(h)), w, h)
-        calls = o.record_calls()
+        calls = hip_calls(fn(float(w), float(h)), w, h)
+        _same(o.record_calls(), calls)
         img = o.read_pixels()
         ss = R.replay(calls, w, h)
         Image.fromarray(ss).save(os.path.join(GOLD, f"ss_{name}.png"), optimize=True)
-        entry = {"width": w, "height": h, "n_calls": len(calls), "oracle_vs_swiftshader": stats(img, ss)}
+        entry = {"width": w, "height": h, "n_calls": len(calls), "calls_from": "libfigdraw_hip front-end (== oracle's)",
+                 "oracle_vs_swiftshader": stats(img, ss)}
         if name in RS.REFERENCE_PNG_SCENES:
             png = RS.REFERENCE_PNG_SCENES[name][3]
             exp = np.array(Image.open(os.path.join(REF_EXPECTED, png)).convert("RGBA"))
@@ -78,12 +97,13 @@ def main():
             o.put_image(k, images[k])
         o.record_begin()
         o.render_frame(sc, w, h)
-        calls = o.record_calls()
+        calls = hip_calls(sc, w, h, atlas_size=RS.ATLAS_GOLDEN_SIZE, images=images)
+        _same(o.record_calls(), calls)
         img = o.read_pixels()
         ss = R.replay(calls, w, h, atlas_size=RS.ATLAS_GOLDEN_SIZE, images=images)
         Image.fromarray(ss).save(os.path.join(GOLD, f"ss_{name}.png"), optimize=True)
         manifest[name] = {"width": w, "height": h, "n_calls": len(calls), "atlas_size": RS.ATLAS_GOLDEN_SIZE,
-                          "n_images": len(images), "oracle_vs_swiftshader": stats(img, ss)}
+                          "n_images": len(images), "calls_from": "libfigdraw_hip front-end (== oracle's)", "oracle_vs_swiftshader": stats(img, ss)}
         print(name, manifest[name])
     # blur-only vectors: random RGBA8 through blur.frag H+V at several radii
     rng = np.random.default_rng(7)
