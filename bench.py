@@ -9,10 +9,15 @@
            (the host-side decomposition and the 90 KB record upload happen once, before the timed region;
            the PCIe-inclusive rate is in DESIGN.md, it is never `value`)
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): frames are independent, so rank r renders its own
-frame (`frame = r`) with no data-path collective -- weak scaling.  After the timed region the ranks' final
-frames are gathered to rank 0 with ONE RCCL gather over xGMI (the north star's "single gather for the final
-image"); its time is reported separately and is not part of `value`.
+N > 1 (launched by torch.distributed.run, one rank per GPU), two ways to shard:
+  --mode frames   (default) frames are independent, so rank r renders its own frames with no data-path collective --
+                  weak scaling.  After the timed region the ranks' final frames are gathered to rank 0 with ONE RCCL
+                  gather over xGMI; its time is reported separately and is not part of `value`.
+  --mode stripes  BASELINE.json configs[4] (run it with --width 7680 --height 4320): a batch of 8 frames (frame = 0..7 in
+                  rotation), every rank renders rows stripe_rows(H, N, r) of EVERY frame (with its redundant blur halo) and
+                  the stripes of each frame are gathered into rank 0's image INSIDE the timed region (grouped RCCL send /
+                  recv, pipelined one frame behind the rendering).  `value` = W*H*frames / wall including the gathers --
+                  strong scaling; `gather_ms` is the part of the wall time rank 0 spent in them.
 """
 import argparse
 import json
@@ -27,6 +32,12 @@ sys.path.insert(0, ROOT)
 
 W, H = 3840, 2160
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
+# VALU issue peak: 256 CUs x 4 SIMDs, one wave64 VALU instruction per SIMD every 2 cycles (SIMD-32; tools/microbench/
+# valu_rate.hip, raw output profiles/r02_valu_rate.txt: v_fma / v_add / v_rndne / v_cvt 0.99 ns = 2 cycles at the ~2.0 GHz the
+# chip sustains under that load, v_exp / v_rcp / v_sqrt 3.4 ns = 4 slots, v_pk_fma_f32 2.0 ns = 2 slots, i.e. no gain over
+# two plain FMAs) at the 2.4 GHz maximum clock.  Transcendentals count as one instruction and cost four slots, so a kernel
+# full of them (this one: sqrt, exp, rcp per edge pixel) cannot reach frac = 1.
+VALU_PEAK_GINST = 256 * 4 * 2.4 / 2.0
 
 
 def frame_tensor(ctx):
@@ -42,6 +53,117 @@ def frame_tensor(ctx):
     return torch.as_tensor(_Surf(), device=f"cuda:{ctx.device}")
 
 
+def run_stripes(args, dist, rank, local_rank, world, on_host):
+    """BASELINE config 5: an 8-frame batch, each frame row-striped over the ranks, stripes gathered to rank 0 per frame."""
+    import torch
+
+    from figdraw_amd.context import HipContext
+    from figdraw_amd.scenes import make_render_tree_100
+    from figdraw_amd.sharding import stripe_rows
+
+    w, h = args.width, args.height
+    NF = 8
+    y0, y1 = stripe_rows(h, world, rank)
+    rows = [stripe_rows(h, world, r) for r in range(world)]
+    ctxs = []
+    for f in range(NF):  # one context per frame of the batch: its records stay resident, its stripe is set once
+        c = HipContext(device=local_rank)
+        c.set_stripe(y0, y1)
+        c.render_frame(make_render_tree_100(w, h, frame=f, full_frame_blur=True), w, h)
+        ctxs.append(c)
+    for c in ctxs:
+        c.sync()
+    surf = [frame_tensor(c) for c in ctxs]  # zero-copy (H, W, 4) views
+    dev = "cpu" if on_host else f"cuda:{local_rank}"
+    full = torch.zeros((h, w, 4), dtype=torch.uint8, device=dev) if rank == 0 else None
+    gather_s = [0.0]
+
+    def gather(f):
+        """stripe of frame f from every rank into rank 0's image: grouped send / recv (ncclGroupStart .. End under RCCL)"""
+        t0 = time.perf_counter()
+        mine = surf[f][y0:y1]
+        if on_host:
+            mine = mine.cpu()
+        if rank == 0:
+            full[y0:y1].copy_(mine, non_blocking=True)
+            ops = [dist.P2POp(dist.irecv, full[a:b], r) for r, (a, b) in enumerate(rows) if r != 0 and b > a] if dist is not None else []
+        else:
+            ops = [dist.P2POp(dist.isend, mine, 0)] if y1 > y0 else []
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        if not on_host:
+            torch.cuda.current_stream().synchronize()
+        gather_s[0] += time.perf_counter() - t0
+
+    def run(n):
+        pending = None
+        for k in range(n):  # render frame k while frame k - 1 is gathered
+            c = ctxs[k % NF]
+            c.replay_async(1)
+            if pending is not None:
+                ctxs[pending].sync()
+                gather(pending)
+            pending = k % NF
+        if pending is not None:
+            ctxs[pending].sync()
+            gather(pending)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        for c in ctxs:
+            c.sync()
+        torch.cuda.synchronize()
+
+    run(args.warmup)
+    barrier()
+    gather_s[0] = 0.0
+    t0 = time.perf_counter()
+    run(args.steps)
+    for c in ctxs:
+        c.sync()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        dist.barrier()
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    if rank != 0:
+        return
+    last = (args.steps - 1) % NF
+    got = full.cpu().numpy()
+    assert int(got[..., 3].min()) == 255, "the gathered frame has unwritten pixels"
+    check = None
+    if not args.no_cpu_baseline:  # the gathered image of the last frame against the oracle (outside the timed region)
+        from oracle import oracle as O
+
+        orc = O.Oracle(threads=min(os.cpu_count() or 1, 16))
+        orc.render_frame(make_render_tree_100(w, h, frame=last, full_frame_blur=True), w, h)
+        d = np.abs(got.astype(int) - orc.read_pixels().astype(int))
+        check = {"frame": last, "parity_max_lsb": int(d.max()), "parity_pixels_differing": int((d.max(axis=2) > 0).sum())}
+        if check["parity_max_lsb"] > 1:
+            print(json.dumps({"error": "gathered frame disagrees with the oracle", "check": check}))
+            sys.exit(1)
+    st = ctxs[0].frame_stats()
+    ms_step = 1e3 * elapsed / args.steps
+    print(json.dumps({
+        "metric": "Mpixels/s composited @3840x2160, 300 SDF rects+shadows; % HBM roofline",
+        "value": round(w * h * args.steps / elapsed / 1e6, 1), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"S300@8Kx8 (BASELINE.json configs[4]): 8-frame batch of the renderlist_100 scene at {w}x{h} with the full-frame blur, "
+                               f"row-striped over {world} rank(s), stripes gathered to rank 0 per frame inside the timed region",
+                   "mode": "stripes", "draws": st.n_draws, "rows_per_rank": [b - a for a, b in rows],
+                   "parallelism": f"row stripes x{world}" if world > 1 else "single GPU (one stripe = the frame)"},
+        "gather_ms": round(1e3 * gather_s[0] / args.steps, 4),
+        "gather_note": "per frame, rank 0's wall time inside the gather calls (includes waiting for the slowest stripe); part of `value`'s wall time",
+        "gathered_frame_check": check,
+        "roofline": None, "cpu_baseline": None,
+    }))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -54,6 +176,9 @@ def main():
                     help="independent render contexts per GPU (own stream + surfaces) whose frames overlap; 1 = strictly one frame at a time")
     ap.add_argument("--width", type=int, default=W)
     ap.add_argument("--height", type=int, default=H)
+    ap.add_argument("--mode", choices=["frames", "stripes"], default="frames",
+                    help="frames: every rank renders whole frames (weak scaling); stripes: every rank renders its row stripe of every frame of an "
+                         "8-frame batch and the stripes are gathered to rank 0 inside the timed region (BASELINE config 5, strong scaling)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -76,6 +201,8 @@ def main():
     else:
         torch.cuda.set_device(local_rank)
     on_host = dist is not None and args.backend != "nccl"  # gloo moves tensors through host memory
+    if args.mode == "stripes":
+        return run_stripes(args, dist, rank, local_rank, world, on_host)
 
     from figdraw_amd.context import HipContext
     from figdraw_amd.scenes import make_render_tree_100
@@ -139,8 +266,11 @@ def main():
     # Integrity of the frames-in-flight mode (outside the timed region): every context must hold exactly the frame it
     # renders with the GPU to itself.  (The blur passes once failed this as two kernels: DESIGN.md section 4.)
     in_flight_differing = 0
+    in_flight_frames = []
+    in_flight_vs_oracle = None
     for c in ctxs:
         got_in_flight = c.read_pixels()
+        in_flight_frames.append(got_in_flight)
         c.replay(1)
         c.sync()
         in_flight_differing += int((got_in_flight != c.read_pixels()).any(axis=2).sum())
@@ -201,43 +331,64 @@ def main():
 
     mpix = world * w * h * args.steps / elapsed / 1e6
 
-    def roof(bytes_per_launch, ms):
-        if not ms or ms <= 0:
-            return None
-        gbs = bytes_per_launch / (ms * 1e-3) / 1e9
-        return {"bound": "hbm", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(gbs / HBM_PEAK_GBS, 5), "traffic": None}
+    def hbm(bytes_, ms):
+        gbs = bytes_ / (ms * 1e-3) / 1e9
+        return {"achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5)}
 
-    roofline = roof(st.bytes_composite_main, st.ms_composite_main)
-    if roofline is not None:
-        roofline["kernel"] = "k_composite_tiles (phase 0)"
-        roofline["ms_per_launch"] = round(st.ms_composite_main, 4)
-        roofline["algorithmic_bytes_per_launch"] = int(st.bytes_composite_main)
-        roofline["note"] = ("fused tile compositor: VALU/transcendental-bound by construction, it moves 4 B/pixel out + "
-                            "128 B/draw in; the HBM-bound kernels are the blur passes (roofline_blur)")
-    blur_ms = st.ms_blur_h + st.ms_blur_v
-    roofline_blur = roof(st.bytes_blur, blur_ms)
-    if roofline_blur is not None:
-        roofline_blur["kernel"] = "blur passes of a frame: k_blur_mx<.., false|true> (full-frame node, matrix pipe) + k_blur_h / k_blur_v (360x240 node)"
-        roofline_blur["ms_per_frame"] = round(blur_ms, 4)
-        roofline_blur["arithmetic"] = ("v_mfma_f32_32x32x16_f16, f32 accumulate: RGBA8 texels as exact f16 subnormals x weights split into "
-                                       "two f16 halves (22 bits), every product exact; <= 1 LSB from the f32 FIR")
-        roofline_blur["algorithmic_bytes_per_frame"] = int(st.bytes_blur)
-    frame_gbs = st.bytes_algorithmic / (ms_step * 1e-3) / 1e9
-    # HBM traffic per launch from PMC counters cannot be collected inside this process; it comes from the committed
-    # rocprofv3 --pmc passes over this very command (profiles/*_pmc_traffic.json, corrected as MI355X_MICROARCH.md
-    # prescribes) and is attached only when the workload is the one those passes profiled.
+    # Counters that cannot be collected inside this process (HBM bytes, instruction counts) come from the newest committed
+    # rocprofv3 --pmc passes over this very command (tools/pmc_traffic.sh -> profiles/r*_pmc_traffic.json, corrected as
+    # MI355X_MICROARCH.md prescribes) and are attached only when the workload is the one those passes profiled.
+    pmc, pmc_src = {}, None
     try:
         import glob
+        import hashlib
 
-        pmc = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[-1]))["kernels"]
+        from figdraw_amd import context as C_
+
+        f = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[-1]
+        j = json.load(open(f))
         if (w, h) == (W, H) and 700 <= st.n_draws <= 715:
-            if roofline is not None:
-                roofline["traffic"] = pmc["k_composite_tiles.phase0"]["hbm_bytes"]
-            if roofline_blur is not None:
-                roofline_blur["traffic"] = sum(pmc[k]["hbm_bytes"] for k in pmc if k.startswith("k_blur_"))
+            pmc = j["kernels"]
+            lib = os.environ.get("FIGDRAW_HIP_LIB", C_.LIB_PATH)
+            sha = hashlib.sha256(open(lib, "rb").read()).hexdigest()[:16]
+            pmc_src = {"file": os.path.relpath(f, ROOT), "profiled_library_sha16": j.get("library_sha16"), "this_library_sha16": sha,
+                       "same_build": j.get("library_sha16") == sha,
+                       "note": "counters from the committed rocprofv3 --pmc passes, not measured in this run"}
     except Exception:
         pass
+
+    # Dominant launch = k_composite_tiles, phase 0.  It is VALU-issue bound (it moves 4 B per pixel whatever the overdraw):
+    # achieved = wave-level VALU instructions per launch (SQ_INSTS_VALU, PMC pass) / the launch's duration in THIS run.
+    roofline = None
+    if st.ms_composite_main > 0:
+        k = pmc.get("k_composite_tiles.phase0", {})
+        insts = k.get("SQ_INSTS_VALU")
+        roofline = {"kernel": "k_composite_tiles<0> (phase 0)", "ms_per_launch": round(st.ms_composite_main, 4),
+                    "bound": "valu", "unit": "G wave-instructions/s", "peak": round(VALU_PEAK_GINST, 1),
+                    "achieved": round(insts / (st.ms_composite_main * 1e-3) / 1e9, 1) if insts else None,
+                    "frac": round(insts / (st.ms_composite_main * 1e-3) / 1e9 / VALU_PEAK_GINST, 4) if insts else None,
+                    "valu_instructions_per_launch": insts, "salu_instructions_per_launch": k.get("SQ_INSTS_SALU"),
+                    "traffic": k.get("hbm_bytes"), "traffic_source": pmc_src,
+                    "hbm": dict(hbm(st.bytes_composite_main, st.ms_composite_main), algorithmic_bytes_per_launch=int(st.bytes_composite_main)),
+                    "note": "fused tile compositor: one wave64 VALU instruction per SIMD per 2 cycles is the ceiling (peak = 1024 SIMDs x 2.4 GHz / 2; transcendentals take 4 slots); "
+                            "HBM-wise it moves 4 B/pixel out + 128 B/draw in by construction (`hbm`); the HBM-bound launches are the blur passes (roofline_blur)"}
+    # The HBM-bound launches: the two passes of the frame's largest blur node (full frame here), each against its own bytes
+    roofline_blur = None
+    if st.ms_blur_big_h > 0 and st.ms_blur_big_v > 0:
+        bh, bv = int(st.bytes_blur_big_h), int(st.bytes_blur_big_v)
+        both = hbm(bh + bv, st.ms_blur_big_h + st.ms_blur_big_v)
+        th, tv = pmc.get("k_blur_mx.h", {}).get("hbm_bytes"), pmc.get("k_blur_mx.v", {}).get("hbm_bytes")
+        roofline_blur = dict(both, bound="hbm", kernel="k_blur_mx<NK, false> + k_blur_mx<NK, true>: horizontal and vertical pass of the full-frame blur node (matrix pipe)",
+                             ms_per_frame=round(st.ms_blur_big_h + st.ms_blur_big_v, 4), algorithmic_bytes_per_frame=bh + bv,
+                             traffic=(th + tv) if th and tv else None, traffic_source=pmc_src,
+                             passes={"horizontal": dict(hbm(bh, st.ms_blur_big_h), ms=round(st.ms_blur_big_h, 4), algorithmic_bytes=bh, traffic=th),
+                                     "vertical": dict(hbm(bv, st.ms_blur_big_v), ms=round(st.ms_blur_big_v, 4), algorithmic_bytes=bv, traffic=tv)},
+                             all_blur_launches_ms=round(st.ms_blur_h + st.ms_blur_v, 4),
+                             arithmetic="v_mfma_f32_32x32x16_f16, f32 accumulate: RGBA8 texels as exact f16 subnormals x weights split into "
+                                        "two f16 halves (22 bits), every product exact; <= 1 LSB from the f32 FIR",
+                             bytes_note="H: region + halo rows read and written; V: those rows read, the region written; the fused composite reads the "
+                                        "surface only where it has to blend (the cleared opaque surface of this frame: nowhere but the quad's border blocks)")
+    frame_gbs = st.bytes_algorithmic / (ms_step * 1e-3) / 1e9
 
     cpu_baseline = None
     if world == 1 and not args.no_cpu_baseline:
@@ -264,6 +415,10 @@ def main():
         d = np.abs(got.astype(int) - orc.read_pixels().astype(int))
         cpu_baseline["parity_max_lsb"] = int(d.max())
         cpu_baseline["parity_pixels_differing"] = int((d.max(axis=2) > 0).sum())
+        if F > 1:  # one of the frames that were rendered IN FLIGHT (kept from before the re-render above) against the oracle
+            orc.render_frame(make_render_tree_100(w, h, frame=rank + world * (F - 1), full_frame_blur=True), w, h)
+            d = np.abs(in_flight_frames[F - 1].astype(int) - orc.read_pixels().astype(int))
+            in_flight_vs_oracle = {"context": F - 1, "parity_max_lsb": int(d.max()), "parity_pixels_differing": int((d.max(axis=2) > 0).sum())}
 
     out = {
         "metric": "Mpixels/s composited @3840x2160, 300 SDF rects+shadows; % HBM roofline",
@@ -283,7 +438,7 @@ def main():
                    "draws": st.n_draws, "phases": st.n_phases, "blur_nodes": st.n_blurs, "fragments": int(st.fragments),
                    "parallelism": f"frame-parallel x{world}" if world > 1 else "single GPU", "frames_in_flight_per_gpu": F},
         "frames_in_flight_check": {"contexts": F, "identical_to_each_frame_rendered_alone": in_flight_differing == 0,
-                                   "pixels_differing": in_flight_differing},
+                                   "pixels_differing": in_flight_differing, "in_flight_frame_vs_oracle": in_flight_vs_oracle},
         "one_frame_at_a_time": {"value": round(w * h * args.steps / single_elapsed / 1e6, 1), "unit": "Mpixels/s (this rank)",
                                 "ms_per_step": round(1e3 * single_elapsed / args.steps, 4)},
         "roofline": roofline,
@@ -303,7 +458,15 @@ def main():
     }
     if gather_ms is not None:
         out["gather_ms"] = round(gather_ms, 3)
+    # a frame that came out differently in flight than alone (or off the oracle) voids the throughput figure
+    bad = in_flight_differing != 0 or (in_flight_vs_oracle is not None and in_flight_vs_oracle["parity_max_lsb"] > 1) or \
+        (cpu_baseline is not None and cpu_baseline["parity_max_lsb"] > 1)
+    if bad:
+        out["value"] = None
+        out["error"] = "frames rendered in flight differ from the same frames rendered alone, or from the oracle"
     print(json.dumps(out))
+    if bad:
+        sys.exit(1)
 
 
 if __name__ == "__main__":

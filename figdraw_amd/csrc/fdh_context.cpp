@@ -1165,13 +1165,22 @@ void Context::submit(bool upload) {
   // algorithmic bytes of this frame: final store + per blur (pre-blur store is the store above for
   // a full-frame node; H read + H write + V read + V write + composite read) + records once
   int64_t bytes = 4LL * W_ * H_ + (int64_t)n * (int64_t)sizeof(DrawRec), bytes_blur = 0;
-  for (auto& j : blurs_) {
+  // a cleared opaque surface stays opaque under SRC_ALPHA / ONE_MINUS_SRC_ALPHA blending (a' = sa + da (1 - sa), da = 1): a
+  // fused vertical pass then replaces pixels under full coverage without reading them
+  const bool surface_opaque = clear_ && (clear_rgba8_ >> 24) == 255u;
+  big_blur_ = -1;
+  int64_t big_area = 0;
+  stats_.bytes_blur_big_h = stats_.bytes_blur_big_v = 0;
+  for (size_t bi = 0; bi < blurs_.size(); bi++) {
+    const BlurJob& j = blurs_[bi];
     const int ylo = std::max(0, j.y0 - j.taps.reach), yhi = std::min(H_, j.y1 + j.taps.reach);
     const int64_t a_h = (int64_t)(j.x1 - j.x0) * (yhi - ylo), a_v = (int64_t)(j.x1 - j.x0) * (j.y1 - j.y0);
-    bytes_blur += 4 * a_h + 4 * a_h + 4 * a_h + 4 * a_v;  // H read, H write, V read, V write
-    // the consuming composite: fused into the V pass it reads the live surface there; otherwise a composite launch
-    // reads the blurred snapshot
-    if (j.fuse_draw >= 0) bytes_blur += 4 * a_v; else bytes += 4 * a_v;
+    int64_t b_h = 4 * a_h + 4 * a_h, b_v = 4 * a_h + 4 * a_v;  // H read + H write; V read + V write
+    // the consuming composite: fused into the V pass it reads the live surface there (where it has to blend); otherwise a
+    // composite launch reads the blurred snapshot
+    if (j.fuse_draw >= 0) { if (!surface_opaque) b_v += 4 * a_v; } else bytes += 4 * a_v;
+    bytes_blur += b_h + b_v;
+    if (a_v > big_area) { big_area = a_v; big_blur_ = (int)bi; stats_.bytes_blur_big_h = b_h; stats_.bytes_blur_big_v = b_v; }
   }
   bytes += bytes_blur;
   stats_.bytes_blur = bytes_blur;
@@ -1208,8 +1217,9 @@ void Context::launch_frame(bool profile) {
       }
     }
   }
-  auto span_begin = [&](int kind) { if (profile) { Span sp{kind, next_event(), next_event()}; FDH_HIP(hipEventRecord(sp.a, stream_)); spans_.push_back(sp); } };
-  auto span_end = [&]() { if (profile) FDH_HIP(hipEventRecord(spans_.back().b, stream_)); };
+  // profile mode: every launch stamps its own pair of events (set_launch_events: the kernel's execution time, no gaps)
+  auto span_begin = [&](int kind) { if (profile) { Span sp{kind, next_event(), next_event()}; set_launch_events(sp.a, sp.b); spans_.push_back(sp); } };
+  auto span_end = [&]() { if (profile) { if (!launch_events_used()) spans_.pop_back(); set_launch_events(nullptr, nullptr); } };
   span_begin(0);
   BinParams B;
   B.bbox = dv_.bboxes; B.draws = dv_.recs; B.binbox = dv_.binbox; B.chunkbox = dv_.chunkbox; B.n_draws = (int)recs_.size(); B.binbox_shift = binbox_shift_; B.lists = d_lists_.ptr; B.counts = d_counts_.ptr; B.phase_first = dv_.phase_first;
@@ -1244,14 +1254,14 @@ void Context::launch_frame(bool profile) {
         bp.mx_w = (size_t)ph.blur < mx_w_h_.size() ? mx_w_h_[ph.blur] : nullptr;
         bp.src = fb_; bp.dst = blur_tmp_;
         bp.x0 = j.x0; bp.x1 = j.x1; bp.y0 = std::max(0, vy0 - j.taps.reach); bp.y1 = std::min(H_, vy1 + j.taps.reach);
-        span_begin(3);
+        span_begin(ph.blur == big_blur_ ? 5 : 3);
         launch_blur_h(stream_, bp);
         span_end();
         bp.src = blur_tmp_; bp.dst = j.fuse_draw >= 0 ? fb_ : backdrop_;
         bp.mx_w = (size_t)ph.blur < mx_w_v_.size() ? mx_w_v_[ph.blur] : nullptr;
         bp.fuse_draw = j.fuse_draw;
         bp.y0 = vy0; bp.y1 = vy1;
-        span_begin(4);
+        span_begin(ph.blur == big_blur_ ? 6 : 4);
         launch_blur_v(stream_, bp, dv_.recs, dv_.exts);
         span_end();
       }
@@ -1345,7 +1355,7 @@ void Context::profile(int times) {
   if (!have_frame_) throw Error(FDH_ERR_INVALID, "profile: no frame has been submitted");
   FDH_HIP(hipSetDevice(device_));
   if (times <= 0) return;
-  double acc[5] = {0, 0, 0, 0, 0};
+  double acc[7] = {0, 0, 0, 0, 0, 0, 0};
   for (int i = 0; i < times; i++) {
     ev_used_ = 0;
     spans_.clear();
@@ -1353,15 +1363,17 @@ void Context::profile(int times) {
     FDH_HIP(hipStreamSynchronize(stream_));
     for (auto& sp : spans_) {
       float t = 0.0f;
-      FDH_HIP(hipEventElapsedTime(&t, sp.a, sp.b));
-      acc[sp.kind] += t;
+      if (hipEventElapsedTime(&t, sp.a, sp.b) == hipSuccess) acc[sp.kind] += t;  // (a span whose launch had nothing to do never stamped its events)
+      else (void)hipGetLastError();
     }
   }
   stats_.ms_bin = (float)(acc[0] / times);
   stats_.ms_composite_main = (float)(acc[1] / times);
   stats_.ms_composite = (float)((acc[1] + acc[2]) / times);
-  stats_.ms_blur_h = (float)(acc[3] / times);
-  stats_.ms_blur_v = (float)(acc[4] / times);
+  stats_.ms_blur_h = (float)((acc[3] + acc[5]) / times);
+  stats_.ms_blur_v = (float)((acc[4] + acc[6]) / times);
+  stats_.ms_blur_big_h = (float)(acc[5] / times);
+  stats_.ms_blur_big_v = (float)(acc[6] / times);
 }
 
 // ------------------------------------------------------------------ readback (glcontext.nim:2094-2135)

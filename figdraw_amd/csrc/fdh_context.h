@@ -213,6 +213,7 @@ class Context {
   // device state
   uint32_t *fb_ = nullptr, *backdrop_ = nullptr, *blur_tmp_ = nullptr;
   uint32_t* dbg_snap_ = nullptr;
+  int big_blur_ = -1;       // index of the frame's largest blur job (its passes are timed on their own)
   bool host_only_ = false;  // FDH_CREATE_RECORD_ONLY
   bool rec_on_ = false, rec_first_ = true;
   std::string rec_;  // FDH_DEBUG_SNAP=1 (diagnostic): the surface as phase 0 left it, copied in-stream

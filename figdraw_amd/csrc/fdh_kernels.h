@@ -53,6 +53,9 @@ struct BlurParams {
   BlurTaps taps;
 };
 
+// profile mode: the next launch_* call stamps these events with its kernel's own start / end (nullptr: plain launches)
+void set_launch_events(hipEvent_t start, hipEvent_t stop);
+bool launch_events_used();
 void launch_bin(hipStream_t s, const BinParams& P);
 void launch_composite(hipStream_t s, const DrawRec* draws, const QuadExt* exts, CompositeParams P);
 void launch_blur_h(hipStream_t s, const BlurParams& P);

@@ -14,6 +14,7 @@
 // the lines it follows.  Only the blur FIR is a contraction and runs on MFMA; everything else is VALU + transcendental work
 // (SURVEY.md 8d).  The translation unit is compiled WITHOUT packed-FP32 instructions (csrc/Makefile): DESIGN.md section 4.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 #include "fdh_kernels.h"
@@ -1694,14 +1695,6 @@ __global__ __launch_bounds__(64, 2) void k_blur_mx(BlurParams P, const DrawRec* 
   const unsigned long long T0 = FDH_NOW();
   unsigned long long T_wait = 0, T_st = 0, T_mma = 0, T_epi = 0, T_iss = 0;
 #endif
-  h8 whi[NK], wlo[NK];
-#pragma unroll
-  for (int m = 0; m < NK; m++) {
-    H8Bits a, b;
-    const uint4 va = P.mx_w[(2 * m) * 64 + lane], vb = P.mx_w[(2 * m + 1) * 64 + lane];
-    a.u[0] = va.x; a.u[1] = va.y; a.u[2] = va.z; a.u[3] = va.w; b.u[0] = vb.x; b.u[1] = vb.y; b.u[2] = vb.z; b.u[3] = vb.w;
-    whi[m] = a.v; wlo[m] = b.v;
-  }
   const uint32_t ring_lds = (uint32_t)reinterpret_cast<uintptr_t>(ring);
 
   // LDS-DMA of k-step s (texels w0a + 16 s .. + 15 along the filter, 32 lines) into slot s % R; returns the instructions issued
@@ -1758,6 +1751,20 @@ __global__ __launch_bounds__(64, 2) void k_blur_mx(BlurParams P, const DrawRec* 
   for (int s = 0; s < NK; s++) issue(s);
   int last_batch = 0;
   if (n_blocks > 1) { last_batch = issue(NK); last_batch += issue(NK + 1); }
+  // The weight fragments are fetched behind the first k-steps and waited for HERE, with a wait the compiler can see.  (Left
+  // to itself it keeps `s_waitcnt vmcnt(3 .. 0)` for them in front of the MFMAs of every block -- it cannot know they landed
+  // long ago -- and since vmcnt counts every memory operation of the wave, those waits drained the prefetch of the next
+  // block and the stores of the last one in every iteration.)
+  h8 whi[NK], wlo[NK];
+#pragma unroll
+  for (int m = 0; m < NK; m++) {
+    H8Bits a, b;
+    const uint4 va = P.mx_w[(2 * m) * 64 + lane], vb = P.mx_w[(2 * m + 1) * 64 + lane];
+    a.u[0] = va.x; a.u[1] = va.y; a.u[2] = va.z; a.u[3] = va.w; b.u[0] = vb.x; b.u[1] = vb.y; b.u[2] = vb.z; b.u[3] = vb.w;
+    whi[m] = a.v; wlo[m] = b.v;
+  }
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) (expcnt, lgkmcnt untouched)
+  last_batch = 0;                      // (everything issued so far has landed)
   // the consuming quad's saturated core; the rest of its record is fetched by the few blocks on its border (32 fewer
   // SGPRs held through the walk: the vertical pass was spilling them into VGPR lanes)
   int core_x0 = 0, core_y0 = 0, core_x1 = 0, core_y1 = 0;
@@ -1966,6 +1973,9 @@ __global__ __launch_bounds__(64, 2) void k_blur_mx(BlurParams P, const DrawRec* 
           Fd.w = __builtin_rintf(__builtin_fmaf(Fd.w, ia, A));
           pend[rr] = pack255(Fd);
         }
+        // (a wait the compiler can see: otherwise it assumes one of these masked loads may still be in flight when their
+        // registers are reused at the top of the walk and puts a vmcnt(0) there -- in front of EVERY block's stores)
+        __builtin_amdgcn_s_waitcnt(0x0F70);
       }
       __builtin_amdgcn_wave_barrier();
       }
@@ -1999,9 +2009,21 @@ __global__ void k_fill_u32(uint32_t* p, uint32_t v, size_t n) {
 }
 
 // ------------------------------------------------------------------ launch wrappers (called from fdh_context.cpp)
+// Per-kernel timing (fdh_profile): with a pair of events set, the next launch goes through hipExtLaunchKernelGGL, which stamps
+// them from the dispatch's own start / end timestamps -- the kernel's execution time as rocprofv3 reports it.  (Events
+// recorded around a launch also count the gap to the neighbouring dispatches: +2..5 us on a 20 us kernel.)
+static thread_local hipEvent_t t_prof_start = nullptr, t_prof_stop = nullptr;
+static thread_local bool t_prof_used = false;
+void set_launch_events(hipEvent_t start, hipEvent_t stop) { t_prof_start = start; t_prof_stop = stop; t_prof_used = false; }
+bool launch_events_used() { return t_prof_used; }  // false: the launch_* call between had nothing to launch
+#define FDH_LAUNCH(kern, grid, block, lds, stream, ...)                                                                  \
+  do {                                                                                                                   \
+    if (t_prof_start) { hipExtLaunchKernelGGL(kern, grid, block, lds, stream, t_prof_start, t_prof_stop, 0, __VA_ARGS__); t_prof_used = true; } \
+    else hipLaunchKernelGGL(kern, grid, block, lds, stream, __VA_ARGS__);                                                \
+  } while (0)
 void launch_bin(hipStream_t s, const BinParams& P) {
   const int n = P.n_phases * P.bins_x * P.bins_y;
-  if (n > 0) hipLaunchKernelGGL(k_bin_draws, dim3(n), dim3(64), 0, s, P);
+  if (n > 0) FDH_LAUNCH(k_bin_draws, dim3(n), dim3(64), 0, s, P);
 }
 void launch_composite(hipStream_t s, const DrawRec* draws, const QuadExt* exts, CompositeParams P) {
   const int n = P.bin_nx * P.bin_ny * kWgsPerBin;
@@ -2016,9 +2038,9 @@ void launch_composite(hipStream_t s, const DrawRec* draws, const QuadExt* exts, 
   if (force == 3) P.has_slow = 1;
   if (force == 2) P.has_atlas = 1;
   const size_t lds = P.has_masks ? sizeof(uint32_t) * kMaskDepth * 64 : sizeof(uint32_t) * 256;
-  if (P.has_slow) hipLaunchKernelGGL(k_composite_tiles<3>, dim3(grid), blk, lds, s, draws, exts, P);
-  else if (P.has_atlas) hipLaunchKernelGGL(k_composite_tiles<2>, dim3(grid), blk, lds, s, draws, exts, P);
-  else hipLaunchKernelGGL(k_composite_tiles<0>, dim3(grid), blk, lds, s, draws, exts, P);
+  if (P.has_slow) FDH_LAUNCH(k_composite_tiles<3>, dim3(grid), blk, lds, s, draws, exts, P);
+  else if (P.has_atlas) FDH_LAUNCH(k_composite_tiles<2>, dim3(grid), blk, lds, s, draws, exts, P);
+  else FDH_LAUNCH(k_composite_tiles<0>, dim3(grid), blk, lds, s, draws, exts, P);
 }
 // small regions: fewer outputs per thread -> more, shorter waves (see NOUT above)
 #ifndef FDH_BLUR_NOUT
@@ -2055,13 +2077,13 @@ static int blur_pick_nout(int extent, int quantum, int reach) {
 }
 template <int NOUT> static void launch_blur_h_n(hipStream_t s, const BlurParams& P) {
   dim3 grid((P.x1 - P.x0 + 64 * NOUT - 1) / (64 * NOUT), (P.y1 - P.y0 + 3) / 4);
-  hipLaunchKernelGGL(k_blur_h<NOUT>, grid, dim3(256), 0, s, P);
+  FDH_LAUNCH(k_blur_h<NOUT>, grid, dim3(256), 0, s, P);
 }
 template <int NOUT, int WAVES> static void launch_blur_v_n(hipStream_t s, const BlurParams& P, const DrawRec* draws, const QuadExt* exts) {
   const int ntx = (P.x1 - P.x0 + kBlurVW - 1) / kBlurVW, nty = (P.y1 - P.y0 + WAVES * NOUT - 1) / (WAVES * NOUT);
   dim3 grid(8 * ((ntx * nty + 7) / 8));  // 8 XCDs x an eighth of the tile sequence each
   const size_t lds = (size_t)(WAVES * NOUT + 2 * P.taps.reach) * kBlurVW * sizeof(uint32_t);
-  hipLaunchKernelGGL((k_blur_v<NOUT, WAVES>), grid, dim3(64 * WAVES), lds, s, P, draws, exts);
+  FDH_LAUNCH((k_blur_v<NOUT, WAVES>), grid, dim3(64 * WAVES), lds, s, P, draws, exts);
 }
 // Matrix-pipe passes: NK k-steps of 16 texels must cover a block's 32 + 2 reach window (+ up to 3 texels of alignment
 // for the horizontal pass); T blocks per wave, as many as still leave every SIMD a couple of waves.
@@ -2083,7 +2105,7 @@ static int mx_pick_t(int nk, long long outputs_along, long long lines) {
 template <int NK, bool kV> static void launch_blur_mx(hipStream_t s, const BlurParams& P, const DrawRec* draws, const QuadExt* exts, int t) {
   const int a_lo = kV ? P.y0 : P.x0, a_hi = kV ? P.y1 : P.x1, l_lo = kV ? (P.x0 & ~31) : P.y0, l_hi = kV ? P.x1 : P.y1;
   const int total = ((a_hi - (a_lo & ~31) + 32 * t - 1) / (32 * t)) * ((l_hi - l_lo + 31) / 32);
-  hipLaunchKernelGGL((k_blur_mx<NK, kV>), dim3(8 * ((total + 7) / 8)), dim3(64), (size_t)(NK + 4) * kMxSlot * sizeof(uint32_t), s, P, draws, exts, t);
+  FDH_LAUNCH((k_blur_mx<NK, kV>), dim3(8 * ((total + 7) / 8)), dim3(64), (size_t)(NK + 4) * kMxSlot * sizeof(uint32_t), s, P, draws, exts, t);
 }
 template <bool kV> static bool launch_blur_mx_nk(hipStream_t s, const BlurParams& P, const DrawRec* draws, const QuadExt* exts) {
   // LDS-DMA moves 16-byte pieces: rows have to start on 16-byte boundaries

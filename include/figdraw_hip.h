@@ -281,8 +281,15 @@ typedef struct {
    * the upload, and issuing the copies + kernel launches; all asynchronous to the GPU */
   float ms_host_record, ms_host_upload, ms_host_launch;
   float _reserved;
+  /* the frame's LARGEST blur node on its own (the bench frame: the full-frame node, i.e. the HBM-bound launches):
+   * fdh_profile times of its horizontal and vertical pass, and the algorithmic bytes each must move -- H: region + halo rows
+   * read and written; V: the same rows read, the region written, plus the region read where the fused composite has to
+   * blend (not when the surface is known opaque: the pass then only stores) */
+  float ms_blur_big_h, ms_blur_big_v;
+  int64_t bytes_blur_big_h, bytes_blur_big_v;
 } FdhFrameStats;
-/* Run `times` more frames with hipEvents around every kernel launch and fill the per-kernel averages. */
+/* Run `times` more frames and fill the per-kernel averages.  Each launch is stamped with its own start / end events
+ * (hipExtLaunchKernelGGL): kernel execution time as rocprofv3 --kernel-trace reports it, no launch gaps in it. */
 FDH_API int fdh_profile(FdhContext*, int times);
 FDH_API int fdh_get_frame_stats(FdhContext*, FdhFrameStats* out);
 FDH_API int fdh_sizeof_fig(void);

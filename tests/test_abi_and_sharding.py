@@ -243,3 +243,36 @@ def test_blur_weight_fragments_blur_like_the_reference(radius):
     assert mx <= 1 and n0 <= 0.005 * src.shape[0] * src.shape[1], (radius, "vs oracle", mx, n0)
     mx, n0, n1 = diff_stats(got, load_png(f"ss_blur_r{radius:g}.png"))
     assert mx <= 2, (radius, "vs blur.frag on SwiftShader", mx, n0)
+
+
+def _run_bench_two_ranks(extra, port):
+    """bench.py's N > 1 path on a one-GPU box: two ranks on device 0, gloo for the process group (tensors go through host
+    memory; RCCL needs one GPU per rank)."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--all-ranks-on-device0", "--backend", "gloo"] + extra
+    procs = [subprocess.Popen(cmd, env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE) for r in range(2)]
+    outs = [p.communicate(timeout=900) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1].decode()[-2000:] for o in outs]
+    import json
+
+    return json.loads([ln for ln in outs[0][0].decode().splitlines() if ln.startswith("{")][-1])
+
+
+@pytest.mark.gpu
+def test_bench_stripes_mode_two_ranks_gathers_the_frame():
+    """BASELINE config 5's run mode (row stripes + gather inside the timed region) through bench.py itself: the image rank 0
+    assembles from the two ranks' stripes must be the oracle's frame."""
+    d = _run_bench_two_ranks(["--mode", "stripes", "--width", "1920", "--height", "1080", "--steps", "9", "--warmup", "2"], 29531)
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["mode"] == "stripes"
+    assert sum(d["config"]["rows_per_rank"]) == 1080
+    assert d["gathered_frame_check"]["parity_max_lsb"] <= 1 and d["gathered_frame_check"]["parity_pixels_differing"] < 0.005 * 1920 * 1080
+    assert d["value"] > 0 and d["gather_ms"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_frames_mode_two_ranks():
+    """bench.py's default N > 1 mode (frame-parallel, weak scaling) on two ranks."""
+    d = _run_bench_two_ranks(["--width", "1280", "--height", "720", "--steps", "8", "--warmup", "2", "--no-cpu-baseline"], 29533)
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak"
+    assert d["frames_in_flight_check"]["pixels_differing"] == 0
+    assert d["value"] > 0 and d["gather_ms"] > 0

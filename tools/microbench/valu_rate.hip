@@ -18,6 +18,11 @@ template <int MODE> __global__ __launch_bounds__(256) void k(float* out, float a
       if (MODE == 1) acc[i] = __builtin_elementwise_fma(acc[i], m, m);                                                      // 1 pk_fma, VGPR operands
       if (MODE == 2) acc[i] = __builtin_elementwise_fma(acc[i], ms, acc[i]);                                                // pk_fma with SGPR operand
       if (MODE == 3) { acc[i].x = __builtin_fmaf(acc[i].x, m.x, m.y); }                                                     // 1 scalar fma
+      if (MODE == 6) { acc[i].x = __builtin_amdgcn_exp2f(acc[i].x); }                                                       // v_exp_f32
+      if (MODE == 7) { acc[i].x = __builtin_amdgcn_rcpf(acc[i].x); }                                                        // v_rcp_f32
+      if (MODE == 8) { acc[i].x = __builtin_amdgcn_sqrtf(acc[i].x); }                                                       // v_sqrt_f32
+      if (MODE == 9) { acc[i].x = __builtin_fminf(acc[i].x, m.x); acc[i].y = acc[i].y > m.y ? acc[i].x : acc[i].y; }         // v_min_f32 + v_cmp + v_cndmask
+      if (MODE == 10) { acc[i].x = __builtin_rintf(acc[i].x + m.x); }                                                       // v_add_f32 + v_rndne_f32
     }
     if (MODE == 4) {  // the blur inner loop mix: one texel = 4 byte->float converts + 16 packed FMAs with uniform coefficients
       const unsigned t = __float_as_uint(acc[0].x) + it;
@@ -54,11 +59,17 @@ template <int MODE> double run(const char* name, double ops_per_iter_per_lane) {
   return ms;
 }
 int main() {
+  printf("# VALU issue rates on this GPU: ns (and cycles at 2.4 GHz) one wave64 instruction occupies a SIMD, 8 waves per SIMD, 8 independent chains per wave\n");
   run<0>("2x v_fma_f32", 2);
   run<1>("v_pk_fma_f32 (vgpr)", 1);
   run<2>("v_pk_fma_f32 (sgpr mult)", 1);
   run<3>("1x v_fma_f32", 1);
   run<4>("blur mix (4 cvt + 16 pk_fma)/8", 20.0 / 8);
   run<5>("cvt_ubyte + add", 2);
+  run<6>("v_exp_f32", 1);
+  run<7>("v_rcp_f32", 1);
+  run<8>("v_sqrt_f32", 1);
+  run<9>("v_min + v_cmp + v_cndmask", 3);
+  run<10>("v_add_f32 + v_rndne_f32", 2);
   return 0;
 }

@@ -5,7 +5,7 @@
 tag=${1:-rXX}
 root=$(pwd)
 export TMPDIR=/tmp
-for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
+for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_VALU_MFMA_BUSY_CYCLES"; do
   name=$(echo $set | cut -d' ' -f1)
   out=$root/gpurun_out/traffic_${tag}_$name
   mkdir -p $out
