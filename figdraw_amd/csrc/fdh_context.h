@@ -34,10 +34,12 @@ struct DeviceBuf {
   size_t cap = 0;
   void reserve(size_t n) {
     if (n <= cap) return;
-    if (ptr) FDH_HIP(hipFree(ptr));
     size_t want = cap ? cap : 256;
     while (want < n) want *= 2;
-    FDH_HIP(hipMalloc((void**)&ptr, want * sizeof(T)));
+    T* fresh = nullptr;  // allocate first: a failing hipMalloc (FDH_HIP throws) must leave ptr / cap describing a live block
+    FDH_HIP(hipMalloc((void**)&fresh, want * sizeof(T)));
+    if (ptr) (void)hipFree(ptr);
+    ptr = fresh;
     cap = want;
   }
   void release() {
@@ -53,10 +55,12 @@ struct PinnedBuf {
   size_t cap = 0;
   void reserve(size_t n) {
     if (n <= cap) return;
-    if (ptr) FDH_HIP(hipHostFree(ptr));
     size_t want = cap ? cap : 256;
     while (want < n) want *= 2;
-    FDH_HIP(hipHostMalloc((void**)&ptr, want * sizeof(T), hipHostMallocDefault));
+    T* fresh = nullptr;
+    FDH_HIP(hipHostMalloc((void**)&fresh, want * sizeof(T), hipHostMallocDefault));
+    if (ptr) (void)hipHostFree(ptr);
+    ptr = fresh;
     cap = want;
   }
   void release() {

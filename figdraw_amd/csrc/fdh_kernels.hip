@@ -2091,37 +2091,44 @@ template <int NOUT, int WAVES> static void launch_blur_v_n(hipStream_t s, const 
 #define FDH_BLUR_MX 1
 #endif
 // Blocks per wave: the smallest T for which every wave of the launch is resident at once.  A wave lives for the whole pass
-// (prologue + T blocks), so a second, partly filled round of waves costs a whole wave lifetime.  Slots per CU = LDS (a
-// ring of NK + 4 slots of 2 KB per wave) and at most 3 waves per SIMD (168 registers).  (4K, NK = 5: T = 4, 2040 waves for
-// 2048 slots; leaving a tenth of the slots free, T = 5, measured 1 us slower on the vertical pass.)
-static int mx_pick_t(int nk, long long outputs_along, long long lines) {
+// (prologue + T blocks), so a second, partly filled round of waves costs a whole wave lifetime.  Waves per CU = what the
+// runtime's occupancy query gives the instantiation with its LDS ring (NK + 4 slots of 2 KB per wave; registers: three waves
+// per SIMD for the narrow filters, two for the widest ones).  (4K, NK = 5: T = 4, 2040 waves for 2048 slots; leaving a
+// tenth of the slots free, T = 5, measured 1 us slower on the vertical pass.)
+static int mx_pick_t(long long per_cu, long long outputs_along, long long lines) {
   static const int forced = [] { const char* e = std::getenv("FDH_MX_T"); return e ? std::atoi(e) : 0; }();  // experiments
   if (forced) return forced;
-  const long long per_cu = std::min<long long>(12, 160 / ((nk + 4) * 2)), slots = 256 * per_cu;
+  const long long slots = 256 * per_cu;
   const long long along_blocks = (outputs_along + 31) / 32, line_groups = (lines + 31) / 32;
   for (int t = 1; t < 64; t++) if (line_groups * ((along_blocks + t - 1) / t) <= slots) return t;
   return 64;
 }
-template <int NK, bool kV> static void launch_blur_mx(hipStream_t s, const BlurParams& P, const DrawRec* draws, const QuadExt* exts, int t) {
+template <int NK, bool kV> static void launch_blur_mx(hipStream_t s, const BlurParams& P, const DrawRec* draws, const QuadExt* exts) {
+  const size_t lds = (size_t)(NK + 4) * kMxSlot * sizeof(uint32_t);
+  static const int per_cu = [lds] {  // single-wave workgroups resident per CU, asked once per instantiation
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_blur_mx<NK, kV>, 64, lds) != hipSuccess || n <= 0) n = std::min<int>(8, 160 / ((NK + 4) * 2));
+    return n;
+  }();
+  const int t = kV ? mx_pick_t(per_cu, P.y1 - P.y0, P.x1 - P.x0) : mx_pick_t(per_cu, P.x1 - P.x0, P.y1 - P.y0);
   const int a_lo = kV ? P.y0 : P.x0, a_hi = kV ? P.y1 : P.x1, l_lo = kV ? (P.x0 & ~31) : P.y0, l_hi = kV ? P.x1 : P.y1;
   const int total = ((a_hi - (a_lo & ~31) + 32 * t - 1) / (32 * t)) * ((l_hi - l_lo + 31) / 32);
-  FDH_LAUNCH((k_blur_mx<NK, kV>), dim3(8 * ((total + 7) / 8)), dim3(64), (size_t)(NK + 4) * kMxSlot * sizeof(uint32_t), s, P, draws, exts, t);
+  FDH_LAUNCH((k_blur_mx<NK, kV>), dim3(8 * ((total + 7) / 8)), dim3(64), lds, s, P, draws, exts, t);
 }
 template <bool kV> static bool launch_blur_mx_nk(hipStream_t s, const BlurParams& P, const DrawRec* draws, const QuadExt* exts) {
   // LDS-DMA moves 16-byte pieces: rows have to start on 16-byte boundaries
   if (!P.mx_w || (P.pitch & 3) || (reinterpret_cast<uintptr_t>(P.src) & 15) || P.W < 4) return false;
   const int nk = mx_nk(P.taps.reach, kV);
-  const int t = kV ? mx_pick_t(nk, P.y1 - P.y0, P.x1 - P.x0) : mx_pick_t(nk, P.x1 - P.x0, P.y1 - P.y0);
   switch (nk) {
-    case 3: launch_blur_mx<3, kV>(s, P, draws, exts, t); return true;
-    case 4: launch_blur_mx<4, kV>(s, P, draws, exts, t); return true;
-    case 5: launch_blur_mx<5, kV>(s, P, draws, exts, t); return true;
-    case 6: launch_blur_mx<6, kV>(s, P, draws, exts, t); return true;
-    case 7: launch_blur_mx<7, kV>(s, P, draws, exts, t); return true;
-    case 8: launch_blur_mx<8, kV>(s, P, draws, exts, t); return true;
-    case 9: launch_blur_mx<9, kV>(s, P, draws, exts, t); return true;
-    case 10: launch_blur_mx<10, kV>(s, P, draws, exts, t); return true;
-    case 11: launch_blur_mx<11, kV>(s, P, draws, exts, t); return true;  // reach 66 = the widest filter (radius clamp 64)
+    case 3: launch_blur_mx<3, kV>(s, P, draws, exts); return true;
+    case 4: launch_blur_mx<4, kV>(s, P, draws, exts); return true;
+    case 5: launch_blur_mx<5, kV>(s, P, draws, exts); return true;
+    case 6: launch_blur_mx<6, kV>(s, P, draws, exts); return true;
+    case 7: launch_blur_mx<7, kV>(s, P, draws, exts); return true;
+    case 8: launch_blur_mx<8, kV>(s, P, draws, exts); return true;
+    case 9: launch_blur_mx<9, kV>(s, P, draws, exts); return true;
+    case 10: launch_blur_mx<10, kV>(s, P, draws, exts); return true;
+    case 11: launch_blur_mx<11, kV>(s, P, draws, exts); return true;  // reach 66 = the widest filter (radius clamp 64)
     default: return false;
   }
 }

@@ -1,22 +1,77 @@
-import sys, os, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+#!/usr/bin/env python3
+"""GPU-box helper: every BASELINE.json config on the current build -- frame time (one frame at a time, replayed resident
+records), per-kernel times (fdh_profile: each launch's own timestamps), rate, and parity against the oracle (max LSB, pixels
+differing).  Prints one JSON document (-> profiles/<tag>_configs.json).
+
+usage: python3 tools/perf_configs.py [only]     only = 1..5 : run just that config (for a rocprofv3 --kernel-trace --stats pass per config)"""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
-from figdraw_amd.context import HipContext
-from figdraw_amd.scenes import make_render_tree_100, make_glyph_scene, load_glyph_fixture
+
 import ref_scenes as RS
-def run(name, ctx, sc, w, h, n=100):
-    t=time.perf_counter(); ctx.render_frame(sc, w, h); ctx.sync(); t1=time.perf_counter()-t
-    ctx.replay(10); ctx.replay(n); st=ctx.frame_stats(); ms=st.ms_total
-    ctx.profile(20); st=ctx.frame_stats()
-    print(f"{name}: {w}x{h} draws={st.n_draws} phases={st.n_phases} frame={ms*1e3:.1f} us -> {w*h/ms/1e3:.0f} Mpix/s; first-frame host {t1*1e3:.1f} ms; bin {st.ms_bin*1e3:.1f} comp {st.ms_composite*1e3:.1f} blur {1e3*(st.ms_blur_h+st.ms_blur_v):.1f} us")
-ctx=HipContext(device=0)
-run('cfg1 rgb_boxes_sdf', ctx, RS.rgb_boxes_sdf(800.,600.), 800, 600)
-run('cfg2 S100@1080p', ctx, make_render_tree_100(1920,1080,0), 1920, 1080)
-run('cfg3 S300@4K', ctx, make_render_tree_100(3840,2160,0,full_frame_blur=True), 3840, 2160)
-run('cfg5 S300@8K frame', ctx, make_render_tree_100(7680,4320,0,full_frame_blur=True), 7680, 4320, 30)
-ctx.close()
-imgs=load_glyph_fixture(os.path.join(ROOT, 'tests', 'golden', 'glyphs_ubuntu20.npz'))
-ctx=HipContext(atlas_size=1024, device=0)
-sc=make_glyph_scene(3840,2160,imgs)
-for k,v in RS.used_images(sc,imgs).items(): ctx.put_image(k,v)
-run('cfg4 T10k@4K', ctx, sc, 3840, 2160)
+from figdraw_amd.context import HipContext
+from figdraw_amd.scenes import load_glyph_fixture, make_glyph_scene, make_render_tree_100
+from oracle import oracle as O
+
+only = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+out = {}
+
+
+def run(key, what, ctx, sc, w, h, n=100, oracle_kw=None, images=None):
+    t = time.perf_counter()
+    ctx.render_frame(sc, w, h)
+    ctx.sync()
+    first = time.perf_counter() - t
+    got = ctx.read_pixels()
+    ctx.replay(10)
+    ctx.replay(n)
+    ms = ctx.frame_stats().ms_total
+    ctx.profile(20)
+    st = ctx.frame_stats()
+    e = {"workload": what, "width": w, "height": h, "draws": st.n_draws, "phases": st.n_phases, "blur_nodes": st.n_blurs,
+         "frame_us": round(1e3 * ms, 1), "mpixels_per_s": round(w * h / ms / 1e3, 0), "gfragments_per_s": round(st.fragments / ms / 1e6, 1),
+         "kernel_us": {"bin": round(1e3 * st.ms_bin, 1), "composite_phase0": round(1e3 * st.ms_composite_main, 1),
+                       "composite_all": round(1e3 * st.ms_composite, 1), "blur_h_all": round(1e3 * st.ms_blur_h, 1),
+                       "blur_v_all": round(1e3 * st.ms_blur_v, 1), "largest_blur_h": round(1e3 * st.ms_blur_big_h, 1),
+                       "largest_blur_v": round(1e3 * st.ms_blur_big_v, 1)},
+         "first_frame_host_ms": round(1e3 * first, 1)}
+    if not only:  # parity leg (the oracle takes seconds per frame; skipped under rocprofv3)
+        orc = O.Oracle(threads=min(os.cpu_count() or 1, 16), **(oracle_kw or {}))
+        for k in sorted(images or {}):
+            orc.put_image(k, images[k])
+        orc.render_frame(sc, w, h)
+        d = np.abs(got.astype(int) - orc.read_pixels().astype(int))
+        e["parity_vs_oracle"] = {"max_lsb": int(d.max()), "pixels_differing": int((d.max(axis=2) > 0).sum())}
+    out[key] = e
+
+
+if only in (0, 1, 2, 3, 5):
+    ctx = HipContext(device=0)
+    if only in (0, 1):
+        run("config1", "tests/trender_rgb_boxes_sdf.nim scene, 800x600 (4 nodes)", ctx, RS.rgb_boxes_sdf(800.0, 600.0), 800, 600)
+    if only in (0, 2):
+        run("config2", "S100@1080p: renderlist_100 (304 nodes) at 1920x1080", ctx, make_render_tree_100(1920, 1080, 0), 1920, 1080)
+    if only in (0, 3):
+        run("config3", "S300@4K: renderlist_100 + full-frame blur(18) at 3840x2160 (the bench frame)", ctx,
+            make_render_tree_100(3840, 2160, 0, full_frame_blur=True), 3840, 2160)
+    if only in (0, 5):
+        run("config5_one_frame", "one 7680x4320 frame of config 3's tree (the 8-frame, striped run: bench.py --mode stripes)", ctx,
+            make_render_tree_100(7680, 4320, 0, full_frame_blur=True), 7680, 4320, 30)
+    ctx.close()
+if only in (0, 4):
+    imgs = load_glyph_fixture(os.path.join(ROOT, "tests", "golden", "glyphs_ubuntu20.npz"))
+    ctx = HipContext(atlas_size=1024, device=0)
+    sc = make_glyph_scene(3840, 2160, imgs)
+    used = RS.used_images(sc, imgs)
+    for k in sorted(used):
+        ctx.put_image(k, used[k])
+    run("config4", "T10k@4K: 10 000 glyph quads (5 000 coverage + 5 000 MSDF) over a 3-stop gradient, 3840x2160", ctx, sc, 3840, 2160,
+        oracle_kw={"atlas_size": 1024}, images=used)
+    ctx.close()
+print(json.dumps(out, indent=1))
