@@ -2104,8 +2104,8 @@ static int mx_pick_t(long long per_cu, long long outputs_along, long long lines)
   return 64;
 }
 template <int NK, bool kV> static void launch_blur_mx(hipStream_t s, const BlurParams& P, const DrawRec* draws, const QuadExt* exts) {
-  const size_t lds = (size_t)(NK + 4) * kMxSlot * sizeof(uint32_t);
-  static const int per_cu = [lds] {  // single-wave workgroups resident per CU, asked once per instantiation
+  constexpr size_t lds = (size_t)(NK + 4) * kMxSlot * sizeof(uint32_t);
+  static const int per_cu = [] {  // single-wave workgroups resident per CU, asked once per instantiation
     int n = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_blur_mx<NK, kV>, 64, lds) != hipSuccess || n <= 0) n = std::min<int>(8, 160 / ((NK + 4) * 2));
     return n;
