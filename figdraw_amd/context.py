@@ -104,6 +104,13 @@ def load():
     L.fdh_atlas_packed_area.argtypes = [vp, C.POINTER(C.c_int64)]
     L.fdh_read_pixels.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]
     L.fdh_debug_read_surface.argtypes = [vp, C.c_int, vp]
+    L.fdh_scene_retain.argtypes = [vp, vp, C.c_float, C.c_float, C.c_int, _F4]
+    L.fdh_scene_update_nodes.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp]
+    L.fdh_scene_replace_root.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, vp]
+    L.fdh_scene_insert_root.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, vp]
+    L.fdh_scene_render.argtypes = [vp]
+    L.fdh_scene_stats.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    L.fdh_debug_record_digest.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.fdh_record_begin.argtypes = [vp]
     L.fdh_record_json.argtypes = [vp]
     L.fdh_record_json.restype = C.c_char_p
@@ -335,6 +342,51 @@ class HipContext:
         self._ck(self.L.fdh_set_ui_scale(self.h, ui_scale))
         self.W, self.H = int(w * ui_scale), int(h * ui_scale)
         self._ck(self.L.fdh_render_frame(self.h, cs.byref(), float(w), float(h), int(bool(clear)), _F4(*color)))
+
+    # ---- retained scenes (renderfragments.nim:426-544: the tree lives in the context, edits re-decompose only what they touch)
+    @staticmethod
+    def _marshal_nodes(figs):
+        """a node list -> (CScene keeping the arrays alive, pointer to its FdhFig array, count, pointer to the side-array scene)"""
+        tmp = S.Renders()
+        lst = S.RenderList()
+        lst.nodes = list(figs)
+        tmp.setLayer(0, lst)
+        cs = tmp.to_c()
+        return cs, C.cast(cs.struct.layers[0].nodes, C.c_void_p), len(lst.nodes), cs.byref()
+
+    def scene_retain(self, renders: S.Renders, w, h, clear=True, color=(1.0, 1.0, 1.0, 1.0), ui_scale=1.0):
+        cs = renders.to_c()
+        self._ck(self.L.fdh_set_ui_scale(self.h, ui_scale))
+        self.W, self.H = int(w * ui_scale), int(h * ui_scale)
+        self._ck(self.L.fdh_scene_retain(self.h, cs.byref(), float(w), float(h), int(bool(clear)), _F4(*color)))
+
+    def scene_update_nodes(self, layer: int, first: int, figs):
+        """overwrite nodes [first, first + len(figs)) of layer number `layer` (same tree shape, new properties)"""
+        cs, ptr, n, side = self._marshal_nodes(figs)
+        self._ck(self.L.fdh_scene_update_nodes(self.h, int(layer), int(first), n, ptr, side))
+
+    def scene_replace_root(self, layer: int, slot: int, figs):
+        """replace the subtree under root slot `slot`; figs[0] is the new root (parent -1), later parents are relative to figs;
+        an empty list removes the root"""
+        cs, ptr, n, side = self._marshal_nodes(figs)
+        self._ck(self.L.fdh_scene_replace_root(self.h, int(layer), int(slot), ptr if n else None, n, side))
+
+    def scene_insert_root(self, layer: int, slot: int, figs):
+        cs, ptr, n, side = self._marshal_nodes(figs)
+        self._ck(self.L.fdh_scene_insert_root(self.h, int(layer), int(slot), ptr if n else None, n, side))
+
+    def scene_render(self):
+        self._ck(self.L.fdh_scene_render(self.h))
+
+    def scene_stats(self):
+        a, b = C.c_int64(), C.c_int64()
+        self._ck(self.L.fdh_scene_stats(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def record_digest(self) -> int:
+        out = C.c_uint64()
+        self._ck(self.L.fdh_debug_record_digest(self.h, C.byref(out)))
+        return out.value
 
     def replay_calls(self, calls):
         """Replay a recorded BackendContext call stream (same format as the test harnesses use)."""

@@ -192,6 +192,34 @@ int fdh_render_frame(FdhContext* c, const FdhScene* scene, float fw, float fh, i
     C(c)->render_frame(scene, fw, fh, clear != 0, rgba ? rgba : white);
   });
 }
+int fdh_scene_retain(FdhContext* c, const FdhScene* scene, float fw, float fh, int clear, const float rgba[4]) {
+  return guard([&] {
+    const float white[4] = {1, 1, 1, 1};
+    C(c)->scene_retain(scene, fw, fh, clear != 0, rgba ? rgba : white);
+  });
+}
+int fdh_scene_update_nodes(FdhContext* c, int layer, int first, int count, const FdhFig* nodes, const FdhScene* side) {
+  return guard([&] { C(c)->scene_update_nodes(layer, first, count, nodes, side); });
+}
+int fdh_scene_replace_root(FdhContext* c, int layer, int slot, const FdhFig* subtree, int n, const FdhScene* side) {
+  return guard([&] { C(c)->scene_replace_root(layer, slot, subtree, n, side, false); });
+}
+int fdh_scene_insert_root(FdhContext* c, int layer, int slot, const FdhFig* subtree, int n, const FdhScene* side) {
+  return guard([&] { C(c)->scene_replace_root(layer, slot, subtree, n, side, true); });
+}
+int fdh_scene_render(FdhContext* c) { return guard([&] { C(c)->scene_render(); }); }
+int fdh_scene_stats(FdhContext* c, int64_t* walked, int64_t* reused) {
+  return guard([&] {
+    if (!walked || !reused) throw fdh::Error(FDH_ERR_INVALID, "null output");
+    C(c)->scene_stats(walked, reused);
+  });
+}
+int fdh_debug_record_digest(FdhContext* c, uint64_t* out) {
+  return guard([&] {
+    if (!out) throw fdh::Error(FDH_ERR_INVALID, "null output");
+    *out = C(c)->record_digest();
+  });
+}
 int fdh_set_stripe(FdhContext* c, int y0, int y1) { return guard([&] { C(c)->set_stripe(y0, y1); }); }
 int fdh_replay(FdhContext* c, int times) { return guard([&] { C(c)->replay(times); }); }
 int fdh_replay_async(FdhContext* c, int times) { return guard([&] { C(c)->replay_async(times); }); }

@@ -107,6 +107,7 @@ void Context::alloc_atlas(int size) {
   }
   heights_.assign((size_t)s, 0);
   entries_.clear();
+  atlas_epoch_++;  // cached draw records of image nodes carry atlas positions (RetainedRoot::atlas_epoch)
 }
 void Context::reset_atlas(int minimum_size) {
   sync();
@@ -179,6 +180,7 @@ void Context::put_image(int64_t key, int w, int h, const uint8_t* rgba, int out_
   int x, y;
   find_empty_rect(w, h, &x, &y);
   entries_[key] = AtlasEntry{x, y, w, h};
+  atlas_epoch_++;
   sync();  // a frame in flight may still sample the atlas
   put_levels(x, y, w, h, rgba);
   if (out_rect) { out_rect[0] = x; out_rect[1] = y; out_rect[2] = w; out_rect[3] = h; }
@@ -236,6 +238,7 @@ void Context::put_mips(int64_t key, int n, const int* ws, const int* hs, const u
   int rx = 0, ry = 0;
   find_empty_rect(ws[0], hs[0], &rx, &ry);
   entries_[key] = AtlasEntry{rx, ry, ws[0], hs[0]};
+  atlas_epoch_++;
   if (out_rect) { out_rect[0] = rx; out_rect[1] = ry; out_rect[2] = ws[0]; out_rect[3] = hs[0]; }
   sync();
   for (int l = 0; l < n && l < n_levels_; l++) upload_atlas_rect(l, rx >> l, ry >> l, ws[l], hs[l], premul_rgba[l]);
@@ -1393,6 +1396,17 @@ void Context::debug_read_surface(int which, uint8_t* out) {
   FDH_HIP(hipSetDevice(device_));
   FDH_HIP(hipStreamSynchronize(stream_));
   FDH_HIP(hipMemcpy(out, src, (size_t)W_ * H_ * 4, hipMemcpyDeviceToHost));
+}
+uint64_t Context::record_digest() const {
+  uint64_t h = 1469598103934665603ull;
+  auto mix = [&](const void* p, size_t n) { const uint8_t* b = static_cast<const uint8_t*>(p); for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 1099511628211ull; } };
+  const uint64_t n = recs_.size();
+  mix(&n, sizeof n);
+  for (const DrawRec& r : recs_) mix(&r, sizeof r);
+  for (const BBox& b : bboxes_) mix(&b, sizeof b);
+  for (const QuadExt& q : exts_) mix(&q, sizeof q);
+  for (const Phase& ph : phases_) { mix(&ph.first, sizeof ph.first); mix(&ph.count, sizeof ph.count); mix(&ph.blur, sizeof ph.blur); }
+  return h;
 }
 void Context::frame_device_ptr(void** p, int* w, int* h, int64_t* pitch_bytes) {
   need_device("frame_device_ptr");

@@ -87,6 +87,38 @@ struct BlurJob {
   BlurTaps taps;
 };
 
+// Retained scene (fdh_scene_*): the library-side half of the reference's RenderFragments (renderfragments.nim:426-544) --
+// a deep copy of the node tree plus, per root, the draw records its decomposition produced.  A frame re-decomposes only the
+// roots an update touched; every other root's records are spliced back from the cache.
+struct RetainedRoot {
+  std::vector<DrawRec> recs;
+  std::vector<BBox> bboxes;
+  std::vector<QuadExt> exts;     // of this root's records, DrawRec::ext relative to exts.front()
+  int64_t fragments = 0;
+  bool cacheable = false;        // no blur node inside (those split the frame into phases: re-walked every frame)
+  bool dirty = true;
+  uint64_t atlas_epoch = 0;      // image draws carry atlas positions: stale after the atlas was rebuilt
+};
+struct RetainedLayer {
+  int32_t zlevel = 0;
+  std::vector<FdhFig> nodes;
+  std::vector<int32_t> roots;
+  std::vector<RetainedRoot> cache;  // parallel to `roots`
+};
+struct RetainedScene {
+  bool valid = false;
+  float fw = 0, fh = 0, rgba[4] = {1, 1, 1, 1};
+  bool clear = true;
+  float ui_scale = 1.0f, aa = 0.0f;
+  std::vector<RetainedLayer> layers;
+  std::vector<FdhGlyph> glyphs;
+  std::vector<int64_t> variant_ids;  // [glyphs][FDH_GLYPH_VARIANT_STEPS] or empty
+  std::vector<FdhDrawOp> ops;
+  std::vector<float> controls;
+  std::vector<FdhTextRect> text_rects;
+  int64_t roots_walked = 0, roots_reused = 0;  // of the last fdh_scene_render
+};
+
 struct RectMaskEntry { int kind; };  // 1 = fast analytic, 2 = real mask (glcontext.nim:36-44)
 
 class Context {
@@ -136,7 +168,7 @@ class Context {
   void update_image(int64_t key, int w, int h, const uint8_t* rgba);
   void put_mips(int64_t key, int n, const int* ws, const int* hs, const uint8_t* const* premul_rgba, int out_rect[4]);
   void put_flippy(int64_t key, const uint8_t* data, size_t n, int out_rect[4]);
-  void remove_image(int64_t key) { entries_.erase(key); }
+  void remove_image(int64_t key) { entries_.erase(key); atlas_epoch_++; }
   bool has_image(int64_t key) const { return entries_.count(key) != 0; }
   void reset_atlas(int minimum_size);
   int atlas_size() const { return atlas_size_; }
@@ -156,6 +188,13 @@ class Context {
   void set_ui_scale(float s) { ui_scale_ = s; }
   float ui_scale() const { return ui_scale_; }
   void render_frame(const FdhScene* scene, float fw, float fh, bool clear, const float rgba[4]);
+  // retained scenes (fdh_frontend.cpp)
+  void scene_retain(const FdhScene* scene, float fw, float fh, bool clear, const float rgba[4]);
+  void scene_update_nodes(int layer, int first, int count, const FdhFig* nodes, const FdhScene* side);
+  void scene_replace_root(int layer, int slot, const FdhFig* subtree, int n, const FdhScene* side, bool insert);
+  void scene_render();
+  void scene_stats(int64_t* walked, int64_t* reused) const { *walked = retained_.roots_walked; *reused = retained_.roots_reused; }
+  uint64_t record_digest() const;  // FNV-1a over the last frame's draw records (diagnostic: works on record-only contexts)
 
   // multi-GPU / measurement
   void set_stripe(int y0, int y1) { stripe_y0_ = y0; stripe_y1_ = y1; }
@@ -218,6 +257,9 @@ class Context {
   uint32_t *fb_ = nullptr, *backdrop_ = nullptr, *blur_tmp_ = nullptr;
   uint32_t* dbg_snap_ = nullptr;
   int big_blur_ = -1;       // index of the frame's largest blur job (its passes are timed on their own)
+  RetainedScene retained_;
+  uint64_t atlas_epoch_ = 1;
+  void rebase_side(FdhFig* nodes, int n, const FdhScene* side);
   bool host_only_ = false;  // FDH_CREATE_RECORD_ONLY
   bool rec_on_ = false, rec_first_ = true;
   std::string rec_;  // FDH_DEBUG_SNAP=1 (diagnostic): the surface as phase 0 left it, copied in-stream

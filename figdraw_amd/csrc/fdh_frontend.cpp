@@ -562,4 +562,210 @@ void Context::render_frame(const FdhScene* scene, float fw, float fh, bool clear
   end_frame();
 }
 
+// ------------------------------------------------------------------ retained scenes (renderfragments.nim:426-544, common/transfer.nim)
+// The reference keeps a base `Renders` and lets the application insert / append / replace fragments of it between frames
+// (insertChildren, addChildren, insertRoot, updateFragment :523); its renderer still walks the whole tree every frame.  Here
+// the tree lives in the context: fdh_scene_retain copies it, fdh_scene_update_nodes / fdh_scene_replace_root / fdh_scene_insert_root
+// edit it, and fdh_scene_render re-decomposes only the roots an edit touched -- the draw records of every other root are
+// spliced back from the per-root cache (a memcpy), so a frame after a small edit costs the launches, not a tree walk.
+void Context::rebase_side(FdhFig* nodes, int n, const FdhScene* side) {
+  // the new nodes index glyph / op / control / text-rect arrays of `side`: append what they use to the retained arrays
+  RetainedScene& R = retained_;
+  for (int i = 0; i < n; i++) {
+    FdhFig& f = nodes[i];
+    if (f.glyph_count > 0) {
+      if (!side || !side->glyphs || f.glyph_first < 0 || f.glyph_first + f.glyph_count > side->n_glyphs) throw Error(FDH_ERR_INVALID, "scene update: glyph range outside the side arrays");
+      const int base = (int)R.glyphs.size();
+      R.glyphs.insert(R.glyphs.end(), side->glyphs + f.glyph_first, side->glyphs + f.glyph_first + f.glyph_count);
+      if (!R.variant_ids.empty() || side->glyph_variant_ids) {
+        R.variant_ids.resize((size_t)base * FDH_GLYPH_VARIANT_STEPS, 0);
+        for (int g = 0; g < f.glyph_count; g++)
+          for (int st = 0; st < FDH_GLYPH_VARIANT_STEPS; st++)
+            R.variant_ids.push_back(side->glyph_variant_ids ? side->glyph_variant_ids[(size_t)(f.glyph_first + g) * FDH_GLYPH_VARIANT_STEPS + st] : side->glyphs[f.glyph_first + g].image_id);
+      }
+      f.glyph_first = base;
+    }
+    if (f.text_rect_count > 0) {
+      if (!side || !side->text_rects || f.text_rect_first < 0 || f.text_rect_first + f.text_rect_count > side->n_text_rects) throw Error(FDH_ERR_INVALID, "scene update: text-rect range outside the side arrays");
+      const int base = (int)R.text_rects.size();
+      R.text_rects.insert(R.text_rects.end(), side->text_rects + f.text_rect_first, side->text_rects + f.text_rect_first + f.text_rect_count);
+      f.text_rect_first = base;
+    }
+    if (f.op_count > 0) {
+      if (!side || !side->ops || f.op_first < 0 || f.op_first + f.op_count > side->n_ops) throw Error(FDH_ERR_INVALID, "scene update: drawable-op range outside the side arrays");
+      const int base = (int)R.ops.size();
+      for (int k = 0; k < f.op_count; k++) {
+        FdhDrawOp op = side->ops[f.op_first + k];
+        if (op.ctrl_count > 0) {
+          if (!side->controls || op.ctrl_first < 0 || op.ctrl_first + op.ctrl_count > side->n_controls) throw Error(FDH_ERR_INVALID, "scene update: control-point range outside the side arrays");
+          const int cb = (int)(R.controls.size() / 2);
+          R.controls.insert(R.controls.end(), side->controls + 2 * op.ctrl_first, side->controls + 2 * (op.ctrl_first + op.ctrl_count));
+          op.ctrl_first = cb;
+        }
+        R.ops.push_back(op);
+      }
+      f.op_first = base;
+    }
+  }
+}
+
+void Context::scene_retain(const FdhScene* scene, float fw, float fh, bool clear, const float rgba[4]) {
+  if (!scene) throw Error(FDH_ERR_INVALID, "scene_retain: null scene");
+  RetainedScene& R = retained_;
+  R = RetainedScene{};
+  R.fw = fw; R.fh = fh; R.clear = clear;
+  for (int i = 0; i < 4; i++) R.rgba[i] = rgba[i];
+  if (scene->glyphs && scene->n_glyphs > 0) R.glyphs.assign(scene->glyphs, scene->glyphs + scene->n_glyphs);
+  if (scene->glyph_variant_ids && scene->n_glyphs > 0) R.variant_ids.assign(scene->glyph_variant_ids, scene->glyph_variant_ids + (size_t)scene->n_glyphs * FDH_GLYPH_VARIANT_STEPS);
+  if (scene->ops && scene->n_ops > 0) R.ops.assign(scene->ops, scene->ops + scene->n_ops);
+  if (scene->controls && scene->n_controls > 0) R.controls.assign(scene->controls, scene->controls + 2 * (size_t)scene->n_controls);
+  if (scene->text_rects && scene->n_text_rects > 0) R.text_rects.assign(scene->text_rects, scene->text_rects + scene->n_text_rects);
+  R.layers.resize((size_t)std::max(scene->n_layers, 0));
+  for (int l = 0; l < scene->n_layers; l++) {
+    const FdhLayer& L = scene->layers[l];
+    RetainedLayer& D = R.layers[(size_t)l];
+    D.zlevel = L.zlevel;
+    if (L.n_nodes > 0) D.nodes.assign(L.nodes, L.nodes + L.n_nodes);
+    if (L.n_roots > 0) D.roots.assign(L.root_ids, L.root_ids + L.n_roots);
+    for (int r : D.roots) if (r < 0 || r >= L.n_nodes) throw Error(FDH_ERR_INVALID, "scene_retain: root index out of range");
+    D.cache.assign(D.roots.size(), RetainedRoot{});
+  }
+  R.valid = true;
+  scene_render();
+}
+
+// the root (index into the layer's nodes) each node hangs under; parents precede their children in a RenderList (fignodes.nim:119-163)
+static std::vector<int> roots_of(const RetainedLayer& D) {
+  std::vector<int> ro(D.nodes.size());
+  for (size_t i = 0; i < D.nodes.size(); i++) {
+    const int p = D.nodes[i].parent;
+    ro[i] = (p < 0 || (size_t)p >= i) ? (int)i : ro[(size_t)p];
+  }
+  return ro;
+}
+
+void Context::scene_update_nodes(int layer, int first, int count, const FdhFig* nodes, const FdhScene* side) {
+  RetainedScene& R = retained_;
+  if (!R.valid) throw Error(FDH_ERR_INVALID, "scene_update_nodes: no retained scene (fdh_scene_retain first)");
+  if (layer < 0 || (size_t)layer >= R.layers.size()) throw Error(FDH_ERR_INVALID, "scene_update_nodes: layer out of range");
+  RetainedLayer& D = R.layers[(size_t)layer];
+  if (count <= 0) return;
+  if (!nodes || first < 0 || (size_t)first + (size_t)count > D.nodes.size()) throw Error(FDH_ERR_INVALID, "scene_update_nodes: node range out of bounds");
+  // the roots above the range before the edit (a node may change its parent) ...
+  std::vector<int> before = roots_of(D);
+  std::vector<FdhFig> fresh(nodes, nodes + count);
+  rebase_side(fresh.data(), count, side);
+  std::copy(fresh.begin(), fresh.end(), D.nodes.begin() + first);
+  std::vector<int> after = roots_of(D);  // ... and after it
+  for (size_t s = 0; s < D.roots.size(); s++)
+    for (int i = first; i < first + count; i++)
+      if (before[(size_t)i] == D.roots[s] || after[(size_t)i] == D.roots[s]) { D.cache[s].dirty = true; break; }
+}
+
+void Context::scene_replace_root(int layer, int slot, const FdhFig* subtree, int n, const FdhScene* side, bool insert) {
+  RetainedScene& R = retained_;
+  if (!R.valid) throw Error(FDH_ERR_INVALID, "scene_replace_root: no retained scene (fdh_scene_retain first)");
+  if (layer < 0 || (size_t)layer >= R.layers.size()) throw Error(FDH_ERR_INVALID, "scene_replace_root: layer out of range");
+  RetainedLayer& D = R.layers[(size_t)layer];
+  if (slot < 0 || (size_t)slot > D.roots.size() || (!insert && (size_t)slot == D.roots.size())) throw Error(FDH_ERR_INVALID, "scene_replace_root: root slot out of range");
+  if (n < 0 || (n > 0 && !subtree)) throw Error(FDH_ERR_INVALID, "scene_replace_root: bad subtree");
+  if (n > 0 && subtree[0].parent >= 0) throw Error(FDH_ERR_INVALID, "scene_replace_root: the subtree's first node must be its root (parent -1)");
+  for (int i = 1; i < n; i++)
+    if (subtree[i].parent < 0 || subtree[i].parent >= i) throw Error(FDH_ERR_INVALID, "scene_replace_root: subtree parents must precede their children");
+  if (D.nodes.size() + (size_t)n > 32767u + (insert ? 0u : 32767u)) {}  // (checked after the removal below)
+  if (!insert) {  // drop the old subtree, compacting the node array
+    const std::vector<int> ro = roots_of(D);
+    const int old_root = D.roots[(size_t)slot];
+    std::vector<int> remap(D.nodes.size(), -1);
+    std::vector<FdhFig> kept;
+    kept.reserve(D.nodes.size());
+    for (size_t i = 0; i < D.nodes.size(); i++)
+      if (ro[i] != old_root) { remap[i] = (int)kept.size(); kept.push_back(D.nodes[i]); }
+    for (FdhFig& f : kept) if (f.parent >= 0) f.parent = remap[(size_t)f.parent];
+    for (size_t s = 0; s < D.roots.size(); s++) if ((int)s != slot) D.roots[s] = remap[(size_t)D.roots[s]];
+    D.nodes.swap(kept);
+    if (n == 0) { D.roots.erase(D.roots.begin() + slot); D.cache.erase(D.cache.begin() + slot); return; }
+  } else {
+    if (n == 0) return;
+    D.roots.insert(D.roots.begin() + slot, 0);
+    D.cache.insert(D.cache.begin() + slot, RetainedRoot{});
+  }
+  if (D.nodes.size() + (size_t)n > 32767u) throw Error(FDH_ERR_INVALID, "scene_replace_root: more than 32767 nodes in a layer (FigIdx is int16, fignodes.nim:119)");
+  const int base = (int)D.nodes.size();
+  std::vector<FdhFig> fresh(subtree, subtree + n);
+  rebase_side(fresh.data(), n, side);
+  for (int i = 1; i < n; i++) fresh[(size_t)i].parent += base;
+  D.nodes.insert(D.nodes.end(), fresh.begin(), fresh.end());
+  D.roots[(size_t)slot] = base;
+  D.cache[(size_t)slot] = RetainedRoot{};
+}
+
+void Context::scene_render() {
+  RetainedScene& R = retained_;
+  if (!R.valid) throw Error(FDH_ERR_INVALID, "scene_render: no retained scene (fdh_scene_retain first)");
+  const float w = R.fw * ui_scale_, h = R.fh * ui_scale_;
+  if (w <= 0.0f || h <= 0.0f) return;
+  const bool config_changed = R.ui_scale != ui_scale_ || R.aa != aa_;  // every cached record depends on these
+  R.ui_scale = ui_scale_; R.aa = aa_;
+  std::vector<FdhLayer> views(R.layers.size());
+  for (size_t l = 0; l < R.layers.size(); l++) {
+    RetainedLayer& D = R.layers[l];
+    views[l] = FdhLayer{D.zlevel, (int32_t)D.nodes.size(), (int32_t)D.roots.size(), 0, D.nodes.data(), D.roots.data()};
+  }
+  FdhScene view{};
+  view.layers = views.data(); view.n_layers = (int32_t)views.size();
+  view.glyphs = R.glyphs.data(); view.n_glyphs = (int32_t)R.glyphs.size();
+  view.glyph_variant_ids = R.variant_ids.empty() ? nullptr : R.variant_ids.data();
+  view.ops = R.ops.data(); view.n_ops = (int32_t)R.ops.size();
+  view.controls = R.controls.data(); view.n_controls = (int32_t)(R.controls.size() / 2);
+  view.text_rects = R.text_rects.data(); view.n_text_rects = (int32_t)R.text_rects.size();
+  R.roots_walked = R.roots_reused = 0;
+  begin_frame((int)w, (int)h, R.clear, R.rgba);
+  try {
+    save_transform();
+    scale(pixel_scale_, pixel_scale_);
+    Walker wk{*this, view, ui_scale_};
+    for (size_t l = 0; l < R.layers.size(); l++) {
+      RetainedLayer& D = R.layers[l];
+      for (size_t s = 0; s < D.roots.size(); s++) {
+        RetainedRoot& C = D.cache[s];
+        if (!C.dirty && C.cacheable && !config_changed && C.atlas_epoch == atlas_epoch_) {
+          // splice the cached records back: extension indices move with the frame's extension array
+          const uint32_t e0 = (uint32_t)exts_.size();
+          const size_t r0 = recs_.size();
+          recs_.insert(recs_.end(), C.recs.begin(), C.recs.end());
+          bboxes_.insert(bboxes_.end(), C.bboxes.begin(), C.bboxes.end());
+          exts_.insert(exts_.end(), C.exts.begin(), C.exts.end());
+          if (!C.exts.empty())
+            for (size_t i = r0; i < recs_.size(); i++) if (recs_[i].op_mode & F_GENERAL) recs_[i].ext += e0;
+          phases_.back().count += (int)C.recs.size();
+          fragments_ += C.fragments;
+          R.roots_reused++;
+          continue;
+        }
+        const size_t r0 = recs_.size(), e0 = exts_.size(), p0 = phases_.size(), b0 = blurs_.size();
+        const int64_t f0 = fragments_;
+        wk.node(views[l], D.roots[s]);
+        R.roots_walked++;
+        C.dirty = false;
+        C.atlas_epoch = atlas_epoch_;
+        C.cacheable = phases_.size() == p0 && blurs_.size() == b0;
+        C.recs.clear(); C.bboxes.clear(); C.exts.clear();
+        if (C.cacheable) {
+          C.recs.assign(recs_.begin() + (std::ptrdiff_t)r0, recs_.end());
+          C.bboxes.assign(bboxes_.begin() + (std::ptrdiff_t)r0, bboxes_.end());
+          C.exts.assign(exts_.begin() + (std::ptrdiff_t)e0, exts_.end());
+          for (DrawRec& r : C.recs) if (r.op_mode & F_GENERAL) r.ext -= (uint32_t)e0;
+          C.fragments = fragments_ - f0;
+        }
+      }
+    }
+    restore_transform();
+  } catch (...) {
+    frame_begun_ = false;
+    throw;
+  }
+  end_frame();
+}
+
 }  // namespace fdh

@@ -254,6 +254,32 @@ FDH_API int fdh_sync(FdhContext*);
 FDH_API int fdh_set_ui_scale(FdhContext*, float s); /* common/shared.nim:69-98 */
 FDH_API int fdh_render_frame(FdhContext*, const FdhScene*, float frame_w, float frame_h, int clear_main, const float clear_rgba[4]);
 
+/* ------------------------------------------------------------------ retained scenes (renderfragments.nim:426-544, common/transfer.nim:44-191)
+ * The reference lets an application keep a base `Renders` and insert / append / replace fragments of it between frames
+ * (insertChildren :426, addChildren :457, insertRoot, updateFragment :523) and ships such updates across threads
+ * (transfer.nim); its renderer re-walks the whole tree every frame.  Here the tree lives in the context:
+ *   fdh_scene_retain        copy `scene` into the context (nodes, roots, glyph / op / control / text-rect arrays), render it
+ *   fdh_scene_update_nodes  overwrite nodes [first, first + count) of a layer -- same tree shape, new properties (the
+ *                           animation case; = updateFragment with a fragment of unchanged shape)
+ *   fdh_scene_replace_root  replace the whole subtree under root slot `slot` by `subtree` (n nodes, node 0 its root with
+ *                           parent -1, later nodes' parents relative to the subtree); n = 0 removes the root
+ *   fdh_scene_insert_root   insert a new root subtree in front of root slot `slot` (slot = number of roots: append)
+ *   fdh_scene_render        render the retained scene: only roots an update touched (and roots holding a blur node) are
+ *                           decomposed again; the draw records of every other root are spliced back from a per-root cache
+ * `side` carries the glyph / drawable-op / control-point / text-rect arrays the NEW nodes index (NULL when they use none);
+ * the ranges are re-based into the context's own arrays.  Results are identical, record for record, to fdh_render_frame of
+ * the edited tree (tests/test_retained_scene.py). */
+FDH_API int fdh_scene_retain(FdhContext*, const FdhScene* scene, float frame_w, float frame_h, int clear_main, const float clear_rgba[4]);
+FDH_API int fdh_scene_update_nodes(FdhContext*, int layer, int first, int count, const FdhFig* nodes, const FdhScene* side);
+FDH_API int fdh_scene_replace_root(FdhContext*, int layer, int slot, const FdhFig* subtree, int n, const FdhScene* side);
+FDH_API int fdh_scene_insert_root(FdhContext*, int layer, int slot, const FdhFig* subtree, int n, const FdhScene* side);
+FDH_API int fdh_scene_render(FdhContext*);
+/* roots decomposed / roots reused from the cache by the last fdh_scene_render */
+FDH_API int fdh_scene_stats(FdhContext*, int64_t* roots_walked, int64_t* roots_reused);
+/* Diagnostic: FNV-1a digest of the draw records, bounds, quad extensions and phase table of the last frame (also on
+ * FDH_CREATE_RECORD_ONLY contexts): two frames with equal digests hand the kernels identical input. */
+FDH_API int fdh_debug_record_digest(FdhContext*, uint64_t* out);
+
 /* ------------------------------------------------------------------ multi-GPU / measurement hooks (no reference counterpart) */
 /* Restrict rasterisation to rows [y0, y1) of the frame (row-stripe sharding).  Rows outside the
  * stripe are left untouched; blur halos are rendered redundantly so no exchange is needed.  y1 <= y0 disables it. */
