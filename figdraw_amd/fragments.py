@@ -3,9 +3,12 @@ physically unchanged while independently replaceable sub-trees (fragments) are i
 
 The renderer traverses it through `roots(lvl)` / `children(cursor)` (renderfragments.nim:277-313); `flatten()` runs
 exactly that traversal and emits a plain `Renders`, which is what `HipContext.render_frame` / the oracle consume -- the
-draw stream is the one `figrender.render` produces for the fragment tree.  (SURVEY.md 8f #3 also imagines device-side
-draw lists with sub-range replacement; re-walking and re-uploading the whole tree costs ~35 us of host time and the
-per-frame path is GPU-bound, DESIGN.md 1, so the fragment tree is flattened per frame instead.)
+draw stream is the one `figrender.render` produces for the fragment tree.
+
+The device-side half (persistent draw lists with sub-range replacement) is `DeviceFragments` below: it keeps
+the flattened tree RETAINED in a HipContext (fdh_scene_*, include/figdraw_hip.h) and turns what changed between two frames
+-- an updateFragment, an inserted or removed root -- into fdh_scene_replace_root / insert_root calls, so the library
+re-decomposes only those roots and splices every other root's draw records from its cache.
 """
 from __future__ import annotations
 
@@ -320,3 +323,61 @@ class RenderFragments:  # :27-31
                 emit(r, -1)
             out.layers[lvl] = lst
         return out
+
+
+class DeviceFragments:
+    """A RenderFragments tree kept retained in a HipContext: `render(w, h)` sends only the roots that changed since the last
+    call (per layer: a diff of the roots' contents), then renders.  Same pixels / same draw records as
+    `ctx.render_frame(fragments.flatten(), w, h)`."""
+
+    def __init__(self, ctx, fragments: "RenderFragments"):
+        self.ctx = ctx
+        self.fragments = fragments
+        self._roots = None  # per layer: [(digest, subtree)] as last sent
+        self._size = None
+
+    @staticmethod
+    def _subtrees(lst: RenderList):
+        root_of = []
+        for i, n in enumerate(lst.nodes):
+            root_of.append(i if n.parent < 0 else root_of[n.parent])
+        members = {r: [] for r in lst.rootIds}
+        for i, r in enumerate(root_of):
+            if r in members:
+                members[r].append(i)
+        out = []
+        for r in lst.rootIds:
+            idx = members[r]
+            pos = {g: k for k, g in enumerate(idx)}
+            sub = []
+            for g in idx:
+                f = copy.copy(lst.nodes[g])
+                f.parent = -1 if g == r else pos[f.parent]
+                sub.append(f)
+            out.append((repr(sub), sub))  # (the dataclass repr covers every field: a content key)
+        return out
+
+    def render(self, w, h, **kw):
+        import difflib
+
+        flat = self.fragments.flatten()
+        now = [self._subtrees(lst) for lst in flat.layers.values()]
+        if self._roots is None or self._size != (w, h) or len(now) != len(self._roots):
+            self.ctx.scene_retain(flat, w, h, **kw)
+        else:
+            for layer, (old, new) in enumerate(zip(self._roots, now)):
+                sm = difflib.SequenceMatcher(a=[k for k, _ in old], b=[k for k, _ in new], autojunk=False)
+                shift = 0  # slots already inserted / removed in front of the current opcode
+                for tag, i0, i1, j0, j1 in sm.get_opcodes():
+                    if tag == "equal":
+                        continue
+                    n_old, n_new = i1 - i0, j1 - j0
+                    for k in range(min(n_old, n_new)):
+                        self.ctx.scene_replace_root(layer, i0 + shift + k, new[j0 + k][1])
+                    for k in range(n_new, n_old):  # surplus old roots go
+                        self.ctx.scene_replace_root(layer, i0 + shift + n_new, [])
+                    for k in range(n_old, n_new):  # surplus new roots come
+                        self.ctx.scene_insert_root(layer, i0 + shift + k, new[j0 + k][1])
+                    shift += n_new - n_old
+            self.ctx.scene_render()
+        self._roots, self._size = now, (w, h)

@@ -154,3 +154,61 @@ def test_flatten_renders_the_same_pixels_as_the_equivalent_plain_tree():
     a.render_frame(plain, 96, 64)
     b.render_frame(fr.flatten(), 96, 64)
     assert np.array_equal(a.read_pixels(), b.read_pixels())
+
+
+def test_device_fragments_send_only_what_changed():
+    """DeviceFragments: the fragment tree retained in a context (record-only here: no GPU).  After every fragment operation the
+    retained frame's draw records equal those of a full render of fragments.flatten(), and only the touched roots were walked."""
+    import random
+
+    from figdraw_amd.context import HipContext
+    from figdraw_amd.fragments import DeviceFragments, RenderFragments
+    from figdraw_amd.scene import Fig, FigKind, RenderList, Renders, rect, rgba
+
+    rnd = random.Random(3)
+    w, h = 400, 300
+
+    def box(i, n=0):
+        return Fig(kind=FigKind.nkRectangle, screenBox=rect(10 + 13 * (i % 20), 8 + 11 * (i // 20) + n, 40 + i % 7, 30), fill=rgba(20 * (i % 12), 255 - 9 * (i % 25), 40 + i, 255),
+                   corners=[i % 9] * 4)
+
+    base = Renders()
+    lst = RenderList()
+    parents = [lst.addRoot(box(i)) for i in range(24)]
+    base.setLayer(0, lst)
+    fr = RenderFragments(base)
+    cursors = []
+    for i in (3, 9, 17):  # three fragments hanging under base roots
+        child = RenderList()
+        r = child.addRoot(box(100 + i))
+        child.addChild(r, box(200 + i))
+        cursors += fr.insertChildren(0, parents[i], child, 0)
+    ctx = HipContext(record_only=True)
+    dev = DeviceFragments(ctx, fr)
+
+    def check(max_walked):
+        dev.render(w, h)
+        ref = HipContext(record_only=True)
+        ref.render_frame(fr.flatten(), w, h)
+        assert ctx.record_digest() == ref.record_digest()
+        ref.close()
+        walked, reused = ctx.scene_stats()
+        assert walked <= max_walked, (walked, reused)
+
+    check(10 ** 6)  # first frame: everything
+    check(0)        # nothing changed: nothing walked
+    for step in range(10):
+        if cursors and step % 2 == 0:  # updateFragment: one fragment's contents change -> one base root re-decomposed
+            upd = RenderList()
+            r = upd.addRoot(box(300 + step, n=step))
+            for k in range(rnd.randrange(0, 3)):
+                upd.addChild(r, box(400 + 10 * step + k))
+            cur = cursors[rnd.randrange(len(cursors))]
+            new = fr.updateFragment(cur, upd)
+            cursors = [c for c in cursors if c != cur] + list(new or [])
+            check(1)
+        else:  # a new root in the base tree
+            fr.insertRoot(0, box(500 + step), rnd.randrange(0, 5))
+            # (cursors into the base layer shift with it: RenderFragments keeps them valid itself)
+            check(2)
+    ctx.close()
