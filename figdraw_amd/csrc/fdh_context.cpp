@@ -470,7 +470,14 @@ static void set_saturated_core(DrawRec& r, float w_px, float h_px) {
   if (inset) { xl += r.p2; xr += r.p2; yb -= r.p3; yt -= r.p3; }  // the shadow shape sits at (p2, -p3) in the quad's frame
   if (!(xr > xl && yt > yb)) return;
   // local -> pixel centres: cx = ox + w_px * (x / (2 qhx) + 0.5), cy = oy + h_px * (0.5 - y / (2 qhy))
-  const double slack = 1.0;
+  // slack: what float rounding in the kernels' coordinate arithmetic can move a pixel centre against the level set (~2e-3 px at
+  // 4K, 8e-3 at 16K), with room.  (It was a whole pixel: a quad ending on the frame edge -- the full-frame backdrop blur -- then
+  // kept its outermost pixel ring out of the core although the coverage is exactly 1 there (centre 0.5 px inside, threshold
+  // 0.5 / aa = 0.417): every block on the frame border took the vertical blur pass's slow path.)
+#ifndef FDH_CORE_SLACK
+#define FDH_CORE_SLACK (1.0 / 16.0)
+#endif
+  const double slack = FDH_CORE_SLACK;
   const double cxl = r.ox + w_px * (xl / (2.0 * qhx) + 0.5) + slack, cxr = r.ox + w_px * (xr / (2.0 * qhx) + 0.5) - slack;
   const double cyt = r.oy + h_px * (0.5 - yt / (2.0 * qhy)) + slack, cyb = r.oy + h_px * (0.5 - yb / (2.0 * qhy)) - slack;
   double ix0 = std::ceil(cxl - 0.5), ix1 = std::floor(cxr - 0.5) + 1.0, iy0 = std::ceil(cyt - 0.5), iy1 = std::floor(cyb - 0.5) + 1.0;
