@@ -102,6 +102,8 @@ def load():
     L.fdh_reset_atlas.argtypes = [vp, C.c_int]
     L.fdh_atlas_size.argtypes = [vp, C.POINTER(C.c_int)]
     L.fdh_atlas_packed_area.argtypes = [vp, C.POINTER(C.c_int64)]
+    L.fdh_put_glyph_outline.argtypes = [vp, C.c_int64, C.c_int, C.c_int, vp, C.c_int, C.c_uint32, C.c_int * 4]
+    L.fdh_put_glyph_image.argtypes = [vp, C.c_int64, C.c_int, C.c_int, vp, C.c_uint32, C.c_int * 4]
     L.fdh_read_pixels.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]
     L.fdh_debug_read_surface.argtypes = [vp, C.c_int, vp]
     L.fdh_scene_retain.argtypes = [vp, vp, C.c_float, C.c_float, C.c_int, _F4]
@@ -264,6 +266,20 @@ class HipContext:
         rgba = np.ascontiguousarray(rgba, dtype=np.uint8)
         out = (C.c_int * 4)()
         self._ck(self.L.fdh_put_image(self.h, int(key), rgba.shape[1], rgba.shape[0], rgba.ctypes.data, out))
+        return tuple(out)
+
+    def put_glyph_outline(self, key, segs: np.ndarray, w: int, h: int, lcd_filter: bool = False):
+        """rasterise a glyph outline (n x 6: x0, y0, cx, cy, x1, y1; cx = NaN for a line) on the device into the atlas"""
+        segs = np.ascontiguousarray(segs, dtype=np.float32).reshape(-1, 6)
+        out = (C.c_int * 4)()
+        self._ck(self.L.fdh_put_glyph_outline(self.h, int(key), int(w), int(h), segs.ctypes.data, len(segs), 1 if lcd_filter else 0, out))
+        return tuple(out)
+
+    def put_glyph_image(self, key, rgba: np.ndarray, lcd_filter: bool = False):
+        """a rasterised glyph, processed on the device on its way into the atlas (LCD filter, mip chain): pixie_raster.nim:12-95"""
+        rgba = np.ascontiguousarray(rgba, dtype=np.uint8)
+        out = (C.c_int * 4)()
+        self._ck(self.L.fdh_put_glyph_image(self.h, int(key), rgba.shape[1], rgba.shape[0], rgba.ctypes.data, 1 if lcd_filter else 0, out))
         return tuple(out)
 
     def put_image_mips(self, key, mips):

@@ -147,6 +147,12 @@ int fdh_set_text_subpixel_shift(FdhContext* c, float s) { return guard([&] { C(c
 int fdh_put_image(FdhContext* c, int64_t key, int w, int h, const uint8_t* rgba, int out_rect[4]) {
   return guard([&] { C(c)->put_image(key, w, h, rgba, out_rect); });
 }
+int fdh_put_glyph_image(FdhContext* c, int64_t key, int w, int h, const uint8_t* rgba, uint32_t flags, int out_rect[4]) {
+  return guard([&] { C(c)->put_glyph_image(key, w, h, rgba, flags, out_rect); });
+}
+int fdh_put_glyph_outline(FdhContext* c, int64_t key, int w, int h, const float* segs, int n, uint32_t flags, int out_rect[4]) {
+  return guard([&] { C(c)->put_glyph_outline(key, w, h, segs, n, flags, out_rect); });
+}
 int fdh_put_image_mips(FdhContext* c, int64_t key, int n_levels, const int* widths, const int* heights,
                        const uint8_t* const* premul_rgba8, int out_rect[4]) {
   return guard([&] { C(c)->put_mips(key, n_levels, widths, heights, premul_rgba8, out_rect); });

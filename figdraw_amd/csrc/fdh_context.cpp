@@ -185,6 +185,88 @@ void Context::put_image(int64_t key, int w, int h, const uint8_t* rgba, int out_
   put_levels(x, y, w, h, rgba);
   if (out_rect) { out_rect[0] = x; out_rect[1] = y; out_rect[2] = w; out_rect[3] = h; }
 }
+// A rasterised glyph on its way into the atlas, processed on the device: optional LCD filter (applyLcdFilter, common/
+// textrasters/pixie_raster.nim:12-43, what renderPixieGlyph does between fillText and loadGlyphImage :83-91), then the
+// level chain of updateSubImage (textures.nim:106-119) -- every step a kernel on the context's stream.
+void Context::put_glyph_image(int64_t key, int w, int h, const uint8_t* rgba, uint32_t flags, int out_rect[4]) {
+  if (w <= 0 || h <= 0 || !rgba) throw Error(FDH_ERR_INVALID, "put_glyph_image: empty image");
+  if (flags & ~(uint32_t)FDH_GLYPH_LCD_FILTER) throw Error(FDH_ERR_INVALID, "put_glyph_image: unknown flag");
+  int x, y;
+  find_empty_rect(w, h, &x, &y);
+  entries_[key] = AtlasEntry{x, y, w, h};
+  atlas_epoch_++;
+  if (out_rect) { out_rect[0] = x; out_rect[1] = y; out_rect[2] = w; out_rect[3] = h; }
+  if (host_only_) return;
+  FDH_HIP(hipSetDevice(device_));
+  sync();  // a frame in flight may still sample the atlas
+  const size_t n = (size_t)w * h;
+  glyph_a_.reserve(n);
+  glyph_b_.reserve(n);
+  FDH_HIP(hipMemcpyAsync(glyph_a_.ptr, rgba, n * 4, hipMemcpyHostToDevice, stream_));
+  glyph_to_atlas(glyph_a_.ptr, glyph_b_.ptr, w, h, x, y, flags);
+}
+// device image -> (LCD filter) -> atlas level chain, all on the context's stream; waits for it (the caller's buffers are free after)
+void Context::glyph_to_atlas(uint32_t* cur, uint32_t* nxt, int w, int h, int x, int y, uint32_t flags) {
+  if (flags & FDH_GLYPH_LCD_FILTER) { launch_lcd_filter(stream_, cur, nxt, w, h); std::swap(cur, nxt); }
+  int cw = w, ch = h, lx = x, ly = y, level = 0;
+  while (cw > 1 && ch > 1 && level < n_levels_) {
+    launch_atlas_blit(stream_, atlas_levels_[level], atlas_size_ >> level, lx, ly, cur, cw, ch);
+    const int nw = cw / 2, nh = ch / 2;
+    launch_minify2(stream_, cur, nxt, cw, nw, nh);
+    std::swap(cur, nxt);
+    cw = nw; ch = nh; lx /= 2; ly /= 2; level++;
+  }
+  FDH_HIP(hipStreamSynchronize(stream_));
+  FDH_HIP(hipGetLastError());
+}
+
+// generateGlyph's job (common/fontglyphs.nim:61-106) with an own rasteriser in pixie's place: a glyph OUTLINE (quadratic segments in
+// pixel units of the w x h image, y down; cx = NaN marks a straight line) becomes coverage on the device and goes into the atlas.
+// The curves are flattened here on the host (chord error <= 0.025 px; the same float formula as oracle/figdraw_oracle.c,
+// fo_flatten_outline), the area accumulation runs in k_rasterize_lines.  pixie's texels are third-party and unpinned
+// (SURVEY.md 8c): parity is defined against the oracle's restatement of the same published algorithm.
+static int flatten_count(const float* q) {
+  const float ddx = q[0] - 2.0f * q[2] + q[4], ddy = q[1] - 2.0f * q[3] + q[5];
+  const float dev = std::sqrt(ddx * ddx + ddy * ddy);
+  const int n = (int)std::ceil(std::sqrt(dev * 10.0f));  // error of n chords = dev / (4 n^2) <= 0.025 px
+  return n < 1 ? 1 : (n > 64 ? 64 : n);
+}
+void Context::put_glyph_outline(int64_t key, int w, int h, const float* segs, int n, uint32_t flags, int out_rect[4]) {
+  if (w <= 0 || h <= 0 || w > 4096 || h > 4096) throw Error(FDH_ERR_INVALID, "put_glyph_outline: image size must be in 1..4096");
+  if (n < 0 || (n > 0 && !segs)) throw Error(FDH_ERR_INVALID, "put_glyph_outline: bad outline");
+  if (flags & ~(uint32_t)FDH_GLYPH_LCD_FILTER) throw Error(FDH_ERR_INVALID, "put_glyph_outline: unknown flag");
+  std::vector<float> lines;
+  lines.reserve((size_t)n * 16);
+  for (int i = 0; i < n; i++) {
+    const float* q = segs + 6 * (size_t)i;
+    if (q[2] != q[2]) { lines.insert(lines.end(), {q[0], q[1], q[4], q[5]}); continue; }
+    const int k = flatten_count(q);
+    float px = q[0], py = q[1];
+    for (int j = 1; j <= k; j++) {
+      const float t = (float)j / (float)k, u = 1.0f - t;
+      const float x = j == k ? q[4] : (u * u) * q[0] + (2.0f * u * t) * q[2] + (t * t) * q[4];
+      const float y = j == k ? q[5] : (u * u) * q[1] + (2.0f * u * t) * q[3] + (t * t) * q[5];
+      lines.insert(lines.end(), {px, py, x, y});
+      px = x; py = y;
+    }
+  }
+  int x, y;
+  find_empty_rect(w, h, &x, &y);
+  entries_[key] = AtlasEntry{x, y, w, h};
+  atlas_epoch_++;
+  if (out_rect) { out_rect[0] = x; out_rect[1] = y; out_rect[2] = w; out_rect[3] = h; }
+  if (host_only_) return;
+  FDH_HIP(hipSetDevice(device_));
+  sync();
+  const size_t npx = (size_t)w * h, m = lines.size() / 4;
+  glyph_a_.reserve(npx);
+  glyph_b_.reserve(npx);
+  glyph_lines_.reserve(std::max<size_t>(lines.size(), 4));
+  glyph_acc_.reserve((size_t)h * (w + 2));
+  if (m) FDH_HIP(hipMemcpyAsync(glyph_lines_.ptr, lines.data(), lines.size() * sizeof(float), hipMemcpyHostToDevice, stream_));
+  launch_rasterize_lines(stream_, reinterpret_cast<const float4*>(glyph_lines_.ptr), (int)m, w, h, glyph_acc_.ptr, glyph_a_.ptr);
+  glyph_to_atlas(glyph_a_.ptr, glyph_b_.ptr, w, h, x, y, flags);  // (synchronises: `lines` stays alive until then)
+}
 // Flippy: figdraw's mip-mapped image container (common/formatflippy.nim:77-149).  Layout: "flip", u32 version (1), then per
 // mip level "mip!", u32 width, u32 height, u32 zlen, and a raw-snappy block holding straight RGBA8.  The reference
 // converts every texel to pixie's premultiplied ColorRGBX on load and uploads level l at (x >> l, y >> l)

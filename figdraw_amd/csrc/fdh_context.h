@@ -165,6 +165,8 @@ class Context {
 
   // atlas
   void put_image(int64_t key, int w, int h, const uint8_t* rgba, int out_rect[4]);
+  void put_glyph_image(int64_t key, int w, int h, const uint8_t* rgba, uint32_t flags, int out_rect[4]);
+  void put_glyph_outline(int64_t key, int w, int h, const float* segs, int n, uint32_t flags, int out_rect[4]);
   void update_image(int64_t key, int w, int h, const uint8_t* rgba);
   void put_mips(int64_t key, int n, const int* ws, const int* hs, const uint8_t* const* premul_rgba, int out_rect[4]);
   void put_flippy(int64_t key, const uint8_t* data, size_t n, int out_rect[4]);
@@ -257,6 +259,9 @@ class Context {
   uint32_t *fb_ = nullptr, *backdrop_ = nullptr, *blur_tmp_ = nullptr;
   uint32_t* dbg_snap_ = nullptr;
   int big_blur_ = -1;       // index of the frame's largest blur job (its passes are timed on their own)
+  void glyph_to_atlas(uint32_t* cur, uint32_t* nxt, int w, int h, int x, int y, uint32_t flags);
+  DeviceBuf<float> glyph_lines_, glyph_acc_;
+  DeviceBuf<uint32_t> glyph_a_, glyph_b_;  // put_glyph_image: the raster and its filtered / minified successors
   RetainedScene retained_;
   uint64_t atlas_epoch_ = 1;
   void rebase_side(FdhFig* nodes, int n, const FdhScene* side);

@@ -61,6 +61,12 @@ void launch_composite(hipStream_t s, const DrawRec* draws, const QuadExt* exts, 
 void launch_blur_h(hipStream_t s, const BlurParams& P);
 void launch_blur_v(hipStream_t s, const BlurParams& P, const DrawRec* draws, const QuadExt* exts);
 void launch_fill(hipStream_t s, uint32_t* p, uint32_t v, size_t n);
+// glyph images: LCD filter (pixie_raster.nim:12-43), one minifyBy2 step, copy into an atlas level
+// glyph outline (flattened to lines x0, y0, x1, y1) -> premultiplied white coverage; scratch: h x (w + 2) floats
+void launch_rasterize_lines(hipStream_t s, const float4* lines, int n, int w, int h, float* scratch, uint32_t* out);
+void launch_lcd_filter(hipStream_t s, const uint32_t* src, uint32_t* dst, int w, int h);
+void launch_minify2(hipStream_t s, const uint32_t* src, uint32_t* dst, int sw, int nw, int nh);
+void launch_atlas_blit(hipStream_t s, uint32_t* level, int LS, int x, int y, const uint32_t* src, int w, int h);
 void launch_upload(hipStream_t s, void* dst, const void* src_mapped, size_t bytes);  // src: device view of pinned host memory
 
 }  // namespace fdh

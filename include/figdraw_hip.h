@@ -229,6 +229,20 @@ FDH_API int fdh_set_text_subpixel_glyph_variants(FdhContext*, int enabled); /* t
  * The shim derives the UV entry as rect / atlasSize (glcontext.nim:584).  The atlas doubles when full (:536-539),
  * which invalidates every earlier entry exactly as in the reference (resetImageAtlas :634-641). */
 FDH_API int fdh_put_image(FdhContext*, int64_t key, int width, int height, const uint8_t* rgba8, int out_rect[4]);
+/* A freshly rasterised glyph (what renderPixieGlyph hands to loadGlyphImage, common/textrasters/pixie_raster.nim:45-95), processed
+ * on the device: with FDH_GLYPH_LCD_FILTER FreeType's default 5-tap LCD filter is applied first -- applyLcdFilter :12-43:
+ * weights 8, 77, 86, 77, 8 over x-2 .. x+2, columns clamped to the image, per channel (sum + 128) >> 8 -- then the image and
+ * its minifyBy2 chain go into the atlas like fdh_put_image's.  Integer arithmetic, bit-exact with the reference's. */
+enum { FDH_GLYPH_LCD_FILTER = 1 };
+FDH_API int fdh_put_glyph_image(FdhContext*, int64_t key, int width, int height, const uint8_t* rgba8, uint32_t flags, int out_rect[4]);
+/* A glyph OUTLINE rasterised on the device into the atlas -- generateGlyph's job (common/fontglyphs.nim:61-106; the reference calls
+ * pixie's fillText for it, common/textrasters/pixie_raster.nim:83-87).  segs: n x 6 floats {x0, y0, cx, cy, x1, y1} in pixel units of
+ * the width x height glyph image, y down: quadratic Bezier segments with control point (cx, cy), or straight lines when cx is
+ * NaN; contours closed, non-zero winding.  Sub-pixel variants are the same outline shifted by variant / steps in x
+ * (pixie_raster.nim:69-72).  Coverage = exact-area scanline accumulation (curves flattened to <= 0.025 px chord error), stored
+ * premultiplied white like pixie's white paint; flags as for fdh_put_glyph_image.  pixie's own texels are third-party and
+ * unpinned: the oracle restates the same published algorithm and the two agree bit for bit. */
+FDH_API int fdh_put_glyph_outline(FdhContext*, int64_t key, int width, int height, const float* segs, int n_segs, uint32_t flags, int out_rect[4]);
 /* putFlippy (glcontext.nim:610-620): `bytes` is a whole .flippy file (common/formatflippy.nim:77-149: "flip", version 1, then per
  * mip "mip!", w, h, zlen, raw-snappy straight RGBA8); every stored level is uploaded as is at (x >> l, y >> l). */
 FDH_API int fdh_put_image_mips(FdhContext*, int64_t key, int n_levels, const int* widths, const int* heights,

@@ -853,6 +853,146 @@ static int place_rect(FoCtx* c, int64_t key, int w, int h, int* ox, int* oy) { /
   *ox = rx; *oy = ry;
   return 0;
 }
+/* ------------------------------------------------------------------ glyph outlines -> coverage
+ * The reference rasterises glyphs with pixie (`image.fillText`, common/textrasters/pixie_raster.nim:83-87): third-party code that is
+ * not under /root/reference, so the TEXELS it produces are unpinned.  What is restated here is the published
+ * exact-area scanline accumulation every modern font rasteriser uses (font-rs / stb_truetype v2 / pixie's own fill): each
+ * outline segment adds its signed area to the cells of the pixel rows it crosses, a running sum along the row turns areas
+ * into coverage, non-zero winding via |sum| clamped to 1.  Output = what pixie hands to putImage for white paint:
+ * premultiplied white, coverage in all four channels.
+ *   segs: n x 6 floats {x0, y0, cx, cy, x1, y1} in pixel units of the w x h image, y down; a quadratic Bezier with control
+ *   point (cx, cy), or a straight line when cx is NaN.  Contours must be closed (each ends where it started). */
+static int flatten_count(const float* q) { /* segments for a quadratic so that the chord error stays under 0.025 px */
+  float ddx = q[0] - 2.0f * q[2] + q[4], ddy = q[1] - 2.0f * q[3] + q[5];
+  float dev = sqrtf(ddx * ddx + ddy * ddy);
+  int n = (int)ceilf(sqrtf(dev * 10.0f)); /* error of n chords = dev / (4 n^2) <= 0.025 px */
+  return n < 1 ? 1 : (n > 64 ? 64 : n);
+}
+int fo_flatten_outline(const float* segs, int n, float* lines /* 4 floats each */, int cap) {
+  int m = 0;
+  for (int i = 0; i < n; i++) {
+    const float* q = segs + 6 * i;
+    if (q[2] != q[2]) { /* NaN: a line */
+      if (m < cap) { lines[4 * m] = q[0]; lines[4 * m + 1] = q[1]; lines[4 * m + 2] = q[4]; lines[4 * m + 3] = q[5]; }
+      m++;
+      continue;
+    }
+    int k = flatten_count(q);
+    float px = q[0], py = q[1];
+    for (int j = 1; j <= k; j++) {
+      float t = (float)j / (float)k, u = 1.0f - t;
+      float x = j == k ? q[4] : (u * u) * q[0] + (2.0f * u * t) * q[2] + (t * t) * q[4];
+      float y = j == k ? q[5] : (u * u) * q[1] + (2.0f * u * t) * q[3] + (t * t) * q[5];
+      if (m < cap) { lines[4 * m] = px; lines[4 * m + 1] = py; lines[4 * m + 2] = x; lines[4 * m + 3] = y; }
+      m++;
+      px = x; py = y;
+    }
+  }
+  return m;
+}
+/* one pixel row of the accumulation: the part of line (x0,y0)-(x1,y1) inside rows [y, y + 1) adds to acc[0 .. w] */
+static void raster_row_line(float* acc, int w, int y, float x0, float y0, float x1, float y1) {
+  if (y0 == y1) return;
+  float dir = 1.0f;
+  if (y0 > y1) { float t = x0; x0 = x1; x1 = t; t = y0; y0 = y1; y1 = t; dir = -1.0f; }
+  float ya = y0 > (float)y ? y0 : (float)y, yb = y1 < (float)(y + 1) ? y1 : (float)(y + 1);
+  if (!(yb > ya)) return;
+  float dxdy = (x1 - x0) / (y1 - y0);
+  float xa = x0 + (ya - y0) * dxdy, xb = x0 + (yb - y0) * dxdy;
+  float d = (yb - ya) * dir;
+  float xl = xa < xb ? xa : xb, xr = xa < xb ? xb : xa;
+  /* cells left of the image take everything at cell 0 (full coverage to their right), cells right of it nothing */
+  if (xl < 0.0f) xl = 0.0f;
+  if (xr < 0.0f) xr = 0.0f;
+  if (xl > (float)w) xl = (float)w;
+  if (xr > (float)w) xr = (float)w;
+  float x0floor = floorf(xl);
+  int x0i = (int)x0floor;
+  float x1ceil = ceilf(xr);
+  int x1i = (int)x1ceil;
+  if (x1i <= x0i + 1) {
+    float xmf = 0.5f * (xl + xr) - x0floor;
+    acc[x0i] += d - d * xmf;
+    if (x0i + 1 <= w) acc[x0i + 1] += d * xmf;
+  } else {
+    float s = 1.0f / (xr - xl);
+    float x0f = xl - x0floor;
+    float a0 = 0.5f * s * (1.0f - x0f) * (1.0f - x0f);
+    float x1f = xr - x1ceil + 1.0f;
+    float am = 0.5f * s * x1f * x1f;
+    acc[x0i] += d * a0;
+    if (x1i == x0i + 2) {
+      acc[x0i + 1] += d * (1.0f - a0 - am);
+    } else {
+      float a1 = s * (1.5f - x0f);
+      acc[x0i + 1] += d * (a1 - a0);
+      for (int xi = x0i + 2; xi < x1i - 1; xi++) acc[xi] += d * s;
+      float a2 = a1 + (float)(x1i - x0i - 3) * s;
+      acc[x1i - 1] += d * (1.0f - a2 - am);
+    }
+    if (x1i <= w) acc[x1i] += d * am;
+  }
+}
+void fo_rasterize_lines(const float* lines, int n, int w, int h, uint8_t* out_rgba) {
+  float* acc = (float*)malloc((size_t)(w + 2) * sizeof(float));
+  for (int y = 0; y < h; y++) {
+    for (int x = 0; x < w + 2; x++) acc[x] = 0.0f;
+    for (int i = 0; i < n; i++) raster_row_line(acc, w, y, lines[4 * i], lines[4 * i + 1], lines[4 * i + 2], lines[4 * i + 3]);
+    float sum = 0.0f;
+    for (int x = 0; x < w; x++) {
+      sum += acc[x];
+      float c = fabsf(sum);
+      if (c > 1.0f) c = 1.0f;
+      uint8_t v = (uint8_t)(c * 255.0f + 0.5f);
+      uint8_t* p = out_rgba + ((size_t)y * w + x) * 4;
+      p[0] = p[1] = p[2] = p[3] = v;
+    }
+  }
+  free(acc);
+}
+int fo_rasterize_outline(const float* segs, int n, int w, int h, uint8_t* out_rgba) {
+  int m = fo_flatten_outline(segs, n, NULL, 0);
+  float* lines = (float*)malloc((size_t)(m > 0 ? m : 1) * 4 * sizeof(float));
+  fo_flatten_outline(segs, n, lines, m);
+  fo_rasterize_lines(lines, m, w, h, out_rgba);
+  free(lines);
+  return m;
+}
+int fo_put_glyph_image(FoCtx* c, int64_t key, int w, int h, const uint8_t* rgba, unsigned flags, int out_rect[4]);
+/* generateGlyph's job (common/fontglyphs.nim:61-106) with the rasteriser above in pixie's place: outline -> coverage -> (LCD) -> atlas */
+int fo_put_glyph_outline(FoCtx* c, int64_t key, int w, int h, const float* segs, int n, unsigned flags, int out_rect[4]) {
+  uint8_t* img = (uint8_t*)malloc((size_t)w * h * 4);
+  fo_rasterize_outline(segs, n, w, h, img);
+  int rc = fo_put_glyph_image(c, key, w, h, img, flags, out_rect);
+  free(img);
+  return rc;
+}
+
+/* applyLcdFilter: common/textrasters/pixie_raster.nim:12-43 (FreeType's default 5-tap LCD filter, horizontal, columns clamped) */
+void fo_lcd_filter(const uint8_t* src, uint8_t* dst, int w, int h) {
+  static const int wt[5] = {8, 77, 86, 77, 8};
+  int maxx = w - 1;
+  for (int y = 0; y < h; y++)
+    for (int x = 0; x < w; x++) {
+      int sum[4] = {0, 0, 0, 0};
+      for (int i = 0; i < 5; i++) {
+        int sx = x + i - 2;
+        sx = sx < 0 ? 0 : (sx > maxx ? maxx : sx);
+        const uint8_t* p = src + ((size_t)y * w + sx) * 4;
+        for (int k = 0; k < 4; k++) sum[k] += (int)p[k] * wt[i];
+      }
+      for (int k = 0; k < 4; k++) dst[((size_t)y * w + x) * 4 + k] = (uint8_t)((sum[k] + 128) >> 8);
+    }
+}
+/* renderPixieGlyph's tail (pixie_raster.nim:83-91): optional LCD filter, then loadGlyphImage -> putImage */
+int fo_put_glyph_image(FoCtx* c, int64_t key, int w, int h, const uint8_t* rgba, unsigned flags, int out_rect[4]) {
+  if (!(flags & 1u)) return fo_put_image(c, key, w, h, rgba, out_rect);
+  uint8_t* f = (uint8_t*)malloc((size_t)w * h * 4);
+  fo_lcd_filter(rgba, f, w, h);
+  int rc = fo_put_image(c, key, w, h, f, out_rect);
+  free(f);
+  return rc;
+}
 int fo_put_image(FoCtx* c, int64_t key, int w, int h, const uint8_t* rgba, int out_rect[4]) {
   int S = c->atlas_size, rx, ry;
   if (place_rect(c, key, w, h, &rx, &ry) != 0) return -1;

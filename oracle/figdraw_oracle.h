@@ -164,6 +164,14 @@ void fo_pop_mask(FoCtx*);
 void fo_begin_rect_mask(FoCtx*, const float rect[4], const float radii_x[4], const float radii_y[4]);
 void fo_pop_rect_mask(FoCtx*);
 int fo_put_image(FoCtx*, int64_t key, int w, int h, const uint8_t* rgba, int out_rect[4]);
+/* glyph outlines -> premultiplied white coverage (exact-area accumulation; pixie's texels themselves are unpinned) */
+int fo_flatten_outline(const float* segs, int n, float* lines, int cap);
+void fo_rasterize_lines(const float* lines, int n, int w, int h, uint8_t* out_rgba);
+int fo_rasterize_outline(const float* segs, int n, int w, int h, uint8_t* out_rgba);
+int fo_put_glyph_outline(FoCtx*, int64_t key, int w, int h, const float* segs, int n, unsigned flags, int out_rect[4]);
+/* applyLcdFilter (common/textrasters/pixie_raster.nim:12-43) and the glyph upload with it (flags bit 0) */
+void fo_lcd_filter(const uint8_t* src, uint8_t* dst, int w, int h);
+int fo_put_glyph_image(FoCtx*, int64_t key, int w, int h, const uint8_t* rgba, unsigned flags, int out_rect[4]);
 int fo_put_flippy(FoCtx*, int64_t key, const uint8_t* file_bytes, size_t n, int out_rect[4]); /* putFlippy glcontext.nim:610-620 */
 void fo_set_text_subpixel(FoCtx*, int enabled, float shift);
 void fo_set_text_subpixel_glyph_variants(FoCtx*, int enabled);

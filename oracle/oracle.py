@@ -65,6 +65,11 @@ def lib():
         L.fo_pop_mask.argtypes = [C.c_void_p]
         L.fo_begin_rect_mask.argtypes = [C.c_void_p, _F4, _F4, _F4]
         L.fo_pop_rect_mask.argtypes = [C.c_void_p]
+        L.fo_put_glyph_outline.restype = C.c_int
+        L.fo_put_glyph_outline.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_uint, C.c_int * 4]
+        L.fo_put_glyph_image.restype = C.c_int
+        L.fo_put_glyph_image.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_uint, C.c_int * 4]
+        L.fo_lcd_filter.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
         L.fo_put_image.restype = C.c_int
         L.fo_put_image.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_int * 4]
         L.fo_put_flippy.restype = C.c_int
@@ -195,6 +200,22 @@ class Oracle:
             raise RuntimeError("oracle atlas full")
         return tuple(out)
 
+    def put_glyph_outline(self, key, segs: np.ndarray, w: int, h: int, lcd_filter: bool = False):
+        segs = np.ascontiguousarray(segs, dtype=np.float32).reshape(-1, 6)
+        out = (C.c_int * 4)()
+        rc = self.L.fo_put_glyph_outline(self.h, int(key), int(w), int(h), segs.ctypes.data, len(segs), 1 if lcd_filter else 0, out)
+        if rc != 0:
+            raise RuntimeError("oracle atlas full")
+        return tuple(out)
+
+    def put_glyph_image(self, key, rgba: np.ndarray, lcd_filter: bool = False):
+        rgba = np.ascontiguousarray(rgba, dtype=np.uint8)
+        out = (C.c_int * 4)()
+        rc = self.L.fo_put_glyph_image(self.h, int(key), rgba.shape[1], rgba.shape[0], rgba.ctypes.data, 1 if lcd_filter else 0, out)
+        if rc != 0:
+            raise RuntimeError("oracle atlas full")
+        return tuple(out)
+
     def set_text_subpixel(self, enabled: bool, shift: float = 0.0, glyph_variants: bool = False):
         self.L.fo_set_text_subpixel(self.h, int(bool(enabled)), float(shift))
         self.L.fo_set_text_subpixel_glyph_variants(self.h, int(bool(glyph_variants)))
@@ -261,4 +282,24 @@ def blur_image(rgba: np.ndarray, radius: float) -> np.ndarray:
     rgba = np.ascontiguousarray(rgba, dtype=np.uint8)
     out = np.zeros_like(rgba)
     lib().fo_blur_image(rgba.shape[1], rgba.shape[0], rgba.ctypes.data, out.ctypes.data, radius)
+    return out
+
+
+def lcd_filter(rgba: np.ndarray) -> np.ndarray:
+    """applyLcdFilter (common/textrasters/pixie_raster.nim:12-43) on an (h, w, 4) uint8 image"""
+    rgba = np.ascontiguousarray(rgba, dtype=np.uint8)
+    out = np.zeros_like(rgba)
+    lib().fo_lcd_filter.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    lib().fo_lcd_filter(rgba.ctypes.data, out.ctypes.data, rgba.shape[1], rgba.shape[0])
+    return out
+
+
+def rasterize_outline(segs: np.ndarray, w: int, h: int) -> np.ndarray:
+    """glyph outline (n x 6: x0, y0, cx, cy, x1, y1; cx = NaN for a line; pixel units, y down) -> (h, w, 4) premultiplied white coverage"""
+    segs = np.ascontiguousarray(segs, dtype=np.float32).reshape(-1, 6)
+    out = np.zeros((h, w, 4), np.uint8)
+    L = lib()
+    L.fo_rasterize_outline.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    L.fo_rasterize_outline.restype = C.c_int
+    L.fo_rasterize_outline(segs.ctypes.data, len(segs), w, h, out.ctypes.data)
     return out
