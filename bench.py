@@ -335,9 +335,9 @@ def main():
         walked, reused = ctx.scene_stats()
         dynamic["retained"] = {"ms_per_frame": round(1e3 * tr / n_dyn, 4), "mpixels_per_s": round(w * h * n_dyn / tr / 1e6, 1),
                                "host_record_us": round(1e3 * sr.ms_host_record, 1), "host_launch_us": round(1e3 * sr.ms_host_launch, 1),
-                               "roots_walked": walked, "roots_reused": reused,
+                               "roots_walked": walked, "roots_reused": reused, "uploaded_bytes_per_frame": ctx.last_upload_bytes(),
                                "note": "fdh_scene_update_nodes (one of 304 roots moves) + fdh_scene_render per frame: the edited root is decomposed again, "
-                                       "the others' draw records come from the per-root cache; records are re-uploaded whole (90 KB)"}
+                                       "the others' draw records come from the per-root cache; only the 256-byte chunks of the record block that changed are uploaded"}
         ctx.render_frame(scene, w, h)  # back to the benchmark frame for the gather / parity legs below
         ctx.sync()
 

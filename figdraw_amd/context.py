@@ -113,6 +113,7 @@ def load():
     L.fdh_scene_render.argtypes = [vp]
     L.fdh_scene_stats.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.fdh_debug_record_digest.argtypes = [vp, C.POINTER(C.c_uint64)]
+    L.fdh_last_upload_bytes.argtypes = [vp, C.POINTER(C.c_int64)]
     L.fdh_record_begin.argtypes = [vp]
     L.fdh_record_json.argtypes = [vp]
     L.fdh_record_json.restype = C.c_char_p
@@ -398,6 +399,11 @@ class HipContext:
         a, b = C.c_int64(), C.c_int64()
         self._ck(self.L.fdh_scene_stats(self.h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def last_upload_bytes(self) -> int:
+        out = C.c_int64()
+        self._ck(self.L.fdh_last_upload_bytes(self.h, C.byref(out)))
+        return out.value
 
     def record_digest(self) -> int:
         out = C.c_uint64()

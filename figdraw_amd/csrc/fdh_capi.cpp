@@ -214,6 +214,12 @@ int fdh_scene_insert_root(FdhContext* c, int layer, int slot, const FdhFig* subt
   return guard([&] { C(c)->scene_replace_root(layer, slot, subtree, n, side, true); });
 }
 int fdh_scene_render(FdhContext* c) { return guard([&] { C(c)->scene_render(); }); }
+int fdh_last_upload_bytes(FdhContext* c, int64_t* out) {
+  return guard([&] {
+    if (!out) throw fdh::Error(FDH_ERR_INVALID, "null output");
+    *out = C(c)->uploaded_bytes();
+  });
+}
 int fdh_scene_stats(FdhContext* c, int64_t* walked, int64_t* reused) {
   return guard([&] {
     if (!walked || !reused) throw fdh::Error(FDH_ERR_INVALID, "null output");

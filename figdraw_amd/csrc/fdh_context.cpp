@@ -1250,7 +1250,38 @@ void Context::submit(bool upload) {
       if (o_mxh[i]) { build_mx_weights(blurs_[i].taps, false, s + o_mxh[i]); build_mx_weights(blurs_[i].taps, true, s + o_mxv[i]); }
     void* s_dev = nullptr;
     FDH_HIP(hipHostGetDevicePointer(&s_dev, s, 0));
-    launch_upload(stream_, d_frame_.ptr, s_dev, total);  // whole 16-byte groups: both sides are padded to 256 B
+    // Only what differs from the block the device already holds travels: after an edit of a retained scene (or between two
+    // frames of an animation) that is a few hundred bytes of records, bounds and bin boxes out of ~110 KB.  The comparison runs
+    // against a host shadow of the device block in 256-byte chunks; up to kUploadRuns runs go out in ONE launch.
+    std::vector<size_t> layout{total, o_recs, o_ext, o_bb, o_box, o_chunk, o_pf};
+    for (size_t i = 0; i < blurs_.size(); i++) { layout.push_back(o_mxh[i]); layout.push_back(o_mxv[i]); }
+    bool patched = false;
+    if (shadow_dev_ == d_frame_.ptr && shadow_layout_ == layout && shadow_.size() == total) {
+      UploadRuns R{};
+      size_t dirty = 0;
+      bool fits = true;
+      for (size_t at = 0; at < total && fits; at += 256) {
+        const size_t len = std::min<size_t>(256, total - at);
+        if (std::memcmp(shadow_.data() + at, s + at, len) == 0) continue;
+        dirty += len;
+        if (R.n > 0 && (size_t)(R.off16[R.n - 1] + R.len16[R.n - 1]) * 16 == at) R.len16[R.n - 1] += (uint32_t)((len + 15) / 16);
+        else if (R.n < (uint32_t)kUploadRuns) { R.off16[R.n] = (uint32_t)(at / 16); R.len16[R.n] = (uint32_t)((len + 15) / 16); R.n++; }
+        else fits = false;
+      }
+      if (fits && dirty * 2 < total) {
+        launch_upload_runs(stream_, d_frame_.ptr, s_dev, R);
+        for (uint32_t r = 0; r < R.n; r++) std::memcpy(shadow_.data() + (size_t)R.off16[r] * 16, s + (size_t)R.off16[r] * 16, std::min((size_t)R.len16[r] * 16, total - (size_t)R.off16[r] * 16));
+        uploaded_bytes_ = (int64_t)dirty;
+        patched = true;
+      }
+    }
+    if (!patched) {
+      launch_upload(stream_, d_frame_.ptr, s_dev, total);  // whole 16-byte groups: both sides are padded to 256 B
+      shadow_.assign(s, s + total);
+      shadow_layout_ = layout;
+      shadow_dev_ = d_frame_.ptr;
+      uploaded_bytes_ = (int64_t)total;
+    }
     FDH_HIP(hipEventRecord(staging_ev_[slot], stream_));
     staging_busy_[slot] = true;
   }

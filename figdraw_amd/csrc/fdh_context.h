@@ -196,6 +196,7 @@ class Context {
   void scene_replace_root(int layer, int slot, const FdhFig* subtree, int n, const FdhScene* side, bool insert);
   void scene_render();
   void scene_stats(int64_t* walked, int64_t* reused) const { *walked = retained_.roots_walked; *reused = retained_.roots_reused; }
+  int64_t uploaded_bytes() const { return uploaded_bytes_; }
   uint64_t record_digest() const;  // FNV-1a over the last frame's draw records (diagnostic: works on record-only contexts)
 
   // multi-GPU / measurement
@@ -282,6 +283,10 @@ class Context {
   // frame N+1 and N+2 while frame N still runs (a single buffer forced a stream sync per frame)
   static constexpr int kStaging = 3;
   PinnedBuf<uint8_t> staging_[kStaging];
+  std::vector<uint8_t> shadow_;       // host copy of what the device's frame block holds (submit: upload only what differs)
+  std::vector<size_t> shadow_layout_; // the offsets that block was laid out with
+  const void* shadow_dev_ = nullptr;  // ... and where it lives
+  int64_t uploaded_bytes_ = 0;        // by the last submit
   hipEvent_t staging_ev_[kStaging] = {};
   bool staging_busy_[kStaging] = {};
   int staging_i_ = 0;

@@ -67,6 +67,10 @@ void launch_rasterize_lines(hipStream_t s, const float4* lines, int n, int w, in
 void launch_lcd_filter(hipStream_t s, const uint32_t* src, uint32_t* dst, int w, int h);
 void launch_minify2(hipStream_t s, const uint32_t* src, uint32_t* dst, int sw, int nw, int nh);
 void launch_atlas_blit(hipStream_t s, uint32_t* level, int LS, int x, int y, const uint32_t* src, int w, int h);
-void launch_upload(hipStream_t s, void* dst, const void* src_mapped, size_t bytes);  // src: device view of pinned host memory
+void launch_upload(hipStream_t s, void* dst, const void* src_mapped, size_t bytes);
+// a few 16-byte-aligned runs of the same block (offsets and lengths in 16-byte units, identical on both sides)
+constexpr int kUploadRuns = 16;
+struct UploadRuns { uint32_t n; uint32_t off16[kUploadRuns]; uint32_t len16[kUploadRuns]; };
+void launch_upload_runs(hipStream_t s, void* dst, const void* src_mapped, const UploadRuns& R);  // src: device view of pinned host memory
 
 }  // namespace fdh

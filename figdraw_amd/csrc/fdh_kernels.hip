@@ -2275,6 +2275,21 @@ __global__ void k_upload(uint4* __restrict__ dst, const uint4* __restrict__ src,
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n16) dst[i] = src[i];
 }
+// The same copy for a few byte runs of the block (what an edit of a retained scene changed): one launch, the runs in the
+// kernel arguments; thread i finds its run by walking the (at most kUploadRuns) prefix sums.
+__global__ void k_upload_runs(uint4* __restrict__ dst, const uint4* __restrict__ src, UploadRuns R) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  for (uint32_t r = 0; r < R.n; r++) {
+    if (i < R.len16[r]) { dst[R.off16[r] + i] = src[R.off16[r] + i]; return; }
+    i -= R.len16[r];
+  }
+}
+void launch_upload_runs(hipStream_t s, void* dst, const void* src_mapped, const UploadRuns& R) {
+  uint32_t total = 0;
+  for (uint32_t r = 0; r < R.n; r++) total += R.len16[r];
+  if (total == 0) return;
+  hipLaunchKernelGGL(k_upload_runs, dim3((total + 255) / 256), dim3(256), 0, s, reinterpret_cast<uint4*>(dst), reinterpret_cast<const uint4*>(src_mapped), R);
+}
 void launch_upload(hipStream_t s, void* dst, const void* src_mapped, size_t bytes) {
   const size_t n16 = (bytes + 15) / 16;
   if (n16 == 0) return;

@@ -290,6 +290,9 @@ FDH_API int fdh_scene_insert_root(FdhContext*, int layer, int slot, const FdhFig
 FDH_API int fdh_scene_render(FdhContext*);
 /* roots decomposed / roots reused from the cache by the last fdh_scene_render */
 FDH_API int fdh_scene_stats(FdhContext*, int64_t* roots_walked, int64_t* roots_reused);
+/* bytes of the frame block (records, bounds, bin boxes, blur weight tables) the last frame submission sent to the device: the
+ * whole block for a new layout, only the 256-byte chunks that differ from what the device already holds otherwise */
+FDH_API int fdh_last_upload_bytes(FdhContext*, int64_t* out);
 /* Diagnostic: FNV-1a digest of the draw records, bounds, quad extensions and phase table of the last frame (also on
  * FDH_CREATE_RECORD_ONLY contexts): two frames with equal digests hand the kernels identical input. */
 FDH_API int fdh_debug_record_digest(FdhContext*, uint64_t* out);

@@ -52,6 +52,12 @@ def _flatten(subtrees):
     return sc
 
 
+def Renders_of(lst):
+    sc = Renders()
+    sc.setLayer(0, lst)
+    return sc
+
+
 def _fresh_digest(scene, w, h):
     ctx = HipContext(record_only=True)
     ctx.render_frame(scene, w, h)
@@ -209,5 +215,16 @@ def test_retained_scene_pixels_equal_full_render():
         assert np.array_equal(ret.read_pixels(), ref.read_pixels()), step
         walked, reused = ret.scene_stats()
         assert walked <= 4 and reused >= len(subs) - 4
+    # a property edit that keeps the record count: only the 256-byte chunks that changed travel to the device
+    lst = _flatten(subs).layers[0]
+    ret.scene_retain(_flatten(subs), w, h)
+    node = lst.nodes[lst.rootIds[40]]
+    x, y, bw, bh = node.screenBox
+    node.screenBox = rect(x + 17.0, y + 9.0, bw, bh)
+    ret.scene_update_nodes(0, lst.rootIds[40], [node])
+    ret.scene_render()
+    assert 0 < ret.last_upload_bytes() <= 8192 < ret.frame_stats().n_draws * 128  # (a record is 128 bytes: the block is ~100 KB)
+    ref.render_frame(Renders_of(lst), w, h)
+    assert np.array_equal(ret.read_pixels(), ref.read_pixels())
     ret.close()
     ref.close()
