@@ -19,24 +19,25 @@ struct BinParams {
 };
 
 struct CompositeParams {
-  const uint2* lists;      // this phase's [bin][stride]
-  const uint32_t* counts;  // this phase's [bin]
-  const uint32_t* backdrop;  // blurred snapshot sampled by mode 17
-  uint32_t* fb;
-  AtlasView atlas;
-  int W, H, pitch;          // pitch in pixels
-  int bins_x, stride;
-  int bin_x0, bin_y0, bin_nx, bin_ny;  // sub-grid of bins this launch covers
-  int row_lo, row_hi;       // stripe: only rows in [row_lo,row_hi) are produced
-  int load_fb;              // 0: start from clear_rgba8
-  uint32_t clear_rgba8;
-  int n_wg;                 // total workgroups (for the XCD remap)
+  // (what a wave needs first comes first: with kernel-argument preloading the leading dwords arrive in SGPRs with the wave)
   const int* order;         // bins of a full-grid launch sorted by list length, longest first, or null (built by the
                             // previous frame's launch)
   int* order_next;          // if set, one extra wavefront of this launch sorts this frame's counts into it
+  const uint32_t* counts;  // this phase's [bin]
+  const uint2* lists;      // this phase's [bin][stride]
+  int bin_x0, bin_y0, bin_nx, bin_ny;  // sub-grid of bins this launch covers
+  int bins_x, stride;
+  int row_lo, row_hi;       // stripe: only rows in [row_lo,row_hi) are produced
+  int W, H, pitch;          // pitch in pixels
+  int load_fb;              // 0: start from clear_rgba8
+  uint32_t clear_rgba8;
+  int n_wg;                 // total workgroups (for the XCD remap)
+  uint32_t* fb;
+  const uint32_t* backdrop;  // blurred snapshot sampled by mode 17
   int has_masks;            // the phase holds clip / rect-mask ops (disables per-strip occlusion culling)
   int has_slow;             // the phase holds draws that need the one-pixel-slot path (k_composite_tiles<3>)
   int has_atlas;            // ... or axis-aligned atlas quads at >= 1:1 (k_composite_tiles<2>)
+  AtlasView atlas;
 };
 
 struct BlurParams {

@@ -778,8 +778,15 @@ __device__ unsigned int g_edge_bad[4096 * 8];
 // kPaths: bit 0 = the one-pixel-slot path (rotated / skewed quads, bezier strokes, rect-mask setup, minified images),
 // bit 1 = the 4-wide atlas path (axis-aligned glyphs, images at >= 1:1, MSDF).  0: SDF draws, clips and rect masks only.
 template <int kPaths>
-__global__ __launch_bounds__(64, (kPaths & 1) ? 4 : FDH_FAST_WAVES) void k_composite_tiles(const DrawRec* __restrict__ draws,
-                                                         const QuadExt* __restrict__ exts, CompositeParams P) {
+__global__ __launch_bounds__(64, (kPaths & 1) ? 4 : FDH_FAST_WAVES) void k_composite_tiles(
+    // the sixteen dwords a wave needs before anything else, as leading scalar arguments: with kernel-argument preloading
+    // (-amdgpu-kernarg-preload-count, csrc/Makefile) they arrive in SGPRs with the wave instead of through a first s_load
+    const int* __restrict__ a_order, int* __restrict__ a_order_next, const uint32_t* __restrict__ a_counts, const uint2* __restrict__ a_lists,
+    int a_bin_x0, int a_bin_y0, int a_bin_nx, int a_bin_ny, int a_bins_x, int a_stride, int a_row_lo, int a_row_hi,
+    const DrawRec* __restrict__ draws, const QuadExt* __restrict__ exts, CompositeParams P) {
+  P.order = a_order; P.order_next = a_order_next; P.counts = a_counts; P.lists = a_lists;
+  P.bin_x0 = a_bin_x0; P.bin_y0 = a_bin_y0; P.bin_nx = a_bin_nx; P.bin_ny = a_bin_ny;
+  P.bins_x = a_bins_x; P.stride = a_stride; P.row_lo = a_row_lo; P.row_hi = a_row_hi;
   // clip stack: 4 pixels' q8 mask values packed per lane and level.  Dynamic LDS: 4 KB when the phase has clip operations,
   // 1 KB (what the bin-ordering wavefront needs) when it has none -- a phase's waves then fit beside the 18-KB rings of
   // another frame's blur pass on the same CU (20 x 4 KB + 8 x 18 KB do not)
@@ -2152,9 +2159,9 @@ void launch_composite(hipStream_t s, const DrawRec* draws, const QuadExt* exts, 
   if (force == 3) P.has_slow = 1;
   if (force == 2) P.has_atlas = 1;
   const size_t lds = P.has_masks ? sizeof(uint32_t) * kMaskDepth * 64 : sizeof(uint32_t) * 256;
-  if (P.has_slow) FDH_LAUNCH(k_composite_tiles<3>, dim3(grid), blk, lds, s, draws, exts, P);
-  else if (P.has_atlas) FDH_LAUNCH(k_composite_tiles<2>, dim3(grid), blk, lds, s, draws, exts, P);
-  else FDH_LAUNCH(k_composite_tiles<0>, dim3(grid), blk, lds, s, draws, exts, P);
+  if (P.has_slow) FDH_LAUNCH(k_composite_tiles<3>, dim3(grid), blk, lds, s, P.order, P.order_next, P.counts, P.lists, P.bin_x0, P.bin_y0, P.bin_nx, P.bin_ny, P.bins_x, P.stride, P.row_lo, P.row_hi, draws, exts, P);
+  else if (P.has_atlas) FDH_LAUNCH(k_composite_tiles<2>, dim3(grid), blk, lds, s, P.order, P.order_next, P.counts, P.lists, P.bin_x0, P.bin_y0, P.bin_nx, P.bin_ny, P.bins_x, P.stride, P.row_lo, P.row_hi, draws, exts, P);
+  else FDH_LAUNCH(k_composite_tiles<0>, dim3(grid), blk, lds, s, P.order, P.order_next, P.counts, P.lists, P.bin_x0, P.bin_y0, P.bin_nx, P.bin_ny, P.bins_x, P.stride, P.row_lo, P.row_hi, draws, exts, P);
 }
 // small regions: fewer outputs per thread -> more, shorter waves (see NOUT above)
 #ifndef FDH_BLUR_NOUT
