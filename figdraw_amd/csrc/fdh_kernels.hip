@@ -253,7 +253,12 @@ __device__ __forceinline__ uint32_t strip_mask_inside(int x0, int y0, int x1, in
 // List entry flags (uint2.x high bits; the low 30 bits are the draw index)
 constexpr uint32_t LE_PLAIN = 1u << 31;  // axis-aligned SDF draw with ONE colour: on its core strips it is a uniform blend
 constexpr uint32_t LE_OPAQUE = 1u << 30;  // a fill whose source alpha is 255 everywhere: on its core strips it REPLACES the surface
-constexpr uint32_t LE_INDEX = (1u << 30) - 1u;
+// bits 26..29: which straight-line shading path the draw's EDGE strips can take, decided here so that the compositor
+// branches on the list entry (already in an SGPR) and fetches the record once, instead of fetching the mode word, waiting,
+// decoding it and only then fetching the rest.  0: the general path; 1..4: one colour, no gradient, OP_DRAW, mode 3 / 7 / 9 /
+// 12 with circular corners; 5..8: the same with elliptical corners
+constexpr int LE_PATH_SHIFT = 26;
+constexpr uint32_t LE_INDEX = (1u << LE_PATH_SHIFT) - 1u;
 
 // One WAVEFRONT per (phase, bin): ordered stream compaction of the phase's draws that touch the bin.  An entry is
 // {draw index | flags, strips touched (16 bits) | strips inside the draw's saturated core (16 bits)}; strips where an
@@ -279,14 +284,19 @@ __device__ __forceinline__ void bin_entry(const BinParams& P, int i, int x0, int
   const bool sdf = !(om & F_GENERAL) && !atlas_mode && mode < 18u && (op == OP_DRAW || op == OP_MASK_PUSH);
   if (!sdf) return;
   const uint32_t core = strip_mask_inside(r->ix0 - x0, r->iy0 - y0, r->ix1 - x0, r->iy1 - y0) & strips;
+  const uint32_t fill_mode = (om >> 9) & 7u;
   if (op == OP_DRAW && (mode == 9u || mode == 11u || mode == 12u)) {
     strips &= ~core;  // alpha == 0 there (stroke interior) or too small to change an 8-bit channel (deep inside an inner shadow)
     hit = strips != 0u;
+    if ((om & F_SOLID) && fill_mode == 0u && mode != 11u) word |= ((mode == 9u ? 3u : 4u) + ((om & F_ELLIP) ? 4u : 0u)) << LE_PATH_SHIFT;
     return;
   }
   strips |= core << 16;
-  const uint32_t fill_mode = (om >> 9) & 7u;
-  if (op == OP_DRAW && (om & F_SOLID) && fill_mode == 0u && mode != 17u) word |= LE_PLAIN;
+  if (op == OP_DRAW && (om & F_SOLID) && fill_mode == 0u && mode != 17u) {
+    word |= LE_PLAIN;
+    const uint32_t code = mode == 3u ? 1u : mode == 7u ? 2u : 0u;  // (9 and 12 were tagged above)
+    if (code) word |= (code + ((om & F_ELLIP) ? 4u : 0u)) << LE_PATH_SHIFT;
+  }
   if (op == OP_DRAW && mode == 3u) {
     uint32_t a = r->col[0] & r->col[1] & r->col[2] & r->col[3];
     if (fill_mode != 0u) a &= r->mid & r->stop;
@@ -544,6 +554,24 @@ __device__ __forceinline__ DrawRec load_rec(const DrawRec* __restrict__ p) {
   uint4* dst = reinterpret_cast<uint4*>(&r);
 #pragma unroll
   for (int i = 0; i < 8; i++) dst[i] = src[i];
+  return r;
+}
+
+// The same with every field pinned in SGPRs at this point: the compiler may not sink part of the fetch into the branches
+// that use it (a second round trip to L2 per draw)
+__device__ __forceinline__ DrawRec load_rec_whole(const DrawRec* __restrict__ p) {
+  const uint4* __restrict__ src = reinterpret_cast<const uint4*>(p);
+  uint4 q[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) q[i] = src[i];
+  asm volatile("" : "+s"(q[0].x), "+s"(q[0].y), "+s"(q[0].z), "+s"(q[0].w), "+s"(q[1].x), "+s"(q[1].y), "+s"(q[1].z), "+s"(q[1].w), "+s"(q[2].x), "+s"(q[2].y),
+               "+s"(q[2].z), "+s"(q[2].w), "+s"(q[3].x), "+s"(q[3].y), "+s"(q[3].z), "+s"(q[3].w));
+  asm volatile("" : "+s"(q[4].x), "+s"(q[4].y), "+s"(q[4].z), "+s"(q[4].w), "+s"(q[5].x), "+s"(q[5].y), "+s"(q[5].z), "+s"(q[5].w), "+s"(q[6].x), "+s"(q[6].y),
+               "+s"(q[6].z), "+s"(q[6].w), "+s"(q[7].x));
+  DrawRec r;
+  uint4* dst = reinterpret_cast<uint4*>(&r);
+#pragma unroll
+  for (int i = 0; i < 8; i++) dst[i] = q[i];
   return r;
 }
 
@@ -825,6 +853,7 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? 4 : FDH_FAST_WAVES) void k_compo
   if (ty0 + kTileH <= P.row_lo || ty0 >= P.row_hi) return;
   const int tx1 = tx0 + kTileW, ty1 = ty0 + kTileH;
   const int px0 = tx0 + (lane & 7) * 4, py = ty0 + (lane >> 3);
+  constexpr bool kMasks = (kPaths & 4) == 0;  // <4>: a phase without clip / rect-mask operations -- no mask registers, no stack
 #if FDH_TIMING
   const unsigned long long T0 = FDH_NOW();
   unsigned long long T_cull = 0, T_rec = 0, T_shade = 0, T_cnt = 0, n_draws_t = 0, T_cull_core = 0, n_core_t = 0;
@@ -877,7 +906,7 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? 4 : FDH_FAST_WAVES) void k_compo
     }
     unsigned long long m = __ballot(hit);
     const unsigned long long m_core = __ballot(hit && in_core);
-    if (!P.has_masks) {
+    if (!kMasks || !P.has_masks) {
       // Occlusion: an opaque fill that covers the whole strip makes every earlier draw of the strip invisible.  (Only in
       // phases without clip / rect masks: a skipped push or pop would derail the mask stack.)
       const unsigned long long m_opaque = __ballot(hit && in_core && (idx & LE_OPAQUE) != 0u);
@@ -887,6 +916,100 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? 4 : FDH_FAST_WAVES) void k_compo
     T_cull += FDH_NOW() - Tc0 + (m & 0ull);
 #endif
     if (m == 0) continue;
+    // ---- the common edge strip: ONE colour, nothing clipping, mode fill / drop shadow / inner shadow / AA stroke (list-entry
+    // path codes 1..8, k_bin_draws).  Written on float2 pairs -- pixels (0,1) and (2,3) of the lane side by side; same
+    // formulas, same order of operations as the general path in shade() below.
+    auto simple_edge = [&](const DrawRec& r, const uint32_t mode, const bool ellip, F4& A0, F4& A1, F4& A2, F4& A3) __attribute__((always_inline)) {
+      const bool inset = mode == 9u;
+      const float shx = inset ? r.p0 : r.p2, shy = inset ? r.p1 : r.p3;
+      const float tq = (cy - r.oy) * r.inv_h;
+      const float pyy = -((tq - 0.5f) * 2.0f * r.p1);
+      const f2 cxa = {cx0, cx0 + 1.0f}, cxb = {cx0 + 2.0f, cx0 + 3.0f};
+      const f2 ua = (cxa - r.ox) * r.inv_w, ub = (cxb - r.ox) * r.inv_w;
+      const f2 lxa = (ua - 0.5f) * 2.0f * r.p0, lxb = (ub - 0.5f) * 2.0f * r.p0;
+      // sdRoundedBox (atlas.frag:51-69) of the lane's four pixels at height py for half extents (bx, by)
+      auto dist4 = [&](const f2 pxa, const f2 pxb, const float py_, const float bx, const float by, f2& da, f2& db) __attribute__((always_inline)) {
+        const bool top = py_ > 0.0f;
+        const float rR = top ? r.r[0] : r.r[1], rL = top ? r.r[2] : r.r[3];
+        const float ay = __builtin_fabsf(py_) - by;
+        const f2 rra = {pxa.x > 0.0f ? rR : rL, pxa.y > 0.0f ? rR : rL}, rrb = {pxb.x > 0.0f ? rR : rL, pxb.y > 0.0f ? rR : rL};
+        const f2 axa = {__builtin_fabsf(pxa.x), __builtin_fabsf(pxa.y)}, axb = {__builtin_fabsf(pxb.x), __builtin_fabsf(pxb.y)};
+        const f2 qxa = axa - bx + rra, qxb = axb - bx + rrb;
+        const f2 qya = ay + rra, qyb = ay + rrb;
+        const f2 mxa = {__builtin_fmaxf(qxa.x, 0.0f), __builtin_fmaxf(qxa.y, 0.0f)}, mxb = {__builtin_fmaxf(qxb.x, 0.0f), __builtin_fmaxf(qxb.y, 0.0f)};
+        const f2 mya = {__builtin_fmaxf(qya.x, 0.0f), __builtin_fmaxf(qya.y, 0.0f)}, myb = {__builtin_fmaxf(qyb.x, 0.0f), __builtin_fmaxf(qyb.y, 0.0f)};
+        f2 lena = {__builtin_fmaxf(mxa.x, mya.x), __builtin_fmaxf(mxa.y, mya.y)}, lenb = {__builtin_fmaxf(mxb.x, myb.x), __builtin_fmaxf(mxb.y, myb.y)};
+        const f2 lowa = {__builtin_fminf(qxa.x, qya.x), __builtin_fminf(qxa.y, qya.y)}, lowb = {__builtin_fminf(qxb.x, qyb.x), __builtin_fminf(qxb.y, qyb.y)};
+        if (__any(lowa.x > 0.0f || lowa.y > 0.0f || lowb.x > 0.0f || lowb.y > 0.0f)) {  // some lane sits in a corner cell
+          const f2 sa2 = mxa * mxa + mya * mya, sb2 = mxb * mxb + myb * myb;
+          lena.x = lowa.x > 0.0f ? fsqrt(sa2.x) : lena.x; lena.y = lowa.y > 0.0f ? fsqrt(sa2.y) : lena.y;
+          lenb.x = lowb.x > 0.0f ? fsqrt(sb2.x) : lenb.x; lenb.y = lowb.y > 0.0f ? fsqrt(sb2.y) : lenb.y;
+        }
+        const f2 ina = {__builtin_fminf(__builtin_fmaxf(qxa.x, qya.x), 0.0f), __builtin_fminf(__builtin_fmaxf(qxa.y, qya.y), 0.0f)};
+        const f2 inb = {__builtin_fminf(__builtin_fmaxf(qxb.x, qyb.x), 0.0f), __builtin_fminf(__builtin_fmaxf(qxb.y, qyb.y), 0.0f)};
+        da = ina + lena - rra; db = inb + lenb - rrb;
+      };
+      // elliptical corners (atlas.frag:96-115): the distance itself comes from the general routine, four pixels
+      // unpacked; coverage and blend below stay packed
+      auto dist4e = [&](const f2 pxa, const f2 pxb, const float py_, const float bx, const float by, f2& oa, f2& ob) __attribute__((always_inline)) {
+        const float px4[4] = {pxa.x, pxa.y, pxb.x, pxb.y};
+        float d4[4];
+        shape_distN<4>(true, px4, py_, bx, by, r.r[0], r.r[1], r.r[2], r.r[3], d4);
+        oa = {d4[0], d4[1]}; ob = {d4[2], d4[3]};
+      };
+      f2 da, db;
+      if ((kPaths & 3) == 0 && ellip) dist4e(lxa, lxb, pyy, shx, shy, da, db); else dist4(lxa, lxb, pyy, shx, shy, da, db);
+      f2 ala, alb;  // coverage
+      if (mode == 3u) {
+        const f2 ta = da * r.aa + 0.5f, tb = db * r.aa + 0.5f;
+        ala = {1.0f - clamp01(ta.x), 1.0f - clamp01(ta.y)}; alb = {1.0f - clamp01(tb.x), 1.0f - clamp01(tb.y)};
+      } else if (mode == 12u) {
+        const float h = r.f0 * 0.5f;
+        const f2 ea = da + h, eb = db + h;
+        const f2 ga = {__builtin_fabsf(ea.x), __builtin_fabsf(ea.y)}, gb = {__builtin_fabsf(eb.x), __builtin_fabsf(eb.y)};
+        const f2 ta = (ga - h) * r.aa + 0.5f, tb = (gb - h) * r.aa + 0.5f;
+        ala = {1.0f - clamp01(ta.x), 1.0f - clamp01(ta.y)}; alb = {1.0f - clamp01(tb.x), 1.0f - clamp01(tb.y)};
+        if (__all(ala.x == 0.0f && ala.y == 0.0f && alb.x == 0.0f && alb.y == 0.0f)) return;  // inside the stroke: no-op
+      } else if (inset) {  // 9: atlas.frag:364-380 -- clip alpha of the node's own shape x the falloff inside the offset shape
+        f2 sha, shb;
+        if ((kPaths & 3) == 0 && ellip) dist4e(lxa - r.p2, lxb - r.p2, pyy + r.p3, r.p0, r.p1, sha, shb); else dist4(lxa - r.p2, lxb - r.p2, pyy + r.p3, r.p0, r.p1, sha, shb);
+        const float spread = r.f1;
+        const f2 sda = sha + spread, sdb = shb + spread;
+        const float rs = frcp(__builtin_fmaxf(0.5f * r.f0, 0.5f));
+        const f2 za = sda * rs, zb = sdb * rs;
+        const f2 ea = -0.72134752044f * za * za, eb = -0.72134752044f * zb * zb;
+        const f2 ta = da * r.aa + 0.5f, tb = db * r.aa + 0.5f;
+        ala = {(1.0f - clamp01(ta.x)) * (sda.x < 0.0f ? __builtin_fminf(fexp2(ea.x), 1.0f) : 1.0f),
+               (1.0f - clamp01(ta.y)) * (sda.y < 0.0f ? __builtin_fminf(fexp2(ea.y), 1.0f) : 1.0f)};
+        alb = {(1.0f - clamp01(tb.x)) * (sdb.x < 0.0f ? __builtin_fminf(fexp2(eb.x), 1.0f) : 1.0f),
+               (1.0f - clamp01(tb.y)) * (sdb.y < 0.0f ? __builtin_fminf(fexp2(eb.y), 1.0f) : 1.0f)};
+      } else {  // 7: atlas.frag:330-343
+        const float spread = r.f1;
+        const f2 sda = da - spread, sdb = db - spread;
+        if (__all(sda.x <= 0.0f && sda.y <= 0.0f && sdb.x <= 0.0f && sdb.y <= 0.0f)) {
+          ala = 1.0f; alb = 1.0f;
+        } else {
+          const float rs = frcp(__builtin_fmaxf(0.5f * r.f0, 0.5f));
+          const f2 za = sda * rs, zb = sdb * rs;
+          const f2 ea = -0.72134752044f * za * za, eb = -0.72134752044f * zb * zb;
+          ala = {sda.x > 0.0f ? __builtin_fminf(fexp2(ea.x), 1.0f) : 1.0f, sda.y > 0.0f ? __builtin_fminf(fexp2(ea.y), 1.0f) : 1.0f};
+          alb = {sdb.x > 0.0f ? __builtin_fminf(fexp2(eb.x), 1.0f) : 1.0f, sdb.y > 0.0f ? __builtin_fminf(fexp2(eb.y), 1.0f) : 1.0f};
+        }
+      }
+      // coverage of the quad: unsigned (x - bx0) < width, width 0 on rows outside it
+      const uint32_t xrel = (uint32_t)(px0 - (int)r.bx0);
+      const uint32_t wcov = (py >= r.by0 && py < r.by1) ? (uint32_t)((int)r.bx1 - (int)r.bx0) : 0u;
+      const F4 c0u = unpack255(r.col[0]);
+      const float cw = c0u.w * inv255;
+      f2 saa = ala * cw, sab = alb * cw;
+      saa.x = xrel < wcov ? saa.x : 0.0f; saa.y = xrel + 1u < wcov ? saa.y : 0.0f;
+      sab.x = xrel + 2u < wcov ? sab.x : 0.0f; sab.y = xrel + 3u < wcov ? sab.y : 0.0f;
+      const f2 Aa = saa * 255.0f, Ab = sab * 255.0f, iaa = 1.0f - saa, iab = 1.0f - sab;
+      const f2 crg = {c0u.x * inv255, c0u.y * inv255};
+      const float cb = c0u.z * inv255;
+      { const f2 b1 = {cb, 1.0f}; blend_pre(A0, crg * Aa.x, b1 * Aa.x, iaa.x); blend_pre(A1, crg * Aa.y, b1 * Aa.y, iaa.y);
+        blend_pre(A2, crg * Ab.x, b1 * Ab.x, iab.x); blend_pre(A3, crg * Ab.y, b1 * Ab.y, iab.y); }
+    };
     // One draw = one lambda call.  The record of the NEXT surviving draw is fetched (scalar loads) before the
     // current one is shaded, so the ~L2-latency of the fetch overlaps the shading arithmetic.
     auto shade = [&](const uint32_t d, const DrawRec& r, const bool core) {
@@ -895,7 +1018,7 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? 4 : FDH_FAST_WAVES) void k_compo
       const uint32_t mode = om & 255u;
       touched = true;
       FDH_COUNT(0);
-      if (op == OP_MASK_POP) {
+      if (kMasks && op == OP_MASK_POP) {
         mask_depth--;
         if (mask_depth > 0) {
           const uint32_t w = mask_stack[mslot][mask_depth - 1][lane];
@@ -906,9 +1029,9 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? 4 : FDH_FAST_WAVES) void k_compo
         }
         return;
       }
-      if (op == OP_RMASK_END) { rm0 = rm1 = rm2 = rm3 = 1.0f; rmask_on = false; return; }
+      if (kMasks && op == OP_RMASK_END) { rm0 = rm1 = rm2 = rm3 = 1.0f; rmask_on = false; return; }
       const bool atlas_mode = (mode == 0u) || (mode >= 13u && mode <= 16u);
-      const bool fast = !(om & F_GENERAL) && !atlas_mode && mode < 18u && (op == OP_DRAW || op == OP_MASK_PUSH);
+      const bool fast = !(om & F_GENERAL) && !atlas_mode && mode < 18u && (op == OP_DRAW || (kMasks && op == OP_MASK_PUSH));
       // ---- axis-aligned atlas quads (glyphs, images at >= 1:1, MSDF / MTSDF): 4 pixels per lane in lock-step.  All
       // sixteen bilinear texel fetches of the lane are issued before any of them is used, so the wave pays the atlas
       // latency once per draw instead of once per pixel slot.  (Minified images, lod > 0, keep the trilinear slot path.)
@@ -1041,117 +1164,6 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? 4 : FDH_FAST_WAVES) void k_compo
 #ifdef FDH_ABLATE_EDGE  // ablation build (make variant): edge strips are skipped, core strips shaded
       if (!core) return;
 #endif
-#if FDH_SIMPLE_EDGE
-      // ---- the common edge strip, written out in packed pairs: ONE colour, nothing clipping, mode
-      // fill / drop shadow / inner shadow / AA stroke.  Pixels (0,1) and (2,3) of the lane share every add / mul / fma
-      // (v_pk_*_f32); only compares, selects, min/max and the transcendentals stay per pixel.  Same formulas, same
-      // order of operations as the generic path below.
-#if FDH_EDGE_CHECK
-      F4 S0 = F0, S1 = F1, S2 = F2, S3 = F3;
-      bool did_simple = false;
-#endif
-      if (!core && (kPaths == 0 || !ellip) && (om & F_SOLID) && fill_mode == 0u && op == OP_DRAW && mask_depth == 0 && !rmask_on &&
-          (mode == 3u || mode == 7u || mode == 9u || mode == 12u)) {
-        const bool inset = mode == 9u;
-        const float shx = inset ? r.p0 : r.p2, shy = inset ? r.p1 : r.p3;
-        const float tq = (cy - r.oy) * r.inv_h;
-        const float pyy = -((tq - 0.5f) * 2.0f * r.p1);
-        const f2 cxa = {cx0, cx0 + 1.0f}, cxb = {cx0 + 2.0f, cx0 + 3.0f};
-        const f2 ua = (cxa - r.ox) * r.inv_w, ub = (cxb - r.ox) * r.inv_w;
-        const f2 lxa = (ua - 0.5f) * 2.0f * r.p0, lxb = (ub - 0.5f) * 2.0f * r.p0;
-        // sdRoundedBox (atlas.frag:51-69) of the lane's four pixels at height py for half extents (bx, by)
-        auto dist4 = [&](const f2 pxa, const f2 pxb, const float py_, const float bx, const float by, f2& da, f2& db) __attribute__((always_inline)) {
-          const bool top = py_ > 0.0f;
-          const float rR = top ? r.r[0] : r.r[1], rL = top ? r.r[2] : r.r[3];
-          const float ay = __builtin_fabsf(py_) - by;
-          const f2 rra = {pxa.x > 0.0f ? rR : rL, pxa.y > 0.0f ? rR : rL}, rrb = {pxb.x > 0.0f ? rR : rL, pxb.y > 0.0f ? rR : rL};
-          const f2 axa = {__builtin_fabsf(pxa.x), __builtin_fabsf(pxa.y)}, axb = {__builtin_fabsf(pxb.x), __builtin_fabsf(pxb.y)};
-          const f2 qxa = axa - bx + rra, qxb = axb - bx + rrb;
-          const f2 qya = ay + rra, qyb = ay + rrb;
-          const f2 mxa = {__builtin_fmaxf(qxa.x, 0.0f), __builtin_fmaxf(qxa.y, 0.0f)}, mxb = {__builtin_fmaxf(qxb.x, 0.0f), __builtin_fmaxf(qxb.y, 0.0f)};
-          const f2 mya = {__builtin_fmaxf(qya.x, 0.0f), __builtin_fmaxf(qya.y, 0.0f)}, myb = {__builtin_fmaxf(qyb.x, 0.0f), __builtin_fmaxf(qyb.y, 0.0f)};
-          f2 lena = {__builtin_fmaxf(mxa.x, mya.x), __builtin_fmaxf(mxa.y, mya.y)}, lenb = {__builtin_fmaxf(mxb.x, myb.x), __builtin_fmaxf(mxb.y, myb.y)};
-          const f2 lowa = {__builtin_fminf(qxa.x, qya.x), __builtin_fminf(qxa.y, qya.y)}, lowb = {__builtin_fminf(qxb.x, qyb.x), __builtin_fminf(qxb.y, qyb.y)};
-          if (__any(lowa.x > 0.0f || lowa.y > 0.0f || lowb.x > 0.0f || lowb.y > 0.0f)) {  // some lane sits in a corner cell
-            const f2 sa2 = mxa * mxa + mya * mya, sb2 = mxb * mxb + myb * myb;
-            lena.x = lowa.x > 0.0f ? fsqrt(sa2.x) : lena.x; lena.y = lowa.y > 0.0f ? fsqrt(sa2.y) : lena.y;
-            lenb.x = lowb.x > 0.0f ? fsqrt(sb2.x) : lenb.x; lenb.y = lowb.y > 0.0f ? fsqrt(sb2.y) : lenb.y;
-          }
-          const f2 ina = {__builtin_fminf(__builtin_fmaxf(qxa.x, qya.x), 0.0f), __builtin_fminf(__builtin_fmaxf(qxa.y, qya.y), 0.0f)};
-          const f2 inb = {__builtin_fminf(__builtin_fmaxf(qxb.x, qyb.x), 0.0f), __builtin_fminf(__builtin_fmaxf(qxb.y, qyb.y), 0.0f)};
-          da = ina + lena - rra; db = inb + lenb - rrb;
-        };
-        // elliptical corners (atlas.frag:96-115): the distance itself comes from the general routine, four pixels
-        // unpacked; coverage and blend below stay packed
-        auto dist4e = [&](const f2 pxa, const f2 pxb, const float py_, const float bx, const float by, f2& oa, f2& ob) __attribute__((always_inline)) {
-          const float px4[4] = {pxa.x, pxa.y, pxb.x, pxb.y};
-          float d4[4];
-          shape_distN<4>(true, px4, py_, bx, by, r.r[0], r.r[1], r.r[2], r.r[3], d4);
-          oa = {d4[0], d4[1]}; ob = {d4[2], d4[3]};
-        };
-        f2 da, db;
-        if (kPaths == 0 && ellip) dist4e(lxa, lxb, pyy, shx, shy, da, db); else dist4(lxa, lxb, pyy, shx, shy, da, db);
-        f2 ala, alb;  // coverage
-        if (mode == 3u) {
-          const f2 ta = da * r.aa + 0.5f, tb = db * r.aa + 0.5f;
-          ala = {1.0f - clamp01(ta.x), 1.0f - clamp01(ta.y)}; alb = {1.0f - clamp01(tb.x), 1.0f - clamp01(tb.y)};
-        } else if (mode == 12u) {
-          const float h = r.f0 * 0.5f;
-          const f2 ea = da + h, eb = db + h;
-          const f2 ga = {__builtin_fabsf(ea.x), __builtin_fabsf(ea.y)}, gb = {__builtin_fabsf(eb.x), __builtin_fabsf(eb.y)};
-          const f2 ta = (ga - h) * r.aa + 0.5f, tb = (gb - h) * r.aa + 0.5f;
-          ala = {1.0f - clamp01(ta.x), 1.0f - clamp01(ta.y)}; alb = {1.0f - clamp01(tb.x), 1.0f - clamp01(tb.y)};
-          if (__all(ala.x == 0.0f && ala.y == 0.0f && alb.x == 0.0f && alb.y == 0.0f)) return;  // inside the stroke: no-op
-        } else if (inset) {  // 9: atlas.frag:364-380 -- clip alpha of the node's own shape x the falloff inside the offset shape
-          f2 sha, shb;
-          if (kPaths == 0 && ellip) dist4e(lxa - r.p2, lxb - r.p2, pyy + r.p3, r.p0, r.p1, sha, shb); else dist4(lxa - r.p2, lxb - r.p2, pyy + r.p3, r.p0, r.p1, sha, shb);
-          const float spread = r.f1;
-          const f2 sda = sha + spread, sdb = shb + spread;
-          const float rs = frcp(__builtin_fmaxf(0.5f * r.f0, 0.5f));
-          const f2 za = sda * rs, zb = sdb * rs;
-          const f2 ea = -0.72134752044f * za * za, eb = -0.72134752044f * zb * zb;
-          const f2 ta = da * r.aa + 0.5f, tb = db * r.aa + 0.5f;
-          ala = {(1.0f - clamp01(ta.x)) * (sda.x < 0.0f ? __builtin_fminf(fexp2(ea.x), 1.0f) : 1.0f),
-                 (1.0f - clamp01(ta.y)) * (sda.y < 0.0f ? __builtin_fminf(fexp2(ea.y), 1.0f) : 1.0f)};
-          alb = {(1.0f - clamp01(tb.x)) * (sdb.x < 0.0f ? __builtin_fminf(fexp2(eb.x), 1.0f) : 1.0f),
-                 (1.0f - clamp01(tb.y)) * (sdb.y < 0.0f ? __builtin_fminf(fexp2(eb.y), 1.0f) : 1.0f)};
-        } else {  // 7: atlas.frag:330-343
-          const float spread = r.f1;
-          const f2 sda = da - spread, sdb = db - spread;
-          if (__all(sda.x <= 0.0f && sda.y <= 0.0f && sdb.x <= 0.0f && sdb.y <= 0.0f)) {
-            ala = 1.0f; alb = 1.0f;
-          } else {
-            const float rs = frcp(__builtin_fmaxf(0.5f * r.f0, 0.5f));
-            const f2 za = sda * rs, zb = sdb * rs;
-            const f2 ea = -0.72134752044f * za * za, eb = -0.72134752044f * zb * zb;
-            ala = {sda.x > 0.0f ? __builtin_fminf(fexp2(ea.x), 1.0f) : 1.0f, sda.y > 0.0f ? __builtin_fminf(fexp2(ea.y), 1.0f) : 1.0f};
-            alb = {sdb.x > 0.0f ? __builtin_fminf(fexp2(eb.x), 1.0f) : 1.0f, sdb.y > 0.0f ? __builtin_fminf(fexp2(eb.y), 1.0f) : 1.0f};
-          }
-        }
-        // coverage of the quad: unsigned (x - bx0) < width, width 0 on rows outside it
-        const uint32_t xrel = (uint32_t)(px0 - (int)r.bx0);
-        const uint32_t wcov = (py >= r.by0 && py < r.by1) ? (uint32_t)((int)r.bx1 - (int)r.bx0) : 0u;
-        const F4 c0u = unpack255(r.col[0]);
-        const float cw = c0u.w * inv255;
-        f2 saa = ala * cw, sab = alb * cw;
-        saa.x = xrel < wcov ? saa.x : 0.0f; saa.y = xrel + 1u < wcov ? saa.y : 0.0f;
-        sab.x = xrel + 2u < wcov ? sab.x : 0.0f; sab.y = xrel + 3u < wcov ? sab.y : 0.0f;
-        const f2 Aa = saa * 255.0f, Ab = sab * 255.0f, iaa = 1.0f - saa, iab = 1.0f - sab;
-        const f2 crg = {c0u.x * inv255, c0u.y * inv255};
-        const float cb = c0u.z * inv255;
-#if FDH_EDGE_CHECK
-        { const f2 b1 = {cb, 1.0f}; blend_pre(S0, crg * Aa.x, b1 * Aa.x, iaa.x); blend_pre(S1, crg * Aa.y, b1 * Aa.y, iaa.y);
-          blend_pre(S2, crg * Ab.x, b1 * Ab.x, iab.x); blend_pre(S3, crg * Ab.y, b1 * Ab.y, iab.y); }
-        did_simple = true;
-#else
-        { const f2 b1 = {cb, 1.0f}; blend_pre(F0, crg * Aa.x, b1 * Aa.x, iaa.x); blend_pre(F1, crg * Aa.y, b1 * Aa.y, iaa.y);
-          blend_pre(F2, crg * Ab.x, b1 * Ab.x, iab.x); blend_pre(F3, crg * Ab.y, b1 * Ab.y, iab.y); }
-#endif
-#if !FDH_EDGE_CHECK
-        return;
-#endif
-      }
-#endif
       FDH_COUNT(8 + (mode & 31u));
       if (ellip) FDH_COUNT(2);
       if (!(om & F_SOLID)) FDH_COUNT(3);
@@ -1229,7 +1241,7 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? 4 : FDH_FAST_WAVES) void k_compo
         shape_distN<4>(true, lx, -ly, shx, shy, r.r[0], r.r[1], r.r[2], r.r[3], dist);
       }
 
-      if (op == OP_MASK_PUSH) {
+      if (kMasks && op == OP_MASK_PUSH) {
         // mask.frag:186-234 drawn through the blender into a cleared R8 plane: stored = q8(a*a), a = shape*parent
         float mk[4] = {mk0, mk1, mk2, mk3};
         uint32_t packed = 0;
@@ -1335,18 +1347,6 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? 4 : FDH_FAST_WAVES) void k_compo
       blend(F1, sr[1], sg[1], sb[1], cov[1] ? sa[1] * mk1 * rm1 : 0.0f);
       blend(F2, sr[2], sg[2], sb[2], cov[2] ? sa[2] * mk2 * rm2 : 0.0f);
       blend(F3, sr[3], sg[3], sb[3], cov[3] ? sa[3] * mk3 * rm3 : 0.0f);
-#if FDH_EDGE_CHECK
-      if (did_simple) {
-        const float gS[16] = {S0.x, S0.y, S0.z, S0.w, S1.x, S1.y, S1.z, S1.w, S2.x, S2.y, S2.z, S2.w, S3.x, S3.y, S3.z, S3.w};
-        const float gF[16] = {F0.x, F0.y, F0.z, F0.w, F1.x, F1.y, F1.z, F1.w, F2.x, F2.y, F2.z, F2.w, F3.x, F3.y, F3.z, F3.w};
-#pragma unroll
-        for (int e = 0; e < 16; e++)
-          if (__float_as_uint(gS[e]) != __float_as_uint(gF[e])) {
-            const unsigned int i = atomicAdd(&g_edge_bad_n, 1u);
-            if (i < 4096u) { unsigned int* o = g_edge_bad + 8 * i; o[0] = mode; o[1] = blockIdx.x; o[2] = d; o[3] = (unsigned)e; o[4] = (unsigned)lane; o[5] = (ellip ? 1u : 0u) | ((unsigned)(reinterpret_cast<uintptr_t>(P.fb) >> 12) << 1); o[6] = __float_as_uint(gS[e]); o[7] = __float_as_uint(gF[e]); }
-          }
-      }
-#endif
     };
     while (m != 0) {
       const int bit = __builtin_ctzll(m);
@@ -1354,7 +1354,8 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? 4 : FDH_FAST_WAVES) void k_compo
       const uint32_t word = __builtin_amdgcn_readlane(idx, bit);
       const uint32_t d = word & LE_INDEX;
       const bool core = (m_core >> bit) & 1ull;
-      if (core && (word & LE_PLAIN) && mask_depth == 0 && !rmask_on) {
+      const bool unclipped = !kMasks || (mask_depth == 0 && !rmask_on);
+      if (core && (word & LE_PLAIN) && unclipped) {
         // One colour, coverage 1, nothing clipping: the whole strip gets the same source term.  Only the colour is
         // fetched (4 bytes instead of the 128-byte record) and nothing of the record is decoded.
         const F4 c0 = unpack255(draws[d].col[0]);
@@ -1364,6 +1365,36 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? 4 : FDH_FAST_WAVES) void k_compo
         touched = true;
         continue;
       }
+#if FDH_SIMPLE_EDGE && !defined(FDH_ABLATE_SHADING) && !defined(FDH_ABLATE_EDGE)
+      // the path code rides in the list entry: the branch is taken on a value that is already in an SGPR, and the record
+      // is fetched whole, once, behind it
+      const uint32_t code = (word >> LE_PATH_SHIFT) & 15u;
+      if (!core && code != 0u && (code <= 4u || (kPaths & 3) == 0) && unclipped) {
+        const DrawRec r = load_rec_whole(draws + d);
+        const uint32_t c4 = (code - 1u) & 3u;
+        const uint32_t mode = c4 == 0u ? 3u : c4 == 1u ? 7u : c4 == 2u ? 9u : 12u;
+        touched = true;
+#if FDH_EDGE_CHECK
+        F4 S0 = F0, S1 = F1, S2 = F2, S3 = F3;
+        simple_edge(r, mode, code > 4u, S0, S1, S2, S3);
+        shade(d, r, core);
+        {
+          const bool ellip = code > 4u;
+          const float gS[16] = {S0.x, S0.y, S0.z, S0.w, S1.x, S1.y, S1.z, S1.w, S2.x, S2.y, S2.z, S2.w, S3.x, S3.y, S3.z, S3.w};
+          const float gF[16] = {F0.x, F0.y, F0.z, F0.w, F1.x, F1.y, F1.z, F1.w, F2.x, F2.y, F2.z, F2.w, F3.x, F3.y, F3.z, F3.w};
+#pragma unroll
+          for (int e = 0; e < 16; e++)
+            if (__float_as_uint(gS[e]) != __float_as_uint(gF[e])) {
+              const unsigned int i = atomicAdd(&g_edge_bad_n, 1u);
+              if (i < 4096u) { unsigned int* o = g_edge_bad + 8 * i; o[0] = mode; o[1] = blockIdx.x; o[2] = d; o[3] = (unsigned)e; o[4] = (unsigned)lane; o[5] = (ellip ? 1u : 0u) | ((unsigned)(reinterpret_cast<uintptr_t>(P.fb) >> 12) << 1); o[6] = __float_as_uint(gS[e]); o[7] = __float_as_uint(gF[e]); }
+            }
+        }
+#else
+        simple_edge(r, mode, code > 4u, F0, F1, F2, F3);
+#endif
+        continue;
+      }
+#endif
       const DrawRec r = load_rec(draws + d);
 #if FDH_TIMING
       const unsigned long long Ts0 = FDH_NOW() + (r.op_mode & 0u);
@@ -2161,6 +2192,7 @@ void launch_composite(hipStream_t s, const DrawRec* draws, const QuadExt* exts, 
   const size_t lds = P.has_masks ? sizeof(uint32_t) * kMaskDepth * 64 : sizeof(uint32_t) * 256;
   if (P.has_slow) FDH_LAUNCH(k_composite_tiles<3>, dim3(grid), blk, lds, s, P.order, P.order_next, P.counts, P.lists, P.bin_x0, P.bin_y0, P.bin_nx, P.bin_ny, P.bins_x, P.stride, P.row_lo, P.row_hi, draws, exts, P);
   else if (P.has_atlas) FDH_LAUNCH(k_composite_tiles<2>, dim3(grid), blk, lds, s, P.order, P.order_next, P.counts, P.lists, P.bin_x0, P.bin_y0, P.bin_nx, P.bin_ny, P.bins_x, P.stride, P.row_lo, P.row_hi, draws, exts, P);
+  else if (!P.has_masks) FDH_LAUNCH(k_composite_tiles<4>, dim3(grid), blk, lds, s, P.order, P.order_next, P.counts, P.lists, P.bin_x0, P.bin_y0, P.bin_nx, P.bin_ny, P.bins_x, P.stride, P.row_lo, P.row_hi, draws, exts, P);
   else FDH_LAUNCH(k_composite_tiles<0>, dim3(grid), blk, lds, s, P.order, P.order_next, P.counts, P.lists, P.bin_x0, P.bin_y0, P.bin_nx, P.bin_ny, P.bins_x, P.stride, P.row_lo, P.row_hi, draws, exts, P);
 }
 // small regions: fewer outputs per thread -> more, shorter waves (see NOUT above)

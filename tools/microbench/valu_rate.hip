@@ -23,6 +23,8 @@ template <int MODE> __global__ __launch_bounds__(256) void k(float* out, float a
       if (MODE == 8) { acc[i].x = __builtin_amdgcn_sqrtf(acc[i].x); }                                                       // v_sqrt_f32
       if (MODE == 9) { acc[i].x = __builtin_fminf(acc[i].x, m.x); acc[i].y = acc[i].y > m.y ? acc[i].x : acc[i].y; }         // v_min_f32 + v_cmp + v_cndmask
       if (MODE == 10) { acc[i].x = __builtin_rintf(acc[i].x + m.x); }                                                       // v_add_f32 + v_rndne_f32
+      if (MODE == 11) { acc[0].x = __builtin_fmaf(acc[0].x, m.x, m.y); }                                                     // ONE dependent chain
+      if (MODE == 12) { acc[i & 1].x = __builtin_fmaf(acc[i & 1].x, m.x, m.y); }                                             // two chains
     }
     if (MODE == 4) {  // the blur inner loop mix: one texel = 4 byte->float converts + 16 packed FMAs with uniform coefficients
       const unsigned t = __float_as_uint(acc[0].x) + it;
@@ -58,6 +60,24 @@ template <int MODE> double run(const char* name, double ops_per_iter_per_lane) {
   hipFree(d);
   return ms;
 }
+// occupancy sweep: W waves per SIMD (256 x W workgroups of 4 waves), how fast does ONE SIMD issue?
+template <int MODE> void sweep(const char* name) {
+  float* d; hipMalloc(&d, 256 * 1024 * 256 * 4);
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  printf("%-34s", name);
+  for (int W : {1, 2, 3, 4, 5, 6, 8}) {
+    const int grid = 256 * W;
+    hipLaunchKernelGGL(k<MODE>, dim3(grid), dim3(256), 0, 0, d, 1.0000001f, 1e-9f);
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(k<MODE>, dim3(grid), dim3(256), 0, 0, d, 1.0000001f, 1e-9f);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    const double per_simd = (double)grid * 4 * kIter * 8 / 1024.0;
+    printf("  W=%d %.2f", W, ms * 1e6 / per_simd);
+  }
+  printf("   (ns per wave-instr per SIMD)\n");
+  hipFree(d);
+}
 int main() {
   printf("# VALU issue rates on this GPU: ns (and cycles at 2.4 GHz) one wave64 instruction occupies a SIMD, 8 waves per SIMD, 8 independent chains per wave\n");
   run<0>("2x v_fma_f32", 2);
@@ -71,5 +91,11 @@ int main() {
   run<8>("v_sqrt_f32", 1);
   run<9>("v_min + v_cmp + v_cndmask", 3);
   run<10>("v_add_f32 + v_rndne_f32", 2);
+  printf("# the same against occupancy\n");
+  sweep<3>("v_fma_f32, 8 independent chains");
+  sweep<12>("v_fma_f32, 2 chains");
+  sweep<11>("v_fma_f32, 1 dependent chain");
+  sweep<9>("min+cmp+cndmask (x3 instr)");
+  sweep<6>("v_exp_f32, 8 chains");
   return 0;
 }
