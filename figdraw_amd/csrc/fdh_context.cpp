@@ -1351,7 +1351,8 @@ void Context::launch_frame(bool profile) {
   span_end();
   // Phase 0's full-grid composite takes its bins longest-list first, in the order its predecessor sorted (an extra
   // wavefront of that launch); it sorts this frame's counts for its successor.  Any permutation is a correct schedule.
-  if (order_valid_ && order_nb_ != nb) order_valid_ = false;  // frame size changed
+  const int order_key = bins_x_ * 65536 + bins_y_;  // entries are (row << 16 | column) of THIS grid
+  if (order_valid_ && order_nb_ != order_key) order_valid_ = false;  // frame size changed
   const bool sorting = clear_ && np > 0 && nb <= 8192 && phases_[0].count > 0;
   const int* order_now = (sorting && order_valid_) ? d_order_[order_read_].ptr : nullptr;
   int* order_next = nullptr;
@@ -1360,7 +1361,7 @@ void Context::launch_frame(bool profile) {
     d_order_[wr].reserve(nb);
     order_next = d_order_[wr].ptr;
     order_read_ = wr;
-    order_nb_ = nb;
+    order_nb_ = order_key;
     order_valid_ = true;
   }
   for (int p = 0; p < np; p++) {

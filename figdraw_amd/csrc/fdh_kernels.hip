@@ -396,7 +396,7 @@ __global__ __launch_bounds__(64) void k_bin_draws(BinParams P) {
 // schedule changes).  A strip's cost is roughly its list length, and a launch ends when its last wave does: started in
 // frame order, a 60-entry strip picked up near the end ran on alone for a fifth of the kernel (58 -> 48 us).  The sort is
 // done by ONE wavefront with 256 words of LDS, from inside k_composite_tiles (see there)
-__device__ __forceinline__ void order_bins_wave(const uint32_t* __restrict__ counts, int* __restrict__ order, int nb, uint32_t* offs, int lane) {
+__device__ __forceinline__ void order_bins_wave(const uint32_t* __restrict__ counts, int* __restrict__ order, int nx, int nb, uint32_t* offs, int lane) {
 #pragma unroll
   for (int k = 0; k < 4; k++) offs[lane + 64 * k] = 0;
   __builtin_amdgcn_wave_barrier();
@@ -427,7 +427,11 @@ __device__ __forceinline__ void order_bins_wave(const uint32_t* __restrict__ cou
 #pragma unroll
     for (int k = 0; k < kU; k++) c[k] = i0 + 64 * k < nb ? counts[i0 + 64 * k] : 0xffffffffu;
 #pragma unroll
-    for (int k = 0; k < kU; k++) if (c[k] != 0xffffffffu) order[atomicAdd(&offs[255u - min(c[k], 255u)], 1u)] = i0 + 64 * k;
+    for (int k = 0; k < kU; k++)
+      if (c[k] != 0xffffffffu) {  // stored as (row << 16 | column) of the launch's bin grid: the reader is spared a division
+        const int i = i0 + 64 * k, row = i / nx;
+        order[atomicAdd(&offs[255u - min(c[k], 255u)], 1u)] = (row << 16) | (i - row * nx);
+      }
   }
 }
 
@@ -835,16 +839,21 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? 4 : FDH_FAST_WAVES) void k_compo
     // One extra wavefront per full-frame launch sorts THIS frame's bin counts for the NEXT frame's launch (any
     // permutation is a correct schedule, and list lengths barely change from frame to frame).  As a kernel of its own the
     // sort was a ~6 us serial step of every frame; here it runs beside 32 000 compositing waves.
-    order_bins_wave(P.counts, P.order_next, P.bin_nx * P.bin_ny, &mask_stack[0][0][0], threadIdx.x);
+    order_bins_wave(P.counts, P.order_next, P.bin_nx, P.bin_nx * P.bin_ny, &mask_stack[0][0][0], threadIdx.x);
     return;
   }
   int bin_local = xcd + 8 * (q / kStripsPerBin);
   const int sidx = q % kStripsPerBin;
   if (bin_local >= P.bin_nx * P.bin_ny) return;
-  if (P.order) bin_local = P.order[bin_local];  // longest lists first: see k_order_bins
   const int j = sidx >> 2, wave = sidx & 3, lane = threadIdx.x & 63, mslot = 0;
   const int sbit = j * 4 + wave;  // this strip's bit in the list entries' strip masks
-  const int bly = bin_local / P.bin_nx, blx = bin_local - bly * P.bin_nx;
+  int bly, blx;
+  if (P.order) {  // longest lists first (order_bins_wave): entries are row << 16 | column
+    const int rc = P.order[bin_local];
+    bly = rc >> 16; blx = rc & 0xffff;
+  } else {
+    bly = bin_local / P.bin_nx; blx = bin_local - bly * P.bin_nx;
+  }
   const int bin_x = P.bin_x0 + blx, bin_y = P.bin_y0 + bly;
   const int bin = bin_y * P.bins_x + bin_x;
   const int tx0 = bin_x * kBin + (j & 1) * kWgW;
@@ -1395,7 +1404,7 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? 4 : FDH_FAST_WAVES) void k_compo
         continue;
       }
 #endif
-      const DrawRec r = load_rec(draws + d);
+      const DrawRec r = load_rec_whole(draws + d);
 #if FDH_TIMING
       const unsigned long long Ts0 = FDH_NOW() + (r.op_mode & 0u);
 #endif
