@@ -31,6 +31,22 @@ namespace fdh {
 #ifndef FDH_STATS
 #define FDH_STATS 0  // `make stats`: per-strip draw classification counters (tools/strip_stats.py); never in the product build
 #endif
+// Two translation units from this one file (csrc/Makefile).  FDH_TU 0: everything except the compositor build for phases
+// without clip operations, k_composite_tiles<4>.  FDH_TU 1 (fdh_composite_uniform.hip): that build and its launcher only,
+// compiled with -structurizecfg-skip-uniform-regions.  hipcc structurizes EVERY region of a kernel's control flow, uniform
+// branches included; in the draw loop that turns each wave-uniform branch into a predicate in an SGPR pair and keeps the
+// texels that merge at the loop latch out of the registers they came from (eight v_mov_b64 per draw).  With the switch a
+// region whose branches are all wave-uniform is left as the branches it is: k_composite_tiles<4> 38 -> 34 us at 4K.  The
+// switch is NOT safe for code that nests uniform branches inside divergent ones (k_composite_tiles<3>, the blur passes and
+// the atlas path come out wrong with it -- measured), so it stays confined to this one kernel, whose loop nest holds no
+// divergent branch at all (tools/lint_isa.py checks that after every build; the note at shadow_profile() says how the
+// source keeps it so).  Instrumented builds (FDH_STATS, FDH_EDGE_CHECK, FDH_MX_CHECK) are single-unit builds.
+#ifndef FDH_TU
+#define FDH_TU 0
+#endif
+#ifndef FDH_SPLIT_UNIFORM
+#define FDH_SPLIT_UNIFORM 0  // the Makefile's product and variant builds set 1
+#endif
 
 // ------------------------------------------------------------------ small device helpers
 __device__ __forceinline__ float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
@@ -100,6 +116,12 @@ __device__ __forceinline__ float shape_dist(bool ellip, float px, float py, floa
   return ellip ? sd_elliptical_rounded_box(px, py, bx, by, r0, r1, r2, r3) : sd_rounded_box(px, py, bx, by, r0, r1, r2, r3);
 }
 // atlas.frag:211-216 -- exp(-0.5 z^2) as exp2
+// NOTE on selects below: an expensive expression (v_exp / v_sqrt / v_rcp inside) is always evaluated in a statement of its
+// own and then SELECTED, never written inside the arm of a ternary: there the compiler keeps a divergent branch around it,
+// and ONE divergent branch anywhere in the compositor's draw loop makes LLVM structurize the whole loop nest -- every
+// wave-uniform branch in it becomes a predicate in an SGPR pair (s_cselect_b64 / s_and_b64 / s_cbranch_vccnz instead of
+// s_cbranch_scc) and the texels that merge at the loop latch can no longer share registers with the ones they replace
+// (eight v_mov_b64 per draw).
 __device__ __forceinline__ float shadow_profile(float sd, float blur_radius) {
   float sigma = __builtin_fmaxf(0.5f * blur_radius, 0.5f);
   float z = sd * frcp(sigma);
@@ -272,6 +294,7 @@ constexpr uint32_t LE_INDEX = (1u << LE_PATH_SHIFT) - 1u;
 // more than 128 bins along an axis; the exact test follows for the hits).  With U = (bx | by << 8 | (127 - bx) << 16 |
 // (127 - by) << 24) | 0x80808080, the four byte-wise differences U - q keep their guard bit exactly when
 // x0 <= bx, y0 <= by, bx <= x1, by <= y1: one subtract, one and, one compare per draw.
+#if FDH_TU == 0
 __device__ __forceinline__ bool binbox_hits(uint32_t q, uint32_t U) { return ((U - q) & 0x80808080u) == 0x80808080u; }
 __device__ __forceinline__ void bin_entry(const BinParams& P, int i, int x0, int y0, bool& hit, uint32_t& word, uint32_t& strips) {
   const BBox b = P.bbox[i];
@@ -390,6 +413,8 @@ __global__ __launch_bounds__(64) void k_bin_draws(BinParams P) {
   flush();
   if (lane == 0) P.counts[(size_t)phase * nb + bin] = count;
 }
+
+#endif  // FDH_TU == 0
 
 // Longest-processing-time-first order for the compositor: bins sorted by list length, descending (counting sort on
 // min(count, 255); the order among equal keys is whatever the LDS atomics give -- bins are independent, only the
@@ -610,7 +635,8 @@ __device__ __forceinline__ float sd_ellipse_nb(float px, float py, float rx, flo
   const float bx = ax * isx, by = ay * isy;
   const float k1 = fsqrt(bx * bx + by * by);
   const float d = k0 * (k0 - 1.0f) * frcp(__builtin_fmaxf(k1, 0.000001f));
-  return k0 <= 0.000001f ? -__builtin_fminf(sx, sy) : d;
+  const float inner = -__builtin_fminf(sx, sy);  // (both arms are plain values: see the note on selects at shadow_profile)
+  return k0 <= 0.000001f ? inner : d;
 }
 // distance of N pixels of one row at once (sdRoundedBox :51-69 / sdEllipticalRoundedBox :96-115)
 template <int N>
@@ -741,18 +767,20 @@ __device__ __forceinline__ Src shade_one(const DrawRec* __restrict__ rp, const Q
     }
     case 11u: { float h = r.f0 * 0.5f; float sd = __builtin_fabsf(dist + h) - h; alpha = sd < 0.0f ? 1.0f : 0.0f; break; }
     case 12u: { float h = r.f0 * 0.5f; float sd = __builtin_fabsf(dist + h) - h; alpha = 1.0f - clamp01(r.aa * sd + 0.5f); break; }
-    case 7u: { float sd = dist - spread; alpha = sd > 0.0f ? __builtin_fminf(shadow_profile(sd, r.f0), 1.0f) : 1.0f; break; }
+    case 7u: { float sd = dist - spread; const float sp = __builtin_fminf(shadow_profile(sd, r.f0), 1.0f); alpha = sd > 0.0f ? sp : 1.0f; break; }
     case 8u: {
       float inside = 1.0f - clamp01(r.aa * dist + 0.5f);
       float sd = dist - spread;
-      alpha = sd >= 0.0f ? __builtin_fminf(shadow_profile(sd, r.f0), 1.0f) : inside;
+      const float sp = __builtin_fminf(shadow_profile(sd, r.f0), 1.0f);
+      alpha = sd >= 0.0f ? sp : inside;
       break;
     }
     case 9u: {  // atlas.frag:364-380
       float clip_a = 1.0f - clamp01(r.aa * dist + 0.5f);
       float shd = shape_dist(ellip, lx - r.p2, -ly + r.p3, qhx, qhy, r.r[0], r.r[1], r.r[2], r.r[3]);
       float sd = shd + spread;
-      float ia = sd < 0.0f ? __builtin_fminf(shadow_profile(sd, r.f0), 1.0f) : 1.0f;
+      const float sp = __builtin_fminf(shadow_profile(sd, r.f0), 1.0f);
+      float ia = sd < 0.0f ? sp : 1.0f;
       alpha = clip_a * ia;
       break;
     }
@@ -905,20 +933,16 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? 4 : FDH_FAST_WAVES) void k_compo
     const unsigned long long Tc0 = FDH_NOW();
 #endif
     const uint32_t i = base + lane;
-    uint32_t idx = 0;
-    bool hit = false, in_core = false;
-    if (i < cnt) {
-      const uint2 e = list[i];  // {draw index | flags, strips touched | strips inside the saturated core << 16}
-      idx = e.x;
-      hit = (e.y >> sbit) & 1u;
-      in_core = (e.y >> (16 + sbit)) & 1u;
-    }
-    unsigned long long m = __ballot(hit);
-    const unsigned long long m_core = __ballot(hit && in_core);
+    // (no branch around the load: lanes past the end read the last entry and drop it)
+    const uint2 e = list[min(i, cnt - 1u)];  // {draw index | flags, strips touched | strips inside the saturated core << 16}
+    const uint32_t idx = e.x;
+    const uint32_t ey = i < cnt ? e.y : 0u;
+    unsigned long long m = __ballot((ey & (1u << sbit)) != 0u);
+    const unsigned long long m_core = __ballot((ey & (0x10000u << sbit)) != 0u);  // (a core strip is a touched strip: k_bin_draws)
     if (!kMasks || !P.has_masks) {
       // Occlusion: an opaque fill that covers the whole strip makes every earlier draw of the strip invisible.  (Only in
       // phases without clip / rect masks: a skipped push or pop would derail the mask stack.)
-      const unsigned long long m_opaque = __ballot(hit && in_core && (idx & LE_OPAQUE) != 0u);
+      const unsigned long long m_opaque = __ballot((ey & (0x10000u << sbit)) != 0u && (idx & LE_OPAQUE) != 0u);
       if (m_opaque != 0) m &= ~((1ull << (63 - __builtin_clzll(m_opaque))) - 1ull);
     }
 #if FDH_TIMING
@@ -1230,7 +1254,7 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? 4 : FDH_FAST_WAVES) void k_compo
         bool one = false, zero = false;
         if (op == OP_MASK_PUSH || mode == 3u || mode == 17u) one = r.aa * dm + 0.5f <= 0.0f;
         else if (mode == 7u) one = dm - spread <= 0.0f;
-        else if (mode == 12u) { const float h = r.f0 * 0.5f; zero = (dm + h < 0.0f) && (r.aa * (-(dm + h) - h) + 0.5f >= 1.0f); }
+        else if (mode == 12u) { const float h = r.f0 * 0.5f; zero = (dm + h < 0.0f) & (r.aa * (-(dm + h) - h) + 0.5f >= 1.0f); }
         if (__all(one)) cls = 1;
         else if (__all(zero)) cls = 2;
         if (cls == 1) FDH_COUNT(5);
@@ -1290,7 +1314,8 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? 4 : FDH_FAST_WAVES) void k_compo
 #pragma unroll
           for (int k = 0; k < 4; k++) {
             const float sd = dist[k] - spread;
-            alpha[k] = sd > 0.0f ? __builtin_fminf(shadow_profile(sd, r.f0), 1.0f) : 1.0f;
+            const float sp = __builtin_fminf(shadow_profile(sd, r.f0), 1.0f);
+            alpha[k] = sd > 0.0f ? sp : 1.0f;
           }
           break;
         }
@@ -1299,7 +1324,8 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? 4 : FDH_FAST_WAVES) void k_compo
           for (int k = 0; k < 4; k++) {
             const float inside = 1.0f - clamp01(r.aa * dist[k] + 0.5f);
             const float sd = dist[k] - spread;
-            alpha[k] = sd >= 0.0f ? __builtin_fminf(shadow_profile(sd, r.f0), 1.0f) : inside;
+            const float sp = __builtin_fminf(shadow_profile(sd, r.f0), 1.0f);
+            alpha[k] = sd >= 0.0f ? sp : inside;
           }
           break;
         }
@@ -1312,7 +1338,8 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? 4 : FDH_FAST_WAVES) void k_compo
           for (int k = 0; k < 4; k++) {
             const float clip_a = 1.0f - clamp01(r.aa * dist[k] + 0.5f);
             const float sd = shd[k] + spread;
-            const float ia = sd < 0.0f ? __builtin_fminf(shadow_profile(sd, r.f0), 1.0f) : 1.0f;
+            const float sp = __builtin_fminf(shadow_profile(sd, r.f0), 1.0f);
+            const float ia = sd < 0.0f ? sp : 1.0f;
             alpha[k] = clip_a * ia;
           }
           break;
@@ -1327,12 +1354,17 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? 4 : FDH_FAST_WAVES) void k_compo
       if (mode == 17u) {  // atlas.frag:381-388: the blurred backdrop at this fragment's own pixel
         F4 b[4] = {F0, F1, F2, F3};
         if (!(om & F_SELF_BACKDROP)) {
-          if (vec_ok) {
+          if (__all(vec_ok)) {  // (wave-uniform on purpose: see )
             const uint4 q = *reinterpret_cast<const uint4*>(P.backdrop + pix);
             b[0] = unpack255(q.x); b[1] = unpack255(q.y); b[2] = unpack255(q.z); b[3] = unpack255(q.w);
-          } else if (row_ok) {
+          } else {  // a strip on the frame's right or bottom edge: clamped addresses, no branch
+            const size_t rowp = (size_t)min(py, P.H - 1) * P.pitch;
 #pragma unroll
-            for (int k = 0; k < 4; k++) if (px0 + k < P.W) b[k] = unpack255(P.backdrop[pix + k]);
+            for (int k = 0; k < 4; k++) {
+              const F4 t = unpack255(P.backdrop[rowp + min(px0 + k, P.W - 1)]);
+              const bool in = row_ok && px0 + k < P.W;
+              b[k].x = in ? t.x : b[k].x; b[k].y = in ? t.y : b[k].y; b[k].z = in ? t.z : b[k].z; b[k].w = in ? t.w : b[k].w;
+            }
           }
         }
 #pragma unroll
@@ -1440,6 +1472,7 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? 4 : FDH_FAST_WAVES) void k_compo
   }
 }
 
+#if FDH_TU == 0
 // ------------------------------------------------------------------ blur (blur.frag:11-32 as a merged FIR)
 // blur.frag takes 17 bilinear taps at i*step px.  The step is constant, so tap i has the same bilinear fraction at
 // every pixel and the pass is a fixed FIR over integer offsets (BlurTaps, built on the host).  Each thread produces
@@ -2169,10 +2202,14 @@ __global__ void k_fill_u32(uint32_t* p, uint32_t v, size_t n) {
   for (; i < n; i += stride) p[i] = v;
 }
 
+#endif  // FDH_TU == 0
+
+#if FDH_TU == 0
 // ------------------------------------------------------------------ launch wrappers (called from fdh_context.cpp)
 // Per-kernel timing (fdh_profile): with a pair of events set, the next launch goes through hipExtLaunchKernelGGL, which stamps
 // them from the dispatch's own start / end timestamps -- the kernel's execution time as rocprofv3 reports it.  (Events
 // recorded around a launch also count the gap to the neighbouring dispatches: +2..5 us on a 20 us kernel.)
+void launch_composite_uniform(hipStream_t s, hipEvent_t e0, hipEvent_t e1, int grid, size_t lds, const DrawRec* draws, const QuadExt* exts, const CompositeParams& P);  // FDH_TU 1
 static thread_local hipEvent_t t_prof_start = nullptr, t_prof_stop = nullptr;
 static thread_local bool t_prof_used = false;
 void set_launch_events(hipEvent_t start, hipEvent_t stop) { t_prof_start = start; t_prof_stop = stop; t_prof_used = false; }
@@ -2201,7 +2238,11 @@ void launch_composite(hipStream_t s, const DrawRec* draws, const QuadExt* exts, 
   const size_t lds = P.has_masks ? sizeof(uint32_t) * kMaskDepth * 64 : sizeof(uint32_t) * 256;
   if (P.has_slow) FDH_LAUNCH(k_composite_tiles<3>, dim3(grid), blk, lds, s, P.order, P.order_next, P.counts, P.lists, P.bin_x0, P.bin_y0, P.bin_nx, P.bin_ny, P.bins_x, P.stride, P.row_lo, P.row_hi, draws, exts, P);
   else if (P.has_atlas) FDH_LAUNCH(k_composite_tiles<2>, dim3(grid), blk, lds, s, P.order, P.order_next, P.counts, P.lists, P.bin_x0, P.bin_y0, P.bin_nx, P.bin_ny, P.bins_x, P.stride, P.row_lo, P.row_hi, draws, exts, P);
+#if FDH_SPLIT_UNIFORM
+  else if (!P.has_masks) { launch_composite_uniform(s, t_prof_start, t_prof_stop, grid, lds, draws, exts, P); if (t_prof_start) t_prof_used = true; }
+#else
   else if (!P.has_masks) FDH_LAUNCH(k_composite_tiles<4>, dim3(grid), blk, lds, s, P.order, P.order_next, P.counts, P.lists, P.bin_x0, P.bin_y0, P.bin_nx, P.bin_ny, P.bins_x, P.stride, P.row_lo, P.row_hi, draws, exts, P);
+#endif
   else FDH_LAUNCH(k_composite_tiles<0>, dim3(grid), blk, lds, s, P.order, P.order_next, P.counts, P.lists, P.bin_x0, P.bin_y0, P.bin_nx, P.bin_ny, P.bins_x, P.stride, P.row_lo, P.row_hi, draws, exts, P);
 }
 // small regions: fewer outputs per thread -> more, shorter waves (see NOUT above)
@@ -2377,4 +2418,10 @@ void debug_counters(unsigned long long out[64], bool reset) {
 }
 #endif
 
+#else  // FDH_TU 1: the one launcher of this unit
+void launch_composite_uniform(hipStream_t s, hipEvent_t e0, hipEvent_t e1, int grid, size_t lds, const DrawRec* draws, const QuadExt* exts, const CompositeParams& P) {
+  if (e0) hipExtLaunchKernelGGL(k_composite_tiles<4>, dim3(grid), dim3(64), lds, s, e0, e1, 0, P.order, P.order_next, P.counts, P.lists, P.bin_x0, P.bin_y0, P.bin_nx, P.bin_ny, P.bins_x, P.stride, P.row_lo, P.row_hi, draws, exts, P);
+  else hipLaunchKernelGGL(k_composite_tiles<4>, dim3(grid), dim3(64), lds, s, P.order, P.order_next, P.counts, P.lists, P.bin_x0, P.bin_y0, P.bin_nx, P.bin_ny, P.bins_x, P.stride, P.row_lo, P.row_hi, draws, exts, P);
+}
+#endif  // FDH_TU
 }  // namespace fdh

@@ -7,6 +7,10 @@ for every `pair * other.y` broadcast) now and then reads that operand as 0 in la
 same SIMD is issuing v_mfma.  figdraw's matrix-pipe blur passes of one context run beside the compositor waves of the
 others, so the product is built with -packed-fp32-ops (measured: not slower) and this script keeps it that way.
 
+Second check: k_composite_tiles<4> is compiled with -structurizecfg-skip-uniform-regions (csrc/Makefile, the FDH_TU note in
+fdh_kernels.hip), which is only sound while its draw loop nest holds no divergent branch.  The loop nest -- every backward
+branch whose range holds the draw loop's s_ff1_i32_b64 -- must therefore not write the exec mask.
+
 usage: lint_isa.py <library.so> [--allow-packed]   exit status 1 if a forbidden opcode is present"""
 import re
 import struct
@@ -37,12 +41,102 @@ def code_objects(blob: bytes):
         at += len(MAGIC)
 
 
+UNIFORM_KERNEL = "k_composite_tilesILi4E"
+EXEC_WRITE = re.compile(r"^\s*(s_\w*saveexec\w*|s_\w+\s+exec(_lo|_hi)?\b)")
+
+
+def exec_writes_in_draw_loop(lines):
+    """lines: disassembly of one kernel.  Returns the offending lines inside the natural loops that hold s_ff1_i32_b64."""
+    ins = []  # (address, text)
+    for l in lines:
+        m = re.search(r"// ([0-9A-F]{12}):", l)
+        if m and l.strip():
+            ins.append((int(m.group(1), 16), l))
+    at = {a: i for i, (a, _) in enumerate(ins)}
+    succ = [[] for _ in ins]
+    for i, (a, l) in enumerate(ins):
+        op = l.split()[0]
+        m = re.match(r"\s*(s_cbranch_\w+|s_branch)\s+(\d+)", l)
+        if m:
+            off = int(m.group(2))
+            off -= 65536 if off >= 32768 else 0
+            t = at.get(a + 4 + 4 * off)
+            if t is not None:
+                succ[i].append(t)
+            if op != "s_branch" and i + 1 < len(ins):
+                succ[i].append(i + 1)
+        elif op != "s_endpgm" and i + 1 < len(ins):
+            succ[i].append(i + 1)
+    # basic blocks
+    leader = {0}
+    for i, ss in enumerate(succ):
+        if len(ss) != 1 or ss[0] != i + 1:
+            leader.update(ss)
+            if i + 1 < len(ins):
+                leader.add(i + 1)
+    starts = sorted(leader)
+    blk_of = {}
+    blocks = []
+    for k, st in enumerate(starts):
+        en = starts[k + 1] if k + 1 < len(starts) else len(ins)
+        blocks.append((st, en))
+        for i in range(st, en):
+            blk_of[i] = k
+    bsucc = [sorted({blk_of[t] for t in succ[en - 1]}) for st, en in blocks]
+    bpred = [[] for _ in blocks]
+    for k, ss in enumerate(bsucc):
+        for t in ss:
+            bpred[t].append(k)
+    # dominators (iterative, bit sets)
+    n = len(blocks)
+    full = (1 << n) - 1
+    dom = [full] * n
+    dom[0] = 1
+    changed = True
+    while changed:
+        changed = False
+        for k in range(1, n):
+            d = full
+            for q in bpred[k]:
+                d &= dom[q]
+            d |= 1 << k
+            if d != dom[k]:
+                dom[k] = d
+                changed = True
+    marks = {blk_of[i] for i, (_, l) in enumerate(ins) if "s_ff1_i32_b64" in l}
+    if not marks:
+        return ["(draw loop not found)"]
+    body = set()
+    for u in range(n):
+        for h in bsucc[u]:
+            if not (dom[u] >> h) & 1:
+                continue  # not a back edge
+            loop, work = {h, u}, [u]
+            while work:
+                x = work.pop()
+                if x == h:
+                    continue
+                for q in bpred[x]:
+                    if q not in loop:
+                        loop.add(q)
+                        work.append(q)
+            if marks & loop:
+                body |= loop
+    if not body:
+        return ["(draw loop not found)"]
+    out = []
+    for k in sorted(body):
+        out += [ins[i][1].strip() for i in range(*blocks[k]) if EXEC_WRITE.search(ins[i][1])]
+    return out
+
+
 def main():
     path = sys.argv[1]
     blob = open(path, "rb").read()
     found = False
     bad = {}
     n_inst = 0
+    uniform_lines = []
     for triple, obj in code_objects(blob):
         found = True
         with tempfile.NamedTemporaryFile(suffix=".co") as f:
@@ -55,6 +149,8 @@ def main():
             if m:
                 kernel = m.group(1)
                 continue
+            if UNIFORM_KERNEL in kernel:
+                uniform_lines.append(line)
             n_inst += 1
             m = FORBIDDEN.search(line)
             if m:
@@ -69,6 +165,15 @@ def main():
             print(f"  {k[:100]}: {v}")
         return 1
     print(f"lint_isa: {path}: {n_inst} lines of gfx950 disassembly, packed-FP32 instructions: {sum(sum(v.values()) for v in bad.values())}")
+    if uniform_lines:
+        w = exec_writes_in_draw_loop(uniform_lines)
+        if w:
+            print("lint_isa: k_composite_tiles<4> has a divergent branch inside its draw loop (it is compiled with "
+                  "-structurizecfg-skip-uniform-regions, which needs that loop nest free of them):")
+            for l in w[:10]:
+                print("  " + l[:100])
+            return 1
+        print("lint_isa: k_composite_tiles<4>: no exec-mask write inside the draw loop nest")
     return 0
 
 
