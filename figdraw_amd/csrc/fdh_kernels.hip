@@ -19,6 +19,7 @@
 
 #include "fdh_kernels.h"
 
+#include <cstddef>
 #include <cstdlib>
 
 namespace fdh {
@@ -588,21 +589,30 @@ __device__ __forceinline__ DrawRec load_rec(const DrawRec* __restrict__ p) {
 
 // The same with every field pinned in SGPRs at this point: the compiler may not sink part of the fetch into the branches
 // that use it (a second round trip to L2 per draw)
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ DrawRec load_rec_whole(const DrawRec* __restrict__ p) {
-  const uint4* __restrict__ src = reinterpret_cast<const uint4*>(p);
-  uint4 q[8];
+  const u32x4* __restrict__ src = reinterpret_cast<const u32x4*>(p);
+  u32x4 q[8];
 #pragma unroll
   for (int i = 0; i < 8; i++) q[i] = src[i];
-  asm volatile("" : "+s"(q[0].x), "+s"(q[0].y), "+s"(q[0].z), "+s"(q[0].w), "+s"(q[1].x), "+s"(q[1].y), "+s"(q[1].z), "+s"(q[1].w), "+s"(q[2].x), "+s"(q[2].y),
-               "+s"(q[2].z), "+s"(q[2].w), "+s"(q[3].x), "+s"(q[3].y), "+s"(q[3].z), "+s"(q[3].w));
-  asm volatile("" : "+s"(q[4].x), "+s"(q[4].y), "+s"(q[4].z), "+s"(q[4].w), "+s"(q[5].x), "+s"(q[5].y), "+s"(q[5].z), "+s"(q[5].w), "+s"(q[6].x), "+s"(q[6].y),
-               "+s"(q[6].z), "+s"(q[6].w), "+s"(q[7].x));
-  DrawRec r;
-  uint4* dst = reinterpret_cast<uint4*>(&r);
-#pragma unroll
-  for (int i = 0; i < 8; i++) dst[i] = q[i];
+  // (128-bit operands: the values stay in the aligned SGPR tuples the loads wrote; pinned dword by dword the compiler
+  // reshuffled them with ~20 s_mov_b32 per record)
+  asm volatile("" : "+s"(q[0]), "+s"(q[1]), "+s"(q[2]), "+s"(q[3]), "+s"(q[4]), "+s"(q[5]), "+s"(q[6]), "+s"(q[7]));
+  DrawRec r;  // (field by field: a cast of &r to a vector pointer parks the record in scratch)
+  const auto f = [](uint32_t v) { return __uint_as_float(v); };
+  r.op_mode = q[0].x; r.ext = q[0].y; r.ox = f(q[0].z); r.oy = f(q[0].w);
+  r.inv_w = f(q[1].x); r.inv_h = f(q[1].y); r.p0 = f(q[1].z); r.p1 = f(q[1].w);
+  r.p2 = f(q[2].x); r.p3 = f(q[2].y); r.f0 = f(q[2].z); r.f1 = f(q[2].w);
+  r.r[0] = f(q[3].x); r.r[1] = f(q[3].y); r.r[2] = f(q[3].z); r.r[3] = f(q[3].w);
+  r.col[0] = q[4].x; r.col[1] = q[4].y; r.col[2] = q[4].z; r.col[3] = q[4].w;
+  r.mid = q[5].x; r.stop = q[5].y; r.aa = f(q[5].z); r.aux = f(q[5].w);
+  r.aux2 = f(q[6].x);
+  r.bx0 = (int16_t)(q[6].y & 0xffffu); r.by0 = (int16_t)(q[6].y >> 16); r.bx1 = (int16_t)(q[6].z & 0xffffu); r.by1 = (int16_t)(q[6].z >> 16);
+  r.ix0 = (int16_t)(q[6].w & 0xffffu); r.iy0 = (int16_t)(q[6].w >> 16); r.ix1 = (int16_t)(q[7].x & 0xffffu); r.iy1 = (int16_t)(q[7].x >> 16);
+  r._pad[0] = r._pad[1] = r._pad[2] = 0u;
   return r;
 }
+static_assert(offsetof(DrawRec, aux2) == 96 && offsetof(DrawRec, bx0) == 100 && offsetof(DrawRec, ix0) == 108 && offsetof(DrawRec, aa) == 88, "load_rec_whole follows DrawRec's layout");
 
 // ---- branch-free shape distance: no per-lane exec juggling (divergent control flow is paid in
 // s_and_saveexec/s_or sequences on the CU's single scalar unit).  The two-sqrt ellipse evaluation is skipped with
@@ -835,10 +845,13 @@ __device__ unsigned int g_edge_bad[4096 * 8];
 #ifndef FDH_FAST_WAVES
 #define FDH_FAST_WAVES 5
 #endif
+#ifndef FDH_UNIFORM_WAVES
+#define FDH_UNIFORM_WAVES 6  // waves per SIMD of the no-clip build <4>: 80 VGPRs, no spills
+#endif
 // kPaths: bit 0 = the one-pixel-slot path (rotated / skewed quads, bezier strokes, rect-mask setup, minified images),
 // bit 1 = the 4-wide atlas path (axis-aligned glyphs, images at >= 1:1, MSDF).  0: SDF draws, clips and rect masks only.
 template <int kPaths>
-__global__ __launch_bounds__(64, (kPaths & 1) ? 4 : FDH_FAST_WAVES) void k_composite_tiles(
+__global__ __launch_bounds__(64, (kPaths & 1) ? 4 : kPaths == 4 ? FDH_UNIFORM_WAVES : FDH_FAST_WAVES) void k_composite_tiles(
     // the sixteen dwords a wave needs before anything else, as leading scalar arguments: with kernel-argument preloading
     // (-amdgpu-kernarg-preload-count, csrc/Makefile) they arrive in SGPRs with the wave instead of through a first s_load
     const int* __restrict__ a_order, int* __restrict__ a_order_next, const uint32_t* __restrict__ a_counts, const uint2* __restrict__ a_lists,
@@ -1064,7 +1077,9 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? 4 : FDH_FAST_WAVES) void k_compo
       }
       if (kMasks && op == OP_RMASK_END) { rm0 = rm1 = rm2 = rm3 = 1.0f; rmask_on = false; return; }
       const bool atlas_mode = (mode == 0u) || (mode >= 13u && mode <= 16u);
-      const bool fast = !(om & F_GENERAL) && !atlas_mode && mode < 18u && (op == OP_DRAW || (kMasks && op == OP_MASK_PUSH));
+      // (builds without the slot path and the atlas path only ever see `fast` draws: the host picks the build per phase from
+      // exactly these properties, Context::submit -- no need to decode them again per draw)
+      const bool fast = (kPaths & 3) == 0 || (!(om & F_GENERAL) && !atlas_mode && mode < 18u && (op == OP_DRAW || (kMasks && op == OP_MASK_PUSH)));
       // ---- axis-aligned atlas quads (glyphs, images at >= 1:1, MSDF / MTSDF): 4 pixels per lane in lock-step.  All
       // sixteen bilinear texel fetches of the lane are issued before any of them is used, so the wave pays the atlas
       // latency once per draw instead of once per pixel slot.  (Minified images, lod > 0, keep the trilinear slot path.)
@@ -1358,11 +1373,13 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? 4 : FDH_FAST_WAVES) void k_compo
             const uint4 q = *reinterpret_cast<const uint4*>(P.backdrop + pix);
             b[0] = unpack255(q.x); b[1] = unpack255(q.y); b[2] = unpack255(q.z); b[3] = unpack255(q.w);
           } else {  // a strip on the frame's right or bottom edge: clamped addresses, no branch
-            const size_t rowp = (size_t)min(py, P.H - 1) * P.pitch;
+            int here = 0;  // (opaque: keeps the address arithmetic of this rare branch from being hoisted into every strip's prologue)
+            asm volatile("" : "+s"(here));
+            const size_t rowp = (size_t)min(py + here, P.H - 1) * P.pitch;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-              const F4 t = unpack255(P.backdrop[rowp + min(px0 + k, P.W - 1)]);
-              const bool in = row_ok && px0 + k < P.W;
+              const F4 t = unpack255(P.backdrop[rowp + min(px0 + k + here, P.W - 1)]);
+              const bool in = row_ok && px0 + k + here < P.W;
               b[k].x = in ? t.x : b[k].x; b[k].y = in ? t.y : b[k].y; b[k].z = in ? t.z : b[k].z; b[k].w = in ? t.w : b[k].w;
             }
           }
@@ -1460,15 +1477,22 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? 4 : FDH_FAST_WAVES) void k_compo
     for (int i = 0; i < 4; i++) { row[8 + i] = T_mode[i]; row[12 + i] = N_mode[i]; }
   }
 #endif
-  if (!(touched || !P.load_fb) || py < P.row_lo || py >= P.row_hi) return;
-  if (vec_ok) {
+  // The store address is derived again from an (opaque) lane index: kept from the prologue it held three VGPRs across
+  // the whole draw loop, the three that stood between the no-clip build and six waves per SIMD.
+  int lane_e = threadIdx.x & 63;
+  asm volatile("" : "+v"(lane_e));
+  const int px0e = tx0 + (lane_e & 7) * 4, pye = ty0 + (lane_e >> 3);
+  if (!(touched || !P.load_fb) || pye < P.row_lo || pye >= P.row_hi) return;
+  const bool row_ok_e = pye < P.H;
+  const size_t pixe = (size_t)pye * P.pitch + px0e;
+  if (row_ok_e && px0e + 3 < P.W && (P.pitch & 3) == 0) {
     uint4 o = {pack255(F0), pack255(F1), pack255(F2), pack255(F3)};
-    *reinterpret_cast<uint4*>(P.fb + pix) = o;
-  } else if (row_ok) {
-    if (px0 + 0 < P.W) P.fb[pix + 0] = pack255(F0);
-    if (px0 + 1 < P.W) P.fb[pix + 1] = pack255(F1);
-    if (px0 + 2 < P.W) P.fb[pix + 2] = pack255(F2);
-    if (px0 + 3 < P.W) P.fb[pix + 3] = pack255(F3);
+    *reinterpret_cast<uint4*>(P.fb + pixe) = o;
+  } else if (row_ok_e) {
+    if (px0e + 0 < P.W) P.fb[pixe + 0] = pack255(F0);
+    if (px0e + 1 < P.W) P.fb[pixe + 1] = pack255(F1);
+    if (px0e + 2 < P.W) P.fb[pixe + 2] = pack255(F2);
+    if (px0e + 3 < P.W) P.fb[pixe + 3] = pack255(F3);
   }
 }
 
