@@ -473,7 +473,8 @@ struct Frag {
 // per-triangle affine interpolation of the four vertex colours on an axis-aligned quad:
 // triangles (TL,BL,BR) and (TR,TL,BR) (glcontext.nim:418-429); s,t = quad-normalised x, y-down
 __device__ __forceinline__ float tri_lerp(float tl, float bl, float br, float tr, float s, float t) {
-  return (s > t) ? (tl + (tr - tl) * s + (br - tr) * t) : (tl + (bl - tl) * t + (br - bl) * s);
+  const float upper = tl + (tr - tl) * s + (br - tr) * t, lower = tl + (bl - tl) * t + (br - bl) * s;  // (both, then a select)
+  return (s > t) ? upper : lower;
 }
 
 __device__ __forceinline__ Frag make_frag(const DrawRec& r, const QuadExt* __restrict__ exts, int px, int py) {
@@ -2233,7 +2234,7 @@ __global__ void k_fill_u32(uint32_t* p, uint32_t v, size_t n) {
 // Per-kernel timing (fdh_profile): with a pair of events set, the next launch goes through hipExtLaunchKernelGGL, which stamps
 // them from the dispatch's own start / end timestamps -- the kernel's execution time as rocprofv3 reports it.  (Events
 // recorded around a launch also count the gap to the neighbouring dispatches: +2..5 us on a 20 us kernel.)
-void launch_composite_uniform(hipStream_t s, hipEvent_t e0, hipEvent_t e1, int grid, size_t lds, const DrawRec* draws, const QuadExt* exts, const CompositeParams& P);  // FDH_TU 1
+void launch_composite_uniform(hipStream_t s, hipEvent_t e0, hipEvent_t e1, int grid, size_t lds, const DrawRec* draws, const QuadExt* exts, const CompositeParams& P, int paths);  // FDH_TU 1
 static thread_local hipEvent_t t_prof_start = nullptr, t_prof_stop = nullptr;
 static thread_local bool t_prof_used = false;
 void set_launch_events(hipEvent_t start, hipEvent_t stop) { t_prof_start = start; t_prof_stop = stop; t_prof_used = false; }
@@ -2260,14 +2261,15 @@ void launch_composite(hipStream_t s, const DrawRec* draws, const QuadExt* exts, 
   if (force == 3) P.has_slow = 1;
   if (force == 2) P.has_atlas = 1;
   const size_t lds = P.has_masks ? sizeof(uint32_t) * kMaskDepth * 64 : sizeof(uint32_t) * 256;
+#if FDH_SPLIT_UNIFORM
+  if (P.has_slow) FDH_LAUNCH(k_composite_tiles<3>, dim3(grid), blk, lds, s, P.order, P.order_next, P.counts, P.lists, P.bin_x0, P.bin_y0, P.bin_nx, P.bin_ny, P.bins_x, P.stride, P.row_lo, P.row_hi, draws, exts, P);
+  else { launch_composite_uniform(s, t_prof_start, t_prof_stop, grid, lds, draws, exts, P, P.has_atlas ? 2 : P.has_masks ? 0 : 4); if (t_prof_start) t_prof_used = true; }
+#else
   if (P.has_slow) FDH_LAUNCH(k_composite_tiles<3>, dim3(grid), blk, lds, s, P.order, P.order_next, P.counts, P.lists, P.bin_x0, P.bin_y0, P.bin_nx, P.bin_ny, P.bins_x, P.stride, P.row_lo, P.row_hi, draws, exts, P);
   else if (P.has_atlas) FDH_LAUNCH(k_composite_tiles<2>, dim3(grid), blk, lds, s, P.order, P.order_next, P.counts, P.lists, P.bin_x0, P.bin_y0, P.bin_nx, P.bin_ny, P.bins_x, P.stride, P.row_lo, P.row_hi, draws, exts, P);
-#if FDH_SPLIT_UNIFORM
-  else if (!P.has_masks) { launch_composite_uniform(s, t_prof_start, t_prof_stop, grid, lds, draws, exts, P); if (t_prof_start) t_prof_used = true; }
-#else
   else if (!P.has_masks) FDH_LAUNCH(k_composite_tiles<4>, dim3(grid), blk, lds, s, P.order, P.order_next, P.counts, P.lists, P.bin_x0, P.bin_y0, P.bin_nx, P.bin_ny, P.bins_x, P.stride, P.row_lo, P.row_hi, draws, exts, P);
-#endif
   else FDH_LAUNCH(k_composite_tiles<0>, dim3(grid), blk, lds, s, P.order, P.order_next, P.counts, P.lists, P.bin_x0, P.bin_y0, P.bin_nx, P.bin_ny, P.bins_x, P.stride, P.row_lo, P.row_hi, draws, exts, P);
+#endif
 }
 // small regions: fewer outputs per thread -> more, shorter waves (see NOUT above)
 #ifndef FDH_BLUR_NOUT
@@ -2443,9 +2445,15 @@ void debug_counters(unsigned long long out[64], bool reset) {
 #endif
 
 #else  // FDH_TU 1: the one launcher of this unit
-void launch_composite_uniform(hipStream_t s, hipEvent_t e0, hipEvent_t e1, int grid, size_t lds, const DrawRec* draws, const QuadExt* exts, const CompositeParams& P) {
-  if (e0) hipExtLaunchKernelGGL(k_composite_tiles<4>, dim3(grid), dim3(64), lds, s, e0, e1, 0, P.order, P.order_next, P.counts, P.lists, P.bin_x0, P.bin_y0, P.bin_nx, P.bin_ny, P.bins_x, P.stride, P.row_lo, P.row_hi, draws, exts, P);
-  else hipLaunchKernelGGL(k_composite_tiles<4>, dim3(grid), dim3(64), lds, s, P.order, P.order_next, P.counts, P.lists, P.bin_x0, P.bin_y0, P.bin_nx, P.bin_ny, P.bins_x, P.stride, P.row_lo, P.row_hi, draws, exts, P);
+template <int kPaths>
+static void launch_uniform(hipStream_t s, hipEvent_t e0, hipEvent_t e1, int grid, size_t lds, const DrawRec* draws, const QuadExt* exts, const CompositeParams& P) {
+  if (e0) hipExtLaunchKernelGGL(k_composite_tiles<kPaths>, dim3(grid), dim3(64), lds, s, e0, e1, 0, P.order, P.order_next, P.counts, P.lists, P.bin_x0, P.bin_y0, P.bin_nx, P.bin_ny, P.bins_x, P.stride, P.row_lo, P.row_hi, draws, exts, P);
+  else hipLaunchKernelGGL(k_composite_tiles<kPaths>, dim3(grid), dim3(64), lds, s, P.order, P.order_next, P.counts, P.lists, P.bin_x0, P.bin_y0, P.bin_nx, P.bin_ny, P.bins_x, P.stride, P.row_lo, P.row_hi, draws, exts, P);
+}
+void launch_composite_uniform(hipStream_t s, hipEvent_t e0, hipEvent_t e1, int grid, size_t lds, const DrawRec* draws, const QuadExt* exts, const CompositeParams& P, int paths) {
+  if (paths == 2) launch_uniform<2>(s, e0, e1, grid, lds, draws, exts, P);
+  else if (paths == 0) launch_uniform<0>(s, e0, e1, grid, lds, draws, exts, P);
+  else launch_uniform<4>(s, e0, e1, grid, lds, draws, exts, P);
 }
 #endif  // FDH_TU
 }  // namespace fdh
