@@ -1097,26 +1097,35 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? 4 : kPaths == 4 ? FDH_UNIFORM_WA
         const int y0 = (int)fy & msk, y1 = (y0 + 1) & msk;
         const uint32_t xrel = (uint32_t)(px0 - (int)r.bx0);
         const uint32_t wcov = (py >= r.by0 && py < r.by1) ? (uint32_t)((int)r.bx1 - (int)r.bx0) : 0u;
-        const float ushift = (mode == 0u && (om & F_SUBPIXEL)) ? r.aux * frcp(__builtin_fmaxf(fS, 1.0f)) : 0.0f;
+        float ushift = 0.0f;
+        if (mode == 0u && (om & F_SUBPIXEL)) ushift = r.aux * frcp(__builtin_fmaxf(fS, 1.0f));  // wave-uniform
         float sK[4], uK[4], axK[4];
         uint32_t q00[4], q01[4], q10[4], q11[4];
+        // texel addresses as 32-bit byte offsets from the (scalar) level pointer: one shift and two adds per column instead of
+        // sign extensions and 64-bit adds (a level is at most 16384^2 x 4 bytes = 1 GiB)
+        const char* __restrict__ texb = reinterpret_cast<const char*>(tex);
+        const uint32_t row0 = ((uint32_t)y0 * (uint32_t)S) << 2, row1 = ((uint32_t)y1 * (uint32_t)S) << 2;
+        auto texel = [&](uint32_t off) __attribute__((always_inline)) { return *reinterpret_cast<const uint32_t*>(texb + off); };
 #pragma unroll
         for (int k = 0; k < 4; k++) {
           sK[k] = (cx0 + (float)k - r.ox) * r.inv_w;
           uK[k] = uax + (utx - uax) * sK[k];
           const float tx_ = (uK[k] - ushift) * fS - 0.5f, fx = __builtin_floorf(tx_);
           axK[k] = tx_ - fx;
-          const int x0 = (int)fx & msk, x1 = (x0 + 1) & msk;
-          q00[k] = tex[(size_t)y0 * S + x0]; q01[k] = tex[(size_t)y0 * S + x1];
-          q10[k] = tex[(size_t)y1 * S + x0]; q11[k] = tex[(size_t)y1 * S + x1];
+          const uint32_t x0 = (uint32_t)((int)fx & msk), x1 = (x0 + 1u) & (uint32_t)msk;
+          q00[k] = texel(row0 + (x0 << 2)); q01[k] = texel(row0 + (x1 << 2));
+          q10[k] = texel(row1 + (x0 << 2)); q11[k] = texel(row1 + (x1 << 2));
         }
         const bool solid = (om & F_SOLID) != 0u;
         const bool masked = mask_depth > 0 || rmask_on;
         const bool msdf = mode != 0u;
         const bool is_mtsdf = (mode == 14u || mode == 16u), is_stroke = (mode == 15u || mode == 16u);
-        const float unit = r.f0 * frcp(r.p0);  // pxRange / atlas size (atlas.frag:45-49)
-        const float fw_u = __builtin_fabsf((utx - uax) * r.inv_w), fw_v = __builtin_fabsf((uty - uay) * r.inv_h);
-        const float spr = __builtin_fmaxf(0.5f * (unit * frcp(fw_u) + unit * frcp(fw_v)), 1.0f);
+        float spr = 1.0f;
+        if (msdf) {  // wave-uniform (three v_rcp a coverage glyph has no use for)
+          const float unit = r.f0 * frcp(r.p0);  // pxRange / atlas size (atlas.frag:45-49)
+          const float fw_u = __builtin_fabsf((utx - uax) * r.inv_w), fw_v = __builtin_fabsf((uty - uay) * r.inv_h);
+          spr = __builtin_fmaxf(0.5f * (unit * frcp(fw_u) + unit * frcp(fw_v)), 1.0f);
+        }
         const F4 c0u = unpack255(r.col[0]);
         auto pixel = [&](const int k, F4& F, const float mk, const float rm) __attribute__((always_inline)) {
           const F4 a = unpack255(q00[k]), b = unpack255(q01[k]), c = unpack255(q10[k]), d = unpack255(q11[k]);
