@@ -392,7 +392,7 @@ def main():
     if st.ms_composite_main > 0:
         k = pmc.get("k_composite_tiles.phase0", {})
         insts = k.get("SQ_INSTS_VALU")
-        roofline = {"kernel": "k_composite_tiles<0> (phase 0)", "ms_per_launch": round(st.ms_composite_main, 4),
+        roofline = {"kernel": "k_composite_tiles<4> (phase 0; the build for phases without clip operations)", "ms_per_launch": round(st.ms_composite_main, 4),
                     "bound": "valu", "unit": "G wave-instructions/s", "peak": round(VALU_PEAK_GINST, 1),
                     "achieved": round(insts / (st.ms_composite_main * 1e-3) / 1e9, 1) if insts else None,
                     "frac": round(insts / (st.ms_composite_main * 1e-3) / 1e9 / VALU_PEAK_GINST, 4) if insts else None,

@@ -5,7 +5,8 @@
 //   k_composite_tiles  one single-wave workgroup per 32x8-pixel strip (four 8x8 tiles side by side, four pixels per lane)
 //                      walks the bin's list in painter's order keeping RGBA in registers, re-quantising to RGBA8 after every
 //                      draw like the GL framebuffer does (utils/glutils.nim:150-154 blend + RGBA8 target), and stores the
-//                      strip once.  Three builds <0|2|3> picked per phase (SDF only / + 4-wide atlas path / + general quads)
+//                      strip once.  Four builds picked per phase: <4> SDF draws only, <0> + clip masks, <2> + the 4-wide atlas
+//                      path, <3> + general quads (one pixel slot at a time)
 //   k_blur_mx<NK,kV>   the separable backdrop blur of glsl/blur.frag for regions of 0.4 Mpx and more: the merged FIR as a banded
 //                      Toeplitz product on the matrix pipe (v_mfma_f32_32x32x16_f16), texels staged by LDS-DMA into a per-wave ring
 //   k_blur_h/k_blur_v  the same FIR with VALU FMAs for small regions and unaligned pitches, LDS line staging
@@ -32,16 +33,18 @@ namespace fdh {
 #ifndef FDH_STATS
 #define FDH_STATS 0  // `make stats`: per-strip draw classification counters (tools/strip_stats.py); never in the product build
 #endif
-// Two translation units from this one file (csrc/Makefile).  FDH_TU 0: everything except the compositor build for phases
-// without clip operations, k_composite_tiles<4>.  FDH_TU 1 (fdh_composite_uniform.hip): that build and its launcher only,
-// compiled with -structurizecfg-skip-uniform-regions.  hipcc structurizes EVERY region of a kernel's control flow, uniform
-// branches included; in the draw loop that turns each wave-uniform branch into a predicate in an SGPR pair and keeps the
-// texels that merge at the loop latch out of the registers they came from (eight v_mov_b64 per draw).  With the switch a
-// region whose branches are all wave-uniform is left as the branches it is: k_composite_tiles<4> 38 -> 34 us at 4K.  The
-// switch is NOT safe for code that nests uniform branches inside divergent ones (k_composite_tiles<3>, the blur passes and
-// the atlas path come out wrong with it -- measured), so it stays confined to this one kernel, whose loop nest holds no
-// divergent branch at all (tools/lint_isa.py checks that after every build; the note at shadow_profile() says how the
-// source keeps it so).  Instrumented builds (FDH_STATS, FDH_EDGE_CHECK, FDH_MX_CHECK) are single-unit builds.
+// Two translation units from this one file (csrc/Makefile).  FDH_TU 0: everything except the compositor builds <0>, <2>
+// and <4>.  FDH_TU 1 (fdh_composite_uniform.hip): those three and their launcher only, compiled with
+// -structurizecfg-skip-uniform-regions.  hipcc structurizes EVERY region of a kernel's control flow, uniform branches
+// included; in the draw loop that turns each wave-uniform branch into a predicate in an SGPR pair (s_cselect_b64 / s_and_b64
+// / s_cbranch_vccnz where one s_cbranch_scc would do) and keeps the texels that merge at the loop latch out of the
+// registers they came from (eight v_mov_b64 per draw).  With the switch, a region whose branches are all wave-uniform is
+// left as the branches it is: phase 0 of the bench frame 38 -> 34 us, and with the registers that freed, six waves per SIMD.
+// The switch is NOT safe for code that nests uniform branches inside divergent ones: with it the slot path <3> and the blur
+// passes come out wrong (measured: 23 of the 57 GPU parity tests fail), so it stays confined to kernels whose draw loop
+// nest holds no divergent branch at all -- tools/lint_isa.py checks exactly that on the built code object after every
+// build, and the note at shadow_profile() says how the source keeps it so.  Instrumented builds (FDH_STATS, FDH_TIMING,
+// FDH_EDGE_CHECK, FDH_MX_CHECK: device-side counters) are single-unit builds (`make variant SINGLE=1`).
 #ifndef FDH_TU
 #define FDH_TU 0
 #endif

@@ -1,4 +1,9 @@
-python -m pytest tests -m gpu -q 2>&1 | tail -3
-python3 tools/perf_configs.py > gpurun_out/cfg_new.json 2>/dev/null; python3 -c "
-import json;d=json.load(open('gpurun_out/cfg_new.json'))
-for k,v in d.items(): print(k, v['frame_us'], v['kernel_us']['composite_phase0'], v['parity_vs_oracle'])"
+export TMPDIR=/tmp
+root=$(pwd); out=$root/gpurun_out/r02_d; mkdir -p $out
+for n in 1 2 3 4 5; do
+  (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $out/pc$n -o r -- python3 $root/tools/perf_configs.py $n > /dev/null 2>&1)
+  cp $(ls $out/pc$n/*kernel_stats.csv $out/pc$n/*/*kernel_stats.csv 2>/dev/null | head -1) $out/r02_config${n}_kernel_stats.csv
+  rm -rf $out/pc$n
+done
+python3 bench.py --mode stripes --width 7680 --height 4320 --steps 40 --warmup 4 --no-cpu-baseline 2>&1 | tail -1 > $out/r02_d_bench_stripes_8k.json
+cat $out/r02_d_bench_stripes_8k.json | cut -c1-900
