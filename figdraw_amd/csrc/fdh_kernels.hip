@@ -1737,6 +1737,12 @@ template <int c> __device__ __forceinline__ h8 mx_frag(const uint32_t (&R)[8]) {
   for (int q = 0; q < 4; q++) o.u[q] = __builtin_amdgcn_perm(R[2 * q + 1], R[2 * q], sel);
   return o.v;
 }
+// ring slots of a wave: the NK k-steps of the block being multiplied + the two the next block adds; the vertical pass keeps
+// two more that are idle for the length of an iteration -- its fused composite moves alphas through them
+#ifndef FDH_MX_H_EXTRA
+#define FDH_MX_H_EXTRA 0
+#endif
+constexpr int mx_ring_slots(int nk, bool vertical) { return nk + 2 + (vertical ? 2 : FDH_MX_H_EXTRA); }
 constexpr float kMxScale = 16384.0f;  // 2^24 (subnormal texels) / 2^10 (weight scale)
 constexpr int kMxSlot = 512;          // dwords of one k-step in LDS: 16 texels along the filter x 32 lines
 // LDS-DMA: 16 (or 4) bytes per lane from `src` to LDS byte address `lds` + 16 (4) * lane.  Written as inline assembly on
@@ -1777,7 +1783,7 @@ __device__ unsigned int g_mx_bad[4096 * 8];
 #endif
 template <int NK, bool kV>
 __global__ __launch_bounds__(64, 2) void k_blur_mx(BlurParams P, const DrawRec* __restrict__ draws, const QuadExt* __restrict__ exts, int T) {
-  constexpr int R = NK + 4;
+  constexpr int R = mx_ring_slots(NK, kV);
   extern __shared__ __attribute__((aligned(16))) uint32_t ring[];  // R slots
   // blocks sit at absolute multiples of 32 along the filter direction: a pixel's sum is then grouped into MFMAs the same
   // way whatever region or stripe it is rendered in (stripes of a frame must reproduce the full frame bit for bit)
@@ -2339,16 +2345,18 @@ template <int NOUT, int WAVES> static void launch_blur_v_n(hipStream_t s, const 
 static int mx_pick_t(long long per_cu, long long outputs_along, long long lines) {
   static const int forced = [] { const char* e = std::getenv("FDH_MX_T"); return e ? std::atoi(e) : 0; }();  // experiments
   if (forced) return forced;
-  const long long slots = 256 * per_cu;
+  // (two waves per SIMD at most: with the horizontal pass's smaller ring eleven fit a CU, and T = 3 with 2720 shorter waves
+  // measured 24.6 us against 23.4 for the two blur launches of the bench frame)
+  const long long slots = 256 * std::min<long long>(per_cu, 8);
   const long long along_blocks = (outputs_along + 31) / 32, line_groups = (lines + 31) / 32;
   for (int t = 1; t < 64; t++) if (line_groups * ((along_blocks + t - 1) / t) <= slots) return t;
   return 64;
 }
 template <int NK, bool kV> static void launch_blur_mx(hipStream_t s, const BlurParams& P, const DrawRec* draws, const QuadExt* exts) {
-  constexpr size_t lds = (size_t)(NK + 4) * kMxSlot * sizeof(uint32_t);
+  constexpr size_t lds = (size_t)mx_ring_slots(NK, kV) * kMxSlot * sizeof(uint32_t);
   static const int per_cu = [] {  // single-wave workgroups resident per CU, asked once per instantiation
     int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_blur_mx<NK, kV>, 64, lds) != hipSuccess || n <= 0) n = std::min<int>(8, 160 / ((NK + 4) * 2));
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_blur_mx<NK, kV>, 64, lds) != hipSuccess || n <= 0) n = std::min<int>(8, 160 / (mx_ring_slots(NK, kV) * 2));
     return n;
   }();
   const int t = kV ? mx_pick_t(per_cu, P.y1 - P.y0, P.x1 - P.x0) : mx_pick_t(per_cu, P.x1 - P.x0, P.y1 - P.y0);
