@@ -1130,16 +1130,25 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? 4 : kPaths == 4 ? FDH_UNIFORM_WA
           spr = __builtin_fmaxf(0.5f * (unit * frcp(fw_u) + unit * frcp(fw_v)), 1.0f);
         }
         const F4 c0u = unpack255(r.col[0]);
+        // The vertex-colour term once per lane where it cannot differ between the lane's four pixels: one colour, or a
+        // vertical gradient (BL == BR and TR == TL -- what a text tint is).  With equal colours on both sides, tri_lerp's two
+        // triangle formulas reduce to the same fma(bl - tl, t, tl) whatever s is (the s terms multiply an exact 0), so
+        // this is the value every pixel computed before, bit for bit.
+        const bool lane_col = solid || (r.col[0] == r.col[1] && r.col[2] == r.col[3]);  // wave-uniform
+        F4 colL = {c0u.x * inv255, c0u.y * inv255, c0u.z * inv255, c0u.w * inv255};
+        if (!solid && lane_col) {
+          const F4 br = unpack255(r.col[1]), tr = unpack255(r.col[2]), tl = unpack255(r.col[3]);
+          colL.x = tri_lerp(tl.x, c0u.x, br.x, tr.x, sK[0], t) * inv255;
+          colL.y = tri_lerp(tl.y, c0u.y, br.y, tr.y, sK[0], t) * inv255;
+          colL.z = tri_lerp(tl.z, c0u.z, br.z, tr.z, sK[0], t) * inv255;
+          colL.w = tri_lerp(tl.w, c0u.w, br.w, tr.w, sK[0], t) * inv255;
+        }
+        const bool msdf3 = msdf && !is_mtsdf;  // the distance is the median of r, g, b: the alpha channel is not sampled
         auto pixel = [&](const int k, F4& F, const float mk, const float rm) __attribute__((always_inline)) {
           const F4 a = unpack255(q00[k]), b = unpack255(q01[k]), c = unpack255(q10[k]), d = unpack255(q11[k]);
           const float ax = axK[k];
-          F4 tx;  // GL_LINEAR, 0..1
-          tx.x = (mixf(a.x, b.x, ax) * (1.0f - ayf) + mixf(c.x, d.x, ax) * ayf) * inv255;
-          tx.y = (mixf(a.y, b.y, ax) * (1.0f - ayf) + mixf(c.y, d.y, ax) * ayf) * inv255;
-          tx.z = (mixf(a.z, b.z, ax) * (1.0f - ayf) + mixf(c.z, d.z, ax) * ayf) * inv255;
-          tx.w = (mixf(a.w, b.w, ax) * (1.0f - ayf) + mixf(c.w, d.w, ax) * ayf) * inv255;
-          F4 col = {c0u.x * inv255, c0u.y * inv255, c0u.z * inv255, c0u.w * inv255};
-          if (!solid) {  // wave-uniform
+          F4 col = colL;
+          if (!lane_col) {  // wave-uniform
             const F4 br = unpack255(r.col[1]), tr = unpack255(r.col[2]), tl = unpack255(r.col[3]);
             col.x = tri_lerp(tl.x, c0u.x, br.x, tr.x, sK[k], t) * inv255;
             col.y = tri_lerp(tl.y, c0u.y, br.y, tr.y, sK[k], t) * inv255;
@@ -1147,14 +1156,30 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? 4 : kPaths == 4 ? FDH_UNIFORM_WA
             col.w = tri_lerp(tl.w, c0u.w, br.w, tr.w, sK[k], t) * inv255;
           }
           float sr, sg, sb, sa;
-          if (!msdf) {  // atlas.frag:284-295
-            sr = tx.x * col.x; sg = tx.y * col.y; sb = tx.z * col.z; sa = tx.w * col.w;
-          } else {  // atlas.frag:296-318
+          if (msdf3) {  // wave-uniform.  atlas.frag:296-318; median3(k x, k y, k z) == k median3(x, y, z) exactly for k > 0
+            const float bx_ = mixf(a.x, b.x, ax) * (1.0f - ayf) + mixf(c.x, d.x, ax) * ayf;
+            const float by_ = mixf(a.y, b.y, ax) * (1.0f - ayf) + mixf(c.y, d.y, ax) * ayf;
+            const float bz_ = mixf(a.z, b.z, ax) * (1.0f - ayf) + mixf(c.z, d.z, ax) * ayf;
             const F4 fc = eval_fill_rec(r, col, fill_mode, uK[k], v);
-            const float sd = is_mtsdf ? tx.w : median3(tx.x, tx.y, tx.z);
+            const float sd = median3(bx_, by_, bz_) * inv255;
             const float spd = spr * (sd - r.f1);
             const float alpha = is_stroke ? clamp01(__builtin_fmaxf(r.p1, 0.0f) * 0.5f - __builtin_fabsf(spd) + 0.5f) : clamp01(spd + 0.5f);
             sr = fc.x; sg = fc.y; sb = fc.z; sa = fc.w * alpha;
+          } else {
+            F4 tx;  // GL_LINEAR, 0..1
+            tx.x = (mixf(a.x, b.x, ax) * (1.0f - ayf) + mixf(c.x, d.x, ax) * ayf) * inv255;
+            tx.y = (mixf(a.y, b.y, ax) * (1.0f - ayf) + mixf(c.y, d.y, ax) * ayf) * inv255;
+            tx.z = (mixf(a.z, b.z, ax) * (1.0f - ayf) + mixf(c.z, d.z, ax) * ayf) * inv255;
+            tx.w = (mixf(a.w, b.w, ax) * (1.0f - ayf) + mixf(c.w, d.w, ax) * ayf) * inv255;
+            if (!msdf) {  // atlas.frag:284-295
+              sr = tx.x * col.x; sg = tx.y * col.y; sb = tx.z * col.z; sa = tx.w * col.w;
+            } else {  // atlas.frag:296-318 (MTSDF: the distance is in alpha)
+              const F4 fc = eval_fill_rec(r, col, fill_mode, uK[k], v);
+              const float sd = is_mtsdf ? tx.w : median3(tx.x, tx.y, tx.z);
+              const float spd = spr * (sd - r.f1);
+              const float alpha = is_stroke ? clamp01(__builtin_fmaxf(r.p1, 0.0f) * 0.5f - __builtin_fabsf(spd) + 0.5f) : clamp01(spd + 0.5f);
+              sr = fc.x; sg = fc.y; sb = fc.z; sa = fc.w * alpha;
+            }
           }
           if (masked) sa = sa * mk * rm;
           blend(F, sr, sg, sb, (xrel + (uint32_t)k) < wcov ? sa : 0.0f);
