@@ -1133,6 +1133,8 @@ void Context::submit(bool upload) {
   const auto t_s0 = std::chrono::steady_clock::now();
   FDH_HIP(hipSetDevice(device_));
   const size_t n = recs_.size();
+  // a list entry carries the draw index in 26 bits beside its path code and flags (k_bin_draws, LE_INDEX)
+  if (n >= (1u << 26)) throw Error(FDH_ERR_INVALID, "more than 67 108 863 draw records in one frame");
   bins_x_ = (W_ + kBin - 1) / kBin;
   bins_y_ = (H_ + kBin - 1) / kBin;
   const int nb = bins_x_ * bins_y_;
