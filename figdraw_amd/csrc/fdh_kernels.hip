@@ -2298,11 +2298,12 @@ void launch_composite(hipStream_t s, const DrawRec* draws, const QuadExt* exts, 
   const int bins8 = (P.bin_nx * P.bin_ny + 7) / 8;  // bins per XCD
   const int grid = 8 * bins8 * kWgsPerBin * kWavesPerWg + (P.order_next ? 8 : 0);  // 16 strips per bin, one wavefront each (+ the sorting one)
   const dim3 blk(64);
-  // FDH_FORCE_KERNEL_PATHS=3 (or 2): run a more general build than the phase needs -- a test hook: every build must give
+  // FDH_FORCE_KERNEL_PATHS=3 (or 2, or 1): run a more general build than the phase needs -- a test hook: every build must give
   // the same pixels (tests/test_hip_parity.py)
   static const int force = [] { const char* e = std::getenv("FDH_FORCE_KERNEL_PATHS"); return e ? std::atoi(e) : 0; }();
   if (force == 3) P.has_slow = 1;
   if (force == 2) P.has_atlas = 1;
+  if (force == 1) P.has_masks = 1;  // (the build with mask registers and the 4-KB stack, even where no clip is open)
   const size_t lds = P.has_masks ? sizeof(uint32_t) * kMaskDepth * 64 : sizeof(uint32_t) * 256;
 #if FDH_SPLIT_UNIFORM
   if (P.has_slow) FDH_LAUNCH(k_composite_tiles<3>, dim3(grid), blk, lds, s, P.order, P.order_next, P.counts, P.lists, P.bin_x0, P.bin_y0, P.bin_nx, P.bin_ny, P.bins_x, P.stride, P.row_lo, P.row_hi, draws, exts, P);

@@ -80,11 +80,12 @@ def test_render_is_deterministic_and_replay_is_idempotent(hip):
     assert (a == b).all() and (a == c).all()
 
 
-@pytest.mark.parametrize("paths", [2, 3])
+@pytest.mark.parametrize("paths", [1, 2, 3])
 def test_every_kernel_build_gives_the_same_pixels(hip, paths):
-    """k_composite_tiles comes in three builds (SDF only / + 4-wide atlas path / + one-pixel-slot path) picked per phase.
-    Forcing the more general builds onto SDF-only scenes (a child process with FDH_FORCE_KERNEL_PATHS) must not change a
-    pixel."""
+    """k_composite_tiles comes in four builds picked per phase: <4> SDF draws without clip operations, <0> + clip masks,
+    <2> + the 4-wide atlas path, <3> + the one-pixel-slot path (the first three live in the uniform-regions translation
+    unit, the last one in the default one).  Forcing the more general builds (1: <0>, 2: <2>, 3: <3>) onto scenes that do
+    not need them (a child process with FDH_FORCE_KERNEL_PATHS) must not change a pixel."""
     import os
     import subprocess
     import sys
