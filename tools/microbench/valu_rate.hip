@@ -11,6 +11,9 @@ template <int MODE> __global__ __launch_bounds__(256) void k(float* out, float a
   for (int i = 0; i < 8; i++) acc[i] = {(float)threadIdx.x, (float)i};
   f2 m = {a + threadIdx.x * 1e-9f, b};
   f2 ms = {a, b};  // uniform
+  const unsigned long long mask = __ballot(threadIdx.x & 1);
+  float m2[8];
+  for (int i = 0; i < 8; i++) m2[i] = a * i + threadIdx.x;
   for (int it = 0; it < kIter; it++) {
 #pragma unroll
     for (int i = 0; i < 8; i++) {
@@ -23,6 +26,35 @@ template <int MODE> __global__ __launch_bounds__(256) void k(float* out, float a
       if (MODE == 8) { acc[i].x = __builtin_amdgcn_sqrtf(acc[i].x); }                                                       // v_sqrt_f32
       if (MODE == 9) { acc[i].x = __builtin_fminf(acc[i].x, m.x); acc[i].y = acc[i].y > m.y ? acc[i].x : acc[i].y; }         // v_min_f32 + v_cmp + v_cndmask
       if (MODE == 10) { acc[i].x = __builtin_rintf(acc[i].x + m.x); }                                                       // v_add_f32 + v_rndne_f32
+      if (MODE == 13) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(acc[i].x) : "v"(m.x), "v"(m.y));       // VOP3, three VGPR sources
+      if (MODE == 14) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(acc[i].x) : "v"(m.x), "v"(m.y));           // VOP2, D += S0 * S1
+      if (MODE == 15) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(acc[i].x) : "s"(a), "v"(m.y));          // VOP3, one SGPR source
+      if (MODE == 16) asm volatile("v_mul_f32 %0, %1, %0" : "+v"(acc[i].x) : "v"(m.x));                      // VOP2
+      if (MODE == 17) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(acc[i].x) : "v"(m.x));                  // VOP3, a source used twice
+      if (MODE == 18) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(acc[i].x) : "v"(m.x));             // VOP2 select on VCC
+      if (MODE == 19) asm volatile("v_cndmask_b32 %0, %0, %1, %2" : "+v"(acc[i].x) : "v"(m.x), "s"(mask));   // VOP3 select on an SGPR pair
+      if (MODE == 20) asm volatile("v_cmp_gt_f32 vcc, %0, %1" :: "v"(acc[i].x), "v"(m.x) : "vcc");           // compare into VCC
+      if (MODE == 21) asm volatile("v_max_f32 %0, %0, %1" : "+v"(acc[i].x) : "v"(m.x));                      // VOP2
+      if (MODE == 22) asm volatile("v_mul_f32 %0, %1, %0" : "+v"(acc[i].x) : "s"(a));                        // VOP2, SGPR src0
+      if (MODE == 23) asm volatile("v_add_f32 %0, %1, %0" : "+v"(acc[i].x) : "s"(a));                        // VOP2, SGPR src0
+      if (MODE == 24) asm volatile("v_add_f32 %0, %1, %0" : "+v"(acc[i].x) : "v"(m.x));                      // VOP2
+      if (MODE == 25) asm volatile("v_min_f32 %0, %1, %0" : "+v"(acc[i].x) : "v"(m.x));                      // VOP2
+      if (MODE == 26) asm volatile("v_fma_f32 %0, %0, %1, 0.5" : "+v"(acc[i].x) : "v"(m.x));                 // VOP3, inline constant
+      if (MODE == 27) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(acc[i].x) : "s"(a), "v"(m.y));             // VOP2, SGPR src0
+      if (MODE == 28) asm volatile("v_med3_f32 %0, %0, %1, %2" : "+v"(acc[i].x) : "v"(m.x), "v"(m.y));       // VOP3
+      if (MODE == 29) asm volatile("v_rndne_f32 %0, %0" : "+v"(acc[i].x));                                   // VOP1
+      if (MODE == 30) asm volatile("v_cvt_f32_ubyte1 %0, %0" : "+v"(acc[i].x));                              // VOP1
+      if (MODE == 31) asm volatile("v_mul_f32 %0, 0x3b808081, %0" : "+v"(acc[i].x));                         // VOP2, 32-bit literal
+      if (MODE == 32) asm volatile("v_max_f32 %0, 0, %0" : "+v"(acc[i].x));                                  // VOP2, inline constant
+      if (MODE == 33) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(acc[i].x) : "v"(m.x));                      // VOP2
+      if (MODE == 34) asm volatile("v_and_b32 %0, %1, %0" : "+v"(acc[i].x) : "v"(m.x));                      // VOP2 integer
+      if (MODE == 35) asm volatile("v_add_u32 %0, %1, %0" : "+v"(acc[i].x) : "v"(m.x));                      // VOP2 integer
+      if (MODE == 36) asm volatile("v_mov_b32 %0, %1" : "=v"(acc[i].x) : "v"(acc[(i + 1) & 7].y));           // VOP1
+      if (MODE == 37) asm volatile("v_fma_f32 %0, %0, %1, %2 clamp" : "+v"(acc[i].x) : "v"(m.x), "v"(m.y));  // VOP3 + clamp
+      // two kinds of VALU work side by side: M = v_rndne (4-cycle class), F = v_fma (2-cycle class)
+      if (MODE == 40 || MODE == 41 || MODE == 42) asm volatile("v_rndne_f32 %0, %0" : "+v"(acc[i].x));
+      if (MODE == 41 || MODE == 42 || MODE == 43) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(acc[i].y) : "v"(m.x), "v"(m.y));
+      if (MODE == 42 || MODE == 43) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(m2[i]) : "v"(m.x), "v"(m.y));
       if (MODE == 11) { acc[0].x = __builtin_fmaf(acc[0].x, m.x, m.y); }                                                     // ONE dependent chain
       if (MODE == 12) { acc[i & 1].x = __builtin_fmaf(acc[i & 1].x, m.x, m.y); }                                             // two chains
     }
@@ -42,7 +74,7 @@ template <int MODE> __global__ __launch_bounds__(256) void k(float* out, float a
     }
   }
   float s = 0;
-  for (int i = 0; i < 8; i++) s += acc[i].x + acc[i].y;
+  for (int i = 0; i < 8; i++) s += acc[i].x + acc[i].y + m2[i];
   out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 template <int MODE> double run(const char* name, double ops_per_iter_per_lane) {
@@ -91,6 +123,37 @@ int main() {
   run<8>("v_sqrt_f32", 1);
   run<9>("v_min + v_cmp + v_cndmask", 3);
   run<10>("v_add_f32 + v_rndne_f32", 2);
+  printf("# encodings (inline assembly, 8 independent chains)\n");
+  run<13>("v_fma_f32 d, d, v, v  (VOP3)", 1);
+  run<17>("v_fma_f32 d, d, v, v (same v)", 1);
+  run<15>("v_fma_f32 d, d, s, v  (VOP3)", 1);
+  run<14>("v_fmac_f32 d, v, v   (VOP2)", 1);
+  run<16>("v_mul_f32 d, v, d    (VOP2)", 1);
+  run<21>("v_max_f32 d, d, v    (VOP2)", 1);
+  run<18>("v_cndmask_b32 .. vcc (VOP2)", 1);
+  run<19>("v_cndmask_b32 .. s[] (VOP3)", 1);
+  run<20>("v_cmp_gt_f32 vcc     (VOPC)", 1);
+  run<24>("v_add_f32 d, v, d    (VOP2)", 1);
+  run<33>("v_sub_f32 d, d, v    (VOP2)", 1);
+  run<25>("v_min_f32 d, v, d    (VOP2)", 1);
+  run<32>("v_max_f32 d, 0, d    (VOP2)", 1);
+  run<28>("v_med3_f32           (VOP3)", 1);
+  run<37>("v_fma_f32 .. clamp   (VOP3)", 1);
+  run<26>("v_fma_f32 d, d, v, 0.5", 1);
+  run<22>("v_mul_f32 d, s, d    (VOP2)", 1);
+  run<23>("v_add_f32 d, s, d    (VOP2)", 1);
+  run<27>("v_fmac_f32 d, s, v   (VOP2)", 1);
+  run<31>("v_mul_f32 d, literal, d", 1);
+  run<29>("v_rndne_f32          (VOP1)", 1);
+  run<30>("v_cvt_f32_ubyte1     (VOP1)", 1);
+  run<36>("v_mov_b32            (VOP1)", 1);
+  run<34>("v_and_b32            (VOP2)", 1);
+  run<35>("v_add_u32            (VOP2)", 1);
+  printf("# do the two classes overlap?  time per loop step (8 x the instructions named), ns per SIMD\n");
+  run<40>("8 rndne", 1);
+  run<41>("8 rndne + 8 fma   (per pair)", 1);
+  run<42>("8 rndne + 16 fma  (per triple)", 1);
+  run<43>("16 fma            (per pair)", 1);
   printf("# the same against occupancy\n");
   sweep<3>("v_fma_f32, 8 independent chains");
   sweep<12>("v_fma_f32, 2 chains");
