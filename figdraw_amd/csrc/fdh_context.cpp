@@ -154,22 +154,37 @@ void Context::upload_atlas_rect(int level, int x, int y, int w, int h, const uin
   FDH_HIP(hipMemcpy2D(atlas_levels_[level] + (size_t)y * LS + x, (size_t)LS * 4, rgba, (size_t)w * 4, (size_t)w * 4, h,
                       hipMemcpyHostToDevice));  // synchronous: image uploads are rare and the source is pageable
 }
+// pixie's Image.minifyBy2 on premultiplied RGBA8 (the arithmetic the reference's data/img1.flippy pins: its stored levels are this
+// chain): box SUM div 4; an odd extent rounds the result size up, the extra column / row holding mix(a, b, 0.5) * 0.5 of the last
+// source column / row (mix = (127 a + 128 b) div 255, * 0.5 = (128 v) div 255) and the extra corner the last texel * 0.25 =
+// (64 v) div 255.  k_minify2 is the device form of the same step.
+static void minify_by2_host(const uint8_t* src, int w, int h, uint8_t* dst) {
+  const int nw = (w + 1) / 2, nh = (h + 1) / 2;
+  auto at = [&](int x, int y, int k) -> unsigned { return src[((size_t)y * w + x) * 4 + k]; };
+  for (int y = 0; y < nh; y++) {
+    const bool row_pair = 2 * y + 1 < h;
+    for (int x = 0; x < nw; x++) {
+      const bool col_pair = 2 * x + 1 < w;
+      for (int k = 0; k < 4; k++) {
+        unsigned v;
+        if (col_pair && row_pair) v = (at(2 * x, 2 * y, k) + at(2 * x + 1, 2 * y, k) + at(2 * x + 1, 2 * y + 1, k) + at(2 * x, 2 * y + 1, k)) >> 2;
+        else if (row_pair) v = ((at(w - 1, 2 * y, k) * 127u + at(w - 1, 2 * y + 1, k) * 128u) / 255u) * 128u / 255u;
+        else if (col_pair) v = ((at(2 * x, h - 1, k) * 127u + at(2 * x + 1, h - 1, k) * 128u) / 255u) * 128u / 255u;
+        else v = at(w - 1, h - 1, k) * 64u / 255u;
+        dst[((size_t)y * nw + x) * 4 + k] = (uint8_t)v;
+      }
+    }
+  }
+}
 void Context::put_levels(int x, int y, int w, int h, const uint8_t* rgba) {
-  // updateSubImage: level chain by repeated minifyBy2 while width > 1 and height > 1 (textures.nim:106-119);
-  // pixie's minifyBy2 is a 2x2 box average with round-half-up: (a+b+c+d+2) div 4.
+  // updateSubImage: level chain by repeated minifyBy2 while width > 1 and height > 1 (textures.nim:106-119).
   std::vector<uint8_t> cur(rgba, rgba + (size_t)w * h * 4), nxt;
   int cw = w, ch = h, lx = x, ly = y, level = 0;
   while (cw > 1 && ch > 1 && level < n_levels_) {
     upload_atlas_rect(level, lx, ly, cw, ch, cur.data());
-    const int nw = cw / 2, nh = ch / 2;
-    nxt.assign((size_t)std::max(nw, 1) * std::max(nh, 1) * 4, 0);
-    for (int yy = 0; yy < nh; yy++)
-      for (int xx = 0; xx < nw; xx++)
-        for (int k = 0; k < 4; k++) {
-          unsigned s = cur[((size_t)(2 * yy) * cw + 2 * xx) * 4 + k] + cur[((size_t)(2 * yy) * cw + 2 * xx + 1) * 4 + k] +
-                       cur[((size_t)(2 * yy + 1) * cw + 2 * xx) * 4 + k] + cur[((size_t)(2 * yy + 1) * cw + 2 * xx + 1) * 4 + k];
-          nxt[((size_t)yy * nw + xx) * 4 + k] = (uint8_t)((s + 2) / 4);
-        }
+    const int nw = (cw + 1) / 2, nh = (ch + 1) / 2;
+    nxt.assign((size_t)nw * nh * 4, 0);
+    minify_by2_host(cur.data(), cw, ch, nxt.data());
     cur.swap(nxt);
     cw = nw; ch = nh; lx /= 2; ly /= 2; level++;
   }
@@ -211,8 +226,8 @@ void Context::glyph_to_atlas(uint32_t* cur, uint32_t* nxt, int w, int h, int x, 
   int cw = w, ch = h, lx = x, ly = y, level = 0;
   while (cw > 1 && ch > 1 && level < n_levels_) {
     launch_atlas_blit(stream_, atlas_levels_[level], atlas_size_ >> level, lx, ly, cur, cw, ch);
-    const int nw = cw / 2, nh = ch / 2;
-    launch_minify2(stream_, cur, nxt, cw, nw, nh);
+    const int nw = (cw + 1) / 2, nh = (ch + 1) / 2;
+    launch_minify2(stream_, cur, nxt, cw, ch);
     std::swap(cur, nxt);
     cw = nw; ch = nh; lx /= 2; ly /= 2; level++;
   }

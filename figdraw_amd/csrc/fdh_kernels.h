@@ -66,7 +66,7 @@ void launch_fill(hipStream_t s, uint32_t* p, uint32_t v, size_t n);
 // glyph outline (flattened to lines x0, y0, x1, y1) -> premultiplied white coverage; scratch: h x (w + 2) floats
 void launch_rasterize_lines(hipStream_t s, const float4* lines, int n, int w, int h, float* scratch, uint32_t* out);
 void launch_lcd_filter(hipStream_t s, const uint32_t* src, uint32_t* dst, int w, int h);
-void launch_minify2(hipStream_t s, const uint32_t* src, uint32_t* dst, int sw, int nw, int nh);
+void launch_minify2(hipStream_t s, const uint32_t* src, uint32_t* dst, int sw, int sh);  // dst: ((sw + 1) / 2) x ((sh + 1) / 2)
 void launch_atlas_blit(hipStream_t s, uint32_t* level, int LS, int x, int y, const uint32_t* src, int w, int h);
 void launch_upload(hipStream_t s, void* dst, const void* src_mapped, size_t bytes);
 // a few 16-byte-aligned runs of the same block (offsets and lengths in 16-byte units, identical on both sides)

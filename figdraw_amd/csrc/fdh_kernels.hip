@@ -2168,15 +2168,27 @@ __global__ void k_lcd_filter(const uint32_t* __restrict__ src, uint32_t* __restr
   dst[(size_t)y * w + x] = (uint32_t)(((sr + 128) >> 8) & 255) | ((uint32_t)(((sg + 128) >> 8) & 255) << 8) |
                            ((uint32_t)(((sb + 128) >> 8) & 255) << 16) | ((uint32_t)(((sa + 128) >> 8) & 255) << 24);
 }
-// one mip step of updateSubImage (textures.nim:106-119): 2x2 box average with round-half-up, (a + b + c + d + 2) / 4 per channel
-__global__ void k_minify2(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, int sw, int nw, int nh) {
+// one mip step of updateSubImage (textures.nim:106-119) = pixie's Image.minifyBy2 on premultiplied RGBA8: box sum div 4; an odd
+// extent rounds the result size up and the extra column / row / corner carry half / half / quarter coverage (the arithmetic
+// is pinned by the reference's data/img1.flippy: minify_by2_host in fdh_context.cpp spells it out)
+__global__ void k_minify2(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, int sw, int sh) {
+  const int nw = (sw + 1) >> 1, nh = (sh + 1) >> 1;
   const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
   if (x >= nw || y >= nh) return;
-  const uint32_t a = src[(size_t)(2 * y) * sw + 2 * x], b = src[(size_t)(2 * y) * sw + 2 * x + 1];
-  const uint32_t c = src[(size_t)(2 * y + 1) * sw + 2 * x], d = src[(size_t)(2 * y + 1) * sw + 2 * x + 1];
+  const bool col_pair = 2 * x + 1 < sw, row_pair = 2 * y + 1 < sh;
+  const int x0 = col_pair ? 2 * x : sw - 1, x1 = col_pair ? 2 * x + 1 : sw - 1, y0 = row_pair ? 2 * y : sh - 1, y1 = row_pair ? 2 * y + 1 : sh - 1;
+  const uint32_t a = src[(size_t)y0 * sw + x0], b = src[(size_t)y0 * sw + x1], c = src[(size_t)y1 * sw + x0], d = src[(size_t)y1 * sw + x1];
   uint32_t o = 0;
 #pragma unroll
-  for (int k = 0; k < 32; k += 8) o |= ((((a >> k) & 255u) + ((b >> k) & 255u) + ((c >> k) & 255u) + ((d >> k) & 255u) + 2u) >> 2) << k;
+  for (int k = 0; k < 32; k += 8) {
+    const uint32_t ca = (a >> k) & 255u, cb = (b >> k) & 255u, cc = (c >> k) & 255u, cd = (d >> k) & 255u;
+    uint32_t v;
+    if (col_pair && row_pair) v = (ca + cb + cc + cd) >> 2;
+    else if (row_pair) v = ((ca * 127u + cc * 128u) / 255u) * 128u / 255u;  // last column: rows 2y, 2y + 1
+    else if (col_pair) v = ((ca * 127u + cb * 128u) / 255u) * 128u / 255u;  // last row: columns 2x, 2x + 1
+    else v = ca * 64u / 255u;
+    o |= v << k;
+  }
   dst[(size_t)y * nw + x] = o;
 }
 // a w x h image into the rectangle (x, y) of one atlas level (LS texels wide); texels outside the level are dropped
@@ -2257,8 +2269,9 @@ void launch_rasterize_lines(hipStream_t s, const float4* lines, int n, int w, in
 void launch_lcd_filter(hipStream_t s, const uint32_t* src, uint32_t* dst, int w, int h) {
   if (w > 0 && h > 0) hipLaunchKernelGGL(k_lcd_filter, dim3((w + 63) / 64, h), dim3(64), 0, s, src, dst, w, h);
 }
-void launch_minify2(hipStream_t s, const uint32_t* src, uint32_t* dst, int sw, int nw, int nh) {
-  if (nw > 0 && nh > 0) hipLaunchKernelGGL(k_minify2, dim3((nw + 63) / 64, nh), dim3(64), 0, s, src, dst, sw, nw, nh);
+void launch_minify2(hipStream_t s, const uint32_t* src, uint32_t* dst, int sw, int sh) {
+  const int nw = (sw + 1) / 2, nh = (sh + 1) / 2;
+  if (sw > 0 && sh > 0) hipLaunchKernelGGL(k_minify2, dim3((nw + 63) / 64, nh), dim3(64), 0, s, src, dst, sw, sh);
 }
 void launch_atlas_blit(hipStream_t s, uint32_t* level, int LS, int x, int y, const uint32_t* src, int w, int h) {
   if (w > 0 && h > 0) hipLaunchKernelGGL(k_atlas_blit, dim3((w + 63) / 64, h), dim3(64), 0, s, level, LS, x, y, src, w, h);

@@ -13,8 +13,13 @@
  * its published definition ("parity unpinned" for these two items only):
  *   - vmath (any version, figdraw.nimble:20): Mat4 column-major, translate/scale/ortho/inverse; rotateZ(a) maps
  *     (x, y) to (cos x + sin y, -sin x + cos y) -- this one IS pinned, by tests/expected/render_line_rect.png.
- *   - pixie >= 5.0.1 Image.minifyBy2 used for atlas mip levels
- *     (opengl/textures.nim:106-119): 2x2 box average, (sum+2) div 4.
+ *   - pixie >= 5.0.1 Image.minifyBy2 used for atlas mip levels (opengl/textures.nim:106-119).  pixie is not in
+ *     /root/reference; its arithmetic is PINNED by the reference's own data/img1.flippy, whose eight stored levels
+ *     (100, 50, 25, 13, 7, 4, 2, 1 px) are pngToFlippy's minifyBy2 chain of the opaque level 0 (formatflippy.nim:101-112):
+ *     2x2 box sum DIV 4 (no rounding); an odd width or height rounds the result size UP, and the extra column / row is
+ *     mix(a, b, 0.5) * 0.5 of the last source column / row -- mix = (a*127 + b*128) div 255, * 0.5 = (v*128) div 255 --
+ *     the extra corner the last source texel * 0.25 = (v*64) div 255 (premultiplied: the edge's coverage is halved).
+ *     tests/test_oracle.py::test_minify_by2_reproduces_the_flippy_levels.
  */
 #include "figdraw_oracle.h"
 
@@ -993,6 +998,29 @@ int fo_put_glyph_image(FoCtx* c, int64_t key, int w, int h, const uint8_t* rgba,
   free(f);
   return rc;
 }
+/* pixie Image.minifyBy2 (see the header of this file for how its arithmetic is pinned): dst is ((w + 1) / 2) x ((h + 1) / 2) */
+void fo_minify_by2(const uint8_t* src, int w, int h, uint8_t* dst) {
+  const int ew = w / 2, eh = h / 2, nw = (w + 1) / 2, nh = (h + 1) / 2;
+  for (int y = 0; y < nh; y++)
+    for (int x = 0; x < nw; x++)
+      for (int k = 0; k < 4; k++) {
+        unsigned v;
+        if (x < ew && y < eh) {
+          v = (src[((size_t)(2 * y) * w + 2 * x) * 4 + k] + src[((size_t)(2 * y) * w + 2 * x + 1) * 4 + k] +
+               src[((size_t)(2 * y + 1) * w + 2 * x + 1) * 4 + k] + src[((size_t)(2 * y + 1) * w + 2 * x) * 4 + k]) / 4;
+        } else if (y < eh) { /* odd width: the last source column, two rows mixed, half coverage */
+          unsigned a = src[((size_t)(2 * y) * w + (w - 1)) * 4 + k], b = src[((size_t)(2 * y + 1) * w + (w - 1)) * 4 + k];
+          v = (((a * 127u + b * 128u) / 255u) * 128u) / 255u;
+        } else if (x < ew) { /* odd height: the last source row */
+          unsigned a = src[((size_t)(h - 1) * w + 2 * x) * 4 + k], b = src[((size_t)(h - 1) * w + 2 * x + 1) * 4 + k];
+          v = (((a * 127u + b * 128u) / 255u) * 128u) / 255u;
+        } else { /* both odd: the last texel, quarter coverage */
+          v = (src[((size_t)(h - 1) * w + (w - 1)) * 4 + k] * 64u) / 255u;
+        }
+        dst[((size_t)y * nw + x) * 4 + k] = (uint8_t)v;
+      }
+}
+
 int fo_put_image(FoCtx* c, int64_t key, int w, int h, const uint8_t* rgba, int out_rect[4]) {
   int S = c->atlas_size, rx, ry;
   if (place_rect(c, key, w, h, &rx, &ry) != 0) return -1;
@@ -1008,15 +1036,9 @@ int fo_put_image(FoCtx* c, int64_t key, int w, int h, const uint8_t* rgba, int o
         int tx = lx + xx, ty = ly + yy;
         if (tx >= 0 && ty >= 0 && tx < LS && ty < LS) memcpy(c->atlas[level] + ((size_t)ty * LS + tx) * 4, cur + ((size_t)yy * cw + xx) * 4, 4);
       }
-    int nw = cw / 2, nh = ch / 2;
-    uint8_t* nxt = (uint8_t*)malloc((size_t)(nw > 0 ? nw : 1) * (nh > 0 ? nh : 1) * 4);
-    for (int yy = 0; yy < nh; yy++)
-      for (int xx = 0; xx < nw; xx++)
-        for (int k = 0; k < 4; k++) {
-          unsigned s = cur[((size_t)(2 * yy) * cw + 2 * xx) * 4 + k] + cur[((size_t)(2 * yy) * cw + 2 * xx + 1) * 4 + k] +
-                       cur[((size_t)(2 * yy + 1) * cw + 2 * xx) * 4 + k] + cur[((size_t)(2 * yy + 1) * cw + 2 * xx + 1) * 4 + k];
-          nxt[((size_t)yy * nw + xx) * 4 + k] = (uint8_t)((s + 2) / 4);
-        }
+    int nw = (cw + 1) / 2, nh = (ch + 1) / 2;
+    uint8_t* nxt = (uint8_t*)malloc((size_t)nw * nh * 4);
+    fo_minify_by2(cur, cw, ch, nxt);
     free(cur);
     cur = nxt; cw = nw; ch = nh; lx /= 2; ly /= 2; level++;
   }

@@ -163,6 +163,9 @@ void fo_end_mask(FoCtx*);
 void fo_pop_mask(FoCtx*);
 void fo_begin_rect_mask(FoCtx*, const float rect[4], const float radii_x[4], const float radii_y[4]);
 void fo_pop_rect_mask(FoCtx*);
+/* pixie Image.minifyBy2 on RGBA8 texels (premultiplied): dst is ((w + 1) / 2) x ((h + 1) / 2).  textures.nim:106-119's mip step;
+ * arithmetic pinned by the reference's data/img1.flippy (figdraw_oracle.c header). */
+void fo_minify_by2(const uint8_t* src, int w, int h, uint8_t* dst);
 int fo_put_image(FoCtx*, int64_t key, int w, int h, const uint8_t* rgba, int out_rect[4]);
 /* glyph outlines -> premultiplied white coverage (exact-area accumulation; pixie's texels themselves are unpinned) */
 int fo_flatten_outline(const float* segs, int n, float* lines, int cap);

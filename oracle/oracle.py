@@ -285,6 +285,17 @@ def blur_image(rgba: np.ndarray, radius: float) -> np.ndarray:
     return out
 
 
+def minify_by2(rgba: np.ndarray) -> np.ndarray:
+    """pixie Image.minifyBy2 (the mip step of textures.nim:106-119) on an (h, w, 4) uint8 premultiplied image"""
+    rgba = np.ascontiguousarray(rgba, dtype=np.uint8)
+    h, w = rgba.shape[:2]
+    out = np.zeros(((h + 1) // 2, (w + 1) // 2, 4), dtype=np.uint8)
+    lib().fo_minify_by2.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    lib().fo_minify_by2.restype = None
+    lib().fo_minify_by2(rgba.ctypes.data, w, h, out.ctypes.data)
+    return out
+
+
 def lcd_filter(rgba: np.ndarray) -> np.ndarray:
     """applyLcdFilter (common/textrasters/pixie_raster.nim:12-43) on an (h, w, 4) uint8 image"""
     rgba = np.ascontiguousarray(rgba, dtype=np.uint8)

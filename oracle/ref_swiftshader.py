@@ -408,15 +408,23 @@ class RefGL:
 
     @staticmethod
     def minify_by2(img: np.ndarray) -> np.ndarray:
-        """pixie Image.minifyBy2 (third-party, pixie >= 5.0.1): 2x2 box average of
-        premultiplied RGBA8 with +2 rounding bias ((a+b+c+d+2) div 4)."""
+        """pixie Image.minifyBy2 (third-party, pixie >= 5.0.1) on premultiplied RGBA8, with the arithmetic the reference's own
+        data/img1.flippy pins (its stored levels are this chain; tests/test_oracle.py::test_minify_by2_reproduces_the_flippy_levels):
+        2x2 box SUM div 4; an odd extent rounds the result size up, the extra column / row is mix(a, b, 0.5) * 0.5 of the last
+        source column / row (mix = (127 a + 128 b) div 255, * 0.5 = (128 v) div 255), the extra corner the last texel * 0.25."""
+        img = img.astype(np.uint32)
         h, w = img.shape[:2]
-        h2, w2 = h // 2, w // 2
-        a = img[: h2 * 2 : 2, : w2 * 2 : 2].astype(np.uint32)
-        b = img[: h2 * 2 : 2, 1 : w2 * 2 : 2].astype(np.uint32)
-        c = img[1 : h2 * 2 : 2, : w2 * 2 : 2].astype(np.uint32)
-        d = img[1 : h2 * 2 : 2, 1 : w2 * 2 : 2].astype(np.uint32)
-        return ((a + b + c + d + 2) // 4).astype(np.uint8)
+        eh, ew = h // 2, w // 2
+        out = np.zeros(((h + 1) // 2, (w + 1) // 2, 4), np.uint32)
+        out[:eh, :ew] = (img[0:2 * eh:2, 0:2 * ew:2] + img[0:2 * eh:2, 1:2 * ew:2] + img[1:2 * eh:2, 1:2 * ew:2] + img[1:2 * eh:2, 0:2 * ew:2]) // 4
+        half = lambda p, q: ((p * 127 + q * 128) // 255) * 128 // 255
+        if w % 2:
+            out[:eh, -1] = half(img[0:2 * eh:2, w - 1], img[1:2 * eh:2, w - 1])
+        if h % 2:
+            out[-1, :ew] = half(img[h - 1, 0:2 * ew:2], img[h - 1, 1:2 * ew:2])
+            if w % 2:
+                out[-1, -1] = img[h - 1, w - 1] * 64 // 255
+        return out.astype(np.uint8)
 
     def put_image(self, key, rgba: np.ndarray):
         rgba = np.ascontiguousarray(rgba, dtype=np.uint8)

@@ -232,6 +232,32 @@ def test_oracle_atlas_sampling_matches_reference_shaders(name):
     assert mx <= 2 and n1 <= 0.001 * w * h, (name, mx, n0, n1)
 
 
+def test_minify_by2_reproduces_the_flippy_levels():
+    """pixie's Image.minifyBy2 (third-party, not in the reference tree) builds every atlas mip chain (textures.nim:106-119).  The
+    reference's own data/img1.flippy pins its arithmetic: pngToFlippy (formatflippy.nim:101-112) stores level 0 (opaque, so
+    premultiplied == straight) and the minifyBy2 chain of it -- 100, 50, 25, 13, 7, 4, 2, 1 px: even and odd extents, the
+    half-coverage edge column / row and the quarter-coverage corner.  The restatement must reproduce every stored level; stored
+    texels are straight alpha (`c.color.rgba()`, formatflippy.nim:87-88), hence the division on the way out.  Two texels of the
+    2 x 2 level differ by 1 (the float path of that conversion, which is not part of minifyBy2)."""
+    from conftest import load_flippy_levels
+
+    levels = load_flippy_levels("img1.flippy")
+    assert [l.shape[0] for l in levels] == [100, 50, 25, 13, 7, 4, 2, 1]
+    assert (levels[0][..., 3] == 255).all()
+    cur, off = levels[0], 0
+    for want in levels[1:]:
+        cur = O.minify_by2(cur)
+        assert cur.shape == want.shape
+        a = cur[..., 3:4].astype(int)
+        straight = np.concatenate([np.where(a > 0, cur[..., :3].astype(int) * 255 // np.maximum(a, 1), 0), a], axis=2)
+        d = np.abs(straight - want.astype(int))
+        assert d.max() <= 1, (want.shape, int(d.max()))
+        off += int((d > 0).sum())
+        if want.shape[0] >= 4:
+            assert (d == 0).all(), want.shape  # the levels down to 4 x 4 match bit for bit
+    assert off <= 2, off
+
+
 def test_oracle_flippy_image_matches_reference_png():
     """putFlippy (glcontext.nim:610-620, formatflippy.nim:114-149) + nkImage: the reference's own tests/trender_image.nim
     scene with its own data/img1.flippy, against its own tests/expected/render_image.png."""
