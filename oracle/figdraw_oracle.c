@@ -9,8 +9,9 @@
  * (tile-binned, masks analytic, blur restricted to footprints), which is what
  * makes HIP-vs-oracle parity meaningful.
  *
- * Third-party arithmetic that is not under /root/reference and is restated from
- * its published definition ("parity unpinned" for these two items only):
+ * Third-party arithmetic that is not under /root/reference and is restated from its published definition.  Both items
+ * below turned out to be pinned by data the reference ships; what remains "parity unpinned" is said where it is used (the
+ * straight -> premultiplied rounding of translucent Flippy texels, pixie's glyph rasteriser texels):
  *   - vmath (any version, figdraw.nimble:20): Mat4 column-major, translate/scale/ortho/inverse; rotateZ(a) maps
  *     (x, y) to (cos x + sin y, -sin x + cos y) -- this one IS pinned, by tests/expected/render_line_rect.png.
  *   - pixie >= 5.0.1 Image.minifyBy2 used for atlas mip levels (opengl/textures.nim:106-119).  pixie is not in
