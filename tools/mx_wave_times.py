@@ -27,3 +27,20 @@ for mark, name in ((2, "horizontal"), (3, "vertical")):
           f"prologue {r[:,1].mean()*tick:.0f}; per block: wait {(r[:,2]/r[:,8]).mean()*tick:.0f} stores {(r[:,3]/r[:,8]).mean()*tick:.0f} "
           f"lds+mfma {(r[:,4]/r[:,8]).mean()*tick:.0f} epilogue {(r[:,5]/r[:,8]).mean()*tick:.0f} issue {(r[:,7]/r[:,8]).mean()*tick:.0f}; "
           f"launch span {(r[:,9].max() + r[r[:,9].argmax(),0] - r[:,9].min())*tick/1000:.1f} us, start spread {(r[:,9].max()-r[:,9].min())*tick/1000:.1f} us")
+
+# where the slow waves are: mean / max lifetime by position along the filter direction (sa) -- the first and the last
+# segment of a line group fetch k-steps that cross the frame edge (one texel per lane, clamped)
+for mark, name, n_lines, n_along in ((2, "horizontal", (h + 31) // 32, (w + 127) // 128), (3, "vertical", (w + 31) // 32, (h + 127) // 128)):
+    sel = np.nonzero(wt[:, 6] == mark)[0]
+    if not len(sel): continue
+    total = n_lines * n_along
+    per = (total + 7) // 8
+    item = (sel & 7) * per + (sel >> 3)
+    if mark == 2:
+        sa = item % n_along
+    else:
+        band = item // (16 * n_along); rem = item - band * 16 * n_along
+        bw = np.minimum(16, n_lines - band * 16)
+        sa = rem // bw
+    life = wt[sel, 0].astype(np.float64) / 2100.0
+    print(name, "wave lifetime (us) by segment along the filter: ", " ".join(f"{int(k)}:{life[sa == k].mean():.1f}/{life[sa == k].max():.1f}" for k in np.unique(sa)))
