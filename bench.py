@@ -307,7 +307,8 @@ def main():
         td = time.perf_counter() - td
         sd = ctx.frame_stats()
         dynamic = {"ms_per_frame": round(1e3 * td / n_dyn, 4), "mpixels_per_s": round(w * h * n_dyn / td / 1e6, 1),
-                   "host_record_us": round(1e3 * sd.ms_host_record, 1), "host_launch_us": round(1e3 * sd.ms_host_launch, 1),
+                   "host_record_us": round(1e3 * sd.ms_host_record, 1), "host_upload_prep_us": round(1e3 * sd.ms_host_upload, 1),
+                   "host_launch_us": round(1e3 * sd.ms_host_launch, 1),
                    "note": "scene tree walked, decomposed and uploaded every frame (the drop-in's per-frame cost); `value` replays resident records"}
         # ... and the RETAINED path (fdh_scene_*): the tree lives in the context, one rectangle moves per frame, only its root
         # (and the two roots holding blur nodes) is decomposed again, every other root's records are spliced from the cache

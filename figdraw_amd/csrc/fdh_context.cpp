@@ -1264,7 +1264,28 @@ void Context::submit(bool upload) {
     }
     std::memcpy(s + o_pf, pf.data(), b_pf);
     for (size_t i = 0; i < blurs_.size(); i++)
-      if (o_mxh[i]) { build_mx_weights(blurs_[i].taps, false, s + o_mxh[i]); build_mx_weights(blurs_[i].taps, true, s + o_mxv[i]); }
+      if (o_mxh[i]) {
+        // the fragments depend on the filter alone: an animation blurs with the same radii frame after frame, and building
+        // the four tables of the bench frame took 35 of the 54 us this function spent before its first launch
+        const BlurTaps& t = blurs_[i].taps;
+        const size_t bh = mx_table_bytes(mx_nk(t.reach, false)), bv = mx_table_bytes(mx_nk(t.reach, true));
+        const MxTables* hit = nullptr;
+        for (const MxTables& c : mx_cache_)
+          if (c.reach == t.reach && std::memcmp(c.dense.data(), t.dense + kBlurPad, sizeof(float) * (2 * t.reach + 1)) == 0) { hit = &c; break; }
+        if (!hit) {
+          if (mx_cache_.size() >= 8) mx_cache_.erase(mx_cache_.begin());
+          MxTables c;
+          c.reach = t.reach;
+          c.dense.assign(t.dense + kBlurPad, t.dense + kBlurPad + 2 * t.reach + 1);
+          c.h.resize(bh); c.v.resize(bv);
+          build_mx_weights(t, false, c.h.data());
+          build_mx_weights(t, true, c.v.data());
+          mx_cache_.push_back(std::move(c));
+          hit = &mx_cache_.back();
+        }
+        std::memcpy(s + o_mxh[i], hit->h.data(), bh);
+        std::memcpy(s + o_mxv[i], hit->v.data(), bv);
+      }
     void* s_dev = nullptr;
     FDH_HIP(hipHostGetDevicePointer(&s_dev, s, 0));
     // Only what differs from the block the device already holds travels: after an edit of a retained scene (or between two

@@ -281,6 +281,8 @@ class Context {
   bool order_valid_ = false;
   // three pinned staging buffers in rotation, each guarded by an event recorded after its copies: the host builds
   // frame N+1 and N+2 while frame N still runs (a single buffer forced a stream sync per frame)
+  struct MxTables { int reach; std::vector<float> dense; std::vector<uint8_t> h, v; };  // k_blur_mx weight fragments of one filter
+  std::vector<MxTables> mx_cache_;
   static constexpr int kStaging = 3;
   PinnedBuf<uint8_t> staging_[kStaging];
   std::vector<uint8_t> shadow_;       // host copy of what the device's frame block holds (submit: upload only what differs)
