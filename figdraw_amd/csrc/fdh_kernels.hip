@@ -563,7 +563,8 @@ __device__ __forceinline__ void blend(F4& F, float r, float g, float b, float sa
   F.z = __builtin_rintf(__builtin_fmaf(F.z, ia, b * A));
   F.w = __builtin_rintf(__builtin_fmaf(F.w, ia, A));
 }
-// the same blend with the source term (rgb * 255 sa, 255 sa) and 1 - sa already formed: two packed FMAs per pixel
+// the same blend with the source term (rgb * 255 sa, 255 sa) and 1 - sa already formed: four FMAs per pixel (written on
+// float2 pairs for packed FMAs once; the library is built without packed-FP32 instructions, see csrc/Makefile)
 __device__ __forceinline__ void blend_pre(F4& F, f2 c_rg, f2 c_ba, float ia) {
   f2 xy = {F.x, F.y}, zw = {F.z, F.w};
   const f2 ia2 = {ia, ia};
@@ -837,8 +838,8 @@ __device__ unsigned long long g_counters[64];
 #else
 #define FDH_COUNT(i) do { } while (0)
 #endif
-// kSlow = false is the build for phases made only of axis-aligned SDF draws, clips and rect masks (no atlas sampling,
-// no rotated quads, no bezier strokes): without the one-pixel-slot path the kernel needs no scratch and fits 5 waves/SIMD.
+// The builds without the one-pixel-slot path (phases made only of axis-aligned SDF draws, clips, axis-aligned atlas quads:
+// no rotated quads, no bezier strokes, no rect-mask setup) need no scratch: 80 - 96 VGPRs, five or six waves per SIMD.
 #ifndef FDH_EDGE_CHECK
 #define FDH_EDGE_CHECK 0  // experiment builds only: every packed edge strip is also shaded by the generic path and compared
 #endif
@@ -1539,7 +1540,7 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? 4 : kPaths == 4 ? FDH_UNIFORM_WA
 // blur.frag takes 17 bilinear taps at i*step px.  The step is constant, so tap i has the same bilinear fraction at
 // every pixel and the pass is a fixed FIR over integer offsets (BlurTaps, built on the host).  Each thread produces
 // FOUR consecutive outputs along the filter direction: every staged texel is unpacked once (4 x v_cvt_f32_ubyte)
-// and feeds up to four accumulators with packed FMAs, instead of being re-read and re-unpacked per tap.
+// and feeds up to four accumulators (float2 pairs: r, g and b, a), instead of being re-read and re-unpacked per tap.
 __device__ __forceinline__ void unpack2(uint32_t c, f2& rg, f2& ba) {
   rg.x = (float)(c & 255u);
   rg.y = (float)((c >> 8) & 255u);
@@ -1560,7 +1561,7 @@ __device__ __forceinline__ uint32_t pack2(f2 rg, f2 ba) {
 // empty machine; at NOUT = 2 four times as many waves each run a four times shorter chain).
 
 // One thread's kBlurOut consecutive outputs of the merged FIR.  `tex(j)` returns window texel j (output p sees it at
-// offset j - p - reach); every texel is unpacked once and feeds the accumulators with packed FMAs.  The first and last
+// offset j - p - reach); every texel is unpacked once and feeds the accumulators pair by pair.  The first and last
 // kBlurOut - 1 window texels reach only some of the outputs (the rest would multiply the zero padding of `dense`):
 // those two triangles are peeled with the in-range (p, j) pairs spelled out at compile time.
 template <int kBlurOut, typename Tex>
@@ -1732,7 +1733,7 @@ __global__ __launch_bounds__(64 * kVWaves) void k_blur_v(BlurParams P, const Dra
     F4 F = unpack255(P.dst[pix]);
     const float sa = b.w * k * alpha, A = 255.0f * sa;
     const f2 brg = {b.x, b.y};
-    blend_pre(F, brg * k * A, f2{b.z * k * A, A}, 1.0f - sa);  // = blend(F, b.rgb / 255, sa), two packed FMAs
+    blend_pre(F, brg * k * A, f2{b.z * k * A, A}, 1.0f - sa);  // = blend(F, b.rgb / 255, sa)
     P.dst[pix] = pack255(F);
   }
 }
@@ -2345,7 +2346,7 @@ static bool blur_small(const BlurParams& P) {
   return (long long)(P.x1 - P.x0) * (P.y1 - P.y0) < 384 * 1024;
 }
 // Outputs per thread for a large region: more outputs share each unpacked texel (4 converts per texel and n outputs
-// against the 2 * taps packed FMAs every output needs anyway), but the extent along the pass is cut into units of
+// against the 2 * taps pair FMAs every output needs anyway), but the extent along the pass is cut into units of
 // `quantum * n` and the last unit of every row / column runs with idle lanes.  3840 px in 512-px waves is 7.5 waves per row
 // (1/16 of the pass wasted); in 768-px waves it is exactly 5.  Cost model = padded extent x instructions per output.
 static int blur_pick_nout(int extent, int quantum, int reach) {
