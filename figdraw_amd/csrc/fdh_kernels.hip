@@ -816,13 +816,14 @@ __device__ __forceinline__ Src shade_one(const DrawRec* __restrict__ rp, const Q
 // One wavefront = one 32x8 pixel tile: lane l owns the 4 horizontally adjacent pixels x = tx0 + 4*(l&7) .. +3 of
 // row ty0 + (l>>3) -- i.e. four side-by-side 8x8 sub-tiles shaded in lock-step, so every record fetch, mode
 // dispatch and loop step is paid once per 256 pixels, loads/stores of the surface are 16 B per lane and a wave
-// reads or writes 8 full 128-byte lines.  A workgroup stacks 4 waves (32x32); 4 workgroups tile a 64x64 bin.
+// reads or writes 8 full 128-byte lines.  A workgroup is ONE wavefront; the sixteen strips of a 64x64 bin are sixteen
+// consecutive workgroups of an XCD.
 //
 // Axis-aligned SDF draws (fills, strokes, shadows, clip pushes, blur composites -- all but a handful of calls in
 // real scenes) take the 4-wide straight-line path.  Everything else goes through shade_one() one pixel slot at a
 // time; the per-lane state arrays are rotated between slots so they are only ever indexed statically.
 #ifndef FDH_TIMING
-#define FDH_TIMING 0  // `make variant DEFS="-DFDH_STATS=1 -DFDH_TIMING=1"`: per-wave phase times (100 MHz ticks) instead of counts
+#define FDH_TIMING 0  // `make variant SINGLE=1 DEFS="-DFDH_STATS=1 -DFDH_TIMING=1"`: per-wave phase times (shader cycles) instead of counts
 #endif
 #if FDH_TIMING
 #define FDH_NOW() clock64()
