@@ -1203,7 +1203,7 @@ void Context::submit(bool upload) {
     for (size_t i = 0; i < phases_.size(); i++) pf[i] = phases_[i].first;
     pf[phases_.size()] = (int)n;
     auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
-    const size_t b_recs = n * sizeof(DrawRec), b_ext = exts_.size() * sizeof(QuadExt), b_bb = n * sizeof(BBox), b_pf = pf.size() * sizeof(int);
+    const size_t b_recs = n * sizeof(DrawRec), b_ext = exts_.size() * sizeof(QuadExt), b_bb = n * sizeof(BinRec), b_pf = pf.size() * sizeof(int);
     const size_t b_box = ((n + 3) & ~(size_t)3) * sizeof(uint32_t);
     const size_t n_chunks = (n + 255) / 256, b_chunk = std::max<size_t>(n_chunks, 1) * sizeof(uint32_t);
     const size_t o_recs = 0, o_ext = up(o_recs + b_recs), o_bb = up(o_ext + b_ext), o_box = up(o_bb + b_bb), o_chunk = up(o_box + b_box),
@@ -1220,7 +1220,7 @@ void Context::submit(bool upload) {
     d_frame_.reserve(total);
     dv_.recs = reinterpret_cast<DrawRec*>(d_frame_.ptr + o_recs);
     dv_.exts = reinterpret_cast<QuadExt*>(d_frame_.ptr + o_ext);
-    dv_.bboxes = reinterpret_cast<BBox*>(d_frame_.ptr + o_bb);
+    dv_.binrecs = reinterpret_cast<BinRec*>(d_frame_.ptr + o_bb);
     dv_.phase_first = reinterpret_cast<int*>(d_frame_.ptr + o_pf);
     dv_.binbox = reinterpret_cast<uint32_t*>(d_frame_.ptr + o_box);
     dv_.chunkbox = reinterpret_cast<uint32_t*>(d_frame_.ptr + o_chunk);
@@ -1235,7 +1235,36 @@ void Context::submit(bool upload) {
     uint8_t* s = staging_[slot].ptr;
     if (b_recs) std::memcpy(s + o_recs, recs_.data(), b_recs);
     if (b_ext) std::memcpy(s + o_ext, exts_.data(), b_ext);
-    if (b_bb) std::memcpy(s + o_bb, bboxes_.data(), b_bb);
+    {  // what the bin kernel reads of a draw: bounds, saturated core, and the bin-independent part of its list entries
+      BinRec* br = reinterpret_cast<BinRec*>(s + o_bb);
+      for (size_t i = 0; i < n; i++) {
+        const DrawRec& r = recs_[i];
+        const uint32_t om = r.op_mode, op = (om >> 12) & 15u, mode = om & 255u, fill_mode = (om >> 9) & 7u;
+        const bool atlas_mode = mode == 0u || (mode >= 13u && mode <= 16u);
+        const bool sdf = !(om & F_GENERAL) && !atlas_mode && mode < 18u && (op == OP_DRAW || op == OP_MASK_PUSH);
+        const uint32_t ell = (om & F_ELLIP) ? 4u : 0u;
+        uint32_t flags = 0;
+        if (sdf) {
+          flags |= BR_HAS_CORE;
+          if (op == OP_DRAW && (mode == 9u || mode == 11u || mode == 12u)) {
+            flags |= BR_CORE_REMOVED;  // the stroke's interior, or so deep inside an inner shadow that no 8-bit channel moves
+            if ((om & F_SOLID) && fill_mode == 0u && mode != 11u) flags |= ((mode == 9u ? 3u : 4u) + ell) << LE_PATH_SHIFT;
+          } else {
+            if (op == OP_DRAW && (om & F_SOLID) && fill_mode == 0u && mode != 17u) {
+              flags |= LE_PLAIN;
+              const uint32_t code = mode == 3u ? 1u : mode == 7u ? 2u : 0u;
+              if (code) flags |= (code + ell) << LE_PATH_SHIFT;
+            }
+            if (op == OP_DRAW && mode == 3u) {
+              uint32_t a = r.col[0] & r.col[1] & r.col[2] & r.col[3];
+              if (fill_mode != 0u) a &= r.mid & r.stop;
+              if ((a >> 24) == 255u) flags |= LE_OPAQUE;
+            }
+          }
+        }
+        br[i] = BinRec{bboxes_[i], r.ix0, r.iy0, r.ix1, r.iy1, flags, 0u};
+      }
+    }
     {  // bin boxes (what k_bin_draws scans): 7-bit inclusive bounds in bin units, upper bounds complemented
       uint32_t* bxp = reinterpret_cast<uint32_t*>(s + o_box);
       binbox_shift_ = (bins_x_ > 128 || bins_y_ > 128) ? 1 : 0;
@@ -1383,7 +1412,7 @@ void Context::launch_frame(bool profile) {
   auto span_end = [&]() { if (profile) { if (!launch_events_used()) spans_.pop_back(); set_launch_events(nullptr, nullptr); } };
   span_begin(0);
   BinParams B;
-  B.bbox = dv_.bboxes; B.draws = dv_.recs; B.binbox = dv_.binbox; B.chunkbox = dv_.chunkbox; B.n_draws = (int)recs_.size(); B.binbox_shift = binbox_shift_; B.lists = d_lists_.ptr; B.counts = d_counts_.ptr; B.phase_first = dv_.phase_first;
+  B.binrec = dv_.binrecs; B.binbox = dv_.binbox; B.chunkbox = dv_.chunkbox; B.n_draws = (int)recs_.size(); B.binbox_shift = binbox_shift_; B.lists = d_lists_.ptr; B.counts = d_counts_.ptr; B.phase_first = dv_.phase_first;
   B.n_phases = np; B.bins_x = bins_x_; B.bins_y = bins_y_; B.stride = list_stride_;
   launch_bin(stream_, B);
   span_end();

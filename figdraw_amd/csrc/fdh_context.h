@@ -273,7 +273,7 @@ class Context {
   // records, quad extensions, bounding boxes and phase offsets of a frame live in ONE device block and arrive with ONE
   // copy (four small hipMemcpyAsync calls cost the host ~100 us per frame); the typed views point into it
   DeviceBuf<uint8_t> d_frame_;
-  struct View { DrawRec* recs = nullptr; QuadExt* exts = nullptr; BBox* bboxes = nullptr; int* phase_first = nullptr; uint32_t* binbox = nullptr; uint32_t* chunkbox = nullptr; } dv_;
+  struct View { DrawRec* recs = nullptr; QuadExt* exts = nullptr; BinRec* binrecs = nullptr; int* phase_first = nullptr; uint32_t* binbox = nullptr; uint32_t* chunkbox = nullptr; } dv_;
   DeviceBuf<uint2> d_lists_;
   DeviceBuf<uint32_t> d_counts_;
   DeviceBuf<int> d_order_[2];  // phase 0's bins, longest list first: read by this frame's launch / written for the next

@@ -7,8 +7,7 @@
 namespace fdh {
 
 struct BinParams {
-  const BBox* bbox;     // per draw, clipped pixel bounds (ops that must reach every tile carry the frame)
-  const DrawRec* draws; // op_mode and the saturated core of the draws that hit a bin
+  const BinRec* binrec;  // per draw: clipped pixel bounds (ops that must reach every tile carry the frame), saturated core, entry flags
   const uint32_t* binbox; // per draw: x0 | y0 << 8 | (127 - x1) << 16 | (127 - y1) << 24 in (64 << binbox_shift)-px units, padded to 4 draws
   const uint32_t* chunkbox;  // per 256 draws: byte-wise min of their bin boxes = the union box, same format
   int n_draws, binbox_shift;

@@ -277,15 +277,6 @@ __device__ __forceinline__ uint32_t strip_mask_inside(int x0, int y0, int x1, in
 }
 
 // List entry flags (uint2.x high bits; the low 30 bits are the draw index)
-constexpr uint32_t LE_PLAIN = 1u << 31;  // axis-aligned SDF draw with ONE colour: on its core strips it is a uniform blend
-constexpr uint32_t LE_OPAQUE = 1u << 30;  // a fill whose source alpha is 255 everywhere: on its core strips it REPLACES the surface
-// bits 26..29: which straight-line shading path the draw's EDGE strips can take, decided here so that the compositor
-// branches on the list entry (already in an SGPR) and fetches the record once, instead of fetching the mode word, waiting,
-// decoding it and only then fetching the rest.  0: the general path; 1..4: one colour, no gradient, OP_DRAW, mode 3 / 7 / 9 /
-// 12 with circular corners; 5..8: the same with elliptical corners
-constexpr int LE_PATH_SHIFT = 26;
-constexpr uint32_t LE_INDEX = (1u << LE_PATH_SHIFT) - 1u;
-
 // One WAVEFRONT per (phase, bin): ordered stream compaction of the phase's draws that touch the bin.  An entry is
 // {draw index | flags, strips touched (16 bits) | strips inside the draw's saturated core (16 bits)}; strips where an
 // annular stroke is provably invisible (its core) are dropped from the entry, and the entry with them if none is left.
@@ -301,34 +292,19 @@ constexpr uint32_t LE_INDEX = (1u << LE_PATH_SHIFT) - 1u;
 #if FDH_TU == 0
 __device__ __forceinline__ bool binbox_hits(uint32_t q, uint32_t U) { return ((U - q) & 0x80808080u) == 0x80808080u; }
 __device__ __forceinline__ void bin_entry(const BinParams& P, int i, int x0, int y0, bool& hit, uint32_t& word, uint32_t& strips) {
-  const BBox b = P.bbox[i];
+  const BinRec r = P.binrec[i];
+  const BBox b = r.box;
   if (!(b.x0 < x0 + kBin && b.x1 > x0 && b.y0 < y0 + kBin && b.y1 > y0)) { hit = false; return; }  // exact test
   strips = strip_mask(b.x0 - x0, b.y0 - y0, b.x1 - x0, b.y1 - y0);
-  word = (uint32_t)i;
-  const DrawRec* r = P.draws + i;
-  const uint32_t om = r->op_mode, op = (om >> 12) & 15u, mode = om & 255u;
-  const bool atlas_mode = mode == 0u || (mode >= 13u && mode <= 16u);
-  const bool sdf = !(om & F_GENERAL) && !atlas_mode && mode < 18u && (op == OP_DRAW || op == OP_MASK_PUSH);
-  if (!sdf) return;
-  const uint32_t core = strip_mask_inside(r->ix0 - x0, r->iy0 - y0, r->ix1 - x0, r->iy1 - y0) & strips;
-  const uint32_t fill_mode = (om >> 9) & 7u;
-  if (op == OP_DRAW && (mode == 9u || mode == 11u || mode == 12u)) {
+  word = (uint32_t)i | (r.flags & ~LE_INDEX);
+  if (!(r.flags & BR_HAS_CORE)) return;
+  const uint32_t core = strip_mask_inside(r.ix0 - x0, r.iy0 - y0, r.ix1 - x0, r.iy1 - y0) & strips;
+  if (r.flags & BR_CORE_REMOVED) {
     strips &= ~core;  // alpha == 0 there (stroke interior) or too small to change an 8-bit channel (deep inside an inner shadow)
     hit = strips != 0u;
-    if ((om & F_SOLID) && fill_mode == 0u && mode != 11u) word |= ((mode == 9u ? 3u : 4u) + ((om & F_ELLIP) ? 4u : 0u)) << LE_PATH_SHIFT;
     return;
   }
   strips |= core << 16;
-  if (op == OP_DRAW && (om & F_SOLID) && fill_mode == 0u && mode != 17u) {
-    word |= LE_PLAIN;
-    const uint32_t code = mode == 3u ? 1u : mode == 7u ? 2u : 0u;  // (9 and 12 were tagged above)
-    if (code) word |= (code + ((om & F_ELLIP) ? 4u : 0u)) << LE_PATH_SHIFT;
-  }
-  if (op == OP_DRAW && mode == 3u) {
-    uint32_t a = r->col[0] & r->col[1] & r->col[2] & r->col[3];
-    if (fill_mode != 0u) a &= r->mid & r->stop;
-    if ((a >> 24) == 255u) word |= LE_OPAQUE;
-  }
 }
 __global__ __launch_bounds__(64) void k_bin_draws(BinParams P) {
   const int nb = P.bins_x * P.bins_y;

@@ -78,6 +78,23 @@ static_assert(sizeof(QuadExt) == 144, "QuadExt must be 144 bytes");
 
 struct alignas(8) BBox { int16_t x0, y0, x1, y1; };
 
+// What k_bin_draws needs of a draw, in one 24-byte piece (built on the host at submit): the clipped pixel bounds, the
+// saturated core, and the parts of a list entry that do not depend on the bin -- flags and path code in their entry
+// positions (bits 26..31: LE_PATH, LE_OPAQUE, LE_PLAIN), bit 0: the draw has a core worth testing (axis-aligned SDF draw or
+// clip push), bit 1: its core strips are REMOVED from the entry (stroke interiors, deep inside an inner shadow).  Before, a
+// hit walked bounds -> mode word -> core -> colours: three dependent round trips per batch of hits.
+struct alignas(8) BinRec { BBox box; int16_t ix0, iy0, ix1, iy1; uint32_t flags; uint32_t pad; };
+static_assert(sizeof(BinRec) == 24, "BinRec must be 24 bytes");
+constexpr uint32_t BR_HAS_CORE = 1u, BR_CORE_REMOVED = 2u;
+constexpr uint32_t LE_PLAIN = 1u << 31;  // axis-aligned SDF draw with ONE colour: on its core strips it is a uniform blend
+constexpr uint32_t LE_OPAQUE = 1u << 30;  // a fill whose source alpha is 255 everywhere: on its core strips it REPLACES the surface
+// bits 26..29: which straight-line shading path the draw's EDGE strips can take, decided on the host so that the
+// compositor branches on the list entry (already in an SGPR) and fetches the record once, instead of fetching the mode word, waiting,
+// decoding it and only then fetching the rest.  0: the general path; 1..4: one colour, no gradient, OP_DRAW, mode 3 / 7 / 9 /
+// 12 with circular corners; 5..8: the same with elliptical corners
+constexpr int LE_PATH_SHIFT = 26;
+constexpr uint32_t LE_INDEX = (1u << LE_PATH_SHIFT) - 1u;
+
 constexpr int kMaxBlurReach = 66;
 constexpr int kBlurPad = 15;  // >= (largest outputs-per-thread) - 1
 struct BlurTaps {  // merged FIR of blur.frag:19-29 for one radius: out = sum coef[k] * src[x + off[k]]
