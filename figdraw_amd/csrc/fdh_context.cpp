@@ -71,6 +71,7 @@ Context::~Context() {
   if (blur_tmp_) (void)hipFree(blur_tmp_);
   if (dbg_snap_) (void)hipFree(dbg_snap_);
   d_frame_.release(); d_lists_.release(); d_counts_.release(); d_order_[0].release(); d_order_[1].release();
+  glyph_a_.release(); glyph_b_.release(); glyph_lines_.release(); glyph_acc_.release();
   for (auto& b : staging_) b.release();
   for (auto& e : staging_ev_) if (e) (void)hipEventDestroy(e);
   if (own_stream_) (void)hipStreamDestroy(own_stream_);

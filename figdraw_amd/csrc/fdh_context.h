@@ -110,6 +110,8 @@ struct RetainedScene {
   float fw = 0, fh = 0, rgba[4] = {1, 1, 1, 1};
   bool clear = true;
   float ui_scale = 1.0f, aa = 0.0f;
+  bool subpixel = false, variants = false;  // the text front-end settings the cached records were made under
+  uint32_t table_epoch = 0, table_epoch_seen = 0;  // bumped when a glyph-variant table first appears (rebase_side)
   std::vector<RetainedLayer> layers;
   std::vector<FdhGlyph> glyphs;
   std::vector<int64_t> variant_ids;  // [glyphs][FDH_GLYPH_VARIANT_STEPS] or empty
@@ -266,6 +268,7 @@ class Context {
   RetainedScene retained_;
   uint64_t atlas_epoch_ = 1;
   void rebase_side(FdhFig* nodes, int n, const FdhScene* side);
+  void compact_side();
   bool host_only_ = false;  // FDH_CREATE_RECORD_ONLY
   bool rec_on_ = false, rec_first_ = true;
   std::string rec_;  // FDH_DEBUG_SNAP=1 (diagnostic): the surface as phase 0 left it, copied in-stream

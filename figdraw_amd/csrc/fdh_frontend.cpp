@@ -578,7 +578,12 @@ void Context::rebase_side(FdhFig* nodes, int n, const FdhScene* side) {
       const int base = (int)R.glyphs.size();
       R.glyphs.insert(R.glyphs.end(), side->glyphs + f.glyph_first, side->glyphs + f.glyph_first + f.glyph_count);
       if (!R.variant_ids.empty() || side->glyph_variant_ids) {
-        R.variant_ids.resize((size_t)base * FDH_GLYPH_VARIANT_STEPS, 0);
+        // glyphs retained before any variant table existed fall back to their own image, as the new-glyph branch below does.
+        // (The table's mere presence changes how renderText treats EVERY glyph under variant positioning -- key lookup with
+        // shift 0 instead of the fractional shift -- so records cached without it are stale: table_epoch.)
+        if (R.variant_ids.empty()) R.table_epoch++;
+        for (size_t g0 = R.variant_ids.size() / FDH_GLYPH_VARIANT_STEPS; g0 < (size_t)base; g0++)
+          for (int st = 0; st < FDH_GLYPH_VARIANT_STEPS; st++) R.variant_ids.push_back(R.glyphs[g0].image_id);
         for (int g = 0; g < f.glyph_count; g++)
           for (int st = 0; st < FDH_GLYPH_VARIANT_STEPS; st++)
             R.variant_ids.push_back(side->glyph_variant_ids ? side->glyph_variant_ids[(size_t)(f.glyph_first + g) * FDH_GLYPH_VARIANT_STEPS + st] : side->glyphs[f.glyph_first + g].image_id);
@@ -607,6 +612,73 @@ void Context::rebase_side(FdhFig* nodes, int n, const FdhScene* side) {
       f.op_first = base;
     }
   }
+}
+
+// An edit either lands whole or not at all: rebase_side appends to the retained side arrays before it has seen every node of
+// the edit, so a bad range found late must take the appended entries back.
+namespace {
+struct SideMark {
+  RetainedScene& R;
+  const size_t g, v, o, c, t;
+  bool keep = false;
+  explicit SideMark(RetainedScene& r) : R(r), g(r.glyphs.size()), v(r.variant_ids.size()), o(r.ops.size()), c(r.controls.size()), t(r.text_rects.size()) {}
+  ~SideMark() {
+    if (keep) return;
+    R.glyphs.resize(g); R.variant_ids.resize(v); R.ops.resize(o); R.controls.resize(c); R.text_rects.resize(t);
+  }
+};
+}  // namespace
+
+// Every update_nodes / replace_root appends the side entries of the new nodes and orphans those of the old ones; an animated
+// text or drawable node would grow the arrays without bound (and n_glyphs past int32).  When the live entries are less than
+// half of an array that has grown past a few thousand, the arrays are rebuilt from the nodes that still reference them.  Node
+// ranges move, draw records do not depend on them: the per-root caches stay valid.
+void Context::compact_side() {
+  RetainedScene& R = retained_;
+  size_t live_g = 0, live_o = 0, live_t = 0;
+  for (const RetainedLayer& D : R.layers)
+    for (const FdhFig& f : D.nodes) { live_g += (size_t)std::max(f.glyph_count, 0); live_o += (size_t)std::max(f.op_count, 0); live_t += (size_t)std::max(f.text_rect_count, 0); }
+  auto bloated = [](size_t live, size_t have) { return have > 4096 && live * 2 < have; };
+  if (!bloated(live_g, R.glyphs.size()) && !bloated(live_o, R.ops.size()) && !bloated(live_t, R.text_rects.size())) return;
+  std::vector<FdhGlyph> glyphs;
+  std::vector<int64_t> variants;
+  std::vector<FdhDrawOp> ops;
+  std::vector<float> controls;
+  std::vector<FdhTextRect> rects;
+  const bool has_var = !R.variant_ids.empty();
+  for (RetainedLayer& D : R.layers)
+    for (FdhFig& f : D.nodes) {
+      if (f.glyph_count > 0 && f.glyph_first >= 0 && (size_t)f.glyph_first + (size_t)f.glyph_count <= R.glyphs.size()) {
+        const int base = (int)glyphs.size();
+        glyphs.insert(glyphs.end(), R.glyphs.begin() + f.glyph_first, R.glyphs.begin() + f.glyph_first + f.glyph_count);
+        if (has_var)
+          for (int g = f.glyph_first; g < f.glyph_first + f.glyph_count; g++)
+            for (int st = 0; st < FDH_GLYPH_VARIANT_STEPS; st++) {
+              const size_t at = (size_t)g * FDH_GLYPH_VARIANT_STEPS + st;
+              variants.push_back(at < R.variant_ids.size() ? R.variant_ids[at] : R.glyphs[(size_t)g].image_id);
+            }
+        f.glyph_first = base;
+      } else if (f.glyph_count > 0) f.glyph_count = 0;
+      if (f.text_rect_count > 0 && f.text_rect_first >= 0 && (size_t)f.text_rect_first + (size_t)f.text_rect_count <= R.text_rects.size()) {
+        const int base = (int)rects.size();
+        rects.insert(rects.end(), R.text_rects.begin() + f.text_rect_first, R.text_rects.begin() + f.text_rect_first + f.text_rect_count);
+        f.text_rect_first = base;
+      } else if (f.text_rect_count > 0) f.text_rect_count = 0;
+      if (f.op_count > 0 && f.op_first >= 0 && (size_t)f.op_first + (size_t)f.op_count <= R.ops.size()) {
+        const int base = (int)ops.size();
+        for (int k = 0; k < f.op_count; k++) {
+          FdhDrawOp op = R.ops[(size_t)(f.op_first + k)];
+          if (op.ctrl_count > 0 && op.ctrl_first >= 0 && 2 * ((size_t)op.ctrl_first + (size_t)op.ctrl_count) <= R.controls.size()) {
+            const int cb = (int)(controls.size() / 2);
+            controls.insert(controls.end(), R.controls.begin() + 2 * op.ctrl_first, R.controls.begin() + 2 * (op.ctrl_first + op.ctrl_count));
+            op.ctrl_first = cb;
+          } else op.ctrl_count = 0;
+          ops.push_back(op);
+        }
+        f.op_first = base;
+      } else if (f.op_count > 0) f.op_count = 0;
+    }
+  R.glyphs.swap(glyphs); R.variant_ids.swap(variants); R.ops.swap(ops); R.controls.swap(controls); R.text_rects.swap(rects);
 }
 
 void Context::scene_retain(const FdhScene* scene, float fw, float fh, bool clear, const float rgba[4]) {
@@ -654,12 +726,17 @@ void Context::scene_update_nodes(int layer, int first, int count, const FdhFig* 
   // the roots above the range before the edit (a node may change its parent) ...
   std::vector<int> before = roots_of(D);
   std::vector<FdhFig> fresh(nodes, nodes + count);
-  rebase_side(fresh.data(), count, side);
+  {
+    SideMark mark(R);  // a bad side range throws out of rebase_side: the entries it had appended go with it
+    rebase_side(fresh.data(), count, side);
+    mark.keep = true;
+  }
   std::copy(fresh.begin(), fresh.end(), D.nodes.begin() + first);
   std::vector<int> after = roots_of(D);  // ... and after it
   for (size_t s = 0; s < D.roots.size(); s++)
     for (int i = first; i < first + count; i++)
       if (before[(size_t)i] == D.roots[s] || after[(size_t)i] == D.roots[s]) { D.cache[s].dirty = true; break; }
+  compact_side();
 }
 
 void Context::scene_replace_root(int layer, int slot, const FdhFig* subtree, int n, const FdhScene* side, bool insert) {
@@ -672,32 +749,48 @@ void Context::scene_replace_root(int layer, int slot, const FdhFig* subtree, int
   if (n > 0 && subtree[0].parent >= 0) throw Error(FDH_ERR_INVALID, "scene_replace_root: the subtree's first node must be its root (parent -1)");
   for (int i = 1; i < n; i++)
     if (subtree[i].parent < 0 || subtree[i].parent >= i) throw Error(FDH_ERR_INVALID, "scene_replace_root: subtree parents must precede their children");
-  if (D.nodes.size() + (size_t)n > 32767u + (insert ? 0u : 32767u)) {}  // (checked after the removal below)
+  // Everything that can fail happens BEFORE the retained layer is touched: the node budget, and the re-basing of the new
+  // nodes' side ranges (into a copy; what it appended to the side arrays is taken back if it throws).  A failed call leaves
+  // the scene exactly as it was.
+  std::vector<int> ro;
+  size_t kept_count = D.nodes.size();
+  int old_root = -1;
+  if (!insert) {
+    ro = roots_of(D);
+    old_root = D.roots[(size_t)slot];
+    kept_count = 0;
+    for (size_t i = 0; i < D.nodes.size(); i++) if (ro[i] != old_root) kept_count++;
+  }
+  if (kept_count + (size_t)n > 32767u) throw Error(FDH_ERR_INVALID, "scene_replace_root: more than 32767 nodes in a layer (FigIdx is int16, fignodes.nim:119)");
+  std::vector<FdhFig> fresh;
+  if (n > 0) {
+    fresh.assign(subtree, subtree + n);
+    SideMark mark(R);
+    rebase_side(fresh.data(), n, side);
+    mark.keep = true;
+  }
+  // ---- commit (nothing below throws but std::bad_alloc)
   if (!insert) {  // drop the old subtree, compacting the node array
-    const std::vector<int> ro = roots_of(D);
-    const int old_root = D.roots[(size_t)slot];
     std::vector<int> remap(D.nodes.size(), -1);
     std::vector<FdhFig> kept;
-    kept.reserve(D.nodes.size());
+    kept.reserve(kept_count + (size_t)n);
     for (size_t i = 0; i < D.nodes.size(); i++)
       if (ro[i] != old_root) { remap[i] = (int)kept.size(); kept.push_back(D.nodes[i]); }
     for (FdhFig& f : kept) if (f.parent >= 0) f.parent = remap[(size_t)f.parent];
     for (size_t s = 0; s < D.roots.size(); s++) if ((int)s != slot) D.roots[s] = remap[(size_t)D.roots[s]];
     D.nodes.swap(kept);
-    if (n == 0) { D.roots.erase(D.roots.begin() + slot); D.cache.erase(D.cache.begin() + slot); return; }
+    if (n == 0) { D.roots.erase(D.roots.begin() + slot); D.cache.erase(D.cache.begin() + slot); compact_side(); return; }
   } else {
     if (n == 0) return;
     D.roots.insert(D.roots.begin() + slot, 0);
     D.cache.insert(D.cache.begin() + slot, RetainedRoot{});
   }
-  if (D.nodes.size() + (size_t)n > 32767u) throw Error(FDH_ERR_INVALID, "scene_replace_root: more than 32767 nodes in a layer (FigIdx is int16, fignodes.nim:119)");
   const int base = (int)D.nodes.size();
-  std::vector<FdhFig> fresh(subtree, subtree + n);
-  rebase_side(fresh.data(), n, side);
   for (int i = 1; i < n; i++) fresh[(size_t)i].parent += base;
   D.nodes.insert(D.nodes.end(), fresh.begin(), fresh.end());
   D.roots[(size_t)slot] = base;
   D.cache[(size_t)slot] = RetainedRoot{};
+  compact_side();
 }
 
 void Context::scene_render() {
@@ -705,8 +798,13 @@ void Context::scene_render() {
   if (!R.valid) throw Error(FDH_ERR_INVALID, "scene_render: no retained scene (fdh_scene_retain first)");
   const float w = R.fw * ui_scale_, h = R.fh * ui_scale_;
   if (w <= 0.0f || h <= 0.0f) return;
-  const bool config_changed = R.ui_scale != ui_scale_ || R.aa != aa_;  // every cached record depends on these
-  R.ui_scale = ui_scale_; R.aa = aa_;
+  // every cached record depends on these front-end settings (the text path snaps glyph positions and picks shifts / variant
+  // images by the two sub-pixel switches, figrender.nim:464-476)
+  const bool config_changed = R.ui_scale != ui_scale_ || R.aa != aa_ || R.subpixel != subpixel_enabled_ || R.variants != subpixel_variants_ ||
+                              R.table_epoch != R.table_epoch_seen;
+  R.ui_scale = ui_scale_; R.aa = aa_; R.subpixel = subpixel_enabled_; R.variants = subpixel_variants_; R.table_epoch_seen = R.table_epoch;
+  for (const RetainedLayer& D : R.layers)
+    for (int r : D.roots) if (r < 0 || (size_t)r >= D.nodes.size()) throw Error(FDH_ERR_INVALID, "scene_render: root index out of range");
   std::vector<FdhLayer> views(R.layers.size());
   for (size_t l = 0; l < R.layers.size(); l++) {
     RetainedLayer& D = R.layers[l];

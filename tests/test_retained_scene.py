@@ -193,6 +193,136 @@ def test_bad_edits_are_rejected():
     ctx.close()
 
 
+def _text_scene(n_glyphs=6, variants=False, x0=10.3):
+    from figdraw_amd.scene import Glyph, TextRect
+
+    r = Renders()
+    r.addRoot(0, Fig(kind=FigKind.nkRectangle, screenBox=rect(0, 0, 256, 128), fill=rgba(240, 240, 240, 255)))
+    gl = [Glyph(image_id=7, x=x0 + 9.37 * i, y=2.0, subpixel_shift=-1.0, variant_ids=[100 + k for k in range(10)] if variants else None) for i in range(n_glyphs)]
+    r.addRoot(0, Fig(kind=FigKind.nkText, screenBox=rect(20, 30, 200, 30), glyphs=gl, textRects=[TextRect(1.0, 20.0, 50.0, 2.0, kind=1, fill=fill(rgba(200, 0, 0, 255)))]))
+    r.addRoot(0, Fig(kind=FigKind.nkRectangle, screenBox=rect(30, 80, 60, 20), fill=rgba(10, 60, 200, 255), corners=[4] * 4))
+    return r
+
+
+def _text_ctx():
+    ctx = HipContext(atlas_size=256, record_only=True)
+    img = np.zeros((10, 8, 4), np.uint8)
+    for k in [7] + [100 + k for k in range(10)]:
+        ctx.put_image(k, img)
+    return ctx
+
+
+def _fresh_text_digest(scene, subpixel, variants):
+    ctx = _text_ctx()
+    ctx.set_text_subpixel(subpixel, 0.0, glyph_variants=variants)
+    ctx.render_frame(scene, 256, 128)
+    d = ctx.record_digest()
+    ctx.close()
+    return d
+
+
+def test_text_settings_invalidate_the_per_root_cache():
+    """fdh_set_text_subpixel_* between two fdh_scene_render calls: the text roots' cached records were made under the old
+    settings (glyph snapping, shift, variant keys -- figrender.nim:464-476) and must be decomposed again"""
+    sc = _text_scene(variants=True)
+    ctx = _text_ctx()
+    ctx.scene_retain(sc, 256, 128)
+    seen = set()
+    for subpixel, variants in ((False, False), (True, False), (True, True), (False, False)):
+        ctx.set_text_subpixel(subpixel, 0.0, glyph_variants=variants)
+        ctx.scene_render()
+        assert ctx.record_digest() == _fresh_text_digest(sc, subpixel, variants), (subpixel, variants)
+        seen.add(ctx.record_digest())
+    assert len(seen) == 3  # the three settings really give three different record streams
+    ctx.close()
+
+
+def test_variant_ids_arriving_late_fall_back_to_the_glyphs_own_image():
+    """a retained scene without variant ids, then an update whose side arrays bring some: the OLD glyphs must keep drawing
+    their own image under glyph-variant positioning (they were back-filled with key 0 = a missing image once)"""
+    base = _text_scene(variants=False)
+    ctx = _text_ctx()
+    ctx.set_text_subpixel(True, 0.0, glyph_variants=True)
+    ctx.scene_retain(base, 256, 128)
+    lst_old = next(iter(base.layers.values()))
+    newer = _text_scene(variants=True, x0=31.7)
+    lst_new = next(iter(newer.layers.values()))
+    extra = copy.deepcopy(lst_new.nodes[1])
+    extra.screenBox = rect(20, 70, 200, 30)
+    ctx.scene_insert_root(0, 3, [extra])
+    ctx.scene_render()
+    # the same tree built in one go: old glyphs without ids, new glyphs with ids (to_c fills the gaps with image_id)
+    whole = _text_scene(variants=False)
+    next(iter(whole.layers.values())).addRoot(copy.deepcopy(extra))
+    assert ctx.record_digest() == _fresh_text_digest(whole, True, True)
+    # every text root was decomposed again (the table's appearance changes how all glyphs are treated) ...
+    assert ctx.scene_stats()[0] >= 2
+    # ... and a later property edit of the OLD text node still finds its glyphs' fallback keys (7, never 0 = a missing image)
+    old = lst_old.nodes[1]
+    old.screenBox = rect(22, 30, 200, 30)
+    ctx.scene_update_nodes(0, 1, [old])
+    ctx.record_begin()
+    ctx.scene_render()
+    keys = [c[1] for c in ctx.record_calls() if c[0] == "draw_image"]
+    assert keys == [7] * 6
+    ctx.close()
+
+
+def test_failed_structural_edit_leaves_the_scene_untouched():
+    """fdh_scene_replace_root / insert_root with a bad side range (or over the node budget) must fail BEFORE anything is
+    committed: same digest afterwards, same roots walked, and further edits still work"""
+    from figdraw_amd.context import FigdrawHipError
+    import ctypes as C
+
+    sc = _text_scene()
+    ctx = _text_ctx()
+    ctx.scene_retain(sc, 256, 128)
+    want = ctx.record_digest()
+    lst = next(iter(sc.layers.values()))
+    good = copy.deepcopy(lst.nodes[1])
+    cs, ptr, n, side = ctx._marshal_nodes([good])
+    nodes = C.cast(ptr, C.POINTER(type(cs.struct.layers[0].nodes[0])))
+    nodes[0].glyph_first = 3
+    nodes[0].glyph_count = 1000  # past the side arrays
+    for call in (ctx.L.fdh_scene_replace_root, ctx.L.fdh_scene_insert_root):
+        assert call(ctx.h, 0, 1, ptr, n, side) == -1
+        ctx.scene_render()
+        assert ctx.record_digest() == want
+        assert ctx.scene_stats()[0] == 0  # nothing was marked dirty, no root was dropped or added
+    nodes[0].glyph_count = 2  # and the same call with a valid range goes through
+    assert ctx.L.fdh_scene_replace_root(ctx.h, 0, 1, ptr, n, side) == 0
+    ctx.scene_render()
+    assert ctx.scene_stats() == (1, 2)
+    # node budget: 32767 nodes per layer (FigIdx is int16)
+    big = [copy.deepcopy(lst.nodes[2]) for _ in range(32767)]
+    for i, f in enumerate(big):
+        f.parent = -1 if i == 0 else 0
+    d0 = ctx.record_digest()
+    with pytest.raises(FigdrawHipError):
+        ctx.scene_insert_root(0, 0, big)
+    ctx.scene_render()
+    assert ctx.record_digest() == d0 and sum(ctx.scene_stats()) == 3
+    ctx.close()
+
+
+def test_animated_text_node_does_not_grow_the_side_arrays():
+    """every update appends the new node's glyphs / text rects to the retained side arrays; they are compacted once dead
+    entries dominate, and the records stay those of a fresh render"""
+    ctx = _text_ctx()
+    sc = _text_scene(n_glyphs=40)
+    ctx.scene_retain(sc, 256, 128)
+    lst = next(iter(sc.layers.values()))
+    for step in range(300):  # 300 x 40 glyphs appended = 12 000 > the 4096-entry threshold, 40 live
+        node = lst.nodes[1]
+        node.screenBox = rect(20 + (step % 7), 30, 200, 30)
+        ctx.scene_update_nodes(0, 1, [node])
+        if step % 60 == 59:
+            ctx.scene_render()
+            assert ctx.record_digest() == _fresh_text_digest(sc, False, False), step
+            assert ctx.scene_stats() == (1, 2)
+    ctx.close()
+
+
 @pytest.mark.gpu
 def test_retained_scene_pixels_equal_full_render():
     """GPU: after each edit the retained context's frame equals a full fdh_render_frame of the edited tree, bit for bit"""

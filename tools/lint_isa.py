@@ -11,7 +11,8 @@ Second check: k_composite_tiles<0|2|4> are compiled with -structurizecfg-skip-un
 fdh_kernels.hip), which is only sound while its draw loop nest holds no divergent branch.  The loop nest -- every backward
 branch whose range holds the draw loop's s_ff1_i32_b64 -- must therefore not write the exec mask.
 
-usage: lint_isa.py <library.so> [--allow-packed]   exit status 1 if a forbidden opcode is present"""
+usage: lint_isa.py <library.so> [--allow-packed] [--allow-missing]   exit status 1 if a forbidden opcode is present, a uniform-build
+kernel writes exec inside its draw loop, or one of those kernels is not in the library at all"""
 import re
 import struct
 import subprocess
@@ -42,7 +43,9 @@ def code_objects(blob: bytes):
 
 
 UNIFORM_KERNELS = ("k_composite_tilesILi4E", "k_composite_tilesILi0E", "k_composite_tilesILi2E")
-EXEC_WRITE = re.compile(r"^\s*(s_\w*saveexec\w*|s_\w+\s+exec(_lo|_hi)?\b)")
+# writes of the exec mask: s_*saveexec*, any scalar instruction whose destination is exec / exec_lo / exec_hi, and the VOPC
+# compares that write exec directly (v_cmpx_*)
+EXEC_WRITE = re.compile(r"^\s*(s_\w*saveexec\w*|s_\w+\s+exec(_lo|_hi)?\b|v_cmpx_\w+)")
 
 
 def exec_writes_in_draw_loop(lines):
@@ -167,6 +170,12 @@ def main():
         return 1
     print(f"lint_isa: {path}: {n_inst} lines of gfx950 disassembly, packed-FP32 instructions: {sum(sum(v.values()) for v in bad.values())}")
     rc = 0
+    # (a renamed or dropped kernel must not turn the check into a silent pass: the Makefile still compiles that unit with the switch)
+    missing = [uk for uk in UNIFORM_KERNELS if uk not in uniform_lines]
+    if missing and "--allow-missing" not in sys.argv:
+        print(f"lint_isa: kernels compiled with -structurizecfg-skip-uniform-regions not found in {path}: {missing} "
+              "(update UNIFORM_KERNELS in tools/lint_isa.py when the compositor's template arguments change)")
+        rc = 1
     for uk, lines in sorted(uniform_lines.items()):
         name = "k_composite_tiles<%s>" % uk[len("k_composite_tilesILi"):-1]
         w = exec_writes_in_draw_loop(lines)

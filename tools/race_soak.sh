@@ -5,7 +5,9 @@
 out=$1; lib=$2; shift 2
 export PYTHONUNBUFFERED=1
 [ -n "$lib" ] && export FIGDRAW_HIP_LIB=$lib
-echo "library: ${lib:-figdraw_amd/libfigdraw_hip.so}  ($(python3 tools/lint_isa.py ${lib:-figdraw_amd/libfigdraw_hip.so} --allow-packed | tail -1))" >> $out
+lint=$(python3 tools/lint_isa.py ${lib:-figdraw_amd/libfigdraw_hip.so} --allow-packed); lint_rc=$?
+echo "library: ${lib:-figdraw_amd/libfigdraw_hip.so}  ($(echo "$lint" | tail -1))  lint_isa exit status: $lint_rc" >> $out
+[ $lint_rc -ne 0 ] && echo "WARNING: lint_isa failed for this library (exec-mask write in a uniform build, or a kernel missing): results below are for a build the product Makefile would reject" | tee -a $out
 for spec in $*; do
   IFS=: read size nc iters mode <<< "$spec"
   t0=$(date +%s)
