@@ -37,7 +37,9 @@ class FrameStats(C.Structure):
                 ("bytes_algorithmic", C.c_int64), ("bytes_composite_main", C.c_int64), ("bytes_blur", C.c_int64),
                 ("fragments", C.c_int64), ("ms_host_record", C.c_float), ("ms_host_upload", C.c_float),
                 ("ms_host_launch", C.c_float), ("_reserved", C.c_float),
-                ("ms_blur_big_h", C.c_float), ("ms_blur_big_v", C.c_float), ("bytes_blur_big_h", C.c_int64), ("bytes_blur_big_v", C.c_int64)]
+                ("ms_blur_big_h", C.c_float), ("ms_blur_big_v", C.c_float), ("bytes_blur_big_h", C.c_int64), ("bytes_blur_big_v", C.c_int64),
+                ("fragments_main_by_mode", C.c_int64 * 4), ("fragments_main_elliptical", C.c_int64), ("fragments_main_other", C.c_int64),
+                ("flops_composite_main", C.c_int64)]
 
 
 def build(force: bool = False) -> str:
@@ -119,6 +121,7 @@ def load():
     L.fdh_record_json.restype = C.c_char_p
     L.fdh_frame_device_ptr.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int64)]
     L.fdh_sync.argtypes = [vp]
+    L.fdh_flush.argtypes = [vp]
     L.fdh_set_ui_scale.argtypes = [vp, C.c_float]
     L.fdh_render_frame.argtypes = [vp, vp, C.c_float, C.c_float, C.c_int, _F4]
     L.fdh_set_stripe.argtypes = [vp, C.c_int, C.c_int]
@@ -143,13 +146,17 @@ class HipContext:
     """One GPU, one HIP stream, one RGBA8 surface (newContext, glcontext.nim:255-261)."""
 
     RECORD_ONLY = 1  # FDH_CREATE_RECORD_ONLY
+    SYNC_SUBMIT = 2  # FDH_CREATE_SYNC_SUBMIT
 
-    def __init__(self, atlas_size: int = 1024, pixel_scale: float = 1.0, device: int = 0, record_only: bool = False):
+    def __init__(self, atlas_size: int = 1024, pixel_scale: float = 1.0, device: int = 0, record_only: bool = False,
+                 sync_submit: bool = False):
         """record_only: a call recorder -- the scene front-end and the atlas packer run, nothing is drawn and no GPU is
-        needed (the RecordingBackend of the reference's tests/ttransform.nim); see record_begin / record_calls."""
+        needed (the RecordingBackend of the reference's tests/ttransform.nim); see record_begin / record_calls.
+        sync_submit: end_frame prepares, uploads and launches on the calling thread instead of the context's submit thread."""
         self.L = load()
         h = C.c_void_p()
-        rc = self.L.fdh_create(C.byref(h), atlas_size, pixel_scale, device, self.RECORD_ONLY if record_only else 0)
+        rc = self.L.fdh_create(C.byref(h), atlas_size, pixel_scale, device,
+                               (self.RECORD_ONLY if record_only else 0) | (self.SYNC_SUBMIT if sync_submit else 0))
         if rc != 0:
             raise FigdrawHipError(rc, self.L.fdh_last_error().decode())
         self.h = h
@@ -262,6 +269,9 @@ class HipContext:
         self._ck(self.L.fdh_set_text_subpixel_glyph_variants(self.h, int(bool(glyph_variants))))
         self._ck(self.L.fdh_set_text_subpixel_shift(self.h, shift))
 
+    def set_text_subpixel_shift(self, shift: float):
+        self._ck(self.L.fdh_set_text_subpixel_shift(self.h, float(shift)))
+
     # ---- atlas
     def put_image(self, key, rgba: np.ndarray):
         rgba = np.ascontiguousarray(rgba, dtype=np.uint8)
@@ -349,6 +359,10 @@ class HipContext:
 
     def sync(self):
         self._ck(self.L.fdh_sync(self.h))
+
+    def flush(self):
+        """every submitted frame is enqueued on the stream (no wait for the GPU)"""
+        self._ck(self.L.fdh_flush(self.h))
 
     def set_stream(self, stream_ptr: Optional[int]):
         self._ck(self.L.fdh_set_stream(self.h, C.c_void_p(stream_ptr or 0)))

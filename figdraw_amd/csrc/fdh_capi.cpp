@@ -191,6 +191,7 @@ int fdh_debug_read_surface(FdhContext* c, int which, uint8_t* out) {
   });
 }
 int fdh_sync(FdhContext* c) { return guard([&] { C(c)->sync(); }); }
+int fdh_flush(FdhContext* c) { return guard([&] { C(c)->flush(); }); }
 int fdh_set_ui_scale(FdhContext* c, float s) { return guard([&] { C(c)->set_ui_scale(s); }); }
 int fdh_render_frame(FdhContext* c, const FdhScene* scene, float fw, float fh, int clear, const float rgba[4]) {
   return guard([&] {

@@ -57,10 +57,17 @@ Context::Context(int atlas_size, float pixel_scale, int device, uint32_t flags) 
   for (auto& e : staging_ev_) FDH_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   initial_atlas_size_ = atlas_size > 0 ? atlas_size : 1024;  // newContext default, glcontext.nim:255-261
   alloc_atlas(initial_atlas_size_);
+  static const bool env_sync = [] { const char* e = std::getenv("FDH_SYNC_SUBMIT"); return e && std::atoi(e) != 0; }();
+  if (!(flags & FDH_CREATE_SYNC_SUBMIT) && !env_sync) worker_ = std::thread([this] { worker_main(); });
 }
 
 Context::~Context() {
   if (host_only_) return;
+  if (worker_.joinable()) {
+    { std::lock_guard<std::mutex> lk(mu_); quit_ = true; }
+    cv_job_.notify_all();
+    worker_.join();
+  }
   (void)hipSetDevice(device_);
   if (stream_) (void)hipStreamSynchronize(stream_);
   for (auto& e : ev_) if (e) (void)hipEventDestroy(e);
@@ -79,14 +86,64 @@ Context::~Context() {
 
 void Context::set_stream(void* s) {
   need_device("set_stream");
+  drain();
   FDH_HIP(hipStreamSynchronize(stream_));
   stream_ = s ? (hipStream_t)s : own_stream_;
 }
 void Context::need_device(const char* what) const {
   if (host_only_) throw Error(FDH_ERR_NO_DEVICE, std::string(what) + ": this context was created with FDH_CREATE_RECORD_ONLY (it records calls, it draws nothing)");
 }
+// ------------------------------------------------------------------ the submit thread
+// end_frame prepares the frame on the calling thread, hands the LaunchJob over and returns; this thread issues the launches
+// (Context::issue: ~20 us of HIP runtime calls per bench frame that used to sit between the caller's tree walks).  One job at
+// a time; the caller only waits when it has the NEXT frame prepared before this one's launches are out.
+// Both sides spin briefly before they sleep: at 10 000 frames/s a futex round trip per hand-over would be a tenth of a frame.
+static inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+  __builtin_ia32_pause();
+#else
+  std::this_thread::yield();
+#endif
+}
+void Context::worker_main() {
+  (void)hipSetDevice(device_);
+  for (;;) {
+    bool have = false;
+    for (int spin = 0; spin < 4000 && !have; spin++) { have = pending_.load(std::memory_order_acquire); if (!have) cpu_relax(); }
+    if (!have) {
+      std::unique_lock<std::mutex> lk(mu_);
+      cv_job_.wait(lk, [&] { return pending_.load(std::memory_order_acquire) || quit_; });
+      if (!pending_.load(std::memory_order_acquire)) return;  // quit_
+    }
+    try {
+      issue(job_);
+    } catch (...) {
+      worker_error_ = std::current_exception();
+    }
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      pending_.store(false, std::memory_order_release);
+    }
+    cv_done_.notify_all();
+  }
+}
+void Context::drain() {
+  if (!worker_.joinable()) return;
+  for (int spin = 0; spin < 4000 && pending_.load(std::memory_order_acquire); spin++) cpu_relax();
+  if (pending_.load(std::memory_order_acquire)) {
+    std::unique_lock<std::mutex> lk(mu_);
+    cv_done_.wait(lk, [&] { return !pending_.load(std::memory_order_acquire); });
+  }
+  if (worker_error_) {
+    std::exception_ptr e = worker_error_;
+    worker_error_ = nullptr;
+    std::rethrow_exception(e);
+  }
+}
+
 void Context::sync() {
   if (host_only_) return;
+  drain();
   FDH_HIP(hipSetDevice(device_));
   FDH_HIP(hipStreamSynchronize(stream_));
 }
@@ -431,6 +488,7 @@ const char* Context::record_json() {
   return rec_.c_str();
 }
 void Context::set_aa(float aa) { { FDH_REC("set_aa_factor").f(aa); } aa_ = aa; }
+void Context::set_subpixel_shift(float s) { { FDH_REC("set_text_subpixel_shift").f(s); } subpixel_shift_ = s; }  // setTextSubpixelShift figbackend.nim:663-686
 
 void Context::save_transform() { { FDH_REC("save_transform"); } mats_.push_back(mat_); }
 void Context::restore_transform() {
@@ -458,6 +516,7 @@ bool Context::transform_mirrors_y() const { return mat_.a * mat_.d - mat_.b * ma
 // ------------------------------------------------------------------ frame
 void Context::ensure_surfaces() {
   if (host_only_ || (surf_w_ == W_ && surf_h_ == H_ && fb_)) return;
+  drain();  // the frame in submission still renders into the old surfaces
   FDH_HIP(hipStreamSynchronize(stream_));
   if (fb_) FDH_HIP(hipFree(fb_));
   if (backdrop_) FDH_HIP(hipFree(backdrop_));
@@ -497,6 +556,7 @@ void Context::begin_frame(int w, int h, bool clear, const float rgba[4]) {  // g
   phases_.clear();
   blurs_.clear();
   fragments_ = 0;
+  rec_diff_upload_ = false;
   phases_.push_back(Phase{});
 }
 
@@ -1084,17 +1144,35 @@ void Context::draw_backdrop_blur(const float rect[4], const float rx[4], const f
 }
 
 // ------------------------------------------------------------------ submission
+// end_frame = prepare (this thread) + issue (the context's submit thread).
+//   prepare  builds everything the device needs from the recorded frame -- list stride, bin records, bin boxes, the phase table --
+//            straight into a pinned staging buffer, and a LaunchJob describing the launches.  It runs on the CALLING thread:
+//            the records it reads were written microseconds ago by this very core.  (First version: the whole submission on the
+//            other thread.  Recording then took 120 us instead of 40: every record line the caller wrote had last been read by
+//            the submit thread's core, and a line costs ~100 ns to pull across the host's core complexes.)
+//   issue    launches the upload kernel and the frame's kernels (~20 us of HIP runtime calls) from the submit thread, so the
+//            caller is already walking the next frame's tree.  FDH_CREATE_SYNC_SUBMIT contexts run it inline.
 void Context::end_frame() {  // glcontext.nim:1982-1989
   { FDH_REC("end_frame"); }
   if (!frame_begun_) throw Error(FDH_ERR_INVALID, "ctx.beginFrame was not called first.");
   if (mask_depth_ != 0) throw Error(FDH_ERR_INVALID, "Not all masks have been popped.");
   if (!rect_masks_.empty()) throw Error(FDH_ERR_INVALID, "Not all rect masks have been popped.");
   frame_begun_ = false;
-  have_frame_ = true;
   const auto t1 = std::chrono::steady_clock::now();
   host_record_ms_ = std::chrono::duration<float, std::milli>(t1 - t_begin_frame_).count();
-  if (host_only_) { have_frame_ = false; return; }
-  submit(true);
+  // a list entry carries the draw index in 26 bits beside its path code and flags (k_bin_draws, LE_INDEX)
+  if (recs_.size() >= (1u << 26)) throw Error(FDH_ERR_INVALID, "more than 67 108 863 draw records in one frame");
+  if (host_only_) return;
+  prepare(next_);
+  drain();  // the previous frame's launches (normally long issued: they ran while this frame was being recorded)
+  std::swap(job_, next_);
+  have_frame_ = true;
+  if (!worker_.joinable()) { issue(job_); return; }
+  {
+    std::lock_guard<std::mutex> lk(mu_);
+    pending_.store(true, std::memory_order_release);
+  }
+  cv_job_.notify_one();
 }
 
 // Weight fragments of a matrix-pipe blur pass (k_blur_mx, fdh_kernels.hip).  Lane (j, g) of fragment m holds, for the window
@@ -1145,12 +1223,25 @@ void blur_weight_fragments(float blur_radius, bool vertical, float* dense, uint1
   build_mx_weights(t, vertical, reinterpret_cast<uint8_t*>(frag_bits));
 }
 
-void Context::submit(bool upload) {
+// a device buffer the frame in submission may still use: wait for it before the block moves
+template <typename Buf> void Context::reserve_quiet(Buf& buf, size_t n) {
+  if (n <= buf.cap) return;
+  drain();
+  FDH_HIP(hipStreamSynchronize(stream_));
+  buf.reserve(n);
+}
+
+void Context::prepare(LaunchJob& J) {
   const auto t_s0 = std::chrono::steady_clock::now();
   FDH_HIP(hipSetDevice(device_));
   const size_t n = recs_.size();
-  // a list entry carries the draw index in 26 bits beside its path code and flags (k_bin_draws, LE_INDEX)
-  if (n >= (1u << 26)) throw Error(FDH_ERR_INVALID, "more than 67 108 863 draw records in one frame");
+  J.W = W_; J.H = H_; J.clear = clear_; J.clear_rgba8 = clear_rgba8_;
+  J.phases = phases_;  // (copies: the recording side keeps its own for fdh_debug_record_digest)
+  J.blurs = blurs_;
+  J.n_recs = (int)n;
+  int& bins_x_ = J.bins_x; int& bins_y_ = J.bins_y; int& list_stride_ = J.list_stride; int& binbox_shift_ = J.binbox_shift; int& big_blur_ = J.big_blur;
+  std::vector<const uint4*>&mx_w_h_ = J.mx_w_h, &mx_w_v_ = J.mx_w_v;
+  LaunchJob::View& dv_ = J.dv;
   bins_x_ = (W_ + kBin - 1) / kBin;
   bins_y_ = (H_ + kBin - 1) / kBin;
   const int nb = bins_x_ * bins_y_;
@@ -1158,31 +1249,22 @@ void Context::submit(bool upload) {
   // array (O(draws + bins) per phase).  Sizing the lists for "every draw of the phase in every bin" cost 163 MB for
   // the 10 001-draw glyph frame; the exact bound is 2040 bins x a few dozen entries.
   int max_count = 1;
-  std::vector<int> diff((size_t)(bins_x_ + 1) * (bins_y_ + 1));
-  for (auto& p : phases_) {
-    std::fill(diff.begin(), diff.end(), 0);
-    const int dw = bins_x_ + 1;
-    for (int i = p.first; i < p.first + p.count; i++) {
-      const BBox& b = bboxes_[i];
-      if (bbox_empty(b)) continue;
-      const int bx0 = b.x0 / kBin, by0 = b.y0 / kBin, bx1 = (b.x1 - 1) / kBin + 1, by1 = (b.y1 - 1) / kBin + 1;  // [bx0,bx1) x [by0,by1)
-      diff[(size_t)by0 * dw + bx0]++; diff[(size_t)by0 * dw + bx1]--; diff[(size_t)by1 * dw + bx0]--; diff[(size_t)by1 * dw + bx1]++;
-    }
-    for (int y = 0; y < bins_y_; y++) {
-      int run = 0;
-      for (int x = 0; x < bins_x_; x++) {
-        run += diff[(size_t)y * dw + x];
-        int& cell = diff[(size_t)y * dw + x];
-        cell = run + (y > 0 ? diff[(size_t)(y - 1) * dw + x] : 0);  // column prefix over the row prefixes
-        max_count = std::max(max_count, cell);
-      }
-    }
+  std::vector<int>& diff = diff_scratch_;
+  const int dw = bins_x_ + 1;
+  diff.resize((size_t)dw * (bins_y_ + 1));
+  constexpr int kBinShift = 6;
+  static_assert((1 << kBinShift) == kBin, "bins are 64 px");
+  int64_t frag_mode[4] = {0, 0, 0, 0}, frag_ellip = 0, frag_other = 0;  // phase 0, by SdfMode 3 / 7 / 9 / 12 (SURVEY.md 8d flop table)
+  for (size_t pi = 0; pi < J.phases.size(); pi++) {
+    Phase& p = J.phases[pi];
+    // one pass over the phase's draws: union of the bounds, which compositor build the phase needs, fragment counts by mode
     BBox u{0, 0, 0, 0};
     p.has_slow = false;
     p.has_atlas = false;
     p.has_masks = false;
     for (int i = p.first; i < p.first + p.count; i++) {
-      bbox_union(u, bboxes_[i]);
+      const BBox& b = bboxes_[i];
+      bbox_union(u, b);
       // mirrors the `fast` predicate of k_composite_tiles
       const uint32_t om = recs_[i].op_mode, op = (om >> 12) & 15u, mode = om & 255u;
       const bool atlas_mode = mode == 0u || (mode >= 13u && mode <= 16u);
@@ -1191,18 +1273,46 @@ void Context::submit(bool upload) {
       const bool atlas4 = atlas_mode && !(om & F_GENERAL) && op == OP_DRAW && !(mode == 0u && recs_[i].aux2 > 0.0f && n_levels_ >= 2);
       if (atlas4) p.has_atlas = true;
       else if (op == OP_RMASK_BEGIN || ((op == OP_DRAW || op == OP_MASK_PUSH) && ((om & F_GENERAL) || atlas_mode || mode >= 18u))) p.has_slow = true;
+      if (pi == 0 && op == OP_DRAW && !bbox_empty(b)) {
+        const int64_t area = (int64_t)(b.x1 - b.x0) * (b.y1 - b.y0);
+        if (mode == 3u) frag_mode[0] += area; else if (mode == 7u) frag_mode[1] += area; else if (mode == 9u) frag_mode[2] += area;
+        else if (mode == 12u) frag_mode[3] += area; else frag_other += area;
+        if (om & F_ELLIP) frag_ellip += area;
+      }
     }
-    p.bin_x0 = u.x0 / kBin; p.bin_y0 = u.y0 / kBin;
-    p.bin_x1 = bbox_empty(u) ? p.bin_x0 : (u.x1 + kBin - 1) / kBin;
-    p.bin_y1 = bbox_empty(u) ? p.bin_y0 : (u.y1 + kBin - 1) / kBin;
+    p.bin_x0 = u.x0 >> kBinShift; p.bin_y0 = u.y0 >> kBinShift;
+    p.bin_x1 = bbox_empty(u) ? p.bin_x0 : (u.x1 + kBin - 1) >> kBinShift;
+    p.bin_y1 = bbox_empty(u) ? p.bin_y0 : (u.y1 + kBin - 1) >> kBinShift;
+    if (bbox_empty(u)) continue;
+    // the count, over the bins the phase reaches only (the phases behind a blur are a handful of draws on a few bins)
+    const int cx0 = p.bin_x0, cy0 = p.bin_y0, cx1 = p.bin_x1, cy1 = p.bin_y1;  // cells [cx0, cx1] x [cy0, cy1] of the difference array
+    for (int y = cy0; y <= cy1; y++) std::fill(diff.begin() + (size_t)y * dw + cx0, diff.begin() + (size_t)y * dw + cx1 + 1, 0);
+    for (int i = p.first; i < p.first + p.count; i++) {
+      const BBox& b = bboxes_[i];
+      if (bbox_empty(b)) continue;
+      const int bx0 = b.x0 >> kBinShift, by0 = b.y0 >> kBinShift, bx1 = ((b.x1 - 1) >> kBinShift) + 1, by1 = ((b.y1 - 1) >> kBinShift) + 1;  // [bx0,bx1) x [by0,by1)
+      diff[(size_t)by0 * dw + bx0]++; diff[(size_t)by0 * dw + bx1]--; diff[(size_t)by1 * dw + bx0]--; diff[(size_t)by1 * dw + bx1]++;
+    }
+    for (int y = cy0; y < cy1; y++) {
+      int run = 0;
+      int* row = diff.data() + (size_t)y * dw;
+      const int* above = y > cy0 ? row - dw : nullptr;
+      for (int x = cx0; x < cx1; x++) {
+        run += row[x];
+        const int cell = run + (above ? above[x] : 0);  // column prefix over the row prefixes
+        row[x] = cell;
+        max_count = std::max(max_count, cell);
+      }
+    }
   }
   list_stride_ = (max_count + 7) & ~7;
-  if (upload) {
-    d_lists_.reserve((size_t)phases_.size() * nb * list_stride_);
-    d_counts_.reserve((size_t)phases_.size() * nb);
-    std::vector<int> pf(phases_.size() + 1);
-    for (size_t i = 0; i < phases_.size(); i++) pf[i] = phases_[i].first;
-    pf[phases_.size()] = (int)n;
+  {
+    reserve_quiet(d_lists_, (size_t)J.phases.size() * nb * list_stride_);
+    reserve_quiet(d_counts_, (size_t)J.phases.size() * nb);
+    J.lists = d_lists_.ptr; J.counts = d_counts_.ptr;
+    std::vector<int> pf(J.phases.size() + 1);
+    for (size_t i = 0; i < J.phases.size(); i++) pf[i] = J.phases[i].first;
+    pf[J.phases.size()] = (int)n;
     auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
     const size_t b_recs = n * sizeof(DrawRec), b_ext = exts_.size() * sizeof(QuadExt), b_bb = n * sizeof(BinRec), b_pf = pf.size() * sizeof(int);
     const size_t b_box = ((n + 3) & ~(size_t)3) * sizeof(uint32_t);
@@ -1210,29 +1320,31 @@ void Context::submit(bool upload) {
     const size_t o_recs = 0, o_ext = up(o_recs + b_recs), o_bb = up(o_ext + b_ext), o_box = up(o_bb + b_bb), o_chunk = up(o_box + b_box),
                  o_pf = up(o_chunk + b_chunk);
     // weight fragments of the matrix-pipe blur passes, two tables (H, V) per blur job
-    std::vector<size_t> o_mxh(blurs_.size(), 0), o_mxv(blurs_.size(), 0);
+    std::vector<size_t> o_mxh(J.blurs.size(), 0), o_mxv(J.blurs.size(), 0);
     size_t total = up(o_pf + b_pf);
-    for (size_t i = 0; i < blurs_.size(); i++) {
-      const int nkh = mx_nk(blurs_[i].taps.reach, false), nkv = mx_nk(blurs_[i].taps.reach, true);
+    for (size_t i = 0; i < J.blurs.size(); i++) {
+      const int nkh = mx_nk(J.blurs[i].taps.reach, false), nkv = mx_nk(J.blurs[i].taps.reach, true);
       if (nkh > kMxMaxNK || nkv > kMxMaxNK) continue;
       o_mxh[i] = total; total = up(total + mx_table_bytes(nkh));
       o_mxv[i] = total; total = up(total + mx_table_bytes(nkv));
     }
-    d_frame_.reserve(total);
+    reserve_quiet(d_frame_, total);
     dv_.recs = reinterpret_cast<DrawRec*>(d_frame_.ptr + o_recs);
     dv_.exts = reinterpret_cast<QuadExt*>(d_frame_.ptr + o_ext);
     dv_.binrecs = reinterpret_cast<BinRec*>(d_frame_.ptr + o_bb);
     dv_.phase_first = reinterpret_cast<int*>(d_frame_.ptr + o_pf);
     dv_.binbox = reinterpret_cast<uint32_t*>(d_frame_.ptr + o_box);
     dv_.chunkbox = reinterpret_cast<uint32_t*>(d_frame_.ptr + o_chunk);
-    mx_w_h_.assign(blurs_.size(), nullptr);
-    mx_w_v_.assign(blurs_.size(), nullptr);
-    for (size_t i = 0; i < blurs_.size(); i++)
+    mx_w_h_.assign(J.blurs.size(), nullptr);
+    mx_w_v_.assign(J.blurs.size(), nullptr);
+    for (size_t i = 0; i < J.blurs.size(); i++)
       if (o_mxh[i]) { mx_w_h_[i] = reinterpret_cast<const uint4*>(d_frame_.ptr + o_mxh[i]); mx_w_v_[i] = reinterpret_cast<const uint4*>(d_frame_.ptr + o_mxv[i]); }
     const int slot = staging_i_;
     staging_i_ = (staging_i_ + 1) % kStaging;
-    if (staging_busy_[slot]) FDH_HIP(hipEventSynchronize(staging_ev_[slot]));  // its copy of three frames ago
+    // its copy of kStaging frames ago (that frame's issue was waited for by the end_frame after it: the event is recorded)
+    if (staging_busy_[slot]) FDH_HIP(hipEventSynchronize(staging_ev_[slot]));
     staging_[slot].reserve(total);
+    J.staging_slot = slot;
     uint8_t* s = staging_[slot].ptr;
     if (b_recs) std::memcpy(s + o_recs, recs_.data(), b_recs);
     if (b_ext) std::memcpy(s + o_ext, exts_.data(), b_ext);
@@ -1269,13 +1381,13 @@ void Context::submit(bool upload) {
     {  // bin boxes (what k_bin_draws scans): 7-bit inclusive bounds in bin units, upper bounds complemented
       uint32_t* bxp = reinterpret_cast<uint32_t*>(s + o_box);
       binbox_shift_ = (bins_x_ > 128 || bins_y_ > 128) ? 1 : 0;
-      const int unit = kBin << binbox_shift_;
+      const int ush = kBinShift + binbox_shift_;  // (bounds are clipped to the frame: non-negative, a shift divides)
       for (size_t i = 0; i < b_box / sizeof(uint32_t); i++) {
         uint32_t v = 0x7f7f7f7fu;  // x0 = y0 = 127, x1 = y1 = 0: never hits
         if (i < n && !bbox_empty(bboxes_[i])) {
           const BBox& b = bboxes_[i];
-          v = (uint32_t)(b.x0 / unit) | ((uint32_t)(b.y0 / unit) << 8) | ((127u - (uint32_t)((b.x1 - 1) / unit)) << 16) |
-              ((127u - (uint32_t)((b.y1 - 1) / unit)) << 24);
+          v = (uint32_t)(b.x0 >> ush) | ((uint32_t)(b.y0 >> ush) << 8) | ((127u - (uint32_t)((b.x1 - 1) >> ush)) << 16) |
+              ((127u - (uint32_t)((b.y1 - 1) >> ush)) << 24);
         }
         bxp[i] = v;
       }
@@ -1293,11 +1405,25 @@ void Context::submit(bool upload) {
       }
     }
     std::memcpy(s + o_pf, pf.data(), b_pf);
-    for (size_t i = 0; i < blurs_.size(); i++)
+    // The weight tables depend on the filters alone and sit behind everything else in the block: when the device block already
+    // holds these very tables at these very offsets (an animation blurs with the same radii frame after frame) they are neither
+    // staged nor uploaded again -- 40 of the bench frame's 130 KB.
+    std::vector<size_t> layout{total, o_recs, o_ext, o_bb, o_box, o_chunk, o_pf};
+    for (size_t i = 0; i < J.blurs.size(); i++) { layout.push_back(o_mxh[i]); layout.push_back(o_mxv[i]); }
+    std::vector<float> tables_sig;
+    for (size_t i = 0; i < J.blurs.size(); i++)
+      if (o_mxh[i]) { const BlurTaps& t = J.blurs[i].taps; tables_sig.push_back((float)t.reach); tables_sig.insert(tables_sig.end(), t.dense + kBlurPad, t.dense + kBlurPad + 2 * t.reach + 1); }
+    const size_t o_tables = up(o_pf + b_pf);
+    // (the diff route of retained scenes compares against a host shadow of the WHOLE block: without a valid shadow the tables
+    // are staged once more so that one can be taken)
+    if (!rec_diff_upload_) shadow_dev_ = nullptr;
+    const bool shadow_ok = rec_diff_upload_ && shadow_dev_ == d_frame_.ptr && shadow_layout_ == layout && shadow_.size() == total;
+    const bool tables_resident = tables_dev_ == d_frame_.ptr && tables_layout_ == layout && tables_sig_ == tables_sig && (!rec_diff_upload_ || shadow_ok);
+    for (size_t i = 0; i < J.blurs.size() && !tables_resident; i++)
       if (o_mxh[i]) {
         // the fragments depend on the filter alone: an animation blurs with the same radii frame after frame, and building
         // the four tables of the bench frame took 35 of the 54 us this function spent before its first launch
-        const BlurTaps& t = blurs_[i].taps;
+        const BlurTaps& t = J.blurs[i].taps;
         const size_t bh = mx_table_bytes(mx_nk(t.reach, false)), bv = mx_table_bytes(mx_nk(t.reach, true));
         const MxTables* hit = nullptr;
         for (const MxTables& c : mx_cache_)
@@ -1321,15 +1447,17 @@ void Context::submit(bool upload) {
     // Only what differs from the block the device already holds travels: after an edit of a retained scene (or between two
     // frames of an animation) that is a few hundred bytes of records, bounds and bin boxes out of ~110 KB.  The comparison runs
     // against a host shadow of the device block in 256-byte chunks; up to kUploadRuns runs go out in ONE launch.
-    std::vector<size_t> layout{total, o_recs, o_ext, o_bb, o_box, o_chunk, o_pf};
-    for (size_t i = 0; i < blurs_.size(); i++) { layout.push_back(o_mxh[i]); layout.push_back(o_mxv[i]); }
     bool patched = false;
-    if (shadow_dev_ == d_frame_.ptr && shadow_layout_ == layout && shadow_.size() == total) {
+    J.s_dev = s_dev; J.d_dst = d_frame_.ptr; J.runs = UploadRuns{};
+    // (a frame recorded from scratch differs from its predecessor nearly everywhere: comparing 110 KB to find that out, and
+    // keeping the shadow current, cost 12 us per frame -- only frames of a retained scene take the diff route)
+    const size_t staged = tables_resident ? o_tables : total;  // bytes of the staging buffer that hold this frame
+    if (shadow_ok) {
       UploadRuns R{};
       size_t dirty = 0;
       bool fits = true;
-      for (size_t at = 0; at < total && fits; at += 256) {
-        const size_t len = std::min<size_t>(256, total - at);
+      for (size_t at = 0; at < staged && fits; at += 256) {
+        const size_t len = std::min<size_t>(256, staged - at);
         if (std::memcmp(shadow_.data() + at, s + at, len) == 0) continue;
         dirty += len;
         if (R.n > 0 && (size_t)(R.off16[R.n - 1] + R.len16[R.n - 1]) * 16 == at) R.len16[R.n - 1] += (uint32_t)((len + 15) / 16);
@@ -1337,21 +1465,24 @@ void Context::submit(bool upload) {
         else fits = false;
       }
       if (fits && dirty * 2 < total) {
-        launch_upload_runs(stream_, d_frame_.ptr, s_dev, R);
-        for (uint32_t r = 0; r < R.n; r++) std::memcpy(shadow_.data() + (size_t)R.off16[r] * 16, s + (size_t)R.off16[r] * 16, std::min((size_t)R.len16[r] * 16, total - (size_t)R.off16[r] * 16));
+        J.runs = R;
+        for (uint32_t r = 0; r < R.n; r++) std::memcpy(shadow_.data() + (size_t)R.off16[r] * 16, s + (size_t)R.off16[r] * 16, std::min((size_t)R.len16[r] * 16, staged - (size_t)R.off16[r] * 16));
         uploaded_bytes_ = (int64_t)dirty;
         patched = true;
       }
     }
+    J.patched = patched;
     if (!patched) {
-      launch_upload(stream_, d_frame_.ptr, s_dev, total);  // whole 16-byte groups: both sides are padded to 256 B
-      shadow_.assign(s, s + total);
-      shadow_layout_ = layout;
-      shadow_dev_ = d_frame_.ptr;
-      uploaded_bytes_ = (int64_t)total;
+      J.upload_bytes = staged;  // whole 16-byte groups: both sides are padded to 256 B
+      if (rec_diff_upload_) {
+        if (tables_resident) std::memcpy(shadow_.data(), s, staged);  // (shadow_ok: the tables behind are what they were)
+        else shadow_.assign(s, s + total);
+        shadow_layout_ = layout;
+        shadow_dev_ = d_frame_.ptr;
+      }
+      uploaded_bytes_ = (int64_t)J.upload_bytes;
     }
-    FDH_HIP(hipEventRecord(staging_ev_[slot], stream_));
-    staging_busy_[slot] = true;
+    tables_dev_ = d_frame_.ptr; tables_layout_ = layout; tables_sig_.swap(tables_sig);
   }
   // algorithmic bytes of this frame: final store + per blur (pre-blur store is the store above for
   // a full-frame node; H read + H write + V read + V write + composite read) + records once
@@ -1362,8 +1493,8 @@ void Context::submit(bool upload) {
   big_blur_ = -1;
   int64_t big_area = 0;
   stats_.bytes_blur_big_h = stats_.bytes_blur_big_v = 0;
-  for (size_t bi = 0; bi < blurs_.size(); bi++) {
-    const BlurJob& j = blurs_[bi];
+  for (size_t bi = 0; bi < J.blurs.size(); bi++) {
+    const BlurJob& j = J.blurs[bi];
     const int ylo = std::max(0, j.y0 - j.taps.reach), yhi = std::min(H_, j.y1 + j.taps.reach);
     const int64_t a_h = (int64_t)(j.x1 - j.x0) * (yhi - ylo), a_v = (int64_t)(j.x1 - j.x0) * (j.y1 - j.y0);
     int64_t b_h = 4 * a_h + 4 * a_h, b_v = 4 * a_h + 4 * a_v;  // H read + H write; V read + V write
@@ -1375,36 +1506,59 @@ void Context::submit(bool upload) {
   }
   bytes += bytes_blur;
   stats_.bytes_blur = bytes_blur;
-  stats_.bytes_composite_main = 4LL * W_ * H_ * (clear_ ? 1 : 2) + (int64_t)phases_[0].count * (int64_t)sizeof(DrawRec);
+  stats_.bytes_composite_main = 4LL * W_ * H_ * (clear_ ? 1 : 2) + (int64_t)J.phases[0].count * (int64_t)sizeof(DrawRec);
+  // algorithmic flops of the phase-0 composite launch, SURVEY.md 8(d): per fragment ClipAA 25, DropShadow 35 + exp, InsetShadow
+  // 70 + exp, AnnularAA 28 (other modes priced as ClipAA), elliptical corners + 30, blend + re-quantise + 16
+  for (int k = 0; k < 4; k++) stats_.fragments_main_by_mode[k] = frag_mode[k];
+  stats_.fragments_main_elliptical = frag_ellip;
+  stats_.fragments_main_other = frag_other;
+  stats_.flops_composite_main = frag_mode[0] * 25 + frag_mode[1] * 36 + frag_mode[2] * 71 + frag_mode[3] * 28 + frag_other * 25 + frag_ellip * 30 +
+                                (frag_mode[0] + frag_mode[1] + frag_mode[2] + frag_mode[3] + frag_other) * 16;
   stats_.n_draws = (int32_t)n;
-  stats_.n_phases = (int32_t)phases_.size();
-  stats_.n_blurs = (int32_t)blurs_.size();
+  stats_.n_phases = (int32_t)J.phases.size();
+  stats_.n_blurs = (int32_t)J.blurs.size();
   stats_.n_bins = nb;
   stats_.bytes_algorithmic = bytes;
   stats_.fragments = fragments_;
   const auto t_l0 = std::chrono::steady_clock::now();
-  launch_frame(false);
-  const auto t_l1 = std::chrono::steady_clock::now();
   stats_.ms_host_record = host_record_ms_;
   stats_.ms_host_upload = std::chrono::duration<float, std::milli>(t_l0 - t_s0).count();
-  stats_.ms_host_launch = std::chrono::duration<float, std::milli>(t_l1 - t_l0).count();
 }
 
-void Context::launch_frame(bool profile) {
+// The launches of one prepared frame: the upload (a kernel on the render stream reading the pinned staging buffer), then
+// binning, blur passes and compositing.  Submit thread (or the caller's, FDH_CREATE_SYNC_SUBMIT).
+void Context::issue(LaunchJob& J) {
+  const auto t_l0 = std::chrono::steady_clock::now();
+  FDH_HIP(hipSetDevice(device_));
+  if (J.patched) launch_upload_runs(stream_, J.d_dst, J.s_dev, J.runs);
+  else launch_upload(stream_, J.d_dst, J.s_dev, J.upload_bytes);
+  if (J.staging_slot >= 0) {
+    FDH_HIP(hipEventRecord(staging_ev_[J.staging_slot], stream_));
+    staging_busy_[J.staging_slot] = true;
+  }
+  launch_frame(J, false);
+  launch_ms_.store(std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_l0).count(), std::memory_order_relaxed);
+}
+
+
+void Context::launch_frame(const LaunchJob& J, bool profile) {
+  const int bins_x_ = J.bins_x, bins_y_ = J.bins_y, list_stride_ = J.list_stride, binbox_shift_ = J.binbox_shift, big_blur_ = J.big_blur;
+  const std::vector<const uint4*>&mx_w_h_ = J.mx_w_h, &mx_w_v_ = J.mx_w_v;
+  const LaunchJob::View& dv_ = J.dv;
   const int nb = bins_x_ * bins_y_;
-  const int np = (int)phases_.size();
+  const int np = (int)J.phases.size();
   // rows each phase has to produce: the stripe, widened by the vertical reach of every later blur
-  int s0 = 0, s1 = H_;
-  if (stripe_y1_ > stripe_y0_) { s0 = std::max(0, stripe_y0_); s1 = std::min(H_, stripe_y1_); }
+  int s0 = 0, s1 = J.H;
+  if (stripe_y1_ > stripe_y0_) { s0 = std::max(0, stripe_y0_); s1 = std::min(J.H, stripe_y1_); }
   std::vector<int> lo(np), hi(np);
   {
     int l = s0, h = s1;
     for (int p = np - 1; p >= 0; p--) {
       lo[p] = l; hi[p] = h;
-      if (phases_[p].blur >= 0) {
-        const int reach = blurs_[phases_[p].blur].taps.reach;
+      if (J.phases[p].blur >= 0) {
+        const int reach = J.blurs[J.phases[p].blur].taps.reach;
         l = std::max(0, l - reach);
-        h = std::min(H_, h + reach);
+        h = std::min(J.H, h + reach);
       }
     }
   }
@@ -1413,7 +1567,7 @@ void Context::launch_frame(bool profile) {
   auto span_end = [&]() { if (profile) { if (!launch_events_used()) spans_.pop_back(); set_launch_events(nullptr, nullptr); } };
   span_begin(0);
   BinParams B;
-  B.binrec = dv_.binrecs; B.binbox = dv_.binbox; B.chunkbox = dv_.chunkbox; B.n_draws = (int)recs_.size(); B.binbox_shift = binbox_shift_; B.lists = d_lists_.ptr; B.counts = d_counts_.ptr; B.phase_first = dv_.phase_first;
+  B.binrec = dv_.binrecs; B.binbox = dv_.binbox; B.chunkbox = dv_.chunkbox; B.n_draws = J.n_recs; B.binbox_shift = binbox_shift_; B.lists = J.lists; B.counts = J.counts; B.phase_first = dv_.phase_first;
   B.n_phases = np; B.bins_x = bins_x_; B.bins_y = bins_y_; B.stride = list_stride_;
   launch_bin(stream_, B);
   span_end();
@@ -1421,7 +1575,7 @@ void Context::launch_frame(bool profile) {
   // wavefront of that launch); it sorts this frame's counts for its successor.  Any permutation is a correct schedule.
   const int order_key = bins_x_ * 65536 + bins_y_;  // entries are (row << 16 | column) of THIS grid
   if (order_valid_ && order_nb_ != order_key) order_valid_ = false;  // frame size changed
-  const bool sorting = clear_ && np > 0 && nb <= 8192 && phases_[0].count > 0;
+  const bool sorting = J.clear && np > 0 && nb <= 8192 && J.phases[0].count > 0;
   const int* order_now = (sorting && order_valid_) ? d_order_[order_read_].ptr : nullptr;
   int* order_next = nullptr;
   if (sorting) {
@@ -1433,19 +1587,19 @@ void Context::launch_frame(bool profile) {
     order_valid_ = true;
   }
   for (int p = 0; p < np; p++) {
-    const Phase& ph = phases_[p];
+    const Phase& ph = J.phases[p];
     if (ph.blur >= 0) {
-      const BlurJob& j = blurs_[ph.blur];
+      const BlurJob& j = J.blurs[ph.blur];
       // V output: footprint rows this phase must produce; H output: those rows widened by the tap reach
       const int vy0 = std::max(j.y0, lo[p]), vy1 = std::min(j.y1, hi[p]);
       if (vy1 > vy0 && j.x1 > j.x0) {
         BlurParams bp;
-        bp.W = W_; bp.H = H_; bp.pitch = W_;
+        bp.W = J.W; bp.H = J.H; bp.pitch = J.W;
         bp.taps = j.taps;
         bp.fuse_draw = -1;
         bp.mx_w = (size_t)ph.blur < mx_w_h_.size() ? mx_w_h_[ph.blur] : nullptr;
         bp.src = fb_; bp.dst = blur_tmp_;
-        bp.x0 = j.x0; bp.x1 = j.x1; bp.y0 = std::max(0, vy0 - j.taps.reach); bp.y1 = std::min(H_, vy1 + j.taps.reach);
+        bp.x0 = j.x0; bp.x1 = j.x1; bp.y0 = std::max(0, vy0 - j.taps.reach); bp.y1 = std::min(J.H, vy1 + j.taps.reach);
         span_begin(ph.blur == big_blur_ ? 5 : 3);
         launch_blur_h(stream_, bp);
         span_end();
@@ -1459,20 +1613,20 @@ void Context::launch_frame(bool profile) {
       }
     }
     CompositeParams C;
-    C.lists = d_lists_.ptr + (size_t)p * nb * list_stride_;
-    C.counts = d_counts_.ptr + (size_t)p * nb;
+    C.lists = J.lists + (size_t)p * nb * list_stride_;
+    C.counts = J.counts + (size_t)p * nb;
     C.backdrop = backdrop_;
     C.fb = fb_;
     for (int l = 0; l < kMaxMips; l++) C.atlas.level[l] = atlas_levels_[l];
     C.atlas.size = atlas_size_; C.atlas.n_levels = n_levels_;
-    C.W = W_; C.H = H_; C.pitch = W_;
+    C.W = J.W; C.H = J.H; C.pitch = J.W;
     C.bins_x = bins_x_; C.stride = list_stride_;
-    const bool full = (p == 0 && clear_);
+    const bool full = (p == 0 && J.clear);
     C.bin_x0 = full ? 0 : ph.bin_x0; C.bin_y0 = full ? 0 : ph.bin_y0;
     C.bin_nx = full ? bins_x_ : ph.bin_x1 - ph.bin_x0; C.bin_ny = full ? bins_y_ : ph.bin_y1 - ph.bin_y0;
     C.row_lo = lo[p]; C.row_hi = hi[p];
     C.load_fb = full ? 0 : 1;
-    C.clear_rgba8 = clear_rgba8_;
+    C.clear_rgba8 = J.clear_rgba8;
     C.n_wg = 0;
     C.order = full ? order_now : nullptr;
     C.order_next = full ? order_next : nullptr;
@@ -1484,8 +1638,8 @@ void Context::launch_frame(bool profile) {
     span_end();
     static const bool snap = [] { const char* e = std::getenv("FDH_DEBUG_SNAP"); return e && std::atoi(e) != 0; }();
     if (snap && p == 0) {  // diagnostic only (tools/race_probe.py): what the first blur pass is about to read
-      if (!dbg_snap_) FDH_HIP(hipMalloc((void**)&dbg_snap_, (size_t)W_ * H_ * 4));
-      FDH_HIP(hipMemcpyAsync(dbg_snap_, fb_, (size_t)W_ * H_ * 4, hipMemcpyDeviceToDevice, stream_));
+      if (!dbg_snap_) FDH_HIP(hipMalloc((void**)&dbg_snap_, (size_t)J.W * J.H * 4));
+      FDH_HIP(hipMemcpyAsync(dbg_snap_, fb_, (size_t)J.W * J.H * 4, hipMemcpyDeviceToDevice, stream_));
     }
   }
   FDH_HIP(hipGetLastError());
@@ -1493,11 +1647,12 @@ void Context::launch_frame(bool profile) {
 
 void Context::replay(int times) {
   need_device("replay");
+  drain();
   if (!have_frame_) throw Error(FDH_ERR_INVALID, "replay: no frame has been submitted");
   FDH_HIP(hipSetDevice(device_));
   if (times <= 0) return;
   FDH_HIP(hipEventRecord(ev_[0], stream_));
-  for (int i = 0; i < times; i++) launch_frame(false);
+  for (int i = 0; i < times; i++) launch_frame(job_, false);
   FDH_HIP(hipEventRecord(ev_[1], stream_));
   FDH_HIP(hipEventSynchronize(ev_[1]));
   float ms = 0.0f;
@@ -1508,14 +1663,16 @@ void Context::replay(int times) {
 // enqueue only: several contexts (own streams, own surfaces) can then have frames in flight on one GPU at once
 void Context::replay_async(int times) {
   need_device("replay_async");
+  drain();
   if (!have_frame_) throw Error(FDH_ERR_INVALID, "replay: no frame has been submitted");
   FDH_HIP(hipSetDevice(device_));
-  for (int i = 0; i < times; i++) launch_frame(false);
+  for (int i = 0; i < times; i++) launch_frame(job_, false);
 }
 
 // `times` frames back to back with one event between consecutive frames: ms_out[i] = duration of frame i on the stream
 void Context::replay_timed(int times, float* ms_out) {
   need_device("replay_timed");
+  drain();
   if (!have_frame_) throw Error(FDH_ERR_INVALID, "replay: no frame has been submitted");
   if (times <= 0 || !ms_out) return;
   FDH_HIP(hipSetDevice(device_));
@@ -1524,7 +1681,7 @@ void Context::replay_timed(int times, float* ms_out) {
   marks.push_back(next_event());
   FDH_HIP(hipEventRecord(marks.back(), stream_));
   for (int i = 0; i < times; i++) {
-    launch_frame(false);
+    launch_frame(job_, false);
     marks.push_back(next_event());
     FDH_HIP(hipEventRecord(marks.back(), stream_));
   }
@@ -1544,6 +1701,7 @@ hipEvent_t Context::next_event() {
 // Per-kernel timing: events bracket every launch, so this is kept apart from replay()'s batch timing.
 void Context::profile(int times) {
   need_device("profile");
+  drain();
   if (!have_frame_) throw Error(FDH_ERR_INVALID, "profile: no frame has been submitted");
   FDH_HIP(hipSetDevice(device_));
   if (times <= 0) return;
@@ -1551,7 +1709,7 @@ void Context::profile(int times) {
   for (int i = 0; i < times; i++) {
     ev_used_ = 0;
     spans_.clear();
-    launch_frame(true);
+    launch_frame(job_, true);
     FDH_HIP(hipStreamSynchronize(stream_));
     for (auto& sp : spans_) {
       float t = 0.0f;
@@ -1571,6 +1729,7 @@ void Context::profile(int times) {
 // ------------------------------------------------------------------ readback (glcontext.nim:2094-2135)
 void Context::read_pixels(int x, int y, int w, int h, uint8_t* out) {
   need_device("read_pixels");
+  drain();
   if (!fb_) throw Error(FDH_ERR_INVALID, "readPixels before the first frame");
   FDH_HIP(hipSetDevice(device_));
   if (w <= 0 || h <= 0) { x = 0; y = 0; w = W_; h = H_; }
@@ -1580,13 +1739,15 @@ void Context::read_pixels(int x, int y, int w, int h, uint8_t* out) {
 }
 void Context::debug_read_surface(int which, uint8_t* out) {
   need_device("debug_read_surface");
+  drain();
   const uint32_t* src = which == 0 ? fb_ : which == 1 ? blur_tmp_ : which == 2 ? backdrop_ : which == 3 ? dbg_snap_ : nullptr;
   if (!src) throw Error(FDH_ERR_INVALID, "debug_read_surface: no such surface (or no frame yet)");
   FDH_HIP(hipSetDevice(device_));
   FDH_HIP(hipStreamSynchronize(stream_));
   FDH_HIP(hipMemcpy(out, src, (size_t)W_ * H_ * 4, hipMemcpyDeviceToHost));
 }
-uint64_t Context::record_digest() const {
+uint64_t Context::record_digest() {
+  drain();
   uint64_t h = 1469598103934665603ull;
   auto mix = [&](const void* p, size_t n) { const uint8_t* b = static_cast<const uint8_t*>(p); for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 1099511628211ull; } };
   const uint64_t n = recs_.size();
@@ -1599,6 +1760,7 @@ uint64_t Context::record_digest() const {
 }
 void Context::frame_device_ptr(void** p, int* w, int* h, int64_t* pitch_bytes) {
   need_device("frame_device_ptr");
+  drain();
   if (!fb_) throw Error(FDH_ERR_INVALID, "no frame surface yet");
   *p = fb_; *w = W_; *h = H_; *pitch_bytes = (int64_t)W_ * 4;
 }

@@ -2,11 +2,16 @@
 // backend calls into draw records (what glcontext.nim does into vertex streams) and submits them.
 #pragma once
 #include <hip/hip_runtime.h>
-#include <chrono>
 
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
 #include <cstdint>
+#include <exception>
+#include <mutex>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -121,6 +126,32 @@ struct RetainedScene {
   int64_t roots_walked = 0, roots_reused = 0;  // of the last fdh_scene_render
 };
 
+// What the launch side needs of one frame: filled by Context::prepare on the calling thread (which also fills the pinned
+// staging buffer the upload kernel reads), consumed by Context::issue / launch_frame on the context's submit thread, and kept
+// for fdh_replay / fdh_profile.
+struct LaunchJob {
+  struct View { DrawRec* recs = nullptr; QuadExt* exts = nullptr; BinRec* binrecs = nullptr; int* phase_first = nullptr; uint32_t* binbox = nullptr; uint32_t* chunkbox = nullptr; };
+  int W = 0, H = 0;
+  bool clear = true;
+  uint32_t clear_rgba8 = 0xFFFFFFFFu;
+  std::vector<Phase> phases;
+  std::vector<BlurJob> blurs;
+  std::vector<const uint4*> mx_w_h, mx_w_v;  // per blur job: weight fragments of the matrix-pipe passes (in the frame block), or null
+  int n_recs = 0;
+  View dv;                 // typed views into the device frame block
+  uint2* lists = nullptr;  // bin lists / counts (device)
+  uint32_t* counts = nullptr;
+  int bins_x = 0, bins_y = 0, list_stride = 0, binbox_shift = 0;
+  int big_blur = -1;       // index of the frame's largest blur job (its passes are timed on their own)
+  // the upload: `upload_bytes` from the head of the staging buffer, or (a retained scene's edit) a few runs of it
+  const void* s_dev = nullptr;
+  void* d_dst = nullptr;
+  size_t upload_bytes = 0;
+  bool patched = false;
+  UploadRuns runs{};
+  int staging_slot = -1;
+};
+
 struct RectMaskEntry { int kind; };  // 1 = fast analytic, 2 = real mask (glcontext.nim:36-44)
 
 class Context {
@@ -163,7 +194,7 @@ class Context {
   bool subpixel_enabled() const { return subpixel_enabled_; }
   void set_subpixel_variants(bool e) { subpixel_variants_ = e; }
   bool subpixel_variants() const { return subpixel_variants_; }
-  void set_subpixel_shift(float s) { subpixel_shift_ = s; }
+  void set_subpixel_shift(float s);
 
   // atlas
   void put_image(int64_t key, int w, int h, const uint8_t* rgba, int out_rect[4]);
@@ -198,16 +229,20 @@ class Context {
   void scene_replace_root(int layer, int slot, const FdhFig* subtree, int n, const FdhScene* side, bool insert);
   void scene_render();
   void scene_stats(int64_t* walked, int64_t* reused) const { *walked = retained_.roots_walked; *reused = retained_.roots_reused; }
-  int64_t uploaded_bytes() const { return uploaded_bytes_; }
-  uint64_t record_digest() const;  // FNV-1a over the last frame's draw records (diagnostic: works on record-only contexts)
+  int64_t uploaded_bytes() { drain(); return uploaded_bytes_; }
+  uint64_t record_digest();  // FNV-1a over the last frame's draw records (diagnostic: works on record-only contexts)
 
   // multi-GPU / measurement
-  void set_stripe(int y0, int y1) { stripe_y0_ = y0; stripe_y1_ = y1; }
+  void set_stripe(int y0, int y1) { drain(); stripe_y0_ = y0; stripe_y1_ = y1; }
   void replay(int times);
   void replay_timed(int times, float* ms_out);
   void replay_async(int times);
   void profile(int times);
-  void frame_stats(FdhFrameStats* out) const { *out = stats_; }
+  void frame_stats(FdhFrameStats* out) { drain(); *out = stats_; out->ms_host_launch = launch_ms_.load(std::memory_order_relaxed); }
+  // Submission is asynchronous: end_frame hands the recorded frame to the context's submit thread (upload preparation, the
+  // upload, the kernel launches) and returns.  flush() returns once everything submitted so far has been ENQUEUED on the
+  // stream (a consumer that orders its own work after the frame on the same stream calls it first); sync() also waits for the GPU.
+  void flush() { drain(); }
 
  private:
   void push_rec(const DrawRec& r, const BBox& b);
@@ -218,8 +253,12 @@ class Context {
   void put_levels(int x, int y, int w, int h, const uint8_t* rgba);
   void alloc_atlas(int size);
   void find_empty_rect(int w, int h, int* ox, int* oy);
-  void submit(bool upload);
-  void launch_frame(bool profile);
+  void prepare(LaunchJob& J);  // calling thread: recorded frame -> staging buffer + launch description
+  void issue(LaunchJob& J);    // submit thread: upload + kernel launches
+  void launch_frame(const LaunchJob& J, bool profile);
+  template <typename Buf> void reserve_quiet(Buf& buf, size_t n);
+  void drain();        // wait until the submit thread is idle; rethrows what its last job threw
+  void worker_main();
   hipEvent_t next_event();
   void ensure_surfaces();
   void need_device(const char* what) const;
@@ -248,20 +287,36 @@ class Context {
   float subpixel_shift_ = 0.0f;
   int stripe_y0_ = 0, stripe_y1_ = 0;
 
+  // submit thread (device contexts, unless FDH_CREATE_SYNC_SUBMIT): one job in flight at most.  The flag both sides poll
+  // sits on a cache line of its own, and so do the submission side's state and the recording side's: an idle submit thread
+  // polling `pending_` next to the vector headers the caller bumps with every draw call tripled the cost of recording.
+  std::thread worker_;
+  alignas(128) std::atomic<bool> pending_{false};
+  alignas(128) std::mutex mu_;
+  std::condition_variable cv_job_, cv_done_;
+  bool quit_ = false;
+  std::exception_ptr worker_error_;
+  alignas(128) LaunchJob job_;  // the frame being (or last) issued; what fdh_replay / fdh_profile launch again
+  std::atomic<float> launch_ms_{0.0f};
+  alignas(128) LaunchJob next_; // the frame being prepared (calling thread)
+  const void* tables_dev_ = nullptr;  // the device block whose tail holds the blur weight tables described by ...
+  std::vector<size_t> tables_layout_;
+  std::vector<float> tables_sig_;
+
   // recorded frame
+  alignas(128) bool rec_diff_upload_ = false;
   std::vector<DrawRec> recs_;
   std::vector<BBox> bboxes_;
   std::vector<QuadExt> exts_;
   std::vector<Phase> phases_;
   std::vector<BlurJob> blurs_;
-  std::vector<const uint4*> mx_w_h_, mx_w_v_;  // per blur job: weight fragments of the matrix-pipe passes (in d_frame_), or null
   int64_t fragments_ = 0;
   bool have_frame_ = false;
 
-  // device state
-  uint32_t *fb_ = nullptr, *backdrop_ = nullptr, *blur_tmp_ = nullptr;
+  // device state (submission side)
+  alignas(128) uint32_t* fb_ = nullptr;
+  uint32_t *backdrop_ = nullptr, *blur_tmp_ = nullptr;
   uint32_t* dbg_snap_ = nullptr;
-  int big_blur_ = -1;       // index of the frame's largest blur job (its passes are timed on their own)
   void glyph_to_atlas(uint32_t* cur, uint32_t* nxt, int w, int h, int x, int y, uint32_t flags);
   DeviceBuf<float> glyph_lines_, glyph_acc_;
   DeviceBuf<uint32_t> glyph_a_, glyph_b_;  // put_glyph_image: the raster and its filtered / minified successors
@@ -276,7 +331,6 @@ class Context {
   // records, quad extensions, bounding boxes and phase offsets of a frame live in ONE device block and arrive with ONE
   // copy (four small hipMemcpyAsync calls cost the host ~100 us per frame); the typed views point into it
   DeviceBuf<uint8_t> d_frame_;
-  struct View { DrawRec* recs = nullptr; QuadExt* exts = nullptr; BinRec* binrecs = nullptr; int* phase_first = nullptr; uint32_t* binbox = nullptr; uint32_t* chunkbox = nullptr; } dv_;
   DeviceBuf<uint2> d_lists_;
   DeviceBuf<uint32_t> d_counts_;
   DeviceBuf<int> d_order_[2];  // phase 0's bins, longest list first: read by this frame's launch / written for the next
@@ -295,7 +349,7 @@ class Context {
   hipEvent_t staging_ev_[kStaging] = {};
   bool staging_busy_[kStaging] = {};
   int staging_i_ = 0;
-  int bins_x_ = 0, bins_y_ = 0, list_stride_ = 0, binbox_shift_ = 0;
+  std::vector<int> diff_scratch_;
 
   // atlas
   int atlas_size_ = 0, initial_atlas_size_ = 0, atlas_margin_ = 4, n_levels_ = 0;

@@ -819,6 +819,7 @@ void Context::scene_render() {
   view.text_rects = R.text_rects.data(); view.n_text_rects = (int32_t)R.text_rects.size();
   R.roots_walked = R.roots_reused = 0;
   begin_frame((int)w, (int)h, R.clear, R.rgba);
+  rec_diff_upload_ = true;  // consecutive frames of a retained scene differ in a few records: Context::submit uploads the difference
   try {
     save_transform();
     scale(pixel_scale_, pixel_scale_);

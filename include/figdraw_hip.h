@@ -169,7 +169,12 @@ typedef struct {
  * and runs the scene front-end and the atlas packer, but draws nothing and touches no device: the counterpart of the
  * RecordingBackend in the reference's tests/ttransform.nim.  Every entry point that needs pixels (read_pixels, replay, ...)
  * fails with FDH_ERR_NO_DEVICE on such a context. */
-enum { FDH_CREATE_RECORD_ONLY = 1 };
+enum { FDH_CREATE_RECORD_ONLY = 1,
+       /* fdh_end_frame prepares, uploads and launches the frame on the calling thread.  Default (flag clear): the recorded frame
+        * is handed to the context's own submit thread and fdh_end_frame returns at once, so the caller records frame n + 1
+        * (the reference's render loop: examples/windy_non_clip_benchmark.nim:113-147) while frame n is being submitted.  Results
+        * are identical either way; every entry point that needs the submitted frame waits for the submit thread first. */
+       FDH_CREATE_SYNC_SUBMIT = 2 };
 FDH_API int fdh_create(FdhContext** out, int atlas_size, float pixel_scale, int device, uint32_t flags);
 FDH_API int fdh_destroy(FdhContext*);
 FDH_API const char* fdh_last_error(void);
@@ -263,6 +268,9 @@ FDH_API int fdh_read_pixels(FdhContext*, int x, int y, int w, int h, uint8_t* ou
  * (RCCL gather of stripes / frames, torch.from_blob).  Valid until the next begin_frame with another size. */
 FDH_API int fdh_frame_device_ptr(FdhContext*, void** out_ptr, int* out_width, int* out_height, int64_t* out_pitch_bytes);
 FDH_API int fdh_sync(FdhContext*);
+/* Returns when every frame submitted so far has been ENQUEUED on the context's stream (it does not wait for the GPU): call it
+ * before ordering other work after the frame on that stream (fdh_set_stream with a caller-owned stream, a collective). */
+FDH_API int fdh_flush(FdhContext*);
 
 /* ------------------------------------------------------------------ whole-scene entry (renderFrame figrender.nim:1960-1995) */
 FDH_API int fdh_set_ui_scale(FdhContext*, float s); /* common/shared.nim:69-98 */
@@ -330,6 +338,11 @@ typedef struct {
    * blend (not when the surface is known opaque: the pass then only stores) */
   float ms_blur_big_h, ms_blur_big_v;
   int64_t bytes_blur_big_h, bytes_blur_big_v;
+  /* the phase-0 composite launch in SURVEY.md 8(d)'s work units: covered fragments (sum of quad areas) by SdfMode 3 (ClipAA) / 7
+   * (DropShadow) / 9 (InsetShadow) / 12 (AnnularAA), those of draws with elliptical corners, all other modes; and the algorithmic
+   * flops they amount to: 25 / 36 / 71 / 28 per fragment (other modes priced as ClipAA), + 30 elliptical, + 16 blend + re-quantise */
+  int64_t fragments_main_by_mode[4], fragments_main_elliptical, fragments_main_other;
+  int64_t flops_composite_main;
 } FdhFrameStats;
 /* Run `times` more frames and fill the per-kernel averages.  Each launch is stamped with its own start / end events
  * (hipExtLaunchKernelGGL): kernel execution time as rocprofv3 --kernel-trace reports it, no launch gaps in it. */

@@ -371,6 +371,8 @@ void fo_apply_transform(FoCtx* c, const float m[16]) {
 void fo_set_aa_factor(FoCtx* c, float aa) { rec_open(c, "set_aa_factor"); rec_f(c, aa); rec_close(c); c->aa = aa; }
 void fo_set_text_subpixel(FoCtx* c, int enabled, float shift) { c->subpixel_enabled = enabled; c->subpixel_shift = shift; }
 void fo_set_text_subpixel_glyph_variants(FoCtx* c, int enabled) { c->subpixel_variants = enabled; }
+/* setTextSubpixelShift figbackend.nim:663-686: what renderText calls before every glyph (figrender.nim:476) */
+void fo_set_text_subpixel_shift(FoCtx* c, float shift) { rec_open(c, "set_text_subpixel_shift"); rec_f(c, shift); rec_close(c); c->subpixel_shift = shift; }
 
 /* beginFrame: glcontext.nim:2080-2092, 1951-1980 */
 void fo_begin_frame(FoCtx* c, int w, int h, int clear, const float rgba[4]) {
@@ -1824,10 +1826,10 @@ static void render_text(FoCtx* c, const FoScene* sc, const FoFig* n) { /* render
         }
       }
     }
-    c->subpixel_shift = shift;
+    fo_set_text_subpixel_shift(c, shift);
     fo_draw_image(c, key, pos, gl->colors, size, 0);
   }
-  c->subpixel_shift = 0.0f;
+  fo_set_text_subpixel_shift(c, 0.0f);
   fo_restore_transform(c);
 }
 

@@ -178,6 +178,7 @@ int fo_put_glyph_image(FoCtx*, int64_t key, int w, int h, const uint8_t* rgba, u
 int fo_put_flippy(FoCtx*, int64_t key, const uint8_t* file_bytes, size_t n, int out_rect[4]); /* putFlippy glcontext.nim:610-620 */
 void fo_set_text_subpixel(FoCtx*, int enabled, float shift);
 void fo_set_text_subpixel_glyph_variants(FoCtx*, int enabled);
+void fo_set_text_subpixel_shift(FoCtx*, float shift);
 /* readPixels: top-down RGBA8, (x,y,w,h) in top-down pixel coordinates; w<=0 -> whole frame */
 int fo_read_pixels(FoCtx*, int x, int y, int w, int h, uint8_t* out);
 int fo_read_mask(FoCtx*, int level, uint8_t* out_r8);

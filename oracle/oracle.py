@@ -76,6 +76,7 @@ def lib():
         L.fo_put_flippy.argtypes = [C.c_void_p, C.c_int64, C.c_char_p, C.c_size_t, C.c_int * 4]
         L.fo_set_text_subpixel.argtypes = [C.c_void_p, C.c_int, C.c_float]
         L.fo_set_text_subpixel_glyph_variants.argtypes = [C.c_void_p, C.c_int]
+        L.fo_set_text_subpixel_shift.argtypes = [C.c_void_p, C.c_float]
         L.fo_read_pixels.restype = C.c_int
         L.fo_read_pixels.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.fo_read_mask.restype = C.c_int
@@ -247,6 +248,9 @@ class Oracle:
         self.L.fo_set_ui_scale(self.h, ui_scale)
         self.W, self.H = int(w * ui_scale), int(h * ui_scale)
         self.L.fo_render_frame(self.h, cs.byref(), float(w), float(h), int(bool(clear)), _F4(*color))
+
+    def set_text_subpixel_shift(self, shift: float):
+        self.L.fo_set_text_subpixel_shift(self.h, float(shift))
 
     def record_begin(self):
         self.L.fo_record_begin(self.h)

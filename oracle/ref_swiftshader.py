@@ -465,6 +465,9 @@ class RefGL:
         m = np.array(m16, dtype=f32).reshape(4, 4).T
         self.mat = (self.mat @ m).astype(f32)
 
+    def set_text_subpixel_shift(self, shift):  # setTextSubpixelShift figbackend.nim:663-686
+        self.subpixel_shift = f32(shift)
+
     def set_aa_factor(self, aa):
         self.aa = f32(aa)
 
