@@ -5,9 +5,11 @@
   workload BASELINE.json configs[2]: examples/renderlist_100_common.nim restated at 3840x2160
            (300 shadowed SDF rects: 304 nodes -> ~700 draws) plus one full-frame nkBackdropBlur(18)
            ahead of the demo's own 360x240 blur node and overlay (SURVEY.md 8d "S300@4K")
-  step     one frame: binning + tile compositing + both blurs, from draw records already resident in HBM
-           (the host-side decomposition and the 90 KB record upload happen once, before the timed region;
-           the PCIe-inclusive rate is in DESIGN.md, it is never `value`)
+  step     one frame through fdh_render_frame: the scene tree goes in, the RGBA8 surface comes out (C++ tree walk,
+           draw records, 90 KB upload, binning, tile compositing, both blurs), as the reference's benchmark times
+           renderFrame per frame (examples/windy_non_clip_benchmark.nim:113-147); frames_in_flight contexts per GPU.
+           Beside it: the same frames through the ~710-call BackendContext seam (`per_call_path`), the GPU work
+           alone from resident records (`replay_resident_records`), one frame at a time
 
 N > 1 (launched by torch.distributed.run, one rank per GPU), two ways to shard:
   --mode frames   (default) frames are independent, so rank r renders its own frames with no data-path collective --
@@ -38,6 +40,8 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
 # two plain FMAs) at the 2.4 GHz maximum clock.  Transcendentals count as one instruction and cost four slots, so a kernel
 # full of them (this one: sqrt, exp, rcp per edge pixel) cannot reach frac = 1.
 VALU_PEAK_GINST = 256 * 4 * 2.4 / 2.0
+# FP32 vector peak (/opt/skills/guides/MI355X_MICROARCH.md): 256 CUs x 4 SIMDs x 64 lanes x 2 flops (FMA) per 2 cycles x 2.4 GHz
+VALU_PEAK_TFLOPS = 157.3
 
 
 def frame_tensor(ctx):
@@ -169,6 +173,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--repeats", type=int, default=5, help="timed batches of --steps frames each; the median batch is reported")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for the 1-GPU self-test)")
     ap.add_argument("--all-ranks-on-device0", action="store_true", help="self-test of the N>1 code path on a 1-GPU box")
@@ -204,26 +209,28 @@ def main():
     if args.mode == "stripes":
         return run_stripes(args, dist, rank, local_rank, world, on_host)
 
+    from figdraw_amd import call_stream as CS
     from figdraw_amd.context import HipContext
     from figdraw_amd.scenes import make_render_tree_100
 
     w, h = args.width, args.height
-    ctx = HipContext(device=local_rank)
-    scene = make_render_tree_100(w, h, frame=rank, full_frame_blur=True)
+    # F contexts per GPU, each with its own stream, surfaces and submit thread: frames are independent, and one frame at a time
+    # leaves the machine idle in every kernel's ramp and tail and in the small dependent launches that end a frame.
+    F = max(1, min(args.frames_in_flight, args.steps))
+    NS = 8  # distinct frames of the animation in rotation (rank r: frame = r + world * i)
+    scenes = [make_render_tree_100(w, h, frame=rank + world * i, full_frame_blur=True) for i in range(NS)]
+    cscenes = [sc.to_c() for sc in scenes]  # marshalled once: the timed loop hands the library FdhScene pointers
+    scene = scenes[0]
+    ctxs = [HipContext(device=local_rank) for _ in range(F)]
+    ctx = ctxs[0]
     t_host0 = time.perf_counter()
     ctx.render_frame(scene, w, h)  # decomposition + upload + first GPU pass
     ctx.sync()
     t_host1 = time.perf_counter()
-
-    # Frames are independent, so a GPU keeps F of them in flight: F contexts, each with its own stream and surfaces,
-    # rendering different frames of the animation.  One frame at a time leaves the machine idle in every kernel's ramp
-    # and tail and in the small dependent launches of a frame (measured: 53 -> 81 / 82 Gpixel/s from F = 1 -> 3 / 4; a fifth stream has no hardware queue of its own and loses).
-    F = max(1, min(args.frames_in_flight, args.steps))
-    ctxs = [ctx]
-    for i in range(1, F):
-        c = HipContext(device=local_rank)
-        c.render_frame(make_render_tree_100(w, h, frame=rank + world * i, full_frame_blur=True), w, h)
-        ctxs.append(c)
+    for i, c in enumerate(ctxs[1:], 1):
+        c.render_frame(scenes[i % NS], w, h)
+        c.sync()
+    player = CS.Player()  # tools/call_player.c: the frame loop in C, no Python between the library calls
 
     def sync_all():
         for c in ctxs:
@@ -235,8 +242,86 @@ def main():
             dist.barrier()
         sync_all()
 
-    def run_frames(total):
-        """`total` frames over the F contexts, enqueued round-robin a few at a time so every stream stays fed."""
+    def timed(fn, steps):
+        """barrier + synchronize, `steps` frames, synchronize; MAX over ranks.  Seconds."""
+        barrier()
+        t0 = time.perf_counter()
+        fn(steps)
+        sync_all()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            dist.barrier()
+            tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if on_host else f"cuda:{local_rank}")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt
+
+    def batches(fn, steps, repeats):
+        """`repeats` timed batches of exactly `steps` frames each; (median seconds, all of them in ms).  A 20-frame batch is a
+        1.2 ms timed region: one of them says little, the median of five is stable."""
+        ts = sorted(timed(fn, steps) for _ in range(repeats))
+        return ts[len(ts) // 2], [round(1e3 * t, 4) for t in ts]
+
+    # ---- THE PATH (`value`): scene tree in -> pixels out, every frame: fdh_render_frame = C++ tree walk + draw-record build +
+    # upload + binning + both blurs + compositing, frame k of the animation on context k % F.  What the reference's benchmark
+    # times per frame (examples/windy_non_clip_benchmark.nim:113-147: renderFrame(renders, frameSize)).
+    def run_dynamic(n):
+        player.play_scenes(ctxs, cscenes, n, w, h)
+
+    run_dynamic(args.warmup)
+    elapsed, batch_ms = batches(run_dynamic, args.steps, args.repeats)
+    # Integrity of the frames-in-flight mode (outside the timed region): every context must hold exactly the frame it
+    # renders with the GPU to itself.  (Wrong pixels once came from a packed-FP32 misread beside another context's MFMAs:
+    # DESIGN.md section 4.)  Context i rendered frame (last k with k % F == i) of the batch.
+    in_flight_differing = 0
+    in_flight_frames, in_flight_scene = [], []
+    for i, c in enumerate(ctxs):
+        k_last = max(k for k in range(max(args.steps - F, 0), args.steps) if k % F == i) if args.steps > i else None
+        got_in_flight = c.read_pixels()
+        in_flight_frames.append(got_in_flight)
+        si = (k_last % NS) if k_last is not None else (i % NS)
+        in_flight_scene.append(si)
+        c.render_frame(scenes[si], w, h)
+        c.sync()
+        in_flight_differing += int((got_in_flight != c.read_pixels()).any(axis=2).sum())
+    in_flight_vs_oracle = None
+    ms_step = 1e3 * elapsed / args.steps
+
+    # ---- the same frames through the PER-CALL seam: ~710 fdh_draw_* calls between fdh_begin_frame / fdh_end_frame per frame,
+    # issued from C (what a Nim HipContext shim behind figrender.nim would do: figbackend.nim:468-634)
+    rec = HipContext(record_only=True)
+    streams = []
+    for sc in scenes:
+        rec.record_begin()
+        rec.render_frame(sc, w, h)
+        calls = rec.record_calls()
+        streams.append(CS.pack(calls))
+    calls_per_frame = len(calls)
+    rec.close()
+
+    def run_calls(n):
+        player.play_frames(ctxs, streams, n, w, h)
+
+    run_calls(args.warmup)
+    pc_elapsed, pc_batch_ms = batches(run_calls, args.steps, args.repeats)
+    per_call_differing = 0
+    for i, c in enumerate(ctxs):  # the per-call frames are the same frames: same pixels
+        k_last = max(k for k in range(max(args.steps - F, 0), args.steps) if k % F == i) if args.steps > i else None
+        if k_last is not None:
+            got = c.read_pixels()
+            c.render_frame(scenes[k_last % NS], w, h)
+            c.sync()
+            per_call_differing += int((got != c.read_pixels()).any(axis=2).sum())
+    per_call = {"value": round(world * w * h * args.steps / pc_elapsed / 1e6, 1), "unit": "Mpixels/s", "ms_per_step": round(1e3 * pc_elapsed / args.steps, 4),
+                "batches_ms": pc_batch_ms, "calls_per_frame": calls_per_frame,
+                "pixels_differing_from_fdh_render_frame": per_call_differing,
+                "note": "the reference's plug-in seam: every BackendContext call of the frame (figbackend.nim:468-634) as one C-ABI call from "
+                        "tools/call_player.c, fdh_begin_frame .. fdh_end_frame per frame, same contexts in flight"}
+    st0 = ctx.frame_stats()
+
+    # ---- resident records: the GPU side alone (binning + blurs + compositing of a frame whose records stay in HBM; no tree walk,
+    # no upload).  Round 1 / 2's headline; here the ceiling the dynamic path is measured against.
+    def run_replay(total):
         left = [total // F + (1 if i < total % F else 0) for i in range(F)]
         while any(left):
             for i, c in enumerate(ctxs):
@@ -245,7 +330,18 @@ def main():
                     c.replay_async(n)
                     left[i] -= n
 
-    # strictly one frame at a time first (the latency figure; also what the per-kernel numbers below refer to)
+    run_replay(args.warmup)
+    rp_elapsed, rp_batch_ms = batches(run_replay, args.steps, args.repeats)
+    replay = {"value": round(world * w * h * args.steps / rp_elapsed / 1e6, 1), "unit": "Mpixels/s", "ms_per_step": round(1e3 * rp_elapsed / args.steps, 4),
+              "batches_ms": rp_batch_ms, "note": "fdh_replay_async: the frame's GPU work from records already resident in HBM (no tree walk, no upload)"}
+
+    # ---- strictly one frame at a time (the latency figures; also what the per-kernel numbers below refer to)
+    def run_single_dynamic(n):
+        player.play_scenes(ctxs[:1], cscenes, n, w, h)
+
+    run_single_dynamic(args.warmup)
+    sd_elapsed, sd_batch_ms = batches(run_single_dynamic, args.steps, args.repeats)
+    ctx.render_frame(scene, w, h)
     ctx.replay(args.warmup)
     barrier()
     ts0 = time.perf_counter()
@@ -254,64 +350,19 @@ def main():
     single_elapsed = time.perf_counter() - ts0
     st_batch = ctx.frame_stats()
 
-    run_frames(args.warmup)
-    barrier()
-    t0 = time.perf_counter()
-    run_frames(args.steps)  # EXACTLY K frames in total, one sync at the end
-    sync_all()
-    t1 = time.perf_counter()
-    if dist is not None:
-        dist.barrier()
-    elapsed = t1 - t0
-    # Integrity of the frames-in-flight mode (outside the timed region): every context must hold exactly the frame it
-    # renders with the GPU to itself.  (The blur passes once failed this as two kernels: DESIGN.md section 4.)
-    in_flight_differing = 0
-    in_flight_frames = []
-    in_flight_vs_oracle = None
-    for c in ctxs:
-        got_in_flight = c.read_pixels()
-        in_flight_frames.append(got_in_flight)
-        c.replay(1)
-        c.sync()
-        in_flight_differing += int((got_in_flight != c.read_pixels()).any(axis=2).sum())
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if on_host else f"cuda:{local_rank}")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    ms_step = 1e3 * elapsed / args.steps
-
     # per-frame distribution (SURVEY.md 8d timing protocol): one event between consecutive frames
     ft = ctx.replay_timed(min(args.steps, 120))
     frame_dist = {"n": int(len(ft)), "min": round(float(ft.min()), 4), "p50": round(float(np.percentile(ft, 50)), 4),
                   "p95": round(float(np.percentile(ft, 95)), 4), "max": round(float(ft.max()), 4)}
-    # per-kernel durations, HIP events on the context's stream around every launch (same frames, same records)
+    # per-kernel durations, HIP events on the context's stream stamped by each launch itself (same frames, same records)
     ctx.profile(min(args.steps, 50))
     st = ctx.frame_stats()
 
-    # the DYNAMIC path next to it (not `value`): fdh_render_frame every frame = C++ tree walk + record upload + kernels,
-    # four different frames of the animation in rotation, scenes marshalled to the C structs beforehand
     dynamic = None
     if rank == 0:
-        from figdraw_amd import context as C_
-
-        cs = [make_render_tree_100(w, h, frame=f, full_frame_blur=True).to_c() for f in range(4)]
-        col = C_._F4(1.0, 1.0, 1.0, 1.0)
-        n_dyn = min(args.steps, 100)
-        for i in range(8):
-            ctx._ck(ctx.L.fdh_render_frame(ctx.h, cs[i & 3].byref(), float(w), float(h), 1, col))
-        ctx.sync()
-        td = time.perf_counter()
-        for i in range(n_dyn):
-            ctx._ck(ctx.L.fdh_render_frame(ctx.h, cs[i & 3].byref(), float(w), float(h), 1, col))
-        ctx.sync()
-        td = time.perf_counter() - td
-        sd = ctx.frame_stats()
-        dynamic = {"ms_per_frame": round(1e3 * td / n_dyn, 4), "mpixels_per_s": round(w * h * n_dyn / td / 1e6, 1),
-                   "host_record_us": round(1e3 * sd.ms_host_record, 1), "host_upload_prep_us": round(1e3 * sd.ms_host_upload, 1),
-                   "host_launch_us": round(1e3 * sd.ms_host_launch, 1),
-                   "note": "scene tree walked, decomposed and uploaded every frame (the drop-in's per-frame cost); `value` replays resident records"}
-        # ... and the RETAINED path (fdh_scene_*): the tree lives in the context, one rectangle moves per frame, only its root
+        # the RETAINED path (fdh_scene_*): the tree lives in the context, one rectangle moves per frame, only its root
         # (and the two roots holding blur nodes) is decomposed again, every other root's records are spliced from the cache
+        n_dyn = min(args.steps, 100)
         sc_r = make_render_tree_100(w, h, frame=0, full_frame_blur=True)
         ctx.scene_retain(sc_r, w, h)
         lst = next(iter(sc_r.layers.values()))
@@ -334,11 +385,16 @@ def main():
         tr = time.perf_counter() - tr
         sr = ctx.frame_stats()
         walked, reused = ctx.scene_stats()
-        dynamic["retained"] = {"ms_per_frame": round(1e3 * tr / n_dyn, 4), "mpixels_per_s": round(w * h * n_dyn / tr / 1e6, 1),
-                               "host_record_us": round(1e3 * sr.ms_host_record, 1), "host_launch_us": round(1e3 * sr.ms_host_launch, 1),
-                               "roots_walked": walked, "roots_reused": reused, "uploaded_bytes_per_frame": ctx.last_upload_bytes(),
-                               "note": "fdh_scene_update_nodes (one of 304 roots moves) + fdh_scene_render per frame: the edited root is decomposed again, "
-                                       "the others' draw records come from the per-root cache; only the 256-byte chunks of the record block that changed are uploaded"}
+        dynamic = {"one_context": {"ms_per_frame": round(1e3 * sd_elapsed / args.steps, 4), "mpixels_per_s": round(w * h * args.steps / sd_elapsed / 1e6, 1), "batches_ms": sd_batch_ms},
+                   "host_record_us": round(1e3 * st0.ms_host_record, 1), "host_prepare_us": round(1e3 * st0.ms_host_upload, 1),
+                   "host_issue_us": round(1e3 * st0.ms_host_launch, 1),
+                   "note": "`value` IS this path with frames_in_flight contexts; host_*: per frame, calling thread records (tree walk) and prepares "
+                           "(staging buffer), the context's submit thread issues (upload kernel + launches)",
+                   "retained": {"ms_per_frame": round(1e3 * tr / n_dyn, 4), "mpixels_per_s": round(w * h * n_dyn / tr / 1e6, 1),
+                                "host_record_us": round(1e3 * sr.ms_host_record, 1), "host_issue_us": round(1e3 * sr.ms_host_launch, 1),
+                                "roots_walked": walked, "roots_reused": reused, "uploaded_bytes_per_frame": ctx.last_upload_bytes(),
+                                "note": "one context: fdh_scene_update_nodes (one of 304 roots moves) + fdh_scene_render per frame: the edited root is decomposed again, "
+                                        "the others' draw records come from the per-root cache; only the 256-byte chunks of the record block that changed are uploaded"}}
         ctx.render_frame(scene, w, h)  # back to the benchmark frame for the gather / parity legs below
         ctx.sync()
 
@@ -393,15 +449,32 @@ def main():
     if st.ms_composite_main > 0:
         k = pmc.get("k_composite_tiles.phase0", {})
         insts = k.get("SQ_INSTS_VALU")
-        roofline = {"kernel": "k_composite_tiles<4> (phase 0; the build for phases without clip operations)", "ms_per_launch": round(st.ms_composite_main, 4),
-                    "bound": "valu", "unit": "G wave-instructions/s", "peak": round(VALU_PEAK_GINST, 1),
-                    "achieved": round(insts / (st.ms_composite_main * 1e-3) / 1e9, 1) if insts else None,
-                    "frac": round(insts / (st.ms_composite_main * 1e-3) / 1e9 / VALU_PEAK_GINST, 4) if insts else None,
-                    "valu_instructions_per_launch": insts, "salu_instructions_per_launch": k.get("SQ_INSTS_SALU"),
+        sec = st.ms_composite_main * 1e-3
+        fm = list(st.fragments_main_by_mode)
+        tflops = st.flops_composite_main / sec / 1e12
+        # ALGORITHMIC figure first (flops per covered fragment by mode x the fragments this launch covers, over the
+        # launch's duration measured in this run, against the FP32 vector peak); the instruction ISSUE rate beside it
+        roofline = {"kernel": "k_composite_tiles<4, true>: the launch that starts a frame (every bin, from the clear colour; the build for phases "
+                              "without clip operations) -- a row of its own in profiles/*_kernel_stats*.csv",
+                    "ms_per_launch": round(st.ms_composite_main, 4),
+                    "bound": "valu", "unit": "TFLOP/s", "peak": VALU_PEAK_TFLOPS, "achieved": round(tflops, 2), "frac": round(tflops / VALU_PEAK_TFLOPS, 4),
+                    "algorithmic": {"flops_per_launch": int(st.flops_composite_main),
+                                    "fragments_by_mode": {"ClipAA(3)": fm[0], "DropShadow(7)": fm[1], "InsetShadow(9)": fm[2], "AnnularAA(12)": fm[3],
+                                                          "other": int(st.fragments_main_other), "of_which_elliptical_corners": int(st.fragments_main_elliptical)},
+                                    "flops_per_fragment": {"ClipAA(3)": 25, "DropShadow(7)": 36, "InsetShadow(9)": 71, "AnnularAA(12)": 28, "other": 25,
+                                                           "elliptical_corners": 30, "blend_and_requantise": 16},
+                                    "note": "SURVEY.md 8(d) per-fragment flop counts (35 + exp, 70 + exp with exp as 1) x sum of quad areas per mode"},
+                    "issue_rate": {"unit": "G wave-instructions/s", "peak": round(VALU_PEAK_GINST, 1),
+                                   "achieved": round(insts / sec / 1e9, 1) if insts else None,
+                                   "frac": round(insts / sec / 1e9 / VALU_PEAK_GINST, 4) if insts else None,
+                                   "valu_instructions_per_launch": insts, "salu_instructions_per_launch": k.get("SQ_INSTS_SALU"),
+                                   "issued_lane_ops_per_algorithmic_flop": round(insts * 64 / st.flops_composite_main, 3) if insts and st.flops_composite_main else None,
+                                   "note": "SQ_INSTS_VALU per launch (PMC pass) / this run's launch time against one wave64 VALU instruction per SIMD per 2 cycles "
+                                           "(1024 SIMDs x 2.4 GHz / 2); an issue rate, not an algorithmic fraction: more instructions would raise it"},
                     "traffic": k.get("hbm_bytes"), "traffic_source": pmc_src,
                     "hbm": dict(hbm(st.bytes_composite_main, st.ms_composite_main), algorithmic_bytes_per_launch=int(st.bytes_composite_main)),
-                    "note": "fused tile compositor: one wave64 VALU instruction per SIMD per 2 cycles is the ceiling (peak = 1024 SIMDs x 2.4 GHz / 2; transcendentals take 4 slots); "
-                            "HBM-wise it moves 4 B/pixel out + 128 B/draw in by construction (`hbm`); the HBM-bound launches are the blur passes (roofline_blur)"}
+                    "note": "fused tile compositor: VALU-bound (it moves 4 B/pixel out + 128 B/draw in by construction, `hbm`: ~0.1 of the HBM peak says nothing "
+                            "about the kernel); the HBM-bound launches are the blur passes (roofline_blur)"}
     # The HBM-bound launches: the two passes of the frame's largest blur node (full frame here), each against its own bytes
     roofline_blur = None
     if st.ms_blur_big_h > 0 and st.ms_blur_big_v > 0:
@@ -419,6 +492,8 @@ def main():
                              bytes_note="H: region + halo rows read and written; V: those rows read, the region written; the fused composite reads the "
                                         "surface only where it has to blend (the cleared opaque surface of this frame: nowhere but the quad's border blocks)")
     frame_gbs = st.bytes_algorithmic / (ms_step * 1e-3) / 1e9
+    single_dyn_ms = 1e3 * sd_elapsed / args.steps
+    single_gbs = st.bytes_algorithmic / (single_dyn_ms * 1e-3) / 1e9
 
     cpu_baseline = None
     if world == 1 and not args.no_cpu_baseline:
@@ -446,9 +521,10 @@ def main():
         cpu_baseline["parity_max_lsb"] = int(d.max())
         cpu_baseline["parity_pixels_differing"] = int((d.max(axis=2) > 0).sum())
         if F > 1:  # one of the frames that were rendered IN FLIGHT (kept from before the re-render above) against the oracle
-            orc.render_frame(make_render_tree_100(w, h, frame=rank + world * (F - 1), full_frame_blur=True), w, h)
+            orc.render_frame(scenes[in_flight_scene[F - 1]], w, h)
             d = np.abs(in_flight_frames[F - 1].astype(int) - orc.read_pixels().astype(int))
-            in_flight_vs_oracle = {"context": F - 1, "parity_max_lsb": int(d.max()), "parity_pixels_differing": int((d.max(axis=2) > 0).sum())}
+            in_flight_vs_oracle = {"context": F - 1, "animation_frame": rank + world * in_flight_scene[F - 1], "parity_max_lsb": int(d.max()),
+                                   "parity_pixels_differing": int((d.max(axis=2) > 0).sum())}
 
     out = {
         "metric": "Mpixels/s composited @3840x2160, 300 SDF rects+shadows; % HBM roofline",
@@ -458,6 +534,12 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": round(ms_step, 4),
+        "repeats": args.repeats,
+        "batches_ms": batch_ms,
+        "timing": f"median of {args.repeats} timed batches of exactly {args.steps} frames each, every batch bracketed by barrier + synchronize "
+                  "(`batches_ms`: all of them, sorted); `value` = pixels of one batch / the median batch's wall time",
+        "step": "one frame through fdh_render_frame: scene tree in -> RGBA8 surface out (C++ tree walk, draw records, upload, binning, both blurs, "
+                "compositing), frame k of the animation on context k % frames_in_flight; the loop is C (tools/call_player.c)",
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
@@ -469,12 +551,17 @@ def main():
                    "parallelism": f"frame-parallel x{world}" if world > 1 else "single GPU", "frames_in_flight_per_gpu": F},
         "frames_in_flight_check": {"contexts": F, "identical_to_each_frame_rendered_alone": in_flight_differing == 0,
                                    "pixels_differing": in_flight_differing, "in_flight_frame_vs_oracle": in_flight_vs_oracle},
-        "one_frame_at_a_time": {"value": round(w * h * args.steps / single_elapsed / 1e6, 1), "unit": "Mpixels/s (this rank)",
-                                "ms_per_step": round(1e3 * single_elapsed / args.steps, 4)},
+        "per_call_path": per_call,
+        "replay_resident_records": replay,
+        "one_frame_at_a_time": {"value": round(w * h * args.steps / sd_elapsed / 1e6, 1), "unit": "Mpixels/s (this rank)",
+                                "ms_per_step": round(single_dyn_ms, 4), "batches_ms": sd_batch_ms,
+                                "replay_resident_records": {"value": round(w * h * args.steps / single_elapsed / 1e6, 1), "ms_per_step": round(1e3 * single_elapsed / args.steps, 4)},
+                                "note": "one context: fdh_render_frame per frame (the submit thread still overlaps frame n's launches with frame n + 1's tree walk)"},
         "roofline": roofline,
         "roofline_blur": roofline_blur,
         "frame": {"algorithmic_bytes": int(st.bytes_algorithmic), "achieved_GBs": round(frame_gbs, 1),
                   "frac_of_hbm_peak": round(frame_gbs / HBM_PEAK_GBS, 5),
+                  "one_frame_at_a_time": {"achieved_GBs": round(single_gbs, 1), "frac_of_hbm_peak": round(single_gbs / HBM_PEAK_GBS, 5)},
                   "gfragments_per_s": round(world * st.fragments * args.steps / elapsed / 1e9, 2),
                   "ms_event_timed": round(st_batch.ms_total, 4), "ms_per_frame_dist": frame_dist,
                   "gl_equivalent_bytes": int(8 * st.fragments),  # 8 B x fragments: what a GL rasteriser's blend RMW moves; context only
@@ -489,7 +576,7 @@ def main():
     if gather_ms is not None:
         out["gather_ms"] = round(gather_ms, 3)
     # a frame that came out differently in flight than alone (or off the oracle) voids the throughput figure
-    bad = in_flight_differing != 0 or (in_flight_vs_oracle is not None and in_flight_vs_oracle["parity_max_lsb"] > 1) or \
+    bad = in_flight_differing != 0 or per_call_differing != 0 or (in_flight_vs_oracle is not None and in_flight_vs_oracle["parity_max_lsb"] > 1) or \
         (cpu_baseline is not None and cpu_baseline["parity_max_lsb"] > 1)
     if bad:
         out["value"] = None

@@ -832,14 +832,18 @@ __device__ unsigned int g_edge_bad[4096 * 8];
 #endif
 // kPaths: bit 0 = the one-pixel-slot path (rotated / skewed quads, bezier strokes, rect-mask setup, minified images),
 // bit 1 = the 4-wide atlas path (axis-aligned glyphs, images at >= 1:1, MSDF).  0: SDF draws, clips and rect masks only.
-template <int kPaths>
+// kFull: the launch that starts a frame -- every bin of the grid, from the clear colour (nothing is loaded), bins taken longest
+// list first, with the sort for the next frame riding along.  A symbol of its own, so that the dominant launch of a frame is a
+// row of its own in a rocprofv3 kernel summary (the later phases' launches cover a blur node's footprint and take microseconds).
+template <int kPaths, bool kFull>
 __global__ __launch_bounds__(64, (kPaths & 1) ? 4 : kPaths == 4 ? FDH_UNIFORM_WAVES : FDH_FAST_WAVES) void k_composite_tiles(
     // the sixteen dwords a wave needs before anything else, as leading scalar arguments: with kernel-argument preloading
     // (-amdgpu-kernarg-preload-count, csrc/Makefile) they arrive in SGPRs with the wave instead of through a first s_load
     const int* __restrict__ a_order, int* __restrict__ a_order_next, const uint32_t* __restrict__ a_counts, const uint2* __restrict__ a_lists,
     int a_bin_x0, int a_bin_y0, int a_bin_nx, int a_bin_ny, int a_bins_x, int a_stride, int a_row_lo, int a_row_hi,
     const DrawRec* __restrict__ draws, const QuadExt* __restrict__ exts, CompositeParams P) {
-  P.order = a_order; P.order_next = a_order_next; P.counts = a_counts; P.lists = a_lists;
+  P.order = kFull ? a_order : nullptr; P.order_next = kFull ? a_order_next : nullptr; P.counts = a_counts; P.lists = a_lists;
+  if (kFull) P.load_fb = 0;
   P.bin_x0 = a_bin_x0; P.bin_y0 = a_bin_y0; P.bin_nx = a_bin_nx; P.bin_ny = a_bin_ny;
   P.bins_x = a_bins_x; P.stride = a_stride; P.row_lo = a_row_lo; P.row_hi = a_row_hi;
   // clip stack: 4 pixels' q8 mask values packed per lane and level.  Dynamic LDS: 4 KB when the phase has clip operations,
@@ -895,14 +899,14 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? 4 : kPaths == 4 ? FDH_UNIFORM_WA
 #if FDH_TIMING
   T_cnt = FDH_NOW() - T0 + (cnt & 0u);
 #endif
-  if (cnt == 0 && P.load_fb) return;  // nothing lands in this bin: the surface already holds the result
+  if (!kFull && cnt == 0 && P.load_fb) return;  // nothing lands in this bin: the surface already holds the result
 
   const bool row_ok = py < P.H;
   const bool vec_ok = row_ok && px0 + 3 < P.W && (P.pitch & 3) == 0;  // whole 16-byte group inside the frame
   const size_t pix = (size_t)py * P.pitch + px0;
   F4 F0, F1, F2, F3;
   F0 = F1 = F2 = F3 = unpack255(P.clear_rgba8);
-  if (P.load_fb) {
+  if (!kFull && P.load_fb) {
     if (vec_ok) {
       const uint4 q = *reinterpret_cast<const uint4*>(P.fb + pix);
       F0 = unpack255(q.x); F1 = unpack255(q.y); F2 = unpack255(q.z); F3 = unpack255(q.w);
@@ -1498,7 +1502,7 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? 4 : kPaths == 4 ? FDH_UNIFORM_WA
   int lane_e = threadIdx.x & 63;
   asm volatile("" : "+v"(lane_e));
   const int px0e = tx0 + (lane_e & 7) * 4, pye = ty0 + (lane_e >> 3);
-  if (!(touched || !P.load_fb) || pye < P.row_lo || pye >= P.row_hi) return;
+  if (!(touched || kFull || !P.load_fb) || pye < P.row_lo || pye >= P.row_hi) return;
   const bool row_ok_e = pye < P.H;
   const size_t pixe = (size_t)pye * P.pitch + px0e;
   if (row_ok_e && px0e + 3 < P.W && (P.pitch & 3) == 0) {
@@ -2296,15 +2300,20 @@ void launch_composite(hipStream_t s, const DrawRec* draws, const QuadExt* exts, 
   if (force == 2) P.has_atlas = 1;
   if (force == 1) P.has_masks = 1;  // (the build with mask registers and the 4-KB stack, even where no clip is open)
   const size_t lds = P.has_masks ? sizeof(uint32_t) * kMaskDepth * 64 : sizeof(uint32_t) * 256;
+  const bool full = P.load_fb == 0;  // the launch that starts a frame (k_composite_tiles<., true>)
+#define FDH_COMPOSITE(paths) \
+  do { if (full) FDH_LAUNCH((k_composite_tiles<paths, true>), dim3(grid), blk, lds, s, P.order, P.order_next, P.counts, P.lists, P.bin_x0, P.bin_y0, P.bin_nx, P.bin_ny, P.bins_x, P.stride, P.row_lo, P.row_hi, draws, exts, P); \
+       else FDH_LAUNCH((k_composite_tiles<paths, false>), dim3(grid), blk, lds, s, P.order, P.order_next, P.counts, P.lists, P.bin_x0, P.bin_y0, P.bin_nx, P.bin_ny, P.bins_x, P.stride, P.row_lo, P.row_hi, draws, exts, P); } while (0)
 #if FDH_SPLIT_UNIFORM
-  if (P.has_slow) FDH_LAUNCH(k_composite_tiles<3>, dim3(grid), blk, lds, s, P.order, P.order_next, P.counts, P.lists, P.bin_x0, P.bin_y0, P.bin_nx, P.bin_ny, P.bins_x, P.stride, P.row_lo, P.row_hi, draws, exts, P);
+  if (P.has_slow) FDH_COMPOSITE(3);
   else { launch_composite_uniform(s, t_prof_start, t_prof_stop, grid, lds, draws, exts, P, P.has_atlas ? 2 : P.has_masks ? 0 : 4); if (t_prof_start) t_prof_used = true; }
 #else
-  if (P.has_slow) FDH_LAUNCH(k_composite_tiles<3>, dim3(grid), blk, lds, s, P.order, P.order_next, P.counts, P.lists, P.bin_x0, P.bin_y0, P.bin_nx, P.bin_ny, P.bins_x, P.stride, P.row_lo, P.row_hi, draws, exts, P);
-  else if (P.has_atlas) FDH_LAUNCH(k_composite_tiles<2>, dim3(grid), blk, lds, s, P.order, P.order_next, P.counts, P.lists, P.bin_x0, P.bin_y0, P.bin_nx, P.bin_ny, P.bins_x, P.stride, P.row_lo, P.row_hi, draws, exts, P);
-  else if (!P.has_masks) FDH_LAUNCH(k_composite_tiles<4>, dim3(grid), blk, lds, s, P.order, P.order_next, P.counts, P.lists, P.bin_x0, P.bin_y0, P.bin_nx, P.bin_ny, P.bins_x, P.stride, P.row_lo, P.row_hi, draws, exts, P);
-  else FDH_LAUNCH(k_composite_tiles<0>, dim3(grid), blk, lds, s, P.order, P.order_next, P.counts, P.lists, P.bin_x0, P.bin_y0, P.bin_nx, P.bin_ny, P.bins_x, P.stride, P.row_lo, P.row_hi, draws, exts, P);
+  if (P.has_slow) FDH_COMPOSITE(3);
+  else if (P.has_atlas) FDH_COMPOSITE(2);
+  else if (!P.has_masks) FDH_COMPOSITE(4);
+  else FDH_COMPOSITE(0);
 #endif
+#undef FDH_COMPOSITE
 }
 // small regions: fewer outputs per thread -> more, shorter waves (see NOUT above)
 #ifndef FDH_BLUR_NOUT
@@ -2482,10 +2491,15 @@ void debug_counters(unsigned long long out[64], bool reset) {
 #endif
 
 #else  // FDH_TU 1: the one launcher of this unit
+template <int kPaths, bool kFull>
+static void launch_uniform2(hipStream_t s, hipEvent_t e0, hipEvent_t e1, int grid, size_t lds, const DrawRec* draws, const QuadExt* exts, const CompositeParams& P) {
+  if (e0) hipExtLaunchKernelGGL((k_composite_tiles<kPaths, kFull>), dim3(grid), dim3(64), lds, s, e0, e1, 0, P.order, P.order_next, P.counts, P.lists, P.bin_x0, P.bin_y0, P.bin_nx, P.bin_ny, P.bins_x, P.stride, P.row_lo, P.row_hi, draws, exts, P);
+  else hipLaunchKernelGGL((k_composite_tiles<kPaths, kFull>), dim3(grid), dim3(64), lds, s, P.order, P.order_next, P.counts, P.lists, P.bin_x0, P.bin_y0, P.bin_nx, P.bin_ny, P.bins_x, P.stride, P.row_lo, P.row_hi, draws, exts, P);
+}
 template <int kPaths>
 static void launch_uniform(hipStream_t s, hipEvent_t e0, hipEvent_t e1, int grid, size_t lds, const DrawRec* draws, const QuadExt* exts, const CompositeParams& P) {
-  if (e0) hipExtLaunchKernelGGL(k_composite_tiles<kPaths>, dim3(grid), dim3(64), lds, s, e0, e1, 0, P.order, P.order_next, P.counts, P.lists, P.bin_x0, P.bin_y0, P.bin_nx, P.bin_ny, P.bins_x, P.stride, P.row_lo, P.row_hi, draws, exts, P);
-  else hipLaunchKernelGGL(k_composite_tiles<kPaths>, dim3(grid), dim3(64), lds, s, P.order, P.order_next, P.counts, P.lists, P.bin_x0, P.bin_y0, P.bin_nx, P.bin_ny, P.bins_x, P.stride, P.row_lo, P.row_hi, draws, exts, P);
+  if (P.load_fb == 0) launch_uniform2<kPaths, true>(s, e0, e1, grid, lds, draws, exts, P);  // the launch that starts a frame
+  else launch_uniform2<kPaths, false>(s, e0, e1, grid, lds, draws, exts, P);
 }
 void launch_composite_uniform(hipStream_t s, hipEvent_t e0, hipEvent_t e1, int grid, size_t lds, const DrawRec* draws, const QuadExt* exts, const CompositeParams& P, int paths) {
   if (paths == 2) launch_uniform<2>(s, e0, e1, grid, lds, draws, exts, P);

@@ -42,7 +42,7 @@ def code_objects(blob: bytes):
         at += len(MAGIC)
 
 
-UNIFORM_KERNELS = ("k_composite_tilesILi4E", "k_composite_tilesILi0E", "k_composite_tilesILi2E")
+UNIFORM_KERNELS = tuple("k_composite_tilesILi%dELb%dE" % (paths, full) for paths in (4, 0, 2) for full in (1, 0))
 # writes of the exec mask: s_*saveexec*, any scalar instruction whose destination is exec / exec_lo / exec_hi, and the VOPC
 # compares that write exec directly (v_cmpx_*)
 EXEC_WRITE = re.compile(r"^\s*(s_\w*saveexec\w*|s_\w+\s+exec(_lo|_hi)?\b|v_cmpx_\w+)")
@@ -177,7 +177,7 @@ def main():
               "(update UNIFORM_KERNELS in tools/lint_isa.py when the compositor's template arguments change)")
         rc = 1
     for uk, lines in sorted(uniform_lines.items()):
-        name = "k_composite_tiles<%s>" % uk[len("k_composite_tilesILi"):-1]
+        name = "k_composite_tiles<%s, %s>" % (uk[len("k_composite_tilesILi")], "true" if uk.endswith("Lb1E") else "false")
         w = exec_writes_in_draw_loop(lines)
         if w:
             print(f"lint_isa: {name} has a divergent branch inside its draw loop (it is compiled with "
