@@ -677,6 +677,8 @@ void Context::emit_quad_pts(DrawRec& r, const float vx[4], const float vy[4], in
     r.oy = py[3];
     r.inv_w = 1.0f / (px[1] - px[0]);
     r.inv_h = 1.0f / (py[0] - py[3]);
+    r.kx = 2.0f * r.p0 * r.inv_w;  // (meaningful for SDF quads, where p0, p1 are the quad's half extents)
+    r.ky = 2.0f * r.p1 * r.inv_h;
     set_saturated_core(r, px[1] - px[0], py[0] - py[3]);
   } else {
     QuadExt q;
@@ -1160,8 +1162,8 @@ void Context::end_frame() {  // glcontext.nim:1982-1989
   frame_begun_ = false;
   const auto t1 = std::chrono::steady_clock::now();
   host_record_ms_ = std::chrono::duration<float, std::milli>(t1 - t_begin_frame_).count();
-  // a list entry carries the draw index in 26 bits beside its path code and flags (k_bin_draws, LE_INDEX)
-  if (recs_.size() >= (1u << 26)) throw Error(FDH_ERR_INVALID, "more than 67 108 863 draw records in one frame");
+  // a list entry carries the draw index in 25 bits beside its path code and flags (k_bin_draws, LE_INDEX)
+  if (recs_.size() >= LE_INDEX) throw Error(FDH_ERR_INVALID, "more than 33 554 430 draw records in one frame");
   if (host_only_) return;
   prepare(next_);
   drain();  // the previous frame's launches (normally long issued: they ran while this frame was being recorded)
@@ -1373,6 +1375,21 @@ void Context::prepare(LaunchJob& J) {
               if (fill_mode != 0u) a &= r.mid & r.stop;
               if ((a >> 24) == 255u) flags |= LE_OPAQUE;
             }
+          }
+        }
+        // the next draw shares this one's distance field (LE_SHARE): both one-colour fill / stroke / inner shadow (path codes
+        // 1, 3, 4 and their elliptical twins) over the same quad, radii and AA factor, the same shape half extents
+        if (((flags >> LE_PATH_SHIFT) & 15u) != 0u && mode != 7u && i + 1 < n) {
+          const DrawRec& b = recs_[i + 1];
+          const uint32_t omb = b.op_mode, modeb = omb & 255u;
+          const bool simple_b = ((omb >> 12) & 15u) == OP_DRAW && !(omb & F_GENERAL) && (omb & F_SOLID) && ((omb >> 9) & 7u) == 0u &&
+                                (modeb == 3u || modeb == 9u || modeb == 12u) && ((omb ^ om) & F_ELLIP) == 0u;
+          bool same_phase = false;
+          for (const Phase& ph : J.phases) if ((int)i >= ph.first && (int)i + 1 < ph.first + ph.count) same_phase = true;
+          if (simple_b && same_phase && std::memcmp(&r.ox, &b.ox, 6 * sizeof(float)) == 0 && std::memcmp(r.r, b.r, sizeof r.r) == 0 &&
+              std::memcmp(&r.bx0, &b.bx0, 4 * sizeof(int16_t)) == 0 && r.aa == b.aa) {
+            const float sax = mode == 9u ? r.p0 : r.p2, say = mode == 9u ? r.p1 : r.p3, sbx = modeb == 9u ? b.p0 : b.p2, sby = modeb == 9u ? b.p1 : b.p3;
+            if (sax == sbx && say == sby) flags |= LE_SHARE;
           }
         }
         br[i] = BinRec{bboxes_[i], r.ix0, r.iy0, r.ix1, r.iy1, flags, 0u};

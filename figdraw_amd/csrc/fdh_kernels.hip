@@ -590,10 +590,27 @@ __device__ __forceinline__ DrawRec load_rec_whole(const DrawRec* __restrict__ p)
   r.aux2 = f(q[6].x);
   r.bx0 = (int16_t)(q[6].y & 0xffffu); r.by0 = (int16_t)(q[6].y >> 16); r.bx1 = (int16_t)(q[6].z & 0xffffu); r.by1 = (int16_t)(q[6].z >> 16);
   r.ix0 = (int16_t)(q[6].w & 0xffffu); r.iy0 = (int16_t)(q[6].w >> 16); r.ix1 = (int16_t)(q[7].x & 0xffffu); r.iy1 = (int16_t)(q[7].x >> 16);
-  r._pad[0] = r._pad[1] = r._pad[2] = 0u;
+  r.kx = f(q[7].y); r.ky = f(q[7].z); r._pad = 0u;
   return r;
 }
-static_assert(offsetof(DrawRec, aux2) == 96 && offsetof(DrawRec, bx0) == 100 && offsetof(DrawRec, ix0) == 108 && offsetof(DrawRec, aa) == 88, "load_rec_whole follows DrawRec's layout");
+static_assert(offsetof(DrawRec, p2) == 32 && offsetof(DrawRec, col) == 64 && offsetof(DrawRec, aux2) == 96 && offsetof(DrawRec, bx0) == 100 && offsetof(DrawRec, ix0) == 108 && offsetof(DrawRec, aa) == 88 && offsetof(DrawRec, kx) == 116, "load_rec_whole follows DrawRec's layout");
+
+// Local-frame coordinates of a lane's pixels on an axis-aligned SDF quad (atlas.frag:252-262: p = (uv - 0.5) * 2 * quadHalfExtents,
+// uv = (pixel centre - quad origin) / quad extent).  Pixel 0 follows the shader's own operations ((c - o) * inv - 0.5, times 2 p);
+// its neighbours are pixel 0 plus multiples of the per-pixel step kx = 2 p0 inv_w the host put into the record -- 6
+// instructions for the four x, 3 for y, where the shader's formula per pixel costs 4 each.  Every path of every build uses these
+// (the builds must agree to the bit: tests/test_hip_parity.py::test_every_kernel_build_gives_the_same_pixels).
+__device__ __forceinline__ void local_x4(const DrawRec& r, float cx0, float (&lx)[4]) {
+  lx[0] = __builtin_fmaf(cx0 - r.ox, r.inv_w, -0.5f) * (2.0f * r.p0);
+  lx[1] = lx[0] + r.kx;
+  lx[2] = __builtin_fmaf(2.0f, r.kx, lx[0]);
+  lx[3] = __builtin_fmaf(3.0f, r.kx, lx[0]);
+}
+__device__ __forceinline__ float local_y_up(const DrawRec& r, float cy) {  // -ly: the shader flips y (p.y = -p.y, atlas.frag:262)
+  return __builtin_fmaf(r.oy - cy, r.inv_h, 0.5f) * (2.0f * r.p1);
+}
+// 1 - clamp(aa d + 0.5, 0, 1) (atlas.frag:389-393) as ONE instruction: clamp(0.5 - aa d, 0, 1) = v_fma with the clamp modifier
+__device__ __forceinline__ float cover_aa(float d, float aa) { return clamp01(__builtin_fmaf(-d, aa, 0.5f)); }
 
 // ---- branch-free shape distance: no per-lane exec juggling (divergent control flow is paid in
 // s_and_saveexec/s_or sequences on the CU's single scalar unit).  The two-sqrt ellipse evaluation is skipped with
@@ -948,80 +965,82 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? 4 : kPaths == 4 ? FDH_UNIFORM_WA
     T_cull += FDH_NOW() - Tc0 + (m & 0ull);
 #endif
     if (m == 0) continue;
+    // sdRoundedBox (atlas.frag:51-69) of the lane's four pixels at height py for half extents (bx, by)
+    auto dist4 = [&](const DrawRec& r, const f2 pxa, const f2 pxb, const float py_, const float bx, const float by, f2& da, f2& db) __attribute__((always_inline)) {
+      const bool top = py_ > 0.0f;
+      const float rR = top ? r.r[0] : r.r[1], rL = top ? r.r[2] : r.r[3];
+      const float ay = __builtin_fabsf(py_) - by;
+      const f2 rra = {pxa.x > 0.0f ? rR : rL, pxa.y > 0.0f ? rR : rL}, rrb = {pxb.x > 0.0f ? rR : rL, pxb.y > 0.0f ? rR : rL};
+      const f2 axa = {__builtin_fabsf(pxa.x), __builtin_fabsf(pxa.y)}, axb = {__builtin_fabsf(pxb.x), __builtin_fabsf(pxb.y)};
+      const f2 qxa = axa - bx + rra, qxb = axb - bx + rrb;
+      const f2 qya = ay + rra, qyb = ay + rrb;
+      const f2 mxa = {__builtin_fmaxf(qxa.x, 0.0f), __builtin_fmaxf(qxa.y, 0.0f)}, mxb = {__builtin_fmaxf(qxb.x, 0.0f), __builtin_fmaxf(qxb.y, 0.0f)};
+      const f2 mya = {__builtin_fmaxf(qya.x, 0.0f), __builtin_fmaxf(qya.y, 0.0f)}, myb = {__builtin_fmaxf(qyb.x, 0.0f), __builtin_fmaxf(qyb.y, 0.0f)};
+      f2 lena = {__builtin_fmaxf(mxa.x, mya.x), __builtin_fmaxf(mxa.y, mya.y)}, lenb = {__builtin_fmaxf(mxb.x, myb.x), __builtin_fmaxf(mxb.y, myb.y)};
+      const f2 lowa = {__builtin_fminf(qxa.x, qya.x), __builtin_fminf(qxa.y, qya.y)}, lowb = {__builtin_fminf(qxb.x, qyb.x), __builtin_fminf(qxb.y, qyb.y)};
+      if (__any(lowa.x > 0.0f || lowa.y > 0.0f || lowb.x > 0.0f || lowb.y > 0.0f)) {  // some lane sits in a corner cell
+        const f2 sa2 = mxa * mxa + mya * mya, sb2 = mxb * mxb + myb * myb;
+        lena.x = lowa.x > 0.0f ? fsqrt(sa2.x) : lena.x; lena.y = lowa.y > 0.0f ? fsqrt(sa2.y) : lena.y;
+        lenb.x = lowb.x > 0.0f ? fsqrt(sb2.x) : lenb.x; lenb.y = lowb.y > 0.0f ? fsqrt(sb2.y) : lenb.y;
+      }
+      const f2 ina = {__builtin_fminf(__builtin_fmaxf(qxa.x, qya.x), 0.0f), __builtin_fminf(__builtin_fmaxf(qxa.y, qya.y), 0.0f)};
+      const f2 inb = {__builtin_fminf(__builtin_fmaxf(qxb.x, qyb.x), 0.0f), __builtin_fminf(__builtin_fmaxf(qxb.y, qyb.y), 0.0f)};
+      da = ina + lena - rra; db = inb + lenb - rrb;
+    };
+    // elliptical corners (atlas.frag:96-115): the distance itself comes from the general routine, four pixels
+    // unpacked; coverage and blend below stay packed
+    auto dist4e = [&](const DrawRec& r, const f2 pxa, const f2 pxb, const float py_, const float bx, const float by, f2& oa, f2& ob) __attribute__((always_inline)) {
+      const float px4[4] = {pxa.x, pxa.y, pxb.x, pxb.y};
+      float d4[4];
+      shape_distN<4>(true, px4, py_, bx, by, r.r[0], r.r[1], r.r[2], r.r[3], d4);
+      oa = {d4[0], d4[1]}; ob = {d4[2], d4[3]};
+    };
     // ---- the common edge strip: ONE colour, nothing clipping, mode fill / drop shadow / inner shadow / AA stroke (list-entry
     // path codes 1..8, k_bin_draws).  Written on float2 pairs -- pixels (0,1) and (2,3) of the lane side by side; same
-    // formulas, same order of operations as the general path in shade() below.
-    auto simple_edge = [&](const DrawRec& r, const uint32_t mode, const bool ellip, F4& A0, F4& A1, F4& A2, F4& A3) __attribute__((always_inline)) {
-      const bool inset = mode == 9u;
+    // formulas, same order of operations as the general path in shade() below.  Two halves: the distance field of the node's
+    // shape at the lane's pixels (edge_geom), and what ONE draw makes of it -- coverage by mode, blend (edge_blend).  A node's
+    // fill, stroke and inner shadows are consecutive draws over the same quad and the same shape
+    // (renderRoundedShapeScaledCorners figrender.nim:806-873, renderInnerShadows :716-744): the draw loop evaluates the field
+    // once for such a run (LE_SHARE) and calls edge_blend per draw with that draw's own few parameters.
+    auto edge_geom = [&](const DrawRec& r, const bool inset, const bool ellip, f2& lxa, f2& lxb, float& pyy, f2& da, f2& db) __attribute__((always_inline)) {
       const float shx = inset ? r.p0 : r.p2, shy = inset ? r.p1 : r.p3;
-      const float tq = (cy - r.oy) * r.inv_h;
-      const float pyy = -((tq - 0.5f) * 2.0f * r.p1);
-      const f2 cxa = {cx0, cx0 + 1.0f}, cxb = {cx0 + 2.0f, cx0 + 3.0f};
-      const f2 ua = (cxa - r.ox) * r.inv_w, ub = (cxb - r.ox) * r.inv_w;
-      const f2 lxa = (ua - 0.5f) * 2.0f * r.p0, lxb = (ub - 0.5f) * 2.0f * r.p0;
-      // sdRoundedBox (atlas.frag:51-69) of the lane's four pixels at height py for half extents (bx, by)
-      auto dist4 = [&](const f2 pxa, const f2 pxb, const float py_, const float bx, const float by, f2& da, f2& db) __attribute__((always_inline)) {
-        const bool top = py_ > 0.0f;
-        const float rR = top ? r.r[0] : r.r[1], rL = top ? r.r[2] : r.r[3];
-        const float ay = __builtin_fabsf(py_) - by;
-        const f2 rra = {pxa.x > 0.0f ? rR : rL, pxa.y > 0.0f ? rR : rL}, rrb = {pxb.x > 0.0f ? rR : rL, pxb.y > 0.0f ? rR : rL};
-        const f2 axa = {__builtin_fabsf(pxa.x), __builtin_fabsf(pxa.y)}, axb = {__builtin_fabsf(pxb.x), __builtin_fabsf(pxb.y)};
-        const f2 qxa = axa - bx + rra, qxb = axb - bx + rrb;
-        const f2 qya = ay + rra, qyb = ay + rrb;
-        const f2 mxa = {__builtin_fmaxf(qxa.x, 0.0f), __builtin_fmaxf(qxa.y, 0.0f)}, mxb = {__builtin_fmaxf(qxb.x, 0.0f), __builtin_fmaxf(qxb.y, 0.0f)};
-        const f2 mya = {__builtin_fmaxf(qya.x, 0.0f), __builtin_fmaxf(qya.y, 0.0f)}, myb = {__builtin_fmaxf(qyb.x, 0.0f), __builtin_fmaxf(qyb.y, 0.0f)};
-        f2 lena = {__builtin_fmaxf(mxa.x, mya.x), __builtin_fmaxf(mxa.y, mya.y)}, lenb = {__builtin_fmaxf(mxb.x, myb.x), __builtin_fmaxf(mxb.y, myb.y)};
-        const f2 lowa = {__builtin_fminf(qxa.x, qya.x), __builtin_fminf(qxa.y, qya.y)}, lowb = {__builtin_fminf(qxb.x, qyb.x), __builtin_fminf(qxb.y, qyb.y)};
-        if (__any(lowa.x > 0.0f || lowa.y > 0.0f || lowb.x > 0.0f || lowb.y > 0.0f)) {  // some lane sits in a corner cell
-          const f2 sa2 = mxa * mxa + mya * mya, sb2 = mxb * mxb + myb * myb;
-          lena.x = lowa.x > 0.0f ? fsqrt(sa2.x) : lena.x; lena.y = lowa.y > 0.0f ? fsqrt(sa2.y) : lena.y;
-          lenb.x = lowb.x > 0.0f ? fsqrt(sb2.x) : lenb.x; lenb.y = lowb.y > 0.0f ? fsqrt(sb2.y) : lenb.y;
-        }
-        const f2 ina = {__builtin_fminf(__builtin_fmaxf(qxa.x, qya.x), 0.0f), __builtin_fminf(__builtin_fmaxf(qxa.y, qya.y), 0.0f)};
-        const f2 inb = {__builtin_fminf(__builtin_fmaxf(qxb.x, qyb.x), 0.0f), __builtin_fminf(__builtin_fmaxf(qxb.y, qyb.y), 0.0f)};
-        da = ina + lena - rra; db = inb + lenb - rrb;
-      };
-      // elliptical corners (atlas.frag:96-115): the distance itself comes from the general routine, four pixels
-      // unpacked; coverage and blend below stay packed
-      auto dist4e = [&](const f2 pxa, const f2 pxb, const float py_, const float bx, const float by, f2& oa, f2& ob) __attribute__((always_inline)) {
-        const float px4[4] = {pxa.x, pxa.y, pxb.x, pxb.y};
-        float d4[4];
-        shape_distN<4>(true, px4, py_, bx, by, r.r[0], r.r[1], r.r[2], r.r[3], d4);
-        oa = {d4[0], d4[1]}; ob = {d4[2], d4[3]};
-      };
-      f2 da, db;
-      if ((kPaths & 3) == 0 && ellip) dist4e(lxa, lxb, pyy, shx, shy, da, db); else dist4(lxa, lxb, pyy, shx, shy, da, db);
+      pyy = local_y_up(r, cy);
+      float lx4[4];
+      local_x4(r, cx0, lx4);
+      lxa = {lx4[0], lx4[1]}; lxb = {lx4[2], lx4[3]};
+      if ((kPaths & 3) == 0 && ellip) dist4e(r, lxa, lxb, pyy, shx, shy, da, db); else dist4(r, lxa, lxb, pyy, shx, shy, da, db);
+    };
+    // r: the run's geometry (quad, radii, AA factor, bounds); m_*: the draw's own sdfParams.zw, sdfFactors and colour
+    auto edge_blend = [&](const DrawRec& r, const uint32_t mode, const bool ellip, const float m_p2, const float m_p3, const float m_f0, const float m_f1,
+                          const uint32_t m_col, const f2 lxa, const f2 lxb, const float pyy, const f2 da, const f2 db, F4& A0, F4& A1, F4& A2, F4& A3) __attribute__((always_inline)) {
       f2 ala, alb;  // coverage
       if (mode == 3u) {
-        const f2 ta = da * r.aa + 0.5f, tb = db * r.aa + 0.5f;
-        ala = {1.0f - clamp01(ta.x), 1.0f - clamp01(ta.y)}; alb = {1.0f - clamp01(tb.x), 1.0f - clamp01(tb.y)};
+        ala = {cover_aa(da.x, r.aa), cover_aa(da.y, r.aa)}; alb = {cover_aa(db.x, r.aa), cover_aa(db.y, r.aa)};
       } else if (mode == 12u) {
-        const float h = r.f0 * 0.5f;
+        const float h = m_f0 * 0.5f;
         const f2 ea = da + h, eb = db + h;
         const f2 ga = {__builtin_fabsf(ea.x), __builtin_fabsf(ea.y)}, gb = {__builtin_fabsf(eb.x), __builtin_fabsf(eb.y)};
-        const f2 ta = (ga - h) * r.aa + 0.5f, tb = (gb - h) * r.aa + 0.5f;
-        ala = {1.0f - clamp01(ta.x), 1.0f - clamp01(ta.y)}; alb = {1.0f - clamp01(tb.x), 1.0f - clamp01(tb.y)};
+        ala = {cover_aa(ga.x - h, r.aa), cover_aa(ga.y - h, r.aa)}; alb = {cover_aa(gb.x - h, r.aa), cover_aa(gb.y - h, r.aa)};
         if (__all(ala.x == 0.0f && ala.y == 0.0f && alb.x == 0.0f && alb.y == 0.0f)) return;  // inside the stroke: no-op
-      } else if (inset) {  // 9: atlas.frag:364-380 -- clip alpha of the node's own shape x the falloff inside the offset shape
+      } else if (mode == 9u) {  // atlas.frag:364-380 -- clip alpha of the node's own shape x the falloff inside the offset shape
         f2 sha, shb;
-        if ((kPaths & 3) == 0 && ellip) dist4e(lxa - r.p2, lxb - r.p2, pyy + r.p3, r.p0, r.p1, sha, shb); else dist4(lxa - r.p2, lxb - r.p2, pyy + r.p3, r.p0, r.p1, sha, shb);
-        const float spread = r.f1;
+        if ((kPaths & 3) == 0 && ellip) dist4e(r, lxa - m_p2, lxb - m_p2, pyy + m_p3, r.p0, r.p1, sha, shb); else dist4(r, lxa - m_p2, lxb - m_p2, pyy + m_p3, r.p0, r.p1, sha, shb);
+        const float spread = m_f1;
         const f2 sda = sha + spread, sdb = shb + spread;
-        const float rs = frcp(__builtin_fmaxf(0.5f * r.f0, 0.5f));
+        const float rs = frcp(__builtin_fmaxf(0.5f * m_f0, 0.5f));
         const f2 za = sda * rs, zb = sdb * rs;
         const f2 ea = -0.72134752044f * za * za, eb = -0.72134752044f * zb * zb;
-        const f2 ta = da * r.aa + 0.5f, tb = db * r.aa + 0.5f;
-        ala = {(1.0f - clamp01(ta.x)) * (sda.x < 0.0f ? __builtin_fminf(fexp2(ea.x), 1.0f) : 1.0f),
-               (1.0f - clamp01(ta.y)) * (sda.y < 0.0f ? __builtin_fminf(fexp2(ea.y), 1.0f) : 1.0f)};
-        alb = {(1.0f - clamp01(tb.x)) * (sdb.x < 0.0f ? __builtin_fminf(fexp2(eb.x), 1.0f) : 1.0f),
-               (1.0f - clamp01(tb.y)) * (sdb.y < 0.0f ? __builtin_fminf(fexp2(eb.y), 1.0f) : 1.0f)};
+        ala = {cover_aa(da.x, r.aa) * (sda.x < 0.0f ? __builtin_fminf(fexp2(ea.x), 1.0f) : 1.0f),
+               cover_aa(da.y, r.aa) * (sda.y < 0.0f ? __builtin_fminf(fexp2(ea.y), 1.0f) : 1.0f)};
+        alb = {cover_aa(db.x, r.aa) * (sdb.x < 0.0f ? __builtin_fminf(fexp2(eb.x), 1.0f) : 1.0f),
+               cover_aa(db.y, r.aa) * (sdb.y < 0.0f ? __builtin_fminf(fexp2(eb.y), 1.0f) : 1.0f)};
       } else {  // 7: atlas.frag:330-343
-        const float spread = r.f1;
+        const float spread = m_f1;
         const f2 sda = da - spread, sdb = db - spread;
         if (__all(sda.x <= 0.0f && sda.y <= 0.0f && sdb.x <= 0.0f && sdb.y <= 0.0f)) {
           ala = 1.0f; alb = 1.0f;
         } else {
-          const float rs = frcp(__builtin_fmaxf(0.5f * r.f0, 0.5f));
+          const float rs = frcp(__builtin_fmaxf(0.5f * m_f0, 0.5f));
           const f2 za = sda * rs, zb = sdb * rs;
           const f2 ea = -0.72134752044f * za * za, eb = -0.72134752044f * zb * zb;
           ala = {sda.x > 0.0f ? __builtin_fminf(fexp2(ea.x), 1.0f) : 1.0f, sda.y > 0.0f ? __builtin_fminf(fexp2(ea.y), 1.0f) : 1.0f};
@@ -1031,7 +1050,7 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? 4 : kPaths == 4 ? FDH_UNIFORM_WA
       // coverage of the quad: unsigned (x - bx0) < width, width 0 on rows outside it
       const uint32_t xrel = (uint32_t)(px0 - (int)r.bx0);
       const uint32_t wcov = (py >= r.by0 && py < r.by1) ? (uint32_t)((int)r.bx1 - (int)r.bx0) : 0u;
-      const F4 c0u = unpack255(r.col[0]);
+      const F4 c0u = unpack255(m_col);
       const float cw = c0u.w * inv255;
       f2 saa = ala * cw, sab = alb * cw;
       saa.x = xrel < wcov ? saa.x : 0.0f; saa.y = xrel + 1u < wcov ? saa.y : 0.0f;
@@ -1042,6 +1061,14 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? 4 : kPaths == 4 ? FDH_UNIFORM_WA
       { const f2 b1 = {cb, 1.0f}; blend_pre(A0, crg * Aa.x, b1 * Aa.x, iaa.x); blend_pre(A1, crg * Aa.y, b1 * Aa.y, iaa.y);
         blend_pre(A2, crg * Ab.x, b1 * Ab.x, iab.x); blend_pre(A3, crg * Ab.y, b1 * Ab.y, iab.y); }
     };
+#if FDH_EDGE_CHECK
+    auto simple_edge = [&](const DrawRec& r, const uint32_t mode, const bool ellip, F4& A0, F4& A1, F4& A2, F4& A3) __attribute__((always_inline)) {
+      f2 lxa, lxb, da, db;
+      float pyy;
+      edge_geom(r, mode == 9u, ellip, lxa, lxb, pyy, da, db);
+      edge_blend(r, mode, ellip, r.p2, r.p3, r.f0, r.f1, r.col[0], lxa, lxb, pyy, da, db, A0, A1, A2, A3);
+    };
+#endif
     // One draw = one lambda call.  The record of the NEXT surviving draw is fetched (scalar loads) before the
     // current one is shaded, so the ~L2-latency of the fetch overlaps the shading arithmetic.
     auto shade = [&](const uint32_t d, const DrawRec& r, const bool core) {
@@ -1266,9 +1293,8 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? 4 : kPaths == 4 ? FDH_UNIFORM_WA
       const bool inset = mode == 9u && op == OP_DRAW;
       const float shx = inset ? qhx : r.p2, shy = inset ? qhy : r.p3;
       float lx[4], dist[4];
-#pragma unroll
-      for (int k = 0; k < 4; k++) lx[k] = (u[k] - 0.5f) * 2.0f * qhx;
-      const float ly = (t - 0.5f) * 2.0f * qhy;
+      local_x4(r, cx0, lx);
+      const float ly = -local_y_up(r, cy);
       const float spread = fill_mode == 0u ? r.f1 : 0.0f;
       // Tile classification.  Along a row the rounded-box distance is quasi-convex (its sub-level sets are
       // intervals), so if the two OUTER pixels of every lane's 4-pixel run give the same saturated alpha, the two
@@ -1287,9 +1313,9 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? 4 : kPaths == 4 ? FDH_UNIFORM_WA
         dist[3] = d2[1];
         const float dm = __builtin_fmaxf(d2[0], d2[1]);
         bool one = false, zero = false;
-        if (op == OP_MASK_PUSH || mode == 3u || mode == 17u) one = r.aa * dm + 0.5f <= 0.0f;
+        if (op == OP_MASK_PUSH || mode == 3u || mode == 17u) one = __builtin_fmaf(-dm, r.aa, 0.5f) >= 1.0f;
         else if (mode == 7u) one = dm - spread <= 0.0f;
-        else if (mode == 12u) { const float h = r.f0 * 0.5f; zero = (dm + h < 0.0f) & (r.aa * (-(dm + h) - h) + 0.5f >= 1.0f); }
+        else if (mode == 12u) { const float h = r.f0 * 0.5f; zero = (dm + h < 0.0f) & (__builtin_fmaf(-(-(dm + h) - h), r.aa, 0.5f) <= 0.0f); }
         if (__all(one)) cls = 1;
         else if (__all(zero)) cls = 2;
         if (cls == 1) FDH_COUNT(5);
@@ -1315,7 +1341,7 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? 4 : kPaths == 4 ? FDH_UNIFORM_WA
         uint32_t packed = 0;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-          float a = (1.0f - clamp01(r.aa * dist[k] + 0.5f)) * col[k].w * mk[k];
+          float a = cover_aa(dist[k], r.aa) * col[k].w * mk[k];
           a = cov[k] ? a : 0.0f;
           const float q = __builtin_rintf(a * a * 255.0f);
           packed |= (uint32_t)q << (8 * k);
@@ -1342,7 +1368,7 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? 4 : kPaths == 4 ? FDH_UNIFORM_WA
         case 12u: {
           const float h = r.f0 * 0.5f;
 #pragma unroll
-          for (int k = 0; k < 4; k++) alpha[k] = 1.0f - clamp01(r.aa * (__builtin_fabsf(dist[k] + h) - h) + 0.5f);
+          for (int k = 0; k < 4; k++) alpha[k] = cover_aa(__builtin_fabsf(dist[k] + h) - h, r.aa);
           break;
         }
         case 7u: {
@@ -1357,7 +1383,7 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? 4 : kPaths == 4 ? FDH_UNIFORM_WA
         case 8u: {
 #pragma unroll
           for (int k = 0; k < 4; k++) {
-            const float inside = 1.0f - clamp01(r.aa * dist[k] + 0.5f);
+            const float inside = cover_aa(dist[k], r.aa);
             const float sd = dist[k] - spread;
             const float sp = __builtin_fminf(shadow_profile(sd, r.f0), 1.0f);
             alpha[k] = sd >= 0.0f ? sp : inside;
@@ -1371,7 +1397,7 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? 4 : kPaths == 4 ? FDH_UNIFORM_WA
           shape_distN<4>(ellip, sx, -ly + r.p3, qhx, qhy, r.r[0], r.r[1], r.r[2], r.r[3], shd);
 #pragma unroll
           for (int k = 0; k < 4; k++) {
-            const float clip_a = 1.0f - clamp01(r.aa * dist[k] + 0.5f);
+            const float clip_a = cover_aa(dist[k], r.aa);
             const float sd = shd[k] + spread;
             const float sp = __builtin_fminf(shadow_profile(sd, r.f0), 1.0f);
             const float ia = sd < 0.0f ? sp : 1.0f;
@@ -1381,7 +1407,7 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? 4 : kPaths == 4 ? FDH_UNIFORM_WA
         }
         default: {  // ClipAA / BackdropBlur / others: atlas.frag:389-393
 #pragma unroll
-          for (int k = 0; k < 4; k++) alpha[k] = 1.0f - clamp01(r.aa * dist[k] + 0.5f);
+          for (int k = 0; k < 4; k++) alpha[k] = cover_aa(dist[k], r.aa);
           break;
         }
       }
@@ -1441,6 +1467,7 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? 4 : kPaths == 4 ? FDH_UNIFORM_WA
         const f2 c_rg = {c0.x * inv255 * A, c0.y * inv255 * A}, c_ba = {c0.z * inv255 * A, A};
         blend_pre(F0, c_rg, c_ba, ia); blend_pre(F1, c_rg, c_ba, ia); blend_pre(F2, c_rg, c_ba, ia); blend_pre(F3, c_rg, c_ba, ia);
         touched = true;
+        FDH_COUNT(35);
         continue;
       }
 #if FDH_SIMPLE_EDGE && !defined(FDH_ABLATE_SHADING) && !defined(FDH_ABLATE_EDGE)
@@ -1452,6 +1479,7 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? 4 : kPaths == 4 ? FDH_UNIFORM_WA
         const uint32_t c4 = (code - 1u) & 3u;
         const uint32_t mode = c4 == 0u ? 3u : c4 == 1u ? 7u : c4 == 2u ? 9u : 12u;
         touched = true;
+        FDH_COUNT(48 + code);
 #if FDH_EDGE_CHECK
         F4 S0 = F0, S1 = F1, S2 = F2, S3 = F3;
         simple_edge(r, mode, code > 4u, S0, S1, S2, S3);
@@ -1468,7 +1496,34 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? 4 : kPaths == 4 ? FDH_UNIFORM_WA
             }
         }
 #else
-        simple_edge(r, mode, code > 4u, F0, F1, F2, F3);
+        {
+          const bool ellip = code > 4u;
+          f2 lxa, lxb, da, db;
+          float pyy;
+          edge_geom(r, mode == 9u, ellip, lxa, lxb, pyy, da, db);
+          edge_blend(r, mode, ellip, r.p2, r.p3, r.f0, r.f1, r.col[0], lxa, lxb, pyy, da, db, F0, F1, F2, F3);
+          // The draws that follow over the same quad and shape (the node's stroke, its inner shadows: LE_SHARE on the entry of
+          // the draw before them) reuse the field: their entries are taken off the list here.  All conditions are wave-uniform.
+          uint32_t wcur = word, dcur = d;
+          while ((wcur & LE_SHARE) != 0u && m != 0) {
+            const int nb = __builtin_ctzll(m);
+            const uint32_t w2 = __builtin_amdgcn_readlane(idx, nb);
+            const uint32_t code2 = (w2 >> LE_PATH_SHIFT) & 15u;
+            if ((w2 & LE_INDEX) != dcur + 1u || ((m_core >> nb) & 1ull) != 0ull || code2 == 0u || (code2 > 4u) != ellip) break;
+            m &= m - 1;
+            dcur++;
+            wcur = w2;
+            // the member's own parameters: sdfParams.zw + sdfFactors (16 bytes at offset 32) and its colour (offset 64)
+            const u32x4* __restrict__ mp = reinterpret_cast<const u32x4*>(draws + dcur);
+            u32x4 q = mp[2];
+            uint32_t mcol = reinterpret_cast<const uint32_t*>(draws + dcur)[16];
+            asm volatile("" : "+s"(q), "+s"(mcol));
+            const uint32_t c42 = (code2 - 1u) & 3u;
+            const uint32_t mode2 = c42 == 0u ? 3u : c42 == 1u ? 7u : c42 == 2u ? 9u : 12u;
+            FDH_COUNT(57);
+            edge_blend(r, mode2, ellip, __uint_as_float(q.x), __uint_as_float(q.y), __uint_as_float(q.z), __uint_as_float(q.w), mcol, lxa, lxb, pyy, da, db, F0, F1, F2, F3);
+          }
+        }
 #endif
         continue;
       }

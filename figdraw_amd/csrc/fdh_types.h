@@ -58,7 +58,10 @@ struct alignas(16) DrawRec {
   // the annular stroke modes 11/12, alpha == 0 -- or, for an inner shadow (mode 9), alpha too small to change any 8-bit
   // channel.  Conservative by a pixel; lets a strip be classified by a bit test.
   int16_t ix0, iy0, ix1, iy1;
-  uint32_t _pad[3];
+  // axis-aligned SDF quads: local-frame steps per pixel, kx = 2 p0 inv_w, ky = 2 p1 inv_h (atlas.frag:252-262: p = (uv - 0.5) * 2 *
+  // quadHalfExtents): a lane's pixels 1..3 are pixel 0's local x plus multiples of kx
+  float kx, ky;
+  uint32_t _pad;
 };
 static_assert(sizeof(DrawRec) == 128, "DrawRec must be 128 bytes");
 
@@ -80,7 +83,7 @@ struct alignas(8) BBox { int16_t x0, y0, x1, y1; };
 
 // What k_bin_draws needs of a draw, in one 24-byte piece (built on the host at submit): the clipped pixel bounds, the
 // saturated core, and the parts of a list entry that do not depend on the bin -- flags and path code in their entry
-// positions (bits 26..31: LE_PATH, LE_OPAQUE, LE_PLAIN), bit 0: the draw has a core worth testing (axis-aligned SDF draw or
+// positions (bits 25..31: LE_SHARE, LE_PATH, LE_OPAQUE, LE_PLAIN), bit 0: the draw has a core worth testing (axis-aligned SDF draw or
 // clip push), bit 1: its core strips are REMOVED from the entry (stroke interiors, deep inside an inner shadow).  Before, a
 // hit walked bounds -> mode word -> core -> colours: three dependent round trips per batch of hits.
 struct alignas(8) BinRec { BBox box; int16_t ix0, iy0, ix1, iy1; uint32_t flags; uint32_t pad; };
@@ -93,7 +96,11 @@ constexpr uint32_t LE_OPAQUE = 1u << 30;  // a fill whose source alpha is 255 ev
 // decoding it and only then fetching the rest.  0: the general path; 1..4: one colour, no gradient, OP_DRAW, mode 3 / 7 / 9 /
 // 12 with circular corners; 5..8: the same with elliptical corners
 constexpr int LE_PATH_SHIFT = 26;
-constexpr uint32_t LE_INDEX = (1u << LE_PATH_SHIFT) - 1u;
+// bit 25: the NEXT draw (index + 1) is drawn over the same quad with the same shape -- a node's fill, then its stroke, then its
+// inner shadows (figrender.nim:806-873, 716-744) -- so on a strip where both take a packed edge path the compositor evaluates the
+// distance field once for the run
+constexpr uint32_t LE_SHARE = 1u << 25;
+constexpr uint32_t LE_INDEX = LE_SHARE - 1u;
 
 constexpr int kMaxBlurReach = 66;
 constexpr int kBlurPad = 15;  // >= (largest outputs-per-thread) - 1

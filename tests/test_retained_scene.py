@@ -325,11 +325,15 @@ def test_animated_text_node_does_not_grow_the_side_arrays():
 
 @pytest.mark.gpu
 def test_retained_scene_pixels_equal_full_render():
-    """GPU: after each edit the retained context's frame equals a full fdh_render_frame of the edited tree, bit for bit"""
+    """GPU: after each edit the retained context's frame equals a full fdh_render_frame of the edited tree, bit for bit, and
+    the oracle's frame of the edited tree within the suite's parity bar"""
     rnd = random.Random(11)
     w, h = 1280, 720
     sc = make_render_tree_100(w, h, frame=2, full_frame_blur=True)
     subs = _subtrees(next(iter(sc.layers.values())))
+    from oracle import oracle as O
+
+    orc = O.Oracle(threads=8)
     ret, ref = HipContext(device=0), HipContext(device=0)
     ret.scene_retain(_flatten(subs), w, h)
     for step in range(8):
@@ -342,9 +346,14 @@ def test_retained_scene_pixels_equal_full_render():
             ret.scene_replace_root(0, slot, subs[slot])
         ret.scene_render()
         ref.render_frame(_flatten(subs), w, h)
-        assert np.array_equal(ret.read_pixels(), ref.read_pixels()), step
+        got = ret.read_pixels()
+        assert np.array_equal(got, ref.read_pixels()), step
         walked, reused = ret.scene_stats()
         assert walked <= 4 and reused >= len(subs) - 4
+        # ... and the frame is the ORACLE's frame of the edited tree (parity, not only self-consistency)
+        orc.render_frame(_flatten(subs), w, h)
+        d = np.abs(got.astype(int) - orc.read_pixels().astype(int)).max(axis=2)
+        assert d.max() <= 1 and (d > 0).sum() <= 0.005 * w * h, (step, int(d.max()), int((d > 0).sum()))
     # a property edit that keeps the record count: only the 256-byte chunks that changed travel to the device
     lst = _flatten(subs).layers[0]
     ret.scene_retain(_flatten(subs), w, h)
@@ -355,6 +364,10 @@ def test_retained_scene_pixels_equal_full_render():
     ret.scene_render()
     assert 0 < ret.last_upload_bytes() <= 8192 < ret.frame_stats().n_draws * 128  # (a record is 128 bytes: the block is ~100 KB)
     ref.render_frame(Renders_of(lst), w, h)
-    assert np.array_equal(ret.read_pixels(), ref.read_pixels())
+    got = ret.read_pixels()
+    assert np.array_equal(got, ref.read_pixels())
+    orc.render_frame(Renders_of(lst), w, h)  # after fdh_scene_update_nodes too: the oracle's frame of the edited tree
+    d = np.abs(got.astype(int) - orc.read_pixels().astype(int)).max(axis=2)
+    assert d.max() <= 1 and (d > 0).sum() <= 0.005 * w * h, (int(d.max()), int((d > 0).sum()))
     ret.close()
     ref.close()

@@ -31,8 +31,13 @@ for i in range(8):
 for m in range(32):
     if c[8 + m]:
         print(f"fast mode {m:2d}: {c[8 + m]:10d}   of which cls1 {c[40 + (m & 15)] if m < 16 else 0:10d}")
-for i, n in ((32, "core: stroke no-op"), (33, "core: solid uniform blend"), (34, "core: other (gradient / push / blur)")):
+for i, n in ((32, "core: stroke no-op"), (33, "core: solid uniform blend"), (34, "core: other (gradient / push / blur)"),
+             (35, "core: plain colour, record not fetched")):
     print(f"{n:34s} {c[i]:10d}")
+for code, n in enumerate(("", "fill", "drop shadow", "inner shadow", "AA stroke", "fill, elliptical", "drop shadow, elliptical", "inner shadow, elliptical",
+                          "AA stroke, elliptical")):
+    if code:
+        print(f"packed edge path {code} ({n:24s}) {c[48 + code]:10d}")
 if hasattr(L, "fdh_debug_wave_times") and os.environ.get("FDH_TIMING"):
     import numpy as np
     wt = np.zeros((65536, 16), dtype=np.uint64)
