@@ -57,40 +57,71 @@ def frame_tensor(ctx):
     return torch.as_tensor(_Surf(), device=f"cuda:{ctx.device}")
 
 
+def setup_comm(ctxs, dist, rank, world):
+    """One RCCL communicator per process through the library's own C ABI (fdh_comm_*): rank 0 makes the id, torch.distributed
+    carries the 128 bytes, the first context owns the communicator and the others borrow it."""
+    from figdraw_amd.context import HipContext
+
+    box = [HipContext.comm_unique_id() if rank == 0 else None]
+    if dist is not None:
+        dist.broadcast_object_list(box, src=0)
+    ctxs[0].comm_init(box[0], rank, world)
+    for c in ctxs[1:]:
+        c.comm_share(ctxs[0])
+
+
 def run_stripes(args, dist, rank, local_rank, world, on_host):
-    """BASELINE config 5: an 8-frame batch, each frame row-striped over the ranks, stripes gathered to rank 0 per frame."""
+    """BASELINE config 5: an 8-frame batch, each frame row-striped over the ranks, stripes gathered to rank 0 per frame.
+    Every rank renders rows fdh_stripe_rows(H, world, rank) of EVERY frame through fdh_render_frame (tree in, rows out; the
+    vertical blur halo is re-rendered, so nothing is exchanged while a frame renders) on frames_in_flight contexts, and each
+    frame's stripes are gathered into rank 0's surface INSIDE the timed region:
+      --gather c_abi (default with RCCL): fdh_gather_stripes -- grouped ncclSend / ncclRecv issued by the library on the context's
+                     stream behind the frame's kernels, received in place into rank 0's own surface: no host synchronisation
+                     per frame, no staging copy
+      --gather torch (gloo self-test, or on request): torch.distributed grouped isend / irecv with a host sync per frame"""
     import torch
 
+    from figdraw_amd import call_stream as CS  # noqa: F401  (the C player is not used here: per-frame gathers sit between the frames)
+    from figdraw_amd import context as C_
     from figdraw_amd.context import HipContext
     from figdraw_amd.scenes import make_render_tree_100
     from figdraw_amd.sharding import stripe_rows
 
     w, h = args.width, args.height
-    NF = 8
+    NS = 8
+    F = max(1, min(args.frames_in_flight, args.steps))
     y0, y1 = stripe_rows(h, world, rank)
     rows = [stripe_rows(h, world, r) for r in range(world)]
+    scenes = [make_render_tree_100(w, h, frame=f, full_frame_blur=True) for f in range(NS)]
+    cs = [sc.to_c() for sc in scenes]
+    col = C_._F4(1.0, 1.0, 1.0, 1.0)
     ctxs = []
-    for f in range(NF):  # one context per frame of the batch: its records stay resident, its stripe is set once
+    for i in range(F):
         c = HipContext(device=local_rank)
         c.set_stripe(y0, y1)
-        c.render_frame(make_render_tree_100(w, h, frame=f, full_frame_blur=True), w, h)
+        c.render_frame(scenes[i % NS], w, h)
         ctxs.append(c)
     for c in ctxs:
         c.sync()
-    surf = [frame_tensor(c) for c in ctxs]  # zero-copy (H, W, 4) views
+    use_c_abi = args.gather == "c_abi" and not on_host
     dev = "cpu" if on_host else f"cuda:{local_rank}"
-    full = torch.zeros((h, w, 4), dtype=torch.uint8, device=dev) if rank == 0 else None
     gather_s = [0.0]
+    if use_c_abi:
+        setup_comm(ctxs, dist, rank, world)
+    else:
+        surf = [frame_tensor(c) for c in ctxs]  # zero-copy (H, W, 4) views
+        full = [torch.zeros((h, w, 4), dtype=torch.uint8, device=dev) for _ in range(F)] if rank == 0 else None
 
-    def gather(f):
-        """stripe of frame f from every rank into rank 0's image: grouped send / recv (ncclGroupStart .. End under RCCL)"""
+    def gather_torch(i):
+        """stripe of context i from every rank into rank 0's image: grouped send / recv (ncclGroupStart .. End under RCCL)"""
         t0 = time.perf_counter()
-        mine = surf[f][y0:y1]
+        ctxs[i].sync()
+        mine = surf[i][y0:y1]
         if on_host:
             mine = mine.cpu()
         if rank == 0:
-            full[y0:y1].copy_(mine, non_blocking=True)
-            ops = [dist.P2POp(dist.irecv, full[a:b], r) for r, (a, b) in enumerate(rows) if r != 0 and b > a] if dist is not None else []
+            full[i][y0:y1].copy_(mine, non_blocking=True)
+            ops = [dist.P2POp(dist.irecv, full[i][a:b], r) for r, (a, b) in enumerate(rows) if r != 0 and b > a] if dist is not None else []
         else:
             ops = [dist.P2POp(dist.isend, mine, 0)] if y1 > y0 else []
         if ops:
@@ -102,16 +133,23 @@ def run_stripes(args, dist, rank, local_rank, world, on_host):
 
     def run(n):
         pending = None
-        for k in range(n):  # render frame k while frame k - 1 is gathered
-            c = ctxs[k % NF]
-            c.replay_async(1)
-            if pending is not None:
-                ctxs[pending].sync()
-                gather(pending)
-            pending = k % NF
+        for k in range(n):
+            i = k % F
+            c = ctxs[i]
+            if not use_c_abi and pending is not None and pending == i:
+                gather_torch(pending)  # (the surface is about to be overwritten)
+                pending = None
+            c._ck(c.L.fdh_render_frame(c.h, cs[k % NS].byref(), float(w), float(h), 1, col))
+            if use_c_abi:
+                t0 = time.perf_counter()
+                c.gather_stripes(0, None)  # queued on the context's stream behind the frame; rank 0 receives in place
+                gather_s[0] += time.perf_counter() - t0
+            else:
+                if pending is not None:
+                    gather_torch(pending)
+                pending = i
         if pending is not None:
-            ctxs[pending].sync()
-            gather(pending)
+            gather_torch(pending)
 
     def barrier():
         if dist is not None:
@@ -120,49 +158,63 @@ def run_stripes(args, dist, rank, local_rank, world, on_host):
             c.sync()
         torch.cuda.synchronize()
 
+    def timed(steps):
+        barrier()
+        gather_s[0] = 0.0
+        t0 = time.perf_counter()
+        run(steps)
+        for c in ctxs:
+            c.sync()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            dist.barrier()
+            tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt, gather_s[0]
+
     run(args.warmup)
-    barrier()
-    gather_s[0] = 0.0
-    t0 = time.perf_counter()
-    run(args.steps)
-    for c in ctxs:
-        c.sync()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        dist.barrier()
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    res = sorted(timed(args.steps) for _ in range(args.repeats))
+    elapsed, gather_host = res[len(res) // 2]
     if rank != 0:
         return
-    last = (args.steps - 1) % NF
-    got = full.cpu().numpy()
+    last_k = args.steps - 1
+    last_i = last_k % F
+    if use_c_abi:
+        ctxs[last_i].W, ctxs[last_i].H = w, h
+        got = ctxs[last_i].read_pixels()
+    else:
+        got = full[last_i].cpu().numpy()
     assert int(got[..., 3].min()) == 255, "the gathered frame has unwritten pixels"
     check = None
     if not args.no_cpu_baseline:  # the gathered image of the last frame against the oracle (outside the timed region)
         from oracle import oracle as O
 
         orc = O.Oracle(threads=min(os.cpu_count() or 1, 16))
-        orc.render_frame(make_render_tree_100(w, h, frame=last, full_frame_blur=True), w, h)
+        orc.render_frame(scenes[last_k % NS], w, h)
         d = np.abs(got.astype(int) - orc.read_pixels().astype(int))
-        check = {"frame": last, "parity_max_lsb": int(d.max()), "parity_pixels_differing": int((d.max(axis=2) > 0).sum())}
+        check = {"frame": last_k % NS, "parity_max_lsb": int(d.max()), "parity_pixels_differing": int((d.max(axis=2) > 0).sum())}
         if check["parity_max_lsb"] > 1:
             print(json.dumps({"error": "gathered frame disagrees with the oracle", "check": check}))
             sys.exit(1)
     st = ctxs[0].frame_stats()
     ms_step = 1e3 * elapsed / args.steps
     print(json.dumps({
-        "metric": "Mpixels/s composited @3840x2160, 300 SDF rects+shadows; % HBM roofline",
+        "metric": f"Mpixels/s composited @{w}x{h}, 300 SDF rects+shadows, row-striped (BASELINE.json configs[4]; the headline metric is quoted at 3840x2160)",
         "value": round(w * h * args.steps / elapsed / 1e6, 1), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "warmup": args.warmup, "ms_per_step": round(ms_step, 4), "repeats": args.repeats, "batches_ms": [round(1e3 * t, 4) for t, _ in res],
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"S300@8Kx8 (BASELINE.json configs[4]): 8-frame batch of the renderlist_100 scene at {w}x{h} with the full-frame blur, "
-                               f"row-striped over {world} rank(s), stripes gathered to rank 0 per frame inside the timed region",
-                   "mode": "stripes", "draws": st.n_draws, "rows_per_rank": [b - a for a, b in rows],
+                               f"row-striped over {world} rank(s), every frame through fdh_render_frame, stripes gathered to rank 0 per frame inside the timed region",
+                   "mode": "stripes", "draws": st.n_draws, "rows_per_rank": [b - a for a, b in rows], "frames_in_flight_per_gpu": F,
+                   "gather": "fdh_gather_stripes (C ABI: grouped ncclSend / ncclRecv on the context's stream, received in place)" if use_c_abi
+                             else "torch.distributed batch_isend_irecv with a host sync per frame",
                    "parallelism": f"row stripes x{world}" if world > 1 else "single GPU (one stripe = the frame)"},
-        "gather_ms": round(1e3 * gather_s[0] / args.steps, 4),
-        "gather_note": "per frame, rank 0's wall time inside the gather calls (includes waiting for the slowest stripe); part of `value`'s wall time",
+        "gather_ms": round(1e3 * gather_host / args.steps, 4),
+        "gather_note": "per frame, this rank's HOST time inside the gather calls (c_abi: enqueue only -- the transfer runs on the stream; torch: includes "
+                       "waiting for the stripe and the transfer); part of `value`'s wall time",
         "gathered_frame_check": check,
         "roofline": None, "cpu_baseline": None,
     }))
@@ -179,6 +231,9 @@ def main():
     ap.add_argument("--all-ranks-on-device0", action="store_true", help="self-test of the N>1 code path on a 1-GPU box")
     ap.add_argument("--frames-in-flight", type=int, default=4,
                     help="independent render contexts per GPU (own stream + surfaces) whose frames overlap; 1 = strictly one frame at a time")
+    ap.add_argument("--gather", choices=["c_abi", "torch"], default="c_abi",
+                    help="who issues the gather: the library's own fdh_gather_* (RCCL through the C ABI, stream-ordered) or torch.distributed "
+                         "(always used with --backend gloo)")
     ap.add_argument("--width", type=int, default=W)
     ap.add_argument("--height", type=int, default=H)
     ap.add_argument("--mode", choices=["frames", "stripes"], default="frames",
@@ -210,6 +265,7 @@ def main():
         return run_stripes(args, dist, rank, local_rank, world, on_host)
 
     from figdraw_amd import call_stream as CS
+    from figdraw_amd import context as C_mod
     from figdraw_amd.context import HipContext
     from figdraw_amd.scenes import make_render_tree_100
 
@@ -398,19 +454,54 @@ def main():
         ctx.render_frame(scene, w, h)  # back to the benchmark frame for the gather / parity legs below
         ctx.sync()
 
-    gather_ms = None
+    # ---- the one collective of the path: the gather of finished frames to rank 0.  Frames are independent, so
+    # `value` above holds no data-path collective (weak scaling); here (a) one gather of every rank's final frame, timed on its
+    # own, and (b) the same K-frame batch with EVERY frame gathered to rank 0 inside the timed region, reported beside `value`.
+    gather_ms, gather_how, with_gather = None, None, None
     if dist is not None:
-        mine = frame_tensor(ctx).contiguous()
-        if on_host:
-            mine = mine.cpu()
-        outs = [torch.empty_like(mine) for _ in range(world)] if rank == 0 else None
-        barrier()
-        g0 = time.perf_counter()
-        dist.gather(mine, outs, dst=0)
-        torch.cuda.synchronize()
-        gather_ms = 1e3 * (time.perf_counter() - g0)
-        if rank == 0:
-            assert all(int(o[..., 3].min()) == 255 for o in outs), "a gathered frame has unwritten pixels"
+        col = C_mod._F4(1.0, 1.0, 1.0, 1.0)
+        use_c_abi = args.gather == "c_abi" and not on_host
+        if use_c_abi:
+            setup_comm(ctxs, dist, rank, world)
+            dev = f"cuda:{local_rank}"
+            slots = [[torch.empty((h, w, 4), dtype=torch.uint8, device=dev) for _ in range(world)] for _ in range(F)] if rank == 0 else None
+            ptrs = [[t.data_ptr() for t in sl] for sl in slots] if rank == 0 else [None] * F
+            barrier()
+            g0 = time.perf_counter()
+            ctx.gather_frames(0, ptrs[0])
+            ctx.sync()
+            gather_ms = 1e3 * (time.perf_counter() - g0)
+            gather_how = "fdh_gather_frames (C ABI: grouped ncclSend / ncclRecv on the context's stream)"
+            if rank == 0:
+                assert all(int(o[..., 3].min()) == 255 for o in slots[0]), "a gathered frame has unwritten pixels"
+
+            def run_with_gather(n):
+                for k in range(n):
+                    c = ctxs[k % F]
+                    c._ck(c.L.fdh_render_frame(c.h, cscenes[k % NS].byref(), float(w), float(h), 1, col))
+                    c.gather_frames(0, ptrs[k % F])  # behind the frame on the context's stream: no host synchronisation
+
+            run_with_gather(args.warmup)
+            wg_elapsed, wg_batch_ms = batches(run_with_gather, args.steps, args.repeats)
+            with_gather = {"value": round(world * w * h * args.steps / wg_elapsed / 1e6, 1), "unit": "Mpixels/s", "ms_per_step": round(1e3 * wg_elapsed / args.steps, 4),
+                           "batches_ms": wg_batch_ms,
+                           "note": "the same batch with every frame of every rank gathered to rank 0 (fdh_gather_frames) inside the timed region: "
+                                   f"rank 0 takes in {world - 1} x {w * h * 4 / 1e6:.1f} MB per round of frames over its xGMI links"}
+        else:
+            mine = frame_tensor(ctx).contiguous()
+            if on_host:
+                mine = mine.cpu()
+            outs = [torch.empty_like(mine) for _ in range(world)] if rank == 0 else None
+            barrier()
+            g0 = time.perf_counter()
+            dist.gather(mine, outs, dst=0)
+            torch.cuda.synchronize()
+            gather_ms = 1e3 * (time.perf_counter() - g0)
+            gather_how = f"torch.distributed.gather ({args.backend})"
+            if rank == 0:
+                assert all(int(o[..., 3].min()) == 255 for o in outs), "a gathered frame has unwritten pixels"
+        ctx.render_frame(scene, w, h)
+        ctx.sync()
 
     if rank != 0:
         return
@@ -575,6 +666,8 @@ def main():
     }
     if gather_ms is not None:
         out["gather_ms"] = round(gather_ms, 3)
+        out["gather"] = gather_how
+        out["with_gather_every_frame"] = with_gather
     # a frame that came out differently in flight than alone (or off the oracle) voids the throughput figure
     bad = in_flight_differing != 0 or per_call_differing != 0 or (in_flight_vs_oracle is not None and in_flight_vs_oracle["parity_max_lsb"] > 1) or \
         (cpu_baseline is not None and cpu_baseline["parity_max_lsb"] > 1)

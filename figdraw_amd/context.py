@@ -125,6 +125,13 @@ def load():
     L.fdh_set_ui_scale.argtypes = [vp, C.c_float]
     L.fdh_render_frame.argtypes = [vp, vp, C.c_float, C.c_float, C.c_int, _F4]
     L.fdh_set_stripe.argtypes = [vp, C.c_int, C.c_int]
+    L.fdh_stripe_rows.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.fdh_comm_unique_id.argtypes = [C.c_char_p]
+    L.fdh_comm_init.argtypes = [vp, C.c_char_p, C.c_int, C.c_int]
+    L.fdh_comm_destroy.argtypes = [vp]
+    L.fdh_comm_share.argtypes = [vp, vp]
+    L.fdh_gather_stripes.argtypes = [vp, C.c_int, vp]
+    L.fdh_gather_frames.argtypes = [vp, C.c_int, C.POINTER(vp)]
     L.fdh_replay.argtypes = [vp, C.c_int]
     L.fdh_replay_async.argtypes = [vp, C.c_int]
     L.fdh_replay_timed.argtypes = [vp, C.c_int, C.POINTER(C.c_float)]
@@ -436,6 +443,35 @@ class HipContext:
     # ---- multi-GPU / measurement
     def set_stripe(self, y0: int, y1: int):
         self._ck(self.L.fdh_set_stripe(self.h, int(y0), int(y1)))
+
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        """ncclGetUniqueId through the library (rank 0 makes it; the host carries the 128 bytes to the other ranks)"""
+        L = load()
+        buf = C.create_string_buffer(128)
+        rc = L.fdh_comm_unique_id(buf)
+        if rc != 0:
+            raise FigdrawHipError(rc, L.fdh_last_error().decode())
+        return buf.raw
+
+    def comm_init(self, unique_id: bytes, rank: int, world: int):
+        self._ck(self.L.fdh_comm_init(self.h, unique_id, int(rank), int(world)))
+
+    def comm_share(self, owner: "HipContext"):
+        """use `owner`'s communicator (several contexts of one process share one)"""
+        self._ck(self.L.fdh_comm_share(self.h, owner.h))
+
+    def comm_destroy(self):
+        self._ck(self.L.fdh_comm_destroy(self.h))
+
+    def gather_stripes(self, dst_rank: int = 0, dst_ptr: Optional[int] = None):
+        """row-stripe mode: this rank's rows (fdh_stripe_rows) go to dst_rank's image (device pointer; None: its own surface)"""
+        self._ck(self.L.fdh_gather_stripes(self.h, int(dst_rank), C.c_void_p(dst_ptr or 0)))
+
+    def gather_frames(self, dst_rank: int = 0, dst_ptrs=None):
+        """frame-parallel mode: every rank's whole frame goes to dst_rank's dst_ptrs[r] (device pointers)"""
+        arr = (C.c_void_p * len(dst_ptrs))(*dst_ptrs) if dst_ptrs else None
+        self._ck(self.L.fdh_gather_frames(self.h, int(dst_rank), arr))
 
     def replay(self, times: int = 1):
         self._ck(self.L.fdh_replay(self.h, int(times)))

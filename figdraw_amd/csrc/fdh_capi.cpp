@@ -233,6 +233,28 @@ int fdh_debug_record_digest(FdhContext* c, uint64_t* out) {
     *out = C(c)->record_digest();
   });
 }
+int fdh_stripe_rows(int height, int world, int rank, int* y0, int* y1) {
+  return guard([&] {
+    if (!y0 || !y1) throw fdh::Error(FDH_ERR_INVALID, "null output");
+    fdh::stripe_rows(height, world, rank, y0, y1);
+  });
+}
+int fdh_comm_unique_id(uint8_t out[FDH_COMM_ID_BYTES]) {
+  return guard([&] {
+    if (!out) throw fdh::Error(FDH_ERR_INVALID, "null output");
+    fdh::comm_unique_id(out);
+  });
+}
+int fdh_comm_init(FdhContext* c, const uint8_t id[FDH_COMM_ID_BYTES], int rank, int world) {
+  return guard([&] {
+    if (!id) throw fdh::Error(FDH_ERR_INVALID, "null communicator id");
+    C(c)->comm_init(id, rank, world);
+  });
+}
+int fdh_comm_share(FdhContext* c, FdhContext* owner) { return guard([&] { C(c)->comm_share(C(owner)); }); }
+int fdh_comm_destroy(FdhContext* c) { return guard([&] { C(c)->comm_destroy(); }); }
+int fdh_gather_stripes(FdhContext* c, int dst_rank, void* dst_image) { return guard([&] { C(c)->gather_stripes(dst_rank, dst_image); }); }
+int fdh_gather_frames(FdhContext* c, int dst_rank, void* const* dst_images) { return guard([&] { C(c)->gather_frames(dst_rank, dst_images); }); }
 int fdh_set_stripe(FdhContext* c, int y0, int y1) { return guard([&] { C(c)->set_stripe(y0, y1); }); }
 int fdh_replay(FdhContext* c, int times) { return guard([&] { C(c)->replay(times); }); }
 int fdh_replay_async(FdhContext* c, int times) { return guard([&] { C(c)->replay_async(times); }); }

@@ -1,0 +1,178 @@
+// fdh_comm.cpp -- the one exchange step of the multi-GPU path: the gather of finished rows / frames to one rank over RCCL.
+//
+// frames are independent and row stripes re-render their blur halo themselves (fdh_set_stripe), so nothing is
+// exchanged while a frame is rendered; the only collective is the gather of the RGBA8 result -- grouped ncclSend / ncclRecv over
+// the point-to-point xGMI links, one contiguous run of rows per rank (a stripe of a row-major surface is contiguous).  One
+// process per GPU: each process creates its context on its device and joins the communicator with fdh_comm_init.
+// librccl is loaded at the first fdh_comm_* call (dlopen), not linked: a single-GPU host needs no RCCL to use the library.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+
+#include "fdh_context.h"
+
+namespace fdh {
+
+namespace {
+struct Rccl {
+  void* lib = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+Rccl& rccl() {
+  static Rccl R;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    const char* env = std::getenv("FDH_RCCL_LIB");
+    const char* names[] = {env, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* n : names) {  // a copy the process already holds (a PyTorch host brings its own) is taken first
+      if (n && !R.lib) R.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
+    }
+    for (const char* n : names) {
+      if (n && !R.lib) R.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    }
+    if (!R.lib) return;
+    auto sym = [&](const char* s) { return dlsym(R.lib, s); };
+    R.GetUniqueId = reinterpret_cast<decltype(R.GetUniqueId)>(sym("ncclGetUniqueId"));
+    R.CommInitRank = reinterpret_cast<decltype(R.CommInitRank)>(sym("ncclCommInitRank"));
+    R.CommDestroy = reinterpret_cast<decltype(R.CommDestroy)>(sym("ncclCommDestroy"));
+    R.GroupStart = reinterpret_cast<decltype(R.GroupStart)>(sym("ncclGroupStart"));
+    R.GroupEnd = reinterpret_cast<decltype(R.GroupEnd)>(sym("ncclGroupEnd"));
+    R.Send = reinterpret_cast<decltype(R.Send)>(sym("ncclSend"));
+    R.Recv = reinterpret_cast<decltype(R.Recv)>(sym("ncclRecv"));
+    R.GetErrorString = reinterpret_cast<decltype(R.GetErrorString)>(sym("ncclGetErrorString"));
+  });
+  if (!R.lib || !R.GetUniqueId || !R.CommInitRank || !R.CommDestroy || !R.GroupStart || !R.GroupEnd || !R.Send || !R.Recv)
+    throw Error(FDH_ERR_UNSUPPORTED, "librccl could not be loaded (set FDH_RCCL_LIB to its path): the multi-GPU gather needs RCCL");
+  return R;
+}
+void nccl_check(ncclResult_t r, const char* what) {
+  if (r == ncclSuccess) return;
+  Rccl& R = rccl();
+  throw Error(FDH_ERR_HIP, std::string(what) + ": " + (R.GetErrorString ? R.GetErrorString(r) : "RCCL error"));
+}
+#define FDH_NCCL(x) nccl_check((x), #x)
+}  // namespace
+
+void stripe_rows(int height, int world, int rank, int* y0, int* y1) {
+  if (height < 0 || world <= 0 || rank < 0 || rank >= world) throw Error(FDH_ERR_INVALID, "stripe_rows: bad partition");
+  // contiguous, 8-row aligned (a strip of the compositor is 8 rows), covering [0, height) exactly once
+  const int align = 8, tiles = (height + align - 1) / align, base = tiles / world, extra = tiles % world;
+  const int t0 = rank * base + (rank < extra ? rank : extra), t1 = t0 + base + (rank < extra ? 1 : 0);
+  *y0 = t0 * align < height ? t0 * align : height;
+  *y1 = t1 * align < height ? t1 * align : height;
+}
+
+void comm_unique_id(uint8_t out[FDH_COMM_ID_BYTES]) {
+  static_assert(FDH_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "the id travels as 128 opaque bytes");
+  ncclUniqueId id;
+  FDH_NCCL(rccl().GetUniqueId(&id));
+  std::memcpy(out, id.internal, FDH_COMM_ID_BYTES);
+}
+
+void Context::comm_init(const uint8_t id_bytes[FDH_COMM_ID_BYTES], int rank, int world) {
+  need_device("comm_init");
+  if (world <= 0 || rank < 0 || rank >= world) throw Error(FDH_ERR_INVALID, "comm_init: bad rank / world size");
+  comm_destroy();
+  FDH_HIP(hipSetDevice(device_));
+  ncclUniqueId id;
+  std::memcpy(id.internal, id_bytes, FDH_COMM_ID_BYTES);
+  ncclComm_t c = nullptr;
+  FDH_NCCL(rccl().CommInitRank(&c, world, id, rank));
+  comm_ = c;
+  comm_rank_ = rank;
+  comm_world_ = world;
+}
+// Several contexts of one process (frames in flight) use ONE communicator: the others borrow the owner's.  RCCL runs a
+// communicator's operations in the order they were issued, whichever stream each was issued on.
+void Context::comm_share(Context* owner) {
+  need_device("comm_share");
+  if (!owner || owner == this) throw Error(FDH_ERR_INVALID, "comm_share: needs another context that owns a communicator");
+  if (owner->device_ != device_) throw Error(FDH_ERR_INVALID, "comm_share: both contexts must live on the same device");
+  comm_destroy();
+  comm_ = owner->comm_;
+  comm_rank_ = owner->comm_rank_;
+  comm_world_ = owner->comm_world_;
+  comm_borrowed_ = true;
+}
+void Context::comm_destroy() {
+  if (!comm_) return;
+  drain();
+  (void)hipStreamSynchronize(stream_);
+  if (!comm_borrowed_) (void)rccl().CommDestroy(static_cast<ncclComm_t>(comm_));
+  comm_ = nullptr;
+  comm_borrowed_ = false;
+  comm_rank_ = 0;
+  comm_world_ = 1;
+}
+
+// Row-stripe mode: rank r holds rows stripe_rows(H, world, r) of the frame (fdh_set_stripe with those rows before rendering).
+// One grouped send / recv on the context's stream, behind the frame's kernels: no host synchronisation.
+void Context::gather_stripes(int dst_rank, void* dst_image) {
+  need_device("gather_stripes");
+  if (!fb_) throw Error(FDH_ERR_INVALID, "gather_stripes: no frame surface yet");
+  const int world = comm_ ? comm_world_ : 1, rank = comm_ ? comm_rank_ : 0;
+  if (dst_rank < 0 || dst_rank >= world) throw Error(FDH_ERR_INVALID, "gather_stripes: destination rank out of range");
+  drain();  // the frame's launches are on the stream: the transfers queue behind them
+  FDH_HIP(hipSetDevice(device_));
+  const size_t row_bytes = (size_t)W_ * 4;
+  int my0, my1;
+  stripe_rows(H_, world, rank, &my0, &my1);
+  uint8_t* own = reinterpret_cast<uint8_t*>(fb_);
+  uint8_t* dst = dst_image ? static_cast<uint8_t*>(dst_image) : own;
+  if (rank == dst_rank && dst != own && my1 > my0)  // the destination's own rows: a copy on the device
+    FDH_HIP(hipMemcpyAsync(dst + (size_t)my0 * row_bytes, own + (size_t)my0 * row_bytes, (size_t)(my1 - my0) * row_bytes, hipMemcpyDeviceToDevice, stream_));
+  if (world == 1) return;
+  Rccl& R = rccl();
+  ncclComm_t comm = static_cast<ncclComm_t>(comm_);
+  FDH_NCCL(R.GroupStart());
+  if (rank == dst_rank) {
+    for (int r = 0; r < world; r++) {
+      int y0, y1;
+      stripe_rows(H_, world, r, &y0, &y1);
+      if (r != rank && y1 > y0) FDH_NCCL(R.Recv(dst + (size_t)y0 * row_bytes, (size_t)(y1 - y0) * row_bytes, ncclUint8, r, comm, stream_));
+    }
+  } else if (my1 > my0) {
+    FDH_NCCL(R.Send(own + (size_t)my0 * row_bytes, (size_t)(my1 - my0) * row_bytes, ncclUint8, dst_rank, comm, stream_));
+  }
+  FDH_NCCL(R.GroupEnd());
+}
+
+// Frame-parallel mode: every rank holds a whole frame; dst_rank receives rank r's into dst_images[r] (its own by a device copy).
+void Context::gather_frames(int dst_rank, void* const* dst_images) {
+  need_device("gather_frames");
+  if (!fb_) throw Error(FDH_ERR_INVALID, "gather_frames: no frame surface yet");
+  const int world = comm_ ? comm_world_ : 1, rank = comm_ ? comm_rank_ : 0;
+  if (dst_rank < 0 || dst_rank >= world) throw Error(FDH_ERR_INVALID, "gather_frames: destination rank out of range");
+  if (rank == dst_rank && !dst_images) throw Error(FDH_ERR_INVALID, "gather_frames: the destination rank needs one image per rank");
+  drain();
+  FDH_HIP(hipSetDevice(device_));
+  const size_t bytes = (size_t)W_ * H_ * 4;
+  if (rank == dst_rank && dst_images[rank] && dst_images[rank] != fb_)
+    FDH_HIP(hipMemcpyAsync(dst_images[rank], fb_, bytes, hipMemcpyDeviceToDevice, stream_));
+  if (world == 1) return;
+  Rccl& R = rccl();
+  ncclComm_t comm = static_cast<ncclComm_t>(comm_);
+  FDH_NCCL(R.GroupStart());
+  if (rank == dst_rank) {
+    for (int r = 0; r < world; r++)
+      if (r != rank) {
+        if (!dst_images[r]) throw Error(FDH_ERR_INVALID, "gather_frames: null destination image");
+        FDH_NCCL(R.Recv(dst_images[r], bytes, ncclUint8, r, comm, stream_));
+      }
+  } else {
+    FDH_NCCL(R.Send(fb_, bytes, ncclUint8, dst_rank, comm, stream_));
+  }
+  FDH_NCCL(R.GroupEnd());
+}
+
+}  // namespace fdh

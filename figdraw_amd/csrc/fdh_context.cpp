@@ -63,6 +63,7 @@ Context::Context(int atlas_size, float pixel_scale, int device, uint32_t flags) 
 
 Context::~Context() {
   if (host_only_) return;
+  try { comm_destroy(); } catch (...) {}
   if (worker_.joinable()) {
     { std::lock_guard<std::mutex> lk(mu_); quit_ = true; }
     cv_job_.notify_all();

@@ -232,6 +232,13 @@ class Context {
   int64_t uploaded_bytes() { drain(); return uploaded_bytes_; }
   uint64_t record_digest();  // FNV-1a over the last frame's draw records (diagnostic: works on record-only contexts)
 
+  // multi-GPU: the gather over RCCL (fdh_comm.cpp)
+  void comm_init(const uint8_t id[FDH_COMM_ID_BYTES], int rank, int world);
+  void comm_share(Context* owner);
+  void comm_destroy();
+  void gather_stripes(int dst_rank, void* dst_image);
+  void gather_frames(int dst_rank, void* const* dst_images);
+
   // multi-GPU / measurement
   void set_stripe(int y0, int y1) { drain(); stripe_y0_ = y0; stripe_y1_ = y1; }
   void replay(int times);
@@ -265,6 +272,9 @@ class Context {
 
   int device_ = 0;
   uint32_t flags_ = 0;
+  void* comm_ = nullptr;  // ncclComm_t (fdh_comm_init)
+  int comm_rank_ = 0, comm_world_ = 1;
+  bool comm_borrowed_ = false;
   hipStream_t own_stream_ = nullptr, stream_ = nullptr;
   hipEvent_t ev_[2] = {};
   std::vector<hipEvent_t> ev_pool_;
@@ -362,6 +372,8 @@ class Context {
   float host_record_ms_ = 0.0f;
 };
 
+void stripe_rows(int height, int world, int rank, int* y0, int* y1);
+void comm_unique_id(uint8_t out[FDH_COMM_ID_BYTES]);
 void blur_weight_fragments(float blur_radius, bool vertical, float* dense, uint16_t* frag_bits, int* reach, int* k_steps);
 void saturated_core_of(const float rect[4], const float rx[4], const float ry[4], int mode, float factor, float spread,
                        const float shape[2], float aa, int out[4]);

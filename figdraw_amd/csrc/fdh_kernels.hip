@@ -593,6 +593,7 @@ __device__ __forceinline__ DrawRec load_rec_whole(const DrawRec* __restrict__ p)
   r.kx = f(q[7].y); r.ky = f(q[7].z); r._pad = 0u;
   return r;
 }
+static_assert(LE_PLAIN == 0x80000000u, "the compositor tests LE_PLAIN as the sign bit");
 static_assert(offsetof(DrawRec, p2) == 32 && offsetof(DrawRec, col) == 64 && offsetof(DrawRec, aux2) == 96 && offsetof(DrawRec, bx0) == 100 && offsetof(DrawRec, ix0) == 108 && offsetof(DrawRec, aa) == 88 && offsetof(DrawRec, kx) == 116, "load_rec_whole follows DrawRec's layout");
 
 // Local-frame coordinates of a lane's pixels on an axis-aligned SDF quad (atlas.frag:252-262: p = (uv - 0.5) * 2 * quadHalfExtents,
@@ -965,6 +966,15 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? 4 : kPaths == 4 ? FDH_UNIFORM_WA
     T_cull += FDH_NOW() - Tc0 + (m & 0ull);
 #endif
     if (m == 0) continue;
+    // Which straight-line path each surviving entry takes on this strip, decided for all 64 entries at once with vector
+    // compares; the draw loop then tests ONE bit per decision (s_bitcmp1 + s_cbranch_scc) where it used to rebuild the answer per
+    // draw out of four scalar booleans (s_cselect_b64 / s_and_b64 chains on the one scalar unit a CU has).
+    //   m_plainc: the strip lies in the draw's saturated core and the draw has one colour -> a uniform blend, record not fetched
+    //   m_simple: an edge strip of a draw with a packed edge path (list-entry path codes 1..8)
+    // (each is one vector compare on the entry's flag word, combined with the strip masks above on the scalar side)
+    const unsigned long long m_plainc = m_core & __ballot((int32_t)idx < 0);  // LE_PLAIN is the sign bit
+    const uint32_t code_l = idx & (15u << LE_PATH_SHIFT);
+    const unsigned long long m_simple = m & ~m_core & __ballot((kPaths & 3) == 0 ? code_l != 0u : (code_l - 1u) < (4u << LE_PATH_SHIFT));
     // sdRoundedBox (atlas.frag:51-69) of the lane's four pixels at height py for half extents (bx, by)
     auto dist4 = [&](const DrawRec& r, const f2 pxa, const f2 pxb, const float py_, const float bx, const float by, f2& da, f2& db) __attribute__((always_inline)) {
       const bool top = py_ > 0.0f;
@@ -1454,12 +1464,12 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? 4 : kPaths == 4 ? FDH_UNIFORM_WA
     };
     while (m != 0) {
       const int bit = __builtin_ctzll(m);
-      m &= m - 1;
+      const unsigned long long one = 1ull << bit;  // (one shift serves the removal and every class test below)
+      m &= ~one;
       const uint32_t word = __builtin_amdgcn_readlane(idx, bit);
       const uint32_t d = word & LE_INDEX;
-      const bool core = (m_core >> bit) & 1ull;
       const bool unclipped = !kMasks || (mask_depth == 0 && !rmask_on);
-      if (core && (word & LE_PLAIN) && unclipped) {
+      if (unclipped && (m_plainc & one) != 0ull) {
         // One colour, coverage 1, nothing clipping: the whole strip gets the same source term.  Only the colour is
         // fetched (4 bytes instead of the 128-byte record) and nothing of the record is decoded.
         const F4 c0 = unpack255(draws[d].col[0]);
@@ -1474,7 +1484,7 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? 4 : kPaths == 4 ? FDH_UNIFORM_WA
       // the path code rides in the list entry: the branch is taken on a value that is already in an SGPR, and the record
       // is fetched whole, once, behind it
       const uint32_t code = (word >> LE_PATH_SHIFT) & 15u;
-      if (!core && code != 0u && (code <= 4u || (kPaths & 3) == 0) && unclipped) {
+      if (unclipped && (m_simple & one) != 0ull) {
         const DrawRec r = load_rec_whole(draws + d);
         const uint32_t c4 = (code - 1u) & 3u;
         const uint32_t mode = c4 == 0u ? 3u : c4 == 1u ? 7u : c4 == 2u ? 9u : 12u;
@@ -1483,7 +1493,7 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? 4 : kPaths == 4 ? FDH_UNIFORM_WA
 #if FDH_EDGE_CHECK
         F4 S0 = F0, S1 = F1, S2 = F2, S3 = F3;
         simple_edge(r, mode, code > 4u, S0, S1, S2, S3);
-        shade(d, r, core);
+        shade(d, r, false);
         {
           const bool ellip = code > 4u;
           const float gS[16] = {S0.x, S0.y, S0.z, S0.w, S1.x, S1.y, S1.z, S1.w, S2.x, S2.y, S2.z, S2.w, S3.x, S3.y, S3.z, S3.w};
@@ -1509,8 +1519,9 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? 4 : kPaths == 4 ? FDH_UNIFORM_WA
             const int nb = __builtin_ctzll(m);
             const uint32_t w2 = __builtin_amdgcn_readlane(idx, nb);
             const uint32_t code2 = (w2 >> LE_PATH_SHIFT) & 15u;
-            if ((w2 & LE_INDEX) != dcur + 1u || ((m_core >> nb) & 1ull) != 0ull || code2 == 0u || (code2 > 4u) != ellip) break;
-            m &= m - 1;
+            const unsigned long long one2 = 1ull << nb;
+            if ((w2 & LE_INDEX) != dcur + 1u || (m_simple & one2) == 0ull || (code2 > 4u) != ellip) break;
+            m &= ~one2;
             dcur++;
             wcur = w2;
             // the member's own parameters: sdfParams.zw + sdfFactors (16 bytes at offset 32) and its colour (offset 64)
@@ -1529,6 +1540,7 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? 4 : kPaths == 4 ? FDH_UNIFORM_WA
       }
 #endif
       const DrawRec r = load_rec_whole(draws + d);
+      const bool core = (m_core & one) != 0ull;
 #if FDH_TIMING
       const unsigned long long Ts0 = FDH_NOW() + (r.op_mode & 0u);
 #endif

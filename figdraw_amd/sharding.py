@@ -10,7 +10,8 @@ from typing import List, Optional, Tuple
 
 
 def stripe_rows(height: int, world: int, rank: int, align: int = 8) -> Tuple[int, int]:
-    """Rows [y0, y1) of rank `rank`: contiguous, tile-aligned (8 rows), covering [0, height) exactly once."""
+    """Rows [y0, y1) of rank `rank`: contiguous, tile-aligned (8 rows), covering [0, height) exactly once.
+    (The library's fdh_stripe_rows is the same rule in C: tests/test_abi_and_sharding.py compares the two.)"""
     tiles = (height + align - 1) // align
     base, extra = divmod(tiles, world)
     t0 = rank * base + min(rank, extra)

@@ -309,6 +309,29 @@ FDH_API int fdh_debug_record_digest(FdhContext*, uint64_t* out);
 /* Restrict rasterisation to rows [y0, y1) of the frame (row-stripe sharding).  Rows outside the
  * stripe are left untouched; blur halos are rendered redundantly so no exchange is needed.  y1 <= y0 disables it. */
 FDH_API int fdh_set_stripe(FdhContext*, int y0, int y1);
+/* ---- the gather over RCCL / xGMI (one process per GPU).  Nothing is exchanged while a frame renders; the one
+ * collective of the path is the gather of the finished RGBA8 rows or frames to one rank: grouped ncclSend / ncclRecv on the
+ * context's stream, queued behind the frame's kernels (no host synchronisation; fdh_sync on the destination waits for it).
+ * librccl is loaded on first use (dlopen; FDH_RCCL_LIB overrides the name), never linked.
+ *   fdh_stripe_rows      the partition rule: rows [y0, y1) of `rank` when `height` rows are cut into `world` contiguous stripes
+ *                        of whole 8-row strips -- what each rank passes to fdh_set_stripe
+ *   fdh_comm_unique_id   ncclGetUniqueId: rank 0 makes the 128-byte id, the host carries it to the other ranks (its own channel)
+ *   fdh_comm_init        ncclCommInitRank on the context's device; fdh_comm_destroy (also done by fdh_destroy)
+ *   fdh_comm_share       a second context of the same process (frames in flight) borrows `owner`'s communicator instead of
+ *                        creating one; the owner must outlive it
+ *   fdh_gather_stripes   row-stripe mode: rank r sends rows fdh_stripe_rows(H, world, r) of its surface to dst_rank, which
+ *                        receives them into the same rows of dst_image (device, W x H RGBA8; NULL: its own surface, whose own
+ *                        rows are already in place)
+ *   fdh_gather_frames    frame-parallel mode: every rank sends its whole frame, dst_rank receives rank r's into dst_images[r]
+ * Without fdh_comm_init a context is rank 0 of 1 and the gathers reduce to the destination's device copy. */
+#define FDH_COMM_ID_BYTES 128
+FDH_API int fdh_stripe_rows(int height, int world, int rank, int* y0, int* y1);
+FDH_API int fdh_comm_unique_id(uint8_t out[FDH_COMM_ID_BYTES]);
+FDH_API int fdh_comm_init(FdhContext*, const uint8_t id[FDH_COMM_ID_BYTES], int rank, int world);
+FDH_API int fdh_comm_share(FdhContext*, FdhContext* owner);
+FDH_API int fdh_comm_destroy(FdhContext*);
+FDH_API int fdh_gather_stripes(FdhContext*, int dst_rank, void* dst_image);
+FDH_API int fdh_gather_frames(FdhContext*, int dst_rank, void* const* dst_images);
 /* Re-run the GPU work of the last submitted frame `times` times from the draw records already resident in HBM
  * (the host-side decomposition and the upload are not repeated). */
 FDH_API int fdh_replay(FdhContext*, int times);

@@ -216,6 +216,21 @@ int main(int argc, char** argv) {
     CHECK(fdh_replay_timed(c, 2, ms) == FDH_ERR_NO_DEVICE);
     CHECK(fdh_profile(c, 1) == FDH_ERR_NO_DEVICE);
     CHECK(fdh_set_stream(c, NULL) == FDH_ERR_NO_DEVICE);
+    {
+      int y0 = -1, y1 = -1, r, covered = 0;
+      uint8_t id[FDH_COMM_ID_BYTES];
+      for (r = 0; r < 3; r++) { OK(fdh_stripe_rows(2160, 3, r, &y0, &y1)); CHECK(y0 == covered && y0 % 8 == 0 && y1 > y0); covered = y1; }
+      CHECK(covered == 2160);
+      CHECK(fdh_stripe_rows(2160, 3, 3, &y0, &y1) == FDH_ERR_INVALID);
+      memset(id, 0, sizeof id);
+      CHECK(fdh_comm_init(c, id, 0, 1) == FDH_ERR_NO_DEVICE);     /* a communicator lives on a device */
+      CHECK(fdh_gather_stripes(c, 0, NULL) == FDH_ERR_NO_DEVICE);
+      CHECK(fdh_gather_frames(c, 0, NULL) == FDH_ERR_NO_DEVICE);
+      CHECK(fdh_comm_share(c, c) == FDH_ERR_NO_DEVICE);
+      OK(fdh_comm_destroy(c));                                    /* nothing to destroy: fine */
+      r = fdh_comm_unique_id(id);                                 /* needs librccl and a device: either answer is an answer, no crash */
+      CHECK(r == FDH_OK || r == FDH_ERR_UNSUPPORTED || r == FDH_ERR_HIP);
+    }
     OK(fdh_set_stripe(c, 0, 0));
     OK(fdh_sync(c));
     OK(fdh_flush(c));

@@ -145,6 +145,16 @@ def test_stripe_partition_properties():
                 assert b0 == a1 and a0 <= b0
             assert all(a % 8 == 0 or a == h for a, _ in rows)
     assert [frame_of_rank(s, 4, r) for s in range(2) for r in range(4)] == list(range(8))
+    # the C ABI's partition rule (what a Nim host calls) is the same rule
+    from figdraw_amd import context
+
+    L = context.load()
+    for h in (1, 7, 8, 160, 375, 1080, 2160, 4320):
+        for world in (1, 2, 3, 4, 8):
+            for r in range(world):
+                y0, y1 = C.c_int(), C.c_int()
+                assert L.fdh_stripe_rows(h, world, r, C.byref(y0), C.byref(y1)) == 0
+                assert (y0.value, y1.value) == stripe_rows(h, world, r)
 
 
 _WORKER = r"""
@@ -343,9 +353,57 @@ def test_bench_stripes_mode_two_ranks_gathers_the_frame():
 
 
 @pytest.mark.gpu
+def test_bench_stripes_mode_one_rank_gathers_through_the_c_abi():
+    """the same run mode on ONE rank with the default gather: bench.py creates the RCCL communicator through fdh_comm_init
+    (rank 0 of 1 -- what a 1-GPU box can execute of it) and issues fdh_gather_stripes behind every frame on the context's
+    stream, no host synchronisation per frame; the frame left in rank 0's surface must be the oracle's."""
+    import json
+
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--mode", "stripes", "--width", "1920", "--height", "1080", "--steps", "9",
+                        "--warmup", "2", "--repeats", "2"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == 1 and "fdh_gather_stripes" in d["config"]["gather"] and d["config"]["rows_per_rank"] == [1080]
+    assert d["gathered_frame_check"]["parity_max_lsb"] <= 1 and d["value"] > 0
+    assert "1920x1080" in d["metric"]
+
+
+@pytest.mark.gpu
 def test_bench_frames_mode_two_ranks():
     """bench.py's default N > 1 mode (frame-parallel, weak scaling) on two ranks."""
     d = _run_bench_two_ranks(["--width", "1280", "--height", "720", "--steps", "8", "--warmup", "2", "--no-cpu-baseline"], 29533)
     assert d["n_gpus"] == 2 and d["scaling"] == "weak"
     assert d["frames_in_flight_check"]["pixels_differing"] == 0
     assert d["value"] > 0 and d["gather_ms"] > 0
+
+
+@pytest.mark.gpu
+def test_c_abi_gather_on_one_rank():
+    """fdh_comm_* / fdh_gather_*: what a 1-GPU box can execute of the RCCL path -- librccl loads, a one-rank communicator is
+    created on the context's device, a second context borrows it, and both gathers deliver the destination rank's own rows /
+    frame into a separate device image behind the frame's kernels (no host synchronisation in between)."""
+    import ref_scenes as RS
+    from figdraw_amd.context import HipContext
+
+    w, h = 640, 360
+    src, src2, dst = HipContext(device=0), HipContext(device=0), HipContext(device=0)
+    dst.begin_frame(w, h, True, (0.0, 0.0, 0.0, 0.0))
+    dst.end_frame()
+    dst.sync()
+    dptr = dst.frame_device_ptr()[0]
+    uid = HipContext.comm_unique_id()
+    assert len(uid) == 128 and any(uid)
+    src.comm_init(uid, 0, 1)
+    src2.comm_share(src)
+    sc = RS.backdrop_blur(float(w), float(h))
+    src.render_frame(sc, w, h)
+    src.gather_stripes(0, dptr)  # queued behind the frame on src's stream
+    src.sync()
+    assert (dst.read_pixels() == src.read_pixels()).all()
+    src2.render_frame(RS.nested_clips(float(w), float(h)), w, h)
+    src2.gather_frames(0, [dptr])
+    src2.sync()
+    assert (dst.read_pixels() == src2.read_pixels()).all()
+    src2.close()
+    src.close()
+    dst.close()

@@ -9,7 +9,7 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_INSTS_VALU S
   name=$(echo $set | cut -d' ' -f1)
   out=$root/gpurun_out/traffic_${tag}_$name
   mkdir -p $out
-  (cd /tmp && rocprofv3 --kernel-trace --pmc $set --output-format csv -d $out -o run -- python3 $root/bench.py --steps 5 --warmup 1 --no-cpu-baseline > $out.log 2>&1)
+  (cd /tmp && rocprofv3 --kernel-trace --pmc $set --output-format csv -d $out -o run -- python3 $root/bench.py --steps 8 --warmup 2 --repeats 1 --no-cpu-baseline > $out.log 2>&1)
 done
 python3 $root/tools/pmc_traffic.py $tag $root/gpurun_out/traffic_${tag}_*/run_counter_collection.csv > $root/gpurun_out/${tag}_pmc_traffic.json
 cat $root/gpurun_out/${tag}_pmc_traffic.json

@@ -12,7 +12,7 @@ for set in \
   i=$((i+1))
   out=$root/gpurun_out/pmc_${tag}_$i
   mkdir -p $out
-  (cd /tmp && rocprofv3 --kernel-trace --pmc $set --output-format csv -d $out -o run -- python3 $root/bench.py --steps 5 --warmup 1 --no-cpu-baseline > $out.log 2>&1)
+  (cd /tmp && rocprofv3 --kernel-trace --pmc $set --output-format csv -d $out -o run -- python3 $root/bench.py --steps 8 --warmup 2 --repeats 1 --no-cpu-baseline > $out.log 2>&1)
   f=$(ls $out/*counter_collection.csv $out/*/*counter_collection.csv 2>/dev/null | head -1)
   [ -n "$f" ] && python3 $root/tools/pmc_summary.py $f > $out.txt
 done
