@@ -79,7 +79,7 @@ Context::~Context() {
   if (blur_tmp_) (void)hipFree(blur_tmp_);
   if (dbg_snap_) (void)hipFree(dbg_snap_);
   d_frame_.release(); d_lists_.release(); d_counts_.release(); d_order_[0].release(); d_order_[1].release();
-  glyph_a_.release(); glyph_b_.release(); glyph_lines_.release(); glyph_acc_.release();
+  glyph_a_.release(); glyph_b_.release(); glyph_lines_.release(); glyph_acc_.release(); d_mask_spill_.release();
   for (auto& b : staging_) b.release();
   for (auto& e : staging_ev_) if (e) (void)hipEventDestroy(e);
   if (own_stream_) (void)hipStreamDestroy(own_stream_);
@@ -882,16 +882,28 @@ void Context::draw_image(int64_t key, const float pos[2], const FdhColor colors[
   }
   // LOD for the axis-aligned form: rho = max(|du/dx|, |dv/dy|) in level-0 texels per pixel
   const float x0 = pos[0], y0 = pos[1], x1 = pos[0] + dw, y1 = pos[1] + dh;
+  bool one_to_one = false;
+  float qx0 = 0.0f, qy0 = 0.0f;
   {
-    const float qx0 = std::ceil(mat_.a * x0 + mat_.tx), qx1 = std::ceil(mat_.a * x1 + mat_.tx);
-    const float qy0 = std::ceil(mat_.d * y0 + mat_.ty), qy1 = std::ceil(mat_.d * y1 + mat_.ty);
+    qx0 = std::ceil(mat_.a * x0 + mat_.tx);
+    qy0 = std::ceil(mat_.d * y0 + mat_.ty);
+    const float qx1 = std::ceil(mat_.a * x1 + mat_.tx), qy1 = std::ceil(mat_.d * y1 + mat_.ty);
     const float rw = std::fabs(qx1 - qx0), rh = std::fabs(qy1 - qy0);
     if (rw > 0.0f && rh > 0.0f) {
       const float rho = std::max(std::fabs(r.r[2] - r.r[0]) * S / rw, std::fabs(r.r[3] - r.r[1]) * S / rh);
       r.aux2 = rho > 0.0f ? std::log2(rho) : 0.0f;
     }
+    // texels 1:1 on pixels (a glyph as renderText places it): the quad is as large as the image, upright, unshifted
+    one_to_one = !flip_y && qx1 > qx0 && qy1 > qy0 && rw == (float)e.w && rh == (float)e.h && (!subpixel_enabled_ || r.aux == 0.0f) &&
+                 mat_.b == 0.0f && mat_.c == 0.0f && std::fabs(qx0) < 1.0e6f && std::fabs(qy0) < 1.0e6f;
   }
   emit_quad(r, x0, y0, x1, y1, &fragments_);
+  if (one_to_one && !(recs_.back().op_mode & F_GENERAL)) {
+    DrawRec& rr = recs_.back();
+    rr.op_mode |= F_TEXEL_1TO1;
+    rr.ext = (uint32_t)(int32_t)(e.x - (int)qx0);   // texel x = pixel x + tdx
+    rr._pad = (uint32_t)(int32_t)(e.y - (int)qy0);  // texel y = pixel y + tdy
+  }
 }
 
 // drawMsdfImage / drawMtsdfImage: glcontext.nim:1097-1155, drawUvRectAtlasSdf :1022-1093
@@ -999,9 +1011,8 @@ void Context::begin_mask(const float rect[4], const float rx[4], const float ry[
   { FDH_REC("begin_mask").fv(rect, 4).fv(rx, 4).fv(ry, 4); }
   if (!frame_begun_) throw Error(FDH_ERR_INVALID, "ctx.beginFrame has not been called.");
   if (mask_begun_) throw Error(FDH_ERR_INVALID, "ctx.beginMask has already been called.");
-  if (mask_depth_ >= kMaskDepth) throw Error(FDH_ERR_UNSUPPORTED, "clip masks nested deeper than 16");
   mask_begun_ = true;
-  mask_depth_++;
+  mask_depth_++;  // (beyond kMaskDepth levels the compositor's stack spills to a global plane: Context::prepare)
   const FdhColor red{255, 0, 0, 255}, zero{0, 0, 0, 0};
   const FdhColor cols[4] = {red, red, red, red};
   const float shape[2] = {0, 0};
@@ -1257,6 +1268,7 @@ void Context::prepare(LaunchJob& J) {
   diff.resize((size_t)dw * (bins_y_ + 1));
   constexpr int kBinShift = 6;
   static_assert((1 << kBinShift) == kBin, "bins are 64 px");
+  int deepest_clip = 0;  // counted from the records (a retained scene splices cached records in: no begin_mask call sees them)
   int64_t frag_mode[4] = {0, 0, 0, 0}, frag_ellip = 0, frag_other = 0;  // phase 0, by SdfMode 3 / 7 / 9 / 12 (SURVEY.md 8d flop table)
   for (size_t pi = 0; pi < J.phases.size(); pi++) {
     Phase& p = J.phases[pi];
@@ -1265,6 +1277,7 @@ void Context::prepare(LaunchJob& J) {
     p.has_slow = false;
     p.has_atlas = false;
     p.has_masks = false;
+    int depth = 0;  // clip nesting inside the phase (open pushes are re-emitted at a phase's start)
     for (int i = p.first; i < p.first + p.count; i++) {
       const BBox& b = bboxes_[i];
       bbox_union(u, b);
@@ -1272,10 +1285,12 @@ void Context::prepare(LaunchJob& J) {
       const uint32_t om = recs_[i].op_mode, op = (om >> 12) & 15u, mode = om & 255u;
       const bool atlas_mode = mode == 0u || (mode >= 13u && mode <= 16u);
       if (op != OP_DRAW) p.has_masks = true;
+      if (op == OP_MASK_PUSH) { depth++; deepest_clip = std::max(deepest_clip, depth); } else if (op == OP_MASK_POP) depth--;
       // mirrors the path selection of k_composite_tiles: 4-wide atlas path for axis-aligned atlas quads sampled from level 0
       const bool atlas4 = atlas_mode && !(om & F_GENERAL) && op == OP_DRAW && !(mode == 0u && recs_[i].aux2 > 0.0f && n_levels_ >= 2);
       if (atlas4) p.has_atlas = true;
-      else if (op == OP_RMASK_BEGIN || ((op == OP_DRAW || op == OP_MASK_PUSH) && ((om & F_GENERAL) || atlas_mode || mode >= 18u))) p.has_slow = true;
+      // (a rect mask under a rotated transform -- matY.x != 0 -- is set up one pixel slot at a time; an upright one runs 4-wide)
+      else if ((op == OP_RMASK_BEGIN && recs_[i].inv_h != 0.0f) || ((op == OP_DRAW || op == OP_MASK_PUSH) && ((om & F_GENERAL) || atlas_mode || mode >= 18u))) p.has_slow = true;
       if (pi == 0 && op == OP_DRAW && !bbox_empty(b)) {
         const int64_t area = (int64_t)(b.x1 - b.x0) * (b.y1 - b.y0);
         if (mode == 3u) frag_mode[0] += area; else if (mode == 7u) frag_mode[1] += area; else if (mode == 9u) frag_mode[2] += area;
@@ -1313,6 +1328,16 @@ void Context::prepare(LaunchJob& J) {
     reserve_quiet(d_lists_, (size_t)J.phases.size() * nb * list_stride_);
     reserve_quiet(d_counts_, (size_t)J.phases.size() * nb);
     J.lists = d_lists_.ptr; J.counts = d_counts_.ptr;
+    // clip nesting beyond the LDS stack (kMaskDepth levels): one global plane per extra level, 256 bytes per strip
+    J.mask_spill = nullptr;
+    J.spill_stride = (size_t)nb * 16 * 64;
+    if (deepest_clip > kMaskDepth) {
+      const size_t levels = (size_t)(deepest_clip - kMaskDepth);
+      if (levels * J.spill_stride * sizeof(uint32_t) > ((size_t)2 << 30))
+        throw Error(FDH_ERR_UNSUPPORTED, "clip masks nested too deep for this frame size (the spill plane would exceed 2 GiB)");
+      reserve_quiet(d_mask_spill_, levels * J.spill_stride);
+      J.mask_spill = d_mask_spill_.ptr;
+    }
     std::vector<int> pf(J.phases.size() + 1);
     for (size_t i = 0; i < J.phases.size(); i++) pf[i] = J.phases[i].first;
     pf[J.phases.size()] = (int)n;
@@ -1651,6 +1676,7 @@ void Context::launch_frame(const LaunchJob& J, bool profile) {
     C.has_slow = ph.has_slow ? 1 : 0;
     C.has_atlas = ph.has_atlas ? 1 : 0;
     C.has_masks = ph.has_masks ? 1 : 0;
+    C.mask_spill = J.mask_spill; C.spill_stride = J.spill_stride;
     span_begin(p == 0 ? 1 : 2);
     launch_composite(stream_, dv_.recs, dv_.exts, C);
     span_end();

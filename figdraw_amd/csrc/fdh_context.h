@@ -139,6 +139,8 @@ struct LaunchJob {
   std::vector<const uint4*> mx_w_h, mx_w_v;  // per blur job: weight fragments of the matrix-pipe passes (in the frame block), or null
   int n_recs = 0;
   View dv;                 // typed views into the device frame block
+  uint32_t* mask_spill = nullptr;  // clip levels beyond kMaskDepth, [level][strip][lane]; spill_stride dwords per level
+  size_t spill_stride = 0;
   uint2* lists = nullptr;  // bin lists / counts (device)
   uint32_t* counts = nullptr;
   int bins_x = 0, bins_y = 0, list_stride = 0, binbox_shift = 0;
@@ -341,6 +343,7 @@ class Context {
   // records, quad extensions, bounding boxes and phase offsets of a frame live in ONE device block and arrive with ONE
   // copy (four small hipMemcpyAsync calls cost the host ~100 us per frame); the typed views point into it
   DeviceBuf<uint8_t> d_frame_;
+  DeviceBuf<uint32_t> d_mask_spill_;  // clip-stack levels beyond kMaskDepth (Context::prepare sizes it)
   DeviceBuf<uint2> d_lists_;
   DeviceBuf<uint32_t> d_counts_;
   DeviceBuf<int> d_order_[2];  // phase 0's bins, longest list first: read by this frame's launch / written for the next

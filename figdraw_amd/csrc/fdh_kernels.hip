@@ -590,7 +590,7 @@ __device__ __forceinline__ DrawRec load_rec_whole(const DrawRec* __restrict__ p)
   r.aux2 = f(q[6].x);
   r.bx0 = (int16_t)(q[6].y & 0xffffu); r.by0 = (int16_t)(q[6].y >> 16); r.bx1 = (int16_t)(q[6].z & 0xffffu); r.by1 = (int16_t)(q[6].z >> 16);
   r.ix0 = (int16_t)(q[6].w & 0xffffu); r.iy0 = (int16_t)(q[6].w >> 16); r.ix1 = (int16_t)(q[7].x & 0xffffu); r.iy1 = (int16_t)(q[7].x >> 16);
-  r.kx = f(q[7].y); r.ky = f(q[7].z); r._pad = 0u;
+  r.kx = f(q[7].y); r.ky = f(q[7].z); r._pad = q[7].w;
   return r;
 }
 static_assert(LE_PLAIN == 0x80000000u, "the compositor tests LE_PLAIN as the sign bit");
@@ -907,6 +907,18 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? 4 : kPaths == 4 ? FDH_UNIFORM_WA
   if (ty0 + kTileH <= P.row_lo || ty0 >= P.row_hi) return;
   const int tx1 = tx0 + kTileW, ty1 = ty0 + kTileH;
   const int px0 = tx0 + (lane & 7) * 4, py = ty0 + (lane >> 3);
+  // The clip stack: levels 0 .. kMaskDepth - 1 in LDS; deeper nesting (the reference has no limit: one mask plane per level,
+  // glcontext.nim:1886-1914) spills to a global plane the host sizes for the frame's deepest nest -- [level][strip][lane], every
+  // slot written and read by this lane alone (agent-scope accesses: the read must not be served from a stale L1 line).
+  const size_t spill_at = ((size_t)bin * kStripsPerBin + (size_t)sidx) * 64 + (size_t)lane;
+  auto stack_put = [&](const int depth, const uint32_t v) __attribute__((always_inline)) {
+    if (depth < kMaskDepth) mask_stack[mslot][depth][lane] = v;  // (wave-uniform)
+    else __hip_atomic_store(P.mask_spill + (size_t)(depth - kMaskDepth) * P.spill_stride + spill_at, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  auto stack_get = [&](const int depth) __attribute__((always_inline)) -> uint32_t {
+    if (depth < kMaskDepth) return mask_stack[mslot][depth][lane];
+    return __hip_atomic_load(P.mask_spill + (size_t)(depth - kMaskDepth) * P.spill_stride + spill_at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
   constexpr bool kMasks = (kPaths & 4) == 0;  // <4>: a phase without clip / rect-mask operations -- no mask registers, no stack
 #if FDH_TIMING
   const unsigned long long T0 = FDH_NOW();
@@ -1090,7 +1102,7 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? 4 : kPaths == 4 ? FDH_UNIFORM_WA
       if (kMasks && op == OP_MASK_POP) {
         mask_depth--;
         if (mask_depth > 0) {
-          const uint32_t w = mask_stack[mslot][mask_depth - 1][lane];
+          const uint32_t w = stack_get(mask_depth - 1);
           mk0 = (float)(w & 255u) * inv255; mk1 = (float)((w >> 8) & 255u) * inv255;
           mk2 = (float)((w >> 16) & 255u) * inv255; mk3 = (float)(w >> 24) * inv255;
         } else {
@@ -1099,6 +1111,21 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? 4 : kPaths == 4 ? FDH_UNIFORM_WA
         return;
       }
       if (kMasks && op == OP_RMASK_END) { rm0 = rm1 = rm2 = rm3 = 1.0f; rmask_on = false; return; }
+      if (kMasks && op == OP_RMASK_BEGIN && r.inv_h == 0.0f) {
+        // The fast rect mask under a transform without rotation (matY.x == 0: a row of pixels shares its local y), four pixels
+        // at once: rectMaskAlpha atlas_rect_mask.frag:222-237, operation for operation what rect_mask_alpha() does per pixel.
+        // (Rotated masks keep the one-pixel-slot path; this one lets a phase of rect-masked cells run on the <0> build: the
+        // reference's own clip + rect-mask benchmark went through the 128-VGPR slot build for these alone.)
+        float qx[4], dm[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) qx[k] = ((r.ox * (cx0 + (float)k) + r.oy * cy) + r.inv_w) - r.p0;
+        const float qy = ((r.inv_h * cx0 + r.f0 * cy) + r.f1) - r.p1;
+        shape_distN<4>((om & F_ELLIP) != 0u, qx, -qy, r.p2, r.p3, r.r[0], r.r[1], r.r[2], r.r[3], dm);
+        rm0 = 1.0f - clamp01(r.aa * dm[0] + 0.5f); rm1 = 1.0f - clamp01(r.aa * dm[1] + 0.5f);
+        rm2 = 1.0f - clamp01(r.aa * dm[2] + 0.5f); rm3 = 1.0f - clamp01(r.aa * dm[3] + 0.5f);
+        rmask_on = true;
+        return;
+      }
       const bool atlas_mode = (mode == 0u) || (mode >= 13u && mode <= 16u);
       // (builds without the slot path and the atlas path only ever see `fast` draws: the host picks the build per phase from
       // exactly these properties, Context::submit -- no need to decode them again per draw)
@@ -1112,6 +1139,52 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? 4 : kPaths == 4 ? FDH_UNIFORM_WA
         const int S = P.atlas.size, msk = S - 1;
         const float fS = (float)S;
         const uint32_t* __restrict__ tex = P.atlas.level[0];
+        if (mode == 0u && (om & F_TEXEL_1TO1) != 0u) {
+          // ---- a glyph placed texel on pixel (figrender.nim:456-496): the bilinear fractions are 0 up to float noise (a GL
+          // sampler's fixed-point coordinates snap them to 0), so a pixel IS its texel: the lane's four come in one 16-byte
+          // run (4-byte aligned: the atlas origin of a glyph is arbitrary) instead of sixteen dword gathers and their filter
+          // arithmetic.  Lanes outside the quad read texel (0, 0) and blend with alpha 0.
+          const uint32_t xrel = (uint32_t)(px0 - (int)r.bx0);
+          const bool rowc = py >= r.by0 && py < r.by1;
+          const uint32_t wcov = rowc ? (uint32_t)((int)r.bx1 - (int)r.bx0) : 0u;
+          const bool any_px = rowc & (px0 + 3 >= (int)r.bx0) & (px0 < (int)r.bx1);
+          const int tx = px0 + (int)r.ext, ty = py + (int)r._pad;
+          // (the atlas is a power of two wide: a shift, not a multiply -- an expensive arm would bring a divergent branch back)
+          const uint32_t off_in = ((((uint32_t)ty) << (uint32_t)__builtin_ctz((uint32_t)S)) + (uint32_t)tx) << 2;
+          const uint32_t off = any_px ? off_in : 0u;
+          struct __attribute__((packed, aligned(4))) Run4 { uint32_t v[4]; };
+          const Run4 run = *reinterpret_cast<const Run4*>(reinterpret_cast<const char*>(tex) + off);
+          const F4 c0u = unpack255(r.col[0]);
+          const bool solid = (om & F_SOLID) != 0u, masked = mask_depth > 0 || rmask_on;
+          const bool lane_col = solid || (r.col[0] == r.col[1] && r.col[2] == r.col[3]);  // wave-uniform
+          const float t = (cy - r.oy) * r.inv_h;
+          F4 colL = {c0u.x * inv255, c0u.y * inv255, c0u.z * inv255, c0u.w * inv255};
+          if (!solid && lane_col) {  // a vertical tint: one colour per lane (see the general atlas path below)
+            const F4 br = unpack255(r.col[1]), tr = unpack255(r.col[2]), tl = unpack255(r.col[3]);
+            const float s0 = (cx0 - r.ox) * r.inv_w;
+            colL.x = tri_lerp(tl.x, c0u.x, br.x, tr.x, s0, t) * inv255;
+            colL.y = tri_lerp(tl.y, c0u.y, br.y, tr.y, s0, t) * inv255;
+            colL.z = tri_lerp(tl.z, c0u.z, br.z, tr.z, s0, t) * inv255;
+            colL.w = tri_lerp(tl.w, c0u.w, br.w, tr.w, s0, t) * inv255;
+          }
+          auto texel_px = [&](const int k, F4& F, const float mk, const float rm) __attribute__((always_inline)) {
+            const F4 a = unpack255(run.v[k]);
+            F4 col = colL;
+            if (!lane_col) {  // wave-uniform
+              const F4 br = unpack255(r.col[1]), tr = unpack255(r.col[2]), tl = unpack255(r.col[3]);
+              const float sk = (cx0 + (float)k - r.ox) * r.inv_w;
+              col.x = tri_lerp(tl.x, c0u.x, br.x, tr.x, sk, t) * inv255;
+              col.y = tri_lerp(tl.y, c0u.y, br.y, tr.y, sk, t) * inv255;
+              col.z = tri_lerp(tl.z, c0u.z, br.z, tr.z, sk, t) * inv255;
+              col.w = tri_lerp(tl.w, c0u.w, br.w, tr.w, sk, t) * inv255;
+            }
+            float sa = a.w * inv255 * col.w;
+            if (masked) sa = sa * mk * rm;
+            blend(F, a.x * inv255 * col.x, a.y * inv255 * col.y, a.z * inv255 * col.z, (xrel + (uint32_t)k) < wcov ? sa : 0.0f);
+          };
+          texel_px(0, F0, mk0, rm0); texel_px(1, F1, mk1, rm1); texel_px(2, F2, mk2, rm2); texel_px(3, F3, mk3, rm3);
+          return;
+        }
         const float uax = r.r[0], uay = r.r[1], utx = r.r[2], uty = r.r[3];
         const float t = (cy - r.oy) * r.inv_h;
         const float v = uay + (uty - uay) * t;
@@ -1235,7 +1308,7 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? 4 : kPaths == 4 ? FDH_UNIFORM_WA
           { const float t = mk0; mk0 = mk1; mk1 = mk2; mk2 = mk3; mk3 = t; }
           { const float t = rm0; rm0 = rm1; rm1 = rm2; rm2 = rm3; rm3 = t; }
         }
-        if (op == OP_MASK_PUSH) { mask_stack[mslot][mask_depth][lane] = packed; mask_depth++; }
+        if (op == OP_MASK_PUSH) { stack_put(mask_depth, packed); mask_depth++; }
         return;
       }
 
@@ -1358,7 +1431,7 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? 4 : kPaths == 4 ? FDH_UNIFORM_WA
           mk[k] = q * inv255;
         }
         mk0 = mk[0]; mk1 = mk[1]; mk2 = mk[2]; mk3 = mk[3];
-        mask_stack[mslot][mask_depth][lane] = packed;
+        stack_put(mask_depth, packed);
         mask_depth++;
         return;
       }
@@ -2197,6 +2270,286 @@ __global__ __launch_bounds__(64, 2) void k_blur_mx(BlurParams P, const DrawRec* 
     row[0] = FDH_NOW() - T0; row[1] = T_pro; row[2] = T_wait; row[3] = T_st; row[4] = T_mma; row[5] = T_epi; row[6] = kV ? 3 : 2; row[7] = T_iss; row[8] = n_blocks; row[9] = T0;
   }
 #endif
+}
+
+// ------------------------------------------------------------------ both passes of a full-frame node in ONE kernel
+// A backdrop blur that covers the whole frame moved every texel four times: H read + H write (the reference's RGBA8
+// intermediate texture, glcontext.nim:1743-1786), V read + V write.  Here the intermediate never leaves the CU.  One wave owns a
+// strip 32 columns wide and walks DOWN it in blocks of 32 rows: it filters 32 new rows horizontally (the k_blur_mx<., false>
+// product: texels x Toeplitz weights), rounds them to RGBA8 exactly as the H pass stores them, and writes them into a ring of
+// 16-row LDS slots; two blocks behind, the vertical product (k_blur_mx<., true>: weights x texels) reads its NKV k-steps out of
+// that ring, and the epilogue -- scale, RGBA8, the fused mode-17 composite, 128-byte row stores -- is k_blur_mx's.
+//   * Same sums, same grouping: H blocks sit at absolute multiples of 32 in x with the H pass's k-step alignment, V blocks at
+//     absolute multiples of 32 in y with windows starting at y - reach: the result is the two-pass result bit for bit.
+//   * Rows of the ring are H-blocks whose first row is congruent to -reach mod 32, so a V window starts on a slot boundary
+//     and the V weight table of the two-pass kernel is used unchanged.
+//   * Out of place: src is the surface the phase before left, dst another one (Context::launch_frame alternates the two and
+//     starts so that the frame ends in the context's own surface); the fused composite blends over src's texel.
+//   * A segment of T blocks re-filters (NKV - 1) / 2 + 1 extra H-blocks of halo: T is chosen so that every wave of the launch is
+//     resident at once (4K, radius 18: 120 strips x 10 segments of 7 blocks, 1.29x the H work).
+// Bytes: (1 + halo) x 4 A read (the x halo comes out of L2) + 4 A written, against 16 A for the two passes.
+constexpr int fx_vblocks(int nkv) { return ((nkv - 1) >> 1) + 1; }               // H-blocks one V block reads
+constexpr int fx_slots(int nkh, int nkv) { return 2 * nkh + 2 * fx_vblocks(nkv); }  // source k-steps (this block + the next) + the H ring
+template <int NKH, int NKV>
+__global__ __launch_bounds__(64, 2) void k_blur_fx(BlurParams P, const uint4* __restrict__ w_v, const DrawRec* __restrict__ draws, const QuadExt* __restrict__ exts, int T) {
+  constexpr int HB = fx_vblocks(NKV);  // V block b reads H-blocks b .. b + HB - 1
+  constexpr int RV = 2 * HB;           // slots of the H ring
+  extern __shared__ __attribute__((aligned(16))) uint32_t ring[];
+  uint32_t* const src_ring = ring;                   // 2 x NKH slots: [32 rows][16 px], 16-byte pieces XOR-swizzled (as the H pass)
+  uint32_t* const h_ring = ring + 2 * NKH * kMxSlot;  // RV slots: [16 rows][32 px] (as the V pass)
+  const int n_strips = (P.x1 - (P.x0 & ~31) + 31) >> 5;
+  const int y_first = P.y0 & ~31;
+  const int n_seg = (P.y1 - y_first + 32 * T - 1) / (32 * T);
+  const int total = n_strips * n_seg, per = (total + 7) >> 3, q = blockIdx.x >> 3, item = (blockIdx.x & 7) * per + q;
+  if (q >= per || item >= total) return;  // every XCD takes a contiguous eighth of the row-major sequence: a band of the frame
+  const int seg = item / n_strips, strip = item - seg * n_strips;
+  const int lane = threadIdx.x, g = lane >> 5, j = lane & 31;
+  const int reach = P.taps.reach;
+  const int xb = (P.x0 & ~31) + 32 * strip;  // the strip's columns
+  const int ys = y_first + 32 * T * seg;      // first output row of the segment
+  const int n_blocks = min(T, (P.y1 - ys + 31) >> 5);
+  const int ws = ys - reach;                  // first row of H-block 0
+  const int w0a = (xb - reach) & ~3;          // horizontal window start, moved back to a 16-byte boundary (mx_delta)
+  const uint32_t ring_lds = (uint32_t)reinterpret_cast<uintptr_t>(ring);
+
+  // LDS-DMA of the NKH source k-steps of H-block i into half (i & 1) of the source ring; returns the instructions issued
+  auto issue_block = [&](int i) -> int {
+    const int r = lane >> 2, c = lane & 3;
+    const uint32_t* rowp[2];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const int row = 16 * h + r;
+      int y = ws + 32 * i + row;
+      y = y < 0 ? 0 : (y > P.H - 1 ? P.H - 1 : y);  // clamp-to-edge (glcontext.nim:214-215): a clamped row filters to a clamped H row
+      rowp[h] = P.src + (size_t)y * P.pitch + 4 * (c ^ ((row >> 2) & 3));
+    }
+    int n = 0;
+#pragma unroll
+    for (int s = 0; s < NKH; s++) {
+      const uint32_t slot = ring_lds + (uint32_t)((i & 1) * NKH + s) * (kMxSlot * 4u);
+      const int xk = w0a + 16 * s;
+      if (xk >= 0 && xk + 16 <= P.W) {  // wave-uniform
+        lds_dma16(rowp[0] + xk, slot);
+        lds_dma16(rowp[1] + xk, slot + 1024u);
+        n += 2;
+      } else {  // the k-step crosses a frame edge: one texel per lane, clamped
+        const int rr = lane >> 4, pp = lane & 15;
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+          const int row = 4 * e + rr;
+          int y = ws + 32 * i + row;
+          y = y < 0 ? 0 : (y > P.H - 1 ? P.H - 1 : y);
+          int gx = xk + 4 * ((pp >> 2) ^ ((row >> 2) & 3)) + (pp & 3);
+          gx = gx < 0 ? 0 : (gx > P.W - 1 ? P.W - 1 : gx);
+          lds_dma4(P.src + (size_t)y * P.pitch + gx, slot + e * 256u);
+        }
+        n += 8;
+      }
+    }
+    return n;
+  };
+  auto wait_for_all_but = [&](int n) {
+    if (n >= 48) wait_vm<48>(); else if (n >= 24) wait_vm<24>(); else if (n >= 16) wait_vm<16>(); else if (n >= 12) wait_vm<12>(); else if (n >= 10) wait_vm<10>(); else if (n >= 8) wait_vm<8>(); else if (n >= 6) wait_vm<6>(); else wait_vm<0>();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  issue_block(0);
+  // weight fragments of both products, fetched behind the first block's DMA and waited for once (see k_blur_mx)
+  h8 hhi[NKH], hlo[NKH], vhi[NKV], vlo[NKV];
+#pragma unroll
+  for (int m = 0; m < NKH; m++) {
+    H8Bits a, b;
+    const uint4 va = P.mx_w[(2 * m) * 64 + lane], vb = P.mx_w[(2 * m + 1) * 64 + lane];
+    a.u[0] = va.x; a.u[1] = va.y; a.u[2] = va.z; a.u[3] = va.w; b.u[0] = vb.x; b.u[1] = vb.y; b.u[2] = vb.z; b.u[3] = vb.w;
+    hhi[m] = a.v; hlo[m] = b.v;
+  }
+#pragma unroll
+  for (int m = 0; m < NKV; m++) {
+    H8Bits a, b;
+    const uint4 va = w_v[(2 * m) * 64 + lane], vb = w_v[(2 * m + 1) * 64 + lane];
+    a.u[0] = va.x; a.u[1] = va.y; a.u[2] = va.z; a.u[3] = va.w; b.u[0] = vb.x; b.u[1] = vb.y; b.u[2] = vb.z; b.u[3] = vb.w;
+    vhi[m] = a.v; vlo[m] = b.v;
+  }
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+  int core_x0 = 0, core_y0 = 0, core_x1 = 0, core_y1 = 0;
+  if (P.fuse_draw >= 0) { const DrawRec* qd = draws + P.fuse_draw; core_x0 = qd->ix0; core_y0 = qd->iy0; core_x1 = qd->ix1; core_y1 = qd->iy1; }
+
+  const int n_hblocks = n_blocks + HB - 1;
+#pragma unroll 1
+  for (int i = 0; i < n_hblocks; i++) {
+    // the next H-block's texels start their way into the other half of the source ring; this block's have landed
+    int batch = 0;
+    if (i + 1 < n_hblocks) batch = issue_block(i + 1);
+    wait_for_all_but(batch);
+    // ---- horizontal product of H-block i: rows ws + 32 i .. + 31, columns xb .. xb + 31
+    {
+      f32x16 acc[4];
+#pragma unroll
+      for (int c = 0; c < 4; c++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) acc[c][e] = 0.0f;
+#pragma unroll
+      for (int m = 0; m < NKH; m++) {
+        const uint32_t* slot = src_ring + ((i & 1) * NKH + m) * kMxSlot;
+        const uint4* row4 = reinterpret_cast<const uint4*>(slot + j * 16);
+        const int sw = (j >> 2) & 3;
+        const uint4 lo4 = row4[(2 * g) ^ sw], hi4 = row4[(2 * g + 1) ^ sw];
+        const uint32_t t8[8] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
+        const h8 f0 = mx_frag<0>(t8), f1 = mx_frag<1>(t8), f2_ = mx_frag<2>(t8), f3 = mx_frag<3>(t8);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f0, hhi[m], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f1, hhi[m], acc[1], 0, 0, 0);
+        acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f2_, hhi[m], acc[2], 0, 0, 0);
+        acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f3, hhi[m], acc[3], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f0, hlo[m], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f1, hlo[m], acc[1], 0, 0, 0);
+        acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f2_, hlo[m], acc[2], 0, 0, 0);
+        acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f3, hlo[m], acc[3], 0, 0, 0);
+      }
+      // RGBA8 as the H pass stores it (the reference's intermediate texture), into H-ring slots 2 (i % HB), + 1: lane = column,
+      // register rr = row (rr & 3) + 8 (rr >> 2) + 4 g of the block
+      uint32_t* const hs = h_ring + (2 * (i % HB)) * kMxSlot;
+#pragma unroll
+      for (int rr = 0; rr < 16; rr++) {
+        const int row = (rr & 3) + 8 * (rr >> 2) + 4 * g;
+        hs[row * 32 + j] = pack2(f2{acc[0][rr] * kMxScale, acc[1][rr] * kMxScale}, f2{acc[2][rr] * kMxScale, acc[3][rr] * kMxScale});
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int b = i - (HB - 1);  // the V block whose last H-block this was
+    if (b < 0) continue;
+    // ---- vertical product of block b: rows ys + 32 b .. + 31 from k-steps 2 b .. 2 b + NKV - 1 of the H ring
+    f32x16 acc[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+#pragma unroll
+      for (int e = 0; e < 16; e++) acc[c][e] = 0.0f;
+#pragma unroll
+    for (int m = 0; m < NKV; m++) {
+      const uint32_t* slot = h_ring + ((2 * b + m) % RV) * kMxSlot;
+      uint32_t t8[8];
+#pragma unroll
+      for (int t = 0; t < 8; t++) t8[t] = slot[(8 * g + t) * 32 + j];
+      const h8 f0 = mx_frag<0>(t8), f1 = mx_frag<1>(t8), f2_ = mx_frag<2>(t8), f3 = mx_frag<3>(t8);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vhi[m], f0, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vhi[m], f1, acc[1], 0, 0, 0);
+      acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vhi[m], f2_, acc[2], 0, 0, 0);
+      acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vhi[m], f3, acc[3], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vlo[m], f0, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vlo[m], f1, acc[1], 0, 0, 0);
+      acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vlo[m], f2_, acc[2], 0, 0, 0);
+      acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vlo[m], f3, acc[3], 0, 0, 0);
+    }
+    const int bx = xb, by = ys + 32 * b;
+    const int x = bx + j;
+    const bool x_ok = x >= P.x0 && x < P.x1;
+    uint32_t pend[16];
+    uint32_t pmask = 0;
+#pragma unroll
+    for (int rr = 0; rr < 16; rr++)
+      pend[rr] = pack2(f2{acc[0][rr] * kMxScale, acc[1][rr] * kMxScale}, f2{acc[2][rr] * kMxScale, acc[3][rr] * kMxScale});
+    if (bx >= P.x0 && bx + 32 <= P.x1 && by >= P.y0 && by + 32 <= P.y1) {
+      pmask = 0xffffu;
+    } else {
+#pragma unroll
+      for (int rr = 0; rr < 16; rr++) {
+        const int y = by + (rr & 3) + 8 * (rr >> 2) + 4 * g;
+        if (x_ok && y >= P.y0 && y < P.y1) pmask |= 1u << rr;
+      }
+    }
+    if (P.fuse_draw >= 0) {
+      // atlas.frag:381-388 on the blurred texel just produced, blended over the live texel (src: dst is another surface, so
+      // every pixel of the region is written: where the quad does not cover, the live texel passes through the blend unchanged)
+      const bool core = bx >= core_x0 && bx + 32 <= core_x1 && by >= core_y0 && by + 32 <= core_y1;  // coverage alpha == 1 (wave-uniform)
+      bool replace_all = false;
+      if (core) {
+        uint32_t conj = pend[0];
+#pragma unroll
+        for (int rr = 1; rr < 16; rr++) conj &= pend[rr];
+        replace_all = __all((conj >> 24) == 255u);
+      }
+      if (!replace_all) {
+        // (two source slots of the half this iteration consumed: nothing is in flight into them until the next iteration's DMA)
+        uint32_t* const sc0 = src_ring + ((i & 1) * NKH + 0) * kMxSlot;
+        uint32_t* const sc1 = src_ring + ((i & 1) * NKH + 1) * kMxSlot;
+        const uint32_t valid = pmask;
+        if (!core) {
+#pragma unroll
+          for (int rr = 0; rr < 16; rr++) (rr < 8 ? sc0 : sc1)[(rr & 7) * 64 + lane] = __float_as_uint(((valid >> rr) & 1u) ? 1.0f : -1.0f);
+          __builtin_amdgcn_wave_barrier();
+          const DrawRec r = load_rec(draws + P.fuse_draw);
+          const int ra = min(max(core_y0 - by, 0), 32), rb = max(ra, min(max(core_y1 - by, 0), 32));  // rows [ra, rb) lie in the core's rows
+          const int ca = min(max(core_x0 - bx, 0), 32), cb = max(ca, min(max(core_x1 - bx, 0), 32));
+          const int nr = ra + 32 - rb, nc = ca + 32 - cb;
+#pragma unroll 1
+          for (int u0 = 0; u0 < nr + nc; u0 += 2) {
+            const int u = u0 + g;
+            int dx, dy;
+            if (u < nr) { dy = u < ra ? u : rb + (u - ra); dx = j; }
+            else { const int v = u - nr; dx = v < ca ? v : cb + (v - ca); dy = j; }
+            if (u >= nr + nc) continue;
+            const int ex = bx + dx, ey = by + dy;
+            float alpha = -1.0f;
+            if (ex >= P.x0 && ex < P.x1 && ey >= P.y0 && ey < P.y1) {
+              const Frag f = make_frag(r, exts, ex, ey);
+              alpha = 0.0f;  // (outside the quad the live texel stays: a blend with alpha 0)
+              if (f.covered) {
+                const float lx = (f.u - 0.5f) * 2.0f * r.p0, ly = (f.v - 0.5f) * 2.0f * r.p1;
+                const float dist = shape_dist((r.op_mode & F_ELLIP) != 0u, lx, -ly, r.p2, r.p3, r.r[0], r.r[1], r.r[2], r.r[3]);
+                alpha = 1.0f - clamp01(r.aa * dist + 0.5f);
+              }
+            }
+            const int er = (dy & 3) + 4 * (dy >> 3), el = dx + 32 * ((dy >> 2) & 1);  // accumulator register and lane of (dx, dy)
+            (er < 8 ? sc0 : sc1)[(er & 7) * 64 + el] = __float_as_uint(alpha);
+          }
+          __builtin_amdgcn_wave_barrier();
+        }
+        uint32_t blend_mask = 0;
+#pragma unroll
+        for (int rr = 0; rr < 16; rr++) {
+          if (!((valid >> rr) & 1u)) continue;
+          const float al = core ? 1.0f : __uint_as_float((rr < 8 ? sc0 : sc1)[(rr & 7) * 64 + lane]);
+          if (al != 1.0f || (pend[rr] >> 24) != 255u) blend_mask |= 1u << rr;
+        }
+        if (__any(blend_mask != 0u)) {
+          uint32_t dstv[16];
+#pragma unroll
+          for (int rr = 0; rr < 16; rr++)  // all the loads first
+            dstv[rr] = ((blend_mask >> rr) & 1u) ? P.src[(size_t)(by + (rr & 3) + 8 * (rr >> 2) + 4 * g) * P.pitch + x] : 0u;
+          const float k = 1.0f / 255.0f;
+#pragma unroll
+          for (int rr = 0; rr < 16; rr++) {
+            if (!((blend_mask >> rr) & 1u)) continue;
+            const float alpha = core ? 1.0f : __uint_as_float((rr < 8 ? sc0 : sc1)[(rr & 7) * 64 + lane]);
+            const F4 bl = unpack255(pend[rr]);
+            F4 Fd = unpack255(dstv[rr]);
+            const float sa = bl.w * k * alpha, A = 255.0f * sa, ia = 1.0f - sa;
+            Fd.x = __builtin_rintf(__builtin_fmaf(Fd.x, ia, bl.x * k * A));
+            Fd.y = __builtin_rintf(__builtin_fmaf(Fd.y, ia, bl.y * k * A));
+            Fd.z = __builtin_rintf(__builtin_fmaf(Fd.z, ia, bl.z * k * A));
+            Fd.w = __builtin_rintf(__builtin_fmaf(Fd.w, ia, A));
+            pend[rr] = pack255(Fd);
+          }
+          __builtin_amdgcn_s_waitcnt(0x0F70);
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+    // the block's rows: uniform row pointer + one per-lane byte offset
+    {
+      const uint32_t lane_off = ((uint32_t)(4 * g) * (uint32_t)P.pitch + (uint32_t)j) * 4u;
+      char* base = reinterpret_cast<char*>(P.dst + (size_t)by * P.pitch + bx);
+      if (__all(pmask == 0xffffu)) {
+#pragma unroll
+        for (int rr = 0; rr < 16; rr++)
+          *reinterpret_cast<uint32_t*>(base + (size_t)((rr & 3) + 8 * (rr >> 2)) * P.pitch * 4u + lane_off) = pend[rr];
+      } else if (__any(pmask != 0u)) {
+#pragma unroll
+        for (int rr = 0; rr < 16; rr++)
+          if ((pmask >> rr) & 1u) *reinterpret_cast<uint32_t*>(base + (size_t)((rr & 3) + 8 * (rr >> 2)) * P.pitch * 4u + lane_off) = pend[rr];
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
 }
 
 // ------------------------------------------------------------------ glyph images on their way into the atlas

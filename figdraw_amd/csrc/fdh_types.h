@@ -15,7 +15,7 @@ constexpr int kWgW = kTileW;                // 32
 constexpr int kWgH = kTileH * kWavesPerWg;  // 32: the four waves of a workgroup are stacked vertically
 constexpr int kBin = 64;
 constexpr int kWgsPerBin = (kBin / kWgW) * (kBin / kWgH);  // 4
-constexpr int kMaskDepth = 16;                             // per-lane clip stack depth kept in LDS (4 KB per wavefront)
+constexpr int kMaskDepth = 16;                             // per-lane clip stack levels kept in LDS (4 KB per wavefront); deeper levels spill to a global plane
 constexpr int kMaxMips = 14;
 constexpr int kMaxBlurTaps = 36;
 
@@ -36,6 +36,11 @@ constexpr uint32_t F_GENERAL = 1u << 16;
 constexpr uint32_t F_SOLID = 1u << 17;
 constexpr uint32_t F_SELF_BACKDROP = 1u << 18;
 constexpr uint32_t F_SUBPIXEL = 1u << 19;
+// bit 20: an axis-aligned mode-0 quad that maps atlas texels to pixels 1:1 at integer offsets (what renderText emits for every
+// glyph, figrender.nim:456-496): pixel (x, y) shows texel (x + tdx, y + tdy) -- DrawRec::ext / _pad hold tdx / tdy as int32.  The
+// bilinear fractions are 0 up to float noise (GL's fixed-point sampler snaps them to 0): the compositor fetches a lane's four
+// texels as one 16-byte run instead of sixteen gathers.
+constexpr uint32_t F_TEXEL_1TO1 = 1u << 20;
 
 // One BackendContext draw call, 128 bytes, read with wave-uniform (scalar) loads.
 struct alignas(16) DrawRec {

@@ -219,3 +219,67 @@ def make_glyph_scene(w: float, h: float, images, cols: int = 100, rows: int = 10
     out = Renders()
     out.setLayer(0, lst)
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The reference's own two benchmark workloads (the only scenes it times itself), restated node for node in float32.
+def make_non_clip_benchmark(w: float = 1200.0, h: float = 800.0, rows: int = 180, cols: int = 10) -> Renders:
+    """examples/windy_non_clip_benchmark.nim:82-108 `makeNonClipRenderTree`: a background and rows x cols rounded cells, all
+    roots, no clips (defaults :9-17: 180 x 10 cells in a 1200 x 800 window; 20 warm-up + 120 timed frames).  Most rows lie below
+    the window: the reference submits them all the same."""
+    w, h = f32(w), f32(h)
+    margin, gap = f32(18.0), f32(5.0)
+    cellW = f32(f32(f32(w - f32(margin * f32(2.0))) - f32(gap * f32(cols - 1))) / f32(cols))
+    cellH = f32(18.0)
+    lst = RenderList()
+    lst.addRoot(Fig(kind=FigKind.nkRectangle, screenBox=rect(0.0, 0.0, w, h), fill=rgba(248, 249, 251, 255)))
+    for row in range(rows):
+        y = f32(margin + f32(f32(row) * f32(cellH + gap)))
+        for col in range(cols):
+            x = f32(margin + f32(f32(col) * f32(cellW + gap)))
+            shade = (220 + (row * 3 + col * 7) % 35) & 255
+            accent = (80 + (row * 11 + col * 13) % 90) & 255
+            lst.addRoot(Fig(kind=FigKind.nkRectangle, screenBox=rect(x, y, cellW, cellH), corners=[4] * 4,
+                            fill=rgba(shade, (245 - (col % 5) * 5) & 255, accent, 255)))
+    out = Renders()
+    out.setLayer(0, lst)
+    return out
+
+
+def make_clip_mask_benchmark(kind: str, w: float = 1200.0, h: float = 800.0, rows: int = 180, cols: int = 6) -> Renders:
+    """examples/windy_clip_mask_benchmark.nim:147-186 `makeTableRenderTree` + `addCellContent` :104-145: a clipping viewport
+    (NfClipContent, radius 10) holding rows x cols cells, each clipping its three overflowing children with its own
+    NfClipContent (kind = "sub_clip": a second mask level per cell) or NfRectMaskContent (kind = "rect_mask": the analytic
+    rect mask).  Defaults :9-14: 180 x 6 cells, 1200 x 800, scrolled by 37 px."""
+    assert kind in ("sub_clip", "rect_mask")
+    w, h = f32(w), f32(h)
+    margin, gap = f32(22.0), f32(4.0)
+    vx, vy, vw, vh = margin, margin, f32(w - f32(margin * f32(2.0))), f32(h - f32(margin * f32(2.0)))
+    cellH = f32(22.0)
+    cellW = f32(f32(vw - f32(gap * f32(cols + 1))) / f32(cols))
+    scrollY = f32(37.0)
+    cell_flag = FigFlags.NfClipContent if kind == "sub_clip" else FigFlags.NfRectMaskContent
+    lst = RenderList()
+    lst.addRoot(Fig(kind=FigKind.nkRectangle, screenBox=rect(0.0, 0.0, w, h), fill=rgba(248, 249, 251, 255)))
+    viewport = lst.addRoot(Fig(kind=FigKind.nkRectangle, screenBox=rect(vx, vy, vw, vh), fill=rgba(232, 235, 240, 255),
+                               flags=FigFlags.NfClipContent, corners=[10] * 4))
+    for row in range(rows):
+        y = f32(f32(f32(vy + gap) + f32(f32(row) * f32(cellH + gap))) - scrollY)
+        for col in range(cols):
+            x = f32(f32(vx + gap) + f32(f32(col) * f32(cellW + gap)))
+            cell_color = rgba(255, 255, 255, 255) if (row + col) % 2 == 0 else rgba(242, 246, 250, 255)
+            cell = lst.addChild(viewport, Fig(kind=FigKind.nkRectangle, screenBox=rect(x, y, cellW, cellH), fill=cell_color,
+                                              flags=cell_flag, corners=[4] * 4))
+            tone = (42 + (row * 7 + col * 17) % 72) & 255
+            accent = rgba(36, (120 + (row * 5) % 80) & 255, 235, 255)
+            spill = rgba(tone, (170 - (col * 11) % 70) & 255, 220, 255)
+            muted = rgba((190 + (row + col) % 30) & 255, 210, 220, 255)
+            lst.addChild(cell, Fig(kind=FigKind.nkRectangle, fill=accent, corners=[2] * 4,
+                                   screenBox=rect(f32(x - f32(12.0)), f32(y + f32(4.0)), f32(cellW + f32(24.0)), 5.0)))
+            lst.addChild(cell, Fig(kind=FigKind.nkRectangle, fill=spill, corners=[3] * 4,
+                                   screenBox=rect(f32(x + f32(cellW * f32(0.38))), f32(y - f32(5.0)), f32(cellW * f32(0.74)), f32(cellH + f32(10.0)))))
+            lst.addChild(cell, Fig(kind=FigKind.nkRectangle, fill=muted, corners=[2] * 4,
+                                   screenBox=rect(f32(x + f32(7.0)), f32(f32(y + cellH) - f32(7.0)), f32(cellW - f32(14.0)), 8.0)))
+    out = Renders()
+    out.setLayer(0, lst)
+    return out

@@ -210,7 +210,7 @@ static float bezier_stroke_sd(float dist, float px, float py, v2 A, v2 B, v2 C, 
 static float median3(float a, float b, float c) { return maxf(minf(a, b), minf(maxf(a, b), c)); } /* atlas.frag:41-43 */
 
 /* ------------------------------------------------------------------ L4 state */
-#define FO_MAX_MASKS 16
+#define FO_MAX_MASKS 96 /* mask planes are allocated per level on demand; the reference has no limit (glcontext.nim:1886-1914) */
 #define FO_MAX_MATS 256
 #define FO_MAX_MIPS 14
 

@@ -241,6 +241,30 @@ def nested_clips(w=320.0, h=240.0) -> Renders:
     return out
 
 
+def deep_clips(w=400.0, h=300.0, depth=24) -> Renders:
+    """NfClipContent nested `depth` levels deep -- the reference draws one mask plane per level and has no limit
+    (glcontext.nim:1886-1914); the compositor keeps 16 levels in LDS and spills deeper ones to a global plane.  Every level
+    shrinks by a few pixels with alternating corner radii and carries a translucent band that overflows it; the deepest
+    clip holds a child that overflows all of them.  Alpha multiplies down the stack ((alpha * parent)^2 per level), so the
+    inner levels are drawn with opaque fills to stay visible."""
+    lst = RenderList()
+    lst.addRoot(Fig(kind=RECT, screenBox=rect(0, 0, w, h), fill=rgba(255, 255, 255, 255)))
+    parent = None
+    for k in range(depth):
+        inset = 4.0 * k
+        box = rect(10.25 + inset, 8.5 + inset * 0.7, w - 20.5 - 2 * inset, h - 17.0 - 1.4 * inset)
+        node = Fig(kind=RECT, screenBox=box, fill=rgba((40 * k) % 256, (200 - 7 * k) % 256, (90 + 23 * k) % 256, 255),
+                   corners=[(6 + 5 * k) % 30, (3 * k) % 25, 12, (9 + 2 * k) % 40], flags=FigFlags.NfClipContent)
+        idx = lst.addRoot(node) if parent is None else lst.addChild(parent, node)
+        lst.addChild(idx, Fig(kind=RECT, screenBox=rect(0, 20 + 9 * k, w, 6), fill=rgba(255, 255, 255, 140)))
+        parent = idx
+    lst.addChild(parent, Fig(kind=RECT, screenBox=rect(-20, h / 2 - 40, w + 40, 80), fill=rgba(220, 30, 60, 255), corners=[20] * 4))
+    lst.addRoot(Fig(kind=RECT, screenBox=rect(w - 90, h - 50, 80, 40), fill=rgba(30, 30, 30, 200), corners=[8] * 4))
+    out = Renders()
+    out.layers[0] = lst
+    return out
+
+
 def rect_mask_nested(w=320.0, h=240.0) -> Renders:
     """NfRectMaskContent with rounded corners; a second rect mask nested inside falls back to a real mask
     (glcontext.nim:1932-1943); plus a NfClipContent child inside a rect mask."""

@@ -88,3 +88,28 @@ def test_record_only_context_draws_nothing():
         ctx.read_pixels()
     with pytest.raises(FigdrawHipError):
         ctx.replay(1)
+
+
+def test_call_stream_of_deep_clips():
+    """24 nested NfClipContent nodes: no nesting limit on either side (the reference allocates one mask plane per level)"""
+    want, got = _streams(RS.deep_clips(400.0, 300.0, 24), 400, 300)
+    assert sum(1 for c in got if c[0] == "begin_mask") == 24 and sum(1 for c in got if c[0] == "pop_mask") == 24
+    _same(want, got)
+
+
+@pytest.mark.parametrize("which,nodes", [("non_clip", 1801), ("sub_clip", 4322), ("rect_mask", 4322)])
+def test_call_stream_of_the_reference_benchmark_workloads(which, nodes):
+    """examples/windy_non_clip_benchmark.nim (180 x 10 cells) and examples/windy_clip_mask_benchmark.nim (180 x 6 cells under a
+    clipping viewport, sub-clip / rect-mask per cell): node counts as the reference's own static asserts compute them
+    (1 + rows * cols; 2 + rows * cols * 4), one draw per node, one mask / rect mask per clipping node."""
+    from figdraw_amd.scenes import make_clip_mask_benchmark, make_non_clip_benchmark
+
+    sc = make_non_clip_benchmark() if which == "non_clip" else make_clip_mask_benchmark(which)
+    assert len(next(iter(sc.layers.values())).nodes) == nodes
+    want, got = _streams(sc, 1200, 800)
+    assert sum(1 for c in got if c[0] == "draw_rounded_rect_sdf") == nodes
+    if which == "sub_clip":
+        assert sum(1 for c in got if c[0] == "begin_mask") == 1081
+    if which == "rect_mask":
+        assert sum(1 for c in got if c[0] == "begin_rect_mask") == 1080 and sum(1 for c in got if c[0] == "begin_mask") == 1
+    _same(want, got)

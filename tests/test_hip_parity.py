@@ -428,6 +428,36 @@ def test_flippy_image_matches_oracle_and_reference_png():
     ctx.close()
 
 
+@pytest.mark.parametrize("which", ["non_clip", "sub_clip", "rect_mask"])
+def test_reference_benchmark_workloads_match_oracle(hip, which):
+    """The two workloads the reference benchmarks itself with, node for node: examples/windy_non_clip_benchmark.nim:82-108
+    (180 x 10 rounded cells, all roots) and examples/windy_clip_mask_benchmark.nim:147-186 (a clipping viewport of 180 x 6 cells,
+    each clipping its overflowing children with a second clip level or with the analytic rect mask) at their 1200 x 800."""
+    from figdraw_amd.scenes import make_clip_mask_benchmark, make_non_clip_benchmark
+
+    sc = make_non_clip_benchmark() if which == "non_clip" else make_clip_mask_benchmark(which)
+    w, h = 1200, 800
+    hip.render_frame(sc, w, h)
+    got = hip.read_pixels()
+    want = _oracle(lambda *_: sc, w, h)
+    mx, n0, n1 = diff_stats(got, want)
+    assert mx <= 1 and n0 <= 0.005 * w * h, (which, "vs oracle", mx, n0, n1)
+    assert len(np.unique(got.reshape(-1, 4), axis=0)) > 20  # (a real picture)
+
+
+@pytest.mark.parametrize("depth", [16, 17, 24, 40])
+def test_clip_nesting_beyond_the_lds_stack_matches_oracle(hip, depth):
+    """clips nested deeper than the 16 levels the compositor keeps in LDS (the reference has no limit: one mask plane per
+    level, glcontext.nim:1886-1914): levels 17.. live in a global plane sized for the frame's deepest nest"""
+    w, h = 400, 300
+    sc = RS.deep_clips(float(w), float(h), depth)
+    hip.render_frame(sc, w, h)
+    got = hip.read_pixels()
+    want = _oracle(lambda *_: sc, w, h)
+    mx, n0, n1 = diff_stats(got, want)
+    assert mx <= 1 and n0 <= 0.005 * w * h, (depth, "vs oracle", mx, n0, n1)
+
+
 def _sweep_scene(seed, mx=False):
     """the scene tools/fuzz_sweep.py builds for `seed` (sizes, node count, clips / blur / atlas all drawn from the seed)"""
     import os

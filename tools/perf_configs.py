@@ -3,7 +3,11 @@
 records), per-kernel times (fdh_profile: each launch's own timestamps), rate, and parity against the oracle (max LSB, pixels
 differing).  Prints one JSON document (-> profiles/<tag>_configs.json).
 
-usage: python3 tools/perf_configs.py [only]     only = 1..5 : run just that config (for a rocprofv3 --kernel-trace --stats pass per config)"""
+Configs 6 - 8 are the reference's OWN benchmark workloads (the only scenes it times itself): examples/windy_non_clip_benchmark.nim
+(180 x 10 cells, 1200 x 800) and examples/windy_clip_mask_benchmark.nim (clip + sub-clip / clip + rect-mask, 180 x 6 cells); for
+those the dynamic path (fdh_render_frame per frame, what the reference's loop times) is reported beside the replay figure.
+
+usage: python3 tools/perf_configs.py [only]     only = 1..8 : run just that config (for a rocprofv3 --kernel-trace --stats pass per config)"""
 import json
 import os
 import sys
@@ -16,7 +20,7 @@ import numpy as np
 
 import ref_scenes as RS
 from figdraw_amd.context import HipContext
-from figdraw_amd.scenes import load_glyph_fixture, make_glyph_scene, make_render_tree_100
+from figdraw_amd.scenes import load_glyph_fixture, make_clip_mask_benchmark, make_glyph_scene, make_non_clip_benchmark, make_render_tree_100
 from oracle import oracle as O
 
 only = int(sys.argv[1]) if len(sys.argv) > 1 else 0
@@ -41,6 +45,13 @@ def run(key, what, ctx, sc, w, h, n=100, oracle_kw=None, images=None):
                        "blur_v_all": round(1e3 * st.ms_blur_v, 1), "largest_blur_h": round(1e3 * st.ms_blur_big_h, 1),
                        "largest_blur_v": round(1e3 * st.ms_blur_big_v, 1)},
          "first_frame_host_ms": round(1e3 * first, 1)}
+    if key in ("config6", "config7", "config8"):  # the reference's loop: renderFrame per frame, 20 warm-up + 120 timed
+        cs = sc.to_c()
+        from figdraw_amd import call_stream as CS
+        P = CS.Player()
+        P.play_scenes([ctx], [cs], 20, w, h)
+        e["dynamic_us_per_frame"] = round(P.play_scenes([ctx], [cs], 120, w, h) / 120 * 1e6, 1)
+        e["dynamic_fps"] = round(1e6 / e["dynamic_us_per_frame"], 0)
     if not only:  # parity leg (the oracle takes seconds per frame; skipped under rocprofv3)
         orc = O.Oracle(threads=min(os.cpu_count() or 1, 16), **(oracle_kw or {}))
         for k in sorted(images or {}):
@@ -73,5 +84,16 @@ if only in (0, 4):
         ctx.put_image(k, used[k])
     run("config4", "T10k@4K: 10 000 glyph quads (5 000 coverage + 5 000 MSDF) over a 3-stop gradient, 3840x2160", ctx, sc, 3840, 2160,
         oracle_kw={"atlas_size": 1024}, images=used)
+    ctx.close()
+if only in (0, 6, 7, 8):
+    ctx = HipContext(device=0)
+    if only in (0, 6):
+        run("config6", "examples/windy_non_clip_benchmark.nim: 180 x 10 rounded cells, 1200x800 (1801 nodes, all roots)", ctx, make_non_clip_benchmark(), 1200, 800)
+    if only in (0, 7):
+        run("config7", "examples/windy_clip_mask_benchmark.nim, clip + sub-clip: clipping viewport, 180 x 6 cells each a second clip level (4322 nodes), 1200x800",
+            ctx, make_clip_mask_benchmark("sub_clip"), 1200, 800)
+    if only in (0, 8):
+        run("config8", "examples/windy_clip_mask_benchmark.nim, clip + rect-mask: the same table with NfRectMaskContent cells, 1200x800",
+            ctx, make_clip_mask_benchmark("rect_mask"), 1200, 800)
     ctx.close()
 print(json.dumps(out, indent=1))
