@@ -137,6 +137,8 @@ struct LaunchJob {
   std::vector<Phase> phases;
   std::vector<BlurJob> blurs;
   std::vector<const uint4*> mx_w_h, mx_w_v;  // per blur job: weight fragments of the matrix-pipe passes (in the frame block), or null
+  std::vector<char> blur_fused;              // per blur job: both passes run as ONE out-of-place kernel (full-frame nodes)
+  int n_fused = 0;
   int n_recs = 0;
   View dv;                 // typed views into the device frame block
   uint32_t* mask_spill = nullptr;  // clip levels beyond kMaskDepth, [level][strip][lane]; spill_stride dwords per level
@@ -274,6 +276,7 @@ class Context {
 
   int device_ = 0;
   uint32_t flags_ = 0;
+  int submit_slot_ = 0;   // this context's entry in the process-wide table of last submissions (Context::prepare)
   void* comm_ = nullptr;  // ncclComm_t (fdh_comm_init)
   int comm_rank_ = 0, comm_world_ = 1;
   bool comm_borrowed_ = false;
@@ -281,7 +284,7 @@ class Context {
   hipEvent_t ev_[2] = {};
   std::vector<hipEvent_t> ev_pool_;
   size_t ev_used_ = 0;
-  struct Span { int kind; hipEvent_t a, b; };  // kind: 0 bin, 1 composite main, 2 composite later, 3 blur h, 4 blur v
+  struct Span { int kind; hipEvent_t a, b; };  // kind: 0 bin, 1 composite main, 2 composite later, 3 blur h, 4 blur v, 5 / 6 largest node's h / v, 7 fused h + v
   std::vector<Span> spans_;
 
   // frame state
@@ -328,6 +331,7 @@ class Context {
   // device state (submission side)
   alignas(128) uint32_t* fb_ = nullptr;
   uint32_t *backdrop_ = nullptr, *blur_tmp_ = nullptr;
+  uint32_t* alt_ = nullptr;  // second frame surface: a fused full-frame blur renders out of place, phases alternate between fb_ and this
   uint32_t* dbg_snap_ = nullptr;
   void glyph_to_atlas(uint32_t* cur, uint32_t* nxt, int w, int h, int x, int y, uint32_t flags);
   DeviceBuf<float> glyph_lines_, glyph_acc_;

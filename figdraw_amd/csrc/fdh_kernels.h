@@ -62,6 +62,10 @@ void launch_bin(hipStream_t s, const BinParams& P);
 void launch_composite(hipStream_t s, const DrawRec* draws, const QuadExt* exts, CompositeParams P);
 void launch_blur_h(hipStream_t s, const BlurParams& P);
 void launch_blur_v(hipStream_t s, const BlurParams& P, const DrawRec* draws, const QuadExt* exts);
+// both passes of a full-frame node in one kernel, out of place (P.src -> P.dst, the fused mode-17 composite blended over P.src);
+// P.mx_w = the horizontal pass's weight fragments, w_v = the vertical pass's.  false: no instantiation for this filter width
+bool blur_fused_supported(int reach, int W, int pitch);
+bool launch_blur_fused(hipStream_t s, const BlurParams& P, const uint4* w_v, const DrawRec* draws, const QuadExt* exts);
 void launch_fill(hipStream_t s, uint32_t* p, uint32_t v, size_t n);
 // glyph images: LCD filter (pixie_raster.nim:12-43), one minifyBy2 step, copy into an atlas level
 // glyph outline (flattened to lines x0, y0, x1, y1) -> premultiplied white coverage; scratch: h x (w + 2) floats

@@ -2289,14 +2289,14 @@ __global__ __launch_bounds__(64, 2) void k_blur_mx(BlurParams P, const DrawRec* 
 //     resident at once (4K, radius 18: 120 strips x 10 segments of 7 blocks, 1.29x the H work).
 // Bytes: (1 + halo) x 4 A read (the x halo comes out of L2) + 4 A written, against 16 A for the two passes.
 constexpr int fx_vblocks(int nkv) { return ((nkv - 1) >> 1) + 1; }               // H-blocks one V block reads
-constexpr int fx_slots(int nkh, int nkv) { return 2 * nkh + 2 * fx_vblocks(nkv); }  // source k-steps (this block + the next) + the H ring
+constexpr int fx_slots(int nkh, int nkv) { return nkh + 2 * fx_vblocks(nkv); }  // source k-steps of one H-block + the H ring
 template <int NKH, int NKV>
 __global__ __launch_bounds__(64, 2) void k_blur_fx(BlurParams P, const uint4* __restrict__ w_v, const DrawRec* __restrict__ draws, const QuadExt* __restrict__ exts, int T) {
   constexpr int HB = fx_vblocks(NKV);  // V block b reads H-blocks b .. b + HB - 1
   constexpr int RV = 2 * HB;           // slots of the H ring
   extern __shared__ __attribute__((aligned(16))) uint32_t ring[];
-  uint32_t* const src_ring = ring;                   // 2 x NKH slots: [32 rows][16 px], 16-byte pieces XOR-swizzled (as the H pass)
-  uint32_t* const h_ring = ring + 2 * NKH * kMxSlot;  // RV slots: [16 rows][32 px] (as the V pass)
+  uint32_t* const src_ring = ring;               // NKH slots: [32 rows][16 px], 16-byte pieces XOR-swizzled (as the H pass)
+  uint32_t* const h_ring = ring + NKH * kMxSlot;  // RV slots: [16 rows][32 px] (as the V pass)
   const int n_strips = (P.x1 - (P.x0 & ~31) + 31) >> 5;
   const int y_first = P.y0 & ~31;
   const int n_seg = (P.y1 - y_first + 32 * T - 1) / (32 * T);
@@ -2312,7 +2312,9 @@ __global__ __launch_bounds__(64, 2) void k_blur_fx(BlurParams P, const uint4* __
   const int w0a = (xb - reach) & ~3;          // horizontal window start, moved back to a 16-byte boundary (mx_delta)
   const uint32_t ring_lds = (uint32_t)reinterpret_cast<uintptr_t>(ring);
 
-  // LDS-DMA of the NKH source k-steps of H-block i into half (i & 1) of the source ring; returns the instructions issued
+  // LDS-DMA of the NKH source k-steps of H-block i into the source slots (single-buffered: issued as soon as the horizontal
+  // product of block i - 1 has read them, in flight under the vertical product and the stores; 22 KB of LDS per wave instead
+  // of 32 lets seven waves share a CU instead of five); returns the instructions issued
   auto issue_block = [&](int i) -> int {
     const int r = lane >> 2, c = lane & 3;
     const uint32_t* rowp[2];
@@ -2326,7 +2328,7 @@ __global__ __launch_bounds__(64, 2) void k_blur_fx(BlurParams P, const uint4* __
     int n = 0;
 #pragma unroll
     for (int s = 0; s < NKH; s++) {
-      const uint32_t slot = ring_lds + (uint32_t)((i & 1) * NKH + s) * (kMxSlot * 4u);
+      const uint32_t slot = ring_lds + (uint32_t)s * (kMxSlot * 4u);
       const int xk = w0a + 16 * s;
       if (xk >= 0 && xk + 16 <= P.W) {  // wave-uniform
         lds_dma16(rowp[0] + xk, slot);
@@ -2375,12 +2377,13 @@ __global__ __launch_bounds__(64, 2) void k_blur_fx(BlurParams P, const uint4* __
   if (P.fuse_draw >= 0) { const DrawRec* qd = draws + P.fuse_draw; core_x0 = qd->ix0; core_y0 = qd->iy0; core_x1 = qd->ix1; core_y1 = qd->iy1; }
 
   const int n_hblocks = n_blocks + HB - 1;
+  int stores_behind = 0;  // store instructions issued after this block's DMA batch (vmcnt retires in issue order: they may stay out)
 #pragma unroll 1
   for (int i = 0; i < n_hblocks; i++) {
-    // the next H-block's texels start their way into the other half of the source ring; this block's have landed
-    int batch = 0;
-    if (i + 1 < n_hblocks) batch = issue_block(i + 1);
-    wait_for_all_but(batch);
+    // this H-block's texels have landed -- its batch is older than the stores of the V block issued after it, which are NOT
+    // waited for (they would cost a store round trip per iteration)
+    wait_for_all_but(stores_behind);
+    stores_behind = 0;
     // ---- horizontal product of H-block i: rows ws + 32 i .. + 31, columns xb .. xb + 31
     {
       f32x16 acc[4];
@@ -2390,7 +2393,7 @@ __global__ __launch_bounds__(64, 2) void k_blur_fx(BlurParams P, const uint4* __
         for (int e = 0; e < 16; e++) acc[c][e] = 0.0f;
 #pragma unroll
       for (int m = 0; m < NKH; m++) {
-        const uint32_t* slot = src_ring + ((i & 1) * NKH + m) * kMxSlot;
+        const uint32_t* slot = src_ring + m * kMxSlot;
         const uint4* row4 = reinterpret_cast<const uint4*>(slot + j * 16);
         const int sw = (j >> 2) & 3;
         const uint4 lo4 = row4[(2 * g) ^ sw], hi4 = row4[(2 * g + 1) ^ sw];
@@ -2415,6 +2418,9 @@ __global__ __launch_bounds__(64, 2) void k_blur_fx(BlurParams P, const uint4* __
       }
     }
     __builtin_amdgcn_wave_barrier();
+    // the source slots are read: the next H-block's texels start their way in, under the vertical product below
+    __builtin_amdgcn_sched_barrier(0);
+    if (i + 1 < n_hblocks) issue_block(i + 1);
     const int b = i - (HB - 1);  // the V block whose last H-block this was
     if (b < 0) continue;
     // ---- vertical product of block b: rows ys + 32 b .. + 31 from k-steps 2 b .. 2 b + NKV - 1 of the H ring
@@ -2468,9 +2474,10 @@ __global__ __launch_bounds__(64, 2) void k_blur_fx(BlurParams P, const uint4* __
         replace_all = __all((conj >> 24) == 255u);
       }
       if (!replace_all) {
-        // (two source slots of the half this iteration consumed: nothing is in flight into them until the next iteration's DMA)
-        uint32_t* const sc0 = src_ring + ((i & 1) * NKH + 0) * kMxSlot;
-        uint32_t* const sc1 = src_ring + ((i & 1) * NKH + 1) * kMxSlot;
+        // (the two H-ring slots this block's product read first: block b + 1 starts two k-steps further down, and the next
+        // H-block overwrites them only in the next iteration)
+        uint32_t* const sc0 = h_ring + ((2 * b) % RV) * kMxSlot;
+        uint32_t* const sc1 = h_ring + ((2 * b + 1) % RV) * kMxSlot;
         const uint32_t valid = pmask;
         if (!core) {
 #pragma unroll
@@ -2542,10 +2549,12 @@ __global__ __launch_bounds__(64, 2) void k_blur_fx(BlurParams P, const uint4* __
 #pragma unroll
         for (int rr = 0; rr < 16; rr++)
           *reinterpret_cast<uint32_t*>(base + (size_t)((rr & 3) + 8 * (rr >> 2)) * P.pitch * 4u + lane_off) = pend[rr];
+        stores_behind = 16;  // exactly sixteen store instructions
       } else if (__any(pmask != 0u)) {
 #pragma unroll
         for (int rr = 0; rr < 16; rr++)
           if ((pmask >> rr) & 1u) *reinterpret_cast<uint32_t*>(base + (size_t)((rr & 3) + 8 * (rr >> 2)) * P.pitch * 4u + lane_off) = pend[rr];
+        // (an unknown number: the next wait drains everything)
       }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -2826,6 +2835,37 @@ template <bool kV> static bool launch_blur_mx_nk(hipStream_t s, const BlurParams
     case 11: launch_blur_mx<11, kV>(s, P, draws, exts); return true;  // reach 66 = the widest filter (radius clamp 64)
     default: return false;
   }
+}
+// Both passes in one kernel (k_blur_fx): instantiated for the filter widths whose two rings fit five waves' worth of LDS per CU
+// (NKH <= 6: tap reach <= 22, blur radius <= ~21); wider filters keep the two-pass route.
+template <int NKH, int NKV> static void launch_blur_fx(hipStream_t s, const BlurParams& P, const uint4* w_v, const DrawRec* draws, const QuadExt* exts) {
+  constexpr size_t lds = (size_t)fx_slots(NKH, NKV) * kMxSlot * sizeof(uint32_t);
+  static const int per_cu = [] {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_blur_fx<NKH, NKV>, 64, lds) != hipSuccess || n <= 0) n = std::min<int>(8, (int)(160 * 1024 / lds));
+    return n;
+  }();
+  static const int forced = [] { const char* e = std::getenv("FDH_FX_T"); return e ? std::atoi(e) : 0; }();  // experiments
+  const int n_strips = (P.x1 - (P.x0 & ~31) + 31) >> 5, blocks = (P.y1 - (P.y0 & ~31) + 31) >> 5;
+  const long long slots = 256LL * std::min(per_cu, 8);
+  int t = 2;  // (a one-block segment would filter three H-blocks per output block)
+  while (t < 64 && (long long)n_strips * ((blocks + t - 1) / t) > slots) t++;
+  if (forced) t = forced;
+  const int total = n_strips * ((blocks + t - 1) / t);
+  FDH_LAUNCH((k_blur_fx<NKH, NKV>), dim3(8 * ((total + 7) / 8)), dim3(64), lds, s, P, w_v, draws, exts, t);
+}
+bool blur_fused_supported(int reach, int W, int pitch) {
+  const int nkh = mx_nk(reach, false), nkv = mx_nk(reach, true);
+  return FDH_BLUR_MX && (pitch & 3) == 0 && W >= 4 && nkh >= 3 && nkh <= 6 && (nkh == nkv || nkh == nkv + 1);
+}
+bool launch_blur_fused(hipStream_t s, const BlurParams& P, const uint4* w_v, const DrawRec* draws, const QuadExt* exts) {
+  if (P.x1 <= P.x0 || P.y1 <= P.y0) return true;
+  if (!P.mx_w || !w_v || !blur_fused_supported(P.taps.reach, P.W, P.pitch) || (reinterpret_cast<uintptr_t>(P.src) & 15)) return false;
+  const int nkh = mx_nk(P.taps.reach, false), nkv = mx_nk(P.taps.reach, true);
+#define FDH_FX(a, b) if (nkh == a && nkv == b) { launch_blur_fx<a, b>(s, P, w_v, draws, exts); return true; }
+  FDH_FX(3, 3) FDH_FX(4, 3) FDH_FX(4, 4) FDH_FX(5, 4) FDH_FX(5, 5) FDH_FX(6, 5) FDH_FX(6, 6)
+#undef FDH_FX
+  return false;
 }
 void launch_blur_h(hipStream_t s, const BlurParams& P) {
   if (P.x1 <= P.x0 || P.y1 <= P.y0) return;

@@ -366,6 +366,12 @@ typedef struct {
    * flops they amount to: 25 / 36 / 71 / 28 per fragment (other modes priced as ClipAA), + 30 elliptical, + 16 blend + re-quantise */
   int64_t fragments_main_by_mode[4], fragments_main_elliptical, fragments_main_other;
   int64_t flops_composite_main;
+  /* a full-frame blur node whose two passes ran as ONE out-of-place kernel (k_blur_fx): fdh_profile time, and the bytes THAT
+   * kernel must move (the region read once + written once; bytes_blur / bytes_algorithmic keep SURVEY.md 8(d)'s two-pass
+   * formula so that frames stay comparable); bytes_frame_implementation: bytes_algorithmic with such nodes priced at what
+   * this implementation moves */
+  float ms_blur_fused, _reserved2;
+  int64_t bytes_blur_fused, bytes_frame_implementation;
 } FdhFrameStats;
 /* Run `times` more frames and fill the per-kernel averages.  Each launch is stamped with its own start / end events
  * (hipExtLaunchKernelGGL): kernel execution time as rocprofv3 --kernel-trace reports it, no launch gaps in it. */

@@ -428,6 +428,67 @@ def test_flippy_image_matches_oracle_and_reference_png():
     ctx.close()
 
 
+def test_fused_full_frame_blur_equals_the_two_pass_route():
+    """A blur node covering the whole frame runs both passes as ONE out-of-place kernel (k_blur_fx), the surfaces alternating
+    between phases.  Same sums in the same grouping, the intermediate rounded to RGBA8 as the H pass stores it: the frames must
+    equal the two-pass route's (FDH_BLUR_FUSED=0, a child process) bit for bit -- radii across the instantiated filter widths,
+    frame sizes that are not multiples of 32, a translucent clear colour (the fused composite has to blend), two full-frame
+    nodes in one frame (the surfaces flip twice), row stripes -- and stay within the suite's bar of the oracle."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+
+    from oracle import oracle as O
+
+    root, here = os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__))
+    cases = [("r18", 1280, 720, 18.0, (1.0, 1.0, 1.0, 1.0), None, 1), ("r4_odd", 1000, 527, 4.0, (1.0, 1.0, 1.0, 1.0), None, 1),
+             ("r12_glass", 644, 388, 12.0, (0.2, 0.3, 0.4, 0.5), None, 1), ("r21", 960, 540, 21.0, (1.0, 1.0, 1.0, 1.0), None, 1),
+             ("r9_twice", 800, 450, 9.0, (1.0, 1.0, 1.0, 1.0), None, 2), ("r18_stripe", 1280, 720, 18.0, (1.0, 1.0, 1.0, 1.0), (184, 368), 1)]
+    code = (
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "from test_hip_parity import _full_frame_blur_scene\n"
+        "from figdraw_amd.context import HipContext\n"
+        "out = {}\n"
+        "for name, w, h, radius, clear, stripe, nblur in %r:\n"
+        "    ctx = HipContext(device=0)\n"
+        "    if stripe: ctx.set_stripe(*stripe)\n"
+        "    ctx.render_frame(_full_frame_blur_scene(w, h, radius, nblur), w, h, color=clear)\n"
+        "    out[name] = ctx.read_pixels(); ctx.close()\n"
+        "np.savez(sys.argv[1], **out)\n"
+    ) % (root, here, cases)
+    with tempfile.TemporaryDirectory() as td:
+        res = {}
+        # (FDH_FORCE_BLUR_PATH=3: the reference route is the matrix-pipe pair at every size -- the small-region passes sum in
+        # another order and differ from either at rounding ties)
+        for tag, env in (("fused", {"FDH_FORCE_BLUR_PATH": "3"}), ("two_pass", {"FDH_FORCE_BLUR_PATH": "3", "FDH_BLUR_FUSED": "0"})):
+            path = os.path.join(td, tag + ".npz")
+            subprocess.check_call([sys.executable, "-c", code, path], env={**os.environ, **env})
+            res[tag] = dict(np.load(path))
+    for name, w, h, radius, clear, stripe, nblur in cases:
+        a, b = res["fused"][name], res["two_pass"][name]
+        rows = slice(*stripe) if stripe else slice(0, h)
+        assert np.array_equal(a[rows], b[rows]), (name, int((a[rows] != b[rows]).any(axis=2).sum()))
+        orc = O.Oracle(threads=8)
+        orc.render_frame(_full_frame_blur_scene(w, h, radius, nblur), w, h, color=clear)
+        mx, n0, n1 = diff_stats(a[rows], orc.read_pixels()[rows])
+        assert mx <= 1 and n0 <= 0.005 * w * h, (name, "vs oracle", mx, n0, n1)
+
+
+def _full_frame_blur_scene(w, h, radius, nblur=1):
+    """the bench scene's recipe at any size: shadowed rects, `nblur` backdrop-blur nodes covering the whole frame with more rects
+    between and after them"""
+    from figdraw_amd.scene import Fig, FigKind, rect, rgba
+
+    sc = RS.random_scene(77, float(w), float(h), n=50, clips=False, blur=False)
+    lst = next(iter(sc.layers.values()))
+    for k in range(nblur):
+        lst.addRoot(Fig(kind=FigKind.nkBackdropBlur, screenBox=rect(0, 0, w, h), fill=rgba(255, 255, 255, 30 * k), blur=radius))
+        lst.addRoot(Fig(kind=FigKind.nkRectangle, screenBox=rect(w * 0.2 + 40 * k, h * 0.3, w * 0.4, h * 0.25), fill=rgba(250, 200, 40, 160), corners=[18] * 4))
+    return sc
+
+
 @pytest.mark.parametrize("which", ["non_clip", "sub_clip", "rect_mask"])
 def test_reference_benchmark_workloads_match_oracle(hip, which):
     """The two workloads the reference benchmarks itself with, node for node: examples/windy_non_clip_benchmark.nim:82-108

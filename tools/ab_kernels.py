@@ -13,7 +13,7 @@ from figdraw_amd.scenes import make_render_tree_100
 w, h = 3840, 2160
 c = HipContext(device=0); c.render_frame(make_render_tree_100(w, h, frame=0, full_frame_blur=True), w, h); c.replay(30); c.profile(60); s = c.frame_stats()
 c.replay(200); t = c.frame_stats().ms_total
-print("%%-8s composite_main %%6.2f  composite_all %%6.2f  blur_h %%6.2f  blur_v %%6.2f  bin %%5.2f  frame %%6.2f us" %% (sys.argv[1], 1e3 * s.ms_composite_main, 1e3 * s.ms_composite, 1e3 * s.ms_blur_h, 1e3 * s.ms_blur_v, 1e3 * s.ms_bin, 1e3 * t))
+print("%%-8s composite_main %%6.2f  composite_all %%6.2f  blur_h %%6.2f  blur_v %%6.2f  blur_fused %%6.2f  bin %%5.2f  frame %%6.2f us" %% (sys.argv[1], 1e3 * s.ms_composite_main, 1e3 * s.ms_composite, 1e3 * s.ms_blur_h, 1e3 * s.ms_blur_v, 1e3 * s.ms_blur_fused, 1e3 * s.ms_bin, 1e3 * t))
 """ % ROOT
 args = sys.argv[1:]
 reps = int(args.pop(0)) if args and args[0].isdigit() else 2
