@@ -410,9 +410,19 @@ def main():
     ft = ctx.replay_timed(min(args.steps, 120))
     frame_dist = {"n": int(len(ft)), "min": round(float(ft.min()), 4), "p50": round(float(np.percentile(ft, 50)), 4),
                   "p95": round(float(np.percentile(ft, 95)), 4), "max": round(float(ft.max()), 4)}
-    # per-kernel durations, HIP events on the context's stream stamped by each launch itself (same frames, same records)
+    # per-kernel durations, HIP events on the context's stream stamped by each launch itself (same frames, same records); the
+    # full-frame blur node on both of its routes (same pixels): two passes (what frames in flight use) and the fused kernel
+    ctx.set_blur_route(1)
+    ctx.render_frame(scene, w, h)
+    ctx.replay(5)
+    ctx.profile(min(args.steps, 50))
+    st_fx = ctx.frame_stats()
+    ctx.set_blur_route(0)
+    ctx.render_frame(scene, w, h)
+    ctx.replay(5)
     ctx.profile(min(args.steps, 50))
     st = ctx.frame_stats()
+    ctx.set_blur_route(-1)
 
     dynamic = None
     if rank == 0:
@@ -582,6 +592,13 @@ def main():
                                         "two f16 halves (22 bits), every product exact; <= 1 LSB from the f32 FIR",
                              bytes_note="H: region + halo rows read and written; V: those rows read, the region written; the fused composite reads the "
                                         "surface only where it has to blend (the cleared opaque surface of this frame: nowhere but the quad's border blocks)")
+    if roofline_blur is not None and st_fx.ms_blur_fused > 0:
+        bfx = int(st_fx.bytes_blur_fused)
+        roofline_blur["fused_route"] = dict(hbm(bfx, st_fx.ms_blur_fused), ms=round(st_fx.ms_blur_fused, 4), algorithmic_bytes=bfx,
+                                            kernel="k_blur_fx<NKH, NKV>: both passes in one out-of-place kernel, the RGBA8 intermediate in LDS",
+                                            traffic=pmc.get("k_blur_fx", {}).get("hbm_bytes"),
+                                            note="the route a frame takes when no other context has frames in flight (fdh_set_blur_route); its bytes are "
+                                                 "what IT must move (region read once + written once), half the two-pass figure; same pixels bit for bit")
     frame_gbs = st.bytes_algorithmic / (ms_step * 1e-3) / 1e9
     single_dyn_ms = 1e3 * sd_elapsed / args.steps
     single_gbs = st.bytes_algorithmic / (single_dyn_ms * 1e-3) / 1e9

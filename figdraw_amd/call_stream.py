@@ -89,9 +89,11 @@ def build_player(force: bool = False) -> str:
     if not force and os.path.exists(PLAYER_LIB) and os.path.getmtime(PLAYER_LIB) >= max(os.path.getmtime(PLAYER_SRC), os.path.getmtime(context.LIB_PATH)):
         return PLAYER_LIB
     os.makedirs(os.path.dirname(PLAYER_LIB), exist_ok=True)
+    tmp = f"{PLAYER_LIB}.{os.getpid()}.tmp"  # (several ranks may find it stale at once: each links its own file, the rename is atomic)
     subprocess.check_call(["gcc", "-std=c99", "-O2", "-Wall", "-Wextra", "-Werror", "-pedantic", "-D_POSIX_C_SOURCE=199309L", "-fPIC", "-shared",
-                           "-I", os.path.join(ROOT, "include"), PLAYER_SRC, "-o", PLAYER_LIB,
+                           "-I", os.path.join(ROOT, "include"), PLAYER_SRC, "-o", tmp,
                            "-L", _HERE, "-l:libfigdraw_hip.so", "-Wl,-rpath," + _HERE])
+    os.replace(tmp, PLAYER_LIB)
     return PLAYER_LIB
 
 

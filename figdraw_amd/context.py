@@ -126,6 +126,7 @@ def load():
     L.fdh_set_ui_scale.argtypes = [vp, C.c_float]
     L.fdh_render_frame.argtypes = [vp, vp, C.c_float, C.c_float, C.c_int, _F4]
     L.fdh_set_stripe.argtypes = [vp, C.c_int, C.c_int]
+    L.fdh_set_blur_route.argtypes = [vp, C.c_int]
     L.fdh_stripe_rows.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.fdh_comm_unique_id.argtypes = [C.c_char_p]
     L.fdh_comm_init.argtypes = [vp, C.c_char_p, C.c_int, C.c_int]
@@ -444,6 +445,10 @@ class HipContext:
     # ---- multi-GPU / measurement
     def set_stripe(self, y0: int, y1: int):
         self._ck(self.L.fdh_set_stripe(self.h, int(y0), int(y1)))
+
+    def set_blur_route(self, route: int):
+        """full-frame blur nodes: 1 fused kernel, 0 two passes, -1 decided per frame (same pixels either way)"""
+        self._ck(self.L.fdh_set_blur_route(self.h, int(route)))
 
     @staticmethod
     def comm_unique_id() -> bytes:

@@ -255,6 +255,7 @@ int fdh_comm_share(FdhContext* c, FdhContext* owner) { return guard([&] { C(c)->
 int fdh_comm_destroy(FdhContext* c) { return guard([&] { C(c)->comm_destroy(); }); }
 int fdh_gather_stripes(FdhContext* c, int dst_rank, void* dst_image) { return guard([&] { C(c)->gather_stripes(dst_rank, dst_image); }); }
 int fdh_gather_frames(FdhContext* c, int dst_rank, void* const* dst_images) { return guard([&] { C(c)->gather_frames(dst_rank, dst_images); }); }
+int fdh_set_blur_route(FdhContext* c, int route) { return guard([&] { C(c)->set_blur_route(route); }); }
 int fdh_set_stripe(FdhContext* c, int y0, int y1) { return guard([&] { C(c)->set_stripe(y0, y1); }); }
 int fdh_replay(FdhContext* c, int times) { return guard([&] { C(c)->replay(times); }); }
 int fdh_replay_async(FdhContext* c, int times) { return guard([&] { C(c)->replay_async(times); }); }

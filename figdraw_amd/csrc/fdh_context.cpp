@@ -1385,10 +1385,11 @@ void Context::prepare(LaunchJob& J) {
     // frames in flight on the GPU, where total work is what counts, the two-pass route is 3 % faster.  So: fused when no other
     // context of this process has submitted a frame in the last millisecond (FDH_BLUR_FUSED=1 always, =0 never).
     static const int fx_env = [] { const char* e = std::getenv("FDH_BLUR_FUSED"); return e ? (std::atoi(e) != 0 ? 1 : 0) : -1; }();
-    bool fx_on = fx_env != 0;
+    const int route = blur_route_ >= 0 ? blur_route_ : fx_env;
+    bool fx_on = route != 0;
     {
       const int64_t now = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
-      if (fx_env < 0)
+      if (route < 0)
         for (int k = 0; k < kSubmitSlots; k++)
           if (k != submit_slot_ && now - g_last_submit_ns[k].load(std::memory_order_relaxed) < 1000000) { fx_on = false; break; }
       g_last_submit_ns[submit_slot_].store(now, std::memory_order_relaxed);

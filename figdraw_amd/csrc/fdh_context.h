@@ -245,6 +245,7 @@ class Context {
 
   // multi-GPU / measurement
   void set_stripe(int y0, int y1) { drain(); stripe_y0_ = y0; stripe_y1_ = y1; }
+  void set_blur_route(int route) { blur_route_ = route < 0 ? -1 : (route ? 1 : 0); }
   void replay(int times);
   void replay_timed(int times, float* ms_out);
   void replay_async(int times);
@@ -276,6 +277,7 @@ class Context {
 
   int device_ = 0;
   uint32_t flags_ = 0;
+  int blur_route_ = -1;   // fdh_set_blur_route: -1 per-frame decision, 0 two passes, 1 fused
   int submit_slot_ = 0;   // this context's entry in the process-wide table of last submissions (Context::prepare)
   void* comm_ = nullptr;  // ncclComm_t (fdh_comm_init)
   int comm_rank_ = 0, comm_world_ = 1;

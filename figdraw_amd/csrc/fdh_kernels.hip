@@ -845,16 +845,22 @@ __device__ unsigned int g_edge_bad[4096 * 8];
 #ifndef FDH_FAST_WAVES
 #define FDH_FAST_WAVES 5
 #endif
+#ifndef FDH_ATLAS_WAVES
+#define FDH_ATLAS_WAVES 5  // waves per SIMD of the atlas build <2>
+#endif
 #ifndef FDH_UNIFORM_WAVES
 #define FDH_UNIFORM_WAVES 6  // waves per SIMD of the no-clip build <4>: 80 VGPRs, no spills
 #endif
+// the strip's texel window in LDS (builds with the atlas path): up to kWinCols x kWinRows texels, rows kWinStride dwords apart
+// (a multiple of four, for the 16-byte stores, that is not a multiple of 32: rows start in different banks)
+constexpr int kWinCols = 64, kWinRows = 12, kWinStride = 68;
 // kPaths: bit 0 = the one-pixel-slot path (rotated / skewed quads, bezier strokes, rect-mask setup, minified images),
 // bit 1 = the 4-wide atlas path (axis-aligned glyphs, images at >= 1:1, MSDF).  0: SDF draws, clips and rect masks only.
 // kFull: the launch that starts a frame -- every bin of the grid, from the clear colour (nothing is loaded), bins taken longest
 // list first, with the sort for the next frame riding along.  A symbol of its own, so that the dominant launch of a frame is a
 // row of its own in a rocprofv3 kernel summary (the later phases' launches cover a blur node's footprint and take microseconds).
 template <int kPaths, bool kFull>
-__global__ __launch_bounds__(64, (kPaths & 1) ? 4 : kPaths == 4 ? FDH_UNIFORM_WAVES : FDH_FAST_WAVES) void k_composite_tiles(
+__global__ __launch_bounds__(64, (kPaths & 1) ? 4 : kPaths == 4 ? FDH_UNIFORM_WAVES : (kPaths & 2) ? FDH_ATLAS_WAVES : FDH_FAST_WAVES) void k_composite_tiles(
     // the sixteen dwords a wave needs before anything else, as leading scalar arguments: with kernel-argument preloading
     // (-amdgpu-kernarg-preload-count, csrc/Makefile) they arrive in SGPRs with the wave instead of through a first s_load
     const int* __restrict__ a_order, int* __restrict__ a_order_next, const uint32_t* __restrict__ a_counts, const uint2* __restrict__ a_lists,
@@ -1196,20 +1202,60 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? 4 : kPaths == 4 ? FDH_UNIFORM_WA
         if (mode == 0u && (om & F_SUBPIXEL)) ushift = r.aux * frcp(__builtin_fmaxf(fS, 1.0f));  // wave-uniform
         float sK[4], uK[4], axK[4];
         uint32_t q00[4], q01[4], q10[4], q11[4];
-        // texel addresses as 32-bit byte offsets from the (scalar) level pointer: one shift and two adds per column instead of
-        // sign extensions and 64-bit adds (a level is at most 16384^2 x 4 bytes = 1 GiB)
-        const char* __restrict__ texb = reinterpret_cast<const char*>(tex);
-        const uint32_t row0 = ((uint32_t)y0 * (uint32_t)S) << 2, row1 = ((uint32_t)y1 * (uint32_t)S) << 2;
-        auto texel = [&](uint32_t off) __attribute__((always_inline)) { return *reinterpret_cast<const uint32_t*>(texb + off); };
+        int fxi[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
           sK[k] = (cx0 + (float)k - r.ox) * r.inv_w;
           uK[k] = uax + (utx - uax) * sK[k];
           const float tx_ = (uK[k] - ushift) * fS - 0.5f, fx = __builtin_floorf(tx_);
           axK[k] = tx_ - fx;
-          const uint32_t x0 = (uint32_t)((int)fx & msk), x1 = (x0 + 1u) & (uint32_t)msk;
-          q00[k] = texel(row0 + (x0 << 2)); q01[k] = texel(row0 + (x1 << 2));
-          q10[k] = texel(row1 + (x0 << 2)); q11[k] = texel(row1 + (x1 << 2));
+          fxi[k] = (int)fx;
+        }
+        const int fyi = (int)fy;
+        // The strip's texel window.  The map pixel -> texel is linear, so the texel columns / rows the strip's 32 x 8 pixels touch
+        // lie between those of its first and last pixel (+ 1 for the second bilinear tap).  When the window is small -- a glyph or
+        // an MSDF image drawn at >= 0.5x: at most 64 x 12 texels -- the wave stages it in LDS with 16-byte runs (two or three
+        // loads per lane) and every pixel takes its four taps from there: sixteen dword gathers per lane and draw kept the CU's
+        // one texture-address unit busier than the arithmetic (config 4: a wave lived 13 us for 1.6 us of issue).
+        const int wxa = __builtin_amdgcn_readlane(fxi[0], 0), wxb = __builtin_amdgcn_readlane(fxi[3], 7);
+        const int wya = __builtin_amdgcn_readlane(fyi, 0), wyb = __builtin_amdgcn_readlane(fyi, 56);
+        const int wx0 = min(wxa, wxb), wx1 = max(wxa, wxb) + 1, wy0 = min(wya, wyb), wy1 = max(wya, wyb) + 1;  // inclusive texel bounds
+        const bool windowed = wx1 - wx0 < kWinCols && wy1 - wy0 < kWinRows && wx0 >= 0 && wy0 >= 0 && wx1 + 3 < S && wy1 < S;  // wave-uniform
+        if (windowed) {
+          uint32_t* const win = composite_lds + (P.has_masks ? kMaskDepth * 64 : 256);
+          {  // 16 lanes x 16 bytes per window row, four rows per pass; lanes past the window repeat its last run / row (no branch)
+            const int lr = lane >> 4, lc = (lane & 15) * 4;
+            const int cc = min(lc, (wx1 - wx0) & ~3);
+            struct __attribute__((packed, aligned(4))) Run4 { uint32_t v[4]; };
+#pragma unroll
+            for (int pass = 0; pass < kWinRows / 4; pass++) {
+              const int row = min(pass * 4 + lr, wy1 - wy0);
+              const Run4 run = *reinterpret_cast<const Run4*>(tex + (((uint32_t)(wy0 + row)) << (uint32_t)__builtin_ctz((uint32_t)S)) + (uint32_t)(wx0 + cc));
+              uint4 q4 = {run.v[0], run.v[1], run.v[2], run.v[3]};
+              *reinterpret_cast<uint4*>(win + (pass * 4 + lr) * kWinStride + lc) = q4;
+            }
+          }
+          __builtin_amdgcn_wave_barrier();
+          const int ly = min(max(fyi - wy0, 0), kWinRows - 2);
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            const int lx = min(max(fxi[k] - wx0, 0), kWinCols - 2);
+            const uint32_t* w0 = win + ly * kWinStride + lx;
+            q00[k] = w0[0]; q01[k] = w0[1]; q10[k] = w0[kWinStride]; q11[k] = w0[kWinStride + 1];
+          }
+          __builtin_amdgcn_wave_barrier();  // (the next draw of this strip overwrites the window)
+        } else {
+          // texel addresses as 32-bit byte offsets from the (scalar) level pointer: one shift and two adds per column instead of
+          // sign extensions and 64-bit adds (a level is at most 16384^2 x 4 bytes = 1 GiB)
+          const char* __restrict__ texb = reinterpret_cast<const char*>(tex);
+          const uint32_t row0 = ((uint32_t)y0 * (uint32_t)S) << 2, row1 = ((uint32_t)y1 * (uint32_t)S) << 2;
+          auto texel = [&](uint32_t off) __attribute__((always_inline)) { return *reinterpret_cast<const uint32_t*>(texb + off); };
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            const uint32_t x0 = (uint32_t)(fxi[k] & msk), x1 = (x0 + 1u) & (uint32_t)msk;
+            q00[k] = texel(row0 + (x0 << 2)); q01[k] = texel(row0 + (x1 << 2));
+            q10[k] = texel(row1 + (x0 << 2)); q11[k] = texel(row1 + (x1 << 2));
+          }
         }
         const bool solid = (om & F_SOLID) != 0u;
         const bool masked = mask_depth > 0 || rmask_on;
@@ -2408,6 +2454,11 @@ __global__ __launch_bounds__(64, 2) void k_blur_fx(BlurParams P, const uint4* __
         acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f2_, hlo[m], acc[2], 0, 0, 0);
         acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f3, hlo[m], acc[3], 0, 0, 0);
       }
+      // the source slots are read (every MFMA above has its operands): the next H-block's texels start their way in, under the
+      // rounding below and the whole vertical product
+      __builtin_amdgcn_sched_barrier(0);
+      if (i + 1 < n_hblocks) issue_block(i + 1);
+      __builtin_amdgcn_sched_barrier(0);
       // RGBA8 as the H pass stores it (the reference's intermediate texture), into H-ring slots 2 (i % HB), + 1: lane = column,
       // register rr = row (rr & 3) + 8 (rr >> 2) + 4 g of the block
       uint32_t* const hs = h_ring + (2 * (i % HB)) * kMxSlot;
@@ -2418,9 +2469,6 @@ __global__ __launch_bounds__(64, 2) void k_blur_fx(BlurParams P, const uint4* __
       }
     }
     __builtin_amdgcn_wave_barrier();
-    // the source slots are read: the next H-block's texels start their way in, under the vertical product below
-    __builtin_amdgcn_sched_barrier(0);
-    if (i + 1 < n_hblocks) issue_block(i + 1);
     const int b = i - (HB - 1);  // the V block whose last H-block this was
     if (b < 0) continue;
     // ---- vertical product of block b: rows ys + 32 b .. + 31 from k-steps 2 b .. 2 b + NKV - 1 of the H ring
@@ -2728,7 +2776,8 @@ void launch_composite(hipStream_t s, const DrawRec* draws, const QuadExt* exts, 
   if (force == 3) P.has_slow = 1;
   if (force == 2) P.has_atlas = 1;
   if (force == 1) P.has_masks = 1;  // (the build with mask registers and the 4-KB stack, even where no clip is open)
-  const size_t lds = P.has_masks ? sizeof(uint32_t) * kMaskDepth * 64 : sizeof(uint32_t) * 256;
+  const size_t lds = (P.has_masks ? sizeof(uint32_t) * kMaskDepth * 64 : sizeof(uint32_t) * 256) +
+                     ((P.has_atlas || P.has_slow) ? sizeof(uint32_t) * kWinRows * kWinStride : 0);  // + the texel window of the atlas path
   const bool full = P.load_fb == 0;  // the launch that starts a frame (k_composite_tiles<., true>)
 #define FDH_COMPOSITE(paths) \
   do { if (full) FDH_LAUNCH((k_composite_tiles<paths, true>), dim3(grid), blk, lds, s, P.order, P.order_next, P.counts, P.lists, P.bin_x0, P.bin_y0, P.bin_nx, P.bin_ny, P.bins_x, P.stride, P.row_lo, P.row_hi, draws, exts, P); \

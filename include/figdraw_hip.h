@@ -332,6 +332,12 @@ FDH_API int fdh_comm_share(FdhContext*, FdhContext* owner);
 FDH_API int fdh_comm_destroy(FdhContext*);
 FDH_API int fdh_gather_stripes(FdhContext*, int dst_rank, void* dst_image);
 FDH_API int fdh_gather_frames(FdhContext*, int dst_rank, void* const* dst_images);
+/* Which route a blur node covering the whole frame takes: 1 = both passes as one out-of-place kernel (k_blur_fx: half the bytes,
+ * the shortest frame when it has the GPU to itself), 0 = the horizontal and the vertical pass as two kernels (less total work:
+ * faster when other contexts' frames are in flight), -1 (default) = decided per frame -- fused unless another context of the
+ * process submitted a frame within the last millisecond.  The pixels are the same bit for bit; FDH_BLUR_FUSED=0|1 in the
+ * environment sets the default. */
+FDH_API int fdh_set_blur_route(FdhContext*, int route);
 /* Re-run the GPU work of the last submitted frame `times` times from the draw records already resident in HBM
  * (the host-side decomposition and the upload are not repeated). */
 FDH_API int fdh_replay(FdhContext*, int times);

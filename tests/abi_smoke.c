@@ -232,6 +232,7 @@ int main(int argc, char** argv) {
       CHECK(r == FDH_OK || r == FDH_ERR_UNSUPPORTED || r == FDH_ERR_HIP);
     }
     OK(fdh_set_stripe(c, 0, 0));
+    OK(fdh_set_blur_route(c, 1)); OK(fdh_set_blur_route(c, -1));
     OK(fdh_sync(c));
     OK(fdh_flush(c));
     OK(fdh_get_frame_stats(c, &st));

@@ -23,6 +23,8 @@ for base, lst in by_kernel.items():
             label = "k_composite_tiles.phase0" if i == 0 else f"k_composite_tiles.later{i}"
         elif base == "k_blur_mx":  # k_blur_mx<NK, false> = horizontal pass, <NK, true> = vertical pass
             label = ("k_blur_mx.v" if "true" in k else "k_blur_mx.h") + ("" if sum(1 for g2, k2 in lst[:i] if ("true" in k2) == ("true" in k)) == 0 else f".{i}")
+        elif base == "k_blur_fx":
+            label = "k_blur_fx" if i == 0 else f"k_blur_fx.{i}"
         elif base in ("k_blur_h", "k_blur_v"):
             label = f"{base}.largest" if i == 0 else f"{base}.{i}"
         else:
