@@ -15,6 +15,7 @@ struct BinParams {
   uint32_t* counts;     // [phase][bin]
   const int* phase_first;  // [n_phases + 1]
   int n_phases, bins_x, bins_y, stride;
+  const DrawRec* draws;    // the frame's records: the bin kernel pulls them into every XCD's L2 for the compositor (see k_bin_draws)
 };
 
 struct CompositeParams {
