@@ -414,15 +414,20 @@ __global__ __launch_bounds__(64) void k_bin_draws(BinParams P) {
 // schedule changes).  A strip's cost is roughly its list length, and a launch ends when its last wave does: started in
 // frame order, a 60-entry strip picked up near the end ran on alone for a fifth of the kernel (58 -> 48 us).  The sort is
 // done by ONE wavefront with 256 words of LDS, from inside k_composite_tiles (see there)
-__device__ __forceinline__ void order_bins_wave(const uint32_t* __restrict__ counts, int* __restrict__ order, int nx, int nb, uint32_t* offs, int lane) {
+// (round 3: ONE CLASS of bins per wave -- the bins with index congruent to `cls` mod 8, written to the positions congruent to
+// cls mod 8 of `order`.  The compositor hands position p to XCD p % 8 and k_bin_draws builds bin b's list on XCD b % 8: with the
+// order sorted per class, a bin's list, its count and -- next frame -- its order entry are read on the XCD whose L2 they were
+// written in, instead of being pulled across XCDs at the very start of every strip's life.)
+__device__ __forceinline__ void order_bins_wave(const uint32_t* __restrict__ counts, int* __restrict__ order, int nx, int nb, uint32_t* offs, int lane, int cls) {
 #pragma unroll
   for (int k = 0; k < 4; k++) offs[lane + 64 * k] = 0;
   __builtin_amdgcn_wave_barrier();
   constexpr int kU = 8;
-  for (int i0 = lane; i0 < nb; i0 += 64 * kU) {
+  const int nc = (nb - cls + 7) >> 3;  // bins of this class: cls, cls + 8, ...
+  for (int i0 = lane; i0 < nc; i0 += 64 * kU) {
     uint32_t c[kU];
 #pragma unroll
-    for (int k = 0; k < kU; k++) c[k] = i0 + 64 * k < nb ? counts[i0 + 64 * k] : 0xffffffffu;
+    for (int k = 0; k < kU; k++) c[k] = i0 + 64 * k < nc ? counts[cls + 8 * (i0 + 64 * k)] : 0xffffffffu;
 #pragma unroll
     for (int k = 0; k < kU; k++) if (c[k] != 0xffffffffu) atomicAdd(&offs[255u - min(c[k], 255u)], 1u);
   }
@@ -440,15 +445,15 @@ __device__ __forceinline__ void order_bins_wave(const uint32_t* __restrict__ cou
     offs[4 * lane] = base; offs[4 * lane + 1] = base + a; offs[4 * lane + 2] = base + a + b; offs[4 * lane + 3] = base + a + b + c2;
   }
   __builtin_amdgcn_wave_barrier();
-  for (int i0 = lane; i0 < nb; i0 += 64 * kU) {
+  for (int i0 = lane; i0 < nc; i0 += 64 * kU) {
     uint32_t c[kU];
 #pragma unroll
-    for (int k = 0; k < kU; k++) c[k] = i0 + 64 * k < nb ? counts[i0 + 64 * k] : 0xffffffffu;
+    for (int k = 0; k < kU; k++) c[k] = i0 + 64 * k < nc ? counts[cls + 8 * (i0 + 64 * k)] : 0xffffffffu;
 #pragma unroll
     for (int k = 0; k < kU; k++)
       if (c[k] != 0xffffffffu) {  // stored as (row << 16 | column) of the launch's bin grid: the reader is spared a division
-        const int i = i0 + 64 * k, row = i / nx;
-        order[atomicAdd(&offs[255u - min(c[k], 255u)], 1u)] = (row << 16) | (i - row * nx);
+        const int i = cls + 8 * (i0 + 64 * k), row = i / nx;
+        order[8 * (int)atomicAdd(&offs[255u - min(c[k], 255u)], 1u) + cls] = (row << 16) | (i - row * nx);
       }
   }
 }
@@ -894,16 +899,15 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? 4 : kPaths == 4 ? FDH_UNIFORM_WA
   // of the ones holding the emptier top and bottom of the frame.
   constexpr int kStripsPerBin = kWgsPerBin * kWavesPerWg;  // 16
   // (a workgroup is ONE wavefront: nothing is shared between strips, and the dispatcher refills wave slots one at a time)
-  // (with a sort riding along, the first eight workgroups are its: one sorts, dispatched first so it is done long before
-  // the launch ends; the numbering of the rest shifts by eight and keeps its XCD phase)
+  // (with a sort riding along, the first eight workgroups are its -- one per XCD, each sorts the bins of its class --, dispatched
+  // first so they are done long before the launch ends; the numbering of the rest shifts by eight and keeps its XCD phase)
   const int blk = P.order_next ? (int)blockIdx.x - 8 : (int)blockIdx.x;
-  if (blk < 0 && blockIdx.x != 0) return;
   const int q = blk >> 3, xcd = blk & 7;
   if (blk < 0) {
     // One extra wavefront per full-frame launch sorts THIS frame's bin counts for the NEXT frame's launch (any
     // permutation is a correct schedule, and list lengths barely change from frame to frame).  As a kernel of its own the
     // sort was a ~6 us serial step of every frame; here it runs beside 32 000 compositing waves.
-    order_bins_wave(P.counts, P.order_next, P.bin_nx, P.bin_nx * P.bin_ny, &mask_stack[0][0][0], threadIdx.x);
+    order_bins_wave(P.counts, P.order_next, P.bin_nx, P.bin_nx * P.bin_ny, &mask_stack[0][0][0], threadIdx.x, (int)blockIdx.x);
     return;
   }
   int bin_local = xcd + 8 * (q / kStripsPerBin);
