@@ -109,14 +109,13 @@ def run_stripes(args, dist, rank, local_rank, world, on_host):
     if use_c_abi:
         setup_comm(ctxs, dist, rank, world)
     else:
-        surf = [frame_tensor(c) for c in ctxs]  # zero-copy (H, W, 4) views
         full = [torch.zeros((h, w, 4), dtype=torch.uint8, device=dev) for _ in range(F)] if rank == 0 else None
 
     def gather_torch(i):
         """stripe of context i from every rank into rank 0's image: grouped send / recv (ncclGroupStart .. End under RCCL)"""
         t0 = time.perf_counter()
         ctxs[i].sync()
-        mine = surf[i][y0:y1]
+        mine = frame_tensor(ctxs[i])[y0:y1]  # (asked again per frame: a context alternates between two surfaces)
         if on_host:
             mine = mine.cpu()
         if rank == 0:
@@ -225,7 +224,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--repeats", type=int, default=5, help="timed batches of --steps frames each; the median batch is reported")
+    ap.add_argument("--repeats", type=int, default=7, help="timed batches of --steps frames each; the median batch is reported")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for the 1-GPU self-test)")
     ap.add_argument("--all-ranks-on-device0", action="store_true", help="self-test of the N>1 code path on a 1-GPU box")

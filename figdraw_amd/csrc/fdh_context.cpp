@@ -1377,8 +1377,7 @@ void Context::prepare(LaunchJob& J) {
     for (size_t i = 0; i < J.blurs.size(); i++)
       if (o_mxh[i]) { mx_w_h_[i] = reinterpret_cast<const uint4*>(d_frame_.ptr + o_mxh[i]); mx_w_v_[i] = reinterpret_cast<const uint4*>(d_frame_.ptr + o_mxv[i]); }
     // A blur node that covers the whole frame, composited by its own vertical pass (no clip open), in a frame that starts from
-    // the clear colour: both passes as ONE kernel, out of place (k_blur_fx) -- launch_frame alternates fb_ and alt_ and starts
-    // so that the frame ends in fb_.
+    // the clear colour: both passes as ONE kernel, out of place (k_blur_fx) -- launch_frame alternates between fb_ and alt_.
     // Which route is a matter of speed only -- the two give the same pixels bit for bit (tests/test_hip_parity.py).  The fused
     // kernel moves half the bytes and shortens a frame rendered ALONE (4K bench frame: both passes 38.5 -> 34 us), but it
     // re-filters 40 % more rows horizontally (segment halos) and holds 22 KB of LDS and 249 VGPRs per wave: with other contexts'
@@ -1679,9 +1678,12 @@ void Context::launch_frame(const LaunchJob& J, bool profile) {
     order_nb_ = order_key;
     order_valid_ = true;
   }
-  // the surface that holds the live image: fused full-frame blurs render out of place and flip it; an odd number of them
-  // starts the frame in alt_ so that it ends in fb_ (phase 0 writes every pixel it is responsible for: J.clear)
-  uint32_t* cur = (J.n_fused & 1) ? alt_ : fb_;
+  // The surface that holds the live image.  A fused full-frame blur renders out of place and flips it; a frame that flips an odd
+  // number of times ends in alt_, and the two pointers trade places: the frame surface IS the one the frame ended in
+  // (fdh_frame_device_ptr is asked again after every frame).  Phase 0 always starts in fb_, i.e. on the surface the previous
+  // frame's last pass WROTE: starting in the other one -- the surface that pass had only read -- cost the phase-0 launch 2 us
+  // (32.1 against 30.2: its 33 MB of stores then land on lines other XCDs' L2s hold clean copies of).
+  uint32_t* cur = fb_;
   for (int p = 0; p < np; p++) {
     const Phase& ph = J.phases[p];
     if (ph.blur >= 0) {
@@ -1754,6 +1756,7 @@ void Context::launch_frame(const LaunchJob& J, bool profile) {
       FDH_HIP(hipMemcpyAsync(dbg_snap_, cur, (size_t)J.W * J.H * 4, hipMemcpyDeviceToDevice, stream_));
     }
   }
+  if (cur != fb_) std::swap(fb_, alt_);  // the frame ended in the other surface: it is the frame surface now
   FDH_HIP(hipGetLastError());
 }
 

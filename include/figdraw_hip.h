@@ -264,8 +264,9 @@ FDH_API int fdh_atlas_packed_area(FdhContext*, int64_t* out); /* atlasPackedArea
 /* readPixels(frame, readFront) figbackend.nim:660-661, glcontext.nim:2094-2135: RGBA8, top-down rows.
  * (x, y, w, h) is in top-down pixel coordinates; w <= 0 or h <= 0 reads the whole frame. Blocks until the frame is done. */
 FDH_API int fdh_read_pixels(FdhContext*, int x, int y, int w, int h, uint8_t* out_rgba8);
-/* Device pointer (hipDeviceptr_t as void*) + pitch of the RGBA8 surface, for zero-copy consumers
- * (RCCL gather of stripes / frames, torch.from_blob).  Valid until the next begin_frame with another size. */
+/* Device pointer (hipDeviceptr_t as void*) + pitch of the RGBA8 surface that holds the last submitted frame, for zero-copy
+ * consumers (torch.from_blob, a gather of one's own).  Ask again after every frame: a context owns two surfaces of the frame's
+ * size and a frame may end in either (a full-frame blur node rendered as one out-of-place kernel flips them). */
 FDH_API int fdh_frame_device_ptr(FdhContext*, void** out_ptr, int* out_width, int* out_height, int64_t* out_pitch_bytes);
 FDH_API int fdh_sync(FdhContext*);
 /* Returns when every frame submitted so far has been ENQUEUED on the context's stream (it does not wait for the GPU): call it

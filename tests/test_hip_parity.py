@@ -428,6 +428,37 @@ def test_flippy_image_matches_oracle_and_reference_png():
     ctx.close()
 
 
+def test_submit_thread_hands_over_frames_in_order():
+    """fdh_end_frame returns after preparing the frame; the context's submit thread issues the launches while the caller records
+    the next frame.  A burst of different frames with no synchronisation in between, reads at arbitrary points, a frame-size
+    change mid-burst (surfaces are reallocated: the frame in submission must be waited for) and the per-call entry points must
+    leave exactly what a FDH_CREATE_SYNC_SUBMIT context renders."""
+    import random
+
+    from figdraw_amd.context import HipContext
+
+    rnd = random.Random(5)
+    a, b = HipContext(device=0), HipContext(device=0, sync_submit=True)
+    sizes = [(640, 360), (640, 360), (800, 450), (800, 450), (333, 217), (640, 360)]
+    for step in range(40):
+        w, h = sizes[(step // 7) % len(sizes)]
+        sc = RS.random_scene(100 + step % 9, float(w), float(h), n=30 + step % 20, clips=step % 3 == 0, blur=step % 4 == 1)
+        a.render_frame(sc, w, h)
+        b.render_frame(sc, w, h)
+        if rnd.random() < 0.3:
+            assert np.array_equal(a.read_pixels(), b.read_pixels()), step
+    assert np.array_equal(a.read_pixels(), b.read_pixels())
+    # per-call frames back to back (no sync), then a read
+    for k in range(6):
+        for c in (a, b):
+            c.begin_frame(320, 200, True, (1.0, 1.0, 1.0, 1.0))
+            c.draw_rounded_rect_sdf((10.0 + 7 * k, 12.0, 200.0, 120.0), [(200, 40 * k, 30, 255)] * 4, (12.0,) * 4, (12.0,) * 4, 3)
+            c.end_frame()
+    assert np.array_equal(a.read_pixels(), b.read_pixels())
+    a.close()
+    b.close()
+
+
 def test_fused_full_frame_blur_equals_the_two_pass_route():
     """A blur node covering the whole frame runs both passes as ONE out-of-place kernel (k_blur_fx), the surfaces alternating
     between phases.  Same sums in the same grouping, the intermediate rounded to RGBA8 as the H pass stores it: the frames must
