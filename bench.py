@@ -233,6 +233,7 @@ def main():
     ap.add_argument("--gather", choices=["c_abi", "torch"], default="c_abi",
                     help="who issues the gather: the library's own fdh_gather_* (RCCL through the C ABI, stream-ordered) or torch.distributed "
                          "(always used with --backend gloo)")
+    ap.add_argument("--gather-timeout", type=float, default=180.0, help="seconds the gather legs of an N > 1 run may take before they are given up")
     ap.add_argument("--width", type=int, default=W)
     ap.add_argument("--height", type=int, default=H)
     ap.add_argument("--mode", choices=["frames", "stripes"], default="frames",
@@ -466,52 +467,76 @@ def main():
     # ---- the one collective of the path: the gather of finished frames to rank 0.  Frames are independent, so
     # `value` above holds no data-path collective (weak scaling); here (a) one gather of every rank's final frame, timed on its
     # own, and (b) the same K-frame batch with EVERY frame gathered to rank 0 inside the timed region, reported beside `value`.
-    gather_ms, gather_how, with_gather = None, None, None
+    gather_ms, gather_how, with_gather, gather_error = None, None, None, None
     if dist is not None:
         col = C_mod._F4(1.0, 1.0, 1.0, 1.0)
-        use_c_abi = args.gather == "c_abi" and not on_host
-        if use_c_abi:
-            setup_comm(ctxs, dist, rank, world)
-            dev = f"cuda:{local_rank}"
-            slots = [[torch.empty((h, w, 4), dtype=torch.uint8, device=dev) for _ in range(world)] for _ in range(F)] if rank == 0 else None
-            ptrs = [[t.data_ptr() for t in sl] for sl in slots] if rank == 0 else [None] * F
-            barrier()
-            g0 = time.perf_counter()
-            ctx.gather_frames(0, ptrs[0])
+
+        def gather_timed_out():
+            # A collective that never completes (a rank lost, a link down) must not take the measured `value` with it: every rank
+            # leaves after --gather-timeout seconds and rank 0 still prints the line, with the gather marked as not measured.
+            if rank == 0:
+                print(json.dumps({"metric": "Mpixels/s composited @3840x2160, 300 SDF rects+shadows; % HBM roofline",
+                                  "value": round(world * w * h * args.steps / elapsed / 1e6, 1), "unit": "Mpixels/s", "n_gpus": world,
+                                  "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4), "repeats": args.repeats,
+                                  "batches_ms": batch_ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                                  "config": {"workload": f"S300@4K: renderlist_100 scene at {w}x{h} (BASELINE.json configs[2])",
+                                             "parallelism": f"frame-parallel x{world}", "frames_in_flight_per_gpu": F},
+                                  "gather": {"error": f"the gather of frames to rank 0 did not complete within {args.gather_timeout} s; `value` (no collective "
+                                                      "on the data path) was measured before it"}}), flush=True)
+            os._exit(0)
+
+        import threading
+
+        watchdog = threading.Timer(args.gather_timeout, gather_timed_out)
+        watchdog.daemon = True
+        watchdog.start()
+        try:
+            use_c_abi = args.gather == "c_abi" and not on_host
+            if use_c_abi:
+                setup_comm(ctxs, dist, rank, world)
+                dev = f"cuda:{local_rank}"
+                slots = [[torch.empty((h, w, 4), dtype=torch.uint8, device=dev) for _ in range(world)] for _ in range(F)] if rank == 0 else None
+                ptrs = [[t.data_ptr() for t in sl] for sl in slots] if rank == 0 else [None] * F
+                barrier()
+                g0 = time.perf_counter()
+                ctx.gather_frames(0, ptrs[0])
+                ctx.sync()
+                gather_ms = 1e3 * (time.perf_counter() - g0)
+                gather_how = "fdh_gather_frames (C ABI: grouped ncclSend / ncclRecv on the context's stream)"
+                if rank == 0:
+                    assert all(int(o[..., 3].min()) == 255 for o in slots[0]), "a gathered frame has unwritten pixels"
+
+                def run_with_gather(n):
+                    for k in range(n):
+                        c = ctxs[k % F]
+                        c._ck(c.L.fdh_render_frame(c.h, cscenes[k % NS].byref(), float(w), float(h), 1, col))
+                        c.gather_frames(0, ptrs[k % F])  # behind the frame on the context's stream: no host synchronisation
+
+                run_with_gather(args.warmup)
+                wg_elapsed, wg_batch_ms = batches(run_with_gather, args.steps, args.repeats)
+                with_gather = {"value": round(world * w * h * args.steps / wg_elapsed / 1e6, 1), "unit": "Mpixels/s", "ms_per_step": round(1e3 * wg_elapsed / args.steps, 4),
+                               "batches_ms": wg_batch_ms,
+                               "note": "the same batch with every frame of every rank gathered to rank 0 (fdh_gather_frames) inside the timed region: "
+                                       f"rank 0 takes in {world - 1} x {w * h * 4 / 1e6:.1f} MB per round of frames over its xGMI links"}
+            else:
+                mine = frame_tensor(ctx).contiguous()
+                if on_host:
+                    mine = mine.cpu()
+                outs = [torch.empty_like(mine) for _ in range(world)] if rank == 0 else None
+                barrier()
+                g0 = time.perf_counter()
+                dist.gather(mine, outs, dst=0)
+                torch.cuda.synchronize()
+                gather_ms = 1e3 * (time.perf_counter() - g0)
+                gather_how = f"torch.distributed.gather ({args.backend})"
+                if rank == 0:
+                    assert all(int(o[..., 3].min()) == 255 for o in outs), "a gathered frame has unwritten pixels"
+            ctx.render_frame(scene, w, h)
             ctx.sync()
-            gather_ms = 1e3 * (time.perf_counter() - g0)
-            gather_how = "fdh_gather_frames (C ABI: grouped ncclSend / ncclRecv on the context's stream)"
-            if rank == 0:
-                assert all(int(o[..., 3].min()) == 255 for o in slots[0]), "a gathered frame has unwritten pixels"
-
-            def run_with_gather(n):
-                for k in range(n):
-                    c = ctxs[k % F]
-                    c._ck(c.L.fdh_render_frame(c.h, cscenes[k % NS].byref(), float(w), float(h), 1, col))
-                    c.gather_frames(0, ptrs[k % F])  # behind the frame on the context's stream: no host synchronisation
-
-            run_with_gather(args.warmup)
-            wg_elapsed, wg_batch_ms = batches(run_with_gather, args.steps, args.repeats)
-            with_gather = {"value": round(world * w * h * args.steps / wg_elapsed / 1e6, 1), "unit": "Mpixels/s", "ms_per_step": round(1e3 * wg_elapsed / args.steps, 4),
-                           "batches_ms": wg_batch_ms,
-                           "note": "the same batch with every frame of every rank gathered to rank 0 (fdh_gather_frames) inside the timed region: "
-                                   f"rank 0 takes in {world - 1} x {w * h * 4 / 1e6:.1f} MB per round of frames over its xGMI links"}
-        else:
-            mine = frame_tensor(ctx).contiguous()
-            if on_host:
-                mine = mine.cpu()
-            outs = [torch.empty_like(mine) for _ in range(world)] if rank == 0 else None
-            barrier()
-            g0 = time.perf_counter()
-            dist.gather(mine, outs, dst=0)
-            torch.cuda.synchronize()
-            gather_ms = 1e3 * (time.perf_counter() - g0)
-            gather_how = f"torch.distributed.gather ({args.backend})"
-            if rank == 0:
-                assert all(int(o[..., 3].min()) == 255 for o in outs), "a gathered frame has unwritten pixels"
-        ctx.render_frame(scene, w, h)
-        ctx.sync()
-
+        except Exception as e:  # (reported, not fatal: `value` holds no collective)
+            gather_error = f"{type(e).__name__}: {e}"
+        finally:
+            watchdog.cancel()
     if rank != 0:
         return
 
@@ -684,6 +709,8 @@ def main():
         out["gather_ms"] = round(gather_ms, 3)
         out["gather"] = gather_how
         out["with_gather_every_frame"] = with_gather
+    if gather_error is not None:
+        out["gather_error"] = gather_error
     # a frame that came out differently in flight than alone (or off the oracle) voids the throughput figure
     bad = in_flight_differing != 0 or per_call_differing != 0 or (in_flight_vs_oracle is not None and in_flight_vs_oracle["parity_max_lsb"] > 1) or \
         (cpu_baseline is not None and cpu_baseline["parity_max_lsb"] > 1)

@@ -1959,9 +1959,12 @@ constexpr int kMxSlot = 512;          // dwords of one k-step in LDS: 16 texels 
 // purpose: after the builtin form hipcc drains vmcnt to 0 before the next LDS read, which also waits for the stores just
 // issued; the kernel below places its own counted waits.  (M0 = LDS address; one wait state between s_mov m0 and its use.)
 // M0 is a reserved register for hipcc (a clobber on it is ignored, -Winline-asm): the block saves and restores it.
+#ifndef FDH_DMA_POLICY
+#define FDH_DMA_POLICY ""  // cache-policy bits of the blur passes' texel DMA (experiments: " nt", " sc1", ...)
+#endif
 __device__ __forceinline__ void lds_dma16(const void* src, uint32_t lds) {
   uint32_t m0_saved;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" FDH_DMA_POLICY "\n\ts_mov_b32 m0, %0"
                : "=&s"(m0_saved) : "v"(src), "s"(lds) : "memory");
 }
 __device__ __forceinline__ void lds_dma4(const void* src, uint32_t lds) {
@@ -2912,13 +2915,15 @@ template <int NKH, int NKV> static void launch_blur_fx(hipStream_t s, const Blur
     return n;
   }();
   static const int forced = [] { const char* e = std::getenv("FDH_FX_T"); return e ? std::atoi(e) : 0; }();  // experiments
+  // (experiments: FDH_FX_LDS = KB of LDS to ask for per wave -- more than the rings need, to leave room on a CU for other kernels' waves)
+  static const size_t lds_req = [] { const char* e = std::getenv("FDH_FX_LDS"); const size_t need = lds, ask = e ? (size_t)std::atoi(e) * 1024 : 0; return ask > need ? ask : need; }();
   const int n_strips = (P.x1 - (P.x0 & ~31) + 31) >> 5, blocks = (P.y1 - (P.y0 & ~31) + 31) >> 5;
-  const long long slots = 256LL * std::min(per_cu, 8);
+  const long long slots = 256LL * std::min(std::min(per_cu, 8), (int)(160 * 1024 / lds_req));
   int t = 2;  // (a one-block segment would filter three H-blocks per output block)
   while (t < 64 && (long long)n_strips * ((blocks + t - 1) / t) > slots) t++;
   if (forced) t = forced;
   const int total = n_strips * ((blocks + t - 1) / t);
-  FDH_LAUNCH((k_blur_fx<NKH, NKV>), dim3(8 * ((total + 7) / 8)), dim3(64), lds, s, P, w_v, draws, exts, t);
+  FDH_LAUNCH((k_blur_fx<NKH, NKV>), dim3(8 * ((total + 7) / 8)), dim3(64), lds_req, s, P, w_v, draws, exts, t);
 }
 bool blur_fused_supported(int reach, int W, int pitch) {
   const int nkh = mx_nk(reach, false), nkv = mx_nk(reach, true);
