@@ -61,6 +61,14 @@ void nccl_check(ncclResult_t r, const char* what) {
   throw Error(FDH_ERR_HIP, std::string(what) + ": " + (R.GetErrorString ? R.GetErrorString(r) : "RCCL error"));
 }
 #define FDH_NCCL(x) nccl_check((x), #x)
+// ncclGroupStart .. ncclGroupEnd around the sends / receives of one gather; a call that fails in between still closes the group
+struct Group {
+  Rccl& R;
+  bool open = true;
+  explicit Group(Rccl& r) : R(r) { FDH_NCCL(R.GroupStart()); }
+  void end() { open = false; FDH_NCCL(R.GroupEnd()); }
+  ~Group() { if (open) (void)R.GroupEnd(); }
+};
 }  // namespace
 
 void stripe_rows(int height, int world, int rank, int* y0, int* y1) {
@@ -88,29 +96,30 @@ void Context::comm_init(const uint8_t id_bytes[FDH_COMM_ID_BYTES], int rank, int
   std::memcpy(id.internal, id_bytes, FDH_COMM_ID_BYTES);
   ncclComm_t c = nullptr;
   FDH_NCCL(rccl().CommInitRank(&c, world, id, rank));
-  comm_ = c;
+  comm_ = std::shared_ptr<void>(static_cast<void*>(c), [](void* p) {
+    try { (void)rccl().CommDestroy(static_cast<ncclComm_t>(p)); } catch (...) {}
+  });
   comm_rank_ = rank;
   comm_world_ = world;
 }
-// Several contexts of one process (frames in flight) use ONE communicator: the others borrow the owner's.  RCCL runs a
+// Several contexts of one process (frames in flight) use ONE communicator: the others borrow the owner's (a shared reference:
+// the communicator is destroyed when its last holder lets go, in whichever order the contexts are destroyed).  RCCL runs a
 // communicator's operations in the order they were issued, whichever stream each was issued on.
 void Context::comm_share(Context* owner) {
   need_device("comm_share");
   if (!owner || owner == this) throw Error(FDH_ERR_INVALID, "comm_share: needs another context that owns a communicator");
   if (owner->device_ != device_) throw Error(FDH_ERR_INVALID, "comm_share: both contexts must live on the same device");
+  if (!owner->comm_) throw Error(FDH_ERR_INVALID, "comm_share: the other context holds no communicator");
   comm_destroy();
   comm_ = owner->comm_;
   comm_rank_ = owner->comm_rank_;
   comm_world_ = owner->comm_world_;
-  comm_borrowed_ = true;
 }
 void Context::comm_destroy() {
   if (!comm_) return;
   drain();
-  (void)hipStreamSynchronize(stream_);
-  if (!comm_borrowed_) (void)rccl().CommDestroy(static_cast<ncclComm_t>(comm_));
-  comm_ = nullptr;
-  comm_borrowed_ = false;
+  (void)hipStreamSynchronize(stream_);  // this context's transfers are done; the last holder's reset destroys the communicator
+  comm_.reset();
   comm_rank_ = 0;
   comm_world_ = 1;
 }
@@ -133,8 +142,8 @@ void Context::gather_stripes(int dst_rank, void* dst_image) {
     FDH_HIP(hipMemcpyAsync(dst + (size_t)my0 * row_bytes, own + (size_t)my0 * row_bytes, (size_t)(my1 - my0) * row_bytes, hipMemcpyDeviceToDevice, stream_));
   if (world == 1) return;
   Rccl& R = rccl();
-  ncclComm_t comm = static_cast<ncclComm_t>(comm_);
-  FDH_NCCL(R.GroupStart());
+  ncclComm_t comm = static_cast<ncclComm_t>(comm_.get());
+  Group g(R);
   if (rank == dst_rank) {
     for (int r = 0; r < world; r++) {
       int y0, y1;
@@ -144,7 +153,7 @@ void Context::gather_stripes(int dst_rank, void* dst_image) {
   } else if (my1 > my0) {
     FDH_NCCL(R.Send(own + (size_t)my0 * row_bytes, (size_t)(my1 - my0) * row_bytes, ncclUint8, dst_rank, comm, stream_));
   }
-  FDH_NCCL(R.GroupEnd());
+  g.end();
 }
 
 // Frame-parallel mode: every rank holds a whole frame; dst_rank receives rank r's into dst_images[r] (its own by a device copy).
@@ -154,6 +163,9 @@ void Context::gather_frames(int dst_rank, void* const* dst_images) {
   const int world = comm_ ? comm_world_ : 1, rank = comm_ ? comm_rank_ : 0;
   if (dst_rank < 0 || dst_rank >= world) throw Error(FDH_ERR_INVALID, "gather_frames: destination rank out of range");
   if (rank == dst_rank && !dst_images) throw Error(FDH_ERR_INVALID, "gather_frames: the destination rank needs one image per rank");
+  if (rank == dst_rank)
+    for (int r = 0; r < world; r++)
+      if (r != rank && !dst_images[r]) throw Error(FDH_ERR_INVALID, "gather_frames: null destination image");
   drain();
   FDH_HIP(hipSetDevice(device_));
   const size_t bytes = (size_t)W_ * H_ * 4;
@@ -161,18 +173,15 @@ void Context::gather_frames(int dst_rank, void* const* dst_images) {
     FDH_HIP(hipMemcpyAsync(dst_images[rank], fb_, bytes, hipMemcpyDeviceToDevice, stream_));
   if (world == 1) return;
   Rccl& R = rccl();
-  ncclComm_t comm = static_cast<ncclComm_t>(comm_);
-  FDH_NCCL(R.GroupStart());
+  ncclComm_t comm = static_cast<ncclComm_t>(comm_.get());
+  Group g(R);
   if (rank == dst_rank) {
     for (int r = 0; r < world; r++)
-      if (r != rank) {
-        if (!dst_images[r]) throw Error(FDH_ERR_INVALID, "gather_frames: null destination image");
-        FDH_NCCL(R.Recv(dst_images[r], bytes, ncclUint8, r, comm, stream_));
-      }
+      if (r != rank) FDH_NCCL(R.Recv(dst_images[r], bytes, ncclUint8, r, comm, stream_));
   } else {
     FDH_NCCL(R.Send(fb_, bytes, ncclUint8, dst_rank, comm, stream_));
   }
-  FDH_NCCL(R.GroupEnd());
+  g.end();
 }
 
 }  // namespace fdh

@@ -8,6 +8,7 @@
 #include <condition_variable>
 #include <cstdint>
 #include <exception>
+#include <memory>
 #include <mutex>
 #include <stdexcept>
 #include <string>
@@ -279,9 +280,8 @@ class Context {
   uint32_t flags_ = 0;
   int blur_route_ = -1;   // fdh_set_blur_route: -1 per-frame decision, 0 two passes, 1 fused
   int submit_slot_ = 0;   // this context's entry in the process-wide table of last submissions (Context::prepare)
-  void* comm_ = nullptr;  // ncclComm_t (fdh_comm_init)
+  std::shared_ptr<void> comm_;  // ncclComm_t (fdh_comm_init), shared with the contexts that borrowed it: destroyed with its last holder
   int comm_rank_ = 0, comm_world_ = 1;
-  bool comm_borrowed_ = false;
   hipStream_t own_stream_ = nullptr, stream_ = nullptr;
   hipEvent_t ev_[2] = {};
   std::vector<hipEvent_t> ev_pool_;

@@ -318,8 +318,8 @@ FDH_API int fdh_set_stripe(FdhContext*, int y0, int y1);
  *                        of whole 8-row strips -- what each rank passes to fdh_set_stripe
  *   fdh_comm_unique_id   ncclGetUniqueId: rank 0 makes the 128-byte id, the host carries it to the other ranks (its own channel)
  *   fdh_comm_init        ncclCommInitRank on the context's device; fdh_comm_destroy (also done by fdh_destroy)
- *   fdh_comm_share       a second context of the same process (frames in flight) borrows `owner`'s communicator instead of
- *                        creating one; the owner must outlive it
+ *   fdh_comm_share       a second context of the same process (frames in flight) shares `owner`'s communicator instead of
+ *                        creating one; the communicator goes when the last context holding it is destroyed (any order)
  *   fdh_gather_stripes   row-stripe mode: rank r sends rows fdh_stripe_rows(H, world, r) of its surface to dst_rank, which
  *                        receives them into the same rows of dst_image (device, W x H RGBA8; NULL: its own surface, whose own
  *                        rows are already in place)
