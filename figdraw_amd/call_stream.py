@@ -90,7 +90,7 @@ def build_player(force: bool = False) -> str:
         return PLAYER_LIB
     os.makedirs(os.path.dirname(PLAYER_LIB), exist_ok=True)
     tmp = f"{PLAYER_LIB}.{os.getpid()}.tmp"  # (several ranks may find it stale at once: each links its own file, the rename is atomic)
-    subprocess.check_call(["gcc", "-std=c99", "-O2", "-Wall", "-Wextra", "-Werror", "-pedantic", "-D_POSIX_C_SOURCE=199309L", "-fPIC", "-shared",
+    subprocess.check_call(["gcc", "-std=c99", "-O2", "-Wall", "-Wextra", "-Werror", "-pedantic", "-D_POSIX_C_SOURCE=200112L", "-pthread", "-fPIC", "-shared",
                            "-I", os.path.join(ROOT, "include"), PLAYER_SRC, "-o", tmp,
                            "-L", _HERE, "-l:libfigdraw_hip.so", "-Wl,-rpath," + _HERE])
     os.replace(tmp, PLAYER_LIB)
@@ -107,6 +107,7 @@ class Player:
         self.P.fdh_play_calls.argtypes = [vp, vp, C.c_size_t, C.c_int, C.c_int]
         self.P.fdh_play_frames.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t), C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
         self.P.fdh_play_scenes.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(vp), C.c_int, C.c_int, C.c_float, C.c_float, C.POINTER(C.c_double)]
+        self.P.fdh_play_scenes_threads.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(vp), C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.POINTER(C.c_double)]
 
     def play(self, ctx, stream: np.ndarray, w: int, h: int):
         """one frame through the per-call entry points of `ctx` (a HipContext)"""
@@ -127,12 +128,16 @@ class Player:
         ctxs[0]._ck(rc)
         return sec.value
 
-    def play_scenes(self, ctxs, cscenes, frames: int, w: float, h: float) -> float:
-        """frame k = fdh_render_frame(cscenes[k % n]) on ctxs[k % len(ctxs)] from C; seconds of wall time.  cscenes: Renders.to_c() objects"""
+    def play_scenes(self, ctxs, cscenes, frames: int, w: float, h: float, threads: int = 1) -> float:
+        """frame k = fdh_render_frame(cscenes[k % n]) on ctxs[k % len(ctxs)] from C; seconds of wall time.  cscenes: Renders.to_c() objects.
+        threads > 1: context c is driven by host thread c % threads (fdh_play_scenes_threads)"""
         hs = (C.c_void_p * len(ctxs))(*[c.h for c in ctxs])
         ps = (C.c_void_p * len(cscenes))(*[C.addressof(cs.struct) for cs in cscenes])
         sec = C.c_double()
-        rc = self.P.fdh_play_scenes(hs, len(ctxs), ps, len(cscenes), int(frames), float(w), float(h), C.byref(sec))
+        if threads > 1:
+            rc = self.P.fdh_play_scenes_threads(hs, len(ctxs), ps, len(cscenes), int(frames), float(w), float(h), int(threads), C.byref(sec))
+        else:
+            rc = self.P.fdh_play_scenes(hs, len(ctxs), ps, len(cscenes), int(frames), float(w), float(h), C.byref(sec))
         for c in ctxs:
             c.W, c.H = int(w), int(h)
         ctxs[0]._ck(rc)

@@ -459,6 +459,43 @@ def test_submit_thread_hands_over_frames_in_order():
     b.close()
 
 
+def test_c_player_drives_the_library_like_the_bindings_do():
+    """tools/call_player.c (C99) is the driver bench.py times: the recorded BackendContext calls of a frame through the per-call entry
+    points, whole scenes through fdh_render_frame, and the same with one host thread per group of contexts.  Whatever the driver,
+    a context must end up holding exactly the frame the Python binding renders on a context of its own."""
+    from figdraw_amd import call_stream as CS
+    from figdraw_amd.context import HipContext
+
+    w, h = 960, 540
+    scenes = [RS.random_scene(300 + i, float(w), float(h), n=40 + 3 * i, clips=i % 2 == 0, blur=i % 3 == 0) for i in range(6)]
+    ref = HipContext(device=0, sync_submit=True)
+    want = []
+    for sc in scenes:
+        ref.render_frame(sc, w, h)
+        want.append(ref.read_pixels())
+    player = CS.Player()
+    # (a) the per-call stream of every scene
+    rec = HipContext(record_only=True)
+    ctx = HipContext(device=0)
+    for sc, px in zip(scenes, want):
+        rec.record_begin()
+        rec.render_frame(sc, w, h)
+        player.play(ctx, CS.pack(rec.record_calls()), w, h)
+        assert np.array_equal(ctx.read_pixels(), px)
+    ctx.close()
+    # (b) whole scenes, four contexts, one / two / four host threads; frame k = scene k % 6 on context k % 4
+    cs = [sc.to_c() for sc in scenes]
+    frames = 22
+    for threads in (1, 2, 4):
+        ctxs = [HipContext(device=0) for _ in range(4)]
+        player.play_scenes(ctxs, cs, frames, w, h, threads=threads)
+        for i, c in enumerate(ctxs):
+            k_last = max(k for k in range(frames) if k % 4 == i)
+            assert np.array_equal(c.read_pixels(), want[k_last % 6]), (threads, i)
+            c.close()
+    ref.close()
+
+
 def test_fused_full_frame_blur_equals_the_two_pass_route():
     """A blur node covering the whole frame runs both passes as ONE out-of-place kernel (k_blur_fx), the surfaces alternating
     between phases.  Same sums in the same grouping, the intermediate rounded to RGBA8 as the H pass stores it: the frames must

@@ -14,6 +14,7 @@
 #include <stddef.h>
 #include <stdint.h>
 #include <string.h>
+#include <pthread.h>
 #include <time.h>
 
 #include "figdraw_hip.h"
@@ -121,6 +122,66 @@ FDH_API int fdh_play_scenes(FdhContext* const* ctxs, int n_ctx, const FdhScene* 
   for (k = 0; k < frames && rc == 0; k++) rc = fdh_render_frame(ctxs[k % n_ctx], scenes[k % n_scenes], frame_w, frame_h, 1, white);
   for (k = 0; k < n_ctx; k++) { const int r2 = fdh_sync(ctxs[k]); if (rc == 0) rc = r2; }
   clock_gettime(CLOCK_MONOTONIC, &t1);
+  if (seconds) *seconds = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+  return rc;
+}
+
+/* The same frames with one host thread per group of contexts: thread t drives the contexts c with c % n_threads == t (a context is
+ * only ever driven by its one thread; frame k still goes to context k % n_ctx with scene k % n_scenes).  What an application with
+ * several windows does -- one render thread per window -- and what takes the tree walk of frame k + 1 off the path of frame k's
+ * neighbours: with one calling thread the walks of all contexts' frames queue up behind each other. */
+struct fdh_play_gate { pthread_mutex_t mu; pthread_cond_t cv; int go; };
+struct fdh_play_thread {
+  FdhContext* const* ctxs;
+  const FdhScene* const* scenes;
+  int n_ctx, n_scenes, frames, n_threads, t, rc;
+  float frame_w, frame_h;
+  struct fdh_play_gate* gate;
+};
+static void* fdh_play_thread_main(void* arg) {
+  struct fdh_play_thread* a = (struct fdh_play_thread*)arg;
+  const float white[4] = {1.0f, 1.0f, 1.0f, 1.0f};
+  int k, rc = 0, go;
+  pthread_mutex_lock(&a->gate->mu);
+  while ((go = a->gate->go) == 0) pthread_cond_wait(&a->gate->cv, &a->gate->mu);
+  pthread_mutex_unlock(&a->gate->mu);
+  if (go < 0) return NULL;  /* a sibling could not be started: nothing is drawn */
+  for (k = 0; k < a->frames && rc == 0; k++)
+    if ((k % a->n_ctx) % a->n_threads == a->t) rc = fdh_render_frame(a->ctxs[k % a->n_ctx], a->scenes[k % a->n_scenes], a->frame_w, a->frame_h, 1, white);
+  for (k = a->t; k < a->n_ctx; k += a->n_threads) { const int r2 = fdh_sync(a->ctxs[k]); if (rc == 0) rc = r2; }
+  a->rc = rc;
+  return NULL;
+}
+FDH_API int fdh_play_scenes_threads(FdhContext* const* ctxs, int n_ctx, const FdhScene* const* scenes, int n_scenes, int frames, float frame_w,
+                                    float frame_h, int n_threads, double* seconds) {
+  enum { MAX_THREADS = 64 };
+  struct fdh_play_thread args[MAX_THREADS];
+  pthread_t th[MAX_THREADS];
+  struct fdh_play_gate gate;
+  struct timespec t0, t1;
+  int t, made = 0, rc = 0;
+  if (n_ctx <= 0 || n_scenes <= 0 || n_threads <= 0) return -100;
+  if (n_threads > n_ctx) n_threads = n_ctx;
+  if (n_threads > MAX_THREADS) n_threads = MAX_THREADS;
+  if (pthread_mutex_init(&gate.mu, NULL) != 0) return -101;
+  if (pthread_cond_init(&gate.cv, NULL) != 0) { pthread_mutex_destroy(&gate.mu); return -101; }
+  gate.go = 0;
+  for (t = 0; t < n_threads; t++) {
+    args[t].ctxs = ctxs; args[t].scenes = scenes; args[t].n_ctx = n_ctx; args[t].n_scenes = n_scenes; args[t].frames = frames;
+    args[t].n_threads = n_threads; args[t].t = t; args[t].rc = 0; args[t].frame_w = frame_w; args[t].frame_h = frame_h; args[t].gate = &gate;
+    if (pthread_create(&th[t], NULL, fdh_play_thread_main, &args[t]) != 0) break;
+    made++;
+  }
+  if (made != n_threads) rc = -102;
+  clock_gettime(CLOCK_MONOTONIC, &t0);  /* the threads exist and wait at the gate: the timed region is frames + syncs + joins */
+  pthread_mutex_lock(&gate.mu);
+  gate.go = made == n_threads ? 1 : -1;
+  pthread_cond_broadcast(&gate.cv);
+  pthread_mutex_unlock(&gate.mu);
+  for (t = 0; t < made; t++) { pthread_join(th[t], NULL); if (rc == 0) rc = args[t].rc; }
+  clock_gettime(CLOCK_MONOTONIC, &t1);
+  pthread_cond_destroy(&gate.cv);
+  pthread_mutex_destroy(&gate.mu);
   if (seconds) *seconds = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
   return rc;
 }
