@@ -256,12 +256,67 @@ void Context::put_levels(int x, int y, int w, int h, const uint8_t* rgba) {
     cw = nw; ch = nh; lx /= 2; ly /= 2; level++;
   }
 }
+// the ink boxes of an image whose texels the host holds (AtlasEntry): one pass, sixteen running boxes
+static void measure_ink(AtlasEntry& e, const uint8_t* rgba) {
+  if (e.w > 32767 || e.h > 32767) return;
+  for (int k = 0; k < kInkLevels; k++) e.ink_a[k] = e.ink_rgb[k] = InkBox{32767, 32767, 0, 0};
+  auto grow = [](InkBox& b, int x, int y) {
+    b.x0 = (int16_t)std::min<int>(b.x0, x); b.y0 = (int16_t)std::min<int>(b.y0, y);
+    b.x1 = (int16_t)std::max<int>(b.x1, x + 1); b.y1 = (int16_t)std::max<int>(b.y1, y + 1);
+  };
+  for (int y = 0; y < e.h; y++) {
+    const uint8_t* row = rgba + (size_t)y * e.w * 4;
+    for (int x = 0; x < e.w; x++) {
+      const int a = row[4 * x + 3], m = std::max<int>(row[4 * x], std::max<int>(row[4 * x + 1], row[4 * x + 2]));
+      for (int k = 0; k < kInkLevels && a > 16 * k; k++) grow(e.ink_a[k], x, y);
+      for (int k = 0; k < kInkLevels && m > 16 * k; k++) grow(e.ink_rgb[k], x, y);
+    }
+  }
+  for (int k = 0; k < kInkLevels; k++) {  // nothing above the level: an empty box at the origin
+    if (e.ink_a[k].x1 <= e.ink_a[k].x0) e.ink_a[k] = InkBox{0, 0, 0, 0};
+    if (e.ink_rgb[k].x1 <= e.ink_rgb[k].x0) e.ink_rgb[k] = InkBox{0, 0, 0, 0};
+  }
+  e.has_ink = true;
+}
+// The record just emitted (an upright atlas quad sampling level 0 of `e`) covers nothing outside the image of the ink box at
+// level `level_t` (values <= level_t give coverage exactly 0 for this draw): its pixel bounds shrink to that image.  A bilinear
+// sample at texel coordinate t reads texels floor(t) and floor(t) + 1, the sub-pixel shift moves t by less than one texel: the box
+// is widened by three texels and the pixel range by one pixel on every side, far beyond any rounding of the linear map.
+void Context::shrink_to_ink(const AtlasEntry& e, bool use_alpha, int level_t) {
+  static const bool enabled = [] { const char* v = std::getenv("FDH_INK_BOUNDS"); return !v || std::atoi(v) != 0; }();
+  if (!enabled || !e.has_ink || level_t < 0 || recs_.empty()) return;
+  DrawRec& r = recs_.back();
+  BBox& b = bboxes_.back();
+  if ((r.op_mode & F_GENERAL) || b.x1 <= b.x0 || b.y1 <= b.y0) return;
+  const InkBox ib = (use_alpha ? e.ink_a : e.ink_rgb)[std::min(level_t / 16, kInkLevels - 1)];
+  if (ib.x1 <= ib.x0 || ib.y1 <= ib.y0) { b = BBox{0, 0, 0, 0}; r.bx0 = r.by0 = r.bx1 = r.by1 = 0; return; }  // nothing in the image reaches the level
+  const double S = (double)atlas_size_;
+  auto range = [&](double ua, double ut, double o, double inv, double lo_t, double hi_t, int& p0, int& p1) {
+    // texel coordinate at pixel centre c: t(c) = (ua + (ut - ua) (c - o) inv) S - 0.5; pixels whose t lies in [lo_t - 3, hi_t + 2]
+    const double A = (ut - ua) * inv * S, B = ua * S - 0.5 - A * o;
+    if (!(std::fabs(A) > 1e-12)) return;
+    double c0 = ((lo_t - 3.0) - B) / A, c1 = ((hi_t + 2.0) - B) / A;
+    if (c0 > c1) std::swap(c0, c1);
+    if (!(c0 > -1.0e6 && c1 < 1.0e6)) return;
+    p0 = std::max(p0, (int)std::floor(c0 - 0.5) - 1);
+    p1 = std::min(p1, (int)std::ceil(c1 - 0.5) + 2);
+  };
+  int x0 = b.x0, x1 = b.x1, y0 = b.y0, y1 = b.y1;
+  range(r.r[0], r.r[2], r.ox, r.inv_w, (double)(e.x + ib.x0), (double)(e.x + ib.x1), x0, x1);
+  range(r.r[1], r.r[3], r.oy, r.inv_h, (double)(e.y + ib.y0), (double)(e.y + ib.y1), y0, y1);
+  if (x1 <= x0 || y1 <= y0) { x0 = y0 = x1 = y1 = 0; }
+  b = BBox{(int16_t)x0, (int16_t)y0, (int16_t)x1, (int16_t)y1};
+  r.bx0 = b.x0; r.by0 = b.y0; r.bx1 = b.x1; r.by1 = b.y1;
+}
+
 void Context::put_image(int64_t key, int w, int h, const uint8_t* rgba, int out_rect[4]) {
   if (w <= 0 || h <= 0 || !rgba) throw Error(FDH_ERR_INVALID, "put_image: empty image");
   if (!host_only_) FDH_HIP(hipSetDevice(device_));
   int x, y;
   find_empty_rect(w, h, &x, &y);
-  entries_[key] = AtlasEntry{x, y, w, h};
+  AtlasEntry ent{x, y, w, h};
+  measure_ink(ent, rgba);
+  entries_[key] = ent;
   atlas_epoch_++;
   sync();  // a frame in flight may still sample the atlas
   put_levels(x, y, w, h, rgba);
@@ -275,7 +330,7 @@ void Context::put_glyph_image(int64_t key, int w, int h, const uint8_t* rgba, ui
   if (flags & ~(uint32_t)FDH_GLYPH_LCD_FILTER) throw Error(FDH_ERR_INVALID, "put_glyph_image: unknown flag");
   int x, y;
   find_empty_rect(w, h, &x, &y);
-  entries_[key] = AtlasEntry{x, y, w, h};
+  entries_[key] = AtlasEntry{x, y, w, h, false, {}, {}};
   atlas_epoch_++;
   if (out_rect) { out_rect[0] = x; out_rect[1] = y; out_rect[2] = w; out_rect[3] = h; }
   if (host_only_) return;
@@ -334,7 +389,7 @@ void Context::put_glyph_outline(int64_t key, int w, int h, const float* segs, in
   }
   int x, y;
   find_empty_rect(w, h, &x, &y);
-  entries_[key] = AtlasEntry{x, y, w, h};
+  entries_[key] = AtlasEntry{x, y, w, h, false, {}, {}};
   atlas_epoch_++;
   if (out_rect) { out_rect[0] = x; out_rect[1] = y; out_rect[2] = w; out_rect[3] = h; }
   if (host_only_) return;
@@ -401,7 +456,7 @@ void Context::put_mips(int64_t key, int n, const int* ws, const int* hs, const u
   if (!host_only_) FDH_HIP(hipSetDevice(device_));
   int rx = 0, ry = 0;
   find_empty_rect(ws[0], hs[0], &rx, &ry);
-  entries_[key] = AtlasEntry{rx, ry, ws[0], hs[0]};
+  entries_[key] = AtlasEntry{rx, ry, ws[0], hs[0], false, {}, {}};
   atlas_epoch_++;
   if (out_rect) { out_rect[0] = rx; out_rect[1] = ry; out_rect[2] = ws[0]; out_rect[3] = hs[0]; }
   sync();
@@ -913,6 +968,9 @@ void Context::draw_image(int64_t key, const float pos[2], const FdhColor colors[
     rr.ext = (uint32_t)(int32_t)(e.x - (int)qx0);   // texel x = pixel x + tdx
     rr._pad = (uint32_t)(int32_t)(e.y - (int)qy0);  // texel y = pixel y + tdy
   }
+  // atlas.frag:284-295: the source alpha is texel alpha x vertex alpha -- 0 wherever all four taps have alpha 0.  (Level 0 only:
+  // a minified image, aux2 > 0, takes its taps from coarser levels.)
+  if (!(recs_.back().aux2 > 0.0f)) shrink_to_ink(e, true, 0);
 }
 
 // drawMsdfImage / drawMtsdfImage: glcontext.nim:1097-1155, drawUvRectAtlasSdf :1022-1093
@@ -936,6 +994,20 @@ void Context::draw_msdf(int64_t key, const float pos[2], FdhColor color, const f
   for (int i = 0; i < 4; i++) r.col[i] = pack_color(color);
   r.aa = aa_;
   emit_quad(r, pos[0], pos[1], pos[0] + size[0], pos[1] + size[1], &fragments_);
+  // atlas.frag:296-318, the fill variants: alpha = clamp(spr (sd - threshold) + 0.5), sd the median of the filtered r, g, b
+  // (MTSDF: the filtered alpha) -- exactly 0 wherever sd <= threshold - 0.5 / spr.  Where all four taps have every channel <= t
+  // the filtered channels, hence their median, are <= t: the box of texels above a level safely below that bound is all the
+  // draw can touch.  (Stroke variants cover a band around the outline whatever sd is beyond it: left alone.)
+  if (!(sw > 0.0f) && !(recs_.back().op_mode & F_GENERAL)) {
+    const DrawRec& rr = recs_.back();
+    const double unit = (double)px_range / (double)S;
+    const double fw_u = std::fabs((double)(rr.r[2] - rr.r[0]) * rr.inv_w), fw_v = std::fabs((double)(rr.r[3] - rr.r[1]) * rr.inv_h);
+    if (fw_u > 0.0 && fw_v > 0.0) {
+      const double spr = std::max(0.5 * (unit / fw_u + unit / fw_v), 1.0);
+      const double cut = (double)sd_threshold - 0.5 / spr - 0.008;  // two 8-bit steps below the bound (the kernel's rcp is good to 1e-7)
+      shrink_to_ink(e, mtsdf, (int)std::floor(cut * 255.0) - 1);
+    }
+  }
 }
 
 // drawQuadraticBezierSdf: glcontext.nim:1619-1741

@@ -76,7 +76,18 @@ struct PinnedBuf {
   }
 };
 
-struct AtlasEntry { int x, y, w, h; };
+// An atlas entry and, when its level-0 texels were seen on the host (fdh_put_image), the bounds of what is IN it: for eight
+// levels t = 0, 16, .. 112 the box (entry-relative texels, x1 / y1 exclusive) of texels whose alpha, and whose largest colour
+// channel, exceeds t.  A draw whose coverage is exactly 0 wherever the sampled value is <= t (a glyph image: alpha 0; an MSDF
+// image: distance below threshold - 0.5 / screen range) shrinks its pixel bounds to the image of that box: the strips outside
+// would blend with alpha 0, which leaves every texel as it is (Context::shrink_to_ink).
+constexpr int kInkLevels = 8;
+struct InkBox { int16_t x0, y0, x1, y1; };
+struct AtlasEntry {
+  int x, y, w, h;
+  bool has_ink = false;
+  InkBox ink_a[kInkLevels], ink_rgb[kInkLevels];
+};
 
 struct Phase {
   int first = 0, count = 0;
@@ -262,6 +273,7 @@ class Context {
   void emit_quad(DrawRec& r, float x0, float y0, float x1, float y1, int64_t* fragments);
   void emit_quad_pts(DrawRec& r, const float vx[4], const float vy[4], int64_t* fragments);
   const AtlasEntry& rect_entry();
+  void shrink_to_ink(const AtlasEntry& e, bool use_alpha, int level_t);
   void upload_atlas_rect(int level, int x, int y, int w, int h, const uint8_t* rgba);
   void put_levels(int x, int y, int w, int h, const uint8_t* rgba);
   void alloc_atlas(int size);

@@ -496,6 +496,79 @@ def test_c_player_drives_the_library_like_the_bindings_do():
     ref.close()
 
 
+def _ink_bounds_frames(out_path):
+    """(child process of test_ink_bounds_change_no_pixel) atlas draws at many scales / thresholds / ranges -> npz of frames"""
+    import os
+
+    from figdraw_amd.context import HipContext
+    from figdraw_amd.scenes import load_glyph_fixture
+
+    imgs = load_glyph_fixture(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "glyphs_ubuntu20.npz"))
+    w, h = 1100, 700
+    ctx = HipContext(atlas_size=1024, device=0)
+    codes = [65, 105, 87, 46, 103, 64, 124, 81]
+    for c in codes:
+        ctx.put_image(1000 + c, imgs[1000 + c])
+        ctx.put_image(2000 + c, imgs[2000 + c])
+    ctx.put_image(3000, imgs[3000])
+    out = {}
+    for case, (subpixel, ox, oy) in enumerate(((False, 0.0, 0.0), (True, 0.37, 0.61), (False, 0.5, 0.25))):
+        ctx.set_text_subpixel(subpixel, 0.0)
+        ctx.begin_frame(w, h, True, (0.93, 0.95, 0.98, 1.0))
+        ctx.draw_rect((0.0, 0.0, float(w), float(h)), (235, 240, 250, 255))
+        y = 6.0 + oy
+        for row, (scale, px_range, thr, mtsdf, flip) in enumerate(((0.6, 4.0, 0.5, False, False), (1.0, 4.0, 0.5, False, False), (1.5, 4.0, 0.5, False, True),
+                                                                   (3.0, 4.0, 0.5, False, False), (2.0, 2.0, 0.4, False, False), (2.0, 8.0, 0.6, False, False),
+                                                                   (1.5, 4.0, 0.5, True, False), (2.5, 4.0, 0.3, True, True), (1.2, 1.0, 0.5, False, False))):
+            x = 5.0 + ox
+            for i, c in enumerate(codes):
+                size = 32.0 * scale
+                ctx.draw_msdf(2000 + c, (x, y), (10 + 20 * i, 60, 200 - 20 * i, 200 + 5 * i), (size, size), px_range, thr, 0.0, mtsdf, flip)
+                if subpixel:
+                    ctx.set_text_subpixel_shift(0.11 * i)
+                ctx.draw_image(1000 + c, (x + size + 2.0, y + 3.0), [(20, 30, 120, 255)] * 2 + [(160, 20, 40, 230)] * 2)   # 1:1 (unless shifted)
+                ctx.draw_image(1000 + c, (x + size + 22.0, y + 1.0), [(0, 0, 0, 255)] * 4, (2.3 * imgs[1000 + c].shape[1], 2.3 * imgs[1000 + c].shape[0]), i % 2 == 1)
+                x += size + 70.0
+            y += 32.0 * scale + 6.0
+        ctx.save_transform()
+        ctx.translate(700.0, 420.0)
+        ctx.scale(1.7, 0.8)
+        for i, c in enumerate(codes):
+            ctx.draw_msdf(2000 + c, (40.0 * i, 0.0), (200, 40, 30, 255), (36.0, 36.0), 4.0, 0.5, 0.0, False, False)
+            ctx.draw_msdf(2000 + c, (40.0 * i, 50.0), (30, 40, 200, 255), (36.0, 36.0), 4.0, 0.5, 1.5, False, False)  # a stroke variant (never shrunk)
+        ctx.restore_transform()
+        ctx.draw_image(3000, (820.0, 500.0), [(255, 255, 255, 255)] * 4, (150.0, 150.0))
+        ctx.end_frame()
+        out[f"frame{case}"] = ctx.read_pixels()
+    ctx.close()
+    np.savez(out_path, **out)
+
+
+def test_ink_bounds_change_no_pixel():
+    """An atlas draw's pixel bounds shrink to the part of its image that can give non-zero coverage (glyph images: alpha > 0; MSDF
+    fills: a distance level safely below threshold - 0.5 / screen range, from boxes measured at fdh_put_image).  Skipped strips would
+    have blended with alpha 0 -- so frames with the shrink (default) and without (FDH_INK_BOUNDS=0) must be the same bit for bit:
+    MSDF / MTSDF at 0.6x .. 3x, three ranges and thresholds, flips, sub-pixel shifts, scaled and 1:1 glyph images, an anisotropic
+    transform, stroke variants beside them."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import test_hip_parity as T; T._ink_bounds_frames(sys.argv[1])" % (os.path.dirname(here), here)
+    with tempfile.TemporaryDirectory() as td:
+        res = {}
+        for tag, env in (("shrunk", {}), ("full", {"FDH_INK_BOUNDS": "0"})):
+            path = os.path.join(td, tag + ".npz")
+            subprocess.check_call([sys.executable, "-c", code, path], env={**os.environ, **env})
+            res[tag] = dict(np.load(path))
+    for k in sorted(res["full"]):
+        a, b = res["shrunk"][k], res["full"][k]
+        assert np.array_equal(a, b), (k, int((a != b).any(axis=2).sum()))
+        assert int((a != a[0, 0]).any(axis=2).sum()) > 20000  # (the frames are not blank)
+
+
 def test_fused_full_frame_blur_equals_the_two_pass_route():
     """A blur node covering the whole frame runs both passes as ONE out-of-place kernel (k_blur_fx), the surfaces alternating
     between phases.  Same sums in the same grouping, the intermediate rounded to RGBA8 as the H pass stores it: the frames must
