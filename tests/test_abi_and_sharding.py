@@ -430,6 +430,11 @@ def test_c_abi_gather_on_one_rank():
     src2.gather_frames(0, [dptr])
     src2.sync()
     assert (dst.read_pixels() == src2.read_pixels()).all()
-    src2.close()
+    # the communicator belongs to whoever still holds it: the context that created it may go first
     src.close()
+    src2.render_frame(sc, w, h)
+    src2.gather_frames(0, [dptr])
+    src2.sync()
+    assert (dst.read_pixels() == src2.read_pixels()).all()
+    src2.close()
     dst.close()
