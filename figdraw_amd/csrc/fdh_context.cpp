@@ -21,7 +21,7 @@ void hip_check(hipError_t e, const char* what) {
 }
 
 static inline float nim_round(float x) { return x >= 0.0f ? std::floor(x + 0.5f) : -std::floor(-x + 0.5f); }  // Nim math.round
-static inline float clampf(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); }
+static inline float clampf(float x, float lo, float hi) { return !(x >= lo) ? lo : (x > hi ? hi : x); }  // (a NaN comes out as lo)
 static inline uint32_t pack_color(FdhColor c) { return (uint32_t)c.r | ((uint32_t)c.g << 8) | ((uint32_t)c.b << 16) | ((uint32_t)c.a << 24); }
 
 static Aff aff_mul(const Aff& m, const Aff& n) {
@@ -875,7 +875,7 @@ void Context::draw_rounded_rect_sdf(const float rect[4], const FdhColor colors[4
                                     float mid_pos) {
   { FDH_REC("draw_rounded_rect_sdf").fv(rect, 4).cols(colors).fv(rx, 4).fv(ry, 4).i(mode).f(factor).f(spread).fv(shape, 2).i(fill_mode).col(mid).col(stop).f(mid_pos); }
   if (!frame_begun_) throw Error(FDH_ERR_INVALID, "ctx.beginFrame has not been called.");
-  if (rect[2] <= 0.0f || rect[3] <= 0.0f) return;
+  if (!(rect[2] > 0.0f) || !(rect[3] > 0.0f)) return;  // (a NaN extent draws nothing)
   if (mode >= FDH_SDF_BEZIER_STROKE_AA) throw Error(FDH_ERR_INVALID, "bezier stroke modes go through drawQuadraticBezierSdf");
   DrawRec r;
   fill_sdf_rec(r, rect, colors, rx, ry, mode, factor, spread, shape, fill_mode, mid, stop, mid_pos, aa_);
@@ -1005,7 +1005,7 @@ void Context::draw_msdf(int64_t key, const float pos[2], FdhColor color, const f
     if (fw_u > 0.0 && fw_v > 0.0) {
       const double spr = std::max(0.5 * (unit / fw_u + unit / fw_v), 1.0);
       const double cut = (double)sd_threshold - 0.5 / spr - 0.008;  // two 8-bit steps below the bound (the kernel's rcp is good to 1e-7)
-      shrink_to_ink(e, mtsdf, (int)std::floor(cut * 255.0) - 1);
+      if (cut > 0.0 && cut <= 1.0) shrink_to_ink(e, mtsdf, (int)std::floor(cut * 255.0) - 1);  // (NaN parameters: no shrink)
     }
   }
 }
@@ -1015,7 +1015,7 @@ void Context::draw_quadratic_bezier_sdf(const float rect[4], const FdhFill& fill
                                         const float p2[2], float stroke_weight, int cap) {
   { FDH_REC("draw_quadratic_bezier_sdf").fv(rect, 4).fill(fill).fv(p0, 2).fv(p1, 2).fv(p2, 2).f(stroke_weight).i(cap); }
   if (!frame_begun_) throw Error(FDH_ERR_INVALID, "ctx.beginFrame has not been called.");
-  if (rect[2] <= 0.0f || rect[3] <= 0.0f || stroke_weight <= 0.0f) return;
+  if (!(rect[2] > 0.0f) || !(rect[3] > 0.0f) || !(stroke_weight > 0.0f)) return;
   DrawRec r;
   std::memset(&r, 0, sizeof r);
   r.p0 = rect[2] * 0.5f; r.p1 = rect[3] * 0.5f; r.p2 = p0[0]; r.p3 = p0[1];  // params = (quadHalf, p0)
@@ -1201,7 +1201,7 @@ static BlurTaps make_taps(float blur_radius) {
 void Context::draw_backdrop_blur(const float rect[4], const float rx[4], const float ry[4], float blur_radius) {
   { FDH_REC("draw_backdrop_blur").fv(rect, 4).fv(rx, 4).fv(ry, 4).f(blur_radius); }
   if (!frame_begun_) throw Error(FDH_ERR_INVALID, "ctx.beginFrame has not been called.");
-  if (blur_radius <= 0.0f || rect[2] <= 0.0f || rect[3] <= 0.0f) return;
+  if (!(blur_radius > 0.0f) || !(rect[2] > 0.0f) || !(rect[3] > 0.0f)) return;  // (written so that a NaN draws nothing)
   const FdhColor white{255, 255, 255, 255}, zero{0, 0, 0, 0};
   const FdhColor cols[4] = {white, white, white, white};
   const float shape[2] = {0, 0};

@@ -329,7 +329,8 @@ struct Walker {
   void drawable_ops(const FdhFig& n) {  // renderDrawableOps :1627-1645
     const V2 origin{n.box[0], n.box[1]};
     const FdhStroke& stroke = n.draw_stroke;
-    for (int oi = n.op_first; oi < n.op_first + n.op_count && oi < scene.n_ops; oi++) {
+    // (ranges into the scene's side arrays are clipped to them: a negative start or a count past the end reads nothing it should not)
+    for (long long oi = std::max(n.op_first, 0); scene.ops && oi < (long long)n.op_first + n.op_count && oi < scene.n_ops; oi++) {
       const FdhDrawOp& op = scene.ops[oi];
       switch (op.kind) {
         case FDH_DK_LINE: line(origin, {op.v[0], op.v[1]}, {op.v[2], op.v[3]}, stroke); break;
@@ -358,7 +359,7 @@ struct Walker {
         }
         case FDH_DK_BEZIER: {  // renderDrawableBezier :1457-1486
           const int nc = op.ctrl_count;
-          if (nc < 2 || op.ctrl_first < 0 || op.ctrl_first + nc > scene.n_controls) break;
+          if (nc < 2 || !scene.controls || op.ctrl_first < 0 || (long long)op.ctrl_first + nc > scene.n_controls) break;
           const float* ctrl = scene.controls + 2 * op.ctrl_first;
           if (stroke.weight <= 0.0f || fill_alpha_max(stroke.fill) == 0) break;
           if (nc == 3) {
@@ -429,7 +430,7 @@ struct Walker {
     }
     // selection rectangles first (:435-452), then underline / strikethrough (:371-415), then the glyphs
     for (int pass = 0; pass < 2; pass++) {
-      for (int k = n.text_rect_first; k < n.text_rect_first + n.text_rect_count && k < scene.n_text_rects; k++) {
+      for (long long k = std::max(n.text_rect_first, 0); scene.text_rects && k < (long long)n.text_rect_first + n.text_rect_count && k < scene.n_text_rects; k++) {
         const FdhTextRect& tr = scene.text_rects[k];
         if (tr.kind != pass) continue;
         if (pass == 0) {
@@ -441,7 +442,7 @@ struct Walker {
         }
       }
     }
-    for (int g = n.glyph_first; g < n.glyph_first + n.glyph_count && g < scene.n_glyphs; g++) {
+    for (long long g = std::max(n.glyph_first, 0); scene.glyphs && g < (long long)n.glyph_first + n.glyph_count && g < scene.n_glyphs; g++) {
       const FdhGlyph& gl = scene.glyphs[g];
       float pos[2] = {gl.x, gl.y};
       const float size[2] = {0, 0};
@@ -468,9 +469,13 @@ struct Walker {
     ctx.restore_transform();
   }
 
+  int depth = 0;
   void node(const FdhLayer& L, int idx) {
     const FdhFig& n = L.nodes[idx];
     if (n.flags & FDH_NF_DISABLE_RENDER) return;
+    // (the walk recurses like the reference's: a chain of thousands of only children would run the thread's stack out)
+    if (depth >= 2048) throw Error(FDH_ERR_UNSUPPORTED, "scene: nodes nested deeper than 2048");
+    struct Deeper { int& d; explicit Deeper(int& x) : d(x) { d++; } ~Deeper() { d--; } } deeper(depth);
     float box[4], rx[4], ry[4];
     box_of(n, box);
     radii(n, rx, ry);
@@ -538,7 +543,7 @@ struct Walker {
 }  // namespace
 
 void Context::render_frame(const FdhScene* scene, float fw, float fh, bool clear, const float rgba[4]) {
-  if (!scene) throw Error(FDH_ERR_INVALID, "render_frame: null scene");
+  if (!scene || (scene->n_layers > 0 && !scene->layers)) throw Error(FDH_ERR_INVALID, "render_frame: null scene");
   const float w = fw * ui_scale_, h = fh * ui_scale_;  // frameSize.scaled()
   if (w <= 0.0f || h <= 0.0f) return;
   begin_frame((int)w, (int)h, clear, rgba);
@@ -548,6 +553,7 @@ void Context::render_frame(const FdhScene* scene, float fw, float fh, bool clear
     Walker wk{*this, *scene, ui_scale_};
     for (int l = 0; l < scene->n_layers; l++) {
       const FdhLayer& L = scene->layers[l];
+      if ((L.n_nodes > 0 && !L.nodes) || (L.n_roots > 0 && !L.root_ids)) throw Error(FDH_ERR_INVALID, "render_frame: a layer's node or root array is null");
       for (int r = 0; r < L.n_roots; r++) {
         const int idx = L.root_ids[r];
         if (idx < 0 || idx >= L.n_nodes) throw Error(FDH_ERR_INVALID, "render_frame: root index out of range");

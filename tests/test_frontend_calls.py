@@ -113,3 +113,66 @@ def test_call_stream_of_the_reference_benchmark_workloads(which, nodes):
     if which == "rect_mask":
         assert sum(1 for c in got if c[0] == "begin_rect_mask") == 1080 and sum(1 for c in got if c[0] == "begin_mask") == 1
     _same(want, got)
+
+
+def test_hostile_scene_fields_are_refused_or_drawn_never_a_crash():
+    """The whole-scene entry reads node arrays and side arrays the caller owns.  Indices and counts that point outside them (negative
+    starts, counts past the end, sums that overflow an int), NaN / infinite geometry, unknown kinds, a chain of only children deeper
+    than the walk's limit: fdh_render_frame returns an error code or records a frame; it does not read outside the arrays (no GPU
+    needed: a FDH_CREATE_RECORD_ONLY context runs the same front-end)."""
+    import random
+
+    from figdraw_amd import context as C_
+    from figdraw_amd.context import HipContext
+    from figdraw_amd.scene import Fig, FigKind, RenderList, Renders, rect, rgba
+
+    rnd = random.Random(3)
+    ctx = HipContext(record_only=True)
+    col = C_._F4(1.0, 1.0, 1.0, 1.0)
+    bad_f = [float("nan"), float("inf"), -float("inf"), 1e30, -1e30, 3.4e38, -5.0, 0.0]
+    bad_i = [-1, -5, -2**31, 2**31 - 1, 2**31 - 5, 10**6, 32767, 65536]
+    outcomes = set()
+    for seed in (1, 2, 3, 4, 5, 6):
+        base = RS.random_scene(seed, 640.0, 360.0, n=40, clips=True, blur=True) if seed % 2 else RS.SWIFTSHADER_SCENES["drawables"][0](640.0, 360.0)
+        for trial in range(60):
+            cs = base.to_c()
+            sc = cs.struct
+            for _ in range(rnd.randrange(1, 6)):
+                L = sc.layers[rnd.randrange(sc.n_layers)]
+                if L.n_nodes == 0:
+                    continue
+                n = L.nodes[rnd.randrange(L.n_nodes)]
+                what = rnd.randrange(12)
+                if what == 0: n.glyph_first, n.glyph_count = rnd.choice(bad_i), rnd.choice(bad_i)
+                elif what == 1: n.op_first, n.op_count = rnd.choice(bad_i), rnd.choice(bad_i)
+                elif what == 2: n.text_rect_first, n.text_rect_count = rnd.choice(bad_i), rnd.choice(bad_i)
+                elif what == 3: n.child_count = rnd.choice(bad_i)
+                elif what == 4: n.parent = rnd.choice(bad_i)
+                elif what == 5: n.kind = rnd.choice(bad_i)
+                elif what == 6: n.box[rnd.randrange(4)] = rnd.choice(bad_f)
+                elif what == 7: n.rotation = rnd.choice(bad_f)
+                elif what == 8: n.blur = rnd.choice(bad_f); n.shadows[0].blur = rnd.choice(bad_f); n.shadows[0].spread = rnd.choice(bad_f)
+                elif what == 9: n.stroke.weight = rnd.choice(bad_f); n.draw_stroke.weight = rnd.choice(bad_f)
+                elif what == 10 and L.n_roots > 0: L.root_ids[rnd.randrange(L.n_roots)] = rnd.choice(bad_i)
+                elif what == 11 and sc.n_ops > 0:
+                    op = sc.ops[rnd.randrange(sc.n_ops)]
+                    op.ctrl_first, op.ctrl_count = rnd.choice(bad_i), rnd.choice(bad_i)
+            rc = ctx.L.fdh_render_frame(ctx.h, cs.byref(), 640.0, 360.0, 1, col)
+            outcomes.add(rc == 0)
+    assert outcomes == {True, False}  # some frames were recorded, some refused
+    # a chain of only children deeper than the walk's limit is refused with an error, a shallower one is walked
+    for depth, ok in ((1500, True), (5000, False)):
+        lst = RenderList()
+        idx = lst.addRoot(Fig(kind=FigKind.nkRectangle, screenBox=rect(0, 0, 10, 10), fill=rgba(1, 2, 3, 255)))
+        for _ in range(depth):
+            idx = lst.addChild(idx, Fig(kind=FigKind.nkRectangle, screenBox=rect(0, 0, 10, 10), fill=rgba(1, 2, 3, 255)))
+        r = Renders()
+        r.setLayer(0, lst)
+        rc = ctx.L.fdh_render_frame(ctx.h, r.to_c().byref(), 64.0, 64.0, 1, col)
+        assert (rc == 0) == ok, (depth, rc)
+    # and the context still records a normal frame
+    ctx.record_begin()
+    ctx.render_frame(RS.nested_clips(640.0, 360.0), 640, 360)
+    calls = ctx.record_calls()
+    assert calls[0][0] == "begin_frame" and calls[-1][0] == "end_frame"
+    ctx.close()

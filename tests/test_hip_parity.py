@@ -569,6 +569,20 @@ def test_ink_bounds_change_no_pixel():
         assert int((a != a[0, 0]).any(axis=2).sum()) > 20000  # (the frames are not blank)
 
 
+def test_hostile_arguments_never_crash_or_hang():
+    """tools/abuse.py: NaN, infinities, 1e30, negative and zero sizes, huge blur radii, 1-pixel and 8192-wide frames, missing images,
+    unbalanced masks through the per-call entry points.  Every call returns (an error code or a frame), nothing crashes or hangs,
+    and the context renders a normal frame bit for bit afterwards.  (A NaN blur radius once walked the tap table off its end.)"""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for seed in ("11", "23"):
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "abuse.py"), "150"], env={**os.environ, "SEED": seed}, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and "still renders correctly" in r.stdout, (seed, r.returncode, r.stdout[-600:], r.stderr[-1200:])
+
+
 def test_fused_full_frame_blur_equals_the_two_pass_route():
     """A blur node covering the whole frame runs both passes as ONE out-of-place kernel (k_blur_fx), the surfaces alternating
     between phases.  Same sums in the same grouping, the intermediate rounded to RGBA8 as the H pass stores it: the frames must
