@@ -687,8 +687,21 @@ void Context::compact_side() {
   R.glyphs.swap(glyphs); R.variant_ids.swap(variants); R.ops.swap(ops); R.controls.swap(controls); R.text_rects.swap(rects);
 }
 
+// A retained layer is edited in place (subtrees compacted out, parents remapped): every parent index it holds must be -1 or
+// that of an EARLIER node (parents precede their children in a RenderList, fignodes.nim:119-163).
+static void check_parents(const FdhFig* nodes, int n, int first_index, const char* who) {
+  for (int k = 0; k < n; k++)
+    if (nodes[k].parent < -1 || nodes[k].parent >= first_index + k) throw Error(FDH_ERR_INVALID, std::string(who) + ": a node's parent must be -1 or an earlier node of the layer");
+}
+
 void Context::scene_retain(const FdhScene* scene, float fw, float fh, bool clear, const float rgba[4]) {
-  if (!scene) throw Error(FDH_ERR_INVALID, "scene_retain: null scene");
+  if (!scene || (scene->n_layers > 0 && !scene->layers)) throw Error(FDH_ERR_INVALID, "scene_retain: null scene");
+  for (int l = 0; l < scene->n_layers; l++) {
+    const FdhLayer& L = scene->layers[l];
+    if ((L.n_nodes > 0 && !L.nodes) || (L.n_roots > 0 && !L.root_ids)) throw Error(FDH_ERR_INVALID, "scene_retain: a layer's node or root array is null");
+    if (L.n_nodes > 32767) throw Error(FDH_ERR_INVALID, "scene_retain: more than 32767 nodes in a layer (FigIdx is int16, fignodes.nim:119)");
+    check_parents(L.nodes, L.n_nodes, 0, "scene_retain");
+  }
   RetainedScene& R = retained_;
   R = RetainedScene{};
   R.fw = fw; R.fh = fh; R.clear = clear;
@@ -729,6 +742,7 @@ void Context::scene_update_nodes(int layer, int first, int count, const FdhFig* 
   RetainedLayer& D = R.layers[(size_t)layer];
   if (count <= 0) return;
   if (!nodes || first < 0 || (size_t)first + (size_t)count > D.nodes.size()) throw Error(FDH_ERR_INVALID, "scene_update_nodes: node range out of bounds");
+  check_parents(nodes, count, first, "scene_update_nodes");
   // the roots above the range before the edit (a node may change its parent) ...
   std::vector<int> before = roots_of(D);
   std::vector<FdhFig> fresh(nodes, nodes + count);

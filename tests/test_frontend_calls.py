@@ -176,3 +176,50 @@ def test_hostile_scene_fields_are_refused_or_drawn_never_a_crash():
     calls = ctx.record_calls()
     assert calls[0][0] == "begin_frame" and calls[-1][0] == "end_frame"
     ctx.close()
+
+
+def test_hostile_retained_scene_edits_are_refused_not_crashed():
+    """fdh_scene_update_nodes / replace_root / insert_root edit a tree the library keeps: layers, slots and node ranges outside it,
+    parents that point forward or past the end, subtrees whose shape lies about itself.  Every call returns; the scene stays
+    renderable.  (A node updated to a parent index past the array once sent the next replace_root reading outside its remap table.)"""
+    import copy
+    import random
+
+    from figdraw_amd.context import FigdrawHipError
+    from figdraw_amd.scene import Fig, FigKind, rect, rgba
+
+    bad_i = [-1, -5, -2**31, 2**31 - 1, 10**6, 32767, 65536, 0, 1, 2, 5, 39, 40, 41]
+    for seed in (5, 6):
+        rnd = random.Random(seed)
+        ctx = HipContext(record_only=True)
+        base = RS.random_scene(7, 640.0, 360.0, n=40, clips=True, blur=True)
+        nodes = base.layers[0].nodes
+        ctx.scene_retain(base, 640, 360)
+        ok = refused = 0
+        for it in range(1200):
+            op = rnd.randrange(3)
+            try:
+                if op == 0:
+                    figs = [copy.deepcopy(nodes[rnd.randrange(len(nodes))]) for _ in range(rnd.randrange(1, 4))]
+                    for f in figs:
+                        if rnd.random() < 0.3:
+                            f.parent = rnd.choice(bad_i)
+                        if rnd.random() < 0.3:
+                            f.childCount = rnd.choice([0, 1, 5, 32767, -3])
+                    ctx.scene_update_nodes(rnd.choice([0, 0, 0, 1, -1, 99]), rnd.choice(bad_i), figs)
+                else:
+                    sub = [Fig(kind=FigKind.nkRectangle, screenBox=rect(5, 5, 50, 40), fill=rgba(9, 9, 9, 255))]
+                    if rnd.random() < 0.5:
+                        sub.append(Fig(kind=FigKind.nkRectangle, screenBox=rect(8, 8, 20, 20), fill=rgba(200, 9, 9, 255), parent=rnd.choice([0, 0, 1, -1, 7, -9])))
+                        sub[0].childCount = rnd.choice([1, 1, 0, 9])
+                    if op == 1:
+                        ctx.scene_replace_root(rnd.choice([0, 0, 3, -1]), rnd.choice(bad_i), sub if rnd.random() < 0.8 else [])
+                    else:
+                        ctx.scene_insert_root(rnd.choice([0, 0, 3, -1]), rnd.choice(bad_i), sub)
+                ctx.scene_render()
+                ok += 1
+            except FigdrawHipError:
+                refused += 1
+        assert ok > 100 and refused > 100
+        ctx.scene_render()
+        ctx.close()
