@@ -470,6 +470,22 @@ struct Walker {
   }
 
   int depth = 0;
+  // first_child[i] / next_sibling[i]: the nodes whose parent is i, in index order (a parent precedes its children: a node that
+  // names a later node, or none, is nobody's child -- exactly what the forward scan finds)
+  const FdhLayer* linked = nullptr;
+  std::vector<int> first_child, next_sibling, last_child;
+  void children_of(const FdhLayer& L) {
+    if (linked == &L) return;
+    linked = &L;
+    const size_t n = (size_t)std::max(L.n_nodes, 0);
+    first_child.assign(n, -1); next_sibling.assign(n, -1); last_child.assign(n, -1);
+    for (size_t i = 0; i < n; i++) {
+      const int p = L.nodes[i].parent;
+      if (p < 0 || (size_t)p >= i) continue;
+      if (last_child[(size_t)p] < 0) first_child[(size_t)p] = (int)i; else next_sibling[(size_t)last_child[(size_t)p]] = (int)i;
+      last_child[(size_t)p] = (int)i;
+    }
+  }
   void node(const FdhLayer& L, int idx) {
     const FdhFig& n = L.nodes[idx];
     if (n.flags & FDH_NF_DISABLE_RENDER) return;
@@ -530,9 +546,14 @@ struct Walker {
       default: break;  // nkFrame / nkScrollBar / nkTransform draw nothing themselves
     }
     if (n.kind == FDH_NK_RECTANGLE) inner_shadows(n);
-    int seen = 0;  // childIndex fignodes.nim:165-177: scan forward for nodes whose parent is this one
-    for (int i = idx + 1; i < L.n_nodes && seen < n.child_count; i++)
-      if (L.nodes[i].parent == idx) { seen++; node(L, i); }
+    // childIndex fignodes.nim:165-177 scans forward for the nodes whose parent is this one, the first childCount of them.  The
+    // same nodes in the same order come out of sibling links built in one pass per layer (children_of): a parent of a thousand
+    // children -- a table's viewport -- otherwise strides over all its grandchildren to find them, a few MB of node structs.
+    if (n.child_count > 0) {
+      children_of(L);
+      int seen = 0;
+      for (int i = first_child[(size_t)idx]; i >= 0 && seen < n.child_count; i = next_sibling[(size_t)i]) { seen++; node(L, i); }
+    }
     if (rmask) ctx.pop_rect_mask();
     if (clip) ctx.pop_mask();
     if (xf) ctx.restore_transform();
