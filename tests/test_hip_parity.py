@@ -583,6 +583,19 @@ def test_hostile_arguments_never_crash_or_hang():
         assert r.returncode == 0 and "still renders correctly" in r.stdout, (seed, r.returncode, r.stdout[-600:], r.stderr[-1200:])
 
 
+def test_contexts_on_several_host_threads():
+    """tools/thread_churn.py: four host threads each create, use and destroy contexts of their own at the same time (frames of
+    several sizes, submit thread on and off, reads at arbitrary points).  A handle is single-threaded, different handles are
+    independent: every frame must equal the one a lone context renders."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "thread_churn.py"), "4", "8"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and ": 0 wrong" in r.stdout, (r.returncode, r.stdout[-600:], r.stderr[-1200:])
+
+
 def test_fused_full_frame_blur_equals_the_two_pass_route():
     """A blur node covering the whole frame runs both passes as ONE out-of-place kernel (k_blur_fx), the surfaces alternating
     between phases.  Same sums in the same grouping, the intermediate rounded to RGBA8 as the H pass stores it: the frames must
