@@ -497,7 +497,10 @@ void Context::update_image(int64_t key, int w, int h, const uint8_t* rgba) {  //
   auto it = entries_.find(key);
   if (it == entries_.end()) throw Error(FDH_ERR_INVALID, "update_image: unknown key");
   if (it->second.w != w || it->second.h != h) throw Error(FDH_ERR_INVALID, "update_image: size mismatch");
+  if (!rgba) throw Error(FDH_ERR_INVALID, "update_image: null image");
   sync();
+  measure_ink(it->second, rgba);  // the new texels have bounds of their own (draws shrink to them: shrink_to_ink) ...
+  atlas_epoch_++;                 // ... and records cached for retained scenes hold the old ones
   put_levels(it->second.x, it->second.y, w, h, rgba);
 }
 

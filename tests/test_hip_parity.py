@@ -563,6 +563,26 @@ def test_ink_bounds_change_no_pixel():
             path = os.path.join(td, tag + ".npz")
             subprocess.check_call([sys.executable, "-c", code, path], env={**os.environ, **env})
             res[tag] = dict(np.load(path))
+    # an image updated in place brings its own bounds: a glyph with little ink replaced by a full one is drawn whole
+    from figdraw_amd.context import HipContext
+    from figdraw_amd.scenes import load_glyph_fixture
+
+    imgs = load_glyph_fixture(os.path.join(here, "golden", "glyphs_ubuntu20.npz"))
+    thin = imgs[2000 + 105].copy()                      # MSDF 'i'
+    full = np.full_like(thin, 255)
+    frames = []
+    for first in (thin, full):
+        c = HipContext(atlas_size=256, device=0)
+        c.put_image(9, first)
+        if first is thin:
+            c.update_image(9, full)
+        c.begin_frame(200, 120, True, (1.0, 1.0, 1.0, 1.0))
+        c.draw_msdf(9, (20.0, 10.0), (200, 30, 30, 255), (96.0, 96.0), 4.0, 0.5, 0.0, False, False)
+        c.draw_image(9, (130.0, 10.0), [(0, 0, 0, 255)] * 4, (64.0, 64.0))
+        c.end_frame()
+        frames.append(c.read_pixels())
+        c.close()
+    assert np.array_equal(frames[0], frames[1]), int((frames[0] != frames[1]).any(axis=2).sum())
     for k in sorted(res["full"]):
         a, b = res["shrunk"][k], res["full"][k]
         assert np.array_equal(a, b), (k, int((a != b).any(axis=2).sum()))
