@@ -1492,6 +1492,21 @@ void Context::prepare(LaunchJob& J) {
     J.staging_slot = slot;
     uint8_t* s = staging_[slot].ptr;
     if (b_recs) std::memcpy(s + o_recs, recs_.data(), b_recs);
+    {  // The device's copy of a one-colour upright SDF draw carries the colour once more as three floats, c / 255, in the slots of
+       // the three redundant vertex colours: the compositor's uniform-blend and packed edge paths (the only readers: LE_PLAIN and
+       // the path codes are given to exactly these records below) take them as they are instead of converting and scaling three
+       // bytes per strip.  The same IEEE product the kernels formed (one multiply by the float 1 / 255): bit-identical frames.
+      DrawRec* dr = reinterpret_cast<DrawRec*>(s + o_recs);
+      const float inv255 = 1.0f / 255.0f;
+      for (size_t i = 0; i < n; i++) {
+        const uint32_t om = dr[i].op_mode, mode = om & 255u;
+        const bool atlas_mode = mode == 0u || (mode >= 13u && mode <= 16u);
+        if ((om & F_GENERAL) || atlas_mode || mode >= 18u || ((om >> 12) & 15u) != OP_DRAW || !(om & F_SOLID)) continue;
+        const uint32_t c = dr[i].col[0];
+        const float u[3] = {(float)(c & 255u) * inv255, (float)((c >> 8) & 255u) * inv255, (float)((c >> 16) & 255u) * inv255};
+        std::memcpy(&dr[i].col[1], u, sizeof u);
+      }
+    }
     if (b_ext) std::memcpy(s + o_ext, exts_.data(), b_ext);
     {  // what the bin kernel reads of a draw: bounds, saturated core, and the bin-independent part of its list entries
       BinRec* br = reinterpret_cast<BinRec*>(s + o_bb);

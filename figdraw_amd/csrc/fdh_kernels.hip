@@ -1057,7 +1057,7 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? 4 : kPaths == 4 ? FDH_UNIFORM_WA
     };
     // r: the run's geometry (quad, radii, AA factor, bounds); m_*: the draw's own sdfParams.zw, sdfFactors and colour
     auto edge_blend = [&](const DrawRec& r, const uint32_t mode, const bool ellip, const float m_p2, const float m_p3, const float m_f0, const float m_f1,
-                          const uint32_t m_col, const f2 lxa, const f2 lxb, const float pyy, const f2 da, const f2 db, F4& A0, F4& A1, F4& A2, F4& A3) __attribute__((always_inline)) {
+                          const u32x4 m_col, const f2 lxa, const f2 lxb, const float pyy, const f2 da, const f2 db, F4& A0, F4& A1, F4& A2, F4& A3) __attribute__((always_inline)) {
       f2 ala, alb;  // coverage
       if (mode == 3u) {
         ala = {cover_aa(da.x, r.aa), cover_aa(da.y, r.aa)}; alb = {cover_aa(db.x, r.aa), cover_aa(db.y, r.aa)};
@@ -1095,14 +1095,13 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? 4 : kPaths == 4 ? FDH_UNIFORM_WA
       // coverage of the quad: unsigned (x - bx0) < width, width 0 on rows outside it
       const uint32_t xrel = (uint32_t)(px0 - (int)r.bx0);
       const uint32_t wcov = (py >= r.by0 && py < r.by1) ? (uint32_t)((int)r.bx1 - (int)r.bx0) : 0u;
-      const F4 c0u = unpack255(m_col);
-      const float cw = c0u.w * inv255;
+      const float cw = (float)(m_col.x >> 24) * inv255;  // (m_col: the draw's colour and, as floats, its r, g, b / 255: Context::prepare)
       f2 saa = ala * cw, sab = alb * cw;
       saa.x = xrel < wcov ? saa.x : 0.0f; saa.y = xrel + 1u < wcov ? saa.y : 0.0f;
       sab.x = xrel + 2u < wcov ? sab.x : 0.0f; sab.y = xrel + 3u < wcov ? sab.y : 0.0f;
       const f2 Aa = saa * 255.0f, Ab = sab * 255.0f, iaa = 1.0f - saa, iab = 1.0f - sab;
-      const f2 crg = {c0u.x * inv255, c0u.y * inv255};
-      const float cb = c0u.z * inv255;
+      const f2 crg = {__uint_as_float(m_col.y), __uint_as_float(m_col.z)};
+      const float cb = __uint_as_float(m_col.w);
       { const f2 b1 = {cb, 1.0f}; blend_pre(A0, crg * Aa.x, b1 * Aa.x, iaa.x); blend_pre(A1, crg * Aa.y, b1 * Aa.y, iaa.y);
         blend_pre(A2, crg * Ab.x, b1 * Ab.x, iab.x); blend_pre(A3, crg * Ab.y, b1 * Ab.y, iab.y); }
     };
@@ -1111,7 +1110,7 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? 4 : kPaths == 4 ? FDH_UNIFORM_WA
       f2 lxa, lxb, da, db;
       float pyy;
       edge_geom(r, mode == 9u, ellip, lxa, lxb, pyy, da, db);
-      edge_blend(r, mode, ellip, r.p2, r.p3, r.f0, r.f1, r.col[0], lxa, lxb, pyy, da, db, A0, A1, A2, A3);
+      edge_blend(r, mode, ellip, r.p2, r.p3, r.f0, r.f1, u32x4{r.col[0], r.col[1], r.col[2], r.col[3]}, lxa, lxb, pyy, da, db, A0, A1, A2, A3);
     };
 #endif
     // One draw = one lambda call.  The record of the NEXT surviving draw is fetched (scalar loads) before the
@@ -1608,9 +1607,11 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? 4 : kPaths == 4 ? FDH_UNIFORM_WA
       if (unclipped && (m_plainc & one) != 0ull) {
         // One colour, coverage 1, nothing clipping: the whole strip gets the same source term.  Only the colour is
         // fetched (4 bytes instead of the 128-byte record) and nothing of the record is decoded.
-        const F4 c0 = unpack255(draws[d].col[0]);
-        const float sa = c0.w * inv255, A = 255.0f * sa, ia = 1.0f - sa;
-        const f2 c_rg = {c0.x * inv255 * A, c0.y * inv255 * A}, c_ba = {c0.z * inv255 * A, A};
+        // (col[1..3] of such a record hold c / 255 as floats: Context::prepare)
+        u32x4 c4 = *reinterpret_cast<const u32x4*>(draws[d].col);
+        asm volatile("" : "+s"(c4));
+        const float sa = (float)(c4.x >> 24) * inv255, A = 255.0f * sa, ia = 1.0f - sa;
+        const f2 c_rg = {__uint_as_float(c4.y) * A, __uint_as_float(c4.z) * A}, c_ba = {__uint_as_float(c4.w) * A, A};
         blend_pre(F0, c_rg, c_ba, ia); blend_pre(F1, c_rg, c_ba, ia); blend_pre(F2, c_rg, c_ba, ia); blend_pre(F3, c_rg, c_ba, ia);
         touched = true;
         FDH_COUNT(35);
@@ -1647,7 +1648,7 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? 4 : kPaths == 4 ? FDH_UNIFORM_WA
           f2 lxa, lxb, da, db;
           float pyy;
           edge_geom(r, mode == 9u, ellip, lxa, lxb, pyy, da, db);
-          edge_blend(r, mode, ellip, r.p2, r.p3, r.f0, r.f1, r.col[0], lxa, lxb, pyy, da, db, F0, F1, F2, F3);
+          edge_blend(r, mode, ellip, r.p2, r.p3, r.f0, r.f1, u32x4{r.col[0], r.col[1], r.col[2], r.col[3]}, lxa, lxb, pyy, da, db, F0, F1, F2, F3);
           // The draws that follow over the same quad and shape (the node's stroke, its inner shadows: LE_SHARE on the entry of
           // the draw before them) reuse the field: their entries are taken off the list here.  All conditions are wave-uniform.
           uint32_t wcur = word, dcur = d;
@@ -1663,7 +1664,7 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? 4 : kPaths == 4 ? FDH_UNIFORM_WA
             // the member's own parameters: sdfParams.zw + sdfFactors (16 bytes at offset 32) and its colour (offset 64)
             const u32x4* __restrict__ mp = reinterpret_cast<const u32x4*>(draws + dcur);
             u32x4 q = mp[2];
-            uint32_t mcol = reinterpret_cast<const uint32_t*>(draws + dcur)[16];
+            u32x4 mcol = mp[4];
             asm volatile("" : "+s"(q), "+s"(mcol));
             const uint32_t c42 = (code2 - 1u) & 3u;
             const uint32_t mode2 = c42 == 0u ? 3u : c42 == 1u ? 7u : c42 == 2u ? 9u : 12u;
