@@ -230,6 +230,7 @@ def main():
     ap.add_argument("--all-ranks-on-device0", action="store_true", help="self-test of the N>1 code path on a 1-GPU box")
     ap.add_argument("--frames-in-flight", type=int, default=4,
                     help="independent render contexts per GPU (own stream + surfaces) whose frames overlap; 1 = strictly one frame at a time")
+    ap.add_argument("--host-threads", type=int, default=0, help="host threads driving the contexts of `value` (0 = one per context in flight)")
     ap.add_argument("--gather", choices=["c_abi", "torch"], default="c_abi",
                     help="who issues the gather: the library's own fdh_gather_* (RCCL through the C ABI, stream-ordered) or torch.distributed "
                          "(always used with --backend gloo)")
@@ -321,9 +322,27 @@ def main():
     # ---- THE PATH (`value`): scene tree in -> pixels out, every frame: fdh_render_frame = C++ tree walk + draw-record build +
     # upload + binning + both blurs + compositing, frame k of the animation on context k % F.  What the reference's benchmark
     # times per frame (examples/windy_non_clip_benchmark.nim:113-147: renderFrame(renders, frameSize)).
-    def run_dynamic(n):
-        player.play_scenes(ctxs, cscenes, n, w, h)
+    # Who drives the contexts.  One calling thread walking every context's trees in turn (the reference's render loop, once per
+    # window) or one host thread per context (an application with several windows): on a quiet host the single thread's even
+    # round-robin interleaves the contexts' kernels slightly better, on a busy one its ~50 us of tree walk per frame fall behind
+    # the GPU's rate and a thread per context is faster (profiles/README.md).  --host-threads 0 (default) tries both on untimed
+    # batches and times the run with the faster; the line says which (`host_threads_per_gpu`, `host_threads_calibration`).
+    def make_run(threads):
+        def run(n):
+            player.play_scenes(ctxs, cscenes, n, w, h, threads=threads)
+        return run
 
+    calibration = None
+    if args.host_threads > 0:
+        T = max(1, min(args.host_threads, F))
+    else:
+        calibration = {}
+        for cand in sorted({1, F}):
+            fn = make_run(cand)
+            fn(args.warmup)
+            calibration[str(cand)] = round(1e3 * min(timed(fn, args.steps) for _ in range(2)), 4)  # (max over ranks inside timed)
+        T = int(min(calibration, key=lambda k: calibration[k]))
+    run_dynamic = make_run(T)
     run_dynamic(args.warmup)
     elapsed, batch_ms = batches(run_dynamic, args.steps, args.repeats)
     # Integrity of the frames-in-flight mode (outside the timed region): every context must hold exactly the frame it
@@ -671,7 +690,8 @@ def main():
         "timing": f"median of {args.repeats} timed batches of exactly {args.steps} frames each, every batch bracketed by barrier + synchronize "
                   "(`batches_ms`: all of them, sorted); `value` = pixels of one batch / the median batch's wall time",
         "step": "one frame through fdh_render_frame: scene tree in -> RGBA8 surface out (C++ tree walk, draw records, upload, binning, both blurs, "
-                "compositing), frame k of the animation on context k % frames_in_flight; the loop is C (tools/call_player.c)",
+                "compositing), frame k of the animation on context k % frames_in_flight; the loop is C (tools/call_player.c), on one calling thread or "
+                "one host thread per context, whichever an untimed calibration found faster on this host (config.host_threads_per_gpu)",
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
@@ -680,9 +700,10 @@ def main():
         "config": {"workload": f"S300@4K: renderlist_100 scene at {w}x{h}, 300 shadowed SDF rects + full-frame and 360x240 "
                                f"2-pass Gaussian backdrop blur(18) (BASELINE.json configs[2])",
                    "draws": st.n_draws, "phases": st.n_phases, "blur_nodes": st.n_blurs, "fragments": int(st.fragments),
-                   "parallelism": f"frame-parallel x{world}" if world > 1 else "single GPU", "frames_in_flight_per_gpu": F},
+                   "parallelism": f"frame-parallel x{world}" if world > 1 else "single GPU", "frames_in_flight_per_gpu": F, "host_threads_per_gpu": T},
         "frames_in_flight_check": {"contexts": F, "identical_to_each_frame_rendered_alone": in_flight_differing == 0,
                                    "pixels_differing": in_flight_differing, "in_flight_frame_vs_oracle": in_flight_vs_oracle},
+        "host_threads_calibration": calibration,
         "per_call_path": per_call,
         "replay_resident_records": replay,
         "one_frame_at_a_time": {"value": round(w * h * args.steps / sd_elapsed / 1e6, 1), "unit": "Mpixels/s (this rank)",
