@@ -258,7 +258,10 @@ void Context::put_levels(int x, int y, int w, int h, const uint8_t* rgba) {
 }
 // the ink boxes of an image whose texels the host holds (AtlasEntry): one pass, sixteen running boxes
 static void measure_ink(AtlasEntry& e, const uint8_t* rgba) {
-  if (e.w > 32767 || e.h > 32767) return;
+  // Glyph- and icon-sized images only (a 48 x 48 MSDF cell, a 20 px glyph): that is where a draw covers a fraction of its quad, and
+  // the pass stays in the microseconds.  A photograph is opaque to its edges and would cost a pass over megapixels for nothing.
+  e.has_ink = false;
+  if (e.w > 128 || e.h > 128) return;
   for (int k = 0; k < kInkLevels; k++) e.ink_a[k] = e.ink_rgb[k] = InkBox{32767, 32767, 0, 0};
   auto grow = [](InkBox& b, int x, int y) {
     b.x0 = (int16_t)std::min<int>(b.x0, x); b.y0 = (int16_t)std::min<int>(b.y0, y);
@@ -268,8 +271,12 @@ static void measure_ink(AtlasEntry& e, const uint8_t* rgba) {
     const uint8_t* row = rgba + (size_t)y * e.w * 4;
     for (int x = 0; x < e.w; x++) {
       const int a = row[4 * x + 3], m = std::max<int>(row[4 * x], std::max<int>(row[4 * x + 1], row[4 * x + 2]));
-      for (int k = 0; k < kInkLevels && a > 16 * k; k++) grow(e.ink_a[k], x, y);
-      for (int k = 0; k < kInkLevels && m > 16 * k; k++) grow(e.ink_rgb[k], x, y);
+      // levels the value exceeds: t = 0, 16, .. below it.  The boxes are nested (level k's holds level k + 1's): a texel inside
+      // the highest one it counts for is inside them all.
+      const int la = std::min((a + 15) >> 4, kInkLevels), lm = std::min((m + 15) >> 4, kInkLevels);
+      auto inside = [&](const InkBox& b) { return x >= b.x0 && x < b.x1 && y >= b.y0 && y < b.y1; };
+      if (la > 0 && !inside(e.ink_a[la - 1])) for (int k = 0; k < la; k++) grow(e.ink_a[k], x, y);
+      if (lm > 0 && !inside(e.ink_rgb[lm - 1])) for (int k = 0; k < lm; k++) grow(e.ink_rgb[k], x, y);
     }
   }
   for (int k = 0; k < kInkLevels; k++) {  // nothing above the level: an empty box at the origin
