@@ -46,7 +46,7 @@ class FrameStats(C.Structure):
 def build(force: bool = False) -> str:
     """hipcc --offload-arch=gfx950 the C-ABI library in-tree (cross-compiles without a GPU)."""
     csrc = os.path.join(_HERE, "csrc")
-    args = ["make", "-C", csrc, "-s"]
+    args = ["make", "-C", csrc, "-s", "-j8"]
     if force:
         args.append("-B")
     subprocess.check_call(args)
@@ -127,6 +127,8 @@ def load():
     L.fdh_render_frame.argtypes = [vp, vp, C.c_float, C.c_float, C.c_int, _F4]
     L.fdh_set_stripe.argtypes = [vp, C.c_int, C.c_int]
     L.fdh_set_blur_route.argtypes = [vp, C.c_int]
+    L.fdh_set_cull.argtypes = [vp, C.c_int]
+    L.fdh_culled_draws.argtypes = [vp, C.POINTER(C.c_int64)]
     L.fdh_stripe_rows.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.fdh_comm_unique_id.argtypes = [C.c_char_p]
     L.fdh_comm_init.argtypes = [vp, C.c_char_p, C.c_int, C.c_int]
@@ -445,6 +447,16 @@ class HipContext:
     # ---- multi-GPU / measurement
     def set_stripe(self, y0: int, y1: int):
         self._ck(self.L.fdh_set_stripe(self.h, int(y0), int(y1)))
+
+    def set_cull(self, mode: int):
+        """0: record every draw; 1 (default): drop draws / clipped subtrees no produced pixel lies under, except while the call
+        recorder runs; 2: also then.  Same pixels either way."""
+        self._ck(self.L.fdh_set_cull(self.h, int(mode)))
+
+    def culled_draws(self) -> int:
+        out = C.c_int64()
+        self._ck(self.L.fdh_culled_draws(self.h, C.byref(out)))
+        return out.value
 
     def set_blur_route(self, route: int):
         """full-frame blur nodes: 1 fused kernel, 0 two passes, -1 decided per frame (same pixels either way)"""

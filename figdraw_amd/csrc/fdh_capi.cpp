@@ -257,6 +257,13 @@ int fdh_gather_stripes(FdhContext* c, int dst_rank, void* dst_image) { return gu
 int fdh_gather_frames(FdhContext* c, int dst_rank, void* const* dst_images) { return guard([&] { C(c)->gather_frames(dst_rank, dst_images); }); }
 int fdh_set_blur_route(FdhContext* c, int route) { return guard([&] { C(c)->set_blur_route(route); }); }
 int fdh_set_stripe(FdhContext* c, int y0, int y1) { return guard([&] { C(c)->set_stripe(y0, y1); }); }
+int fdh_set_cull(FdhContext* c, int mode) { return guard([&] { C(c)->set_cull(mode); }); }
+int fdh_culled_draws(FdhContext* c, int64_t* out) {
+  return guard([&] {
+    if (!out) throw fdh::Error(FDH_ERR_INVALID, "null output");
+    *out = C(c)->culled_draws();
+  });
+}
 int fdh_replay(FdhContext* c, int times) { return guard([&] { C(c)->replay(times); }); }
 int fdh_replay_async(FdhContext* c, int times) { return guard([&] { C(c)->replay_async(times); }); }
 int fdh_replay_timed(FdhContext* c, int times, float* ms_out) { return guard([&] { C(c)->replay_timed(times, ms_out); }); }

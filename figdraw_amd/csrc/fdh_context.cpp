@@ -521,8 +521,9 @@ void Context::update_image(int64_t key, int w, int h, const uint8_t* rgba) {  //
 namespace {
 struct Rec {
   std::string& s; bool& first; const bool on;
-  Rec(std::string& s_, bool& first_, bool on_, const char* name) : s(s_), first(first_), on(on_) {
+  Rec(std::string& s_, bool& first_, bool on_, const char* name, size_t* mark, bool* mark_first) : s(s_), first(first_), on(on_) {
     if (!on) return;
+    *mark = s.size(); *mark_first = first;  // (a call that turns out to be culled is taken back: Context::rec_drop_last)
     s += first ? "[\"" : ",\n[\""; s += name; s += "\""; first = false;
   }
   ~Rec() { if (on) s += "]"; }
@@ -553,7 +554,9 @@ struct RecPause {  // a backend method that calls other backend methods records 
   explicit RecPause(bool& o) : on(o), was(o) { on = false; }
   ~RecPause() { on = was; }
 };
-#define FDH_REC(name) Rec rec_scope_(rec_, rec_first_, rec_on_, name); rec_scope_
+#define FDH_REC(name) Rec rec_scope_(rec_, rec_first_, rec_on_, name, &rec_mark_, &rec_mark_first_); rec_scope_
+// cull mode 2 (culling while the recorder runs): the draw call just recorded left no record -- it leaves no entry either
+#define FDH_CULLED() do { culled_draws_++; if (rec_on_) { rec_.resize(rec_mark_); rec_first_ = rec_mark_first_; } } while (0)
 void Context::record_begin() { rec_on_ = true; rec_first_ = true; rec_ = "["; }
 const char* Context::record_json() {
   if (!rec_on_) return "[]";
@@ -633,6 +636,15 @@ void Context::begin_frame(int w, int h, bool clear, const float rgba[4]) {  // g
   fragments_ = 0;
   rec_diff_upload_ = false;
   phases_.push_back(Phase{});
+  // rows a draw has to reach: the frame's, or -- under fdh_set_stripe, when the front-end has told how far the scene's blur nodes
+  // reach (render_frame: the per-call path cannot know what is still to come) -- the stripe's, widened by that reach
+  cull_y0_ = 0; cull_y1_ = H_;
+  if (stripe_y1_ > stripe_y0_ && pending_reach_ >= 0) {
+    cull_y0_ = std::max(0, std::min(H_, stripe_y0_) - pending_reach_);
+    cull_y1_ = std::min(H_, std::max(0, stripe_y1_) + pending_reach_);
+  }
+  pending_reach_ = -1;
+  culled_draws_ = 0;
 }
 
 void Context::push_rec(const DrawRec& r, const BBox& b) {
@@ -723,13 +735,32 @@ static void set_saturated_core(DrawRec& r, float w_px, float h_px) {
 
 // Quad emission: ceil(ctx.mat * corner) per vertex, order BL,BR,TR,TL (glcontext.nim:1498-1509), then either the
 // axis-aligned fast form or the two-triangle general form.
-void Context::emit_quad(DrawRec& r, float x0, float y0, float x1, float y1, int64_t* fragments) {
+bool Context::emit_quad(DrawRec& r, float x0, float y0, float x1, float y1, int64_t* fragments) {
   const float vx[4] = {x0, x1, x1, x0}, vy[4] = {y1, y1, y0, y0};  // BL, BR, TR, TL
-  emit_quad_pts(r, vx, vy, fragments);
+  return emit_quad_pts(r, vx, vy, fragments);
+}
+
+// The pixel bounds emit_quad_pts gives a quad over `rect` (same arithmetic), grown by `pad`: does it reach a row / column the
+// frame will produce?  The scene front-end asks before it opens a clip: content under a mask that lies outside is invisible.
+bool Context::rect_visible(const float rect[4], float pad) const {
+  if (!(rect[2] > 0.0f) || !(rect[3] > 0.0f)) return false;
+  const float vx[4] = {rect[0], rect[0] + rect[2], rect[0] + rect[2], rect[0]}, vy[4] = {rect[1] + rect[3], rect[1] + rect[3], rect[1], rect[1]};
+  float minx = 0, maxx = 0, miny = 0, maxy = 0;
+  for (int i = 0; i < 4; i++) {
+    const float px = std::ceil(mat_.a * vx[i] + mat_.c * vy[i] + mat_.tx), py = std::ceil(mat_.b * vx[i] + mat_.d * vy[i] + mat_.ty);
+    if (i == 0) { minx = maxx = px; miny = maxy = py; }
+    else { minx = std::min(minx, px); maxx = std::max(maxx, px); miny = std::min(miny, py); maxy = std::max(maxy, py); }
+  }
+  const float lim = 1.0e6f;
+  if (!(minx > -lim && maxx < lim && miny > -lim && maxy < lim)) return pad > 0.0f;  // (such a quad is recorded with empty bounds; an analytic mask has no quad)
+  BBox b;
+  b.x0 = (int16_t)clampf(minx - pad, 0.0f, (float)W_); b.x1 = (int16_t)clampf(maxx + pad, 0.0f, (float)W_);
+  b.y0 = (int16_t)clampf(miny - pad, 0.0f, (float)H_); b.y1 = (int16_t)clampf(maxy + pad, 0.0f, (float)H_);
+  return bbox_visible(b);
 }
 
 // Four pre-transform vertices in the reference's vertex order 0..3 (triangles (3,0,1) and (2,3,1), glcontext.nim:418-429).
-void Context::emit_quad_pts(DrawRec& r, const float vx[4], const float vy[4], int64_t* fragments) {
+bool Context::emit_quad_pts(DrawRec& r, const float vx[4], const float vy[4], int64_t* fragments) {
   float px[4], py[4];
   for (int i = 0; i < 4; i++) {
     px[i] = std::ceil(mat_.a * vx[i] + mat_.c * vy[i] + mat_.tx);
@@ -742,9 +773,16 @@ void Context::emit_quad_pts(DrawRec& r, const float vx[4], const float vy[4], in
   }
   const float lim = 1.0e6f;  // keep the integer edge functions far from overflow
   BBox b{0, 0, 0, 0};
-  if (!(minx > -lim && maxx < lim && miny > -lim && maxy < lim)) { r.bx0 = r.by0 = r.bx1 = r.by1 = 0; push_rec(r, b); return; }
+  // A draw that reaches no pixel the frame will produce leaves no trace (it would never be binned).  Clip pushes stay: their
+  // bounds grow to their content's, and a push that is not there would let that content through.
+  const bool cullable = ((r.op_mode >> 12) & 15u) == OP_DRAW && culling();
+  if (!(minx > -lim && maxx < lim && miny > -lim && maxy < lim)) {
+    if (cullable) { FDH_CULLED(); return false; }
+    r.bx0 = r.by0 = r.bx1 = r.by1 = 0; push_rec(r, b); return true;
+  }
   b.x0 = (int16_t)clampf(minx, 0.0f, (float)W_); b.x1 = (int16_t)clampf(maxx, 0.0f, (float)W_);
   b.y0 = (int16_t)clampf(miny, 0.0f, (float)H_); b.y1 = (int16_t)clampf(maxy, 0.0f, (float)H_);
+  if (cullable && !bbox_visible(b)) { FDH_CULLED(); return false; }
   r.bx0 = b.x0; r.by0 = b.y0; r.bx1 = b.x1; r.by1 = b.y1;
   const bool aligned = px[3] == px[0] && px[2] == px[1] && py[3] == py[2] && py[0] == py[1] && px[1] > px[0] && py[0] > py[3];
   if (aligned) {
@@ -810,6 +848,7 @@ void Context::emit_quad_pts(DrawRec& r, const float vx[4], const float vy[4], in
   if (fragments) *fragments += (int64_t)(b.x1 - b.x0) * (b.y1 - b.y0);
   for (auto idx : open_ops_) bbox_union(bboxes_[idx], b);  // clip pushes only need to reach tiles their content touches
   push_rec(r, b);
+  return true;
 }
 
 // radii packing: glcontext.nim:745-817
@@ -887,6 +926,7 @@ void Context::draw_rounded_rect_sdf(const float rect[4], const FdhColor colors[4
   if (!frame_begun_) throw Error(FDH_ERR_INVALID, "ctx.beginFrame has not been called.");
   if (!(rect[2] > 0.0f) || !(rect[3] > 0.0f)) return;  // (a NaN extent draws nothing)
   if (mode >= FDH_SDF_BEZIER_STROKE_AA) throw Error(FDH_ERR_INVALID, "bezier stroke modes go through drawQuadraticBezierSdf");
+  if (culling() && !rect_visible(rect, 0.0f)) { FDH_CULLED(); return; }  // (before the record is built: most of a long table is below the window)
   DrawRec r;
   fill_sdf_rec(r, rect, colors, rx, ry, mode, factor, spread, shape, fill_mode, mid, stop, mid_pos, aa_);
   if (mode == FDH_SDF_BACKDROP_BLUR) r.op_mode |= F_SELF_BACKDROP;  // a bare mode-17 call has no snapshot of its own
@@ -971,7 +1011,7 @@ void Context::draw_image(int64_t key, const float pos[2], const FdhColor colors[
     one_to_one = !flip_y && qx1 > qx0 && qy1 > qy0 && rw == (float)e.w && rh == (float)e.h && (!subpixel_enabled_ || r.aux == 0.0f) &&
                  mat_.b == 0.0f && mat_.c == 0.0f && std::fabs(qx0) < 1.0e6f && std::fabs(qy0) < 1.0e6f;
   }
-  emit_quad(r, x0, y0, x1, y1, &fragments_);
+  if (!emit_quad(r, x0, y0, x1, y1, &fragments_)) return;
   if (one_to_one && !(recs_.back().op_mode & F_GENERAL)) {
     DrawRec& rr = recs_.back();
     rr.op_mode |= F_TEXEL_1TO1;
@@ -1003,7 +1043,7 @@ void Context::draw_msdf(int64_t key, const float pos[2], FdhColor color, const f
   r.f0 = px_range; r.f1 = sd_threshold;
   for (int i = 0; i < 4; i++) r.col[i] = pack_color(color);
   r.aa = aa_;
-  emit_quad(r, pos[0], pos[1], pos[0] + size[0], pos[1] + size[1], &fragments_);
+  if (!emit_quad(r, pos[0], pos[1], pos[0] + size[0], pos[1] + size[1], &fragments_)) return;
   // atlas.frag:296-318, the fill variants: alpha = clamp(spr (sd - threshold) + 0.5), sd the median of the filtered r, g, b
   // (MTSDF: the filtered alpha) -- exactly 0 wherever sd <= threshold - 0.5 / spr.  Where all four taps have every channel <= t
   // the filtered channels, hence their median, are <= t: the box of texels above a level safely below that bound is all the
@@ -1222,6 +1262,7 @@ void Context::draw_backdrop_blur(const float rect[4], const float rx[4], const f
     emit_quad(r, rect[0], rect[1], rect[0] + rect[2], rect[1] + rect[3], &fragments_);
     return;
   }
+  if (culling() && !rect_visible(rect, 0.0f)) { FDH_CULLED(); return; }  // a blurred backdrop nobody sees: no snapshot, no phase
   // A blurred snapshot is a barrier in painter's order: close the phase, blur, continue in a new phase.
   std::vector<DrawRec> reopen;
   for (auto idx : open_ops_) reopen.push_back(recs_[idx]);
@@ -1234,7 +1275,7 @@ void Context::draw_backdrop_blur(const float rect[4], const float rx[4], const f
     push_rec(reopen[i], BBox{0, 0, 0, 0});
   }
   const bool fuse = open_ops_.empty();  // no clip state to carry: the V pass can composite the quad itself
-  emit_quad(r, rect[0], rect[1], rect[0] + rect[2], rect[1] + rect[3], &fragments_);
+  if (!emit_quad(r, rect[0], rect[1], rect[0] + rect[2], rect[1] + rect[3], &fragments_)) throw Error(FDH_ERR_INVALID, "drawBackdropBlur: rect_visible and emit_quad disagree");
   const BBox fb = bboxes_.back();
   BlurJob job;
   job.fuse_draw = -1;
@@ -1341,6 +1382,7 @@ void Context::prepare(LaunchJob& J) {
   FDH_HIP(hipSetDevice(device_));
   const size_t n = recs_.size();
   J.W = W_; J.H = H_; J.clear = clear_; J.clear_rgba8 = clear_rgba8_;
+  J.rec_y0 = culling() ? cull_y0_ : 0; J.rec_y1 = culling() ? cull_y1_ : H_;
   J.phases = phases_;  // (copies: the recording side keeps its own for fdh_debug_record_digest)
   J.blurs = blurs_;
   J.n_recs = (int)n;
@@ -1750,6 +1792,9 @@ void Context::launch_frame(const LaunchJob& J, bool profile) {
         h = std::min(J.H, h + reach);
       }
     }
+    // the records were culled to rows [rec_y0, rec_y1) when they were made (fdh_set_cull): every row a phase produces must lie inside
+    if (s1 > s0 && (l < J.rec_y0 || h > J.rec_y1))
+      throw Error(FDH_ERR_INVALID, "the resident draw records were culled to another row stripe: render the frame again after fdh_set_stripe (or fdh_set_cull(0))");
   }
   // profile mode: every launch stamps its own pair of events (set_launch_events: the kernel's execution time, no gaps)
   auto span_begin = [&](int kind) { if (profile) { Span sp{kind, next_event(), next_event()}; set_launch_events(sp.a, sp.b); spans_.push_back(sp); } };

@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -115,6 +116,7 @@ struct RetainedRoot {
   bool cacheable = false;        // no blur node inside (those split the frame into phases: re-walked every frame)
   bool dirty = true;
   uint64_t atlas_epoch = 0;      // image draws carry atlas positions: stale after the atlas was rebuilt
+  int cull_y0 = 0, cull_y1 = 0;  // the rows the records were culled to (Context::begin_frame)
 };
 struct RetainedLayer {
   int32_t zlevel = 0;
@@ -144,6 +146,7 @@ struct RetainedScene {
 struct LaunchJob {
   struct View { DrawRec* recs = nullptr; QuadExt* exts = nullptr; BinRec* binrecs = nullptr; int* phase_first = nullptr; uint32_t* binbox = nullptr; uint32_t* chunkbox = nullptr; };
   int W = 0, H = 0;
+  int rec_y0 = 0, rec_y1 = 0;  // rows the records were culled to (the frame, or a stripe + blur reach): a replay must stay inside
   bool clear = true;
   uint32_t clear_rgba8 = 0xFFFFFFFFu;
   std::vector<Phase> phases;
@@ -257,6 +260,15 @@ class Context {
 
   // multi-GPU / measurement
   void set_stripe(int y0, int y1) { drain(); stripe_y0_ = y0; stripe_y1_ = y1; }
+  // Culling (fdh_set_cull): draws whose pixel bounds miss the frame -- or, under fdh_set_stripe, the stripe's rows widened by the
+  // reach of the scene's blur nodes -- are not recorded, and the scene front-end skips the content of a clipping node whose mask
+  // lies outside.  0 off, 1 on (default; off while the call recorder runs, so that recorded streams stay the reference's), 2 on
+  // even while recording (tests).  The pixels are the same either way.
+  void set_cull(int mode) { cull_mode_ = mode < 0 ? 0 : (mode > 2 ? 2 : mode); }
+  bool culling() const { return cull_mode_ == 2 || (cull_mode_ == 1 && !rec_on_); }
+  // would a quad over `rect` (pre-transform units), grown by `pad` pixels on every side, reach a pixel the frame will produce?
+  bool rect_visible(const float rect[4], float pad) const;
+  int64_t culled_draws() const { return culled_draws_; }
   void set_blur_route(int route) { blur_route_ = route < 0 ? -1 : (route ? 1 : 0); }
   void replay(int times);
   void replay_timed(int times, float* ms_out);
@@ -270,8 +282,9 @@ class Context {
 
  private:
   void push_rec(const DrawRec& r, const BBox& b);
-  void emit_quad(DrawRec& r, float x0, float y0, float x1, float y1, int64_t* fragments);
-  void emit_quad_pts(DrawRec& r, const float vx[4], const float vy[4], int64_t* fragments);
+  bool emit_quad(DrawRec& r, float x0, float y0, float x1, float y1, int64_t* fragments);  // false: culled, nothing was recorded
+  bool emit_quad_pts(DrawRec& r, const float vx[4], const float vy[4], int64_t* fragments);
+  bool bbox_visible(const BBox& b) const { return b.x1 > b.x0 && std::min<int>(b.y1, cull_y1_) > std::max<int>(b.y0, cull_y0_); }
   const AtlasEntry& rect_entry();
   void shrink_to_ink(const AtlasEntry& e, bool use_alpha, int level_t);
   void upload_atlas_rect(int level, int x, int y, int w, int h, const uint8_t* rgba);
@@ -315,6 +328,10 @@ class Context {
   bool subpixel_enabled_ = false, subpixel_variants_ = false;
   float subpixel_shift_ = 0.0f;
   int stripe_y0_ = 0, stripe_y1_ = 0;
+  int cull_mode_ = 1;
+  int cull_y0_ = 0, cull_y1_ = 0;  // rows a draw must reach to be recorded (begin_frame: the frame, or the stripe + blur reach)
+  int pending_reach_ = -1;         // render_frame / scene_render: summed vertical reach of the scene's blur nodes (-1: unknown)
+  int64_t culled_draws_ = 0;       // of the frame being recorded / last recorded
 
   // submit thread (device contexts, unless FDH_CREATE_SYNC_SUBMIT): one job in flight at most.  The flag both sides poll
   // sits on a cache line of its own, and so do the submission side's state and the recording side's: an idle submit thread
@@ -355,7 +372,8 @@ class Context {
   void rebase_side(FdhFig* nodes, int n, const FdhScene* side);
   void compact_side();
   bool host_only_ = false;  // FDH_CREATE_RECORD_ONLY
-  bool rec_on_ = false, rec_first_ = true;
+  bool rec_on_ = false, rec_first_ = true, rec_mark_first_ = true;
+  size_t rec_mark_ = 0;
   std::string rec_;  // FDH_DEBUG_SNAP=1 (diagnostic): the surface as phase 0 left it, copied in-stream
   int surf_w_ = 0, surf_h_ = 0;
   // records, quad extensions, bounding boxes and phase offsets of a frame live in ONE device block and arrive with ONE

@@ -470,6 +470,7 @@ struct Walker {
   }
 
   int depth = 0;
+  int64_t culled_subtrees = 0;
   // first_child[i] / next_sibling[i]: the nodes whose parent is i, in index order (a parent precedes its children: a node that
   // names a later node, or none, is nobody's child -- exactly what the forward scan finds)
   const FdhLayer* linked = nullptr;
@@ -510,6 +511,19 @@ struct Walker {
       if (n.use_matrix) ctx.apply_transform(n.matrix);
     }
     if (n.kind == FDH_NK_RECTANGLE) drop_shadows(n);
+    // Culling: a node that clips its content to a mask no produced pixel lies under draws nothing from here to its pop -- the
+    // mask plane is 0 there (glcontext.nim:1886-1914: the mask quad never reaches those pixels; the analytic rect mask,
+    // atlas_rect_mask.frag:222-237, is 0 beyond its AA fringe of 0.5 / aa px: hence the pad) -- so neither the node nor its
+    // subtree is walked.  (The reference's own table benchmark scrolls 180 rows through a window that shows 30.)
+    if ((clip || rmask) && ctx.culling()) {
+      const bool dead = (clip && !ctx.rect_visible(box, 0.0f)) || (rmask && ctx.aa() >= 0.05f && !ctx.rect_visible(box, 1.0f + 0.5f / ctx.aa()));
+      if (dead) {
+        culled_subtrees++;
+        if (xf) ctx.restore_transform();
+        if (rot) ctx.restore_transform();
+        return;
+      }
+    }
     if (clip) {
       ctx.begin_mask(box, rx, ry);
       ctx.end_mask();
@@ -563,10 +577,28 @@ struct Walker {
 
 }  // namespace
 
+// How far, in rows, the scene's backdrop blurs can carry a pixel's influence: the sum over its blur nodes of the tap reach of
+// their filters (make_taps: at most max(radius, 8) + 1 rows, 66 for the clamped radius 64).  A row stripe is rendered with that
+// much halo at most (launch_frame widens the stripe phase by phase), so draws beyond it can be culled.
+static int scene_blur_reach(const FdhScene& scene, float ui) {
+  long long reach = 0;
+  for (int l = 0; l < scene.n_layers; l++) {
+    const FdhLayer& L = scene.layers[l];
+    for (int i = 0; i < L.n_nodes && L.nodes; i++) {
+      const FdhFig& n = L.nodes[i];
+      if (n.kind != FDH_NK_BACKDROP_BLUR || !(n.blur > 0.0f)) continue;
+      const float r = std::min(std::max(n.blur * ui, 8.0f), 64.0f);
+      reach += (long long)std::ceil(r) + 2;
+    }
+  }
+  return (int)std::min<long long>(reach, 1 << 20);
+}
+
 void Context::render_frame(const FdhScene* scene, float fw, float fh, bool clear, const float rgba[4]) {
   if (!scene || (scene->n_layers > 0 && !scene->layers)) throw Error(FDH_ERR_INVALID, "render_frame: null scene");
   const float w = fw * ui_scale_, h = fh * ui_scale_;  // frameSize.scaled()
   if (w <= 0.0f || h <= 0.0f) return;
+  if (stripe_y1_ > stripe_y0_ && culling()) pending_reach_ = scene_blur_reach(*scene, ui_scale_);
   begin_frame((int)w, (int)h, clear, rgba);
   try {
     save_transform();
@@ -859,6 +891,7 @@ void Context::scene_render() {
   view.controls = R.controls.data(); view.n_controls = (int32_t)(R.controls.size() / 2);
   view.text_rects = R.text_rects.data(); view.n_text_rects = (int32_t)R.text_rects.size();
   R.roots_walked = R.roots_reused = 0;
+  if (stripe_y1_ > stripe_y0_ && culling()) pending_reach_ = scene_blur_reach(view, ui_scale_);
   begin_frame((int)w, (int)h, R.clear, R.rgba);
   rec_diff_upload_ = true;  // consecutive frames of a retained scene differ in a few records: Context::submit uploads the difference
   try {
@@ -869,7 +902,8 @@ void Context::scene_render() {
       RetainedLayer& D = R.layers[l];
       for (size_t s = 0; s < D.roots.size(); s++) {
         RetainedRoot& C = D.cache[s];
-        if (!C.dirty && C.cacheable && !config_changed && C.atlas_epoch == atlas_epoch_) {
+        // (cached records were culled to the rows in force when they were made: good for any frame that produces no row beyond them)
+        if (!C.dirty && C.cacheable && !config_changed && C.cull_y0 <= cull_y0_ && C.cull_y1 >= cull_y1_ && C.atlas_epoch == atlas_epoch_) {
           // splice the cached records back: extension indices move with the frame's extension array
           const uint32_t e0 = (uint32_t)exts_.size();
           const size_t r0 = recs_.size();
@@ -889,6 +923,7 @@ void Context::scene_render() {
         R.roots_walked++;
         C.dirty = false;
         C.atlas_epoch = atlas_epoch_;
+        C.cull_y0 = cull_y0_; C.cull_y1 = cull_y1_;
         C.cacheable = phases_.size() == p0 && blurs_.size() == b0;
         C.recs.clear(); C.bboxes.clear(); C.exts.clear();
         if (C.cacheable) {

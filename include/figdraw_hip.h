@@ -310,6 +310,15 @@ FDH_API int fdh_debug_record_digest(FdhContext*, uint64_t* out);
 /* Restrict rasterisation to rows [y0, y1) of the frame (row-stripe sharding).  Rows outside the
  * stripe are left untouched; blur halos are rendered redundantly so no exchange is needed.  y1 <= y0 disables it. */
 FDH_API int fdh_set_stripe(FdhContext*, int y0, int y1);
+/* Culling.  A draw whose pixel bounds reach no pixel the frame will produce -- off the frame, or, under fdh_set_stripe with
+ * fdh_render_frame / fdh_scene_render, off the stripe's rows widened by the reach of the scene's blur nodes -- is not recorded, and
+ * the scene front-end does not walk the subtree of a node that clips its content (NfClipContent / NfRectMaskContent) to a mask
+ * lying outside: the mask is 0 on every produced pixel.  The reference hands such draws to GL, which clips them
+ * (examples/windy_non_clip_benchmark.nim submits 180 rows to a window that shows 34); the pixels are the same bit for bit
+ * (tests/test_hip_parity.py, tests/test_culling.py).  mode 0: off; 1 (default): on, except while the call recorder runs (recorded
+ * streams stay call for call the reference's); 2: on even then.  fdh_culled_draws: draws dropped from the last frame. */
+FDH_API int fdh_set_cull(FdhContext*, int mode);
+FDH_API int fdh_culled_draws(FdhContext*, int64_t* out);
 /* ---- the gather over RCCL / xGMI (one process per GPU).  Nothing is exchanged while a frame renders; the one
  * collective of the path is the gather of the finished RGBA8 rows or frames to one rank: grouped ncclSend / ncclRecv on the
  * context's stream, queued behind the frame's kernels (no host synchronisation; fdh_sync on the destination waits for it).
