@@ -129,6 +129,8 @@ def load():
     L.fdh_set_blur_route.argtypes = [vp, C.c_int]
     L.fdh_set_cull.argtypes = [vp, C.c_int]
     L.fdh_culled_draws.argtypes = [vp, C.POINTER(C.c_int64)]
+    L.fdh_set_walk_threads.argtypes = [vp, C.c_int]
+    L.fdh_walk_stats.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int64)]
     L.fdh_stripe_rows.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.fdh_comm_unique_id.argtypes = [C.c_char_p]
     L.fdh_comm_init.argtypes = [vp, C.c_char_p, C.c_int, C.c_int]
@@ -452,6 +454,16 @@ class HipContext:
         """0: record every draw; 1 (default): drop draws / clipped subtrees no produced pixel lies under, except while the call
         recorder runs; 2: also then.  Same pixels either way."""
         self._ck(self.L.fdh_set_cull(self.h, int(mode)))
+
+    def set_walk_threads(self, n: int):
+        """pool threads the scene front-end decomposes large sibling groups on, beside the calling thread (0: serial; < 0: default)"""
+        self._ck(self.L.fdh_set_walk_threads(self.h, int(n)))
+
+    def walk_stats(self):
+        """(threads in force, sibling groups of the last frame that went to the pool)"""
+        t, g = C.c_int(), C.c_int64()
+        self._ck(self.L.fdh_walk_stats(self.h, C.byref(t), C.byref(g)))
+        return t.value, g.value
 
     def culled_draws(self) -> int:
         out = C.c_int64()

@@ -258,6 +258,13 @@ int fdh_gather_frames(FdhContext* c, int dst_rank, void* const* dst_images) { re
 int fdh_set_blur_route(FdhContext* c, int route) { return guard([&] { C(c)->set_blur_route(route); }); }
 int fdh_set_stripe(FdhContext* c, int y0, int y1) { return guard([&] { C(c)->set_stripe(y0, y1); }); }
 int fdh_set_cull(FdhContext* c, int mode) { return guard([&] { C(c)->set_cull(mode); }); }
+int fdh_set_walk_threads(FdhContext* c, int n) { return guard([&] { C(c)->set_walk_threads(n); }); }
+int fdh_walk_stats(FdhContext* c, int* threads, int64_t* parallel_groups) {
+  return guard([&] {
+    if (threads) *threads = C(c)->walk_threads();
+    if (parallel_groups) *parallel_groups = C(c)->parallel_groups();
+  });
+}
 int fdh_culled_draws(FdhContext* c, int64_t* out) {
   return guard([&] {
     if (!out) throw fdh::Error(FDH_ERR_INVALID, "null output");

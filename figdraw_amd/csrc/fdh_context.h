@@ -8,6 +8,8 @@
 #include <chrono>
 #include <condition_variable>
 #include <cstdint>
+#include <cstdlib>
+#include <cstring>
 #include <exception>
 #include <memory>
 #include <mutex>
@@ -77,11 +79,48 @@ struct PinnedBuf {
   }
 };
 
+// A growable array the recording threads write and the upload kernel reads: pinned host memory on device contexts (the GPU
+// fetches it over PCIe: no staging copy), plain memory on FDH_CREATE_RECORD_ONLY ones.  Growth copies (doubling: rare once
+// a context has seen its scene); elements are plain data.
+template <typename T>
+struct HostVec {
+  T* p = nullptr;
+  size_t n = 0, cap = 0;
+  bool pinned = false;
+  HostVec() = default;
+  HostVec(const HostVec&) = delete;
+  HostVec& operator=(const HostVec&) = delete;
+  ~HostVec() { release(); }
+  void release() {
+    if (p) { if (pinned) (void)hipHostFree(p); else std::free(p); }
+    p = nullptr; n = cap = 0;
+  }
+  void reserve(size_t want) {
+    if (want <= cap) return;
+    size_t c = cap ? cap : 256;
+    while (c < want) c *= 2;
+    T* fresh = nullptr;
+    if (pinned) FDH_HIP(hipHostMalloc((void**)&fresh, c * sizeof(T), hipHostMallocDefault));
+    else if (!(fresh = static_cast<T*>(std::aligned_alloc(64, (c * sizeof(T) + 63) & ~(size_t)63)))) throw std::bad_alloc();
+    if (n) std::memcpy(static_cast<void*>(fresh), static_cast<const void*>(p), n * sizeof(T));
+    if (p) { if (pinned) (void)hipHostFree(p); else std::free(p); }
+    p = fresh; cap = c;
+  }
+  T& operator[](size_t i) { return p[i]; }
+  const T& operator[](size_t i) const { return p[i]; }
+  T* slot() { if (n == cap) reserve(n + 1); return p + n; }  // the next element's place (not yet counted)
+  size_t size() const { return n; }
+  bool empty() const { return n == 0; }
+  T& back() { return p[n - 1]; }
+  void clear() { n = 0; }
+  void append(const T* src, size_t k) { if (!k) return; reserve(n + k); std::memcpy(static_cast<void*>(p + n), static_cast<const void*>(src), k * sizeof(T)); n += k; }
+};
+
 // An atlas entry and, when its level-0 texels were seen on the host (fdh_put_image), the bounds of what is IN it: for eight
 // levels t = 0, 16, .. 112 the box (entry-relative texels, x1 / y1 exclusive) of texels whose alpha, and whose largest colour
 // channel, exceeds t.  A draw whose coverage is exactly 0 wherever the sampled value is <= t (a glyph image: alpha 0; an MSDF
 // image: distance below threshold - 0.5 / screen range) shrinks its pixel bounds to the image of that box: the strips outside
-// would blend with alpha 0, which leaves every texel as it is (Context::shrink_to_ink).
+// would blend with alpha 0, which leaves every texel as it is (Recorder::shrink_to_ink).
 constexpr int kInkLevels = 8;
 struct InkBox { int16_t x0, y0, x1, y1; };
 struct AtlasEntry {
@@ -105,13 +144,130 @@ struct BlurJob {
   BlurTaps taps;
 };
 
+// ------------------------------------------------------------------ the recorded frame
+// A frame's draw records are produced in their FINAL form while the calls arrive -- the 128-byte DrawRec the compositor reads,
+// the 24-byte BinRec the bin kernel reads (pixel bounds, saturated core, list-entry flags), the quad extensions -- straight into
+// host memory the GPU fetches from (HostVec): nothing is built a second time or copied at submit.  A LANE is what one thread
+// records: lane 0 belongs to the thread that calls the context, lanes 1.. to the walk pool's threads (fdh_frontend.cpp:
+// large sibling groups of the scene tree are decomposed in parallel).  The frame in painter's order is a list of PIECES, each a
+// run of consecutive records of one lane; the upload kernel gathers the pieces into the dense device arrays (k_upload_frame).
+struct Lane {
+  HostVec<DrawRec> recs;
+  HostVec<BinRec> bins;   // bins[i].box IS the bounds of record i (clip pushes: the union of their content, final at the pop)
+  HostVec<QuadExt> exts;  // DrawRec::ext of an F_GENERAL record indexes THIS array; the upload re-bases it
+  // List stride (the largest number of list entries any bin of any phase can receive: it sizes the bin lists): a 2-D difference
+  // array over the bin grid, four updates per record when its bounds are final, evaluated per phase (count_close).
+  std::vector<int> diff;
+  int dw = 0, dh = 0;
+  int tx0 = 0, ty0 = 0, tx1 = 0, ty1 = 0;
+  bool touched = false;
+  uint64_t stamp = 0;  // the frame a pool thread's lane was last cleared for
+  void set_pinned(bool on) { recs.pinned = bins.pinned = exts.pinned = on; }
+  void clear() { recs.clear(); bins.clear(); exts.clear(); }
+  void count_begin(int bins_x, int bins_y);
+  void count_add(const BBox& b);
+  int count_close();  // the largest count of any bin since the last close; leaves the array zeroed
+};
+
+// what a run of records adds to its phase (kept per parallel chunk by the walk pool's threads, merged by the calling thread)
+struct PhaseSum {
+  BBox u{0, 0, 0, 0};  // union of the records' final bounds
+  bool has_masks = false, has_atlas = false, has_slow = false;
+  int deepest = 0;     // deepest clip nesting reached, relative to the run's start
+  int64_t frag_mode[4] = {0, 0, 0, 0}, frag_ellip = 0, frag_other = 0;  // covered fragments by SdfMode 3 / 7 / 9 / 12
+};
+struct Piece {
+  int lane = 0;                     // (-1: the lane Context::consolidate_pieces copies a frame of too many pieces into)
+  uint32_t first = 0, n = 0;        // records [first, first + n) of the lane
+  uint32_t ext_first = 0, n_ext = 0;  // their quad extensions
+};
+
+struct RectMaskEntry { int kind; };  // 1 = fast analytic, 2 = real mask (glcontext.nim:36-44)
+class Context;
+struct SerialOnly {};  // thrown by a pool thread's recorder at a call only the calling thread can serve (a blur node, the lazily
+                       // created 4x4 "rect" atlas image): the calling thread then walks that sibling group itself
+
+// The BackendContext state machine (glcontext.nim): transform stack, clip / rect-mask stacks, and the draw calls, each turning
+// into records of ONE lane.  Context derives from it (lane 0: the C entry points and the serial walk); the walk pool's threads
+// each own one more (fdh_frontend.cpp).
+class Recorder {
+ public:
+  Recorder(Context* cx, bool is_main) : cx_(cx), is_main_(is_main) {}
+  void save_transform();
+  void restore_transform();
+  void translate(float x, float y);
+  void rotate(float a);
+  void scale(float sx, float sy);
+  void apply_transform(const float m[16]);
+  bool transform_mirrors_y() const;
+  void set_aa(float aa);
+  float aa() const { return aa_; }
+  void draw_rounded_rect_sdf(const float rect[4], const FdhColor colors[4], const float rx[4], const float ry[4], int mode,
+                             float factor, float spread, const float shape[2], int fill_mode, FdhColor mid, FdhColor stop,
+                             float mid_pos);
+  void draw_rounded_rect_fill(const float rect[4], const FdhFill& fill, const float rx[4], const float ry[4], int mode,
+                              float factor, float spread, const float shape[2]);
+  void draw_image(int64_t key, const float pos[2], const FdhColor colors[4], const float size[2], bool flip_y);
+  void draw_msdf(int64_t key, const float pos[2], FdhColor color, const float size[2], float px_range, float sd_threshold,
+                 float stroke_weight, bool mtsdf, bool flip_y);
+  void draw_quadratic_bezier_sdf(const float rect[4], const FdhFill& fill, const float p0[2], const float p1[2], const float p2[2],
+                                 float stroke_weight, int cap);
+  void draw_filled_quad(const float verts[8], const FdhColor colors[4]);
+  void draw_rect(const float rect[4], FdhColor color);
+  void draw_backdrop_blur(const float rect[4], const float rx[4], const float ry[4], float blur_radius);
+  void begin_mask(const float rect[4], const float rx[4], const float ry[4]);
+  void end_mask();
+  void pop_mask();
+  void begin_rect_mask(const float rect[4], const float rx[4], const float ry[4]);
+  void pop_rect_mask();
+  void set_subpixel_shift(float s);
+  bool subpixel_enabled() const;
+  bool subpixel_variants() const;
+  bool culling() const;
+  // would a quad over `rect` (pre-transform units), grown by `pad` pixels on every side, reach a pixel the frame will produce?
+  bool rect_visible(const float rect[4], float pad) const;
+
+  // ---- state (the calling thread's recorder is reset by begin_frame; a pool thread's by adopt())
+  Context* const cx_;
+  const bool is_main_;
+  Lane* lane_ = nullptr;
+  Aff mat_;
+  std::vector<Aff> mats_;
+  float aa_ = 1.2f;
+  float subpixel_shift_ = 0.0f;
+  bool mask_begun_ = false;
+  int mask_depth_ = 0;
+  std::vector<RectMaskEntry> rect_masks_;
+  int outer_rect_masks_ = 0;        // pool threads: rect masks open around the sibling group (begin_rect_mask nests differently inside one)
+  std::vector<uint32_t> open_ops_;  // lane indices of the open MASK_PUSH / RMASK_BEGIN records (their bounds grow with their content)
+  bool outer_open_ = false;         // pool threads: clips are open around the sibling group; their bounds take ...
+  BBox outer_union_{0, 0, 0, 0};    // ... the union of everything emitted here (merged by the calling thread)
+  int depth_now_ = 0;               // clip nesting inside the current phase (open pushes are re-emitted at a phase's start)
+  PhaseSum sum_;                    // of the records committed since the last take_sum()
+  int64_t fragments_ = 0, culled_draws_ = 0;
+  int phase_floor_ = 0;             // lane index of the first record of the current phase in this lane (LE_SHARE never crosses it)
+
+ protected:
+  DrawRec& next_rec();  // the lane's next record slot, zeroed (counted by emit_* when the draw survives culling)
+  bool emit_quad(DrawRec& r, float x0, float y0, float x1, float y1, bool count_fragments);  // false: culled, nothing was recorded
+  bool emit_quad_pts(DrawRec& r, const float vx[4], const float vy[4], bool count_fragments);
+  void push_rec(const BBox& b);  // count the slot next_rec() handed out
+  void commit_bins(uint32_t idx);  // the record's bounds are final: list-entry flags, list-stride count, phase summary
+  void link_share(uint32_t idx);   // LE_SHARE on idx - 1 when record idx is drawn over the same quad with the same shape
+  bool bbox_visible(const BBox& b) const;
+  const AtlasEntry& rect_entry();
+  void shrink_to_ink(const AtlasEntry& e, bool use_alpha, int level_t);
+  friend class Context;
+};
+
 // Retained scene (fdh_scene_*): the library-side half of the reference's RenderFragments (renderfragments.nim:426-544) --
 // a deep copy of the node tree plus, per root, the draw records its decomposition produced.  A frame re-decomposes only the
 // roots an update touched; every other root's records are spliced back from the cache.
 struct RetainedRoot {
-  std::vector<DrawRec> recs;
-  std::vector<BBox> bboxes;
+  std::vector<DrawRec> recs;     // in device form (Recorder::push_rec)
+  std::vector<BinRec> bins;      // bounds, cores, list-entry flags (the last record's LE_SHARE is decided again at every splice)
   std::vector<QuadExt> exts;     // of this root's records, DrawRec::ext relative to exts.front()
+  PhaseSum sum;
   int64_t fragments = 0;
   bool cacheable = false;        // no blur node inside (those split the frame into phases: re-walked every frame)
   bool dirty = true;
@@ -140,8 +296,8 @@ struct RetainedScene {
   int64_t roots_walked = 0, roots_reused = 0;  // of the last fdh_scene_render
 };
 
-// What the launch side needs of one frame: filled by Context::prepare on the calling thread (which also fills the pinned
-// staging buffer the upload kernel reads), consumed by Context::issue / launch_frame on the context's submit thread, and kept
+// What the launch side needs of one frame: filled by Context::prepare on the calling thread (which also fills the run table
+// the upload kernel works through), consumed by Context::issue / launch_frame on the context's submit thread, and kept
 // for fdh_replay / fdh_profile.
 struct LaunchJob {
   struct View { DrawRec* recs = nullptr; QuadExt* exts = nullptr; BinRec* binrecs = nullptr; int* phase_first = nullptr; uint32_t* binbox = nullptr; uint32_t* chunkbox = nullptr; };
@@ -162,58 +318,25 @@ struct LaunchJob {
   uint32_t* counts = nullptr;
   int bins_x = 0, bins_y = 0, list_stride = 0, binbox_shift = 0;
   int big_blur = -1;       // index of the frame's largest blur job (its passes are timed on their own)
-  // the upload: `upload_bytes` from the head of the staging buffer, or (a retained scene's edit) a few runs of it
-  const void* s_dev = nullptr;
+  // the upload: the runs k_upload_frame gathers (records, bin records, extensions of every piece; phase table; blur tables)
+  std::vector<UploadRun> runs;
+  UploadTable table;       // (filled from `runs` when the frame is issued)
+  uint32_t n_chunks = 1;   // 256-draw chunks whose bin boxes the upload builds
   void* d_dst = nullptr;
-  size_t upload_bytes = 0;
-  bool patched = false;
-  UploadRuns runs{};
   int staging_slot = -1;
 };
 
-struct RectMaskEntry { int kind; };  // 1 = fast analytic, 2 = real mask (glcontext.nim:36-44)
-
-class Context {
+class Context : public Recorder {
  public:
   Context(int atlas_size, float pixel_scale, int device, uint32_t flags);
   ~Context();
 
-  // BackendContext surface
+  // BackendContext surface: the draw calls are Recorder's
   void begin_frame(int w, int h, bool clear, const float rgba[4]);
   void end_frame();
-  void save_transform();
-  void restore_transform();
-  void translate(float x, float y);
-  void rotate(float a);
-  void scale(float sx, float sy);
-  void apply_transform(const float m[16]);
-  bool transform_mirrors_y() const;
-  void set_aa(float aa);
-  float aa() const { return aa_; }
   float pixel_scale() const { return pixel_scale_; }
-  void draw_rounded_rect_sdf(const float rect[4], const FdhColor colors[4], const float rx[4], const float ry[4], int mode,
-                             float factor, float spread, const float shape[2], int fill_mode, FdhColor mid, FdhColor stop,
-                             float mid_pos);
-  void draw_rounded_rect_fill(const float rect[4], const FdhFill& fill, const float rx[4], const float ry[4], int mode,
-                              float factor, float spread, const float shape[2]);
-  void draw_image(int64_t key, const float pos[2], const FdhColor colors[4], const float size[2], bool flip_y);
-  void draw_msdf(int64_t key, const float pos[2], FdhColor color, const float size[2], float px_range, float sd_threshold,
-                 float stroke_weight, bool mtsdf, bool flip_y);
-  void draw_quadratic_bezier_sdf(const float rect[4], const FdhFill& fill, const float p0[2], const float p1[2], const float p2[2],
-                                 float stroke_weight, int cap);
-  void draw_filled_quad(const float verts[8], const FdhColor colors[4]);
-  void draw_rect(const float rect[4], FdhColor color);
-  void draw_backdrop_blur(const float rect[4], const float rx[4], const float ry[4], float blur_radius);
-  void begin_mask(const float rect[4], const float rx[4], const float ry[4]);
-  void end_mask();
-  void pop_mask();
-  void begin_rect_mask(const float rect[4], const float rx[4], const float ry[4]);
-  void pop_rect_mask();
   void set_subpixel_enabled(bool e) { subpixel_enabled_ = e; }
-  bool subpixel_enabled() const { return subpixel_enabled_; }
   void set_subpixel_variants(bool e) { subpixel_variants_ = e; }
-  bool subpixel_variants() const { return subpixel_variants_; }
-  void set_subpixel_shift(float s);
 
   // atlas
   void put_image(int64_t key, int w, int h, const uint8_t* rgba, int out_rect[4]);
@@ -257,6 +380,7 @@ class Context {
   void comm_destroy();
   void gather_stripes(int dst_rank, void* dst_image);
   void gather_frames(int dst_rank, void* const* dst_images);
+  int comm_world() const { return comm_ ? comm_world_ : 1; }
 
   // multi-GPU / measurement
   void set_stripe(int y0, int y1) { drain(); stripe_y0_ = y0; stripe_y1_ = y1; }
@@ -265,33 +389,31 @@ class Context {
   // lies outside.  0 off, 1 on (default; off while the call recorder runs, so that recorded streams stay the reference's), 2 on
   // even while recording (tests).  The pixels are the same either way.
   void set_cull(int mode) { cull_mode_ = mode < 0 ? 0 : (mode > 2 ? 2 : mode); }
-  bool culling() const { return cull_mode_ == 2 || (cull_mode_ == 1 && !rec_on_); }
-  // would a quad over `rect` (pre-transform units), grown by `pad` pixels on every side, reach a pixel the frame will produce?
-  bool rect_visible(const float rect[4], float pad) const;
-  int64_t culled_draws() const { return culled_draws_; }
+  int64_t culled_draws() const { return culled_total_; }
+  // The scene front-end decomposes large sibling groups on `n` pool threads beside the calling one (0: serial; default:
+  // FDH_WALK_THREADS or a few, by the host's core count).  Same records either way (fdh_debug_record_digest).
+  void set_walk_threads(int n) { walk_threads_ = n < 0 ? -1 : (n > 64 ? 64 : n); }
+  int walk_threads() const;
+  int64_t parallel_groups() const { return parallel_groups_; }
   void set_blur_route(int route) { blur_route_ = route < 0 ? -1 : (route ? 1 : 0); }
   void replay(int times);
   void replay_timed(int times, float* ms_out);
   void replay_async(int times);
   void profile(int times);
   void frame_stats(FdhFrameStats* out) { drain(); *out = stats_; out->ms_host_launch = launch_ms_.load(std::memory_order_relaxed); }
-  // Submission is asynchronous: end_frame hands the recorded frame to the context's submit thread (upload preparation, the
-  // upload, the kernel launches) and returns.  flush() returns once everything submitted so far has been ENQUEUED on the
+  // Submission is asynchronous: end_frame hands the recorded frame to the context's submit thread (the upload, the kernel
+  // launches) and returns.  flush() returns once everything submitted so far has been ENQUEUED on the
   // stream (a consumer that orders its own work after the frame on the same stream calls it first); sync() also waits for the GPU.
   void flush() { drain(); }
 
  private:
-  void push_rec(const DrawRec& r, const BBox& b);
-  bool emit_quad(DrawRec& r, float x0, float y0, float x1, float y1, int64_t* fragments);  // false: culled, nothing was recorded
-  bool emit_quad_pts(DrawRec& r, const float vx[4], const float vy[4], int64_t* fragments);
-  bool bbox_visible(const BBox& b) const { return b.x1 > b.x0 && std::min<int>(b.y1, cull_y1_) > std::max<int>(b.y0, cull_y0_); }
-  const AtlasEntry& rect_entry();
-  void shrink_to_ink(const AtlasEntry& e, bool use_alpha, int level_t);
+  friend class Recorder;
+  friend struct ParallelWalk;
+  void alloc_atlas(int size);
   void upload_atlas_rect(int level, int x, int y, int w, int h, const uint8_t* rgba);
   void put_levels(int x, int y, int w, int h, const uint8_t* rgba);
-  void alloc_atlas(int size);
   void find_empty_rect(int w, int h, int* ox, int* oy);
-  void prepare(LaunchJob& J);  // calling thread: recorded frame -> staging buffer + launch description
+  void prepare(LaunchJob& J);  // calling thread: recorded frame -> run table + launch description
   void issue(LaunchJob& J);    // submit thread: upload + kernel launches
   void launch_frame(const LaunchJob& J, bool profile);
   template <typename Buf> void reserve_quiet(Buf& buf, size_t n);
@@ -300,12 +422,26 @@ class Context {
   hipEvent_t next_event();
   void ensure_surfaces();
   void need_device(const char* what) const;
+  // pieces / phases (calling thread)
+  void split_phase(int blur);               // a blurred snapshot is a barrier in painter's order
+  void open_piece();                        // lane 0's records from here on form a new piece
+  void close_piece();
+  void add_piece(const Piece& p, const PhaseSum& s, const BBox& outer_union, int64_t fragments, int64_t culled);  // a pool thread's chunk, in order
+  void add_sum(const PhaseSum& s, int depth_base);
+  void close_phase();                       // the phase ends here: summary, bins reached, its share of the list stride
+  uint32_t global_index(uint32_t lane0_index) const { return lane0_index + g0_delta_; }
+  uint32_t global_count() const;            // records of the frame so far
+  Lane& lane(int i) { return i < 0 ? *merge_lane_[(size_t)staging_i_] : *lanes_[(size_t)staging_i_][(size_t)i]; }  // (-1: consolidate_pieces' lane)
+  Lane& ensure_lane(int i);
+  void splice_cached(const RetainedRoot& C);
+  void consolidate_pieces();
+  void pool_slots(int slots);               // lanes 1 .. slots and their recorders, ready for a sibling group
 
   int device_ = 0;
   uint32_t flags_ = 0;
   int blur_route_ = -1;   // fdh_set_blur_route: -1 per-frame decision, 0 two passes, 1 fused
   int submit_slot_ = 0;   // this context's entry in the process-wide table of last submissions (Context::prepare)
-  std::shared_ptr<void> comm_;  // ncclComm_t (fdh_comm_init), shared with the contexts that borrowed it: destroyed with its last holder
+  std::shared_ptr<void> comm_;  // shared communicator object (fdh_comm.cpp), shared with the contexts that borrowed it: destroyed with its last holder
   int comm_rank_ = 0, comm_world_ = 1;
   hipStream_t own_stream_ = nullptr, stream_ = nullptr;
   hipEvent_t ev_[2] = {};
@@ -316,22 +452,19 @@ class Context {
 
   // frame state
   int W_ = 0, H_ = 0;
-  bool frame_begun_ = false, mask_begun_ = false;
+  bool frame_begun_ = false;
   bool clear_ = true;
   uint32_t clear_rgba8_ = 0xFFFFFFFFu;
-  int mask_depth_ = 0;
-  std::vector<RectMaskEntry> rect_masks_;
-  std::vector<uint32_t> open_ops_;  // indices of currently open MASK_PUSH / RMASK_BEGIN records (re-emitted after a blur)
-  Aff mat_;
-  std::vector<Aff> mats_;
-  float aa_ = 1.2f, pixel_scale_ = 1.0f, ui_scale_ = 1.0f;
+  float pixel_scale_ = 1.0f, ui_scale_ = 1.0f;
+  float ctx_aa_ = 1.2f;   // (Recorder::aa_ of lane 0 is the live value; kept across frames)
   bool subpixel_enabled_ = false, subpixel_variants_ = false;
-  float subpixel_shift_ = 0.0f;
   int stripe_y0_ = 0, stripe_y1_ = 0;
   int cull_mode_ = 1;
   int cull_y0_ = 0, cull_y1_ = 0;  // rows a draw must reach to be recorded (begin_frame: the frame, or the stripe + blur reach)
   int pending_reach_ = -1;         // render_frame / scene_render: summed vertical reach of the scene's blur nodes (-1: unknown)
-  int64_t culled_draws_ = 0;       // of the frame being recorded / last recorded
+  int64_t culled_total_ = 0;       // of the last recorded frame
+  int walk_threads_ = -1;
+  int64_t parallel_groups_ = 0;    // sibling groups of the last frame that were decomposed on the pool
 
   // submit thread (device contexts, unless FDH_CREATE_SYNC_SUBMIT): one job in flight at most.  The flag both sides poll
   // sits on a cache line of its own, and so do the submission side's state and the recording side's: an idle submit thread
@@ -349,14 +482,19 @@ class Context {
   std::vector<size_t> tables_layout_;
   std::vector<float> tables_sig_;
 
-  // recorded frame
+  // recorded frame (calling thread)
   alignas(128) bool rec_diff_upload_ = false;
-  std::vector<DrawRec> recs_;
-  std::vector<BBox> bboxes_;
-  std::vector<QuadExt> exts_;
+  std::vector<Piece> pieces_;      // the frame in painter's order
+  bool piece_open_ = false;        // the last piece is lane 0's and still growing
+  uint32_t n_total_ = 0, n_ext_total_ = 0;  // records / extensions in closed pieces
+  uint32_t g0_delta_ = 0;          // global index of a record of lane 0's open piece = its lane index + this
   std::vector<Phase> phases_;
   std::vector<BlurJob> blurs_;
-  int64_t fragments_ = 0;
+  BBox phase_u_{0, 0, 0, 0};       // union of the current phase's record bounds
+  int stride_max_ = 1;             // list stride so far: max over the closed phases
+  int phase_extra_ = 0;            // the current phase: bound contributed by pool threads' lanes (sum of their own maxima)
+  int deepest_clip_ = 0;
+  int64_t frag_mode_[4] = {0, 0, 0, 0}, frag_ellip_ = 0, frag_other_ = 0;  // phase 0
   bool have_frame_ = false;
 
   // device state (submission side)
@@ -374,10 +512,9 @@ class Context {
   bool host_only_ = false;  // FDH_CREATE_RECORD_ONLY
   bool rec_on_ = false, rec_first_ = true, rec_mark_first_ = true;
   size_t rec_mark_ = 0;
-  std::string rec_;  // FDH_DEBUG_SNAP=1 (diagnostic): the surface as phase 0 left it, copied in-stream
+  std::string rec_;
   int surf_w_ = 0, surf_h_ = 0;
-  // records, quad extensions, bounding boxes and phase offsets of a frame live in ONE device block and arrive with ONE
-  // copy (four small hipMemcpyAsync calls cost the host ~100 us per frame); the typed views point into it
+  // records, quad extensions, bin records and phase offsets of a frame live in ONE device block; the typed views point into it
   DeviceBuf<uint8_t> d_frame_;
   DeviceBuf<uint32_t> d_mask_spill_;  // clip-stack levels beyond kMaskDepth (Context::prepare sizes it)
   DeviceBuf<uint2> d_lists_;
@@ -385,20 +522,24 @@ class Context {
   DeviceBuf<int> d_order_[2];  // phase 0's bins, longest list first: read by this frame's launch / written for the next
   int order_read_ = 0, order_nb_ = 0;
   bool order_valid_ = false;
-  // three pinned staging buffers in rotation, each guarded by an event recorded after its copies: the host builds
-  // frame N+1 and N+2 while frame N still runs (a single buffer forced a stream sync per frame)
+  // kStaging sets of lanes in rotation, each guarded by an event recorded behind the upload that reads it: the host records
+  // frames N + 1 .. while frame N's upload has not run yet (one set forced a stream sync per frame)
   struct MxTables { int reach; std::vector<float> dense; std::vector<uint8_t> h, v; };  // k_blur_mx weight fragments of one filter
   std::vector<MxTables> mx_cache_;
-  static constexpr int kStaging = 3;
-  PinnedBuf<uint8_t> staging_[kStaging];
-  std::vector<uint8_t> shadow_;       // host copy of what the device's frame block holds (submit: upload only what differs)
+  static constexpr int kStaging = 4;
+  std::vector<std::unique_ptr<Lane>> lanes_[kStaging];
+  std::unique_ptr<Lane> merge_lane_[kStaging];
+  std::vector<std::unique_ptr<Recorder>> pool_recs_;  // the pool threads' recorders (slot s records into lane s + 1)
+  uint64_t frame_no_ = 0;
+  HostVec<uint8_t> misc_[kStaging];   // per slot: phase table, blur weight tables
+  // retained scenes: host copy of what the device's frame block holds (prepare: upload only what differs)
+  std::vector<uint8_t> shadow_;
   std::vector<size_t> shadow_layout_; // the offsets that block was laid out with
   const void* shadow_dev_ = nullptr;  // ... and where it lives
   int64_t uploaded_bytes_ = 0;        // by the last submit
   hipEvent_t staging_ev_[kStaging] = {};
   bool staging_busy_[kStaging] = {};
   int staging_i_ = 0;
-  std::vector<int> diff_scratch_;
 
   // atlas
   int atlas_size_ = 0, initial_atlas_size_ = 0, atlas_margin_ = 4, n_levels_ = 0;
@@ -411,6 +552,7 @@ class Context {
   float host_record_ms_ = 0.0f;
 };
 
+void record_host_form(DrawRec& r);  // undo the device form of a committed record's colours (fdh_record.cpp)
 void stripe_rows(int height, int world, int rank, int* y0, int* y1);
 void comm_unique_id(uint8_t out[FDH_COMM_ID_BYTES]);
 void blur_weight_fragments(float blur_radius, bool vertical, float* dense, uint16_t* frag_bits, int* reach, int* k_steps);

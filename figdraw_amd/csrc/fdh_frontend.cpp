@@ -9,17 +9,50 @@
 #include <vector>
 
 #include "fdh_context.h"
+#include "fdh_host.h"
+#include "fdh_walkpool.h"
 
 namespace fdh {
 
-FdhColor sample_fill(const FdhFill& f, float t);
+// Who is whose child, found once per layer: first_child[i] / next_sibling[i] are the nodes whose parent is i, in index order (a
+// parent precedes its children: a node that names a later node, or none, is nobody's child -- exactly what the reference's forward
+// scan finds, childIndex fignodes.nim:165-177); blur_below[i]: a backdrop-blur node sits in i's subtree (i included) -- such a
+// subtree splits the frame into phases and is always walked by the calling thread.
+struct LayerLinks {
+  const FdhLayer* layer = nullptr;
+  std::vector<int> first_child, next_sibling, last_child;
+  std::vector<uint8_t> blur_below;
+  void build(const FdhLayer& L) {
+    if (layer == &L) return;
+    layer = &L;
+    const size_t n = (size_t)std::max(L.n_nodes, 0);
+    first_child.assign(n, -1); next_sibling.assign(n, -1); last_child.assign(n, -1);
+    blur_below.assign(n, 0);
+    for (size_t i = 0; i < n; i++) {
+      if (L.nodes[i].kind == FDH_NK_BACKDROP_BLUR) blur_below[i] = 1;
+      const int p = L.nodes[i].parent;
+      if (p < 0 || (size_t)p >= i) continue;
+      if (last_child[(size_t)p] < 0) first_child[(size_t)p] = (int)i; else next_sibling[(size_t)last_child[(size_t)p]] = (int)i;
+      last_child[(size_t)p] = (int)i;
+    }
+    for (size_t i = n; i-- > 0;) {
+      const int p = L.nodes[i].parent;
+      if (blur_below[i] && p >= 0 && (size_t)p < i) blur_below[(size_t)p] = 1;
+    }
+  }
+};
 
-namespace {
+struct Walker;
+struct ParallelWalk {  // (a friend of Context: the pool threads' recorders and lanes are the context's)
+  static bool group(Walker& main, const FdhLayer& L, const int* items, int n);
+};
 
 struct Walker {
-  Context& ctx;
+  Recorder& ctx;
   const FdhScene& scene;
   float ui;
+  LayerLinks* links;       // shared by the calling thread's walker and the pool threads' (built by the former, before a group starts)
+  bool can_fork = false;   // the calling thread's walker outside any group: large sibling groups go to the pool
 
   float scaled(float v) const { return v * ui; }  // common/shared.nim:94-95
 
@@ -471,20 +504,27 @@ struct Walker {
 
   int depth = 0;
   int64_t culled_subtrees = 0;
-  // first_child[i] / next_sibling[i]: the nodes whose parent is i, in index order (a parent precedes its children: a node that
-  // names a later node, or none, is nobody's child -- exactly what the forward scan finds)
-  const FdhLayer* linked = nullptr;
-  std::vector<int> first_child, next_sibling, last_child;
-  void children_of(const FdhLayer& L) {
-    if (linked == &L) return;
-    linked = &L;
-    const size_t n = (size_t)std::max(L.n_nodes, 0);
-    first_child.assign(n, -1); next_sibling.assign(n, -1); last_child.assign(n, -1);
-    for (size_t i = 0; i < n; i++) {
-      const int p = L.nodes[i].parent;
-      if (p < 0 || (size_t)p >= i) continue;
-      if (last_child[(size_t)p] < 0) first_child[(size_t)p] = (int)i; else next_sibling[(size_t)last_child[(size_t)p]] = (int)i;
-      last_child[(size_t)p] = (int)i;
+  bool has_blur(const FdhLayer& L, int idx) {
+    const FdhFig& n = L.nodes[idx];
+    if (n.kind == FDH_NK_BACKDROP_BLUR) return true;
+    if (n.child_count <= 0) return false;
+    links->build(L);
+    return links->blur_below[(size_t)idx] != 0;
+  }
+  // A run of siblings in painter's order (the roots of a layer, the children of a node).  Runs of at least kForkMin nodes
+  // without a blur node below them go to the walk pool when this is the calling thread's walker (ParallelWalk::group); everything
+  // else is walked here, one node after the other, exactly as the reference does.
+  static constexpr int kForkMin = 48;
+  void siblings(const FdhLayer& L, const int* items, int n) {
+    if (!can_fork || n < kForkMin) { for (int k = 0; k < n; k++) node(L, items[k]); return; }
+    int i = 0;
+    while (i < n) {
+      if (has_blur(L, items[i])) { node(L, items[i]); i++; continue; }
+      int j = i;
+      while (j < n && !has_blur(L, items[j])) j++;
+      if (j - i < kForkMin || !ParallelWalk::group(*this, L, items + i, j - i))
+        for (int k = i; k < j; k++) node(L, items[k]);
+      i = j;
     }
   }
   void node(const FdhLayer& L, int idx) {
@@ -564,9 +604,16 @@ struct Walker {
     // same nodes in the same order come out of sibling links built in one pass per layer (children_of): a parent of a thousand
     // children -- a table's viewport -- otherwise strides over all its grandchildren to find them, a few MB of node structs.
     if (n.child_count > 0) {
-      children_of(L);
-      int seen = 0;
-      for (int i = first_child[(size_t)idx]; i >= 0 && seen < n.child_count; i = next_sibling[(size_t)i]) { seen++; node(L, i); }
+      links->build(L);
+      if (can_fork && n.child_count >= kForkMin) {
+        std::vector<int> kids;
+        kids.reserve((size_t)n.child_count);
+        for (int i = links->first_child[(size_t)idx]; i >= 0 && (int)kids.size() < n.child_count; i = links->next_sibling[(size_t)i]) kids.push_back(i);
+        siblings(L, kids.data(), (int)kids.size());
+      } else {
+        int seen = 0;
+        for (int i = links->first_child[(size_t)idx]; i >= 0 && seen < n.child_count; i = links->next_sibling[(size_t)i]) { seen++; node(L, i); }
+      }
     }
     if (rmask) ctx.pop_rect_mask();
     if (clip) ctx.pop_mask();
@@ -575,7 +622,97 @@ struct Walker {
   }
 };
 
-}  // namespace
+// ------------------------------------------------------------------ a sibling group on the walk pool
+// The reference walks the tree on one thread, every frame (figrender.nim:1756-1839, 1960-2002) -- and so did this library until
+// round 4: 50 ns per draw record, which for the reference's own benchmark trees (thousands of nodes, examples/
+// windy_non_clip_benchmark.nim:82-147) was ten times what the GPU needs for the frame.  A run of siblings is independent work
+// once the state they inherit is fixed -- the transform, the AA factor, how many clips and rect masks are open around them -- so
+// it is cut into chunks that pool threads (and this one) decompose into their own lanes of records; the chunks' pieces are
+// then listed in painter's order.  What crosses chunk boundaries is put right by the calling thread: the bounds of the clips open
+// around the group grow by each chunk's union, the phase takes each chunk's summary, the list stride each thread's maximum.
+// Subtrees holding a backdrop-blur node never get here (Walker::siblings): a blur splits the frame into phases.
+bool ParallelWalk::group(Walker& mw, const FdhLayer& L, const int* items, int n) {
+  Context& C = *mw.ctx.cx_;
+  const int helpers = C.walk_threads();
+  if (helpers <= 0 || C.rec_on_ || !C.frame_begun_) return false;
+  const int slots = helpers + 1;
+  const int n_chunks = std::min(n / 12, slots * 4);
+  if (n_chunks < 2) return false;
+  struct alignas(128) Out {
+    Piece p;
+    PhaseSum s;
+    BBox outer{0, 0, 0, 0};
+    int64_t frags = 0, culled = 0;
+    bool serial_only = false;
+    std::exception_ptr err;
+  };
+  std::vector<Out> outs((size_t)n_chunks);
+  mw.links->build(L);  // (the pool threads read the links: built before they start)
+  C.pool_slots(slots);
+  struct Mark { size_t recs, exts; };
+  std::vector<Mark> marks((size_t)slots);
+  for (int s = 0; s < slots; s++) { Lane& Ln = C.lane(s + 1); marks[(size_t)s] = Mark{Ln.recs.n, Ln.exts.n}; }
+  std::vector<int> slot_max((size_t)slots, 0);
+  const Recorder& base = mw.ctx;
+  const int outer_rmasks = (int)base.rect_masks_.size() + base.outer_rect_masks_;
+  const bool outer_open = !base.open_ops_.empty() || base.outer_open_;
+  C.close_piece();
+  auto fn = [&](int slot, int c) {
+    Recorder& R = *C.pool_recs_[(size_t)slot];
+    Lane& Ln = C.lane(slot + 1);
+    if (c < 0) { slot_max[(size_t)slot] = Ln.count_close(); return; }
+    Out& o = outs[(size_t)c];
+    thread_local int t_dev = -1;
+    if (!C.host_only_ && t_dev != C.device_) { (void)hipSetDevice(C.device_); t_dev = C.device_; }  // (a lane that grows allocates pinned memory)
+    R.lane_ = &Ln;
+    R.mat_ = base.mat_; R.mats_.clear();
+    R.aa_ = base.aa_; R.subpixel_shift_ = base.subpixel_shift_;
+    R.mask_begun_ = false; R.mask_depth_ = 0;
+    R.rect_masks_.clear(); R.outer_rect_masks_ = outer_rmasks;
+    R.open_ops_.clear(); R.outer_open_ = outer_open; R.outer_union_ = BBox{0, 0, 0, 0};
+    R.depth_now_ = 0;
+    R.sum_ = PhaseSum{};
+    R.fragments_ = 0; R.culled_draws_ = 0;
+    R.phase_floor_ = (int)Ln.recs.n;
+    o.p.lane = slot + 1; o.p.first = (uint32_t)Ln.recs.n; o.p.ext_first = (uint32_t)Ln.exts.n;
+    try {
+      Walker w{R, mw.scene, mw.ui, mw.links, false};
+      w.depth = mw.depth;
+      const int i0 = (int)((int64_t)c * n / n_chunks), i1 = (int)((int64_t)(c + 1) * n / n_chunks);
+      for (int k = i0; k < i1; k++) w.node(L, items[k]);
+    } catch (const SerialOnly&) {
+      o.serial_only = true;
+    } catch (...) {
+      o.err = std::current_exception();
+    }
+    o.p.n = (uint32_t)Ln.recs.n - o.p.first; o.p.n_ext = (uint32_t)Ln.exts.n - o.p.ext_first;
+    o.s = R.sum_; o.outer = R.outer_union_; o.frags = R.fragments_; o.culled = R.culled_draws_;
+  };
+  const bool ran = WalkPool::get().run(helpers, n_chunks, fn);
+  bool failed = !ran;
+  std::exception_ptr err;
+  for (const Out& o : outs) { if (o.serial_only || o.err) failed = true; if (o.err && !err) err = o.err; }
+  if (failed) {  // nothing of the group stays: the calling thread walks it itself (or the frame ends with the error)
+    for (int s = 0; s < slots; s++) { Lane& Ln = C.lane(s + 1); Ln.recs.n = Ln.bins.n = marks[(size_t)s].recs; Ln.exts.n = marks[(size_t)s].exts; }
+    C.open_piece();
+    if (err) std::rethrow_exception(err);
+    return false;
+  }
+  Piece run{};
+  PhaseSum none{};
+  for (const Out& o : outs) {
+    // (chunks one thread took back to back lie back to back in its lane: one piece)
+    if (run.n && run.lane == o.p.lane && run.first + run.n == o.p.first && run.ext_first + run.n_ext == o.p.ext_first) { run.n += o.p.n; run.n_ext += o.p.n_ext; }
+    else { if (run.n) C.add_piece(run, none, BBox{0, 0, 0, 0}, 0, 0); run = o.p; }
+    Piece nothing{};
+    C.add_piece(nothing, o.s, o.outer, o.frags, o.culled);
+  }
+  if (run.n) C.add_piece(run, none, BBox{0, 0, 0, 0}, 0, 0);
+  for (int s = 0; s < slots; s++) C.phase_extra_ += slot_max[(size_t)s];
+  C.open_piece();
+  C.parallel_groups_++;
+  return true;
+}
 
 // How far, in rows, the scene's backdrop blurs can carry a pixel's influence: the sum over its blur nodes of the tap reach of
 // their filters (make_taps: at most max(radius, 8) + 1 rows, 66 for the clamped radius 64).  A row stripe is rendered with that
@@ -603,15 +740,14 @@ void Context::render_frame(const FdhScene* scene, float fw, float fh, bool clear
   try {
     save_transform();
     scale(pixel_scale_, pixel_scale_);
-    Walker wk{*this, *scene, ui_scale_};
+    LayerLinks links;
+    Walker wk{*this, *scene, ui_scale_, &links, true};
     for (int l = 0; l < scene->n_layers; l++) {
       const FdhLayer& L = scene->layers[l];
       if ((L.n_nodes > 0 && !L.nodes) || (L.n_roots > 0 && !L.root_ids)) throw Error(FDH_ERR_INVALID, "render_frame: a layer's node or root array is null");
-      for (int r = 0; r < L.n_roots; r++) {
-        const int idx = L.root_ids[r];
-        if (idx < 0 || idx >= L.n_nodes) throw Error(FDH_ERR_INVALID, "render_frame: root index out of range");
-        wk.node(L, idx);
-      }
+      for (int r = 0; r < L.n_roots; r++)
+        if (L.root_ids[r] < 0 || L.root_ids[r] >= L.n_nodes) throw Error(FDH_ERR_INVALID, "render_frame: root index out of range");
+      wk.siblings(L, L.root_ids, L.n_roots);
     }
     restore_transform();
   } catch (...) {
@@ -893,45 +1029,44 @@ void Context::scene_render() {
   R.roots_walked = R.roots_reused = 0;
   if (stripe_y1_ > stripe_y0_ && culling()) pending_reach_ = scene_blur_reach(view, ui_scale_);
   begin_frame((int)w, (int)h, R.clear, R.rgba);
-  rec_diff_upload_ = true;  // consecutive frames of a retained scene differ in a few records: Context::submit uploads the difference
+  rec_diff_upload_ = true;  // consecutive frames of a retained scene differ in a few records: Context::prepare uploads the difference
   try {
     save_transform();
     scale(pixel_scale_, pixel_scale_);
-    Walker wk{*this, view, ui_scale_};
+    LayerLinks links;
+    Walker wk{*this, view, ui_scale_, &links, false};  // (roots are walked one by one: each has its cache entry)
+    Lane& L0 = lane(0);
     for (size_t l = 0; l < R.layers.size(); l++) {
       RetainedLayer& D = R.layers[l];
       for (size_t s = 0; s < D.roots.size(); s++) {
         RetainedRoot& C = D.cache[s];
         // (cached records were culled to the rows in force when they were made: good for any frame that produces no row beyond them)
         if (!C.dirty && C.cacheable && !config_changed && C.cull_y0 <= cull_y0_ && C.cull_y1 >= cull_y1_ && C.atlas_epoch == atlas_epoch_) {
-          // splice the cached records back: extension indices move with the frame's extension array
-          const uint32_t e0 = (uint32_t)exts_.size();
-          const size_t r0 = recs_.size();
-          recs_.insert(recs_.end(), C.recs.begin(), C.recs.end());
-          bboxes_.insert(bboxes_.end(), C.bboxes.begin(), C.bboxes.end());
-          exts_.insert(exts_.end(), C.exts.begin(), C.exts.end());
-          if (!C.exts.empty())
-            for (size_t i = r0; i < recs_.size(); i++) if (recs_[i].op_mode & F_GENERAL) recs_[i].ext += e0;
-          phases_.back().count += (int)C.recs.size();
-          fragments_ += C.fragments;
+          splice_cached(C);
           R.roots_reused++;
           continue;
         }
-        const size_t r0 = recs_.size(), e0 = exts_.size(), p0 = phases_.size(), b0 = blurs_.size();
+        const size_t r0 = L0.recs.n, e0 = L0.exts.n, p0 = phases_.size(), b0 = blurs_.size();
         const int64_t f0 = fragments_;
+        const int d0 = depth_now_;
+        add_sum(sum_, 0);  // (what the phase has so far goes to the phase: the root's own summary starts from nothing)
+        sum_ = PhaseSum{};
         wk.node(views[l], D.roots[s]);
         R.roots_walked++;
         C.dirty = false;
         C.atlas_epoch = atlas_epoch_;
         C.cull_y0 = cull_y0_; C.cull_y1 = cull_y1_;
         C.cacheable = phases_.size() == p0 && blurs_.size() == b0;
-        C.recs.clear(); C.bboxes.clear(); C.exts.clear();
+        C.recs.clear(); C.bins.clear(); C.exts.clear();
         if (C.cacheable) {
-          C.recs.assign(recs_.begin() + (std::ptrdiff_t)r0, recs_.end());
-          C.bboxes.assign(bboxes_.begin() + (std::ptrdiff_t)r0, bboxes_.end());
-          C.exts.assign(exts_.begin() + (std::ptrdiff_t)e0, exts_.end());
+          C.recs.assign(L0.recs.p + r0, L0.recs.p + L0.recs.n);
+          C.bins.assign(L0.bins.p + r0, L0.bins.p + L0.bins.n);
+          C.exts.assign(L0.exts.p + e0, L0.exts.p + L0.exts.n);
           for (DrawRec& r : C.recs) if (r.op_mode & F_GENERAL) r.ext -= (uint32_t)e0;
+          if (!C.bins.empty()) C.bins.back().flags &= ~LE_SHARE;  // (what follows the root is decided at every splice: Context::splice_cached)
           C.fragments = fragments_ - f0;
+          C.sum = sum_;
+          C.sum.deepest = std::max(0, sum_.deepest - d0);
         }
       }
     }

@@ -1,0 +1,141 @@
+// fdh_walkpool.cpp -- a small fork-join pool for the scene front-end (fdh_frontend.cpp: ParallelWalk).
+//
+// The reference's renderer walks its node tree on one thread, every frame (figrender.nim:1960-2002), and its own benchmarks time
+// that walk.  Here the walk of a large sibling group -- the roots of a layer, the cells of a table's viewport -- is split into
+// chunks that pool threads decompose side by side, each into its own lane of draw records (fdh_context.h); the calling thread
+// takes chunks too and then puts the pieces in painter's order.  Frames come tens of microseconds apart, so a pool thread that
+// has just worked spins for a while before it sleeps: waking a sleeping thread costs more than a group's walk.
+#include "fdh_walkpool.h"
+
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cstdlib>
+#include <memory>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+namespace fdh {
+
+namespace {
+inline void relax() {
+#if defined(__x86_64__) || defined(__i386__)
+  __builtin_ia32_pause();
+#else
+  std::this_thread::yield();
+#endif
+}
+struct alignas(128) Shared {
+  std::atomic<uint64_t> epoch{0};     // bumped once per group
+  std::atomic<int> next{0};           // the next chunk to hand out
+  std::atomic<int> through{0};        // helper slots that have finished the current group
+  std::atomic<int> asleep{0};         // helpers blocked on the condition variable
+  int helpers = 0, n_chunks = 0;      // of the current group (written before the epoch is bumped)
+  const std::function<void(int, int)>* fn = nullptr;
+  std::mutex mu;
+  std::condition_variable cv;
+  bool quit = false;
+};
+}  // namespace
+
+struct WalkPoolImpl {
+  Shared sh;
+  std::mutex owner;  // one group at a time
+  std::vector<std::thread> threads;
+  int spin_us = 200;
+  void helper_main(int slot) {
+    uint64_t seen = 0;
+    for (;;) {
+      // wait for the next group: spin first (the next frame is tens of microseconds away), then sleep
+      const auto t0 = std::chrono::steady_clock::now();
+      uint64_t e;
+      int spins = 0;
+      while ((e = sh.epoch.load(std::memory_order_acquire)) == seen) {
+        relax();
+        if ((++spins & 255) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(spin_us)) {
+          std::unique_lock<std::mutex> lk(sh.mu);
+          sh.asleep.fetch_add(1, std::memory_order_seq_cst);
+          sh.cv.wait(lk, [&] { return sh.quit || sh.epoch.load(std::memory_order_acquire) != seen; });
+          sh.asleep.fetch_sub(1, std::memory_order_seq_cst);
+          if (sh.quit) return;
+        }
+      }
+      seen = e;
+      if (slot > sh.helpers) continue;  // this group uses fewer helpers
+      const std::function<void(int, int)>& fn = *sh.fn;
+      for (;;) {
+        const int c = sh.next.fetch_add(1, std::memory_order_acq_rel);
+        if (c >= sh.n_chunks) break;
+        fn(slot, c);
+      }
+      fn(slot, -1);
+      sh.through.fetch_add(1, std::memory_order_acq_rel);
+    }
+  }
+  ~WalkPoolImpl() {
+    { std::lock_guard<std::mutex> lk(sh.mu); sh.quit = true; }
+    sh.epoch.fetch_add(1, std::memory_order_release);
+    sh.cv.notify_all();
+    for (auto& t : threads) if (t.joinable()) t.join();
+  }
+};
+
+static WalkPoolImpl& impl() {
+  // (never destroyed: a pool thread may be mid-spin when the process exits; the OS takes the threads with it)
+  static WalkPoolImpl* p = [] {
+    auto* q = new WalkPoolImpl();
+    if (const char* e = std::getenv("FDH_WALK_SPIN_US")) q->spin_us = std::max(0, std::atoi(e));
+    return q;
+  }();
+  return *p;
+}
+
+WalkPool& WalkPool::get() {
+  static WalkPool w;
+  return w;
+}
+
+int WalkPool::default_helpers() {
+  static const int v = [] {
+    if (const char* e = std::getenv("FDH_WALK_THREADS")) return std::min(std::max(std::atoi(e), 0), 64);
+    const unsigned hw = std::thread::hardware_concurrency();
+    if (hw < 4) return 0;
+    return (int)std::min(3u, hw / 4);  // a few: the walk of a frame is tens of microseconds, not a reason to take the machine
+  }();
+  return v;
+}
+
+bool WalkPool::run(int helpers, int n_chunks, const std::function<void(int, int)>& fn) {
+  WalkPoolImpl& P = impl();
+  if (helpers <= 0 || n_chunks <= 0) return false;
+  std::unique_lock<std::mutex> own(P.owner, std::try_to_lock);
+  if (!own.owns_lock()) return false;
+  helpers = std::min(helpers, 64);
+  while ((int)P.threads.size() < helpers) {
+    const int slot = (int)P.threads.size() + 1;
+    P.threads.emplace_back([&P, slot] { P.helper_main(slot); });
+  }
+  Shared& sh = P.sh;
+  sh.helpers = helpers;
+  sh.n_chunks = n_chunks;
+  sh.fn = &fn;
+  sh.next.store(0, std::memory_order_relaxed);
+  sh.through.store(0, std::memory_order_relaxed);
+  sh.epoch.fetch_add(1, std::memory_order_seq_cst);
+  if (sh.asleep.load(std::memory_order_seq_cst) > 0) {
+    std::lock_guard<std::mutex> lk(sh.mu);
+    sh.cv.notify_all();
+  }
+  for (;;) {  // the calling thread is slot 0
+    const int c = sh.next.fetch_add(1, std::memory_order_acq_rel);
+    if (c >= n_chunks) break;
+    fn(0, c);
+  }
+  fn(0, -1);
+  // every helper of this group passes through (one that slept through the work still bumps the counter when it wakes)
+  while (sh.through.load(std::memory_order_acquire) < helpers) relax();
+  return true;
+}
+
+}  // namespace fdh

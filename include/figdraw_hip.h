@@ -318,6 +318,14 @@ FDH_API int fdh_set_stripe(FdhContext*, int y0, int y1);
  * (tests/test_hip_parity.py, tests/test_culling.py).  mode 0: off; 1 (default): on, except while the call recorder runs (recorded
  * streams stay call for call the reference's); 2: on even then.  fdh_culled_draws: draws dropped from the last frame. */
 FDH_API int fdh_set_cull(FdhContext*, int mode);
+/* The scene front-end (fdh_render_frame) decomposes large sibling groups of the tree -- the roots of a layer, the children of a
+ * node: 48 siblings or more, no backdrop-blur node below them -- on `n` threads of a process-wide pool beside the calling thread:
+ * every thread records into its own arrays, the upload gathers them in painter's order.  n = 0: the calling thread alone (the
+ * reference's model: one render thread, figrender.nim:1960-2002); n < 0 (default): FDH_WALK_THREADS from the environment, or
+ * min(3, cores / 4).  The records are the same whatever n is (fdh_debug_record_digest; tests/test_parallel_walk.py).
+ * fdh_walk_stats: the thread count in force and how many sibling groups of the last frame went to the pool. */
+FDH_API int fdh_set_walk_threads(FdhContext*, int n);
+FDH_API int fdh_walk_stats(FdhContext*, int* threads, int64_t* parallel_groups);
 FDH_API int fdh_culled_draws(FdhContext*, int64_t* out);
 /* ---- the gather over RCCL / xGMI (one process per GPU).  Nothing is exchanged while a frame renders; the one
  * collective of the path is the gather of the finished RGBA8 rows or frames to one rank: grouped ncclSend / ncclRecv on the

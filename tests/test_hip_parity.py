@@ -944,3 +944,50 @@ def test_fuzz_sweep_slice_within_the_north_star_tolerance(lo):
         ctx.close()
         assert mx <= 2 and n1 <= 4, (seed, "beyond the north star's +-2 LSB", mx, n0, n1)
         assert n0 <= 0.05 * w * h, (seed, n0)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The walk pool (fdh_set_walk_threads): frames recorded by several threads -- pieces gathered by k_upload_frame, extension indices
+# re-based on the way, bin boxes built on the device -- must equal the frames the calling thread records alone, bit for bit.
+def _render_with_threads(ctx, sc, w, h, threads):
+    ctx.set_walk_threads(threads)
+    ctx.render_frame(sc, w, h)
+    px = ctx.read_pixels()
+    groups = ctx.walk_stats()[1]
+    ctx.set_walk_threads(-1)
+    return px, groups
+
+
+@pytest.mark.parametrize("which", ["bench", "non_clip", "sub_clip", "rect_mask", "wide5", "wide9", "many_groups"])
+def test_frames_recorded_on_the_walk_pool_equal_the_serial_ones(hip, which):
+    from figdraw_amd import scene as S
+    from figdraw_amd.scenes import make_clip_mask_benchmark, make_non_clip_benchmark, make_render_tree_100
+    from test_parallel_walk import _wide_scene
+
+    if which == "bench":
+        w, h, sc = 3840, 2160, make_render_tree_100(3840, 2160, 4, full_frame_blur=True)
+    elif which == "non_clip":
+        w, h, sc = 1200, 800, make_non_clip_benchmark()
+    elif which in ("sub_clip", "rect_mask"):
+        w, h, sc = 1200, 800, make_clip_mask_benchmark(which)
+    elif which.startswith("wide"):
+        w, h = (1280, 720) if which == "wide5" else (1920, 1080)
+        sc = _wide_scene(int(which[4:]), w, h)  # rotated quads (extension indices), clips around the group, blur roots between groups
+    else:
+        w, h = 800, 600
+        lst = S.RenderList()
+        for g in range(14):  # 14 forked groups: more pieces than the upload's run table holds -> consolidated
+            parent = lst.addRoot(S.Fig(kind=S.FigKind.nkFrame, screenBox=S.rect(0, 40.0 * g, w, 40)))
+            for k in range(60):
+                lst.addChild(parent, S.Fig(kind=S.FigKind.nkRectangle, screenBox=S.rect(12.0 * k, 40.0 * g + 4, 10, 30), corners=[2] * 4,
+                                           fill=S.rgba((k * 37) & 255, (g * 53) & 255, 90, 255), rotation=5.0 if k % 9 == 0 else 0.0))
+        sc = S.Renders()
+        sc.setLayer(0, lst)
+    serial, g0 = _render_with_threads(hip, sc, w, h, 0)
+    for threads in (1, 3):
+        forked, g = _render_with_threads(hip, sc, w, h, threads)
+        assert g0 == 0 and g > 0
+        assert np.array_equal(serial, forked), (which, threads)
+    want = _oracle(lambda *_: sc, w, h)
+    mx, n0, n1 = diff_stats(serial, want)
+    assert mx <= 1 and n0 <= 0.005 * w * h, (which, mx, n0, n1)
