@@ -251,7 +251,7 @@ class Recorder {
   DrawRec& next_rec();  // the lane's next record slot, zeroed (counted by emit_* when the draw survives culling)
   bool emit_quad(DrawRec& r, float x0, float y0, float x1, float y1, bool count_fragments);  // false: culled, nothing was recorded
   bool emit_quad_pts(DrawRec& r, const float vx[4], const float vy[4], bool count_fragments);
-  void push_rec(const BBox& b);  // count the slot next_rec() handed out
+  void push_rec(BBox b);  // count the slot next_rec() handed out
   void commit_bins(uint32_t idx);  // the record's bounds are final: list-entry flags, list-stride count, phase summary
   void link_share(uint32_t idx);   // LE_SHARE on idx - 1 when record idx is drawn over the same quad with the same shape
   bool bbox_visible(const BBox& b) const;

@@ -986,7 +986,16 @@ void Context::scene_replace_root(int layer, int slot, const FdhFig* subtree, int
     for (size_t i = 0; i < D.nodes.size(); i++)
       if (ro[i] != old_root) { remap[i] = (int)kept.size(); kept.push_back(D.nodes[i]); }
     for (FdhFig& f : kept) if (f.parent >= 0) f.parent = remap[(size_t)f.parent];
-    for (size_t s = 0; s < D.roots.size(); s++) if ((int)s != slot) D.roots[s] = remap[(size_t)D.roots[s]];
+    // (a root slot whose node hangs inside the removed subtree -- fdh_scene_update_nodes may have given a listed root a parent --
+    // goes with it: it would name a node that no longer exists)
+    for (size_t s = D.roots.size(); s-- > 0;) {
+      if ((int)s == slot) continue;
+      const int to = remap[(size_t)D.roots[s]];
+      if (to >= 0) { D.roots[s] = to; continue; }
+      D.roots.erase(D.roots.begin() + (std::ptrdiff_t)s);
+      D.cache.erase(D.cache.begin() + (std::ptrdiff_t)s);
+      if ((int)s < slot) slot--;
+    }
     D.nodes.swap(kept);
     if (n == 0) { D.roots.erase(D.roots.begin() + slot); D.cache.erase(D.cache.begin() + slot); compact_side(); return; }
   } else {

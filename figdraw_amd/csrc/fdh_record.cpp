@@ -137,7 +137,7 @@ DrawRec& Recorder::next_rec() {
   return *r;
 }
 // counts the slot next_rec() handed out; its BinRec starts as bare bounds (flags follow when the bounds are final: commit_bins)
-void Recorder::push_rec(const BBox& b) {
+void Recorder::push_rec(BBox b) {  // (by value: callers pass bounds that live in the very array slot() may move)
   BinRec* br = lane_->bins.slot();
   *br = BinRec{b, 0, 0, 0, 0, 0u, 0u};
   lane_->recs.n++;
