@@ -130,6 +130,7 @@ def load():
     L.fdh_set_cull.argtypes = [vp, C.c_int]
     L.fdh_culled_draws.argtypes = [vp, C.POINTER(C.c_int64)]
     L.fdh_set_walk_threads.argtypes = [vp, C.c_int]
+    L.fdh_debug_host_times.argtypes = [vp, C.POINTER(C.c_int64)]
     L.fdh_walk_stats.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int64)]
     L.fdh_stripe_rows.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.fdh_comm_unique_id.argtypes = [C.c_char_p]
@@ -458,6 +459,13 @@ class HipContext:
     def set_walk_threads(self, n: int):
         """pool threads the scene front-end decomposes large sibling groups on, beside the calling thread (0: serial; < 0: default)"""
         self._ck(self.L.fdh_set_walk_threads(self.h, int(n)))
+
+    def host_times(self):
+        """ns the calling thread spent in the last frame: begin_frame, upload wait, walk, end, prepare, publish, drain, groups, pool, merge"""
+        out = (C.c_int64 * 12)()
+        self._ck(self.L.fdh_debug_host_times(self.h, out))
+        names = ["begin_frame", "wait_upload", "walk", "end", "prepare", "publish", "drain", "groups", "pool_run", "merge"]
+        return {k: out[i] for i, k in enumerate(names)}
 
     def walk_stats(self):
         """(threads in force, sibling groups of the last frame that went to the pool)"""

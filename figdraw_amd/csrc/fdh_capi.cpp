@@ -258,6 +258,12 @@ int fdh_gather_frames(FdhContext* c, int dst_rank, void* const* dst_images) { re
 int fdh_set_blur_route(FdhContext* c, int route) { return guard([&] { C(c)->set_blur_route(route); }); }
 int fdh_set_stripe(FdhContext* c, int y0, int y1) { return guard([&] { C(c)->set_stripe(y0, y1); }); }
 int fdh_set_cull(FdhContext* c, int mode) { return guard([&] { C(c)->set_cull(mode); }); }
+int fdh_debug_host_times(FdhContext* c, int64_t out_ns[12]) {
+  return guard([&] {
+    if (!out_ns) throw fdh::Error(FDH_ERR_INVALID, "null output");
+    for (int i = 0; i < 12; i++) out_ns[i] = C(c)->host_ns_[i];
+  });
+}
 int fdh_set_walk_threads(FdhContext* c, int n) { return guard([&] { C(c)->set_walk_threads(n); }); }
 int fdh_walk_stats(FdhContext* c, int* threads, int64_t* parallel_groups) {
   return guard([&] {

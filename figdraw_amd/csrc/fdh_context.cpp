@@ -562,7 +562,7 @@ void Context::prepare(LaunchJob& J) {
   J.n_recs = (int)n;
   J.bins_x = (W_ + kBin - 1) / kBin;
   J.bins_y = (H_ + kBin - 1) / kBin;
-  J.binbox_shift = (J.bins_x > 128 || J.bins_y > 128) ? 1 : 0;
+  J.binbox_shift = binbox_shift_;
   const int nb = J.bins_x * J.bins_y;
   // List stride = the largest number of draws any bin of any phase can receive: counted while the frame was recorded
   // (Lane::count_add / count_close per phase; lanes of pool threads add their own maxima: an upper bound)
@@ -649,8 +649,8 @@ void Context::prepare(LaunchJob& J) {
   const int slot = staging_i_;
   J.staging_slot = slot;
   J.d_dst = d_frame_.ptr;
-  // ---- the slot's small print: phase table, then the blur weight tables (when the device block does not hold them already)
-  std::vector<size_t> layout{total, o_recs, o_ext, o_bb, o_box, o_chunk, o_pf};
+  // ---- the slot's small print: chunk boxes, phase table, then the blur weight tables (when the device block does not hold them already)
+  std::vector<size_t> layout{total, o_recs, o_ext, o_bb, o_box, o_chunk, o_pf, n, n_ext};
   for (size_t i = 0; i < J.blurs.size(); i++) { layout.push_back(o_mxh[i]); layout.push_back(o_mxv[i]); }
   std::vector<float> tables_sig;
   for (size_t i = 0; i < J.blurs.size(); i++)
@@ -661,13 +661,25 @@ void Context::prepare(LaunchJob& J) {
   if (!rec_diff_upload_) shadow_dev_ = nullptr;
   const bool shadow_ok = rec_diff_upload_ && shadow_dev_ == d_frame_.ptr && shadow_layout_ == layout && shadow_.size() == total;
   const bool tables_resident = tables_dev_ == d_frame_.ptr && tables_layout_ == layout && tables_sig_ == tables_sig && (!rec_diff_upload_ || shadow_ok);
-  HostVec<uint8_t>& misc = misc_[slot];
-  misc.pinned = true;
-  misc.clear();
-  misc.reserve(total - o_pf);  // (sized for the worst case up front: the run table below points into it)
-  misc.n = total - o_pf;
-  std::memset(misc.p, 0, up(b_pf));
-  std::memcpy(misc.p, pf.data(), b_pf);
+  // (built in ordinary memory -- the retained path compares and keeps it -- and copied to the slot's pinned buffer in one go)
+  std::vector<uint8_t>& misc = misc_host_;
+  const size_t o_misc = o_chunk;  // the block from the chunk boxes on
+  misc.assign((tables_resident ? o_tables : total) - o_misc, 0);
+  std::memcpy(misc.data() + (o_pf - o_misc), pf.data(), b_pf);
+  {  // chunk boxes: the union box of every 256 consecutive draws = byte-wise min of their bin boxes (x0, y0 min; 127 - x1, 127 - y1 min)
+    uint32_t* cb = reinterpret_cast<uint32_t*>(misc.data());
+    for (size_t c = 0; c < n_chunks; c++) cb[c] = 0x7f7f7f7fu;
+    size_t g = 0;
+    for (const Piece& p : pieces_) {
+      const uint32_t* bx = lane(p.lane).boxes.p + p.first;
+      for (uint32_t i = 0; i < p.n; i++, g++) {
+        const uint32_t m = cb[g >> 8], v = bx[i];
+        uint32_t o = 0;
+        for (int sh = 0; sh < 32; sh += 8) o |= std::min((m >> sh) & 255u, (v >> sh) & 255u) << sh;
+        cb[g >> 8] = o;
+      }
+    }
+  }
   for (size_t i = 0; i < J.blurs.size() && !tables_resident; i++)
     if (o_mxh[i]) {
       // the fragments depend on the filter alone: an animation blurs with the same radii frame after frame, and building
@@ -688,9 +700,13 @@ void Context::prepare(LaunchJob& J) {
         mx_cache_.push_back(std::move(c));
         hit = &mx_cache_.back();
       }
-      std::memcpy(misc.p + (o_mxh[i] - o_pf), hit->h.data(), bh);
-      std::memcpy(misc.p + (o_mxv[i] - o_pf), hit->v.data(), bv);
+      std::memcpy(misc.data() + (o_mxh[i] - o_misc), hit->h.data(), bh);
+      std::memcpy(misc.data() + (o_mxv[i] - o_misc), hit->v.data(), bv);
     }
+  HostVec<uint8_t>& up_misc = misc_[slot];
+  up_misc.pinned = true;
+  up_misc.n = 0;
+  up_misc.reserve(misc.size());
   // ---- the runs k_upload_frame gathers.  Every piece brings three: its records (extension indices re-based on the way), its bin
   // records, its extensions; then the phase table (+ tables).  A frame recorded by one thread is one piece.
   auto dev_view = [](const void* host) { void* d = nullptr; FDH_HIP(hipHostGetDevicePointer(&d, const_cast<void*>(host), 0)); return (const uint8_t*)d; };
@@ -698,14 +714,14 @@ void Context::prepare(LaunchJob& J) {
   // device views of the lanes' arrays, index lane + 1 (slot 0: the consolidated lane)
   const size_t n_lanes = lanes_[(size_t)slot].size() + 1;
   std::vector<const uint8_t*> d_recs(n_lanes, nullptr), d_bins(n_lanes, nullptr), d_exts(n_lanes, nullptr);
-  for (const Piece& p : pieces_) {
+  auto views = [&](const Piece& p) {  // (after the piece's lane was published: the mirrors are where they will stay)
     const size_t l = (size_t)(p.lane + 1);
     const Lane& Ln = lane(p.lane);
-    if (!d_recs[l] && Ln.recs.p) d_recs[l] = dev_view(Ln.recs.p);
-    if (!d_bins[l] && Ln.bins.p) d_bins[l] = dev_view(Ln.bins.p);
-    if (!d_exts[l] && Ln.exts.p) d_exts[l] = dev_view(Ln.exts.p);
-  }
-  const uint8_t* d_misc = dev_view(misc.p);
+    if (!d_recs[l] && Ln.up_recs.p) d_recs[l] = dev_view(Ln.up_recs.p);
+    if (!d_bins[l] && Ln.up_bins.p) d_bins[l] = dev_view(Ln.up_bins.p);
+    if (!d_exts[l] && Ln.up_exts.p) d_exts[l] = dev_view(Ln.up_exts.p);
+  };
+  const uint8_t* d_misc = dev_view(up_misc.p);
   J.runs.clear();
   auto add_run = [&](std::vector<UploadRun>& to, const uint8_t* src, size_t dst_off, size_t bytes, uint32_t ext_add, uint32_t kind) {
     if (!bytes) return;
@@ -737,32 +753,45 @@ void Context::prepare(LaunchJob& J) {
     };
     // (one piece of lane 0 starting at extension 0: the records' extension indices are the frame's already)
     if (p0.ext_first == 0) {
+      Lane& Lw = lane(0);
+      Lw.publish(0, 0, 0, 0);  // (the mirrors exist and fit the lane: their addresses are final)
+      views(p0);
       diff(reinterpret_cast<const uint8_t*>(L.recs.p + p0.first), d_recs[1] + (size_t)p0.first * sizeof(DrawRec), o_recs, b_recs, 0u);
       diff(reinterpret_cast<const uint8_t*>(L.exts.p), d_exts[1], o_ext, b_ext, 0u);
-      diff(reinterpret_cast<const uint8_t*>(L.bins.p + p0.first), d_bins[1] + (size_t)p0.first * sizeof(BinRec), o_bb, b_bb, 4u);
-      diff(misc.p, d_misc, o_pf, up(b_pf), 0u);
+      diff(reinterpret_cast<const uint8_t*>(L.bins.p + p0.first), d_bins[1] + (size_t)p0.first * sizeof(BinRec), o_bb, b_bb, 1u);
+      diff(misc.data(), d_misc, o_misc, o_tables - o_misc, 0u);
       if (fits && dirty * 2 < total) {
-        for (size_t k = 0; k < runs.size(); k++) std::memcpy(shadow_.data() + runs[k].dst_off, from[k], runs[k].bytes);
+        for (size_t k = 0; k < runs.size(); k++) {
+          std::memcpy(shadow_.data() + runs[k].dst_off, from[k], runs[k].bytes);
+          // what travels is published now: the dirty chunks alone
+          const size_t off = runs[k].dst_off;
+          if (off >= o_misc) std::memcpy(up_misc.p + (off - o_misc), misc.data() + (off - o_misc), runs[k].bytes);
+          else if (off >= o_bb) Lw.publish_bytes(1, (size_t)p0.first * sizeof(BinRec) + (off - o_bb), runs[k].bytes);
+          else if (off >= o_ext && b_ext) Lw.publish_bytes(2, off - o_ext, runs[k].bytes);
+          else Lw.publish_bytes(0, (size_t)p0.first * sizeof(DrawRec) + (off - o_recs), runs[k].bytes);
+        }
         J.runs = runs;
-        // the bin boxes are rebuilt from ALL bin records at the source (8 bytes per draw over the link)
-        add_run(J.runs, d_bins[1] + (size_t)p0.first * sizeof(BinRec), o_bb, b_bb, 0u, 3u);
-        link_bytes = (int64_t)dirty + (int64_t)n * 8;
+        link_bytes = (int64_t)dirty;
         patched = true;
       }
     }
   }
   if (!patched) {
     uint32_t at_rec = 0, at_ext = 0;
+    std::memcpy(up_misc.p, misc.data(), misc.size());
     for (const Piece& p : pieces_) {
+      // pieces the calling thread recorded are published here (clips open around a sibling group took the group's bounds after
+      // their records were made); a pool thread published its pieces when it finished them
+      if (p.lane <= 0) { HostTimer t(host_ns_[5]); lane(p.lane).publish(p.first, p.n, p.ext_first, p.n_ext); }
+      views(p);
       const size_t l = (size_t)(p.lane + 1);
       add_run(J.runs, d_recs[l] + (size_t)p.first * sizeof(DrawRec), o_recs + (size_t)at_rec * sizeof(DrawRec), (size_t)p.n * sizeof(DrawRec), at_ext - p.ext_first, 2u);
       add_run(J.runs, d_bins[l] + (size_t)p.first * sizeof(BinRec), o_bb + (size_t)at_rec * sizeof(BinRec), (size_t)p.n * sizeof(BinRec), 0u, 1u);
       if (p.n_ext) add_run(J.runs, d_exts[l] + (size_t)p.ext_first * sizeof(QuadExt), o_ext + (size_t)at_ext * sizeof(QuadExt), (size_t)p.n_ext * sizeof(QuadExt), 0u, 0u);
       at_rec += p.n; at_ext += p.n_ext;
     }
-    add_run(J.runs, d_misc, o_pf, tables_resident ? up(b_pf) : total - o_pf, 0u, 0u);
+    add_run(J.runs, d_misc, o_misc, misc.size(), 0u, 0u);
     for (const UploadRun& r : J.runs) link_bytes += r.bytes;
-    link_bytes += (int64_t)n * 8;
     if (rec_diff_upload_) {  // take the shadow this frame's successors are compared with
       if (shadow_.size() != total) shadow_.assign(total, 0);
       else if (!tables_resident) std::fill(shadow_.begin(), shadow_.end(), 0);
@@ -776,7 +805,7 @@ void Context::prepare(LaunchJob& J) {
         if (p.n_ext) std::memcpy(shadow_.data() + o_ext + ae * sizeof(QuadExt), L.exts.p + p.ext_first, (size_t)p.n_ext * sizeof(QuadExt));
         ar += p.n; ae += p.n_ext;
       }
-      std::memcpy(shadow_.data() + o_pf, misc.p, tables_resident ? up(b_pf) : total - o_pf);
+      std::memcpy(shadow_.data() + o_misc, misc.data(), misc.size());
       shadow_layout_ = layout;
       shadow_dev_ = d_frame_.ptr;
     }
@@ -784,8 +813,7 @@ void Context::prepare(LaunchJob& J) {
   uploaded_bytes_ = link_bytes;
   J.table = UploadTable{};
   J.table.n_draws = (uint32_t)n; J.table.binbox_shift = (uint32_t)J.binbox_shift;
-  J.table.bins_off = (uint32_t)o_bb; J.table.box_off = (uint32_t)o_box; J.table.chunk_off = (uint32_t)o_chunk;
-  J.n_chunks = (uint32_t)n_chunks;
+  J.table.bins_off = (uint32_t)o_bb; J.table.box_off = (uint32_t)o_box;
   tables_dev_ = d_frame_.ptr; tables_layout_ = layout; tables_sig_.swap(tables_sig);
   // algorithmic bytes of this frame: final store + per blur (pre-blur store is the store above for
   // a full-frame node; H read + H write + V read + V write + composite read) + records once
@@ -849,6 +877,7 @@ void Context::consolidate_pieces() {
     S.recs.append(L.recs.p + p.first, p.n);
     S.bins.append(L.bins.p + p.first, p.n);
     S.exts.append(L.exts.p + p.ext_first, p.n_ext);
+    S.boxes.append(L.boxes.p + p.first, p.n);
     for (size_t i = r0; i < S.recs.n; i++) if (S.recs[i].op_mode & F_GENERAL) S.recs[i].ext += (uint32_t)e0 - p.ext_first;
   }
   Piece all;
@@ -881,10 +910,10 @@ void Context::issue(LaunchJob& J) {
       if (T.n_runs >= (uint32_t)kMaxUploadRuns) throw Error(FDH_ERR_UNSUPPORTED, "upload: run table overflow");
       T.run[T.n_runs] = r;
       T.unit_first[T.n_runs] = T.copy_units;
-      if (r.kind != 3u) T.copy_units += (r.bytes + 1023u) / 1024u;
+      T.copy_units += (r.bytes + 1023u) / 1024u;
       T.n_runs++;
     }
-    launch_upload_frame(stream_, J.d_dst, T, J.n_chunks);
+    launch_upload_frame(stream_, J.d_dst, T);
   }
   if (J.staging_slot >= 0) {
     FDH_HIP(hipEventRecord(staging_ev_[J.staging_slot], stream_));

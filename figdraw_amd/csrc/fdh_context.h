@@ -79,9 +79,10 @@ struct PinnedBuf {
   }
 };
 
-// A growable array the recording threads write and the upload kernel reads: pinned host memory on device contexts (the GPU
-// fetches it over PCIe: no staging copy), plain memory on FDH_CREATE_RECORD_ONLY ones.  Growth copies (doubling: rare once
-// a context has seen its scene); elements are plain data.
+// A growable array of plain data, in ordinary memory or -- `pinned` -- in host memory the GPU fetches over PCIe (hipHostMalloc).
+// Pinned memory is written once, front to back, and never read by the CPU: on this platform the CPU's loads from it are not
+// served from its caches (a record read back from a pinned lane cost ~100 ns; round 4 measured 82 us for a 700-record frame that
+// took 4 us from ordinary memory).  Growth copies what the array holds (doubling: rare once a context has seen its scene).
 template <typename T>
 struct HostVec {
   T* p = nullptr;
@@ -146,15 +147,23 @@ struct BlurJob {
 
 // ------------------------------------------------------------------ the recorded frame
 // A frame's draw records are produced in their FINAL form while the calls arrive -- the 128-byte DrawRec the compositor reads,
-// the 24-byte BinRec the bin kernel reads (pixel bounds, saturated core, list-entry flags), the quad extensions -- straight into
-// host memory the GPU fetches from (HostVec): nothing is built a second time or copied at submit.  A LANE is what one thread
-// records: lane 0 belongs to the thread that calls the context, lanes 1.. to the walk pool's threads (fdh_frontend.cpp:
-// large sibling groups of the scene tree are decomposed in parallel).  The frame in painter's order is a list of PIECES, each a
-// run of consecutive records of one lane; the upload kernel gathers the pieces into the dense device arrays (k_upload_frame).
+// the 24-byte BinRec the bin kernel reads (pixel bounds, saturated core, list-entry flags), the quad extensions: nothing is
+// built a second time at submit.  A LANE is what one thread records: lane 0 belongs to the thread that calls the context,
+// lanes 1.. to the walk pool's threads (fdh_frontend.cpp: large sibling groups of the scene tree are decomposed in parallel).
+// The frame in painter's order is a list of PIECES, each a run of consecutive records of one lane.  A finished piece is
+// PUBLISHED -- copied, by the thread that recorded it, into the lane's pinned mirror arrays -- and the upload kernel gathers the
+// published pieces into the dense device arrays (k_upload_frame).
 struct Lane {
   HostVec<DrawRec> recs;
   HostVec<BinRec> bins;   // bins[i].box IS the bounds of record i (clip pushes: the union of their content, final at the pop)
   HostVec<QuadExt> exts;  // DrawRec::ext of an F_GENERAL record indexes THIS array; the upload re-bases it
+  HostVec<uint32_t> boxes;  // the records' 4-byte bin boxes (what k_bin_draws scans; the device derives its own from the BinRecs):
+                            // kept here for the chunk boxes -- the union box of every 256 draws -- which prepare builds over the pieces
+  HostVec<DrawRec> up_recs;  // pinned mirrors (device contexts): what the GPU reads; element i = element i of the array above
+  HostVec<BinRec> up_bins;
+  HostVec<QuadExt> up_exts;
+  bool device = false;
+  size_t pub_recs = 0, pub_exts = 0;  // elements below these may have been published this frame (kept across a mirror's growth)
   // List stride (the largest number of list entries any bin of any phase can receive: it sizes the bin lists): a 2-D difference
   // array over the bin grid, four updates per record when its bounds are final, evaluated per phase (count_close).
   std::vector<int> diff;
@@ -162,8 +171,10 @@ struct Lane {
   int tx0 = 0, ty0 = 0, tx1 = 0, ty1 = 0;
   bool touched = false;
   uint64_t stamp = 0;  // the frame a pool thread's lane was last cleared for
-  void set_pinned(bool on) { recs.pinned = bins.pinned = exts.pinned = on; }
-  void clear() { recs.clear(); bins.clear(); exts.clear(); }
+  void set_pinned(bool on) { device = on; up_recs.pinned = up_bins.pinned = up_exts.pinned = on; }
+  void clear() { recs.clear(); bins.clear(); exts.clear(); boxes.clear(); pub_recs = pub_exts = 0; }
+  void publish(uint32_t first, uint32_t n, uint32_t ext_first, uint32_t n_ext);  // records / extensions are final: copy them to the mirrors
+  void publish_bytes(int array, size_t at, size_t len);                          // ... a byte range of one array (0 recs, 1 bins, 2 exts)
   void count_begin(int bins_x, int bins_y);
   void count_add(const BBox& b);
   int count_close();  // the largest count of any bin since the last close; leaves the array zeroed
@@ -321,7 +332,6 @@ struct LaunchJob {
   // the upload: the runs k_upload_frame gathers (records, bin records, extensions of every piece; phase table; blur tables)
   std::vector<UploadRun> runs;
   UploadTable table;       // (filled from `runs` when the frame is issued)
-  uint32_t n_chunks = 1;   // 256-draw chunks whose bin boxes the upload builds
   void* d_dst = nullptr;
   int staging_slot = -1;
 };
@@ -460,6 +470,7 @@ class Context : public Recorder {
   bool subpixel_enabled_ = false, subpixel_variants_ = false;
   int stripe_y0_ = 0, stripe_y1_ = 0;
   int cull_mode_ = 1;
+  int binbox_shift_ = 0;           // bin boxes in 64 << shift px units (frames of more than 128 bins along an axis)
   int cull_y0_ = 0, cull_y1_ = 0;  // rows a draw must reach to be recorded (begin_frame: the frame, or the stripe + blur reach)
   int pending_reach_ = -1;         // render_frame / scene_render: summed vertical reach of the scene's blur nodes (-1: unknown)
   int64_t culled_total_ = 0;       // of the last recorded frame
@@ -531,7 +542,8 @@ class Context : public Recorder {
   std::unique_ptr<Lane> merge_lane_[kStaging];
   std::vector<std::unique_ptr<Recorder>> pool_recs_;  // the pool threads' recorders (slot s records into lane s + 1)
   uint64_t frame_no_ = 0;
-  HostVec<uint8_t> misc_[kStaging];   // per slot: phase table, blur weight tables
+  HostVec<uint8_t> misc_[kStaging];   // per slot (pinned): phase table, blur weight tables
+  std::vector<uint8_t> misc_host_;    // ... as prepare builds them
   // retained scenes: host copy of what the device's frame block holds (prepare: upload only what differs)
   std::vector<uint8_t> shadow_;
   std::vector<size_t> shadow_layout_; // the offsets that block was laid out with
@@ -548,7 +560,18 @@ class Context : public Recorder {
   std::unordered_map<int64_t, AtlasEntry> entries_;
 
   FdhFrameStats stats_ = {};
-  std::chrono::steady_clock::time_point t_begin_frame_;
+ public:
+  // where the calling thread's time went in the last frame, ns (fdh_debug_host_times): 0 begin_frame, 1 of it: waiting for the
+  // lane set's previous upload, 2 walk / calls (begin_frame's end .. end_frame), 3 end_frame before prepare, 4 prepare, 5 of it:
+  // publishing, 6 waiting for the submit thread, 7 sibling groups on the pool (of 2), 8 of it: the pool's run, 9 of it: merging
+  int64_t host_ns_[12] = {};
+  struct HostTimer {
+    int64_t& acc; std::chrono::steady_clock::time_point t0;
+    explicit HostTimer(int64_t& a) : acc(a), t0(std::chrono::steady_clock::now()) {}
+    ~HostTimer() { acc += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); }
+  };
+ private:
+  std::chrono::steady_clock::time_point t_begin_frame_, t_walk_begin_;
   float host_record_ms_ = 0.0f;
 };
 

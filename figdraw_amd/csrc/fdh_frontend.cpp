@@ -635,6 +635,7 @@ bool ParallelWalk::group(Walker& mw, const FdhLayer& L, const int* items, int n)
   Context& C = *mw.ctx.cx_;
   const int helpers = C.walk_threads();
   if (helpers <= 0 || C.rec_on_ || !C.frame_begun_) return false;
+  Context::HostTimer t_group(C.host_ns_[7]);
   const int slots = helpers + 1;
   const int n_chunks = std::min(n / 12, slots * 4);
   if (n_chunks < 2) return false;
@@ -663,7 +664,7 @@ bool ParallelWalk::group(Walker& mw, const FdhLayer& L, const int* items, int n)
     if (c < 0) { slot_max[(size_t)slot] = Ln.count_close(); return; }
     Out& o = outs[(size_t)c];
     thread_local int t_dev = -1;
-    if (!C.host_only_ && t_dev != C.device_) { (void)hipSetDevice(C.device_); t_dev = C.device_; }  // (a lane that grows allocates pinned memory)
+    if (!C.host_only_ && t_dev != C.device_) { (void)hipSetDevice(C.device_); t_dev = C.device_; }  // (a lane's pinned mirror is allocated by the thread that publishes into it)
     R.lane_ = &Ln;
     R.mat_ = base.mat_; R.mats_.clear();
     R.aa_ = base.aa_; R.subpixel_shift_ = base.subpixel_shift_;
@@ -686,18 +687,24 @@ bool ParallelWalk::group(Walker& mw, const FdhLayer& L, const int* items, int n)
       o.err = std::current_exception();
     }
     o.p.n = (uint32_t)Ln.recs.n - o.p.first; o.p.n_ext = (uint32_t)Ln.exts.n - o.p.ext_first;
+    if (!o.serial_only && !o.err) {
+      try { Ln.publish(o.p.first, o.p.n, o.p.ext_first, o.p.n_ext); }  // (final: every clip the chunk opened it closed)
+      catch (...) { o.err = std::current_exception(); }
+    }
     o.s = R.sum_; o.outer = R.outer_union_; o.frags = R.fragments_; o.culled = R.culled_draws_;
   };
-  const bool ran = WalkPool::get().run(helpers, n_chunks, fn);
+  bool ran;
+  { Context::HostTimer t(C.host_ns_[8]); ran = WalkPool::get().run(helpers, n_chunks, fn); }
   bool failed = !ran;
   std::exception_ptr err;
   for (const Out& o : outs) { if (o.serial_only || o.err) failed = true; if (o.err && !err) err = o.err; }
   if (failed) {  // nothing of the group stays: the calling thread walks it itself (or the frame ends with the error)
-    for (int s = 0; s < slots; s++) { Lane& Ln = C.lane(s + 1); Ln.recs.n = Ln.bins.n = marks[(size_t)s].recs; Ln.exts.n = marks[(size_t)s].exts; }
+    for (int s = 0; s < slots; s++) { Lane& Ln = C.lane(s + 1); Ln.recs.n = Ln.bins.n = Ln.boxes.n = marks[(size_t)s].recs; Ln.exts.n = marks[(size_t)s].exts; }
     C.open_piece();
     if (err) std::rethrow_exception(err);
     return false;
   }
+  Context::HostTimer t_merge(C.host_ns_[9]);
   Piece run{};
   PhaseSum none{};
   for (const Out& o : outs) {

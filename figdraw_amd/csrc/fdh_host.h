@@ -28,6 +28,7 @@ inline void bbox_union(BBox& a, const BBox& b) {
   a.x0 = std::min(a.x0, b.x0); a.y0 = std::min(a.y0, b.y0); a.x1 = std::max(a.x1, b.x1); a.y1 = std::max(a.y1, b.y1);
 }
 BlurTaps make_taps(float blur_radius);
+uint32_t bin_box_of(const BBox& b, int shift);
 FdhColor sample_fill(const FdhFill& f, float t);
 void gradient_colors(const FdhFill& f, FdhColor out[4]);
 constexpr int64_t kRectImageKey = 0x7265637452454354LL;  // the 4x4 white image drawRect / drawFilledQuad sample (glcontext.nim:966-970)

@@ -75,19 +75,18 @@ void launch_lcd_filter(hipStream_t s, const uint32_t* src, uint32_t* dst, int w,
 void launch_minify2(hipStream_t s, const uint32_t* src, uint32_t* dst, int sw, int sh);  // dst: ((sw + 1) / 2) x ((sh + 1) / 2)
 void launch_atlas_blit(hipStream_t s, uint32_t* level, int LS, int x, int y, const uint32_t* src, int w, int h);
 // The frame upload (k_upload_frame): a table of runs, each `bytes` of pinned host memory (its device view) going to byte offset
-// dst_off of the frame block.  kind 0: 16-byte units; 1: BinRecs in draw order -- copied in 8-byte units, and the source the bin
-// boxes are built from; 2: DrawRecs -- 16-byte units, and the `ext` of every F_GENERAL record gets ext_add (extension indices are
-// relative to the recording thread's array); 3: BinRecs in draw order that are NOT copied (the device holds them: a retained
-// scene's frame), only read for the bin boxes; 4: 8-byte units, copy only.  The table travels in the kernel arguments (4 KB at most).
+// dst_off of the frame block.  kind 0: 16-byte units; 1: BinRecs -- copied in 8-byte units, and the lane that carries a record's
+// pixel bounds also writes the draw's 4-byte bin box; 2: DrawRecs -- 16-byte units, and the `ext` of every F_GENERAL record gets
+// ext_add (extension indices are relative to the recording thread's array).  The table travels in the kernel arguments (4 KB at most).
 constexpr int kMaxUploadRuns = 96;
 struct UploadRun { const void* src; uint32_t dst_off, bytes, ext_add, kind; };
 struct UploadTable {
   uint32_t n_runs, copy_units, n_draws, binbox_shift;
-  uint32_t bins_off, box_off, chunk_off, _pad;  // byte offsets of the BinRec / bin box / chunk box arrays in the block
+  uint32_t bins_off, box_off, _pad0, _pad1;     // byte offsets of the BinRec / bin box arrays in the block
   uint32_t unit_first[kMaxUploadRuns];           // the first 1-KB unit of run r (ascending)
   UploadRun run[kMaxUploadRuns];
 };
 static_assert(sizeof(UploadTable) <= 4096, "the table must fit the kernel-argument segment");
-void launch_upload_frame(hipStream_t s, void* dst, const UploadTable& T, uint32_t n_chunks);
+void launch_upload_frame(hipStream_t s, void* dst, const UploadTable& T);
 
 }  // namespace fdh

@@ -2968,69 +2968,49 @@ void launch_blur_v(hipStream_t s, const BlurParams& P, const DrawRec* draws, con
 // k_upload_frame GATHERS the frame block: the recording threads leave the frame as PIECES -- runs of DrawRecs, BinRecs and quad
 // extensions in each thread's own pinned arrays (fdh_context.h: Lane) -- and the table in the kernel arguments says where every
 // run goes in the dense device arrays.  One wavefront per 1-KB unit of a run (the whole table sits in SGPRs / the scalar cache:
-// no dependent round trip over the host link before the data's own), and behind those one wavefront per 256 draws that builds
-// what the bin kernel scans -- the 4-byte bin boxes and their per-256 union boxes -- from the BinRecs' pixel bounds, read at
-// the source: the host never writes them.  A piece's extension indices are lane-relative; the copy re-bases them.
+// no dependent round trip over the host link before the data's own).  A piece's extension indices are lane-relative; the copy
+// re-bases them.  The 4-byte bin boxes the bin kernel scans are derived on the way: the lane that copies the first 8 bytes of
+// a BinRec -- its pixel bounds -- writes the draw's box too, so the host never stores or sends them.  (First version: a second
+// role in this kernel read the BinRecs again at the source, per 256 draws, for boxes and chunk boxes: its dependent reads over the
+// host link made the launch 20 us long; the chunk boxes now come from the host, a few dozen bytes.)
 __global__ __launch_bounds__(64) void k_upload_frame(uint8_t* __restrict__ dst, UploadTable T) {
   const uint32_t lane = threadIdx.x;
-  if (blockIdx.x < T.copy_units) {
-    const uint32_t u = blockIdx.x;
-    uint32_t r = 0;
-    for (uint32_t k = 1; k < T.n_runs; k++) r = T.unit_first[k] <= u ? k : r;  // (unit_first ascends: the last run that starts at or before u)
-    const UploadRun R = T.run[r];
-    const uint32_t at = (u - T.unit_first[r]) * 1024u;
-    if (R.kind == 1u || R.kind == 4u) {  // 8-byte units (BinRecs are 24 bytes: a piece starts 8-byte aligned)
+  const uint32_t u = blockIdx.x;
+  uint32_t r = 0;
+  for (uint32_t k = 1; k < T.n_runs; k++) r = T.unit_first[k] <= u ? k : r;  // (unit_first ascends: the last run that starts at or before u)
+  const UploadRun R = T.run[r];
+  const uint32_t at = (u - T.unit_first[r]) * 1024u;
+  if (R.kind == 1u) {  // BinRecs in 8-byte units (24 bytes each: a piece starts 8-byte aligned)
+    const uint32_t ush = 6u + T.binbox_shift;
 #pragma unroll
-      for (int h = 0; h < 2; h++) {
-        const uint32_t o = at + (lane + 64u * h) * 8u;
-        if (o < R.bytes) *reinterpret_cast<uint2*>(dst + R.dst_off + o) = *reinterpret_cast<const uint2*>(static_cast<const uint8_t*>(R.src) + o);
-      }
-      return;
+    for (int h = 0; h < 2; h++) {
+      const uint32_t o = at + (lane + 64u * h) * 8u;
+      if (o >= R.bytes) continue;
+      const uint2 v = *reinterpret_cast<const uint2*>(static_cast<const uint8_t*>(R.src) + o);
+      *reinterpret_cast<uint2*>(dst + R.dst_off + o) = v;
+      const uint32_t rel = R.dst_off - T.bins_off + o;  // byte offset in the BinRec array
+      if (rel % 24u != 0u) continue;
+      const uint32_t draw = rel / 24u;
+      const int x0 = (int)(int16_t)(v.x & 0xffffu), y0 = (int)(int16_t)(v.x >> 16), x1 = (int)(int16_t)(v.y & 0xffffu), y1 = (int)(int16_t)(v.y >> 16);
+      uint32_t q = 0x7f7f7f7fu;  // x0 = y0 = 127, x1 = y1 = 0: never hits
+      if (x1 > x0 && y1 > y0)
+        q = (uint32_t)(x0 >> ush) | ((uint32_t)(y0 >> ush) << 8) | ((127u - (uint32_t)((x1 - 1) >> ush)) << 16) | ((127u - (uint32_t)((y1 - 1) >> ush)) << 24);
+      uint32_t* box = reinterpret_cast<uint32_t*>(dst + T.box_off);
+      box[draw] = q;
+      if (draw + 1u == T.n_draws)  // the array is read four draws at a time: pad the last group
+        for (uint32_t k = draw + 1u; (k & 3u) != 0u; k++) box[k] = 0x7f7f7f7fu;
     }
-    const uint32_t o = at + lane * 16u;
-    if (o >= R.bytes) return;
-    uint4 v = *reinterpret_cast<const uint4*>(static_cast<const uint8_t*>(R.src) + o);
-    if (R.kind == 2u && (o & 127u) == 0u && (v.x & F_GENERAL)) v.y += R.ext_add;  // a record's first 16 bytes: op_mode, ext
-    *reinterpret_cast<uint4*>(dst + R.dst_off + o) = v;
     return;
   }
-  // ---- bin boxes + chunk box of draws [256 c, 256 c + 256)
-  const uint32_t c = blockIdx.x - T.copy_units;
-  const uint32_t i4 = c * 256u + lane * 4u;
-  const uint32_t ush = 6u + T.binbox_shift;
-  uint32_t q[4] = {0x7f7f7f7fu, 0x7f7f7f7fu, 0x7f7f7f7fu, 0x7f7f7f7fu};  // x0 = y0 = 127, x1 = y1 = 0: never hits
-  for (uint32_t r = 0; r < T.n_runs; r++) {
-    if (T.run[r].kind != 1u && T.run[r].kind != 3u) continue;  // the runs that hold BinRecs in draw order
-    const uint32_t first = (T.run[r].dst_off - T.bins_off) / 24u, cnt = T.run[r].bytes / 24u;
-    if (first + cnt <= c * 256u || first >= c * 256u + 256u) continue;  // (wave-uniform)
-    const uint8_t* src = static_cast<const uint8_t*>(T.run[r].src);
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const uint32_t i = i4 + j;
-      if (i < first || i >= first + cnt) continue;
-      const uint2 b = *reinterpret_cast<const uint2*>(src + (size_t)(i - first) * 24u);
-      const int x0 = (int)(int16_t)(b.x & 0xffffu), y0 = (int)(int16_t)(b.x >> 16), x1 = (int)(int16_t)(b.y & 0xffffu), y1 = (int)(int16_t)(b.y >> 16);
-      if (x1 > x0 && y1 > y0)
-        q[j] = (uint32_t)(x0 >> ush) | ((uint32_t)(y0 >> ush) << 8) | ((127u - (uint32_t)((x1 - 1) >> ush)) << 16) | ((127u - (uint32_t)((y1 - 1) >> ush)) << 24);
-    }
-  }
-  if (i4 < ((T.n_draws + 3u) & ~3u)) *reinterpret_cast<uint4*>(dst + T.box_off + (size_t)i4 * 4u) = make_uint4(q[0], q[1], q[2], q[3]);
-  // the chunk's union box = byte-wise minimum (x0, y0 min; 127 - x1, 127 - y1 min)
-  auto bmin = [](uint32_t a, uint32_t b) {
-    uint32_t o = 0;
-#pragma unroll
-    for (int sh = 0; sh < 32; sh += 8) o |= min((a >> sh) & 255u, (b >> sh) & 255u) << sh;
-    return o;
-  };
-  uint32_t m = bmin(bmin(q[0], q[1]), bmin(q[2], q[3]));
-#pragma unroll
-  for (int sh = 32; sh >= 1; sh >>= 1) m = bmin(m, (uint32_t)__shfl_xor((int)m, sh, 64));
-  if (lane == 0) *reinterpret_cast<uint32_t*>(dst + T.chunk_off + (size_t)c * 4u) = m;
+  const uint32_t o = at + lane * 16u;
+  if (o >= R.bytes) return;
+  uint4 v = *reinterpret_cast<const uint4*>(static_cast<const uint8_t*>(R.src) + o);
+  if (R.kind == 2u && (o & 127u) == 0u && (v.x & F_GENERAL)) v.y += R.ext_add;  // a record's first 16 bytes: op_mode, ext
+  *reinterpret_cast<uint4*>(dst + R.dst_off + o) = v;
 }
-void launch_upload_frame(hipStream_t s, void* dst, const UploadTable& T, uint32_t n_chunks) {
-  const uint32_t grid = T.copy_units + n_chunks;
-  if (grid == 0) return;
-  hipLaunchKernelGGL(k_upload_frame, dim3(grid), dim3(64), 0, s, static_cast<uint8_t*>(dst), T);
+void launch_upload_frame(hipStream_t s, void* dst, const UploadTable& T) {
+  if (T.copy_units == 0) return;
+  hipLaunchKernelGGL(k_upload_frame, dim3(T.copy_units), dim3(64), 0, s, static_cast<uint8_t*>(dst), T);
 }
 void launch_fill(hipStream_t s, uint32_t* p, uint32_t v, size_t n) {
   if (n == 0) return;

@@ -140,8 +140,17 @@ DrawRec& Recorder::next_rec() {
 void Recorder::push_rec(BBox b) {  // (by value: callers pass bounds that live in the very array slot() may move)
   BinRec* br = lane_->bins.slot();
   *br = BinRec{b, 0, 0, 0, 0, 0u, 0u};
+  *lane_->boxes.slot() = 0x7f7f7f7fu;
   lane_->recs.n++;
   lane_->bins.n++;
+  lane_->boxes.n++;
+}
+
+// What k_bin_draws scans: 7-bit inclusive bounds in bin units, upper bounds complemented (x0 | y0 << 8 | (127 - x1) << 16 |
+// (127 - y1) << 24; x0 = y0 = 127, x1 = y1 = 0 never hits).  The device derives the same word from the BinRec (k_upload_frame).
+uint32_t bin_box_of(const BBox& b, int shift) {
+  if (bbox_empty(b)) return 0x7f7f7f7fu;
+  return (uint32_t)(b.x0 >> shift) | ((uint32_t)(b.y0 >> shift) << 8) | ((127u - (uint32_t)((b.x1 - 1) >> shift)) << 16) | ((127u - (uint32_t)((b.y1 - 1) >> shift)) << 24);
 }
 
 // The bin-independent part of a draw's list entries (BinRec::flags): which straight-line path its edge strips take, what its
@@ -216,6 +225,7 @@ void Recorder::commit_bins(uint32_t idx) {
   br.ix0 = r.ix0; br.iy0 = r.iy0; br.ix1 = r.ix1; br.iy1 = r.iy1;
   br.flags = binrec_flags(r);
   const BBox b = br.box;
+  lane_->boxes[idx] = bin_box_of(b, 6 + cx_->binbox_shift_);
   lane_->count_add(b);
   bbox_union(sum_.u, b);
   // which compositor build the phase needs (mirrors the path selection of k_composite_tiles)
@@ -241,6 +251,41 @@ void Recorder::commit_bins(uint32_t idx) {
       std::memcpy(&r.col[1], u, sizeof u);
     }
   }
+}
+
+// ------------------------------------------------------------------ publishing (Lane)
+// The mirrors grow with the lane (never shrink, never hold more than the lane); a mirror that had to move is filled again from the
+// lane up to what had been published -- from ordinary memory: pinned memory is not read.
+static void mirror_fit(Lane& L) {
+  auto fit = [](auto& up, const auto& src, size_t published) {
+    if (up.cap >= src.cap) return;
+    up.n = 0;  // (nothing to carry over: reserve() would READ the old pinned block)
+    up.reserve(src.cap);
+    if (published) std::memcpy(static_cast<void*>(up.p), static_cast<const void*>(src.p), published * sizeof(*src.p));
+  };
+  fit(L.up_recs, L.recs, L.pub_recs);
+  fit(L.up_bins, L.bins, L.pub_recs);
+  fit(L.up_exts, L.exts, L.pub_exts);
+}
+void Lane::publish(uint32_t first, uint32_t n, uint32_t ext_first, uint32_t n_ext) {
+  if (!device) return;
+  mirror_fit(*this);
+  if (n) {
+    std::memcpy(static_cast<void*>(up_recs.p + first), static_cast<const void*>(recs.p + first), (size_t)n * sizeof(DrawRec));
+    std::memcpy(static_cast<void*>(up_bins.p + first), static_cast<const void*>(bins.p + first), (size_t)n * sizeof(BinRec));
+    pub_recs = std::max(pub_recs, (size_t)first + n);
+  }
+  if (n_ext) {
+    std::memcpy(static_cast<void*>(up_exts.p + ext_first), static_cast<const void*>(exts.p + ext_first), (size_t)n_ext * sizeof(QuadExt));
+    pub_exts = std::max(pub_exts, (size_t)ext_first + n_ext);
+  }
+}
+void Lane::publish_bytes(int array, size_t at, size_t len) {
+  if (!device || !len) return;
+  mirror_fit(*this);
+  uint8_t* dst = array == 0 ? reinterpret_cast<uint8_t*>(up_recs.p) : array == 1 ? reinterpret_cast<uint8_t*>(up_bins.p) : reinterpret_cast<uint8_t*>(up_exts.p);
+  const uint8_t* src = array == 0 ? reinterpret_cast<const uint8_t*>(recs.p) : array == 1 ? reinterpret_cast<const uint8_t*>(bins.p) : reinterpret_cast<const uint8_t*>(exts.p);
+  std::memcpy(dst + at, src + at, len);
 }
 
 // ------------------------------------------------------------------ list stride (Lane)
@@ -1020,6 +1065,7 @@ void Context::begin_frame(int w, int h, bool clear, const float rgba[4]) {  // g
   if (frame_begun_) throw Error(FDH_ERR_INVALID, "ctx.beginFrame has already been called.");
   if (w <= 0 || h <= 0 || w > 16384 || h > 16384) throw Error(FDH_ERR_INVALID, "beginFrame: frame size must be in 1..16384");
   t_begin_frame_ = std::chrono::steady_clock::now();
+  for (auto& v : host_ns_) v = 0;
   if (!host_only_) FDH_HIP(hipSetDevice(device_));
   W_ = w;
   H_ = h;
@@ -1033,10 +1079,11 @@ void Context::begin_frame(int w, int h, bool clear, const float rgba[4]) {  // g
   // kernel has run by now (that frame's issue was waited for by the end_frame after it: the event is recorded).
   staging_i_ = (staging_i_ + 1) % kStaging;
   frame_no_++;
-  if (!host_only_ && staging_busy_[staging_i_]) { FDH_HIP(hipEventSynchronize(staging_ev_[staging_i_])); staging_busy_[staging_i_] = false; }
+  if (!host_only_ && staging_busy_[staging_i_]) { HostTimer t(host_ns_[1]); FDH_HIP(hipEventSynchronize(staging_ev_[staging_i_])); staging_busy_[staging_i_] = false; }
   Lane& L0 = ensure_lane(0);
   L0.clear();
   L0.count_begin((w + kBin - 1) / kBin, (h + kBin - 1) / kBin);
+  binbox_shift_ = ((w + kBin - 1) / kBin > 128 || (h + kBin - 1) / kBin > 128) ? 1 : 0;
   lane_ = &L0;
   frame_begun_ = true;
   mask_begun_ = false;
@@ -1073,6 +1120,8 @@ void Context::begin_frame(int w, int h, bool clear, const float rgba[4]) {  // g
     cull_y1_ = std::min(H_, std::max(0, stripe_y1_) + pending_reach_);
   }
   pending_reach_ = -1;
+  t_walk_begin_ = std::chrono::steady_clock::now();
+  host_ns_[0] = std::chrono::duration_cast<std::chrono::nanoseconds>(t_walk_begin_ - t_begin_frame_).count();
 }
 
 // end_frame = prepare (this thread) + issue (the context's submit thread).
@@ -1086,16 +1135,19 @@ void Context::end_frame() {  // glcontext.nim:1982-1989
   if (mask_depth_ != 0) throw Error(FDH_ERR_INVALID, "Not all masks have been popped.");
   if (!rect_masks_.empty()) throw Error(FDH_ERR_INVALID, "Not all rect masks have been popped.");
   frame_begun_ = false;
+  const auto t0 = std::chrono::steady_clock::now();
+  host_ns_[2] = std::chrono::duration_cast<std::chrono::nanoseconds>(t0 - t_walk_begin_).count();
   close_phase();
   close_piece();
   culled_total_ = culled_draws_;
   const auto t1 = std::chrono::steady_clock::now();
+  host_ns_[3] = std::chrono::duration_cast<std::chrono::nanoseconds>(t1 - t0).count();
   host_record_ms_ = std::chrono::duration<float, std::milli>(t1 - t_begin_frame_).count();
   // a list entry carries the draw index in 25 bits beside its path code and flags (k_bin_draws, LE_INDEX)
   if (n_total_ >= LE_INDEX) throw Error(FDH_ERR_INVALID, "more than 33 554 430 draw records in one frame");
   if (host_only_) return;
-  prepare(next_);
-  drain();  // the previous frame's launches (normally long issued: they ran while this frame was being recorded)
+  { HostTimer t(host_ns_[4]); prepare(next_); }
+  { HostTimer t(host_ns_[6]); drain(); }  // the previous frame's launches (normally long issued: they ran while this frame was being recorded)
   std::swap(job_, next_);
   have_frame_ = true;
   if (!worker_.joinable()) { issue(job_); return; }
@@ -1142,7 +1194,9 @@ void Context::splice_cached(const RetainedRoot& C) {
   L.exts.append(C.exts.data(), C.exts.size());
   if (!C.exts.empty())
     for (size_t i = r0; i < L.recs.n; i++) if (L.recs[i].op_mode & F_GENERAL) L.recs[i].ext += e0;
-  for (size_t i = r0; i < L.bins.n; i++) L.count_add(L.bins[i].box);
+  L.boxes.reserve(L.bins.n);
+  for (size_t i = r0; i < L.bins.n; i++) { L.count_add(L.bins[i].box); L.boxes[i] = bin_box_of(L.bins[i].box, 6 + binbox_shift_); }
+  L.boxes.n = L.bins.n;
   bbox_union(sum_.u, C.sum.u);
   sum_.has_masks = sum_.has_masks || C.sum.has_masks;
   sum_.has_atlas = sum_.has_atlas || C.sum.has_atlas;

@@ -325,6 +325,11 @@ FDH_API int fdh_set_cull(FdhContext*, int mode);
  * min(3, cores / 4).  The records are the same whatever n is (fdh_debug_record_digest; tests/test_parallel_walk.py).
  * fdh_walk_stats: the thread count in force and how many sibling groups of the last frame went to the pool. */
 FDH_API int fdh_set_walk_threads(FdhContext*, int n);
+/* Diagnostic: where the calling thread spent the last frame, nanoseconds: [0] begin_frame, [1] of it waiting for the previous use
+ * of the frame's record arrays to be uploaded, [2] the calls / the tree walk, [3] end_frame before submission, [4] preparing the
+ * submission, [5] of it copying records into pinned memory, [6] waiting for the submit thread, [7] sibling groups on the walk
+ * pool (part of [2]), [8] of it inside the pool, [9] of it merging; [10], [11] reserved. */
+FDH_API int fdh_debug_host_times(FdhContext*, int64_t out_ns[12]);
 FDH_API int fdh_walk_stats(FdhContext*, int* threads, int64_t* parallel_groups);
 FDH_API int fdh_culled_draws(FdhContext*, int64_t* out);
 /* ---- the gather over RCCL / xGMI (one process per GPU).  Nothing is exchanged while a frame renders; the one

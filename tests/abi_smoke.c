@@ -232,6 +232,7 @@ int main(int argc, char** argv) {
       CHECK(r == FDH_OK || r == FDH_ERR_UNSUPPORTED || r == FDH_ERR_HIP);
     }
     OK(fdh_set_stripe(c, 0, 0));
+    { int64_t ns[12]; OK(fdh_debug_host_times(c, ns)); CHECK(ns[0] >= 0); }
     { int th = -1; int64_t groups = -1; OK(fdh_set_walk_threads(c, 2)); OK(fdh_walk_stats(c, &th, &groups)); CHECK(th == 2 && groups >= 0); OK(fdh_set_walk_threads(c, -1)); }
     { int64_t culled = -1; OK(fdh_set_cull(c, 0)); OK(fdh_set_cull(c, 1)); OK(fdh_culled_draws(c, &culled)); CHECK(culled >= 0); }
     OK(fdh_set_blur_route(c, 1)); OK(fdh_set_blur_route(c, -1));
