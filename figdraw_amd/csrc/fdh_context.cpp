@@ -711,17 +711,16 @@ void Context::prepare(LaunchJob& J) {
   // records, its extensions; then the phase table (+ tables).  A frame recorded by one thread is one piece.
   auto dev_view = [](const void* host) { void* d = nullptr; FDH_HIP(hipHostGetDevicePointer(&d, const_cast<void*>(host), 0)); return (const uint8_t*)d; };
   if (pieces_.size() * 3 + 2 > (size_t)kMaxUploadRuns) consolidate_pieces();  // (more pieces than the kernel-argument table holds: copy them together)
-  // device views of the lanes' arrays, index lane + 1 (slot 0: the consolidated lane)
+  // device views of the lanes' mirrors (taken by whoever allocated them), index lane + 1 (slot 0: the consolidated lane)
   const size_t n_lanes = lanes_[(size_t)slot].size() + 1;
   std::vector<const uint8_t*> d_recs(n_lanes, nullptr), d_bins(n_lanes, nullptr), d_exts(n_lanes, nullptr);
   auto views = [&](const Piece& p) {  // (after the piece's lane was published: the mirrors are where they will stay)
     const size_t l = (size_t)(p.lane + 1);
     const Lane& Ln = lane(p.lane);
-    if (!d_recs[l] && Ln.up_recs.p) d_recs[l] = dev_view(Ln.up_recs.p);
-    if (!d_bins[l] && Ln.up_bins.p) d_bins[l] = dev_view(Ln.up_bins.p);
-    if (!d_exts[l] && Ln.up_exts.p) d_exts[l] = dev_view(Ln.up_exts.p);
+    d_recs[l] = Ln.d_recs; d_bins[l] = Ln.d_bins; d_exts[l] = Ln.d_exts;
   };
-  const uint8_t* d_misc = dev_view(up_misc.p);
+  if (up_misc.p != misc_dev_host_[slot]) { misc_dev_[slot] = dev_view(up_misc.p); misc_dev_host_[slot] = up_misc.p; }
+  const uint8_t* d_misc = misc_dev_[slot];
   J.runs.clear();
   auto add_run = [&](std::vector<UploadRun>& to, const uint8_t* src, size_t dst_off, size_t bytes, uint32_t ext_add, uint32_t kind) {
     if (!bytes) return;

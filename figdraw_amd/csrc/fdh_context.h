@@ -163,6 +163,7 @@ struct Lane {
   HostVec<BinRec> up_bins;
   HostVec<QuadExt> up_exts;
   bool device = false;
+  const uint8_t *d_recs = nullptr, *d_bins = nullptr, *d_exts = nullptr;  // the mirrors as the device sees them (taken when a mirror is allocated)
   size_t pub_recs = 0, pub_exts = 0;  // elements below these may have been published this frame (kept across a mirror's growth)
   // List stride (the largest number of list entries any bin of any phase can receive: it sizes the bin lists): a 2-D difference
   // array over the bin grid, four updates per record when its bounds are final, evaluated per phase (count_close).
@@ -262,6 +263,9 @@ class Recorder {
   DrawRec& next_rec();  // the lane's next record slot, zeroed (counted by emit_* when the draw survives culling)
   bool emit_quad(DrawRec& r, float x0, float y0, float x1, float y1, bool count_fragments);  // false: culled, nothing was recorded
   bool emit_quad_pts(DrawRec& r, const float vx[4], const float vy[4], bool count_fragments);
+  struct QuadPx { float px[4], py[4]; BBox b; bool finite; };
+  void quad_corners(const float vx[4], const float vy[4], QuadPx& q) const;
+  bool emit_corners(DrawRec& r, const QuadPx& q, bool count_fragments);
   void push_rec(BBox b);  // count the slot next_rec() handed out
   void commit_bins(uint32_t idx);  // the record's bounds are final: list-entry flags, list-stride count, phase summary
   void link_share(uint32_t idx);   // LE_SHARE on idx - 1 when record idx is drawn over the same quad with the same shape
@@ -544,6 +548,8 @@ class Context : public Recorder {
   uint64_t frame_no_ = 0;
   HostVec<uint8_t> misc_[kStaging];   // per slot (pinned): phase table, blur weight tables
   std::vector<uint8_t> misc_host_;    // ... as prepare builds them
+  const uint8_t* misc_dev_[kStaging] = {};   // the pinned buffers' device views (hipHostGetDevicePointer costs a third of a microsecond)
+  const uint8_t* misc_dev_host_[kStaging] = {};
   // retained scenes: host copy of what the device's frame block holds (prepare: upload only what differs)
   std::vector<uint8_t> shadow_;
   std::vector<size_t> shadow_layout_; // the offsets that block was laid out with

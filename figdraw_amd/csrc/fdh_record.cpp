@@ -257,15 +257,18 @@ void Recorder::commit_bins(uint32_t idx) {
 // The mirrors grow with the lane (never shrink, never hold more than the lane); a mirror that had to move is filled again from the
 // lane up to what had been published -- from ordinary memory: pinned memory is not read.
 static void mirror_fit(Lane& L) {
-  auto fit = [](auto& up, const auto& src, size_t published) {
+  auto fit = [](auto& up, const auto& src, size_t published, const uint8_t*& dev) {
     if (up.cap >= src.cap) return;
     up.n = 0;  // (nothing to carry over: reserve() would READ the old pinned block)
     up.reserve(src.cap);
     if (published) std::memcpy(static_cast<void*>(up.p), static_cast<const void*>(src.p), published * sizeof(*src.p));
+    void* d = nullptr;
+    FDH_HIP(hipHostGetDevicePointer(&d, up.p, 0));
+    dev = static_cast<const uint8_t*>(d);
   };
-  fit(L.up_recs, L.recs, L.pub_recs);
-  fit(L.up_bins, L.bins, L.pub_recs);
-  fit(L.up_exts, L.exts, L.pub_exts);
+  fit(L.up_recs, L.recs, L.pub_recs, L.d_recs);
+  fit(L.up_bins, L.bins, L.pub_recs, L.d_bins);
+  fit(L.up_exts, L.exts, L.pub_exts, L.d_exts);
 }
 void Lane::publish(uint32_t first, uint32_t n, uint32_t ext_first, uint32_t n_ext) {
   if (!device) return;
@@ -433,29 +436,41 @@ bool Recorder::rect_visible(const float rect[4], float pad) const {
 
 // Four pre-transform vertices in the reference's vertex order 0..3 (triangles (3,0,1) and (2,3,1), glcontext.nim:418-429).
 // `r` is the lane's next record slot (next_rec): counted here unless the draw is culled.
-bool Recorder::emit_quad_pts(DrawRec& r, const float vx[4], const float vy[4], bool count_fragments) {
-  float px[4], py[4];
+// the quad's vertices on the pixel grid -- ceil(ctx.mat * corner) per vertex (glcontext.nim:1498-1509) -- and its clipped bounds
+void Recorder::quad_corners(const float vx[4], const float vy[4], QuadPx& q) const {
   for (int i = 0; i < 4; i++) {
-    px[i] = std::ceil(mat_.a * vx[i] + mat_.c * vy[i] + mat_.tx);
-    py[i] = std::ceil(mat_.b * vx[i] + mat_.d * vy[i] + mat_.ty);
+    q.px[i] = std::ceil(mat_.a * vx[i] + mat_.c * vy[i] + mat_.tx);
+    q.py[i] = std::ceil(mat_.b * vx[i] + mat_.d * vy[i] + mat_.ty);
   }
-  float minx = px[0], maxx = px[0], miny = py[0], maxy = py[0];
+  float minx = q.px[0], maxx = q.px[0], miny = q.py[0], maxy = q.py[0];
   for (int i = 1; i < 4; i++) {
-    minx = std::min(minx, px[i]); maxx = std::max(maxx, px[i]);
-    miny = std::min(miny, py[i]); maxy = std::max(maxy, py[i]);
+    minx = std::min(minx, q.px[i]); maxx = std::max(maxx, q.px[i]);
+    miny = std::min(miny, q.py[i]); maxy = std::max(maxy, q.py[i]);
   }
   const float lim = 1.0e6f;  // keep the integer edge functions far from overflow
-  BBox b{0, 0, 0, 0};
+  q.b = BBox{0, 0, 0, 0};
+  q.finite = minx > -lim && maxx < lim && miny > -lim && maxy < lim;
+  if (!q.finite) return;
+  const float W = (float)cx_->W_, H = (float)cx_->H_;
+  q.b.x0 = (int16_t)clampf(minx, 0.0f, W); q.b.x1 = (int16_t)clampf(maxx, 0.0f, W);
+  q.b.y0 = (int16_t)clampf(miny, 0.0f, H); q.b.y1 = (int16_t)clampf(maxy, 0.0f, H);
+}
+bool Recorder::emit_quad_pts(DrawRec& r, const float vx[4], const float vy[4], bool count_fragments) {
+  QuadPx q;
+  quad_corners(vx, vy, q);
+  return emit_corners(r, q, count_fragments);
+}
+bool Recorder::emit_corners(DrawRec& r, const QuadPx& q, bool count_fragments) {
+  const float* px = q.px;
+  const float* py = q.py;
+  BBox b = q.b;
   // A draw that reaches no pixel the frame will produce leaves no trace (it would never be binned).  Clip pushes stay: their
   // bounds grow to their content's, and a push that is not there would let that content through.
   const bool cullable = ((r.op_mode >> 12) & 15u) == OP_DRAW && culling();
-  if (!(minx > -lim && maxx < lim && miny > -lim && maxy < lim)) {
+  if (!q.finite) {
     if (cullable) { FDH_CULLED(); return false; }
     r.bx0 = r.by0 = r.bx1 = r.by1 = 0; push_rec(b); return true;
   }
-  const float W = (float)cx_->W_, H = (float)cx_->H_;
-  b.x0 = (int16_t)clampf(minx, 0.0f, W); b.x1 = (int16_t)clampf(maxx, 0.0f, W);
-  b.y0 = (int16_t)clampf(miny, 0.0f, H); b.y1 = (int16_t)clampf(maxy, 0.0f, H);
   if (cullable && !bbox_visible(b)) { FDH_CULLED(); return false; }
   r.bx0 = b.x0; r.by0 = b.y0; r.bx1 = b.x1; r.by1 = b.y1;
   const bool aligned = px[3] == px[0] && px[2] == px[1] && py[3] == py[2] && py[0] == py[1] && px[1] > px[0] && py[0] > py[3];
@@ -601,11 +616,18 @@ void Recorder::draw_rounded_rect_sdf(const float rect[4], const FdhColor colors[
   if (!cx_->frame_begun_) throw Error(FDH_ERR_INVALID, "ctx.beginFrame has not been called.");
   if (!(rect[2] > 0.0f) || !(rect[3] > 0.0f)) return;  // (a NaN extent draws nothing)
   if (mode >= FDH_SDF_BEZIER_STROKE_AA) throw Error(FDH_ERR_INVALID, "bezier stroke modes go through drawQuadraticBezierSdf");
-  if (culling() && !rect_visible(rect, 0.0f)) { FDH_CULLED(); return; }  // (before the record is built: most of a long table is below the window)
+  QuadPx q;
+  {
+    const float x0 = rect[0], y0 = rect[1], x1 = rect[0] + rect[2], y1 = rect[1] + rect[3];
+    const float vx[4] = {x0, x1, x1, x0}, vy[4] = {y1, y1, y0, y0};  // BL, BR, TR, TL
+    quad_corners(vx, vy, q);
+  }
+  // (before the record is built: most of a long table is below the window)
+  if (culling() && (!q.finite || !bbox_visible(q.b))) { FDH_CULLED(); return; }
   DrawRec& r = next_rec();
   fill_sdf_rec(r, rect, colors, rx, ry, mode, factor, spread, shape, fill_mode, mid, stop, mid_pos, aa_);
   if (mode == FDH_SDF_BACKDROP_BLUR) r.op_mode |= F_SELF_BACKDROP;  // a bare mode-17 call has no snapshot of its own
-  if (emit_quad(r, rect[0], rect[1], rect[0] + rect[2], rect[1] + rect[3], true)) commit_bins((uint32_t)lane_->recs.n - 1);
+  if (emit_corners(r, q, true)) commit_bins((uint32_t)lane_->recs.n - 1);
 }
 
 // fills: figbackend.nim:129-183
@@ -1142,7 +1164,8 @@ void Context::end_frame() {  // glcontext.nim:1982-1989
   culled_total_ = culled_draws_;
   const auto t1 = std::chrono::steady_clock::now();
   host_ns_[3] = std::chrono::duration_cast<std::chrono::nanoseconds>(t1 - t0).count();
-  host_record_ms_ = std::chrono::duration<float, std::milli>(t1 - t_begin_frame_).count();
+  // (without what begin_frame waited for the GPU -- the lane set's previous upload: back-pressure, not work)
+  host_record_ms_ = std::chrono::duration<float, std::milli>(t1 - t_begin_frame_).count() - (float)host_ns_[1] * 1e-6f;
   // a list entry carries the draw index in 25 bits beside its path code and flags (k_bin_draws, LE_INDEX)
   if (n_total_ >= LE_INDEX) throw Error(FDH_ERR_INVALID, "more than 33 554 430 draw records in one frame");
   if (host_only_) return;

@@ -101,7 +101,7 @@ int WalkPool::default_helpers() {
     if (const char* e = std::getenv("FDH_WALK_THREADS")) return std::min(std::max(std::atoi(e), 0), 64);
     const unsigned hw = std::thread::hardware_concurrency();
     if (hw < 4) return 0;
-    return (int)std::min(3u, hw / 4);  // a few: the walk of a frame is tens of microseconds, not a reason to take the machine
+    return (int)std::min(7u, hw / 8 + 1);  // a few: the walk of a frame is tens of microseconds, not a reason to take the machine
   }();
   return v;
 }

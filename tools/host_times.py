@@ -33,9 +33,9 @@ def run(name, sc, w, h, threads, retained=False, n=200):
 
 w, h = 3840, 2160
 sc = make_render_tree_100(w, h, 0, full_frame_blur=True)
-for th in (0, 1, 3):
+for th in (0, 1, 3, 7):
     run("bench", sc, w, h, th)
 run("bench", sc, w, h, 0, retained=True)
 sc7 = make_clip_mask_benchmark("sub_clip")
-for th in (0, 3):
+for th in (0, 3, 7):
     run("config7", sc7, 1200, 800, th)
