@@ -104,10 +104,17 @@ def run_stripes(args, dist, rank, local_rank, world, on_host):
     for c in ctxs:
         c.sync()
     use_c_abi = args.gather == "c_abi" and not on_host
+    use_host = args.gather == "host"
     dev = "cpu" if on_host else f"cuda:{local_rank}"
     gather_s = [0.0]
+    ranks_seen = None
     if use_c_abi:
         setup_comm(ctxs, dist, rank, world)
+        ranks_seen = ctxs[0].comm_info()[1]  # the communicator's size as fdh_comm_init left it: a SCALE record proves RCCL saw N ranks
+    elif use_host:
+        # the consumer is the host: every rank reads its own rows back over its own PCIe link (8 links in parallel on a node, no xGMI
+        # fan-in into one GPU); pinned destination, one buffer per context
+        stripe_host = [torch.empty((max(y1 - y0, 1), w, 4), dtype=torch.uint8).pin_memory() for _ in range(F)]
     else:
         full = [torch.zeros((h, w, 4), dtype=torch.uint8, device=dev) for _ in range(F)] if rank == 0 else None
 
@@ -138,7 +145,13 @@ def run_stripes(args, dist, rank, local_rank, world, on_host):
             if not use_c_abi and pending is not None and pending == i:
                 gather_torch(pending)  # (the surface is about to be overwritten)
                 pending = None
+            if use_host and k >= F and y1 > y0:  # the frame this context rendered F frames ago goes to the host before its surface is reused
+                t0 = time.perf_counter()
+                c._ck(c.L.fdh_read_pixels(c.h, 0, y0, w, y1 - y0, stripe_host[i].data_ptr()))
+                gather_s[0] += time.perf_counter() - t0
             c._ck(c.L.fdh_render_frame(c.h, cs[k % NS].byref(), float(w), float(h), 1, col))
+            if use_host:
+                continue
             if use_c_abi:
                 t0 = time.perf_counter()
                 c.gather_stripes(0, None)  # queued on the context's stream behind the frame; rank 0 receives in place
@@ -149,6 +162,11 @@ def run_stripes(args, dist, rank, local_rank, world, on_host):
                 pending = i
         if pending is not None:
             gather_torch(pending)
+        if use_host and y1 > y0:  # the last F frames' stripes
+            t0 = time.perf_counter()
+            for i in range(min(F, n)):
+                ctxs[i]._ck(ctxs[i].L.fdh_read_pixels(ctxs[i].h, 0, y0, w, y1 - y0, stripe_host[i].data_ptr()))
+            gather_s[0] += time.perf_counter() - t0
 
     def barrier():
         if dist is not None:
@@ -183,11 +201,25 @@ def run_stripes(args, dist, rank, local_rank, world, on_host):
     if use_c_abi:
         ctxs[last_i].W, ctxs[last_i].H = w, h
         got = ctxs[last_i].read_pixels()
+    elif use_host:
+        got = None  # (every rank holds its own rows: rank 0 checks its stripe against the oracle's)
     else:
         got = full[last_i].cpu().numpy()
-    assert int(got[..., 3].min()) == 255, "the gathered frame has unwritten pixels"
+    if got is not None:
+        assert int(got[..., 3].min()) == 255, "the gathered frame has unwritten pixels"
     check = None
-    if not args.no_cpu_baseline:  # the gathered image of the last frame against the oracle (outside the timed region)
+    if use_host and not args.no_cpu_baseline:
+        from oracle import oracle as O
+
+        orc = O.Oracle(threads=min(os.cpu_count() or 1, 16))
+        orc.render_frame(scenes[last_k % NS], w, h)
+        mine = stripe_host[last_i].numpy()[: y1 - y0]
+        d = np.abs(mine.astype(int) - orc.read_pixels()[y0:y1].astype(int))
+        check = {"frame": last_k % NS, "rows_checked": [y0, y1], "parity_max_lsb": int(d.max()), "parity_pixels_differing": int((d.max(axis=2) > 0).sum())}
+        if check["parity_max_lsb"] > 1:
+            print(json.dumps({"error": "rank 0's stripe (read back by the host) disagrees with the oracle", "check": check}))
+            sys.exit(1)
+    elif not args.no_cpu_baseline:  # the gathered image of the last frame against the oracle (outside the timed region)
         from oracle import oracle as O
 
         orc = O.Oracle(threads=min(os.cpu_count() or 1, 16))
@@ -209,11 +241,14 @@ def run_stripes(args, dist, rank, local_rank, world, on_host):
                                f"row-striped over {world} rank(s), every frame through fdh_render_frame, stripes gathered to rank 0 per frame inside the timed region",
                    "mode": "stripes", "draws": st.n_draws, "rows_per_rank": [b - a for a, b in rows], "frames_in_flight_per_gpu": F,
                    "gather": "fdh_gather_stripes (C ABI: grouped ncclSend / ncclRecv on the context's stream, received in place)" if use_c_abi
+                             else "none: every rank reads its stripe back to pinned host memory over its own PCIe link (fdh_read_pixels); the consumer is the host" if use_host
                              else "torch.distributed batch_isend_irecv with a host sync per frame",
+                   "rccl_ranks_seen": ranks_seen,
                    "parallelism": f"row stripes x{world}" if world > 1 else "single GPU (one stripe = the frame)"},
         "gather_ms": round(1e3 * gather_host / args.steps, 4),
         "gather_note": "per frame, this rank's HOST time inside the gather calls (c_abi: enqueue only -- the transfer runs on the stream; torch: includes "
-                       "waiting for the stripe and the transfer); part of `value`'s wall time",
+                       "waiting for the stripe and the transfer; host: the blocking readback of the stripe rendered frames_in_flight frames earlier); "
+                       "part of `value`'s wall time",
         "gathered_frame_check": check,
         "roofline": None, "cpu_baseline": None,
     }))
@@ -231,9 +266,11 @@ def main():
     ap.add_argument("--frames-in-flight", type=int, default=4,
                     help="independent render contexts per GPU (own stream + surfaces) whose frames overlap; 1 = strictly one frame at a time")
     ap.add_argument("--host-threads", type=int, default=0, help="host threads driving the contexts of `value` (0 = one per context in flight)")
-    ap.add_argument("--gather", choices=["c_abi", "torch"], default="c_abi",
-                    help="who issues the gather: the library's own fdh_gather_* (RCCL through the C ABI, stream-ordered) or torch.distributed "
-                         "(always used with --backend gloo)")
+    ap.add_argument("--gather", choices=["c_abi", "torch", "host"], default=None,
+                    help="who moves the finished rows / frames to rank 0: c_abi = the library's own fdh_gather_* (RCCL through the C ABI, stream-ordered, "
+                         "north_star's single RCCL gather); torch = torch.distributed (always used with --backend gloo); host (--mode stripes) = no gather: "
+                         "every rank reads its stripe back over its OWN PCIe link (fdh_read_pixels) -- the consumer is the host.  Default: c_abi on one "
+                         "rank; torch on several until a two-GPU run of fdh_gather_* has passed (its send / recv pairs have never executed, ADVICE r3)")
     ap.add_argument("--gather-timeout", type=float, default=180.0, help="seconds the gather legs of an N > 1 run may take before they are given up")
     ap.add_argument("--width", type=int, default=W)
     ap.add_argument("--height", type=int, default=H)
@@ -241,6 +278,8 @@ def main():
                     help="frames: every rank renders whole frames (weak scaling); stripes: every rank renders its row stripe of every frame of an "
                          "8-frame batch and the stripes are gathered to rank 0 inside the timed region (BASELINE config 5, strong scaling)")
     args = ap.parse_args()
+    if args.gather is None:
+        args.gather = "c_abi" if int(os.environ.get("WORLD_SIZE", "1")) == 1 or os.environ.get("FDH_BENCH_GATHER") == "c_abi" else "torch"
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -416,6 +455,15 @@ def main():
 
     run_single_dynamic(args.warmup)
     sd_elapsed, sd_batch_ms = batches(run_single_dynamic, args.steps, args.repeats)
+    # where the calling thread's time goes (one context, frames back to back): fdh_debug_host_times per frame, averaged
+    acc = {}
+    n_ht = min(args.steps, 100)
+    for k in range(n_ht):
+        ctx._ck(ctx.L.fdh_render_frame(ctx.h, cscenes[k % NS].byref(), float(w), float(h), 1, C_mod._F4(1.0, 1.0, 1.0, 1.0)))
+        for name, v in ctx.host_times().items():
+            acc[name] = acc.get(name, 0) + v
+    ctx.sync()
+    host_times_us = {name: round(v / n_ht / 1e3, 1) for name, v in acc.items()}
     ctx.render_frame(scene, w, h)
     ctx.replay(args.warmup)
     barrier()
@@ -472,9 +520,11 @@ def main():
         walked, reused = ctx.scene_stats()
         dynamic = {"one_context": {"ms_per_frame": round(1e3 * sd_elapsed / args.steps, 4), "mpixels_per_s": round(w * h * args.steps / sd_elapsed / 1e6, 1), "batches_ms": sd_batch_ms},
                    "host_record_us": round(1e3 * st0.ms_host_record, 1), "host_prepare_us": round(1e3 * st0.ms_host_upload, 1),
-                   "host_issue_us": round(1e3 * st0.ms_host_launch, 1),
-                   "note": "`value` IS this path with frames_in_flight contexts; host_*: per frame, calling thread records (tree walk) and prepares "
-                           "(staging buffer), the context's submit thread issues (upload kernel + launches)",
+                   "host_issue_us": round(1e3 * st0.ms_host_launch, 1), "host_times_us": host_times_us,
+                   "note": "`value` IS this path with frames_in_flight contexts; host_*: per frame, the calling thread records (tree walk, large sibling "
+                           "groups on the walk pool: config.walk_pool_threads) and prepares (layout, run table), the context's submit thread issues (upload "
+                           "kernel + launches); host_record_us excludes what begin_frame waits for the GPU (host_times_us.wait_upload: back-pressure "
+                           "when the host runs ahead); host_times_us: fdh_debug_host_times averaged over a batch of one-at-a-time frames",
                    "retained": {"ms_per_frame": round(1e3 * tr / n_dyn, 4), "mpixels_per_s": round(w * h * n_dyn / tr / 1e6, 1),
                                 "host_record_us": round(1e3 * sr.ms_host_record, 1), "host_issue_us": round(1e3 * sr.ms_host_launch, 1),
                                 "roots_walked": walked, "roots_reused": reused, "uploaded_bytes_per_frame": ctx.last_upload_bytes(),
@@ -487,6 +537,7 @@ def main():
     # `value` above holds no data-path collective (weak scaling); here (a) one gather of every rank's final frame, timed on its
     # own, and (b) the same K-frame batch with EVERY frame gathered to rank 0 inside the timed region, reported beside `value`.
     gather_ms, gather_how, with_gather, gather_error = None, None, None, None
+    rccl_ranks_seen = None
     if dist is not None:
         col = C_mod._F4(1.0, 1.0, 1.0, 1.0)
 
@@ -502,7 +553,7 @@ def main():
                                              "parallelism": f"frame-parallel x{world}", "frames_in_flight_per_gpu": F},
                                   "gather": {"error": f"the gather of frames to rank 0 did not complete within {args.gather_timeout} s; `value` (no collective "
                                                       "on the data path) was measured before it"}}), flush=True)
-            os._exit(0)
+            os._exit(3)  # (non-zero: the multi-GPU leg did not complete; the line above still carries the measured `value`)
 
         import threading
 
@@ -513,6 +564,7 @@ def main():
             use_c_abi = args.gather == "c_abi" and not on_host
             if use_c_abi:
                 setup_comm(ctxs, dist, rank, world)
+                rccl_ranks_seen = ctxs[0].comm_info()[1]
                 dev = f"cuda:{local_rank}"
                 slots = [[torch.empty((h, w, 4), dtype=torch.uint8, device=dev) for _ in range(world)] for _ in range(F)] if rank == 0 else None
                 ptrs = [[t.data_ptr() for t in sl] for sl in slots] if rank == 0 else [None] * F
@@ -700,7 +752,8 @@ def main():
         "config": {"workload": f"S300@4K: renderlist_100 scene at {w}x{h}, 300 shadowed SDF rects + full-frame and 360x240 "
                                f"2-pass Gaussian backdrop blur(18) (BASELINE.json configs[2])",
                    "draws": st.n_draws, "phases": st.n_phases, "blur_nodes": st.n_blurs, "fragments": int(st.fragments),
-                   "parallelism": f"frame-parallel x{world}" if world > 1 else "single GPU", "frames_in_flight_per_gpu": F, "host_threads_per_gpu": T},
+                   "parallelism": f"frame-parallel x{world}" if world > 1 else "single GPU", "frames_in_flight_per_gpu": F, "host_threads_per_gpu": T,
+                   "walk_pool_threads": ctx.walk_stats()[0]},
         "frames_in_flight_check": {"contexts": F, "identical_to_each_frame_rendered_alone": in_flight_differing == 0,
                                    "pixels_differing": in_flight_differing, "in_flight_frame_vs_oracle": in_flight_vs_oracle},
         "host_threads_calibration": calibration,
@@ -730,6 +783,8 @@ def main():
         out["gather_ms"] = round(gather_ms, 3)
         out["gather"] = gather_how
         out["with_gather_every_frame"] = with_gather
+    if world > 1:
+        out["rccl_ranks_seen"] = rccl_ranks_seen  # the communicator size fdh_comm_init reported (null: the gather ran through torch.distributed)
     if gather_error is not None:
         out["gather_error"] = gather_error
     # a frame that came out differently in flight than alone (or off the oracle) voids the throughput figure

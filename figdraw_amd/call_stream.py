@@ -22,7 +22,7 @@ PLAYER_LIB = os.path.join(ROOT, "build", "libfdh_call_player.so")
 OPS = {name: i + 1 for i, name in enumerate([
     "begin_frame", "end_frame", "save_transform", "restore_transform", "translate", "rotate", "scale", "apply_transform",
     "set_aa_factor", "draw_rounded_rect_sdf", "draw_image", "draw_msdf", "draw_backdrop_blur", "begin_mask", "end_mask", "pop_mask",
-    "begin_rect_mask", "pop_rect_mask", "draw_quadratic_bezier_sdf", "draw_filled_quad", "draw_rect", "set_text_subpixel_shift"])}
+    "begin_rect_mask", "pop_rect_mask", "draw_quadratic_bezier_sdf", "draw_filled_quad", "draw_rect", "set_text_subpixel_shift", "draw_image_adj"])}
 
 
 def _f(v):
@@ -59,6 +59,9 @@ def pack(calls) -> np.ndarray:
         elif name == "draw_image":
             key, pos, cols, size, flip = a
             w += _key(key) + [_f(pos[0]), _f(pos[1])] + [_col(c) for c in cols] + [_f(size[0]), _f(size[1]), int(flip)]
+        elif name == "draw_image_adj":
+            key, pos, col, size = a
+            w += _key(key) + [_f(pos[0]), _f(pos[1]), _col(col), _f(size[0]), _f(size[1])]
         elif name == "draw_msdf":
             key, pos, col, size, px_range, thr, stroke, mtsdf, flip = a
             w += _key(key) + [_f(pos[0]), _f(pos[1]), _col(col), _f(size[0]), _f(size[1]), _f(px_range), _f(thr), _f(stroke), int(mtsdf), int(flip)]

@@ -84,6 +84,10 @@ def load():
     L.fdh_draw_rounded_rect_fill.argtypes = [vp, _F4, C.POINTER(S.CFill), _F4, _F4, C.c_int, C.c_float, C.c_float, _F2]
     L.fdh_draw_image.argtypes = [vp, C.c_int64, _F2, _COL4, _F2, C.c_int]
     L.fdh_draw_msdf.argtypes = [vp, C.c_int64, _F2, S.CColor, _F2, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int]
+    L.fdh_draw_image_adj.argtypes = [vp, C.c_int64, _F2, S.CColor, _F2]
+    L.fdh_set_text_lcd_filtering.argtypes = [vp, C.c_int]
+    L.fdh_get_text_lcd_filtering.argtypes = [vp, C.POINTER(C.c_int)]
+    L.fdh_comm_info.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.fdh_draw_quadratic_bezier_sdf.argtypes = [vp, _F4, C.POINTER(S.CFill), _F2, _F2, _F2, C.c_float, C.c_int]
     L.fdh_draw_filled_quad.argtypes = [vp, C.c_float * 8, _COL4]
     L.fdh_draw_rect.argtypes = [vp, _F4, S.CColor]
@@ -245,6 +249,24 @@ class HipContext:
     def draw_image(self, key, pos, colors, size=(0.0, 0.0), flip_y=False):
         self._ck(self.L.fdh_draw_image(self.h, int(key), _F2(*pos), _cols(colors), _F2(*size), int(bool(flip_y))))
 
+    def draw_image_adj(self, key, pos, color, size):
+        """drawImageAdj (glcontext.nim:1369-1381): the image with its uv rect pulled in by two texels on every side"""
+        self._ck(self.L.fdh_draw_image_adj(self.h, int(key), _F2(*pos), S.CColor(*color), _F2(*size)))
+
+    def set_text_lcd_filtering(self, enabled: bool):
+        self._ck(self.L.fdh_set_text_lcd_filtering(self.h, int(bool(enabled))))
+
+    def text_lcd_filtering(self) -> bool:
+        out = C.c_int()
+        self._ck(self.L.fdh_get_text_lcd_filtering(self.h, C.byref(out)))
+        return bool(out.value)
+
+    def comm_info(self):
+        """(rank, world) of the context's communicator; (0, 1) without one"""
+        r, w = C.c_int(), C.c_int()
+        self._ck(self.L.fdh_comm_info(self.h, C.byref(r), C.byref(w)))
+        return r.value, w.value
+
     def draw_msdf(self, key, pos, color, size, px_range, sd_threshold=0.5, stroke_weight=0.0, mtsdf=False, flip_y=False):
         self._ck(self.L.fdh_draw_msdf(self.h, int(key), _F2(*pos), S.CColor(*color), _F2(*size), px_range, sd_threshold,
                                       stroke_weight, int(bool(mtsdf)), int(bool(flip_y))))
@@ -300,11 +322,12 @@ class HipContext:
         self._ck(self.L.fdh_put_glyph_outline(self.h, int(key), int(w), int(h), segs.ctypes.data, len(segs), 1 if lcd_filter else 0, out))
         return tuple(out)
 
-    def put_glyph_image(self, key, rgba: np.ndarray, lcd_filter: bool = False):
+    def put_glyph_image(self, key, rgba: np.ndarray, lcd_filter=False):
         """a rasterised glyph, processed on the device on its way into the atlas (LCD filter, mip chain): pixie_raster.nim:12-95"""
         rgba = np.ascontiguousarray(rgba, dtype=np.uint8)
         out = (C.c_int * 4)()
-        self._ck(self.L.fdh_put_glyph_image(self.h, int(key), rgba.shape[1], rgba.shape[0], rgba.ctypes.data, 1 if lcd_filter else 0, out))
+        flag = 2 if lcd_filter == "context" else (1 if lcd_filter else 0)  # "context": follow set_text_lcd_filtering (FDH_GLYPH_LCD_CONTEXT)
+        self._ck(self.L.fdh_put_glyph_image(self.h, int(key), rgba.shape[1], rgba.shape[0], rgba.ctypes.data, flag, out))
         return tuple(out)
 
     def put_image_mips(self, key, mips):

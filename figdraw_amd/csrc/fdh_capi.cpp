@@ -113,6 +113,12 @@ int fdh_draw_image(FdhContext* c, int64_t key, const float pos[2], const FdhColo
     C(c)->draw_image(key, pos, colors, size ? size : zero2, flip_y != 0);
   });
 }
+int fdh_draw_image_adj(FdhContext* c, int64_t key, const float pos[2], FdhColor color, const float size[2]) {
+  return guard([&] {
+    if (!pos || !size) throw fdh::Error(FDH_ERR_INVALID, "fdh_draw_image_adj: null pointer");
+    C(c)->draw_image_adj(key, pos, color, size);
+  });
+}
 int fdh_draw_msdf(FdhContext* c, int64_t key, const float pos[2], FdhColor color, const float size[2], float px_range,
                   float sd_threshold, float stroke_weight, int mtsdf, int flip_y) {
   return guard([&] { C(c)->draw_msdf(key, pos, color, size, px_range, sd_threshold, stroke_weight, mtsdf != 0, flip_y != 0); });
@@ -143,6 +149,13 @@ int fdh_draw_rect(FdhContext* c, const float rect[4], FdhColor color) { return g
 int fdh_set_text_subpixel_positioning(FdhContext* c, int e) { return guard([&] { C(c)->set_subpixel_enabled(e != 0); }); }
 int fdh_set_text_subpixel_glyph_variants(FdhContext* c, int e) { return guard([&] { C(c)->set_subpixel_variants(e != 0); }); }
 int fdh_set_text_subpixel_shift(FdhContext* c, float s) { return guard([&] { C(c)->set_subpixel_shift(s); }); }
+int fdh_set_text_lcd_filtering(FdhContext* c, int e) { return guard([&] { C(c)->set_text_lcd_filtering(e != 0); }); }
+int fdh_get_text_lcd_filtering(FdhContext* c, int* out) {
+  return guard([&] {
+    if (!out) throw fdh::Error(FDH_ERR_INVALID, "null output");
+    *out = C(c)->text_lcd_filtering() ? 1 : 0;
+  });
+}
 
 int fdh_put_image(FdhContext* c, int64_t key, int w, int h, const uint8_t* rgba, int out_rect[4]) {
   return guard([&] { C(c)->put_image(key, w, h, rgba, out_rect); });
@@ -249,6 +262,12 @@ int fdh_comm_init(FdhContext* c, const uint8_t id[FDH_COMM_ID_BYTES], int rank, 
   return guard([&] {
     if (!id) throw fdh::Error(FDH_ERR_INVALID, "null communicator id");
     C(c)->comm_init(id, rank, world);
+  });
+}
+int fdh_comm_info(FdhContext* c, int* rank, int* world) {
+  return guard([&] {
+    if (!rank || !world) throw fdh::Error(FDH_ERR_INVALID, "null output");
+    C(c)->comm_info(rank, world);
   });
 }
 int fdh_comm_share(FdhContext* c, FdhContext* owner) { return guard([&] { C(c)->comm_share(C(owner)); }); }

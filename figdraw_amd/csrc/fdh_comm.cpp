@@ -6,7 +6,6 @@
 // process per GPU: each process creates its context on its device and joins the communicator with fdh_comm_init.
 // librccl is loaded at the first fdh_comm_* call (dlopen), not linked: a single-GPU host needs no RCCL to use the library.
 #include <dlfcn.h>
-#include <rccl/rccl.h>
 
 #include <cstdlib>
 #include <cstring>
@@ -15,6 +14,16 @@
 #include "fdh_context.h"
 
 namespace fdh {
+
+// The handful of RCCL declarations the gather needs, spelled out here (nccl.h: stable ABI since NCCL 2): the library builds on a
+// host without the RCCL headers, and runs without RCCL until a fdh_comm_* entry point is called.
+extern "C" {
+typedef struct ncclComm* ncclComm_t;
+#define NCCL_UNIQUE_ID_BYTES 128
+typedef struct { char internal[NCCL_UNIQUE_ID_BYTES]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclInt8 = 0, ncclChar = 0, ncclUint8 = 1 } ncclDataType_t;
+}
 
 namespace {
 struct Rccl {
@@ -87,6 +96,14 @@ void comm_unique_id(uint8_t out[FDH_COMM_ID_BYTES]) {
   std::memcpy(out, id.internal, FDH_COMM_ID_BYTES);
 }
 
+// What the contexts of a process share: the communicator and the lock that keeps one gather's group (ncclGroupStart .. End) from
+// interleaving with another context's on another host thread.
+struct SharedComm {
+  ncclComm_t comm = nullptr;
+  std::mutex mu;
+  ~SharedComm() { if (comm) { try { (void)rccl().CommDestroy(comm); } catch (...) {} } }
+};
+
 void Context::comm_init(const uint8_t id_bytes[FDH_COMM_ID_BYTES], int rank, int world) {
   need_device("comm_init");
   if (world <= 0 || rank < 0 || rank >= world) throw Error(FDH_ERR_INVALID, "comm_init: bad rank / world size");
@@ -96,15 +113,18 @@ void Context::comm_init(const uint8_t id_bytes[FDH_COMM_ID_BYTES], int rank, int
   std::memcpy(id.internal, id_bytes, FDH_COMM_ID_BYTES);
   ncclComm_t c = nullptr;
   FDH_NCCL(rccl().CommInitRank(&c, world, id, rank));
-  comm_ = std::shared_ptr<void>(static_cast<void*>(c), [](void* p) {
-    try { (void)rccl().CommDestroy(static_cast<ncclComm_t>(p)); } catch (...) {}
-  });
+  auto sc = std::make_shared<SharedComm>();
+  sc->comm = c;
+  comm_ = std::static_pointer_cast<void>(sc);
   comm_rank_ = rank;
   comm_world_ = world;
 }
 // Several contexts of one process (frames in flight) use ONE communicator: the others borrow the owner's (a shared reference:
 // the communicator is destroyed when its last holder lets go, in whichever order the contexts are destroyed).  RCCL runs a
-// communicator's operations in the order they were issued, whichever stream each was issued on.
+// communicator's operations in the order they were issued, whichever stream each was issued on: a lock inside the shared object
+// keeps two contexts' gathers (possibly on two host threads) from interleaving their groups, and EVERY RANK MUST ISSUE THE GATHERS
+// OF A SHARED COMMUNICATOR IN THE SAME ORDER (context k's gather of frame n on all ranks, then context k + 1's, ...): a rank that
+// issues them in another order pairs its sends with the wrong receives and the collective hangs.
 void Context::comm_share(Context* owner) {
   need_device("comm_share");
   if (!owner || owner == this) throw Error(FDH_ERR_INVALID, "comm_share: needs another context that owns a communicator");
@@ -136,13 +156,18 @@ void Context::gather_stripes(int dst_rank, void* dst_image) {
   const size_t row_bytes = (size_t)W_ * 4;
   int my0, my1;
   stripe_rows(H_, world, rank, &my0, &my1);
+  // what travels is the rule's stripe: a context that rendered another one (fdh_set_stripe) would send rows it never produced
+  if (stripe_y1_ > stripe_y0_ && (std::max(0, stripe_y0_) != my0 || std::min(H_, stripe_y1_) != my1))
+    throw Error(FDH_ERR_INVALID, "gather_stripes: the stripe set with fdh_set_stripe is not this rank's fdh_stripe_rows(height, world, rank)");
   uint8_t* own = reinterpret_cast<uint8_t*>(fb_);
   uint8_t* dst = dst_image ? static_cast<uint8_t*>(dst_image) : own;
   if (rank == dst_rank && dst != own && my1 > my0)  // the destination's own rows: a copy on the device
     FDH_HIP(hipMemcpyAsync(dst + (size_t)my0 * row_bytes, own + (size_t)my0 * row_bytes, (size_t)(my1 - my0) * row_bytes, hipMemcpyDeviceToDevice, stream_));
   if (world == 1) return;
   Rccl& R = rccl();
-  ncclComm_t comm = static_cast<ncclComm_t>(comm_.get());
+  SharedComm& sc = *static_cast<SharedComm*>(comm_.get());
+  std::lock_guard<std::mutex> lock(sc.mu);  // one group at a time on a shared communicator
+  ncclComm_t comm = sc.comm;
   Group g(R);
   if (rank == dst_rank) {
     for (int r = 0; r < world; r++) {
@@ -173,7 +198,9 @@ void Context::gather_frames(int dst_rank, void* const* dst_images) {
     FDH_HIP(hipMemcpyAsync(dst_images[rank], fb_, bytes, hipMemcpyDeviceToDevice, stream_));
   if (world == 1) return;
   Rccl& R = rccl();
-  ncclComm_t comm = static_cast<ncclComm_t>(comm_.get());
+  SharedComm& sc = *static_cast<SharedComm*>(comm_.get());
+  std::lock_guard<std::mutex> lock(sc.mu);
+  ncclComm_t comm = sc.comm;
   Group g(R);
   if (rank == dst_rank) {
     for (int r = 0; r < world; r++)

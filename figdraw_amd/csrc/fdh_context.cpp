@@ -135,6 +135,8 @@ void Context::drain() {
   if (worker_error_) {
     std::exception_ptr e = worker_error_;
     worker_error_ = nullptr;
+    // what that frame was to upload may not have arrived: nothing is taken for resident in the device block any more
+    tables_dev_ = nullptr; shadow_dev_ = nullptr; have_frame_ = false;
     std::rethrow_exception(e);
   }
 }
@@ -297,7 +299,8 @@ void Context::put_image(int64_t key, int w, int h, const uint8_t* rgba, int out_
 // level chain of updateSubImage (textures.nim:106-119) -- every step a kernel on the context's stream.
 void Context::put_glyph_image(int64_t key, int w, int h, const uint8_t* rgba, uint32_t flags, int out_rect[4]) {
   if (w <= 0 || h <= 0 || !rgba) throw Error(FDH_ERR_INVALID, "put_glyph_image: empty image");
-  if (flags & ~(uint32_t)FDH_GLYPH_LCD_FILTER) throw Error(FDH_ERR_INVALID, "put_glyph_image: unknown flag");
+  if (flags & ~(uint32_t)(FDH_GLYPH_LCD_FILTER | FDH_GLYPH_LCD_CONTEXT)) throw Error(FDH_ERR_INVALID, "put_glyph_image: unknown flag");
+  if (flags & FDH_GLYPH_LCD_CONTEXT) flags = text_lcd_filtering_ ? FDH_GLYPH_LCD_FILTER : 0u;  // as setTextLcdFilteringEnabled said
   int x, y;
   find_empty_rect(w, h, &x, &y);
   entries_[key] = AtlasEntry{x, y, w, h, false, {}, {}};
@@ -341,7 +344,8 @@ static int flatten_count(const float* q) {
 void Context::put_glyph_outline(int64_t key, int w, int h, const float* segs, int n, uint32_t flags, int out_rect[4]) {
   if (w <= 0 || h <= 0 || w > 4096 || h > 4096) throw Error(FDH_ERR_INVALID, "put_glyph_outline: image size must be in 1..4096");
   if (n < 0 || (n > 0 && !segs)) throw Error(FDH_ERR_INVALID, "put_glyph_outline: bad outline");
-  if (flags & ~(uint32_t)FDH_GLYPH_LCD_FILTER) throw Error(FDH_ERR_INVALID, "put_glyph_outline: unknown flag");
+  if (flags & ~(uint32_t)(FDH_GLYPH_LCD_FILTER | FDH_GLYPH_LCD_CONTEXT)) throw Error(FDH_ERR_INVALID, "put_glyph_outline: unknown flag");
+  if (flags & FDH_GLYPH_LCD_CONTEXT) flags = text_lcd_filtering_ ? FDH_GLYPH_LCD_FILTER : 0u;
   std::vector<float> lines;
   lines.reserve((size_t)n * 16);
   for (int i = 0; i < n; i++) {

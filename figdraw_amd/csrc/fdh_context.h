@@ -220,6 +220,7 @@ class Recorder {
   void draw_rounded_rect_fill(const float rect[4], const FdhFill& fill, const float rx[4], const float ry[4], int mode,
                               float factor, float spread, const float shape[2]);
   void draw_image(int64_t key, const float pos[2], const FdhColor colors[4], const float size[2], bool flip_y);
+  void draw_image_adj(int64_t key, const float pos[2], FdhColor color, const float size[2]);
   void draw_msdf(int64_t key, const float pos[2], FdhColor color, const float size[2], float px_range, float sd_threshold,
                  float stroke_weight, bool mtsdf, bool flip_y);
   void draw_quadratic_bezier_sdf(const float rect[4], const FdhFill& fill, const float p0[2], const float p1[2], const float p2[2],
@@ -351,6 +352,9 @@ class Context : public Recorder {
   float pixel_scale() const { return pixel_scale_; }
   void set_subpixel_enabled(bool e) { subpixel_enabled_ = e; }
   void set_subpixel_variants(bool e) { subpixel_variants_ = e; }
+  void set_text_lcd_filtering(bool e) { text_lcd_filtering_ = e; }
+  bool text_lcd_filtering() const { return text_lcd_filtering_; }
+  void comm_info(int* rank, int* world) const { *rank = comm_ ? comm_rank_ : 0; *world = comm_ ? comm_world_ : 1; }
 
   // atlas
   void put_image(int64_t key, int w, int h, const uint8_t* rgba, int out_rect[4]);
@@ -471,7 +475,7 @@ class Context : public Recorder {
   uint32_t clear_rgba8_ = 0xFFFFFFFFu;
   float pixel_scale_ = 1.0f, ui_scale_ = 1.0f;
   float ctx_aa_ = 1.2f;   // (Recorder::aa_ of lane 0 is the live value; kept across frames)
-  bool subpixel_enabled_ = false, subpixel_variants_ = false;
+  bool subpixel_enabled_ = false, subpixel_variants_ = false, text_lcd_filtering_ = false;
   int stripe_y0_ = 0, stripe_y1_ = 0;
   int cull_mode_ = 1;
   int binbox_shift_ = 0;           // bin boxes in 64 << shift px units (frames of more than 128 bins along an axis)

@@ -721,6 +721,37 @@ void Recorder::draw_image(int64_t key, const float pos[2], const FdhColor colors
   commit_bins((uint32_t)lane_->recs.n - 1);
 }
 
+// drawImageAdj: glcontext.nim:1369-1381 -- drawImage with the uv rect pulled in by two texels on every side (2 / atlasSize)
+void Recorder::draw_image_adj(int64_t key, const float pos[2], FdhColor color, const float size[2]) {
+  { FDH_REC("draw_image_adj").i(key).fv(pos, 2).col(color).fv(size, 2); }
+  if (!cx_->frame_begun_) throw Error(FDH_ERR_INVALID, "ctx.beginFrame has not been called.");
+  auto it = cx_->entries_.find(key);
+  if (it == cx_->entries_.end()) return;
+  const AtlasEntry& e = it->second;
+  const float S = (float)cx_->atlas_size_;
+  const float ex = (float)e.x / S, ey = (float)e.y / S, ew = (float)e.w / S, eh = (float)e.h / S, adj = 2.0f / S;
+  DrawRec& r = next_rec();
+  r.op_mode = FDH_SDF_ATLAS | F_SOLID;
+  r.r[0] = ex + adj; r.r[1] = ey + adj; r.r[2] = ex + ew - adj; r.r[3] = ey + eh - adj;
+  for (int i = 0; i < 4; i++) r.col[i] = pack_color(color);
+  r.aa = aa_;
+  if (cx_->subpixel_enabled_) {
+    r.op_mode |= F_SUBPIXEL;
+    r.aux = std::max(0.0f, std::min(subpixel_shift_, 0.999f));
+  }
+  const float x0 = pos[0], y0 = pos[1], x1 = pos[0] + size[0], y1 = pos[1] + size[1];
+  {  // LOD of the axis-aligned form, as in draw_image
+    const float qx0 = std::ceil(mat_.a * x0 + mat_.tx), qy0 = std::ceil(mat_.d * y0 + mat_.ty);
+    const float qx1 = std::ceil(mat_.a * x1 + mat_.tx), qy1 = std::ceil(mat_.d * y1 + mat_.ty);
+    const float rw = std::fabs(qx1 - qx0), rh = std::fabs(qy1 - qy0);
+    if (rw > 0.0f && rh > 0.0f) {
+      const float rho = std::max(std::fabs(r.r[2] - r.r[0]) * S / rw, std::fabs(r.r[3] - r.r[1]) * S / rh);
+      r.aux2 = rho > 0.0f ? std::log2(rho) : 0.0f;
+    }
+  }
+  if (emit_quad(r, x0, y0, x1, y1, true)) commit_bins((uint32_t)lane_->recs.n - 1);
+}
+
 // drawMsdfImage / drawMtsdfImage: glcontext.nim:1097-1155, drawUvRectAtlasSdf :1022-1093
 void Recorder::draw_msdf(int64_t key, const float pos[2], FdhColor color, const float size[2], float px_range, float sd_threshold,
                         float stroke_weight, bool mtsdf, bool flip_y) {
@@ -1169,11 +1200,19 @@ void Context::end_frame() {  // glcontext.nim:1982-1989
   // a list entry carries the draw index in 25 bits beside its path code and flags (k_bin_draws, LE_INDEX)
   if (n_total_ >= LE_INDEX) throw Error(FDH_ERR_INVALID, "more than 33 554 430 draw records in one frame");
   if (host_only_) return;
-  { HostTimer t(host_ns_[4]); prepare(next_); }
-  { HostTimer t(host_ns_[6]); drain(); }  // the previous frame's launches (normally long issued: they ran while this frame was being recorded)
-  std::swap(job_, next_);
-  have_frame_ = true;
-  if (!worker_.joinable()) { issue(job_); return; }
+  // prepare() notes what the device block will hold once this frame's upload has run (blur tables, the retained path's shadow):
+  // if the frame is dropped before it is handed over -- prepare or the wait for the previous frame's launches throws, or an
+  // inline issue fails -- those notes are void (a later frame would skip uploads the device never received)
+  try {
+    { HostTimer t(host_ns_[4]); prepare(next_); }
+    { HostTimer t(host_ns_[6]); drain(); }  // the previous frame's launches (normally long issued: they ran while this frame was being recorded)
+    std::swap(job_, next_);
+    have_frame_ = true;
+    if (!worker_.joinable()) { issue(job_); return; }
+  } catch (...) {
+    tables_dev_ = nullptr; shadow_dev_ = nullptr; have_frame_ = false;
+    throw;
+  }
   {
     std::lock_guard<std::mutex> lk(mu_);
     pending_.store(true, std::memory_order_release);

@@ -205,6 +205,9 @@ FDH_API int fdh_draw_rounded_rect_fill(FdhContext*, const float rect[4], const F
                                        const float radii_y[4], int mode, float factor, float spread, const float shape_size[2]);
 /* drawImage(path, pos, colors, size, flipY) figbackend.nim:468-475, glcontext.nim:1350-1367 */
 FDH_API int fdh_draw_image(FdhContext*, int64_t key, const float pos[2], const FdhColor colors[4], const float size[2], int flip_y);
+/* drawImageAdj(path, pos, color, size) figbackend.nim:499-502, glcontext.nim:1369-1381: the image with its uv rect pulled in by
+ * two texels on every side */
+FDH_API int fdh_draw_image_adj(FdhContext*, int64_t key, const float pos[2], FdhColor color, const float size[2]);
 /* drawMsdfImage / drawMtsdfImage figbackend.nim:575-601, glcontext.nim:1097-1155 */
 FDH_API int fdh_draw_msdf(FdhContext*, int64_t key, const float pos[2], FdhColor color, const float size[2], float px_range,
                           float sd_threshold, float stroke_weight, int mtsdf, int flip_y);
@@ -228,6 +231,10 @@ FDH_API int fdh_draw_rect(FdhContext*, const float rect[4], FdhColor color);
 FDH_API int fdh_set_text_subpixel_positioning(FdhContext*, int enabled);
 FDH_API int fdh_set_text_subpixel_shift(FdhContext*, float shift);
 FDH_API int fdh_set_text_subpixel_glyph_variants(FdhContext*, int enabled); /* textSubpixelGlyphVariantsEnabled (figbackend.nim) */
+/* setTextLcdFilteringEnabled / textLcdFilteringEnabled (figbackend.nim:663-667, glcontext.nim:2059-2063): the flag the renderer
+ * reads before it rasterises glyphs (figrender.nim:420); glyph uploads flagged FDH_GLYPH_LCD_CONTEXT follow it. */
+FDH_API int fdh_set_text_lcd_filtering(FdhContext*, int enabled);
+FDH_API int fdh_get_text_lcd_filtering(FdhContext*, int* out);
 
 /* ------------------------------------------------------------------ atlas (hasImage/putImage/updateImage/removeImage/... figbackend.nim:281-294,400-432) */
 /* putImage: skyline packer with margin 4 (glcontext.nim:541-586); out_rect = packed pixel rect x,y,w,h.
@@ -238,7 +245,9 @@ FDH_API int fdh_put_image(FdhContext*, int64_t key, int width, int height, const
  * on the device: with FDH_GLYPH_LCD_FILTER FreeType's default 5-tap LCD filter is applied first -- applyLcdFilter :12-43:
  * weights 8, 77, 86, 77, 8 over x-2 .. x+2, columns clamped to the image, per channel (sum + 128) >> 8 -- then the image and
  * its minifyBy2 chain go into the atlas like fdh_put_image's.  Integer arithmetic, bit-exact with the reference's. */
-enum { FDH_GLYPH_LCD_FILTER = 1 };
+enum { FDH_GLYPH_LCD_FILTER = 1,
+       FDH_GLYPH_LCD_CONTEXT = 2 /* filter iff fdh_set_text_lcd_filtering is on: what renderText's generateGlyph call does with
+                                    ctx.textLcdFilteringEnabled() (figrender.nim:420) */ };
 FDH_API int fdh_put_glyph_image(FdhContext*, int64_t key, int width, int height, const uint8_t* rgba8, uint32_t flags, int out_rect[4]);
 /* A glyph OUTLINE rasterised on the device into the atlas -- generateGlyph's job (common/fontglyphs.nim:61-106; the reference calls
  * pixie's fillText for it, common/textrasters/pixie_raster.nim:83-87).  segs: n x 6 floats {x0, y0, cx, cy, x1, y1} in pixel units of
@@ -307,8 +316,10 @@ FDH_API int fdh_last_upload_bytes(FdhContext*, int64_t* out);
 FDH_API int fdh_debug_record_digest(FdhContext*, uint64_t* out);
 
 /* ------------------------------------------------------------------ multi-GPU / measurement hooks (no reference counterpart) */
-/* Restrict rasterisation to rows [y0, y1) of the frame (row-stripe sharding).  Rows outside the
- * stripe are left untouched; blur halos are rendered redundantly so no exchange is needed.  y1 <= y0 disables it. */
+/* Restrict rasterisation to rows [y0, y1) of the frame (row-stripe sharding); blur halos are rendered redundantly so
+ * no exchange is needed.  Rows outside the stripe hold nothing a caller may use: a frame with a full-frame blur node flips between
+ * the context's two surfaces, so they show whatever an earlier frame left there.  y1 <= y0 disables it.  fdh_gather_stripes sends
+ * the rows fdh_stripe_rows gives this rank and refuses a context whose stripe is another one. */
 FDH_API int fdh_set_stripe(FdhContext*, int y0, int y1);
 /* Culling.  A draw whose pixel bounds reach no pixel the frame will produce -- off the frame, or, under fdh_set_stripe with
  * fdh_render_frame / fdh_scene_render, off the stripe's rows widened by the reach of the scene's blur nodes -- is not recorded, and
@@ -341,7 +352,10 @@ FDH_API int fdh_culled_draws(FdhContext*, int64_t* out);
  *   fdh_comm_unique_id   ncclGetUniqueId: rank 0 makes the 128-byte id, the host carries it to the other ranks (its own channel)
  *   fdh_comm_init        ncclCommInitRank on the context's device; fdh_comm_destroy (also done by fdh_destroy)
  *   fdh_comm_share       a second context of the same process (frames in flight) shares `owner`'s communicator instead of
- *                        creating one; the communicator goes when the last context holding it is destroyed (any order)
+ *                        creating one; the communicator goes when the last context holding it is destroyed (any order).  A lock
+ *                        in the shared object keeps two contexts' gathers from interleaving; EVERY RANK MUST ISSUE THE GATHERS OF A
+ *                        SHARED COMMUNICATOR IN THE SAME ORDER (context by context, frame by frame), or the send / recv pairs
+ *                        of different ranks mismatch and the collective hangs
  *   fdh_gather_stripes   row-stripe mode: rank r sends rows fdh_stripe_rows(H, world, r) of its surface to dst_rank, which
  *                        receives them into the same rows of dst_image (device, W x H RGBA8; NULL: its own surface, whose own
  *                        rows are already in place)
@@ -352,6 +366,8 @@ FDH_API int fdh_stripe_rows(int height, int world, int rank, int* y0, int* y1);
 FDH_API int fdh_comm_unique_id(uint8_t out[FDH_COMM_ID_BYTES]);
 FDH_API int fdh_comm_init(FdhContext*, const uint8_t id[FDH_COMM_ID_BYTES], int rank, int world);
 FDH_API int fdh_comm_share(FdhContext*, FdhContext* owner);
+/* this context's rank and the communicator's size as fdh_comm_init / fdh_comm_share left them (0 of 1 without a communicator) */
+FDH_API int fdh_comm_info(FdhContext*, int* rank, int* world);
 FDH_API int fdh_comm_destroy(FdhContext*);
 FDH_API int fdh_gather_stripes(FdhContext*, int dst_rank, void* dst_image);
 FDH_API int fdh_gather_frames(FdhContext*, int dst_rank, void* const* dst_images);

@@ -1165,6 +1165,18 @@ void fo_draw_image(FoCtx* c, int64_t key, const float pos[2], const FoColor colo
   draw_uv_quad(c, pos[0], pos[1], pos[0] + dw, pos[1] + dh, at, to, colors, 0, z, 0.0f, 0.0f);
 }
 
+/* drawImageAdj(imageId, pos, color, size): glcontext.nim:1369-1381 -- the image's uv rect pulled in by two texels on every side */
+void fo_draw_image_adj(FoCtx* c, int64_t key, const float pos[2], FoColor color, const float size[2]) {
+  rec_open(c, "draw_image_adj"); rec_i(c, key); rec_fv(c, pos, 2); rec_col(c, color); rec_fv(c, size, 2); rec_close(c);
+  AtlasEntry* e = find_entry(c, key);
+  if (!e) return;
+  float adj = 2.0f / (float)c->atlas_size;
+  v2 at = {e->x + adj, e->y + adj}, to = {e->x + e->w - adj, e->y + e->h - adj};
+  v4 z = {0, 0, 0, 0};
+  FoColor cols[4] = {color, color, color, color};
+  draw_uv_quad(c, pos[0], pos[1], pos[0] + size[0], pos[1] + size[1], at, to, cols, 0, z, 0.0f, 0.0f);
+}
+
 /* drawMsdfImage / drawMtsdfImage: glcontext.nim:1097-1155, drawUvRectAtlasSdf :1022-1093 */
 void fo_draw_msdf(FoCtx* c, int64_t key, const float pos[2], FoColor color, const float size[2], float px_range,
                   float sd_threshold, float stroke_weight, int mtsdf, int flip_y) {

@@ -151,6 +151,7 @@ void fo_draw_rounded_rect_sdf(FoCtx*, const float rect[4], const FoColor colors[
 void fo_draw_rounded_rect_fill(FoCtx*, const float rect[4], const FoFill* fill, const float radii_x[4],
                                const float radii_y[4], int mode, float factor, float spread, const float shape[2]);
 void fo_draw_image(FoCtx*, int64_t key, const float pos[2], const FoColor colors[4], const float size[2], int flip_y);
+void fo_draw_image_adj(FoCtx*, int64_t key, const float pos[2], FoColor color, const float size[2]); /* glcontext.nim:1369-1381 */
 void fo_draw_msdf(FoCtx*, int64_t key, const float pos[2], FoColor color, const float size[2], float px_range,
                   float sd_threshold, float stroke_weight, int mtsdf, int flip_y);
 void fo_draw_quadratic_bezier_sdf(FoCtx*, const float rect[4], const FoFill* fill, const float p0[2], const float p1[2],

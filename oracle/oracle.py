@@ -55,6 +55,7 @@ def lib():
         L.fo_draw_rounded_rect_fill.argtypes = [C.c_void_p, _F4, C.POINTER(S.CFill), _F4, _F4, C.c_int, C.c_float,
                                                 C.c_float, _F2]
         L.fo_draw_image.argtypes = [C.c_void_p, C.c_int64, _F2, _COL4, _F2, C.c_int]
+        L.fo_draw_image_adj.argtypes = [C.c_void_p, C.c_int64, _F2, S.CColor, _F2]
         L.fo_draw_msdf.argtypes = [C.c_void_p, C.c_int64, _F2, S.CColor, _F2, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int]
         L.fo_draw_quadratic_bezier_sdf.argtypes = [C.c_void_p, _F4, C.POINTER(S.CFill), _F2, _F2, _F2, C.c_float, C.c_int]
         L.fo_draw_filled_quad.argtypes = [C.c_void_p, C.c_float * 8, _COL4]
@@ -160,6 +161,9 @@ class Oracle:
 
     def draw_image(self, key, pos, colors, size=(0.0, 0.0), flip_y=False):
         self.L.fo_draw_image(self.h, int(key), _F2(*pos), _cols(colors), _F2(*size), int(bool(flip_y)))
+
+    def draw_image_adj(self, key, pos, color, size):
+        self.L.fo_draw_image_adj(self.h, int(key), _F2(*pos), S.CColor(*color), _F2(*size))
 
     def draw_msdf(self, key, pos, color, size, px_range, sd_threshold=0.5, stroke_weight=0.0, mtsdf=False, flip_y=False):
         self.L.fo_draw_msdf(self.h, int(key), _F2(*pos), S.CColor(*color), _F2(*size), px_range, sd_threshold,

@@ -130,6 +130,7 @@ int main(int argc, char** argv) {
     OK(fdh_draw_image(c, 42, pos, cols, size, 0));
     OK(fdh_set_text_subpixel_shift(c, 0.0f));
     OK(fdh_draw_image(c, 999, pos, cols, size, 0)); /* unknown key: warn-and-skip (glcontext.nim:1310-1315) */
+    OK(fdh_draw_image_adj(c, 42, pos, red, size));
     OK(fdh_draw_msdf(c, 42, pos, red, size, 4.0f, 0.5f, 0.0f, 0, 0));
     OK(fdh_draw_quadratic_bezier_sdf(c, rect, &grad, p0, p1, p2, 3.0f, FDH_CAP_ROUND));
     OK(fdh_draw_filled_quad(c, quad, cols));
@@ -233,6 +234,8 @@ int main(int argc, char** argv) {
     }
     OK(fdh_set_stripe(c, 0, 0));
     { int64_t ns[12]; OK(fdh_debug_host_times(c, ns)); CHECK(ns[0] >= 0); }
+    { int lcd = -1, rank = -1, world = -1; OK(fdh_set_text_lcd_filtering(c, 1)); OK(fdh_get_text_lcd_filtering(c, &lcd)); CHECK(lcd == 1); OK(fdh_set_text_lcd_filtering(c, 0));
+      OK(fdh_comm_info(c, &rank, &world)); CHECK(rank == 0 && world == 1); }
     { int th = -1; int64_t groups = -1; OK(fdh_set_walk_threads(c, 2)); OK(fdh_walk_stats(c, &th, &groups)); CHECK(th == 2 && groups >= 0); OK(fdh_set_walk_threads(c, -1)); }
     { int64_t culled = -1; OK(fdh_set_cull(c, 0)); OK(fdh_set_cull(c, 1)); OK(fdh_culled_draws(c, &culled)); CHECK(culled >= 0); }
     OK(fdh_set_blur_route(c, 1)); OK(fdh_set_blur_route(c, -1));

@@ -65,7 +65,8 @@ def test_nim_shim_binds_what_it_calls():
     for method in ("beginFrame", "endFrame", "drawRoundedRectSdf", "drawImage", "drawMsdfImage", "drawMtsdfImage", "drawBackdropBlur", "beginMask",
                    "endMask", "popMask", "beginRectMask", "popRectMask", "readPixels", "putImage", "updateImage", "removeImage", "resetImageAtlas",
                    "translate", "rotate", "scale", "applyTransform", "saveTransform", "restoreTransform", "transformMirrorsY", "drawRect",
-                   "drawFilledQuad", "drawQuadraticBezierSdf", "setTextSubpixelShift", "atlasPackedArea"):
+                   "drawFilledQuad", "drawQuadraticBezierSdf", "setTextSubpixelShift", "atlasPackedArea", "drawImageAdj",
+                   "setTextLcdFilteringEnabled", "textLcdFilteringEnabled"):
         assert re.search(r"method %s\*\(ctx: HipContext" % method, shim), method
 
 
@@ -428,6 +429,24 @@ def test_bench_stripes_mode_one_rank_gathers_through_the_c_abi():
     assert d["n_gpus"] == 1 and "fdh_gather_stripes" in d["config"]["gather"] and d["config"]["rows_per_rank"] == [1080]
     assert d["gathered_frame_check"]["parity_max_lsb"] <= 1 and d["value"] > 0
     assert "1920x1080" in d["metric"]
+
+
+@pytest.mark.gpu
+def test_bench_stripes_mode_with_the_host_as_consumer():
+    """--gather host: no gather -- every rank reads its own stripe back to pinned host memory over its own PCIe link
+    (fdh_read_pixels), the mode for a consumer that is the host.  One rank and two ranks (gloo carries only the barriers):
+    rank 0's rows must be the oracle's, rccl_ranks_seen stays null (no communicator)."""
+    import json
+
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--mode", "stripes", "--gather", "host", "--width", "1920", "--height", "1080",
+                        "--steps", "9", "--warmup", "2", "--repeats", "2"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == 1 and "own PCIe link" in d["config"]["gather"] and d["config"]["rccl_ranks_seen"] is None
+    assert d["gathered_frame_check"]["parity_max_lsb"] <= 1 and d["gathered_frame_check"]["rows_checked"] == [0, 1080] and d["value"] > 0
+    d = _run_bench_two_ranks(["--mode", "stripes", "--gather", "host", "--width", "1920", "--height", "1080", "--steps", "9", "--warmup", "2"], 29537)
+    assert d["n_gpus"] == 2 and sum(d["config"]["rows_per_rank"]) == 1080
+    assert d["gathered_frame_check"]["parity_max_lsb"] <= 1 and d["gathered_frame_check"]["rows_checked"][0] == 0
 
 
 @pytest.mark.gpu

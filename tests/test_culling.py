@@ -107,3 +107,22 @@ def test_culling_keeps_every_visible_record():
         counts[mode] = ctx.culled_draws()
         ctx.close()
     assert counts[0] == 0 and counts[1] > 100
+
+
+def test_draw_image_adj_call_stream_matches_the_oracles():
+    """drawImageAdj through both restatements' recorders: same call, same arguments (CPU)"""
+    import os
+
+    from conftest import GOLDEN
+    from figdraw_amd.scenes import load_glyph_fixture
+
+    img = load_glyph_fixture(os.path.join(GOLDEN, "glyphs_ubuntu20.npz"))[3000]
+    out = []
+    for be in (O.Oracle(atlas_size=256), HipContext(atlas_size=256, record_only=True)):
+        be.put_image(3000, img)
+        be.record_begin()
+        be.begin_frame(64, 64)
+        be.draw_image_adj(3000, (3.5, 4.0), (255, 128, 0, 255), (40.0, 30.0))
+        be.end_frame()
+        out.append(be.record_calls())
+    assert out[0] == out[1] and out[0][1][0] == "draw_image_adj"

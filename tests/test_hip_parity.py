@@ -993,3 +993,50 @@ def test_frames_recorded_on_the_walk_pool_equal_the_serial_ones(hip, which):
     # (the "wide" scenes are 400-node random scenes: held to the north star's tolerance like the fuzz sweep -- an elliptical clip
     # corner with a large radius can put one pixel 2 LSB off)
     assert mx <= 2 and n1 <= 4 and n0 <= 0.005 * w * h, (which, mx, n0, n1)
+
+
+def test_draw_image_adj_and_the_lcd_flag_through_the_seam():
+    """drawImageAdj (glcontext.nim:1369-1381: the uv rect pulled in by two texels) against the oracle, upright, scaled and under a
+    rotation; and setTextLcdFilteringEnabled / textLcdFilteringEnabled (figbackend.nim:663-667): a glyph uploaded with
+    FDH_GLYPH_LCD_CONTEXT is filtered exactly when the context's flag is on."""
+    import os
+
+    from conftest import GOLDEN
+    from figdraw_amd.context import HipContext
+    from figdraw_amd.scenes import load_glyph_fixture
+    from oracle import oracle as O
+
+    imgs = load_glyph_fixture(os.path.join(GOLDEN, "glyphs_ubuntu20.npz"))
+    w, h = 240, 180
+    ctx, o = HipContext(atlas_size=256, device=0), O.Oracle(atlas_size=256)
+    for k in (3000, 2065):
+        assert ctx.put_image(k, imgs[k]) == o.put_image(k, imgs[k])
+    calls = [["begin_frame", 1, [0.2, 0.25, 0.3, 1.0]],
+             ["draw_image_adj", 3000, [10, 12], [255, 255, 255, 255], [100, 100]],
+             ["draw_image_adj", 3000, [120.5, 8.25], [255, 200, 160, 200], [70, 45]],
+             ["save_transform"], ["translate", 60, 120], ["rotate", 0.3],
+             ["draw_image_adj", 2065, [0, 0], [90, 255, 120, 255], [64, 40]],
+             ["restore_transform"], ["end_frame"]]
+    for be in (ctx, o):
+        be.W, be.H = w, h
+    ctx.replay_calls(calls)
+    o.replay(calls)
+    mx, n0, n1 = diff_stats(ctx.read_pixels(), o.read_pixels())
+    assert mx <= 1 and n0 <= 0.005 * w * h, (mx, n0, n1)
+    # the LCD flag
+    assert ctx.text_lcd_filtering() is False
+    g = imgs[1000 + ord("W")]
+    frames = {}
+    for name, flag_on, how in (("ctx_on", True, "context"), ("ctx_off", False, "context"), ("forced", False, True), ("plain", True, False)):
+        c2 = HipContext(atlas_size=256, device=0)
+        c2.set_text_lcd_filtering(flag_on)
+        assert c2.text_lcd_filtering() is flag_on
+        c2.put_glyph_image(7, g, lcd_filter=how)
+        c2.begin_frame(64, 48, True, (0, 0, 0, 1))
+        c2.draw_image(7, (5, 5), [(255, 255, 255, 255)] * 4)
+        c2.end_frame()
+        frames[name] = c2.read_pixels()
+        c2.close()
+    assert np.array_equal(frames["ctx_on"], frames["forced"]) and np.array_equal(frames["ctx_off"], frames["plain"])
+    assert not np.array_equal(frames["ctx_on"], frames["ctx_off"])
+    ctx.close()

@@ -22,7 +22,8 @@
 enum {
   OP_BEGIN_FRAME = 1, OP_END_FRAME, OP_SAVE_TRANSFORM, OP_RESTORE_TRANSFORM, OP_TRANSLATE, OP_ROTATE, OP_SCALE, OP_APPLY_TRANSFORM,
   OP_SET_AA, OP_DRAW_ROUNDED_RECT_SDF, OP_DRAW_IMAGE, OP_DRAW_MSDF, OP_DRAW_BACKDROP_BLUR, OP_BEGIN_MASK, OP_END_MASK, OP_POP_MASK,
-  OP_BEGIN_RECT_MASK, OP_POP_RECT_MASK, OP_DRAW_QUADRATIC_BEZIER_SDF, OP_DRAW_FILLED_QUAD, OP_DRAW_RECT, OP_SET_SUBPIXEL_SHIFT
+  OP_BEGIN_RECT_MASK, OP_POP_RECT_MASK, OP_DRAW_QUADRATIC_BEZIER_SDF, OP_DRAW_FILLED_QUAD, OP_DRAW_RECT, OP_SET_SUBPIXEL_SHIFT,
+  OP_DRAW_IMAGE_ADJ
 };
 
 static float f32(uint32_t w) { float f; memcpy(&f, &w, 4); return f; }
@@ -87,6 +88,11 @@ FDH_API int fdh_play_calls(FdhContext* ctx, const uint32_t* w, size_t n_words, i
       }
       case OP_DRAW_FILLED_QUAD: used = 12; if (i + used > n_words) return -100; floats(a, 8, v8); for (k = 0; k < 4; k++) cols[k] = rgba8(a[8 + k]); rc = fdh_draw_filled_quad(ctx, v8, cols); break;
       case OP_DRAW_RECT: used = 5; if (i + used > n_words) return -100; floats(a, 4, r4); rc = fdh_draw_rect(ctx, r4, rgba8(a[4])); break;
+      case OP_DRAW_IMAGE_ADJ: /* key lo hi, pos2, color, size2 */
+        used = 7; if (i + used > n_words) return -100;
+        floats(a + 2, 2, p2); floats(a + 5, 2, s2);
+        rc = fdh_draw_image_adj(ctx, (int64_t)((uint64_t)a[0] | ((uint64_t)a[1] << 32)), p2, rgba8(a[4]), s2);
+        break;
       case OP_SET_SUBPIXEL_SHIFT: used = 1; if (i + used > n_words) return -100; rc = fdh_set_text_subpixel_shift(ctx, f32(a[0])); break;
       default: return -100;
     }
