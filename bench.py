@@ -519,7 +519,8 @@ def main():
         sr = ctx.frame_stats()
         walked, reused = ctx.scene_stats()
         dynamic = {"one_context": {"ms_per_frame": round(1e3 * sd_elapsed / args.steps, 4), "mpixels_per_s": round(w * h * args.steps / sd_elapsed / 1e6, 1), "batches_ms": sd_batch_ms},
-                   "host_record_us": round(1e3 * st0.ms_host_record, 1), "host_prepare_us": round(1e3 * st0.ms_host_upload, 1),
+                   "host_record_us": round(host_times_us["begin_frame"] - host_times_us["wait_upload"] + host_times_us["walk"] + host_times_us["end"], 1),
+                   "host_prepare_us": host_times_us["prepare"],
                    "host_issue_us": round(1e3 * st0.ms_host_launch, 1), "host_times_us": host_times_us,
                    "note": "`value` IS this path with frames_in_flight contexts; host_*: per frame, the calling thread records (tree walk, large sibling "
                            "groups on the walk pool: config.walk_pool_threads) and prepares (layout, run table), the context's submit thread issues (upload "

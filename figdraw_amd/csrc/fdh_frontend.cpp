@@ -648,7 +648,7 @@ bool ParallelWalk::group(Walker& mw, const FdhLayer& L, const int* items, int n)
   if (helpers <= 0 || C.rec_on_ || !C.frame_begun_) return false;
   Context::HostTimer t_group(C.host_ns_[7]);
   const int slots = helpers + 1;
-  const int n_chunks = std::min(n / 12, slots * 4);
+  const int n_chunks = std::min(n / 12, slots * (slots > 4 ? 2 : 4));  // (every chunk is a piece of the frame: three upload runs, a merge step)
   if (n_chunks < 2) return false;
   struct alignas(128) Out {
     Piece p;

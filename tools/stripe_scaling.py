@@ -24,6 +24,7 @@ from figdraw_amd.sharding import stripe_rows  # noqa: E402
 
 w, h = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (7680, 4320)
 LINK_GBS = 153.0
+PCIE_GBS = 56.0
 F, K = 4, 120
 scenes = [make_render_tree_100(w, h, frame=f, full_frame_blur=True) for f in range(8)]
 cs = [s.to_c() for s in scenes]
@@ -43,12 +44,21 @@ for world in (1, 2, 4, 8):
     link_us = rows_remote * w * 4 / (LINK_GBS * 1e9) * 1e6
     slowest = max(p["us_per_frame"] for p in per_rank)
     period = max(slowest, link_us)
+    # the other consumer (bench.py --mode stripes --gather host): no gather, every rank reads its own stripe back over its own PCIe
+    # link (measured on this pool: 132.7 MB in 2.37 ms = 56 GB/s, profiles/r04_stripes_8k_host.json); the links work in parallel
+    rows_max = max(b - a for a, b in (stripe_rows(h, world, r) for r in range(world)))
+    pcie_us = rows_max * w * 4 / (PCIE_GBS * 1e9) * 1e6
+    host_period = max(slowest, pcie_us)
     out["worlds"][str(world)] = {"stripes": per_rank, "slowest_stripe_us": slowest, "sum_of_stripes_us": round(sum(p["us_per_frame"] for p in per_rank), 2),
                                  "gather_us_per_frame_per_link": round(link_us, 2), "predicted_frame_period_us": round(period, 2),
-                                 "predicted_mpixels_per_s": round(w * h / period, 1), "bound": "gather (one xGMI link)" if link_us > slowest else "slowest stripe (compute)"}
+                                 "predicted_mpixels_per_s": round(w * h / period, 1), "bound": "gather (one xGMI link)" if link_us > slowest else "slowest stripe (compute)",
+                                 "host_consumer": {"readback_us_per_stripe": round(pcie_us, 2), "predicted_frame_period_us": round(host_period, 2),
+                                                   "predicted_mpixels_per_s": round(w * h / host_period, 1),
+                                                   "bound": "each rank's PCIe link" if pcie_us > slowest else "slowest stripe (compute)"}}
 base = out["worlds"]["1"]["predicted_frame_period_us"]
 for k, v in out["worlds"].items():
     v["predicted_speedup"] = round(base / v["predicted_frame_period_us"], 2)
     v["predicted_efficiency"] = round(base / v["predicted_frame_period_us"] / int(k), 3)
     v["halo_and_launch_overhead"] = round(v["sum_of_stripes_us"] / base, 3)  # total GPU time of all stripes / the unstriped frame
+    v["host_consumer"]["predicted_speedup"] = round(out["worlds"]["1"]["host_consumer"]["predicted_frame_period_us"] / v["host_consumer"]["predicted_frame_period_us"], 2)
 print(json.dumps(out, indent=1))
