@@ -36,7 +36,7 @@ class FrameStats(C.Structure):
                 ("ms_composite_main", C.c_float), ("ms_blur_h", C.c_float), ("ms_blur_v", C.c_float),
                 ("bytes_algorithmic", C.c_int64), ("bytes_composite_main", C.c_int64), ("bytes_blur", C.c_int64),
                 ("fragments", C.c_int64), ("ms_host_record", C.c_float), ("ms_host_upload", C.c_float),
-                ("ms_host_launch", C.c_float), ("_reserved", C.c_float),
+                ("ms_host_launch", C.c_float), ("clear_folded", C.c_float),
                 ("ms_blur_big_h", C.c_float), ("ms_blur_big_v", C.c_float), ("bytes_blur_big_h", C.c_int64), ("bytes_blur_big_v", C.c_int64),
                 ("fragments_main_by_mode", C.c_int64 * 4), ("fragments_main_elliptical", C.c_int64), ("fragments_main_other", C.c_int64),
                 ("flops_composite_main", C.c_int64), ("ms_blur_fused", C.c_float), ("_reserved2", C.c_float),

@@ -399,7 +399,7 @@ typedef struct {
   /* host-side cost of the last begin_frame .. end_frame: recording the calls (tree walk for fdh_render_frame), building
    * the upload, and issuing the copies + kernel launches; all asynchronous to the GPU */
   float ms_host_record, ms_host_upload, ms_host_launch;
-  float _reserved;
+  float clear_folded;      /* 1: the frame's first draw -- one colour at full coverage over the whole cleared frame -- was folded into the clear colour */
   /* the frame's LARGEST blur node on its own (the bench frame: the full-frame node, i.e. the HBM-bound launches):
    * fdh_profile times of its horizontal and vertical pass, and the algorithmic bytes each must move -- H: region + halo rows
    * read and written; V: the same rows read, the region written, plus the region read where the fused composite has to

@@ -1040,3 +1040,54 @@ def test_draw_image_adj_and_the_lcd_flag_through_the_seam():
     assert np.array_equal(frames["ctx_on"], frames["forced"]) and np.array_equal(frames["ctx_off"], frames["plain"])
     assert not np.array_equal(frames["ctx_on"], frames["ctx_off"])
     ctx.close()
+
+
+def test_clear_folding_changes_no_pixel():
+    """A cleared frame whose first draw is one colour at full coverage over the whole frame starts, in effect, from
+    blend(clear, colour): Context::prepare folds that draw into the clear colour (FDH_FOLD_CLEAR=0 turns it off; read once per
+    process, hence the child processes).  Same frames bit for bit -- translucent and opaque backgrounds over several clear colours,
+    and backgrounds that must NOT be folded (rounded corners, a gradient, smaller than the frame, a clip opened first)."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+
+    code = (
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "from figdraw_amd import scene as S\n"
+        "from figdraw_amd.context import HipContext\n"
+        "from figdraw_amd.scenes import make_render_tree_100\n"
+        "import ref_scenes as RS\n"
+        "ctx = HipContext(device=0)\n"
+        "out, folded = [], []\n"
+        "def frame(sc, w, h, color=(1.0, 1.0, 1.0, 1.0)):\n"
+        "    ctx.render_frame(sc, w, h, color=color); out.append(ctx.read_pixels().copy()); folded.append(ctx.frame_stats().clear_folded)\n"
+        "frame(make_render_tree_100(1920, 1080, 2, full_frame_blur=True), 1920, 1080)\n"
+        "for k, (bg, clear, corners, grad, inset) in enumerate([((255, 255, 255, 155), (0.2, 0.4, 0.9, 1.0), 0, False, 0), ((10, 200, 90, 255), (1, 1, 1, 1), 0, False, 0),\n"
+        "        ((90, 20, 200, 1), (0.5, 0.5, 0.5, 0.5), 0, False, 0), ((255, 0, 0, 128), (0, 0, 0, 0), 0, False, 0), ((30, 30, 30, 200), (1, 1, 1, 1), 9, False, 0),\n"
+        "        ((30, 30, 30, 200), (1, 1, 1, 1), 0, True, 0), ((30, 30, 30, 200), (1, 1, 1, 1), 0, False, 3)]):\n"
+        "    w, h = 333, 217\n"
+        "    sc = RS.random_scene(40 + k, float(w), float(h), n=25, clips=(k % 2 == 0), blur=(k % 3 == 0))\n"
+        "    lst = sc.layers[0]\n"
+        "    fill = S.linear(S.rgba(*bg), S.rgba(5, 5, 5, 255)) if grad else S.rgba(*bg)\n"
+        "    node = S.Fig(kind=S.FigKind.nkRectangle, screenBox=S.rect(inset, inset, w - 2 * inset, h - 2 * inset), fill=fill, corners=[corners] * 4)\n"
+        "    node.parent = -1\n"
+        "    lst.nodes.insert(0, node)\n"
+        "    for f in lst.nodes[1:]:\n"
+        "        if f.parent >= 0: f.parent += 1\n"
+        "    lst.rootIds = [0] + [r + 1 for r in lst.rootIds]\n"
+        "    frame(sc, w, h, color=clear)\n"
+        "np.savez(sys.argv[1], *out, folded=np.array(folded))\n"
+    ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    with tempfile.TemporaryDirectory() as td:
+        for on in ("1", "0"):
+            path = os.path.join(td, f"fold{on}.npz")
+            subprocess.check_call([sys.executable, "-c", code, path], env=dict(os.environ, FDH_FOLD_CLEAR=on))
+            z = np.load(path)
+            res[on] = ([z[f"arr_{i}"] for i in range(8)], z["folded"].tolist())
+    assert res["0"][1] == [0.0] * 8
+    assert res["1"][1] == [1.0, 1.0, 1.0, 1.0, 1.0, 0.0, 0.0, 0.0], res["1"][1]  # the last three must not fold
+    for a, b in zip(res["0"][0], res["1"][0]):
+        assert np.array_equal(a, b)
