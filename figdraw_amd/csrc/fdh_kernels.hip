@@ -1710,7 +1710,9 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? 4 : kPaths == 4 ? FDH_UNIFORM_WA
   const bool row_ok_e = pye < P.H;
   const size_t pixe = (size_t)pye * P.pitch + px0e;
   if (row_ok_e && px0e + 3 < P.W && (P.pitch & 3) == 0) {
-    uint4 o = {pack255(F0), pack255(F1), pack255(F2), pack255(F3)};
+    // (a strip of the launch that starts the frame on which nothing landed -- wave-uniform -- is the clear colour as it is: no packing)
+    uint4 o = {P.clear_rgba8, P.clear_rgba8, P.clear_rgba8, P.clear_rgba8};
+    if (!kFull || touched) o = uint4{pack255(F0), pack255(F1), pack255(F2), pack255(F3)};
     *reinterpret_cast<uint4*>(P.fb + pixe) = o;
   } else if (row_ok_e) {
     if (px0e + 0 < P.W) P.fb[pixe + 0] = pack255(F0);

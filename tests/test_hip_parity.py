@@ -1068,7 +1068,7 @@ def test_clear_folding_changes_no_pixel():
         "        ((90, 20, 200, 1), (0.5, 0.5, 0.5, 0.5), 0, False, 0), ((255, 0, 0, 128), (0, 0, 0, 0), 0, False, 0), ((30, 30, 30, 200), (1, 1, 1, 1), 9, False, 0),\n"
         "        ((30, 30, 30, 200), (1, 1, 1, 1), 0, True, 0), ((30, 30, 30, 200), (1, 1, 1, 1), 0, False, 3)]):\n"
         "    w, h = 333, 217\n"
-        "    sc = RS.random_scene(40 + k, float(w), float(h), n=25, clips=(k % 2 == 0), blur=(k % 3 == 0))\n"
+        "    sc = RS.random_scene(40 + k, float(w), float(h), n=25, clips=(k %% 2 == 0), blur=(k %% 3 == 0))\n"
         "    lst = sc.layers[0]\n"
         "    fill = S.linear(S.rgba(*bg), S.rgba(5, 5, 5, 255)) if grad else S.rgba(*bg)\n"
         "    node = S.Fig(kind=S.FigKind.nkRectangle, screenBox=S.rect(inset, inset, w - 2 * inset, h - 2 * inset), fill=fill, corners=[corners] * 4)\n"
