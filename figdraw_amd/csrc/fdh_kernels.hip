@@ -1955,7 +1955,15 @@ template <int c> __device__ __forceinline__ h8 mx_frag(const uint32_t (&R)[8]) {
 #ifndef FDH_MX_H_EXTRA
 #define FDH_MX_H_EXTRA 0
 #endif
-constexpr int mx_ring_slots(int nk, bool vertical) { return nk + 2 + (vertical ? 2 : FDH_MX_H_EXTRA); }
+#ifndef FDH_MX_V_EXTRA
+#define FDH_MX_V_EXTRA 0  // (2: rounds 1 - 3 kept two idle slots for the fused composite's alphas -- 18 KB per wave, eight waves per CU)
+#endif
+#ifndef FDH_MX_WAVES
+#define FDH_MX_WAVES 2    // waves per SIMD the passes are compiled for.  (3 -- eleven 14-KB rings fit a CU, 2720 waves of three blocks in one
+                          // round -- measured 21.3 / 22.5 us against 19.9 / 19.6 for the two passes at 4K: more waves per SIMD do not help, the
+                          // passes are paced by the memory system, profiles/r04_blur_notes.txt)
+#endif
+constexpr int mx_ring_slots(int nk, bool vertical) { return nk + 2 + (vertical ? FDH_MX_V_EXTRA : FDH_MX_H_EXTRA); }
 constexpr float kMxScale = 16384.0f;  // 2^24 (subnormal texels) / 2^10 (weight scale)
 constexpr int kMxSlot = 512;          // dwords of one k-step in LDS: 16 texels along the filter x 32 lines
 // LDS-DMA: 16 (or 4) bytes per lane from `src` to LDS byte address `lds` + 16 (4) * lane.  Written as inline assembly on
@@ -1998,7 +2006,7 @@ __device__ unsigned int g_mx_bad_n;
 __device__ unsigned int g_mx_bad[4096 * 8];
 #endif
 template <int NK, bool kV>
-__global__ __launch_bounds__(64, 2) void k_blur_mx(BlurParams P, const DrawRec* __restrict__ draws, const QuadExt* __restrict__ exts, int T) {
+__global__ __launch_bounds__(64, FDH_MX_WAVES) void k_blur_mx(BlurParams P, const DrawRec* __restrict__ draws, const QuadExt* __restrict__ exts, int T) {
   constexpr int R = mx_ring_slots(NK, kV);
   extern __shared__ __attribute__((aligned(16))) uint32_t ring[];  // R slots
   // blocks sit at absolute multiples of 32 along the filter direction: a pixel's sum is then grouped into MFMAs the same
@@ -2239,8 +2247,11 @@ __global__ __launch_bounds__(64, 2) void k_blur_mx(BlurParams P, const DrawRec* 
       }
       if (!replace_all) {
       uint32_t blend_mask = 0;
-      uint32_t* sc0 = ring + (slot0 >= 2 ? slot0 - 2 : slot0 - 2 + R) * kMxSlot;  // the two ring slots block b - 1 gave up: nothing is in
-      uint32_t* sc1 = ring + (slot0 >= 1 ? slot0 - 1 : slot0 - 1 + R) * kMxSlot;  // flight into them until the end of this iteration
+      // Two ring slots nothing is in flight into until the end of this iteration.  With FDH_MX_V_EXTRA = 2: the two idle slots in
+      // front of block b's.  Without them (round 4): block b's OWN first two k-steps -- its products are done, block b + 1 starts two
+      // k-steps further on, and the k-steps of block b + 2 are only issued into them behind this epilogue.
+      uint32_t* sc0 = ring + (FDH_MX_V_EXTRA >= 2 ? (slot0 >= 2 ? slot0 - 2 : slot0 - 2 + R) : slot0) * kMxSlot;
+      uint32_t* sc1 = ring + (FDH_MX_V_EXTRA >= 2 ? (slot0 >= 1 ? slot0 - 1 : slot0 - 1 + R) : (slot0 + 1 >= R ? slot0 + 1 - R : slot0 + 1)) * kMxSlot;
       if (core) {
 #pragma unroll
         for (int rr = 0; rr < 16; rr++) if (((pmask >> rr) & 1u) && (pend[rr] >> 24) != 255u) blend_mask |= 1u << rr;
@@ -2874,7 +2885,8 @@ static int mx_pick_t(long long per_cu, long long outputs_along, long long lines)
   if (forced) return forced;
   // (two waves per SIMD at most: with the horizontal pass's smaller ring eleven fit a CU, and T = 3 with 2720 shorter waves
   // measured 24.6 us against 23.4 for the two blur launches of the bench frame)
-  const long long slots = 256 * std::min<long long>(per_cu, 8);
+  static const int cu_cap = [] { const char* e = std::getenv("FDH_MX_PER_CU"); return e ? std::atoi(e) : 4 * FDH_MX_WAVES; }();
+  const long long slots = 256 * std::min<long long>(per_cu, cu_cap);
   const long long along_blocks = (outputs_along + 31) / 32, line_groups = (lines + 31) / 32;
   for (int t = 1; t < 64; t++) if (line_groups * ((along_blocks + t - 1) / t) <= slots) return t;
   return 64;
@@ -2883,7 +2895,7 @@ template <int NK, bool kV> static void launch_blur_mx(hipStream_t s, const BlurP
   constexpr size_t lds = (size_t)mx_ring_slots(NK, kV) * kMxSlot * sizeof(uint32_t);
   static const int per_cu = [] {  // single-wave workgroups resident per CU, asked once per instantiation
     int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_blur_mx<NK, kV>, 64, lds) != hipSuccess || n <= 0) n = std::min<int>(8, 160 / (mx_ring_slots(NK, kV) * 2));
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_blur_mx<NK, kV>, 64, lds) != hipSuccess || n <= 0) n = std::min<int>(4 * FDH_MX_WAVES, 160 / (mx_ring_slots(NK, kV) * 2));
     return n;
   }();
   const int t = kV ? mx_pick_t(per_cu, P.y1 - P.y0, P.x1 - P.x0) : mx_pick_t(per_cu, P.x1 - P.x0, P.y1 - P.y0);
