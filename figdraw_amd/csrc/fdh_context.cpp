@@ -1045,6 +1045,16 @@ void Context::launch_frame(const LaunchJob& J, bool profile) {
           if (!done) throw Error(FDH_ERR_HIP, "fused blur: no kernel for this filter width (blur_fused_supported out of step with the launcher)");
           cur = other;
         }
+        if (!done && j.fuse_draw < 0 && blur_one_kernel_ok(j.x1 - j.x0, j.y1 - j.y0, j.taps.reach)) {
+          // a small region: one kernel, source window -> LDS -> horizontal -> LDS -> vertical -> the backdrop surface
+          bp.fuse_draw = -1;
+          bp.src = cur; bp.dst = backdrop_;
+          bp.x0 = j.x0; bp.x1 = j.x1; bp.y0 = vy0; bp.y1 = vy1;
+          span_begin(ph.blur == big_blur_ ? 6 : 4);
+          launch_blur_small(stream_, bp);
+          span_end();
+          done = true;
+        }
         if (!done) {
         bp.fuse_draw = -1;
         bp.src = cur; bp.dst = blur_tmp_;

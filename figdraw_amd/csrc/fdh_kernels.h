@@ -63,6 +63,10 @@ void launch_bin(hipStream_t s, const BinParams& P);
 void launch_composite(hipStream_t s, const DrawRec* draws, const QuadExt* exts, CompositeParams P);
 void launch_blur_h(hipStream_t s, const BlurParams& P);
 void launch_blur_v(hipStream_t s, const BlurParams& P, const DrawRec* draws, const QuadExt* exts);
+// a small region (blur_one_kernel_ok): both passes in ONE kernel, P.src -> the blurred snapshot in P.dst (out of place: the backdrop
+// surface), rows [P.y0, P.y1) of columns [P.x0, P.x1); the phase's compositor launch samples it for the mode-17 quad
+bool blur_one_kernel_ok(int w, int h, int reach);
+void launch_blur_small(hipStream_t s, const BlurParams& P);
 // both passes of a full-frame node in one kernel, out of place (P.src -> P.dst, the fused mode-17 composite blended over P.src);
 // P.mx_w = the horizontal pass's weight fragments, w_v = the vertical pass's.  false: no instantiation for this filter width
 bool blur_fused_supported(int reach, int W, int pitch);

@@ -1925,6 +1925,59 @@ __global__ __launch_bounds__(64 * kVWaves) void k_blur_v(BlurParams P, const Dra
   }
 }
 
+// ------------------------------------------------------------------ a small region: both passes in one kernel
+// A 360 x 240 backdrop (the demo's own blur node) took two launches of 5 + 7 us -- latency, not work: < 1 % of the HBM peak -- and
+// a third for the composite behind them.  Here a workgroup produces a 32 x 16 tile of the BLURRED SNAPSHOT: it stages the tile's
+// (32 + 2 reach) x (16 + 2 reach) source window in LDS (clamp-to-edge), filters its 16 + 2 reach rows horizontally into LDS --
+// rounded to RGBA8 exactly as the horizontal pass stores its intermediate texture (glcontext.nim:1743-1786) -- and filters
+// those vertically.  Same per-output sums in the same order as k_blur_h<2> / k_blur_v<2, .> (fir_outputs<2>): the snapshot is
+// the two-pass one bit for bit.  It goes to the backdrop surface, out of place (a tile's neighbours still read the live surface
+// around it), and the phase's compositor launch samples it for the mode-17 quad like any other draw.
+constexpr int kSmallTW = 32, kSmallTH = 16;
+__global__ __launch_bounds__(256) void k_blur_small(BlurParams P) {
+  extern __shared__ uint32_t small_lds[];
+  const int reach = P.taps.reach;
+  const int in_w = kSmallTW + 2 * reach, rows = kSmallTH + 2 * reach;
+  uint32_t* in = small_lds;                    // [rows][in_w]
+  uint32_t* hres = small_lds + rows * in_w;    // [rows][kSmallTW]
+  const int ntx = (P.x1 - P.x0 + kSmallTW - 1) / kSmallTW;
+  const int ty = (int)blockIdx.x / ntx, tx = (int)blockIdx.x - ty * ntx;
+  const int xs = P.x0 + tx * kSmallTW, ys = P.y0 + ty * kSmallTH;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int rr = wave; rr < rows; rr += 4) {
+    int y = ys - reach + rr;
+    y = y < 0 ? 0 : (y > P.H - 1 ? P.H - 1 : y);  // clamp-to-edge (glcontext.nim:214-215)
+    const uint32_t* __restrict__ row = P.src + (size_t)y * P.pitch;
+    for (int cc = lane; cc < in_w; cc += 64) {
+      int x = xs - reach + cc;
+      x = x < 0 ? 0 : (x > P.W - 1 ? P.W - 1 : x);
+      in[rr * in_w + cc] = row[x];
+    }
+  }
+  __syncthreads();
+  // horizontal: a thread produces two consecutive outputs of one row
+  for (int t = threadIdx.x; t < rows * (kSmallTW / 2); t += 256) {
+    const int rr = t / (kSmallTW / 2), c = t - rr * (kSmallTW / 2);
+    f2 rg[2], ba[2];
+    const uint32_t* __restrict__ win = in + rr * in_w + 2 * c;
+    fir_outputs<2>(P.taps.dense, reach, [&](int j) { return win[j]; }, rg, ba);
+    hres[rr * kSmallTW + 2 * c] = pack2(rg[0], ba[0]);
+    hres[rr * kSmallTW + 2 * c + 1] = pack2(rg[1], ba[1]);
+  }
+  __syncthreads();
+  // vertical: a thread produces two consecutive rows of one column
+  for (int t = threadIdx.x; t < kSmallTW * (kSmallTH / 2); t += 256) {
+    const int pr = t / kSmallTW, c = t - pr * kSmallTW;
+    const int x = xs + c, y = ys + 2 * pr;
+    if (x >= P.x1 || y >= P.y1) continue;
+    f2 rg[2], ba[2];
+    const uint32_t* __restrict__ col = hres + (2 * pr) * kSmallTW + c;
+    fir_outputs<2>(P.taps.dense, reach, [&](int j) { return col[j * kSmallTW]; }, rg, ba);
+    P.dst[(size_t)y * P.pitch + x] = pack2(rg[0], ba[0]);
+    if (y + 1 < P.y1) P.dst[(size_t)(y + 1) * P.pitch + x] = pack2(rg[1], ba[1]);
+  }
+}
+
 // ------------------------------------------------------------------ blur on the matrix pipe (large regions)
 // The FIR is the one contraction on the path: 32 consecutive outputs of a line are a banded Toeplitz matrix (32 x (32 + 2 reach))
 // times the line's texels.  As packed-FMA code it ran at ~85 % of the VALU issue rate and 28 % of the HBM roofline; on the
@@ -2032,6 +2085,9 @@ __global__ __launch_bounds__(64, FDH_MX_WAVES) void k_blur_mx(BlurParams P, cons
   }
   const int lane = threadIdx.x, g = lane >> 5, j = lane & 31;
   const int reach = P.taps.reach;
+#if defined(FDH_MX_STAGGER)  // experiment: every other wave of an XCD starts FDH_MX_STAGGER x ~1 us late (do memory and arithmetic phases run in step?)
+  if ((blockIdx.x >> 3) & 1) for (int i = 0; i < FDH_MX_STAGGER; i++) __builtin_amdgcn_s_sleep(32);
+#endif
   const int as = a0 + 32 * T * sa, lb = l0 + 32 * sl;
   const int n_blocks = min(T, (a_hi - as + 31) >> 5);
   const int w0 = as - reach, w0a = kV ? w0 : (w0 & ~3);  // horizontal: window start moved back to a 16-byte boundary (mx_delta)
@@ -2952,6 +3008,19 @@ bool launch_blur_fused(hipStream_t s, const BlurParams& P, const uint4* w_v, con
   FDH_FX(3, 3) FDH_FX(4, 3) FDH_FX(4, 4) FDH_FX(5, 4) FDH_FX(5, 5) FDH_FX(6, 5) FDH_FX(6, 6)
 #undef FDH_FX
   return false;
+}
+// one kernel for a small region (k_blur_small): the region sizes the small-region passes take, filters of reach <= 24 (the tile's
+// source window and its horizontal result stay under 20 KB of LDS; a wider filter re-filters too many halo rows per 16-row tile)
+bool blur_one_kernel_ok(int w, int h, int reach) {
+  static const bool off = [] { const char* e = std::getenv("FDH_BLUR_ONE_KERNEL"); return e && std::atoi(e) == 0; }();
+  if (off || blur_forced_path() || w <= 0 || h <= 0) return false;
+  return (long long)w * h < 384 * 1024 && reach <= 24;
+}
+void launch_blur_small(hipStream_t s, const BlurParams& P) {
+  if (P.x1 <= P.x0 || P.y1 <= P.y0) return;
+  const int reach = P.taps.reach, ntx = (P.x1 - P.x0 + kSmallTW - 1) / kSmallTW, nty = (P.y1 - P.y0 + kSmallTH - 1) / kSmallTH;
+  const size_t lds = (size_t)(kSmallTH + 2 * reach) * (size_t)(2 * kSmallTW + 2 * reach) * sizeof(uint32_t);
+  FDH_LAUNCH(k_blur_small, dim3(ntx * nty), dim3(256), lds, s, P);
 }
 void launch_blur_h(hipStream_t s, const BlurParams& P) {
   if (P.x1 <= P.x0 || P.y1 <= P.y0) return;

@@ -1014,13 +1014,16 @@ void Recorder::draw_backdrop_blur(const float rect[4], const float rx[4], const 
     push_rec(BBox{0, 0, 0, 0});
     if (((nr.op_mode >> 12) & 15u) == OP_MASK_PUSH) { depth_now_++; sum_.deepest = std::max(sum_.deepest, depth_now_); }
   }
-  const bool fuse = open_ops_.empty();  // no clip state to carry: the V pass can composite the quad itself
+  // no clip state to carry: the V pass can composite the quad itself -- unless the region is small enough for the one-kernel
+  // route, whose snapshot goes to the backdrop surface and is sampled by the phase's compositor launch (k_blur_small)
   DrawRec& r = next_rec();
   r = quad;
   if (!emit_quad(r, rect[0], rect[1], rect[0] + rect[2], rect[1] + rect[3], true)) throw Error(FDH_ERR_INVALID, "drawBackdropBlur: rect_visible and emit_quad disagree");
   const uint32_t idx = (uint32_t)lane_->recs.n - 1;
   const BBox fb = lane_->bins[idx].box;
   BlurJob job;
+  job.taps = make_taps(blur_radius);
+  const bool fuse = open_ops_.empty() && !blur_one_kernel_ok(fb.x1 - fb.x0, fb.y1 - fb.y0, job.taps.reach);
   job.fuse_draw = -1;
   if (fuse) {
     job.fuse_draw = (int)C.global_index(idx);
@@ -1029,7 +1032,6 @@ void Recorder::draw_backdrop_blur(const float rect[4], const float rx[4], const 
   commit_bins(idx);
   job.radius = blur_radius;
   job.x0 = fb.x0; job.y0 = fb.y0; job.x1 = fb.x1; job.y1 = fb.y1;
-  job.taps = make_taps(blur_radius);
   C.blurs_.push_back(job);
 }
 

@@ -1091,3 +1091,54 @@ def test_clear_folding_changes_no_pixel():
     assert res["1"][1] == [1.0, 1.0, 1.0, 1.0, 1.0, 0.0, 0.0, 0.0], res["1"][1]  # the last three must not fold
     for a, b in zip(res["0"][0], res["1"][0]):
         assert np.array_equal(a, b)
+
+
+def test_small_blur_in_one_kernel_equals_the_two_pass_route():
+    """k_blur_small (a small region's two passes in one kernel, snapshot to the backdrop surface, composited by the phase's launch)
+    against the two small-region passes with the composite fused into the vertical one (FDH_BLUR_ONE_KERNEL=0; read once per
+    process): regions at the frame's edges (clamped taps), a stripe, several radii, a rounded translucent quad.  The blurred
+    snapshot is the same sum in the same order; the frames must agree bit for bit -- and with the oracle."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+
+    code = (
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "from figdraw_amd import scene as S\n"
+        "from figdraw_amd.context import HipContext\n"
+        "import ref_scenes as RS\n"
+        "ctx = HipContext(device=0)\n"
+        "out = []\n"
+        "for k, (w, h, box, radius, corner, fill, stripe) in enumerate([(640, 360, (100, 60, 360, 240), 18.0, 20, (255, 225, 55, 0), None), (333, 217, (-20, -10, 200, 120), 6.0, 0, (0, 0, 0, 60), None),\n"
+        "        (400, 300, (250, 180, 200, 150), 22.0, 40, (20, 20, 20, 0), None), (512, 512, (30, 40, 300, 400), 9.0, 8, (255, 255, 255, 30), (96, 288)), (300, 200, (10, 10, 280, 180), 3.0, 12, (0, 0, 0, 0), None)]):\n"
+        "    sc = RS.random_scene(70 + k, float(w), float(h), n=30, clips=False, blur=False)\n"
+        "    lst = sc.layers[0]\n"
+        "    lst.addRoot(S.Fig(kind=S.FigKind.nkBackdropBlur, screenBox=S.rect(*box), corners=[corner] * 4, fill=S.rgba(*fill), blur=radius))\n"
+        "    lst.addRoot(S.Fig(kind=S.FigKind.nkRectangle, screenBox=S.rect(box[0] + 10, box[1] + 10, 60, 40), fill=S.rgba(200, 30, 30, 180), corners=[6] * 4))\n"
+        "    if stripe: ctx.set_stripe(*stripe)\n"
+        "    ctx.render_frame(sc, w, h)\n"
+        "    px = ctx.read_pixels()\n"
+        "    out.append(px[stripe[0]:stripe[1]].copy() if stripe else px.copy())\n"
+        "    ctx.set_stripe(0, 0)\n"
+        "np.savez(sys.argv[1], *out)\n"
+    ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    with tempfile.TemporaryDirectory() as td:
+        for on in ("1", "0"):
+            path = os.path.join(td, f"one{on}.npz")
+            subprocess.check_call([sys.executable, "-c", code, path], env=dict(os.environ, FDH_BLUR_ONE_KERNEL=on))
+            z = np.load(path)
+            res[on] = [z[f"arr_{i}"] for i in range(5)]
+    for a, b in zip(res["0"], res["1"]):
+        assert np.array_equal(a, b)
+    # the first scene against the oracle
+    from figdraw_amd import scene as S
+
+    w, h = 640, 360
+    sc = RS.random_scene(70, float(w), float(h), n=30, clips=False, blur=False)
+    sc.layers[0].addRoot(S.Fig(kind=S.FigKind.nkBackdropBlur, screenBox=S.rect(100, 60, 360, 240), corners=[20] * 4, fill=S.rgba(255, 225, 55, 0), blur=18.0))
+    sc.layers[0].addRoot(S.Fig(kind=S.FigKind.nkRectangle, screenBox=S.rect(110, 70, 60, 40), fill=S.rgba(200, 30, 30, 180), corners=[6] * 4))
+    mx, n0, n1 = diff_stats(res["1"][0], _oracle(lambda *_: sc, w, h))
+    assert mx <= 1 and n0 <= 0.005 * w * h, (mx, n0, n1)
