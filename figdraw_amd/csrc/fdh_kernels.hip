@@ -1751,7 +1751,7 @@ __device__ __forceinline__ uint32_t pack2(f2 rg, f2 ba) {
 // offset j - p - reach); every texel is unpacked once and feeds the accumulators pair by pair.  The first and last
 // kBlurOut - 1 window texels reach only some of the outputs (the rest would multiply the zero padding of `dense`):
 // those two triangles are peeled with the in-range (p, j) pairs spelled out at compile time.
-template <int kBlurOut, typename Tex>
+template <int kBlurOut, int kUnroll = 1, typename Tex>
 __device__ __forceinline__ void fir_outputs(const float* __restrict__ d, int reach, Tex tex, f2 (&rg)[kBlurOut], f2 (&ba)[kBlurOut]) {
 #pragma unroll
   for (int p = 0; p < kBlurOut; p++) { rg[p] = 0.0f; ba[p] = 0.0f; }
@@ -1768,7 +1768,9 @@ __device__ __forceinline__ void fir_outputs(const float* __restrict__ d, int rea
       ba[p] += tba * c;
     }
   }
-  // body: every output is in range
+  // body: every output is in range (kUnroll > 1: several texels' LDS reads and coefficient loads are in flight at once -- a
+  // workgroup with one wave per SIMD has nothing else to hide their latency behind; the sums keep their order)
+#pragma unroll kUnroll
   for (int j = kBlurOut - 1; j < nwin - (kBlurOut - 1); j++) {
     f2 trg, tba;
     unpack2(tex(j), trg, tba);
@@ -1933,8 +1935,11 @@ __global__ __launch_bounds__(64 * kVWaves) void k_blur_v(BlurParams P, const Dra
 // those vertically.  Same per-output sums in the same order as k_blur_h<2> / k_blur_v<2, .> (fir_outputs<2>): the snapshot is
 // the two-pass one bit for bit.  It goes to the backdrop surface, out of place (a tile's neighbours still read the live surface
 // around it), and the phase's compositor launch samples it for the mode-17 quad like any other draw.
-constexpr int kSmallTW = 32, kSmallTH = 16;
-__global__ __launch_bounds__(256) void k_blur_small(BlurParams P) {
+// 1024 threads per workgroup: the tile's 832 horizontal tasks (radius 18) are ONE fir_outputs per thread and its 256 vertical
+// tasks one more -- with 256 threads a thread ran 3.25 + 1 of them back to back, each a chain of 38 dependent LDS reads (15 us
+// for the 360 x 240 node against 5 + 7 for the two launches).
+constexpr int kSmallTW = 32, kSmallTH = 16, kSmallThreads = 1024;
+__global__ __launch_bounds__(kSmallThreads) void k_blur_small(BlurParams P) {
   extern __shared__ uint32_t small_lds[];
   const int reach = P.taps.reach;
   const int in_w = kSmallTW + 2 * reach, rows = kSmallTH + 2 * reach;
@@ -1944,7 +1949,7 @@ __global__ __launch_bounds__(256) void k_blur_small(BlurParams P) {
   const int ty = (int)blockIdx.x / ntx, tx = (int)blockIdx.x - ty * ntx;
   const int xs = P.x0 + tx * kSmallTW, ys = P.y0 + ty * kSmallTH;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  for (int rr = wave; rr < rows; rr += 4) {
+  for (int rr = wave; rr < rows; rr += kSmallThreads / 64) {
     int y = ys - reach + rr;
     y = y < 0 ? 0 : (y > P.H - 1 ? P.H - 1 : y);  // clamp-to-edge (glcontext.nim:214-215)
     const uint32_t* __restrict__ row = P.src + (size_t)y * P.pitch;
@@ -1956,23 +1961,23 @@ __global__ __launch_bounds__(256) void k_blur_small(BlurParams P) {
   }
   __syncthreads();
   // horizontal: a thread produces two consecutive outputs of one row
-  for (int t = threadIdx.x; t < rows * (kSmallTW / 2); t += 256) {
+  for (int t = threadIdx.x; t < rows * (kSmallTW / 2); t += kSmallThreads) {
     const int rr = t / (kSmallTW / 2), c = t - rr * (kSmallTW / 2);
     f2 rg[2], ba[2];
     const uint32_t* __restrict__ win = in + rr * in_w + 2 * c;
-    fir_outputs<2>(P.taps.dense, reach, [&](int j) { return win[j]; }, rg, ba);
+    fir_outputs<2, 6>(P.taps.dense, reach, [&](int j) { return win[j]; }, rg, ba);
     hres[rr * kSmallTW + 2 * c] = pack2(rg[0], ba[0]);
     hres[rr * kSmallTW + 2 * c + 1] = pack2(rg[1], ba[1]);
   }
   __syncthreads();
   // vertical: a thread produces two consecutive rows of one column
-  for (int t = threadIdx.x; t < kSmallTW * (kSmallTH / 2); t += 256) {
+  for (int t = threadIdx.x; t < kSmallTW * (kSmallTH / 2); t += kSmallThreads) {
     const int pr = t / kSmallTW, c = t - pr * kSmallTW;
     const int x = xs + c, y = ys + 2 * pr;
     if (x >= P.x1 || y >= P.y1) continue;
     f2 rg[2], ba[2];
     const uint32_t* __restrict__ col = hres + (2 * pr) * kSmallTW + c;
-    fir_outputs<2>(P.taps.dense, reach, [&](int j) { return col[j * kSmallTW]; }, rg, ba);
+    fir_outputs<2, 6>(P.taps.dense, reach, [&](int j) { return col[j * kSmallTW]; }, rg, ba);
     P.dst[(size_t)y * P.pitch + x] = pack2(rg[0], ba[0]);
     if (y + 1 < P.y1) P.dst[(size_t)(y + 1) * P.pitch + x] = pack2(rg[1], ba[1]);
   }
@@ -3020,7 +3025,7 @@ void launch_blur_small(hipStream_t s, const BlurParams& P) {
   if (P.x1 <= P.x0 || P.y1 <= P.y0) return;
   const int reach = P.taps.reach, ntx = (P.x1 - P.x0 + kSmallTW - 1) / kSmallTW, nty = (P.y1 - P.y0 + kSmallTH - 1) / kSmallTH;
   const size_t lds = (size_t)(kSmallTH + 2 * reach) * (size_t)(2 * kSmallTW + 2 * reach) * sizeof(uint32_t);
-  FDH_LAUNCH(k_blur_small, dim3(ntx * nty), dim3(256), lds, s, P);
+  FDH_LAUNCH(k_blur_small, dim3(ntx * nty), dim3(kSmallThreads), lds, s, P);
 }
 void launch_blur_h(hipStream_t s, const BlurParams& P) {
   if (P.x1 <= P.x0 || P.y1 <= P.y0) return;
