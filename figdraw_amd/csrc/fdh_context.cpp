@@ -561,6 +561,7 @@ void Context::prepare(LaunchJob& J) {
   const size_t n = n_total_, n_ext = n_ext_total_;
   J.W = W_; J.H = H_; J.clear = clear_; J.clear_rgba8 = clear_rgba8_;
   J.rec_y0 = culling() ? cull_y0_ : 0; J.rec_y1 = culling() ? cull_y1_ : H_;
+  J.latency_routes = latency_routes_;
   J.phases = phases_;  // (copies: the recording side keeps its own for fdh_debug_record_digest)
   J.blurs = blurs_;
   J.n_recs = (int)n;
@@ -624,16 +625,9 @@ void Context::prepare(LaunchJob& J) {
   // re-filters 40 % more rows horizontally (segment halos) and holds 22 KB of LDS and 249 VGPRs per wave: with other contexts'
   // frames in flight on the GPU, where total work is what counts, the two-pass route is 3 % faster.  So: fused when no other
   // context of this process has submitted a frame in the last millisecond (FDH_BLUR_FUSED=1 always, =0 never).
-  static const int fx_env = [] { const char* e = std::getenv("FDH_BLUR_FUSED"); return e ? (std::atoi(e) != 0 ? 1 : 0) : -1; }();
-  const int route = blur_route_ >= 0 ? blur_route_ : fx_env;
-  bool fx_on = route != 0;
-  {
-    const int64_t now = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
-    if (route < 0)
-      for (int k = 0; k < kSubmitSlots; k++)
-        if (k != submit_slot_ && now - g_last_submit_ns[k].load(std::memory_order_relaxed) < 1000000) { fx_on = false; break; }
-    g_last_submit_ns[submit_slot_].store(now, std::memory_order_relaxed);
-  }
+  const bool fx_on = latency_routes_;  // (decided when the frame began: Context::pick_routes)
+  g_last_submit_ns[submit_slot_].store(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(),
+                                       std::memory_order_relaxed);
   J.blur_fused.assign(J.blurs.size(), 0);
   J.n_fused = 0;
   for (size_t i = 0; i < J.blurs.size(); i++) {
@@ -906,6 +900,23 @@ void Context::prepare(LaunchJob& J) {
   stats_.ms_host_upload = std::chrono::duration<float, std::milli>(t_l0 - t_s0).count();
 }
 
+// Which blur routes a frame takes is a matter of speed only (same pixels either way): the one-kernel routes -- k_blur_fx for a node
+// that covers the frame, k_blur_small for a small one -- shorten a frame rendered ALONE (fewer dependent launches, half the bytes)
+// but lose a few per cent with other contexts' frames in flight on the GPU, where total work and the way the contexts' kernels
+// interleave are what counts (bench.py, alternating runs: 90.8 against 95.2 us one frame at a time, 135 against 141 Gpixel/s with
+// four contexts).  So: the latency routes when no other context of this process has submitted a frame in the last millisecond
+// (fdh_set_blur_route / FDH_BLUR_FUSED = 1: always, 0: never).
+void Context::pick_routes() {
+  static const int fx_env = [] { const char* e = std::getenv("FDH_BLUR_FUSED"); return e ? (std::atoi(e) != 0 ? 1 : 0) : -1; }();
+  const int route = blur_route_ >= 0 ? blur_route_ : fx_env;
+  latency_routes_ = route != 0;
+  if (route < 0 && !host_only_) {
+    const int64_t now = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    for (int k = 0; k < kSubmitSlots; k++)
+      if (k != submit_slot_ && now - g_last_submit_ns[k].load(std::memory_order_relaxed) < 1000000) { latency_routes_ = false; break; }
+  }
+}
+
 // More pieces than the upload's run table holds (a frame with many parallel sibling groups): they are copied together into one
 // spare lane, in order, extension indices re-based -- the frame becomes one piece again.
 void Context::consolidate_pieces() {
@@ -1045,7 +1056,7 @@ void Context::launch_frame(const LaunchJob& J, bool profile) {
           if (!done) throw Error(FDH_ERR_HIP, "fused blur: no kernel for this filter width (blur_fused_supported out of step with the launcher)");
           cur = other;
         }
-        if (!done && j.fuse_draw < 0 && blur_one_kernel_ok(j.x1 - j.x0, j.y1 - j.y0, j.taps.reach)) {
+        if (!done && j.fuse_draw < 0 && J.latency_routes && blur_one_kernel_ok(j.x1 - j.x0, j.y1 - j.y0, j.taps.reach)) {
           // a small region: one kernel, source window -> LDS -> horizontal -> LDS -> vertical -> the backdrop surface
           bp.fuse_draw = -1;
           bp.src = cur; bp.dst = backdrop_;

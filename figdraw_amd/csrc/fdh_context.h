@@ -320,6 +320,7 @@ struct LaunchJob {
   int W = 0, H = 0;
   int rec_y0 = 0, rec_y1 = 0;  // rows the records were culled to (the frame, or a stripe + blur reach): a replay must stay inside
   bool clear = true;
+  bool latency_routes = true;  // the frame was recorded for the one-kernel blur routes (Context::pick_routes)
   uint32_t clear_rgba8 = 0xFFFFFFFFu;
   std::vector<Phase> phases;
   std::vector<BlurJob> blurs;
@@ -453,11 +454,13 @@ class Context : public Recorder {
   Lane& ensure_lane(int i);
   void splice_cached(const RetainedRoot& C);
   void consolidate_pieces();
+  void pick_routes();                       // begin_frame: the one-kernel blur routes (a frame alone) or the two-pass ones (frames in flight)
   void pool_slots(int slots);               // lanes 1 .. slots and their recorders, ready for a sibling group
 
   int device_ = 0;
   uint32_t flags_ = 0;
   int blur_route_ = -1;   // fdh_set_blur_route: -1 per-frame decision, 0 two passes, 1 fused
+  bool latency_routes_ = true;  // this frame takes the one-kernel blur routes (pick_routes)
   int submit_slot_ = 0;   // this context's entry in the process-wide table of last submissions (Context::prepare)
   std::shared_ptr<void> comm_;  // shared communicator object (fdh_comm.cpp), shared with the contexts that borrowed it: destroyed with its last holder
   int comm_rank_ = 0, comm_world_ = 1;

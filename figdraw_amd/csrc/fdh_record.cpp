@@ -1023,7 +1023,7 @@ void Recorder::draw_backdrop_blur(const float rect[4], const float rx[4], const 
   const BBox fb = lane_->bins[idx].box;
   BlurJob job;
   job.taps = make_taps(blur_radius);
-  const bool fuse = open_ops_.empty() && !blur_one_kernel_ok(fb.x1 - fb.x0, fb.y1 - fb.y0, job.taps.reach);
+  const bool fuse = open_ops_.empty() && !(C.latency_routes_ && blur_one_kernel_ok(fb.x1 - fb.x0, fb.y1 - fb.y0, job.taps.reach));
   job.fuse_draw = -1;
   if (fuse) {
     job.fuse_draw = (int)C.global_index(idx);
@@ -1167,6 +1167,7 @@ void Context::begin_frame(int w, int h, bool clear, const float rgba[4]) {  // g
   parallel_groups_ = 0;
   rec_diff_upload_ = false;
   open_piece();
+  pick_routes();
   // rows a draw has to reach: the frame's, or -- under fdh_set_stripe, when the front-end has told how far the scene's blur nodes
   // reach (render_frame: the per-call path cannot know what is still to come) -- the stripe's, widened by that reach
   cull_y0_ = 0; cull_y1_ = H_;
