@@ -371,16 +371,31 @@ def main():
             player.play_scenes(ctxs, cscenes, n, w, h, threads=threads)
         return run
 
+    # ... and who walks the trees: the calling thread with the library's walk pool beside it (fdh_set_walk_threads, the default) or
+    # the calling thread alone.  The bench frame is GPU-bound either way (host 25 - 30 us against 51 us per frame, GPU ~57): what
+    # differs is how the four contexts' kernels interleave -- a host that is only just faster than the GPU keeps the queues short
+    # and the frames staggered -- so the calibration tries both and says which it took (`walk_pool_threads`).
     calibration = None
+    pool_default = ctx.walk_stats()[0]
+    pool = pool_default
     if args.host_threads > 0:
         T = max(1, min(args.host_threads, F))
     else:
         calibration = {}
-        for cand in sorted({1, F}):
+        for cand, pool_n in [(1, pool_default), (F, pool_default), (1, 0)]:
+            key = f"{cand}" if pool_n == pool_default else f"{cand}, walk pool off"
+            if key in calibration:
+                continue
+            for c in ctxs:
+                c.set_walk_threads(pool_n)
             fn = make_run(cand)
             fn(args.warmup)
-            calibration[str(cand)] = round(1e3 * min(timed(fn, args.steps) for _ in range(2)), 4)  # (max over ranks inside timed)
-        T = int(min(calibration, key=lambda k: calibration[k]))
+            calibration[key] = round(1e3 * min(timed(fn, args.steps) for _ in range(2)), 4)  # (max over ranks inside timed)
+        best = min(calibration, key=lambda k: calibration[k])
+        T = int(best.split(",")[0])
+        pool = 0 if "off" in best else pool_default
+    for c in ctxs:
+        c.set_walk_threads(pool)
     run_dynamic = make_run(T)
     run_dynamic(args.warmup)
     elapsed, batch_ms = batches(run_dynamic, args.steps, args.repeats)
@@ -400,6 +415,8 @@ def main():
         in_flight_differing += int((got_in_flight != c.read_pixels()).any(axis=2).sum())
     in_flight_vs_oracle = None
     ms_step = 1e3 * elapsed / args.steps
+    for c in ctxs:
+        c.set_walk_threads(-1)  # (the legs below run with the library's default)
 
     # ---- the same frames through the PER-CALL seam: ~710 fdh_draw_* calls between fdh_begin_frame / fdh_end_frame per frame,
     # issued from C (what a Nim HipContext shim behind figrender.nim would do: figbackend.nim:468-634)
@@ -754,7 +771,7 @@ def main():
                                f"2-pass Gaussian backdrop blur(18) (BASELINE.json configs[2])",
                    "draws": st.n_draws, "phases": st.n_phases, "blur_nodes": st.n_blurs, "fragments": int(st.fragments),
                    "parallelism": f"frame-parallel x{world}" if world > 1 else "single GPU", "frames_in_flight_per_gpu": F, "host_threads_per_gpu": T,
-                   "walk_pool_threads": ctx.walk_stats()[0]},
+                   "walk_pool_threads": pool, "walk_pool_threads_default": pool_default},
         "frames_in_flight_check": {"contexts": F, "identical_to_each_frame_rendered_alone": in_flight_differing == 0,
                                    "pixels_differing": in_flight_differing, "in_flight_frame_vs_oracle": in_flight_vs_oracle},
         "host_threads_calibration": calibration,
