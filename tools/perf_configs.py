@@ -50,7 +50,9 @@ def run(key, what, ctx, sc, w, h, n=100, oracle_kw=None, images=None):
         from figdraw_amd import call_stream as CS
         P = CS.Player()
         P.play_scenes([ctx], [cs], 20, w, h)
-        e["dynamic_us_per_frame"] = round(P.play_scenes([ctx], [cs], 120, w, h) / 120 * 1e6, 1)
+        runs = sorted(round(P.play_scenes([ctx], [cs], 120, w, h) / 120 * 1e6, 1) for _ in range(7))  # 120 frames = a few ms: one late wake-up of a
+        e["dynamic_us_per_frame"] = runs[len(runs) // 2]  # pool thread doubles a single run; the median of seven is the figure, all seven are kept
+        e["dynamic_us_per_frame_runs"] = runs
         e["dynamic_fps"] = round(1e6 / e["dynamic_us_per_frame"], 0)
     if not only:  # parity leg (the oracle takes seconds per frame; skipped under rocprofv3)
         orc = O.Oracle(threads=min(os.cpu_count() or 1, 16), **(oracle_kw or {}))
