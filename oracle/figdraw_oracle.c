@@ -477,8 +477,37 @@ static void bilinear_rgba8_clamp(const uint8_t* tex, int W, int H, float x, floa
     out[k] = top * (1.0f - ay) + bot * ay;
   }
 }
+/* TEST-ONLY sampler model (fo_debug_texcoord_model).  The goldens tests/golden/ss_*.png come from SwiftShader, whose GLES sampler
+ * takes texture coordinates as 16-bit NORMALISED fixed point: on the 256^2 golden atlas a bilinear fraction has 8 bits.  Model 0
+ * (the default, and what every parity test compares the HIP path with) filters at float32 coordinates -- GL leaves filter
+ * precision to the implementation.  Model 1 truncates the coordinate to that grid first (coordinate -> 16 bits, half a texel
+ * subtracted in the same units, texel = high half of coordinate * size, fraction = low half) and filters in float as before:
+ * fitted to the goldens, it takes the MSDF scene's 2-LSB pixels from 13 to 1 (tests/test_oracle.py), which is the evidence that
+ * those differences are the sampler's grid and not the restatement's arithmetic. */
+static int g_tc_model = 0;
+void fo_debug_texcoord_model(int model) { g_tc_model = model; }
+static void bilinear_rgba8_repeat_grid16(const uint8_t* tex, int S, float u, float v, float out[4]) {
+  float c[2] = {u, v}, fr[2];
+  int i0[2], i1[2];
+  for (int k = 0; k < 2; k++) {
+    float w = c[k] - floorf(c[k]);
+    int q = ((int)(w * 65536.0f) - 0x8000 / S) & 0xFFFF;
+    unsigned prod = (unsigned)q * (unsigned)S;
+    i0[k] = (int)(prod >> 16) % S;
+    i1[k] = (i0[k] + 1) % S;
+    fr[k] = (float)(prod & 0xFFFFu) / 65536.0f;
+  }
+  const uint8_t *p00 = tex + ((size_t)i0[1] * S + i0[0]) * 4, *p10 = tex + ((size_t)i0[1] * S + i1[0]) * 4;
+  const uint8_t *p01 = tex + ((size_t)i1[1] * S + i0[0]) * 4, *p11 = tex + ((size_t)i1[1] * S + i1[0]) * 4;
+  for (int k = 0; k < 4; k++) {
+    float top = from_unorm8(p00[k]) * (1.0f - fr[0]) + from_unorm8(p10[k]) * fr[0];
+    float bot = from_unorm8(p01[k]) * (1.0f - fr[0]) + from_unorm8(p11[k]) * fr[0];
+    out[k] = top * (1.0f - fr[1]) + bot * fr[1];
+  }
+}
 /* GL_LINEAR, GL_REPEAT (atlas default wrap, glcontext.nim:157-169) */
 static void bilinear_rgba8_repeat(const uint8_t* tex, int S, float x, float y, float out[4]) {
+  if (g_tc_model > 0) { bilinear_rgba8_repeat_grid16(tex, S, (x + 0.5f) / (float)S, (y + 0.5f) / (float)S, out); return; }
   float fx = floorf(x), fy = floorf(y);
   float ax = x - fx, ay = y - fy;
   int x0 = ((int)fx % S + S) % S, y0 = ((int)fy % S + S) % S;

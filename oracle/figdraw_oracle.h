@@ -197,6 +197,7 @@ const char* fo_record_json(FoCtx*); /* valid until the next fo_record_begin / fo
 void fo_rounded_radii_vec(const float rx[4], const float ry[4], float hx, float hy, float out4[4], int* elliptical);
 void fo_gradient_colors(const FoFill* fill, FoColor out[4]);
 void fo_blur_image(int w, int h, const uint8_t* src, uint8_t* dst, float radius); /* H then V, RGBA8 between */
+void fo_debug_texcoord_model(int model); /* TEST-ONLY: 1 = atlas coordinates on SwiftShader's 16-bit normalised grid (process-wide) */
 int fo_sizeof_fig(void);
 int fo_sizeof_glyph(void);
 int fo_sizeof_draw_op(void);

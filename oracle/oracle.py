@@ -293,6 +293,14 @@ def blur_image(rgba: np.ndarray, radius: float) -> np.ndarray:
     return out
 
 
+def texcoord_model(model: int) -> None:
+    """TEST-ONLY, process-wide: 1 = sample the atlas on SwiftShader's 16-bit normalised coordinate grid (the goldens' sampler),
+    0 = float32 coordinates (the default; what the HIP path is compared with)."""
+    lib().fo_debug_texcoord_model.argtypes = [C.c_int]
+    lib().fo_debug_texcoord_model.restype = None
+    lib().fo_debug_texcoord_model(int(model))
+
+
 def minify_by2(rgba: np.ndarray) -> np.ndarray:
     """pixie Image.minifyBy2 (the mip step of textures.nim:106-119) on an (h, w, 4) uint8 premultiplied image"""
     rgba = np.ascontiguousarray(rgba, dtype=np.uint8)

@@ -232,6 +232,39 @@ def test_oracle_atlas_sampling_matches_reference_shaders(name):
     assert mx <= 2 and n1 <= 0.001 * w * h, (name, mx, n0, n1)
 
 
+def test_the_goldens_two_lsb_pixels_are_the_samplers_coordinate_grid():
+    """The MSDF scene's golden differs from the oracle by 2 LSB on 13 pixels.  SwiftShader's sampler takes texture coordinates as
+    16-bit normalised fixed point (8 fraction bits per texel on the 256^2 golden atlas); an MSDF edge has an alpha slope of
+    screenPxRange per texel, so a coordinate truncated by up to 1/256 texel moves it by up to ~2 LSB.  With the oracle's sampler put
+    on that grid (oracle.texcoord_model(1): coordinates truncated to 16 bits, same float filter) 12 of the 13 pixels agree within
+    1 LSB: the residue is the goldens' sampler, not the restatement.  (The parity bar -- HIP within 1 LSB of the float32 oracle,
+    within 2 LSB of the goldens -- needs no exception for this scene: tests/test_hip_parity.py.)"""
+    import os
+
+    from conftest import GOLDEN
+    from figdraw_amd.scenes import load_glyph_fixture
+
+    name = "images_and_msdf_variants"
+    fn, w, h = RS.ATLAS_SCENES[name]
+    all_images = load_glyph_fixture(os.path.join(GOLDEN, "glyphs_ubuntu20.npz"))
+    sc = fn(float(w), float(h), all_images)
+    gold = load_png(f"ss_{name}.png")
+    n_gt1 = {}
+    try:
+        for model in (0, 1):
+            O.texcoord_model(model)
+            o = O.Oracle(atlas_size=RS.ATLAS_GOLDEN_SIZE, threads=4)
+            for k, img in RS.used_images(sc, all_images).items():
+                o.put_image(k, img)
+            o.render_frame(sc, w, h)
+            mx, n0, n1 = diff_stats(o.read_pixels(), gold)
+            assert mx <= 2
+            n_gt1[model] = n1
+    finally:
+        O.texcoord_model(0)
+    assert n_gt1[0] >= 10 and n_gt1[1] <= 1, n_gt1
+
+
 def test_minify_by2_reproduces_the_flippy_levels():
     """pixie's Image.minifyBy2 (third-party, not in the reference tree) builds every atlas mip chain (textures.nim:106-119).  The
     reference's own data/img1.flippy pins its arithmetic: pngToFlippy (formatflippy.nim:101-112) stores level 0 (opaque, so
