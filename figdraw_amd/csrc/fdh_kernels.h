@@ -16,6 +16,7 @@ struct BinParams {
   const int* phase_first;  // [n_phases + 1]
   int n_phases, bins_x, bins_y, stride;
   const DrawRec* draws;    // the frame's records: the bin kernel pulls them into every XCD's L2 for the compositor (see k_bin_draws)
+  const QuadExt* exts;     // the edge functions of rotated quads (BR_GENERAL draws: strips outside the quad are dropped from the entry)
 };
 
 struct CompositeParams {

@@ -297,6 +297,30 @@ __device__ __forceinline__ void bin_entry(const BinParams& P, int i, int x0, int
   if (!(b.x0 < x0 + kBin && b.x1 > x0 && b.y0 < y0 + kBin && b.y1 > y0)) { hit = false; return; }  // exact test
   strips = strip_mask(b.x0 - x0, b.y0 - y0, b.x1 - x0, b.y1 - y0);
   word = (uint32_t)i | (r.flags & ~LE_INDEX);
+  if (r.flags & BR_GENERAL) {
+    // A rotated quad: a strip all of whose pixel centres fail ONE of the quad's outer edges (bottom, left, right, top: edges 0 and 2
+    // of triangle (TL, BL, BR), 1 and 2 of (TR, TL, BR)) holds no pixel of it.  The largest value an edge function takes on a
+    // strip is at the corner its coefficients' signs pick; 32-bit arithmetic is exact here (F_EDGE32).
+    const QuadExt& q = P.exts[P.draws[i].ext];
+    const QuadExt::Edge ed[4] = {q.e[0][0], q.e[0][2], q.e[1][1], q.e[1][2]};
+    uint32_t keep = 0;
+#pragma unroll 1
+    for (int s = 0; s < 16; s++) {
+      if (!(strips & (1u << s))) continue;
+      const int sx = x0 + ((s >> 2) & 1) * kTileW, sy = y0 + (s >> 3) * 32 + (s & 3) * kTileH;
+      const int Xlo = 2 * sx + 1, Xhi = 2 * (sx + kTileW - 1) + 1, Ylo = 2 * sy + 1, Yhi = 2 * (sy + kTileH - 1) + 1;
+      bool in = true;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int emax = ed[k].a * (ed[k].a > 0 ? Xhi : Xlo) + ed[k].b * (ed[k].b > 0 ? Yhi : Ylo) + (int)(uint32_t)(uint64_t)ed[k].c;
+        in = in && emax >= 0;
+      }
+      if (in) keep |= 1u << s;
+    }
+    strips = keep;
+    hit = strips != 0u;
+    return;
+  }
   if (!(r.flags & BR_HAS_CORE)) return;
   const uint32_t core = strip_mask_inside(r.ix0 - x0, r.iy0 - y0, r.ix1 - x0, r.iy1 - y0) & strips;
   if (r.flags & BR_CORE_REMOVED) {
@@ -665,15 +689,17 @@ __device__ __forceinline__ float sd_ellipse_nb(float px, float py, float rx, flo
   const float inner = -__builtin_fminf(sx, sy);  // (both arms are plain values: see the note on selects at shadow_profile)
   return k0 <= 0.000001f ? inner : d;
 }
-// distance of N pixels of one row at once (sdRoundedBox :51-69 / sdEllipticalRoundedBox :96-115)
-template <int N>
-__device__ __forceinline__ void shape_distN(bool ellip, const float* px, float py, float bx, float by, float r0, float r1, float r2,
-                                            float r3, float* out) {
+// distance of N pixels at once (sdRoundedBox :51-69 / sdEllipticalRoundedBox :96-115): of one row (kPerY = false: they share
+// their local y, *pyv) or each with a local y of its own (rotated quads: pyv[k])
+template <int N, bool kPerY>
+__device__ __forceinline__ void shape_distNy(bool ellip, const float* px, const float* pyv, float bx, float by, float r0, float r1, float r2,
+                                             float r3, float* out) {
   Corner c[N];
   float qx[N], qy[N];
   bool need = false, diag = false;
 #pragma unroll
   for (int k = 0; k < N; k++) {
+    const float py = pyv[kPerY ? k : 0];
     c[k] = pick_corner(ellip, px[k], py, bx, by, r0, r1, r2, r3);
     qx[k] = __builtin_fabsf(px[k]) - bx + c[k].rx;
     qy[k] = __builtin_fabsf(py) - by + c[k].ry;
@@ -706,6 +732,11 @@ __device__ __forceinline__ void shape_distN(bool ellip, const float* px, float p
     }
     out[k] = c[k].same ? out[k] : de;
   }
+}
+template <int N>
+__device__ __forceinline__ void shape_distN(bool ellip, const float* px, float py, float bx, float by, float r0, float r1, float r2,
+                                            float r3, float* out) {
+  shape_distNy<N, false>(ellip, px, &py, bx, by, r0, r1, r2, r3, out);
 }
 
 // evalFillColor atlas.frag:233-250, select-based.  Everything is passed BY VALUE: `c ? a.x : b.x` on lvalues is an
@@ -1339,6 +1370,177 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? 4 : kPaths == 4 ? FDH_UNIFORM_WA
           blend(F, sr, sg, sb, (xrel + (uint32_t)k) < wcov ? sa : 0.0f);
         };
         pixel(0, F0, mk0, rm0); pixel(1, F1, mk1, rm1); pixel(2, F2, mk2, rm2); pixel(3, F3, mk3, rm3);
+        return;
+      }
+      if (kSlow && (om & F_GENERAL) != 0u && (om & F_EDGE32) != 0u && !atlas_mode && mode < 18u && (op == OP_DRAW || (kMasks && op == OP_MASK_PUSH))) {
+        // ---- rotated / skewed SDF quads, 4 pixels per lane in lock-step (round 4; before: one pixel slot at a time through
+        // shade_one(), 15x the time of the same tree unrotated).  The quad is the reference's two triangles (3,0,1) / (2,3,1) over
+        // per-vertex ceil'd corners (glcontext.nim:418-429); a pixel belongs to the first whose three edge functions -- exact
+        // integers in half-pixel units, top-left rule -- admit its centre, and its uv / vertex colour are that triangle's
+        // barycentric interpolation, as in make_frag().  F_EDGE32 (Recorder::emit_corners): every edge value any pixel of the frame
+        // can produce fits 32 bits and the coefficients fit 24, so the strip's scalar base + two v_mad_i32_i24 per edge replace the
+        // 64-bit arithmetic; quads beyond that keep the slot path.  Ownership is folded into the base (E - 1 >= 0 <=> E > 0).
+        FDH_COUNT(1);
+        const QuadExt& q = exts[r.ext];
+        const int X0 = 2 * tx0 + 1, Y0 = 2 * ty0 + 1;
+        const int dxl = 8 * (lane & 7), dyl = 2 * (lane >> 3);
+        int eb[2][3], a2[2][3], nb[2][3];
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+#pragma unroll
+          for (int k = 0; k < 3; k++) {
+            const int a = q.e[t][k].a, b = q.e[t][k].b;
+            nb[t][k] = (int)(((q.own >> (t * 3 + k)) & 1u) ^ 1u);
+            const int base = a * X0 + b * Y0 + (int)(uint32_t)(uint64_t)q.e[t][k].c - nb[t][k];  // (scalar)
+            eb[t][k] = __mul24(b, dyl) + (__mul24(a, dxl) + base);
+            a2[t][k] = 2 * a;
+          }
+        const bool valid0 = q.inv_sum[0] != 0.0f, valid1 = q.inv_sum[1] != 0.0f;
+        const bool solid = (om & F_SOLID) != 0u;
+        const bool rowc = py >= r.by0 && py < r.by1;
+        const F4 cBL = unpack255(r.col[0]), cBR = unpack255(r.col[1]), cTR = unpack255(r.col[2]), cTL = unpack255(r.col[3]);
+        const float qhx = r.p0, qhy = r.p1;
+        float u[4], v[4], lx[4], nly[4];
+        bool cov[4];
+        F4 col[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const int e00 = eb[0][0] + k * a2[0][0], e01 = eb[0][1] + k * a2[0][1], e02 = eb[0][2] + k * a2[0][2];
+          const int e10 = eb[1][0] + k * a2[1][0], e11 = eb[1][1] + k * a2[1][1], e12 = eb[1][2] + k * a2[1][2];
+          const bool in0 = valid0 && ((e00 | e01 | e02) >= 0), in1 = valid1 && ((e10 | e11 | e12) >= 0);
+          const bool use1 = !in0 && in1;
+          cov[k] = rowc && px0 + k >= r.bx0 && px0 + k < r.bx1 && (in0 || in1);
+          const float is = use1 ? q.inv_sum[1] : q.inv_sum[0];
+          // tri 0 = (TL, BL, BR): u = l2, v = l1 + l2;  tri 1 = (TR, TL, BR): u = l0 + l2, v = l2   (uv corners are 0 / 1: the
+          // products of make_frag()'s sums are exact)
+          const float la = (float)((use1 ? e10 : e01) + (use1 ? nb[1][0] : nb[0][1])) * is;
+          const float lb = (float)((use1 ? e12 : e02) + (use1 ? nb[1][2] : nb[0][2])) * is;
+          const float sum = la + lb;
+          u[k] = use1 ? sum : lb;
+          v[k] = use1 ? lb : sum;
+          if (solid) {
+            col[k] = {cBL.x * inv255, cBL.y * inv255, cBL.z * inv255, cBL.w * inv255};
+          } else {
+            const float lc = (float)((use1 ? e11 : e00) + (use1 ? nb[1][1] : nb[0][0])) * is;
+            const float l0 = use1 ? la : lc, l1 = use1 ? lc : la;
+            const float c0x = use1 ? cTR.x : cTL.x, c0y = use1 ? cTR.y : cTL.y, c0z = use1 ? cTR.z : cTL.z, c0w = use1 ? cTR.w : cTL.w;
+            const float c1x = use1 ? cTL.x : cBL.x, c1y = use1 ? cTL.y : cBL.y, c1z = use1 ? cTL.z : cBL.z, c1w = use1 ? cTL.w : cBL.w;
+            col[k].x = (l0 * c0x + l1 * c1x + lb * cBR.x) * inv255;
+            col[k].y = (l0 * c0y + l1 * c1y + lb * cBR.y) * inv255;
+            col[k].z = (l0 * c0z + l1 * c1z + lb * cBR.z) * inv255;
+            col[k].w = (l0 * c0w + l1 * c1w + lb * cBR.w) * inv255;
+          }
+          lx[k] = (u[k] - 0.5f) * 2.0f * qhx;
+          nly[k] = -((v[k] - 0.5f) * 2.0f * qhy);
+        }
+        const bool ellip = (om & F_ELLIP) != 0u;
+        const uint32_t fill_mode = (om >> 9) & 7u;
+        const bool inset = mode == 9u && op == OP_DRAW;
+        const float shx = inset ? qhx : r.p2, shy = inset ? qhy : r.p3;
+        const float spread = fill_mode == 0u ? r.f1 : 0.0f;
+        float dist[4];
+        shape_distNy<4, true>(ellip, lx, nly, shx, shy, r.r[0], r.r[1], r.r[2], r.r[3], dist);
+        if (kMasks && op == OP_MASK_PUSH) {  // mask.frag:186-234, as on the axis-aligned path below
+          float mk[4] = {mk0, mk1, mk2, mk3};
+          uint32_t packed = 0;
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            float a = (1.0f - clamp01(r.aa * dist[k] + 0.5f)) * col[k].w * mk[k];
+            a = cov[k] ? a : 0.0f;
+            const float qq = __builtin_rintf(a * a * 255.0f);
+            packed |= (uint32_t)qq << (8 * k);
+            mk[k] = qq * inv255;
+          }
+          mk0 = mk[0]; mk1 = mk[1]; mk2 = mk[2]; mk3 = mk[3];
+          stack_put(mask_depth, packed);
+          mask_depth++;
+          return;
+        }
+        float alpha[4];
+        switch (mode) {  // wave-uniform; atlas.frag:337-393, operation for operation what shade_one() does per pixel
+          case 11u: {
+            const float h = r.f0 * 0.5f;
+#pragma unroll
+            for (int k = 0; k < 4; k++) alpha[k] = (__builtin_fabsf(dist[k] + h) - h) < 0.0f ? 1.0f : 0.0f;
+            break;
+          }
+          case 12u: {
+            const float h = r.f0 * 0.5f;
+#pragma unroll
+            for (int k = 0; k < 4; k++) alpha[k] = 1.0f - clamp01(r.aa * (__builtin_fabsf(dist[k] + h) - h) + 0.5f);
+            break;
+          }
+          case 7u: {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+              const float sd = dist[k] - spread;
+              const float sp = __builtin_fminf(shadow_profile(sd, r.f0), 1.0f);
+              alpha[k] = sd > 0.0f ? sp : 1.0f;
+            }
+            break;
+          }
+          case 8u: {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+              const float inside = 1.0f - clamp01(r.aa * dist[k] + 0.5f);
+              const float sd = dist[k] - spread;
+              const float sp = __builtin_fminf(shadow_profile(sd, r.f0), 1.0f);
+              alpha[k] = sd >= 0.0f ? sp : inside;
+            }
+            break;
+          }
+          case 9u: {
+            float sx[4], sy[4], shd[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) { sx[k] = lx[k] - r.p2; sy[k] = nly[k] + r.p3; }
+            shape_distNy<4, true>(ellip, sx, sy, qhx, qhy, r.r[0], r.r[1], r.r[2], r.r[3], shd);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+              const float clip_a = 1.0f - clamp01(r.aa * dist[k] + 0.5f);
+              const float sd = shd[k] + spread;
+              const float sp = __builtin_fminf(shadow_profile(sd, r.f0), 1.0f);
+              const float ia = sd < 0.0f ? sp : 1.0f;
+              alpha[k] = clip_a * ia;
+            }
+            break;
+          }
+          default: {
+#pragma unroll
+            for (int k = 0; k < 4; k++) alpha[k] = 1.0f - clamp01(r.aa * dist[k] + 0.5f);
+            break;
+          }
+        }
+        float sr[4], sg[4], sb[4], sa[4];
+        if (mode == 17u) {  // atlas.frag:381-388: the blurred backdrop at this fragment's own pixel (clamped addresses, no branch)
+          F4 b[4] = {F0, F1, F2, F3};
+          if (!(om & F_SELF_BACKDROP)) {
+            const size_t rowp = (size_t)min(py, P.H - 1) * P.pitch;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+              const F4 t = unpack255(P.backdrop[rowp + min(px0 + k, P.W - 1)]);
+              const bool in = row_ok && px0 + k < P.W;
+              b[k].x = in ? t.x : b[k].x; b[k].y = in ? t.y : b[k].y; b[k].z = in ? t.z : b[k].z; b[k].w = in ? t.w : b[k].w;
+            }
+          }
+#pragma unroll
+          for (int k = 0; k < 4; k++) { sr[k] = b[k].x * inv255; sg[k] = b[k].y * inv255; sb[k] = b[k].z * inv255; sa[k] = b[k].w * inv255 * alpha[k]; }
+        } else if (fill_mode == 0u) {
+#pragma unroll
+          for (int k = 0; k < 4; k++) { sr[k] = col[k].x; sg[k] = col[k].y; sb[k] = col[k].z; sa[k] = col[k].w * alpha[k]; }
+        } else {
+          const F4 mc = unpack255(r.mid), sc = unpack255(r.stop);
+          const F4 m01 = {mc.x * inv255, mc.y * inv255, mc.z * inv255, mc.w * inv255}, s01 = {sc.x * inv255, sc.y * inv255, sc.z * inv255, sc.w * inv255};
+          const float mid = __builtin_fminf(__builtin_fmaxf(r.f1, 0.01f), 0.99f);
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            const F4 fc = eval_fill_nb(col[k], m01, s01, fill_mode, mid, u[k], v[k]);
+            sr[k] = fc.x; sg[k] = fc.y; sb[k] = fc.z; sa[k] = fc.w * alpha[k];
+          }
+        }
+        blend(F0, sr[0], sg[0], sb[0], cov[0] ? sa[0] * mk0 * rm0 : 0.0f);
+        blend(F1, sr[1], sg[1], sb[1], cov[1] ? sa[1] * mk1 * rm1 : 0.0f);
+        blend(F2, sr[2], sg[2], sb[2], cov[2] ? sa[2] * mk2 * rm2 : 0.0f);
+        blend(F3, sr[3], sg[3], sb[3], cov[3] ? sa[3] * mk3 * rm3 : 0.0f);
         return;
       }
       if (!kSlow && !fast) return;  // unreachable: the host picks kSlow = true for any phase holding such a draw

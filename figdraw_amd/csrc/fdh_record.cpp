@@ -162,6 +162,7 @@ static uint32_t binrec_flags(const DrawRec& r) {
   const bool sdf = !(om & F_GENERAL) && !atlas_mode && mode < 18u && (op == OP_DRAW || op == OP_MASK_PUSH);
   const uint32_t ell = (om & F_ELLIP) ? 4u : 0u;
   uint32_t flags = 0;
+  if ((om & F_GENERAL) && (om & F_EDGE32) && !atlas_mode && mode < 18u && op == OP_DRAW) return BR_GENERAL;
   if (!sdf) return 0u;
   flags |= BR_HAS_CORE;
   if (op == OP_DRAW && (mode == 9u || mode == 11u || mode == 12u)) {
@@ -490,6 +491,9 @@ bool Recorder::emit_corners(DrawRec& r, const QuadPx& q, bool count_fragments) {
     const bool atlas_mode = mode == 0u || (mode >= 13u && mode <= 16u);
     const float uax = atlas_mode ? r.r[0] : 0.0f, uay = atlas_mode ? r.r[1] : 0.0f, utx = atlas_mode ? r.r[2] : 1.0f, uty = atlas_mode ? r.r[3] : 1.0f;
     const float vu[4] = {uax, utx, utx, uax}, vv[4] = {uty, uty, uay, uay};
+    // F_EDGE32 (fdh_types.h): may the compositor evaluate the edge functions in 32-bit arithmetic at every pixel of the frame's strips?
+    bool edge32 = true;
+    const long long xm = 2LL * cx_->W_ + 129, ym = 2LL * cx_->H_ + 129;  // (every pixel of every 64 x 64 bin that overlaps the frame)
     for (int t = 0; t < 2; t++) {
       long long X[3], Y[3];
       for (int k = 0; k < 3; k++) { X[k] = 2 * (long long)px[TRI[t][k]]; Y[k] = 2 * (long long)py[TRI[t][k]]; }
@@ -501,6 +505,10 @@ bool Recorder::emit_corners(DrawRec& r, const QuadPx& q, bool count_fragments) {
         long long A = -(Y[i1] - Y[i0]) * sgn, B = (X[i1] - X[i0]) * sgn;
         long long C = -(B * Y[i0]) - (A * X[i0]);
         q.e[t][k].a = (int32_t)A; q.e[t][k].b = (int32_t)B; q.e[t][k].c = C;
+        {
+          const long long aa = A < 0 ? -A : A, ab = B < 0 ? -B : B, ac = C < 0 ? -(C + 1) : C;
+          edge32 = edge32 && aa < (1LL << 23) && ab < (1LL << 23) && ac < (1LL << 30) && aa * xm + ab * ym + ac + 2 < (1LL << 31);
+        }
         // top-left rule in image orientation (y down): owns iff top edge (horizontal, interior below) or left edge
         bool own;
         if (Y[i0] == Y[i1]) own = Y[k] > Y[i0];
@@ -531,6 +539,7 @@ bool Recorder::emit_corners(DrawRec& r, const QuadPx& q, bool count_fragments) {
       }
     }
     r.op_mode |= F_GENERAL;
+    if (edge32) r.op_mode |= F_EDGE32;
     r.ext = (uint32_t)lane_->exts.n;  // lane-relative: the upload re-bases it (k_upload_frame)
     lane_->exts.n++;
   }

@@ -41,6 +41,10 @@ constexpr uint32_t F_SUBPIXEL = 1u << 19;
 // bilinear fractions are 0 up to float noise (GL's fixed-point sampler snaps them to 0): the compositor fetches a lane's four
 // texels as one 16-byte run instead of sixteen gathers.
 constexpr uint32_t F_TEXEL_1TO1 = 1u << 20;
+// bit 21 (with F_GENERAL): the quad's edge functions fit 32-bit arithmetic at every pixel a strip of the frame can hold -- |a|, |b| <
+// 2^23 and |a| (2 W + 129) + |b| (2 H + 129) + |c| < 2^31 -- so the compositor's 4-wide path for rotated SDF quads may evaluate them
+// with a scalar base per strip and v_mad_i32_i24 per lane
+constexpr uint32_t F_EDGE32 = 1u << 21;
 
 // One BackendContext draw call, 128 bytes, read with wave-uniform (scalar) loads.
 struct alignas(16) DrawRec {
@@ -94,6 +98,9 @@ struct alignas(8) BBox { int16_t x0, y0, x1, y1; };
 struct alignas(8) BinRec { BBox box; int16_t ix0, iy0, ix1, iy1; uint32_t flags; uint32_t pad; };
 static_assert(sizeof(BinRec) == 24, "BinRec must be 24 bytes");
 constexpr uint32_t BR_HAS_CORE = 1u, BR_CORE_REMOVED = 2u;
+// bit 2: a rotated / skewed SDF draw (F_GENERAL | F_EDGE32, OP_DRAW): its pixel bounds are the quad's bounding box; k_bin_draws drops the
+// strips that lie outside one of the quad's four outer edges (half of the box of a quad rotated by 30 degrees)
+constexpr uint32_t BR_GENERAL = 4u;
 constexpr uint32_t LE_PLAIN = 1u << 31;  // axis-aligned SDF draw with ONE colour: on its core strips it is a uniform blend
 constexpr uint32_t LE_OPAQUE = 1u << 30;  // a fill whose source alpha is 255 everywhere: on its core strips it REPLACES the surface
 // bits 26..29: which straight-line shading path the draw's EDGE strips can take, decided on the host so that the

@@ -171,6 +171,54 @@ def make_render_tree_100(w: float, h: float, frame: int = 0, copies: int = 100, 
     return out
 
 
+def make_rotated_tree(w: float, h: float, frame: int = 0, copies: int = 100) -> Renders:
+    """The renderlist_100 tree with every rectangle rotated about its centre (Fig.rotation, figrender.nim:1768-1777): each draw
+    becomes a rotated quad -- per-vertex ceil, two-triangle rasterisation, the compositor's one-pixel-slot build.  A workload
+    of its own for tools/perf_configs.py (config 9); no backdrop blur (the blur kernels do not care about rotation)."""
+    out = make_render_tree_100(w, h, frame, copies=copies)
+    lst = out.layers[0]
+    keep = []
+    for i, n in enumerate(lst.nodes):
+        if n.kind == FigKind.nkBackdropBlur:
+            continue
+        if i > 0:
+            n.rotation = float(((i * 37) % 61) - 30)
+        keep.append(n)
+    lst.nodes = keep
+    lst.rootIds = list(range(len(keep)))
+    return out
+
+
+def make_curves_scene(w: float, h: float, n: int = 1500, seed: int = 7) -> Renders:
+    """n stroked curves and lines (nkDrawable: quadratic beziers -> drawQuadraticBezierSdf, modes 18 - 20; lines -> rotated boxes;
+    arcs with joins -> filled quads) scattered over the frame: config 10 of tools/perf_configs.py."""
+    from .scene import StrokeCap, StrokeJoin, drawableArc, drawableBezier, drawableLine
+
+    rng = PCG32(seed)
+    lst = RenderList()
+    lst.addRoot(Fig(kind=FigKind.nkRectangle, screenBox=rect(0, 0, w, h), fill=rgba(250, 250, 246, 255)))
+    for i in range(n):
+        x, y = float(rng.uniform(f32(w - 260))), float(rng.uniform(f32(h - 200)))
+        col = fill(rgba(int(rng.next_u32() & 255), int(rng.next_u32() & 255), int(rng.next_u32() & 255), 200 + (i % 56)))
+        weight = 2.0 + float(i % 7)
+        kind = i % 4
+        if kind == 0:
+            ops = [drawableBezier([(5, 10), (120 + (i % 40), 170), (235, 20 + (i % 90))])]
+        elif kind == 1:
+            ops = [drawableBezier([(10, 150), (60, -40), (170, 220), (240, 60)])]  # a cubic: adaptive quadratic spans
+        elif kind == 2:
+            ops = [drawableLine((8, 12 + (i % 60)), (230, 150 - (i % 80)))]
+        else:
+            ops = [drawableArc((120, 90), 70.0, 0.2 * (i % 9), 3.2, steps=6)]
+        lst.addRoot(Fig(kind=FigKind.nkDrawable, screenBox=rect(x, y, 250, 190),
+                        drawStroke=RenderStroke(weight=weight, fill=col, cap=[StrokeCap.scButt, StrokeCap.scRound, StrokeCap.scSquare][i % 3],
+                                                join=[StrokeJoin.sjBevel, StrokeJoin.sjMiter, StrokeJoin.sjRound][(i // 3) % 3]),
+                        drawOps=ops))
+    out = Renders()
+    out.setLayer(0, lst)
+    return out
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 def load_glyph_fixture(path):
     """tests/golden/glyphs_ubuntu20.npz -> {image_id: (h, w, 4) uint8}.  Ids: 1000+code = coverage glyph (20 px

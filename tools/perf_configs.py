@@ -7,7 +7,7 @@ Configs 6 - 8 are the reference's OWN benchmark workloads (the only scenes it ti
 (180 x 10 cells, 1200 x 800) and examples/windy_clip_mask_benchmark.nim (clip + sub-clip / clip + rect-mask, 180 x 6 cells); for
 those the dynamic path (fdh_render_frame per frame, what the reference's loop times) is reported beside the replay figure.
 
-usage: python3 tools/perf_configs.py [only]     only = 1..8 : run just that config (for a rocprofv3 --kernel-trace --stats pass per config)"""
+usage: python3 tools/perf_configs.py [only]     only = 1..10 : run just that config (for a rocprofv3 --kernel-trace --stats pass per config)"""
 import json
 import os
 import sys
@@ -20,7 +20,8 @@ import numpy as np
 
 import ref_scenes as RS
 from figdraw_amd.context import HipContext
-from figdraw_amd.scenes import load_glyph_fixture, make_clip_mask_benchmark, make_glyph_scene, make_non_clip_benchmark, make_render_tree_100
+from figdraw_amd.scenes import (load_glyph_fixture, make_clip_mask_benchmark, make_curves_scene, make_glyph_scene, make_non_clip_benchmark, make_render_tree_100,
+                                make_rotated_tree)
 from oracle import oracle as O
 
 only = int(sys.argv[1]) if len(sys.argv) > 1 else 0
@@ -97,5 +98,14 @@ if only in (0, 6, 7, 8):
     if only in (0, 8):
         run("config8", "examples/windy_clip_mask_benchmark.nim, clip + rect-mask: the same table with NfRectMaskContent cells, 1200x800",
             ctx, make_clip_mask_benchmark("rect_mask"), 1200, 800)
+    ctx.close()
+if only in (0, 9, 10):  # the compositor's one-pixel-slot build (<3>): rotated quads, bezier strokes -- SURVEY.md 8(a) a5 / f1
+    ctx = HipContext(device=0)
+    if only in (0, 9):
+        run("config9", "R300@4K: the renderlist_100 tree with every rectangle rotated (-30 .. 30 degrees), 3840x2160, no blur: every draw a rotated quad",
+            ctx, make_rotated_tree(3840, 2160, 0), 3840, 2160)
+    if only in (0, 10):
+        run("config10", "C1500@4K: 1500 stroked nkDrawable curves / lines / arcs (quadratic-bezier SDF spans, rotated boxes, join quads), 3840x2160",
+            ctx, make_curves_scene(3840, 2160), 3840, 2160)
     ctx.close()
 print(json.dumps(out, indent=1))
