@@ -1102,6 +1102,7 @@ void Context::launch_frame(const LaunchJob& J, bool profile) {
     C.order = full ? order_now : nullptr;
     C.order_next = full ? order_next : nullptr;
     C.has_slow = ph.has_slow ? 1 : 0;
+    C.has_rot = ph.has_rot ? 1 : 0;
     C.has_atlas = ph.has_atlas ? 1 : 0;
     C.has_masks = ph.has_masks ? 1 : 0;
     C.mask_spill = J.mask_spill; C.spill_stride = J.spill_stride;

@@ -301,24 +301,55 @@ __device__ __forceinline__ void bin_entry(const BinParams& P, int i, int x0, int
     // A rotated quad: a strip all of whose pixel centres fail ONE of the quad's outer edges (bottom, left, right, top: edges 0 and 2
     // of triangle (TL, BL, BR), 1 and 2 of (TR, TL, BR)) holds no pixel of it.  The largest value an edge function takes on a
     // strip is at the corner its coefficients' signs pick; 32-bit arithmetic is exact here (F_EDGE32).
-    const QuadExt& q = P.exts[P.draws[i].ext];
-    const QuadExt::Edge ed[4] = {q.e[0][0], q.e[0][2], q.e[1][1], q.e[1][2]};
-    uint32_t keep = 0;
-#pragma unroll 1
+    // (everything the strip loops need is fetched up front, as 16-byte pieces: left to the compiler the loads stayed inside the
+    // loops -- conditional code does not get its loads hoisted -- and sixteen dependent round trips made the bin kernel 4x longer)
+    const uint4* __restrict__ q4 = reinterpret_cast<const uint4*>(P.exts + P.draws[i].ext);
+    const uint4 w0 = q4[0], w1 = q4[2], w2 = q4[4], w3 = q4[5], wc = q4[9], wl0 = q4[10], wl1 = q4[11], wl2 = q4[12];  // e[0][0], e[0][2], e[1][1], e[1][2], core, lm
+    const int ea[4] = {(int)w0.x, (int)w1.x, (int)w2.x, (int)w3.x}, eb[4] = {(int)w0.y, (int)w1.y, (int)w2.y, (int)w3.y}, ec[4] = {(int)w0.z, (int)w1.z, (int)w2.z, (int)w3.z};
+    // the value an edge function takes at the strip's corner (sx, sy) = the bin's corner + 64 a per strip column + 16 b per strip row;
+    // its largest / smallest value on the strip is that plus the spans its coefficients' signs pick (62 |a|, 14 |b|)
+    int e00[4], hi[4], lo[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      e00[k] = ea[k] * (2 * x0 + 1) + eb[k] * (2 * y0 + 1) + ec[k];
+      hi[k] = (ea[k] > 0 ? 62 * ea[k] : 0) + (eb[k] > 0 ? 14 * eb[k] : 0);
+      lo[k] = (ea[k] < 0 ? 62 * ea[k] : 0) + (eb[k] < 0 ? 14 * eb[k] : 0);
+    }
+    const float cxl = __uint_as_float(wc.x), cxr = __uint_as_float(wc.y), cyb = __uint_as_float(wc.z), cyt = __uint_as_float(wc.w);
+    const float lm[12] = {__uint_as_float(wl0.x), __uint_as_float(wl0.y), __uint_as_float(wl0.z), __uint_as_float(wl0.w), __uint_as_float(wl1.x), __uint_as_float(wl1.y),
+                          __uint_as_float(wl1.z), __uint_as_float(wl1.w), __uint_as_float(wl2.x), __uint_as_float(wl2.y), __uint_as_float(wl2.z), __uint_as_float(wl2.w)};
+    const bool has_core = cxr > cxl;
+    uint32_t keep = 0, core = 0;
+#pragma unroll
     for (int s = 0; s < 16; s++) {
-      if (!(strips & (1u << s))) continue;
-      const int sx = x0 + ((s >> 2) & 1) * kTileW, sy = y0 + (s >> 3) * 32 + (s & 3) * kTileH;
-      const int Xlo = 2 * sx + 1, Xhi = 2 * (sx + kTileW - 1) + 1, Ylo = 2 * sy + 1, Yhi = 2 * (sy + kTileH - 1) + 1;
-      bool in = true;
+      const int col = (s >> 2) & 1, row = (s >> 3) * 4 + (s & 3);
+      bool out = false, in = has_core;
 #pragma unroll
       for (int k = 0; k < 4; k++) {
-        const int emax = ed[k].a * (ed[k].a > 0 ? Xhi : Xlo) + ed[k].b * (ed[k].b > 0 ? Yhi : Ylo) + (int)(uint32_t)(uint64_t)ed[k].c;
-        in = in && emax >= 0;
+        const int e = e00[k] + 64 * col * ea[k] + 16 * row * eb[k];
+        out = out || e + hi[k] < 0;
+        in = in && e + lo[k] > 0;
       }
-      if (in) keep |= 1u << s;
+      if (!out) keep |= 1u << s;
+      // inside the quad: do the strip's corner pixels map into the local-frame core rectangle under both triangles' maps? (QuadExt::core)
+      const float Xlo = (float)(2 * (x0 + col * kTileW) + 1), Ylo = (float)(2 * (y0 + row * kTileH) + 1);
+#pragma unroll
+      for (int t = 0; t < 2; t++) {
+        const float* m = lm + 6 * t;
+        const float lx0 = m[0] * Xlo + m[1] * Ylo + m[2], ly0 = m[3] * Xlo + m[4] * Ylo + m[5];
+        const float dxx = 62.0f * m[0], dxy = 14.0f * m[1], dyx = 62.0f * m[3], dyy = 14.0f * m[4];
+        const float lxmin = lx0 + __builtin_fminf(dxx, 0.0f) + __builtin_fminf(dxy, 0.0f), lxmax = lx0 + __builtin_fmaxf(dxx, 0.0f) + __builtin_fmaxf(dxy, 0.0f);
+        const float lymin = ly0 + __builtin_fminf(dyx, 0.0f) + __builtin_fminf(dyy, 0.0f), lymax = ly0 + __builtin_fmaxf(dyx, 0.0f) + __builtin_fmaxf(dyy, 0.0f);
+        in = in && lxmin >= cxl && lxmax <= cxr && lymin >= cyb && lymax <= cyt;
+      }
+      if (in) core |= 1u << s;
     }
+    keep &= strips;
+    core &= keep;
     strips = keep;
-    hit = strips != 0u;
+    if (r.flags & BR_CORE_REMOVED) strips &= ~core;
+    else strips |= core << 16;
+    hit = (strips & 0xffffu) != 0u;
     return;
   }
   if (!(r.flags & BR_HAS_CORE)) return;
@@ -897,19 +928,24 @@ __device__ unsigned int g_edge_bad[4096 * 8];
 #ifndef FDH_ATLAS_WAVES
 #define FDH_ATLAS_WAVES 5  // waves per SIMD of the atlas build <2>
 #endif
+#ifndef FDH_ROT_WAVES
+#define FDH_ROT_WAVES 4  // waves per SIMD of the rotated-quad build <8>
+#endif
 #ifndef FDH_UNIFORM_WAVES
 #define FDH_UNIFORM_WAVES 6  // waves per SIMD of the no-clip build <4>: 80 VGPRs, no spills
 #endif
 // the strip's texel window in LDS (builds with the atlas path): up to kWinCols x kWinRows texels, rows kWinStride dwords apart
 // (a multiple of four, for the 16-byte stores, that is not a multiple of 32: rows start in different banks)
 constexpr int kWinCols = 64, kWinRows = 12, kWinStride = 68;
-// kPaths: bit 0 = the one-pixel-slot path (rotated / skewed quads, bezier strokes, rect-mask setup, minified images),
+// kPaths: bit 3 = the 4-wide path for rotated / skewed SDF quads (F_EDGE32) on top of the axis-aligned SDF paths, with clip masks:
+// build <8>, for phases whose only draws off the fast paths are such quads (a rotated panel does not drag the slot path in);
+// bit 0 = the one-pixel-slot path (rotated / skewed quads, bezier strokes, rect-mask setup, minified images),
 // bit 1 = the 4-wide atlas path (axis-aligned glyphs, images at >= 1:1, MSDF).  0: SDF draws, clips and rect masks only.
 // kFull: the launch that starts a frame -- every bin of the grid, from the clear colour (nothing is loaded), bins taken longest
 // list first, with the sort for the next frame riding along.  A symbol of its own, so that the dominant launch of a frame is a
 // row of its own in a rocprofv3 kernel summary (the later phases' launches cover a blur node's footprint and take microseconds).
 template <int kPaths, bool kFull>
-__global__ __launch_bounds__(64, (kPaths & 1) ? 4 : kPaths == 4 ? FDH_UNIFORM_WAVES : (kPaths & 2) ? FDH_ATLAS_WAVES : FDH_FAST_WAVES) void k_composite_tiles(
+__global__ __launch_bounds__(64, (kPaths & 1) ? 4 : kPaths == 4 ? FDH_UNIFORM_WAVES : (kPaths & 2) ? FDH_ATLAS_WAVES : (kPaths & 8) ? FDH_ROT_WAVES : FDH_FAST_WAVES) void k_composite_tiles(
     // the sixteen dwords a wave needs before anything else, as leading scalar arguments: with kernel-argument preloading
     // (-amdgpu-kernarg-preload-count, csrc/Makefile) they arrive in SGPRs with the wave instead of through a first s_load
     const int* __restrict__ a_order, int* __restrict__ a_order_next, const uint32_t* __restrict__ a_counts, const uint2* __restrict__ a_lists,
@@ -1182,11 +1218,11 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? 4 : kPaths == 4 ? FDH_UNIFORM_WA
       const bool atlas_mode = (mode == 0u) || (mode >= 13u && mode <= 16u);
       // (builds without the slot path and the atlas path only ever see `fast` draws: the host picks the build per phase from
       // exactly these properties, Context::submit -- no need to decode them again per draw)
-      const bool fast = (kPaths & 3) == 0 || (!(om & F_GENERAL) && !atlas_mode && mode < 18u && (op == OP_DRAW || (kMasks && op == OP_MASK_PUSH)));
+      const bool fast = (kPaths & 11) == 0 || (!(om & F_GENERAL) && !atlas_mode && mode < 18u && (op == OP_DRAW || (kMasks && op == OP_MASK_PUSH)));
       // ---- axis-aligned atlas quads (glyphs, images at >= 1:1, MSDF / MTSDF): 4 pixels per lane in lock-step.  All
       // sixteen bilinear texel fetches of the lane are issued before any of them is used, so the wave pays the atlas
       // latency once per draw instead of once per pixel slot.  (Minified images, lod > 0, keep the trilinear slot path.)
-      constexpr bool kSlow = (kPaths & 1) != 0, kAtlas = (kPaths & 2) != 0;
+      constexpr bool kSlow = (kPaths & 1) != 0, kAtlas = (kPaths & 2) != 0, kRot = (kPaths & 9) != 0;
       if (kAtlas && atlas_mode && !(om & F_GENERAL) && op == OP_DRAW && !(mode == 0u && r.aux2 > 0.0f && P.atlas.n_levels >= 2)) {
         const uint32_t fill_mode = (om >> 9) & 7u;
         const int S = P.atlas.size, msk = S - 1;
@@ -1372,7 +1408,7 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? 4 : kPaths == 4 ? FDH_UNIFORM_WA
         pixel(0, F0, mk0, rm0); pixel(1, F1, mk1, rm1); pixel(2, F2, mk2, rm2); pixel(3, F3, mk3, rm3);
         return;
       }
-      if (kSlow && (om & F_GENERAL) != 0u && (om & F_EDGE32) != 0u && !atlas_mode && mode < 18u && (op == OP_DRAW || (kMasks && op == OP_MASK_PUSH))) {
+      if (kRot && (om & F_GENERAL) != 0u && (om & F_EDGE32) != 0u && !atlas_mode && mode < 18u && (op == OP_DRAW || (kMasks && op == OP_MASK_PUSH))) {
         // ---- rotated / skewed SDF quads, 4 pixels per lane in lock-step (round 4; before: one pixel slot at a time through
         // shade_one(), 15x the time of the same tree unrotated).  The quad is the reference's two triangles (3,0,1) / (2,3,1) over
         // per-vertex ceil'd corners (glcontext.nim:418-429); a pixel belongs to the first whose three edge functions -- exact
@@ -1381,6 +1417,7 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? 4 : kPaths == 4 ? FDH_UNIFORM_WA
         // can produce fits 32 bits and the coefficients fit 24, so the strip's scalar base + two v_mad_i32_i24 per edge replace the
         // 64-bit arithmetic; quads beyond that keep the slot path.  Ownership is folded into the base (E - 1 >= 0 <=> E > 0).
         FDH_COUNT(1);
+        if (core && (mode == 9u || mode == 11u || mode == 12u)) return;
         const QuadExt& q = exts[r.ext];
         const int X0 = 2 * tx0 + 1, Y0 = 2 * ty0 + 1;
         const int dxl = 8 * (lane & 7), dyl = 2 * (lane >> 3);
@@ -1439,7 +1476,8 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? 4 : kPaths == 4 ? FDH_UNIFORM_WA
         const float shx = inset ? qhx : r.p2, shy = inset ? qhy : r.p3;
         const float spread = fill_mode == 0u ? r.f1 : 0.0f;
         float dist[4];
-        shape_distNy<4, true>(ellip, lx, nly, shx, shy, r.r[0], r.r[1], r.r[2], r.r[3], dist);
+        if (core) { dist[0] = dist[1] = dist[2] = dist[3] = -1.0e30f; }  // (wave-uniform: the coverage term is saturated on this strip, QuadExt::core)
+        else shape_distNy<4, true>(ellip, lx, nly, shx, shy, r.r[0], r.r[1], r.r[2], r.r[3], dist);
         if (kMasks && op == OP_MASK_PUSH) {  // mask.frag:186-234, as on the axis-aligned path below
           float mk[4] = {mk0, mk1, mk2, mk3};
           uint32_t packed = 0;
@@ -3071,19 +3109,22 @@ void launch_composite(hipStream_t s, const DrawRec* draws, const QuadExt* exts, 
   // the same pixels (tests/test_hip_parity.py)
   static const int force = [] { const char* e = std::getenv("FDH_FORCE_KERNEL_PATHS"); return e ? std::atoi(e) : 0; }();
   if (force == 3) P.has_slow = 1;
+  if (force == 8) P.has_rot = 1;
   if (force == 2) P.has_atlas = 1;
   if (force == 1) P.has_masks = 1;  // (the build with mask registers and the 4-KB stack, even where no clip is open)
   const size_t lds = (P.has_masks ? sizeof(uint32_t) * kMaskDepth * 64 : sizeof(uint32_t) * 256) +
-                     ((P.has_atlas || P.has_slow) ? sizeof(uint32_t) * kWinRows * kWinStride : 0);  // + the texel window of the atlas path
+                     ((P.has_atlas || P.has_slow || (P.has_rot && P.has_atlas)) ? sizeof(uint32_t) * kWinRows * kWinStride : 0);  // + the texel window of the atlas path
   const bool full = P.load_fb == 0;  // the launch that starts a frame (k_composite_tiles<., true>)
 #define FDH_COMPOSITE(paths) \
   do { if (full) FDH_LAUNCH((k_composite_tiles<paths, true>), dim3(grid), blk, lds, s, P.order, P.order_next, P.counts, P.lists, P.bin_x0, P.bin_y0, P.bin_nx, P.bin_ny, P.bins_x, P.stride, P.row_lo, P.row_hi, draws, exts, P); \
        else FDH_LAUNCH((k_composite_tiles<paths, false>), dim3(grid), blk, lds, s, P.order, P.order_next, P.counts, P.lists, P.bin_x0, P.bin_y0, P.bin_nx, P.bin_ny, P.bins_x, P.stride, P.row_lo, P.row_hi, draws, exts, P); } while (0)
 #if FDH_SPLIT_UNIFORM
-  if (P.has_slow) FDH_COMPOSITE(3);
+  if (P.has_slow || (P.has_rot && P.has_atlas)) FDH_COMPOSITE(3);
+  else if (P.has_rot) FDH_COMPOSITE(8);
   else { launch_composite_uniform(s, t_prof_start, t_prof_stop, grid, lds, draws, exts, P, P.has_atlas ? 2 : P.has_masks ? 0 : 4); if (t_prof_start) t_prof_used = true; }
 #else
-  if (P.has_slow) FDH_COMPOSITE(3);
+  if (P.has_slow || (P.has_rot && P.has_atlas)) FDH_COMPOSITE(3);
+  else if (P.has_rot) FDH_COMPOSITE(8);
   else if (P.has_atlas) FDH_COMPOSITE(2);
   else if (!P.has_masks) FDH_COMPOSITE(4);
   else FDH_COMPOSITE(0);

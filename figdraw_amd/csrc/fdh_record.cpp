@@ -162,17 +162,17 @@ static uint32_t binrec_flags(const DrawRec& r) {
   const bool sdf = !(om & F_GENERAL) && !atlas_mode && mode < 18u && (op == OP_DRAW || op == OP_MASK_PUSH);
   const uint32_t ell = (om & F_ELLIP) ? 4u : 0u;
   uint32_t flags = 0;
-  if ((om & F_GENERAL) && (om & F_EDGE32) && !atlas_mode && mode < 18u && op == OP_DRAW) return BR_GENERAL;
-  if (!sdf) return 0u;
-  flags |= BR_HAS_CORE;
+  const bool rot = (om & F_GENERAL) && (om & F_EDGE32) && !atlas_mode && mode < 18u && op == OP_DRAW;  // (its core: QuadExt::core)
+  if (!sdf && !rot) return 0u;
+  flags |= BR_HAS_CORE | (rot ? BR_GENERAL : 0u);
   if (op == OP_DRAW && (mode == 9u || mode == 11u || mode == 12u)) {
     flags |= BR_CORE_REMOVED;  // the stroke's interior, or so deep inside an inner shadow that no 8-bit channel moves
-    if ((om & F_SOLID) && fill_mode == 0u && mode != 11u) flags |= ((mode == 9u ? 3u : 4u) + ell) << LE_PATH_SHIFT;
+    if (!rot && (om & F_SOLID) && fill_mode == 0u && mode != 11u) flags |= ((mode == 9u ? 3u : 4u) + ell) << LE_PATH_SHIFT;
   } else {
     if (op == OP_DRAW && (om & F_SOLID) && fill_mode == 0u && mode != 17u) {
       flags |= LE_PLAIN;
       const uint32_t code = mode == 3u ? 1u : mode == 7u ? 2u : 0u;
-      if (code) flags |= (code + ell) << LE_PATH_SHIFT;
+      if (code && !rot) flags |= (code + ell) << LE_PATH_SHIFT;
     }
     if (op == OP_DRAW && mode == 3u) {
       uint32_t a = r.col[0] & r.col[1] & r.col[2] & r.col[3];
@@ -189,7 +189,7 @@ static uint32_t binrec_flags(const DrawRec& r) {
 static inline bool colour_as_floats(uint32_t om) {
   const uint32_t mode = om & 255u;
   const bool atlas_mode = mode == 0u || (mode >= 13u && mode <= 16u);
-  return !((om & F_GENERAL) || atlas_mode || mode >= 18u || ((om >> 12) & 15u) != OP_DRAW || !(om & F_SOLID));
+  return !(((om & F_GENERAL) && !(om & F_EDGE32)) || atlas_mode || mode >= 18u || ((om >> 12) & 15u) != OP_DRAW || !(om & F_SOLID));  // (F_EDGE32: the 4-wide rotated path)
 }
 void record_host_form(DrawRec& r) {  // what the record held before commit_bins (fdh_debug_record_digest hashes that form)
   if (colour_as_floats(r.op_mode)) r.col[1] = r.col[2] = r.col[3] = r.col[0];
@@ -236,6 +236,7 @@ void Recorder::commit_bins(uint32_t idx) {
   const bool atlas4 = atlas_mode && !(om & F_GENERAL) && op == OP_DRAW && !(mode == 0u && r.aux2 > 0.0f && cx_->n_levels_ >= 2);
   if (atlas4) sum_.has_atlas = true;
   // (a rect mask under a rotated transform -- matY.x != 0 -- is set up one pixel slot at a time; an upright one runs 4-wide)
+  else if ((op == OP_DRAW || op == OP_MASK_PUSH) && (om & F_GENERAL) && (om & F_EDGE32) && !atlas_mode && mode < 18u) sum_.has_rot = true;
   else if ((op == OP_RMASK_BEGIN && r.inv_h != 0.0f) || ((op == OP_DRAW || op == OP_MASK_PUSH) && ((om & F_GENERAL) || atlas_mode || mode >= 18u))) sum_.has_slow = true;
   if (op == OP_DRAW && !bbox_empty(b)) {  // covered fragments by mode (counted for phase 0 by the context)
     const int64_t area = (int64_t)(b.x1 - b.x0) * (b.y1 - b.y0);
@@ -341,11 +342,11 @@ int Lane::count_close() {
 // corners are pulled in by (1 - 1/sqrt 2) r per corner lies inside it.  Elliptical corners use an approximate
 // distance (atlas.frag:71-79), so there the core stays out of the corner cells, where the distance is the plain
 // box distance max(|p| - b).  One pixel of slack on every side absorbs all float rounding.
-static void set_saturated_core(DrawRec& r, float w_px, float h_px) {
-  r.ix0 = r.iy0 = r.ix1 = r.iy1 = 0;
+// (first half: the rectangle {xl..xr} x {yb..yt} of the local frame, y up; false = no core)
+static bool local_core(const DrawRec& r, double& xl, double& xr, double& yb, double& yt) {
   const uint32_t mode = r.op_mode & 255u, op = (r.op_mode >> 12) & 15u;
   const uint32_t fill_mode = (r.op_mode >> 9) & 7u;
-  if (!(op == OP_DRAW || op == OP_MASK_PUSH) || !(r.aa > 0.0f)) return;
+  if (!(op == OP_DRAW || op == OP_MASK_PUSH) || !(r.aa > 0.0f)) return false;
   double e;  // core = {dist <= -e}
   if (op == OP_MASK_PUSH || mode == FDH_SDF_CLIP_AA || mode == FDH_SDF_BACKDROP_BLUR) e = 0.5 / r.aa;
   else if (mode == FDH_SDF_DROP_SHADOW) e = std::max(0.0, -(double)(fill_mode == 0u ? r.f1 : 0.0f));
@@ -356,10 +357,10 @@ static void set_saturated_core(DrawRec& r, float w_px, float h_px) {
     // inside of a stroke.  z > 3.7 leaves a margin over the exact 3.54.
     const double sigma = std::max(0.5 * (double)r.f0, 0.5);
     e = std::max(0.0, 3.7 * sigma + (double)(fill_mode == 0u ? r.f1 : 0.0f));
-  } else return;
+  } else return false;
   const bool inset = mode == FDH_SDF_INSET_SHADOW;
   const double qhx = r.p0, qhy = r.p1, bx = inset ? qhx : (double)r.p2, by = inset ? qhy : (double)r.p3;
-  if (!(qhx > 0.0 && qhy > 0.0 && bx > 0.0 && by > 0.0)) return;
+  if (!(qhx > 0.0 && qhy > 0.0 && bx > 0.0 && by > 0.0)) return false;
   double crx[4], cry[4];  // TR, BR, TL, BL as in DrawRec::r
   for (int k = 0; k < 4; k++) {
     const double sel = r.r[k];
@@ -370,7 +371,6 @@ static void set_saturated_core(DrawRec& r, float w_px, float h_px) {
     cry[k] = hi * by / 4095.0;
   }
   enum { TR = 0, BR = 1, TL = 2, BL = 3 };
-  double xl, xr, yb, yt;  // local frame, y up
   if (!(r.op_mode & F_ELLIP)) {
     const double k = 0.2929;
     auto rr = [&](int i) { return std::max(crx[i] - e, 0.0); };
@@ -388,7 +388,13 @@ static void set_saturated_core(DrawRec& r, float w_px, float h_px) {
     if (ah >= av) { xl = hx0; xr = hx1; yb = hy0; yt = hy1; } else { xl = vx0; xr = vx1; yb = vy0; yt = vy1; }
   }
   if (inset) { xl += r.p2; xr += r.p2; yb -= r.p3; yt -= r.p3; }  // the shadow shape sits at (p2, -p3) in the quad's frame
-  if (!(xr > xl && yt > yb)) return;
+  return xr > xl && yt > yb;
+}
+static void set_saturated_core(DrawRec& r, float w_px, float h_px) {
+  r.ix0 = r.iy0 = r.ix1 = r.iy1 = 0;
+  double xl, xr, yb, yt;
+  if (!local_core(r, xl, xr, yb, yt)) return;
+  const double qhx = r.p0, qhy = r.p1;
   // local -> pixel centres: cx = ox + w_px * (x / (2 qhx) + 0.5), cy = oy + h_px * (0.5 - y / (2 qhy))
   // slack: what float rounding in the kernels' coordinate arithmetic can move a pixel centre against the level set (~2e-3 px at
   // 4K, 8e-3 at 16K), with room.  (It was a whole pixel: a quad ending on the frame edge -- the full-frame backdrop blur -- then
@@ -540,6 +546,31 @@ bool Recorder::emit_corners(DrawRec& r, const QuadPx& q, bool count_fragments) {
     }
     r.op_mode |= F_GENERAL;
     if (edge32) r.op_mode |= F_EDGE32;
+    // the saturated core of a rotated SDF draw, in the local frame, and the two triangles' maps into that frame (QuadExt::core, lm)
+    q.core[0] = q.core[1] = q.core[2] = q.core[3] = 0.0f;
+    double xl, xr, yb, yt;
+    if (edge32 && !atlas_mode && mode < 18u && ((r.op_mode >> 12) & 15u) == OP_DRAW && q.inv_sum[0] != 0.0f && q.inv_sum[1] != 0.0f && local_core(r, xl, xr, yb, yt)) {
+      // tri 0 = (TL, BL, BR): u = E2 is, v = (E1 + E2) is;  tri 1 = (TR, TL, BR): u = (E0 + E2) is, v = E2 is;  local x = (u - 0.5) 2 qhx,
+      // local y (up) = -(v - 0.5) 2 qhy (atlas.frag:252-262)
+      const double qhx = r.p0, qhy = r.p1;
+      double sx = 0.0, sy = 0.0;
+      for (int t = 0; t < 2; t++) {
+        const QuadExt::Edge &E0 = q.e[t][0], &E1 = q.e[t][1], &E2 = q.e[t][2];
+        const double is = (double)q.inv_sum[t];
+        const double ua = t == 0 ? (double)E2.a : (double)E0.a + E2.a, ub = t == 0 ? (double)E2.b : (double)E0.b + E2.b, uc = t == 0 ? (double)E2.c : (double)E0.c + (double)E2.c;
+        const double va = t == 0 ? (double)E1.a + E2.a : (double)E2.a, vb = t == 0 ? (double)E1.b + E2.b : (double)E2.b, vc = t == 0 ? (double)E1.c + (double)E2.c : (double)E2.c;
+        const double kx = 2.0 * qhx * is, ky = -2.0 * qhy * is;
+        const double m[6] = {kx * ua, kx * ub, kx * uc - qhx, ky * va, ky * vb, ky * vc + qhy};
+        for (int k = 0; k < 6; k++) q.lm[t][k] = (float)m[k];
+        sx = std::max(sx, 2.0 * (std::fabs(m[0]) + std::fabs(m[1])));  // local units per pixel step
+        sy = std::max(sy, 2.0 * (std::fabs(m[3]) + std::fabs(m[4])));
+      }
+#ifndef FDH_CORE_SLACK
+#define FDH_CORE_SLACK (1.0 / 16.0)
+#endif
+      xl += sx * FDH_CORE_SLACK; xr -= sx * FDH_CORE_SLACK; yb += sy * FDH_CORE_SLACK; yt -= sy * FDH_CORE_SLACK;
+      if (xr > xl && yt > yb) { q.core[0] = (float)xl; q.core[1] = (float)xr; q.core[2] = (float)yb; q.core[3] = (float)yt; }
+    }
     r.ext = (uint32_t)lane_->exts.n;  // lane-relative: the upload re-bases it (k_upload_frame)
     lane_->exts.n++;
   }
@@ -1079,6 +1110,7 @@ void Context::add_sum(const PhaseSum& s, int depth_base) {
   ph.has_masks = ph.has_masks || s.has_masks;
   ph.has_atlas = ph.has_atlas || s.has_atlas;
   ph.has_slow = ph.has_slow || s.has_slow;
+  ph.has_rot = ph.has_rot || s.has_rot;
   bbox_union(phase_u_, s.u);
   deepest_clip_ = std::max(deepest_clip_, depth_base + s.deepest);
   if (phases_.size() == 1) {  // the phase-0 composite launch's work units
@@ -1275,6 +1307,7 @@ void Context::splice_cached(const RetainedRoot& C) {
   sum_.has_masks = sum_.has_masks || C.sum.has_masks;
   sum_.has_atlas = sum_.has_atlas || C.sum.has_atlas;
   sum_.has_slow = sum_.has_slow || C.sum.has_slow;
+  sum_.has_rot = sum_.has_rot || C.sum.has_rot;
   sum_.deepest = std::max(sum_.deepest, depth_now_ + C.sum.deepest);
   for (int k = 0; k < 4; k++) sum_.frag_mode[k] += C.sum.frag_mode[k];
   sum_.frag_ellip += C.sum.frag_ellip;

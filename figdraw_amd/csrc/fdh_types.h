@@ -84,9 +84,17 @@ struct alignas(16) QuadExt {
   float fw_u[2], fw_v[2];  // |du/dx|+|du/dy|, |dv/dx|+|dv/dy| per triangle (msdf fwidth)
   float lod[2];            // log2(rho) per triangle (atlas mip selection: GL derives rho from per-fragment derivatives,
                            // which are constant on a triangle)
+  // The saturated core of a rotated SDF draw (BR_GENERAL | BR_HAS_CORE), for k_bin_draws: core[] = {xl, xr, yb, yt}, a rectangle in
+  // the shader's local frame (y up) on which the coverage term is saturated -- what DrawRec::ix0..iy1 is for an upright quad --,
+  // already shrunk by the slack that absorbs float rounding; lm[t] = the affine map of triangle t from (X, Y) = (2 px + 1, 2 py + 1)
+  // to that frame: lx = lm[t][0] X + lm[t][1] Y + lm[t][2], ly = lm[t][3] X + lm[t][4] Y + lm[t][5].  A strip that lies inside the
+  // quad and whose four corner pixels map into core[] under BOTH triangles' maps is a core strip (the maps are affine, the
+  // rectangle convex: every pixel of the strip then maps into it whichever triangle it belongs to).
   float _pad[3];
+  float core[4];  // (byte 144: core and lm are read as 16-byte pieces)
+  float lm[2][6];
 };
-static_assert(sizeof(QuadExt) == 144, "QuadExt must be 144 bytes");
+static_assert(sizeof(QuadExt) == 208 && offsetof(QuadExt, core) == 144 && offsetof(QuadExt, lm) == 160, "QuadExt: 208 bytes, core at 144, lm at 160");
 
 struct alignas(8) BBox { int16_t x0, y0, x1, y1; };
 

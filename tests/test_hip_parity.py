@@ -80,18 +80,19 @@ def test_render_is_deterministic_and_replay_is_idempotent(hip):
     assert (a == b).all() and (a == c).all()
 
 
-@pytest.mark.parametrize("paths", [1, 2, 3])
+@pytest.mark.parametrize("paths", [1, 2, 3, 8])
 def test_every_kernel_build_gives_the_same_pixels(hip, paths):
-    """k_composite_tiles comes in four builds picked per phase: <4> SDF draws without clip operations, <0> + clip masks,
-    <2> + the 4-wide atlas path, <3> + the one-pixel-slot path (the first three live in the uniform-regions translation
-    unit, the last one in the default one).  Forcing the more general builds (1: <0>, 2: <2>, 3: <3>) onto scenes that do
-    not need them (a child process with FDH_FORCE_KERNEL_PATHS) must not change a pixel."""
+    """k_composite_tiles comes in five builds picked per phase: <4> SDF draws without clip operations, <0> + clip masks,
+    <2> + the 4-wide atlas path, <8> + the 4-wide path for rotated SDF quads, <3> + everything incl. the one-pixel-slot path (the
+    first three live in the uniform-regions translation unit, the last two in the default one).  Forcing the more general builds
+    (1: <0>, 2: <2>, 8: <8>, 3: <3>) onto scenes that do not need them (a child process with FDH_FORCE_KERNEL_PATHS) must not
+    change a pixel -- the rotated scenes included, whose quads <8> and <3> shade with the same code."""
     import os
     import subprocess
     import sys
     import tempfile
 
-    names = ["oneframe", "nested_clips", "elliptical_and_fractional", "backdrop_blur"]
+    names = ["oneframe", "nested_clips", "elliptical_and_fractional", "backdrop_blur", "rotation_and_transform"]
     code = (
         "import sys, numpy as np\n"
         "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
@@ -104,6 +105,8 @@ def test_every_kernel_build_gives_the_same_pixels(hip, paths):
         "    ctx.render_frame(fn(float(w), float(h)), w, h); out[n] = ctx.read_pixels()\n"
         "sc = RS.random_scene(21, 700.0, 500.0, n=70)\n"
         "ctx.render_frame(sc, 700, 500); out['fuzz'] = ctx.read_pixels()\n"
+        "from figdraw_amd.scenes import make_rotated_tree\n"
+        "ctx.render_frame(make_rotated_tree(1280, 720, 3, copies=30), 1280, 720); out['rotated'] = ctx.read_pixels()\n"
         "np.savez(sys.argv[1], **out)\n"
     ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)), names)
     with tempfile.TemporaryDirectory() as td:
@@ -114,6 +117,30 @@ def test_every_kernel_build_gives_the_same_pixels(hip, paths):
             res[tag] = dict(np.load(path))
         for k in res["default"]:
             assert np.array_equal(res["default"][k], res["forced"][k]), (paths, k)
+
+
+@pytest.mark.parametrize("w,h,copies,frame", [(1280, 720, 40, 0), (1920, 1080, 100, 5), (803, 601, 25, 2)])
+def test_rotated_tree_matches_oracle(w, h, copies, frame):
+    """Every rectangle of the renderlist_100 tree rotated by -30 .. 30 degrees (config 9 of tools/perf_configs.py): rotated quads
+    four pixels per lane (32-bit edge functions, two-triangle barycentrics), strips outside a quad dropped at bin time, saturated
+    cores of rotated boxes (uniform blends, removed stroke interiors, occlusion) -- against the oracle's per-pixel rasteriser."""
+    from figdraw_amd.context import HipContext
+    from figdraw_amd.scenes import make_rotated_tree
+    from oracle import oracle as O
+
+    sc = make_rotated_tree(w, h, frame, copies=copies)
+    ctx = HipContext(device=0)
+    ctx.render_frame(sc, w, h)
+    got = ctx.read_pixels()
+    o = O.Oracle(threads=8)
+    o.render_frame(sc, w, h)
+    mx, n0, n1 = diff_stats(got, o.read_pixels())
+    assert mx <= 1 and n0 <= 0.005 * w * h, (mx, n0, n1)
+    ctx.set_stripe(h // 3 // 8 * 8, h // 3 // 8 * 8 + 104)  # a row stripe of it: the same pixels
+    ctx.render_frame(sc, w, h)
+    y0 = h // 3 // 8 * 8
+    assert np.array_equal(ctx.read_pixels()[y0:y0 + 104], got[y0:y0 + 104])
+    ctx.close()
 
 
 @pytest.mark.parametrize("path", [1, 2, 3])
