@@ -197,6 +197,77 @@ __device__ __forceinline__ float bezier_stroke_sd(float dist, float px, float py
   const float cap = __builtin_fmaxf(-start_proj - trim, end_proj - trim);
   return __builtin_fmaxf(tube - half_w, cap);
 }
+// ---- the same two functions for N pixels at once, straight-line (round 4): what depends on the curve alone is computed once per
+// draw, the cubic's two cases are both evaluated and selected, and the transcendentals are the hardware's (v_log / v_exp for the
+// cube roots, v_sqrt, v_rcp) or short polynomials (acos: Abramowitz & Stegun 4.4.46, |error| <= 2e-8; sin / cos on [0, pi / 3]:
+// Taylor to v^11, <= 4e-9) -- the distance is stationary in the root, so these errors enter squared.  libm's powf / acosf / cosf /
+// sinf cost several hundred instructions per pixel and made a curve the most expensive thing the compositor could draw.
+__device__ __forceinline__ float cbrt_signed(float x) {
+  const float a = __builtin_fabsf(x);
+  const float r = fexp2(__builtin_amdgcn_logf(a) * (1.0f / 3.0f));  // (a = 0: log2 = -inf, exp2 = 0)
+  return __builtin_copysignf(r, x);
+}
+__device__ __forceinline__ float acos_poly(float x) {
+  const float a = __builtin_fabsf(x);
+  float p = -0.0012624911f;
+  p = __builtin_fmaf(p, a, 0.0066700901f); p = __builtin_fmaf(p, a, -0.0170881256f); p = __builtin_fmaf(p, a, 0.0308918810f);
+  p = __builtin_fmaf(p, a, -0.0501743046f); p = __builtin_fmaf(p, a, 0.0889789874f); p = __builtin_fmaf(p, a, -0.2145988016f);
+  p = __builtin_fmaf(p, a, 1.5707963050f);
+  const float f = fsqrt(__builtin_fmaxf(1.0f - a, 0.0f)) * p;
+  return x < 0.0f ? 3.14159265358979f - f : f;
+}
+template <int N>
+__device__ __forceinline__ void sd_bezierN(const float* px, float py, float Ax, float Ay, float Bx, float By, float Cx, float Cy, float* out) {
+  const float ax = Bx - Ax, ay = By - Ay;
+  const float bx = Ax - 2.0f * Bx + Cx, by = Ay - 2.0f * By + Cy;
+  const float bb = bx * bx + by * by;
+  if (bb <= 0.000001f) {  // wave-uniform: a straight span
+    const float bax = Cx - Ax, bay = Cy - Ay;
+    const float il = frcp(__builtin_fmaxf(bax * bax + bay * bay, 0.000001f));
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+      const float h = clamp01(((px[k] - Ax) * bax + (py - Ay) * bay) * il);
+      const float dx = px[k] - (Ax + bax * h), dy = py - (Ay + bay * h);
+      out[k] = fsqrt(dx * dx + dy * dy);
+    }
+    return;
+  }
+  const float cx = ax * 2.0f, cy = ay * 2.0f;
+  const float kk = frcp(bb);
+  const float kx = kk * (ax * bx + ay * by);
+  const float aa2 = 2.0f * (ax * ax + ay * ay);
+  const float dy = Ay - py;
+#pragma unroll
+  for (int k = 0; k < N; k++) {
+    const float dx = Ax - px[k];
+    const float ky = kk * (aa2 + (dx * bx + dy * by)) * (1.0f / 3.0f);
+    const float kz = kk * (dx * ax + dy * ay);
+    const float p = ky - kx * kx;
+    const float p3 = p * p * p;
+    const float q = kx * (2.0f * kx * kx - 3.0f * ky) + kz;
+    const float h = q * q + 4.0f * p3;
+    // h >= 0: one real root
+    const float hs = fsqrt(__builtin_fmaxf(h, 0.0f));
+    const float tA = clamp01(cbrt_signed((hs - q) * 0.5f) + cbrt_signed((-hs - q) * 0.5f) - kx);
+    const float eax = dx + (cx + bx * tA) * tA, eay = dy + (cy + by * tA) * tA;
+    const float resA = eax * eax + eay * eay;
+    // h < 0 (then p < 0): three real roots, the two that can be nearest
+    const float z = fsqrt(__builtin_fmaxf(-p, 0.0f));
+    const float den = p * z * 2.0f;
+    const float arg = __builtin_fminf(__builtin_fmaxf(q * frcp(den), -1.0f), 1.0f);
+    const float v = acos_poly(den == 0.0f ? 0.0f : arg) * (1.0f / 3.0f);
+    const float v2 = v * v;
+    float cm = -1.0f / 3628800.0f, sn = -1.0f / 39916800.0f;
+    cm = __builtin_fmaf(cm, v2, 1.0f / 40320.0f); cm = __builtin_fmaf(cm, v2, -1.0f / 720.0f); cm = __builtin_fmaf(cm, v2, 1.0f / 24.0f); cm = __builtin_fmaf(cm, v2, -0.5f); cm = __builtin_fmaf(cm, v2, 1.0f);
+    sn = __builtin_fmaf(sn, v2, 1.0f / 362880.0f); sn = __builtin_fmaf(sn, v2, -1.0f / 5040.0f); sn = __builtin_fmaf(sn, v2, 1.0f / 120.0f); sn = __builtin_fmaf(sn, v2, -1.0f / 6.0f); sn = __builtin_fmaf(sn, v2, 1.0f);
+    const float m = cm, n = sn * v * 1.732050808f;
+    const float t1 = clamp01((m + m) * z - kx), t2 = clamp01((-n - m) * z - kx);
+    const float e1x = dx + (cx + bx * t1) * t1, e1y = dy + (cy + by * t1) * t1;
+    const float e2x = dx + (cx + bx * t2) * t2, e2y = dy + (cy + by * t2) * t2;
+    const float resB = __builtin_fminf(e1x * e1x + e1y * e1y, e2x * e2x + e2y * e2y);
+    out[k] = fsqrt(h >= 0.0f ? resA : resB);
+  }
+}
 __device__ __forceinline__ float median3(float a, float b, float c) {  // atlas.frag:41-43
   return __builtin_fmaxf(__builtin_fminf(a, b), __builtin_fminf(__builtin_fmaxf(a, b), c));
 }
@@ -1579,6 +1650,85 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? 4 : kPaths == 4 ? FDH_UNIFORM_WA
         blend(F1, sr[1], sg[1], sb[1], cov[1] ? sa[1] * mk1 * rm1 : 0.0f);
         blend(F2, sr[2], sg[2], sb[2], cov[2] ? sa[2] * mk2 * rm2 : 0.0f);
         blend(F3, sr[3], sg[3], sb[3], cov[3] ? sa[3] * mk3 * rm3 : 0.0f);
+        return;
+      }
+      if (kSlow && mode >= 18u && mode <= 20u && (om & F_GENERAL) == 0u && op == OP_DRAW) {
+        // ---- quadratic-bezier strokes on upright quads (drawQuadraticBezierSdf, modes 18 - 20: atlas.frag:121-209, 321-336), four
+        // pixels per lane.  The quad is the span's bounding box; most of it is far from the curve.  The curve lies in the hull of its
+        // control points, inside the box aligned with its chord AC that reaches min(0, b.f) .. max(|AC|, b.f) along it and 0 .. b.g / 2
+        // across (b = B - A): a pixel farther from that box than sqrt 2 (half width + 0.5 / aa) has coverage exactly 0 in every
+        // mode (the square cap of mode 20 reaches that far past an end point), and a strip of such pixels skips the cubic.
+        const float Ax = r.p2, Ay = r.p3, Bx = r.r[0], By = r.r[1], Cx = r.r[2], Cy = r.r[3];
+        const float hw = __builtin_fmaxf(r.f0, 0.0f) * 0.5f;
+        float lx[4], u[4];
+        bool cov[4];
+        const bool rowc = py >= r.by0 && py < r.by1;
+        const float t = (cy - r.oy) * r.inv_h;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          u[k] = (cx0 + (float)k - r.ox) * r.inv_w;
+          cov[k] = rowc && px0 + k >= r.bx0 && px0 + k < r.bx1;
+        }
+        local_x4(r, cx0, lx);
+        const float ly = -local_y_up(r, cy);
+        float fx, fy, sx, sy, ex, ey;  // (wave-uniform: the record's alone)
+        safe_normalize(Cx - Ax, Cy - Ay, 1.0f, 0.0f, fx, fy);
+        {
+          const float bf = (Bx - Ax) * fx + (By - Ay) * fy, bg = (By - Ay) * fx - (Bx - Ax) * fy;
+          const float lac = (Cx - Ax) * fx + (Cy - Ay) * fy;
+          const float x_lo = __builtin_fminf(0.0f, bf), x_hi = __builtin_fmaxf(lac, bf), y_lo = __builtin_fminf(0.0f, 0.5f * bg), y_hi = __builtin_fmaxf(0.0f, 0.5f * bg);
+          const float ocx = 0.5f * (x_lo + x_hi), ohx = 0.5f * (x_hi - x_lo), ocy = 0.5f * (y_lo + y_hi), ohy = 0.5f * (y_hi - y_lo);
+          const float reach = 1.41422f * (hw + 0.5f * frcp(r.aa)) + 0.01f;
+          bool near = false;
+          const float ry = ly - Ay;
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            const float rx = lx[k] - Ax;
+            const float X = rx * fx + ry * fy, Y = ry * fx - rx * fy;
+            const float db = __builtin_fmaxf(__builtin_fabsf(X - ocx) - ohx, __builtin_fabsf(Y - ocy) - ohy);
+            near = near || (cov[k] && db < reach);
+          }
+          if (!__any(near)) return;
+        }
+        float dist[4];
+        sd_bezierN<4>(lx, ly, Ax, Ay, Bx, By, Cx, Cy, dist);
+        float alpha[4];
+        if (mode == 18u) {
+#pragma unroll
+          for (int k = 0; k < 4; k++) alpha[k] = 1.0f - clamp01(r.aa * (dist[k] - hw) + 0.5f);
+        } else {  // bezierStrokeSd atlas.frag:179-209
+          safe_normalize(Bx - Ax, By - Ay, fx, fy, sx, sy);
+          safe_normalize(Cx - Bx, Cy - By, fx, fy, ex, ey);
+          const float trim = mode == 20u ? hw : 0.0f;
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            const float start_proj = (lx[k] - Ax) * sx + (ly - Ay) * sy, end_proj = (lx[k] - Cx) * ex + (ly - Cy) * ey;
+            float tube = dist[k];
+            if (mode == 20u) {  // wave-uniform
+              const float ta = __builtin_fminf(tube, __builtin_fabsf((lx[k] - Ax) * sy - (ly - Ay) * sx));
+              tube = start_proj < 0.0f ? ta : tube;
+              const float tb = __builtin_fminf(tube, __builtin_fabsf((lx[k] - Cx) * ey - (ly - Cy) * ex));
+              tube = end_proj > 0.0f ? tb : tube;
+            }
+            const float cap = __builtin_fmaxf(-start_proj - trim, end_proj - trim);
+            alpha[k] = 1.0f - clamp01(r.aa * __builtin_fmaxf(tube - hw, cap) + 0.5f);
+          }
+        }
+        const uint32_t fill_mode = (om >> 9) & 7u;
+        const F4 c0 = unpack255(r.col[0]);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          F4 col = {c0.x * inv255, c0.y * inv255, c0.z * inv255, c0.w * inv255};
+          if (!(om & F_SOLID)) {  // wave-uniform
+            const F4 br = unpack255(r.col[1]), tr = unpack255(r.col[2]), tl = unpack255(r.col[3]);
+            col.x = tri_lerp(tl.x, c0.x, br.x, tr.x, u[k], t) * inv255; col.y = tri_lerp(tl.y, c0.y, br.y, tr.y, u[k], t) * inv255;
+            col.z = tri_lerp(tl.z, c0.z, br.z, tr.z, u[k], t) * inv255; col.w = tri_lerp(tl.w, c0.w, br.w, tr.w, u[k], t) * inv255;
+          }
+          const F4 fc = eval_fill_rec(r, col, fill_mode, u[k], t);
+          const float mkk = k == 0 ? mk0 : k == 1 ? mk1 : k == 2 ? mk2 : mk3, rmk = k == 0 ? rm0 : k == 1 ? rm1 : k == 2 ? rm2 : rm3;
+          F4& F = k == 0 ? F0 : k == 1 ? F1 : k == 2 ? F2 : F3;
+          blend(F, fc.x, fc.y, fc.z, cov[k] ? fc.w * alpha[k] * mkk * rmk : 0.0f);
+        }
         return;
       }
       if (!kSlow && !fast) return;  // unreachable: the host picks kSlow = true for any phase holding such a draw
