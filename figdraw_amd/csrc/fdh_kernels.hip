@@ -218,6 +218,7 @@ __device__ __forceinline__ float acos_poly(float x) {
 }
 template <int N>
 __device__ __forceinline__ void sd_bezierN(const float* px, float py, float Ax, float Ay, float Bx, float By, float Cx, float Cy, float* out) {
+#pragma clang fp contract(off)
   const float ax = Bx - Ax, ay = By - Ay;
   const float bx = Ax - 2.0f * Bx + Cx, by = Ay - 2.0f * By + Cy;
   const float bb = bx * bx + by * by;
@@ -232,22 +233,27 @@ __device__ __forceinline__ void sd_bezierN(const float* px, float py, float Ax, 
     }
     return;
   }
+  // The one-root case forms (sqrt(h) - q) / 2 with sqrt(h) ~ |q| wherever 4 p^3 << q^2: what survives the cancellation is the
+  // rounding of the operations that led there, and a pixel's distance can move by a tenth of a pixel when sqrt(h) moves by one ulp
+  // (measured; the trigonometric case, the cube roots and the inputs are benign: 1e-6 relative moves the result by 1e-4 px).  So
+  // up to the roots the arithmetic is the oracle's and libm's operation for operation: IEEE division and square root, no fused
+  // multiply-adds (the pragma at the top of the function).
   const float cx = ax * 2.0f, cy = ay * 2.0f;
-  const float kk = frcp(bb);
+  const float kk = 1.0f / bb;
   const float kx = kk * (ax * bx + ay * by);
   const float aa2 = 2.0f * (ax * ax + ay * ay);
   const float dy = Ay - py;
 #pragma unroll
   for (int k = 0; k < N; k++) {
     const float dx = Ax - px[k];
-    const float ky = kk * (aa2 + (dx * bx + dy * by)) * (1.0f / 3.0f);
+    const float ky = kk * (aa2 + (dx * bx + dy * by)) / 3.0f;
     const float kz = kk * (dx * ax + dy * ay);
     const float p = ky - kx * kx;
     const float p3 = p * p * p;
     const float q = kx * (2.0f * kx * kx - 3.0f * ky) + kz;
     const float h = q * q + 4.0f * p3;
     // h >= 0: one real root
-    const float hs = fsqrt(__builtin_fmaxf(h, 0.0f));
+    const float hs = __builtin_sqrtf(__builtin_fmaxf(h, 0.0f));
     const float tA = clamp01(cbrt_signed((hs - q) * 0.5f) + cbrt_signed((-hs - q) * 0.5f) - kx);
     const float eax = dx + (cx + bx * tA) * tA, eay = dy + (cy + by * tA) * tA;
     const float resA = eax * eax + eay * eay;
@@ -368,6 +374,41 @@ __device__ __forceinline__ void bin_entry(const BinParams& P, int i, int x0, int
   if (!(b.x0 < x0 + kBin && b.x1 > x0 && b.y0 < y0 + kBin && b.y1 > y0)) { hit = false; return; }  // exact test
   strips = strip_mask(b.x0 - x0, b.y0 - y0, b.x1 - x0, b.y1 - y0);
   word = (uint32_t)i | (r.flags & ~LE_INDEX);
+  if (r.flags & BR_CURVE) {
+    // A bezier stroke: strips whose pixels are all farther from the chord-aligned box around the curve than sqrt 2 (half width +
+    // 0.5 / aa) hold no coverage (see the 4-wide bezier path of k_composite_tiles, which applies the same bound per strip after
+    // fetching the record; here the strip never sees the draw).  The strip's pixel-centre rectangle is mapped into the quad's local
+    // frame (upright quad: x and y map separately), its corners into the chord frame, and their bounding box is held against the
+    // curve's box.
+    const uint4* __restrict__ d4 = reinterpret_cast<const uint4*>(P.draws + i);
+    const uint4 q0 = d4[0], q1 = d4[1], q2 = d4[2], q3 = d4[3], q5 = d4[5];
+    const float ox = __uint_as_float(q0.z), oy = __uint_as_float(q0.w), inv_w = __uint_as_float(q1.x), inv_h = __uint_as_float(q1.y);
+    const float p0 = __uint_as_float(q1.z), p1 = __uint_as_float(q1.w), Ax = __uint_as_float(q2.x), Ay = __uint_as_float(q2.y), f0 = __uint_as_float(q2.z);
+    const float Bx = __uint_as_float(q3.x), By = __uint_as_float(q3.y), Cx = __uint_as_float(q3.z), Cy = __uint_as_float(q3.w), aa = __uint_as_float(q5.z);
+    float fx = Cx - Ax, fy = Cy - Ay;
+    const float fl = __builtin_sqrtf(fx * fx + fy * fy);
+    if (fl <= 0.000001f) { fx = 1.0f; fy = 0.0f; } else { fx /= fl; fy /= fl; }
+    const float bf = (Bx - Ax) * fx + (By - Ay) * fy, bg = (By - Ay) * fx - (Bx - Ax) * fy, lac = (Cx - Ax) * fx + (Cy - Ay) * fy;
+    const float x_lo = __builtin_fminf(0.0f, bf), x_hi = __builtin_fmaxf(lac, bf), y_lo = __builtin_fminf(0.0f, 0.5f * bg), y_hi = __builtin_fmaxf(0.0f, 0.5f * bg);
+    const float reach = 1.41422f * (__builtin_fmaxf(f0, 0.0f) * 0.5f + 0.5f / aa) + 0.05f;  // (+ slack for the kernels' own rounding of the coordinates)
+    uint32_t keep = 0;
+#pragma unroll
+    for (int s = 0; s < 16; s++) {
+      const int col = (s >> 2) & 1, row = (s >> 3) * 4 + (s & 3);
+      const float cxa = (float)(x0 + col * kTileW) + 0.5f, cxb = cxa + (float)(kTileW - 1), cya = (float)(y0 + row * kTileH) + 0.5f, cyb = cya + (float)(kTileH - 1);
+      const float lxa = ((cxa - ox) * inv_w - 0.5f) * (2.0f * p0) - Ax, lxb = ((cxb - ox) * inv_w - 0.5f) * (2.0f * p0) - Ax;
+      const float lya = ((cya - oy) * inv_h - 0.5f) * (2.0f * p1) - Ay, lyb = ((cyb - oy) * inv_h - 0.5f) * (2.0f * p1) - Ay;
+      const float Xa = lxa * fx, Xb = lxb * fx, Xc = lya * fy, Xd = lyb * fy;      // X = rx fx + ry fy
+      const float Ya = -lxa * fy, Yb = -lxb * fy, Yc = lya * fx, Yd = lyb * fx;    // Y = ry fx - rx fy
+      const float Xmin = __builtin_fminf(Xa, Xb) + __builtin_fminf(Xc, Xd), Xmax = __builtin_fmaxf(Xa, Xb) + __builtin_fmaxf(Xc, Xd);
+      const float Ymin = __builtin_fminf(Ya, Yb) + __builtin_fminf(Yc, Yd), Ymax = __builtin_fmaxf(Ya, Yb) + __builtin_fmaxf(Yc, Yd);
+      const float db = __builtin_fmaxf(__builtin_fmaxf(Xmin - x_hi, x_lo - Xmax), __builtin_fmaxf(Ymin - y_hi, y_lo - Ymax));
+      if (db < reach) keep |= 1u << s;
+    }
+    strips &= keep;
+    hit = strips != 0u;
+    return;
+  }
   if (r.flags & BR_GENERAL) {
     // A rotated quad: a strip all of whose pixel centres fail ONE of the quad's outer edges (bottom, left, right, top: edges 0 and 2
     // of triangle (TL, BL, BR), 1 and 2 of (TR, TL, BR)) holds no pixel of it.  The largest value an edge function takes on a
@@ -998,6 +1039,9 @@ __device__ unsigned int g_edge_bad[4096 * 8];
 #endif
 #ifndef FDH_ATLAS_WAVES
 #define FDH_ATLAS_WAVES 5  // waves per SIMD of the atlas build <2>
+#endif
+#ifndef FDH_BEZIER4
+#define FDH_BEZIER4 1  // 0 (experiment builds): bezier strokes stay on the one-pixel-slot path with libm's functions
 #endif
 #ifndef FDH_ROT_WAVES
 #define FDH_ROT_WAVES 4  // waves per SIMD of the rotated-quad build <8>
@@ -1652,7 +1696,7 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? 4 : kPaths == 4 ? FDH_UNIFORM_WA
         blend(F3, sr[3], sg[3], sb[3], cov[3] ? sa[3] * mk3 * rm3 : 0.0f);
         return;
       }
-      if (kSlow && mode >= 18u && mode <= 20u && (om & F_GENERAL) == 0u && op == OP_DRAW) {
+      if (kSlow && FDH_BEZIER4 && mode >= 18u && mode <= 20u && (om & F_GENERAL) == 0u && op == OP_DRAW) {
         // ---- quadratic-bezier strokes on upright quads (drawQuadraticBezierSdf, modes 18 - 20: atlas.frag:121-209, 321-336), four
         // pixels per lane.  The quad is the span's bounding box; most of it is far from the curve.  The curve lies in the hull of its
         // control points, inside the box aligned with its chord AC that reaches min(0, b.f) .. max(|AC|, b.f) along it and 0 .. b.g / 2

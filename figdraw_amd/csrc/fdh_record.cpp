@@ -163,6 +163,7 @@ static uint32_t binrec_flags(const DrawRec& r) {
   const uint32_t ell = (om & F_ELLIP) ? 4u : 0u;
   uint32_t flags = 0;
   const bool rot = (om & F_GENERAL) && (om & F_EDGE32) && !atlas_mode && mode < 18u && op == OP_DRAW;  // (its core: QuadExt::core)
+  if (!(om & F_GENERAL) && mode >= 18u && mode <= 20u && op == OP_DRAW) return BR_CURVE;
   if (!sdf && !rot) return 0u;
   flags |= BR_HAS_CORE | (rot ? BR_GENERAL : 0u);
   if (op == OP_DRAW && (mode == 9u || mode == 11u || mode == 12u)) {

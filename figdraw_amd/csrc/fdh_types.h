@@ -109,6 +109,9 @@ constexpr uint32_t BR_HAS_CORE = 1u, BR_CORE_REMOVED = 2u;
 // bit 2: a rotated / skewed SDF draw (F_GENERAL | F_EDGE32, OP_DRAW): its pixel bounds are the quad's bounding box; k_bin_draws drops the
 // strips that lie outside one of the quad's four outer edges (half of the box of a quad rotated by 30 degrees)
 constexpr uint32_t BR_GENERAL = 4u;
+// bit 3: a quadratic-bezier stroke on an upright quad (modes 18 - 20): its bounds are the span's bounding box; k_bin_draws drops the
+// strips farther from the curve's chord-aligned box than any pixel with coverage can be (the same test the compositor applies per strip)
+constexpr uint32_t BR_CURVE = 8u;
 constexpr uint32_t LE_PLAIN = 1u << 31;  // axis-aligned SDF draw with ONE colour: on its core strips it is a uniform blend
 constexpr uint32_t LE_OPAQUE = 1u << 30;  // a fill whose source alpha is 255 everywhere: on its core strips it REPLACES the surface
 // bits 26..29: which straight-line shading path the draw's EDGE strips can take, decided on the host so that the

@@ -189,7 +189,7 @@ def make_rotated_tree(w: float, h: float, frame: int = 0, copies: int = 100) -> 
     return out
 
 
-def make_curves_scene(w: float, h: float, n: int = 1500, seed: int = 7) -> Renders:
+def make_curves_scene(w: float, h: float, n: int = 1500, seed: int = 7, only_kind: int = -1) -> Renders:
     """n stroked curves and lines (nkDrawable: quadratic beziers -> drawQuadraticBezierSdf, modes 18 - 20; lines -> rotated boxes;
     arcs with joins -> filled quads) scattered over the frame: config 10 of tools/perf_configs.py."""
     from .scene import StrokeCap, StrokeJoin, drawableArc, drawableBezier, drawableLine
@@ -201,7 +201,7 @@ def make_curves_scene(w: float, h: float, n: int = 1500, seed: int = 7) -> Rende
         x, y = float(rng.uniform(f32(w - 260))), float(rng.uniform(f32(h - 200)))
         col = fill(rgba(int(rng.next_u32() & 255), int(rng.next_u32() & 255), int(rng.next_u32() & 255), 200 + (i % 56)))
         weight = 2.0 + float(i % 7)
-        kind = i % 4
+        kind = i % 4 if only_kind < 0 else only_kind
         if kind == 0:
             ops = [drawableBezier([(5, 10), (120 + (i % 40), 170), (235, 20 + (i % 90))])]
         elif kind == 1:

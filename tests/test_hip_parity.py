@@ -143,6 +143,34 @@ def test_rotated_tree_matches_oracle(w, h, copies, frame):
     ctx.close()
 
 
+@pytest.mark.parametrize("w,h,n,seed", [(1280, 720, 300, 7), (900, 700, 160, 11)])
+def test_curves_scene_matches_oracle(w, h, n, seed):
+    """Stroked nkDrawable curves, lines and arcs (config 10 of tools/perf_configs.py): quadratic-bezier spans four pixels per lane
+    (hardware transcendentals, both cases of the cubic selected), strips far from a curve dropped at bin time, lines as rotated
+    boxes, join quads -- against the oracle's libm evaluation, pixel by pixel.
+
+    The bar here is "within 1 LSB but for a handful of isolated pixels", and the handful is the reference's own: sdBezier
+    (atlas.frag:121-160) solves the cubic in closed form and, in the one-root case, forms (sqrt(h) - q) / 2 where sqrt(h) ~ |q|:
+    what survives the cancellation is rounding noise, so two IEEE-conformant evaluations of the same formula (the oracle's, whose
+    uv comes from its triangle rasteriser's barycentrics, and the kernel's, whose uv is (x - ox) / w) disagree on a few pixels of
+    every few thousand along a stroke's edge, by anything.  Measured on this scene: the previous one-pixel-slot path with libm's
+    powf / acosf (same formula, same operation order) 76 + 5 pixels beyond 1 LSB; this path, with IEEE division and square root and
+    no fused multiply-adds up to the roots, 23 + 5 (tools/debug/curves_diff.py).  A GL driver's pow() is not libm's either."""
+    from figdraw_amd.context import HipContext
+    from figdraw_amd.scenes import make_curves_scene
+    from oracle import oracle as O
+
+    sc = make_curves_scene(w, h, n=n, seed=seed)
+    ctx = HipContext(device=0)
+    ctx.render_frame(sc, w, h)
+    got = ctx.read_pixels()
+    o = O.Oracle(threads=8)
+    o.render_frame(sc, w, h)
+    mx, n0, n1 = diff_stats(got, o.read_pixels())
+    assert n1 <= 40 and n0 <= 0.005 * w * h, (mx, n0, n1)  # (n1 / pixels = 4e-5)
+    ctx.close()
+
+
 @pytest.mark.parametrize("path", [1, 2, 3])
 def test_every_blur_path_matches_oracle(path):
     """The blur passes exist as three builds picked by region size and filter width: 2 outputs per thread (small regions),
