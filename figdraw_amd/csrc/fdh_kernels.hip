@@ -310,6 +310,33 @@ __device__ __forceinline__ F4 atlas_sample(const AtlasView& A, float u, float v,
   return o;
 }
 
+// ---- where a quadratic bezier can be: split at t = 1/2 (de Casteljau) into two sub-curves, each inside the box aligned with its own
+// chord that reaches min(0, b.f) .. max(|chord|, b.f) along it and 0 .. b.g / 2 across (b = its middle control point relative to its
+// start).  The sagitta of a half is a quarter of the whole curve's: the boxes hug the curve where one box around the whole span would
+// be as fat as the curve is bent.  Used by k_bin_draws, per strip.  (Four boxes took the bin kernel from 20 to 36 us on the
+// 1500-curve frame for a quarter fewer strip-draws; queueing a strip's near pixels in LDS and running the cubic on the queue was
+// no faster than four lock-step pixel slots: the spans are short and their reach wide, most pixels of a kept strip are near.)
+struct CurveBox { float ax, ay, fx, fy, x_lo, x_hi, y_lo, y_hi; };
+__device__ __forceinline__ CurveBox curve_box(float Ax, float Ay, float Bx, float By, float Cx, float Cy) {
+  CurveBox b;
+  b.ax = Ax; b.ay = Ay;
+  float fx = Cx - Ax, fy = Cy - Ay;
+  const float fl = fsqrt(fx * fx + fy * fy);
+  const float il = frcp(__builtin_fmaxf(fl, 0.000001f));
+  const bool tiny = fl <= 0.000001f;
+  b.fx = tiny ? 1.0f : fx * il;
+  b.fy = tiny ? 0.0f : fy * il;
+  const float bf = (Bx - Ax) * b.fx + (By - Ay) * b.fy, bg = (By - Ay) * b.fx - (Bx - Ax) * b.fy, lac = (Cx - Ax) * b.fx + (Cy - Ay) * b.fy;
+  b.x_lo = __builtin_fminf(0.0f, bf); b.x_hi = __builtin_fmaxf(lac, bf);
+  b.y_lo = __builtin_fminf(0.0f, 0.5f * bg); b.y_hi = __builtin_fmaxf(0.0f, 0.5f * bg);
+  return b;
+}
+__device__ __forceinline__ void curve_boxes2(float Ax, float Ay, float Bx, float By, float Cx, float Cy, CurveBox (&out)[2]) {
+  const float abx = 0.5f * (Ax + Bx), aby = 0.5f * (Ay + By), bcx = 0.5f * (Bx + Cx), bcy = 0.5f * (By + Cy);
+  const float mx = 0.5f * (abx + bcx), my = 0.5f * (aby + bcy);
+  out[0] = curve_box(Ax, Ay, abx, aby, mx, my);  // halves: (A, AB, M) and (M, BC, C)
+  out[1] = curve_box(mx, my, bcx, bcy, Cx, Cy);
+}
 // ------------------------------------------------------------------ binning
 
 // Which of a bin's 16 strips (32x8 px; strip s = (jy*2 + jx)*4 + w sits at column jx, row jy*4 + w) a bin-relative
@@ -385,25 +412,28 @@ __device__ __forceinline__ void bin_entry(const BinParams& P, int i, int x0, int
     const float ox = __uint_as_float(q0.z), oy = __uint_as_float(q0.w), inv_w = __uint_as_float(q1.x), inv_h = __uint_as_float(q1.y);
     const float p0 = __uint_as_float(q1.z), p1 = __uint_as_float(q1.w), Ax = __uint_as_float(q2.x), Ay = __uint_as_float(q2.y), f0 = __uint_as_float(q2.z);
     const float Bx = __uint_as_float(q3.x), By = __uint_as_float(q3.y), Cx = __uint_as_float(q3.z), Cy = __uint_as_float(q3.w), aa = __uint_as_float(q5.z);
-    float fx = Cx - Ax, fy = Cy - Ay;
-    const float fl = __builtin_sqrtf(fx * fx + fy * fy);
-    if (fl <= 0.000001f) { fx = 1.0f; fy = 0.0f; } else { fx /= fl; fy /= fl; }
-    const float bf = (Bx - Ax) * fx + (By - Ay) * fy, bg = (By - Ay) * fx - (Bx - Ax) * fy, lac = (Cx - Ax) * fx + (Cy - Ay) * fy;
-    const float x_lo = __builtin_fminf(0.0f, bf), x_hi = __builtin_fmaxf(lac, bf), y_lo = __builtin_fminf(0.0f, 0.5f * bg), y_hi = __builtin_fmaxf(0.0f, 0.5f * bg);
+    CurveBox cb[2];
+    curve_boxes2(Ax, Ay, Bx, By, Cx, Cy, cb);
     const float reach = 1.41422f * (__builtin_fmaxf(f0, 0.0f) * 0.5f + 0.5f / aa) + 0.05f;  // (+ slack for the kernels' own rounding of the coordinates)
     uint32_t keep = 0;
 #pragma unroll
     for (int s = 0; s < 16; s++) {
       const int col = (s >> 2) & 1, row = (s >> 3) * 4 + (s & 3);
       const float cxa = (float)(x0 + col * kTileW) + 0.5f, cxb = cxa + (float)(kTileW - 1), cya = (float)(y0 + row * kTileH) + 0.5f, cyb = cya + (float)(kTileH - 1);
-      const float lxa = ((cxa - ox) * inv_w - 0.5f) * (2.0f * p0) - Ax, lxb = ((cxb - ox) * inv_w - 0.5f) * (2.0f * p0) - Ax;
-      const float lya = ((cya - oy) * inv_h - 0.5f) * (2.0f * p1) - Ay, lyb = ((cyb - oy) * inv_h - 0.5f) * (2.0f * p1) - Ay;
-      const float Xa = lxa * fx, Xb = lxb * fx, Xc = lya * fy, Xd = lyb * fy;      // X = rx fx + ry fy
-      const float Ya = -lxa * fy, Yb = -lxb * fy, Yc = lya * fx, Yd = lyb * fx;    // Y = ry fx - rx fy
-      const float Xmin = __builtin_fminf(Xa, Xb) + __builtin_fminf(Xc, Xd), Xmax = __builtin_fmaxf(Xa, Xb) + __builtin_fmaxf(Xc, Xd);
-      const float Ymin = __builtin_fminf(Ya, Yb) + __builtin_fminf(Yc, Yd), Ymax = __builtin_fmaxf(Ya, Yb) + __builtin_fmaxf(Yc, Yd);
-      const float db = __builtin_fmaxf(__builtin_fmaxf(Xmin - x_hi, x_lo - Xmax), __builtin_fmaxf(Ymin - y_hi, y_lo - Ymax));
-      if (db < reach) keep |= 1u << s;
+      const float lxa = ((cxa - ox) * inv_w - 0.5f) * (2.0f * p0), lxb = ((cxb - ox) * inv_w - 0.5f) * (2.0f * p0);
+      const float lya = ((cya - oy) * inv_h - 0.5f) * (2.0f * p1), lyb = ((cyb - oy) * inv_h - 0.5f) * (2.0f * p1);
+      bool near = false;
+#pragma unroll
+      for (int c = 0; c < 2; c++) {  // the strip's rectangle in box c's frame: the bounding box of its four corners
+        const float ra = lxa - cb[c].ax, rb = lxb - cb[c].ax, rc = lya - cb[c].ay, rd = lyb - cb[c].ay;
+        const float Xa = ra * cb[c].fx, Xb = rb * cb[c].fx, Xc = rc * cb[c].fy, Xd = rd * cb[c].fy;        // X = rx fx + ry fy
+        const float Ya = -ra * cb[c].fy, Yb = -rb * cb[c].fy, Yc = rc * cb[c].fx, Yd = rd * cb[c].fx;      // Y = ry fx - rx fy
+        const float Xmin = __builtin_fminf(Xa, Xb) + __builtin_fminf(Xc, Xd), Xmax = __builtin_fmaxf(Xa, Xb) + __builtin_fmaxf(Xc, Xd);
+        const float Ymin = __builtin_fminf(Ya, Yb) + __builtin_fminf(Yc, Yd), Ymax = __builtin_fmaxf(Ya, Yb) + __builtin_fmaxf(Yc, Yd);
+        const float db = __builtin_fmaxf(__builtin_fmaxf(Xmin - cb[c].x_hi, cb[c].x_lo - Xmax), __builtin_fmaxf(Ymin - cb[c].y_hi, cb[c].y_lo - Ymax));
+        near = near || db < reach;
+      }
+      if (near) keep |= 1u << s;
     }
     strips &= keep;
     hit = strips != 0u;
@@ -1531,7 +1561,8 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? 4 : kPaths == 4 ? FDH_UNIFORM_WA
         // barycentric interpolation, as in make_frag().  F_EDGE32 (Recorder::emit_corners): every edge value any pixel of the frame
         // can produce fits 32 bits and the coefficients fit 24, so the strip's scalar base + two v_mad_i32_i24 per edge replace the
         // 64-bit arithmetic; quads beyond that keep the slot path.  Ownership is folded into the base (E - 1 >= 0 <=> E > 0).
-        FDH_COUNT(1);
+        FDH_COUNT(60);
+        if (core) FDH_COUNT(63);
         if (core && (mode == 9u || mode == 11u || mode == 12u)) return;
         const QuadExt& q = exts[r.ext];
         const int X0 = 2 * tx0 + 1, Y0 = 2 * ty0 + 1;
@@ -1732,8 +1763,9 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? 4 : kPaths == 4 ? FDH_UNIFORM_WA
             const float db = __builtin_fmaxf(__builtin_fabsf(X - ocx) - ohx, __builtin_fabsf(Y - ocy) - ohy);
             near = near || (cov[k] && db < reach);
           }
-          if (!__any(near)) return;
+          if (!__any(near)) { FDH_COUNT(62); return; }
         }
+        FDH_COUNT(61);
         float dist[4];
         sd_bezierN<4>(lx, ly, Ax, Ay, Bx, By, Cx, Cy, dist);
         float alpha[4];

@@ -7,13 +7,15 @@ import sys
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from figdraw_amd import context as ctx_mod  # noqa: E402
-from figdraw_amd.scenes import make_render_tree_100  # noqa: E402
+from figdraw_amd.scenes import make_curves_scene, make_render_tree_100, make_rotated_tree  # noqa: E402
 
 w, h = 3840, 2160
 ctx = ctx_mod.HipContext(device=0)
 L = ctx_mod.load()
 buf = (C.c_ulonglong * 64)()
-ctx.render_frame(make_render_tree_100(w, h, frame=0, full_frame_blur=True), w, h)
+which = sys.argv[1] if len(sys.argv) > 1 else "bench"  # bench | rotated | curves
+scene = {"bench": lambda: make_render_tree_100(w, h, frame=0, full_frame_blur=True), "rotated": lambda: make_rotated_tree(w, h, 0), "curves": lambda: make_curves_scene(w, h)}[which]()
+ctx.render_frame(scene, w, h)
 ctx.replay(5)
 ctx.sync()
 ctx.profile(5)
@@ -33,6 +35,8 @@ for m in range(32):
         print(f"fast mode {m:2d}: {c[8 + m]:10d}   of which cls1 {c[40 + (m & 15)] if m < 16 else 0:10d}")
 for i, n in ((32, "core: stroke no-op"), (33, "core: solid uniform blend"), (34, "core: other (gradient / push / blur)"),
              (35, "core: plain colour, record not fetched")):
+    print(f"{n:34s} {c[i]:10d}")
+for i, n in ((60, "rotated quad, 4-wide"), (63, "  of which core strips"), (61, "bezier, 4-wide: evaluated"), (62, "bezier, 4-wide: strip skipped")):
     print(f"{n:34s} {c[i]:10d}")
 for code, n in enumerate(("", "fill", "drop shadow", "inner shadow", "AA stroke", "fill, elliptical", "drop shadow, elliptical", "inner shadow, elliptical",
                           "AA stroke, elliptical")):
