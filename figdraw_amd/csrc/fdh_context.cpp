@@ -1008,6 +1008,8 @@ void Context::launch_frame(const LaunchJob& J, bool profile) {
   span_begin(0);
   BinParams B;
   B.binrec = dv_.binrecs; B.binbox = dv_.binbox; B.chunkbox = dv_.chunkbox; B.n_draws = J.n_recs; B.binbox_shift = binbox_shift_; B.lists = J.lists; B.counts = J.counts; B.phase_first = dv_.phase_first; B.draws = dv_.recs; B.exts = dv_.exts;
+  B.refine = 0;
+  for (const Phase& ph : J.phases) if (ph.has_rot || ph.has_slow) B.refine = 1;
   B.n_phases = np; B.bins_x = bins_x_; B.bins_y = bins_y_; B.stride = list_stride_;
   launch_bin(stream_, B);
   span_end();

@@ -17,6 +17,7 @@ struct BinParams {
   int n_phases, bins_x, bins_y, stride;
   const DrawRec* draws;    // the frame's records: the bin kernel pulls them into every XCD's L2 for the compositor (see k_bin_draws)
   const QuadExt* exts;     // the edge functions of rotated quads (BR_GENERAL draws: strips outside the quad are dropped from the entry)
+  int refine;              // the frame holds BR_GENERAL / BR_CURVE draws: the build of k_bin_draws with their per-strip tests
 };
 
 struct CompositeParams {

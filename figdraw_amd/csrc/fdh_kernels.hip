@@ -395,13 +395,16 @@ __device__ __forceinline__ uint32_t strip_mask_inside(int x0, int y0, int x1, in
 // x0 <= bx, y0 <= by, bx <= x1, by <= y1: one subtract, one and, one compare per draw.
 #if FDH_TU == 0
 __device__ __forceinline__ bool binbox_hits(uint32_t q, uint32_t U) { return ((U - q) & 0x80808080u) == 0x80808080u; }
+// (kRefine: the build for frames that hold bezier strokes or rotated quads -- their per-strip tests cost registers, 193 against 56,
+// which a frame without them should not pay in occupancy: bench frame 5.4 us against 8.7)
+template <bool kRefine>
 __device__ __forceinline__ void bin_entry(const BinParams& P, int i, int x0, int y0, bool& hit, uint32_t& word, uint32_t& strips) {
   const BinRec r = P.binrec[i];
   const BBox b = r.box;
   if (!(b.x0 < x0 + kBin && b.x1 > x0 && b.y0 < y0 + kBin && b.y1 > y0)) { hit = false; return; }  // exact test
   strips = strip_mask(b.x0 - x0, b.y0 - y0, b.x1 - x0, b.y1 - y0);
   word = (uint32_t)i | (r.flags & ~LE_INDEX);
-  if (r.flags & BR_CURVE) {
+  if (kRefine && (r.flags & BR_CURVE)) {
     // A bezier stroke: strips whose pixels are all farther from the chord-aligned box around the curve than sqrt 2 (half width +
     // 0.5 / aa) hold no coverage (see the 4-wide bezier path of k_composite_tiles, which applies the same bound per strip after
     // fetching the record; here the strip never sees the draw).  The strip's pixel-centre rectangle is mapped into the quad's local
@@ -416,7 +419,7 @@ __device__ __forceinline__ void bin_entry(const BinParams& P, int i, int x0, int
     curve_boxes2(Ax, Ay, Bx, By, Cx, Cy, cb);
     const float reach = 1.41422f * (__builtin_fmaxf(f0, 0.0f) * 0.5f + 0.5f / aa) + 0.05f;  // (+ slack for the kernels' own rounding of the coordinates)
     uint32_t keep = 0;
-#pragma unroll
+#pragma unroll 1
     for (int s = 0; s < 16; s++) {
       const int col = (s >> 2) & 1, row = (s >> 3) * 4 + (s & 3);
       const float cxa = (float)(x0 + col * kTileW) + 0.5f, cxb = cxa + (float)(kTileW - 1), cya = (float)(y0 + row * kTileH) + 0.5f, cyb = cya + (float)(kTileH - 1);
@@ -439,7 +442,7 @@ __device__ __forceinline__ void bin_entry(const BinParams& P, int i, int x0, int
     hit = strips != 0u;
     return;
   }
-  if (r.flags & BR_GENERAL) {
+  if (kRefine && (r.flags & BR_GENERAL)) {
     // A rotated quad: a strip all of whose pixel centres fail ONE of the quad's outer edges (bottom, left, right, top: edges 0 and 2
     // of triangle (TL, BL, BR), 1 and 2 of (TR, TL, BR)) holds no pixel of it.  The largest value an edge function takes on a
     // strip is at the corner its coefficients' signs pick; 32-bit arithmetic is exact here (F_EDGE32).
@@ -462,7 +465,7 @@ __device__ __forceinline__ void bin_entry(const BinParams& P, int i, int x0, int
                           __uint_as_float(wl1.z), __uint_as_float(wl1.w), __uint_as_float(wl2.x), __uint_as_float(wl2.y), __uint_as_float(wl2.z), __uint_as_float(wl2.w)};
     const bool has_core = cxr > cxl;
     uint32_t keep = 0, core = 0;
-#pragma unroll
+#pragma unroll 1
     for (int s = 0; s < 16; s++) {
       const int col = (s >> 2) & 1, row = (s >> 3) * 4 + (s & 3);
       bool out = false, in = has_core;
@@ -503,6 +506,7 @@ __device__ __forceinline__ void bin_entry(const BinParams& P, int i, int x0, int
   }
   strips |= core << 16;
 }
+template <bool kRefine>
 __global__ __launch_bounds__(64) void k_bin_draws(BinParams P) {
   const int nb = P.bins_x * P.bins_y;
   const int phase = blockIdx.x / nb, bin = blockIdx.x - phase * nb;
@@ -535,7 +539,7 @@ __global__ __launch_bounds__(64) void k_bin_draws(BinParams P) {
     for (uint32_t c = 0; c < queued; c += 64) {
       bool ok = c + lane < queued;
       uint32_t word = 0, strips = 0;
-      if (ok) bin_entry(P, hits[c + lane], x0, y0, ok, word, strips);  // a stroke may drop out
+      if (ok) bin_entry<kRefine>(P, hits[c + lane], x0, y0, ok, word, strips);  // a stroke may drop out
       const unsigned long long mb = __ballot(ok);
       if (ok) out[count + __builtin_popcountll(mb & lt)] = make_uint2(word, strips);
       count += __builtin_popcountll(mb);
@@ -3322,7 +3326,9 @@ bool launch_events_used() { return t_prof_used; }  // false: the launch_* call b
   } while (0)
 void launch_bin(hipStream_t s, const BinParams& P) {
   const int n = P.n_phases * P.bins_x * P.bins_y;
-  if (n > 0) FDH_LAUNCH(k_bin_draws, dim3(n), dim3(64), 0, s, P);
+  if (n <= 0) return;
+  if (P.refine) FDH_LAUNCH(k_bin_draws<true>, dim3(n), dim3(64), 0, s, P);
+  else FDH_LAUNCH(k_bin_draws<false>, dim3(n), dim3(64), 0, s, P);
 }
 void launch_composite(hipStream_t s, const DrawRec* draws, const QuadExt* exts, CompositeParams P) {
   const int n = P.bin_nx * P.bin_ny * kWgsPerBin;
