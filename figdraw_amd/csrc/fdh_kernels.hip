@@ -1074,6 +1074,9 @@ __device__ unsigned int g_edge_bad[4096 * 8];
 #ifndef FDH_ATLAS_WAVES
 #define FDH_ATLAS_WAVES 5  // waves per SIMD of the atlas build <2>
 #endif
+#ifndef FDH_ROT_ATLAS4
+#define FDH_ROT_ATLAS4 1  // 0 (experiment builds): rotated atlas quads stay on the one-pixel-slot path
+#endif
 #ifndef FDH_BEZIER4
 #define FDH_BEZIER4 1  // 0 (experiment builds): bezier strokes stay on the one-pixel-slot path with libm's functions
 #endif
@@ -1555,6 +1558,81 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? 4 : kPaths == 4 ? FDH_UNIFORM_WA
           blend(F, sr, sg, sb, (xrel + (uint32_t)k) < wcov ? sa : 0.0f);
         };
         pixel(0, F0, mk0, rm0); pixel(1, F1, mk1, rm1); pixel(2, F2, mk2, rm2); pixel(3, F3, mk3, rm3);
+        return;
+      }
+      if (kSlow && FDH_ROT_ATLAS4 && (om & F_GENERAL) != 0u && (om & F_EDGE32) != 0u && atlas_mode && op == OP_DRAW) {
+        // ---- rotated / skewed atlas quads (glyphs, images, MSDF under a rotated transform), four pixels per lane: the two-triangle
+        // coverage and barycentrics of the SDF block below, uv interpolated between the quad's atlas corners, then the sampling
+        // and shading shade_one() does per pixel slot (atlas.frag:284-318) -- unrolled, so the lane's sixteen (trilinear: thirty-two)
+        // texel fetches are in flight together.
+        FDH_COUNT(59);
+        const QuadExt& q = exts[r.ext];
+        const int X0 = 2 * tx0 + 1, Y0 = 2 * ty0 + 1;
+        const int dxl = 8 * (lane & 7), dyl = 2 * (lane >> 3);
+        int eb[2][3], a2[2][3], nb[2][3];
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+#pragma unroll
+          for (int k = 0; k < 3; k++) {
+            const int a = q.e[t][k].a, b = q.e[t][k].b;
+            nb[t][k] = (int)(((q.own >> (t * 3 + k)) & 1u) ^ 1u);
+            const int base = a * X0 + b * Y0 + (int)(uint32_t)(uint64_t)q.e[t][k].c - nb[t][k];  // (scalar)
+            eb[t][k] = __mul24(b, dyl) + (__mul24(a, dxl) + base);
+            a2[t][k] = 2 * a;
+          }
+        const bool valid0 = q.inv_sum[0] != 0.0f, valid1 = q.inv_sum[1] != 0.0f;
+        const bool solid = (om & F_SOLID) != 0u;
+        const bool rowc = py >= r.by0 && py < r.by1;
+        const F4 cBL = unpack255(r.col[0]), cBR = unpack255(r.col[1]), cTR = unpack255(r.col[2]), cTL = unpack255(r.col[3]);
+        const float uax = r.r[0], uay = r.r[1], utx = r.r[2], uty = r.r[3];
+        const uint32_t fill_mode = (om >> 9) & 7u;
+        const bool is_mtsdf = (mode == 14u || mode == 16u), is_stroke = (mode == 15u || mode == 16u);
+        float sr[4], sg[4], sb[4], sa[4];
+        bool cov[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const int e00 = eb[0][0] + k * a2[0][0], e01 = eb[0][1] + k * a2[0][1], e02 = eb[0][2] + k * a2[0][2];
+          const int e10 = eb[1][0] + k * a2[1][0], e11 = eb[1][1] + k * a2[1][1], e12 = eb[1][2] + k * a2[1][2];
+          const bool in0 = valid0 && ((e00 | e01 | e02) >= 0), in1 = valid1 && ((e10 | e11 | e12) >= 0);
+          const bool use1 = !in0 && in1;
+          cov[k] = rowc && px0 + k >= r.bx0 && px0 + k < r.bx1 && (in0 || in1);
+          const float is = use1 ? q.inv_sum[1] : q.inv_sum[0];
+          const float l0 = (float)((use1 ? e10 : e00) + (use1 ? nb[1][0] : nb[0][0])) * is;
+          const float l1 = (float)((use1 ? e11 : e01) + (use1 ? nb[1][1] : nb[0][1])) * is;
+          const float l2 = (float)((use1 ? e12 : e02) + (use1 ? nb[1][2] : nb[0][2])) * is;
+          // triangle 0 = (TL, BL, BR), triangle 1 = (TR, TL, BR): make_frag()'s corner table
+          const float u0 = use1 ? utx : uax, v0 = uay, u1 = uax, v1 = use1 ? uay : uty;
+          float u = l0 * u0 + l1 * u1 + l2 * utx;
+          const float v = l0 * v0 + l1 * v1 + l2 * uty;
+          F4 col = {cBL.x * inv255, cBL.y * inv255, cBL.z * inv255, cBL.w * inv255};
+          if (!solid) {
+            const float c0x = use1 ? cTR.x : cTL.x, c0y = use1 ? cTR.y : cTL.y, c0z = use1 ? cTR.z : cTL.z, c0w = use1 ? cTR.w : cTL.w;
+            const float c1x = use1 ? cTL.x : cBL.x, c1y = use1 ? cTL.y : cBL.y, c1z = use1 ? cTL.z : cBL.z, c1w = use1 ? cTL.w : cBL.w;
+            col.x = (l0 * c0x + l1 * c1x + l2 * cBR.x) * inv255;
+            col.y = (l0 * c0y + l1 * c1y + l2 * cBR.y) * inv255;
+            col.z = (l0 * c0z + l1 * c1z + l2 * cBR.z) * inv255;
+            col.w = (l0 * c0w + l1 * c1w + l2 * cBR.w) * inv255;
+          }
+          const float fwu = use1 ? q.fw_u[1] : q.fw_u[0], fwv = use1 ? q.fw_v[1] : q.fw_v[0], lod = use1 ? q.lod[1] : q.lod[0];
+          if (mode == 0u) {  // wave-uniform; atlas.frag:284-295
+            if (om & F_SUBPIXEL) u -= r.aux * frcp(__builtin_fmaxf((float)P.atlas.size, 1.0f));
+            const F4 t = atlas_sample(P.atlas, u, v, lod);
+            sr[k] = t.x * col.x; sg[k] = t.y * col.y; sb[k] = t.z * col.z; sa[k] = t.w * col.w;
+          } else {  // atlas.frag:296-318
+            const F4 fc = eval_fill_rec(r, col, fill_mode, u, v);
+            const F4 t = atlas_sample(P.atlas, u, v, 0.0f);  // textureLod(atlasTex, uv, 0.0)
+            const float sd = is_mtsdf ? t.w : median3(t.x, t.y, t.z);
+            const float unit = r.f0 * frcp(r.p0);  // pxRange / atlas size (atlas.frag:45-49)
+            const float spr = __builtin_fmaxf(0.5f * (unit * frcp(fwu) + unit * frcp(fwv)), 1.0f);
+            const float spd = spr * (sd - r.f1);
+            const float alpha = is_stroke ? clamp01(__builtin_fmaxf(r.p1, 0.0f) * 0.5f - __builtin_fabsf(spd) + 0.5f) : clamp01(spd + 0.5f);
+            sr[k] = fc.x; sg[k] = fc.y; sb[k] = fc.z; sa[k] = fc.w * alpha;
+          }
+        }
+        blend(F0, sr[0], sg[0], sb[0], cov[0] ? sa[0] * mk0 * rm0 : 0.0f);
+        blend(F1, sr[1], sg[1], sb[1], cov[1] ? sa[1] * mk1 * rm1 : 0.0f);
+        blend(F2, sr[2], sg[2], sb[2], cov[2] ? sa[2] * mk2 * rm2 : 0.0f);
+        blend(F3, sr[3], sg[3], sb[3], cov[3] ? sa[3] * mk3 * rm3 : 0.0f);
         return;
       }
       if (kRot && (om & F_GENERAL) != 0u && (om & F_EDGE32) != 0u && !atlas_mode && mode < 18u && (op == OP_DRAW || (kMasks && op == OP_MASK_PUSH))) {

@@ -233,7 +233,7 @@ def load_glyph_fixture(path):
 
 
 def make_glyph_scene(w: float, h: float, images, cols: int = 100, rows: int = 100, pitch=(38.0, 21.0), origin=(8.0, 6.0),
-                     msdf_size: float = 48.0) -> Renders:
+                     msdf_size: float = 48.0, rotation: float = 0.0) -> Renders:
     """BASELINE.json configs[3] "T10k@4K" (SURVEY.md 8d #4): cols x rows glyph quads (ASCII 33..126 cycling) over a
     3-stop gradient background; even cells are coverage glyphs from the atlas drawn 1:1 at integer positions with a
     2-stop vertical tint (mode 0, what renderText emits: figrender.nim:456-496), odd cells are MSDF images drawn
@@ -256,14 +256,14 @@ def make_glyph_scene(w: float, h: float, images, cols: int = 100, rows: int = 10
             if i % 2 == 0:
                 gh = images[1000 + code].shape[0]
                 glyphs.append(Glyph(image_id=1000 + code, x=float(x), y=float(20 - gh), colors=tint))
-        lst.addRoot(Fig(kind=FigKind.nkText, screenBox=rect(0, y, w, pitch[1]), glyphs=glyphs))
+        lst.addRoot(Fig(kind=FigKind.nkText, screenBox=rect(0, y, w, pitch[1]), glyphs=glyphs, rotation=rotation))  # (rotation: config 11 of tools/perf_configs.py)
         for c in range(cols):
             i = r * cols + c
             if i % 2 == 1:
                 code = 33 + i % 94
                 x = origin[0] + c * pitch[0]
                 lst.addRoot(Fig(kind=FigKind.nkMsdfImage, screenBox=rect(x - 6.0, y - 14.0, msdf_size, msdf_size),
-                                image_id=2000 + code, image_fill=fill(rgba(10, 90, 40, 230)), pxRange=4.0, sdThreshold=0.5))
+                                image_id=2000 + code, image_fill=fill(rgba(10, 90, 40, 230)), pxRange=4.0, sdThreshold=0.5, rotation=rotation * 3.0))
     out = Renders()
     out.setLayer(0, lst)
     return out

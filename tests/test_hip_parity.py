@@ -143,6 +143,27 @@ def test_rotated_tree_matches_oracle(w, h, copies, frame):
     ctx.close()
 
 
+@pytest.mark.parametrize("rotation", [2.0, -11.0, 90.0])
+def test_rotated_glyph_rows_match_oracle(rotation):
+    """Config 11 of tools/perf_configs.py in small: text rows (mode-0 glyph quads with a vertical tint) and MSDF images under a
+    rotated transform -- rotated atlas quads four pixels per lane (two-triangle coverage, barycentric uv between the atlas corners,
+    per-triangle LOD and fwidth) -- against the oracle."""
+    import os
+
+    from conftest import GOLDEN
+    from figdraw_amd.scenes import load_glyph_fixture, make_glyph_scene
+
+    w, h = 900, 500
+    imgs = load_glyph_fixture(os.path.join(GOLDEN, "glyphs_ubuntu20.npz"))
+    sc = make_glyph_scene(w, h, imgs, cols=22, rows=20, rotation=rotation)
+    ctx, o = _atlas_ctx_pair(sc, RS.used_images(sc, imgs), 1024)
+    ctx.render_frame(sc, w, h)
+    o.render_frame(sc, w, h)
+    mx, n0, n1 = diff_stats(ctx.read_pixels(), o.read_pixels())
+    assert mx <= 1 and n0 <= 0.005 * w * h, (rotation, mx, n0, n1)
+    ctx.close()
+
+
 @pytest.mark.parametrize("w,h,n,seed", [(1280, 720, 300, 7), (900, 700, 160, 11)])
 def test_curves_scene_matches_oracle(w, h, n, seed):
     """Stroked nkDrawable curves, lines and arcs (config 10 of tools/perf_configs.py): quadratic-bezier spans four pixels per lane

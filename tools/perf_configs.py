@@ -7,7 +7,7 @@ Configs 6 - 8 are the reference's OWN benchmark workloads (the only scenes it ti
 (180 x 10 cells, 1200 x 800) and examples/windy_clip_mask_benchmark.nim (clip + sub-clip / clip + rect-mask, 180 x 6 cells); for
 those the dynamic path (fdh_render_frame per frame, what the reference's loop times) is reported beside the replay figure.
 
-usage: python3 tools/perf_configs.py [only]     only = 1..10 : run just that config (for a rocprofv3 --kernel-trace --stats pass per config)"""
+usage: python3 tools/perf_configs.py [only]     only = 1..11 : run just that config (for a rocprofv3 --kernel-trace --stats pass per config)"""
 import json
 import os
 import sys
@@ -98,6 +98,16 @@ if only in (0, 6, 7, 8):
     if only in (0, 8):
         run("config8", "examples/windy_clip_mask_benchmark.nim, clip + rect-mask: the same table with NfRectMaskContent cells, 1200x800",
             ctx, make_clip_mask_benchmark("rect_mask"), 1200, 800)
+    ctx.close()
+if only in (0, 11):
+    imgs = load_glyph_fixture(os.path.join(ROOT, "tests", "golden", "glyphs_ubuntu20.npz"))
+    ctx = HipContext(atlas_size=1024, device=0)
+    sc = make_glyph_scene(3840, 2160, imgs, rotation=2.0)
+    used = RS.used_images(sc, imgs)
+    for k in sorted(used):
+        ctx.put_image(k, used[k])
+    run("config11", "T10k@4K rotated: config 4's glyph rows turned by 2 degrees about their centres, its MSDF images by 6: every atlas quad a rotated quad", ctx, sc, 3840, 2160,
+        oracle_kw={"atlas_size": 1024}, images=used)
     ctx.close()
 if only in (0, 9, 10):  # the compositor's one-pixel-slot build (<3>): rotated quads, bezier strokes -- SURVEY.md 8(a) a5 / f1
     ctx = HipContext(device=0)
