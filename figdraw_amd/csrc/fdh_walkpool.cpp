@@ -28,7 +28,13 @@ inline void relax() {
 }
 struct alignas(128) Shared {
   std::atomic<uint64_t> epoch{0};     // bumped once per group
-  std::atomic<int> next{0};           // the next chunk to hand out
+  // A chunk is claimed by whoever sets its flag first.  Slot s starts with its HOME chunks s, s + slots, s + 2 slots, ...: the
+  // same part of the same tree goes to the same thread frame after frame, whose core still holds those nodes (488 bytes each) and
+  // its recorder's state -- handed out first come first served, every chunk's nodes came from another core's cache or from memory,
+  // which on a host of many core complexes cost more than decomposing them.  A slot that has done its own then takes what others
+  // have not started (a viewport's visible rows all lie in the first chunks).
+  static constexpr int kMaxChunks = 512;
+  std::atomic<uint8_t> claimed[kMaxChunks];
   std::atomic<int> through{0};        // helper slots that have finished the current group
   std::atomic<int> asleep{0};         // helpers blocked on the condition variable
   int helpers = 0, n_chunks = 0;      // of the current group (written before the epoch is bumped)
@@ -38,6 +44,14 @@ struct alignas(128) Shared {
   bool quit = false;
 };
 }  // namespace
+
+static void take_chunks(Shared& sh, int slot, const std::function<void(int, int)>& fn) {
+  const int n = sh.n_chunks, slots = sh.helpers + 1;
+  for (int c = slot; c < n; c += slots)  // home chunks
+    if (sh.claimed[c].exchange(1, std::memory_order_acq_rel) == 0) fn(slot, c);
+  for (int c = 0; c < n; c++)            // then whatever nobody has started
+    if (sh.claimed[c].load(std::memory_order_relaxed) == 0 && sh.claimed[c].exchange(1, std::memory_order_acq_rel) == 0) fn(slot, c);
+}
 
 struct WalkPoolImpl {
   Shared sh;
@@ -64,11 +78,7 @@ struct WalkPoolImpl {
       seen = e;
       if (slot > sh.helpers) continue;  // this group uses fewer helpers
       const std::function<void(int, int)>& fn = *sh.fn;
-      for (;;) {
-        const int c = sh.next.fetch_add(1, std::memory_order_acq_rel);
-        if (c >= sh.n_chunks) break;
-        fn(slot, c);
-      }
+      take_chunks(sh, slot, fn);
       fn(slot, -1);
       sh.through.fetch_add(1, std::memory_order_acq_rel);
     }
@@ -108,7 +118,7 @@ int WalkPool::default_helpers() {
 
 bool WalkPool::run(int helpers, int n_chunks, const std::function<void(int, int)>& fn) {
   WalkPoolImpl& P = impl();
-  if (helpers <= 0 || n_chunks <= 0) return false;
+  if (helpers <= 0 || n_chunks <= 0 || n_chunks > Shared::kMaxChunks) return false;
   std::unique_lock<std::mutex> own(P.owner, std::try_to_lock);
   if (!own.owns_lock()) return false;
   helpers = std::min(helpers, 64);
@@ -120,18 +130,14 @@ bool WalkPool::run(int helpers, int n_chunks, const std::function<void(int, int)
   sh.helpers = helpers;
   sh.n_chunks = n_chunks;
   sh.fn = &fn;
-  sh.next.store(0, std::memory_order_relaxed);
+  for (int c = 0; c < n_chunks; c++) sh.claimed[c].store(0, std::memory_order_relaxed);
   sh.through.store(0, std::memory_order_relaxed);
   sh.epoch.fetch_add(1, std::memory_order_seq_cst);
   if (sh.asleep.load(std::memory_order_seq_cst) > 0) {
     std::lock_guard<std::mutex> lk(sh.mu);
     sh.cv.notify_all();
   }
-  for (;;) {  // the calling thread is slot 0
-    const int c = sh.next.fetch_add(1, std::memory_order_acq_rel);
-    if (c >= n_chunks) break;
-    fn(0, c);
-  }
+  take_chunks(sh, 0, fn);  // the calling thread is slot 0
   fn(0, -1);
   // every helper of this group passes through (one that slept through the work still bumps the counter when it wakes)
   while (sh.through.load(std::memory_order_acquire) < helpers) relax();

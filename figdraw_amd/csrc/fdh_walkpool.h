@@ -5,8 +5,8 @@
 namespace fdh {
 
 // One group at a time: run() hands chunk numbers 0 .. n_chunks - 1 to `fn` on up to `helpers` pool threads (slots 1 .. helpers)
-// and on the calling thread (slot 0), each slot taking the next chunk when it is done with its last; when a slot finds no chunk
-// left it is called once more with chunk = -1 (its chance to close what it kept per slot).  Returns when every slot is through;
+// and on the calling thread (slot 0) -- slot s its home chunks s, s + slots, ... first (the same nodes on the same core every frame),
+// then any chunk nobody has started; when a slot finds no chunk left it is called once more with chunk = -1 (its chance to close what it kept per slot).  Returns when every slot is through;
 // false, having done nothing, when another thread is using the pool (the caller then does the work itself).  `fn` must not throw.
 class WalkPool {
  public:
