@@ -216,8 +216,8 @@ __device__ __forceinline__ float acos_poly(float x) {
   const float f = fsqrt(__builtin_fmaxf(1.0f - a, 0.0f)) * p;
   return x < 0.0f ? 3.14159265358979f - f : f;
 }
-template <int N>
-__device__ __forceinline__ void sd_bezierN(const float* px, float py, float Ax, float Ay, float Bx, float By, float Cx, float Cy, float* out) {
+template <int N, bool kPerY>
+__device__ __forceinline__ void sd_bezierN(const float* px, const float* pyv, float Ax, float Ay, float Bx, float By, float Cx, float Cy, float* out) {
 #pragma clang fp contract(off)
   const float ax = Bx - Ax, ay = By - Ay;
   const float bx = Ax - 2.0f * Bx + Cx, by = Ay - 2.0f * By + Cy;
@@ -227,6 +227,7 @@ __device__ __forceinline__ void sd_bezierN(const float* px, float py, float Ax, 
     const float il = frcp(__builtin_fmaxf(bax * bax + bay * bay, 0.000001f));
 #pragma unroll
     for (int k = 0; k < N; k++) {
+      const float py = pyv[kPerY ? k : 0];
       const float h = clamp01(((px[k] - Ax) * bax + (py - Ay) * bay) * il);
       const float dx = px[k] - (Ax + bax * h), dy = py - (Ay + bay * h);
       out[k] = fsqrt(dx * dx + dy * dy);
@@ -242,10 +243,9 @@ __device__ __forceinline__ void sd_bezierN(const float* px, float py, float Ax, 
   const float kk = 1.0f / bb;
   const float kx = kk * (ax * bx + ay * by);
   const float aa2 = 2.0f * (ax * ax + ay * ay);
-  const float dy = Ay - py;
 #pragma unroll
   for (int k = 0; k < N; k++) {
-    const float dx = Ax - px[k];
+    const float dx = Ax - px[k], dy = Ay - pyv[kPerY ? k : 0];
     const float ky = kk * (aa2 + (dx * bx + dy * by)) / 3.0f;
     const float kz = kk * (dx * ax + dy * ay);
     const float p = ky - kx * kx;
@@ -1560,13 +1560,13 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? 4 : kPaths == 4 ? FDH_UNIFORM_WA
         pixel(0, F0, mk0, rm0); pixel(1, F1, mk1, rm1); pixel(2, F2, mk2, rm2); pixel(3, F3, mk3, rm3);
         return;
       }
-      if (kSlow && FDH_ROT_ATLAS4 && (om & F_GENERAL) != 0u && (om & F_EDGE32) != 0u && atlas_mode && op == OP_DRAW) {
-        // ---- rotated / skewed atlas quads (glyphs, images, MSDF under a rotated transform), four pixels per lane: the two-triangle
-        // coverage and barycentrics of the SDF block below, uv interpolated between the quad's atlas corners, then the sampling
-        // and shading shade_one() does per pixel slot (atlas.frag:284-318) -- unrolled, so the lane's sixteen (trilinear: thirty-two)
-        // texel fetches are in flight together.
-        FDH_COUNT(59);
-        const QuadExt& q = exts[r.ext];
+      // Two-triangle coverage and barycentrics of a rotated / skewed quad for the lane's four pixels (make_frag()'s arithmetic, 32-bit:
+      // F_EDGE32).  The quad is the reference's triangles (3,0,1) = (TL, BL, BR) and (2,3,1) = (TR, TL, BR) over per-vertex ceil'd
+      // corners (glcontext.nim:418-429); a pixel belongs to the first whose three edge functions -- exact integers in half-pixel
+      // units, top-left rule -- admit its centre.  An edge value is a scalar base per strip + two v_mad_i32_i24 per lane + one add per
+      // further pixel; ownership is folded into the base (E - 1 >= 0 <=> E > 0), so a triangle's inside test is one v_or3 and a sign
+      // test.  Out: L0..L2 = the hit triangle's barycentrics (edge value x 1 / (E0 + E1 + E2)), T1 = it is the second triangle.
+      auto tri_bary = [&](const QuadExt& q, float (&L0)[4], float (&L1)[4], float (&L2)[4], bool (&T1)[4], bool (&cov)[4]) __attribute__((always_inline)) {
         const int X0 = 2 * tx0 + 1, Y0 = 2 * ty0 + 1;
         const int dxl = 8 * (lane & 7), dyl = 2 * (lane >> 3);
         int eb[2][3], a2[2][3], nb[2][3];
@@ -1581,25 +1581,41 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? 4 : kPaths == 4 ? FDH_UNIFORM_WA
             a2[t][k] = 2 * a;
           }
         const bool valid0 = q.inv_sum[0] != 0.0f, valid1 = q.inv_sum[1] != 0.0f;
-        const bool solid = (om & F_SOLID) != 0u;
         const bool rowc = py >= r.by0 && py < r.by1;
-        const F4 cBL = unpack255(r.col[0]), cBR = unpack255(r.col[1]), cTR = unpack255(r.col[2]), cTL = unpack255(r.col[3]);
-        const float uax = r.r[0], uay = r.r[1], utx = r.r[2], uty = r.r[3];
-        const uint32_t fill_mode = (om >> 9) & 7u;
-        const bool is_mtsdf = (mode == 14u || mode == 16u), is_stroke = (mode == 15u || mode == 16u);
-        float sr[4], sg[4], sb[4], sa[4];
-        bool cov[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
           const int e00 = eb[0][0] + k * a2[0][0], e01 = eb[0][1] + k * a2[0][1], e02 = eb[0][2] + k * a2[0][2];
           const int e10 = eb[1][0] + k * a2[1][0], e11 = eb[1][1] + k * a2[1][1], e12 = eb[1][2] + k * a2[1][2];
           const bool in0 = valid0 && ((e00 | e01 | e02) >= 0), in1 = valid1 && ((e10 | e11 | e12) >= 0);
           const bool use1 = !in0 && in1;
+          T1[k] = use1;
           cov[k] = rowc && px0 + k >= r.bx0 && px0 + k < r.bx1 && (in0 || in1);
           const float is = use1 ? q.inv_sum[1] : q.inv_sum[0];
-          const float l0 = (float)((use1 ? e10 : e00) + (use1 ? nb[1][0] : nb[0][0])) * is;
-          const float l1 = (float)((use1 ? e11 : e01) + (use1 ? nb[1][1] : nb[0][1])) * is;
-          const float l2 = (float)((use1 ? e12 : e02) + (use1 ? nb[1][2] : nb[0][2])) * is;
+          L0[k] = (float)((use1 ? e10 : e00) + (use1 ? nb[1][0] : nb[0][0])) * is;
+          L1[k] = (float)((use1 ? e11 : e01) + (use1 ? nb[1][1] : nb[0][1])) * is;
+          L2[k] = (float)((use1 ? e12 : e02) + (use1 ? nb[1][2] : nb[0][2])) * is;
+        }
+      };
+      if (kSlow && FDH_ROT_ATLAS4 && (om & F_GENERAL) != 0u && (om & F_EDGE32) != 0u && atlas_mode && op == OP_DRAW) {
+        // ---- rotated / skewed atlas quads (glyphs, images, MSDF under a rotated transform), four pixels per lane: the two-triangle
+        // coverage and barycentrics of the SDF block below, uv interpolated between the quad's atlas corners, then the sampling
+        // and shading shade_one() does per pixel slot (atlas.frag:284-318) -- unrolled, so the lane's sixteen (trilinear: thirty-two)
+        // texel fetches are in flight together.
+        FDH_COUNT(59);
+        const QuadExt& q = exts[r.ext];
+        float L0[4], L1[4], L2[4];
+        bool T1[4], cov[4];
+        tri_bary(q, L0, L1, L2, T1, cov);
+        const bool solid = (om & F_SOLID) != 0u;
+        const F4 cBL = unpack255(r.col[0]), cBR = unpack255(r.col[1]), cTR = unpack255(r.col[2]), cTL = unpack255(r.col[3]);
+        const float uax = r.r[0], uay = r.r[1], utx = r.r[2], uty = r.r[3];
+        const uint32_t fill_mode = (om >> 9) & 7u;
+        const bool is_mtsdf = (mode == 14u || mode == 16u), is_stroke = (mode == 15u || mode == 16u);
+        float sr[4], sg[4], sb[4], sa[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const bool use1 = T1[k];
+          const float l0 = L0[k], l1 = L1[k], l2 = L2[k];
           // triangle 0 = (TL, BL, BR), triangle 1 = (TR, TL, BR): make_frag()'s corner table
           const float u0 = use1 ? utx : uax, v0 = uay, u1 = uax, v1 = use1 ? uay : uty;
           float u = l0 * u0 + l1 * u1 + l2 * utx;
@@ -1647,47 +1663,27 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? 4 : kPaths == 4 ? FDH_UNIFORM_WA
         if (core) FDH_COUNT(63);
         if (core && (mode == 9u || mode == 11u || mode == 12u)) return;
         const QuadExt& q = exts[r.ext];
-        const int X0 = 2 * tx0 + 1, Y0 = 2 * ty0 + 1;
-        const int dxl = 8 * (lane & 7), dyl = 2 * (lane >> 3);
-        int eb[2][3], a2[2][3], nb[2][3];
-#pragma unroll
-        for (int t = 0; t < 2; t++)
-#pragma unroll
-          for (int k = 0; k < 3; k++) {
-            const int a = q.e[t][k].a, b = q.e[t][k].b;
-            nb[t][k] = (int)(((q.own >> (t * 3 + k)) & 1u) ^ 1u);
-            const int base = a * X0 + b * Y0 + (int)(uint32_t)(uint64_t)q.e[t][k].c - nb[t][k];  // (scalar)
-            eb[t][k] = __mul24(b, dyl) + (__mul24(a, dxl) + base);
-            a2[t][k] = 2 * a;
-          }
-        const bool valid0 = q.inv_sum[0] != 0.0f, valid1 = q.inv_sum[1] != 0.0f;
+        float L0[4], L1[4], L2[4];
+        bool T1[4], cov[4];
+        tri_bary(q, L0, L1, L2, T1, cov);
         const bool solid = (om & F_SOLID) != 0u;
-        const bool rowc = py >= r.by0 && py < r.by1;
         const F4 cBL = unpack255(r.col[0]), cBR = unpack255(r.col[1]), cTR = unpack255(r.col[2]), cTL = unpack255(r.col[3]);
         const float qhx = r.p0, qhy = r.p1;
         float u[4], v[4], lx[4], nly[4];
-        bool cov[4];
         F4 col[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-          const int e00 = eb[0][0] + k * a2[0][0], e01 = eb[0][1] + k * a2[0][1], e02 = eb[0][2] + k * a2[0][2];
-          const int e10 = eb[1][0] + k * a2[1][0], e11 = eb[1][1] + k * a2[1][1], e12 = eb[1][2] + k * a2[1][2];
-          const bool in0 = valid0 && ((e00 | e01 | e02) >= 0), in1 = valid1 && ((e10 | e11 | e12) >= 0);
-          const bool use1 = !in0 && in1;
-          cov[k] = rowc && px0 + k >= r.bx0 && px0 + k < r.bx1 && (in0 || in1);
-          const float is = use1 ? q.inv_sum[1] : q.inv_sum[0];
           // tri 0 = (TL, BL, BR): u = l2, v = l1 + l2;  tri 1 = (TR, TL, BR): u = l0 + l2, v = l2   (uv corners are 0 / 1: the
           // products of make_frag()'s sums are exact)
-          const float la = (float)((use1 ? e10 : e01) + (use1 ? nb[1][0] : nb[0][1])) * is;
-          const float lb = (float)((use1 ? e12 : e02) + (use1 ? nb[1][2] : nb[0][2])) * is;
+          const bool use1 = T1[k];
+          const float la = use1 ? L0[k] : L1[k], lb = L2[k];
           const float sum = la + lb;
           u[k] = use1 ? sum : lb;
           v[k] = use1 ? lb : sum;
           if (solid) {
             col[k] = {cBL.x * inv255, cBL.y * inv255, cBL.z * inv255, cBL.w * inv255};
           } else {
-            const float lc = (float)((use1 ? e11 : e00) + (use1 ? nb[1][1] : nb[0][0])) * is;
-            const float l0 = use1 ? la : lc, l1 = use1 ? lc : la;
+            const float l0 = L0[k], l1 = L1[k];
             const float c0x = use1 ? cTR.x : cTL.x, c0y = use1 ? cTR.y : cTL.y, c0z = use1 ? cTR.z : cTL.z, c0w = use1 ? cTR.w : cTL.w;
             const float c1x = use1 ? cTL.x : cBL.x, c1y = use1 ? cTL.y : cBL.y, c1z = use1 ? cTL.z : cBL.z, c1w = use1 ? cTL.w : cBL.w;
             col[k].x = (l0 * c0x + l1 * c1x + lb * cBR.x) * inv255;
@@ -1809,7 +1805,7 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? 4 : kPaths == 4 ? FDH_UNIFORM_WA
         blend(F3, sr[3], sg[3], sb[3], cov[3] ? sa[3] * mk3 * rm3 : 0.0f);
         return;
       }
-      if (kSlow && FDH_BEZIER4 && mode >= 18u && mode <= 20u && (om & F_GENERAL) == 0u && op == OP_DRAW) {
+      if (kSlow && FDH_BEZIER4 && mode >= 18u && mode <= 20u && ((om & F_GENERAL) == 0u || (om & F_EDGE32) != 0u) && op == OP_DRAW) {
         // ---- quadratic-bezier strokes on upright quads (drawQuadraticBezierSdf, modes 18 - 20: atlas.frag:121-209, 321-336), four
         // pixels per lane.  The quad is the span's bounding box; most of it is far from the curve.  The curve lies in the hull of its
         // control points, inside the box aligned with its chord AC that reaches min(0, b.f) .. max(|AC|, b.f) along it and 0 .. b.g / 2
@@ -1817,17 +1813,52 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? 4 : kPaths == 4 ? FDH_UNIFORM_WA
         // mode (the square cap of mode 20 reaches that far past an end point), and a strip of such pixels skips the cubic.
         const float Ax = r.p2, Ay = r.p3, Bx = r.r[0], By = r.r[1], Cx = r.r[2], Cy = r.r[3];
         const float hw = __builtin_fmaxf(r.f0, 0.0f) * 0.5f;
-        float lx[4], u[4];
+        const bool general = (om & F_GENERAL) != 0u;  // wave-uniform: the stroke under a rotated transform (uv from the two-triangle barycentrics)
+        float lx[4], lyv[4], u[4], vv[4];
         bool cov[4];
-        const bool rowc = py >= r.by0 && py < r.by1;
-        const float t = (cy - r.oy) * r.inv_h;
+        F4 colv[4];
+        const F4 c0 = unpack255(r.col[0]);
+        if (general) {
+          float L0[4], L1[4], L2[4];
+          bool T1[4];
+          tri_bary(exts[r.ext], L0, L1, L2, T1, cov);
+          const F4 cBR = unpack255(r.col[1]), cTR = unpack255(r.col[2]), cTL = unpack255(r.col[3]);
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-          u[k] = (cx0 + (float)k - r.ox) * r.inv_w;
-          cov[k] = rowc && px0 + k >= r.bx0 && px0 + k < r.bx1;
+          for (int k = 0; k < 4; k++) {
+            const bool use1 = T1[k];
+            const float la = use1 ? L0[k] : L1[k], lb = L2[k], sum = la + lb;
+            u[k] = use1 ? sum : lb;
+            vv[k] = use1 ? lb : sum;
+            lx[k] = (u[k] - 0.5f) * 2.0f * r.p0;
+            lyv[k] = (vv[k] - 0.5f) * 2.0f * r.p1;
+            colv[k] = {c0.x * inv255, c0.y * inv255, c0.z * inv255, c0.w * inv255};
+            if (!(om & F_SOLID)) {
+              const float l0 = L0[k], l1 = L1[k];
+              const float c0x = use1 ? cTR.x : cTL.x, c0y = use1 ? cTR.y : cTL.y, c0z = use1 ? cTR.z : cTL.z, c0w = use1 ? cTR.w : cTL.w;
+              const float c1x = use1 ? cTL.x : c0.x, c1y = use1 ? cTL.y : c0.y, c1z = use1 ? cTL.z : c0.z, c1w = use1 ? cTL.w : c0.w;
+              colv[k].x = (l0 * c0x + l1 * c1x + lb * cBR.x) * inv255; colv[k].y = (l0 * c0y + l1 * c1y + lb * cBR.y) * inv255;
+              colv[k].z = (l0 * c0z + l1 * c1z + lb * cBR.z) * inv255; colv[k].w = (l0 * c0w + l1 * c1w + lb * cBR.w) * inv255;
+            }
+          }
+        } else {
+          const bool rowc = py >= r.by0 && py < r.by1;
+          const float t = (cy - r.oy) * r.inv_h;
+          local_x4(r, cx0, lx);
+          const float ly = -local_y_up(r, cy);
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            u[k] = (cx0 + (float)k - r.ox) * r.inv_w;
+            vv[k] = t;
+            lyv[k] = ly;
+            cov[k] = rowc && px0 + k >= r.bx0 && px0 + k < r.bx1;
+            colv[k] = {c0.x * inv255, c0.y * inv255, c0.z * inv255, c0.w * inv255};
+            if (!(om & F_SOLID)) {  // wave-uniform
+              const F4 br = unpack255(r.col[1]), tr = unpack255(r.col[2]), tl = unpack255(r.col[3]);
+              colv[k].x = tri_lerp(tl.x, c0.x, br.x, tr.x, u[k], t) * inv255; colv[k].y = tri_lerp(tl.y, c0.y, br.y, tr.y, u[k], t) * inv255;
+              colv[k].z = tri_lerp(tl.z, c0.z, br.z, tr.z, u[k], t) * inv255; colv[k].w = tri_lerp(tl.w, c0.w, br.w, tr.w, u[k], t) * inv255;
+            }
+          }
         }
-        local_x4(r, cx0, lx);
-        const float ly = -local_y_up(r, cy);
         float fx, fy, sx, sy, ex, ey;  // (wave-uniform: the record's alone)
         safe_normalize(Cx - Ax, Cy - Ay, 1.0f, 0.0f, fx, fy);
         {
@@ -1837,10 +1868,9 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? 4 : kPaths == 4 ? FDH_UNIFORM_WA
           const float ocx = 0.5f * (x_lo + x_hi), ohx = 0.5f * (x_hi - x_lo), ocy = 0.5f * (y_lo + y_hi), ohy = 0.5f * (y_hi - y_lo);
           const float reach = 1.41422f * (hw + 0.5f * frcp(r.aa)) + 0.01f;
           bool near = false;
-          const float ry = ly - Ay;
 #pragma unroll
           for (int k = 0; k < 4; k++) {
-            const float rx = lx[k] - Ax;
+            const float rx = lx[k] - Ax, ry = lyv[k] - Ay;
             const float X = rx * fx + ry * fy, Y = ry * fx - rx * fy;
             const float db = __builtin_fmaxf(__builtin_fabsf(X - ocx) - ohx, __builtin_fabsf(Y - ocy) - ohy);
             near = near || (cov[k] && db < reach);
@@ -1849,7 +1879,8 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? 4 : kPaths == 4 ? FDH_UNIFORM_WA
         }
         FDH_COUNT(61);
         float dist[4];
-        sd_bezierN<4>(lx, ly, Ax, Ay, Bx, By, Cx, Cy, dist);
+        if (general) sd_bezierN<4, true>(lx, lyv, Ax, Ay, Bx, By, Cx, Cy, dist);  // (wave-uniform)
+        else sd_bezierN<4, false>(lx, lyv, Ax, Ay, Bx, By, Cx, Cy, dist);
         float alpha[4];
         if (mode == 18u) {
 #pragma unroll
@@ -1860,12 +1891,12 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? 4 : kPaths == 4 ? FDH_UNIFORM_WA
           const float trim = mode == 20u ? hw : 0.0f;
 #pragma unroll
           for (int k = 0; k < 4; k++) {
-            const float start_proj = (lx[k] - Ax) * sx + (ly - Ay) * sy, end_proj = (lx[k] - Cx) * ex + (ly - Cy) * ey;
+            const float start_proj = (lx[k] - Ax) * sx + (lyv[k] - Ay) * sy, end_proj = (lx[k] - Cx) * ex + (lyv[k] - Cy) * ey;
             float tube = dist[k];
             if (mode == 20u) {  // wave-uniform
-              const float ta = __builtin_fminf(tube, __builtin_fabsf((lx[k] - Ax) * sy - (ly - Ay) * sx));
+              const float ta = __builtin_fminf(tube, __builtin_fabsf((lx[k] - Ax) * sy - (lyv[k] - Ay) * sx));
               tube = start_proj < 0.0f ? ta : tube;
-              const float tb = __builtin_fminf(tube, __builtin_fabsf((lx[k] - Cx) * ey - (ly - Cy) * ex));
+              const float tb = __builtin_fminf(tube, __builtin_fabsf((lx[k] - Cx) * ey - (lyv[k] - Cy) * ex));
               tube = end_proj > 0.0f ? tb : tube;
             }
             const float cap = __builtin_fmaxf(-start_proj - trim, end_proj - trim);
@@ -1873,16 +1904,9 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? 4 : kPaths == 4 ? FDH_UNIFORM_WA
           }
         }
         const uint32_t fill_mode = (om >> 9) & 7u;
-        const F4 c0 = unpack255(r.col[0]);
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-          F4 col = {c0.x * inv255, c0.y * inv255, c0.z * inv255, c0.w * inv255};
-          if (!(om & F_SOLID)) {  // wave-uniform
-            const F4 br = unpack255(r.col[1]), tr = unpack255(r.col[2]), tl = unpack255(r.col[3]);
-            col.x = tri_lerp(tl.x, c0.x, br.x, tr.x, u[k], t) * inv255; col.y = tri_lerp(tl.y, c0.y, br.y, tr.y, u[k], t) * inv255;
-            col.z = tri_lerp(tl.z, c0.z, br.z, tr.z, u[k], t) * inv255; col.w = tri_lerp(tl.w, c0.w, br.w, tr.w, u[k], t) * inv255;
-          }
-          const F4 fc = eval_fill_rec(r, col, fill_mode, u[k], t);
+          const F4 fc = eval_fill_rec(r, colv[k], fill_mode, u[k], vv[k]);
           const float mkk = k == 0 ? mk0 : k == 1 ? mk1 : k == 2 ? mk2 : mk3, rmk = k == 0 ? rm0 : k == 1 ? rm1 : k == 2 ? rm2 : rm3;
           F4& F = k == 0 ? F0 : k == 1 ? F1 : k == 2 ? F2 : F3;
           blend(F, fc.x, fc.y, fc.z, cov[k] ? fc.w * alpha[k] * mkk * rmk : 0.0f);

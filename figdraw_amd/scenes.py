@@ -189,7 +189,7 @@ def make_rotated_tree(w: float, h: float, frame: int = 0, copies: int = 100) -> 
     return out
 
 
-def make_curves_scene(w: float, h: float, n: int = 1500, seed: int = 7, only_kind: int = -1) -> Renders:
+def make_curves_scene(w: float, h: float, n: int = 1500, seed: int = 7, only_kind: int = -1, rotation: float = 0.0) -> Renders:
     """n stroked curves and lines (nkDrawable: quadratic beziers -> drawQuadraticBezierSdf, modes 18 - 20; lines -> rotated boxes;
     arcs with joins -> filled quads) scattered over the frame: config 10 of tools/perf_configs.py."""
     from .scene import StrokeCap, StrokeJoin, drawableArc, drawableBezier, drawableLine
@@ -213,7 +213,7 @@ def make_curves_scene(w: float, h: float, n: int = 1500, seed: int = 7, only_kin
         lst.addRoot(Fig(kind=FigKind.nkDrawable, screenBox=rect(x, y, 250, 190),
                         drawStroke=RenderStroke(weight=weight, fill=col, cap=[StrokeCap.scButt, StrokeCap.scRound, StrokeCap.scSquare][i % 3],
                                                 join=[StrokeJoin.sjBevel, StrokeJoin.sjMiter, StrokeJoin.sjRound][(i // 3) % 3]),
-                        drawOps=ops))
+                        drawOps=ops, rotation=rotation * (1 + i % 3)))
     out = Renders()
     out.setLayer(0, lst)
     return out

@@ -164,8 +164,8 @@ def test_rotated_glyph_rows_match_oracle(rotation):
     ctx.close()
 
 
-@pytest.mark.parametrize("w,h,n,seed", [(1280, 720, 300, 7), (900, 700, 160, 11)])
-def test_curves_scene_matches_oracle(w, h, n, seed):
+@pytest.mark.parametrize("w,h,n,seed,rotation", [(1280, 720, 300, 7, 0.0), (900, 700, 160, 11, 0.0), (1000, 640, 200, 5, 13.0)])
+def test_curves_scene_matches_oracle(w, h, n, seed, rotation):
     """Stroked nkDrawable curves, lines and arcs (config 10 of tools/perf_configs.py): quadratic-bezier spans four pixels per lane
     (hardware transcendentals, both cases of the cubic selected), strips far from a curve dropped at bin time, lines as rotated
     boxes, join quads -- against the oracle's libm evaluation, pixel by pixel.
@@ -181,7 +181,7 @@ def test_curves_scene_matches_oracle(w, h, n, seed):
     from figdraw_amd.scenes import make_curves_scene
     from oracle import oracle as O
 
-    sc = make_curves_scene(w, h, n=n, seed=seed)
+    sc = make_curves_scene(w, h, n=n, seed=seed, rotation=rotation)  # (rotation: the drawables under rotated transforms -- bezier quads as rotated quads)
     ctx = HipContext(device=0)
     ctx.render_frame(sc, w, h)
     got = ctx.read_pixels()
