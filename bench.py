@@ -103,7 +103,9 @@ def run_stripes(args, dist, rank, local_rank, world, on_host):
         ctxs.append(c)
     for c in ctxs:
         c.sync()
-    use_c_abi = args.gather == "c_abi" and not on_host
+    # (under gloo the library's gather only runs when a transport is named explicitly: FDH_RCCL_LIB -- the tests' stand-in for RCCL, which
+    # refuses two ranks on one device)
+    use_c_abi = args.gather == "c_abi" and (not on_host or bool(os.environ.get("FDH_RCCL_LIB")))
     use_host = args.gather == "host"
     dev = "cpu" if on_host else f"cuda:{local_rank}"
     gather_s = [0.0]
@@ -579,7 +581,7 @@ def main():
         watchdog.daemon = True
         watchdog.start()
         try:
-            use_c_abi = args.gather == "c_abi" and not on_host
+            use_c_abi = args.gather == "c_abi" and (not on_host or bool(os.environ.get("FDH_RCCL_LIB")))
             if use_c_abi:
                 setup_comm(ctxs, dist, rank, world)
                 rccl_ranks_seen = ctxs[0].comm_info()[1]

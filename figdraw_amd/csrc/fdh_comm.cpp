@@ -36,6 +36,8 @@ struct Rccl {
   ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;      // (optional: what the communicator itself reports, fdh_comm_info)
+  ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
 };
 Rccl& rccl() {
   static Rccl R;
@@ -43,7 +45,8 @@ Rccl& rccl() {
   std::call_once(once, [] {
     const char* env = std::getenv("FDH_RCCL_LIB");
     const char* names[] = {env, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-    for (const char* n : names) {  // a copy the process already holds (a PyTorch host brings its own) is taken first
+    if (env && *env) R.lib = dlopen(env, RTLD_NOW | RTLD_LOCAL);  // a library named explicitly wins (RTLD_LOCAL: its symbols stay its own)
+    for (const char* n : names) {  // otherwise a copy the process already holds (a PyTorch host brings its own) is taken first
       if (n && !R.lib) R.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
     }
     for (const char* n : names) {
@@ -59,6 +62,8 @@ Rccl& rccl() {
     R.Send = reinterpret_cast<decltype(R.Send)>(sym("ncclSend"));
     R.Recv = reinterpret_cast<decltype(R.Recv)>(sym("ncclRecv"));
     R.GetErrorString = reinterpret_cast<decltype(R.GetErrorString)>(sym("ncclGetErrorString"));
+    R.CommCount = reinterpret_cast<decltype(R.CommCount)>(sym("ncclCommCount"));
+    R.CommUserRank = reinterpret_cast<decltype(R.CommUserRank)>(sym("ncclCommUserRank"));
   });
   if (!R.lib || !R.GetUniqueId || !R.CommInitRank || !R.CommDestroy || !R.GroupStart || !R.GroupEnd || !R.Send || !R.Recv)
     throw Error(FDH_ERR_UNSUPPORTED, "librccl could not be loaded (set FDH_RCCL_LIB to its path): the multi-GPU gather needs RCCL");
@@ -115,9 +120,15 @@ void Context::comm_init(const uint8_t id_bytes[FDH_COMM_ID_BYTES], int rank, int
   FDH_NCCL(rccl().CommInitRank(&c, world, id, rank));
   auto sc = std::make_shared<SharedComm>();
   sc->comm = c;
+  // fdh_comm_info reports what the COMMUNICATOR says about itself, not what the caller asked for: a bench line that prints N ranks
+  // then proves RCCL saw N (a communicator that disagrees with the request is refused)
+  int seen_world = world, seen_rank = rank;
+  if (rccl().CommCount) FDH_NCCL(rccl().CommCount(c, &seen_world));
+  if (rccl().CommUserRank) FDH_NCCL(rccl().CommUserRank(c, &seen_rank));
+  if (seen_world != world || seen_rank != rank) throw Error(FDH_ERR_HIP, "comm_init: the communicator reports another size / rank than it was created with");
   comm_ = std::static_pointer_cast<void>(sc);
-  comm_rank_ = rank;
-  comm_world_ = world;
+  comm_rank_ = seen_rank;
+  comm_world_ = seen_world;
 }
 // Several contexts of one process (frames in flight) use ONE communicator: the others borrow the owner's (a shared reference:
 // the communicator is destroyed when its last holder lets go, in whichever order the contexts are destroyed).  RCCL runs a

@@ -1,6 +1,7 @@
 """CPU suite, part 2: the C-ABI library loads and exports every symbol include/figdraw_hip.h declares (no compute
 calls without a GPU), fails loudly without a device, and the N>1 sharding path works over gloo (world_size 2)."""
 import ctypes as C
+import json
 import os
 import re
 import subprocess
@@ -413,6 +414,47 @@ def test_bench_stripes_mode_two_ranks_gathers_the_frame():
     assert sum(d["config"]["rows_per_rank"]) == 1080
     assert d["gathered_frame_check"]["parity_max_lsb"] <= 1 and d["gathered_frame_check"]["parity_pixels_differing"] < 0.005 * 1920 * 1080
     assert d["value"] > 0 and d["gather_ms"] > 0
+
+
+def _mock_rccl():
+    """tests/mock/mock_rccl.c -> build/libmock_rccl.so: the stand-in transport for the RCCL entry points fdh_comm.cpp binds"""
+    out = os.path.join(ROOT, "build", "libmock_rccl.so")
+    src = os.path.join(ROOT, "tests", "mock", "mock_rccl.c")
+    if not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        subprocess.check_call(["gcc", "-O2", "-shared", "-fPIC", "-w", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", src, "-o", out, "-L/opt/rocm/lib", "-lamdhip64",
+                               "-lrt", "-Wl,-rpath,/opt/rocm/lib"])
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["stripes", "frames"])
+def test_the_librarys_gather_between_two_ranks_over_a_stand_in_transport(mode):
+    """The N > 1 branch of fdh_gather_stripes / fdh_gather_frames EXECUTED: two processes on device 0 (RCCL itself refuses that:
+    "Duplicate GPU detected", tools/rccl_probe.py), the library bound to tests/mock/mock_rccl.c through FDH_RCCL_LIB -- sends are
+    device-to-host copies into shared-memory mailboxes, receives the copies out.  What this proves is the library's side: which
+    rows each rank sends, the in-place receives into rank 0's surface, four contexts per rank sharing one communicator (the lock,
+    the issue order), fdh_comm_info reporting the communicator's own size.  It says nothing about RCCL or xGMI.  bench.py checks
+    the assembled frame against the oracle (stripes) / every gathered frame for unwritten pixels (frames)."""
+    env_lib = {"FDH_RCCL_LIB": _mock_rccl()}
+    old = {k: os.environ.get(k) for k in env_lib}
+    os.environ.update(env_lib)
+    try:
+        if mode == "stripes":
+            d = _run_bench_two_ranks(["--mode", "stripes", "--gather", "c_abi", "--width", "1920", "--height", "1080", "--steps", "9", "--warmup", "2"], 29541)
+            assert d["n_gpus"] == 2 and "fdh_gather_stripes" in d["config"]["gather"] and d["config"]["rccl_ranks_seen"] == 2
+            assert sum(d["config"]["rows_per_rank"]) == 1080
+            assert d["gathered_frame_check"]["parity_max_lsb"] <= 1 and d["gathered_frame_check"]["parity_pixels_differing"] < 0.005 * 1920 * 1080
+        else:
+            d = _run_bench_two_ranks(["--gather", "c_abi", "--width", "1280", "--height", "720", "--steps", "8", "--warmup", "2", "--no-cpu-baseline"], 29543)
+            assert d["n_gpus"] == 2 and "fdh_gather_frames" in json.dumps(d) and d["frames_in_flight_check"]["pixels_differing"] == 0
+        assert d["value"] > 0 and d["gather_ms"] > 0
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
 
 
 @pytest.mark.gpu
