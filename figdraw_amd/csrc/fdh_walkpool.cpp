@@ -7,7 +7,13 @@
 // has just worked spins for a while before it sleeps: waking a sleeping thread costs more than a group's walk.
 #include "fdh_walkpool.h"
 
+#include <pthread.h>
+#include <sched.h>
+
 #include <atomic>
+#include <cstdio>
+#include <cstring>
+#include <string>
 #include <chrono>
 #include <condition_variable>
 #include <cstdlib>
@@ -44,6 +50,50 @@ struct alignas(128) Shared {
   bool quit = false;
 };
 }  // namespace
+
+// Where the helpers run.  A group's chunks read the same node array and write lanes the calling thread reads back microseconds
+// later: on a host of many core complexes (the pool's boxes: 256 hardware threads, 16-thread complexes) a helper the scheduler
+// put on another complex -- or the other socket -- took 2 - 5x as long over the same 44 records as the calling thread
+// (FDH_WALK_TRACE: 3.1 us against 4 - 18), and a group ends with its slowest chunk.  Helpers are therefore confined to the hardware
+// threads that share a last-level cache with the thread that first used the pool (Linux: cpuN/cache/index3/shared_cpu_list),
+// that thread's own core left out.  An affinity MASK, not a pin: the scheduler still places them.  FDH_WALK_AFFINITY=0, a list
+// that cannot be read, or one too short for the helpers: no mask.
+#if defined(__linux__)
+static bool parse_cpu_list(const char* path, cpu_set_t& out) {
+  CPU_ZERO(&out);
+  FILE* f = std::fopen(path, "r");
+  if (!f) return false;
+  char buf[1024];
+  const bool ok = std::fgets(buf, sizeof buf, f) != nullptr;
+  std::fclose(f);
+  if (!ok) return false;
+  for (const char* p = buf; *p && *p != '\n';) {
+    char* e;
+    const long a = std::strtol(p, &e, 10);
+    if (e == p) break;
+    long b = a;
+    p = e;
+    if (*p == '-') { b = std::strtol(p + 1, &e, 10); p = e; }
+    for (long c = a; c <= b && c < CPU_SETSIZE; c++) CPU_SET((int)c, &out);
+    if (*p == ',') p++;
+  }
+  return CPU_COUNT(&out) > 0;
+}
+static bool helper_mask(int helpers, cpu_set_t& mask) {
+  if (const char* e = std::getenv("FDH_WALK_AFFINITY")) if (std::atoi(e) == 0) return false;
+  const int cpu = sched_getcpu();
+  if (cpu < 0) return false;
+  cpu_set_t allowed, sibs;
+  if (sched_getaffinity(0, sizeof allowed, &allowed) != 0) return false;
+  const std::string base = "/sys/devices/system/cpu/cpu" + std::to_string(cpu);
+  if (!parse_cpu_list((base + "/cache/index3/shared_cpu_list").c_str(), mask)) return false;
+  CPU_AND(&mask, &mask, &allowed);
+  if (parse_cpu_list((base + "/topology/thread_siblings_list").c_str(), sibs)) {  // the caller keeps its core to itself
+    for (int c = 0; c < CPU_SETSIZE; c++) if (CPU_ISSET(c, &sibs)) CPU_CLR(c, &mask);
+  } else CPU_CLR(cpu, &mask);
+  return CPU_COUNT(&mask) >= helpers;
+}
+#endif
 
 static void take_chunks(Shared& sh, int slot, const std::function<void(int, int)>& fn) {
   const int n = sh.n_chunks, slots = sh.helpers + 1;
@@ -122,9 +172,18 @@ bool WalkPool::run(int helpers, int n_chunks, const std::function<void(int, int)
   std::unique_lock<std::mutex> own(P.owner, std::try_to_lock);
   if (!own.owns_lock()) return false;
   helpers = std::min(helpers, 64);
-  while ((int)P.threads.size() < helpers) {
-    const int slot = (int)P.threads.size() + 1;
-    P.threads.emplace_back([&P, slot] { P.helper_main(slot); });
+  if ((int)P.threads.size() < helpers) {
+#if defined(__linux__)
+    cpu_set_t mask;
+    const bool masked = helper_mask(helpers, mask);
+#endif
+    while ((int)P.threads.size() < helpers) {
+      const int slot = (int)P.threads.size() + 1;
+      P.threads.emplace_back([&P, slot] { P.helper_main(slot); });
+#if defined(__linux__)
+      if (masked) (void)pthread_setaffinity_np(P.threads.back().native_handle(), sizeof mask, &mask);
+#endif
+    }
   }
   Shared& sh = P.sh;
   sh.helpers = helpers;
