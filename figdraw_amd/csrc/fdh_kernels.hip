@@ -887,15 +887,16 @@ __device__ __forceinline__ void shape_distNy(bool ellip, const float* px, const 
   // length(max(q, 0)) only needs the (quarter-rate) sqrt where BOTH components are positive, i.e. in the corner
   // arcs; elsewhere it is max(qx, qy, 0).  One wave-uniform branch skips the sqrt for every strip without an arc.
   const bool any_diag = __any(diag);
+  // (min(max(q.x, q.y), 0) + length(max(q, 0)) = (both components positive ? |q| : max(q.x, q.y)), exactly: see dist4 in
+  // k_composite_tiles)
 #pragma unroll
   for (int k = 0; k < N; k++) {
-    const float mx = __builtin_fmaxf(qx[k], 0.0f), my = __builtin_fmaxf(qy[k], 0.0f);
-    float len = __builtin_fmaxf(mx, my);
+    float m = __builtin_fmaxf(qx[k], qy[k]);
     if (any_diag) {  // wave-uniform
-      const float e = fsqrt(mx * mx + my * my);
-      len = (mx > 0.0f && my > 0.0f) ? e : len;
+      const float e = fsqrt(qx[k] * qx[k] + qy[k] * qy[k]);
+      m = (qx[k] > 0.0f && qy[k] > 0.0f) ? e : m;
     }
-    out[k] = __builtin_fminf(__builtin_fmaxf(qx[k], qy[k]), 0.0f) + len - c[k].rx;
+    out[k] = m - c[k].rx;
   }
   if (!ellip) return;  // wave-uniform
   const bool any_ellipse = __any(need);
@@ -1238,18 +1239,19 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? 4 : kPaths == 4 ? FDH_UNIFORM_WA
       const f2 axa = {__builtin_fabsf(pxa.x), __builtin_fabsf(pxa.y)}, axb = {__builtin_fabsf(pxb.x), __builtin_fabsf(pxb.y)};
       const f2 qxa = axa - bx + rra, qxb = axb - bx + rrb;
       const f2 qya = ay + rra, qyb = ay + rrb;
-      const f2 mxa = {__builtin_fmaxf(qxa.x, 0.0f), __builtin_fmaxf(qxa.y, 0.0f)}, mxb = {__builtin_fmaxf(qxb.x, 0.0f), __builtin_fmaxf(qxb.y, 0.0f)};
-      const f2 mya = {__builtin_fmaxf(qya.x, 0.0f), __builtin_fmaxf(qya.y, 0.0f)}, myb = {__builtin_fmaxf(qyb.x, 0.0f), __builtin_fmaxf(qyb.y, 0.0f)};
-      f2 lena = {__builtin_fmaxf(mxa.x, mya.x), __builtin_fmaxf(mxa.y, mya.y)}, lenb = {__builtin_fmaxf(mxb.x, myb.x), __builtin_fmaxf(mxb.y, myb.y)};
+      // sdRoundedBox: min(max(q.x, q.y), 0) + length(max(q, 0)) - r.  With m = max(q.x, q.y): outside the corner cells (not both
+      // components positive) length(max(q, 0)) = max(m, 0), and min(m, 0) + max(m, 0) = m exactly (one of the two is 0); in a corner
+      // cell both components are positive, so max(q, 0) = q and the first term is 0.  So the distance is (corner ? |q| : m) - r,
+      // bit for bit what the three-term form gives, in seven instructions per pixel instead of thirteen where no lane of the
+      // strip sits in a corner cell (round 4).
+      f2 ma = {__builtin_fmaxf(qxa.x, qya.x), __builtin_fmaxf(qxa.y, qya.y)}, mb = {__builtin_fmaxf(qxb.x, qyb.x), __builtin_fmaxf(qxb.y, qyb.y)};
       const f2 lowa = {__builtin_fminf(qxa.x, qya.x), __builtin_fminf(qxa.y, qya.y)}, lowb = {__builtin_fminf(qxb.x, qyb.x), __builtin_fminf(qxb.y, qyb.y)};
       if (__any(lowa.x > 0.0f || lowa.y > 0.0f || lowb.x > 0.0f || lowb.y > 0.0f)) {  // some lane sits in a corner cell
-        const f2 sa2 = mxa * mxa + mya * mya, sb2 = mxb * mxb + myb * myb;
-        lena.x = lowa.x > 0.0f ? fsqrt(sa2.x) : lena.x; lena.y = lowa.y > 0.0f ? fsqrt(sa2.y) : lena.y;
-        lenb.x = lowb.x > 0.0f ? fsqrt(sb2.x) : lenb.x; lenb.y = lowb.y > 0.0f ? fsqrt(sb2.y) : lenb.y;
+        const f2 sa2 = qxa * qxa + qya * qya, sb2 = qxb * qxb + qyb * qyb;
+        ma.x = lowa.x > 0.0f ? fsqrt(sa2.x) : ma.x; ma.y = lowa.y > 0.0f ? fsqrt(sa2.y) : ma.y;
+        mb.x = lowb.x > 0.0f ? fsqrt(sb2.x) : mb.x; mb.y = lowb.y > 0.0f ? fsqrt(sb2.y) : mb.y;
       }
-      const f2 ina = {__builtin_fminf(__builtin_fmaxf(qxa.x, qya.x), 0.0f), __builtin_fminf(__builtin_fmaxf(qxa.y, qya.y), 0.0f)};
-      const f2 inb = {__builtin_fminf(__builtin_fmaxf(qxb.x, qyb.x), 0.0f), __builtin_fminf(__builtin_fmaxf(qxb.y, qyb.y), 0.0f)};
-      da = ina + lena - rra; db = inb + lenb - rrb;
+      da = ma - rra; db = mb - rrb;
     };
     // elliptical corners (atlas.frag:96-115): the distance itself comes from the general routine, four pixels
     // unpacked; coverage and blend below stay packed
