@@ -1146,8 +1146,15 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? 4 : kPaths == 4 ? FDH_UNIFORM_WA
   const int bin = bin_y * P.bins_x + bin_x;
   const int tx0 = bin_x * kBin + (j & 1) * kWgW;
   const int ty0 = bin_y * kBin + (j >> 1) * kWgH + wave * kTileH;
-  if (tx0 >= P.W || ty0 >= P.H) return;
-  if (ty0 + kTileH <= P.row_lo || ty0 >= P.row_hi) return;
+  // (four plain scalar compare-and-branch pairs: written with ||, each pair became two s_cselect_b64 masks, an s_and_b64 and a vcc branch)
+  // (the empty asm statements keep the compiler from folding the four exits back into that form)
+  if (tx0 >= P.W) return;
+  asm volatile("");
+  if (ty0 >= P.H) return;
+  asm volatile("");
+  if (ty0 + kTileH <= P.row_lo) return;
+  asm volatile("");
+  if (ty0 >= P.row_hi) return;
   const int tx1 = tx0 + kTileW, ty1 = ty0 + kTileH;
   const int px0 = tx0 + (lane & 7) * 4, py = ty0 + (lane >> 3);
   // The clip stack: levels 0 .. kMaskDepth - 1 in LDS; deeper nesting (the reference has no limit: one mask plane per level,
