@@ -30,6 +30,20 @@ static std::atomic<int64_t> g_last_submit_ns[kSubmitSlots];
 static std::atomic<int> g_next_submit_slot{0};
 
 // ------------------------------------------------------------------ lifetime
+// Staging in device memory (HostVec::vram): when the device exposes all of its memory to the host (large BAR: every MI355X box of
+// the pool) the recording threads write the frame's records straight into HBM and the gather kernel reads them locally.
+// FDH_VRAM_STAGING=0 keeps pinned host memory (the path for devices without a large BAR), =1 forces device memory.
+bool vram_staging() {
+  static const bool on = [] {
+    if (const char* e = std::getenv("FDH_VRAM_STAGING")) return std::atoi(e) != 0;
+    int dev = 0, large = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    if (hipDeviceGetAttribute(&large, hipDeviceAttributeIsLargeBar, dev) != hipSuccess) return false;
+    return large != 0;
+  }();
+  return on;
+}
+
 Context::Context(int atlas_size, float pixel_scale, int device, uint32_t flags) : Recorder(this, true), device_(device), flags_(flags), pixel_scale_(pixel_scale) {
   host_only_ = (flags & FDH_CREATE_RECORD_ONLY) != 0;
   if (host_only_) {  // a call recorder: the front-end and the atlas packer run, nothing is drawn, no device is touched
@@ -742,11 +756,11 @@ void Context::prepare(LaunchJob& J) {
     }
   HostVec<uint8_t>& up_misc = misc_[slot];
   up_misc.pinned = true;
+  up_misc.vram = vram_staging();
   up_misc.n = 0;
   up_misc.reserve(misc.size());
   // ---- the runs k_upload_frame gathers.  Every piece brings three: its records (extension indices re-based on the way), its bin
   // records, its extensions; then the phase table (+ tables).  A frame recorded by one thread is one piece.
-  auto dev_view = [](const void* host) { void* d = nullptr; FDH_HIP(hipHostGetDevicePointer(&d, const_cast<void*>(host), 0)); return (const uint8_t*)d; };
   if (pieces_.size() * 3 + 2 > (size_t)kMaxUploadRuns) consolidate_pieces();  // (more pieces than the kernel-argument table holds: copy them together)
   // device views of the lanes' mirrors (taken by whoever allocated them), index lane + 1 (slot 0: the consolidated lane)
   const size_t n_lanes = lanes_[(size_t)slot].size() + 1;
@@ -756,7 +770,7 @@ void Context::prepare(LaunchJob& J) {
     const Lane& Ln = lane(p.lane);
     d_recs[l] = Ln.d_recs; d_bins[l] = Ln.d_bins; d_exts[l] = Ln.d_exts;
   };
-  if (up_misc.p != misc_dev_host_[slot]) { misc_dev_[slot] = dev_view(up_misc.p); misc_dev_host_[slot] = up_misc.p; }
+  if (up_misc.p != misc_dev_host_[slot]) { misc_dev_[slot] = up_misc.device_view(); misc_dev_host_[slot] = up_misc.p; }
   const uint8_t* d_misc = misc_dev_[slot];
   J.runs.clear();
   auto add_run = [&](std::vector<UploadRun>& to, const uint8_t* src, size_t dst_off, size_t bytes, uint32_t ext_add, uint32_t kind) {
@@ -895,6 +909,7 @@ void Context::prepare(LaunchJob& J) {
   stats_.bytes_frame_implementation = bytes - bytes_saved;
   stats_.fragments = fragments_;
   if (folded) folded_br->box = folded_box;  // (the recorded frame stays what the calls produced)
+  if (vram_staging()) store_fence();  // (what this thread wrote into device memory is on its way before the launches are)
   const auto t_l0 = std::chrono::steady_clock::now();
   stats_.ms_host_record = host_record_ms_;
   stats_.ms_host_upload = std::chrono::duration<float, std::milli>(t_l0 - t_s0).count();

@@ -83,17 +83,33 @@ struct PinnedBuf {
 // Pinned memory is written once, front to back, and never read by the CPU: on this platform the CPU's loads from it are not
 // served from its caches (a record read back from a pinned lane cost ~100 ns; round 4 measured 82 us for a 700-record frame that
 // took 4 us from ordinary memory).  Growth copies what the array holds (doubling: rare once a context has seen its scene).
+//
+// `vram` (with `pinned`): the same role in DEVICE memory the host writes through the PCIe BAR.  On the MI355X boxes all of HBM is
+// host-addressable (large BAR): the CPU's stores into a hipExtMallocWithFlags(hipDeviceMallocUncached) block are write-combined
+// posted writes (measured: 128 KB in 3.2 us = 41 GB/s, tools/microbench/bar_write.hip) and the GPU reads what they wrote from its
+// own memory instead of fetching it over the link with a round trip per lane: k_upload_frame 7.1 -> ~3 us.  Write-only for the
+// CPU -- a load from it crosses the link uncached -- so growth does NOT carry contents over (callers set n = 0 first, as the pinned
+// mirrors always did), and a store fence (store_fence()) precedes the hand-over to whoever launches the kernels.
+bool vram_staging();  // large-BAR device and FDH_VRAM_STAGING != 0 (fdh_context.cpp)
+inline void store_fence() {
+#if defined(__x86_64__) || defined(__i386__)
+  __builtin_ia32_sfence();
+#else
+  __sync_synchronize();
+#endif
+}
 template <typename T>
 struct HostVec {
   T* p = nullptr;
   size_t n = 0, cap = 0;
-  bool pinned = false;
+  bool pinned = false, vram = false;
   HostVec() = default;
   HostVec(const HostVec&) = delete;
   HostVec& operator=(const HostVec&) = delete;
   ~HostVec() { release(); }
+  void free_block(T* q) { if (!q) return; if (pinned && vram) (void)hipFree(q); else if (pinned) (void)hipHostFree(q); else std::free(q); }
   void release() {
-    if (p) { if (pinned) (void)hipHostFree(p); else std::free(p); }
+    free_block(p);
     p = nullptr; n = cap = 0;
   }
   void reserve(size_t want) {
@@ -101,11 +117,20 @@ struct HostVec {
     size_t c = cap ? cap : 256;
     while (c < want) c *= 2;
     T* fresh = nullptr;
-    if (pinned) FDH_HIP(hipHostMalloc((void**)&fresh, c * sizeof(T), hipHostMallocDefault));
+    if (pinned && vram) FDH_HIP(hipExtMallocWithFlags((void**)&fresh, c * sizeof(T), hipDeviceMallocUncached));
+    else if (pinned) FDH_HIP(hipHostMalloc((void**)&fresh, c * sizeof(T), hipHostMallocDefault));
     else if (!(fresh = static_cast<T*>(std::aligned_alloc(64, (c * sizeof(T) + 63) & ~(size_t)63)))) throw std::bad_alloc();
-    if (n) std::memcpy(static_cast<void*>(fresh), static_cast<const void*>(p), n * sizeof(T));
-    if (p) { if (pinned) (void)hipHostFree(p); else std::free(p); }
+    if (n && !(pinned && vram)) std::memcpy(static_cast<void*>(fresh), static_cast<const void*>(p), n * sizeof(T));
+    free_block(p);
     p = fresh; cap = c;
+  }
+  // the block as the GPU addresses it
+  const uint8_t* device_view() const {
+    if (!p) return nullptr;
+    if (pinned && vram) return reinterpret_cast<const uint8_t*>(p);
+    void* d = nullptr;
+    FDH_HIP(hipHostGetDevicePointer(&d, const_cast<void*>(static_cast<const void*>(p)), 0));
+    return static_cast<const uint8_t*>(d);
   }
   T& operator[](size_t i) { return p[i]; }
   const T& operator[](size_t i) const { return p[i]; }
@@ -173,7 +198,7 @@ struct Lane {
   int tx0 = 0, ty0 = 0, tx1 = 0, ty1 = 0;
   bool touched = false;
   uint64_t stamp = 0;  // the frame a pool thread's lane was last cleared for
-  void set_pinned(bool on) { device = on; up_recs.pinned = up_bins.pinned = up_exts.pinned = on; }
+  void set_pinned(bool on) { device = on; up_recs.pinned = up_bins.pinned = up_exts.pinned = on; up_recs.vram = up_bins.vram = up_exts.vram = on && vram_staging(); }
   void clear() { recs.clear(); bins.clear(); exts.clear(); boxes.clear(); pub_recs = pub_exts = 0; }
   void publish(uint32_t first, uint32_t n, uint32_t ext_first, uint32_t n_ext);  // records / extensions are final: copy them to the mirrors
   void publish_bytes(int array, size_t at, size_t len);                          // ... a byte range of one array (0 recs, 1 bins, 2 exts)

@@ -265,9 +265,7 @@ static void mirror_fit(Lane& L) {
     up.n = 0;  // (nothing to carry over: reserve() would READ the old pinned block)
     up.reserve(src.cap);
     if (published) std::memcpy(static_cast<void*>(up.p), static_cast<const void*>(src.p), published * sizeof(*src.p));
-    void* d = nullptr;
-    FDH_HIP(hipHostGetDevicePointer(&d, up.p, 0));
-    dev = static_cast<const uint8_t*>(d);
+    dev = up.device_view();
   };
   fit(L.up_recs, L.recs, L.pub_recs, L.d_recs);
   fit(L.up_bins, L.bins, L.pub_recs, L.d_bins);
@@ -285,6 +283,7 @@ void Lane::publish(uint32_t first, uint32_t n, uint32_t ext_first, uint32_t n_ex
     std::memcpy(static_cast<void*>(up_exts.p + ext_first), static_cast<const void*>(exts.p + ext_first), (size_t)n_ext * sizeof(QuadExt));
     pub_exts = std::max(pub_exts, (size_t)ext_first + n_ext);
   }
+  if (up_recs.vram) store_fence();  // (write-combined stores into device memory: drained before this thread says the piece is there)
 }
 void Lane::publish_bytes(int array, size_t at, size_t len) {
   if (!device || !len) return;
@@ -292,6 +291,7 @@ void Lane::publish_bytes(int array, size_t at, size_t len) {
   uint8_t* dst = array == 0 ? reinterpret_cast<uint8_t*>(up_recs.p) : array == 1 ? reinterpret_cast<uint8_t*>(up_bins.p) : reinterpret_cast<uint8_t*>(up_exts.p);
   const uint8_t* src = array == 0 ? reinterpret_cast<const uint8_t*>(recs.p) : array == 1 ? reinterpret_cast<const uint8_t*>(bins.p) : reinterpret_cast<const uint8_t*>(exts.p);
   std::memcpy(dst + at, src + at, len);
+  if (up_recs.vram) store_fence();
 }
 
 // ------------------------------------------------------------------ list stride (Lane)

@@ -1163,6 +1163,52 @@ def test_clear_folding_changes_no_pixel():
         assert np.array_equal(a, b)
 
 
+def test_staging_in_device_memory_changes_no_pixel():
+    """Where the recording threads put a frame's records for the gather kernel: device memory written through the PCIe BAR (the
+    default on a large-BAR device) or pinned host memory (FDH_VRAM_STAGING=0; read once per process, hence the child processes).
+    Same frames bit for bit: the bench frame with the walk pool on, a frame recorded through more pieces than the run table
+    holds (consolidated), a retained scene's diff upload after an edit, and a frame that grows the mirrors mid-way."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+
+    code = (
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "from figdraw_amd import scene as S\n"
+        "from figdraw_amd.context import HipContext\n"
+        "from figdraw_amd.scenes import make_render_tree_100, make_non_clip_benchmark\n"
+        "import ref_scenes as RS\n"
+        "ctx = HipContext(device=0)\n"
+        "out = []\n"
+        "ctx.set_walk_threads(5)\n"
+        "for k in (0, 3): ctx.render_frame(make_render_tree_100(1920, 1080, k, full_frame_blur=True), 1920, 1080); out.append(ctx.read_pixels().copy())\n"
+        "lst = S.RenderList()\n"
+        "for g in range(14):\n"
+        "    parent = lst.addRoot(S.Fig(kind=S.FigKind.nkFrame, screenBox=S.rect(0, 40.0 * g, 800, 40)))\n"
+        "    for k in range(60):\n"
+        "        lst.addChild(parent, S.Fig(kind=S.FigKind.nkRectangle, screenBox=S.rect(12.0 * k, 40.0 * g + 4, 10, 30), corners=[2] * 4, fill=S.rgba((k * 37) & 255, (g * 53) & 255, 90, 255)))\n"
+        "sc = S.Renders(); sc.setLayer(0, lst)\n"
+        "ctx.render_frame(sc, 800, 600); out.append(ctx.read_pixels().copy())\n"
+        "ctx.render_frame(make_non_clip_benchmark(), 1200, 800); out.append(ctx.read_pixels().copy())\n"
+        "sc = RS.random_scene(5, 640.0, 480.0, n=40)\n"
+        "ctx.scene_retain(sc, 640, 480); out.append(ctx.read_pixels().copy())\n"
+        "n = sc.layers[0].nodes[3]; n.screenBox = S.rect(33, 44, 120, 80)\n"
+        "ctx.scene_update_nodes(0, 3, [n]); ctx.scene_render(); out.append(ctx.read_pixels().copy())\n"
+        "np.savez(sys.argv[1], *out)\n"
+    ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    with tempfile.TemporaryDirectory() as td:
+        for on in ("1", "0"):
+            path = os.path.join(td, f"st{on}.npz")
+            subprocess.check_call([sys.executable, "-c", code, path], env=dict(os.environ, FDH_VRAM_STAGING=on))
+            z = np.load(path)
+            res[on] = [z[f"arr_{i}"] for i in range(6)]
+    for a, b in zip(res["0"], res["1"]):
+        assert np.array_equal(a, b)
+
+
 def test_small_blur_in_one_kernel_equals_the_two_pass_route():
     """k_blur_small (a small region's two passes in one kernel, snapshot to the backdrop surface, composited by the phase's launch)
     against the two small-region passes with the composite fused into the vertical one (FDH_BLUR_ONE_KERNEL=0; read once per
