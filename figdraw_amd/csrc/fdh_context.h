@@ -513,6 +513,11 @@ class Context : public Recorder {
   int64_t culled_total_ = 0;       // of the last recorded frame
   int walk_threads_ = -1;
   int64_t parallel_groups_ = 0;    // sibling groups of the last frame that were decomposed on the pool
+  // Where the last frames cut their forked sibling groups into chunks, and what each chunk cost (records made + a share per item
+  // visited): a group that comes again -- same first item, same length -- is cut where that cost says the work is, not into equal
+  // item counts (a viewport's visible rows are a fifth of its cells).  Boundaries change nothing a frame records.
+  struct GroupCuts { int first_item = -1, n = 0; std::vector<int> cut; std::vector<float> cost; uint64_t used = 0; };
+  std::vector<GroupCuts> group_cuts_;
 
   // submit thread (device contexts, unless FDH_CREATE_SYNC_SUBMIT): one job in flight at most.  The flag both sides poll
   // sits on a cache line of its own, and so do the submission side's state and the recording side's: an idle submit thread

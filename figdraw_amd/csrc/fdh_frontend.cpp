@@ -663,6 +663,44 @@ bool ParallelWalk::group(Walker& mw, const FdhLayer& L, const int* items, int n)
     int64_t t0 = 0, t1 = 0;  // FDH_WALK_TRACE: when the chunk ran, ns since the group began
   };
   std::vector<Out> outs((size_t)n_chunks);
+  // chunk c covers items [cut[c], cut[c + 1]): equal counts the first time a group is seen, then by what the chunks cost last time
+  // (cost spread evenly over a chunk's items; the new cuts are the quantiles of that piecewise-constant density)
+  Context::GroupCuts* gc = nullptr;
+  for (auto& g : C.group_cuts_) if (g.first_item == items[0] && g.n == n && (int)g.cut.size() == n_chunks + 1) { gc = &g; break; }
+  if (!gc) {
+    if (C.group_cuts_.size() >= 16) {  // (forget the one that has not come for the longest)
+      size_t old = 0;
+      for (size_t i = 1; i < C.group_cuts_.size(); i++) if (C.group_cuts_[i].used < C.group_cuts_[old].used) old = i;
+      C.group_cuts_.erase(C.group_cuts_.begin() + (long)old);
+    }
+    C.group_cuts_.emplace_back();
+    gc = &C.group_cuts_.back();
+    gc->first_item = items[0]; gc->n = n;
+    gc->cut.resize((size_t)n_chunks + 1);
+    for (int c = 0; c <= n_chunks; c++) gc->cut[(size_t)c] = (int)((int64_t)c * n / n_chunks);
+  } else if ((int)gc->cost.size() == n_chunks) {
+    double total = 0;
+    for (float v : gc->cost) total += v;
+    if (total > 0) {
+      std::vector<int> cut((size_t)n_chunks + 1, 0);
+      cut[(size_t)n_chunks] = n;
+      int c_old = 0;
+      double before = 0;  // cost of the old chunks before c_old
+      for (int c = 1; c < n_chunks; c++) {
+        const double want = total * c / n_chunks;
+        while (c_old < n_chunks - 1 && before + gc->cost[(size_t)c_old] < want) { before += gc->cost[(size_t)c_old]; c_old++; }
+        const int a = gc->cut[(size_t)c_old], b = gc->cut[(size_t)c_old + 1];
+        const double f = gc->cost[(size_t)c_old] > 0 ? (want - before) / gc->cost[(size_t)c_old] : 0.0;
+        int at = a + (int)std::lround(f * (b - a));
+        at = std::max(at, cut[(size_t)c - 1] + 1);           // every chunk keeps at least one item ...
+        at = std::min(at, n - (n_chunks - c));                // ... and leaves one for each chunk behind it
+        cut[(size_t)c] = at;
+      }
+      gc->cut = cut;
+    }
+  }
+  gc->used = C.frame_no_;
+  const std::vector<int> cut = gc->cut;  // (a copy: the pool threads read it while nothing else may touch the cache)
   mw.links->build(L);  // (the pool threads read the links: built before they start)
   C.pool_slots(slots);
   struct Mark { size_t recs, exts; };
@@ -698,7 +736,7 @@ bool ParallelWalk::group(Walker& mw, const FdhLayer& L, const int* items, int n)
     try {
       Walker w{R, mw.scene, mw.ui, mw.links, false};
       w.depth = mw.depth;
-      const int i0 = (int)((int64_t)c * n / n_chunks), i1 = (int)((int64_t)(c + 1) * n / n_chunks);
+      const int i0 = cut[(size_t)c], i1 = cut[(size_t)c + 1];
       for (int k = i0; k < i1; k++) { if (k + 1 < i1) Walker::prefetch_node(L, items[k + 1]); w.node(L, items[k]); }
     } catch (const SerialOnly&) {
       o.serial_only = true;
@@ -730,6 +768,8 @@ bool ParallelWalk::group(Walker& mw, const FdhLayer& L, const int* items, int n)
     return false;
   }
   Context::HostTimer t_merge(C.host_ns_[9]);
+  gc->cost.resize((size_t)n_chunks);
+  for (int c = 0; c < n_chunks; c++) gc->cost[(size_t)c] = (float)outs[(size_t)c].p.n + 0.25f * (float)(cut[(size_t)c + 1] - cut[(size_t)c]);
   Piece run{};
   PhaseSum none{};
   for (const Out& o : outs) {
