@@ -427,6 +427,16 @@ def _mock_rccl():
     return out
 
 
+def test_stand_in_transport_exports_what_the_library_binds():
+    """tests/mock/mock_rccl.c (CPU suite: it builds here, and offers every entry point fdh_comm.cpp looks up with dlsym)"""
+    lib = C.CDLL(_mock_rccl())
+    src = open(os.path.join(ROOT, "figdraw_amd", "csrc", "fdh_comm.cpp")).read()
+    wanted = sorted(set(re.findall(r'sym\("(nccl[A-Za-z]+)"\)', src)))
+    assert len(wanted) >= 10, wanted
+    for name in wanted:
+        assert hasattr(lib, name), name
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode", ["stripes", "frames"])
 def test_the_librarys_gather_between_two_ranks_over_a_stand_in_transport(mode):
