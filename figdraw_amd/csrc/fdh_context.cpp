@@ -38,8 +38,18 @@ bool vram_staging() {
     if (const char* e = std::getenv("FDH_VRAM_STAGING")) return std::atoi(e) != 0;
     int dev = 0, large = 0;
     if (hipGetDevice(&dev) != hipSuccess) return false;
-    if (hipDeviceGetAttribute(&large, hipDeviceAttributeIsLargeBar, dev) != hipSuccess) return false;
-    return large != 0;
+    if (hipDeviceGetAttribute(&large, hipDeviceAttributeIsLargeBar, dev) != hipSuccess || !large) return false;
+    // ... and a round trip to make sure: the CPU stores a pattern into such a block, a device-to-host copy must bring it back
+    uint32_t* d = nullptr;
+    if (hipExtMallocWithFlags((void**)&d, 4096, hipDeviceMallocUncached) != hipSuccess || !d) return false;
+    bool ok = true;
+    for (uint32_t i = 0; i < 1024; i++) d[i] = 0x9e3779b9u * (i + 1);
+    store_fence();
+    uint32_t back[1024];
+    if (hipMemcpy(back, d, sizeof back, hipMemcpyDeviceToHost) != hipSuccess) ok = false;
+    for (uint32_t i = 0; ok && i < 1024; i++) ok = back[i] == 0x9e3779b9u * (i + 1);
+    (void)hipFree(d);
+    return ok;
   }();
   return on;
 }
