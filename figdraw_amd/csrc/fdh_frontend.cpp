@@ -28,14 +28,15 @@ struct LayerLinks {
     const size_t n = (size_t)std::max(L.n_nodes, 0);
     first_child.assign(n, -1); next_sibling.assign(n, -1); last_child.assign(n, -1);
     blur_below.assign(n, 0);
+    bool any_blur = false;
     for (size_t i = 0; i < n; i++) {
-      if (L.nodes[i].kind == FDH_NK_BACKDROP_BLUR) blur_below[i] = 1;
+      if (L.nodes[i].kind == FDH_NK_BACKDROP_BLUR) { blur_below[i] = 1; any_blur = true; }
       const int p = L.nodes[i].parent;
       if (p < 0 || (size_t)p >= i) continue;
       if (last_child[(size_t)p] < 0) first_child[(size_t)p] = (int)i; else next_sibling[(size_t)last_child[(size_t)p]] = (int)i;
       last_child[(size_t)p] = (int)i;
     }
-    for (size_t i = n; i-- > 0;) {
+    for (size_t i = n; any_blur && i-- > 0;) {  // (a second walk over the node array only where a blur node has to mark its ancestors)
       const int p = L.nodes[i].parent;
       if (blur_below[i] && p >= 0 && (size_t)p < i) blur_below[(size_t)p] = 1;
     }
@@ -812,7 +813,8 @@ void Context::render_frame(const FdhScene* scene, float fw, float fh, bool clear
   try {
     save_transform();
     scale(pixel_scale_, pixel_scale_);
-    LayerLinks links;
+    static thread_local LayerLinks links;  // (the arrays keep their capacity from frame to frame)
+    links.layer = nullptr;
     Walker wk{*this, *scene, ui_scale_, &links, true};
     for (int l = 0; l < scene->n_layers; l++) {
       const FdhLayer& L = scene->layers[l];
@@ -1114,7 +1116,8 @@ void Context::scene_render() {
   try {
     save_transform();
     scale(pixel_scale_, pixel_scale_);
-    LayerLinks links;
+    static thread_local LayerLinks links;  // (the arrays keep their capacity from frame to frame)
+    links.layer = nullptr;
     Walker wk{*this, view, ui_scale_, &links, false};  // (roots are walked one by one: each has its cache entry)
     Lane& L0 = lane(0);
     for (size_t l = 0; l < R.layers.size(); l++) {
