@@ -7,14 +7,15 @@ import sys
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from figdraw_amd import context as ctx_mod  # noqa: E402
-from figdraw_amd.scenes import make_curves_scene, make_render_tree_100, make_rotated_tree  # noqa: E402
+from figdraw_amd.scenes import make_clip_mask_benchmark, make_curves_scene, make_render_tree_100, make_rotated_tree  # noqa: E402
 
 w, h = 3840, 2160
 ctx = ctx_mod.HipContext(device=0)
 L = ctx_mod.load()
 buf = (C.c_ulonglong * 64)()
-which = sys.argv[1] if len(sys.argv) > 1 else "bench"  # bench | rotated | curves
-scene = {"bench": lambda: make_render_tree_100(w, h, frame=0, full_frame_blur=True), "rotated": lambda: make_rotated_tree(w, h, 0), "curves": lambda: make_curves_scene(w, h)}[which]()
+which = sys.argv[1] if len(sys.argv) > 1 else "bench"  # bench | rotated | curves | sub_clip | rect_mask (the reference's clip benchmark, 1200 x 800)
+if which in ("sub_clip", "rect_mask"): w, h = 1200, 800
+scene = {"bench": lambda: make_render_tree_100(w, h, frame=0, full_frame_blur=True), "rotated": lambda: make_rotated_tree(w, h, 0), "curves": lambda: make_curves_scene(w, h), "sub_clip": lambda: make_clip_mask_benchmark("sub_clip"), "rect_mask": lambda: make_clip_mask_benchmark("rect_mask")}[which]()
 ctx.render_frame(scene, w, h)
 ctx.replay(5)
 ctx.sync()
