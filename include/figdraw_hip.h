@@ -333,12 +333,14 @@ FDH_API int fdh_set_cull(FdhContext*, int mode);
  * node: 48 siblings or more, no backdrop-blur node below them -- on `n` threads of a process-wide pool beside the calling thread:
  * every thread records into its own arrays, the upload gathers them in painter's order.  n = 0: the calling thread alone (the
  * reference's model: one render thread, figrender.nim:1960-2002); n < 0 (default): FDH_WALK_THREADS from the environment, or
- * min(3, cores / 4).  The records are the same whatever n is (fdh_debug_record_digest; tests/test_parallel_walk.py).
+ * min(7, cores / 8 + 1); the pool's threads keep to the hardware threads that share a last-level cache with the thread that first
+ * used the pool (FDH_WALK_AFFINITY=0 lifts that).  The records are the same whatever n is (fdh_debug_record_digest;
+ * tests/test_parallel_walk.py).
  * fdh_walk_stats: the thread count in force and how many sibling groups of the last frame went to the pool. */
 FDH_API int fdh_set_walk_threads(FdhContext*, int n);
 /* Diagnostic: where the calling thread spent the last frame, nanoseconds: [0] begin_frame, [1] of it waiting for the previous use
  * of the frame's record arrays to be uploaded, [2] the calls / the tree walk, [3] end_frame before submission, [4] preparing the
- * submission, [5] of it copying records into pinned memory, [6] waiting for the submit thread, [7] sibling groups on the walk
+ * submission, [5] of it copying records into the staging mirrors the GPU reads (device memory written through the PCIe BAR, or pinned host memory), [6] waiting for the submit thread, [7] sibling groups on the walk
  * pool (part of [2]), [8] of it inside the pool, [9] of it merging; [10], [11] reserved. */
 FDH_API int fdh_debug_host_times(FdhContext*, int64_t out_ns[12]);
 FDH_API int fdh_walk_stats(FdhContext*, int* threads, int64_t* parallel_groups);
