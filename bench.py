@@ -463,6 +463,10 @@ def main():
                     c.replay_async(n)
                     left[i] -= n
 
+    # (the checks above re-rendered every context ALONE, i.e. with the one-kernel blur routes a frame takes when it has the GPU to itself;
+    # a short batch with all contexts in flight leaves each context's resident job on the routes frames in flight take)
+    run_dynamic(2 * F)
+    sync_all()
     run_replay(args.warmup)
     rp_elapsed, rp_batch_ms = batches(run_replay, args.steps, args.repeats)
     replay = {"value": round(world * w * h * args.steps / rp_elapsed / 1e6, 1), "unit": "Mpixels/s", "ms_per_step": round(1e3 * rp_elapsed / args.steps, 4),
