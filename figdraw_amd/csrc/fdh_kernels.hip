@@ -1081,6 +1081,9 @@ __device__ unsigned int g_edge_bad[4096 * 8];
 #ifndef FDH_BEZIER4
 #define FDH_BEZIER4 1  // 0 (experiment builds): bezier strokes stay on the one-pixel-slot path with libm's functions
 #endif
+#ifndef FDH_SLOW_WAVES
+#define FDH_SLOW_WAVES 4  // waves per SIMD of the build with every path <3>
+#endif
 #ifndef FDH_ROT_WAVES
 #define FDH_ROT_WAVES 4  // waves per SIMD of the rotated-quad build <8>
 #endif
@@ -1098,7 +1101,7 @@ constexpr int kWinCols = 64, kWinRows = 12, kWinStride = 68;
 // list first, with the sort for the next frame riding along.  A symbol of its own, so that the dominant launch of a frame is a
 // row of its own in a rocprofv3 kernel summary (the later phases' launches cover a blur node's footprint and take microseconds).
 template <int kPaths, bool kFull>
-__global__ __launch_bounds__(64, (kPaths & 1) ? 4 : kPaths == 4 ? FDH_UNIFORM_WAVES : (kPaths & 2) ? FDH_ATLAS_WAVES : (kPaths & 8) ? FDH_ROT_WAVES : FDH_FAST_WAVES) void k_composite_tiles(
+__global__ __launch_bounds__(64, (kPaths & 1) ? FDH_SLOW_WAVES : kPaths == 4 ? FDH_UNIFORM_WAVES : (kPaths & 2) ? FDH_ATLAS_WAVES : (kPaths & 8) ? FDH_ROT_WAVES : FDH_FAST_WAVES) void k_composite_tiles(
     // the sixteen dwords a wave needs before anything else, as leading scalar arguments: with kernel-argument preloading
     // (-amdgpu-kernarg-preload-count, csrc/Makefile) they arrive in SGPRs with the wave instead of through a first s_load
     const int* __restrict__ a_order, int* __restrict__ a_order_next, const uint32_t* __restrict__ a_counts, const uint2* __restrict__ a_lists,
