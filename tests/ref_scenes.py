@@ -340,6 +340,30 @@ REFERENCE_PNG_SCENES = {
     "circle_rect": (circle_rect, 800, 600, "render_circle_rect.png"),
 }
 
+def rotated_tree(w=900.0, h=600.0) -> Renders:
+    """Thirty rotated rectangles of the renderlist_100 tree (elliptical corners, strokes, drop and inner shadows, 2- and 3-stop
+    gradients; -30 .. 30 degrees): the workload of tools/perf_configs.py config 9 in small -- rotated quads four pixels per lane,
+    strips outside a quad, saturated cores of rotated boxes."""
+    from figdraw_amd.scenes import make_rotated_tree
+
+    out = make_rotated_tree(w, h, 2, copies=10)
+    # circular corners only: SwiftShader interpolates a per-quad constant with a relative error of ~1e-4 on rotated triangles, and an
+    # elliptical corner's radii travel PACKED in one float (x + 4096 y, atlas.frag:88-94) -- at some angles the decoded radii are
+    # garbage (a rotated elliptical stroke vanishes at 10 and -17 degrees, is exact at 25; circular radii survive the error).  A
+    # harness artefact like the sdfMode one (DESIGN.md section 5), not the shader's: elliptical corners under rotation are covered
+    # against the oracle (test_rotated_tree_matches_oracle), and unrotated against SwiftShader (elliptical_and_fractional).
+    for n in out.layers[0].nodes:
+        n.flags &= ~FigFlags.NfEllipticalCorners
+    return out
+
+
+def curves(w=640.0, h=420.0) -> Renders:
+    """Forty stroked nkDrawable curves, lines and arcs (config 10 in small): quadratic-bezier spans, rotated boxes, join quads."""
+    from figdraw_amd.scenes import make_curves_scene
+
+    return make_curves_scene(w, h, n=40, seed=3)
+
+
 SWIFTSHADER_SCENES = {
     "oneframe": (oneframe, 240, 160),
     "rect_mask_mixed_batch": (rect_mask_mixed_batch, 480, 180),
@@ -349,6 +373,20 @@ SWIFTSHADER_SCENES = {
     "backdrop_blur": (backdrop_blur, 320, 240),
     "rotation_and_transform": (rotation_and_transform, 320, 240),
     "drawables": (drawables, 420, 300),
+}
+
+
+# Goldens whose tests COUNT the pixels beyond the bar instead of bounding every pixel, because the reference's shaders on SwiftShader
+# and a float evaluation legitimately differ at isolated pixels there: (name: builder, width, height, pixels allowed beyond the bar)
+#   rotated_tree: pixel centres lying EXACTLY on an outer edge of a rotated quad (integer vertices: a slope-5/9 edge passes through a
+#     centre every 9 pixels).  GL leaves the fill rule to the implementation as long as shared edges are watertight; the oracle and
+#     the kernels use the top-left rule on exact integer edge functions, SwiftShader does not draw those centres.  All 26 pixels
+#     that differ by more than 1 LSB at generation time lie at distance 0.000 - 0.004 px from such an edge (manifest.json).
+#   curves: sdBezier's closed-form cubic cancels catastrophically at isolated pixels ("Rotated quads and
+#     curves"): two conformant evaluations of it differ there by anything.
+OUTLIER_SCENES = {
+    "rotated_tree": (rotated_tree, 900, 600, 40),
+    "curves": (curves, 640, 420, 8),
 }
 
 

@@ -54,6 +54,17 @@ def test_oracle_matches_reference_shaders_on_swiftshader(name):
     assert mx <= 1, (name, mx, n0, n1)
 
 
+@pytest.mark.parametrize("name", sorted(RS.OUTLIER_SCENES))
+def test_oracle_matches_reference_shaders_but_for_counted_pixels(name):
+    """the two goldens whose differences are counted (ref_scenes.OUTLIER_SCENES says why): within 1 LSB of the reference's shaders
+    on SwiftShader but for a handful of isolated pixels -- centres exactly on an outer edge of a rotated quad, ill-conditioned
+    roots of the bezier cubic"""
+    fn, w, h, allowed = RS.OUTLIER_SCENES[name]
+    img = _render(fn, w, h)
+    mx, n0, n1 = diff_stats(img, load_png(f"ss_{name}.png"))
+    assert n1 <= allowed and n0 <= 0.005 * w * h, (name, mx, n0, n1)
+
+
 def test_reference_point_checks():
     # tfigrender_oneframe_screenshot.nim:89-92
     img = _render(RS.oneframe, 240, 160)

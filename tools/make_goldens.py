@@ -54,6 +54,7 @@ def main():
     manifest = {}
     scenes = {k: v[:3] for k, v in RS.REFERENCE_PNG_SCENES.items()}
     scenes.update(RS.SWIFTSHADER_SCENES)
+    scenes.update({k: v[:3] for k, v in RS.OUTLIER_SCENES.items()})
     for name, (fn, w, h) in scenes.items():
         o = O.Oracle(threads=8)
         o.record_begin()
