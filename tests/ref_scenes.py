@@ -433,8 +433,22 @@ def images_and_msdf_variants(w=360.0, h=260.0, images=None) -> Renders:
 # 65536/atlasSize sub-texel steps; on a 1024 atlas that is 6 bits and MSDF edges (alpha slope = screenPxRange)
 # land up to 7 LSB away from exact bilinear filtering, at 256 the same scenes agree within 2 LSB (measured, see
 # DESIGN.md).  Texture-filter precision is implementation-defined in GL; the oracle and the HIP path filter in float.
+def glyph_rows_rotated(w=330.0, h=110.0, images=None) -> Renders:
+    """glyphs_small with its text rows turned by 7 degrees and its MSDF images by 21: every atlas quad a rotated quad (per-triangle
+    LOD and fwidth, trilinear sampling at rho just above 1) -- the rotated atlas path of round 4."""
+    from figdraw_amd.scenes import make_glyph_scene
+
+    return make_glyph_scene(w, h, images, cols=8, rows=3, rotation=7.0, origin=(8.0, 16.0))
+
+
 ATLAS_GOLDEN_SIZE = 256
+# (oracle vs golden: max LSB, share of pixels beyond 1 LSB; HIP vs golden: pixels allowed beyond 2 LSB).  The rotated rows are sampled
+# trilinearly at rho just above 1 from coordinates SwiftShader keeps in 16-bit fixed point AND derives its LOD from per-fragment
+# differences of those: 47 of 36 300 pixels sit 2 LSB from the float evaluation, two of them 3 (manifest.json; with the oracle's
+# sampler on the 16-bit grid, 35).
+ATLAS_TOLERANCE = {"glyph_rows_rotated": (3, 0.002, 8)}
 ATLAS_SCENES = {
+    "glyph_rows_rotated": (glyph_rows_rotated, 330, 110),
     "glyphs_small": (glyphs_small, 330, 90),
     "images_and_msdf_variants": (images_and_msdf_variants, 360, 260),
 }
