@@ -1578,7 +1578,10 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? FDH_SLOW_WAVES : kPaths == 4 ? F
       // units, top-left rule -- admit its centre.  An edge value is a scalar base per strip + two v_mad_i32_i24 per lane + one add per
       // further pixel; ownership is folded into the base (E - 1 >= 0 <=> E > 0), so a triangle's inside test is one v_or3 and a sign
       // test.  Out: L0..L2 = the hit triangle's barycentrics (edge value x 1 / (E0 + E1 + E2)), T1 = it is the second triangle.
-      auto tri_bary = [&](const QuadExt& q, float (&L0)[4], float (&L1)[4], float (&L2)[4], bool (&T1)[4], bool (&cov)[4]) __attribute__((always_inline)) {
+      // `exact`: the barycentrics as the ORACLE's rasteriser forms them -- (float)(E x 1 / (E0 + E1 + E2)) in DOUBLE precision -- instead of
+      // float(E) x float(1 / sum).  The two differ in the last bit now and then, which no shading path cares about but one: the
+      // bezier distance's closed-form cubic amplifies a last-bit difference of its input into pixels (see sd_bezierN).
+      auto tri_bary = [&](const QuadExt& q, float (&L0)[4], float (&L1)[4], float (&L2)[4], bool (&T1)[4], bool (&cov)[4], const bool exact) __attribute__((always_inline)) {
         const int X0 = 2 * tx0 + 1, Y0 = 2 * ty0 + 1;
         const int dxl = 8 * (lane & 7), dyl = 2 * (lane >> 3);
         int eb[2][3], a2[2][3], nb[2][3];
@@ -1594,6 +1597,14 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? FDH_SLOW_WAVES : kPaths == 4 ? F
           }
         const bool valid0 = q.inv_sum[0] != 0.0f, valid1 = q.inv_sum[1] != 0.0f;
         const bool rowc = py >= r.by0 && py < r.by1;
+        // (exact) E0 + E1 + E2 is the same at every point of the plane: one double-precision reciprocal per triangle and lane.  The oracle
+        // divides in pixel units, w = E / 4 and 1 / (sum / 4): powers of two, the same quotient bit for bit.
+        double invd0 = 0.0, invd1 = 0.0;
+        if (exact) {
+          const int s0 = eb[0][0] + eb[0][1] + eb[0][2] + nb[0][0] + nb[0][1] + nb[0][2], s1 = eb[1][0] + eb[1][1] + eb[1][2] + nb[1][0] + nb[1][1] + nb[1][2];
+          invd0 = 1.0 / (double)(valid0 ? s0 : 1);
+          invd1 = 1.0 / (double)(valid1 ? s1 : 1);
+        }
 #pragma unroll
         for (int k = 0; k < 4; k++) {
           const int e00 = eb[0][0] + k * a2[0][0], e01 = eb[0][1] + k * a2[0][1], e02 = eb[0][2] + k * a2[0][2];
@@ -1602,10 +1613,15 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? FDH_SLOW_WAVES : kPaths == 4 ? F
           const bool use1 = !in0 && in1;
           T1[k] = use1;
           cov[k] = rowc && px0 + k >= r.bx0 && px0 + k < r.bx1 && (in0 || in1);
-          const float is = use1 ? q.inv_sum[1] : q.inv_sum[0];
-          L0[k] = (float)((use1 ? e10 : e00) + (use1 ? nb[1][0] : nb[0][0])) * is;
-          L1[k] = (float)((use1 ? e11 : e01) + (use1 ? nb[1][1] : nb[0][1])) * is;
-          L2[k] = (float)((use1 ? e12 : e02) + (use1 ? nb[1][2] : nb[0][2])) * is;
+          const int E0 = (use1 ? e10 : e00) + (use1 ? nb[1][0] : nb[0][0]), E1 = (use1 ? e11 : e01) + (use1 ? nb[1][1] : nb[0][1]),
+                    E2 = (use1 ? e12 : e02) + (use1 ? nb[1][2] : nb[0][2]);
+          if (exact) {  // (compile-time at every call site) oracle: w = edge function in pixel units (= E / 4), l = (float)(w / (w0 + w1 + w2))
+            const double inv = use1 ? invd1 : invd0;
+            L0[k] = (float)((double)E0 * inv); L1[k] = (float)((double)E1 * inv); L2[k] = (float)((double)E2 * inv);
+          } else {
+            const float is = use1 ? q.inv_sum[1] : q.inv_sum[0];
+            L0[k] = (float)E0 * is; L1[k] = (float)E1 * is; L2[k] = (float)E2 * is;
+          }
         }
       };
       if (kSlow && FDH_ROT_ATLAS4 && (om & F_GENERAL) != 0u && (om & F_EDGE32) != 0u && atlas_mode && op == OP_DRAW) {
@@ -1617,7 +1633,7 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? FDH_SLOW_WAVES : kPaths == 4 ? F
         const QuadExt& q = exts[r.ext];
         float L0[4], L1[4], L2[4];
         bool T1[4], cov[4];
-        tri_bary(q, L0, L1, L2, T1, cov);
+        tri_bary(q, L0, L1, L2, T1, cov, false);
         const bool solid = (om & F_SOLID) != 0u;
         const F4 cBL = unpack255(r.col[0]), cBR = unpack255(r.col[1]), cTR = unpack255(r.col[2]), cTL = unpack255(r.col[3]);
         const float uax = r.r[0], uay = r.r[1], utx = r.r[2], uty = r.r[3];
@@ -1677,7 +1693,7 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? FDH_SLOW_WAVES : kPaths == 4 ? F
         const QuadExt& q = exts[r.ext];
         float L0[4], L1[4], L2[4];
         bool T1[4], cov[4];
-        tri_bary(q, L0, L1, L2, T1, cov);
+        tri_bary(q, L0, L1, L2, T1, cov, false);
         const bool solid = (om & F_SOLID) != 0u;
         const F4 cBL = unpack255(r.col[0]), cBR = unpack255(r.col[1]), cTR = unpack255(r.col[2]), cTL = unpack255(r.col[3]);
         const float qhx = r.p0, qhy = r.p1;
@@ -1833,7 +1849,7 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? FDH_SLOW_WAVES : kPaths == 4 ? F
         if (general) {
           float L0[4], L1[4], L2[4];
           bool T1[4];
-          tri_bary(exts[r.ext], L0, L1, L2, T1, cov);
+          tri_bary(exts[r.ext], L0, L1, L2, T1, cov, true);
           const F4 cBR = unpack255(r.col[1]), cTR = unpack255(r.col[2]), cTL = unpack255(r.col[3]);
 #pragma unroll
           for (int k = 0; k < 4; k++) {

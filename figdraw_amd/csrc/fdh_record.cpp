@@ -163,7 +163,7 @@ static uint32_t binrec_flags(const DrawRec& r) {
   const uint32_t ell = (om & F_ELLIP) ? 4u : 0u;
   uint32_t flags = 0;
   const bool rot = (om & F_GENERAL) && (om & F_EDGE32) && !atlas_mode && mode < 18u && op == OP_DRAW;  // (its core: QuadExt::core)
-  if (!(om & F_GENERAL) && mode >= 18u && mode <= 20u && op == OP_DRAW) return BR_CURVE;
+  if (mode >= 18u && mode <= 20u && op == OP_DRAW && r.inv_w != 0.0f) return BR_CURVE;  // (an upright quad: ox .. inv_h are set, emit_corners)
   if (!sdf && !rot) return 0u;
   flags |= BR_HAS_CORE | (rot ? BR_GENERAL : 0u);
   if (op == OP_DRAW && (mode == 9u || mode == 11u || mode == 12u)) {
@@ -482,6 +482,11 @@ bool Recorder::emit_corners(DrawRec& r, const QuadPx& q, bool count_fragments) {
   if (cullable && !bbox_visible(b)) { FDH_CULLED(); return false; }
   r.bx0 = b.x0; r.by0 = b.y0; r.bx1 = b.x1; r.by1 = b.y1;
   const bool aligned = px[3] == px[0] && px[2] == px[1] && py[3] == py[2] && py[0] == py[1] && px[1] > px[0] && py[0] > py[3];
+  // A bezier stroke (modes 18 - 20) always takes the two-triangle form, upright or not: its distance is a closed-form cubic that turns a
+  // last-bit difference of its input into pixels, so the kernels form its uv exactly as the reference's rasteriser does (barycentrics
+  // of the quad's two triangles, in double precision: tri_bary(exact) in k_composite_tiles), not as (x - ox) / w.  An upright one
+  // keeps ox .. inv_h too: k_bin_draws maps strips through them (BR_CURVE).
+  const bool bezier = (r.op_mode & 255u) >= 18u && (r.op_mode & 255u) <= 20u;
   if (aligned) {
     r.ox = px[3];
     r.oy = py[3];
@@ -489,8 +494,9 @@ bool Recorder::emit_corners(DrawRec& r, const QuadPx& q, bool count_fragments) {
     r.inv_h = 1.0f / (py[0] - py[3]);
     r.kx = 2.0f * r.p0 * r.inv_w;  // (meaningful for SDF quads, where p0, p1 are the quad's half extents)
     r.ky = 2.0f * r.p1 * r.inv_h;
-    set_saturated_core(r, px[1] - px[0], py[0] - py[3]);
-  } else {
+    if (!bezier) set_saturated_core(r, px[1] - px[0], py[0] - py[3]);
+  }
+  if (!aligned || bezier) {
     QuadExt& q = *lane_->exts.slot();
     std::memset(static_cast<void*>(&q), 0, sizeof q);
     static const int TRI[2][3] = {{3, 0, 1}, {2, 3, 1}};  // glcontext.nim:418-429
