@@ -29,10 +29,16 @@ out = {}
 
 
 def run(key, what, ctx, sc, w, h, n=100, oracle_kw=None, images=None):
+    # the context's FIRST frame, timed where the library starts: the scene already marshalled into FdhFig arrays, one fdh_render_frame
+    # + fdh_sync from C (allocations, staging sets, the kernels' first launches, upload).  (Round 3 timed ctx.render_frame from
+    # Python here: 23 - 90 ms of which all but a few were ctypes marshalling of the node list.)
+    from figdraw_amd import call_stream as CS
+    cs0 = sc.to_c()
+    first = CS.Player().play_scenes([ctx], [cs0], 1, w, h)
     t = time.perf_counter()
     ctx.render_frame(sc, w, h)
     ctx.sync()
-    first = time.perf_counter() - t
+    through_python = time.perf_counter() - t
     got = ctx.read_pixels()
     ctx.replay(10)
     ctx.replay(n)
@@ -45,7 +51,7 @@ def run(key, what, ctx, sc, w, h, n=100, oracle_kw=None, images=None):
                        "composite_all": round(1e3 * st.ms_composite, 1), "blur_h_all": round(1e3 * st.ms_blur_h, 1),
                        "blur_v_all": round(1e3 * st.ms_blur_v, 1), "largest_blur_h": round(1e3 * st.ms_blur_big_h, 1),
                        "largest_blur_v": round(1e3 * st.ms_blur_big_v, 1)},
-         "first_frame_host_ms": round(1e3 * first, 1)}
+         "first_frame_host_ms": round(1e3 * first, 2), "frame_through_python_binding_ms": round(1e3 * through_python, 1)}
     if key in ("config6", "config7", "config8"):  # the reference's loop: renderFrame per frame, 20 warm-up + 120 timed
         cs = sc.to_c()
         from figdraw_amd import call_stream as CS
