@@ -2616,12 +2616,24 @@ template <int c> __device__ __forceinline__ h8 mx_frag(const uint32_t (&R)[8]) {
 #ifndef FDH_MX_V_EXTRA
 #define FDH_MX_V_EXTRA 0  // (2: rounds 1 - 3 kept two idle slots for the fused composite's alphas -- 18 KB per wave, eight waves per CU)
 #endif
+#ifndef FDH_MX_WG_H
+#define FDH_MX_WG_H 1     // waves per WORKGROUP of k_blur_mx, horizontal / vertical pass (mx_wg).  Each wave works alone (own ring, no barrier); what
+#endif                    // a workgroup decides is WHERE they run: its waves are neighbours along the filter direction on ONE CU, so the halo they
+#ifndef FDH_MX_WG_V       // share (38 of every 166 texels at radius 18) comes out of that CU's vector cache.  Measured with four (4K, same box, both
+#define FDH_MX_WG_V 1     // builds): the horizontal pass 19.7 -> 17.4 us -- and the vertical one behind it 19.5 -> 20.7 (20.2 with four vertical
+#endif                    // neighbours per workgroup); the sum 39.2 -> 38.0, `value` the same within the boxes' noise.  Left at one.
 #ifndef FDH_MX_WAVES
 #define FDH_MX_WAVES 2    // waves per SIMD the passes are compiled for.  (3 -- eleven 14-KB rings fit a CU, 2720 waves of three blocks in one
                           // round -- measured 21.3 / 22.5 us against 19.9 / 19.6 for the two passes at 4K: more waves per SIMD do not help, the
                           // passes are paced by the memory system, profiles/r04_blur_notes.txt)
 #endif
 constexpr int mx_ring_slots(int nk, bool vertical) { return nk + 2 + (vertical ? FDH_MX_V_EXTRA : FDH_MX_H_EXTRA); }
+// waves per workgroup of an instantiation: FDH_MX_WG_H / _V where two such workgroups' rings fit a CU's LDS (eight waves per CU,
+// two per SIMD, as with one-wave workgroups); one for the wide filters, whose rings would leave room for a single workgroup
+constexpr int mx_wg(int nk, bool vertical) {
+  const int want = vertical ? FDH_MX_WG_V : FDH_MX_WG_H;
+  return 2 * want * mx_ring_slots(nk, vertical) * 2 <= 160 ? want : 1;
+}
 constexpr float kMxScale = 16384.0f;  // 2^24 (subnormal texels) / 2^10 (weight scale)
 constexpr int kMxSlot = 512;          // dwords of one k-step in LDS: 16 texels along the filter x 32 lines
 // LDS-DMA: 16 (or 4) bytes per lane from `src` to LDS byte address `lds` + 16 (4) * lane.  Written as inline assembly on
@@ -2664,15 +2676,18 @@ __device__ unsigned int g_mx_bad_n;
 __device__ unsigned int g_mx_bad[4096 * 8];
 #endif
 template <int NK, bool kV>
-__global__ __launch_bounds__(64, FDH_MX_WAVES) void k_blur_mx(BlurParams P, const DrawRec* __restrict__ draws, const QuadExt* __restrict__ exts, int T) {
+__global__ __launch_bounds__(64 * mx_wg(NK, kV), FDH_MX_WAVES) void k_blur_mx(BlurParams P, const DrawRec* __restrict__ draws, const QuadExt* __restrict__ exts, int T) {
   constexpr int R = mx_ring_slots(NK, kV);
-  extern __shared__ __attribute__((aligned(16))) uint32_t ring[];  // R slots
+  extern __shared__ __attribute__((aligned(16))) uint32_t ring_wg[];  // R slots per wave
+  constexpr int kWG = mx_wg(NK, kV);
+  const int wave_in_wg = kWG > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
+  uint32_t* const ring = ring_wg + wave_in_wg * (R * kMxSlot);
   // blocks sit at absolute multiples of 32 along the filter direction: a pixel's sum is then grouped into MFMAs the same
   // way whatever region or stripe it is rendered in (stripes of a frame must reproduce the full frame bit for bit)
   const int a_lo = kV ? P.y0 : P.x0, a_hi = kV ? P.y1 : P.x1, a0 = a_lo & ~31;
   const int l0 = kV ? (P.x0 & ~31) : P.y0, l_hi = kV ? P.x1 : P.y1;
   const int n_along = (a_hi - a0 + 32 * T - 1) / (32 * T), n_lines = (l_hi - l0 + 31) >> 5;
-  const int total = n_along * n_lines, per = (total + 7) >> 3, q = blockIdx.x >> 3, item = (blockIdx.x & 7) * per + q;
+  const int total = n_along * n_lines, per = (total + 7) >> 3, q = (int)(blockIdx.x >> 3) * kWG + wave_in_wg, item = (blockIdx.x & 7) * per + q;
   if (q >= per || item >= total) return;  // every XCD takes a contiguous eighth of the sequence: neighbours along the filter share an L2
   // Sequence: horizontal pass, along the rows (neighbours in x run together and share their halo); vertical pass, bands of
   // 16 strips (2 KB of every row) walked segment row by segment row -- the waves in flight on an XCD then read each row
@@ -2682,13 +2697,19 @@ __global__ __launch_bounds__(64, FDH_MX_WAVES) void k_blur_mx(BlurParams P, cons
     constexpr int kBand = 16;
     const int per_band = kBand * n_along, band = item / per_band, rem = item - band * per_band;
     const int bw = min(kBand, n_lines - band * kBand);
-    sa = rem / bw;
-    sl = band * kBand + rem - sa * bw;
+    if (kWG > 1) {  // strip by strip inside a band: the waves of a workgroup are vertical neighbours and share halo ROWS
+      const int st = rem / n_along;
+      sa = rem - st * n_along;
+      sl = band * kBand + st;
+    } else {
+      sa = rem / bw;
+      sl = band * kBand + rem - sa * bw;
+    }
   } else {
     sl = item / n_along;
     sa = item - sl * n_along;
   }
-  const int lane = threadIdx.x, g = lane >> 5, j = lane & 31;
+  const int lane = threadIdx.x & 63, g = lane >> 5, j = lane & 31;
   const int reach = P.taps.reach;
 #if defined(FDH_MX_STAGGER)  // experiment: every other wave of an XCD starts FDH_MX_STAGGER x ~1 us late (do memory and arithmetic phases run in step?)
   if ((blockIdx.x >> 3) & 1) for (int i = 0; i < FDH_MX_STAGGER; i++) __builtin_amdgcn_s_sleep(32);
@@ -3031,6 +3052,8 @@ __global__ __launch_bounds__(64, FDH_MX_WAVES) void k_blur_mx(BlurParams P, cons
 // Bytes: (1 + halo) x 4 A read (the x halo comes out of L2) + 4 A written, against 16 A for the two passes.
 constexpr int fx_vblocks(int nkv) { return ((nkv - 1) >> 1) + 1; }               // H-blocks one V block reads
 constexpr int fx_slots(int nkh, int nkv) { return nkh + 2 * fx_vblocks(nkv); }  // source k-steps of one H-block + the H ring
+// (One wave per workgroup.  Two or three -- x-neighbours on one CU, as in k_blur_mx -- cost more in waves per CU, six instead of seven,
+// than the shared source columns give back: 36.4 / 38.1 us against 34.6.)
 template <int NKH, int NKV>
 __global__ __launch_bounds__(64, 2) void k_blur_fx(BlurParams P, const uint4* __restrict__ w_v, const DrawRec* __restrict__ draws, const QuadExt* __restrict__ exts, int T) {
   constexpr int HB = fx_vblocks(NKV);  // V block b reads H-blocks b .. b + HB - 1
@@ -3559,15 +3582,16 @@ static int mx_pick_t(long long per_cu, long long outputs_along, long long lines)
 }
 template <int NK, bool kV> static void launch_blur_mx(hipStream_t s, const BlurParams& P, const DrawRec* draws, const QuadExt* exts) {
   constexpr size_t lds = (size_t)mx_ring_slots(NK, kV) * kMxSlot * sizeof(uint32_t);
-  static const int per_cu = [] {  // single-wave workgroups resident per CU, asked once per instantiation
+  constexpr int kWG = mx_wg(NK, kV);
+  static const int per_cu = [] {  // waves resident per CU, asked once per instantiation
     int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_blur_mx<NK, kV>, 64, lds) != hipSuccess || n <= 0) n = std::min<int>(4 * FDH_MX_WAVES, 160 / (mx_ring_slots(NK, kV) * 2));
-    return n;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_blur_mx<NK, kV>, 64 * kWG, lds * kWG) != hipSuccess || n <= 0) n = std::min<int>(4 * FDH_MX_WAVES, 160 / (mx_ring_slots(NK, kV) * 2)) / kWG;
+    return n * kWG;  // (waves)
   }();
   const int t = kV ? mx_pick_t(per_cu, P.y1 - P.y0, P.x1 - P.x0) : mx_pick_t(per_cu, P.x1 - P.x0, P.y1 - P.y0);
   const int a_lo = kV ? P.y0 : P.x0, a_hi = kV ? P.y1 : P.x1, l_lo = kV ? (P.x0 & ~31) : P.y0, l_hi = kV ? P.x1 : P.y1;
   const int total = ((a_hi - (a_lo & ~31) + 32 * t - 1) / (32 * t)) * ((l_hi - l_lo + 31) / 32);
-  FDH_LAUNCH((k_blur_mx<NK, kV>), dim3(8 * ((total + 7) / 8)), dim3(64), lds, s, P, draws, exts, t);
+  FDH_LAUNCH((k_blur_mx<NK, kV>), dim3(8 * ((total + 8 * kWG - 1) / (8 * kWG))), dim3(64 * kWG), lds * kWG, s, P, draws, exts, t);
 }
 template <bool kV> static bool launch_blur_mx_nk(hipStream_t s, const BlurParams& P, const DrawRec* draws, const QuadExt* exts) {
   // LDS-DMA moves 16-byte pieces: rows have to start on 16-byte boundaries
