@@ -103,6 +103,7 @@ Context::~Context() {
   for (auto& set : lanes_) set.clear();  // (pinned arrays: freed while the device is still this thread's)
   for (auto& m : misc_) m.release();
   for (auto& e : staging_ev_) if (e) (void)hipEventDestroy(e);
+  if (seq_host_) (void)hipHostFree((void*)seq_host_);
   if (own_stream_) (void)hipStreamDestroy(own_stream_);
 }
 
@@ -163,6 +164,23 @@ void Context::drain() {
     tables_dev_ = nullptr; shadow_dev_ = nullptr; have_frame_ = false;
     std::rethrow_exception(e);
   }
+}
+
+void Context::wait_staging(int slot) {
+  if (staging_busy_[slot] == 2) {
+    // the word is pinned host memory the device writes: a load of it is an uncached read (~100 ns); spin, then yield, and after
+    // a few milliseconds stop trusting it and wait for the stream (the frame is then done for certain)
+    const uint32_t want = staging_seq_[slot];
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t spins = 0; (int32_t)(*seq_host_ - want) < 0; spins++) {
+      if (spins < 2000) { cpu_relax(); continue; }
+      if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) { FDH_HIP(hipStreamSynchronize(stream_)); break; }
+      std::this_thread::yield();
+    }
+  } else if (staging_busy_[slot] == 1) {
+    FDH_HIP(hipEventSynchronize(staging_ev_[slot]));
+  }
+  staging_busy_[slot] = 0;
 }
 
 void Context::sync() {
@@ -994,16 +1012,37 @@ void Context::issue(LaunchJob& J) {
     }
     launch_upload_frame(stream_, J.d_dst, T);
   }
+  // WHO RELEASES THE STAGING SET.  The calling thread may write into a set of lanes again once the upload that read it has run.
+  // An event recorded behind the upload said so until round 4 -- and cost the GPU 5.7 - 5.9 us of idle time on every frame: the
+  // bin launch started that long after the upload had ended, whether the event was a packet of its own (hipEventRecord) or rode on
+  // the upload's dispatch (hipExtLaunchKernelGGL's stop event: 4.6 us), and not at all without one
+  // (tools/trace_gaps.sh).  Now the BIN launch says it: its first wave stores the frame's sequence number to a word of pinned host
+  // memory (k_bin_draws) -- it has started, so the upload in front of it is done -- and begin_frame compares that word.
+  // (A frame without a bin launch -- no phase -- keeps the event.  FDH_STAGING_EVENT=1: always the event.)
+  static const bool by_event = [] { const char* e = std::getenv("FDH_STAGING_EVENT"); return e && std::atoi(e) != 0; }();
+  uint32_t seq = 0;
   if (J.staging_slot >= 0) {
-    FDH_HIP(hipEventRecord(staging_ev_[J.staging_slot], stream_));
-    staging_busy_[J.staging_slot] = true;
+    const bool binned = !by_event && !J.phases.empty() && J.bins_x * J.bins_y > 0;
+    if (binned && !seq_host_) {
+      FDH_HIP(hipHostMalloc((void**)&seq_host_, 64, hipHostMallocDefault));
+      *seq_host_ = 0;
+    }
+    if (binned) {
+      seq = ++upload_seq_;
+      if (seq == 0) seq = ++upload_seq_;  // (0 = no store)
+      staging_seq_[J.staging_slot] = seq;
+      staging_busy_[J.staging_slot] = 2;
+    } else {
+      FDH_HIP(hipEventRecord(staging_ev_[J.staging_slot], stream_));
+      staging_busy_[J.staging_slot] = 1;
+    }
   }
-  launch_frame(J, false);
+  launch_frame(J, false, seq);
   launch_ms_.store(std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_l0).count(), std::memory_order_relaxed);
 }
 
 
-void Context::launch_frame(const LaunchJob& J, bool profile) {
+void Context::launch_frame(const LaunchJob& J, bool profile, uint32_t upload_seq) {
   const int bins_x_ = J.bins_x, bins_y_ = J.bins_y, list_stride_ = J.list_stride, binbox_shift_ = J.binbox_shift, big_blur_ = J.big_blur;
   const std::vector<const uint4*>&mx_w_h_ = J.mx_w_h, &mx_w_v_ = J.mx_w_v;
   const LaunchJob::View& dv_ = J.dv;
@@ -1036,6 +1075,7 @@ void Context::launch_frame(const LaunchJob& J, bool profile) {
   B.refine = 0;
   for (const Phase& ph : J.phases) if (ph.has_rot || ph.has_slow) B.refine = 1;
   B.n_phases = np; B.bins_x = bins_x_; B.bins_y = bins_y_; B.stride = list_stride_;
+  if (upload_seq) { B.seq_out = const_cast<uint32_t*>(seq_host_); B.seq = upload_seq; }
   launch_bin(stream_, B);
   span_end();
   // Phase 0's full-grid composite takes its bins longest-list first, in the order its predecessor sorted (an extra

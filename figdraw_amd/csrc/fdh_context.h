@@ -460,7 +460,7 @@ class Context : public Recorder {
   void find_empty_rect(int w, int h, int* ox, int* oy);
   void prepare(LaunchJob& J);  // calling thread: recorded frame -> run table + launch description
   void issue(LaunchJob& J);    // submit thread: upload + kernel launches
-  void launch_frame(const LaunchJob& J, bool profile);
+  void launch_frame(const LaunchJob& J, bool profile, uint32_t upload_seq = 0);  // upload_seq: the bin launch reports it to the host
   template <typename Buf> void reserve_quiet(Buf& buf, size_t n);
   void drain();        // wait until the submit thread is idle; rethrows what its last job threw
   void worker_main();
@@ -594,7 +594,11 @@ class Context : public Recorder {
   const void* shadow_dev_ = nullptr;  // ... and where it lives
   int64_t uploaded_bytes_ = 0;        // by the last submit
   hipEvent_t staging_ev_[kStaging] = {};
-  bool staging_busy_[kStaging] = {};
+  char staging_busy_[kStaging] = {};     // 0: free; 1: until staging_ev_ fires; 2: until *seq_host_ reaches staging_seq_ (Context::issue)
+  uint32_t staging_seq_[kStaging] = {};
+  volatile uint32_t* seq_host_ = nullptr;  // pinned: the sequence number of the last frame whose bin launch has started (k_bin_draws)
+  uint32_t upload_seq_ = 0;
+  void wait_staging(int slot);             // calling thread: until the set's last upload has run
   int staging_i_ = 0;
 
   // atlas

@@ -18,6 +18,8 @@ struct BinParams {
   const DrawRec* draws;    // the frame's records: the bin kernel pulls them into every XCD's L2 for the compositor (see k_bin_draws)
   const QuadExt* exts;     // the edge functions of rotated quads (BR_GENERAL draws: strips outside the quad are dropped from the entry)
   int refine;              // the frame holds BR_GENERAL / BR_CURVE draws: the build of k_bin_draws with their per-strip tests
+  uint32_t* seq_out = nullptr;  // pinned host word that receives `seq` when the launch starts (or null): see k_bin_draws
+  uint32_t seq = 0;
 };
 
 struct CompositeParams {

@@ -515,6 +515,9 @@ __global__ __launch_bounds__(64) void k_bin_draws(BinParams P) {
   const int first = P.phase_first[phase], last = P.phase_first[phase + 1];
   uint2* out = P.lists + ((size_t)phase * nb + bin) * P.stride;
   const int lane = threadIdx.x;
+  // "The upload in front of this launch has finished" for the host (Context::issue: what releases a staging set): this launch has
+  // started, so everything before it on the stream is done.  One posted store to a word of pinned host memory.
+  if (P.seq_out && blockIdx.x == 0 && lane == 0) __hip_atomic_store(P.seq_out, P.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   // Warm-up for the compositor: a frame's records were just written by the upload kernel, i.e. they sit in ONE XCD's L2 or in
   // memory, and the compositor fetches them with scalar loads it waits for (a record round trip per edge draw: a fresh frame's
   // phase-0 launch ran 34 us against 31 for a replayed one whose records were L2-resident).  A record is one 128-byte line:

@@ -1182,7 +1182,7 @@ void Context::begin_frame(int w, int h, bool clear, const float rgba[4]) {  // g
   // kernel has run by now (that frame's issue was waited for by the end_frame after it: the event is recorded).
   staging_i_ = (staging_i_ + 1) % kStaging;
   frame_no_++;
-  if (!host_only_ && staging_busy_[staging_i_]) { HostTimer t(host_ns_[1]); FDH_HIP(hipEventSynchronize(staging_ev_[staging_i_])); staging_busy_[staging_i_] = false; }
+  if (!host_only_ && staging_busy_[staging_i_]) { HostTimer t(host_ns_[1]); wait_staging(staging_i_); }
   Lane& L0 = ensure_lane(0);
   L0.clear();
   L0.count_begin((w + kBin - 1) / kBin, (h + kBin - 1) / kBin);
