@@ -575,7 +575,8 @@ class Context : public Recorder {
   DeviceBuf<int> d_order_[2];  // phase 0's bins, longest list first: read by this frame's launch / written for the next
   int order_read_ = 0, order_nb_ = 0;
   bool order_valid_ = false;
-  // kStaging sets of lanes in rotation, each guarded by an event recorded behind the upload that reads it: the host records
+  // kStaging sets of lanes in rotation, each released when the upload that reads it has run (the bin launch behind it says so
+  // through *seq_host_, Context::issue; an event where a frame has no bin launch): the host records
   // frames N + 1 .. while frame N's upload has not run yet (one set forced a stream sync per frame)
   struct MxTables { int reach; std::vector<float> dense; std::vector<uint8_t> h, v; };  // k_blur_mx weight fragments of one filter
   std::vector<MxTables> mx_cache_;
