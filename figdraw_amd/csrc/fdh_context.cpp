@@ -1076,6 +1076,21 @@ void Context::launch_frame(const LaunchJob& J, bool profile, uint32_t upload_seq
   for (const Phase& ph : J.phases) if (ph.has_rot || ph.has_slow) B.refine = 1;
   B.n_phases = np; B.bins_x = bins_x_; B.bins_y = bins_y_; B.stride = list_stride_;
   if (upload_seq) { B.seq_out = const_cast<uint32_t*>(seq_host_); B.seq = upload_seq; }
+  static const bool sub_on = [] { const char* e = std::getenv("FDH_BIN_SUBGRIDS"); return !e || std::atoi(e) != 0; }();
+  if (sub_on && np >= 1 && np <= BinParams::kBinSubs) {  // later phases: the bins their compositor launch reads (the same Phase::bin_* box)
+    int at = 0;
+    for (int p = 0; p < np; p++) {
+      const Phase& ph = J.phases[p];
+      const bool whole = p == 0;
+      const int x0 = whole ? 0 : std::max(0, ph.bin_x0), y0 = whole ? 0 : std::max(0, ph.bin_y0);
+      const int x1 = whole ? bins_x_ : std::min(bins_x_, ph.bin_x1), y1 = whole ? bins_y_ : std::min(bins_y_, ph.bin_y1);
+      const int nx = std::max(0, x1 - x0), ny = std::max(0, y1 - y0);
+      B.sub_first[p] = at; B.sub_x0[p] = x0; B.sub_y0[p] = y0; B.sub_nx[p] = std::max(1, nx);
+      at += nx * ny;
+    }
+    B.sub_first[np] = at;
+    B.sub_n = np;
+  }
   launch_bin(stream_, B);
   span_end();
   // Phase 0's full-grid composite takes its bins longest-list first, in the order its predecessor sorted (an extra

@@ -20,6 +20,14 @@ struct BinParams {
   int refine;              // the frame holds BR_GENERAL / BR_CURVE draws: the build of k_bin_draws with their per-strip tests
   uint32_t* seq_out = nullptr;  // pinned host word that receives `seq` when the launch starts (or null): see k_bin_draws
   uint32_t seq = 0;
+  // Bins per phase: phase p's workgroups are sub_first[p] .. sub_first[p + 1] - 1 and cover the sub_nx[p] bins wide block at
+  // (sub_x0[p], sub_y0[p]) -- what that phase's compositor launch will read (a later phase touches the bins of ITS draws; a
+  // workgroup per bin of the whole grid for every phase was two thirds of the bench frame's bin launch doing nothing).
+  // sub_n = 0: more than kBinSubs phases, every phase gets the whole grid.
+  static constexpr int kBinSubs = 8;
+  int sub_n = 0;
+  int sub_first[kBinSubs + 1] = {};
+  int sub_x0[kBinSubs] = {}, sub_y0[kBinSubs] = {}, sub_nx[kBinSubs] = {};
 };
 
 struct CompositeParams {

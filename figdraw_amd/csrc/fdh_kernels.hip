@@ -509,8 +509,20 @@ __device__ __forceinline__ void bin_entry(const BinParams& P, int i, int x0, int
 template <bool kRefine>
 __global__ __launch_bounds__(64) void k_bin_draws(BinParams P) {
   const int nb = P.bins_x * P.bins_y;
-  const int phase = blockIdx.x / nb, bin = blockIdx.x - phase * nb;
-  const int by = bin / P.bins_x, bx = bin - by * P.bins_x;
+  int phase, bin, bx, by;
+  if (P.sub_n) {  // (scalar: the table is in the kernel arguments)
+    int s_first = 0, s_x0 = 0, s_y0 = 0, s_nx = P.sub_nx[0];
+    phase = 0;
+#pragma unroll
+    for (int k = 1; k < BinParams::kBinSubs; k++)
+      if (k < P.sub_n && (int)blockIdx.x >= P.sub_first[k]) { phase = k; s_first = P.sub_first[k]; s_x0 = P.sub_x0[k]; s_y0 = P.sub_y0[k]; s_nx = P.sub_nx[k]; }
+    const int local = (int)blockIdx.x - s_first, ly = local / s_nx;
+    bx = s_x0 + local - ly * s_nx; by = s_y0 + ly;
+    bin = by * P.bins_x + bx;
+  } else {
+    phase = blockIdx.x / nb; bin = blockIdx.x - phase * nb;
+    by = bin / P.bins_x; bx = bin - by * P.bins_x;
+  }
   const int x0 = bx * kBin, y0 = by * kBin;
   const int first = P.phase_first[phase], last = P.phase_first[phase + 1];
   uint2* out = P.lists + ((size_t)phase * nb + bin) * P.stride;
@@ -3481,7 +3493,7 @@ bool launch_events_used() { return t_prof_used; }  // false: the launch_* call b
     else hipLaunchKernelGGL(kern, grid, block, lds, stream, __VA_ARGS__);                                                \
   } while (0)
 void launch_bin(hipStream_t s, const BinParams& P) {
-  const int n = P.n_phases * P.bins_x * P.bins_y;
+  const int n = P.sub_n ? P.sub_first[P.sub_n] : P.n_phases * P.bins_x * P.bins_y;
   if (n <= 0) return;
   if (P.refine) FDH_LAUNCH(k_bin_draws<true>, dim3(n), dim3(64), 0, s, P);
   else FDH_LAUNCH(k_bin_draws<false>, dim3(n), dim3(64), 0, s, P);
