@@ -465,8 +465,7 @@ def main():
                     c.replay_async(n)
                     left[i] -= n
 
-    # (the checks above re-rendered every context ALONE, i.e. with the one-kernel blur routes a frame takes when it has the GPU to itself;
-    # a short batch with all contexts in flight leaves each context's resident job on the routes frames in flight take)
+    # (a short batch with all contexts in flight leaves each context's resident job as the dynamic leg's frames were recorded)
     run_dynamic(2 * F)
     sync_all()
     run_replay(args.warmup)
@@ -503,7 +502,7 @@ def main():
     frame_dist = {"n": int(len(ft)), "min": round(float(ft.min()), 4), "p50": round(float(np.percentile(ft, 50)), 4),
                   "p95": round(float(np.percentile(ft, 95)), 4), "max": round(float(ft.max()), 4)}
     # per-kernel durations, HIP events on the context's stream stamped by each launch itself (same frames, same records); the
-    # full-frame blur node on both of its routes (same pixels): two passes (what frames in flight use) and the fused kernel
+    # full-frame blur node on both of its routes (same pixels): the fused kernel (the default) and two passes
     ctx.set_blur_route(1)
     ctx.render_frame(scene, w, h)
     ctx.replay(5)
@@ -703,7 +702,8 @@ def main():
         bh, bv = int(st.bytes_blur_big_h), int(st.bytes_blur_big_v)
         both = hbm(bh + bv, st.ms_blur_big_h + st.ms_blur_big_v)
         th, tv = pmc.get("k_blur_mx.h", {}).get("hbm_bytes"), pmc.get("k_blur_mx.v", {}).get("hbm_bytes")
-        roofline_blur = dict(both, bound="hbm", kernel="k_blur_mx<NK, false> + k_blur_mx<NK, true>: horizontal and vertical pass of the full-frame blur node (matrix pipe)",
+        roofline_blur = dict(both, bound="hbm", kernel="k_blur_mx<NK, false> + k_blur_mx<NK, true>: horizontal and vertical pass of the full-frame blur node (matrix pipe) -- the TWO-PASS route "
+                                    "(fdh_set_blur_route(0)), profiled on its own; the frames of `value` take the one-kernel route, `fused_route` below",
                              ms_per_frame=round(st.ms_blur_big_h + st.ms_blur_big_v, 4), algorithmic_bytes_per_frame=bh + bv,
                              traffic=(th + tv) if th and tv else None, traffic_source=pmc_src,
                              passes={"horizontal": dict(hbm(bh, st.ms_blur_big_h), ms=round(st.ms_blur_big_h, 4), algorithmic_bytes=bh, traffic=th),
@@ -718,7 +718,12 @@ def main():
         roofline_blur["fused_route"] = dict(hbm(bfx, st_fx.ms_blur_fused), ms=round(st_fx.ms_blur_fused, 4), algorithmic_bytes=bfx,
                                             kernel="k_blur_fx<NKH, NKV>: both passes in one out-of-place kernel, the RGBA8 intermediate in LDS",
                                             traffic=pmc.get("k_blur_fx", {}).get("hbm_bytes"),
-                                            note="the route a frame takes when no other context has frames in flight (fdh_set_blur_route); its bytes are "
+                                            survey_8d_bytes=dict(hbm(bh + bv, st_fx.ms_blur_fused), algorithmic_bytes=bh + bv,
+                                                                 note="SURVEY.md 8(d) counts a blur node as H read + H write + V read + V write; this kernel "
+                                                                      "produces that result without the intermediate's round trip through memory"),
+                                            headline_route=True,
+                                            note="the route every frame takes by default since the end of round 4 (fdh_set_blur_route(-1 | 1)): faster than the two "
+                                                 "passes alone AND with four contexts in flight (tools/ab_routes.sh); `algorithmic_bytes` / `frac` are against "
                                                  "what IT must move (region read once + written once), half the two-pass figure; same pixels bit for bit")
     frame_gbs = st.bytes_algorithmic / (ms_step * 1e-3) / 1e9
     single_dyn_ms = 1e3 * sd_elapsed / args.steps

@@ -25,9 +25,6 @@ void hip_check(hipError_t e, const char* what) {
 
 // when each device context of the process last submitted a frame (steady-clock ns; 0 = never): Context::prepare asks whether
 // frames of OTHER contexts are in flight
-static constexpr int kSubmitSlots = 64;
-static std::atomic<int64_t> g_last_submit_ns[kSubmitSlots];
-static std::atomic<int> g_next_submit_slot{0};
 
 // ------------------------------------------------------------------ lifetime
 // Staging in device memory (HostVec::vram): when the device exposes all of its memory to the host (large BAR: every MI355X box of
@@ -75,7 +72,6 @@ Context::Context(int atlas_size, float pixel_scale, int device, uint32_t flags) 
   for (auto& e : staging_ev_) FDH_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   initial_atlas_size_ = atlas_size > 0 ? atlas_size : 1024;  // newContext default, glcontext.nim:255-261
   alloc_atlas(initial_atlas_size_);
-  submit_slot_ = g_next_submit_slot.fetch_add(1) % kSubmitSlots;
   static const bool env_sync = [] { const char* e = std::getenv("FDH_SYNC_SUBMIT"); return e && std::atoi(e) != 0; }();
   if (!(flags & FDH_CREATE_SYNC_SUBMIT) && !env_sync) worker_ = std::thread([this] { worker_main(); });
 }
@@ -662,14 +658,8 @@ void Context::prepare(LaunchJob& J) {
     if (o_mxh[i]) { J.mx_w_h[i] = reinterpret_cast<const uint4*>(d_frame_.ptr + o_mxh[i]); J.mx_w_v[i] = reinterpret_cast<const uint4*>(d_frame_.ptr + o_mxv[i]); }
   // A blur node that covers the whole frame, composited by its own vertical pass (no clip open), in a frame that starts from
   // the clear colour: both passes as ONE kernel, out of place (k_blur_fx) -- launch_frame alternates between fb_ and alt_.
-  // Which route is a matter of speed only -- the two give the same pixels bit for bit (tests/test_hip_parity.py).  The fused
-  // kernel moves half the bytes and shortens a frame rendered ALONE (4K bench frame: both passes 38.5 -> 34 us), but it
-  // re-filters 40 % more rows horizontally (segment halos) and holds 22 KB of LDS and 249 VGPRs per wave: with other contexts'
-  // frames in flight on the GPU, where total work is what counts, the two-pass route is 3 % faster.  So: fused when no other
-  // context of this process has submitted a frame in the last millisecond (FDH_BLUR_FUSED=1 always, =0 never).
+  // Which route is a matter of speed only -- the two give the same pixels bit for bit (tests/test_hip_parity.py): Context::pick_routes.
   const bool fx_on = latency_routes_;  // (decided when the frame began: Context::pick_routes)
-  g_last_submit_ns[submit_slot_].store(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(),
-                                       std::memory_order_relaxed);
   J.blur_fused.assign(J.blurs.size(), 0);
   J.n_fused = 0;
   for (size_t i = 0; i < J.blurs.size(); i++) {
@@ -944,20 +934,17 @@ void Context::prepare(LaunchJob& J) {
 }
 
 // Which blur routes a frame takes is a matter of speed only (same pixels either way): the one-kernel routes -- k_blur_fx for a node
-// that covers the frame, k_blur_small for a small one -- shorten a frame rendered ALONE (fewer dependent launches, half the bytes)
-// but lose a few per cent with other contexts' frames in flight on the GPU, where total work and the way the contexts' kernels
-// interleave are what counts (bench.py, alternating runs: 90.8 against 95.2 us one frame at a time, 135 against 141 Gpixel/s with
-// four contexts).  So: the latency routes when no other context of this process has submitted a frame in the last millisecond
-// (fdh_set_blur_route / FDH_BLUR_FUSED = 1: always, 0: never).
+// that covers the frame, k_blur_small for a small one: fewer dependent launches, half the bytes -- or the two passes as two
+// kernels.  Rounds 3 and early 4 chose per frame: one-kernel routes for a frame rendered alone, two-pass routes when another
+// context of the process had submitted a frame within the last millisecond, where they measured 3 - 4 % faster (135 against 141
+// Gpixel/s with four contexts).  With the last bubbles out of the launch chain (no event behind the upload, bin workgroups per
+// phase box) that has turned: one-kernel routes 150.0 - 150.6 Gpixel/s against 145.1 - 147.3 with four contexts (tools/ab_routes.sh,
+// three alternations on one box), and 84 against 94 us one frame at a time.  So: the one-kernel routes, always
+// (fdh_set_blur_route / FDH_BLUR_FUSED = 0: the two-pass routes).
 void Context::pick_routes() {
   static const int fx_env = [] { const char* e = std::getenv("FDH_BLUR_FUSED"); return e ? (std::atoi(e) != 0 ? 1 : 0) : -1; }();
   const int route = blur_route_ >= 0 ? blur_route_ : fx_env;
   latency_routes_ = route != 0;
-  if (route < 0 && !host_only_) {
-    const int64_t now = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
-    for (int k = 0; k < kSubmitSlots; k++)
-      if (k != submit_slot_ && now - g_last_submit_ns[k].load(std::memory_order_relaxed) < 1000000) { latency_routes_ = false; break; }
-  }
 }
 
 // More pieces than the upload's run table holds (a frame with many parallel sibling groups): they are copied together into one

@@ -487,7 +487,6 @@ class Context : public Recorder {
   uint32_t flags_ = 0;
   int blur_route_ = -1;   // fdh_set_blur_route: -1 per-frame decision, 0 two passes, 1 fused
   bool latency_routes_ = true;  // this frame takes the one-kernel blur routes (pick_routes)
-  int submit_slot_ = 0;   // this context's entry in the process-wide table of last submissions (Context::prepare)
   std::shared_ptr<void> comm_;  // shared communicator object (fdh_comm.cpp), shared with the contexts that borrowed it: destroyed with its last holder
   int comm_rank_ = 0, comm_world_ = 1;
   hipStream_t own_stream_ = nullptr, stream_ = nullptr;

@@ -373,10 +373,10 @@ FDH_API int fdh_comm_info(FdhContext*, int* rank, int* world);
 FDH_API int fdh_comm_destroy(FdhContext*);
 FDH_API int fdh_gather_stripes(FdhContext*, int dst_rank, void* dst_image);
 FDH_API int fdh_gather_frames(FdhContext*, int dst_rank, void* const* dst_images);
-/* Which route a blur node covering the whole frame takes: 1 = both passes as one out-of-place kernel (k_blur_fx: half the bytes,
- * the shortest frame when it has the GPU to itself), 0 = the horizontal and the vertical pass as two kernels (less total work:
- * faster when other contexts' frames are in flight), -1 (default) = decided per frame -- fused unless another context of the
- * process submitted a frame within the last millisecond.  The pixels are the same bit for bit; FDH_BLUR_FUSED=0|1 in the
+/* Which routes the blur nodes of a frame take: 1 = the one-kernel routes (a node covering the whole frame: both passes as one
+ * out-of-place kernel, k_blur_fx, half the bytes; a small node: k_blur_small), 0 = the horizontal and the vertical pass as two
+ * kernels each, -1 (default) = the library's choice: the one-kernel routes (until round 4 it chose per frame, two-pass routes beside
+ * other contexts' frames; they no longer measure faster there).  The pixels are the same bit for bit; FDH_BLUR_FUSED=0|1 in the
  * environment sets the default. */
 FDH_API int fdh_set_blur_route(FdhContext*, int route);
 /* Re-run the GPU work of the last submitted frame `times` times from the draw records already resident in HBM
