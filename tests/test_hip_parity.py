@@ -1224,6 +1224,49 @@ def test_staging_in_device_memory_changes_no_pixel():
         assert np.array_equal(a, b)
 
 
+def test_launch_chain_switches_change_no_pixel():
+    """Round 4's two changes to the launch chain are speed only: who tells the host that a staging set is free again (the bin
+    launch's store to a pinned word -- or the event behind the upload, FDH_STAGING_EVENT=1) and which bins a later phase's part of
+    the bin launch covers (the phase's own box -- or the whole grid, FDH_BIN_SUBGRIDS=0).  Both are read once per process, hence the
+    child processes.  A burst of animation frames through one context (the staging sets rotate and are waited for), a frame of
+    four phases with blur nodes of different footprints, a clipped tree and a stripe: same frames bit for bit."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+
+    code = (
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "from figdraw_amd import scene as S\n"
+        "from figdraw_amd.context import HipContext\n"
+        "from figdraw_amd.scenes import make_render_tree_100, make_clip_mask_benchmark\n"
+        "ctx = HipContext(device=0)\n"
+        "out = []\n"
+        "for k in range(12): ctx.render_frame(make_render_tree_100(1280, 720, k, full_frame_blur=(k %% 2 == 0)), 1280, 720)\n"
+        "out.append(ctx.read_pixels().copy())\n"
+        "sc = make_render_tree_100(1920, 1080, 5, full_frame_blur=True)\n"
+        "lst = sc.layers[0]\n"
+        "lst.addRoot(S.Fig(kind=S.FigKind.nkBackdropBlur, corners=[12] * 4, screenBox=S.rect(1500, 40, 300, 200), fill=S.rgba(0, 0, 0, 0), blur=7.0))\n"
+        "lst.addRoot(S.Fig(kind=S.FigKind.nkRectangle, corners=[12] * 4, screenBox=S.rect(1480, 30, 200, 120), fill=S.rgba(40, 200, 90, 130)))\n"
+        "ctx.render_frame(sc, 1920, 1080); out.append(ctx.read_pixels().copy())\n"
+        "ctx.render_frame(make_clip_mask_benchmark('sub_clip'), 1200, 800); out.append(ctx.read_pixels().copy())\n"
+        "ctx.set_stripe(270, 540)\n"
+        "ctx.render_frame(make_render_tree_100(1920, 1080, 2, full_frame_blur=True), 1920, 1080); out.append(ctx.read_pixels()[270:540].copy())\n"
+        "np.savez(sys.argv[1], *out)\n"
+    ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    with tempfile.TemporaryDirectory() as td:
+        for name, env in (("default", {}), ("event", {"FDH_STAGING_EVENT": "1"}), ("whole_grid", {"FDH_BIN_SUBGRIDS": "0"})):
+            path = os.path.join(td, f"{name}.npz")
+            subprocess.check_call([sys.executable, "-c", code, path], env=dict(os.environ, **env))
+            z = np.load(path)
+            res[name] = [z[f"arr_{i}"] for i in range(4)]
+    for name in ("event", "whole_grid"):
+        for a, b in zip(res["default"], res[name]):
+            assert np.array_equal(a, b), name
+
+
 def test_small_blur_in_one_kernel_equals_the_two_pass_route():
     """k_blur_small (a small region's two passes in one kernel, snapshot to the backdrop surface, composited by the phase's launch)
     against the two small-region passes with the composite fused into the vertical one (FDH_BLUR_ONE_KERNEL=0; read once per
