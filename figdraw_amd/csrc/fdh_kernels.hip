@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <stdint.h>
+#include <algorithm>
 
 #include "fdh_kernels.h"
 
@@ -3707,11 +3708,12 @@ void launch_blur_v(hipStream_t s, const BlurParams& P, const DrawRec* draws, con
 // host link made the launch 20 us long; the chunk boxes now come from the host, a few dozen bytes.)
 __global__ __launch_bounds__(64) void k_upload_frame(uint8_t* __restrict__ dst, UploadTable T) {
   const uint32_t lane = threadIdx.x;
-  const uint32_t u = blockIdx.x;
-  uint32_t r = 0;
-  for (uint32_t k = 1; k < T.n_runs; k++) r = T.unit_first[k] <= u ? k : r;  // (unit_first ascends: the last run that starts at or before u)
-  const UploadRun R = T.run[r];
-  const uint32_t at = (u - T.unit_first[r]) * 1024u;
+  // blockIdx.y = the run, blockIdx.x = the 1-KB unit inside it (the grid is as wide as the longest run; the workgroups past a
+  // shorter run's end leave at once).  First version: a linear grid and a search of the run table for the unit's run -- one
+  // scalar load and a wait per table entry, ~30 entries for a frame recorded by the walk pool: half of the launch's 4.5 us.
+  const UploadRun R = T.run[blockIdx.y];
+  const uint32_t at = blockIdx.x * 1024u;
+  if (at >= R.bytes) return;
   if (R.kind == 1u) {  // BinRecs in 8-byte units (24 bytes each: a piece starts 8-byte aligned)
     const uint32_t ush = 6u + T.binbox_shift;
 #pragma unroll
@@ -3742,7 +3744,9 @@ __global__ __launch_bounds__(64) void k_upload_frame(uint8_t* __restrict__ dst, 
 }
 void launch_upload_frame(hipStream_t s, void* dst, const UploadTable& T) {
   if (T.copy_units == 0) return;
-  hipLaunchKernelGGL(k_upload_frame, dim3(T.copy_units), dim3(64), 0, s, static_cast<uint8_t*>(dst), T);
+  uint32_t widest = 1;
+  for (uint32_t r = 0; r < T.n_runs; r++) widest = std::max(widest, (T.run[r].bytes + 1023u) / 1024u);
+  hipLaunchKernelGGL(k_upload_frame, dim3(widest, T.n_runs), dim3(64), 0, s, static_cast<uint8_t*>(dst), T);
 }
 void launch_fill(hipStream_t s, uint32_t* p, uint32_t v, size_t n) {
   if (n == 0) return;
