@@ -2564,16 +2564,25 @@ __global__ __launch_bounds__(kSmallThreads) void k_blur_small(BlurParams P) {
   const int ntx = (P.x1 - P.x0 + kSmallTW - 1) / kSmallTW;
   const int ty = (int)blockIdx.x / ntx, tx = (int)blockIdx.x - ty * ntx;
   const int xs = P.x0 + tx * kSmallTW, ys = P.y0 + ty * kSmallTH;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  for (int rr = wave; rr < rows; rr += kSmallThreads / 64) {
-    int y = ys - reach + rr;
+  // Staging: every thread asks for ALL its texels of the window, then stores them (at most kSmallStage each: (32 + 48) x (16 + 48)
+  // texels for the widest eligible filter).  Written as a row loop inside a column loop, each thread fetched and stored one texel
+  // after the other -- up to seven dependent round trips to memory at the head of a kernel that is little else.
+  constexpr int kSmallStage = 5;
+  const int n_in = rows * in_w;
+  uint32_t texel[kSmallStage];
+#pragma unroll
+  for (int k = 0; k < kSmallStage; k++) {
+    const int i = min((int)threadIdx.x + k * kSmallThreads, n_in - 1);
+    const int rr = i / in_w, cc = i - rr * in_w;
+    int y = ys - reach + rr, x = xs - reach + cc;
     y = y < 0 ? 0 : (y > P.H - 1 ? P.H - 1 : y);  // clamp-to-edge (glcontext.nim:214-215)
-    const uint32_t* __restrict__ row = P.src + (size_t)y * P.pitch;
-    for (int cc = lane; cc < in_w; cc += 64) {
-      int x = xs - reach + cc;
-      x = x < 0 ? 0 : (x > P.W - 1 ? P.W - 1 : x);
-      in[rr * in_w + cc] = row[x];
-    }
+    x = x < 0 ? 0 : (x > P.W - 1 ? P.W - 1 : x);
+    texel[k] = P.src[(size_t)y * P.pitch + x];
+  }
+#pragma unroll
+  for (int k = 0; k < kSmallStage; k++) {
+    const int i = (int)threadIdx.x + k * kSmallThreads;
+    if (i < n_in) in[i] = texel[k];
   }
   __syncthreads();
   // horizontal: a thread produces two consecutive outputs of one row
