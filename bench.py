@@ -695,7 +695,9 @@ def main():
                     "traffic": k.get("hbm_bytes"), "traffic_source": pmc_src,
                     "hbm": dict(hbm(st.bytes_composite_main, st.ms_composite_main), algorithmic_bytes_per_launch=int(st.bytes_composite_main)),
                     "note": "fused tile compositor: VALU-bound (it moves 4 B/pixel out + 128 B/draw in by construction, `hbm`: ~0.1 of the HBM peak says nothing "
-                            "about the kernel); the HBM-bound launches are the blur passes (roofline_blur)"}
+                            "about the kernel); the HBM-bound launches are the blur passes (roofline_blur).  Since every frame takes the one-kernel blur route, the frame's "
+                            "LONGEST launch is k_blur_fx (roofline_blur.fused_route: ~32 us against this one's ~26); this object stays on the compositor, the kernel "
+                            "rounds 1 - 3 were judged on, which still holds the larger share of the SIMDs' issue cycles (15.7 M VALU against 6.3 M + 0.78 M MFMA)"}
     # The HBM-bound launches: the two passes of the frame's largest blur node (full frame here), each against its own bytes
     roofline_blur = None
     if st.ms_blur_big_h > 0 and st.ms_blur_big_v > 0:
