@@ -502,7 +502,7 @@ class HipContext:
         return out.value
 
     def set_blur_route(self, route: int):
-        """full-frame blur nodes: 1 fused kernel, 0 two passes, -1 decided per frame (same pixels either way)"""
+        """blur routes: 1 the one-kernel routes (k_blur_fx / k_blur_small), 0 two passes per node, -1 the library's default = the one-kernel routes (same pixels either way)"""
         self._ck(self.L.fdh_set_blur_route(self.h, int(route)))
 
     @staticmethod
