@@ -1111,6 +1111,7 @@ void Context::launch_frame(const LaunchJob& J, bool profile, uint32_t upload_seq
         BlurParams bp;
         bp.W = J.W; bp.H = J.H; bp.pitch = J.W;
         bp.taps = j.taps;
+        bp.node_pixels = (long long)(j.x1 - j.x0) * (j.y1 - j.y0);
         bp.fuse_draw = -1;
         bp.mx_w = (size_t)ph.blur < mx_w_h_.size() ? mx_w_h_[ph.blur] : nullptr;
         bool done = false;

@@ -67,6 +67,9 @@ struct BlurParams {
   // or null: the packed-FMA passes then take the launch
   const uint4* mx_w;
   BlurTaps taps;
+  // pixels of the NODE's whole footprint (0: of this launch's region): which passes take the launch -- matrix pipe or VALU -- goes by
+  // it, so that a row stripe of a large node runs the kernels the whole frame runs (their sums differ in the last bits)
+  long long node_pixels = 0;
 };
 
 // profile mode: the next launch_* call stamps these events with its kernel's own start / end (nullptr: plain launches)

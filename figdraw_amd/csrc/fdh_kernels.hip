@@ -3555,7 +3555,7 @@ static bool blur_small(const BlurParams& P) {
   if (blur_forced_path()) return blur_forced_path() == 1;
   // tools/blur_size_sweep.py, full-frame blur(18), H + V: 640x360 16.4 us on these passes / 17.3 on the matrix pipe,
   // 960x540 20.8 / 16.3, 1280x720 26.1 / 18.9
-  return (long long)(P.x1 - P.x0) * (P.y1 - P.y0) < 384 * 1024;
+  return (P.node_pixels > 0 ? P.node_pixels : (long long)(P.x1 - P.x0) * (P.y1 - P.y0)) < 384 * 1024;
 }
 // Outputs per thread for a large region: more outputs share each unpacked texel (4 converts per texel and n outputs
 // against the 2 * taps pair FMAs every output needs anyway), but the extent along the pass is cut into units of

@@ -991,6 +991,27 @@ def test_stripe_culling_changes_no_pixel_of_the_stripe(hip, stripe):
     assert np.array_equal(culled, whole[stripe[0]:stripe[1]])
 
 
+@pytest.mark.parametrize("route", [0, 1])
+def test_a_stripe_of_a_large_blur_node_runs_the_whole_frames_kernels(route):
+    """Which blur passes take a launch -- matrix pipe or VALU, whose sums differ in the last bits -- goes by the NODE's footprint,
+    not by the rows a stripe leaves of it: a 136-row stripe of a 1920x1080 full-frame blur (0.33 Mpx with its halo: under the
+    0.4-Mpx crossover) must equal the whole frame's rows bit for bit on the two-pass route too (round 4: it differed in 1 - 5
+    pixels by 1 LSB there; the one-kernel route, the default, never did)."""
+    from figdraw_amd.context import HipContext
+    from figdraw_amd.scenes import make_render_tree_100
+
+    w, h = 1920, 1080
+    sc = make_render_tree_100(w, h, frame=2, full_frame_blur=True)
+    ctx = HipContext(device=0)
+    ctx.set_blur_route(route)
+    ctx.render_frame(sc, w, h)
+    whole = ctx.read_pixels().copy()
+    for y0, y1 in ((0, 136), (272, 408), (944, 1080)):
+        ctx.set_stripe(y0, y1)
+        ctx.render_frame(sc, w, h)
+        assert np.array_equal(ctx.read_pixels()[y0:y1], whole[y0:y1]), (route, y0, y1)
+
+
 def test_replay_refuses_a_stripe_the_records_were_not_culled_for(hip):
     from figdraw_amd.context import FigdrawHipError
     from figdraw_amd.scenes import make_render_tree_100
