@@ -51,6 +51,29 @@ bool vram_staging() {
   return on;
 }
 
+namespace {
+std::mutex g_vram_mu;
+std::vector<void*> g_vram_free[48];  // by log2 of the size class
+int vram_class(size_t bytes) { int k = 12; while (((size_t)1 << k) < bytes) k++; return k; }
+}  // namespace
+void* vram_block_acquire(size_t bytes, size_t* size_class) {
+  const int k = vram_class(bytes);
+  *size_class = (size_t)1 << k;
+  {
+    std::lock_guard<std::mutex> lk(g_vram_mu);
+    if (!g_vram_free[k].empty()) { void* p = g_vram_free[k].back(); g_vram_free[k].pop_back(); return p; }
+  }
+  void* p = nullptr;
+  FDH_HIP(hipExtMallocWithFlags(&p, (size_t)1 << k, hipDeviceMallocUncached));
+  return p;
+}
+void vram_block_release(void* p, size_t size_class) {
+  if (!p) return;
+  if (!size_class) { (void)hipFree(p); return; }
+  std::lock_guard<std::mutex> lk(g_vram_mu);
+  g_vram_free[vram_class(size_class)].push_back(p);
+}
+
 Context::Context(int atlas_size, float pixel_scale, int device, uint32_t flags) : Recorder(this, true), device_(device), flags_(flags), pixel_scale_(pixel_scale) {
   host_only_ = (flags & FDH_CREATE_RECORD_ONLY) != 0;
   if (host_only_) {  // a call recorder: the front-end and the atlas packer run, nothing is drawn, no device is touched
@@ -66,6 +89,10 @@ Context::Context(int atlas_size, float pixel_scale, int device, uint32_t flags) 
   FDH_HIP(hipGetDeviceProperties(&prop, device));
   if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
     throw Error(FDH_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library carries gfx950 code only");
+  // host writes into device memory through the BAR pass the GPU's host data path, which may hold them: its flush register (mapped
+  // for exactly this: HSA_AMD_AGENT_INFO_HDP_FLUSH) is written before the launches that read the staging mirrors (Context::prepare)
+  static const bool hdp_on = [] { const char* e = std::getenv("FDH_HDP_FLUSH"); return !e || std::atoi(e) != 0; }();
+  hdp_flush_reg_ = hdp_on ? prop.hdpMemFlushCntl : nullptr;
   FDH_HIP(hipStreamCreateWithFlags(&own_stream_, hipStreamNonBlocking));
   stream_ = own_stream_;
   for (auto& e : ev_) FDH_HIP(hipEventCreate(&e));
@@ -927,7 +954,12 @@ void Context::prepare(LaunchJob& J) {
   stats_.bytes_frame_implementation = bytes - bytes_saved;
   stats_.fragments = fragments_;
   if (folded) folded_br->box = folded_box;  // (the recorded frame stays what the calls produced)
-  if (vram_staging()) store_fence();  // (what this thread wrote into device memory is on its way before the launches are)
+  if (vram_staging()) {
+    store_fence();  // (what this thread wrote into device memory is on its way before the launches are)
+    // ... and what it and the pool's threads wrote is pushed out of the host data path: without this, frames of fresh contexts on
+    // several host threads came out wrong -- or faulted -- in ~5 % of tools/thread_churn.py runs (end of round 4)
+    if (hdp_flush_reg_) { *hdp_flush_reg_ = 1u; store_fence(); }
+  }
   const auto t_l0 = std::chrono::steady_clock::now();
   stats_.ms_host_record = host_record_ms_;
   stats_.ms_host_upload = std::chrono::duration<float, std::milli>(t_l0 - t_s0).count();

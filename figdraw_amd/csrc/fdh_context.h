@@ -91,6 +91,13 @@ struct PinnedBuf {
 // CPU -- a load from it crosses the link uncached -- so growth does NOT carry contents over (callers set n = 0 first, as the pinned
 // mirrors always did), and a store fence (store_fence()) precedes the hand-over to whoever launches the kernels.
 bool vram_staging();  // large-BAR device and FDH_VRAM_STAGING != 0 (fdh_context.cpp)
+// Device blocks for staging come from, and go back to, a process-wide store by size class (powers of two from 4 KB): they are
+// never handed back to the driver while the process lives.  A block the driver recycles may be memory another allocation's
+// kernels wrote through the L2s; the host's stores reach memory BESIDE those caches, and a line written back later lands on top
+// of them (tools/thread_churn.py: fresh contexts on four host threads, wrong first frames or a fault in ~5 % of runs).  Staging
+// blocks are only ever written by the host and read uncached by the device, so recycled among themselves they carry no such lines.
+void* vram_block_acquire(size_t bytes, size_t* size_class);  // throws Error on failure
+void vram_block_release(void* p, size_t size_class);
 inline void store_fence() {
 #if defined(__x86_64__) || defined(__i386__)
   __builtin_ia32_sfence();
@@ -107,7 +114,8 @@ struct HostVec {
   HostVec(const HostVec&) = delete;
   HostVec& operator=(const HostVec&) = delete;
   ~HostVec() { release(); }
-  void free_block(T* q) { if (!q) return; if (pinned && vram) (void)hipFree(q); else if (pinned) (void)hipHostFree(q); else std::free(q); }
+  void free_block(T* q) { if (!q) return; if (pinned && vram) vram_block_release(q, vram_bytes_); else if (pinned) (void)hipHostFree(q); else std::free(q); }
+  size_t vram_bytes_ = 0;  // size class of the device block p (vram_block_acquire)
   void release() {
     free_block(p);
     p = nullptr; n = cap = 0;
@@ -117,12 +125,13 @@ struct HostVec {
     size_t c = cap ? cap : 256;
     while (c < want) c *= 2;
     T* fresh = nullptr;
-    if (pinned && vram) FDH_HIP(hipExtMallocWithFlags((void**)&fresh, c * sizeof(T), hipDeviceMallocUncached));
+    size_t fresh_bytes = 0;
+    if (pinned && vram) fresh = static_cast<T*>(vram_block_acquire(c * sizeof(T), &fresh_bytes));
     else if (pinned) FDH_HIP(hipHostMalloc((void**)&fresh, c * sizeof(T), hipHostMallocDefault));
     else if (!(fresh = static_cast<T*>(std::aligned_alloc(64, (c * sizeof(T) + 63) & ~(size_t)63)))) throw std::bad_alloc();
     if (n && !(pinned && vram)) std::memcpy(static_cast<void*>(fresh), static_cast<const void*>(p), n * sizeof(T));
     free_block(p);
-    p = fresh; cap = c;
+    p = fresh; cap = c; vram_bytes_ = fresh_bytes;
   }
   // the block as the GPU addresses it
   const uint8_t* device_view() const {
@@ -490,6 +499,7 @@ class Context : public Recorder {
   std::shared_ptr<void> comm_;  // shared communicator object (fdh_comm.cpp), shared with the contexts that borrowed it: destroyed with its last holder
   int comm_rank_ = 0, comm_world_ = 1;
   hipStream_t own_stream_ = nullptr, stream_ = nullptr;
+  volatile unsigned int* hdp_flush_reg_ = nullptr;  // the device's HDP_MEM_COHERENCY_FLUSH_CNTL register, mapped by the runtime (or null)
   hipEvent_t ev_[2] = {};
   std::vector<hipEvent_t> ev_pool_;
   size_t ev_used_ = 0;

@@ -697,8 +697,11 @@ def test_contexts_on_several_host_threads():
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "thread_churn.py"), "4", "8"], capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0 and ": 0 wrong" in r.stdout, (r.returncode, r.stdout[-600:], r.stderr[-1200:])
+    # (six runs: until the end of round 4 one run in twenty came out wrong -- first frames of fresh contexts whose staging blocks the
+    # driver had recycled; a single run passed most of the time.  Staging blocks are kept in a process-wide store since.)
+    for _ in range(6):
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "thread_churn.py"), "4", "8"], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and ": 0 wrong" in r.stdout, (r.returncode, r.stdout[-600:], r.stderr[-1200:])
 
 
 def test_fused_full_frame_blur_equals_the_two_pass_route():

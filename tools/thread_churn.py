@@ -35,8 +35,11 @@ def work(t):
                 w, h, sc = scenes[i]
                 ctx.render_frame(sc, w, h)
                 if k != 1:  # (sometimes two frames back to back without a read in between)
-                    if not np.array_equal(ctx.read_pixels(), want[i]):
-                        bad.append((t, it, i))
+                    got = ctx.read_pixels()
+                    if not np.array_equal(got, want[i]):
+                        d = (got != want[i]).any(axis=2)
+                        ys, xs = np.nonzero(d)
+                        bad.append((t, it, i, k, f"{int(d.sum())} px, rows {ys.min()}..{ys.max()}, cols {xs.min()}..{xs.max()}, max {int(np.abs(got.astype(int) - want[i].astype(int)).max())}, sync_submit {(it + t) % 3 == 0}"))
             ctx.close()
     except Exception as e:  # noqa: BLE001
         bad.append((t, "exception", repr(e)))
