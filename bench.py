@@ -70,7 +70,7 @@ def setup_comm(ctxs, dist, rank, world):
         c.comm_share(ctxs[0])
 
 
-def run_stripes(args, dist, rank, local_rank, world, on_host):
+def run_stripes(args, dist, rank, local_rank, world, on_host, gather):
     """BASELINE config 5: an 8-frame batch, each frame row-striped over the ranks, stripes gathered to rank 0 per frame.
     Every rank renders rows fdh_stripe_rows(H, world, rank) of EVERY frame through fdh_render_frame (tree in, rows out; the
     vertical blur halo is re-rendered, so nothing is exchanged while a frame renders) on frames_in_flight contexts, and each
@@ -105,8 +105,8 @@ def run_stripes(args, dist, rank, local_rank, world, on_host):
         c.sync()
     # (under gloo the library's gather only runs when a transport is named explicitly: FDH_RCCL_LIB -- the tests' stand-in for RCCL, which
     # refuses two ranks on one device)
-    use_c_abi = args.gather == "c_abi" and (not on_host or bool(os.environ.get("FDH_RCCL_LIB")))
-    use_host = args.gather == "host"
+    use_c_abi = gather == "c_abi" and (not on_host or bool(os.environ.get("FDH_RCCL_LIB")))
+    use_host = gather == "host"
     dev = "cpu" if on_host else f"cuda:{local_rank}"
     gather_s = [0.0]
     ranks_seen = None
@@ -197,7 +197,9 @@ def run_stripes(args, dist, rank, local_rank, world, on_host):
     res = sorted(timed(args.steps) for _ in range(args.repeats))
     elapsed, gather_host = res[len(res) // 2]
     if rank != 0:
-        return
+        for c in ctxs:
+            c.close()
+        return None
     last_k = args.steps - 1
     last_i = last_k % F
     if use_c_abi:
@@ -233,7 +235,7 @@ def run_stripes(args, dist, rank, local_rank, world, on_host):
             sys.exit(1)
     st = ctxs[0].frame_stats()
     ms_step = 1e3 * elapsed / args.steps
-    print(json.dumps({
+    out = {
         "metric": f"Mpixels/s composited @{w}x{h}, 300 SDF rects+shadows, row-striped (BASELINE.json configs[4]; the headline metric is quoted at 3840x2160)",
         "value": round(w * h * args.steps / elapsed / 1e6, 1), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_step, 4), "repeats": args.repeats, "batches_ms": [round(1e3 * t, 4) for t, _ in res],
@@ -253,13 +255,138 @@ def run_stripes(args, dist, rank, local_rank, world, on_host):
                        "part of `value`'s wall time",
         "gathered_frame_check": check,
         "roofline": None, "cpu_baseline": None,
-    }))
+    }
+    for c in ctxs:
+        c.close()
+    return out
+
+
+class Watchdog:
+    """A collective that never completes (a rank lost, a link down, a first-ever ncclSend / ncclRecv pair that hangs) must not take the
+    figures measured before it along: after `seconds` every rank leaves with exit code 3, rank 0 printing `line()` first."""
+
+    def __init__(self, seconds, rank, line):
+        import threading
+
+        def fire():
+            if rank == 0:
+                print(json.dumps(line()), flush=True)
+            os._exit(3)
+
+        self.t = threading.Timer(seconds, fire)
+        self.t.daemon = True
+
+    def __enter__(self):
+        self.t.start()
+        return self
+
+    def __exit__(self, *exc):
+        self.t.cancel()
+        return False
+
+
+def write_provisional(out):
+    """rank 0, before the C-ABI gather leg: the line as it stands, where the launcher (self_launch) finds it if the ranks die in that leg"""
+    try:
+        os.makedirs(os.path.dirname(PROVISIONAL), exist_ok=True)
+        json.dump(out, open(PROVISIONAL, "w"))
+    except OSError:
+        pass
+
+
+def stripes_main(args, dist, rank, local_rank, world, on_host):
+    """--mode stripes: one leg per gather.  With --gather both (the default on several ranks) the torch.distributed leg runs first and
+    owns `value`; the library's fdh_gather_stripes leg follows under the watchdog and is reported as `c_abi_gather`."""
+    first = "torch" if args.gather == "both" else args.gather
+    out = run_stripes(args, dist, rank, local_rank, world, on_host, first)
+    if rank == 0:
+        out["torch_world_size"] = dist.get_world_size() if dist is not None else 1
+    if args.gather == "both" and world > 1:
+        can = not on_host or bool(os.environ.get("FDH_RCCL_LIB"))
+        if not can:
+            if rank == 0:
+                out["c_abi_gather"] = {"skipped": "gloo run with no stand-in transport named (FDH_RCCL_LIB): the library's gather needs RCCL, one GPU per rank"}
+        else:
+            if rank == 0:
+                write_provisional(out)
+
+            def late():
+                return dict(out, c_abi_gather={"error": f"the fdh_gather_stripes leg did not complete within {args.gather_timeout} s; `value` (torch.distributed gather) was measured before it"})
+
+            with Watchdog(args.gather_timeout, rank, late):
+                try:
+                    leg = run_stripes(args, dist, rank, local_rank, world, on_host, "c_abi")
+                    if rank == 0:
+                        out["c_abi_gather"] = {"value": leg["value"], "unit": leg["unit"], "ms_per_step": leg["ms_per_step"], "batches_ms": leg["batches_ms"],
+                                               "gather_ms": leg["gather_ms"], "gather": leg["config"]["gather"], "rccl_ranks_seen": leg["config"]["rccl_ranks_seen"],
+                                               "gathered_frame_check": leg["gathered_frame_check"]}
+                        out["config"]["rccl_ranks_seen"] = leg["config"]["rccl_ranks_seen"]
+                except Exception as e:  # (reported; `value` was measured through the other gather)
+                    if rank == 0:
+                        out["c_abi_gather"] = {"error": f"{type(e).__name__}: {e}"}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+
+
+
+
+def free_port():
+    import socket
+
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+PROVISIONAL = os.path.join(ROOT, "gpurun_out", "bench_provisional_line.json")
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` with no WORLD_SIZE in the environment: start the N ranks as a CHILD (python -m torch.distributed.run,
+    one rank per GPU) before this process has made any GPU call -- it never makes one --, relay rank 0's JSON line and the child's
+    exit code.  Refuses (rc 4) a line whose n_gpus is not the N that was asked for."""
+    import subprocess
+
+    port = os.environ.get("MASTER_PORT") or str(free_port())
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.pop("MASTER_PORT", None)
+    try:
+        os.remove(PROVISIONAL)
+    except OSError:
+        pass
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", port, os.path.abspath(__file__)] + argv
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    rc = r.returncode
+    if not lines and os.path.exists(PROVISIONAL):
+        # the ranks died inside the C-ABI gather leg (after `value` and the torch gather were measured and written down)
+        d = json.load(open(PROVISIONAL))
+        d["c_abi_gather"] = {"error": f"the ranks exited with code {rc} inside the fdh_gather_* leg; `value` and the torch.distributed gather were measured before it"}
+        lines = [json.dumps(d)]
+        rc = rc or 3
+    if not lines:
+        sys.stderr.write(r.stdout[-4000:])
+        sys.exit(rc or 1)
+    line = lines[-1]
+    try:
+        n = json.loads(line).get("n_gpus")
+    except ValueError:
+        n = None
+    print(line, flush=True)
+    if n != args.gpus:
+        sys.stderr.write(f"bench.py: asked for --gpus {args.gpus}, the line says n_gpus = {n}\n")
+        sys.exit(rc or 4)
+    sys.exit(rc)
 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--gpus", type=int, default=None,
+                    help="ranks (one per GPU).  With no WORLD_SIZE in the environment and N > 1 this process starts them itself (a torch.distributed.run "
+                         "child); under a launcher it must equal WORLD_SIZE")
+    ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--repeats", type=int, default=7, help="timed batches of --steps frames each; the median batch is reported")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -268,24 +395,61 @@ def main():
     ap.add_argument("--frames-in-flight", type=int, default=4,
                     help="independent render contexts per GPU (own stream + surfaces) whose frames overlap; 1 = strictly one frame at a time")
     ap.add_argument("--host-threads", type=int, default=0, help="host threads driving the contexts of `value` (0 = one per context in flight)")
-    ap.add_argument("--gather", choices=["c_abi", "torch", "host"], default=None,
+    ap.add_argument("--gather", choices=["c_abi", "torch", "host", "both"], default=None,
                     help="who moves the finished rows / frames to rank 0: c_abi = the library's own fdh_gather_* (RCCL through the C ABI, stream-ordered, "
-                         "north_star's single RCCL gather); torch = torch.distributed (always used with --backend gloo); host (--mode stripes) = no gather: "
-                         "every rank reads its stripe back over its OWN PCIe link (fdh_read_pixels) -- the consumer is the host.  Default: c_abi on one "
-                         "rank; torch on several until a two-GPU run of fdh_gather_* has passed (its send / recv pairs have never executed, ADVICE r3)")
+                         "north_star's single RCCL gather); torch = torch.distributed; host (--mode stripes) = no gather: every rank reads its stripe back "
+                         "over its OWN PCIe link (fdh_read_pixels) -- the consumer is the host; both = the torch leg first (its figures are `value` / "
+                         "`gather_ms`), then the c_abi leg under a watchdog, reported beside it.  Default: c_abi on one rank, both on several")
     ap.add_argument("--gather-timeout", type=float, default=180.0, help="seconds the gather legs of an N > 1 run may take before they are given up")
-    ap.add_argument("--width", type=int, default=W)
-    ap.add_argument("--height", type=int, default=H)
-    ap.add_argument("--mode", choices=["frames", "stripes"], default="frames",
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--mode", choices=["frames", "stripes"], default=None,
                     help="frames: every rank renders whole frames (weak scaling); stripes: every rank renders its row stripe of every frame of an "
                          "8-frame batch and the stripes are gathered to rank 0 inside the timed region (BASELINE config 5, strong scaling)")
+    ap.add_argument("--config", type=int, choices=[3, 5], default=3,
+                    help="BASELINE.json configs by their 1-based number: 3 = the headline (S300@4K, frames mode); 5 = configs[4], S300@8Kx8: "
+                         "--mode stripes --width 7680 --height 4320 --steps 8")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="only prove the launch: the ranks meet (all-reduce of ones over --backend) and rank 0 prints n_gpus; no GPU call, no rendering")
+    argv = sys.argv[1:]
     args = ap.parse_args()
-    if args.gather is None:
-        args.gather = "c_abi" if int(os.environ.get("WORLD_SIZE", "1")) == 1 or os.environ.get("FDH_BENCH_GATHER") == "c_abi" else "torch"
+    if args.config == 5:
+        args.mode = args.mode or "stripes"
+        args.width, args.height = args.width or 7680, args.height or 4320
+        args.steps = args.steps or 8
+    args.mode = args.mode or "frames"
+    args.width, args.height = args.width or W, args.height or H
+    args.steps = args.steps or 200
 
+    env_world = os.environ.get("WORLD_SIZE")
+    if args.gpus is None:
+        args.gpus = int(env_world or "1")
+    if env_world is None and args.gpus > 1:
+        return self_launch(args, argv)  # (nothing above this line touches the GPU or imports torch)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = int(env_world or "1")
+    if world != args.gpus:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} under a launcher with WORLD_SIZE = {world}: refusing to print a line for the wrong N\n")
+        sys.exit(4)
+    if args.gather is None:
+        args.gather = "c_abi" if world == 1 else os.environ.get("FDH_BENCH_GATHER", "both")
+    if args.launch_check:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        seen = 1
+        if world > 1:
+            import torch
+
+            dist.init_process_group("gloo" if args.backend != "nccl" else "nccl", rank=rank, world_size=world)
+            t = torch.ones(1, dtype=torch.int64, device="cpu" if args.backend != "nccl" else f"cuda:{local_rank}")
+            dist.all_reduce(t)
+            seen = int(t.item())
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"launch_check": True, "n_gpus": world, "ranks_reduced": seen, "backend": args.backend}), flush=True)
+        return
     import torch
 
     dist = None
@@ -304,7 +468,7 @@ def main():
         torch.cuda.set_device(local_rank)
     on_host = dist is not None and args.backend != "nccl"  # gloo moves tensors through host memory
     if args.mode == "stripes":
-        return run_stripes(args, dist, rank, local_rank, world, on_host)
+        return stripes_main(args, dist, rank, local_rank, world, on_host)
 
     from figdraw_amd import call_stream as CS
     from figdraw_amd import context as C_mod
@@ -561,60 +725,21 @@ def main():
     # ---- the one collective of the path: the gather of finished frames to rank 0.  Frames are independent, so
     # `value` above holds no data-path collective (weak scaling); here (a) one gather of every rank's final frame, timed on its
     # own, and (b) the same K-frame batch with EVERY frame gathered to rank 0 inside the timed region, reported beside `value`.
-    gather_ms, gather_how, with_gather, gather_error = None, None, None, None
-    rccl_ranks_seen = None
-    if dist is not None:
-        col = C_mod._F4(1.0, 1.0, 1.0, 1.0)
+    gather_ms, gather_how, gather_error = None, None, None
+    if dist is not None and args.gather in ("torch", "both"):
+        # (a) through torch.distributed -- the leg whose every call has run on real hardware before; measured FIRST
+        def torch_leg_timed_out():
+            return {"metric": "Mpixels/s composited @3840x2160, 300 SDF rects+shadows; % HBM roofline",
+                    "value": round(world * w * h * args.steps / elapsed / 1e6, 1), "unit": "Mpixels/s", "n_gpus": world,
+                    "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4), "repeats": args.repeats,
+                    "batches_ms": batch_ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                    "config": {"workload": f"S300@4K: renderlist_100 scene at {w}x{h} (BASELINE.json configs[2])",
+                               "parallelism": f"frame-parallel x{world}", "frames_in_flight_per_gpu": F},
+                    "gather": {"error": f"torch.distributed.gather of the frames to rank 0 did not complete within {args.gather_timeout} s; `value` (no collective "
+                                        "on the data path) was measured before it"}}
 
-        def gather_timed_out():
-            # A collective that never completes (a rank lost, a link down) must not take the measured `value` with it: every rank
-            # leaves after --gather-timeout seconds and rank 0 still prints the line, with the gather marked as not measured.
-            if rank == 0:
-                print(json.dumps({"metric": "Mpixels/s composited @3840x2160, 300 SDF rects+shadows; % HBM roofline",
-                                  "value": round(world * w * h * args.steps / elapsed / 1e6, 1), "unit": "Mpixels/s", "n_gpus": world,
-                                  "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4), "repeats": args.repeats,
-                                  "batches_ms": batch_ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                                  "config": {"workload": f"S300@4K: renderlist_100 scene at {w}x{h} (BASELINE.json configs[2])",
-                                             "parallelism": f"frame-parallel x{world}", "frames_in_flight_per_gpu": F},
-                                  "gather": {"error": f"the gather of frames to rank 0 did not complete within {args.gather_timeout} s; `value` (no collective "
-                                                      "on the data path) was measured before it"}}), flush=True)
-            os._exit(3)  # (non-zero: the multi-GPU leg did not complete; the line above still carries the measured `value`)
-
-        import threading
-
-        watchdog = threading.Timer(args.gather_timeout, gather_timed_out)
-        watchdog.daemon = True
-        watchdog.start()
-        try:
-            use_c_abi = args.gather == "c_abi" and (not on_host or bool(os.environ.get("FDH_RCCL_LIB")))
-            if use_c_abi:
-                setup_comm(ctxs, dist, rank, world)
-                rccl_ranks_seen = ctxs[0].comm_info()[1]
-                dev = f"cuda:{local_rank}"
-                slots = [[torch.empty((h, w, 4), dtype=torch.uint8, device=dev) for _ in range(world)] for _ in range(F)] if rank == 0 else None
-                ptrs = [[t.data_ptr() for t in sl] for sl in slots] if rank == 0 else [None] * F
-                barrier()
-                g0 = time.perf_counter()
-                ctx.gather_frames(0, ptrs[0])
-                ctx.sync()
-                gather_ms = 1e3 * (time.perf_counter() - g0)
-                gather_how = "fdh_gather_frames (C ABI: grouped ncclSend / ncclRecv on the context's stream)"
-                if rank == 0:
-                    assert all(int(o[..., 3].min()) == 255 for o in slots[0]), "a gathered frame has unwritten pixels"
-
-                def run_with_gather(n):
-                    for k in range(n):
-                        c = ctxs[k % F]
-                        c._ck(c.L.fdh_render_frame(c.h, cscenes[k % NS].byref(), float(w), float(h), 1, col))
-                        c.gather_frames(0, ptrs[k % F])  # behind the frame on the context's stream: no host synchronisation
-
-                run_with_gather(args.warmup)
-                wg_elapsed, wg_batch_ms = batches(run_with_gather, args.steps, args.repeats)
-                with_gather = {"value": round(world * w * h * args.steps / wg_elapsed / 1e6, 1), "unit": "Mpixels/s", "ms_per_step": round(1e3 * wg_elapsed / args.steps, 4),
-                               "batches_ms": wg_batch_ms,
-                               "note": "the same batch with every frame of every rank gathered to rank 0 (fdh_gather_frames) inside the timed region: "
-                                       f"rank 0 takes in {world - 1} x {w * h * 4 / 1e6:.1f} MB per round of frames over its xGMI links"}
-            else:
+        with Watchdog(args.gather_timeout, rank, torch_leg_timed_out):
+            try:
                 mine = frame_tensor(ctx).contiguous()
                 if on_host:
                     mine = mine.cpu()
@@ -627,13 +752,56 @@ def main():
                 gather_how = f"torch.distributed.gather ({args.backend})"
                 if rank == 0:
                     assert all(int(o[..., 3].min()) == 255 for o in outs), "a gathered frame has unwritten pixels"
-            ctx.render_frame(scene, w, h)
-            ctx.sync()
-        except Exception as e:  # (reported, not fatal: `value` holds no collective)
-            gather_error = f"{type(e).__name__}: {e}"
-        finally:
-            watchdog.cancel()
+                del outs
+            except Exception as e:  # (reported, not fatal: `value` holds no collective)
+                gather_error = f"{type(e).__name__}: {e}"
+
+    def c_abi_leg():
+        """(b) the library's own gather (fdh_gather_frames: grouped ncclSend / ncclRecv on the context's stream): one gather of every rank's
+        final frame timed on its own, then the same K-frame batch with EVERY frame gathered to rank 0 inside the timed region."""
+        setup_comm(ctxs, dist, rank, world)
+        seen = ctxs[0].comm_info()[1]
+        col = C_mod._F4(1.0, 1.0, 1.0, 1.0)
+        dev = f"cuda:{local_rank}"
+        slots = [[torch.empty((h, w, 4), dtype=torch.uint8, device=dev) for _ in range(world)] for _ in range(F)] if rank == 0 else None
+        ptrs = [[t.data_ptr() for t in sl] for sl in slots] if rank == 0 else [None] * F
+        ctx.render_frame(scene, w, h)
+        barrier()
+        g0 = time.perf_counter()
+        ctx.gather_frames(0, ptrs[0])
+        ctx.sync()
+        ms = 1e3 * (time.perf_counter() - g0)
+        if rank == 0:
+            assert all(int(o[..., 3].min()) == 255 for o in slots[0]), "a gathered frame has unwritten pixels"
+            # rank 0's own frame comes back through the gather as it sits in its surface
+            assert bool((slots[0][0] == frame_tensor(ctx)).all()), "rank 0's own frame changed on its way through fdh_gather_frames"
+
+        def run_with_gather(n):
+            for k in range(n):
+                c = ctxs[k % F]
+                c._ck(c.L.fdh_render_frame(c.h, cscenes[k % NS].byref(), float(w), float(h), 1, col))
+                c.gather_frames(0, ptrs[k % F])  # behind the frame on the context's stream: no host synchronisation
+
+        run_with_gather(args.warmup)
+        wg_elapsed, wg_batch_ms = batches(run_with_gather, args.steps, args.repeats)
+        ctx.render_frame(scene, w, h)
+        ctx.sync()
+        return {"gather_ms": round(ms, 3), "gather": "fdh_gather_frames (C ABI: grouped ncclSend / ncclRecv on the context's stream)",
+                "rccl_ranks_seen": seen,
+                "with_gather_every_frame": {"value": round(world * w * h * args.steps / wg_elapsed / 1e6, 1), "unit": "Mpixels/s",
+                                            "ms_per_step": round(1e3 * wg_elapsed / args.steps, 4), "batches_ms": wg_batch_ms,
+                                            "note": "the same batch with every frame of every rank gathered to rank 0 (fdh_gather_frames) inside the timed region: "
+                                                    f"rank 0 takes in {world - 1} x {w * h * 4 / 1e6:.1f} MB per round of frames over its xGMI links"}}
+
+    c_abi_wanted = dist is not None and args.gather in ("c_abi", "both")
+    c_abi_can = c_abi_wanted and (not on_host or bool(os.environ.get("FDH_RCCL_LIB")))
     if rank != 0:
+        if c_abi_can:
+            with Watchdog(args.gather_timeout, rank, dict):
+                try:
+                    c_abi_leg()
+                except Exception:
+                    pass  # (rank 0 reports its own side; a rank that failed here leaves rank 0 to the watchdog)
         return
 
     mpix = world * w * h * args.steps / elapsed / 1e6
@@ -815,18 +983,38 @@ def main():
     if gather_ms is not None:
         out["gather_ms"] = round(gather_ms, 3)
         out["gather"] = gather_how
-        out["with_gather_every_frame"] = with_gather
-    if world > 1:
-        out["rccl_ranks_seen"] = rccl_ranks_seen  # the communicator size fdh_comm_init reported (null: the gather ran through torch.distributed)
     if gather_error is not None:
         out["gather_error"] = gather_error
+    if world > 1:
+        out["torch_world_size"] = dist.get_world_size()
+        out["rccl_ranks_seen"] = None  # the communicator size fdh_comm_init reports (null: no fdh_gather_* leg ran)
     # a frame that came out differently in flight than alone (or off the oracle) voids the throughput figure
     bad = in_flight_differing != 0 or per_call_differing != 0 or (in_flight_vs_oracle is not None and in_flight_vs_oracle["parity_max_lsb"] > 1) or \
         (cpu_baseline is not None and cpu_baseline["parity_max_lsb"] > 1)
     if bad:
         out["value"] = None
         out["error"] = "frames rendered in flight differ from the same frames rendered alone, or from the oracle"
-    print(json.dumps(out))
+    if c_abi_wanted and not c_abi_can:
+        out["c_abi_gather"] = {"skipped": "gloo run with no stand-in transport named (FDH_RCCL_LIB): the library's gather needs RCCL, one GPU per rank"}
+    elif c_abi_can:
+        # everything above is measured and written down before the first fdh_gather_* call between ranks
+        write_provisional(out)
+
+        def late():
+            return dict(out, c_abi_gather={"error": f"the fdh_gather_frames leg did not complete within {args.gather_timeout} s; `value` (no collective on the "
+                                                    "data path) and the torch.distributed gather were measured before it"})
+
+        with Watchdog(args.gather_timeout, rank, late):
+            try:
+                leg = c_abi_leg()
+                out["c_abi_gather"] = leg
+                out["rccl_ranks_seen"] = leg["rccl_ranks_seen"]
+                if gather_ms is None:  # (--gather c_abi: the library's gather is the only one)
+                    out["gather_ms"], out["gather"] = leg["gather_ms"], leg["gather"]
+                out["with_gather_every_frame"] = leg["with_gather_every_frame"]
+            except Exception as e:
+                out["c_abi_gather"] = {"error": f"{type(e).__name__}: {e}"}
+    print(json.dumps(out), flush=True)
     if bad:
         sys.exit(1)
 

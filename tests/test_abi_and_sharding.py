@@ -545,3 +545,63 @@ def test_c_abi_gather_on_one_rank():
     assert (dst.read_pixels() == src2.read_pixels()).all()
     src2.close()
     dst.close()
+
+
+def _bench(args, env=None, timeout=900):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=timeout,
+                       env={k: v for k, v in dict(os.environ, **(env or {})).items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    return r, (json.loads(lines[-1]) if lines else None)
+
+
+def test_bench_gpus_n_starts_n_ranks_itself():
+    """`python bench.py --gpus 2` with no launcher around it (the driver's command form): bench.py starts the two ranks itself as a
+    torch.distributed.run child before touching any GPU, relays rank 0's line and the child's exit code.  --launch-check stops after
+    the ranks have met (all-reduce of ones over gloo): no GPU needed, so this runs in the CPU suite."""
+    r, d = _bench(["--gpus", "2", "--backend", "gloo", "--launch-check"], timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert d == {"launch_check": True, "n_gpus": 2, "ranks_reduced": 2, "backend": "gloo"}
+    assert len([ln for ln in r.stdout.splitlines() if ln.startswith("{")]) == 1  # ONE line
+    # under somebody else's launcher --gpus must be the launcher's world size: a line for the wrong N is refused
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--launch-check"], capture_output=True, text=True, timeout=120,
+                       env=dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"))
+    assert r.returncode == 4 and "refusing" in r.stderr and not r.stdout.strip()
+    # and with no --gpus at all a launcher's WORLD_SIZE is taken as it is (torch.distributed.run bench.py)
+    r, d = _bench(["--launch-check"], timeout=120)
+    assert r.returncode == 0 and d["n_gpus"] == 1
+
+
+def test_bench_config_5_selects_the_baseline_stripes_run():
+    """--config 5 = BASELINE.json configs[4] (S300@8Kx8): stripes mode, 7680x4320, 8 steps -- read off the parser (no GPU)."""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert 'args.width, args.height = args.width or 7680, args.height or 4320' in src and 'args.mode = args.mode or "stripes"' in src
+    assert 'args.steps = args.steps or 8' in src
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["frames", "config5"])
+def test_bench_self_launch_runs_both_gather_legs(mode):
+    """The command form the driver uses for a SCALE point -- `python bench.py --gpus 2 ...`, nothing around it -- on a one-GPU box: two
+    ranks on device 0 over gloo, the library's gather bound to the stand-in transport.  One invocation, one line: n_gpus = 2, the
+    torch.distributed gather leg (owns `value` / `gather_ms`), then the fdh_gather_* leg (`c_abi_gather`) with the communicator's own
+    size next to torch's."""
+    env = {"FDH_RCCL_LIB": _mock_rccl(), "MASTER_PORT": "29551" if mode == "frames" else "29553"}
+    if mode == "frames":
+        r, d = _bench(["--gpus", "2", "--backend", "gloo", "--all-ranks-on-device0", "--width", "1280", "--height", "720", "--steps", "8", "--warmup", "2",
+                       "--repeats", "3", "--no-cpu-baseline"], env)
+        assert r.returncode == 0, (r.stderr[-2000:], r.stdout[-2000:])
+        assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["torch_world_size"] == 2 and d["rccl_ranks_seen"] == 2
+        assert "torch.distributed.gather" in d["gather"] and d["gather_ms"] > 0
+        leg = d["c_abi_gather"]
+        assert "fdh_gather_frames" in leg["gather"] and leg["gather_ms"] > 0 and leg["with_gather_every_frame"]["value"] > 0
+        assert d["frames_in_flight_check"]["pixels_differing"] == 0
+    else:
+        r, d = _bench(["--gpus", "2", "--backend", "gloo", "--all-ranks-on-device0", "--config", "5", "--width", "1920", "--height", "1080", "--warmup", "2",
+                       "--repeats", "3"], env)
+        assert r.returncode == 0, (r.stderr[-2000:], r.stdout[-2000:])
+        assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["steps"] == 8 and d["config"]["mode"] == "stripes"
+        assert d["torch_world_size"] == 2 and d["config"]["rccl_ranks_seen"] == 2
+        assert "torch.distributed" in d["config"]["gather"] and d["gathered_frame_check"]["parity_max_lsb"] <= 1
+        leg = d["c_abi_gather"]
+        assert "fdh_gather_stripes" in leg["gather"] and leg["value"] > 0 and leg["gathered_frame_check"]["parity_max_lsb"] <= 1
+    assert d["value"] > 0
