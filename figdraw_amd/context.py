@@ -120,6 +120,7 @@ def load():
     L.fdh_scene_render.argtypes = [vp]
     L.fdh_scene_stats.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.fdh_debug_record_digest.argtypes = [vp, C.POINTER(C.c_uint64)]
+    L.fdh_debug_verify_upload.argtypes = [vp, C.POINTER(C.c_uint32)]
     L.fdh_last_upload_bytes.argtypes = [vp, C.POINTER(C.c_int64)]
     L.fdh_record_begin.argtypes = [vp]
     L.fdh_record_json.argtypes = [vp]
@@ -455,6 +456,12 @@ class HipContext:
         out = C.c_int64()
         self._ck(self.L.fdh_last_upload_bytes(self.h, C.byref(out)))
         return out.value
+
+    def verify_upload(self):
+        """fault hunting: the device's copy of the last frame's records against the host lanes (fdh_debug_verify_upload)"""
+        out = (C.c_uint32 * 24)()
+        self._ck(self.L.fdh_debug_verify_upload(self.h, out))
+        return list(out)
 
     def record_digest(self) -> int:
         out = C.c_uint64()

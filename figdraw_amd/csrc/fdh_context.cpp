@@ -26,52 +26,106 @@ void hip_check(hipError_t e, const char* what) {
 // when each device context of the process last submitted a frame (steady-clock ns; 0 = never): Context::prepare asks whether
 // frames of OTHER contexts are in flight
 
+void poison_fresh(void* p, size_t bytes) {
+  static const int v = [] { const char* e = std::getenv("FDH_POISON"); return e ? (int)std::strtol(e, nullptr, 0) & 255 : -1; }();
+  if (v < 0 || !p || !bytes) return;
+  (void)hipMemset(p, v, bytes);
+  (void)hipDeviceSynchronize();
+}
+
 // ------------------------------------------------------------------ lifetime
 // Staging in device memory (HostVec::vram): when the device exposes all of its memory to the host (large BAR: every MI355X box of
 // the pool) the recording threads write the frame's records straight into HBM and the gather kernel reads them locally.
 // FDH_VRAM_STAGING=0 keeps pinned host memory (the path for devices without a large BAR), =1 forces device memory.
-bool vram_staging() {
-  static const bool on = [] {
-    if (const char* e = std::getenv("FDH_VRAM_STAGING")) return std::atoi(e) != 0;
-    int dev = 0, large = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return false;
-    if (hipDeviceGetAttribute(&large, hipDeviceAttributeIsLargeBar, dev) != hipSuccess || !large) return false;
-    // ... and a round trip to make sure: the CPU stores a pattern into such a block, a device-to-host copy must bring it back
-    uint32_t* d = nullptr;
-    if (hipExtMallocWithFlags((void**)&d, 4096, hipDeviceMallocUncached) != hipSuccess || !d) return false;
-    bool ok = true;
-    for (uint32_t i = 0; i < 1024; i++) d[i] = 0x9e3779b9u * (i + 1);
-    store_fence();
-    uint32_t back[1024];
-    if (hipMemcpy(back, d, sizeof back, hipMemcpyDeviceToHost) != hipSuccess) ok = false;
-    for (uint32_t i = 0; ok && i < 1024; i++) ok = back[i] == 0x9e3779b9u * (i + 1);
-    (void)hipFree(d);
-    return ok;
-  }();
-  return on;
-}
-
+// Decided PER DEVICE (fdh_create takes an ordinal: one process may hold contexts on several GPUs), once, on first use.
 namespace {
+constexpr int kMaxDevices = 64;
 std::mutex g_vram_mu;
-std::vector<void*> g_vram_free[48];  // by log2 of the size class
+int g_vram_probe[kMaxDevices];  // 0 not probed yet, 1 staging in device memory, -1 pinned host memory
+// the store of released blocks: by device, then by log2 of the size class
+std::vector<void*> g_vram_free[kMaxDevices][48];
+int g_vram_contexts[kMaxDevices];  // device contexts alive per device (the store of a device is trimmed when its last one goes)
 int vram_class(size_t bytes) { int k = 12; while (((size_t)1 << k) < bytes) k++; return k; }
+// the calling thread's current device for the scope (pool threads and callers with contexts on several devices allocate here)
+struct DeviceScope {
+  int prev = -1, dev;
+  explicit DeviceScope(int d) : dev(d) { if (hipGetDevice(&prev) != hipSuccess) prev = -1; if (prev != dev) (void)hipSetDevice(dev); }
+  ~DeviceScope() { if (prev >= 0 && prev != dev) (void)hipSetDevice(prev); }
+};
+bool vram_probe(int dev) {
+  if (const char* e = std::getenv("FDH_VRAM_STAGING")) return std::atoi(e) != 0;
+  DeviceScope scope(dev);
+  int large = 0;
+  if (hipDeviceGetAttribute(&large, hipDeviceAttributeIsLargeBar, dev) != hipSuccess || !large) return false;
+  // ... and a round trip to make sure: the CPU stores a pattern into such a block, a device-to-host copy must bring it back
+  uint32_t* d = nullptr;
+  if (hipExtMallocWithFlags((void**)&d, 4096, hipDeviceMallocUncached) != hipSuccess || !d) return false;
+  bool ok = true;
+  for (uint32_t i = 0; i < 1024; i++) d[i] = 0x9e3779b9u * (i + 1);
+  store_fence();
+  uint32_t back[1024];
+  if (hipMemcpy(back, d, sizeof back, hipMemcpyDeviceToHost) != hipSuccess) ok = false;
+  for (uint32_t i = 0; ok && i < 1024; i++) ok = back[i] == 0x9e3779b9u * (i + 1);
+  (void)hipFree(d);
+  return ok;
+}
 }  // namespace
-void* vram_block_acquire(size_t bytes, size_t* size_class) {
+bool vram_staging(int device) {
+  if (device < 0 || device >= kMaxDevices) return false;
+  std::lock_guard<std::mutex> lk(g_vram_mu);
+  if (g_vram_probe[device] == 0) g_vram_probe[device] = vram_probe(device) ? 1 : -1;
+  return g_vram_probe[device] > 0;
+}
+void* vram_block_acquire(int device, size_t bytes, size_t* size_class) {
   const int k = vram_class(bytes);
   *size_class = (size_t)1 << k;
+  if (device < 0 || device >= kMaxDevices) throw Error(FDH_ERR_NO_DEVICE, "staging block asked for a device ordinal out of range");
   {
     std::lock_guard<std::mutex> lk(g_vram_mu);
-    if (!g_vram_free[k].empty()) { void* p = g_vram_free[k].back(); g_vram_free[k].pop_back(); return p; }
+    auto& fl = g_vram_free[device][k];
+    if (!fl.empty()) { void* p = fl.back(); fl.pop_back(); return p; }
   }
+  DeviceScope scope(device);  // (a walk-pool thread's current device is whatever it was created with)
   void* p = nullptr;
   FDH_HIP(hipExtMallocWithFlags(&p, (size_t)1 << k, hipDeviceMallocUncached));
   return p;
 }
-void vram_block_release(void* p, size_t size_class) {
+void vram_block_release(int device, void* p, size_t size_class) {
   if (!p) return;
-  if (!size_class) { (void)hipFree(p); return; }
+  static const bool keep = [] { const char* e = std::getenv("FDH_VRAM_STORE"); return !e || std::atoi(e) != 0; }();  // (0: the round-4 fault hunt's control)
+  if (!keep || !size_class || device < 0 || device >= kMaxDevices) { (void)hipFree(p); return; }
   std::lock_guard<std::mutex> lk(g_vram_mu);
-  g_vram_free[vram_class(size_class)].push_back(p);
+  g_vram_free[device][vram_class(size_class)].push_back(p);
+}
+size_t vram_store_bytes(int device) {
+  if (device < 0 || device >= kMaxDevices) return 0;
+  std::lock_guard<std::mutex> lk(g_vram_mu);
+  size_t b = 0;
+  for (int k = 0; k < 48; k++) b += g_vram_free[device][k].size() << k;
+  return b;
+}
+void vram_context_born(int device) {
+  if (device < 0 || device >= kMaxDevices) return;
+  std::lock_guard<std::mutex> lk(g_vram_mu);
+  g_vram_contexts[device]++;
+}
+// The last device context of a device is gone: its store keeps at most kVramStoreKeep bytes (largest blocks go first -- one huge
+// frame must not pin its HBM for the life of the process).  Called with the device idle (the context has synchronised its stream).
+void vram_context_gone(int device) {
+  if (device < 0 || device >= kMaxDevices) return;
+  std::vector<void*> drop;
+  {
+    std::lock_guard<std::mutex> lk(g_vram_mu);
+    if (--g_vram_contexts[device] > 0) return;
+    size_t held = 0;
+    for (int k = 0; k < 48; k++) held += g_vram_free[device][k].size() << k;
+    for (int k = 47; k >= 12 && held > kVramStoreKeep; k--)
+      while (!g_vram_free[device][k].empty() && held > kVramStoreKeep) { drop.push_back(g_vram_free[device][k].back()); g_vram_free[device][k].pop_back(); held -= (size_t)1 << k; }
+  }
+  if (drop.empty()) return;
+  DeviceScope scope(device);
+  (void)hipDeviceSynchronize();
+  for (void* p : drop) (void)hipFree(p);
 }
 
 Context::Context(int atlas_size, float pixel_scale, int device, uint32_t flags) : Recorder(this, true), device_(device), flags_(flags), pixel_scale_(pixel_scale) {
@@ -101,6 +155,7 @@ Context::Context(int atlas_size, float pixel_scale, int device, uint32_t flags) 
   alloc_atlas(initial_atlas_size_);
   static const bool env_sync = [] { const char* e = std::getenv("FDH_SYNC_SUBMIT"); return e && std::atoi(e) != 0; }();
   if (!(flags & FDH_CREATE_SYNC_SUBMIT) && !env_sync) worker_ = std::thread([this] { worker_main(); });
+  vram_context_born(device_);
 }
 
 Context::~Context() {
@@ -128,6 +183,8 @@ Context::~Context() {
   for (auto& e : staging_ev_) if (e) (void)hipEventDestroy(e);
   if (seq_host_) (void)hipHostFree((void*)seq_host_);
   if (own_stream_) (void)hipStreamDestroy(own_stream_);
+  for (auto& l : merge_lane_) l.reset();  // (their staging blocks go to the store before the store is looked at)
+  vram_context_gone(device_);
 }
 
 void Context::set_stream(void* s) {
@@ -559,6 +616,7 @@ void Context::ensure_surfaces() {
   FDH_HIP(hipMalloc((void**)&fb_, n * 4));
   FDH_HIP(hipMalloc((void**)&backdrop_, n * 4));
   FDH_HIP(hipMalloc((void**)&blur_tmp_, n * 4));
+  poison_fresh(backdrop_, n * 4); poison_fresh(blur_tmp_, n * 4);
   FDH_HIP(hipMemsetAsync(fb_, 0, n * 4, stream_));
   surf_w_ = W_;
   surf_h_ = H_;
@@ -594,7 +652,10 @@ static void build_mx_weights(const BlurTaps& t, bool vertical, uint8_t* out) {
     for (int lane = 0; lane < 64; lane++) {
       const int j = lane & 31, g = lane >> 5;
       for (int e = 0; e < 8; e++) {
-        const int k = 16 * m + 8 * g + e - delta - j;
+        // which window texel element e of lane group g stands for (mx_krow, fdh_types.h): the natural order for the horizontal pass;
+        // for the vertical one the order in which a 32 x 32 accumulator tile holds its rows, so that the fused kernel's horizontal
+        // product feeds the vertical one from registers (k_blur_fx) -- any order serves as long as both operands use the same
+        const int k = 16 * m + mx_krow(g, e, vertical) - delta - j;
         const float w = (k >= 0 && k <= 2 * t.reach) ? t.dense[kBlurPad + k] * 1024.0f : 0.0f;
         const uint16_t hi = half_bits_rne(w), lo = half_bits_rne(w - half_value(hi));
         o[(((size_t)(2 * m) * 64 + lane) * 8) + e] = hi;
@@ -701,6 +762,7 @@ void Context::prepare(LaunchJob& J) {
   }
   if (J.n_fused > 0 && !alt_) {
     FDH_HIP(hipMalloc((void**)&alt_, (size_t)W_ * H_ * 4));
+    poison_fresh(alt_, (size_t)W_ * H_ * 4);
     FDH_HIP(hipMemsetAsync(alt_, 0, (size_t)W_ * H_ * 4, stream_));
   }
   const int slot = staging_i_;
@@ -801,7 +863,8 @@ void Context::prepare(LaunchJob& J) {
     }
   HostVec<uint8_t>& up_misc = misc_[slot];
   up_misc.pinned = true;
-  up_misc.vram = vram_staging();
+  up_misc.vram = vram_staging(device_);
+  up_misc.dev = device_;
   up_misc.n = 0;
   up_misc.reserve(misc.size());
   // ---- the runs k_upload_frame gathers.  Every piece brings three: its records (extension indices re-based on the way), its bin
@@ -954,7 +1017,7 @@ void Context::prepare(LaunchJob& J) {
   stats_.bytes_frame_implementation = bytes - bytes_saved;
   stats_.fragments = fragments_;
   if (folded) folded_br->box = folded_box;  // (the recorded frame stays what the calls produced)
-  if (vram_staging()) {
+  if (vram_staging(device_)) {
     store_fence();  // (what this thread wrote into device memory is on its way before the launches are)
     // ... and what it and the pool's threads wrote is pushed out of the host data path: without this, frames of fresh contexts on
     // several host threads came out wrong -- or faulted -- in ~5 % of tools/thread_churn.py runs (end of round 4)
@@ -983,7 +1046,7 @@ void Context::pick_routes() {
 // spare lane, in order, extension indices re-based -- the frame becomes one piece again.
 void Context::consolidate_pieces() {
   std::unique_ptr<Lane>& slot = merge_lane_[(size_t)staging_i_];
-  if (!slot) { slot.reset(new Lane()); slot->set_pinned(!host_only_); }
+  if (!slot) { slot.reset(new Lane()); slot->set_pinned(!host_only_, device_); }
   Lane& S = *slot;
   S.clear();
   S.recs.reserve(n_total_); S.bins.reserve(n_total_); S.exts.reserve(n_ext_total_);

@@ -37,6 +37,9 @@ struct Aff {
   float a = 1, b = 0, c = 0, d = 1, tx = 0, ty = 0;
 };
 
+// Fault hunting (FDH_POISON=<byte>): every fresh device allocation is filled with that byte before its first use -- a kernel that
+// reads memory nothing has written yet then reads the same garbage every time, not what the allocation's previous owner left.
+void poison_fresh(void* p, size_t bytes);  // fdh_context.cpp
 template <typename T>
 struct DeviceBuf {
   T* ptr = nullptr;
@@ -47,6 +50,7 @@ struct DeviceBuf {
     while (want < n) want *= 2;
     T* fresh = nullptr;  // allocate first: a failing hipMalloc (FDH_HIP throws) must leave ptr / cap describing a live block
     FDH_HIP(hipMalloc((void**)&fresh, want * sizeof(T)));
+    poison_fresh(fresh, want * sizeof(T));
     if (ptr) (void)hipFree(ptr);
     ptr = fresh;
     cap = want;
@@ -90,14 +94,19 @@ struct PinnedBuf {
 // own memory instead of fetching it over the link with a round trip per lane: k_upload_frame 7.1 -> ~3 us.  Write-only for the
 // CPU -- a load from it crosses the link uncached -- so growth does NOT carry contents over (callers set n = 0 first, as the pinned
 // mirrors always did), and a store fence (store_fence()) precedes the hand-over to whoever launches the kernels.
-bool vram_staging();  // large-BAR device and FDH_VRAM_STAGING != 0 (fdh_context.cpp)
+bool vram_staging(int device);  // large-BAR device and FDH_VRAM_STAGING != 0, decided per device ordinal (fdh_context.cpp)
 // Device blocks for staging come from, and go back to, a process-wide store by size class (powers of two from 4 KB): they are
 // never handed back to the driver while the process lives.  A block the driver recycles may be memory another allocation's
 // kernels wrote through the L2s; the host's stores reach memory BESIDE those caches, and a line written back later lands on top
 // of them (tools/thread_churn.py: fresh contexts on four host threads, wrong first frames or a fault in ~5 % of runs).  Staging
 // blocks are only ever written by the host and read uncached by the device, so recycled among themselves they carry no such lines.
-void* vram_block_acquire(size_t bytes, size_t* size_class);  // throws Error on failure
-void vram_block_release(void* p, size_t size_class);
+// The store is keyed by DEVICE ORDINAL: a block allocated on GPU 0 never reaches a context on GPU 1.
+void* vram_block_acquire(int device, size_t bytes, size_t* size_class);  // throws Error on failure
+void vram_block_release(int device, void* p, size_t size_class);
+size_t vram_store_bytes(int device);   // bytes the store of a device holds (released blocks)
+void vram_context_born(int device);    // a device context exists on `device` ...
+void vram_context_gone(int device);    // ... and is gone: with the last one, the device's store is trimmed to kVramStoreKeep
+constexpr size_t kVramStoreKeep = (size_t)16 << 20;
 inline void store_fence() {
 #if defined(__x86_64__) || defined(__i386__)
   __builtin_ia32_sfence();
@@ -110,11 +119,12 @@ struct HostVec {
   T* p = nullptr;
   size_t n = 0, cap = 0;
   bool pinned = false, vram = false;
+  int dev = 0;  // device ordinal of a vram block
   HostVec() = default;
   HostVec(const HostVec&) = delete;
   HostVec& operator=(const HostVec&) = delete;
   ~HostVec() { release(); }
-  void free_block(T* q) { if (!q) return; if (pinned && vram) vram_block_release(q, vram_bytes_); else if (pinned) (void)hipHostFree(q); else std::free(q); }
+  void free_block(T* q) { if (!q) return; if (pinned && vram) vram_block_release(dev, q, vram_bytes_); else if (pinned) (void)hipHostFree(q); else std::free(q); }
   size_t vram_bytes_ = 0;  // size class of the device block p (vram_block_acquire)
   void release() {
     free_block(p);
@@ -126,7 +136,7 @@ struct HostVec {
     while (c < want) c *= 2;
     T* fresh = nullptr;
     size_t fresh_bytes = 0;
-    if (pinned && vram) fresh = static_cast<T*>(vram_block_acquire(c * sizeof(T), &fresh_bytes));
+    if (pinned && vram) fresh = static_cast<T*>(vram_block_acquire(dev, c * sizeof(T), &fresh_bytes));
     else if (pinned) FDH_HIP(hipHostMalloc((void**)&fresh, c * sizeof(T), hipHostMallocDefault));
     else if (!(fresh = static_cast<T*>(std::aligned_alloc(64, (c * sizeof(T) + 63) & ~(size_t)63)))) throw std::bad_alloc();
     if (n && !(pinned && vram)) std::memcpy(static_cast<void*>(fresh), static_cast<const void*>(p), n * sizeof(T));
@@ -207,7 +217,12 @@ struct Lane {
   int tx0 = 0, ty0 = 0, tx1 = 0, ty1 = 0;
   bool touched = false;
   uint64_t stamp = 0;  // the frame a pool thread's lane was last cleared for
-  void set_pinned(bool on) { device = on; up_recs.pinned = up_bins.pinned = up_exts.pinned = on; up_recs.vram = up_bins.vram = up_exts.vram = on && vram_staging(); }
+  void set_pinned(bool on, int dev) {
+    device = on;
+    up_recs.pinned = up_bins.pinned = up_exts.pinned = on;
+    up_recs.vram = up_bins.vram = up_exts.vram = on && vram_staging(dev);
+    up_recs.dev = up_bins.dev = up_exts.dev = dev;
+  }
   void clear() { recs.clear(); bins.clear(); exts.clear(); boxes.clear(); pub_recs = pub_exts = 0; }
   void publish(uint32_t first, uint32_t n, uint32_t ext_first, uint32_t n_ext);  // records / extensions are final: copy them to the mirrors
   void publish_bytes(int array, size_t at, size_t len);                          // ... a byte range of one array (0 recs, 1 bins, 2 exts)
@@ -426,6 +441,7 @@ class Context : public Recorder {
   void scene_render();
   void scene_stats(int64_t* walked, int64_t* reused) const { *walked = retained_.roots_walked; *reused = retained_.roots_reused; }
   int64_t uploaded_bytes() { drain(); return uploaded_bytes_; }
+  void debug_verify_upload(uint32_t out[24]);  // fdh_debug_verify_upload (fdh_record.cpp)
   uint64_t record_digest();  // FNV-1a over the last frame's draw records (diagnostic: works on record-only contexts)
 
   // multi-GPU: the gather over RCCL (fdh_comm.cpp)

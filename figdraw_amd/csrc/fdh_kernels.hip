@@ -18,6 +18,7 @@
 #include <hip/hip_ext.h>
 #include <stdint.h>
 #include <algorithm>
+#include <type_traits>
 
 #include "fdh_kernels.h"
 
@@ -2868,9 +2869,9 @@ __global__ __launch_bounds__(64 * mx_wg(NK, kV), FDH_MX_WAVES) void k_blur_mx(Bl
     for (int m = 0; m < NK; m++) {
       const uint32_t* slot = ring + (slot0 + m >= R ? slot0 + m - R : slot0 + m) * kMxSlot;
       uint32_t t8[8];
-      if (kV) {
+      if (kV) {  // (rows in the order of an accumulator tile's registers: mx_krow)
 #pragma unroll
-        for (int t = 0; t < 8; t++) t8[t] = slot[(8 * g + t) * 32 + j];
+        for (int t = 0; t < 8; t++) t8[t] = slot[((t & 3) + 8 * (t >> 2) + 4 * g) * 32 + j];
       } else {
         const uint4* row4 = reinterpret_cast<const uint4*>(slot + j * 16);
         const int sw = (j >> 2) & 3;
@@ -2880,7 +2881,7 @@ __global__ __launch_bounds__(64 * mx_wg(NK, kV), FDH_MX_WAVES) void k_blur_mx(Bl
 #if FDH_MX_CHECK
 #pragma unroll
       for (int t = 0; t < 8; t++) {
-        const int pos = w0a + 16 * (2 * b + m) + 8 * g + t;
+        const int pos = w0a + 16 * (2 * b + m) + (kV ? (t & 3) + 8 * (t >> 2) + 4 * g : 8 * g + t);
         uint32_t want;
         if (kV) {
           const int yy = pos < 0 ? 0 : (pos > P.H - 1 ? P.H - 1 : pos);
@@ -3061,38 +3062,51 @@ __global__ __launch_bounds__(64 * mx_wg(NK, kV), FDH_MX_WAVES) void k_blur_mx(Bl
 
 // ------------------------------------------------------------------ both passes of a full-frame node in ONE kernel
 // A backdrop blur that covers the whole frame moved every texel four times: H read + H write (the reference's RGBA8
-// intermediate texture, glcontext.nim:1743-1786), V read + V write.  Here the intermediate never leaves the CU.  One wave owns a
-// strip 32 columns wide and walks DOWN it in blocks of 32 rows: it filters 32 new rows horizontally (the k_blur_mx<., false>
-// product: texels x Toeplitz weights), rounds them to RGBA8 exactly as the H pass stores them, and writes them into a ring of
-// 16-row LDS slots; two blocks behind, the vertical product (k_blur_mx<., true>: weights x texels) reads its NKV k-steps out of
-// that ring, and the epilogue -- scale, RGBA8, the fused mode-17 composite, 128-byte row stores -- is k_blur_mx's.
+// intermediate texture, glcontext.nim:1743-1786), V read + V write.  Here the intermediate never leaves the wave's REGISTERS.
+// One wave owns a strip 32 columns wide and walks DOWN it in blocks of 32 rows: it filters 32 new rows horizontally (the
+// k_blur_mx<., false> product: texels x Toeplitz weights) and rounds them to RGBA8 exactly as the H pass stores them; two blocks
+// behind, the vertical product (k_blur_mx<., true>: weights x texels) takes them as its operand, and the epilogue -- scale, RGBA8,
+// the fused mode-17 composite, 128-byte row stores -- is k_blur_mx's.
+//   * The chain (round 5).  The horizontal product leaves a 32 x 32 tile with lane = column, register 8 s + e = row
+//     16 s + (e & 3) + 8 (e >> 2) + 4 g: for the vertical product -- B operand: lane = column, element e of lane group g = some row of
+//     a 16-row k-step -- that IS two k-steps of operand, if the vertical weights are laid out for that row order (mx_krow; the
+//     two-pass vertical kernel reads its rows in the same order, so the sums are grouped alike).  Rounds 3 - 4 wrote the rounded
+//     tile to an LDS ring and read it back texel by texel: 16 + 40 LDS operations, 128 VALU for scale + pack and 80 v_perm for
+//     the operand halves per block.  Now: one FMA per value (acc * 2^14 + 1.5 * 2^23: round to nearest even, the integer in the
+//     low mantissa byte -- what v_cvt_pk_u8_f32 gives for these values, which lie in [0, 255.001]) and one v_perm per PAIR
+//     builds the two f16 subnormals; the vertical product's operands cost nothing more.  No H ring: 12 KB of LDS less per wave.
+//   * Registers: HB H-blocks (HB = 3 for radius 18: 96 VGPRs) rotate through a stash indexed by block number mod HB -- the three
+//     phases are three copies of "round into the stash + vertical MFMAs", chosen by a uniform branch; everything else is one
+//     copy.  The vertical weights live in LDS (10 KB, read as 16-byte fragments next to their MFMAs) so that the stash fits
+//     beside the accumulators at two waves per SIMD; the horizontal ones stay in registers.
 //   * Same sums, same grouping: H blocks sit at absolute multiples of 32 in x with the H pass's k-step alignment, V blocks at
 //     absolute multiples of 32 in y with windows starting at y - reach: the result is the two-pass result bit for bit.
-//   * Rows of the ring are H-blocks whose first row is congruent to -reach mod 32, so a V window starts on a slot boundary
-//     and the V weight table of the two-pass kernel is used unchanged.
+//   * H-blocks start at rows congruent to -reach mod 32, so a V window starts on an H-block boundary and the V weight table of
+//     the two-pass kernel is used unchanged.
 //   * Out of place: src is the surface the phase before left, dst another one (Context::launch_frame alternates the two and
 //     starts so that the frame ends in the context's own surface); the fused composite blends over src's texel.
-//   * A segment of T blocks re-filters (NKV - 1) / 2 + 1 extra H-blocks of halo: T is chosen so that every wave of the launch is
-//     resident at once (4K, radius 18: 120 strips x 10 segments of 7 blocks, 1.29x the H work).
+//   * A segment of T blocks re-filters HB - 1 extra H-blocks of halo: T is chosen so that every wave of the launch is
+//     resident at once (20 KB of LDS per wave at radius 18: eight waves per CU).
 // Bytes: (1 + halo) x 4 A read (the x halo comes out of L2) + 4 A written, against 16 A for the two passes.
 constexpr int fx_vblocks(int nkv) { return ((nkv - 1) >> 1) + 1; }               // H-blocks one V block reads
-constexpr int fx_slots(int nkh, int nkv) { return nkh + 2 * fx_vblocks(nkv); }  // source k-steps of one H-block + the H ring
-// (One wave per workgroup.  Two or three -- x-neighbours on one CU, as in k_blur_mx -- cost more in waves per CU, six instead of seven,
-// than the shared source columns give back: 36.4 / 38.1 us against 34.6.)
+constexpr int kFxWaves = 4;  // waves per workgroup: x-neighbours of one segment row; they share the weight fragments in LDS (and, in L2, their source halo)
+constexpr int fx_slots(int nkh, int nkv) { return nkh + nkv + kFxWaves * nkh; }  // 2-KB LDS slots per WORKGROUP: both weight tables + every wave's source k-steps
+constexpr float kMxMagic = 12582912.0f;  // 1.5 * 2^23: x + this, as f32, is round-to-nearest-even(x) in the low mantissa bits (|x| < 2^22)
 template <int NKH, int NKV>
-__global__ __launch_bounds__(64, 2) void k_blur_fx(BlurParams P, const uint4* __restrict__ w_v, const DrawRec* __restrict__ draws, const QuadExt* __restrict__ exts, int T) {
+__global__ __launch_bounds__(64 * kFxWaves, 2) void k_blur_fx(BlurParams P, const uint4* __restrict__ w_v, const DrawRec* __restrict__ draws, const QuadExt* __restrict__ exts, int T) {
   constexpr int HB = fx_vblocks(NKV);  // V block b reads H-blocks b .. b + HB - 1
-  constexpr int RV = 2 * HB;           // slots of the H ring
   extern __shared__ __attribute__((aligned(16))) uint32_t ring[];
-  uint32_t* const src_ring = ring;               // NKH slots: [32 rows][16 px], 16-byte pieces XOR-swizzled (as the H pass)
-  uint32_t* const h_ring = ring + NKH * kMxSlot;  // RV slots: [16 rows][32 px] (as the V pass)
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const uint4* const hw = reinterpret_cast<const uint4*>(ring);                   // [2 NKH fragments][64 lanes] x 16 bytes
+  const uint4* const vw = reinterpret_cast<const uint4*>(ring + NKH * kMxSlot);  // [2 NKV fragments][64 lanes] x 16 bytes
+  uint32_t* const src_ring = ring + (NKH + NKV + wave * NKH) * kMxSlot;          // this wave's NKH slots: [32 rows][16 px], 16-byte pieces XOR-swizzled (as the H pass)
   const int n_strips = (P.x1 - (P.x0 & ~31) + 31) >> 5;
   const int y_first = P.y0 & ~31;
   const int n_seg = (P.y1 - y_first + 32 * T - 1) / (32 * T);
-  const int total = n_strips * n_seg, per = (total + 7) >> 3, q = blockIdx.x >> 3, item = (blockIdx.x & 7) * per + q;
-  if (q >= per || item >= total) return;  // every XCD takes a contiguous eighth of the row-major sequence: a band of the frame
-  const int seg = item / n_strips, strip = item - seg * n_strips;
-  const int lane = threadIdx.x, g = lane >> 5, j = lane & 31;
+  const int total = n_strips * n_seg, per = (total + 7) >> 3, q = (int)(blockIdx.x >> 3) * kFxWaves + wave, item = (blockIdx.x & 7) * per + q;
+  const bool active = q < per && item < total;  // every XCD takes a contiguous eighth of the row-major sequence: a band of the frame
+  const int seg = active ? item / n_strips : 0, strip = active ? item - seg * n_strips : 0;
+  const int lane = threadIdx.x & 63, g = lane >> 5, j = lane & 31;
   const int reach = P.taps.reach;
   const int xb = (P.x0 & ~31) + 32 * strip;  // the strip's columns
   const int ys = y_first + 32 * T * seg;      // first output row of the segment
@@ -3100,11 +3114,11 @@ __global__ __launch_bounds__(64, 2) void k_blur_fx(BlurParams P, const uint4* __
   const int ws = ys - reach;                  // first row of H-block 0
   const int w0a = (xb - reach) & ~3;          // horizontal window start, moved back to a 16-byte boundary (mx_delta)
   const uint32_t ring_lds = (uint32_t)reinterpret_cast<uintptr_t>(ring);
+  const uint32_t src_lds = ring_lds + (uint32_t)((NKH + NKV + wave * NKH) * kMxSlot * 4);
 
   // LDS-DMA of the NKH source k-steps of H-block i into the source slots (single-buffered: issued as soon as the horizontal
-  // product of block i - 1 has read them, in flight under the vertical product and the stores; 22 KB of LDS per wave instead
-  // of 32 lets seven waves share a CU instead of five); returns the instructions issued
-  auto issue_block = [&](int i) -> int {
+  // product of block i - 1 has read them, in flight under the vertical product and the stores); returns the instructions issued
+  auto issue_block = [&](int i) __attribute__((always_inline)) -> int {
     const int r = lane >> 2, c = lane & 3;
     const uint32_t* rowp[2];
 #pragma unroll
@@ -3117,15 +3131,15 @@ __global__ __launch_bounds__(64, 2) void k_blur_fx(BlurParams P, const uint4* __
     int n = 0;
 #pragma unroll
     for (int s = 0; s < NKH; s++) {
-      const uint32_t slot = ring_lds + (uint32_t)s * (kMxSlot * 4u);
+      const uint32_t slot = src_lds + (uint32_t)s * (kMxSlot * 4u);
       const int xk = w0a + 16 * s;
       if (xk >= 0 && xk + 16 <= P.W) {  // wave-uniform
         lds_dma16(rowp[0] + xk, slot);
         lds_dma16(rowp[1] + xk, slot + 1024u);
         n += 2;
-      } else {  // the k-step crosses a frame edge: one texel per lane, clamped
+      } else {  // the k-step crosses a frame edge: one texel per lane, clamped (a rolled loop: this code exists seven times)
         const int rr = lane >> 4, pp = lane & 15;
-#pragma unroll
+#pragma unroll 1
         for (int e = 0; e < 8; e++) {
           const int row = 4 * e + rr;
           int y = ws + 32 * i + row;
@@ -3139,104 +3153,139 @@ __global__ __launch_bounds__(64, 2) void k_blur_fx(BlurParams P, const uint4* __
     }
     return n;
   };
-  auto wait_for_all_but = [&](int n) {
+  auto wait_for_all_but = [&](int n) __attribute__((always_inline)) {
     if (n >= 48) wait_vm<48>(); else if (n >= 24) wait_vm<24>(); else if (n >= 16) wait_vm<16>(); else if (n >= 12) wait_vm<12>(); else if (n >= 10) wait_vm<10>(); else if (n >= 8) wait_vm<8>(); else if (n >= 6) wait_vm<6>(); else wait_vm<0>();
     __builtin_amdgcn_sched_barrier(0);
   };
 
-  issue_block(0);
-  // weight fragments of both products, fetched behind the first block's DMA and waited for once (see k_blur_mx)
-  h8 hhi[NKH], hlo[NKH], vhi[NKV], vlo[NKV];
+  if (active) issue_block(0);
+  // the weight fragments of both products go to LDS as they lie in memory (lane-linear 16-byte pieces: exactly what the DMA
+  // writes), every wave of the workgroup fetching its share -- the one point at which the waves meet
+  {
+    constexpr int NF = 2 * (NKH + NKV);
 #pragma unroll
-  for (int m = 0; m < NKH; m++) {
-    H8Bits a, b;
-    const uint4 va = P.mx_w[(2 * m) * 64 + lane], vb = P.mx_w[(2 * m + 1) * 64 + lane];
-    a.u[0] = va.x; a.u[1] = va.y; a.u[2] = va.z; a.u[3] = va.w; b.u[0] = vb.x; b.u[1] = vb.y; b.u[2] = vb.z; b.u[3] = vb.w;
-    hhi[m] = a.v; hlo[m] = b.v;
-  }
-#pragma unroll
-  for (int m = 0; m < NKV; m++) {
-    H8Bits a, b;
-    const uint4 va = w_v[(2 * m) * 64 + lane], vb = w_v[(2 * m + 1) * 64 + lane];
-    a.u[0] = va.x; a.u[1] = va.y; a.u[2] = va.z; a.u[3] = va.w; b.u[0] = vb.x; b.u[1] = vb.y; b.u[2] = vb.z; b.u[3] = vb.w;
-    vhi[m] = a.v; vlo[m] = b.v;
+    for (int f0 = 0; f0 < NF; f0 += kFxWaves) {
+      const int f = f0 + wave;
+      if (f < NF) lds_dma16((f < 2 * NKH ? P.mx_w + f * 64 : w_v + (f - 2 * NKH) * 64) + lane, ring_lds + (uint32_t)f * 1024u);
+    }
   }
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+  __syncthreads();
+  if (!active) return;
   int core_x0 = 0, core_y0 = 0, core_x1 = 0, core_y1 = 0;
   if (P.fuse_draw >= 0) { const DrawRec* qd = draws + P.fuse_draw; core_x0 = qd->ix0; core_y0 = qd->iy0; core_x1 = qd->ix1; core_y1 = qd->iy1; }
 
+  // the stash: k-step 2 p + s of it = rows 16 s .. 16 s + 15 of the H-block whose number is p mod HB, one operand (four VGPRs of
+  // f16 pairs) per channel.  Indexed by constants only (phase<PH>): it lives in registers.
+  uint32_t stash[2 * HB][4][4];  // [k-step][channel][VGPR of f16 pairs]
+  auto operand = [](const uint32_t (&u)[4]) { H8Bits o; o.u[0] = u[0]; o.u[1] = u[1]; o.u[2] = u[2]; o.u[3] = u[3]; return o.v; };
+  f32x16 acc[4];
+  // phase PH = (H-block number) mod HB: round the horizontal product into the stash, then -- `vertical` -- multiply the block
+  // that this H-block completes
+  auto phase = [&](auto ph_tag, bool vertical) __attribute__((always_inline)) {
+    constexpr int PH = decltype(ph_tag)::value;
+    // (an opaque marker that differs per phase: without it the optimizer hoists the rounding -- identical in the three copies -- in
+    // front of the branch and turns "which stash slot" into 96 v_cndmask per block)
+    asm volatile("; k_blur_fx: phase %0" ::"n"(PH));
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; s2++)
+#pragma unroll
+        for (int qq = 0; qq < 4; qq++) {
+          const float x0 = __builtin_fmaf(acc[c][8 * s2 + 2 * qq], kMxScale, kMxMagic), x1 = __builtin_fmaf(acc[c][8 * s2 + 2 * qq + 1], kMxScale, kMxMagic);
+          const uint32_t pr = __builtin_amdgcn_perm(__float_as_uint(x1), __float_as_uint(x0), 0x0c040c00u);
+          stash[2 * PH + s2][c][qq] = pr;
+        }
+    // (pinned here: the half of the H-block this V block does not read would otherwise be rounded BEHIND the vertical product --
+    // the optimizer sinks it towards its first use -- with its 32 accumulator registers alive all the way)
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; s2++)
+#pragma unroll
+        for (int qq = 0; qq < 4; qq++) asm volatile("" : "+v"(stash[2 * PH + s2][c][qq]));
+    if (!vertical) return;
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+#pragma unroll
+      for (int e = 0; e < 16; e++) acc[c][e] = 0.0f;
+    constexpr int first = (PH + 1) % HB;  // the V block's first H-block: number i - (HB - 1), i.e. (PH + 1) mod HB
+    // (the weight fragments one k-step ahead, a scheduling fence per k-step: left to itself the scheduler fetches all 2 NKV
+    // fragments first -- 40 registers on top of the stash and the accumulators -- and spills the stash)
+    uint4 va = vw[lane], vb = vw[64 + lane];
+#pragma unroll
+    for (int m = 0; m < NKV; m++) {
+      const int slot = 2 * ((first + (m >> 1)) % HB) + (m & 1);
+      H8Bits whi, wlo;
+      whi.u[0] = va.x; whi.u[1] = va.y; whi.u[2] = va.z; whi.u[3] = va.w; wlo.u[0] = vb.x; wlo.u[1] = vb.y; wlo.u[2] = vb.z; wlo.u[3] = vb.w;
+      if (m + 1 < NKV) { va = vw[(2 * m + 2) * 64 + lane]; vb = vw[(2 * m + 3) * 64 + lane]; }
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi.v, operand(stash[slot][0]), acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi.v, operand(stash[slot][1]), acc[1], 0, 0, 0);
+      acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi.v, operand(stash[slot][2]), acc[2], 0, 0, 0);
+      acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi.v, operand(stash[slot][3]), acc[3], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo.v, operand(stash[slot][0]), acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo.v, operand(stash[slot][1]), acc[1], 0, 0, 0);
+      acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo.v, operand(stash[slot][2]), acc[2], 0, 0, 0);
+      acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo.v, operand(stash[slot][3]), acc[3], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
   const int n_hblocks = n_blocks + HB - 1;
   int stores_behind = 0;  // store instructions issued after this block's DMA batch (vmcnt retires in issue order: they may stay out)
-#pragma unroll 1
-  for (int i = 0; i < n_hblocks; i++) {
+  auto iteration = [&](auto ph_tag, int i) __attribute__((always_inline)) {
     // this H-block's texels have landed -- its batch is older than the stores of the V block issued after it, which are NOT
     // waited for (they would cost a store round trip per iteration)
     wait_for_all_but(stores_behind);
     stores_behind = 0;
     // ---- horizontal product of H-block i: rows ws + 32 i .. + 31, columns xb .. xb + 31
-    {
-      f32x16 acc[4];
-#pragma unroll
-      for (int c = 0; c < 4; c++)
-#pragma unroll
-        for (int e = 0; e < 16; e++) acc[c][e] = 0.0f;
-#pragma unroll
-      for (int m = 0; m < NKH; m++) {
-        const uint32_t* slot = src_ring + m * kMxSlot;
-        const uint4* row4 = reinterpret_cast<const uint4*>(slot + j * 16);
-        const int sw = (j >> 2) & 3;
-        const uint4 lo4 = row4[(2 * g) ^ sw], hi4 = row4[(2 * g + 1) ^ sw];
-        const uint32_t t8[8] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
-        const h8 f0 = mx_frag<0>(t8), f1 = mx_frag<1>(t8), f2_ = mx_frag<2>(t8), f3 = mx_frag<3>(t8);
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f0, hhi[m], acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f1, hhi[m], acc[1], 0, 0, 0);
-        acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f2_, hhi[m], acc[2], 0, 0, 0);
-        acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f3, hhi[m], acc[3], 0, 0, 0);
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f0, hlo[m], acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f1, hlo[m], acc[1], 0, 0, 0);
-        acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f2_, hlo[m], acc[2], 0, 0, 0);
-        acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f3, hlo[m], acc[3], 0, 0, 0);
-      }
-      // the source slots are read (every MFMA above has its operands): the next H-block's texels start their way in, under the
-      // rounding below and the whole vertical product
-      __builtin_amdgcn_sched_barrier(0);
-      if (i + 1 < n_hblocks) issue_block(i + 1);
-      __builtin_amdgcn_sched_barrier(0);
-      // RGBA8 as the H pass stores it (the reference's intermediate texture), into H-ring slots 2 (i % HB), + 1: lane = column,
-      // register rr = row (rr & 3) + 8 (rr >> 2) + 4 g of the block
-      uint32_t* const hs = h_ring + (2 * (i % HB)) * kMxSlot;
-#pragma unroll
-      for (int rr = 0; rr < 16; rr++) {
-        const int row = (rr & 3) + 8 * (rr >> 2) + 4 * g;
-        hs[row * 32 + j] = pack2(f2{acc[0][rr] * kMxScale, acc[1][rr] * kMxScale}, f2{acc[2][rr] * kMxScale, acc[3][rr] * kMxScale});
-      }
-    }
-    __builtin_amdgcn_wave_barrier();
-    const int b = i - (HB - 1);  // the V block whose last H-block this was
-    if (b < 0) continue;
-    // ---- vertical product of block b: rows ys + 32 b .. + 31 from k-steps 2 b .. 2 b + NKV - 1 of the H ring
-    f32x16 acc[4];
 #pragma unroll
     for (int c = 0; c < 4; c++)
 #pragma unroll
       for (int e = 0; e < 16; e++) acc[c][e] = 0.0f;
+    {
+      // (texels and weight fragments one k-step ahead of the MFMAs that use them, a scheduling fence per k-step: see phase())
+      const int sw = (j >> 2) & 3;
+      const uint4* row4 = reinterpret_cast<const uint4*>(src_ring + j * 16);
+      uint4 lo4 = row4[(2 * g) ^ sw], hi4 = row4[(2 * g + 1) ^ sw];
+      uint4 va = hw[lane], vb = hw[64 + lane];
 #pragma unroll
-    for (int m = 0; m < NKV; m++) {
-      const uint32_t* slot = h_ring + ((2 * b + m) % RV) * kMxSlot;
-      uint32_t t8[8];
-#pragma unroll
-      for (int t = 0; t < 8; t++) t8[t] = slot[(8 * g + t) * 32 + j];
-      const h8 f0 = mx_frag<0>(t8), f1 = mx_frag<1>(t8), f2_ = mx_frag<2>(t8), f3 = mx_frag<3>(t8);
-      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vhi[m], f0, acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vhi[m], f1, acc[1], 0, 0, 0);
-      acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vhi[m], f2_, acc[2], 0, 0, 0);
-      acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vhi[m], f3, acc[3], 0, 0, 0);
-      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vlo[m], f0, acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vlo[m], f1, acc[1], 0, 0, 0);
-      acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vlo[m], f2_, acc[2], 0, 0, 0);
-      acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vlo[m], f3, acc[3], 0, 0, 0);
+      for (int m = 0; m < NKH; m++) {
+        const uint32_t t8[8] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
+        H8Bits whi, wlo;
+        whi.u[0] = va.x; whi.u[1] = va.y; whi.u[2] = va.z; whi.u[3] = va.w; wlo.u[0] = vb.x; wlo.u[1] = vb.y; wlo.u[2] = vb.z; wlo.u[3] = vb.w;
+        if (m + 1 < NKH) {
+          const uint4* nx = reinterpret_cast<const uint4*>(src_ring + (m + 1) * kMxSlot + j * 16);
+          lo4 = nx[(2 * g) ^ sw]; hi4 = nx[(2 * g + 1) ^ sw];
+          va = hw[(2 * m + 2) * 64 + lane]; vb = hw[(2 * m + 3) * 64 + lane];
+        }
+        const h8 f0 = mx_frag<0>(t8), f1 = mx_frag<1>(t8), f2_ = mx_frag<2>(t8), f3 = mx_frag<3>(t8);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f0, whi.v, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f1, whi.v, acc[1], 0, 0, 0);
+        acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f2_, whi.v, acc[2], 0, 0, 0);
+        acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f3, whi.v, acc[3], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f0, wlo.v, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f1, wlo.v, acc[1], 0, 0, 0);
+        acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f2_, wlo.v, acc[2], 0, 0, 0);
+        acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f3, wlo.v, acc[3], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
+    const int b = i - (HB - 1);  // the V block whose last H-block this is
     const int bx = xb, by = ys + 32 * b;
+    // A block on the consuming quad's border moves its alphas through the first two source slots (below): the next H-block's
+    // texels must not be on their way into them yet -- for those few blocks the DMA is issued behind the composite instead
+    const bool fuse = P.fuse_draw >= 0;
+    const bool core = bx >= core_x0 && bx + 32 <= core_x1 && by >= core_y0 && by + 32 <= core_y1;  // coverage alpha == 1 (wave-uniform)
+    const bool dma_late = b >= 0 && fuse && !core;
+    // the source slots are read (every MFMA above has its operands): the next H-block's texels start their way in, under the
+    // rounding below and the whole vertical product
+    __builtin_amdgcn_sched_barrier(0);
+    if (!dma_late && i + 1 < n_hblocks) issue_block(i + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    phase(ph_tag, b >= 0);
+    if (b < 0) return;
     const int x = bx + j;
     const bool x_ok = x >= P.x0 && x < P.x1;
     uint32_t pend[16];
@@ -3256,7 +3305,6 @@ __global__ __launch_bounds__(64, 2) void k_blur_fx(BlurParams P, const uint4* __
     if (P.fuse_draw >= 0) {
       // atlas.frag:381-388 on the blurred texel just produced, blended over the live texel (src: dst is another surface, so
       // every pixel of the region is written: where the quad does not cover, the live texel passes through the blend unchanged)
-      const bool core = bx >= core_x0 && bx + 32 <= core_x1 && by >= core_y0 && by + 32 <= core_y1;  // coverage alpha == 1 (wave-uniform)
       bool replace_all = false;
       if (core) {
         uint32_t conj = pend[0];
@@ -3265,10 +3313,9 @@ __global__ __launch_bounds__(64, 2) void k_blur_fx(BlurParams P, const uint4* __
         replace_all = __all((conj >> 24) == 255u);
       }
       if (!replace_all) {
-        // (the two H-ring slots this block's product read first: block b + 1 starts two k-steps further down, and the next
-        // H-block overwrites them only in the next iteration)
-        uint32_t* const sc0 = h_ring + ((2 * b) % RV) * kMxSlot;
-        uint32_t* const sc1 = h_ring + ((2 * b + 1) % RV) * kMxSlot;
+        // (the first two source slots: read by the horizontal product above, and -- dma_late -- nothing is in flight into them)
+        uint32_t* const sc0 = src_ring;
+        uint32_t* const sc1 = src_ring + kMxSlot;
         const uint32_t valid = pmask;
         if (!core) {
 #pragma unroll
@@ -3332,6 +3379,9 @@ __global__ __launch_bounds__(64, 2) void k_blur_fx(BlurParams P, const uint4* __
         __builtin_amdgcn_wave_barrier();
       }
     }
+    __builtin_amdgcn_sched_barrier(0);
+    if (dma_late && i + 1 < n_hblocks) issue_block(i + 1);
+    __builtin_amdgcn_sched_barrier(0);
     // the block's rows: uniform row pointer + one per-lane byte offset
     {
       const uint32_t lane_off = ((uint32_t)(4 * g) * (uint32_t)P.pitch + (uint32_t)j) * 4u;
@@ -3349,6 +3399,12 @@ __global__ __launch_bounds__(64, 2) void k_blur_fx(BlurParams P, const uint4* __
       }
     }
     __builtin_amdgcn_sched_barrier(0);
+  };
+#pragma unroll 1
+  for (int i = 0; i < n_hblocks; i += HB) {
+    iteration(std::integral_constant<int, 0>{}, i);
+    if (HB >= 2) { if (i + 1 >= n_hblocks) break; iteration(std::integral_constant<int, HB >= 2 ? 1 : 0>{}, i + 1); }
+    if (HB >= 3) { if (i + 2 >= n_hblocks) break; iteration(std::integral_constant<int, HB >= 3 ? 2 : 0>{}, i + 2); }
   }
 }
 
@@ -3638,22 +3694,20 @@ template <bool kV> static bool launch_blur_mx_nk(hipStream_t s, const BlurParams
 // Both passes in one kernel (k_blur_fx): instantiated for the filter widths whose two rings fit five waves' worth of LDS per CU
 // (NKH <= 6: tap reach <= 22, blur radius <= ~21); wider filters keep the two-pass route.
 template <int NKH, int NKV> static void launch_blur_fx(hipStream_t s, const BlurParams& P, const uint4* w_v, const DrawRec* draws, const QuadExt* exts) {
-  constexpr size_t lds = (size_t)fx_slots(NKH, NKV) * kMxSlot * sizeof(uint32_t);
-  static const int per_cu = [] {
+  constexpr size_t lds = (size_t)fx_slots(NKH, NKV) * kMxSlot * sizeof(uint32_t);  // per workgroup of kFxWaves waves
+  static const int wg_per_cu = [] {
     int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_blur_fx<NKH, NKV>, 64, lds) != hipSuccess || n <= 0) n = std::min<int>(8, (int)(160 * 1024 / lds));
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_blur_fx<NKH, NKV>, 64 * kFxWaves, lds) != hipSuccess || n <= 0) n = std::min<int>(8 / kFxWaves, (int)(160 * 1024 / lds));
     return n;
   }();
   static const int forced = [] { const char* e = std::getenv("FDH_FX_T"); return e ? std::atoi(e) : 0; }();  // experiments
-  // (experiments: FDH_FX_LDS = KB of LDS to ask for per wave -- more than the rings need, to leave room on a CU for other kernels' waves)
-  static const size_t lds_req = [] { const char* e = std::getenv("FDH_FX_LDS"); const size_t need = lds, ask = e ? (size_t)std::atoi(e) * 1024 : 0; return ask > need ? ask : need; }();
   const int n_strips = (P.x1 - (P.x0 & ~31) + 31) >> 5, blocks = (P.y1 - (P.y0 & ~31) + 31) >> 5;
-  const long long slots = 256LL * std::min(std::min(per_cu, 8), (int)(160 * 1024 / lds_req));
+  const long long slots = 256LL * std::min(wg_per_cu * kFxWaves, 8);
   int t = 2;  // (a one-block segment would filter three H-blocks per output block)
   while (t < 64 && (long long)n_strips * ((blocks + t - 1) / t) > slots) t++;
   if (forced) t = forced;
-  const int total = n_strips * ((blocks + t - 1) / t);
-  FDH_LAUNCH((k_blur_fx<NKH, NKV>), dim3(8 * ((total + 7) / 8)), dim3(64), lds_req, s, P, w_v, draws, exts, t);
+  const int total = n_strips * ((blocks + t - 1) / t), per = (total + 7) / 8;
+  FDH_LAUNCH((k_blur_fx<NKH, NKV>), dim3(8 * ((per + kFxWaves - 1) / kFxWaves)), dim3(64 * kFxWaves), lds, s, P, w_v, draws, exts, t);
 }
 bool blur_fused_supported(int reach, int W, int pitch) {
   const int nkh = mx_nk(reach, false), nkv = mx_nk(reach, true);

@@ -1087,7 +1087,7 @@ Lane& Context::ensure_lane(int i) {
   auto& v = lanes_[(size_t)staging_i_];
   while ((int)v.size() <= i) {
     v.emplace_back(new Lane());
-    v.back()->set_pinned(!host_only_);
+    v.back()->set_pinned(!host_only_, device_);
   }
   return *v[(size_t)i];
 }
@@ -1295,6 +1295,86 @@ uint64_t Context::record_digest() {
   for (const Piece& p : pieces_) { const Lane& L = lane(p.lane); for (uint32_t i = 0; i < p.n_ext; i++) mix(&L.exts[p.ext_first + i], sizeof(QuadExt)); }
   for (const Phase& ph : phases_) { mix(&ph.first, sizeof ph.first); mix(&ph.count, sizeof ph.count); mix(&ph.blur, sizeof ph.blur); }
   return h;
+}
+
+// Fault hunting (fdh_debug_verify_upload): the device's frame block -- what k_upload_frame gathered for the frame last submitted --
+// read back and compared with the lanes the records were made in (ordinary host memory, untouched until the staging set comes
+// round again).  out[0..2] = bytes that differ in records / bin records / extensions, out[3] = bytes compared; out[4..9] describe the
+// first difference: array (0, 1, 2), byte offset in the device array, the piece's lane, device dword, host dword, dwords of the
+// device run that are zero; out[10] = pieces, out[11] = records.
+void Context::debug_verify_upload(uint32_t out[24]) {
+  need_device("debug_verify_upload");
+  drain();
+  FDH_HIP(hipSetDevice(device_));
+  FDH_HIP(hipStreamSynchronize(stream_));
+  for (int i = 0; i < 24; i++) out[i] = 0;
+  const LaunchJob& J = job_;
+  out[10] = (uint32_t)pieces_.size(); out[11] = n_total_;
+  if (!J.dv.recs || n_total_ == 0) return;
+  std::vector<DrawRec> recs(n_total_);
+  std::vector<BinRec> bins(n_total_);
+  std::vector<QuadExt> exts(n_ext_total_);
+  FDH_HIP(hipMemcpy(recs.data(), J.dv.recs, recs.size() * sizeof(DrawRec), hipMemcpyDeviceToHost));
+  FDH_HIP(hipMemcpy(bins.data(), J.dv.binrecs, bins.size() * sizeof(BinRec), hipMemcpyDeviceToHost));
+  if (!exts.empty()) FDH_HIP(hipMemcpy(exts.data(), J.dv.exts, exts.size() * sizeof(QuadExt), hipMemcpyDeviceToHost));
+  bool first = true;
+  auto cmp = [&](int array, int lane_no, const void* dev, const void* host, size_t bytes, size_t dev_off) {
+    const uint32_t* d = static_cast<const uint32_t*>(dev);
+    const uint32_t* h = static_cast<const uint32_t*>(host);
+    out[3] += (uint32_t)bytes;
+    for (size_t i = 0; i < bytes / 4; i++) {
+      if (d[i] == h[i]) continue;
+      out[array] += 4;
+      if (first) {
+        first = false;
+        out[4] = (uint32_t)array; out[5] = (uint32_t)(dev_off + 4 * i); out[6] = (uint32_t)lane_no; out[7] = d[i]; out[8] = h[i];
+        uint32_t z = 0;
+        for (size_t k = 0; k < bytes / 4; k++) z += d[k] == 0u;
+        out[9] = z;
+      }
+    }
+  };
+  uint32_t r0 = 0, e0 = 0;
+  for (const Piece& p : pieces_) {
+    const Lane& L = lane(p.lane);
+    std::vector<DrawRec> want(L.recs.p + p.first, L.recs.p + p.first + p.n);
+    for (DrawRec& r : want) if (r.op_mode & F_GENERAL) r.ext = r.ext - p.ext_first + e0;
+    cmp(0, p.lane, recs.data() + r0, want.data(), (size_t)p.n * sizeof(DrawRec), (size_t)r0 * sizeof(DrawRec));
+    cmp(1, p.lane, bins.data() + r0, L.bins.p + p.first, (size_t)p.n * sizeof(BinRec), (size_t)r0 * sizeof(BinRec));
+    if (p.n_ext) cmp(2, p.lane, exts.data() + e0, L.exts.p + p.ext_first, (size_t)p.n_ext * sizeof(QuadExt), (size_t)e0 * sizeof(QuadExt));
+    r0 += p.n; e0 += p.n_ext;
+  }
+  // the block from the chunk boxes on (chunk boxes, phase table, blur weight tables as far as this frame staged them): out[12] bytes
+  // that differ, out[13] first offset (in that block), out[14] device dword, out[15] host dword, out[16] bytes compared
+  {
+    const size_t o_misc = (size_t)(reinterpret_cast<const uint8_t*>(J.dv.chunkbox) - d_frame_.ptr);
+    std::vector<uint8_t> dev(misc_host_.size());
+    if (!dev.empty()) FDH_HIP(hipMemcpy(dev.data(), d_frame_.ptr + o_misc, dev.size(), hipMemcpyDeviceToHost));
+    out[16] = (uint32_t)dev.size();
+    for (size_t i = 0; i + 4 <= dev.size(); i += 4) {
+      uint32_t a, b;
+      std::memcpy(&a, dev.data() + i, 4); std::memcpy(&b, misc_host_.data() + i, 4);
+      if (a == b) continue;
+      if (!out[12]) { out[13] = (uint32_t)i; out[14] = a; out[15] = b; }
+      out[12] += 4;
+    }
+  }
+  // the bin boxes the upload kernel derives from the bin records: out[17] boxes that differ from the host's, out[18] first index,
+  // out[19] device value, out[20] host value
+  {
+    std::vector<uint32_t> box(n_total_);
+    FDH_HIP(hipMemcpy(box.data(), J.dv.binbox, box.size() * 4, hipMemcpyDeviceToHost));
+    uint32_t g0 = 0;
+    for (const Piece& p : pieces_) {
+      const Lane& L = lane(p.lane);
+      for (uint32_t i = 0; i < p.n; i++, g0++) {
+        if (g0 == 0 && out[1]) continue;  // (a folded clear emptied record 0's box on the device side)
+        if (box[g0] == L.boxes.p[p.first + i]) continue;
+        if (!out[17]) { out[18] = g0; out[19] = box[g0]; out[20] = L.boxes.p[p.first + i]; }
+        out[17]++;
+      }
+    }
+  }
 }
 
 // A retained root's cached records take their place in lane 0 (fdh_scene_render): a memcpy per array, the extension indices

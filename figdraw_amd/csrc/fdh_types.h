@@ -143,6 +143,13 @@ struct BlurTaps {  // merged FIR of blur.frag:19-29 for one radius: out = sum co
 constexpr int kMxMaxNK = 11;  // reach 66 = the widest filter (radius clamp 64)
 inline int mx_nk(int reach, bool vertical) { return (32 + 2 * reach + (vertical ? 0 : 3) + 15) / 16; }
 inline int mx_delta(int reach, bool vertical) { return vertical ? 0 : ((-reach) % 4 + 4) % 4; }  // window start -> 16-byte boundary
+// Row of a 16-texel k-step that element e (0..7) of lane group g (0, 1) carries in the matrix-pipe operands.  Horizontal pass: 8 g + e.
+// Vertical pass: (e & 3) + 8 (e >> 2) + 4 g -- register 8 s + e of a 32 x 32 f32 accumulator tile holds row 16 s + that of the tile, so
+// an accumulator tile IS two k-steps of the next product's operand in this order.
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline int mx_krow(int g, int e, bool vertical) { return vertical ? (e & 3) + 8 * (e >> 2) + 4 * g : 8 * g + e; }
 constexpr size_t mx_table_bytes(int nk) { return (size_t)nk * 2 * 64 * 16; }  // [k-step][hi, lo][lane] x 8 halves
 
 struct AtlasView {

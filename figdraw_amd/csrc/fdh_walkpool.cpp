@@ -33,7 +33,11 @@ inline void relax() {
 #endif
 }
 struct alignas(128) Shared {
-  std::atomic<uint64_t> epoch{0};     // bumped once per group
+  // One word per group: (group number << 8) | helpers of that group.  A helper decides whether it takes part from the value it
+  // LOADED, never from a field it reads afterwards: a helper that is not part of group N and is preempted after seeing N must not
+  // mistake itself for part of group N + 1 (whose fields may be half written) and pass through that group twice -- run() would
+  // return while another helper still works on the caller's stack.
+  std::atomic<uint64_t> word{0};
   // A chunk is claimed by whoever sets its flag first.  Slot s starts with its HOME chunks s, s + slots, s + 2 slots, ...: the
   // same part of the same tree goes to the same thread frame after frame, whose core still holds those nodes (488 bytes each) and
   // its recorder's state -- handed out first come first served, every chunk's nodes came from another core's cache or from memory,
@@ -43,7 +47,7 @@ struct alignas(128) Shared {
   std::atomic<uint8_t> claimed[kMaxChunks];
   std::atomic<int> through{0};        // helper slots that have finished the current group
   std::atomic<int> asleep{0};         // helpers blocked on the condition variable
-  int helpers = 0, n_chunks = 0;      // of the current group (written before the epoch is bumped)
+  int slots = 1, n_chunks = 0;        // of the current group (written before the word is published; read only by its participants)
   const std::function<void(int, int)>* fn = nullptr;
   std::mutex mu;
   std::condition_variable cv;
@@ -96,7 +100,7 @@ static bool helper_mask(int helpers, cpu_set_t& mask) {
 #endif
 
 static void take_chunks(Shared& sh, int slot, const std::function<void(int, int)>& fn) {
-  const int n = sh.n_chunks, slots = sh.helpers + 1;
+  const int n = sh.n_chunks, slots = sh.slots;
   for (int c = slot; c < n; c += slots)  // home chunks
     if (sh.claimed[c].exchange(1, std::memory_order_acq_rel) == 0) fn(slot, c);
   for (int c = 0; c < n; c++)            // then whatever nobody has started
@@ -109,24 +113,27 @@ struct WalkPoolImpl {
   std::vector<std::thread> threads;
   int spin_us = 200;
   void helper_main(int slot) {
-    uint64_t seen = 0;
+    uint64_t seen = 0;  // the group number this helper last looked at
     for (;;) {
       // wait for the next group: spin first (the next frame is tens of microseconds away), then sleep
       const auto t0 = std::chrono::steady_clock::now();
-      uint64_t e;
+      uint64_t wd;
       int spins = 0;
-      while ((e = sh.epoch.load(std::memory_order_acquire)) == seen) {
+      while (((wd = sh.word.load(std::memory_order_seq_cst)) >> 8) == seen) {
         relax();
         if ((++spins & 255) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(spin_us)) {
           std::unique_lock<std::mutex> lk(sh.mu);
           sh.asleep.fetch_add(1, std::memory_order_seq_cst);
-          sh.cv.wait(lk, [&] { return sh.quit || sh.epoch.load(std::memory_order_acquire) != seen; });
+          // (seq_cst: run() publishes the word, THEN reads `asleep`; this side bumps `asleep`, THEN reads the word -- one of the two sees the other)
+          sh.cv.wait(lk, [&] { return sh.quit || (sh.word.load(std::memory_order_seq_cst) >> 8) != seen; });
           sh.asleep.fetch_sub(1, std::memory_order_seq_cst);
           if (sh.quit) return;
         }
       }
-      seen = e;
-      if (slot > sh.helpers) continue;  // this group uses fewer helpers
+      seen = wd >> 8;
+      if (slot > (int)(wd & 0xff)) continue;  // this group uses fewer helpers (decided on the loaded word alone)
+      // a participant: run() does not return, and no later group is published, before this helper has bumped `through` -- the
+      // group's fields cannot change under it
       const std::function<void(int, int)>& fn = *sh.fn;
       take_chunks(sh, slot, fn);
       fn(slot, -1);
@@ -135,7 +142,7 @@ struct WalkPoolImpl {
   }
   ~WalkPoolImpl() {
     { std::lock_guard<std::mutex> lk(sh.mu); sh.quit = true; }
-    sh.epoch.fetch_add(1, std::memory_order_release);
+    sh.word.fetch_add(1u << 8, std::memory_order_seq_cst);
     sh.cv.notify_all();
     for (auto& t : threads) if (t.joinable()) t.join();
   }
@@ -159,7 +166,13 @@ WalkPool& WalkPool::get() {
 int WalkPool::default_helpers() {
   static const int v = [] {
     if (const char* e = std::getenv("FDH_WALK_THREADS")) return std::min(std::max(std::atoi(e), 0), 64);
-    const unsigned hw = std::thread::hardware_concurrency();
+    // the hardware threads this process may run on (a pinned rank, a container's cpuset), not the machine's: helpers that cannot be
+    // scheduled beside the caller make every frame slower than the serial walk
+    unsigned hw = std::thread::hardware_concurrency();
+#if defined(__linux__)
+    cpu_set_t allowed;
+    if (sched_getaffinity(0, sizeof allowed, &allowed) == 0) hw = std::min<unsigned>(hw ? hw : 1u << 20, (unsigned)CPU_COUNT(&allowed));
+#endif
     if (hw < 4) return 0;
     return (int)std::min(7u, hw / 8 + 1);  // a few: the walk of a frame is tens of microseconds, not a reason to take the machine
   }();
@@ -171,7 +184,7 @@ bool WalkPool::run(int helpers, int n_chunks, const std::function<void(int, int)
   if (helpers <= 0 || n_chunks <= 0 || n_chunks > Shared::kMaxChunks) return false;
   std::unique_lock<std::mutex> own(P.owner, std::try_to_lock);
   if (!own.owns_lock()) return false;
-  helpers = std::min(helpers, 64);
+  helpers = std::min(helpers, 64);  // (fits the word's low byte)
   if ((int)P.threads.size() < helpers) {
 #if defined(__linux__)
     cpu_set_t mask;
@@ -186,12 +199,12 @@ bool WalkPool::run(int helpers, int n_chunks, const std::function<void(int, int)
     }
   }
   Shared& sh = P.sh;
-  sh.helpers = helpers;
+  sh.slots = helpers + 1;
   sh.n_chunks = n_chunks;
   sh.fn = &fn;
   for (int c = 0; c < n_chunks; c++) sh.claimed[c].store(0, std::memory_order_relaxed);
   sh.through.store(0, std::memory_order_relaxed);
-  sh.epoch.fetch_add(1, std::memory_order_seq_cst);
+  sh.word.store((((sh.word.load(std::memory_order_relaxed) >> 8) + 1) << 8) | (uint64_t)helpers, std::memory_order_seq_cst);  // (one writer: `owner` is held)
   if (sh.asleep.load(std::memory_order_seq_cst) > 0) {
     std::lock_guard<std::mutex> lk(sh.mu);
     sh.cv.notify_all();
@@ -199,7 +212,11 @@ bool WalkPool::run(int helpers, int n_chunks, const std::function<void(int, int)
   take_chunks(sh, 0, fn);  // the calling thread is slot 0
   fn(0, -1);
   // every helper of this group passes through (one that slept through the work still bumps the counter when it wakes)
-  while (sh.through.load(std::memory_order_acquire) < helpers) relax();
+  // ... spinning briefly (they finish within microseconds of the caller), then yielding: a helper the scheduler has not placed -- a
+  // CPU-limited container, a rank pinned to few cores -- needs this thread's core to run at all
+  for (int spins = 0; sh.through.load(std::memory_order_acquire) < helpers; ) {
+    if (++spins < 4096) relax(); else sched_yield();
+  }
   return true;
 }
 

@@ -314,6 +314,13 @@ FDH_API int fdh_last_upload_bytes(FdhContext*, int64_t* out);
 /* Diagnostic: FNV-1a digest of the draw records, bounds, quad extensions and phase table of the last frame (also on
  * FDH_CREATE_RECORD_ONLY contexts): two frames with equal digests hand the kernels identical input. */
 FDH_API int fdh_debug_record_digest(FdhContext*, uint64_t* out);
+/* Fault hunting: the frame block on the device (what the upload kernel gathered for the frame last submitted) read back and compared
+ * with the host-side records it was gathered from.  out[0..2] = differing bytes in records / bin records / quad extensions, out[3] =
+ * bytes compared, out[4..9] = first difference (array, byte offset, lane, device dword, host dword, zero dwords in that run),
+ * out[10] = pieces, out[11] = records, out[12..16] = the block behind them (chunk boxes, phase table, blur tables: differing bytes,
+ * first offset, device dword, host dword, bytes compared), out[17..20] = derived bin boxes (differing, first index, device, host).
+ * No counterpart in the reference. */
+FDH_API int fdh_debug_verify_upload(FdhContext*, uint32_t out[24]);
 
 /* ------------------------------------------------------------------ multi-GPU / measurement hooks (no reference counterpart) */
 /* Restrict rasterisation to rows [y0, y1) of the frame (row-stripe sharding); blur halos are rendered redundantly so

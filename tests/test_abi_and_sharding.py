@@ -308,11 +308,18 @@ def test_saturated_core_is_conservative_against_the_oracle():
     assert found > 60
 
 
+def _krow(g, t, vertical):
+    """row of a 16-texel k-step that element t of lane group g carries (mx_krow, figdraw_amd/csrc/fdh_types.h)"""
+    return (t & 3) + 8 * (t >> 2) + 4 * g if vertical else 8 * g + t
+
+
 def test_blur_weight_fragments_reproduce_the_fir():
     """Host logic, no GPU: the weight fragments of the matrix-pipe blur passes (fdh_blur_weight_fragments) are the banded
-    Toeplitz form of the merged FIR: lane (j, g) of k-step m holds, for window texels 16 m + 8 g + t, the tap that texel
+    Toeplitz form of the merged FIR: lane (j, g) of k-step m holds, for window texels 16 m + krow(g, t), the tap that texel
     meets at output j (hi + lo halves = tap * 2^10 to 2^-21 relative), zeros outside the band; every output's weights sum
-    to 2^10 (the taps are normalised)."""
+    to 2^10 (the taps are normalised).  krow: 8 g + t for the horizontal pass; for the vertical one the order in which a 32 x 32
+    accumulator tile holds its rows, (t & 3) + 8 (t >> 2) + 4 g (mx_krow, fdh_types.h: the fused kernel's horizontal product
+    feeds the vertical one from registers) -- every row of a k-step exactly once either way."""
     import ctypes as C
 
     from figdraw_amd import context as ctx_mod
@@ -337,11 +344,12 @@ def test_blur_weight_fragments_reproduce_the_fir():
                 for lane in range(64):
                     j, g = lane & 31, lane >> 5
                     for t in range(8):
-                        k = 16 * m + 8 * g + t - delta - j
+                        k = 16 * m + _krow(g, t, vertical) - delta - j
                         want = taps[k] * 1024.0 if 0 <= k <= 2 * r else 0.0
                         assert abs(w[m, lane, t] - want) <= 1024.0 * 2.0 ** -21 * max(want / 1024.0, 2.0 ** -14), (radius, vertical, m, lane, t)
                         per_output[j] += w[m, lane, t]
             assert np.allclose(per_output, 1024.0, atol=2e-2), (radius, vertical)
+            assert sorted(_krow(g, t, vertical) for g in range(2) for t in range(8)) == list(range(16))
 
 
 @pytest.mark.parametrize("radius", [1.0, 5.0, 18.0, 64.0])
@@ -372,7 +380,7 @@ def test_blur_weight_fragments_blur_like_the_reference(radius):
         for m in range(n):
             for g in range(2):
                 for t in range(8):
-                    k = 16 * m + 8 * g + t - delta
+                    k = 16 * m + _krow(g, t, vertical) - delta
                     if 0 <= k <= 2 * r:
                         taps[k] = frag[m, 0, 32 * g, t] + frag[m, 1, 32 * g, t]
         axis = 0 if vertical else 1

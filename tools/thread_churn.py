@@ -39,7 +39,19 @@ def work(t):
                     if not np.array_equal(got, want[i]):
                         d = (got != want[i]).any(axis=2)
                         ys, xs = np.nonzero(d)
-                        bad.append((t, it, i, k, f"{int(d.sum())} px, rows {ys.min()}..{ys.max()}, cols {xs.min()}..{xs.max()}, max {int(np.abs(got.astype(int) - want[i].astype(int)).max())}, sync_submit {(it + t) % 3 == 0}"))
+                        try:
+                            vu = ctx.verify_upload()
+                        except Exception as e:  # noqa: BLE001
+                            vu = repr(e)
+                        try:  # the same GPU work again from the records the device holds, then the whole frame again
+                            ctx.replay(1)
+                            ctx.sync()
+                            again = int((ctx.read_pixels() != want[i]).any(axis=2).sum())
+                            ctx.render_frame(sc, w, h)
+                            anew = int((ctx.read_pixels() != want[i]).any(axis=2).sum())
+                        except Exception as e:  # noqa: BLE001
+                            again = anew = repr(e)
+                        bad.append((t, it, i, k, f"upload check {vu}", f"replayed: {again} px wrong, rendered again: {anew} px wrong", f"{int(d.sum())} px, rows {ys.min()}..{ys.max()}, cols {xs.min()}..{xs.max()}, max {int(np.abs(got.astype(int) - want[i].astype(int)).max())}, sync_submit {(it + t) % 3 == 0}"))
             ctx.close()
     except Exception as e:  # noqa: BLE001
         bad.append((t, "exception", repr(e)))
