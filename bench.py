@@ -863,9 +863,7 @@ def main():
                     "traffic": k.get("hbm_bytes"), "traffic_source": pmc_src,
                     "hbm": dict(hbm(st.bytes_composite_main, st.ms_composite_main), algorithmic_bytes_per_launch=int(st.bytes_composite_main)),
                     "note": "fused tile compositor: VALU-bound (it moves 4 B/pixel out + 128 B/draw in by construction, `hbm`: ~0.1 of the HBM peak says nothing "
-                            "about the kernel); the HBM-bound launches are the blur passes (roofline_blur).  Since every frame takes the one-kernel blur route, the frame's "
-                            "LONGEST launch is k_blur_fx (roofline_blur.fused_route: ~32 us against this one's ~26); this object stays on the compositor, the kernel "
-                            "rounds 1 - 3 were judged on, which still holds the larger share of the SIMDs' issue cycles (15.7 M VALU against 6.3 M + 0.78 M MFMA)"}
+                            "about the kernel); the HBM-side launches are the blur passes (roofline, roofline_blur)"}
     # The HBM-bound launches: the two passes of the frame's largest blur node (full frame here), each against its own bytes
     roofline_blur = None
     if st.ms_blur_big_h > 0 and st.ms_blur_big_v > 0:
@@ -895,6 +893,25 @@ def main():
                                             note="the route every frame takes by default since the end of round 4 (fdh_set_blur_route(-1 | 1)): faster than the two "
                                                  "passes alone AND with four contexts in flight (tools/ab_routes.sh); `algorithmic_bytes` / `frac` are against "
                                                  "what IT must move (region read once + written once), half the two-pass figure; same pixels bit for bit")
+    # `roofline` = the LONGEST launch of the route the frames of `value` take.  Since the end of round 4 that is the fused full-frame blur
+    # (k_blur_fx), an HBM-side kernel: achieved = the bytes IT must move (the region read once + written once; SURVEY.md 8d's per-node figure
+    # minus the intermediate's round trip, which this kernel does not make) / its launch duration measured in this run.  The compositor
+    # -- the longest launch until then, VALU-bound -- stays beside it as `roofline_compositor`.
+    roofline_main = roofline
+    if roofline_blur is not None and "fused_route" in roofline_blur and st_fx.ms_blur_fused >= st.ms_composite_main:
+        fr = roofline_blur["fused_route"]
+        kfx = pmc.get("k_blur_fx", {})
+        roofline_main = {"kernel": "k_blur_fx<NKH, NKV>: the fused full-frame backdrop blur (both separable passes in one out-of-place kernel, the RGBA8 intermediate "
+                                   "in registers) -- the longest launch of a frame; a row of its own in profiles/*_kernel_stats*.csv",
+                         "ms_per_launch": fr["ms"], "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "achieved": fr["achieved"], "frac": fr["frac"],
+                         "algorithmic_bytes_per_launch": fr["algorithmic_bytes"],
+                         "algorithmic_note": "4 B x region pixels read + 4 B x region pixels written (one launch = one full-frame blur node of one frame)",
+                         "traffic": fr.get("traffic"), "traffic_source": pmc_src,
+                         "survey_8d_bytes": fr.get("survey_8d_bytes"),
+                         "instruction_side": {"valu_instructions_per_launch": kfx.get("SQ_INSTS_VALU"), "mfma_busy_cycles_per_launch": kfx.get("SQ_VALU_MFMA_BUSY_CYCLES"),
+                                              "note": "the kernel is not limited by HBM: its SIMDs' cycles go to the two matrix-pipe products (80 v_mfma_f32_32x32x16_f16 per "
+                                                      "32 x 32 block) and the operand / pack VALU work around them (DESIGN.md section 4)"},
+                         "second_longest": {"kernel": "k_composite_tiles<4, true>", "ms_per_launch": round(st.ms_composite_main, 4), "see": "roofline_compositor"}}
     frame_gbs = st.bytes_algorithmic / (ms_step * 1e-3) / 1e9
     single_dyn_ms = 1e3 * sd_elapsed / args.steps
     single_gbs = st.bytes_algorithmic / (single_dyn_ms * 1e-3) / 1e9
@@ -964,7 +981,8 @@ def main():
                                 "ms_per_step": round(single_dyn_ms, 4), "batches_ms": sd_batch_ms,
                                 "replay_resident_records": {"value": round(w * h * args.steps / single_elapsed / 1e6, 1), "ms_per_step": round(1e3 * single_elapsed / args.steps, 4)},
                                 "note": "one context: fdh_render_frame per frame (the submit thread still overlaps frame n's launches with frame n + 1's tree walk)"},
-        "roofline": roofline,
+        "roofline": roofline_main,
+        "roofline_compositor": roofline,
         "roofline_blur": roofline_blur,
         "frame": {"algorithmic_bytes": int(st.bytes_algorithmic), "achieved_GBs": round(frame_gbs, 1),
                   "frac_of_hbm_peak": round(frame_gbs / HBM_PEAK_GBS, 5),

@@ -121,6 +121,7 @@ def load():
     L.fdh_scene_stats.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.fdh_debug_record_digest.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.fdh_debug_verify_upload.argtypes = [vp, C.POINTER(C.c_uint32)]
+    L.fdh_debug_bin_digest.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.fdh_last_upload_bytes.argtypes = [vp, C.POINTER(C.c_int64)]
     L.fdh_record_begin.argtypes = [vp]
     L.fdh_record_json.argtypes = [vp]
@@ -462,6 +463,12 @@ class HipContext:
         out = (C.c_uint32 * 24)()
         self._ck(self.L.fdh_debug_verify_upload(self.h, out))
         return list(out)
+
+    def bin_digest(self):
+        """fault hunting: hash / totals of the bin kernel's output for the last frame (fdh_debug_bin_digest)"""
+        out = (C.c_uint64 * 8)()
+        self._ck(self.L.fdh_debug_bin_digest(self.h, out))
+        return list(out)[:5]
 
     def record_digest(self) -> int:
         out = C.c_uint64()

@@ -252,6 +252,12 @@ int fdh_debug_verify_upload(FdhContext* c, uint32_t out[24]) {
     C(c)->debug_verify_upload(out);
   });
 }
+int fdh_debug_bin_digest(FdhContext* c, uint64_t out[8]) {
+  return guard([&] {
+    if (!out) throw fdh::Error(FDH_ERR_INVALID, "null output");
+    C(c)->debug_bin_digest(out);
+  });
+}
 int fdh_stripe_rows(int height, int world, int rank, int* y0, int* y1) {
   return guard([&] {
     if (!y0 || !y1) throw fdh::Error(FDH_ERR_INVALID, "null output");

@@ -92,8 +92,10 @@ void* vram_block_acquire(int device, size_t bytes, size_t* size_class) {
 }
 void vram_block_release(int device, void* p, size_t size_class) {
   if (!p) return;
-  static const bool keep = [] { const char* e = std::getenv("FDH_VRAM_STORE"); return !e || std::atoi(e) != 0; }();  // (0: the round-4 fault hunt's control)
-  if (!keep || !size_class || device < 0 || device >= kMaxDevices) { (void)hipFree(p); return; }
+  // (fault hunting: FDH_VRAM_STORE=0 gives blocks back to the driver, as until the end of round 4; =2 neither frees nor reuses them)
+  static const int mode = [] { const char* e = std::getenv("FDH_VRAM_STORE"); return e ? std::atoi(e) : 1; }();
+  if (mode == 2) return;
+  if (mode == 0 || !size_class || device < 0 || device >= kMaxDevices) { (void)hipFree(p); return; }
   std::lock_guard<std::mutex> lk(g_vram_mu);
   g_vram_free[device][vram_class(size_class)].push_back(p);
 }
@@ -616,8 +618,10 @@ void Context::ensure_surfaces() {
   FDH_HIP(hipMalloc((void**)&fb_, n * 4));
   FDH_HIP(hipMalloc((void**)&backdrop_, n * 4));
   FDH_HIP(hipMalloc((void**)&blur_tmp_, n * 4));
-  poison_fresh(backdrop_, n * 4); poison_fresh(blur_tmp_, n * 4);
-  FDH_HIP(hipMemsetAsync(fb_, 0, n * 4, stream_));
+  poison_fresh(backdrop_, n * 4); poison_fresh(blur_tmp_, n * 4); poison_fresh(fb_, n * 4);
+  // (fault hunting, FDH_POISON set: the surface starts as 0x11 bytes instead of zeros -- a zero pixel in a frame is then nobody's of ours)
+  static const bool marked = std::getenv("FDH_POISON") != nullptr;
+  FDH_HIP(hipMemsetAsync(fb_, marked ? 0x11 : 0, n * 4, stream_));
   surf_w_ = W_;
   surf_h_ = H_;
 }

@@ -441,7 +441,8 @@ class Context : public Recorder {
   void scene_render();
   void scene_stats(int64_t* walked, int64_t* reused) const { *walked = retained_.roots_walked; *reused = retained_.roots_reused; }
   int64_t uploaded_bytes() { drain(); return uploaded_bytes_; }
-  void debug_verify_upload(uint32_t out[24]);  // fdh_debug_verify_upload (fdh_record.cpp)
+  void debug_verify_upload(uint32_t out[24]);
+  void debug_bin_digest(uint64_t out[8]);        // fdh_debug_bin_digest (fdh_record.cpp)  // fdh_debug_verify_upload (fdh_record.cpp)
   uint64_t record_digest();  // FNV-1a over the last frame's draw records (diagnostic: works on record-only contexts)
 
   // multi-GPU: the gather over RCCL (fdh_comm.cpp)

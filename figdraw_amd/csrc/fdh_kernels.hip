@@ -3089,7 +3089,11 @@ __global__ __launch_bounds__(64 * mx_wg(NK, kV), FDH_MX_WAVES) void k_blur_mx(Bl
 //     resident at once (20 KB of LDS per wave at radius 18: eight waves per CU).
 // Bytes: (1 + halo) x 4 A read (the x halo comes out of L2) + 4 A written, against 16 A for the two passes.
 constexpr int fx_vblocks(int nkv) { return ((nkv - 1) >> 1) + 1; }               // H-blocks one V block reads
-constexpr int kFxWaves = 4;  // waves per workgroup: x-neighbours of one segment row; they share the weight fragments in LDS (and, in L2, their source halo)
+// Waves per workgroup: x-neighbours of one segment row; they share the weight fragments in LDS (and, in L2, their source halo).
+// (Eight -- a CU's worth -- with the halves of the workgroup kept one segment of the block apart by an s_barrier per segment, so that one
+// wave of a SIMD multiplies while the other rounds, packs and stores: built and measured in round 5, 36.6 - 40.2 us against 33.1: every
+// segment then lasts as long as the slowest of EIGHT waves' memory waits.  Not kept.)
+constexpr int kFxWaves = 4;
 constexpr int fx_slots(int nkh, int nkv) { return nkh + nkv + kFxWaves * nkh; }  // 2-KB LDS slots per WORKGROUP: both weight tables + every wave's source k-steps
 constexpr float kMxMagic = 12582912.0f;  // 1.5 * 2^23: x + this, as f32, is round-to-nearest-even(x) in the low mantissa bits (|x| < 2^22)
 template <int NKH, int NKV>
@@ -3117,47 +3121,55 @@ __global__ __launch_bounds__(64 * kFxWaves, 2) void k_blur_fx(BlurParams P, cons
   const uint32_t src_lds = ring_lds + (uint32_t)((NKH + NKV + wave * NKH) * kMxSlot * 4);
 
   // LDS-DMA of the NKH source k-steps of H-block i into the source slots (single-buffered: issued as soon as the horizontal
-  // product of block i - 1 has read them, in flight under the vertical product and the stores); returns the instructions issued
-  auto issue_block = [&](int i) __attribute__((always_inline)) -> int {
+  // product of block i - 1 has read them, in flight under the vertical product and the stores).  (Spread through the vertical
+  // product instead -- one k-step's two pieces behind each of its k-steps' MFMAs -- the batch's ~1.1 us of issue time per block,
+  // tools/fx_wave_times.py, only moved into the products: 35.9 us against 34.7.  Not kept.)
+  const uint32_t* dma_row[2] = {nullptr, nullptr};
+  int dma_block = 0;
+  auto issue_rows = [&](int i) __attribute__((always_inline)) {
     const int r = lane >> 2, c = lane & 3;
-    const uint32_t* rowp[2];
+    dma_block = i;
 #pragma unroll
     for (int h = 0; h < 2; h++) {
       const int row = 16 * h + r;
       int y = ws + 32 * i + row;
       y = y < 0 ? 0 : (y > P.H - 1 ? P.H - 1 : y);  // clamp-to-edge (glcontext.nim:214-215): a clamped row filters to a clamped H row
-      rowp[h] = P.src + (size_t)y * P.pitch + 4 * (c ^ ((row >> 2) & 3));
+      dma_row[h] = P.src + (size_t)y * P.pitch + 4 * (c ^ ((row >> 2) & 3));
     }
-    int n = 0;
-#pragma unroll
-    for (int s = 0; s < NKH; s++) {
-      const uint32_t slot = src_lds + (uint32_t)s * (kMxSlot * 4u);
-      const int xk = w0a + 16 * s;
-      if (xk >= 0 && xk + 16 <= P.W) {  // wave-uniform
-        lds_dma16(rowp[0] + xk, slot);
-        lds_dma16(rowp[1] + xk, slot + 1024u);
-        n += 2;
-      } else {  // the k-step crosses a frame edge: one texel per lane, clamped (a rolled loop: this code exists seven times)
-        const int rr = lane >> 4, pp = lane & 15;
+  };
+  auto issue_kstep = [&](int s) __attribute__((always_inline)) {
+    const uint32_t slot = src_lds + (uint32_t)s * (kMxSlot * 4u);
+    const int xk = w0a + 16 * s;
+    if (xk >= 0 && xk + 16 <= P.W) {  // wave-uniform
+      lds_dma16(dma_row[0] + xk, slot);
+      lds_dma16(dma_row[1] + xk, slot + 1024u);
+    } else {  // the k-step crosses a frame edge: one texel per lane, clamped (a rolled loop: this code exists many times)
+      const int rr = lane >> 4, pp = lane & 15;
 #pragma unroll 1
-        for (int e = 0; e < 8; e++) {
-          const int row = 4 * e + rr;
-          int y = ws + 32 * i + row;
-          y = y < 0 ? 0 : (y > P.H - 1 ? P.H - 1 : y);
-          int gx = xk + 4 * ((pp >> 2) ^ ((row >> 2) & 3)) + (pp & 3);
-          gx = gx < 0 ? 0 : (gx > P.W - 1 ? P.W - 1 : gx);
-          lds_dma4(P.src + (size_t)y * P.pitch + gx, slot + e * 256u);
-        }
-        n += 8;
+      for (int e = 0; e < 8; e++) {
+        const int row = 4 * e + rr;
+        int y = ws + 32 * dma_block + row;
+        y = y < 0 ? 0 : (y > P.H - 1 ? P.H - 1 : y);
+        int gx = xk + 4 * ((pp >> 2) ^ ((row >> 2) & 3)) + (pp & 3);
+        gx = gx < 0 ? 0 : (gx > P.W - 1 ? P.W - 1 : gx);
+        lds_dma4(P.src + (size_t)y * P.pitch + gx, slot + e * 256u);
       }
     }
-    return n;
+  };
+  auto issue_block = [&](int i) __attribute__((always_inline)) {
+    issue_rows(i);
+#pragma unroll
+    for (int s = 0; s < NKH; s++) issue_kstep(s);
   };
   auto wait_for_all_but = [&](int n) __attribute__((always_inline)) {
     if (n >= 48) wait_vm<48>(); else if (n >= 24) wait_vm<24>(); else if (n >= 16) wait_vm<16>(); else if (n >= 12) wait_vm<12>(); else if (n >= 10) wait_vm<10>(); else if (n >= 8) wait_vm<8>(); else if (n >= 6) wait_vm<6>(); else wait_vm<0>();
     __builtin_amdgcn_sched_barrier(0);
   };
 
+#if FDH_TIMING  // per-wave phase times in shader cycles (tools/fx_wave_times.py)
+  const unsigned long long T0 = FDH_NOW();
+  unsigned long long T_wait = 0, T_h = 0, T_v = 0, T_epi = 0, T_st = 0, T_cv = 0, T_cv_mark = 0, T_dma = 0;
+#endif
   if (active) issue_block(0);
   // the weight fragments of both products go to LDS as they lie in memory (lane-linear 16-byte pieces: exactly what the DMA
   // writes), every wave of the workgroup fetching its share -- the one point at which the waves meet
@@ -3172,6 +3184,9 @@ __global__ __launch_bounds__(64 * kFxWaves, 2) void k_blur_fx(BlurParams P, cons
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
   __syncthreads();
   if (!active) return;
+#if FDH_TIMING
+  const unsigned long long T_pro = FDH_NOW() - T0;
+#endif
   int core_x0 = 0, core_y0 = 0, core_x1 = 0, core_y1 = 0;
   if (P.fuse_draw >= 0) { const DrawRec* qd = draws + P.fuse_draw; core_x0 = qd->ix0; core_y0 = qd->iy0; core_x1 = qd->ix1; core_y1 = qd->iy1; }
 
@@ -3205,6 +3220,9 @@ __global__ __launch_bounds__(64 * kFxWaves, 2) void k_blur_fx(BlurParams P, cons
       for (int s2 = 0; s2 < 2; s2++)
 #pragma unroll
         for (int qq = 0; qq < 4; qq++) asm volatile("" : "+v"(stash[2 * PH + s2][c][qq]));
+#if FDH_TIMING
+    T_cv_mark = FDH_NOW() + (__builtin_amdgcn_readfirstlane(stash[2 * PH][0][0] ^ stash[2 * PH + 1][3][3]) & 0u);
+#endif
     if (!vertical) return;
 #pragma unroll
     for (int c = 0; c < 4; c++)
@@ -3237,8 +3255,14 @@ __global__ __launch_bounds__(64 * kFxWaves, 2) void k_blur_fx(BlurParams P, cons
   auto iteration = [&](auto ph_tag, int i) __attribute__((always_inline)) {
     // this H-block's texels have landed -- its batch is older than the stores of the V block issued after it, which are NOT
     // waited for (they would cost a store round trip per iteration)
+#if FDH_TIMING
+    const unsigned long long Ta = FDH_NOW();
+#endif
     wait_for_all_but(stores_behind);
     stores_behind = 0;
+#if FDH_TIMING
+    const unsigned long long Tb = FDH_NOW();
+#endif
     // ---- horizontal product of H-block i: rows ws + 32 i .. + 31, columns xb .. xb + 31
 #pragma unroll
     for (int c = 0; c < 4; c++)
@@ -3272,6 +3296,10 @@ __global__ __launch_bounds__(64 * kFxWaves, 2) void k_blur_fx(BlurParams P, cons
         __builtin_amdgcn_sched_barrier(0);
       }
     }
+#if FDH_TIMING
+    const unsigned long long Tc = FDH_NOW() + (__builtin_amdgcn_readfirstlane(__float_as_uint(acc[0][0] + acc[1][0] + acc[2][0] + acc[3][0])) & 0u);
+    T_wait += Tb - Ta; T_h += Tc - Tb;
+#endif
     const int b = i - (HB - 1);  // the V block whose last H-block this is
     const int bx = xb, by = ys + 32 * b;
     // A block on the consuming quad's border moves its alphas through the first two source slots (below): the next H-block's
@@ -3284,7 +3312,14 @@ __global__ __launch_bounds__(64 * kFxWaves, 2) void k_blur_fx(BlurParams P, cons
     __builtin_amdgcn_sched_barrier(0);
     if (!dma_late && i + 1 < n_hblocks) issue_block(i + 1);
     __builtin_amdgcn_sched_barrier(0);
+#if FDH_TIMING
+    const unsigned long long Tc2 = FDH_NOW();
+#endif
     phase(ph_tag, b >= 0);
+#if FDH_TIMING
+    const unsigned long long Td = FDH_NOW() + (__builtin_amdgcn_readfirstlane(__float_as_uint(acc[0][0] + acc[1][0] + acc[2][0] + acc[3][0])) & 0u);
+    T_v += Td - Tc; T_cv += T_cv_mark - Tc2; T_dma += Tc2 - Tc;
+#endif
     if (b < 0) return;
     const int x = bx + j;
     const bool x_ok = x >= P.x0 && x < P.x1;
@@ -3379,6 +3414,10 @@ __global__ __launch_bounds__(64 * kFxWaves, 2) void k_blur_fx(BlurParams P, cons
         __builtin_amdgcn_wave_barrier();
       }
     }
+#if FDH_TIMING
+    const unsigned long long Te = FDH_NOW() + (__builtin_amdgcn_readfirstlane(pend[0] + pend[15]) & 0u);
+    T_epi += Te - Td;
+#endif
     __builtin_amdgcn_sched_barrier(0);
     if (dma_late && i + 1 < n_hblocks) issue_block(i + 1);
     __builtin_amdgcn_sched_barrier(0);
@@ -3399,6 +3438,9 @@ __global__ __launch_bounds__(64 * kFxWaves, 2) void k_blur_fx(BlurParams P, cons
       }
     }
     __builtin_amdgcn_sched_barrier(0);
+#if FDH_TIMING
+    T_st += FDH_NOW() - Te;
+#endif
   };
 #pragma unroll 1
   for (int i = 0; i < n_hblocks; i += HB) {
@@ -3406,6 +3448,15 @@ __global__ __launch_bounds__(64 * kFxWaves, 2) void k_blur_fx(BlurParams P, cons
     if (HB >= 2) { if (i + 1 >= n_hblocks) break; iteration(std::integral_constant<int, HB >= 2 ? 1 : 0>{}, i + 1); }
     if (HB >= 3) { if (i + 2 >= n_hblocks) break; iteration(std::integral_constant<int, HB >= 3 ? 2 : 0>{}, i + 2); }
   }
+#if FDH_TIMING
+  if (lane == 0) {
+    const size_t w_id = (size_t)blockIdx.x * kFxWaves + wave;
+    if (w_id < 32768) {
+      unsigned long long* row = g_wave_times + 16 * w_id;
+      row[0] = FDH_NOW() - T0; row[1] = T_pro; row[2] = T_wait; row[3] = T_h; row[4] = T_v; row[5] = T_epi; row[6] = 7; row[7] = T_st; row[8] = n_hblocks; row[9] = T0; row[10] = n_blocks; row[11] = T_cv; row[12] = T_dma;
+    }
+  }
+#endif
 }
 
 // ------------------------------------------------------------------ glyph images on their way into the atlas

@@ -1377,6 +1377,42 @@ void Context::debug_verify_upload(uint32_t out[24]) {
   }
 }
 
+// Fault hunting (fdh_debug_bin_digest): what the bin kernel left for the frame last submitted -- per phase and bin the count and the
+// list entries it covers.  out[0] = FNV-1a over them, out[1] = sum of the counts, out[2] = bins with count 0, out[3] = list entries
+// whose first word is 0, out[4] = bins whose count exceeds the list stride (garbage).
+void Context::debug_bin_digest(uint64_t out[8]) {
+  need_device("debug_bin_digest");
+  drain();
+  FDH_HIP(hipSetDevice(device_));
+  FDH_HIP(hipStreamSynchronize(stream_));
+  for (int i = 0; i < 8; i++) out[i] = 0;
+  const LaunchJob& J = job_;
+  const size_t nb = (size_t)J.bins_x * J.bins_y, np = J.phases.size(), stride = (size_t)J.list_stride;
+  if (!nb || !np || !J.counts || !J.lists) return;
+  std::vector<uint32_t> counts(np * nb);
+  std::vector<uint2> lists(np * nb * stride);
+  FDH_HIP(hipMemcpy(counts.data(), J.counts, counts.size() * 4, hipMemcpyDeviceToHost));
+  FDH_HIP(hipMemcpy(lists.data(), J.lists, lists.size() * sizeof(uint2), hipMemcpyDeviceToHost));
+  uint64_t h = 1469598103934665603ull;
+  auto mix = [&](uint32_t v) { for (int k = 0; k < 4; k++) { h ^= (v >> (8 * k)) & 255u; h *= 1099511628211ull; } };
+  for (size_t p = 0; p < np; p++) {
+    const Phase& ph = J.phases[p];
+    const bool whole = p == 0;
+    for (int by = 0; by < J.bins_y; by++)
+      for (int bx = 0; bx < J.bins_x; bx++) {
+        if (!whole && (bx < ph.bin_x0 || bx >= ph.bin_x1 || by < ph.bin_y0 || by >= ph.bin_y1)) continue;  // (bins the phase's launches never look at)
+        const size_t b = p * nb + (size_t)by * J.bins_x + bx;
+        const uint32_t c = counts[b];
+        mix(c);
+        out[1] += c;
+        if (c == 0) out[2]++;
+        if (c > stride) { out[4]++; continue; }
+        for (uint32_t e = 0; e < c; e++) { const uint2 v = lists[b * stride + e]; mix(v.x); mix(v.y); if (v.x == 0) out[3]++; }
+      }
+  }
+  out[0] = h;
+}
+
 // A retained root's cached records take their place in lane 0 (fdh_scene_render): a memcpy per array, the extension indices
 // moved to where the extensions landed, the list-stride count and the phase summary brought up to date.
 void Context::splice_cached(const RetainedRoot& C) {

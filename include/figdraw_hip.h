@@ -321,6 +321,10 @@ FDH_API int fdh_debug_record_digest(FdhContext*, uint64_t* out);
  * first offset, device dword, host dword, bytes compared), out[17..20] = derived bin boxes (differing, first index, device, host).
  * No counterpart in the reference. */
 FDH_API int fdh_debug_verify_upload(FdhContext*, uint32_t out[24]);
+/* Fault hunting: what the bin kernel left on the device for the frame last submitted.  out[0] = a hash of every (phase, bin) count and
+ * the list entries it covers, out[1] = sum of the counts, out[2] = bins with count 0, out[3] = entries whose first word is 0,
+ * out[4] = bins whose count exceeds the list stride.  No counterpart in the reference. */
+FDH_API int fdh_debug_bin_digest(FdhContext*, uint64_t out[8]);
 
 /* ------------------------------------------------------------------ multi-GPU / measurement hooks (no reference counterpart) */
 /* Restrict rasterisation to rows [y0, y1) of the frame (row-stripe sharding); blur halos are rendered redundantly so

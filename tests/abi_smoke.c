@@ -152,6 +152,7 @@ int main(int argc, char** argv) {
   CHECK(json != NULL && strstr(json, "[\"translate\",5,-4]") != NULL);
   OK(fdh_debug_record_digest(c, &d_frame)); CHECK(d_frame != 0);
   { uint32_t vu[24]; CHECK(fdh_debug_verify_upload(c, vu) == FDH_ERR_NO_DEVICE); } /* (a recorder holds no device block) */
+  { uint64_t bd[8]; CHECK(fdh_debug_bin_digest(c, bd) == FDH_ERR_NO_DEVICE); }
 
   /* whole scenes and retained scenes */
   {

@@ -379,14 +379,19 @@ SWIFTSHADER_SCENES = {
 # Goldens whose tests COUNT the pixels beyond the bar instead of bounding every pixel, because the reference's shaders on SwiftShader
 # and a float evaluation legitimately differ at isolated pixels there: (name: builder, width, height, pixels allowed beyond the bar)
 #   rotated_tree: pixel centres lying EXACTLY on an outer edge of a rotated quad (integer vertices: a slope-5/9 edge passes through a
-#     centre every 9 pixels).  GL leaves the fill rule to the implementation as long as shared edges are watertight; the oracle and
-#     the kernels use the top-left rule on exact integer edge functions, SwiftShader does not draw those centres.  All 26 pixels
-#     that differ by more than 1 LSB at generation time lie at distance 0.000 - 0.004 px from such an edge (manifest.json).
+#     centre every 9 pixels).  Not a fill-rule difference -- tools/debug/tie_rule_probe.py: SwiftShader draws the ties of left edges
+#     and only those (96 of 96 over every edge class and mirror image), the top-left rule the oracle and the kernels apply on exact
+#     integer edge functions; y orientation cannot matter, a y flip keeps left edges left.  But the SAME quad -- (238, 478), (553, 653),
+#     (669, 443), (355, 268), the one that owns 25 of the 26 -- loses ALL its tie pixels in frames of 900 x 600, 900 x 640, 800 x 600
+#     and keeps ALL of them at 900 x 700 and 900 x 601: its vertices reach the rasteriser through the float32 projection and viewport
+#     transform, come back off the integers in the last bits, and the 1/256-px snap keeps the residue (the 26 centres lie 0.000 -
+#     0.004 px from the edge, manifest.json).  Which side they fall is a property of (W, H) and of the implementation's arithmetic;
+#     no rule reproduces it and another conformant rasteriser need not agree.  Counted: 26 measured, 28 allowed.
 #   curves: sdBezier's closed-form cubic cancels catastrophically at isolated pixels ("Rotated quads and
 #     curves"): two conformant evaluations of it differ there by anything.
 OUTLIER_SCENES = {
-    "rotated_tree": (rotated_tree, 900, 600, 40),
-    "curves": (curves, 640, 420, 8),
+    "rotated_tree": (rotated_tree, 900, 600, 28),  # 26 measured (oracle and HIP alike)
+    "curves": (curves, 640, 420, 3),               # 1 measured
 }
 
 

@@ -1,0 +1,27 @@
+#!/usr/bin/env python3
+"""GPU-box helper: per-wave phase times of the fused full-frame blur (k_blur_fx) from an instrumented build
+(make -C figdraw_amd/csrc variant NAME=timing SINGLE=1 DEFS="-DFDH_STATS=1 -DFDH_TIMING=1"; FIGDRAW_HIP_LIB=build/libfigdraw_hip_timing.so)."""
+import ctypes as C, os, sys
+import numpy as np
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from figdraw_amd import context as ctx_mod
+from figdraw_amd.scenes import make_render_tree_100
+w, h = 3840, 2160
+ctx = ctx_mod.HipContext(device=0); L = ctx_mod.load()
+ctx.render_frame(make_render_tree_100(w, h, frame=0, full_frame_blur=True), w, h); ctx.sync()
+wt = np.zeros((65536, 16), dtype=np.uint64)
+L.fdh_debug_wave_times(wt.ctypes.data_as(C.c_void_p))  # (reading clears the rows)
+ctx.replay(1); ctx.sync()
+L.fdh_debug_wave_times(wt.ctypes.data_as(C.c_void_p))  # exactly one frame
+sel = np.nonzero(wt[:, 6] == 7)[0]
+r = wt[sel].astype(np.float64)
+tick = 1.0 / 2.1  # shader cycles at ~2.1 GHz -> ns
+nb = r[:, 8]
+print(f"k_blur_fx: {len(r)} waves, {nb.mean():.1f} H-blocks each; per wave (ns): total {r[:,0].mean()*tick:.0f} (p10 {np.percentile(r[:,0],10)*tick:.0f}, p90 {np.percentile(r[:,0],90)*tick:.0f}, "
+      f"max {r[:,0].max()*tick:.0f}) prologue {r[:,1].mean()*tick:.0f}; per H-block: wait {(r[:,2]/nb).mean()*tick:.0f} h-product {(r[:,3]/nb).mean()*tick:.0f} "
+      f"[dma issue {(r[:,12]/nb).mean()*tick:.0f} + rounding {(r[:,11]/nb).mean()*tick:.0f} + v-product =] {(r[:,4]/nb).mean()*tick:.0f} epilogue {(r[:,5]/nb).mean()*tick:.0f} dma-late+stores {(r[:,7]/nb).mean()*tick:.0f}")
+for x in range(0):
+    q = wt[sel[((sel // 4) % 8) == x]].astype(np.float64)
+    if len(q):
+        print(f"  XCD {x}: {len(q)} waves, kernel span {((q[:,9]+q[:,0]).max()-q[:,9].min())*tick/1000:.1f} us, start spread {(q[:,9].max()-q[:,9].min())*tick/1000:.1f} us, "
+              f"mean life {q[:,0].mean()*tick/1000:.1f} us, max {q[:,0].max()*tick/1000:.1f} us")

@@ -39,19 +39,28 @@ def work(t):
                     if not np.array_equal(got, want[i]):
                         d = (got != want[i]).any(axis=2)
                         ys, xs = np.nonzero(d)
+                        wrong = got[d]
+                        vals, cnts = np.unique(wrong.view(np.uint32).ravel(), return_counts=True)
+                        top = sorted(zip(cnts.tolist(), [hex(v) for v in vals.tolist()]), reverse=True)[:4]
+                        ys_, xs_ = np.nonzero(d)
+                        runs = f"wrong values (count, RGBA as 0xAABBGGRR): {top}; wrong pixels per 64-px bin row {np.bincount(ys_ // 64).tolist()}"
                         try:
                             vu = ctx.verify_upload()
                         except Exception as e:  # noqa: BLE001
                             vu = repr(e)
                         try:  # the same GPU work again from the records the device holds, then the whole frame again
+                            bd0 = ctx.bin_digest()
                             ctx.replay(1)
+                            ctx.sync()
+                            bd1 = ctx.bin_digest()
+                            vu = f"{vu} bins as left {bd0} after the replay {bd1}"
                             ctx.sync()
                             again = int((ctx.read_pixels() != want[i]).any(axis=2).sum())
                             ctx.render_frame(sc, w, h)
                             anew = int((ctx.read_pixels() != want[i]).any(axis=2).sum())
                         except Exception as e:  # noqa: BLE001
                             again = anew = repr(e)
-                        bad.append((t, it, i, k, f"upload check {vu}", f"replayed: {again} px wrong, rendered again: {anew} px wrong", f"{int(d.sum())} px, rows {ys.min()}..{ys.max()}, cols {xs.min()}..{xs.max()}, max {int(np.abs(got.astype(int) - want[i].astype(int)).max())}, sync_submit {(it + t) % 3 == 0}"))
+                        bad.append((t, it, i, k, runs, f"upload check {vu}", f"replayed: {again} px wrong, rendered again: {anew} px wrong", f"{int(d.sum())} px, rows {ys.min()}..{ys.max()}, cols {xs.min()}..{xs.max()}, max {int(np.abs(got.astype(int) - want[i].astype(int)).max())}, sync_submit {(it + t) % 3 == 0}"))
             ctx.close()
     except Exception as e:  # noqa: BLE001
         bad.append((t, "exception", repr(e)))
