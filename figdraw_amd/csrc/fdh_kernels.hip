@@ -3269,30 +3269,54 @@ __global__ __launch_bounds__(64 * kFxWaves, 2) void k_blur_fx(BlurParams P, cons
 #pragma unroll
       for (int e = 0; e < 16; e++) acc[c][e] = 0.0f;
     {
-      // (texels and weight fragments one k-step ahead of the MFMAs that use them, a scheduling fence per k-step: see phase())
+      // A software pipeline two k-steps deep, its order pinned with scheduling groups.  Left to the scheduler (round 5, first form:
+      // loads one k-step ahead in the source, a fence per k-step) the LDS reads of k-step m + 1 sat behind all but the last one or
+      // two MFMAs of k-step m and their v_perm straight behind the last: the wave waited out the LDS latency and the sixteen
+      // v_perm five times per block with its matrix pipe idle -- 1.04 us per product against 0.5 for the vertical one, which has
+      // no operands to build (tools/fx_wave_times.py).  Now, per k-step m: the LDS reads of k-step m + 2 FIRST, then four MFMAs,
+      // the sixteen v_perm of k-step m + 1 (its texels were asked for a whole k-step ago), four MFMAs.
       const int sw = (j >> 2) & 3;
-      const uint4* row4 = reinterpret_cast<const uint4*>(src_ring + j * 16);
-      uint4 lo4 = row4[(2 * g) ^ sw], hi4 = row4[(2 * g + 1) ^ sw];
-      uint4 va = hw[lane], vb = hw[64 + lane];
+      auto texels = [&](int m, uint4& lo4, uint4& hi4) __attribute__((always_inline)) {
+        const uint4* rowq = reinterpret_cast<const uint4*>(src_ring + m * kMxSlot + j * 16);
+        lo4 = rowq[(2 * g) ^ sw]; hi4 = rowq[(2 * g + 1) ^ sw];
+      };
+      uint4 tl[3], th[3], wa[2], wb[2];  // raw texels of k-steps m, m + 1, m + 2 (rotating); weight fragments of k-steps m, m + 1
+      h8 fr[2][4];                       // operand halves of k-steps m, m + 1
+      texels(0, tl[0], th[0]);
+      wa[0] = hw[lane]; wb[0] = hw[64 + lane];
+      if (NKH > 1) { texels(1, tl[1], th[1]); wa[1] = hw[2 * 64 + lane]; wb[1] = hw[3 * 64 + lane]; }
+      {
+        const uint32_t t8[8] = {tl[0].x, tl[0].y, tl[0].z, tl[0].w, th[0].x, th[0].y, th[0].z, th[0].w};
+        fr[0][0] = mx_frag<0>(t8); fr[0][1] = mx_frag<1>(t8); fr[0][2] = mx_frag<2>(t8); fr[0][3] = mx_frag<3>(t8);
+      }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int m = 0; m < NKH; m++) {
-        const uint32_t t8[8] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
+        const int cur = m & 1, nxt = cur ^ 1;
         H8Bits whi, wlo;
-        whi.u[0] = va.x; whi.u[1] = va.y; whi.u[2] = va.z; whi.u[3] = va.w; wlo.u[0] = vb.x; wlo.u[1] = vb.y; wlo.u[2] = vb.z; wlo.u[3] = vb.w;
+        whi.u[0] = wa[cur].x; whi.u[1] = wa[cur].y; whi.u[2] = wa[cur].z; whi.u[3] = wa[cur].w;
+        wlo.u[0] = wb[cur].x; wlo.u[1] = wb[cur].y; wlo.u[2] = wb[cur].z; wlo.u[3] = wb[cur].w;
+        if (m + 2 < NKH) texels(m + 2, tl[(m + 2) % 3], th[(m + 2) % 3]);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[cur][0], whi.v, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[cur][1], whi.v, acc[1], 0, 0, 0);
+        acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[cur][2], whi.v, acc[2], 0, 0, 0);
+        acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[cur][3], whi.v, acc[3], 0, 0, 0);
         if (m + 1 < NKH) {
-          const uint4* nx = reinterpret_cast<const uint4*>(src_ring + (m + 1) * kMxSlot + j * 16);
-          lo4 = nx[(2 * g) ^ sw]; hi4 = nx[(2 * g + 1) ^ sw];
-          va = hw[(2 * m + 2) * 64 + lane]; vb = hw[(2 * m + 3) * 64 + lane];
+          const uint4 &a4 = tl[(m + 1) % 3], &b4 = th[(m + 1) % 3];
+          const uint32_t t8[8] = {a4.x, a4.y, a4.z, a4.w, b4.x, b4.y, b4.z, b4.w};
+          fr[nxt][0] = mx_frag<0>(t8); fr[nxt][1] = mx_frag<1>(t8); fr[nxt][2] = mx_frag<2>(t8); fr[nxt][3] = mx_frag<3>(t8);
         }
-        const h8 f0 = mx_frag<0>(t8), f1 = mx_frag<1>(t8), f2_ = mx_frag<2>(t8), f3 = mx_frag<3>(t8);
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f0, whi.v, acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f1, whi.v, acc[1], 0, 0, 0);
-        acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f2_, whi.v, acc[2], 0, 0, 0);
-        acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f3, whi.v, acc[3], 0, 0, 0);
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f0, wlo.v, acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f1, wlo.v, acc[1], 0, 0, 0);
-        acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f2_, wlo.v, acc[2], 0, 0, 0);
-        acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f3, wlo.v, acc[3], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[cur][0], wlo.v, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[cur][1], wlo.v, acc[1], 0, 0, 0);
+        acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[cur][2], wlo.v, acc[2], 0, 0, 0);
+        acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[cur][3], wlo.v, acc[3], 0, 0, 0);
+        if (m + 2 < NKH) { wa[cur] = hw[(2 * m + 4) * 64 + lane]; wb[cur] = hw[(2 * m + 5) * 64 + lane]; }  // (this k-step's weights are in the MFMAs' hands)
+        // the order above, made binding: DS reads (texels m + 2) | 4 MFMA | 16 VALU | 4 MFMA | DS reads (weights m + 2)
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 16, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
