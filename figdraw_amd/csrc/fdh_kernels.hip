@@ -2974,15 +2974,17 @@ __global__ __launch_bounds__(64 * mx_wg(NK, kV), FDH_MX_WAVES) void k_blur_mx(Bl
         for (int rr = 0; rr < 16; rr++) (rr < 8 ? sc0 : sc1)[(rr & 7) * 64 + lane] = __float_as_uint(((valid >> rr) & 1u) ? 1.0f : -1.0f);
         __builtin_amdgcn_wave_barrier();
         const DrawRec r = load_rec(draws + P.fuse_draw);
-        const int ra = min(max(core_y0 - by, 0), 32), rb = max(ra, min(max(core_y1 - by, 0), 32));  // rows [ra, rb) lie in the core's rows
-        const int ca = min(max(core_x0 - bx, 0), 32), cb = max(ca, min(max(core_x1 - bx, 0), 32));
-        const int nr = ra + 32 - rb, nc = ca + 32 - cb;
+        // (rows / columns of the block inside the region, [ry0, ry1) x [rx0, rx1), less the core's [ra, rb) x [ca, cb): see k_blur_fx)
+        const int ry0 = min(max(P.y0 - by, 0), 32), ry1 = max(ry0, min(P.y1 - by, 32)), rx0 = min(max(P.x0 - bx, 0), 32), rx1 = max(rx0, min(P.x1 - bx, 32));
+        const int ra = min(max(core_y0 - by, ry0), ry1), rb = max(ra, min(max(core_y1 - by, ry0), ry1));
+        const int ca = min(max(core_x0 - bx, rx0), rx1), cb = max(ca, min(max(core_x1 - bx, rx0), rx1));
+        const int nra = ra - ry0, nca = ca - rx0, nr = nra + ry1 - rb, nc = nca + rx1 - cb;
 #pragma unroll 1
         for (int u0 = 0; u0 < nr + nc; u0 += 2) {
           const int u = u0 + g;
           int dx, dy;
-          if (u < nr) { dy = u < ra ? u : rb + (u - ra); dx = j; }
-          else { const int v = u - nr; dx = v < ca ? v : cb + (v - ca); dy = j; }
+          if (u < nr) { dy = u < nra ? ry0 + u : rb + (u - nra); dx = j; }
+          else { const int v = u - nr; dx = v < nca ? rx0 + v : cb + (v - nca); dy = j; }
           if (u >= nr + nc) continue;
           const int ex = bx + dx, ey = by + dy;
           float alpha = -1.0f;
@@ -3094,41 +3096,49 @@ constexpr int fx_vblocks(int nkv) { return ((nkv - 1) >> 1) + 1; }              
 // wave of a SIMD multiplies while the other rounds, packs and stores: built and measured in round 5, 36.6 - 40.2 us against 33.1: every
 // segment then lasts as long as the slowest of EIGHT waves' memory waits.  Not kept.)
 constexpr int kFxWaves = 4;
-constexpr int fx_slots(int nkh, int nkv) { return nkh + nkv + kFxWaves * nkh; }  // 2-KB LDS slots per WORKGROUP: both weight tables + every wave's source k-steps
+constexpr int fx_wg_ksteps(int nkh) { return nkh + 2 * (kFxWaves - 1); }  // k-steps of the window the workgroup's kFxWaves strips share: 32 columns = 2 k-steps per strip
+// 2-KB LDS slots per WORKGROUP: both weight tables + the shared source window of one H-block row, twice (block i is read while block i + 1 lands)
+constexpr int fx_slots(int nkh, int nkv) { return nkh + nkv + 2 * fx_wg_ksteps(nkh); }
 constexpr float kMxMagic = 12582912.0f;  // 1.5 * 2^23: x + this, as f32, is round-to-nearest-even(x) in the low mantissa bits (|x| < 2^22)
 template <int NKH, int NKV>
 __global__ __launch_bounds__(64 * kFxWaves, 2) void k_blur_fx(BlurParams P, const uint4* __restrict__ w_v, const DrawRec* __restrict__ draws, const QuadExt* __restrict__ exts, int T) {
-  constexpr int HB = fx_vblocks(NKV);  // V block b reads H-blocks b .. b + HB - 1
+  constexpr int HB = fx_vblocks(NKV);      // V block b reads H-blocks b .. b + HB - 1
+  constexpr int NKW = fx_wg_ksteps(NKH);   // k-steps of the workgroup's shared source window
   extern __shared__ __attribute__((aligned(16))) uint32_t ring[];
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const uint4* const hw = reinterpret_cast<const uint4*>(ring);                   // [2 NKH fragments][64 lanes] x 16 bytes
   const uint4* const vw = reinterpret_cast<const uint4*>(ring + NKH * kMxSlot);  // [2 NKV fragments][64 lanes] x 16 bytes
-  uint32_t* const src_ring = ring + (NKH + NKV + wave * NKH) * kMxSlot;          // this wave's NKH slots: [32 rows][16 px], 16-byte pieces XOR-swizzled (as the H pass)
-  const int n_strips = (P.x1 - (P.x0 & ~31) + 31) >> 5;
+  // The source window.  The workgroup's kFxWaves strips are x-neighbours: their horizontal windows overlap by all but two k-steps,
+  // so ONE window of NKW = NKH + 2 (kFxWaves - 1) k-steps serves them all -- wave w reads k-steps 2 w .. 2 w + NKH - 1 of it -- and
+  // each wave fetches a quarter of it: 5.5 LDS-DMA pieces per wave and block at radius 18 instead of 10.  (An LDS-DMA piece holds its
+  // wave for 100 - 270 cycles until the memory pipeline has taken it, and a CU's pieces go through at about one per 100 cycles:
+  // tools/fx_wave_times.py, MI355X_MICROARCH.md "ldsdma-fill" -- at ten pieces per wave and block the FILL was what a block cost.)
+  // Two copies: block i is multiplied out of one while block i + 1 lands in the other, one s_barrier per block.
+  // Slot image [32 rows][16 px], 16-byte pieces XOR-swizzled (as the H pass).
+  uint32_t* const src_base = ring + (NKH + NKV) * kMxSlot;
+  const int n_strips = (P.x1 - (P.x0 & ~31) + 31) >> 5, n_sg = (n_strips + kFxWaves - 1) / kFxWaves;
   const int y_first = P.y0 & ~31;
   const int n_seg = (P.y1 - y_first + 32 * T - 1) / (32 * T);
-  const int total = n_strips * n_seg, per = (total + 7) >> 3, q = (int)(blockIdx.x >> 3) * kFxWaves + wave, item = (blockIdx.x & 7) * per + q;
-  const bool active = q < per && item < total;  // every XCD takes a contiguous eighth of the row-major sequence: a band of the frame
-  const int seg = active ? item / n_strips : 0, strip = active ? item - seg * n_strips : 0;
+  const int total = n_sg * n_seg, per = (total + 7) >> 3, q = (int)(blockIdx.x >> 3), item = (blockIdx.x & 7) * per + q;
+  if (q >= per || item >= total) return;  // (the whole workgroup) every XCD takes a contiguous eighth of the row-major sequence: a band of the frame
+  const int seg = item / n_sg, sg = item - seg * n_sg;
+  const int strip = kFxWaves * sg + wave;
+  const bool active = strip < n_strips;   // a wave past the region's last strip still fetches its share of the window and meets the barriers
   const int lane = threadIdx.x & 63, g = lane >> 5, j = lane & 31;
   const int reach = P.taps.reach;
   const int xb = (P.x0 & ~31) + 32 * strip;  // the strip's columns
   const int ys = y_first + 32 * T * seg;      // first output row of the segment
   const int n_blocks = min(T, (P.y1 - ys + 31) >> 5);
   const int ws = ys - reach;                  // first row of H-block 0
-  const int w0a = (xb - reach) & ~3;          // horizontal window start, moved back to a 16-byte boundary (mx_delta)
+  const int w0a = ((P.x0 & ~31) + 32 * kFxWaves * sg - reach) & ~3;  // the shared window's start, moved back to a 16-byte boundary (mx_delta); strip w's own window starts 32 w further on
   const uint32_t ring_lds = (uint32_t)reinterpret_cast<uintptr_t>(ring);
-  const uint32_t src_lds = ring_lds + (uint32_t)((NKH + NKV + wave * NKH) * kMxSlot * 4);
+  const uint32_t src_lds = ring_lds + (uint32_t)((NKH + NKV) * kMxSlot * 4);
 
-  // LDS-DMA of the NKH source k-steps of H-block i into the source slots (single-buffered: issued as soon as the horizontal
-  // product of block i - 1 has read them, in flight under the vertical product and the stores).  (Spread through the vertical
-  // product instead -- one k-step's two pieces behind each of its k-steps' MFMAs -- the batch's ~1.1 us of issue time per block,
-  // tools/fx_wave_times.py, only moved into the products: 35.9 us against 34.7.  Not kept.)
-  const uint32_t* dma_row[2] = {nullptr, nullptr};
-  int dma_block = 0;
-  auto issue_rows = [&](int i) __attribute__((always_inline)) {
+  // This wave's share of H-block row i's window: k-steps wave, wave + kFxWaves, .. into copy i & 1.  Returns nothing: the wait at the
+  // top of the next block allows exactly the stores issued behind it (vmcnt retires in order).
+  auto issue_block = [&](int i) __attribute__((always_inline)) {
     const int r = lane >> 2, c = lane & 3;
-    dma_block = i;
+    const uint32_t* dma_row[2];
 #pragma unroll
     for (int h = 0; h < 2; h++) {
       const int row = 16 * h + r;
@@ -3136,33 +3146,32 @@ __global__ __launch_bounds__(64 * kFxWaves, 2) void k_blur_fx(BlurParams P, cons
       y = y < 0 ? 0 : (y > P.H - 1 ? P.H - 1 : y);  // clamp-to-edge (glcontext.nim:214-215): a clamped row filters to a clamped H row
       dma_row[h] = P.src + (size_t)y * P.pitch + 4 * (c ^ ((row >> 2) & 3));
     }
-  };
-  auto issue_kstep = [&](int s) __attribute__((always_inline)) {
-    const uint32_t slot = src_lds + (uint32_t)s * (kMxSlot * 4u);
-    const int xk = w0a + 16 * s;
-    if (xk >= 0 && xk + 16 <= P.W) {  // wave-uniform
-      lds_dma16(dma_row[0] + xk, slot);
-      lds_dma16(dma_row[1] + xk, slot + 1024u);
-    } else {  // the k-step crosses a frame edge: one texel per lane, clamped (a rolled loop: this code exists many times)
-      const int rr = lane >> 4, pp = lane & 15;
+    const uint32_t copy = src_lds + (uint32_t)((i & 1) * NKW) * (kMxSlot * 4u);
+#pragma unroll
+    for (int s0 = 0; s0 < NKW; s0 += kFxWaves) {
+      const int s = s0 + wave;
+      if (s >= NKW) break;
+      const uint32_t slot = copy + (uint32_t)s * (kMxSlot * 4u);
+      const int xk = w0a + 16 * s;
+      if (xk >= 0 && xk + 16 <= P.W) {  // wave-uniform
+        lds_dma16(dma_row[0] + xk, slot);
+        lds_dma16(dma_row[1] + xk, slot + 1024u);
+      } else {  // the k-step crosses a frame edge: one texel per lane, clamped (a rolled loop: this code exists several times)
+        const int rr = lane >> 4, pp = lane & 15;
 #pragma unroll 1
-      for (int e = 0; e < 8; e++) {
-        const int row = 4 * e + rr;
-        int y = ws + 32 * dma_block + row;
-        y = y < 0 ? 0 : (y > P.H - 1 ? P.H - 1 : y);
-        int gx = xk + 4 * ((pp >> 2) ^ ((row >> 2) & 3)) + (pp & 3);
-        gx = gx < 0 ? 0 : (gx > P.W - 1 ? P.W - 1 : gx);
-        lds_dma4(P.src + (size_t)y * P.pitch + gx, slot + e * 256u);
+        for (int e = 0; e < 8; e++) {
+          const int row = 4 * e + rr;
+          int y = ws + 32 * i + row;
+          y = y < 0 ? 0 : (y > P.H - 1 ? P.H - 1 : y);
+          int gx = xk + 4 * ((pp >> 2) ^ ((row >> 2) & 3)) + (pp & 3);
+          gx = gx < 0 ? 0 : (gx > P.W - 1 ? P.W - 1 : gx);
+          lds_dma4(P.src + (size_t)y * P.pitch + gx, slot + e * 256u);
+        }
       }
     }
   };
-  auto issue_block = [&](int i) __attribute__((always_inline)) {
-    issue_rows(i);
-#pragma unroll
-    for (int s = 0; s < NKH; s++) issue_kstep(s);
-  };
   auto wait_for_all_but = [&](int n) __attribute__((always_inline)) {
-    if (n >= 48) wait_vm<48>(); else if (n >= 24) wait_vm<24>(); else if (n >= 16) wait_vm<16>(); else if (n >= 12) wait_vm<12>(); else if (n >= 10) wait_vm<10>(); else if (n >= 8) wait_vm<8>(); else if (n >= 6) wait_vm<6>(); else wait_vm<0>();
+    if (n >= 16) wait_vm<16>(); else wait_vm<0>();
     __builtin_amdgcn_sched_barrier(0);
   };
 
@@ -3170,7 +3179,7 @@ __global__ __launch_bounds__(64 * kFxWaves, 2) void k_blur_fx(BlurParams P, cons
   const unsigned long long T0 = FDH_NOW();
   unsigned long long T_wait = 0, T_h = 0, T_v = 0, T_epi = 0, T_st = 0, T_cv = 0, T_cv_mark = 0, T_dma = 0;
 #endif
-  if (active) issue_block(0);
+  issue_block(0);
   // the weight fragments of both products go to LDS as they lie in memory (lane-linear 16-byte pieces: exactly what the DMA
   // writes), every wave of the workgroup fetching its share -- the one point at which the waves meet
   {
@@ -3181,9 +3190,7 @@ __global__ __launch_bounds__(64 * kFxWaves, 2) void k_blur_fx(BlurParams P, cons
       if (f < NF) lds_dma16((f < 2 * NKH ? P.mx_w + f * 64 : w_v + (f - 2 * NKH) * 64) + lane, ring_lds + (uint32_t)f * 1024u);
     }
   }
-  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
-  __syncthreads();
-  if (!active) return;
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's pieces of block 0 and its weight fragments have landed ...
 #if FDH_TIMING
   const unsigned long long T_pro = FDH_NOW() - T0;
 #endif
@@ -3258,8 +3265,14 @@ __global__ __launch_bounds__(64 * kFxWaves, 2) void k_blur_fx(BlurParams P, cons
 #if FDH_TIMING
     const unsigned long long Ta = FDH_NOW();
 #endif
-    wait_for_all_but(stores_behind);
+    wait_for_all_but(stores_behind);  // this wave's pieces of block row i have landed (the stores issued behind them may stay out) ...
     stores_behind = 0;
+    __builtin_amdgcn_s_barrier();       // ... and so have the other waves'; every wave has also finished reading block row i - 1's copy,
+    __builtin_amdgcn_sched_barrier(0);  // into which the next row's pieces go now: they have a whole block's time to land
+    if (i + 1 < n_hblocks) issue_block(i + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (!active) return;
+    const uint32_t* const src_ring = src_base + ((i & 1) * NKW + 2 * wave) * kMxSlot;  // this strip's NKH k-steps of the window
 #if FDH_TIMING
     const unsigned long long Tb = FDH_NOW();
 #endif
@@ -3326,15 +3339,7 @@ __global__ __launch_bounds__(64 * kFxWaves, 2) void k_blur_fx(BlurParams P, cons
 #endif
     const int b = i - (HB - 1);  // the V block whose last H-block this is
     const int bx = xb, by = ys + 32 * b;
-    // A block on the consuming quad's border moves its alphas through the first two source slots (below): the next H-block's
-    // texels must not be on their way into them yet -- for those few blocks the DMA is issued behind the composite instead
-    const bool fuse = P.fuse_draw >= 0;
     const bool core = bx >= core_x0 && bx + 32 <= core_x1 && by >= core_y0 && by + 32 <= core_y1;  // coverage alpha == 1 (wave-uniform)
-    const bool dma_late = b >= 0 && fuse && !core;
-    // the source slots are read (every MFMA above has its operands): the next H-block's texels start their way in, under the
-    // rounding below and the whole vertical product
-    __builtin_amdgcn_sched_barrier(0);
-    if (!dma_late && i + 1 < n_hblocks) issue_block(i + 1);
     __builtin_amdgcn_sched_barrier(0);
 #if FDH_TIMING
     const unsigned long long Tc2 = FDH_NOW();
@@ -3372,47 +3377,60 @@ __global__ __launch_bounds__(64 * kFxWaves, 2) void k_blur_fx(BlurParams P, cons
         replace_all = __all((conj >> 24) == 255u);
       }
       if (!replace_all) {
-        // (the first two source slots: read by the horizontal product above, and -- dma_late -- nothing is in flight into them)
-        uint32_t* const sc0 = src_ring;
-        uint32_t* const sc1 = src_ring + kMxSlot;
+        // `al16[rr]`: the quad's coverage at this lane's pixel of row rr.  A block on the quad's border (a few hundred of 8100 at 4K):
+        // its rows and columns inside the core have alpha == 1; the others are evaluated densely -- one row (lane = x) or one column
+        // (lane = y) per lane group and step, as in k_blur_mx -- and each lane then FETCHES the alphas of its own sixteen pixels
+        // from the lanes that evaluated them (ds_bpermute: the LDS crossbar, no LDS memory; rounds 3 - 4 went through two idle ring
+        // slots, which the shared source window no longer has).
         const uint32_t valid = pmask;
-        if (!core) {
+        float al16[16];
 #pragma unroll
-          for (int rr = 0; rr < 16; rr++) (rr < 8 ? sc0 : sc1)[(rr & 7) * 64 + lane] = __float_as_uint(((valid >> rr) & 1u) ? 1.0f : -1.0f);
-          __builtin_amdgcn_wave_barrier();
+        for (int rr = 0; rr < 16; rr++) al16[rr] = 1.0f;
+        if (!core) {
           const DrawRec r = load_rec(draws + P.fuse_draw);
-          const int ra = min(max(core_y0 - by, 0), 32), rb = max(ra, min(max(core_y1 - by, 0), 32));  // rows [ra, rb) lie in the core's rows
-          const int ca = min(max(core_x0 - bx, 0), 32), cb = max(ca, min(max(core_x1 - bx, 0), 32));
-          const int nr = ra + 32 - rb, nc = ca + 32 - cb;
+          // the block's rows / columns INSIDE THE REGION, [ry0, ry1) x [rx0, rx1), less those in the core's, [ra, rb) x [ca, cb): what is left
+          // above / below (left / right of) the core is evaluated.  (Rounds 3 - 4 evaluated every row of the block outside the core's:
+          // the frame's last block row -- 2160 = 67.5 blocks -- spent seventeen steps on a block with ONE row on the quad's edge and
+          // sixteen below the frame; those waves lived 32 - 35 us against 24, and the kernel lasts as long as its slowest wave.)
+          const int ry0 = min(max(P.y0 - by, 0), 32), ry1 = max(ry0, min(P.y1 - by, 32)), rx0 = min(max(P.x0 - bx, 0), 32), rx1 = max(rx0, min(P.x1 - bx, 32));
+          const int ra = min(max(core_y0 - by, ry0), ry1), rb = max(ra, min(max(core_y1 - by, ry0), ry1));
+          const int ca = min(max(core_x0 - bx, rx0), rx1), cb = max(ca, min(max(core_x1 - bx, rx0), rx1));
+          const int nra = ra - ry0, nca = ca - rx0, nr = nra + ry1 - rb, nc = nca + rx1 - cb;
 #pragma unroll 1
           for (int u0 = 0; u0 < nr + nc; u0 += 2) {
-            const int u = u0 + g;
+            const int u = min(u0 + g, nr + nc - 1);  // (an odd count: the second lane group repeats the last step)
             int dx, dy;
-            if (u < nr) { dy = u < ra ? u : rb + (u - ra); dx = j; }
-            else { const int v = u - nr; dx = v < ca ? v : cb + (v - ca); dy = j; }
-            if (u >= nr + nc) continue;
+            if (u < nr) { dy = u < nra ? ry0 + u : rb + (u - nra); dx = j; }
+            else { const int v = u - nr; dx = v < nca ? rx0 + v : cb + (v - nca); dy = j; }
             const int ex = bx + dx, ey = by + dy;
-            float alpha = -1.0f;
+            float alpha = 0.0f;  // (outside the quad the live texel stays: a blend with alpha 0; outside the region nothing is stored)
             if (ex >= P.x0 && ex < P.x1 && ey >= P.y0 && ey < P.y1) {
               const Frag f = make_frag(r, exts, ex, ey);
-              alpha = 0.0f;  // (outside the quad the live texel stays: a blend with alpha 0)
               if (f.covered) {
                 const float lx = (f.u - 0.5f) * 2.0f * r.p0, ly = (f.v - 0.5f) * 2.0f * r.p1;
                 const float dist = shape_dist((r.op_mode & F_ELLIP) != 0u, lx, -ly, r.p2, r.p3, r.r[0], r.r[1], r.r[2], r.r[3]);
                 alpha = 1.0f - clamp01(r.aa * dist + 0.5f);
               }
             }
-            const int er = (dy & 3) + 4 * (dy >> 3), el = dx + 32 * ((dy >> 2) & 1);  // accumulator register and lane of (dx, dy)
-            (er < 8 ? sc0 : sc1)[(er & 7) * 64 + el] = __float_as_uint(alpha);
+            const int abits = (int)__float_as_uint(alpha);
+#pragma unroll
+            for (int rr = 0; rr < 16; rr++) {
+              const int y = (rr & 3) + 8 * (rr >> 2) + 4 * g;  // this lane's pixel (j, y): which step evaluated it, in which lane?
+              int su = -2, sl = 0;  // (a pixel outside the region is never stored: its alpha stays whatever it is)
+              if (y >= ry0 && y < ry1 && j >= rx0 && j < rx1) {
+                if (y < ra || y >= rb) { su = y < ra ? y - ry0 : nra + (y - rb); sl = j; }
+                else if (j < ca || j >= cb) { su = nr + (j < ca ? j - rx0 : nca + (j - cb)); sl = y; }
+              }
+              const int v = __builtin_amdgcn_ds_bpermute(4 * (sl + 32 * (su & 1)), abits);
+              if ((su & ~1) == u0) al16[rr] = __uint_as_float((uint32_t)v);
+            }
           }
-          __builtin_amdgcn_wave_barrier();
         }
         uint32_t blend_mask = 0;
 #pragma unroll
         for (int rr = 0; rr < 16; rr++) {
           if (!((valid >> rr) & 1u)) continue;
-          const float al = core ? 1.0f : __uint_as_float((rr < 8 ? sc0 : sc1)[(rr & 7) * 64 + lane]);
-          if (al != 1.0f || (pend[rr] >> 24) != 255u) blend_mask |= 1u << rr;
+          if (al16[rr] != 1.0f || (pend[rr] >> 24) != 255u) blend_mask |= 1u << rr;
         }
         if (__any(blend_mask != 0u)) {
           uint32_t dstv[16];
@@ -3423,7 +3441,7 @@ __global__ __launch_bounds__(64 * kFxWaves, 2) void k_blur_fx(BlurParams P, cons
 #pragma unroll
           for (int rr = 0; rr < 16; rr++) {
             if (!((blend_mask >> rr) & 1u)) continue;
-            const float alpha = core ? 1.0f : __uint_as_float((rr < 8 ? sc0 : sc1)[(rr & 7) * 64 + lane]);
+            const float alpha = al16[rr];
             const F4 bl = unpack255(pend[rr]);
             F4 Fd = unpack255(dstv[rr]);
             const float sa = bl.w * k * alpha, A = 255.0f * sa, ia = 1.0f - sa;
@@ -3435,15 +3453,12 @@ __global__ __launch_bounds__(64 * kFxWaves, 2) void k_blur_fx(BlurParams P, cons
           }
           __builtin_amdgcn_s_waitcnt(0x0F70);
         }
-        __builtin_amdgcn_wave_barrier();
       }
     }
 #if FDH_TIMING
     const unsigned long long Te = FDH_NOW() + (__builtin_amdgcn_readfirstlane(pend[0] + pend[15]) & 0u);
     T_epi += Te - Td;
 #endif
-    __builtin_amdgcn_sched_barrier(0);
-    if (dma_late && i + 1 < n_hblocks) issue_block(i + 1);
     __builtin_amdgcn_sched_barrier(0);
     // the block's rows: uniform row pointer + one per-lane byte offset
     {
@@ -3776,13 +3791,13 @@ template <int NKH, int NKV> static void launch_blur_fx(hipStream_t s, const Blur
     return n;
   }();
   static const int forced = [] { const char* e = std::getenv("FDH_FX_T"); return e ? std::atoi(e) : 0; }();  // experiments
-  const int n_strips = (P.x1 - (P.x0 & ~31) + 31) >> 5, blocks = (P.y1 - (P.y0 & ~31) + 31) >> 5;
-  const long long slots = 256LL * std::min(wg_per_cu * kFxWaves, 8);
+  const int n_strips = (P.x1 - (P.x0 & ~31) + 31) >> 5, n_sg = (n_strips + kFxWaves - 1) / kFxWaves, blocks = (P.y1 - (P.y0 & ~31) + 31) >> 5;
+  const long long slots = 256LL * std::min(wg_per_cu, 8 / kFxWaves);  // workgroups resident at once
   int t = 2;  // (a one-block segment would filter three H-blocks per output block)
-  while (t < 64 && (long long)n_strips * ((blocks + t - 1) / t) > slots) t++;
+  while (t < 64 && (long long)n_sg * ((blocks + t - 1) / t) > slots) t++;
   if (forced) t = forced;
-  const int total = n_strips * ((blocks + t - 1) / t), per = (total + 7) / 8;
-  FDH_LAUNCH((k_blur_fx<NKH, NKV>), dim3(8 * ((per + kFxWaves - 1) / kFxWaves)), dim3(64 * kFxWaves), lds, s, P, w_v, draws, exts, t);
+  const int total = n_sg * ((blocks + t - 1) / t), per = (total + 7) / 8;
+  FDH_LAUNCH((k_blur_fx<NKH, NKV>), dim3(8 * per), dim3(64 * kFxWaves), lds, s, P, w_v, draws, exts, t);
 }
 bool blur_fused_supported(int reach, int W, int pitch) {
   const int nkh = mx_nk(reach, false), nkv = mx_nk(reach, true);

@@ -20,8 +20,20 @@ nb = r[:, 8]
 print(f"k_blur_fx: {len(r)} waves, {nb.mean():.1f} H-blocks each; per wave (ns): total {r[:,0].mean()*tick:.0f} (p10 {np.percentile(r[:,0],10)*tick:.0f}, p90 {np.percentile(r[:,0],90)*tick:.0f}, "
       f"max {r[:,0].max()*tick:.0f}) prologue {r[:,1].mean()*tick:.0f}; per H-block: wait {(r[:,2]/nb).mean()*tick:.0f} h-product {(r[:,3]/nb).mean()*tick:.0f} "
       f"[dma issue {(r[:,12]/nb).mean()*tick:.0f} + rounding {(r[:,11]/nb).mean()*tick:.0f} + v-product =] {(r[:,4]/nb).mean()*tick:.0f} epilogue {(r[:,5]/nb).mean()*tick:.0f} dma-late+stores {(r[:,7]/nb).mean()*tick:.0f}")
-for x in range(0):
-    q = wt[sel[((sel // 4) % 8) == x]].astype(np.float64)
-    if len(q):
-        print(f"  XCD {x}: {len(q)} waves, kernel span {((q[:,9]+q[:,0]).max()-q[:,9].min())*tick/1000:.1f} us, start spread {(q[:,9].max()-q[:,9].min())*tick/1000:.1f} us, "
-              f"mean life {q[:,0].mean()*tick/1000:.1f} us, max {q[:,0].max()*tick/1000:.1f} us")
+# which waves live longest: by strip (column position) and by segment (row position) -- the T the launcher chose is what n_hblocks says
+T = int(round(nb.max())) - 2
+n_sg, n_seg = (w // 32 + 3) // 4, (h // 32 + T - 1) // T
+total = n_sg * n_seg
+per = (total + 7) // 8
+wgs = sel // 4
+item = (wgs % 8) * per + wgs // 8
+seg, sg, wv = item // n_sg, item % n_sg, sel % 4
+strip = 4 * sg + wv
+life = r[:, 0] * tick / 1000
+print(f"T = {T}: {n_sg} strip groups x {n_seg} segments")
+print("mean / max life (us) by strip:", " ".join(f"{int(k)}:{life[strip == k].mean():.1f}/{life[strip == k].max():.1f}" for k in np.unique(strip) if k < 6 or k > w // 32 - 7 or k % 16 == 0))
+for k in (1, n_seg - 1):
+    m_ = seg == k
+    print(f"segment {k}: per H-block (ns) wait {(r[m_,2]/nb[m_]).mean()*tick:.0f} h-product {(r[m_,3]/nb[m_]).mean()*tick:.0f} rounding + v-product {(r[m_,4]/nb[m_]).mean()*tick:.0f} "
+          f"epilogue {(r[m_,5]/nb[m_]).mean()*tick:.0f} stores {(r[m_,7]/nb[m_]).mean()*tick:.0f} prologue {r[m_,1].mean()*tick:.0f}; V blocks {r[m_,10].mean():.1f}")
+print("mean / max life (us) by segment:", " ".join(f"{int(k)}:{life[seg == k].mean():.1f}/{life[seg == k].max():.1f}" for k in np.unique(seg)))
