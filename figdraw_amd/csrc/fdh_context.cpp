@@ -27,10 +27,13 @@ void hip_check(hipError_t e, const char* what) {
 // frames of OTHER contexts are in flight
 
 void poison_fresh(void* p, size_t bytes) {
-  static const int v = [] { const char* e = std::getenv("FDH_POISON"); return e ? (int)std::strtol(e, nullptr, 0) & 255 : -1; }();
-  if (v < 0 || !p || !bytes) return;
-  (void)hipMemset(p, v, bytes);
+#if defined(FDH_POISON)  // fault-hunting builds only (make variant DEFS=-DFDH_POISON=0xA5)
+  if (!p || !bytes) return;
+  (void)hipMemset(p, FDH_POISON, bytes);
   (void)hipDeviceSynchronize();
+#else
+  (void)p; (void)bytes;
+#endif
 }
 
 // ------------------------------------------------------------------ lifetime
@@ -147,8 +150,7 @@ Context::Context(int atlas_size, float pixel_scale, int device, uint32_t flags) 
     throw Error(FDH_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library carries gfx950 code only");
   // host writes into device memory through the BAR pass the GPU's host data path, which may hold them: its flush register (mapped
   // for exactly this: HSA_AMD_AGENT_INFO_HDP_FLUSH) is written before the launches that read the staging mirrors (Context::prepare)
-  static const bool hdp_on = [] { const char* e = std::getenv("FDH_HDP_FLUSH"); return !e || std::atoi(e) != 0; }();
-  hdp_flush_reg_ = hdp_on ? prop.hdpMemFlushCntl : nullptr;
+  hdp_flush_reg_ = prop.hdpMemFlushCntl;
   FDH_HIP(hipStreamCreateWithFlags(&own_stream_, hipStreamNonBlocking));
   stream_ = own_stream_;
   for (auto& e : ev_) FDH_HIP(hipEventCreate(&e));
@@ -619,9 +621,11 @@ void Context::ensure_surfaces() {
   FDH_HIP(hipMalloc((void**)&backdrop_, n * 4));
   FDH_HIP(hipMalloc((void**)&blur_tmp_, n * 4));
   poison_fresh(backdrop_, n * 4); poison_fresh(blur_tmp_, n * 4); poison_fresh(fb_, n * 4);
-  // (fault hunting, FDH_POISON set: the surface starts as 0x11 bytes instead of zeros -- a zero pixel in a frame is then nobody's of ours)
-  static const bool marked = std::getenv("FDH_POISON") != nullptr;
-  FDH_HIP(hipMemsetAsync(fb_, marked ? 0x11 : 0, n * 4, stream_));
+#if defined(FDH_POISON)  // (fault-hunting builds: the surface starts as 0x11 bytes instead of zeros -- a zero pixel in a frame is then nobody's of ours)
+  FDH_HIP(hipMemsetAsync(fb_, 0x11, n * 4, stream_));
+#else
+  FDH_HIP(hipMemsetAsync(fb_, 0, n * 4, stream_));
+#endif
   surf_w_ = W_;
   surf_h_ = H_;
 }
@@ -778,6 +782,10 @@ void Context::prepare(LaunchJob& J) {
   // applies to every strip (blend_pre: F = rint(fma(F, 1 - sa, c * 255 sa)) per channel, IEEE single, no approximations), computed
   // once here.  The draw's bin record goes to the device with empty bounds (it is never binned); the lanes keep what was recorded
   // (fdh_debug_record_digest).  Bench frame: 32 640 uniform blends fewer, 8 % of the phase-0 launch's VALU instructions.
+  // (more pieces than the upload's kernel-argument table holds: they are copied together first -- BEFORE the fold below empties the
+  // first record's bounds in its lane: the copy would carry the emptied box, and the restore at the end of this function would
+  // reach the original lane only, leaving fdh_debug_record_digest an empty box for record 0 of such a frame -- ADVICE r4)
+  if (pieces_.size() * 3 + 2 > (size_t)kMaxUploadRuns) consolidate_pieces();
   bool folded = false;
   BBox folded_box{0, 0, 0, 0};
   BinRec* folded_br = nullptr;
@@ -873,7 +881,6 @@ void Context::prepare(LaunchJob& J) {
   up_misc.reserve(misc.size());
   // ---- the runs k_upload_frame gathers.  Every piece brings three: its records (extension indices re-based on the way), its bin
   // records, its extensions; then the phase table (+ tables).  A frame recorded by one thread is one piece.
-  if (pieces_.size() * 3 + 2 > (size_t)kMaxUploadRuns) consolidate_pieces();  // (more pieces than the kernel-argument table holds: copy them together)
   // device views of the lanes' mirrors (taken by whoever allocated them), index lane + 1 (slot 0: the consolidated lane)
   const size_t n_lanes = lanes_[(size_t)slot].size() + 1;
   std::vector<const uint8_t*> d_recs(n_lanes, nullptr), d_bins(n_lanes, nullptr), d_exts(n_lanes, nullptr);
@@ -1104,11 +1111,10 @@ void Context::issue(LaunchJob& J) {
   // the upload's dispatch (hipExtLaunchKernelGGL's stop event: 4.6 us), and not at all without one
   // (tools/trace_gaps.sh).  Now the BIN launch says it: its first wave stores the frame's sequence number to a word of pinned host
   // memory (k_bin_draws) -- it has started, so the upload in front of it is done -- and begin_frame compares that word.
-  // (A frame without a bin launch -- no phase -- keeps the event.  FDH_STAGING_EVENT=1: always the event.)
-  static const bool by_event = [] { const char* e = std::getenv("FDH_STAGING_EVENT"); return e && std::atoi(e) != 0; }();
+  // (A frame without a bin launch -- no phase -- keeps the event.)
   uint32_t seq = 0;
   if (J.staging_slot >= 0) {
-    const bool binned = !by_event && !J.phases.empty() && J.bins_x * J.bins_y > 0;
+    const bool binned = !J.phases.empty() && J.bins_x * J.bins_y > 0;
     if (binned && !seq_host_) {
       FDH_HIP(hipHostMalloc((void**)&seq_host_, 64, hipHostMallocDefault));
       *seq_host_ = 0;
@@ -1278,11 +1284,6 @@ void Context::launch_frame(const LaunchJob& J, bool profile, uint32_t upload_seq
     span_begin(p == 0 ? 1 : 2);
     launch_composite(stream_, dv_.recs, dv_.exts, C);
     span_end();
-    static const bool snap = [] { const char* e = std::getenv("FDH_DEBUG_SNAP"); return e && std::atoi(e) != 0; }();
-    if (snap && p == 0) {  // diagnostic only (tools/race_probe.py): what the first blur pass is about to read
-      if (!dbg_snap_) FDH_HIP(hipMalloc((void**)&dbg_snap_, (size_t)J.W * J.H * 4));
-      FDH_HIP(hipMemcpyAsync(dbg_snap_, cur, (size_t)J.W * J.H * 4, hipMemcpyDeviceToDevice, stream_));
-    }
   }
   if (cur != fb_) std::swap(fb_, alt_);  // the frame ended in the other surface: it is the frame surface now
   FDH_HIP(hipGetLastError());

@@ -37,7 +37,7 @@ struct Aff {
   float a = 1, b = 0, c = 0, d = 1, tx = 0, ty = 0;
 };
 
-// Fault hunting (FDH_POISON=<byte>): every fresh device allocation is filled with that byte before its first use -- a kernel that
+// Fault-hunting builds (-DFDH_POISON=<byte>): every fresh device allocation is filled with that byte before its first use -- a kernel that
 // reads memory nothing has written yet then reads the same garbage every time, not what the allocation's previous owner left.
 void poison_fresh(void* p, size_t bytes);  // fdh_context.cpp
 template <typename T>

@@ -661,7 +661,6 @@ bool ParallelWalk::group(Walker& mw, const FdhLayer& L, const int* items, int n)
     bool serial_only = false;
     std::exception_ptr err;
     int slot = -1;
-    int64_t t0 = 0, t1 = 0;  // FDH_WALK_TRACE: when the chunk ran, ns since the group began
   };
   std::vector<Out> outs((size_t)n_chunks);
   // chunk c covers items [cut[c], cut[c + 1]): equal counts the first time a group is seen, then by what the chunks cost last time
@@ -712,15 +711,11 @@ bool ParallelWalk::group(Walker& mw, const FdhLayer& L, const int* items, int n)
   const int outer_rmasks = (int)base.rect_masks_.size() + base.outer_rect_masks_;
   const bool outer_open = !base.open_ops_.empty() || base.outer_open_;
   C.close_piece();
-  static const bool trace = [] { const char* e = std::getenv("FDH_WALK_TRACE"); return e && std::atoi(e) != 0; }();
-  const auto g0 = std::chrono::steady_clock::now();
-  auto since = [&] { return (int64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - g0).count(); };
   auto fn = [&](int slot, int c) {
     Recorder& R = *C.pool_recs_[(size_t)slot];
     Lane& Ln = C.lane(slot + 1);
     if (c < 0) { slot_max[(size_t)slot] = Ln.count_close(); return; }
     Out& o = outs[(size_t)c];
-    if (trace) { o.slot = slot; o.t0 = since(); }
     thread_local int t_dev = -1;
     if (!C.host_only_ && t_dev != C.device_) { (void)hipSetDevice(C.device_); t_dev = C.device_; }  // (a lane's pinned mirror is allocated by the thread that publishes into it)
     R.lane_ = &Ln;
@@ -750,15 +745,9 @@ bool ParallelWalk::group(Walker& mw, const FdhLayer& L, const int* items, int n)
       catch (...) { o.err = std::current_exception(); }
     }
     o.s = R.sum_; o.outer = R.outer_union_; o.frags = R.fragments_; o.culled = R.culled_draws_;
-    if (trace) o.t1 = since();
   };
   bool ran;
   { Context::HostTimer t(C.host_ns_[8]); ran = WalkPool::get().run(helpers, n_chunks, fn); }
-  if (trace) {
-    std::fprintf(stderr, "walk group: %d items, %d chunks, %d slots, joined after %.1f us:", n, n_chunks, slots, since() * 1e-3);
-    for (int c = 0; c < n_chunks; c++) std::fprintf(stderr, " [%d s%d %.1f-%.1f n%u]", c, outs[(size_t)c].slot, outs[(size_t)c].t0 * 1e-3, outs[(size_t)c].t1 * 1e-3, outs[(size_t)c].p.n);
-    std::fprintf(stderr, "\n");
-  }
   bool failed = !ran;
   std::exception_ptr err;
   for (const Out& o : outs) { if (o.serial_only || o.err) failed = true; if (o.err && !err) err = o.err; }

@@ -2666,12 +2666,9 @@ constexpr int kMxSlot = 512;          // dwords of one k-step in LDS: 16 texels 
 // purpose: after the builtin form hipcc drains vmcnt to 0 before the next LDS read, which also waits for the stores just
 // issued; the kernel below places its own counted waits.  (M0 = LDS address; one wait state between s_mov m0 and its use.)
 // M0 is a reserved register for hipcc (a clobber on it is ignored, -Winline-asm): the block saves and restores it.
-#ifndef FDH_DMA_POLICY
-#define FDH_DMA_POLICY ""  // cache-policy bits of the blur passes' texel DMA (experiments: " nt", " sc1", ...)
-#endif
 __device__ __forceinline__ void lds_dma16(const void* src, uint32_t lds) {
   uint32_t m0_saved;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" FDH_DMA_POLICY "\n\ts_mov_b32 m0, %0"
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                : "=&s"(m0_saved) : "v"(src), "s"(lds) : "memory");
 }
 __device__ __forceinline__ void lds_dma4(const void* src, uint32_t lds) {
@@ -2737,9 +2734,6 @@ __global__ __launch_bounds__(64 * mx_wg(NK, kV), FDH_MX_WAVES) void k_blur_mx(Bl
   }
   const int lane = threadIdx.x & 63, g = lane >> 5, j = lane & 31;
   const int reach = P.taps.reach;
-#if defined(FDH_MX_STAGGER)  // experiment: every other wave of an XCD starts FDH_MX_STAGGER x ~1 us late (do memory and arithmetic phases run in step?)
-  if ((blockIdx.x >> 3) & 1) for (int i = 0; i < FDH_MX_STAGGER; i++) __builtin_amdgcn_s_sleep(32);
-#endif
   const int as = a0 + 32 * T * sa, lb = l0 + 32 * sl;
   const int n_blocks = min(T, (a_hi - as + 31) >> 5);
   const int w0 = as - reach, w0a = kV ? w0 : (w0 & ~3);  // horizontal: window start moved back to a 16-byte boundary (mx_delta)
@@ -3741,12 +3735,12 @@ template <int NOUT, int WAVES> static void launch_blur_v_n(hipStream_t s, const 
 // per SIMD for the narrow filters, two for the widest ones).  (4K, NK = 5: T = 4, 2040 waves for 2048 slots; leaving a
 // tenth of the slots free, T = 5, measured 1 us slower on the vertical pass.)
 static int mx_pick_t(long long per_cu, long long outputs_along, long long lines) {
-  static const int forced = [] { const char* e = std::getenv("FDH_MX_T"); return e ? std::atoi(e) : 0; }();  // experiments
-  if (forced) return forced;
+#if defined(FDH_MX_T)  // experiment builds only (make variant DEFS=-DFDH_MX_T=n): a fixed T
+  return FDH_MX_T;
+#endif
   // (two waves per SIMD at most: with the horizontal pass's smaller ring eleven fit a CU, and T = 3 with 2720 shorter waves
   // measured 24.6 us against 23.4 for the two blur launches of the bench frame)
-  static const int cu_cap = [] { const char* e = std::getenv("FDH_MX_PER_CU"); return e ? std::atoi(e) : 4 * FDH_MX_WAVES; }();
-  const long long slots = 256 * std::min<long long>(per_cu, cu_cap);
+  const long long slots = 256 * std::min<long long>(per_cu, 4 * FDH_MX_WAVES);
   const long long along_blocks = (outputs_along + 31) / 32, line_groups = (lines + 31) / 32;
   for (int t = 1; t < 64; t++) if (line_groups * ((along_blocks + t - 1) / t) <= slots) return t;
   return 64;
@@ -3790,12 +3784,13 @@ template <int NKH, int NKV> static void launch_blur_fx(hipStream_t s, const Blur
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_blur_fx<NKH, NKV>, 64 * kFxWaves, lds) != hipSuccess || n <= 0) n = std::min<int>(8 / kFxWaves, (int)(160 * 1024 / lds));
     return n;
   }();
-  static const int forced = [] { const char* e = std::getenv("FDH_FX_T"); return e ? std::atoi(e) : 0; }();  // experiments
   const int n_strips = (P.x1 - (P.x0 & ~31) + 31) >> 5, n_sg = (n_strips + kFxWaves - 1) / kFxWaves, blocks = (P.y1 - (P.y0 & ~31) + 31) >> 5;
   const long long slots = 256LL * std::min(wg_per_cu, 8 / kFxWaves);  // workgroups resident at once
   int t = 2;  // (a one-block segment would filter three H-blocks per output block)
   while (t < 64 && (long long)n_sg * ((blocks + t - 1) / t) > slots) t++;
-  if (forced) t = forced;
+#if defined(FDH_FX_T)  // experiment builds only (make variant DEFS=-DFDH_FX_T=n; tools/fx_t_sweep.sh): a fixed T
+  t = FDH_FX_T;
+#endif
   const int total = n_sg * ((blocks + t - 1) / t), per = (total + 7) / 8;
   FDH_LAUNCH((k_blur_fx<NKH, NKV>), dim3(8 * per), dim3(64 * kFxWaves), lds, s, P, w_v, draws, exts, t);
 }
@@ -3815,8 +3810,7 @@ bool launch_blur_fused(hipStream_t s, const BlurParams& P, const uint4* w_v, con
 // one kernel for a small region (k_blur_small): the region sizes the small-region passes take, filters of reach <= 24 (the tile's
 // source window and its horizontal result stay under 20 KB of LDS; a wider filter re-filters too many halo rows per 16-row tile)
 bool blur_one_kernel_ok(int w, int h, int reach) {
-  static const bool off = [] { const char* e = std::getenv("FDH_BLUR_ONE_KERNEL"); return e && std::atoi(e) == 0; }();
-  if (off || blur_forced_path() || w <= 0 || h <= 0) return false;
+  if (blur_forced_path() || w <= 0 || h <= 0) return false;
   return (long long)w * h < 384 * 1024 && reach <= 24;
 }
 void launch_blur_small(hipStream_t s, const BlurParams& P) {

@@ -58,7 +58,7 @@ struct alignas(128) Shared {
 // Where the helpers run.  A group's chunks read the same node array and write lanes the calling thread reads back microseconds
 // later: on a host of many core complexes (the pool's boxes: 256 hardware threads, 16-thread complexes) a helper the scheduler
 // put on another complex -- or the other socket -- took 2 - 5x as long over the same 44 records as the calling thread
-// (FDH_WALK_TRACE: 3.1 us against 4 - 18), and a group ends with its slowest chunk.  Helpers are therefore confined to the hardware
+// (a per-chunk trace, round 4: 3.1 us against 4 - 18), and a group ends with its slowest chunk.  Helpers are therefore confined to the hardware
 // threads that share a last-level cache with the thread that first used the pool (Linux: cpuN/cache/index3/shared_cpu_list),
 // that thread's own core left out.  An affinity MASK, not a pin: the scheduler still places them.  FDH_WALK_AFFINITY=0, a list
 // that cannot be read, or one too short for the helpers: no mask.
@@ -152,7 +152,6 @@ static WalkPoolImpl& impl() {
   // (never destroyed: a pool thread may be mid-spin when the process exits; the OS takes the threads with it)
   static WalkPoolImpl* p = [] {
     auto* q = new WalkPoolImpl();
-    if (const char* e = std::getenv("FDH_WALK_SPIN_US")) q->spin_us = std::max(0, std::atoi(e));
     return q;
   }();
   return *p;

@@ -1104,6 +1104,43 @@ def test_frames_recorded_on_the_walk_pool_equal_the_serial_ones(hip, which):
     assert mx <= 2 and n1 <= 4 and n0 <= 0.005 * w * h, (which, mx, n0, n1)
 
 
+def test_a_folded_clear_in_a_consolidated_frame_keeps_the_record_digest(hip):
+    """A frame whose first draw is a full-frame one-colour rectangle (its clear is folded: the draw's bin record travels with empty
+    bounds) AND whose pieces outnumber the upload's run table (consolidated into one lane): after the GPU frame the recorded frame
+    must still be what the calls produced -- fdh_debug_record_digest equal to the serial walk's and to a record-only context's
+    (the fold used to empty the box before the consolidation copied it)."""
+    from figdraw_amd import scene as S
+    from figdraw_amd.context import HipContext
+
+    w, h = 800, 600
+    lst = S.RenderList()
+    lst.addRoot(S.Fig(kind=S.FigKind.nkRectangle, screenBox=S.rect(0, 0, w, h), fill=S.rgba(240, 244, 250, 255)))
+    for g in range(14):
+        parent = lst.addRoot(S.Fig(kind=S.FigKind.nkFrame, screenBox=S.rect(0, 40.0 * g, w, 40)))
+        for k in range(60):
+            lst.addChild(parent, S.Fig(kind=S.FigKind.nkRectangle, screenBox=S.rect(12.0 * k, 40.0 * g + 4, 10, 30), corners=[2] * 4,
+                                       fill=S.rgba((k * 37) & 255, (g * 53) & 255, 90, 255)))
+    sc = S.Renders()
+    sc.setLayer(0, lst)
+    rec = HipContext(record_only=True)
+    rec.render_frame(sc, w, h)
+    want = rec.record_digest()
+    rec.close()
+    hip.set_walk_threads(0)
+    hip.render_frame(sc, w, h)
+    hip.sync()
+    assert hip.frame_stats().clear_folded == 1.0
+    serial_px = hip.read_pixels()
+    assert hip.record_digest() == want
+    hip.set_walk_threads(3)
+    hip.render_frame(sc, w, h)
+    hip.sync()
+    assert hip.walk_stats()[1] == 14 and hip.frame_stats().clear_folded == 1.0
+    assert hip.record_digest() == want
+    assert np.array_equal(hip.read_pixels(), serial_px)
+    hip.set_walk_threads(-1)
+
+
 def test_draw_image_adj_and_the_lcd_flag_through_the_seam():
     """drawImageAdj (glcontext.nim:1369-1381: the uv rect pulled in by two texels) against the oracle, upright, scaled and under a
     rotation; and setTextLcdFilteringEnabled / textLcdFilteringEnabled (figbackend.nim:663-667): a glyph uploaded with
@@ -1249,10 +1286,10 @@ def test_staging_in_device_memory_changes_no_pixel():
 
 
 def test_launch_chain_switches_change_no_pixel():
-    """Round 4's two changes to the launch chain are speed only: who tells the host that a staging set is free again (the bin
-    launch's store to a pinned word -- or the event behind the upload, FDH_STAGING_EVENT=1) and which bins a later phase's part of
-    the bin launch covers (the phase's own box -- or the whole grid, FDH_BIN_SUBGRIDS=0).  Both are read once per process, hence the
-    child processes.  A burst of animation frames through one context (the staging sets rotate and are waited for), a frame of
+    """Round 4's change to the bin launch is speed only: which bins a later phase's part of it covers (the phase's own box -- or the
+    whole grid, FDH_BIN_SUBGRIDS=0; read once per process, hence the child processes).  (Its other change -- the bin launch's first
+    wave, not an event behind the upload, tells the host that a staging set is free again -- had a switch too until round 5 pruned
+    it; a frame without a bin launch still takes the event.)  A burst of animation frames through one context (the staging sets rotate and are waited for), a frame of
     four phases with blur nodes of different footprints, a clipped tree and a stripe: same frames bit for bit."""
     import os
     import subprocess
@@ -1281,20 +1318,20 @@ def test_launch_chain_switches_change_no_pixel():
     ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
     res = {}
     with tempfile.TemporaryDirectory() as td:
-        for name, env in (("default", {}), ("event", {"FDH_STAGING_EVENT": "1"}), ("whole_grid", {"FDH_BIN_SUBGRIDS": "0"})):
+        for name, env in (("default", {}), ("whole_grid", {"FDH_BIN_SUBGRIDS": "0"})):
             path = os.path.join(td, f"{name}.npz")
             subprocess.check_call([sys.executable, "-c", code, path], env=dict(os.environ, **env))
             z = np.load(path)
             res[name] = [z[f"arr_{i}"] for i in range(4)]
-    for name in ("event", "whole_grid"):
+    for name in ("whole_grid",):
         for a, b in zip(res["default"], res[name]):
             assert np.array_equal(a, b), name
 
 
 def test_small_blur_in_one_kernel_equals_the_two_pass_route():
     """k_blur_small (a small region's two passes in one kernel, snapshot to the backdrop surface, composited by the phase's launch)
-    against the two small-region passes with the composite fused into the vertical one (FDH_BLUR_ONE_KERNEL=0; read once per
-    process): regions at the frame's edges (clamped taps), a stripe, several radii, a rounded translucent quad.  The blurred
+    against the two small-region passes with the composite fused into the vertical one (FDH_BLUR_FUSED=0: the two-pass routes for
+    every node; read once per process): regions at the frame's edges (clamped taps), a stripe, several radii, a rounded translucent quad.  The blurred
     snapshot is the same sum in the same order; the frames must agree bit for bit -- and with the oracle."""
     import os
     import subprocess
@@ -1326,7 +1363,7 @@ def test_small_blur_in_one_kernel_equals_the_two_pass_route():
     with tempfile.TemporaryDirectory() as td:
         for on in ("1", "0"):
             path = os.path.join(td, f"one{on}.npz")
-            subprocess.check_call([sys.executable, "-c", code, path], env=dict(os.environ, FDH_BLUR_ONE_KERNEL=on))
+            subprocess.check_call([sys.executable, "-c", code, path], env=dict(os.environ, FDH_BLUR_FUSED=on))
             z = np.load(path)
             res[on] = [z[f"arr_{i}"] for i in range(5)]
     for a, b in zip(res["0"], res["1"]):

@@ -32,7 +32,7 @@ iters = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 NB = int(os.environ.get("NB", str(NC)))  # contexts 0 .. NB-1 carry the full-frame (matrix-pipe) blur, the others none
 scenes = [make_render_tree_100(w, h, frame=f, copies=COPIES, full_frame_blur=f < NB, full_frame_blur_radius=RADII[f % len(RADII)]) for f in range(NC)]
 hip = HipContext(device=0)
-SNAP = os.environ.get("FDH_DEBUG_SNAP", "0") != "0"  # the library then copies the surface in-stream after phase 0
+SNAP = False  # (round 1 - 4: FDH_DEBUG_SNAP made the library copy the surface in-stream after phase 0; the switch was pruned in round 5)
 alone, alone_h, alone_p0 = [], [], []
 for sc in scenes:
     hip.render_frame(sc, w, h)
