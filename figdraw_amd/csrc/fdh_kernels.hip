@@ -420,25 +420,47 @@ __device__ __forceinline__ void bin_entry(const BinParams& P, int i, int x0, int
     CurveBox cb[2];
     curve_boxes2(Ax, Ay, Bx, By, Cx, Cy, cb);
     const float reach = 1.41422f * (__builtin_fmaxf(f0, 0.0f) * 0.5f + 0.5f / aa) + 0.05f;  // (+ slack for the kernels' own rounding of the coordinates)
-    uint32_t keep = 0;
-#pragma unroll 1
-    for (int s = 0; s < 16; s++) {
-      const int col = (s >> 2) & 1, row = (s >> 3) * 4 + (s & 3);
-      const float cxa = (float)(x0 + col * kTileW) + 0.5f, cxb = cxa + (float)(kTileW - 1), cya = (float)(y0 + row * kTileH) + 0.5f, cyb = cya + (float)(kTileH - 1);
-      const float lxa = ((cxa - ox) * inv_w - 0.5f) * (2.0f * p0), lxb = ((cxb - ox) * inv_w - 0.5f) * (2.0f * p0);
-      const float lya = ((cya - oy) * inv_h - 0.5f) * (2.0f * p1), lyb = ((cyb - oy) * inv_h - 0.5f) * (2.0f * p1);
-      bool near = false;
+    // Pixel centre -> local frame is separable and affine (upright quad): lx = sx px + tx, ly = sy py + ty.  A rectangle of pixel
+    // centres with centre (mx, my) and half sizes (hx, hy) has, in box c's chord frame (a rotation by (fx, fy) about (ax, ay)), the
+    // bounding box  centre (Xc, Yc) = R (l(mx, my) - a),  half sizes (|fx| hx' + |fy| hy', |fy| hx' + |fx| hy')  with hx' = |sx| hx,
+    // hy' = |sy| hy -- the same box the four mapped corners span (round 4 mapped the corners: ~30 operations per strip and box
+    // against 8 here, and 103 VGPRs).  It is near the curve's box iff both centre distances are under the summed half sizes + reach.
+    // The WHOLE bin first: most bins inside a long stroke's quad are nowhere near the curve, and sixteen strip tests end there.
+    const float sx = inv_w * (2.0f * p0), sy = inv_h * (2.0f * p1);
+    const float tx = (-ox * inv_w - 0.5f) * (2.0f * p0), ty = (-oy * inv_h - 0.5f) * (2.0f * p1);
+    const float asx = __builtin_fabsf(sx), asy = __builtin_fabsf(sy);
+    float X0[2], Y0[2], dXc[2], dXr[2], dYc[2], dYr[2], ex[2], ey[2], bcx[2], bcy[2];
+    bool bin_near = false;
+    const float eps = 0.002f;  // (the centre / half-size form rounds differently from the corner form by a few ulps of ~1e3: keep, never drop)
 #pragma unroll
-      for (int c = 0; c < 2; c++) {  // the strip's rectangle in box c's frame: the bounding box of its four corners
-        const float ra = lxa - cb[c].ax, rb = lxb - cb[c].ax, rc = lya - cb[c].ay, rd = lyb - cb[c].ay;
-        const float Xa = ra * cb[c].fx, Xb = rb * cb[c].fx, Xc = rc * cb[c].fy, Xd = rd * cb[c].fy;        // X = rx fx + ry fy
-        const float Ya = -ra * cb[c].fy, Yb = -rb * cb[c].fy, Yc = rc * cb[c].fx, Yd = rd * cb[c].fx;      // Y = ry fx - rx fy
-        const float Xmin = __builtin_fminf(Xa, Xb) + __builtin_fminf(Xc, Xd), Xmax = __builtin_fmaxf(Xa, Xb) + __builtin_fmaxf(Xc, Xd);
-        const float Ymin = __builtin_fminf(Ya, Yb) + __builtin_fminf(Yc, Yd), Ymax = __builtin_fmaxf(Ya, Yb) + __builtin_fmaxf(Yc, Yd);
-        const float db = __builtin_fmaxf(__builtin_fmaxf(Xmin - cb[c].x_hi, cb[c].x_lo - Xmax), __builtin_fmaxf(Ymin - cb[c].y_hi, cb[c].y_lo - Ymax));
-        near = near || db < reach;
+    for (int c = 0; c < 2; c++) {
+      const float afx = __builtin_fabsf(cb[c].fx), afy = __builtin_fabsf(cb[c].fy);
+      bcx[c] = 0.5f * (cb[c].x_lo + cb[c].x_hi); bcy[c] = 0.5f * (cb[c].y_lo + cb[c].y_hi);
+      const float bhx = 0.5f * (cb[c].x_hi - cb[c].x_lo), bhy = 0.5f * (cb[c].y_hi - cb[c].y_lo);
+      // strip (0, 0): pixel centres x0 + 0.5 .. x0 + 31.5, y0 + 0.5 .. y0 + 7.5
+      const float l0x = sx * ((float)x0 + 16.0f) + tx - cb[c].ax, l0y = sy * ((float)y0 + 4.0f) + ty - cb[c].ay;
+      X0[c] = l0x * cb[c].fx + l0y * cb[c].fy; Y0[c] = l0y * cb[c].fx - l0x * cb[c].fy;
+      dXc[c] = 32.0f * sx * cb[c].fx; dXr[c] = 8.0f * sy * cb[c].fy; dYc[c] = -32.0f * sx * cb[c].fy; dYr[c] = 8.0f * sy * cb[c].fx;
+      const float hx = 15.5f * asx, hy = 3.5f * asy;
+      ex[c] = bhx + afx * hx + afy * hy + reach + eps; ey[c] = bhy + afy * hx + afx * hy + reach + eps;
+      // the bin: centre = strip (0, 0)'s + half a strip column + 3.5 strip rows, half sizes 31.5 px
+      const float Xb = X0[c] + 0.5f * dXc[c] + 3.5f * dXr[c], Yb = Y0[c] + 0.5f * dYc[c] + 3.5f * dYr[c];
+      const float Hx = 31.5f * asx, Hy = 31.5f * asy;
+      bin_near = bin_near || (__builtin_fabsf(Xb - bcx[c]) < bhx + afx * Hx + afy * Hy + reach + eps && __builtin_fabsf(Yb - bcy[c]) < bhy + afy * Hx + afx * Hy + reach + eps);
+    }
+    uint32_t keep = 0;
+    if (bin_near) {
+#pragma unroll 4
+      for (int s = 0; s < 16; s++) {
+        const float col = (float)((s >> 2) & 1), row = (float)((s >> 3) * 4 + (s & 3));
+        bool near = false;
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+          const float Xc = X0[c] + col * dXc[c] + row * dXr[c], Yc = Y0[c] + col * dYc[c] + row * dYr[c];
+          near = near || (__builtin_fabsf(Xc - bcx[c]) < ex[c] && __builtin_fabsf(Yc - bcy[c]) < ey[c]);
+        }
+        if (near) keep |= 1u << s;
       }
-      if (near) keep |= 1u << s;
     }
     strips &= keep;
     hit = strips != 0u;
@@ -467,6 +489,33 @@ __device__ __forceinline__ void bin_entry(const BinParams& P, int i, int x0, int
                           __uint_as_float(wl1.z), __uint_as_float(wl1.w), __uint_as_float(wl2.x), __uint_as_float(wl2.y), __uint_as_float(wl2.z), __uint_as_float(wl2.w)};
     const bool has_core = cxr > cxl;
     uint32_t keep = 0, core = 0;
+    // The WHOLE bin first (its pixel centres span 126 half-pixel units each way): outside one edge -> the draw leaves the bin; inside
+    // all four AND, under both triangles' maps, inside the core rectangle -> every strip is a core strip; inside all four without
+    // a core -> every strip stays.  A large rotated panel covers most of its bins whole: for those the sixteen strip tests are skipped.
+    bool bin_out = false, bin_in = true;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int bhi = (ea[k] > 0 ? 126 * ea[k] : 0) + (eb[k] > 0 ? 126 * eb[k] : 0), blo = (ea[k] < 0 ? 126 * ea[k] : 0) + (eb[k] < 0 ? 126 * eb[k] : 0);
+      bin_out = bin_out || e00[k] + bhi < 0;
+      bin_in = bin_in && e00[k] + blo > 0;
+    }
+    if (bin_out) { hit = false; return; }
+    bool bin_core = bin_in && has_core;
+    if (bin_core) {
+      const float Xlo = (float)(2 * x0 + 1), Ylo = (float)(2 * y0 + 1);
+#pragma unroll
+      for (int t = 0; t < 2; t++) {
+        const float* m = lm + 6 * t;
+        const float lx0 = m[0] * Xlo + m[1] * Ylo + m[2], ly0 = m[3] * Xlo + m[4] * Ylo + m[5];
+        const float dxx = 126.0f * m[0], dxy = 126.0f * m[1], dyx = 126.0f * m[3], dyy = 126.0f * m[4];
+        const float lxmin = lx0 + __builtin_fminf(dxx, 0.0f) + __builtin_fminf(dxy, 0.0f), lxmax = lx0 + __builtin_fmaxf(dxx, 0.0f) + __builtin_fmaxf(dxy, 0.0f);
+        const float lymin = ly0 + __builtin_fminf(dyx, 0.0f) + __builtin_fminf(dyy, 0.0f), lymax = ly0 + __builtin_fmaxf(dyx, 0.0f) + __builtin_fmaxf(dyy, 0.0f);
+        bin_core = bin_core && lxmin >= cxl && lxmax <= cxr && lymin >= cyb && lymax <= cyt;
+      }
+    }
+    if (bin_core) { keep = 0xffffu; core = 0xffffu; }
+    else if (bin_in && !has_core) { keep = 0xffffu; }
+    else
 #pragma unroll 1
     for (int s = 0; s < 16; s++) {
       const int col = (s >> 2) & 1, row = (s >> 3) * 4 + (s & 3);

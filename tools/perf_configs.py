@@ -27,6 +27,62 @@ from oracle import oracle as O
 only = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 out = {}
 
+# ---- the algorithmic model of a frame (extended to the atlas / MSDF / bezier modes for round 5): flops per COVERED
+# fragment counted off the reference's fragment shader, x the fragments the frame's draws cover (quad areas), and the bytes a frame
+# must move.  The shader lines each figure is counted from:
+#   ClipAA(3) 25, DropShadow(7) 35 + exp, InsetShadow(9) 70 + exp, AnnularAA(12) 28, BackdropBlur(17) 25: SURVEY.md 8(d) (atlas.frag:252-405)
+#   elliptical corners + 30 (sdEllipticalRoundedBox, atlas.frag:51-115)
+#   Atlas(0) 32: one LINEAR texture2D = 3 lerps x 4 channels x 2 flops + 4 for the texel coordinates, x the tint, 4 (atlas.frag:284-295)
+#   Msdf / Mtsdf(13 - 16) 48: the same fetch (28) + median 4 + msdfScreenPxRange ~10 + threshold, clamp, alpha 6 (atlas.frag:296-318)
+#   bezier strokes(18 - 20) ~120: sdBezier's closed-form cubic (atlas.frag:121-209: dot products, a sqrt, acos / cos or two cube roots)
+#   + 16 per fragment for the fixed-function blend and the RGBA8 round (utils/glutils.nim:150-154)
+FLOPS = {0: 32, 3: 25, 7: 36, 9: 71, 12: 28, 13: 48, 14: 48, 15: 48, 16: 48, 17: 25, 18: 120, 19: 120, 20: 120}
+VALU_PEAK_TFLOPS, HBM_PEAK_GBS = 157.3, 8000.0
+
+
+def algorithmic(sc, w, h, images=None, atlas_size=1024):
+    """fragments by mode (quad areas clipped to nothing: the shader runs on every fragment of a quad inside the frame or not -- the
+    frame's own rectangle is applied), flops, bytes: from the BackendContext calls the scene decomposes into (a record-only context)"""
+    rec = HipContext(record_only=True, atlas_size=atlas_size)
+    for k in sorted(images or {}):
+        rec.put_image(k, images[k])
+    rec.record_begin()
+    rec.render_frame(sc, w, h)
+    calls = rec.record_calls()
+    rec.close()
+    frags, ellip, texels, n_draws = {}, 0, {}, 0
+    scale, stack = 1.0, []
+    for c in calls:
+        name = c[0]
+        if name == "save_transform":
+            stack.append(scale)
+        elif name == "restore_transform":
+            scale = stack.pop() if stack else 1.0
+        elif name == "scale":
+            scale *= abs(float(c[1]) * float(c[2] if len(c) > 2 and c[2] is not None else c[1]))
+        elif name == "draw_rounded_rect_sdf":
+            area = max(float(c[1][2]), 0.0) * max(float(c[1][3]), 0.0) * scale
+            mode = int(c[5])
+            frags[mode] = frags.get(mode, 0.0) + min(area, float(w * h))
+            if list(c[3]) != list(c[4]):
+                ellip += min(area, float(w * h))
+            n_draws += 1
+        elif name in ("draw_image", "draw_image_adj"):
+            sz = c[4] if len(c) > 4 else [0, 0]
+            iw, ih = (float(sz[0]), float(sz[1])) if sz and sz[0] > 0 and sz[1] > 0 else ((images[c[1]].shape[1], images[c[1]].shape[0]) if images and c[1] in images else (0.0, 0.0))
+            frags[0] = frags.get(0, 0.0) + iw * ih * scale
+            if images and c[1] in images: texels[c[1]] = images[c[1]].shape[0] * images[c[1]].shape[1]
+            n_draws += 1
+        elif name == "draw_msdf":
+            frags[13] = frags.get(13, 0.0) + float(c[4][0]) * float(c[4][1]) * scale
+            if images and c[1] in images: texels[c[1]] = images[c[1]].shape[0] * images[c[1]].shape[1]
+            n_draws += 1
+        elif name == "draw_quadratic_bezier_sdf":
+            n_draws += 1  # (its quad's area is not in the call: counted from the library's own fragment total below)
+        elif name in ("draw_filled_quad", "draw_rect", "draw_backdrop_blur"):
+            n_draws += 1
+    return frags, ellip, sum(texels.values()), n_draws
+
 
 def run(key, what, ctx, sc, w, h, n=100, oracle_kw=None, images=None):
     # the context's FIRST frame, timed where the library starts: the scene already marshalled into FdhFig arrays, one fdh_render_frame
@@ -52,6 +108,23 @@ def run(key, what, ctx, sc, w, h, n=100, oracle_kw=None, images=None):
                        "blur_v_all": round(1e3 * st.ms_blur_v, 1), "largest_blur_h": round(1e3 * st.ms_blur_big_h, 1),
                        "largest_blur_v": round(1e3 * st.ms_blur_big_v, 1)},
          "first_frame_host_ms": round(1e3 * first, 2), "frame_through_python_binding_ms": round(1e3 * through_python, 1)}
+    # ---- roofline of the frame's compositing (round 5): algorithmic flops over the compositor launches' time against the FP32 vector
+    # peak, algorithmic bytes over the frame's time against the HBM peak
+    frags, ellip, atlas_texels, _ = algorithmic(sc, w, h, images, (oracle_kw or {}).get("atlas_size", 1024))
+    counted = sum(frags.values())
+    other = max(float(st.fragments) - counted, 0.0)  # bezier strokes, filled quads, shadows' extra quads: what the calls' rectangles do not give
+    curve_frames = key == "config10"
+    flops = sum(FLOPS.get(m, 25) * a for m, a in frags.items()) + 30 * ellip + (120 if curve_frames else 25) * other + 16 * (counted + other)
+    byts = 4 * w * h + 128 * st.n_draws + 4 * atlas_texels + int(st.bytes_algorithmic - 4 * w * h - 128 * st.n_draws if st.n_blurs else 0)
+    comp_s = st.ms_composite * 1e-3
+    e["roofline"] = {"kernel": "k_composite_tiles (all phases of the frame)", "bound": "valu", "unit": "TFLOP/s", "peak": VALU_PEAK_TFLOPS,
+                     "achieved": round(flops / comp_s / 1e12, 2) if comp_s > 0 else None, "frac": round(flops / comp_s / 1e12 / VALU_PEAK_TFLOPS, 4) if comp_s > 0 else None,
+                     "algorithmic_flops": int(flops), "fragments_by_mode": {str(m): int(a) for m, a in sorted(frags.items())}, "fragments_other": int(other),
+                     "fragments_elliptical": int(ellip),
+                     "hbm": {"algorithmic_bytes": int(byts), "atlas_texels_touched": int(atlas_texels), "achieved_GBs": round(byts / (ms * 1e-3) / 1e9, 1),
+                             "frac": round(byts / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
+                     "note": "flops per covered fragment counted off atlas.frag (tools/perf_configs.py FLOPS) x quad areas; bytes = 4 W H + 128 B x draws + atlas "
+                             "texels of the images drawn (once each) + the blur nodes' bytes (SURVEY.md 8d)"}
     if key in ("config6", "config7", "config8"):  # the reference's loop: renderFrame per frame, 20 warm-up + 120 timed
         cs = sc.to_c()
         from figdraw_amd import call_stream as CS
