@@ -122,6 +122,7 @@ def load():
     L.fdh_debug_record_digest.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.fdh_debug_verify_upload.argtypes = [vp, C.POINTER(C.c_uint32)]
     L.fdh_debug_bin_digest.argtypes = [vp, C.POINTER(C.c_uint64)]
+    L.fdh_debug_staging_store_bytes.argtypes = [C.c_int, C.POINTER(C.c_int64)]
     L.fdh_last_upload_bytes.argtypes = [vp, C.POINTER(C.c_int64)]
     L.fdh_record_begin.argtypes = [vp]
     L.fdh_record_json.argtypes = [vp]

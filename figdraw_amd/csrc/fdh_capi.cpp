@@ -252,6 +252,12 @@ int fdh_debug_verify_upload(FdhContext* c, uint32_t out[24]) {
     C(c)->debug_verify_upload(out);
   });
 }
+int fdh_debug_staging_store_bytes(int device, int64_t* out) {
+  return guard([&] {
+    if (!out) throw fdh::Error(FDH_ERR_INVALID, "null output");
+    *out = (int64_t)fdh::vram_store_bytes(device);
+  });
+}
 int fdh_debug_bin_digest(FdhContext* c, uint64_t out[8]) {
   return guard([&] {
     if (!out) throw fdh::Error(FDH_ERR_INVALID, "null output");

@@ -325,6 +325,10 @@ FDH_API int fdh_debug_verify_upload(FdhContext*, uint32_t out[24]);
  * the list entries it covers, out[1] = sum of the counts, out[2] = bins with count 0, out[3] = entries whose first word is 0,
  * out[4] = bins whose count exceeds the list stride.  No counterpart in the reference. */
 FDH_API int fdh_debug_bin_digest(FdhContext*, uint64_t out[8]);
+/* Bytes of released staging blocks (device memory the host writes through the PCIe BAR) the library holds for `device` -- its store is keyed
+ * by device ordinal: a block allocated on one GPU never reaches a context on another.  0 for an ordinal no context has used.  No counterpart
+ * in the reference. */
+FDH_API int fdh_debug_staging_store_bytes(int device, int64_t* out);
 
 /* ------------------------------------------------------------------ multi-GPU / measurement hooks (no reference counterpart) */
 /* Restrict rasterisation to rows [y0, y1) of the frame (row-stripe sharding); blur halos are rendered redundantly so

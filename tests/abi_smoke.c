@@ -153,6 +153,7 @@ int main(int argc, char** argv) {
   OK(fdh_debug_record_digest(c, &d_frame)); CHECK(d_frame != 0);
   { uint32_t vu[24]; CHECK(fdh_debug_verify_upload(c, vu) == FDH_ERR_NO_DEVICE); } /* (a recorder holds no device block) */
   { uint64_t bd[8]; CHECK(fdh_debug_bin_digest(c, bd) == FDH_ERR_NO_DEVICE); }
+  { int64_t held = -1; OK(fdh_debug_staging_store_bytes(7, &held)); CHECK(held == 0); } /* (an ordinal nothing has used) */
 
   /* whole scenes and retained scenes */
   {

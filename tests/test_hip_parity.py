@@ -1141,6 +1141,47 @@ def test_a_folded_clear_in_a_consolidated_frame_keeps_the_record_digest(hip):
     hip.set_walk_threads(-1)
 
 
+def test_fault_hunting_probes_and_the_staging_store_by_device():
+    import os
+
+    """Round 5's probes on a healthy frame, and the staging store's keying.  fdh_debug_verify_upload: the device's frame block equals the
+    host lanes it was gathered from (but for bin record 0's box when the clear was folded: 4 bytes, by design); fdh_debug_bin_digest: a
+    replay of the resident records leaves the same counts and lists; fdh_debug_staging_store_bytes: blocks a closed context released
+    are held under ITS device ordinal and under no other (ADVICE r4: the store used to be process-wide)."""
+    import ctypes as C
+    import os
+
+    from figdraw_amd import context as ctx_mod
+    from figdraw_amd.context import HipContext
+    from figdraw_amd.scenes import make_render_tree_100
+
+    L = ctx_mod.load()
+
+    def held(dev):
+        out = C.c_int64(-1)
+        assert L.fdh_debug_staging_store_bytes(dev, C.byref(out)) == 0
+        return out.value
+
+    w, h = 1280, 720
+    c = HipContext(device=0)
+    c.set_walk_threads(3)
+    c.render_frame(make_render_tree_100(w, h, 3, full_frame_blur=True), w, h)
+    c.sync()
+    v = c.verify_upload()
+    assert v[0] == 0 and v[2] == 0 and v[1] in (0, 4) and v[3] > 0 and v[12] == 0 and v[17] == 0, v
+    d0 = c.bin_digest()
+    assert d0[1] > 0 and d0[4] == 0
+    c.replay(1)
+    c.sync()
+    assert c.bin_digest() == d0
+    before = held(0)
+    c.close()
+    after = held(0)
+    if os.environ.get("FDH_VRAM_STAGING", "1") != "0" and os.environ.get("FDH_VRAM_STORE", "1") == "1":
+        assert after > before, (before, after)  # the context's staging blocks went to device 0's store ...
+    assert held(1) == 0 and held(5) == 0      # ... and to no other ordinal's
+
+
 def test_draw_image_adj_and_the_lcd_flag_through_the_seam():
     """drawImageAdj (glcontext.nim:1369-1381: the uv rect pulled in by two texels) against the oracle, upright, scaled and under a
     rotation; and setTextLcdFilteringEnabled / textLcdFilteringEnabled (figbackend.nim:663-667): a glyph uploaded with
