@@ -620,7 +620,7 @@ __global__ __launch_bounds__(64) void k_bin_draws(BinParams P) {
   // layout order, so a run of 256 glyphs touches a handful of bins and most (bin, chunk) pairs end at the ballot.
   // The boxes of up to four live chunks are fetched together: with two waves per SIMD nothing else hides the L2 latency
   // of a dependent load per step.
-  constexpr int kAhead = 4;
+  constexpr int kAhead = 4;  // (eight, round 5: no change on the 8910-draw curve frame -- 22.4 us either way; its launch is paced by the hits' record fetches)
   const int c_last = (last - 1) >> 8;
   for (int c0 = first >> 8; c0 <= c_last && first < last; c0 += 64) {
     const int cl = c0 + lane;
@@ -3214,7 +3214,7 @@ __global__ __launch_bounds__(64 * kFxWaves, 2) void k_blur_fx(BlurParams P, cons
     }
   };
   auto wait_for_all_but = [&](int n) __attribute__((always_inline)) {
-    if (n >= 16) wait_vm<16>(); else wait_vm<0>();
+    if (n >= 16) wait_vm<16>(); else if (n >= 3) wait_vm<3>(); else if (n == 2) wait_vm<2>(); else if (n == 1) wait_vm<1>(); else wait_vm<0>();
     __builtin_amdgcn_sched_barrier(0);
   };
 
@@ -3225,15 +3225,21 @@ __global__ __launch_bounds__(64 * kFxWaves, 2) void k_blur_fx(BlurParams P, cons
   issue_block(0);
   // the weight fragments of both products go to LDS as they lie in memory (lane-linear 16-byte pieces: exactly what the DMA
   // writes), every wave of the workgroup fetching its share -- the one point at which the waves meet
+  // -- the horizontal table first: the first block's product needs it; the vertical one is first read HB - 1 blocks later, so this
+  // wave's pieces of it (`v_pieces`, the youngest in the queue) may still be in flight at the first barrier: the second block's wait
+  // covers them
+  int v_pieces = 0;
   {
     constexpr int NF = 2 * (NKH + NKV);
 #pragma unroll
     for (int f0 = 0; f0 < NF; f0 += kFxWaves) {
       const int f = f0 + wave;
-      if (f < NF) lds_dma16((f < 2 * NKH ? P.mx_w + f * 64 : w_v + (f - 2 * NKH) * 64) + lane, ring_lds + (uint32_t)f * 1024u);
+      if (f < NF) {
+        lds_dma16((f < 2 * NKH ? P.mx_w + f * 64 : w_v + (f - 2 * NKH) * 64) + lane, ring_lds + (uint32_t)f * 1024u);
+        if (f >= 2 * NKH) v_pieces++;
+      }
     }
   }
-  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's pieces of block 0 and its weight fragments have landed ...
 #if FDH_TIMING
   const unsigned long long T_pro = FDH_NOW() - T0;
 #endif
@@ -3301,7 +3307,7 @@ __global__ __launch_bounds__(64 * kFxWaves, 2) void k_blur_fx(BlurParams P, cons
   };
 
   const int n_hblocks = n_blocks + HB - 1;
-  int stores_behind = 0;  // store instructions issued after this block's DMA batch (vmcnt retires in issue order: they may stay out)
+  int stores_behind = v_pieces;  // memory instructions issued after this block's DMA batch that may stay out (vmcnt retires in issue order): the V block's stores; for block 0 the vertical weights' pieces
   auto iteration = [&](auto ph_tag, int i) __attribute__((always_inline)) {
     // this H-block's texels have landed -- its batch is older than the stores of the V block issued after it, which are NOT
     // waited for (they would cost a store round trip per iteration)
