@@ -43,9 +43,9 @@ extern "C++" { namespace fdh { void debug_mx_bad(unsigned int* n, unsigned int* 
 __attribute__((visibility("default"))) int fdh_debug_mx_bad(unsigned int* n, unsigned int* out, int reset) { fdh::debug_mx_bad(n, out, reset != 0); return 0; }
 #endif
 #if FDH_STATS
-extern "C++" { namespace fdh { void debug_counters(unsigned long long out[64], bool reset); void debug_wave_times(unsigned long long* out); } }
+extern "C++" { namespace fdh { void debug_counters(unsigned long long out[128], bool reset); void debug_wave_times(unsigned long long* out); } }
 __attribute__((visibility("default"))) int fdh_debug_wave_times(unsigned long long* out) { fdh::debug_wave_times(out); return 0; }
-__attribute__((visibility("default"))) int fdh_debug_counters(unsigned long long out[64], int reset) { fdh::debug_counters(out, reset != 0); return 0; }
+__attribute__((visibility("default"))) int fdh_debug_counters(unsigned long long out[128], int reset) { fdh::debug_counters(out, reset != 0); return 0; }
 #endif
 int fdh_saturated_core(const float rect[4], const float rx[4], const float ry[4], int mode, float factor, float spread,
                        const float shape[2], float aa, int out_px[4]) {

@@ -553,9 +553,15 @@ __device__ __forceinline__ void bin_entry(const BinParams& P, int i, int x0, int
   if (r.flags & BR_CORE_REMOVED) {
     strips &= ~core;  // alpha == 0 there (stroke interior) or too small to change an 8-bit channel (deep inside an inner shadow)
     hit = strips != 0u;
-    return;
+    if (!hit) return;
+  } else {
+    strips |= core << 16;
   }
-  strips |= core << 16;
+  // edge strips wholly inside the quad's pixel bounds: state (0, 1) -- fdh_types.h, BR_BOX_EXACT
+  if (r.flags & BR_BOX_EXACT) {
+    const uint32_t inq = strip_mask_inside(b.x0 - x0, b.y0 - y0, b.x1 - x0, b.y1 - y0) & strips & ~(strips >> 16) & 0xffffu;
+    strips = (strips & ~inq) | (inq << 16);
+  }
 }
 template <bool kRefine>
 __global__ __launch_bounds__(64) void k_bin_draws(BinParams P) {
@@ -736,8 +742,10 @@ struct Frag {
 
 // per-triangle affine interpolation of the four vertex colours on an axis-aligned quad:
 // triangles (TL,BL,BR) and (TR,TL,BR) (glcontext.nim:418-429); s,t = quad-normalised x, y-down
+__device__ __forceinline__ float tri_upper(float tl, float br, float tr, float s, float t) { return tl + (tr - tl) * s + (br - tr) * t; }
+__device__ __forceinline__ float tri_lower(float tl, float bl, float br, float s, float t) { return tl + (bl - tl) * t + (br - bl) * s; }
 __device__ __forceinline__ float tri_lerp(float tl, float bl, float br, float tr, float s, float t) {
-  const float upper = tl + (tr - tl) * s + (br - tr) * t, lower = tl + (bl - tl) * t + (br - bl) * s;  // (both, then a select)
+  const float upper = tri_upper(tl, br, tr, s, t), lower = tri_lower(tl, bl, br, s, t);  // (both, then a select)
   return (s > t) ? upper : lower;
 }
 
@@ -832,6 +840,11 @@ __device__ __forceinline__ void blend_pre(F4& F, f2 c_rg, f2 c_ba, float ia) {
   xy = __builtin_elementwise_fma(xy, ia2, c_rg);
   zw = __builtin_elementwise_fma(zw, ia2, c_ba);
   F.x = __builtin_rintf(xy.x); F.y = __builtin_rintf(xy.y); F.z = __builtin_rintf(zw.x); F.w = __builtin_rintf(zw.y);
+}
+
+// a black source: the r, g, b terms of the source are +0
+__device__ __forceinline__ void blend_black(F4& F, float A, float ia) {
+  F.x = __builtin_rintf(F.x * ia); F.y = __builtin_rintf(F.y * ia); F.z = __builtin_rintf(F.z * ia); F.w = __builtin_rintf(__builtin_fmaf(F.w, ia, A));
 }
 
 // atlas_rect_mask.frag:222-237
@@ -986,7 +999,7 @@ __device__ __forceinline__ void shape_distN(bool ellip, const float* px, float p
 // evalFillColor atlas.frag:233-250, select-based.  Everything is passed BY VALUE: `c ? a.x : b.x` on lvalues is an
 // lvalue conditional (pointer select, then a load), which pins arrays of F4 in scratch.
 __device__ __forceinline__ float selectf(bool c, float a, float b) { return c ? a : b; }
-__device__ __forceinline__ F4 eval_fill_nb(F4 col, F4 m, F4 s, uint32_t fill_mode, float mid, float u, float v) {
+__device__ __forceinline__ float fill_t(uint32_t fill_mode, float u, float v) {  // the gradient parameter, clamped (atlas.frag:236-243)
   float t;
   switch (fill_mode) {  // wave-uniform
     case 1u: t = u; break;
@@ -994,7 +1007,10 @@ __device__ __forceinline__ F4 eval_fill_nb(F4 col, F4 m, F4 s, uint32_t fill_mod
     case 3u: t = 0.5f * (u + v); break;
     default: t = 0.5f * (u + (1.0f - v)); break;
   }
-  t = clamp01(t);
+  return clamp01(t);
+}
+__device__ __forceinline__ F4 eval_fill_nb(F4 col, F4 m, F4 s, uint32_t fill_mode, float mid, float u, float v) {
+  const float t = fill_t(fill_mode, u, v);
   const bool lo = t <= mid;
   const float w = selectf(lo, t * frcp(mid), (t - mid) * frcp(1.0f - mid));
   F4 o;
@@ -1117,7 +1133,7 @@ __device__ __forceinline__ Src shade_one(const DrawRec* __restrict__ rp, const Q
 #endif
 #if FDH_STATS
 __device__ unsigned long long g_wave_times[16 * 65536];  // FDH_TIMING: one row per wave (no atomics: they would serialise)
-__device__ unsigned long long g_counters[64];
+__device__ unsigned long long g_counters[128];
 #if FDH_TIMING
 #define FDH_COUNT(i) do { } while (0)
 #else
@@ -1285,12 +1301,15 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? FDH_SLOW_WAVES : kPaths == 4 ? F
     const uint2 e = list[min(i, cnt - 1u)];  // {draw index | flags, strips touched | strips inside the saturated core << 16}
     const uint32_t idx = e.x;
     const uint32_t ey = i < cnt ? e.y : 0u;
-    unsigned long long m = __ballot((ey & (1u << sbit)) != 0u);
-    const unsigned long long m_core = __ballot((ey & (0x10000u << sbit)) != 0u);  // (a core strip is a touched strip: k_bin_draws)
+    // this strip's state in the entry (fdh_types.h): (1, 0) touched, (1, 1) core, (0, 1) an edge strip wholly inside the draw's quad
+    const uint32_t st = (ey >> sbit) & 0x10001u;
+    unsigned long long m = __ballot(st != 0u);
+    const unsigned long long m_core = __ballot(st == 0x10001u);
+    const unsigned long long m_inq = __ballot(st == 0x10000u);  // every pixel of the strip is covered by the quad: no per-pixel test
     if (!kMasks || !P.has_masks) {
       // Occlusion: an opaque fill that covers the whole strip makes every earlier draw of the strip invisible.  (Only in
       // phases without clip / rect masks: a skipped push or pop would derail the mask stack.)
-      const unsigned long long m_opaque = __ballot((ey & (0x10000u << sbit)) != 0u && (idx & LE_OPAQUE) != 0u);
+      const unsigned long long m_opaque = __ballot(st == 0x10001u && (idx & LE_OPAQUE) != 0u);
       if (m_opaque != 0) m &= ~((1ull << (63 - __builtin_clzll(m_opaque))) - 1ull);
     }
 #if FDH_TIMING
@@ -1353,7 +1372,8 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? FDH_SLOW_WAVES : kPaths == 4 ? F
       if ((kPaths & 3) == 0 && ellip) dist4e(r, lxa, lxb, pyy, shx, shy, da, db); else dist4(r, lxa, lxb, pyy, shx, shy, da, db);
     };
     // r: the run's geometry (quad, radii, AA factor, bounds); m_*: the draw's own sdfParams.zw, sdfFactors and colour
-    auto edge_blend = [&](const DrawRec& r, const uint32_t mode, const bool ellip, const float m_p2, const float m_p3, const float m_f0, const float m_f1,
+    // inq (wave-uniform, from the list entry): the strip lies wholly inside the quad's pixel bounds
+    auto edge_blend = [&](const DrawRec& r, const uint32_t mode, const bool ellip, const bool inq, const float m_p2, const float m_p3, const float m_f0, const float m_f1,
                           const u32x4 m_col, const f2 lxa, const f2 lxb, const float pyy, const f2 da, const f2 db, F4& A0, F4& A1, F4& A2, F4& A3) __attribute__((always_inline)) {
       f2 ala, alb;  // coverage
       if (mode == 3u) {
@@ -1370,12 +1390,13 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? FDH_SLOW_WAVES : kPaths == 4 ? F
         const float spread = m_f1;
         const f2 sda = sha + spread, sdb = shb + spread;
         const float rs = frcp(__builtin_fmaxf(0.5f * m_f0, 0.5f));
-        const f2 za = sda * rs, zb = sdb * rs;
+        // falloff(sd) = sd < 0 ? min(exp2(-0.7213 z^2), 1) : 1 with z = sd rs, written as exp2(-0.7213 z'^2) with z' = min(sd, 0) rs:
+        // the same operations on the same values where sd < 0; exp2(-0) = 1 where it is not; and v_exp_f32 of a non-positive
+        // input is never above 1 (tools/microbench/exp2_le1.hip tries every such float), so the min never acted
+        const f2 za = f2{__builtin_fminf(sda.x, 0.0f), __builtin_fminf(sda.y, 0.0f)} * rs, zb = f2{__builtin_fminf(sdb.x, 0.0f), __builtin_fminf(sdb.y, 0.0f)} * rs;
         const f2 ea = -0.72134752044f * za * za, eb = -0.72134752044f * zb * zb;
-        ala = {cover_aa(da.x, r.aa) * (sda.x < 0.0f ? __builtin_fminf(fexp2(ea.x), 1.0f) : 1.0f),
-               cover_aa(da.y, r.aa) * (sda.y < 0.0f ? __builtin_fminf(fexp2(ea.y), 1.0f) : 1.0f)};
-        alb = {cover_aa(db.x, r.aa) * (sdb.x < 0.0f ? __builtin_fminf(fexp2(eb.x), 1.0f) : 1.0f),
-               cover_aa(db.y, r.aa) * (sdb.y < 0.0f ? __builtin_fminf(fexp2(eb.y), 1.0f) : 1.0f)};
+        ala = {cover_aa(da.x, r.aa) * fexp2(ea.x), cover_aa(da.y, r.aa) * fexp2(ea.y)};
+        alb = {cover_aa(db.x, r.aa) * fexp2(eb.x), cover_aa(db.y, r.aa) * fexp2(eb.y)};
       } else {  // 7: atlas.frag:330-343
         const float spread = m_f1;
         const f2 sda = da - spread, sdb = db - spread;
@@ -1383,20 +1404,31 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? FDH_SLOW_WAVES : kPaths == 4 ? F
           ala = 1.0f; alb = 1.0f;
         } else {
           const float rs = frcp(__builtin_fmaxf(0.5f * m_f0, 0.5f));
-          const f2 za = sda * rs, zb = sdb * rs;
+          // (sd > 0 ? min(exp2(..), 1) : 1 as exp2 of max(sd, 0): see the inner shadow above)
+          const f2 za = f2{__builtin_fmaxf(sda.x, 0.0f), __builtin_fmaxf(sda.y, 0.0f)} * rs, zb = f2{__builtin_fmaxf(sdb.x, 0.0f), __builtin_fmaxf(sdb.y, 0.0f)} * rs;
           const f2 ea = -0.72134752044f * za * za, eb = -0.72134752044f * zb * zb;
-          ala = {sda.x > 0.0f ? __builtin_fminf(fexp2(ea.x), 1.0f) : 1.0f, sda.y > 0.0f ? __builtin_fminf(fexp2(ea.y), 1.0f) : 1.0f};
-          alb = {sdb.x > 0.0f ? __builtin_fminf(fexp2(eb.x), 1.0f) : 1.0f, sdb.y > 0.0f ? __builtin_fminf(fexp2(eb.y), 1.0f) : 1.0f};
+          ala = {fexp2(ea.x), fexp2(ea.y)};
+          alb = {fexp2(eb.x), fexp2(eb.y)};
         }
       }
-      // coverage of the quad: unsigned (x - bx0) < width, width 0 on rows outside it
-      const uint32_t xrel = (uint32_t)(px0 - (int)r.bx0);
-      const uint32_t wcov = (py >= r.by0 && py < r.by1) ? (uint32_t)((int)r.bx1 - (int)r.bx0) : 0u;
       const float cw = (float)(m_col.x >> 24) * inv255;  // (m_col: the draw's colour and, as floats, its r, g, b / 255: Context::prepare)
       f2 saa = ala * cw, sab = alb * cw;
-      saa.x = xrel < wcov ? saa.x : 0.0f; saa.y = xrel + 1u < wcov ? saa.y : 0.0f;
-      sab.x = xrel + 2u < wcov ? sab.x : 0.0f; sab.y = xrel + 3u < wcov ? sab.y : 0.0f;
+      FDH_COUNT(inq ? 64 : 65);
+      if ((m_col.y | m_col.z | m_col.w) == 0u) FDH_COUNT(71);
+      if (!inq) {
+        // coverage of the quad: unsigned (x - bx0) < width, width 0 on rows outside it
+        const uint32_t xrel = (uint32_t)(px0 - (int)r.bx0);
+        const uint32_t wcov = (py >= r.by0 && py < r.by1) ? (uint32_t)((int)r.bx1 - (int)r.bx0) : 0u;
+        saa.x = xrel < wcov ? saa.x : 0.0f; saa.y = xrel + 1u < wcov ? saa.y : 0.0f;
+        sab.x = xrel + 2u < wcov ? sab.x : 0.0f; sab.y = xrel + 3u < wcov ? sab.y : 0.0f;
+      }
       const f2 Aa = saa * 255.0f, Ab = sab * 255.0f, iaa = 1.0f - saa, iab = 1.0f - sab;
+      if ((m_col.y | m_col.z | m_col.w) == 0u) {
+        // a black source (every drop shadow of the reference's scenes, most strokes): the colour terms are +0 and fma(F, 1 - sa, +0)
+        // is the product F (1 - sa) itself (F >= 0, 1 - sa >= 0): three multiplies per pixel less, the same bits
+        blend_black(A0, Aa.x, iaa.x); blend_black(A1, Aa.y, iaa.y); blend_black(A2, Ab.x, iab.x); blend_black(A3, Ab.y, iab.y);
+        return;
+      }
       const f2 crg = {__uint_as_float(m_col.y), __uint_as_float(m_col.z)};
       const float cb = __uint_as_float(m_col.w);
       { const f2 b1 = {cb, 1.0f}; blend_pre(A0, crg * Aa.x, b1 * Aa.x, iaa.x); blend_pre(A1, crg * Aa.y, b1 * Aa.y, iaa.y);
@@ -1407,12 +1439,12 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? FDH_SLOW_WAVES : kPaths == 4 ? F
       f2 lxa, lxb, da, db;
       float pyy;
       edge_geom(r, mode == 9u, ellip, lxa, lxb, pyy, da, db);
-      edge_blend(r, mode, ellip, r.p2, r.p3, r.f0, r.f1, u32x4{r.col[0], r.col[1], r.col[2], r.col[3]}, lxa, lxb, pyy, da, db, A0, A1, A2, A3);
+      edge_blend(r, mode, ellip, false, r.p2, r.p3, r.f0, r.f1, u32x4{r.col[0], r.col[1], r.col[2], r.col[3]}, lxa, lxb, pyy, da, db, A0, A1, A2, A3);
     };
 #endif
     // One draw = one lambda call.  The record of the NEXT surviving draw is fetched (scalar loads) before the
     // current one is shaded, so the ~L2-latency of the fetch overlaps the shading arithmetic.
-    auto shade = [&](const uint32_t d, const DrawRec& r, const bool core) {
+    auto shade = [&](const uint32_t d, const DrawRec& r, const bool core, const bool inq) {
       const uint32_t om = r.op_mode;
       const uint32_t op = (om >> 12) & 15u;
       const uint32_t mode = om & 255u;
@@ -2076,6 +2108,9 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? FDH_SLOW_WAVES : kPaths == 4 ? F
       if (fill_mode != 0u) FDH_COUNT(4);
       const float t = (cy - r.oy) * r.inv_h;  // v of the quad (uv = (0,0)-(1,1) for SDF quads)
       const bool rowc = py >= r.by0 && py < r.by1;
+      // (wave-uniform) every pixel of the strip is covered by the quad: the strip lies in the draw's saturated core, which lies inside
+      // the quad (set_saturated_core), or k_bin_draws found it inside the quad's pixel bounds (BR_BOX_EXACT)
+      const bool all_cov = core || inq;
       float u[4];
       bool cov[4];
 #pragma unroll
@@ -2091,12 +2126,29 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? FDH_SLOW_WAVES : kPaths == 4 ? F
           for (int k = 0; k < 4; k++) col[k] = {c0.x * inv255, c0.y * inv255, c0.z * inv255, c0.w * inv255};
         } else {
           const F4 br = unpack255(r.col[1]), tr = unpack255(r.col[2]), tl = unpack255(r.col[3]);
+          // Which of the quad's two triangles interpolates (s > t: the upper one) is the same for every pixel of most strips -- the
+          // diagonal crosses few of them: then only that triangle's expression is evaluated (two FMAs per channel instead of four and a select)
+          const bool up_all = __all(u[0] > t && u[1] > t && u[2] > t && u[3] > t), low_all = __all(!(u[0] > t) && !(u[1] > t) && !(u[2] > t) && !(u[3] > t));
+          if (up_all) {
 #pragma unroll
-          for (int k = 0; k < 4; k++) {
-            col[k].x = tri_lerp(tl.x, c0.x, br.x, tr.x, u[k], t) * inv255;
-            col[k].y = tri_lerp(tl.y, c0.y, br.y, tr.y, u[k], t) * inv255;
-            col[k].z = tri_lerp(tl.z, c0.z, br.z, tr.z, u[k], t) * inv255;
-            col[k].w = tri_lerp(tl.w, c0.w, br.w, tr.w, u[k], t) * inv255;
+            for (int k = 0; k < 4; k++) {
+              col[k].x = tri_upper(tl.x, br.x, tr.x, u[k], t) * inv255; col[k].y = tri_upper(tl.y, br.y, tr.y, u[k], t) * inv255;
+              col[k].z = tri_upper(tl.z, br.z, tr.z, u[k], t) * inv255; col[k].w = tri_upper(tl.w, br.w, tr.w, u[k], t) * inv255;
+            }
+          } else if (low_all) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+              col[k].x = tri_lower(tl.x, c0.x, br.x, u[k], t) * inv255; col[k].y = tri_lower(tl.y, c0.y, br.y, u[k], t) * inv255;
+              col[k].z = tri_lower(tl.z, c0.z, br.z, u[k], t) * inv255; col[k].w = tri_lower(tl.w, c0.w, br.w, u[k], t) * inv255;
+            }
+          } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+              col[k].x = tri_lerp(tl.x, c0.x, br.x, tr.x, u[k], t) * inv255;
+              col[k].y = tri_lerp(tl.y, c0.y, br.y, tr.y, u[k], t) * inv255;
+              col[k].z = tri_lerp(tl.z, c0.z, br.z, tr.z, u[k], t) * inv255;
+              col[k].w = tri_lerp(tl.w, c0.w, br.w, tr.w, u[k], t) * inv255;
+            }
           }
         }
       }
@@ -2184,11 +2236,7 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? FDH_SLOW_WAVES : kPaths == 4 ? F
         }
         case 7u: {
 #pragma unroll
-          for (int k = 0; k < 4; k++) {
-            const float sd = dist[k] - spread;
-            const float sp = __builtin_fminf(shadow_profile(sd, r.f0), 1.0f);
-            alpha[k] = sd > 0.0f ? sp : 1.0f;
-          }
+          for (int k = 0; k < 4; k++) alpha[k] = shadow_profile(__builtin_fmaxf(dist[k] - spread, 0.0f), r.f0);  // (= sd > 0 ? min(profile, 1) : 1: edge_blend)
           break;
         }
         case 8u: {
@@ -2207,13 +2255,7 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? FDH_SLOW_WAVES : kPaths == 4 ? F
           for (int k = 0; k < 4; k++) sx[k] = lx[k] - r.p2;
           shape_distN<4>(ellip, sx, -ly + r.p3, qhx, qhy, r.r[0], r.r[1], r.r[2], r.r[3], shd);
 #pragma unroll
-          for (int k = 0; k < 4; k++) {
-            const float clip_a = cover_aa(dist[k], r.aa);
-            const float sd = shd[k] + spread;
-            const float sp = __builtin_fminf(shadow_profile(sd, r.f0), 1.0f);
-            const float ia = sd < 0.0f ? sp : 1.0f;
-            alpha[k] = clip_a * ia;
-          }
+          for (int k = 0; k < 4; k++) alpha[k] = cover_aa(dist[k], r.aa) * shadow_profile(__builtin_fminf(shd[k] + spread, 0.0f), r.f0);  // (edge_blend)
           break;
         }
         default: {  // ClipAA / BackdropBlur / others: atlas.frag:389-393
@@ -2250,18 +2292,51 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? FDH_SLOW_WAVES : kPaths == 4 ? F
         const F4 mc = unpack255(r.mid), sc = unpack255(r.stop);
         const F4 m01 = {mc.x * inv255, mc.y * inv255, mc.z * inv255, mc.w * inv255}, s01 = {sc.x * inv255, sc.y * inv255, sc.z * inv255, sc.w * inv255};
         const float mid = __builtin_fminf(__builtin_fmaxf(r.f1, 0.01f), 0.99f);
+        // evalFillColor (atlas.frag:233-250) picks the stop pair (start, mid) or (mid, end) per pixel by t <= mid.  A 32 x 8 strip
+        // nearly always lies on ONE side of the middle stop: then the pair is the same for the whole strip and the eight selects per
+        // pixel (and the select between the two weights) are not needed -- the operands they would have picked are used as they are
+        float tt[4];
+        bool lo_all = true, lo_none = true;
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-          const F4 fc = eval_fill_nb(col[k], m01, s01, fill_mode, mid, u[k], t);
-          sr[k] = fc.x; sg[k] = fc.y; sb[k] = fc.z; sa[k] = fc.w * alpha[k];
+        for (int k = 0; k < 4; k++) { tt[k] = fill_t(fill_mode, u[k], t); lo_all = lo_all && tt[k] <= mid; lo_none = lo_none && !(tt[k] <= mid); }
+        FDH_COUNT(__all(lo_all) ? 68 : __all(lo_none) ? 69 : 70);
+        if (__all(lo_all)) {
+          const float rw = frcp(mid);
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            const float w = tt[k] * rw;
+            sr[k] = mixf(col[k].x, m01.x, w); sg[k] = mixf(col[k].y, m01.y, w); sb[k] = mixf(col[k].z, m01.z, w); sa[k] = mixf(col[k].w, m01.w, w) * alpha[k];
+          }
+        } else if (__all(lo_none)) {
+          const float rw = frcp(1.0f - mid);
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            const float w = (tt[k] - mid) * rw;
+            sr[k] = mixf(m01.x, s01.x, w); sg[k] = mixf(m01.y, s01.y, w); sb[k] = mixf(m01.z, s01.z, w); sa[k] = mixf(m01.w, s01.w, w) * alpha[k];
+          }
+        } else {
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            const F4 fc = eval_fill_nb(col[k], m01, s01, fill_mode, mid, u[k], t);
+            sr[k] = fc.x; sg[k] = fc.y; sb[k] = fc.z; sa[k] = fc.w * alpha[k];
+          }
         }
       }
       // mask multiply (atlas.frag:401-404), rect mask (atlas_rect_mask.frag:425); outside the quad alpha is forced
       // to 0: blending with alpha 0 leaves the integer texel exactly as it is
-      blend(F0, sr[0], sg[0], sb[0], cov[0] ? sa[0] * mk0 * rm0 : 0.0f);
-      blend(F1, sr[1], sg[1], sb[1], cov[1] ? sa[1] * mk1 * rm1 : 0.0f);
-      blend(F2, sr[2], sg[2], sb[2], cov[2] ? sa[2] * mk2 * rm2 : 0.0f);
-      blend(F3, sr[3], sg[3], sb[3], cov[3] ? sa[3] * mk3 * rm3 : 0.0f);
+      // (the masked alphas are formed BEFORE the uniform branch, for both of its sides: as arms of the selects below they became a
+      // divergent branch around two multiplies in the builds with masks -- tools/lint_isa.py)
+      const float am[4] = {sa[0] * mk0 * rm0, sa[1] * mk1 * rm1, sa[2] * mk2 * rm2, sa[3] * mk3 * rm3};
+      FDH_COUNT(all_cov ? 66 : 67);
+      if (all_cov) {
+        blend(F0, sr[0], sg[0], sb[0], am[0]); blend(F1, sr[1], sg[1], sb[1], am[1]);
+        blend(F2, sr[2], sg[2], sb[2], am[2]); blend(F3, sr[3], sg[3], sb[3], am[3]);
+        return;
+      }
+      blend(F0, sr[0], sg[0], sb[0], cov[0] ? am[0] : 0.0f);
+      blend(F1, sr[1], sg[1], sb[1], cov[1] ? am[1] : 0.0f);
+      blend(F2, sr[2], sg[2], sb[2], cov[2] ? am[2] : 0.0f);
+      blend(F3, sr[3], sg[3], sb[3], cov[3] ? am[3] : 0.0f);
     };
     while (m != 0) {
       const int bit = __builtin_ctzll(m);
@@ -2270,6 +2345,12 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? FDH_SLOW_WAVES : kPaths == 4 ? F
       const uint32_t word = __builtin_amdgcn_readlane(idx, bit);
       const uint32_t d = word & LE_INDEX;
       const bool unclipped = !kMasks || (mask_depth == 0 && !rmask_on);
+#ifdef FDH_ABLATE_PATHS  // ablation builds (tools/ablate_paths.sh): what each path of the draw loop costs, by leaving it out
+      if ((FDH_ABLATE_PATHS & 1) && unclipped && (m_plainc & one) != 0ull) { touched = true; continue; }
+      if (unclipped && (m_simple & one) != 0ull && ((FDH_ABLATE_PATHS >> (1 + ((((word >> LE_PATH_SHIFT) & 15u) - 1u) & 3u))) & 1)) { touched = true; continue; }
+      if ((FDH_ABLATE_PATHS & 32) && !(unclipped && ((m_plainc | m_simple) & one) != 0ull) && (m_core & one) != 0ull) { touched = true; continue; }
+      if ((FDH_ABLATE_PATHS & 64) && !(unclipped && ((m_plainc | m_simple) & one) != 0ull) && (m_core & one) == 0ull) { touched = true; continue; }
+#endif
       if (unclipped && (m_plainc & one) != 0ull) {
         // One colour, coverage 1, nothing clipping: the whole strip gets the same source term.  Only the colour is
         // fetched (4 bytes instead of the 128-byte record) and nothing of the record is decoded.
@@ -2296,7 +2377,7 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? FDH_SLOW_WAVES : kPaths == 4 ? F
 #if FDH_EDGE_CHECK
         F4 S0 = F0, S1 = F1, S2 = F2, S3 = F3;
         simple_edge(r, mode, code > 4u, S0, S1, S2, S3);
-        shade(d, r, false);
+        shade(d, r, false, false);
         {
           const bool ellip = code > 4u;
           const float gS[16] = {S0.x, S0.y, S0.z, S0.w, S1.x, S1.y, S1.z, S1.w, S2.x, S2.y, S2.z, S2.w, S3.x, S3.y, S3.z, S3.w};
@@ -2314,7 +2395,8 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? FDH_SLOW_WAVES : kPaths == 4 ? F
           f2 lxa, lxb, da, db;
           float pyy;
           edge_geom(r, mode == 9u, ellip, lxa, lxb, pyy, da, db);
-          edge_blend(r, mode, ellip, r.p2, r.p3, r.f0, r.f1, u32x4{r.col[0], r.col[1], r.col[2], r.col[3]}, lxa, lxb, pyy, da, db, F0, F1, F2, F3);
+          const bool inq = (m_inq & one) != 0ull;
+          edge_blend(r, mode, ellip, inq, r.p2, r.p3, r.f0, r.f1, u32x4{r.col[0], r.col[1], r.col[2], r.col[3]}, lxa, lxb, pyy, da, db, F0, F1, F2, F3);
           // The draws that follow over the same quad and shape (the node's stroke, its inner shadows: LE_SHARE on the entry of
           // the draw before them) reuse the field: their entries are taken off the list here.  All conditions are wave-uniform.
           uint32_t wcur = word, dcur = d;
@@ -2335,7 +2417,7 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? FDH_SLOW_WAVES : kPaths == 4 ? F
             const uint32_t c42 = (code2 - 1u) & 3u;
             const uint32_t mode2 = c42 == 0u ? 3u : c42 == 1u ? 7u : c42 == 2u ? 9u : 12u;
             FDH_COUNT(57);
-            edge_blend(r, mode2, ellip, __uint_as_float(q.x), __uint_as_float(q.y), __uint_as_float(q.z), __uint_as_float(q.w), mcol, lxa, lxb, pyy, da, db, F0, F1, F2, F3);
+            edge_blend(r, mode2, ellip, (m_inq & one2) != 0ull, __uint_as_float(q.x), __uint_as_float(q.y), __uint_as_float(q.z), __uint_as_float(q.w), mcol, lxa, lxb, pyy, da, db, F0, F1, F2, F3);
           }
         }
 #endif
@@ -2347,7 +2429,7 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? FDH_SLOW_WAVES : kPaths == 4 ? F
 #if FDH_TIMING
       const unsigned long long Ts0 = FDH_NOW() + (r.op_mode & 0u);
 #endif
-      shade(d, r, core);
+      shade(d, r, core, (m_inq & one) != 0ull);
 #if FDH_TIMING
       {
         const unsigned long long Ts1 = FDH_NOW() + (__builtin_amdgcn_readfirstlane(__float_as_uint(F0.x + F1.x + F2.x + F3.x)) & 0u);
@@ -3977,9 +4059,9 @@ void debug_wave_times(unsigned long long* out) {
   void* p = nullptr;  // cleared after every read: the next read then holds exactly the launches in between
   if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_wave_times)) == hipSuccess) (void)hipMemset(p, 0, sizeof(unsigned long long) * 16 * 65536);
 }
-void debug_counters(unsigned long long out[64], bool reset) {
-  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_counters), 64 * sizeof(unsigned long long));
-  if (reset) { unsigned long long z[64] = {}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_counters), z, sizeof z); }
+void debug_counters(unsigned long long out[128], bool reset) {
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_counters), 128 * sizeof(unsigned long long));
+  if (reset) { unsigned long long z[128] = {}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_counters), z, sizeof z); }
 }
 #endif
 

@@ -227,6 +227,7 @@ void Recorder::commit_bins(uint32_t idx) {
   br.ix0 = r.ix0; br.iy0 = r.iy0; br.ix1 = r.ix1; br.iy1 = r.iy1;
   br.flags = binrec_flags(r);
   const BBox b = br.box;
+  if (op == OP_DRAW && (br.flags & BR_HAS_CORE) && !(br.flags & BR_GENERAL) && b.x0 == r.bx0 && b.y0 == r.by0 && b.x1 == r.bx1 && b.y1 == r.by1) br.flags |= BR_BOX_EXACT;
   lane_->boxes[idx] = bin_box_of(b, 6 + cx_->binbox_shift_);
   lane_->count_add(b);
   bbox_union(sum_.u, b);

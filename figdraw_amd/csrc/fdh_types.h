@@ -112,6 +112,12 @@ constexpr uint32_t BR_GENERAL = 4u;
 // bit 3: a quadratic-bezier stroke on an upright quad (modes 18 - 20): its bounds are the span's bounding box; k_bin_draws drops the
 // strips farther from the curve's chord-aligned box than any pixel with coverage can be (the same test the compositor applies per strip)
 constexpr uint32_t BR_CURVE = 8u;
+// bit 4: an upright SDF draw whose bounds ARE its quad's pixel bounds (DrawRec::bx0..by1): a strip that lies inside them is covered by
+// the quad at every pixel, and k_bin_draws says so in the entry (see the strip states below) -- the compositor then skips the
+// per-pixel quad test (eight compares / selects per strip-draw on the packed edge paths, sixteen on the generic one)
+constexpr uint32_t BR_BOX_EXACT = 16u;
+// A list entry's second word holds two bits per strip of the bin, bit s and bit 16 + s:  (1, 0) touched;  (1, 1) touched and inside the
+// draw's saturated core;  (0, 1) touched, not core, and wholly inside the quad (BR_BOX_EXACT draws only);  (0, 0) not touched.
 constexpr uint32_t LE_PLAIN = 1u << 31;  // axis-aligned SDF draw with ONE colour: on its core strips it is a uniform blend
 constexpr uint32_t LE_OPAQUE = 1u << 30;  // a fill whose source alpha is 255 everywhere: on its core strips it REPLACES the surface
 // bits 26..29: which straight-line shading path the draw's EDGE strips can take, decided on the host so that the

@@ -48,8 +48,9 @@ UNIFORM_KERNELS = tuple("k_composite_tilesILi%dELb%dE" % (paths, full) for paths
 EXEC_WRITE = re.compile(r"^\s*(s_\w*saveexec\w*|s_\w+\s+exec(_lo|_hi)?\b|v_cmpx_\w+)")
 
 
-def exec_writes_in_draw_loop(lines):
-    """lines: disassembly of one kernel.  Returns the offending lines inside the natural loops that hold s_ff1_i32_b64."""
+def draw_loop_body(lines):
+    """lines: disassembly of one kernel.  Returns the instructions (text) of the natural loops that hold s_ff1_i32_b64, in address
+    order, or None when there is no such loop."""
     ins = []  # (address, text)
     for l in lines:
         m = re.search(r"// ([0-9A-F]{12}):", l)
@@ -108,7 +109,7 @@ def exec_writes_in_draw_loop(lines):
                 changed = True
     marks = {blk_of[i] for i, (_, l) in enumerate(ins) if "s_ff1_i32_b64" in l}
     if not marks:
-        return ["(draw loop not found)"]
+        return None
     body = set()
     for u in range(n):
         for h in bsucc[u]:
@@ -126,11 +127,19 @@ def exec_writes_in_draw_loop(lines):
             if marks & loop:
                 body |= loop
     if not body:
-        return ["(draw loop not found)"]
+        return None
     out = []
     for k in sorted(body):
-        out += [ins[i][1].strip() for i in range(*blocks[k]) if EXEC_WRITE.search(ins[i][1])]
+        out += [ins[i][1].strip() for i in range(*blocks[k])]
     return out
+
+
+def exec_writes_in_draw_loop(lines):
+    """Returns the offending lines inside the natural loops that hold s_ff1_i32_b64."""
+    body = draw_loop_body(lines)
+    if body is None:
+        return ["(draw loop not found)"]
+    return [l for l in body if EXEC_WRITE.search(l)]
 
 
 def main():

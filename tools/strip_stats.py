@@ -12,7 +12,7 @@ from figdraw_amd.scenes import make_clip_mask_benchmark, make_curves_scene, make
 w, h = 3840, 2160
 ctx = ctx_mod.HipContext(device=0)
 L = ctx_mod.load()
-buf = (C.c_ulonglong * 64)()
+buf = (C.c_ulonglong * 128)()
 which = sys.argv[1] if len(sys.argv) > 1 else "bench"  # bench | rotated | curves | sub_clip | rect_mask (the reference's clip benchmark, 1200 x 800)
 if which in ("sub_clip", "rect_mask"): w, h = 1200, 800
 scene = {"bench": lambda: make_render_tree_100(w, h, frame=0, full_frame_blur=True), "rotated": lambda: make_rotated_tree(w, h, 0), "curves": lambda: make_curves_scene(w, h), "sub_clip": lambda: make_clip_mask_benchmark("sub_clip"), "rect_mask": lambda: make_clip_mask_benchmark("rect_mask")}[which]()
@@ -43,6 +43,10 @@ for code, n in enumerate(("", "fill", "drop shadow", "inner shadow", "AA stroke"
                           "AA stroke, elliptical")):
     if code:
         print(f"packed edge path {code} ({n:24s}) {c[48 + code]:10d}")
+for i, n in ((64, "packed edge: strip inside the quad (no per-pixel quad test)"), (65, "packed edge: quad test per pixel"), (71, "packed edge: black source"),
+             (66, "generic path: strip covered (core or inside the quad)"), (67, "generic path: quad test per pixel"),
+             (68, "3-stop fill: strip below the middle stop"), (69, "3-stop fill: strip above the middle stop"), (70, "3-stop fill: strip straddles the middle stop")):
+    print(f"{n:62s} {c[i]:10d}")
 if hasattr(L, "fdh_debug_wave_times") and os.environ.get("FDH_TIMING"):
     import numpy as np
     wt = np.zeros((65536, 16), dtype=np.uint64)
