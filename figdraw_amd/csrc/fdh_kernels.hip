@@ -281,13 +281,9 @@ __device__ __forceinline__ float median3(float a, float b, float c) {  // atlas.
 }
 
 // GL_LINEAR + GL_REPEAT fetch from one atlas level, texel-space coords (s*S - 0.5); returns 0..1 floats
-__device__ __forceinline__ F4 atlas_bilinear(const uint32_t* __restrict__ tex, int S, float x, float y) {
-  float fx = __builtin_floorf(x), fy = __builtin_floorf(y);
-  float ax = x - fx, ay = y - fy;
-  int m = S - 1;  // S is a power of two
-  int x0 = (int)fx & m, y0 = (int)fy & m, x1 = (x0 + 1) & m, y1 = (y0 + 1) & m;
-  F4 a = unpack255(tex[(size_t)y0 * S + x0]), b = unpack255(tex[(size_t)y0 * S + x1]);
-  F4 c = unpack255(tex[(size_t)y1 * S + x0]), d = unpack255(tex[(size_t)y1 * S + x1]);
+// the GL_LINEAR weighting of four RGBA8 texels (row y0: q00, q01; row y1: q10, q11), 0..1 floats
+__device__ __forceinline__ F4 bilinear_of(uint32_t q00, uint32_t q01, uint32_t q10, uint32_t q11, float ax, float ay) {
+  const F4 a = unpack255(q00), b = unpack255(q01), c = unpack255(q10), d = unpack255(q11);
   const float k = 1.0f / 255.0f;
   F4 o;
   o.x = (mixf(a.x, b.x, ax) * (1.0f - ay) + mixf(c.x, d.x, ax) * ay) * k;
@@ -295,6 +291,13 @@ __device__ __forceinline__ F4 atlas_bilinear(const uint32_t* __restrict__ tex, i
   o.z = (mixf(a.z, b.z, ax) * (1.0f - ay) + mixf(c.z, d.z, ax) * ay) * k;
   o.w = (mixf(a.w, b.w, ax) * (1.0f - ay) + mixf(c.w, d.w, ax) * ay) * k;
   return o;
+}
+__device__ __forceinline__ F4 atlas_bilinear(const uint32_t* __restrict__ tex, int S, float x, float y) {
+  float fx = __builtin_floorf(x), fy = __builtin_floorf(y);
+  float ax = x - fx, ay = y - fy;
+  int m = S - 1;  // S is a power of two
+  int x0 = (int)fx & m, y0 = (int)fy & m, x1 = (x0 + 1) & m, y1 = (y0 + 1) & m;
+  return bilinear_of(tex[(size_t)y0 * S + x0], tex[(size_t)y0 * S + x1], tex[(size_t)y1 * S + x0], tex[(size_t)y1 * S + x1], ax, ay);
 }
 // texture(atlasTex, uv) with LINEAR_MIPMAP_LINEAR min / LINEAR mag (glcontext.nim:157-169); lod = log2(rho)
 __device__ __forceinline__ F4 atlas_sample(const AtlasView& A, float u, float v, float lod) {
@@ -1738,6 +1741,110 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? FDH_SLOW_WAVES : kPaths == 4 ? F
         const uint32_t fill_mode = (om >> 9) & 7u;
         const bool is_mtsdf = (mode == 14u || mode == 16u), is_stroke = (mode == 15u || mode == 16u);
         float sr[4], sg[4], sb[4], sa[4];
+        // Round 5.  An MSDF image, or magnified / 1:1 under both triangles (lod <= 0: any glyph row, any image not shrunk): every pixel samples level 0
+        // with GL_LINEAR -- wave-uniform, so no per-lane branch stands between the lane's sixteen texel fetches (atlas_sample() below
+        // decides per pixel, and four dependent round trips per strip-draw made the 10 000-glyph rotated frame 4.5 x the upright one).
+        // And the texels any covered pixel can touch lie in the quad's own atlas rectangle (uv is a convex combination of the corners'):
+        // when that rectangle fits the strip's LDS window -- 64 x 12, 32 x 24 or 16 x 48 texels: every glyph -- the wave stages it with
+        // 16-byte runs and the taps come from LDS, as on the upright path.
+        if (mode != 0u || P.atlas.n_levels < 2 || (!(q.lod[0] > 0.0f) && !(q.lod[1] > 0.0f))) {  // (MSDF: textureLod(.., 0.0), atlas.frag:296-318)
+          const int S = P.atlas.size, msk = S - 1;
+          const float fS = (float)S;
+          const uint32_t* __restrict__ tex = P.atlas.level[0];
+          const bool shifted = mode == 0u && (om & F_SUBPIXEL) != 0u;
+          float ushift = 0.0f;
+          if (shifted) ushift = r.aux * frcp(__builtin_fmaxf(fS, 1.0f));  // (the same expression as the per-pixel form below)
+          float uK[4], vK[4], axK[4], ayK[4];
+          int fxi[4], fyi[4];
+          F4 colK[4];
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            const bool use1 = T1[k];
+            const float l0 = L0[k], l1 = L1[k], l2 = L2[k];
+            const float u0 = use1 ? utx : uax, v0 = uay, u1 = uax, v1 = use1 ? uay : uty;
+            uK[k] = l0 * u0 + l1 * u1 + l2 * utx;
+            vK[k] = l0 * v0 + l1 * v1 + l2 * uty;
+            colK[k] = {cBL.x * inv255, cBL.y * inv255, cBL.z * inv255, cBL.w * inv255};
+            if (!solid) {
+              const float c0x = use1 ? cTR.x : cTL.x, c0y = use1 ? cTR.y : cTL.y, c0z = use1 ? cTR.z : cTL.z, c0w = use1 ? cTR.w : cTL.w;
+              const float c1x = use1 ? cTL.x : cBL.x, c1y = use1 ? cTL.y : cBL.y, c1z = use1 ? cTL.z : cBL.z, c1w = use1 ? cTL.w : cBL.w;
+              colK[k].x = (l0 * c0x + l1 * c1x + l2 * cBR.x) * inv255;
+              colK[k].y = (l0 * c0y + l1 * c1y + l2 * cBR.y) * inv255;
+              colK[k].z = (l0 * c0z + l1 * c1z + l2 * cBR.z) * inv255;
+              colK[k].w = (l0 * c0w + l1 * c1w + l2 * cBR.w) * inv255;
+            }
+            float us = uK[k];
+            if (shifted) us -= ushift;
+            const float x = us * fS - 0.5f, y = vK[k] * fS - 0.5f;  // (atlas_sample: u S - 0.5)
+            const float fx = __builtin_floorf(x), fy = __builtin_floorf(y);
+            axK[k] = x - fx; ayK[k] = y - fy;
+            fxi[k] = (int)fx; fyi[k] = (int)fy;
+          }
+          // the quad's atlas rectangle in texels, a texel of slack on every side (the barycentrics sum to 1 only up to rounding)
+          const float ulo = __builtin_fminf(uax, utx) - __builtin_fabsf(ushift), uhi = __builtin_fmaxf(uax, utx) + __builtin_fabsf(ushift);
+          const float vlo = __builtin_fminf(uay, uty), vhi = __builtin_fmaxf(uay, uty);
+          const int wx0 = __builtin_amdgcn_readfirstlane((int)__builtin_floorf(ulo * fS - 0.5f)) - 1, wx1 = __builtin_amdgcn_readfirstlane((int)__builtin_floorf(uhi * fS - 0.5f)) + 2;
+          const int wy0 = __builtin_amdgcn_readfirstlane((int)__builtin_floorf(vlo * fS - 0.5f)) - 1, wy1 = __builtin_amdgcn_readfirstlane((int)__builtin_floorf(vhi * fS - 0.5f)) + 2;
+          const int WW = wx1 - wx0 + 1, WH = wy1 - wy0 + 1;  // texels
+          const int wsh = WW <= 16 ? 4 : WW <= 32 ? 5 : 6;    // log2 of the row stride in dwords: 768 dwords as 48 x 16, 24 x 32 or 12 x 64
+          const bool windowed = WW <= 64 && WH <= (768 >> wsh) && wx0 >= 0 && wy0 >= 0 && wx1 + 3 < S && wy1 < S;  // wave-uniform
+          uint32_t q00[4], q01[4], q10[4], q11[4];
+          if (windowed) {
+            uint32_t* const win = composite_lds + (P.has_masks ? kMaskDepth * 64 : 256);
+            {
+              const int lpr_sh = wsh - 2;  // lanes per window row = stride / 4
+              const int lr = lane >> lpr_sh, lc = (lane & ((1 << lpr_sh) - 1)) * 4, rpp = 64 >> lpr_sh;
+              const int cc = min(lc, (WW - 1) & ~3);
+              struct __attribute__((packed, aligned(4))) Run4 { uint32_t v[4]; };
+              for (int row0 = 0; row0 < WH; row0 += rpp) {  // (wave-uniform trip count: two passes for a 12 x 20 glyph)
+                const int row = min(row0 + lr, WH - 1);
+                const Run4 run = *reinterpret_cast<const Run4*>(tex + (((uint32_t)(wy0 + row)) << (uint32_t)__builtin_ctz((uint32_t)S)) + (uint32_t)(wx0 + cc));
+                uint4 q4 = {run.v[0], run.v[1], run.v[2], run.v[3]};
+                *reinterpret_cast<uint4*>(win + ((row0 + lr) << wsh) + lc) = q4;
+              }
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int k = 0; k < 4; k++) {  // (a pixel outside the quad may point anywhere: clamped into the window, blended with alpha 0)
+              const int lx = min(max(fxi[k] - wx0, 0), WW - 2), ly = min(max(fyi[k] - wy0, 0), WH - 2);
+              const uint32_t* w0 = win + (ly << wsh) + lx;
+              q00[k] = w0[0]; q01[k] = w0[1]; q10[k] = w0[1 << wsh]; q11[k] = w0[(1 << wsh) + 1];
+            }
+            __builtin_amdgcn_wave_barrier();  // (the next draw of this strip overwrites the window)
+          } else {
+            const char* __restrict__ texb = reinterpret_cast<const char*>(tex);
+            auto texel = [&](uint32_t off) __attribute__((always_inline)) { return *reinterpret_cast<const uint32_t*>(texb + off); };
+#pragma unroll
+            for (int k = 0; k < 4; k++) {  // GL_REPEAT, as atlas_bilinear()
+              const uint32_t x0 = (uint32_t)(fxi[k] & msk), x1 = (x0 + 1u) & (uint32_t)msk, y0 = (uint32_t)(fyi[k] & msk), y1 = (y0 + 1u) & (uint32_t)msk;
+              const uint32_t row0 = (y0 * (uint32_t)S) << 2, row1 = (y1 * (uint32_t)S) << 2;
+              q00[k] = texel(row0 + (x0 << 2)); q01[k] = texel(row0 + (x1 << 2));
+              q10[k] = texel(row1 + (x0 << 2)); q11[k] = texel(row1 + (x1 << 2));
+            }
+          }
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            const F4 t = bilinear_of(q00[k], q01[k], q10[k], q11[k], axK[k], ayK[k]);
+            if (mode == 0u) {  // wave-uniform; atlas.frag:284-295
+              sr[k] = t.x * colK[k].x; sg[k] = t.y * colK[k].y; sb[k] = t.z * colK[k].z; sa[k] = t.w * colK[k].w;
+            } else {  // atlas.frag:296-318
+              const bool use1 = T1[k];
+              const float fwu = use1 ? q.fw_u[1] : q.fw_u[0], fwv = use1 ? q.fw_v[1] : q.fw_v[0];
+              const F4 fc = eval_fill_rec(r, colK[k], fill_mode, uK[k], vK[k]);
+              const float sd = is_mtsdf ? t.w : median3(t.x, t.y, t.z);
+              const float unit = r.f0 * frcp(r.p0);  // pxRange / atlas size (atlas.frag:45-49)
+              const float spr = __builtin_fmaxf(0.5f * (unit * frcp(fwu) + unit * frcp(fwv)), 1.0f);
+              const float spd = spr * (sd - r.f1);
+              const float alpha = is_stroke ? clamp01(__builtin_fmaxf(r.p1, 0.0f) * 0.5f - __builtin_fabsf(spd) + 0.5f) : clamp01(spd + 0.5f);
+              sr[k] = fc.x; sg[k] = fc.y; sb[k] = fc.z; sa[k] = fc.w * alpha;
+            }
+          }
+          blend(F0, sr[0], sg[0], sb[0], cov[0] ? sa[0] * mk0 * rm0 : 0.0f);
+          blend(F1, sr[1], sg[1], sb[1], cov[1] ? sa[1] * mk1 * rm1 : 0.0f);
+          blend(F2, sr[2], sg[2], sb[2], cov[2] ? sa[2] * mk2 * rm2 : 0.0f);
+          blend(F3, sr[3], sg[3], sb[3], cov[3] ? sa[3] * mk3 * rm3 : 0.0f);
+          return;
+        }
 #pragma unroll
         for (int k = 0; k < 4; k++) {
           const bool use1 = T1[k];
