@@ -347,22 +347,18 @@ __device__ __forceinline__ void curve_boxes2(float Ax, float Ay, float Bx, float
 // Which of a bin's 16 strips (32x8 px; strip s = (jy*2 + jx)*4 + w sits at column jx, row jy*4 + w) a bin-relative
 // pixel box [x0,x1) x [y0,y1) touches.  The compositor's per-strip culling is then one bit test on the list entry
 // instead of a dependent bounding-box fetch.
+// strip rows (8 bits, row r = jy * 4 + w) x the two strip columns -> strip bits: column 0 holds rows 0..3 in bits 0..3 and rows 4..7 in
+// bits 8..11, column 1 the same four bits higher (closed form: the loop over the eight rows it replaces was a fifth of k_bin_draws<false>)
+__device__ __forceinline__ uint32_t strips_of_rows(uint32_t rows, bool col0, bool col1) {
+  const uint32_t c0 = (rows & 15u) | ((rows & 0xf0u) << 4);
+  return (col0 ? c0 : 0u) | (col1 ? c0 << 4 : 0u);
+}
 __device__ __forceinline__ uint32_t strip_mask(int x0, int y0, int x1, int y1) {
   x0 = x0 < 0 ? 0 : x0; y0 = y0 < 0 ? 0 : y0;
   x1 = x1 > kBin ? kBin : x1; y1 = y1 > kBin ? kBin : y1;
   const int r0 = y0 >> 3, r1 = (y1 + 7) >> 3;                   // strip rows [r0, r1) of 8
   const uint32_t rows = ((1u << r1) - 1u) & ~((1u << r0) - 1u);  // 8 bits
-  const uint32_t cols = (x0 < kTileW ? 1u : 0u) | (x1 > kTileW ? 2u : 0u);
-  uint32_t m = 0;
-#pragma unroll
-  for (int r = 0; r < 8; r++) {
-    if (rows & (1u << r)) {
-      const int jy = r >> 2, w = r & 3;
-      if (cols & 1u) m |= 1u << ((jy * 2 + 0) * 4 + w);
-      if (cols & 2u) m |= 1u << ((jy * 2 + 1) * 4 + w);
-    }
-  }
-  return m;
+  return strips_of_rows(rows, x0 < kTileW, x1 > kTileW);
 }
 
 // the strips of a bin that lie entirely inside a bin-relative pixel box (the draw's saturated core)
@@ -372,17 +368,7 @@ __device__ __forceinline__ uint32_t strip_mask_inside(int x0, int y0, int x1, in
   r0 = r0 < 0 ? 0 : r0; r1 = r1 > 8 ? 8 : r1;
   if (r1 <= r0) return 0u;
   const uint32_t rows = ((1u << r1) - 1u) & ~((1u << r0) - 1u);
-  const uint32_t cols = ((x0 <= 0 && x1 >= kTileW) ? 1u : 0u) | ((x0 <= kTileW && x1 >= 2 * kTileW) ? 2u : 0u);
-  uint32_t m = 0;
-#pragma unroll
-  for (int r = 0; r < 8; r++) {
-    if (rows & (1u << r)) {
-      const int jy = r >> 2, w = r & 3;
-      if (cols & 1u) m |= 1u << ((jy * 2 + 0) * 4 + w);
-      if (cols & 2u) m |= 1u << ((jy * 2 + 1) * 4 + w);
-    }
-  }
-  return m;
+  return strips_of_rows(rows, x0 <= 0 && x1 >= kTileW, x0 <= kTileW && x1 >= 2 * kTileW);
 }
 
 // List entry flags (uint2.x high bits; the low 30 bits are the draw index)
@@ -404,7 +390,17 @@ __device__ __forceinline__ bool binbox_hits(uint32_t q, uint32_t U) { return ((U
 // which a frame without them should not pay in occupancy: bench frame 5.4 us against 8.7)
 template <bool kRefine>
 __device__ __forceinline__ void bin_entry(const BinParams& P, int i, int x0, int y0, bool& hit, uint32_t& word, uint32_t& strips) {
-  const BinRec r = P.binrec[i];
+  // (the 24-byte BinRec in ONE round trip -- a 16- and an 8-byte load issued together, pinned: read field by field the compiler sank
+  // each field's load behind the test before it, three to four dependent L2 latencies per batch of hits)
+  BinRec r;
+  {
+    const uint2* __restrict__ src = reinterpret_cast<const uint2*>(P.binrec + i);
+    uint2 q0 = src[0], q1 = src[1], q2 = src[2];
+    asm volatile("" : "+v"(q0), "+v"(q1), "+v"(q2));
+    r.box.x0 = (int16_t)(q0.x & 0xffffu); r.box.y0 = (int16_t)(q0.x >> 16); r.box.x1 = (int16_t)(q0.y & 0xffffu); r.box.y1 = (int16_t)(q0.y >> 16);
+    r.ix0 = (int16_t)(q1.x & 0xffffu); r.iy0 = (int16_t)(q1.x >> 16); r.ix1 = (int16_t)(q1.y & 0xffffu); r.iy1 = (int16_t)(q1.y >> 16);
+    r.flags = q2.x; r.pad = q2.y;
+  }
   const BBox b = r.box;
   if (!(b.x0 < x0 + kBin && b.x1 > x0 && b.y0 < y0 + kBin && b.y1 > y0)) { hit = false; return; }  // exact test
   strips = strip_mask(b.x0 - x0, b.y0 - y0, b.x1 - x0, b.y1 - y0);
