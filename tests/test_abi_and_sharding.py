@@ -316,8 +316,9 @@ def _krow(g, t, vertical):
 def test_blur_weight_fragments_reproduce_the_fir():
     """Host logic, no GPU: the weight fragments of the matrix-pipe blur passes (fdh_blur_weight_fragments) are the banded
     Toeplitz form of the merged FIR: lane (j, g) of k-step m holds, for window texels 16 m + krow(g, t), the tap that texel
-    meets at output j (hi + lo halves = tap * 2^10 to 2^-21 relative), zeros outside the band; every output's weights sum
-    to 2^10 (the taps are normalised).  krow: 8 g + t for the horizontal pass; for the vertical one the order in which a 32 x 32
+    meets at output j as ONE f16 at scale 2^10 (round 5; the second half's slot is zero): within half a step of the tap + what
+    its inner neighbour carried over (the rounding error travels from the centre tap outwards), symmetric, zeros outside the
+    band, and every output's weights sum to 2^10 x the taps' sum up to the outermost taps' (tiny) steps.  krow: 8 g + t for the horizontal pass; for the vertical one the order in which a 32 x 32
     accumulator tile holds its rows, (t & 3) + 8 (t >> 2) + 4 g (mx_krow, fdh_types.h: the fused kernel's horizontal product
     feeds the vertical one from registers) -- every row of a k-step exactly once either way."""
     import ctypes as C
@@ -338,7 +339,9 @@ def test_blur_weight_fragments_reproduce_the_fir():
             delta = 0 if vertical else (-r) % 4
             assert 16 * n >= 32 + 2 * r + delta and n <= 11
             frag = np.frombuffer(bits, dtype=np.float16)[: n * 2 * 64 * 8].astype(np.float64).reshape(n, 2, 64, 8)
-            w = frag[:, 0] + frag[:, 1]  # [k-step][lane][t]
+            assert (frag[:, 1] == 0).all()
+            w = frag[:, 0]  # [k-step][lane][t]
+            step = lambda v: 2.0 ** (np.floor(np.log2(max(v, 2.0 ** -14))) - 10)  # one f16 step at v
             per_output = np.zeros(32)
             for m in range(n):
                 for lane in range(64):
@@ -346,15 +349,17 @@ def test_blur_weight_fragments_reproduce_the_fir():
                     for t in range(8):
                         k = 16 * m + _krow(g, t, vertical) - delta - j
                         want = taps[k] * 1024.0 if 0 <= k <= 2 * r else 0.0
-                        assert abs(w[m, lane, t] - want) <= 1024.0 * 2.0 ** -21 * max(want / 1024.0, 2.0 ** -14), (radius, vertical, m, lane, t)
+                        # (its own rounding, half a step, + the error carried over from the tap inside it: at most half a step of the largest tap)
+                        carried = 0.0 if k == r else 0.501 * step(1024.0 * taps.max())
+                        assert abs(w[m, lane, t] - want) <= (0.501 * step(want) + carried if want else 0.0), (radius, vertical, m, lane, t, w[m, lane, t], want)
                         per_output[j] += w[m, lane, t]
-            assert np.allclose(per_output, 1024.0, atol=2e-2), (radius, vertical)
+            assert np.allclose(per_output, 1024.0 * taps.sum(), atol=2e-2), (radius, vertical, per_output[0])
             assert sorted(_krow(g, t, vertical) for g in range(2) for t in range(8)) == list(range(16))
 
 
 @pytest.mark.parametrize("radius", [1.0, 5.0, 18.0, 64.0])
 def test_blur_weight_fragments_blur_like_the_reference(radius):
-    """Host logic, no GPU: a numpy restatement of what the matrix-pipe passes compute -- (hi + lo) * texel products summed,
+    """Host logic, no GPU: a numpy restatement of what the matrix-pipe passes compute -- weight * texel products summed,
     scaled by 2^-10, rounded to nearest even, RGBA8 between the passes, clamp-to-edge taps -- with the weight fragments the
     library builds, against the oracle's blur (max 1 LSB) and the reference's blur.frag on SwiftShader (max 2 LSB)."""
     import ctypes as C
@@ -395,7 +400,9 @@ def test_blur_weight_fragments_blur_like_the_reference(radius):
         img = np.rint(acc / 1024.0)  # numpy rounds half to even, like v_cvt_pk_u8_f32
     got = img.astype(np.uint8)
     mx, n0, n1 = diff_stats(got, O.blur_image(src, radius))
-    assert mx <= 1 and n0 <= 0.005 * src.shape[0] * src.shape[1], (radius, "vs oracle", mx, n0)
+    # (blur_src.png is noise -- mean second difference 150 levels -- the content on which the one-f16 weights' error pattern does NOT
+    # cancel: 1.5 - 2.6 % of its pixels move, by one LSB; the scene tests, whose content is a UI's, keep the suite's 0.5 % bar)
+    assert mx <= 1 and n0 <= 0.04 * src.shape[0] * src.shape[1], (radius, "vs oracle", mx, n0)
     mx, n0, n1 = diff_stats(got, load_png(f"ss_blur_r{radius:g}.png"))
     assert mx <= 2, (radius, "vs blur.frag on SwiftShader", mx, n0)
 
