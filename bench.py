@@ -884,8 +884,9 @@ def main():
                              passes={"horizontal": dict(hbm(bh, st.ms_blur_big_h), ms=round(st.ms_blur_big_h, 4), algorithmic_bytes=bh, traffic=th),
                                      "vertical": dict(hbm(bv, st.ms_blur_big_v), ms=round(st.ms_blur_big_v, 4), algorithmic_bytes=bv, traffic=tv)},
                              all_blur_launches_ms=round(st.ms_blur_h + st.ms_blur_v, 4),
-                             arithmetic="v_mfma_f32_32x32x16_f16, f32 accumulate: RGBA8 texels as exact f16 subnormals x weights split into "
-                                        "two f16 halves (22 bits), every product exact; <= 1 LSB from the f32 FIR",
+                             arithmetic="v_mfma_f32_32x32x16_f16, f32 accumulate: RGBA8 texels as exact f16 subnormals x the taps as one f16 each at scale 2^10 "
+                                        "(rounded from the centre tap outwards, the error carried from tap to tap; rounds 2 - 4: two halves, 22 bits, twice the MFMAs), "
+                                        "every product exact; <= 1 LSB from the f32 FIR at ~0.1 % of a UI frame's pixels (DESIGN.md section 4)",
                              bytes_note="H: region + halo rows read and written; V: those rows read, the region written; the fused composite reads the "
                                         "surface only where it has to blend (the cleared opaque surface of this frame: nowhere but the quad's border blocks)")
     if roofline_blur is not None and st_fx.ms_blur_fused > 0:
@@ -916,9 +917,16 @@ def main():
                          "traffic": fr.get("traffic"), "traffic_source": pmc_src,
                          "survey_8d_bytes": fr.get("survey_8d_bytes"),
                          "instruction_side": {"valu_instructions_per_launch": kfx.get("SQ_INSTS_VALU"), "mfma_busy_cycles_per_launch": kfx.get("SQ_VALU_MFMA_BUSY_CYCLES"),
-                                              "note": "the kernel is not limited by HBM: its SIMDs' cycles go to the two matrix-pipe products (80 v_mfma_f32_32x32x16_f16 per "
-                                                      "32 x 32 block) and the operand / pack VALU work around them (DESIGN.md section 4)"},
+                                              "note": "the kernel is not limited by HBM: its SIMDs' cycles go to the two matrix-pipe products (40 v_mfma_f32_32x32x16_f16 per "
+                                                      "32 x 32 block since the end of round 5, 80 before) and the operand / pack VALU work around them (DESIGN.md section 4)"},
                          "second_longest": {"kernel": "k_composite_tiles<4, true>", "ms_per_launch": round(st.ms_composite_main, 4), "see": "roofline_compositor"}}
+    elif roofline_blur is not None and "fused_route" in roofline_blur:
+        # (end of round 5: with one MFMA per operand the fused blur is the SHORTER of the two large launches again; the compositor -- VALU-bound, the
+        # FP32 vector peak its roofline -- is the longest and `roofline` is its; the blur stays in view here and in `roofline_blur.fused_route`)
+        fr = roofline_blur["fused_route"]
+        roofline_main = dict(roofline, second_longest={"kernel": "k_blur_fx<NKH, NKV>: the fused full-frame backdrop blur", "ms_per_launch": fr["ms"], "bound": "hbm",
+                                                       "unit": "GB/s", "peak": HBM_PEAK_GBS, "achieved": fr["achieved"], "frac": fr["frac"],
+                                                       "algorithmic_bytes_per_launch": fr["algorithmic_bytes"], "traffic": fr.get("traffic"), "see": "roofline_blur.fused_route"})
     frame_gbs = st.bytes_algorithmic / (ms_step * 1e-3) / 1e9
     single_dyn_ms = 1e3 * sd_elapsed / args.steps
     single_gbs = st.bytes_algorithmic / (single_dyn_ms * 1e-3) / 1e9

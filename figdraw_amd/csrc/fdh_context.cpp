@@ -661,6 +661,9 @@ static float half_value(uint16_t h) {
 // the exact taps: 0.00 - 0.23 % of a UI-like image's texels move, by one LSB; 0.4 - 1.0 % of white noise's.  Rounding every tap on its
 // own moves 0.3 - 1.0 % / 2 - 8 %; carrying the error from the outside in and letting the centre tap keep the sum, 0.2 - 0.7 %: the
 // centre tap's step is the coarsest of all.)  q[k], k = 0 .. 2 reach, in units of 2^-10.
+#ifndef FDH_MX_LO
+#define FDH_MX_LO 0  // (as in fdh_kernels.hip)
+#endif
 static void quantise_taps_f16(const BlurTaps& t, float* q) {
   const int r = t.reach;
   const double centre = (double)t.dense[kBlurPad + r] * 1024.0;
@@ -687,8 +690,13 @@ static void build_mx_weights(const BlurTaps& t, bool vertical, uint8_t* out) {
         // for the vertical one the order in which a 32 x 32 accumulator tile holds its rows, so that the fused kernel's horizontal
         // product feeds the vertical one from registers (k_blur_fx) -- any order serves as long as both operands use the same
         const int k = 16 * m + mx_krow(g, e, vertical) - delta - j;
+#if FDH_MX_LO  // (variant builds: the 22-bit weights of rounds 2 - 4, hi = RNE(w), lo = RNE(w - hi); the kernels then multiply twice)
+        const float w = (k >= 0 && k <= 2 * t.reach) ? t.dense[kBlurPad + k] * 1024.0f : 0.0f;
+        const uint16_t hi = half_bits_rne(w), lo = half_bits_rne(w - half_value(hi));
+#else
         const float w = (k >= 0 && k <= 2 * t.reach) ? q[k] : 0.0f;
         const uint16_t hi = half_bits_rne(w), lo = 0;  // (the fragment layout keeps the second half's slot: zeros)
+#endif
         o[(((size_t)(2 * m) * 64 + lane) * 8) + e] = hi;
         o[(((size_t)(2 * m + 1) * 64 + lane) * 8) + e] = lo;
       }

@@ -2849,8 +2849,8 @@ __global__ __launch_bounds__(kSmallThreads) void k_blur_small(BlurParams P) {
 // matrix pipe (v_mfma_f32_32x32x16_f16, f32 accumulate) the arithmetic drops under the memory time.
 //   * texels need no conversion: a byte b in the low bits of a half IS the subnormal b * 2^-24, and the matrix pipe honours
 //     f16 subnormals (tools/microbench/mfma_f16_probe.hip) -- one v_perm_b32 builds two operand halves of one channel;
-//   * weights w * 2^10 are split hi + lo into two halves (22 significant bits; every product is exact in f32), both
-//     MFMAs accumulate into the same f32 tile, so out = acc * 2^14;
+//   * weights: the taps at scale 2^10 as ONE f16 each (round 5: FDH_MX_LO below; rounds 2 - 4 split them hi + lo, 22 bits, two
+//     MFMAs per operand); every product with an 8-bit texel is exact in f32, so out = acc * 2^14;
 //   * operands: A[i][k] = Toeplitz weights (i = output inside the block), B[k][j] = texels (j = lane & 31: a column for the
 //     vertical pass, a row for the horizontal one; k = 16 texels along the filter direction per MFMA, lane group g = lane >> 5
 //     holds k = 8 g .. 8 g + 7); D[i][j]: lane (j, g), register r <-> i = (r & 3) + 8 (r >> 2) + 4 g.

@@ -463,8 +463,10 @@ FDH_API int fdh_saturated_core(const float rect[4], const float radii_x[4], cons
                                float spread, const float shape[2], float aa, int out_px[4]);
 /* Diagnostic, host-only: the tap table of a backdrop blur of `blur_radius` (the merged FIR of blur.frag:11-32, glcontext.nim
  * :1743-1786: dense weights over offsets -reach..+reach into `dense`, capacity >= 133) and the weight fragments the
- * matrix-pipe pass (vertical != 0: vertical pass) multiplies with: k-steps x {hi, lo} x 64 lanes x 8 binary16 values into
- * `frag_bits` (capacity >= 11 * 2 * 64 * 8).  Returns the tap reach in *reach and the number of k-steps in *k_steps. */
+ * matrix-pipe pass (vertical != 0: vertical pass) multiplies with: k-steps x 2 x 64 lanes x 8 binary16 values into
+ * `frag_bits` (capacity >= 11 * 2 * 64 * 8) -- the first of the two halves holds the taps at scale 2^10, one binary16 each, rounded
+ * from the centre tap outwards with the rounding error carried to the next tap; the second half (rounds 2 - 4: the low part of a
+ * 22-bit weight) is zero.  Returns the tap reach in *reach and the number of k-steps in *k_steps. */
 FDH_API int fdh_blur_weight_fragments(float blur_radius, int vertical, float* dense, uint16_t* frag_bits, int* reach, int* k_steps);
 FDH_API const char* fdh_version(void);
 
