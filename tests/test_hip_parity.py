@@ -254,6 +254,43 @@ def test_every_blur_path_matches_oracle(path):
         assert n0 <= 0.005 * w * h, (path, name, "vs oracle: too many 1-LSB pixels", n0)
 
 
+def test_matrix_pipe_blur_weights_keep_flat_colours():
+    """The matrix-pipe passes multiply the taps as ONE f16 each (round 5): the rounding error is carried from the
+    centre tap outwards so that the weights still sum to 1 (to ~1e-7).  A flat backdrop must therefore come out of a full-frame blur
+    node exactly as it went in, for every filter width, both on the fused route and on the two passes, through a transparent and
+    through a tinting node -- FDH_FORCE_BLUR_PATH=3 puts every blur on the matrix pipe (a child process)."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+
+    w, h = 512, 192
+    radii = [0.8, 1.0, 2.5, 5.0, 9.0, 13.0, 18.0, 27.5, 40.0, 64.0]
+    colours = [(37, 129, 255, 255), (255, 255, 255, 255), (1, 2, 3, 255), (200, 100, 50, 255)]
+    code = (
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "from ref_scenes import Fig, FigKind, RenderList, Renders, rect, rgba, RECT\n"
+        "from figdraw_amd.context import HipContext\n"
+        "ctx = HipContext(device=0)\n"
+        "bad = []\n"
+        "for route in (1, 0):\n"
+        "    ctx.set_blur_route(route)\n"
+        "    for radius in %r:\n"
+        "        for c in %r:\n"
+        "            lst = RenderList()\n"
+        "            lst.addRoot(Fig(kind=RECT, screenBox=rect(0, 0, %d, %d), fill=rgba(*c)))\n"
+        "            lst.addRoot(Fig(kind=FigKind.nkBackdropBlur, screenBox=rect(0, 0, %d, %d), fill=rgba(0, 0, 0, 0), blur=radius))\n"
+        "            sc = Renders(); sc.layers[0] = lst\n"
+        "            ctx.render_frame(sc, %d, %d); got = ctx.read_pixels()\n"
+        "            if not (got == np.array(c, dtype=np.uint8)).all(): bad.append((route, radius, c, int((got != np.array(c, dtype=np.uint8)).any(axis=2).sum())))\n"
+        "print('BAD', bad)\n"
+        "sys.exit(1 if bad else 0)\n"
+    ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)), radii, colours, w, h, w, h, w, h)
+    r = subprocess.run([sys.executable, "-c", code], env={**os.environ, "FDH_FORCE_BLUR_PATH": "3"}, capture_output=True, text=True)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
+
+
 def test_contexts_in_flight_do_not_disturb_each_other(hip):
     """bench.py keeps several frames in flight on one GPU (one context = one stream + surface set each): every context
     must end up with exactly the frame it renders alone."""
