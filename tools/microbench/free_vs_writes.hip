@@ -10,7 +10,7 @@
 //                                                   mode 4: hipExtMallocWithFlags(Uncached) once, kept (the process-wide store's way)
 //                                                   mode 0: nothing (control)
 // Every k_check reports words of Y that are not v: lost or stale data of the launches before it on its own stream.
-// hipcc --offload-arch=gfx950 -O2 -pthread tools/microbench/free_vs_writes.hip -o build/free_vs_writes ; usage: free_vs_writes <mode> [seconds] [writers]
+// hipcc --offload-arch=gfx950 -O2 -pthread tools/microbench/free_vs_writes.hip -o build/free_vs_writes ; usage: free_vs_writes <mode> [seconds] [writers] [fresh]
 #include <hip/hip_runtime.h>
 #include <immintrin.h>
 
@@ -38,6 +38,49 @@ __global__ void k_check(const uint32_t* p, size_t n, uint32_t v, uint32_t* bad, 
 
 static std::atomic<bool> g_stop{false};
 static std::atomic<uint64_t> g_rounds{0}, g_bad_rounds{0}, g_bad_words{0}, g_churn{0};
+
+// "fresh" writers (usage: 5th argument 1): what a fresh context does -- every round allocates its buffers anew, clears them with
+// hipMemsetAsync (a marker byte, as the library's FDH_POISON build does), renders into them and gives them back; a wrong word that
+// holds the marker is the CLEAR landing after (or a stale line of it surviving) the kernel's stores
+static int g_fresh = 0;
+static std::atomic<uint64_t> g_marker_words{0};
+__global__ void k_check_marker(const uint32_t* p, size_t n, uint32_t v, uint32_t marker, uint32_t* bad, uint32_t* first, uint32_t* n_marker) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const uint32_t want = (v + (uint32_t)(n - 1 - i)) ^ 0x5a5a5a5au;
+    if (p[i] != want) {
+      if (atomicAdd(bad, 1u) == 0) { first[0] = (uint32_t)i; first[1] = p[i]; first[2] = want; }
+      if (p[i] == marker) atomicAdd(n_marker, 1u);
+    }
+  }
+}
+static void writer_fresh(int t) {
+  CK(hipSetDevice(0));
+  hipStream_t s;
+  CK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  const size_t n = (size_t)1 << 20;
+  uint32_t* bad;
+  CK(hipHostMalloc((void**)&bad, 64, 0));
+  for (uint32_t it = 1; !g_stop.load(std::memory_order_relaxed); it++) {
+    const uint32_t v = it * 2654435761u + (uint32_t)t;
+    uint32_t *x, *y;
+    CK(hipMalloc((void**)&x, n * 4));
+    CK(hipMalloc((void**)&y, n * 4));
+    CK(hipMemsetAsync(x, 0x11, n * 4, s));
+    CK(hipMemsetAsync(y, 0xA5, n * 4, s));
+    bad[0] = 0; bad[4] = 0;
+    hipLaunchKernelGGL(k_fill, dim3(512), dim3(256), 0, s, x, n, v);
+    hipLaunchKernelGGL(k_copy, dim3(512), dim3(256), 0, s, x, y, n);
+    hipLaunchKernelGGL(k_check_marker, dim3(512), dim3(256), 0, s, y, n, v, 0xA5A5A5A5u, bad, bad + 1, bad + 4);
+    CK(hipStreamSynchronize(s));
+    g_rounds++;
+    if (bad[0]) {
+      g_bad_words += bad[0]; g_marker_words += bad[4];
+      if (g_bad_rounds++ < 8) std::printf("  fresh writer %d round %u: %u of %zu words wrong (%u hold the clear's marker); first at %u: got %08x want %08x\n", t, it, bad[0], n, bad[4], bad[1], bad[2], bad[3]);
+    }
+    CK(hipFree(x)); CK(hipFree(y));
+  }
+  (void)hipHostFree(bad); (void)hipStreamDestroy(s);
+}
 
 static void writer(int t) {
   CK(hipSetDevice(0));
@@ -95,16 +138,18 @@ static void churn(int mode) {
 
 int main(int argc, char** argv) {
   const int mode = argc > 1 ? std::atoi(argv[1]) : 1, seconds = argc > 2 ? std::atoi(argv[2]) : 10, writers = argc > 3 ? std::atoi(argv[3]) : 3;
+  g_fresh = argc > 4 ? std::atoi(argv[4]) : 0;
   CK(hipSetDevice(0));
   std::vector<std::thread> th;
-  for (int t = 0; t < writers; t++) th.emplace_back(writer, t);
+  for (int t = 0; t < writers; t++) th.emplace_back(g_fresh ? writer_fresh : writer, t);
   std::thread c(churn, mode);
   std::this_thread::sleep_for(std::chrono::seconds(seconds));
   g_stop = true;
   for (auto& x : th) x.join();
   c.join();
   static const char* names[] = {"no churn", "hipExtMallocWithFlags(Uncached) + hipFree", "hipMalloc + hipFree, 4 - 256 KB", "hipMalloc + hipFree, 8 MB", "Uncached blocks kept, CPU stores only"};
-  std::printf("free_vs_writes: mode %d (%s), %d writers, %d s: %llu rounds, %llu churn batches; rounds with wrong words: %llu (words %llu)\n", mode, names[mode], writers, seconds,
-              (unsigned long long)g_rounds.load(), (unsigned long long)g_churn.load(), (unsigned long long)g_bad_rounds.load(), (unsigned long long)g_bad_words.load());
+  std::printf("free_vs_writes: mode %d (%s), %d %swriters, %d s: %llu rounds, %llu churn batches; rounds with wrong words: %llu (words %llu, holding the clear's marker %llu)\n", mode, names[mode], writers,
+              g_fresh ? "FRESH (malloc + memset + free per round) " : "", seconds,
+              (unsigned long long)g_rounds.load(), (unsigned long long)g_churn.load(), (unsigned long long)g_bad_rounds.load(), (unsigned long long)g_bad_words.load(), (unsigned long long)g_marker_words.load());
   return g_bad_rounds.load() ? 1 : 0;
 }
