@@ -927,6 +927,20 @@ def main():
         roofline_main = dict(roofline, second_longest={"kernel": "k_blur_fx<NKH, NKV>: the fused full-frame backdrop blur", "ms_per_launch": fr["ms"], "bound": "hbm",
                                                        "unit": "GB/s", "peak": HBM_PEAK_GBS, "achieved": fr["achieved"], "frac": fr["frac"],
                                                        "algorithmic_bytes_per_launch": fr["algorithmic_bytes"], "traffic": fr.get("traffic"), "see": "roofline_blur.fused_route"})
+    # how the matrix-pipe blur kernels hold a tap: asked of the library itself (the lo halves of its weight fragments are zero in the one-f16 build)
+    import ctypes as C
+
+    _dense, _bits, _reach, _nk = (C.c_float * 160)(), (C.c_uint16 * (11 * 2 * 64 * 8))(), C.c_int(), C.c_int()
+    ctx.L.fdh_blur_weight_fragments.argtypes = [C.c_float, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_uint16), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    weights_bits = None
+    if ctx.L.fdh_blur_weight_fragments(18.0, 0, _dense, _bits, C.byref(_reach), C.byref(_nk)) == 0:
+        fr_bits = np.frombuffer(_bits, dtype=np.uint16)[: _nk.value * 2 * 64 * 8].reshape(_nk.value, 2, 64, 8)
+        weights_bits = 22 if fr_bits[:, 1].any() else 11
+    if roofline_blur is not None:
+        roofline_blur["weights_bits"] = weights_bits
+        roofline_blur["weights"] = ("each tap ONE f16 at scale 2^10, rounding error carried to the next tap out; products u8 (as f16 subnormal) x f16 -> f32 accumulators on the "
+                                    "matrix pipe; blur.frag computes in f32.  Worst case 255 sum|w - w^| = 0.09 LSB per pass before the RGBA8 rounding "
+                                    "(tests/test_abi_and_sharding.py); on white noise / a 1-px checkerboard vs blur.frag on SwiftShader: profiles/r06_blur_weights_pin.txt")
     frame_gbs = st.bytes_algorithmic / (ms_step * 1e-3) / 1e9
     single_dyn_ms = 1e3 * sd_elapsed / args.steps
     single_gbs = st.bytes_algorithmic / (single_dyn_ms * 1e-3) / 1e9
@@ -946,7 +960,10 @@ def main():
             dt = time.perf_counter() - c0
             if dt >= 12.0 or n_frames >= 64:
                 break
-        cpu_baseline = {"value": round(n_frames * w * h / dt / 1e6, 3), "unit": "Mpixels/s", "cores": cores, "kind": "port",
+        cpu_baseline = {"value": round(n_frames * w * h / dt / 1e6, 3), "unit": "Mpixels/s", "cores": cores, "kind": "port", "threads_cap": 16,
+                        "threads_cap_reason": "the oracle is GL-structured on purpose (one full pass over the quad per draw, rows split over threads, a join per draw: "
+                                              "it is the checker and mirrors the reference's draw-by-draw blending); past ~16 threads the 700 fork/joins per frame cost "
+                                              f"more than the rows they save.  Host has {os.cpu_count()} hardware threads",
                         "sample": f"{n_frames} frames (frame = 0..{n_frames - 1}) of the same {w}x{h} scene ({st.n_draws} draws each), "
                                   f"oracle/figdraw_oracle.c, OpenMP over rows, {dt:.1f} s"}
         if n_frames > 1:  # parity check below compares frame 0
@@ -980,7 +997,7 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32",
+        "dtype": "f32 (blur taps: u8 x f16 -> f32 MFMA)",
         "data": "synthetic",
         "config": {"workload": f"S300@4K: renderlist_100 scene at {w}x{h}, 300 shadowed SDF rects + full-frame and 360x240 "
                                f"2-pass Gaussian backdrop blur(18) (BASELINE.json configs[2])",

@@ -116,17 +116,18 @@ void vram_context_born(int device) {
 }
 // The last device context of a device is gone: its store keeps at most kVramStoreKeep bytes (largest blocks go first -- one huge
 // frame must not pin its HBM for the life of the process).  Called with the device idle (the context has synchronised its stream).
+// The blocks are unmapped UNDER g_vram_mu, and a context counts itself in (vram_context_born) before it creates its stream: freeing
+// uncached BAR-visible blocks while another context renders is the trigger of round 4's stale-line faults, so
+// while a trim runs no context of the device exists and none can come to exist -- a constructor on another thread waits at the lock.
 void vram_context_gone(int device) {
   if (device < 0 || device >= kMaxDevices) return;
+  std::lock_guard<std::mutex> lk(g_vram_mu);
+  if (--g_vram_contexts[device] > 0) return;
   std::vector<void*> drop;
-  {
-    std::lock_guard<std::mutex> lk(g_vram_mu);
-    if (--g_vram_contexts[device] > 0) return;
-    size_t held = 0;
-    for (int k = 0; k < 48; k++) held += g_vram_free[device][k].size() << k;
-    for (int k = 47; k >= 12 && held > kVramStoreKeep; k--)
-      while (!g_vram_free[device][k].empty() && held > kVramStoreKeep) { drop.push_back(g_vram_free[device][k].back()); g_vram_free[device][k].pop_back(); held -= (size_t)1 << k; }
-  }
+  size_t held = 0;
+  for (int k = 0; k < 48; k++) held += g_vram_free[device][k].size() << k;
+  for (int k = 47; k >= 12 && held > kVramStoreKeep; k--)
+    while (!g_vram_free[device][k].empty() && held > kVramStoreKeep) { drop.push_back(g_vram_free[device][k].back()); g_vram_free[device][k].pop_back(); held -= (size_t)1 << k; }
   if (drop.empty()) return;
   DeviceScope scope(device);
   (void)hipDeviceSynchronize();
@@ -151,15 +152,22 @@ Context::Context(int atlas_size, float pixel_scale, int device, uint32_t flags) 
   // host writes into device memory through the BAR pass the GPU's host data path, which may hold them: its flush register (mapped
   // for exactly this: HSA_AMD_AGENT_INFO_HDP_FLUSH) is written before the launches that read the staging mirrors (Context::prepare)
   hdp_flush_reg_ = prop.hdpMemFlushCntl;
-  FDH_HIP(hipStreamCreateWithFlags(&own_stream_, hipStreamNonBlocking));
-  stream_ = own_stream_;
-  for (auto& e : ev_) FDH_HIP(hipEventCreate(&e));
-  for (auto& e : staging_ev_) FDH_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-  initial_atlas_size_ = atlas_size > 0 ? atlas_size : 1024;  // newContext default, glcontext.nim:255-261
-  alloc_atlas(initial_atlas_size_);
-  static const bool env_sync = [] { const char* e = std::getenv("FDH_SYNC_SUBMIT"); return e && std::atoi(e) != 0; }();
-  if (!(flags & FDH_CREATE_SYNC_SUBMIT) && !env_sync) worker_ = std::thread([this] { worker_main(); });
+  // counted in BEFORE the first piece of device state: from here on no trim of the staging store can run (vram_context_gone); a
+  // constructor that fails below counts itself out again (the destructor of a half-built object never runs)
   vram_context_born(device_);
+  try {
+    FDH_HIP(hipStreamCreateWithFlags(&own_stream_, hipStreamNonBlocking));
+    stream_ = own_stream_;
+    for (auto& e : ev_) FDH_HIP(hipEventCreate(&e));
+    for (auto& e : staging_ev_) FDH_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    initial_atlas_size_ = atlas_size > 0 ? atlas_size : 1024;  // newContext default, glcontext.nim:255-261
+    alloc_atlas(initial_atlas_size_);
+    static const bool env_sync = [] { const char* e = std::getenv("FDH_SYNC_SUBMIT"); return e && std::atoi(e) != 0; }();
+    if (!(flags & FDH_CREATE_SYNC_SUBMIT) && !env_sync) worker_ = std::thread([this] { worker_main(); });
+  } catch (...) {
+    vram_context_gone(device_);
+    throw;
+  }
 }
 
 Context::~Context() {
@@ -661,9 +669,6 @@ static float half_value(uint16_t h) {
 // the exact taps: 0.00 - 0.23 % of a UI-like image's texels move, by one LSB; 0.4 - 1.0 % of white noise's.  Rounding every tap on its
 // own moves 0.3 - 1.0 % / 2 - 8 %; carrying the error from the outside in and letting the centre tap keep the sum, 0.2 - 0.7 %: the
 // centre tap's step is the coarsest of all.)  q[k], k = 0 .. 2 reach, in units of 2^-10.
-#ifndef FDH_MX_LO
-#define FDH_MX_LO 0  // (as in fdh_kernels.hip)
-#endif
 static void quantise_taps_f16(const BlurTaps& t, float* q) {
   const int r = t.reach;
   const double centre = (double)t.dense[kBlurPad + r] * 1024.0;

@@ -2876,10 +2876,8 @@ template <int c> __device__ __forceinline__ h8 mx_frag(const uint32_t (&R)[8]) {
 // with the rounding error carried from tap to tap (fdh_context.cpp, build_mx_weights): 11 bits each, their sum kept, the error an
 // alternating pattern that smooth content cancels.  Against the exact taps 0.07 - 0.35 % of a UI-like frame's texels move by one LSB
 // (the suite's oracle bars -- at most 1 LSB, at most 0.5 % of the pixels -- are unchanged and met).
-// -DFDH_MX_LO=1 (make variant) restores the second MFMA per operand, for fragments built with both halves.
-#ifndef FDH_MX_LO
-#define FDH_MX_LO 0
-#endif
+// -DFDH_MX_LO=1 (make variant) restores the second MFMA per operand, for fragments built with both halves (the switch lives in
+// fdh_types.h: the host side builds the fragments, the device side multiplies them, and the two must agree).
 #ifndef FDH_MX_H_EXTRA
 #define FDH_MX_H_EXTRA 0
 #endif

@@ -2,6 +2,14 @@
 #pragma once
 #include <stdint.h>
 
+// How the matrix-pipe blur passes hold a tap: 0 = ONE f16 at scale 2^10, rounding error carried to the next tap out (the product build,
+// round 5: quantise_taps_f16 in fdh_context.cpp); 1 = hi + lo, 22 bits, two MFMAs per operand (rounds 2 - 4; `make variant
+// DEFS=-DFDH_MX_LO=1`, what tools/blur_weights_pin.py measures the product build against).  ONE definition: the host side builds the weight
+// fragments and the kernels multiply them, an object built without the define would silently drop the lo halves.
+#ifndef FDH_MX_LO
+#define FDH_MX_LO 0
+#endif
+
 namespace fdh {
 
 // Tile geometry: the shading unit is the 8x8 pixel tile; one wavefront (64 lanes) shades four of them side by

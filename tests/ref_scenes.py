@@ -41,6 +41,22 @@ def rgb_boxes_sdf(w=800.0, h=600.0) -> Renders:
     return out
 
 
+def rgb_boxes(w=800.0, h=600.0) -> Renders:
+    """tests/trender_rgb_boxes.nim:12-100 (golden: tests/expected/render_rgb_boxes.png): the solid-colour twin of rgb_boxes_sdf."""
+    lst = RenderList()
+    root = lst.addRoot(Fig(kind=RECT, screenBox=rect(0, 0, w, h), fill=rgba(255, 255, 255, 255)))
+    lst.addChild(root, Fig(kind=RECT, corners=[10, 20, 30, 40], screenBox=rect(60, 60, 220, 140),
+                           fill=rgba(220, 40, 40, 255), stroke=RenderStroke(weight=5.0, fill=fill(rgba(0, 0, 0, 255)))))
+    lst.addChild(root, Fig(kind=RECT, screenBox=rect(320, 120, 220, 140), fill=rgba(40, 180, 90, 255),
+                           shadows=[RenderShadow(style=DROP, blur=10, spread=10, x=10, y=10, fill=fill(rgba(0, 0, 0, 55)))]))
+    lst.addChild(root, Fig(kind=RECT, screenBox=rect(180, 300, 220, 140), fill=rgba(60, 90, 220, 255),
+                           shadows=[RenderShadow(style=INNER, blur=12, spread=0, x=-6, y=-6, fill=fill(rgba(55, 55, 55, 155))),
+                                    RenderShadow(style=INNER, blur=12, spread=0, x=6, y=6, fill=fill(rgba(255, 255, 255, 255)))]))
+    out = Renders()
+    out.layers[0] = lst
+    return out
+
+
 def oneframe(w=240.0, h=160.0) -> Renders:
     """tests/tfigrender_oneframe_screenshot.nim:20-42."""
     lst = RenderList()
@@ -333,6 +349,7 @@ def rotation_and_transform(w=320.0, h=240.0) -> Renders:
 REFERENCE_PNG_SCENES = {
     # name: (builder, width, height, reference golden png under tests/expected/)
     "rgb_boxes_sdf": (rgb_boxes_sdf, 800, 600, "render_rgb_boxes_sdf.png"),
+    "rgb_boxes": (rgb_boxes, 800, 600, "render_rgb_boxes.png"),
     "linear_gradient": (linear_gradient, 800, 600, "render_linear_gradient.png"),
     "layers_clip": (lambda w, h: layers_clip(w, h, False), 800, 375, "render_layers_clip.png"),
     "layers_rect_mask": (lambda w, h: layers_clip(w, h, True), 800, 375, "render_layers_clip.png"),
@@ -602,6 +619,46 @@ def random_scene(seed: int, w: float, h: float, n: int = 40, clips: bool = True,
             c = rnd.randrange(0, 30)
             lst.addRoot(Fig(kind=FigKind.nkBackdropBlur, screenBox=rect(rnd.uniform(0, w - bw), rnd.uniform(0, h - bh), bw, bh),
                             corners=[c] * 4, fill=rgba(0, 0, 0, 0), blur=rnd.choice([3.0, 9.0, 18.0, 40.0])))
+    out = Renders()
+    out.layers[0] = lst
+    return out
+
+
+# Hostile content for the backdrop blur (glsl/blur.frag:11-32): the product's matrix-pipe passes multiply each tap as one f16, so their
+# error is largest where neighbouring texels are uncorrelated.  Opaque white noise and a 0 / 255 checkerboard of 1-pixel cells, at a size
+# that takes the matrix-pipe kernels without being forced to (>= 384 K pixels, fdh_context.cpp Context::prepare).  The sources are rebuilt
+# from this recipe; tests/golden/ss_blur_big_<kind>_r<radius>.png holds what the reference's blur.frag makes of them on SwiftShader.
+# Powers of two on purpose: SwiftShader samples on a 16-bit normalised coordinate grid (oracle.texcoord_model), on which the texel centres
+# of a 1024 x 512 surface lie exactly.  At 896 x 448 they do not, and with radius 64 -- tap step 8 px: every tap ON a texel centre, the
+# exact result is the checkerboard itself -- each tap leaks up to 0.7 % of its neighbour: SwiftShader's frame then reads 2..3 / 252..253
+# where blur.frag's own arithmetic gives 0 / 255, a property of that rasteriser's sampler, not of the shader.
+HOSTILE_BLUR_SIZE = (1024, 512)
+HOSTILE_BLUR_KINDS = ("noise", "checker")
+HOSTILE_BLUR_RADII = (5.0, 18.0, 64.0)
+HOSTILE_BLUR_KEY = 0x626C7572
+
+
+def hostile_blur_source(kind):
+    import numpy as np
+
+    w, h = HOSTILE_BLUR_SIZE
+    if kind == "noise":
+        src = np.random.default_rng(20260).integers(0, 256, size=(h, w, 4), dtype=np.uint8)
+    elif kind == "checker":
+        yy, xx = np.mgrid[0:h, 0:w]
+        src = np.repeat((((xx + yy) & 1) * 255).astype(np.uint8)[:, :, None], 4, axis=2)
+    else:
+        raise ValueError(kind)
+    src[:, :, 3] = 255  # opaque: drawn 1:1 it REPLACES the frame, so the frame the blur node snapshots is the source itself
+    return np.ascontiguousarray(src)
+
+
+def hostile_blur_scene(radius):
+    """the source as a 1:1 image over the whole frame, then one transparent full-frame nkBackdropBlur: the frame is blur(source)"""
+    w, h = HOSTILE_BLUR_SIZE
+    lst = RenderList()
+    lst.addRoot(Fig(kind=FigKind.nkImage, screenBox=rect(0, 0, w, h), image_id=HOSTILE_BLUR_KEY))
+    lst.addRoot(Fig(kind=FigKind.nkBackdropBlur, screenBox=rect(0, 0, w, h), fill=rgba(0, 0, 0, 0), blur=radius))
     out = Renders()
     out.layers[0] = lst
     return out

@@ -291,6 +291,45 @@ def test_matrix_pipe_blur_weights_keep_flat_colours():
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
 
 
+@pytest.mark.parametrize("kind", RS.HOSTILE_BLUR_KINDS)
+@pytest.mark.parametrize("radius", RS.HOSTILE_BLUR_RADII)
+def test_matrix_pipe_blur_on_hostile_content_matches_blur_frag(kind, radius, capsys):
+    """The matrix-pipe passes (k_blur_fx, k_blur_mx) multiply every tap as ONE f16 with the rounding error carried outwards -- the one place
+    where the product's arithmetic is deliberately narrower than blur.frag's float (glsl/blur.frag:11-32, glcontext.nim:1743-1786).  UI
+    content forgives that; this is the content that does not: opaque white noise and a 0 / 255 checkerboard of 1-pixel cells at a size the
+    kernels take natively (no FDH_FORCE_BLUR_PATH), both routes, against what the reference's own shader makes of it on SwiftShader
+    (tests/golden/ss_blur_big_*.png, north-star bar: 2 LSB) and against the oracle (1 LSB).  The counts are printed: tools/blur_weights_pin.py
+    commits them next to those of the 22-bit hi + lo build (profiles/r06_blur_weights_pin.txt)."""
+    from figdraw_amd.context import HipContext
+    from oracle import oracle as O
+
+    w, h = RS.HOSTILE_BLUR_SIZE
+    src = RS.hostile_blur_source(kind)
+    gold = load_png(f"ss_blur_big_{kind}_r{radius:g}.png")
+    want = O.blur_image(src, radius)
+    ctx = HipContext(device=0, atlas_size=2048)
+    ctx.put_image(RS.HOSTILE_BLUR_KEY, src)
+    sc = RS.hostile_blur_scene(radius)
+    for route, field in ((1, "ms_blur_fused"), (0, "ms_blur_big_h")):
+        ctx.set_blur_route(route)
+        ctx.render_frame(sc, w, h)
+        got = ctx.read_pixels()
+        ctx.profile(1)
+        assert getattr(ctx.frame_stats(), field) > 0, (route, "the frame did not take the matrix-pipe kernel this test is about")
+        g_mx, g_n0, g_n1 = diff_stats(got, gold)
+        o_mx, o_n0, o_n1 = diff_stats(got, want)
+        with capsys.disabled():
+            print(f"\n  blur r={radius:g} {kind} route={route}: vs blur.frag golden max {g_mx} LSB ({g_n0} px differ, {g_n1} by > 1); vs oracle max {o_mx} ({o_n0} px)", end="")
+        assert g_mx <= 2, (kind, radius, route, "vs the reference shader's frame", g_mx, g_n0, g_n1)
+        assert o_mx <= 1, (kind, radius, route, "vs oracle", o_mx, o_n0, o_n1)
+        # one f16 per tap moves 0.4 - 1.0 % of white noise's texels by one step against the exact taps (fdh_context.cpp quantise_taps_f16);
+        # the checkerboard's exact result sits ON a rounding tie (127.5) wherever the tap step is not a whole number of pixels, so there
+        # the count says nothing and only the maxima are asserted
+        if kind == "noise":
+            assert o_n0 <= 0.02 * w * h, (kind, radius, route, o_n0)
+    ctx.close()
+
+
 def test_contexts_in_flight_do_not_disturb_each_other(hip):
     """bench.py keeps several frames in flight on one GPU (one context = one stream + surface set each): every context
     must end up with exactly the frame it renders alone."""

@@ -92,6 +92,16 @@ def test_blur_matches_reference_blur_frag(radius):
     assert mx <= 1
 
 
+@pytest.mark.parametrize("kind", RS.HOSTILE_BLUR_KINDS)
+@pytest.mark.parametrize("radius", RS.HOSTILE_BLUR_RADII)
+def test_blur_of_hostile_content_matches_reference_blur_frag(kind, radius):
+    """white noise and a 1-pixel checkerboard, 1024 x 512 (ref_scenes.hostile_blur_source): the frames the GPU suite holds the
+    matrix-pipe kernels to pin the oracle first"""
+    out = O.blur_image(RS.hostile_blur_source(kind), radius)
+    mx, n0, n1 = diff_stats(out, load_png(f"ss_blur_big_{kind}_r{radius:g}.png"))
+    assert mx <= 1
+
+
 # The call-stream tests below run twice: on the oracle's front-end and on the HIP library's own front-end
 # (figdraw_amd/csrc/fdh_frontend.cpp behind the C ABI, a FDH_CREATE_RECORD_ONLY context: no GPU needed).  The known answers
 # are the reference's (tests/ttransform.nim, tests/trender_rgb_boxes_sdf.nim); both restatements have to give them.

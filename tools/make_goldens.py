@@ -48,6 +48,24 @@ def stats(a, b):
     return {"max": int(d.max()), "n_gt0": int((d > 0).sum()), "n_gt1": int((d > 1).sum())}
 
 
+def big_blur_goldens():
+    """blur.frag (glsl/blur.frag:11-32, two passes with RGBA8 between them: glcontext.nim:1743-1786) over HOSTILE content at a size the
+    product blurs on its matrix-pipe kernels without being forced to (>= 384 K pixels): opaque white noise and a 0 / 255 checkerboard,
+    both rebuilt from their recipe by the tests (ref_scenes.hostile_blur_source) -- only the blurred frames are stored."""
+    out = {}
+    w, h = RS.HOSTILE_BLUR_SIZE
+    for kind in RS.HOSTILE_BLUR_KINDS:
+        src = RS.hostile_blur_source(kind)
+        for radius in RS.HOSTILE_BLUR_RADII:
+            gl = R.RefGL(w, h)
+            ss = gl.blur_only(src, radius)
+            gl.close()
+            Image.fromarray(ss).save(os.path.join(GOLD, f"ss_blur_big_{kind}_r{radius:g}.png"), optimize=True)
+            out[f"blur_big_{kind}_r{radius:g}"] = {"width": w, "height": h, "oracle_vs_swiftshader": stats(O.blur_image(src, radius), ss)}
+            print("blur_big", kind, radius, out[f"blur_big_{kind}_r{radius:g}"])
+    return out
+
+
 def main():
     assert R.available(), "needs /root/reference and SwiftShader"
     os.makedirs(GOLD, exist_ok=True)
@@ -117,9 +135,17 @@ def main():
         Image.fromarray(out).save(os.path.join(GOLD, f"ss_blur_r{radius:g}.png"))
         manifest[f"blur_r{radius:g}"] = {"oracle_vs_swiftshader": stats(O.blur_image(src, radius), out)}
         print("blur", radius, manifest[f"blur_r{radius:g}"])
+    manifest.update(big_blur_goldens())
     with open(os.path.join(GOLD, "manifest.json"), "w") as f:
         json.dump(manifest, f, indent=1, sort_keys=True)
 
 
 if __name__ == "__main__":
-    main()
+    if sys.argv[1:] == ["big_blur"]:  # only the hostile-content blur frames (the manifest keeps its other entries)
+        with open(os.path.join(GOLD, "manifest.json")) as f:
+            m = json.load(f)
+        m.update(big_blur_goldens())
+        with open(os.path.join(GOLD, "manifest.json"), "w") as f:
+            json.dump(m, f, indent=1, sort_keys=True)
+    else:
+        main()
