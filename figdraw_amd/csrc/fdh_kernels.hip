@@ -2548,7 +2548,7 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? FDH_SLOW_WAVES : kPaths == 4 ? F
   if (lane == 0 && blockIdx.x < 65536) {
     const unsigned long long T1 = FDH_NOW();
     unsigned long long* row = g_wave_times + 16 * (size_t)blockIdx.x;
-    row[0] = T1 - T0; row[1] = T_cnt; row[2] = T_cull; row[3] = T_rec; row[4] = T_shade; row[5] = n_draws_t; row[6] = 1; row[7] = T_cull_core * 1024 + n_core_t;
+    row[0] = T1 - T0; row[1] = T0 + (T_cnt & 0ull) /* absolute start: tools/wave_timeline.py */; row[2] = T_cull; row[3] = T_rec; row[4] = T_shade; row[5] = n_draws_t; row[6] = 1; row[7] = T_cull_core * 1024 + n_core_t;
     for (int i = 0; i < 4; i++) { row[8 + i] = T_mode[i]; row[12 + i] = N_mode[i]; }
   }
 #endif

@@ -13,9 +13,10 @@ w, h = 3840, 2160
 ctx = ctx_mod.HipContext(device=0)
 L = ctx_mod.load()
 buf = (C.c_ulonglong * 128)()
-which = sys.argv[1] if len(sys.argv) > 1 else "bench"  # bench | rotated | curves | sub_clip | rect_mask (the reference's clip benchmark, 1200 x 800)
+which = sys.argv[1] if len(sys.argv) > 1 else "bench"  # bench | bench1080 (BASELINE config 2: the same tree at 1920 x 1080, no full-frame blur) | rotated | curves | sub_clip | rect_mask (the reference's clip benchmark, 1200 x 800)
 if which in ("sub_clip", "rect_mask"): w, h = 1200, 800
-scene = {"bench": lambda: make_render_tree_100(w, h, frame=0, full_frame_blur=True), "rotated": lambda: make_rotated_tree(w, h, 0), "curves": lambda: make_curves_scene(w, h), "sub_clip": lambda: make_clip_mask_benchmark("sub_clip"), "rect_mask": lambda: make_clip_mask_benchmark("rect_mask")}[which]()
+if which == "bench1080": w, h = 1920, 1080
+scene = {"bench1080": lambda: make_render_tree_100(w, h, frame=0), "bench": lambda: make_render_tree_100(w, h, frame=0, full_frame_blur=True), "rotated": lambda: make_rotated_tree(w, h, 0), "curves": lambda: make_curves_scene(w, h), "sub_clip": lambda: make_clip_mask_benchmark("sub_clip"), "rect_mask": lambda: make_clip_mask_benchmark("rect_mask")}[which]()
 ctx.render_frame(scene, w, h)
 ctx.replay(5)
 ctx.sync()
@@ -70,6 +71,6 @@ if hasattr(L, "fdh_debug_wave_times") and os.environ.get("FDH_TIMING"):
           np.percentile(wt[:, 0], 50) / 1000, np.percentile(wt[:, 0], 90) / 1000, wt[:, 0].max() / 1000)
 if c[56]:
     n = c[56]
-    print(f"timing build: {n} waves, mean per wave in kilo-cycles (s_memtime): total {c[50] / n / 1000:.2f}  counts-load {c[51] / n / 1000:.2f}  "
+    print(f"timing build: {n} waves, mean per wave in kilo-cycles (s_memtime): total {c[50] / n / 1000:.2f}  "
           f"cull {c[52] / n / 1000:.2f}  record-wait {c[53] / n / 1000:.2f}  shade {c[54] / n / 1000:.2f}  draws/wave {c[55] / n:.2f}")
 print("strips:", (w // 32) * (h // 8))
