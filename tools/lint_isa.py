@@ -45,7 +45,9 @@ def code_objects(blob: bytes):
 UNIFORM_KERNELS = tuple("k_composite_tilesILi%dELb%dE" % (paths, full) for paths in (4, 0, 2) for full in (1, 0))
 # writes of the exec mask: s_*saveexec*, any scalar instruction whose destination is exec / exec_lo / exec_hi, and the VOPC
 # compares that write exec directly (v_cmpx_*)
-EXEC_WRITE = re.compile(r"^\s*(s_\w*saveexec\w*|s_\w+\s+exec(_lo|_hi)?\b|v_cmpx_\w+)")
+# (s_cmp_* / s_bitcmp* name exec as a SOURCE and write SCC only -- `s_cmp_lg_u64 exec, 0` is a wave vote over a condition the
+# compiler folded to true --: not writes)
+EXEC_WRITE = re.compile(r"^\s*(s_\w*saveexec\w*|(?!s_cmp_|s_bitcmp)s_\w+\s+exec(_lo|_hi)?\b|v_cmpx_\w+)")
 
 
 def draw_loop_body(lines):

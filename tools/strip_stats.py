@@ -72,5 +72,5 @@ if hasattr(L, "fdh_debug_wave_times") and os.environ.get("FDH_TIMING"):
 if c[56]:
     n = c[56]
     print(f"timing build: {n} waves, mean per wave in kilo-cycles (s_memtime): total {c[50] / n / 1000:.2f}  "
-          f"cull {c[52] / n / 1000:.2f}  record-wait {c[53] / n / 1000:.2f}  shade {c[54] / n / 1000:.2f}  draws/wave {c[55] / n:.2f}")
+          f"record-wait {c[53] / n / 1000:.2f}  shade {c[54] / n / 1000:.2f}  draws/wave {c[55] / n:.2f}")
 print("strips:", (w // 32) * (h // 8))

@@ -27,28 +27,34 @@ print(f"{w}x{h}: timing build composite_main {st.ms_composite_main * 1000:.1f} u
 buf = (C.c_ulonglong * 128)()
 L.fdh_debug_counters(buf, 1)
 wt = np.zeros((65536, 16), dtype=np.uint64)
-L.fdh_debug_wave_times(wt.ctypes.data_as(C.c_void_p))  # reset
+L.fdh_debug_wave_times.argtypes = [C.c_void_p]
+L.fdh_debug_wave_times(wt.ctypes.data)  # (a read clears the rows)
 ctx.replay(1)
 ctx.sync()
-L.fdh_debug_wave_times(wt.ctypes.data_as(C.c_void_p))
-ok = wt[:, 6] == 1
+L.fdh_debug_wave_times(wt.ctypes.data)
+print("rows with any entry:", int((wt != 0).any(axis=1).sum()), " column 6 values:", np.unique(wt[:, 6])[:5])
+ok = wt[:, 0] != 0  # (column 6, the "row written" flag, reads 0 on this toolchain; a duration never does)
 t = wt[ok].astype(np.float64)
-start, dur, draws = t[:, 1], t[:, 0], t[:, 5]
-# (the later phases' launches overwrite the low rows; the full-frame launch is the bulk: keep waves that start within its span)
-t0 = np.percentile(start, 1)
-keep = (start >= t0 - 1e5) & (start < t0 + 5e6)
-start, dur, draws = start[keep] - start[keep].min(), dur[keep], draws[keep]
-end = start + dur
+print("rows flagged:", int(ok.sum()))
+WALL = 100.0  # wall_clock64: 100 MHz, one counter for the whole device (clock64 is per XCD)
+start, end, cyc, draws = t[:, 1] / WALL, t[:, 2] / WALL, t[:, 0], t[:, 5]
+# (the later phases' launches overwrite the low rows; the full-frame launch is the bulk: keep the waves that start within 200 us of the median start)
+keep = np.abs(start - np.median(start)) < 200.0
+start, end, cyc, draws = start[keep], end[keep], cyc[keep], draws[keep]
+t0 = start.min()
+start -= t0
+end -= t0
+dur = end - start
 span = end.max()
-MHZ = span / (st.ms_composite_main * 1000.0)  # ticks per us, calibrated: the launch's span in ticks against its measured time (clock64 = shader clock, ~2.1 - 2.4 GHz)
-print(f"clock: {MHZ:.0f} ticks per us (span of the launch in ticks / its event-timed duration)")
-print(f"waves {len(start)}, span {span / MHZ:.1f} us, sum of wave durations {dur.sum() / MHZ / 1e3:.1f} ms = {dur.sum() / span:.0f} waves in flight on average (6144 slots at 6 per SIMD)")
-print(f"wave duration us: p10 {np.percentile(dur, 10) / MHZ:.1f}  p50 {np.percentile(dur, 50) / MHZ:.1f}  p90 {np.percentile(dur, 90) / MHZ:.1f}  p99 {np.percentile(dur, 99) / MHZ:.1f}  max {dur.max() / MHZ:.1f}")
+print(f"waves {len(start)}, span {span:.1f} us (event-timed launch: {st.ms_composite_main * 1000:.1f}), sum of wave durations {dur.sum() / 1e3:.1f} ms = {dur.sum() / span:.0f} waves in flight on average (6144 slots at 6 per SIMD)")
+print(f"shader clock: {np.median(cyc[dur > 1] / dur[dur > 1]):.0f} cycles per us")
+print(f"wave duration us: p10 {np.percentile(dur, 10):.1f}  p50 {np.percentile(dur, 50):.1f}  p90 {np.percentile(dur, 90):.1f}  p99 {np.percentile(dur, 99):.1f}  max {dur.max():.1f}")
 print(f"draws shaded per wave: p50 {np.percentile(draws, 50):.0f}  p90 {np.percentile(draws, 90):.0f}  p99 {np.percentile(draws, 99):.0f}  max {draws.max():.0f}  total {draws.sum():.0f}")
 for lo, hi in ((0, 0), (1, 4), (5, 9), (10, 19), (20, 29), (30, 39), (40, 59), (60, 999)):
     m = (draws >= lo) & (draws <= hi)
     if m.any():
-        print(f"  waves with {lo:3d}..{hi:3d} draws: {int(m.sum()):6d}   duration mean {dur[m].mean() / MHZ:6.2f} us  ({dur[m].mean() / max(draws[m].mean(), 1) / MHZ * 1e3:6.0f} ns per draw)   start mean {start[m].mean() / MHZ:6.2f} us")
-print("waves in flight at deciles of the span:", [int(((start <= f * span) & (end > f * span)).sum()) for f in np.linspace(0.05, 0.95, 10)])
-last = np.argsort(end)[-5:]
-print("the five waves that end last: (start us, duration us, draws)", [(round(start[i] / MHZ, 1), round(dur[i] / MHZ, 1), int(draws[i])) for i in last])
+        print(f"  waves with {lo:3d}..{hi:3d} draws: {int(m.sum()):6d}   duration mean {dur[m].mean():6.2f} us  ({dur[m].sum() / max(draws[m].sum(), 1) * 1e3:6.0f} ns per draw)   start mean {start[m].mean():6.2f} us   end max {end[m].max():6.2f}")
+print("waves in flight at 5 %, 15 %, .. 95 % of the span:", [int(((start <= f * span) & (end > f * span)).sum()) for f in np.linspace(0.05, 0.95, 10)])
+print("waves started by then:                            ", [int((start <= f * span).sum()) for f in np.linspace(0.05, 0.95, 10)])
+last = np.argsort(end)[-6:]
+print("the six waves that end last: (start us, duration us, draws)", [(round(float(start[i]), 1), round(float(dur[i]), 1), int(draws[i])) for i in last])
