@@ -39,7 +39,7 @@ class FrameStats(C.Structure):
                 ("ms_host_launch", C.c_float), ("clear_folded", C.c_float),
                 ("ms_blur_big_h", C.c_float), ("ms_blur_big_v", C.c_float), ("bytes_blur_big_h", C.c_int64), ("bytes_blur_big_v", C.c_int64),
                 ("fragments_main_by_mode", C.c_int64 * 4), ("fragments_main_elliptical", C.c_int64), ("fragments_main_other", C.c_int64),
-                ("flops_composite_main", C.c_int64), ("ms_blur_fused", C.c_float), ("_reserved2", C.c_float),
+                ("flops_composite_main", C.c_int64), ("ms_blur_fused", C.c_float), ("deep_bins", C.c_float),
                 ("bytes_blur_fused", C.c_int64), ("bytes_frame_implementation", C.c_int64)]
 
 

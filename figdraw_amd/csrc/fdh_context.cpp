@@ -194,6 +194,7 @@ Context::~Context() {
   for (auto& m : misc_) m.release();
   for (auto& e : staging_ev_) if (e) (void)hipEventDestroy(e);
   if (seq_host_) (void)hipHostFree((void*)seq_host_);
+  if (deep_host_) (void)hipHostFree((void*)deep_host_);
   if (own_stream_) (void)hipStreamDestroy(own_stream_);
   for (auto& l : merge_lane_) l.reset();  // (their staging blocks go to the store before the store is looked at)
   vram_context_gone(device_);
@@ -1236,6 +1237,22 @@ void Context::launch_frame(const LaunchJob& J, bool profile, uint32_t upload_seq
     order_nb_ = order_key;
     order_valid_ = true;
   }
+  // Quarter strips for the frame's longest lists (k_composite_tiles, round 6): the sorting waves of earlier full-frame launches left, per
+  // class of bins, how many hold at least deep_min draws; that many leading positions of the order (x 8 classes) get four waves per
+  // strip.  Whatever value is there serves -- a frame or two stale, 0 before the first launch has run: any count is a correct schedule.
+  static const int deep_min = [] { const char* e = std::getenv("FDH_DEEP_MIN"); return e ? std::atoi(e) : kDeepMinDefault; }();
+  int deep_k8 = 0;
+  if (sorting && deep_min > 0) {
+    if (!deep_host_) {
+      FDH_HIP(hipHostMalloc((void**)&deep_host_, 64, hipHostMallocDefault));
+      for (int c = 0; c < 8; c++) deep_host_[c] = 0;
+    }
+    if (order_now) {
+      uint32_t most = 0;
+      for (int c = 0; c < 8; c++) most = std::max(most, (uint32_t)deep_host_[c]);
+      deep_k8 = 8 * (int)std::min<uint32_t>(most, 1024u);
+    }
+  }
   // The surface that holds the live image.  A fused full-frame blur renders out of place and flips it; a frame that flips an odd
   // number of times ends in alt_, and the two pointers trade places: the frame surface IS the one the frame ended in
   // (fdh_frame_device_ptr is asked again after every frame).  Phase 0 always starts in fb_, i.e. on the surface the previous
@@ -1312,6 +1329,10 @@ void Context::launch_frame(const LaunchJob& J, bool profile, uint32_t upload_seq
     C.n_wg = 0;
     C.order = full ? order_now : nullptr;
     C.order_next = full ? order_next : nullptr;
+    C.deep_k8 = full ? deep_k8 : 0;
+    if (full) stats_.deep_bins = (float)((ph.has_slow || ph.has_rot || ph.has_atlas || ph.has_masks || !order_now || !order_next) ? 0 : std::min(deep_k8, 8 * ((nb + 7) / 8)));
+    C.deep_min = deep_min;
+    C.deep_out = (full && order_next && deep_min > 0) ? const_cast<uint32_t*>(deep_host_) : nullptr;
     C.has_slow = ph.has_slow ? 1 : 0;
     C.has_rot = ph.has_rot ? 1 : 0;
     C.has_atlas = ph.has_atlas ? 1 : 0;

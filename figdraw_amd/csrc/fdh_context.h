@@ -623,6 +623,7 @@ class Context : public Recorder {
   hipEvent_t staging_ev_[kStaging] = {};
   char staging_busy_[kStaging] = {};     // 0: free; 1: until staging_ev_ fires; 2: until *seq_host_ reaches staging_seq_ (Context::issue)
   uint32_t staging_seq_[kStaging] = {};
+  volatile uint32_t* deep_host_ = nullptr;  // pinned, 8 words: bins per class with lists of at least deep_min draws, written by the compositor's sorting waves
   volatile uint32_t* seq_host_ = nullptr;  // pinned: the sequence number of the last frame whose bin launch has started (k_bin_draws)
   uint32_t upload_seq_ = 0;
   void wait_staging(int slot);             // calling thread: until the set's last upload has run

@@ -53,6 +53,12 @@ struct CompositeParams {
   uint32_t* mask_spill;     // clip-stack levels beyond kMaskDepth: [level - kMaskDepth][strip][lane] (null when no frame nests that deep)
   size_t spill_stride;      // dwords per level = strips of the frame x 64
   AtlasView atlas;
+  // quarter strips (round 6, k_composite_tiles): the first deep_k8 positions of `order` (a multiple of 8) are shaded by four waves per
+  // strip; deep_min / deep_out: the sorting waves count the bins with at least deep_min draws per class into deep_out[0..7]
+  // (pinned host memory, or null)
+  int deep_k8 = 0;
+  int deep_min = 0;
+  uint32_t* deep_out = nullptr;
 };
 
 struct BlurParams {

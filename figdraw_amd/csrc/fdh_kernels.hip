@@ -1255,7 +1255,7 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? FDH_SLOW_WAVES : kPaths == 4 ? F
   };
   constexpr bool kMasks = (kPaths & 4) == 0;  // <4>: a phase without clip / rect-mask operations -- no mask registers, no stack
 #if FDH_TIMING
-  const unsigned long long T0 = FDH_NOW();
+  const unsigned long long T0 = FDH_NOW(), W0 = wall_clock64();
   unsigned long long T_cull = 0, T_rec = 0, T_shade = 0, T_cnt = 0, n_draws_t = 0, T_cull_core = 0, n_core_t = 0;
   unsigned long long T_mode[4] = {0, 0, 0, 0}, N_mode[4] = {0, 0, 0, 0};  // edge draws by mode: 3, 7, 9, 12
 #endif
@@ -2548,7 +2548,7 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? FDH_SLOW_WAVES : kPaths == 4 ? F
   if (lane == 0 && blockIdx.x < 65536) {
     const unsigned long long T1 = FDH_NOW();
     unsigned long long* row = g_wave_times + 16 * (size_t)blockIdx.x;
-    row[0] = T1 - T0; row[1] = T0 + (T_cnt & 0ull) /* absolute start: tools/wave_timeline.py */; row[2] = T_cull; row[3] = T_rec; row[4] = T_shade; row[5] = n_draws_t; row[6] = 1; row[7] = T_cull_core * 1024 + n_core_t;
+    row[0] = T1 - T0; row[1] = W0 + (T_cnt & 0ull); row[2] = wall_clock64() + (T_cull & 0ull);  // (wall clock, 100 MHz, one counter for the device: tools/wave_timeline.py) row[3] = T_rec; row[4] = T_shade; row[5] = n_draws_t; row[6] = 1; row[7] = T_cull_core * 1024 + n_core_t;
     for (int i = 0; i < 4; i++) { row[8 + i] = T_mode[i]; row[12 + i] = N_mode[i]; }
   }
 #endif
@@ -4190,6 +4190,7 @@ void debug_wave_times(unsigned long long* out) {
   (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_times), sizeof(unsigned long long) * 16 * 65536);
   void* p = nullptr;  // cleared after every read: the next read then holds exactly the launches in between
   if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_wave_times)) == hipSuccess) (void)hipMemset(p, 0, sizeof(unsigned long long) * 16 * 65536);
+  (void)hipDeviceSynchronize();  // (the memset is asynchronous, the contexts' streams do not wait for the null stream: without this it clears rows of the NEXT launch)
 }
 void debug_counters(unsigned long long out[128], bool reset) {
   (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_counters), 128 * sizeof(unsigned long long));

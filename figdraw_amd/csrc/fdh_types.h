@@ -24,6 +24,9 @@ constexpr int kWgH = kTileH * kWavesPerWg;  // 32: the four waves of a workgroup
 constexpr int kBin = 64;
 constexpr int kWgsPerBin = (kBin / kWgW) * (kBin / kWgH);  // 4
 constexpr int kMaskDepth = 16;                             // per-lane clip stack levels kept in LDS (4 KB per wavefront); deeper levels spill to a global plane
+// a bin whose list holds at least this many draws gets quarter-strip waves in the next frames' full-frame launch (k_composite_tiles;
+// FDH_DEEP_MIN overrides, 0 turns the quarter strips off)
+constexpr int kDeepMinDefault = 24;
 constexpr int kMaxMips = 14;
 constexpr int kMaxBlurTaps = 36;
 

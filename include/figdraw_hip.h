@@ -432,7 +432,9 @@ typedef struct {
    * kernel must move (the region read once + written once; bytes_blur / bytes_algorithmic keep SURVEY.md 8(d)'s two-pass
    * formula so that frames stay comparable); bytes_frame_implementation: bytes_algorithmic with such nodes priced at what
    * this implementation moves */
-  float ms_blur_fused, _reserved2;
+  /* deep_bins: how many of the frame's longest-listed bins the LAST full-frame compositor launch shaded with four waves per
+   * strip (k_composite_tiles' quarter strips, round 6; 0: none -- no list reached the threshold, or the order is not known yet) */
+  float ms_blur_fused, deep_bins;
   int64_t bytes_blur_fused, bytes_frame_implementation;
 } FdhFrameStats;
 /* Run `times` more frames and fill the per-kernel averages.  Each launch is stamped with its own start / end events
