@@ -1332,6 +1332,8 @@ void Context::launch_frame(const LaunchJob& J, bool profile, uint32_t upload_seq
     C.deep_k8 = full ? deep_k8 : 0;
     if (full) stats_.deep_bins = (float)((ph.has_slow || ph.has_rot || ph.has_atlas || ph.has_masks || !order_now || !order_next) ? 0 : std::min(deep_k8, 8 * ((nb + 7) / 8)));
     C.deep_min = deep_min;
+    static const int deep_strip_min = [] { const char* e = std::getenv("FDH_DEEP_STRIP_MIN"); return e ? std::atoi(e) : kDeepStripMinDefault; }();
+    C.deep_strip_min = deep_strip_min;
     C.deep_out = (full && order_next && deep_min > 0) ? const_cast<uint32_t*>(deep_host_) : nullptr;
     C.has_slow = ph.has_slow ? 1 : 0;
     C.has_rot = ph.has_rot ? 1 : 0;

@@ -57,6 +57,7 @@ struct CompositeParams {
   // strip; deep_min / deep_out: the sorting waves count the bins with at least deep_min draws per class into deep_out[0..7]
   // (pinned host memory, or null)
   int deep_k8 = 0;
+  int deep_strip_min = 0;   // ... those of their strips that have at least this many draws to SHADE (strip_shade_count); the others keep their one wave
   int deep_min = 0;
   uint32_t* deep_out = nullptr;
 };

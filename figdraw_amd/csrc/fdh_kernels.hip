@@ -690,7 +690,10 @@ __global__ __launch_bounds__(64) void k_bin_draws(BinParams P) {
 // cls mod 8 of `order`.  The compositor hands position p to XCD p % 8 and k_bin_draws builds bin b's list on XCD b % 8: with the
 // order sorted per class, a bin's list, its count and -- next frame -- its order entry are read on the XCD whose L2 they were
 // written in, instead of being pulled across XCDs at the very start of every strip's life.)
-__device__ __forceinline__ void order_bins_wave(const uint32_t* __restrict__ counts, int* __restrict__ order, int nx, int nb, uint32_t* offs, int lane, int cls) {
+// (round 6: the wave also leaves, in pinned host memory, how many bins of its class hold at least `deep_min` draws -- the exclusive
+// prefix of that bucket of the descending histogram.  The host sizes the NEXT launches' deep-strip part from it: k_composite_deep.)
+__device__ __forceinline__ void order_bins_wave(const uint32_t* __restrict__ counts, int* __restrict__ order, int nx, int nb, uint32_t* offs, int lane, int cls,
+                                                int deep_min = 0, uint32_t* __restrict__ deep_out = nullptr) {
 #pragma unroll
   for (int k = 0; k < 4; k++) offs[lane + 64 * k] = 0;
   __builtin_amdgcn_wave_barrier();
@@ -715,6 +718,12 @@ __device__ __forceinline__ void order_bins_wave(const uint32_t* __restrict__ cou
     const uint32_t base = incl - (a + b + c2 + d);
     __builtin_amdgcn_wave_barrier();
     offs[4 * lane] = base; offs[4 * lane + 1] = base + a; offs[4 * lane + 2] = base + a + b; offs[4 * lane + 3] = base + a + b + c2;
+  }
+  __builtin_amdgcn_wave_barrier();
+  // bucket k holds the bins with min(count, 255) = 255 - k: counts >= m are buckets 0 .. 255 - m, the start of bucket 256 - m
+  if (deep_out != nullptr && lane == 0) {
+    const int m = min(max(deep_min, 1), 255);
+    __hip_atomic_store(deep_out + cls, offs[256 - m], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
   __builtin_amdgcn_wave_barrier();
   for (int i0 = lane; i0 < nc; i0 += 64 * kU) {
@@ -1168,6 +1177,9 @@ __device__ unsigned int g_edge_bad[4096 * 8];
 #ifndef FDH_ROT_WAVES
 #define FDH_ROT_WAVES 4  // waves per SIMD of the rotated-quad build <8>
 #endif
+#ifndef FDH_DEEP_PRIO
+#define FDH_DEEP_PRIO 1  // a deep strip's waves raise their issue priority (s_setprio: blender 3, shaders 2)
+#endif
 #ifndef FDH_UNIFORM_WAVES
 #define FDH_UNIFORM_WAVES 6  // waves per SIMD of the no-clip build <4>: 80 VGPRs, no spills
 #endif
@@ -1181,6 +1193,66 @@ constexpr int kWinCols = 64, kWinRows = 12, kWinStride = 68;
 // kFull: the launch that starts a frame -- every bin of the grid, from the clear colour (nothing is loaded), bins taken longest
 // list first, with the sort for the next frame riding along.  A symbol of its own, so that the dominant launch of a frame is a
 // row of its own in a rocprofv3 kernel summary (the later phases' launches cover a blur node's footprint and take microseconds).
+// ---- Deep strips (round 6).  A wave walks its strip's list one draw after the other, and alone on a SIMD it gets through a draw's ~200
+// dependent instructions no faster than with five neighbours: at 1920 x 1080 the bench tree's lists are four times as deep as at 4K, and
+// the full-frame launch was the serial chain of its longest strips -- the 128 strips of the eight longest bins, shaded with NOTHING else on
+// the chip, take the launch's whole 29 us (profiles/r06_1080p_critical_path.txt).  What is serial in a strip is only the BLEND -- a draw's
+// source term (coverage from the distance field, colour from the fill) depends on nothing before it.  So the strips of the frame's deepest
+// bins get a workgroup of four waves (k_composite_deep): waves 1..3 (kRole 2, "shaders") each take every third draw that needs per-pixel
+// work, evaluate its source term with the code below and put it into a ring of slots in LDS; wave 0 (kRole 1, the "blender") walks the same
+// list, blends the one-colour core strips itself and every other draw's source term out of the ring, in list order.  Same operations on the
+// same values as one wave would do (the blender's arithmetic is the tail of edge_blend / shade, moved): bit-identical frames.
+// Slot payload per lane: packed edge paths 4 floats (the four source alphas; the draw's colour rides in the slot's header), the generic path
+// 16 (r, g, b, masked alpha of the four pixels).
+constexpr int kDeepSlots = 6;                               // ring depth: source terms a strip's shaders may be ahead of its blender
+constexpr int kDeepSlotFloats = 16 * 64;                    // 4 KB of payload per slot: [float index 0..15][lane]
+constexpr int kDeepHdr = 8;                                 // dwords of header per slot: tag, colour words / uniform terms
+[[maybe_unused]] constexpr int kDeepLdsDwords = kDeepSlots * (kDeepSlotFloats + kDeepHdr) + kDeepSlots + 2;  // + ready[] + consumed
+constexpr uint32_t DT_NOP = 0, DT_PACKED = 1, DT_PACKED_BLACK = 2, DT_GENERIC = 3, DT_SELF17 = 4, DT_UNIFORM_PRE = 5;
+struct DeepRing {
+  float* data;         // [slot][16][64]
+  uint32_t* hdr;       // [slot][kDeepHdr]
+  uint32_t* ready;     // [slot]: rank + 1 of the source term the slot holds
+  uint32_t* consumed;  // ranks the blender is done with
+  __device__ __forceinline__ explicit DeepRing(uint32_t* lds)
+      : data(reinterpret_cast<float*>(lds)), hdr(lds + kDeepSlots * kDeepSlotFloats), ready(lds + kDeepSlots * (kDeepSlotFloats + kDeepHdr)),
+        consumed(lds + kDeepSlots * (kDeepSlotFloats + kDeepHdr) + kDeepSlots) {}
+};
+// (a wait that can never be satisfied must not hang the device: after ~2^20 polls a wave goes on -- wrong pixels, which the tests see)
+__device__ __forceinline__ void deep_wait_ge(const uint32_t* p, const uint32_t want) {
+  for (int spins = 0; spins < (1 << 20); spins++) {
+    const uint32_t v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
+    if ((int32_t)(v - want) >= 0) return;
+    __builtin_amdgcn_s_sleep(1);
+  }
+}
+
+// How many draws of its list a strip has to SHADE -- survivors of the strip test and of the occlusion cut that are not one-colour core strips
+// (those are a uniform blend: cheap) --, counted the way the draw loop walks the list.  A strip of a deep bin goes to k_composite_deep when
+// this reaches P.deep_strip_min, and to its usual wave otherwise: both kernels ask this function, so they agree.
+__device__ __forceinline__ uint32_t strip_shade_count(const CompositeParams& P, const int bin, const int sbit, const int lane) {
+  const uint32_t cnt = P.counts[bin];
+  const uint2* __restrict__ list = P.lists + (size_t)bin * P.stride;
+  uint32_t n = 0;
+  for (uint32_t base = 0; base < cnt; base += 64) {
+    const uint32_t i = base + lane;
+    const uint2 e = list[min(i, cnt - 1u)];
+    const uint32_t ey = i < cnt ? e.y : 0u;
+    const uint32_t st = (ey >> sbit) & 0x10001u;
+    unsigned long long m = __ballot(st != 0u);
+    const unsigned long long m_opaque = __ballot(st == 0x10001u && (e.x & LE_OPAQUE) != 0u);
+    if (m_opaque != 0) m &= ~((1ull << (63 - __builtin_clzll(m_opaque))) - 1ull);
+    m &= ~__ballot(st == 0x10001u && (int32_t)e.x < 0);
+    n += (uint32_t)__builtin_popcountll(m);
+  }
+  return n;
+}
+
+template <int kPaths, bool kFull, int kRole>
+__device__ __forceinline__ void composite_strip(const CompositeParams& P, const DrawRec* __restrict__ draws, const QuadExt* __restrict__ exts,
+                                                uint32_t* composite_lds, const int bin, const int sidx, const int sbit, const int tx0, const int ty0,
+                                                const int lane, const int shader_id);
+
 template <int kPaths, bool kFull>
 __global__ __launch_bounds__(64, (kPaths & 1) ? FDH_SLOW_WAVES : kPaths == 4 ? FDH_UNIFORM_WAVES : (kPaths & 2) ? FDH_ATLAS_WAVES : (kPaths & 8) ? FDH_ROT_WAVES : FDH_FAST_WAVES) void k_composite_tiles(
     // the sixteen dwords a wave needs before anything else, as leading scalar arguments: with kernel-argument preloading
@@ -1211,13 +1283,13 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? FDH_SLOW_WAVES : kPaths == 4 ? F
     // One extra wavefront per full-frame launch sorts THIS frame's bin counts for the NEXT frame's launch (any
     // permutation is a correct schedule, and list lengths barely change from frame to frame).  As a kernel of its own the
     // sort was a ~6 us serial step of every frame; here it runs beside 32 000 compositing waves.
-    order_bins_wave(P.counts, P.order_next, P.bin_nx, P.bin_nx * P.bin_ny, &mask_stack[0][0][0], threadIdx.x, (int)blockIdx.x);
+    order_bins_wave(P.counts, P.order_next, P.bin_nx, P.bin_nx * P.bin_ny, &mask_stack[0][0][0], threadIdx.x, (int)blockIdx.x, P.deep_min, P.deep_out);
     return;
   }
   int bin_local = xcd + 8 * (q / kStripsPerBin);
   const int sidx = q % kStripsPerBin;
   if (bin_local >= P.bin_nx * P.bin_ny) return;
-  const int j = sidx >> 2, wave = sidx & 3, lane = threadIdx.x & 63, mslot = 0;
+  const int j = sidx >> 2, wave = sidx & 3, lane = threadIdx.x & 63;
   const int sbit = j * 4 + wave;  // this strip's bit in the list entries' strip masks
   int bly, blx;
   if (P.order) {  // longest lists first (order_bins_wave): entries are row << 16 | column
@@ -1239,6 +1311,81 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? FDH_SLOW_WAVES : kPaths == 4 ? F
   if (ty0 + kTileH <= P.row_lo) return;
   asm volatile("");
   if (ty0 >= P.row_hi) return;
+  composite_strip<kPaths, kFull, 0>(P, draws, exts, composite_lds, bin, sidx, sbit, tx0, ty0, lane, 0);
+}
+
+// The full-frame launch of a frame that HAS deep bins (P.deep_k8 > 0; k_composite_tiles<4, true> otherwise), workgroups of four waves:
+//   workgroups 0..7: wave 0 of each sorts one class of this frame's bin counts for the next frame (order_bins_wave);
+//   then 16 per bin of the first P.deep_k8 positions of `order`: one deep strip each -- if the strip has P.deep_strip_min draws to shade;
+//   then 4 per bin of the frame: sixteen one-wave strips as k_composite_tiles shades them, four to a workgroup (a strip the deep part took
+//   leaves its wave idle).
+// One launch, so that the deep strips' shaders and blenders run BESIDE the other strips' waves: as a launch of their own in front they
+// added their whole duration (sweeps in profiles/r06_deep_strips.txt).  Workgroup b runs on XCD b % 8; every part's size is a multiple of
+// 8, so position p keeps XCD p % 8 in both parts, like the strips of k_composite_tiles.
+template <int kUnit>  // (a template so that only the translation unit that launches it holds the symbol)
+__global__ __launch_bounds__(256, FDH_UNIFORM_WAVES) void k_composite_deep(const DrawRec* __restrict__ draws, const QuadExt* __restrict__ exts, CompositeParams P) {
+  extern __shared__ uint32_t composite_lds[];
+  constexpr int kStripsPerBin = kWgsPerBin * kWavesPerWg;  // 16
+  // (which wave of the workgroup this is, as a value the compiler KNOWS to be wave-uniform: taken from the thread index alone it counted as
+  // divergent, and with it every branch on whose turn a shading unit is -- the whole draw loop ran under exec masks)
+  const int lane = threadIdx.x & 63, wg_wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  int blk = (int)blockIdx.x - 8;
+  if (blk < 0) {
+    if (wg_wave == 0) order_bins_wave(P.counts, P.order_next, P.bin_nx, P.bin_nx * P.bin_ny, composite_lds, lane, (int)blockIdx.x, P.deep_min, P.deep_out);
+    return;
+  }
+  const int n_deep = P.deep_k8 * kStripsPerBin;
+  const bool deep = blk < n_deep;
+  int bin_local, sidx;
+  if (deep) {
+    const int q = blk >> 3;
+    bin_local = (blk & 7) + 8 * (q / kStripsPerBin);
+    sidx = q % kStripsPerBin;
+  } else {
+    blk -= n_deep;
+    const int q = blk >> 3;
+    bin_local = (blk & 7) + 8 * (q >> 2);
+    sidx = 4 * (q & 3) + wg_wave;
+  }
+  if (bin_local >= P.bin_nx * P.bin_ny) return;
+  const int j = sidx >> 2, wave = sidx & 3;
+  const int sbit = j * 4 + wave;
+  const int rc = P.order[bin_local];
+  const int bly = rc >> 16, blx = rc & 0xffff;
+  const int bin_x = P.bin_x0 + blx, bin_y = P.bin_y0 + bly;
+  const int bin = bin_y * P.bins_x + bin_x;
+  const int tx0 = bin_x * kBin + (j & 1) * kWgW;
+  const int ty0 = bin_y * kBin + (j >> 1) * kWgH + wave * kTileH;
+  if (tx0 >= P.W || ty0 >= P.H || ty0 + kTileH <= P.row_lo || ty0 >= P.row_hi) return;
+  const bool is_deep = bin_local < P.deep_k8 && strip_shade_count(P, bin, sbit, lane) >= (uint32_t)P.deep_strip_min;
+  if (!deep) {  // one wave, one strip
+    if (!is_deep) composite_strip<4, true, 0>(P, draws, exts, composite_lds, bin, sidx, sbit, tx0, ty0, lane, 0);
+    return;
+  }
+  if (!is_deep) return;  // (the whole workgroup: one strip, one answer -- its usual wave shades it)
+  if (threadIdx.x < kDeepSlots + 2) composite_lds[kDeepSlots * (kDeepSlotFloats + kDeepHdr) + threadIdx.x] = 0u;  // ready[], consumed
+  __syncthreads();
+  // (the deep strips are the launch's critical path, and of a deep strip its blender: they go first where a SIMD has a choice)
+  if (wg_wave == 0) {
+    if (FDH_DEEP_PRIO) __builtin_amdgcn_s_setprio(3);
+    composite_strip<4, true, 1>(P, draws, exts, composite_lds, bin, sidx, sbit, tx0, ty0, lane, 0);
+  } else {
+    if (FDH_DEEP_PRIO) __builtin_amdgcn_s_setprio(2);
+    composite_strip<4, true, 2>(P, draws, exts, composite_lds, bin, sidx, sbit, tx0, ty0, lane, wg_wave - 1);
+  }
+}
+
+template <int kPaths, bool kFull, int kRole>
+__device__ __forceinline__ void composite_strip(const CompositeParams& P, const DrawRec* __restrict__ draws, const QuadExt* __restrict__ exts,
+                                                uint32_t* composite_lds, const int bin, const int sidx, const int sbit, const int tx0, const int ty0,
+                                                const int lane, const int shader_id) {
+  static_assert(kRole == 0 || (kPaths == 4 && kFull), "deep strips: the no-clip build's full-frame launch only");
+  constexpr int kStripsPerBin = kWgsPerBin * kWavesPerWg;  // 16
+  constexpr int mslot = 0;
+  constexpr bool kBlender = kRole == 1, kShader = kRole == 2;
+  uint32_t (*mask_stack)[kMaskDepth][64] = reinterpret_cast<uint32_t (*)[kMaskDepth][64]>(composite_lds);
+  const DeepRing ring(composite_lds);
+  uint32_t rank = 0, unit = 0;  // deep strips: source terms / shading units (a draw, or a run of draws over one distance field) so far in the list
   const int tx1 = tx0 + kTileW, ty1 = ty0 + kTileH;
   const int px0 = tx0 + (lane & 7) * 4, py = ty0 + (lane >> 3);
   // The clip stack: levels 0 .. kMaskDepth - 1 in LDS; deeper nesting (the reference has no limit: one mask plane per level,
@@ -1256,7 +1403,7 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? FDH_SLOW_WAVES : kPaths == 4 ? F
   constexpr bool kMasks = (kPaths & 4) == 0;  // <4>: a phase without clip / rect-mask operations -- no mask registers, no stack
 #if FDH_TIMING
   const unsigned long long T0 = FDH_NOW(), W0 = wall_clock64();
-  unsigned long long T_cull = 0, T_rec = 0, T_shade = 0, T_cnt = 0, n_draws_t = 0, T_cull_core = 0, n_core_t = 0;
+  unsigned long long T_cull = 0, T_rec = 0, T_shade = 0, T_cnt = 0, n_draws_t = 0, T_cull_core = 0, n_core_t = 0, n_all_t = 0;
   unsigned long long T_mode[4] = {0, 0, 0, 0}, N_mode[4] = {0, 0, 0, 0};  // edge draws by mode: 3, 7, 9, 12
 #endif
   const uint32_t cnt = P.counts[bin];
@@ -1291,6 +1438,66 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? FDH_SLOW_WAVES : kPaths == 4 ? F
   const float cx0 = (float)px0 + 0.5f;
   const float inv255 = 1.0f / 255.0f;
 
+  // ---- deep strips: the ring between the strip's shaders and its blender (every store below is made by all 64 lanes with the same
+  // value: a branch on the lane index would be the draw loop's only divergent one -- tools/lint_isa.py)
+  auto deep_slot = [&](const uint32_t rk) __attribute__((always_inline)) -> uint32_t {  // shader: the slot of source term rk, once the blender has freed it
+    if (rk >= (uint32_t)kDeepSlots) deep_wait_ge(ring.consumed, rk - (uint32_t)kDeepSlots + 1u);
+    return rk % (uint32_t)kDeepSlots;
+  };
+  auto deep_publish = [&](const uint32_t slot, const uint32_t rk, const uint32_t tag, const uint32_t h1, const uint32_t h2, const uint32_t h3, const uint32_t h4, const uint32_t h5) __attribute__((always_inline)) {
+    uint32_t* h = ring.hdr + slot * kDeepHdr;
+    h[0] = tag; h[1] = h1; h[2] = h2; h[3] = h3; h[4] = h4; h[5] = h5;
+    __hip_atomic_store(ring.ready + slot, rk + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+  };
+  auto deep_nop = [&](const uint32_t rk) __attribute__((always_inline)) { deep_publish(deep_slot(rk), rk, DT_NOP, 0u, 0u, 0u, 0u, 0u); };
+  // blender: source term rk out of its slot, blended into the strip
+  auto deep_consume = [&](const uint32_t rk) __attribute__((always_inline)) {
+    const uint32_t slot = rk % (uint32_t)kDeepSlots;
+    const uint32_t* h = ring.hdr + slot * kDeepHdr;
+    const float* v = ring.data + slot * kDeepSlotFloats + lane;
+    // The slot's sequence number, its header and the first four payload floats are read in ONE round trip to LDS, then the number is
+    // looked at: LDS returns a wave's reads in order, so values read after a number that says "published" are the published ones.
+    // (Before: wait for the number, then the header, then the payload -- three dependent round trips per source term on the one wave
+    // whose chain a deep strip's time is.)
+    uint32_t tag, h1, h2, h3, h4, h5;
+    float v0, v1, v2, v3;
+    for (int spins = 0; spins < (1 << 20); spins++) {
+      const uint32_t seq = __hip_atomic_load(ring.ready + slot, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      tag = h[0]; h1 = h[1]; h2 = h[2]; h3 = h[3]; h4 = h[4]; h5 = h[5];
+      v0 = v[0]; v1 = v[64]; v2 = v[128]; v3 = v[192];
+      asm volatile("" : "+v"(tag), "+v"(h1), "+v"(h2), "+v"(h3), "+v"(h4), "+v"(h5), "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3));  // (read HERE, after the number)
+      if ((int32_t)((uint32_t)__builtin_amdgcn_readfirstlane(seq) - (rk + 1u)) >= 0) break;
+      __builtin_amdgcn_s_sleep(1);
+    }
+    tag = __builtin_amdgcn_readfirstlane(tag);
+    if (tag == DT_PACKED || tag == DT_PACKED_BLACK) {
+      const f2 saa = {v0, v1}, sab = {v2, v3};
+      const f2 Aa = saa * 255.0f, Ab = sab * 255.0f, iaa = 1.0f - saa, iab = 1.0f - sab;
+      if (tag == DT_PACKED_BLACK) {
+        blend_black(F0, Aa.x, iaa.x); blend_black(F1, Aa.y, iaa.y); blend_black(F2, Ab.x, iab.x); blend_black(F3, Ab.y, iab.y);
+      } else {
+        const f2 crg = {__uint_as_float(__builtin_amdgcn_readfirstlane(h1)), __uint_as_float(__builtin_amdgcn_readfirstlane(h2))};
+        const float cb = __uint_as_float(__builtin_amdgcn_readfirstlane(h3));
+        const f2 b1 = {cb, 1.0f};
+        blend_pre(F0, crg * Aa.x, b1 * Aa.x, iaa.x); blend_pre(F1, crg * Aa.y, b1 * Aa.y, iaa.y);
+        blend_pre(F2, crg * Ab.x, b1 * Ab.x, iab.x); blend_pre(F3, crg * Ab.y, b1 * Ab.y, iab.y);
+      }
+    } else if (tag == DT_GENERIC) {
+      blend(F0, v0, v[4 * 64], v[8 * 64], v[12 * 64]); blend(F1, v1, v[5 * 64], v[9 * 64], v[13 * 64]);
+      blend(F2, v2, v[6 * 64], v[10 * 64], v[14 * 64]); blend(F3, v3, v[7 * 64], v[11 * 64], v[15 * 64]);
+    } else if (tag == DT_SELF17) {  // mode 17 over the live surface (blur radius <= 0.5): the source IS the strip's own texel (atlas.frag:381-388)
+      const float k255 = 1.0f / 255.0f;
+      blend(F0, F0.x * k255, F0.y * k255, F0.z * k255, F0.w * k255 * v0); blend(F1, F1.x * k255, F1.y * k255, F1.z * k255, F1.w * k255 * v1);
+      blend(F2, F2.x * k255, F2.y * k255, F2.z * k255, F2.w * k255 * v2); blend(F3, F3.x * k255, F3.y * k255, F3.z * k255, F3.w * k255 * v3);
+    } else if (tag == DT_UNIFORM_PRE) {
+      const f2 c_rg = {__uint_as_float(__builtin_amdgcn_readfirstlane(h1)), __uint_as_float(__builtin_amdgcn_readfirstlane(h2))};
+      const f2 c_ba = {__uint_as_float(__builtin_amdgcn_readfirstlane(h3)), __uint_as_float(__builtin_amdgcn_readfirstlane(h4))};
+      const float ia = __uint_as_float(__builtin_amdgcn_readfirstlane(h5));
+      blend_pre(F0, c_rg, c_ba, ia); blend_pre(F1, c_rg, c_ba, ia); blend_pre(F2, c_rg, c_ba, ia); blend_pre(F3, c_rg, c_ba, ia);
+    }
+    // (the slot is free once its values are in registers: the loads above have landed before the store below is made -- release)
+    __hip_atomic_store(ring.consumed, rk + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+  };
   for (uint32_t base = 0; base < cnt; base += 64) {
 #if FDH_TIMING
     const unsigned long long Tc0 = FDH_NOW();
@@ -1322,6 +1529,10 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? FDH_SLOW_WAVES : kPaths == 4 ? F
     //   m_simple: an edge strip of a draw with a packed edge path (list-entry path codes 1..8)
     // (each is one vector compare on the entry's flag word, combined with the strip masks above on the scalar side)
     const unsigned long long m_plainc = m_core & __ballot((int32_t)idx < 0);  // LE_PLAIN is the sign bit
+    // (a deep strip's blender: the colours of the batch's one-colour core strips, lane i <-> entry i, in ONE vector load -- fetched draw by
+    // draw through the scalar cache each was a round trip to L2 on the strip's critical wave)
+    u32x4 plain_col = {0u, 0u, 0u, 0u};
+    if (kBlender) plain_col = *reinterpret_cast<const u32x4*>(draws[idx & LE_INDEX].col);
     const uint32_t code_l = idx & (15u << LE_PATH_SHIFT);
     const unsigned long long m_simple = m & ~m_core & __ballot((kPaths & 3) == 0 ? code_l != 0u : (code_l - 1u) < (4u << LE_PATH_SHIFT));
     // sdRoundedBox (atlas.frag:51-69) of the lane's four pixels at height py for half extents (bx, by)
@@ -1372,8 +1583,9 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? FDH_SLOW_WAVES : kPaths == 4 ? F
     };
     // r: the run's geometry (quad, radii, AA factor, bounds); m_*: the draw's own sdfParams.zw, sdfFactors and colour
     // inq (wave-uniform, from the list entry): the strip lies wholly inside the quad's pixel bounds
+    // (rk: a deep strip's shader puts the draw's source alphas into the ring as source term rk instead of blending them -- deep_consume is the rest)
     auto edge_blend = [&](const DrawRec& r, const uint32_t mode, const bool ellip, const bool inq, const float m_p2, const float m_p3, const float m_f0, const float m_f1,
-                          const u32x4 m_col, const f2 lxa, const f2 lxb, const float pyy, const f2 da, const f2 db, F4& A0, F4& A1, F4& A2, F4& A3) __attribute__((always_inline)) {
+                          const u32x4 m_col, const f2 lxa, const f2 lxb, const float pyy, const f2 da, const f2 db, F4& A0, F4& A1, F4& A2, F4& A3, const uint32_t rk) __attribute__((always_inline)) {
       f2 ala, alb;  // coverage
       if (mode == 3u) {
         ala = {cover_aa(da.x, r.aa), cover_aa(da.y, r.aa)}; alb = {cover_aa(db.x, r.aa), cover_aa(db.y, r.aa)};
@@ -1382,7 +1594,10 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? FDH_SLOW_WAVES : kPaths == 4 ? F
         const f2 ea = da + h, eb = db + h;
         const f2 ga = {__builtin_fabsf(ea.x), __builtin_fabsf(ea.y)}, gb = {__builtin_fabsf(eb.x), __builtin_fabsf(eb.y)};
         ala = {cover_aa(ga.x - h, r.aa), cover_aa(ga.y - h, r.aa)}; alb = {cover_aa(gb.x - h, r.aa), cover_aa(gb.y - h, r.aa)};
-        if (__all(ala.x == 0.0f && ala.y == 0.0f && alb.x == 0.0f && alb.y == 0.0f)) return;  // inside the stroke: no-op
+        if (__all(ala.x == 0.0f && ala.y == 0.0f && alb.x == 0.0f && alb.y == 0.0f)) {  // inside the stroke: no-op
+          if (kShader) deep_nop(rk);
+          return;
+        }
       } else if (mode == 9u) {  // atlas.frag:364-380 -- clip alpha of the node's own shape x the falloff inside the offset shape
         f2 sha, shb;
         if ((kPaths & 3) == 0 && ellip) dist4e(r, lxa - m_p2, lxb - m_p2, pyy + m_p3, r.p0, r.p1, sha, shb); else dist4(r, lxa - m_p2, lxb - m_p2, pyy + m_p3, r.p0, r.p1, sha, shb);
@@ -1421,6 +1636,13 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? FDH_SLOW_WAVES : kPaths == 4 ? F
         saa.x = xrel < wcov ? saa.x : 0.0f; saa.y = xrel + 1u < wcov ? saa.y : 0.0f;
         sab.x = xrel + 2u < wcov ? sab.x : 0.0f; sab.y = xrel + 3u < wcov ? sab.y : 0.0f;
       }
+      if (kShader) {
+        const uint32_t slot = deep_slot(rk);
+        float* v = ring.data + slot * kDeepSlotFloats + lane;
+        v[0] = saa.x; v[64] = saa.y; v[128] = sab.x; v[192] = sab.y;
+        deep_publish(slot, rk, (m_col.y | m_col.z | m_col.w) == 0u ? DT_PACKED_BLACK : DT_PACKED, m_col.y, m_col.z, m_col.w, 0u, 0u);
+        return;
+      }
       const f2 Aa = saa * 255.0f, Ab = sab * 255.0f, iaa = 1.0f - saa, iab = 1.0f - sab;
       if ((m_col.y | m_col.z | m_col.w) == 0u) {
         // a black source (every drop shadow of the reference's scenes, most strokes): the colour terms are +0 and fma(F, 1 - sa, +0)
@@ -1438,12 +1660,12 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? FDH_SLOW_WAVES : kPaths == 4 ? F
       f2 lxa, lxb, da, db;
       float pyy;
       edge_geom(r, mode == 9u, ellip, lxa, lxb, pyy, da, db);
-      edge_blend(r, mode, ellip, false, r.p2, r.p3, r.f0, r.f1, u32x4{r.col[0], r.col[1], r.col[2], r.col[3]}, lxa, lxb, pyy, da, db, A0, A1, A2, A3);
+      edge_blend(r, mode, ellip, false, r.p2, r.p3, r.f0, r.f1, u32x4{r.col[0], r.col[1], r.col[2], r.col[3]}, lxa, lxb, pyy, da, db, A0, A1, A2, A3, 0u);
     };
 #endif
     // One draw = one lambda call.  The record of the NEXT surviving draw is fetched (scalar loads) before the
     // current one is shaded, so the ~L2-latency of the fetch overlaps the shading arithmetic.
-    auto shade = [&](const uint32_t d, const DrawRec& r, const bool core, const bool inq) {
+    auto shade = [&](const uint32_t d, const DrawRec& r, const bool core, const bool inq, const uint32_t rk) {
       const uint32_t om = r.op_mode;
       const uint32_t op = (om >> 12) & 15u;
       const uint32_t mode = om & 255u;
@@ -2184,7 +2406,7 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? FDH_SLOW_WAVES : kPaths == 4 ? F
       { F0.x += core ? 1e-30f : 0.0f; return; }
 #endif
       if (core) {
-        if (mode == 9u || mode == 11u || mode == 12u) { FDH_COUNT(32); return; }
+        if (mode == 9u || mode == 11u || mode == 12u) { FDH_COUNT(32); if (kShader) deep_nop(rk); return; }
         if (op == OP_DRAW && (om & F_SOLID) && fill_mode == 0u && mode != 17u) {
           FDH_COUNT(33);
           const F4 c0 = unpack255(r.col[0]);
@@ -2192,6 +2414,10 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? FDH_SLOW_WAVES : kPaths == 4 ? F
           if (mask_depth == 0 && !rmask_on) {  // one source term for the whole strip
             const float A = 255.0f * sa, ia = 1.0f - sa;
             const f2 c_rg = {c0.x * inv255 * A, c0.y * inv255 * A}, c_ba = {c0.z * inv255 * A, A};
+            if (kShader) {
+              deep_publish(deep_slot(rk), rk, DT_UNIFORM_PRE, __float_as_uint(c_rg.x), __float_as_uint(c_rg.y), __float_as_uint(c_ba.x), __float_as_uint(c_ba.y), __float_as_uint(ia));
+              return;
+            }
             blend_pre(F0, c_rg, c_ba, ia); blend_pre(F1, c_rg, c_ba, ia); blend_pre(F2, c_rg, c_ba, ia); blend_pre(F3, c_rg, c_ba, ia);
           } else {
             const float cr = c0.x * inv255, cg = c0.y * inv255, cb = c0.z * inv255;
@@ -2288,7 +2514,7 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? FDH_SLOW_WAVES : kPaths == 4 ? F
         if (cls == 2) FDH_COUNT(6);
         if (cls == 1 && r.bx0 <= tx0 && r.bx1 >= tx1 && r.by0 <= ty0 && r.by1 >= ty1) FDH_COUNT(7);
         if (cls == 1) FDH_COUNT(40 + (mode & 15u));
-        if (cls == 2) return;
+        if (cls == 2) { if (kShader) deep_nop(rk); return; }
         if (cls == 0) {
           const float lxi[2] = {lx[1], lx[2]};
           shape_distN<2>(false, lxi, -ly, shx, shy, r.r[0], r.r[1], r.r[2], r.r[3], d2);
@@ -2431,6 +2657,23 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? FDH_SLOW_WAVES : kPaths == 4 ? F
       // divergent branch around two multiplies in the builds with masks -- tools/lint_isa.py)
       const float am[4] = {sa[0] * mk0 * rm0, sa[1] * mk1 * rm1, sa[2] * mk2 * rm2, sa[3] * mk3 * rm3};
       FDH_COUNT(all_cov ? 66 : 67);
+      if (kShader) {  // a deep strip's shader: the source term goes into the ring, the blender does what follows (deep_consume)
+        const uint32_t slot = deep_slot(rk);
+        float* v = ring.data + slot * kDeepSlotFloats + lane;
+        if (mode == 17u && (om & F_SELF_BACKDROP) != 0u) {  // the source is the strip's own texel, which only the blender holds: the coverage goes over
+#pragma unroll
+          for (int k = 0; k < 4; k++) { const float a = alpha[k]; v[64 * k] = all_cov ? a : (cov[k] ? a : 0.0f); }
+          deep_publish(slot, rk, DT_SELF17, 0u, 0u, 0u, 0u, 0u);
+          return;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          v[64 * k] = sr[k]; v[64 * (4 + k)] = sg[k]; v[64 * (8 + k)] = sb[k];
+          v[64 * (12 + k)] = all_cov ? am[k] : (cov[k] ? am[k] : 0.0f);
+        }
+        deep_publish(slot, rk, DT_GENERIC, 0u, 0u, 0u, 0u, 0u);
+        return;
+      }
       if (all_cov) {
         blend(F0, sr[0], sg[0], sb[0], am[0]); blend(F1, sr[1], sg[1], sb[1], am[1]);
         blend(F2, sr[2], sg[2], sb[2], am[2]); blend(F3, sr[3], sg[3], sb[3], am[3]);
@@ -2447,6 +2690,9 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? FDH_SLOW_WAVES : kPaths == 4 ? F
       m &= ~one;
       const uint32_t word = __builtin_amdgcn_readlane(idx, bit);
       const uint32_t d = word & LE_INDEX;
+#if FDH_TIMING
+      n_all_t++;
+#endif
       const bool unclipped = !kMasks || (mask_depth == 0 && !rmask_on);
 #ifdef FDH_ABLATE_PATHS  // ablation builds (tools/ablate_paths.sh): what each path of the draw loop costs, by leaving it out
       if ((FDH_ABLATE_PATHS & 1) && unclipped && (m_plainc & one) != 0ull) { touched = true; continue; }
@@ -2455,11 +2701,18 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? FDH_SLOW_WAVES : kPaths == 4 ? F
       if ((FDH_ABLATE_PATHS & 64) && !(unclipped && ((m_plainc | m_simple) & one) != 0ull) && (m_core & one) == 0ull) { touched = true; continue; }
 #endif
       if (unclipped && (m_plainc & one) != 0ull) {
+        if (kShader) continue;  // (a deep strip: the blender's own)
         // One colour, coverage 1, nothing clipping: the whole strip gets the same source term.  Only the colour is
         // fetched (4 bytes instead of the 128-byte record) and nothing of the record is decoded.
         // (col[1..3] of such a record hold c / 255 as floats: Context::prepare)
-        u32x4 c4 = *reinterpret_cast<const u32x4*>(draws[d].col);
-        asm volatile("" : "+s"(c4));
+        u32x4 c4;
+        if (kBlender) {
+          c4 = u32x4{(uint32_t)__builtin_amdgcn_readlane(plain_col.x, bit), (uint32_t)__builtin_amdgcn_readlane(plain_col.y, bit),
+                     (uint32_t)__builtin_amdgcn_readlane(plain_col.z, bit), (uint32_t)__builtin_amdgcn_readlane(plain_col.w, bit)};
+        } else {
+          c4 = *reinterpret_cast<const u32x4*>(draws[d].col);
+          asm volatile("" : "+s"(c4));
+        }
         const float sa = (float)(c4.x >> 24) * inv255, A = 255.0f * sa, ia = 1.0f - sa;
         const f2 c_rg = {__uint_as_float(c4.y) * A, __uint_as_float(c4.z) * A}, c_ba = {__uint_as_float(c4.w) * A, A};
         blend_pre(F0, c_rg, c_ba, ia); blend_pre(F1, c_rg, c_ba, ia); blend_pre(F2, c_rg, c_ba, ia); blend_pre(F3, c_rg, c_ba, ia);
@@ -2467,11 +2720,36 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? FDH_SLOW_WAVES : kPaths == 4 ? F
         FDH_COUNT(35);
         continue;
       }
+      if (kBlender) {  // a deep strip's blender: every other draw's source term comes out of the ring, in list order
+        touched = true;
+        deep_consume(rank);
+        rank++;
+        continue;
+      }
 #if FDH_SIMPLE_EDGE && !defined(FDH_ABLATE_SHADING) && !defined(FDH_ABLATE_EDGE)
       // the path code rides in the list entry: the branch is taken on a value that is already in an SGPR, and the record
       // is fetched whole, once, behind it
       const uint32_t code = (word >> LE_PATH_SHIFT) & 15u;
       if (unclipped && (m_simple & one) != 0ull) {
+        // (a deep strip's shaders take the shading units -- this draw and the run that shares its field -- in turn; the others' are
+        // walked over on the list words alone, counting their source terms)
+        const bool mine = !kShader || unit % 3u == (uint32_t)shader_id;
+        unit++;
+        if (kShader && !mine) {
+          rank++;
+          uint32_t wcur = word, dcur = d;
+          while ((wcur & LE_SHARE) != 0u && m != 0) {
+            const int nb = __builtin_ctzll(m);
+            const uint32_t w2 = __builtin_amdgcn_readlane(idx, nb);
+            const unsigned long long one2 = 1ull << nb;
+            if ((w2 & LE_INDEX) != dcur + 1u || (m_simple & one2) == 0ull || (((w2 >> LE_PATH_SHIFT) & 15u) > 4u) != (code > 4u)) break;
+            m &= ~one2;
+            dcur++;
+            wcur = w2;
+            rank++;
+          }
+          continue;
+        }
         const DrawRec r = load_rec_whole(draws + d);
         const uint32_t c4 = (code - 1u) & 3u;
         const uint32_t mode = c4 == 0u ? 3u : c4 == 1u ? 7u : c4 == 2u ? 9u : 12u;
@@ -2480,7 +2758,7 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? FDH_SLOW_WAVES : kPaths == 4 ? F
 #if FDH_EDGE_CHECK
         F4 S0 = F0, S1 = F1, S2 = F2, S3 = F3;
         simple_edge(r, mode, code > 4u, S0, S1, S2, S3);
-        shade(d, r, false, false);
+        shade(d, r, false, false, 0u);
         {
           const bool ellip = code > 4u;
           const float gS[16] = {S0.x, S0.y, S0.z, S0.w, S1.x, S1.y, S1.z, S1.w, S2.x, S2.y, S2.z, S2.w, S3.x, S3.y, S3.z, S3.w};
@@ -2499,7 +2777,8 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? FDH_SLOW_WAVES : kPaths == 4 ? F
           float pyy;
           edge_geom(r, mode == 9u, ellip, lxa, lxb, pyy, da, db);
           const bool inq = (m_inq & one) != 0ull;
-          edge_blend(r, mode, ellip, inq, r.p2, r.p3, r.f0, r.f1, u32x4{r.col[0], r.col[1], r.col[2], r.col[3]}, lxa, lxb, pyy, da, db, F0, F1, F2, F3);
+          edge_blend(r, mode, ellip, inq, r.p2, r.p3, r.f0, r.f1, u32x4{r.col[0], r.col[1], r.col[2], r.col[3]}, lxa, lxb, pyy, da, db, F0, F1, F2, F3, rank);
+          rank++;
           // The draws that follow over the same quad and shape (the node's stroke, its inner shadows: LE_SHARE on the entry of
           // the draw before them) reuse the field: their entries are taken off the list here.  All conditions are wave-uniform.
           uint32_t wcur = word, dcur = d;
@@ -2520,19 +2799,26 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? FDH_SLOW_WAVES : kPaths == 4 ? F
             const uint32_t c42 = (code2 - 1u) & 3u;
             const uint32_t mode2 = c42 == 0u ? 3u : c42 == 1u ? 7u : c42 == 2u ? 9u : 12u;
             FDH_COUNT(57);
-            edge_blend(r, mode2, ellip, (m_inq & one2) != 0ull, __uint_as_float(q.x), __uint_as_float(q.y), __uint_as_float(q.z), __uint_as_float(q.w), mcol, lxa, lxb, pyy, da, db, F0, F1, F2, F3);
+            edge_blend(r, mode2, ellip, (m_inq & one2) != 0ull, __uint_as_float(q.x), __uint_as_float(q.y), __uint_as_float(q.z), __uint_as_float(q.w), mcol, lxa, lxb, pyy, da, db, F0, F1, F2, F3, rank);
+            rank++;
           }
         }
 #endif
         continue;
       }
 #endif
+      if (kShader) {  // (a unit of one draw)
+        const bool mine = unit % 3u == (uint32_t)shader_id;
+        unit++;
+        if (!mine) { rank++; continue; }
+      }
       const DrawRec r = load_rec_whole(draws + d);
       const bool core = (m_core & one) != 0ull;
 #if FDH_TIMING
       const unsigned long long Ts0 = FDH_NOW() + (r.op_mode & 0u);
 #endif
-      shade(d, r, core, (m_inq & one) != 0ull);
+      shade(d, r, core, (m_inq & one) != 0ull, rank);
+      rank++;
 #if FDH_TIMING
       {
         const unsigned long long Ts1 = FDH_NOW() + (__builtin_amdgcn_readfirstlane(__float_as_uint(F0.x + F1.x + F2.x + F3.x)) & 0u);
@@ -2545,15 +2831,17 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? FDH_SLOW_WAVES : kPaths == 4 ? F
     }
   }
 #if FDH_TIMING
-  if (lane == 0 && blockIdx.x < 65536) {
+  if (lane == 0 && blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6) < 65536) {  // (one row per wave: the four of a k_composite_deep workgroup side by side)
     const unsigned long long T1 = FDH_NOW();
-    unsigned long long* row = g_wave_times + 16 * (size_t)blockIdx.x;
-    row[0] = T1 - T0; row[1] = W0 + (T_cnt & 0ull); row[2] = wall_clock64() + (T_cull & 0ull);  // (wall clock, 100 MHz, one counter for the device: tools/wave_timeline.py) row[3] = T_rec; row[4] = T_shade; row[5] = n_draws_t; row[6] = 1; row[7] = T_cull_core * 1024 + n_core_t;
+    unsigned long long* row = g_wave_times + 16 * ((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    row[0] = T1 - T0; row[1] = W0 + (T_cnt & 0ull); row[2] = wall_clock64() + (T_cull & 0ull);  // (wall clock, 100 MHz, one counter for the device: tools/wave_timeline.py)
+    row[3] = T_rec; row[4] = T_shade; row[5] = n_all_t; row[6] = 1 + kRole; row[7] = T_cull_core * 1024 + n_core_t;  // (row[5]: list entries walked; row[6]: 1 a strip's one wave, 2 a deep strip's blender, 3 one of its shaders)
     for (int i = 0; i < 4; i++) { row[8 + i] = T_mode[i]; row[12 + i] = N_mode[i]; }
   }
 #endif
   // The store address is derived again from an (opaque) lane index: kept from the prologue it held three VGPRs across
   // the whole draw loop, the three that stood between the no-clip build and six waves per SIMD.
+  if (kShader) return;  // (a deep strip's shaders hold no texels)
   int lane_e = threadIdx.x & 63;
   asm volatile("" : "+v"(lane_e));
   const int px0e = tx0 + (lane_e & 7) * 4, pye = ty0 + (lane_e >> 3);
@@ -3934,6 +4222,9 @@ void launch_composite(hipStream_t s, const DrawRec* draws, const QuadExt* exts, 
   const size_t lds = (P.has_masks ? sizeof(uint32_t) * kMaskDepth * 64 : sizeof(uint32_t) * 256) +
                      ((P.has_atlas || P.has_slow || (P.has_rot && P.has_atlas)) ? sizeof(uint32_t) * kWinRows * kWinStride : 0);  // + the texel window of the atlas path
   const bool full = P.load_fb == 0;  // the launch that starts a frame (k_composite_tiles<., true>)
+  // deep strips (k_composite_deep): only beside the no-clip build's full-frame launch, and only with the order at hand
+  if (!(full && P.order && P.order_next && !P.has_slow && !P.has_rot && !P.has_atlas && !P.has_masks)) P.deep_k8 = 0;
+  P.deep_k8 = std::min(P.deep_k8 & ~7, 8 * bins8);
 #define FDH_COMPOSITE(paths) \
   do { if (full) FDH_LAUNCH((k_composite_tiles<paths, true>), dim3(grid), blk, lds, s, P.order, P.order_next, P.counts, P.lists, P.bin_x0, P.bin_y0, P.bin_nx, P.bin_ny, P.bins_x, P.stride, P.row_lo, P.row_hi, draws, exts, P); \
        else FDH_LAUNCH((k_composite_tiles<paths, false>), dim3(grid), blk, lds, s, P.order, P.order_next, P.counts, P.lists, P.bin_x0, P.bin_y0, P.bin_nx, P.bin_ny, P.bins_x, P.stride, P.row_lo, P.row_hi, draws, exts, P); } while (0)
@@ -3945,7 +4236,12 @@ void launch_composite(hipStream_t s, const DrawRec* draws, const QuadExt* exts, 
   if (P.has_slow || (P.has_rot && P.has_atlas)) FDH_COMPOSITE(3);
   else if (P.has_rot) FDH_COMPOSITE(8);
   else if (P.has_atlas) FDH_COMPOSITE(2);
-  else if (!P.has_masks) FDH_COMPOSITE(4);
+  else if (!P.has_masks) {
+    if (P.deep_k8 > 0 && P.order && P.order_next) {  // a frame with deep bins: the launch of four-wave workgroups
+      const dim3 g(8 + P.deep_k8 * 16 + 8 * bins8 * kWgsPerBin);
+      FDH_LAUNCH((k_composite_deep<0>), g, dim3(256), sizeof(uint32_t) * kDeepLdsDwords, s, draws, exts, P);
+    } else FDH_COMPOSITE(4);
+  }
   else FDH_COMPOSITE(0);
 #endif
 #undef FDH_COMPOSITE
@@ -4201,6 +4497,13 @@ void debug_counters(unsigned long long out[128], bool reset) {
 #else  // FDH_TU 1: the one launcher of this unit
 template <int kPaths, bool kFull>
 static void launch_uniform2(hipStream_t s, hipEvent_t e0, hipEvent_t e1, int grid, size_t lds, const DrawRec* draws, const QuadExt* exts, const CompositeParams& P) {
+  if (kPaths == 4 && kFull && P.deep_k8 > 0 && P.order && P.order_next) {  // a frame with deep bins: the launch of four-wave workgroups
+    const int bins8 = (P.bin_nx * P.bin_ny + 7) / 8;
+    const dim3 g(8 + P.deep_k8 * 16 + 8 * bins8 * kWgsPerBin);
+    if (e0) hipExtLaunchKernelGGL((k_composite_deep<1>), g, dim3(256), sizeof(uint32_t) * kDeepLdsDwords, s, e0, e1, 0, draws, exts, P);
+    else hipLaunchKernelGGL((k_composite_deep<1>), g, dim3(256), sizeof(uint32_t) * kDeepLdsDwords, s, draws, exts, P);
+    return;
+  }
   if (e0) hipExtLaunchKernelGGL((k_composite_tiles<kPaths, kFull>), dim3(grid), dim3(64), lds, s, e0, e1, 0, P.order, P.order_next, P.counts, P.lists, P.bin_x0, P.bin_y0, P.bin_nx, P.bin_ny, P.bins_x, P.stride, P.row_lo, P.row_hi, draws, exts, P);
   else hipLaunchKernelGGL((k_composite_tiles<kPaths, kFull>), dim3(grid), dim3(64), lds, s, P.order, P.order_next, P.counts, P.lists, P.bin_x0, P.bin_y0, P.bin_nx, P.bin_ny, P.bins_x, P.stride, P.row_lo, P.row_hi, draws, exts, P);
 }

@@ -133,6 +133,56 @@ def test_every_kernel_build_gives_the_same_pixels(hip, paths):
             assert np.array_equal(res["default"][k], res["forced"][k]), (paths, k)
 
 
+@pytest.mark.parametrize("deep_min", [1, 12])
+def test_deep_strips_give_the_same_pixels(deep_min):
+    """Round 6: the strips of the bins with the frame's longest lists are shaded by a workgroup of four waves -- three evaluate the draws'
+    source terms, one blends them out of a ring in LDS, in list order (k_composite_deep, composite_strip's kRole).  Same operations on the
+    same values as the one-wave strips: frames must not change by a bit whether no bin (FDH_DEEP_MIN=0), every bin that holds a draw (1) or
+    the deep ones (12) go that way -- the bench tree at 1080p, at a size that is no multiple of 32 and at 4K with its blur nodes (solid /
+    gradient / 3-stop fills, strokes, drop and inner shadows, elliptical corners, shared distance fields, opaque cores that cut the lists),
+    fuzz scenes.  Child processes (the threshold is read once); every scene is rendered four times: the second frame on has the order, the
+    third the sorting waves' count of deep bins."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+
+    code = (
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import ref_scenes as RS\n"
+        "from figdraw_amd.context import HipContext\n"
+        "from figdraw_amd.scenes import make_render_tree_100\n"
+        "out = {}; q = {}\n"
+        "cases = [('tree1080', lambda: make_render_tree_100(1920, 1080, 3), 1920, 1080), ('tree_odd', lambda: make_render_tree_100(1003, 617, 1, copies=60), 1003, 617),\n"
+        "         ('tree720', lambda: make_render_tree_100(1280, 720, 7), 1280, 720),\n"
+        "         ('tree4k_blur', lambda: make_render_tree_100(3840, 2160, 0, full_frame_blur=True), 3840, 2160),\n"
+        "         ('fuzz31', lambda: RS.random_scene(31, 900.0, 500.0, n=120, clips=False, blur=False), 900, 500),\n"
+        "         ('fuzz32', lambda: RS.random_scene(32, 640.0, 360.0, n=200, clips=False, blur=True), 640, 360)]\n"
+        "for name, fn, w, h in cases:\n"
+        "    ctx = HipContext(device=0)\n"
+        "    for i in range(4):\n"
+        "        ctx.render_frame(fn(), w, h); ctx.sync()\n"
+        "    out[name] = ctx.read_pixels(); q[name] = ctx.frame_stats().deep_bins; ctx.close()\n"
+        "np.savez(sys.argv[1], **out)\n"
+        "print('DEEP', q)\n"
+    ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.TemporaryDirectory() as td:
+        res, deep = {}, {}
+        for tag, env in (("off", {"FDH_DEEP_MIN": "0"}), ("on", {"FDH_DEEP_MIN": str(deep_min)})):
+            path = os.path.join(td, tag + ".npz")
+            r = subprocess.run([sys.executable, "-c", code, path], env={**os.environ, **env}, capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, r.stderr[-2000:]
+            res[tag] = dict(np.load(path))
+            deep[tag] = eval([ln for ln in r.stdout.splitlines() if ln.startswith("DEEP ")][-1][5:])
+    assert all(v == 0 for v in deep["off"].values()), deep
+    # (the fuzz scenes' first phase holds rotated quads: another build of the kernel, no deep strips -- they ride along as a check that
+    # the switch changes nothing there either)
+    assert deep["on"]["tree1080"] > 0 and deep["on"]["tree_odd"] > 0 and deep["on"]["tree720"] > 0 and (deep_min > 1 or deep["on"]["tree4k_blur"] > 0), deep
+    for k in res["off"]:
+        assert np.array_equal(res["off"][k], res["on"][k]), (deep_min, k, int((res["off"][k] != res["on"][k]).any(axis=2).sum()), deep["on"][k])
+
+
 @pytest.mark.parametrize("w,h,copies,frame", [(1280, 720, 40, 0), (1920, 1080, 100, 5), (803, 601, 25, 2)])
 def test_rotated_tree_matches_oracle(w, h, copies, frame):
     """Every rectangle of the renderlist_100 tree rotated by -30 .. 30 degrees (config 9 of tools/perf_configs.py): rotated quads

@@ -42,7 +42,7 @@ def code_objects(blob: bytes):
         at += len(MAGIC)
 
 
-UNIFORM_KERNELS = tuple("k_composite_tilesILi%dELb%dE" % (paths, full) for paths in (4, 0, 2) for full in (1, 0))
+UNIFORM_KERNELS = tuple("k_composite_tilesILi%dELb%dE" % (paths, full) for paths in (4, 0, 2) for full in (1, 0)) + ("k_composite_deepILi1EE",)
 # writes of the exec mask: s_*saveexec*, any scalar instruction whose destination is exec / exec_lo / exec_hi, and the VOPC
 # compares that write exec directly (v_cmpx_*)
 # (s_cmp_* / s_bitcmp* name exec as a SOURCE and write SCC only -- `s_cmp_lg_u64 exec, 0` is a wave vote over a condition the

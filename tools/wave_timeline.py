@@ -32,29 +32,32 @@ L.fdh_debug_wave_times(wt.ctypes.data)  # (a read clears the rows)
 ctx.replay(1)
 ctx.sync()
 L.fdh_debug_wave_times(wt.ctypes.data)
-print("rows with any entry:", int((wt != 0).any(axis=1).sum()), " column 6 values:", np.unique(wt[:, 6])[:5])
-ok = wt[:, 0] != 0  # (column 6, the "row written" flag, reads 0 on this toolchain; a duration never does)
+ok = wt[:, 6] != 0
 t = wt[ok].astype(np.float64)
 print("rows flagged:", int(ok.sum()))
 WALL = 100.0  # wall_clock64: 100 MHz, one counter for the whole device (clock64 is per XCD)
-start, end, cyc, draws = t[:, 1] / WALL, t[:, 2] / WALL, t[:, 0], t[:, 5]
+start, end, cyc, draws, role = t[:, 1] / WALL, t[:, 2] / WALL, t[:, 0], t[:, 5], t[:, 6]
 # (the later phases' launches overwrite the low rows; the full-frame launch is the bulk: keep the waves that start within 200 us of the median start)
 keep = np.abs(start - np.median(start)) < 200.0
-start, end, cyc, draws = start[keep], end[keep], cyc[keep], draws[keep]
+start, end, cyc, draws, role = start[keep], end[keep], cyc[keep], draws[keep], role[keep]
 t0 = start.min()
 start -= t0
 end -= t0
 dur = end - start
 span = end.max()
-print(f"waves {len(start)}, span {span:.1f} us (event-timed launch: {st.ms_composite_main * 1000:.1f}), sum of wave durations {dur.sum() / 1e3:.1f} ms = {dur.sum() / span:.0f} waves in flight on average (6144 slots at 6 per SIMD)")
+print(f"waves {len(start)}, span {span:.1f} us (event-timed launch: {st.ms_composite_main * 1000:.1f}), sum of wave durations {dur.sum() / 1e3:.1f} ms = {dur.sum() / span:.0f} waves in flight on average (6144 slots at 6 per SIMD); deep bins: {st.deep_bins:.0f}")
 print(f"shader clock: {np.median(cyc[dur > 1] / dur[dur > 1]):.0f} cycles per us")
-print(f"wave duration us: p10 {np.percentile(dur, 10):.1f}  p50 {np.percentile(dur, 50):.1f}  p90 {np.percentile(dur, 90):.1f}  p99 {np.percentile(dur, 99):.1f}  max {dur.max():.1f}")
-print(f"draws shaded per wave: p50 {np.percentile(draws, 50):.0f}  p90 {np.percentile(draws, 90):.0f}  p99 {np.percentile(draws, 99):.0f}  max {draws.max():.0f}  total {draws.sum():.0f}")
-for lo, hi in ((0, 0), (1, 4), (5, 9), (10, 19), (20, 29), (30, 39), (40, 59), (60, 999)):
-    m = (draws >= lo) & (draws <= hi)
-    if m.any():
-        print(f"  waves with {lo:3d}..{hi:3d} draws: {int(m.sum()):6d}   duration mean {dur[m].mean():6.2f} us  ({dur[m].sum() / max(draws[m].sum(), 1) * 1e3:6.0f} ns per draw)   start mean {start[m].mean():6.2f} us   end max {end[m].max():6.2f}")
+for rl, name in ((1, "one-wave strips"), (2, "deep strips' blenders"), (3, "deep strips' shaders")):
+    k = role == rl
+    if not k.any():
+        continue
+    d_, n_, s_, e_ = dur[k], draws[k], start[k], end[k]
+    print(f"-- {name}: {int(k.sum())} waves; duration us p50 {np.percentile(d_, 50):.1f} p90 {np.percentile(d_, 90):.1f} p99 {np.percentile(d_, 99):.1f} max {d_.max():.1f}; list entries walked p50 {np.percentile(n_, 50):.0f} p90 {np.percentile(n_, 90):.0f} max {n_.max():.0f}; start p50 {np.percentile(s_, 50):.1f} max {s_.max():.1f}; end max {e_.max():.1f}")
+    for lo, hi in ((0, 0), (1, 4), (5, 9), (10, 19), (20, 29), (30, 39), (40, 59), (60, 999)):
+        m = (n_ >= lo) & (n_ <= hi)
+        if m.any():
+            print(f"     {lo:3d}..{hi:3d} entries: {int(m.sum()):6d} waves   duration mean {d_[m].mean():6.2f} us  ({d_[m].sum() / max(n_[m].sum(), 1) * 1e3:6.0f} ns per entry)   start mean {s_[m].mean():6.2f}   end max {e_[m].max():6.2f}")
 print("waves in flight at 5 %, 15 %, .. 95 % of the span:", [int(((start <= f * span) & (end > f * span)).sum()) for f in np.linspace(0.05, 0.95, 10)])
 print("waves started by then:                            ", [int((start <= f * span).sum()) for f in np.linspace(0.05, 0.95, 10)])
 last = np.argsort(end)[-6:]
-print("the six waves that end last: (start us, duration us, draws)", [(round(float(start[i]), 1), round(float(dur[i]), 1), int(draws[i])) for i in last])
+print("the six waves that end last: (role, start us, duration us, entries)", [(int(role[i]), round(float(start[i]), 1), round(float(dur[i]), 1), int(draws[i])) for i in last])
