@@ -1127,6 +1127,16 @@ int Context::walk_threads() const { return walk_threads_ >= 0 ? walk_threads_ : 
 
 // The launches of one prepared frame: the upload (a kernel on the render stream gathering the recorded pieces out of pinned host
 // memory), then binning, blur passes and compositing.  Submit thread (or the caller's, FDH_CREATE_SYNC_SUBMIT).
+// A frame every phase of which holds at most 64 draws, none of them a rotated quad or a curve (their entries need the bin kernel's
+// per-strip tests): no bin launch, the compositor's waves make their entries themselves (k_composite_tiles, "direct").  FDH_DIRECT=0: never.
+static bool direct_frame(const LaunchJob& J) {
+  static const bool on = [] { const char* e = std::getenv("FDH_DIRECT"); return !e || std::atoi(e) != 0; }();
+  if (!on || J.phases.empty()) return false;
+  for (const Phase& ph : J.phases)
+    if (ph.count > 64 || ph.has_rot || ph.has_slow) return false;
+  return true;
+}
+
 void Context::issue(LaunchJob& J) {
   const auto t_l0 = std::chrono::steady_clock::now();
   FDH_HIP(hipSetDevice(device_));
@@ -1151,7 +1161,7 @@ void Context::issue(LaunchJob& J) {
   // (A frame without a bin launch -- no phase -- keeps the event.)
   uint32_t seq = 0;
   if (J.staging_slot >= 0) {
-    const bool binned = !J.phases.empty() && J.bins_x * J.bins_y > 0;
+    const bool binned = !J.phases.empty() && J.bins_x * J.bins_y > 0 && !direct_frame(J);
     if (binned && !seq_host_) {
       FDH_HIP(hipHostMalloc((void**)&seq_host_, 64, hipHostMallocDefault));
       *seq_host_ = 0;
@@ -1198,6 +1208,7 @@ void Context::launch_frame(const LaunchJob& J, bool profile, uint32_t upload_seq
   // profile mode: every launch stamps its own pair of events (set_launch_events: the kernel's execution time, no gaps)
   auto span_begin = [&](int kind) { if (profile) { Span sp{kind, next_event(), next_event()}; set_launch_events(sp.a, sp.b); spans_.push_back(sp); } };
   auto span_end = [&]() { if (profile) { if (!launch_events_used()) spans_.pop_back(); set_launch_events(nullptr, nullptr); } };
+  const bool direct = direct_frame(J);
   span_begin(0);
   BinParams B;
   B.binrec = dv_.binrecs; B.binbox = dv_.binbox; B.chunkbox = dv_.chunkbox; B.n_draws = J.n_recs; B.binbox_shift = binbox_shift_; B.lists = J.lists; B.counts = J.counts; B.phase_first = dv_.phase_first; B.draws = dv_.recs; B.exts = dv_.exts;
@@ -1220,13 +1231,13 @@ void Context::launch_frame(const LaunchJob& J, bool profile, uint32_t upload_seq
     B.sub_first[np] = at;
     B.sub_n = np;
   }
-  launch_bin(stream_, B);
+  if (!direct) launch_bin(stream_, B);
   span_end();
   // Phase 0's full-grid composite takes its bins longest-list first, in the order its predecessor sorted (an extra
   // wavefront of that launch); it sorts this frame's counts for its successor.  Any permutation is a correct schedule.
   const int order_key = bins_x_ * 65536 + bins_y_;  // entries are (row << 16 | column) of THIS grid
   if (order_valid_ && order_nb_ != order_key) order_valid_ = false;  // frame size changed
-  const bool sorting = J.clear && np > 0 && nb <= 8192 && J.phases[0].count > 0;
+  const bool sorting = J.clear && np > 0 && nb <= 8192 && J.phases[0].count > 0 && !direct;  // (a direct frame has no counts to sort by)
   const int* order_now = (sorting && order_valid_) ? d_order_[order_read_].ptr : nullptr;
   int* order_next = nullptr;
   if (sorting) {
@@ -1327,6 +1338,7 @@ void Context::launch_frame(const LaunchJob& J, bool profile, uint32_t upload_seq
     C.load_fb = full ? 0 : 1;
     C.clear_rgba8 = J.clear_rgba8;
     C.n_wg = 0;
+    C.direct = direct ? 1 : 0; C.direct_first = ph.first; C.direct_n = ph.count; C.binrec = dv_.binrecs;
     C.order = full ? order_now : nullptr;
     C.order_next = full ? order_next : nullptr;
     C.deep_k8 = full ? deep_k8 : 0;

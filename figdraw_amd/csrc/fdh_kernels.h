@@ -56,6 +56,10 @@ struct CompositeParams {
   // quarter strips (round 6, k_composite_tiles): the first deep_k8 positions of `order` (a multiple of 8) are shaded by four waves per
   // strip; deep_min / deep_out: the sorting waves count the bins with at least deep_min draws per class into deep_out[0..7]
   // (pinned host memory, or null)
+  // a direct launch (round 6): the phase has at most 64 draws and no list -- the compositor's waves make their bin's entries themselves
+  // from the bin records of draws [direct_first, direct_first + direct_n)
+  int direct = 0, direct_first = 0, direct_n = 0;
+  const BinRec* binrec = nullptr;
   int deep_k8 = 0;
   int deep_strip_min = 0;   // ... those of their strips that have at least this many draws to SHADE (strip_shade_count); the others keep their one wave
   int deep_min = 0;

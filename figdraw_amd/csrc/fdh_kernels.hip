@@ -362,13 +362,14 @@ __device__ __forceinline__ uint32_t strip_mask(int x0, int y0, int x1, int y1) {
 }
 
 // the strips of a bin that lie entirely inside a bin-relative pixel box (the draw's saturated core)
+// (no branch: the compositor's direct launches make entries inside their draw loop, which must hold no divergent one -- tools/lint_isa.py)
 __device__ __forceinline__ uint32_t strip_mask_inside(int x0, int y0, int x1, int y1) {
-  if (x1 <= x0 || y1 <= y0) return 0u;
   int r0 = (y0 + 7) >> 3, r1 = y1 >> 3;  // strip rows [r0, r1) fully inside
-  r0 = r0 < 0 ? 0 : r0; r1 = r1 > 8 ? 8 : r1;
-  if (r1 <= r0) return 0u;
+  r0 = r0 < 0 ? 0 : r0; r0 = r0 > 8 ? 8 : r0; r1 = r1 > 8 ? 8 : r1;
+  r1 = r1 < r0 ? r0 : r1;                // (no row: the mask below is empty)
   const uint32_t rows = ((1u << r1) - 1u) & ~((1u << r0) - 1u);
-  return strips_of_rows(rows, x0 <= 0 && x1 >= kTileW, x0 <= kTileW && x1 >= 2 * kTileW);
+  const uint32_t m = strips_of_rows(rows, x0 <= 0 && x1 >= kTileW, x0 <= kTileW && x1 >= 2 * kTileW);
+  return (x1 <= x0 || y1 <= y0) ? 0u : m;
 }
 
 // List entry flags (uint2.x high bits; the low 30 bits are the draw index)
@@ -384,17 +385,13 @@ __device__ __forceinline__ uint32_t strip_mask_inside(int x0, int y0, int x1, in
 // more than 128 bins along an axis; the exact test follows for the hits).  With U = (bx | by << 8 | (127 - bx) << 16 |
 // (127 - by) << 24) | 0x80808080, the four byte-wise differences U - q keep their guard bit exactly when
 // x0 <= bx, y0 <= by, bx <= x1, by <= y1: one subtract, one and, one compare per draw.
-#if FDH_TU == 0
-__device__ __forceinline__ bool binbox_hits(uint32_t q, uint32_t U) { return ((U - q) & 0x80808080u) == 0x80808080u; }
-// (kRefine: the build for frames that hold bezier strokes or rotated quads -- their per-strip tests cost registers, 193 against 56,
-// which a frame without them should not pay in occupancy: bench frame 5.4 us against 8.7)
-template <bool kRefine>
-__device__ __forceinline__ void bin_entry(const BinParams& P, int i, int x0, int y0, bool& hit, uint32_t& word, uint32_t& strips) {
-  // (the 24-byte BinRec in ONE round trip -- a 16- and an 8-byte load issued together, pinned: read field by field the compiler sank
-  // each field's load behind the test before it, three to four dependent L2 latencies per batch of hits)
-  BinRec r;
+// The two ends of an entry's making that every draw goes through -- both translation units hold them: the compositor of a frame with at
+// most 64 draws per phase makes its entries itself (round 6: "direct" launches, k_composite_tiles).
+// (the 24-byte BinRec in ONE round trip -- a 16- and an 8-byte load issued together, pinned: read field by field the compiler sank
+// each field's load behind the test before it, three to four dependent L2 latencies per batch of hits)
+__device__ __forceinline__ bool bin_entry_head(const BinRec* __restrict__ binrec, int i, int x0, int y0, BinRec& r, uint32_t& word, uint32_t& strips) {
   {
-    const uint2* __restrict__ src = reinterpret_cast<const uint2*>(P.binrec + i);
+    const uint2* __restrict__ src = reinterpret_cast<const uint2*>(binrec + i);
     uint2 q0 = src[0], q1 = src[1], q2 = src[2];
     asm volatile("" : "+v"(q0), "+v"(q1), "+v"(q2));
     r.box.x0 = (int16_t)(q0.x & 0xffffu); r.box.y0 = (int16_t)(q0.x >> 16); r.box.x1 = (int16_t)(q0.y & 0xffffu); r.box.y1 = (int16_t)(q0.y >> 16);
@@ -402,9 +399,34 @@ __device__ __forceinline__ void bin_entry(const BinParams& P, int i, int x0, int
     r.flags = q2.x; r.pad = q2.y;
   }
   const BBox b = r.box;
-  if (!(b.x0 < x0 + kBin && b.x1 > x0 && b.y0 < y0 + kBin && b.y1 > y0)) { hit = false; return; }  // exact test
   strips = strip_mask(b.x0 - x0, b.y0 - y0, b.x1 - x0, b.y1 - y0);
   word = (uint32_t)i | (r.flags & ~LE_INDEX);
+  return b.x0 < x0 + kBin && b.x1 > x0 && b.y0 < y0 + kBin && b.y1 > y0;  // exact test
+}
+// (written without branches, for the same reason: every step is computed and selected)
+__device__ __forceinline__ void bin_entry_tail(const BinRec& r, int x0, int y0, bool& hit, uint32_t& strips) {
+  const bool has_core = (r.flags & BR_HAS_CORE) != 0u, removed = (r.flags & BR_CORE_REMOVED) != 0u, exact = (r.flags & BR_BOX_EXACT) != 0u;
+  const uint32_t core = strip_mask_inside(r.ix0 - x0, r.iy0 - y0, r.ix1 - x0, r.iy1 - y0) & strips;
+  // alpha == 0 on the core (stroke interior) or too small to change an 8-bit channel (deep inside an inner shadow): those strips leave
+  // the entry, and the entry goes with them if none is left; any other core is marked in the high half
+  const uint32_t s_removed = strips & ~core, s_marked = strips | (core << 16);
+  const uint32_t s1 = has_core ? (removed ? s_removed : s_marked) : strips;
+  const bool gone = has_core && removed && s_removed == 0u;
+  // edge strips wholly inside the quad's pixel bounds: state (0, 1) -- fdh_types.h, BR_BOX_EXACT
+  const BBox b = r.box;
+  const uint32_t inq = strip_mask_inside(b.x0 - x0, b.y0 - y0, b.x1 - x0, b.y1 - y0) & s1 & ~(s1 >> 16) & 0xffffu;
+  const uint32_t s2 = (s1 & ~inq) | (inq << 16);
+  strips = (has_core && !gone && exact) ? s2 : s1;
+  hit = hit && !gone;
+}
+#if FDH_TU == 0
+__device__ __forceinline__ bool binbox_hits(uint32_t q, uint32_t U) { return ((U - q) & 0x80808080u) == 0x80808080u; }
+// (kRefine: the build for frames that hold bezier strokes or rotated quads -- their per-strip tests cost registers, 193 against 56,
+// which a frame without them should not pay in occupancy: bench frame 5.4 us against 8.7)
+template <bool kRefine>
+__device__ __forceinline__ void bin_entry(const BinParams& P, int i, int x0, int y0, bool& hit, uint32_t& word, uint32_t& strips) {
+  BinRec r;
+  if (!bin_entry_head(P.binrec, i, x0, y0, r, word, strips)) { hit = false; return; }
   if (kRefine && (r.flags & BR_CURVE)) {
     // A bezier stroke: strips whose pixels are all farther from the chord-aligned box around the curve than sqrt 2 (half width +
     // 0.5 / aa) hold no coverage (see the 4-wide bezier path of k_composite_tiles, which applies the same bound per strip after
@@ -547,20 +569,7 @@ __device__ __forceinline__ void bin_entry(const BinParams& P, int i, int x0, int
     hit = (strips & 0xffffu) != 0u;
     return;
   }
-  if (!(r.flags & BR_HAS_CORE)) return;
-  const uint32_t core = strip_mask_inside(r.ix0 - x0, r.iy0 - y0, r.ix1 - x0, r.iy1 - y0) & strips;
-  if (r.flags & BR_CORE_REMOVED) {
-    strips &= ~core;  // alpha == 0 there (stroke interior) or too small to change an 8-bit channel (deep inside an inner shadow)
-    hit = strips != 0u;
-    if (!hit) return;
-  } else {
-    strips |= core << 16;
-  }
-  // edge strips wholly inside the quad's pixel bounds: state (0, 1) -- fdh_types.h, BR_BOX_EXACT
-  if (r.flags & BR_BOX_EXACT) {
-    const uint32_t inq = strip_mask_inside(b.x0 - x0, b.y0 - y0, b.x1 - x0, b.y1 - y0) & strips & ~(strips >> 16) & 0xffffu;
-    strips = (strips & ~inq) | (inq << 16);
-  }
+  bin_entry_tail(r, x0, y0, hit, strips);
 }
 template <bool kRefine>
 __global__ __launch_bounds__(64) void k_bin_draws(BinParams P) {
@@ -1406,7 +1415,12 @@ __device__ __forceinline__ void composite_strip(const CompositeParams& P, const 
   unsigned long long T_cull = 0, T_rec = 0, T_shade = 0, T_cnt = 0, n_draws_t = 0, T_cull_core = 0, n_core_t = 0, n_all_t = 0;
   unsigned long long T_mode[4] = {0, 0, 0, 0}, N_mode[4] = {0, 0, 0, 0};  // edge draws by mode: 3, 7, 9, 12
 #endif
-  const uint32_t cnt = P.counts[bin];
+  // A DIRECT launch (round 6): a phase of at most 64 draws has no list -- k_bin_draws was not launched for the frame --, every strip's
+  // wave makes the entries of its bin itself, lane i the one of the phase's draw i, with the two functions the bin kernel makes them
+  // with.  A frame of a handful of draws (a dialog, the reference's 4-node test scene) is one launch less: its launches are latency,
+  // 4 - 5 us each, not work.
+  const bool direct = P.direct != 0;
+  const uint32_t cnt = direct ? (uint32_t)P.direct_n : P.counts[bin];
 #if FDH_TIMING
   T_cnt = FDH_NOW() - T0 + (cnt & 0u);
 #endif
@@ -1504,7 +1518,17 @@ __device__ __forceinline__ void composite_strip(const CompositeParams& P, const 
 #endif
     const uint32_t i = base + lane;
     // (no branch around the load: lanes past the end read the last entry and drop it)
-    const uint2 e = list[min(i, cnt - 1u)];  // {draw index | flags, strips touched | strips inside the saturated core << 16}
+    uint2 e;
+    if (direct) {  // (wave-uniform; what is inside compiles to selects)
+      const int by = bin / P.bins_x, bx = bin - by * P.bins_x;
+      BinRec br;
+      uint32_t word = 0, strips = 0;
+      bool hit = bin_entry_head(P.binrec, P.direct_first + (int)min(i, cnt - 1u), bx * kBin, by * kBin, br, word, strips);
+      bin_entry_tail(br, bx * kBin, by * kBin, hit, strips);
+      e = make_uint2(word, hit ? strips : 0u);
+    } else {
+      e = list[min(i, cnt - 1u)];  // {draw index | flags, strips touched | strips inside the saturated core << 16}
+    }
     const uint32_t idx = e.x;
     const uint32_t ey = i < cnt ? e.y : 0u;
     // this strip's state in the entry (fdh_types.h): (1, 0) touched, (1, 1) core, (0, 1) an edge strip wholly inside the draw's quad

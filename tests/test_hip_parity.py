@@ -133,6 +133,51 @@ def test_every_kernel_build_gives_the_same_pixels(hip, paths):
             assert np.array_equal(res["default"][k], res["forced"][k]), (paths, k)
 
 
+def test_direct_launches_give_the_same_pixels():
+    """Round 6: a frame every phase of which holds at most 64 draws has no bin launch -- the compositor's waves make their bin's list
+    entries themselves, with the functions k_bin_draws makes them with (bin_entry_head / bin_entry_tail; fdh_context.cpp direct_frame).
+    FDH_DIRECT=0 keeps the bin launch: the frames must be equal bit for bit -- scenes of every build of the kernel that has the path (no
+    clips, clips and rect masks, atlas quads), stroke interiors that drop out of their entries, a blur node (two phases), a frame size that
+    is no multiple of 64, and one scene ABOVE the limit that must not take the path."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+
+    names = ["rgb_boxes_sdf", "rgb_boxes", "linear_gradient", "layers_clip", "layers_rect_mask", "oneframe", "elliptical_and_fractional", "nested_clips", "rect_mask_nested",
+             "backdrop_blur", "rect_mask_mixed_batch"]
+    code = (
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import ref_scenes as RS\n"
+        "from figdraw_amd.context import HipContext\n"
+        "from figdraw_amd.scenes import make_render_tree_100\n"
+        "ALL = {k: v[:3] for k, v in RS.REFERENCE_PNG_SCENES.items()}; ALL.update(RS.SWIFTSHADER_SCENES)\n"
+        "ctx = HipContext(device=0)\n"
+        "out = {}; bins = {}\n"
+        "for n in %r:\n"
+        "    fn, w, h = ALL[n]\n"
+        "    ctx.render_frame(fn(float(w), float(h)), w, h); out[n] = ctx.read_pixels(); ctx.profile(1); bins[n] = ctx.frame_stats().ms_bin\n"
+        "ctx.render_frame(make_render_tree_100(700, 500, 2, copies=9), 700, 500); out['tree9'] = ctx.read_pixels(); ctx.profile(1); bins['tree9'] = ctx.frame_stats().ms_bin\n"
+        "ctx.render_frame(make_render_tree_100(700, 500, 2, copies=40), 700, 500); out['tree40'] = ctx.read_pixels(); ctx.profile(1); bins['tree40'] = ctx.frame_stats().ms_bin\n"
+        "np.savez(sys.argv[1], **out)\n"
+        "print('BINMS', bins)\n"
+    ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)), names)
+    with tempfile.TemporaryDirectory() as td:
+        res, binms = {}, {}
+        for tag, env in (("bin", {"FDH_DIRECT": "0"}), ("direct", {"FDH_DIRECT": "1"})):
+            path = os.path.join(td, tag + ".npz")
+            r = subprocess.run([sys.executable, "-c", code, path], env={**os.environ, **env}, capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, r.stderr[-2000:]
+            res[tag] = dict(np.load(path))
+            binms[tag] = eval([ln for ln in r.stdout.splitlines() if ln.startswith("BINMS ")][-1][6:])
+    assert all(v > 0 for v in binms["bin"].values()), binms
+    assert binms["direct"]["rgb_boxes_sdf"] == 0 and binms["direct"]["nested_clips"] == 0 and binms["direct"]["tree9"] == 0, binms   # no bin launch
+    assert binms["direct"]["tree40"] > 0, binms  # (122 draws: over the limit)
+    for k in res["bin"]:
+        assert np.array_equal(res["bin"][k], res["direct"][k]), (k, int((res["bin"][k] != res["direct"][k]).any(axis=2).sum()))
+
+
 @pytest.mark.parametrize("deep_min", [1, 12])
 def test_deep_strips_give_the_same_pixels(deep_min):
     """Round 6: the strips of the bins with the frame's longest lists are shaded by a workgroup of four waves -- three evaluate the draws'
