@@ -34,14 +34,6 @@ inline Context* C(FdhContext* c) {
 extern "C" {
 
 const char* fdh_last_error(void) { return g_last_error.c_str(); }
-#if defined(FDH_EDGE_CHECK) && FDH_EDGE_CHECK
-extern "C++" { namespace fdh { void debug_edge_bad(unsigned int* n, unsigned int* out, bool reset); } }
-__attribute__((visibility("default"))) int fdh_debug_edge_bad(unsigned int* n, unsigned int* out, int reset) { fdh::debug_edge_bad(n, out, reset != 0); return 0; }
-#endif
-#if defined(FDH_MX_CHECK) && FDH_MX_CHECK
-extern "C++" { namespace fdh { void debug_mx_bad(unsigned int* n, unsigned int* out, bool reset); } }
-__attribute__((visibility("default"))) int fdh_debug_mx_bad(unsigned int* n, unsigned int* out, int reset) { fdh::debug_mx_bad(n, out, reset != 0); return 0; }
-#endif
 #if FDH_STATS
 extern "C++" { namespace fdh { void debug_counters(unsigned long long out[128], bool reset); void debug_wave_times(unsigned long long* out); } }
 __attribute__((visibility("default"))) int fdh_debug_wave_times(unsigned long long* out) { fdh::debug_wave_times(out); return 0; }

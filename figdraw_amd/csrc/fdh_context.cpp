@@ -639,7 +639,7 @@ void Context::ensure_surfaces() {
   surf_h_ = H_;
 }
 
-// Weight fragments of a matrix-pipe blur pass (k_blur_mx, fdh_kernels.hip).  Lane (j, g) of fragment m holds, for the window
+// Weight fragments of a matrix-pipe blur pass (k_blur_mx, k_blur_mx.hip).  Lane (j, g) of fragment m holds, for the window
 // texels 16 m + 8 g + t (t = 0..7) of a 32-output block, the tap each meets at output j: k = texel - delta - j, weight
 // q[k] (the tap at scale 2^10 as one f16: quantise_taps_f16 below) when 0 <= k <= 2 reach, else 0.  Every product with an 8-bit
 // texel is exact in f32.  (Rounds 2 - 4 carried a second half, lo = RNE(w - hi), 22 significant bits: its slot in the layout remains, zero.)
@@ -662,7 +662,7 @@ static float half_value(uint16_t h) {
   const float v = e == 0 ? std::ldexp((float)m, -24) : std::ldexp((float)(m + 1024), e - 25);
   return (h & 0x8000u) ? -v : v;
 }
-// Round 5: the taps as ONE f16 each at scale 2^10 (the kernels multiply once per operand and k-step: FDH_MX_LO in fdh_kernels.hip).
+// Round 5: the taps as ONE f16 each at scale 2^10 (the kernels multiply once per operand and k-step: FDH_MX_LO in fdh_types.h).
 // Rounded from the CENTRE tap outwards, the rounding error carried to the next tap out (the filter is symmetric: each side takes half
 // of the centre's error): a tap's error is made good by its neighbour, and what is left at the end falls on the outermost taps, whose
 // f16 steps are thousands of times finer than the centre's -- the sum of the weights is kept to ~1e-7 (a flat region keeps its value)

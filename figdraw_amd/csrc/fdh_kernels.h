@@ -1,4 +1,4 @@
-// fdh_kernels.h -- kernel parameter blocks and launchers shared by fdh_kernels.hip and the host context.
+// fdh_kernels.h -- kernel parameter blocks and launchers shared by the kernel units (k_*.hip) and the host context.
 #pragma once
 #include <hip/hip_runtime.h>
 

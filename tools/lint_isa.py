@@ -8,7 +8,7 @@ same SIMD is issuing v_mfma.  figdraw's matrix-pipe blur passes of one context r
 others, so the product is built with -packed-fp32-ops (measured: not slower) and this script keeps it that way.
 
 Second check: k_composite_tiles<0|2|4> are compiled with -structurizecfg-skip-uniform-regions (csrc/Makefile, the FDH_TU note in
-fdh_kernels.hip), which is only sound while its draw loop nest holds no divergent branch.  The loop nest -- every backward
+k_composite.hip), which is only sound while its draw loop nest holds no divergent branch.  The loop nest -- every backward
 branch whose range holds the draw loop's s_ff1_i32_b64 -- must therefore not write the exec mask.
 
 usage: lint_isa.py <library.so> [--allow-packed] [--allow-missing]   exit status 1 if a forbidden opcode is present, a uniform-build

@@ -123,7 +123,7 @@ __global__ __launch_bounds__(64) void k_victim(Report* rep, int iters, float ua,
 }
 
 
-// Victim 2: the compositor's core-strip blend as hipcc compiles it (fdh_kernels.hip, k_composite_tiles, LE_PLAIN entries): one
+// Victim 2: the compositor's core-strip blend as hipcc compiles it (k_composite.hip, k_composite_tiles, LE_PLAIN entries): one
 // colour per step arrives through a scalar load, is unpacked with v_cvt_f32_ubyte{0..3} from the SGPR, scaled with packed
 // multiplies (op_sel / op_sel_hi broadcasts) and blended into four pixels per lane with v_pk_fma_f32 + v_rndne_f32.  Every
 // lane computes the SAME values (the inputs are wave-uniform), so a lane whose result differs from lane 0's is wrong:

@@ -98,7 +98,8 @@ def check(ctxs, it, counts):
 
 
 def dump_mx_bad():
-    """FDH_MX_CHECK builds: texels a wave read from its LDS ring that differ from global memory"""
+    """FDH_MX_CHECK builds (round 2; the switch was pruned from the kernels in round 6 -- git history has it): texels a wave read from its
+    LDS ring that differ from global memory.  A library without the entry point: nothing to dump."""
     L = hip.L
     if not hasattr(L, "fdh_debug_mx_bad"):
         return
@@ -126,7 +127,7 @@ def dump_mx_bad():
 
 
 def dump_edge_bad():
-    """FDH_EDGE_CHECK builds: packed edge path vs generic path, same strip, same draw"""
+    """FDH_EDGE_CHECK builds (round 2; pruned in round 6 like FDH_MX_CHECK): packed edge path vs generic path, same strip, same draw"""
     L = hip.L
     try:
         f = L.fdh_debug_edge_bad
