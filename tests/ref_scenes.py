@@ -664,6 +664,116 @@ def hostile_blur_scene(radius):
     return out
 
 
+# ---- the reference's invert tests (tests/trender_image_msdf_invert.nim, tests/trender_text_invert.nim): a node drawn as it is, the same
+# node under a parent that mirrors y (nkTransform: translation (0, h), matrix scale(1, -1, 1)), and the same with NfInvertY, which must
+# stand upright again.  The reference asserts ROW PROFILES, not pixels: restated as known answers in test_oracle.py (oracle) and
+# test_hip_parity.py (HIP).
+INVERT_BITMAP_KEY, INVERT_MSDF_KEY = 0x696E7631, 0x696E7632
+INVERT_RECTS = {"image_base": (40, 50, 180, 180), "image_no_invert": (260, 50, 180, 180), "image_invert": (480, 50, 180, 180),
+                "msdf_base": (40, 270, 180, 180), "msdf_no_invert": (260, 270, 180, 180), "msdf_invert": (480, 270, 180, 180)}
+
+
+def invert_test_images():
+    """makeAsymmetricImage / makeSyntheticMsdfField (trender_image_msdf_invert.nim:11-33): 24 x 24, the top third one colour, the rest another"""
+    import numpy as np
+
+    bitmap = np.zeros((24, 24, 4), np.uint8); bitmap[:8] = (0, 0, 0, 255); bitmap[8:] = (255, 230, 0, 255)
+    field_ = np.zeros((24, 24, 4), np.uint8); field_[:8] = (255, 255, 255, 255); field_[8:] = (0, 0, 0, 255)
+    return {INVERT_BITMAP_KEY: bitmap, INVERT_MSDF_KEY: field_}
+
+
+def _mirrored_input(r, h):  # mirroredInputRect (:98-99)
+    return rect(r[0], h - r[1] - r[3], r[2], r[3])
+
+
+def image_msdf_invert(w=720.0, h=520.0) -> Renders:
+    """trender_image_msdf_invert.nim:101-201"""
+    R = INVERT_RECTS
+    lst = RenderList()
+    lst.addRoot(Fig(kind=RECT, screenBox=rect(0, 0, w, h), fill=rgba(255, 255, 255, 255)))
+    lst.addRoot(Fig(kind=FigKind.nkImage, screenBox=rect(*R["image_base"]), image_id=INVERT_BITMAP_KEY))
+    lst.addRoot(Fig(kind=FigKind.nkMsdfImage, screenBox=rect(*R["msdf_base"]), image_id=INVERT_MSDF_KEY, image_fill=fill(rgba(0, 0, 0, 255)),
+                    pxRange=4.0, sdThreshold=0.5))
+    m = lst.addRoot(Fig(kind=FigKind.nkTransform, translation=(0.0, h), useMatrix=True, matrix=[1, 0, 0, 0, 0, -1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1]))
+    lst.addChild(m, Fig(kind=FigKind.nkImage, screenBox=_mirrored_input(R["image_no_invert"], h), image_id=INVERT_BITMAP_KEY))
+    lst.addChild(m, Fig(kind=FigKind.nkImage, screenBox=_mirrored_input(R["image_invert"], h), image_id=INVERT_BITMAP_KEY, flags=FigFlags.NfInvertY))
+    lst.addChild(m, Fig(kind=FigKind.nkMsdfImage, screenBox=_mirrored_input(R["msdf_no_invert"], h), image_id=INVERT_MSDF_KEY,
+                        image_fill=fill(rgba(0, 0, 0, 255)), pxRange=4.0, sdThreshold=0.5))
+    lst.addChild(m, Fig(kind=FigKind.nkMsdfImage, screenBox=_mirrored_input(R["msdf_invert"], h), image_id=INVERT_MSDF_KEY,
+                        image_fill=fill(rgba(0, 0, 0, 255)), pxRange=4.0, sdThreshold=0.5, flags=FigFlags.NfInvertY))
+    out = Renders()
+    out.layers[0] = lst
+    return out
+
+
+def text_invert(w=640.0, h=360.0, images=None) -> Renders:
+    """trender_text_invert.nim:818-892 in structure: a selected text node, and the same node with NfInvertY under a parent that mirrors y.
+    The reference typesets one 72-px "g" with pixie (third party, absent): here the row is "gjpy" out of the 20-px glyph fixture, placed
+    by hand, with the selection rectangle the layout would have produced handed over as a TextRect."""
+    from figdraw_amd.scene import Glyph, TextRect
+
+    sel = fill(rgba(255, 210, 70, 210))
+    glyphs = [Glyph(image_id=1000 + ord(ch), x=float(6 + 14 * i), y=float(30 - images[1000 + ord(ch)].shape[0] + (5 if ch in "gjpy" else 0)))
+              for i, ch in enumerate("gjpy")]
+    rects = [TextRect(kind=0, x=4.0, y=6.0, w=60.0, h=32.0)]
+    lst = RenderList()
+    lst.addRoot(Fig(kind=RECT, screenBox=rect(0, 0, w, h), fill=rgba(255, 255, 255, 255)))
+    lst.addRoot(Fig(kind=FigKind.nkText, flags=FigFlags.NfSelectText, screenBox=rect(96, 120, 220, 140), fill=sel, glyphs=glyphs, textRects=rects))
+    m = lst.addRoot(Fig(kind=FigKind.nkTransform, translation=(0.0, h), useMatrix=True, matrix=[1, 0, 0, 0, 0, -1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1]))
+    lst.addChild(m, Fig(kind=FigKind.nkText, flags=FigFlags.NfInvertY | FigFlags.NfSelectText, screenBox=_mirrored_input((352, 120, 220, 140), h),
+                        fill=sel, glyphs=glyphs, textRects=rects))
+    out = Renders()
+    out.layers[0] = lst
+    return out
+
+
+def row_profile(img, r):
+    """rowProfile (trender_image_msdf_invert.nim:35-51): per row of the rectangle, the sum over its pixels of (255 - r) + (255 - g) + (255 - b)"""
+    import numpy as np
+
+    x0, y0 = max(0, int(r[0])), max(0, int(r[1]))
+    x1, y1 = min(img.shape[1] - 1, int(r[0] + r[2]) - 1), min(img.shape[0] - 1, int(r[1] + r[3]) - 1)
+    return (255 * 3 - img[y0:y1 + 1, x0:x1 + 1, :3].astype(np.int64).sum(axis=2)).sum(axis=1)
+
+
+def check_image_msdf_invert(img):
+    """the assertions of trender_image_msdf_invert.nim:224-262"""
+    import numpy as np
+
+    P = {k: row_profile(img, r) for k, r in INVERT_RECTS.items()}
+    assert all(len(v) > 0 for v in P.values())
+    assert P["image_base"].max() - P["image_base"].min() > 500 and P["msdf_base"].max() - P["msdf_base"].min() > 500
+    d = lambda a, b: int(np.abs(a - b).sum())
+    for kind in ("image", "msdf"):
+        base, no_inv, inv = P[kind + "_base"], P[kind + "_no_invert"], P[kind + "_invert"]
+        assert d(base, no_inv[::-1]) < d(base, no_inv), kind      # under the mirroring parent the node stands on its head ...
+        assert d(base, inv) <= d(base, inv[::-1]), kind           # ... and NfInvertY puts it upright again
+    return {k: int(v.max() - v.min()) for k, v in P.items()}
+
+
+def check_text_invert(img):
+    """the assertions of trender_text_invert.nim:918-943 (ink / highlight classifiers :20-24)"""
+    import numpy as np
+
+    def bounds(mask, x0, y0, w, h):
+        sub = mask[y0:y0 + h, x0:x0 + w]
+        ys, xs = np.nonzero(sub)
+        assert len(ys) > 0
+        return xs.min() + x0, ys.min() + y0, xs.max() + x0, ys.max() + y0
+    r, g, b, a = (img[:, :, k].astype(int) for k in range(4))
+    ink = (a >= 20) & ((r < 220) | (g < 220) | (b < 220))
+    hl = (a >= 20) & (r >= 180) & (g >= 150) & (b <= 140)
+    lb, rb = bounds(ink, 32, 40, 260, 260), bounds(ink, 300, 40, 260, 260)
+    lh, rh = bounds(hl, 32, 40, 260, 260), bounds(hl, 300, 40, 260, 260)
+    assert abs((lb[3] - lb[1]) - (rb[3] - rb[1])) <= 4 and abs(rb[1] - lb[1]) <= 4, (lb, rb)
+    assert abs((lh[3] - lh[1]) - (rh[3] - rh[1])) <= 2 and abs(rh[1] - lh[1]) <= 2, (lh, rh)
+    prof = lambda bb: ink[bb[1]:bb[3] + 1, bb[0]:bb[2] + 1].sum(axis=1)
+    lp, rp = prof(lb), prof(rb)
+    n = min(len(lp), len(rp))
+    assert int(np.abs(lp[:n] - rp[:n]).sum()) <= int(np.abs(lp[:n] - rp[:n][::-1]).sum())
+    return lb, rb, lh, rh
+
+
 FLIPPY_IMAGE_KEY = 0x696D6731  # any key: the reference hashes the file name (figbasics.nim imgId)
 
 

@@ -133,6 +133,30 @@ def test_every_kernel_build_gives_the_same_pixels(hip, paths):
             assert np.array_equal(res["default"][k], res["forced"][k]), (paths, k)
 
 
+def test_invert_known_answers_of_the_references_tests():
+    """The reference's own assertions on NfInvertY (tests/trender_image_msdf_invert.nim:224-262, tests/trender_text_invert.nim:918-943:
+    row profiles and ink bounds, ref_scenes.check_*) on the HIP path's frames, which must also be the oracle's within the suite's bar."""
+    import os
+
+    from figdraw_amd.context import HipContext
+    from figdraw_amd.scenes import load_glyph_fixture
+    from oracle import oracle as O
+
+    glyphs = load_glyph_fixture(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "glyphs_ubuntu20.npz"))
+    text = RS.text_invert(640.0, 360.0, glyphs)
+    for sc, imgs, w, h, check in ((RS.image_msdf_invert(), RS.invert_test_images(), 720, 520, RS.check_image_msdf_invert),
+                                  (text, RS.used_images(text, glyphs), 640, 360, RS.check_text_invert)):
+        ctx, orc = HipContext(device=0, atlas_size=1024), O.Oracle(atlas_size=1024, threads=8)
+        for k in sorted(imgs):
+            ctx.put_image(k, imgs[k]); orc.put_image(k, imgs[k])
+        ctx.render_frame(sc, w, h); orc.render_frame(sc, w, h)
+        got = ctx.read_pixels()
+        check(got)
+        mx, n0, n1 = diff_stats(got, orc.read_pixels())
+        assert mx <= 1 and n0 <= 0.005 * w * h, (mx, n0, n1)
+        ctx.close()
+
+
 def test_direct_launches_give_the_same_pixels():
     """Round 6: a frame every phase of which holds at most 64 draws has no bin launch -- the compositor's waves make their bin's list
     entries themselves, with the functions k_bin_draws makes them with (bin_entry_head / bin_entry_tail; fdh_context.cpp direct_frame).

@@ -92,6 +92,32 @@ def test_blur_matches_reference_blur_frag(radius):
     assert mx <= 1
 
 
+def test_invert_known_answers_of_the_references_tests():
+    """tests/trender_image_msdf_invert.nim:224-262 and tests/trender_text_invert.nim:918-943: a node under a parent that mirrors y stands
+    on its head, NfInvertY puts it upright again -- asserted, as the reference does, on row profiles and ink bounds of the frame
+    (ref_scenes.check_image_msdf_invert / check_text_invert).  The same two checks run on the HIP path in the GPU suite."""
+    import os
+
+    from figdraw_amd.scenes import load_glyph_fixture
+
+    imgs = RS.invert_test_images()
+    o = O.Oracle(atlas_size=1024, threads=4)
+    for k in sorted(imgs):
+        o.put_image(k, imgs[k])
+    o.render_frame(RS.image_msdf_invert(), 720, 520)
+    spans = RS.check_image_msdf_invert(o.read_pixels())
+    assert spans["image_no_invert"] == spans["image_base"] and spans["msdf_invert"] == spans["msdf_base"]
+    glyphs = load_glyph_fixture(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "glyphs_ubuntu20.npz"))
+    sc = RS.text_invert(640.0, 360.0, glyphs)
+    used = RS.used_images(sc, glyphs)
+    o = O.Oracle(atlas_size=1024, threads=4)
+    for k in sorted(used):
+        o.put_image(k, used[k])
+    o.render_frame(sc, 640, 360)
+    lb, rb, lh, rh = RS.check_text_invert(o.read_pixels())
+    assert rb[0] - lb[0] == 256 and rh[1] == lh[1]  # (the two nodes sit 256 px apart at the same height)
+
+
 @pytest.mark.parametrize("kind", RS.HOSTILE_BLUR_KINDS)
 @pytest.mark.parametrize("radius", RS.HOSTILE_BLUR_RADII)
 def test_blur_of_hostile_content_matches_reference_blur_frag(kind, radius):
