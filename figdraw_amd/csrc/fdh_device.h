@@ -373,7 +373,7 @@ __device__ __forceinline__ uint32_t strip_mask_inside(int x0, int y0, int x1, in
   r1 = r1 < r0 ? r0 : r1;                // (no row: the mask below is empty)
   const uint32_t rows = ((1u << r1) - 1u) & ~((1u << r0) - 1u);
   const uint32_t m = strips_of_rows(rows, x0 <= 0 && x1 >= kTileW, x0 <= kTileW && x1 >= 2 * kTileW);
-  return (x1 <= x0 || y1 <= y0) ? 0u : m;
+  return m & (0u - (uint32_t)(x1 > x0 && y1 > y0));
 }
 
 // List entry flags (uint2.x high bits; the low 30 bits are the draw index)
@@ -407,21 +407,21 @@ __device__ __forceinline__ bool bin_entry_head(const BinRec* __restrict__ binrec
   word = (uint32_t)i | (r.flags & ~LE_INDEX);
   return b.x0 < x0 + kBin && b.x1 > x0 && b.y0 < y0 + kBin && b.y1 > y0;  // exact test
 }
-// (written without branches, for the same reason: every step is computed and selected)
+// (written without branches, for the same reason -- and without `?:` on anything but flags: the compiler turned selects between
+// computed masks back into branches in one build of the compositor; bit masks it cannot)
 __device__ __forceinline__ void bin_entry_tail(const BinRec& r, int x0, int y0, bool& hit, uint32_t& strips) {
-  const bool has_core = (r.flags & BR_HAS_CORE) != 0u, removed = (r.flags & BR_CORE_REMOVED) != 0u, exact = (r.flags & BR_BOX_EXACT) != 0u;
-  const uint32_t core = strip_mask_inside(r.ix0 - x0, r.iy0 - y0, r.ix1 - x0, r.iy1 - y0) & strips;
+  const uint32_t m_core = 0u - (uint32_t)((r.flags & BR_HAS_CORE) != 0u), m_removed = 0u - (uint32_t)((r.flags & BR_CORE_REMOVED) != 0u),
+                 m_exact = 0u - (uint32_t)((r.flags & BR_BOX_EXACT) != 0u);  // all ones / zero
+  const uint32_t core = strip_mask_inside(r.ix0 - x0, r.iy0 - y0, r.ix1 - x0, r.iy1 - y0) & strips & m_core;
   // alpha == 0 on the core (stroke interior) or too small to change an 8-bit channel (deep inside an inner shadow): those strips leave
   // the entry, and the entry goes with them if none is left; any other core is marked in the high half
-  const uint32_t s_removed = strips & ~core, s_marked = strips | (core << 16);
-  const uint32_t s1 = has_core ? (removed ? s_removed : s_marked) : strips;
-  const bool gone = has_core && removed && s_removed == 0u;
-  // edge strips wholly inside the quad's pixel bounds: state (0, 1) -- fdh_types.h, BR_BOX_EXACT
+  const uint32_t s1 = (strips & ~(core & m_removed)) | ((core & ~m_removed) << 16);
+  const uint32_t m_gone = m_core & m_removed & (0u - (uint32_t)((s1 & 0xffffu) == 0u));
+  // edge strips wholly inside the quad's pixel bounds: state (0, 1) -- fdh_types.h, BR_BOX_EXACT (draws with a core only: as round 5 had it)
   const BBox b = r.box;
-  const uint32_t inq = strip_mask_inside(b.x0 - x0, b.y0 - y0, b.x1 - x0, b.y1 - y0) & s1 & ~(s1 >> 16) & 0xffffu;
-  const uint32_t s2 = (s1 & ~inq) | (inq << 16);
-  strips = (has_core && !gone && exact) ? s2 : s1;
-  hit = hit && !gone;
+  const uint32_t inq = strip_mask_inside(b.x0 - x0, b.y0 - y0, b.x1 - x0, b.y1 - y0) & s1 & ~(s1 >> 16) & 0xffffu & m_core & m_exact & ~m_gone;
+  strips = (s1 & ~inq) | (inq << 16);
+  hit = hit && m_gone == 0u;
 }
 // ------------------------------------------------------------------ compositing
 

@@ -372,12 +372,12 @@ __device__ __forceinline__ uint32_t strip_shade_count(const CompositeParams& P, 
   return n;
 }
 
-template <int kPaths, bool kFull, int kRole>
+template <int kPaths, bool kFull, int kRole, bool kDirect = false>
 __device__ __forceinline__ void composite_strip(const CompositeParams& P, const DrawRec* __restrict__ draws, const QuadExt* __restrict__ exts,
                                                 uint32_t* composite_lds, const int bin, const int sidx, const int sbit, const int tx0, const int ty0,
                                                 const int lane, const int shader_id);
 
-template <int kPaths, bool kFull>
+template <int kPaths, bool kFull, bool kDirect = false>
 __global__ __launch_bounds__(64, (kPaths & 1) ? kSlowWaves : kPaths == 4 ? kUniformWaves : (kPaths & 2) ? kAtlasWaves : (kPaths & 8) ? kRotWaves : kFastWaves) void k_composite_tiles(
     // the sixteen dwords a wave needs before anything else, as leading scalar arguments: with kernel-argument preloading
     // (-amdgpu-kernarg-preload-count, csrc/Makefile) they arrive in SGPRs with the wave instead of through a first s_load
@@ -435,7 +435,7 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? kSlowWaves : kPaths == 4 ? kUnif
   if (ty0 + kTileH <= P.row_lo) return;
   asm volatile("");
   if (ty0 >= P.row_hi) return;
-  composite_strip<kPaths, kFull, 0>(P, draws, exts, composite_lds, bin, sidx, sbit, tx0, ty0, lane, 0);
+  composite_strip<kPaths, kFull, 0, kDirect>(P, draws, exts, composite_lds, bin, sidx, sbit, tx0, ty0, lane, 0);
 }
 
 // The full-frame launch of a frame that HAS deep bins (P.deep_k8 > 0; k_composite_tiles<4, true> otherwise), workgroups of four waves:
@@ -494,7 +494,7 @@ __global__ __launch_bounds__(256, kUniformWaves) void k_composite_deep(const Dra
   else composite_strip<4, true, 2>(P, draws, exts, composite_lds, bin, sidx, sbit, tx0, ty0, lane, wg_wave - 1);
 }
 
-template <int kPaths, bool kFull, int kRole>
+template <int kPaths, bool kFull, int kRole, bool kDirect>
 __device__ __forceinline__ void composite_strip(const CompositeParams& P, const DrawRec* __restrict__ draws, const QuadExt* __restrict__ exts,
                                                 uint32_t* composite_lds, const int bin, const int sidx, const int sbit, const int tx0, const int ty0,
                                                 const int lane, const int shader_id) {
@@ -529,7 +529,9 @@ __device__ __forceinline__ void composite_strip(const CompositeParams& P, const 
   // wave makes the entries of its bin itself, lane i the one of the phase's draw i, with the two functions the bin kernel makes them
   // with.  A frame of a handful of draws (a dialog, the reference's 4-node test scene) is one launch less: its launches are latency,
   // 4 - 5 us each, not work.
-  const bool direct = P.direct != 0;
+  // (a build of its own, kDirect: as a run-time branch of every build the entry code cost the bench frame's launch sixteen spilled
+  // scalar registers and 1.6 us of its 26 -- same-box A/B against round 5's library, profiles/r06_ab_r05g.txt)
+  constexpr bool direct = kDirect;
   const uint32_t cnt = direct ? (uint32_t)P.direct_n : P.counts[bin];
 #if FDH_TIMING
   T_cnt = FDH_NOW() - T0 + (cnt & 0u);
@@ -1978,6 +1980,9 @@ void launch_composite(hipStream_t s, const DrawRec* draws, const QuadExt* exts, 
   // deep strips (k_composite_deep): only beside the no-clip build's full-frame launch, and only with the order at hand
   if (!(full && P.order && P.order_next && !P.has_slow && !P.has_rot && !P.has_atlas && !P.has_masks)) P.deep_k8 = 0;
   P.deep_k8 = std::min(P.deep_k8 & ~7, 8 * bins8);
+#define FDH_COMPOSITE_DIRECT(paths) \
+  do { if (full) FDH_LAUNCH((k_composite_tiles<paths, true, true>), dim3(grid), blk, lds, s, P.order, P.order_next, P.counts, P.lists, P.bin_x0, P.bin_y0, P.bin_nx, P.bin_ny, P.bins_x, P.stride, P.row_lo, P.row_hi, draws, exts, P); \
+       else FDH_LAUNCH((k_composite_tiles<paths, false, true>), dim3(grid), blk, lds, s, P.order, P.order_next, P.counts, P.lists, P.bin_x0, P.bin_y0, P.bin_nx, P.bin_ny, P.bins_x, P.stride, P.row_lo, P.row_hi, draws, exts, P); } while (0)
 #define FDH_COMPOSITE(paths) \
   do { if (full) FDH_LAUNCH((k_composite_tiles<paths, true>), dim3(grid), blk, lds, s, P.order, P.order_next, P.counts, P.lists, P.bin_x0, P.bin_y0, P.bin_nx, P.bin_ny, P.bins_x, P.stride, P.row_lo, P.row_hi, draws, exts, P); \
        else FDH_LAUNCH((k_composite_tiles<paths, false>), dim3(grid), blk, lds, s, P.order, P.order_next, P.counts, P.lists, P.bin_x0, P.bin_y0, P.bin_nx, P.bin_ny, P.bins_x, P.stride, P.row_lo, P.row_hi, draws, exts, P); } while (0)
@@ -1988,6 +1993,7 @@ void launch_composite(hipStream_t s, const DrawRec* draws, const QuadExt* exts, 
 #else
   if (P.has_slow || (P.has_rot && P.has_atlas)) FDH_COMPOSITE(3);
   else if (P.has_rot) FDH_COMPOSITE(8);
+  else if (P.direct) { if (P.has_atlas) FDH_COMPOSITE_DIRECT(2); else if (!P.has_masks) FDH_COMPOSITE_DIRECT(4); else FDH_COMPOSITE_DIRECT(0); }
   else if (P.has_atlas) FDH_COMPOSITE(2);
   else if (!P.has_masks) {
     if (P.deep_k8 > 0 && P.order && P.order_next) {  // a frame with deep bins: the launch of four-wave workgroups
@@ -1998,6 +2004,7 @@ void launch_composite(hipStream_t s, const DrawRec* draws, const QuadExt* exts, 
   else FDH_COMPOSITE(0);
 #endif
 #undef FDH_COMPOSITE
+#undef FDH_COMPOSITE_DIRECT
 }
 #else  // FDH_TU 1: the one launcher of this unit
 template <int kPaths, bool kFull>
@@ -2007,6 +2014,11 @@ static void launch_uniform2(hipStream_t s, hipEvent_t e0, hipEvent_t e1, int gri
     const dim3 g(8 + P.deep_k8 * 16 + 8 * bins8 * kWgsPerBin);
     if (e0) hipExtLaunchKernelGGL((k_composite_deep<1>), g, dim3(256), sizeof(uint32_t) * kDeepLdsDwords, s, e0, e1, 0, draws, exts, P);
     else hipLaunchKernelGGL((k_composite_deep<1>), g, dim3(256), sizeof(uint32_t) * kDeepLdsDwords, s, draws, exts, P);
+    return;
+  }
+  if (P.direct) {  // a frame without a bin launch: the builds whose waves make their list entries themselves
+    if (e0) hipExtLaunchKernelGGL((k_composite_tiles<kPaths, kFull, true>), dim3(grid), dim3(64), lds, s, e0, e1, 0, P.order, P.order_next, P.counts, P.lists, P.bin_x0, P.bin_y0, P.bin_nx, P.bin_ny, P.bins_x, P.stride, P.row_lo, P.row_hi, draws, exts, P);
+    else hipLaunchKernelGGL((k_composite_tiles<kPaths, kFull, true>), dim3(grid), dim3(64), lds, s, P.order, P.order_next, P.counts, P.lists, P.bin_x0, P.bin_y0, P.bin_nx, P.bin_ny, P.bins_x, P.stride, P.row_lo, P.row_hi, draws, exts, P);
     return;
   }
   if (e0) hipExtLaunchKernelGGL((k_composite_tiles<kPaths, kFull>), dim3(grid), dim3(64), lds, s, e0, e1, 0, P.order, P.order_next, P.counts, P.lists, P.bin_x0, P.bin_y0, P.bin_nx, P.bin_ny, P.bins_x, P.stride, P.row_lo, P.row_hi, draws, exts, P);

@@ -164,8 +164,8 @@ def main():
                 kernel = m.group(1)
                 continue
             for uk in UNIFORM_KERNELS:
-                if uk in kernel:
-                    uniform_lines.setdefault(uk, []).append(line)
+                if uk in kernel:  # (one entry per KERNEL: a pattern matches several instantiations -- <., ., direct> -- and their lines must not be analysed as one)
+                    uniform_lines.setdefault((uk, kernel), []).append(line)
             n_inst += 1
             m = FORBIDDEN.search(line)
             if m:
@@ -182,13 +182,13 @@ def main():
     print(f"lint_isa: {path}: {n_inst} lines of gfx950 disassembly, packed-FP32 instructions: {sum(sum(v.values()) for v in bad.values())}")
     rc = 0
     # (a renamed or dropped kernel must not turn the check into a silent pass: the Makefile still compiles that unit with the switch)
-    missing = [uk for uk in UNIFORM_KERNELS if uk not in uniform_lines]
+    missing = [uk for uk in UNIFORM_KERNELS if uk not in {k[0] for k in uniform_lines}]
     if missing and "--allow-missing" not in sys.argv:
         print(f"lint_isa: kernels compiled with -structurizecfg-skip-uniform-regions not found in {path}: {missing} "
               "(update UNIFORM_KERNELS in tools/lint_isa.py when the compositor's template arguments change)")
         rc = 1
-    for uk, lines in sorted(uniform_lines.items()):
-        name = "k_composite_tiles<%s, %s>" % (uk[len("k_composite_tilesILi")], "true" if uk.endswith("Lb1E") else "false")
+    for (uk, kernel), lines in sorted(uniform_lines.items()):
+        name = subprocess.run(["c++filt", kernel], capture_output=True, text=True).stdout.strip().split("(")[0].replace("void fdh::", "") or kernel
         w = exec_writes_in_draw_loop(lines)
         if w:
             print(f"lint_isa: {name} has a divergent branch inside its draw loop (it is compiled with "
