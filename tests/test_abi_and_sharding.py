@@ -163,8 +163,9 @@ def test_built_code_object_passes_the_isa_lint():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "lint_isa.py"), context.LIB_PATH], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "packed-FP32 instructions: 0" in r.stdout
-    for build in ("<0, true>", "<2, true>", "<4, true>", "<0, false>", "<2, false>", "<4, false>"):
-        assert f"k_composite_tiles{build}: no exec-mask write inside the draw loop nest" in r.stdout, r.stdout
+    # (every instantiation: builds <0|2|4>, first launch of a frame or not, with or without the direct entries -- and the deep strips' launch)
+    for build in [f"k_composite_tiles<{p}, {f}, {d}>" for p in (0, 2, 4) for f in ("true", "false") for d in ("true", "false")] + ["k_composite_deep<1>"]:
+        assert f"{build}: no exec-mask write inside the draw loop nest" in r.stdout, r.stdout
 
 
 def test_struct_layouts_match_python_mirror():
