@@ -1130,7 +1130,14 @@ int Context::walk_threads() const { return walk_threads_ >= 0 ? walk_threads_ : 
 // A frame every phase of which holds at most 64 draws, none of them a rotated quad or a curve (their entries need the bin kernel's
 // per-strip tests): no bin launch, the compositor's waves make their entries themselves (k_composite_tiles, "direct").  FDH_DIRECT=0: never.
 static bool direct_frame(const LaunchJob& J) {
-  static const bool on = [] { const char* e = std::getenv("FDH_DIRECT"); return !e || std::atoi(e) != 0; }();
+  // (FDH_FORCE_KERNEL_PATHS=3 / 8, the test hook that puts a frame on the builds with the slot path / the rotated-quad path: those two
+  // have no direct form)
+  static const bool on = [] {
+    const char* e = std::getenv("FDH_DIRECT");
+    const char* f = std::getenv("FDH_FORCE_KERNEL_PATHS");
+    const int forced = f ? std::atoi(f) : 0;
+    return (!e || std::atoi(e) != 0) && forced != 3 && forced != 8;
+  }();
   if (!on || J.phases.empty()) return false;
   for (const Phase& ph : J.phases)
     if (ph.count > 64 || ph.has_rot || ph.has_slow) return false;

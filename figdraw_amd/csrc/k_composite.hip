@@ -435,7 +435,19 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? kSlowWaves : kPaths == 4 ? kUnif
   if (ty0 + kTileH <= P.row_lo) return;
   asm volatile("");
   if (ty0 >= P.row_hi) return;
+  // The strip's shading, k_composite_strip.inc: as a CALL in the uniform-regions unit and as TEXT in the other.  Same source either way, but
+  // the register allocator lands elsewhere: called, the bench frame's <4, true> has no spilled scalar register (as text: nine), and as text the
+  // <3> build keeps round 5's size and scratch (called: 9 KB more code than the instruction cache likes, config 10 19 % slower) --
+  // same-box A/B against round 5's library in profiles/r06_ab_r05g.txt.
+#if FDH_TU == 1
   composite_strip<kPaths, kFull, 0, kDirect>(P, draws, exts, composite_lds, bin, sidx, sbit, tx0, ty0, lane, 0);
+#else
+  constexpr int kRole = 0;
+  constexpr int shader_id = 0;
+  {  // (a scope of its own: the body names some of what the mapping above has named)
+#include "k_composite_strip.inc"
+  }
+#endif
 }
 
 // The full-frame launch of a frame that HAS deep bins (P.deep_k8 > 0; k_composite_tiles<4, true> otherwise), workgroups of four waves:
@@ -498,1464 +510,7 @@ template <int kPaths, bool kFull, int kRole, bool kDirect>
 __device__ __forceinline__ void composite_strip(const CompositeParams& P, const DrawRec* __restrict__ draws, const QuadExt* __restrict__ exts,
                                                 uint32_t* composite_lds, const int bin, const int sidx, const int sbit, const int tx0, const int ty0,
                                                 const int lane, const int shader_id) {
-  static_assert(kRole == 0 || (kPaths == 4 && kFull), "deep strips: the no-clip build's full-frame launch only");
-  constexpr int kStripsPerBin = kWgsPerBin * kWavesPerWg;  // 16
-  constexpr int mslot = 0;
-  constexpr bool kBlender = kRole == 1, kShader = kRole == 2;
-  uint32_t (*mask_stack)[kMaskDepth][64] = reinterpret_cast<uint32_t (*)[kMaskDepth][64]>(composite_lds);
-  const DeepRing ring(composite_lds);
-  uint32_t rank = 0, unit = 0;  // deep strips: source terms / shading units (a draw, or a run of draws over one distance field) so far in the list
-  const int tx1 = tx0 + kTileW, ty1 = ty0 + kTileH;
-  const int px0 = tx0 + (lane & 7) * 4, py = ty0 + (lane >> 3);
-  // The clip stack: levels 0 .. kMaskDepth - 1 in LDS; deeper nesting (the reference has no limit: one mask plane per level,
-  // glcontext.nim:1886-1914) spills to a global plane the host sizes for the frame's deepest nest -- [level][strip][lane], every
-  // slot written and read by this lane alone (agent-scope accesses: the read must not be served from a stale L1 line).
-  const size_t spill_at = ((size_t)bin * kStripsPerBin + (size_t)sidx) * 64 + (size_t)lane;
-  auto stack_put = [&](const int depth, const uint32_t v) __attribute__((always_inline)) {
-    if (depth < kMaskDepth) mask_stack[mslot][depth][lane] = v;  // (wave-uniform)
-    else __hip_atomic_store(P.mask_spill + (size_t)(depth - kMaskDepth) * P.spill_stride + spill_at, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  };
-  auto stack_get = [&](const int depth) __attribute__((always_inline)) -> uint32_t {
-    if (depth < kMaskDepth) return mask_stack[mslot][depth][lane];
-    return __hip_atomic_load(P.mask_spill + (size_t)(depth - kMaskDepth) * P.spill_stride + spill_at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  };
-  constexpr bool kMasks = (kPaths & 4) == 0;  // <4>: a phase without clip / rect-mask operations -- no mask registers, no stack
-#if FDH_TIMING
-  const unsigned long long T0 = FDH_NOW(), W0 = wall_clock64();
-  unsigned long long T_cull = 0, T_rec = 0, T_shade = 0, T_cnt = 0, n_draws_t = 0, T_cull_core = 0, n_core_t = 0, n_all_t = 0;
-  unsigned long long T_mode[4] = {0, 0, 0, 0}, N_mode[4] = {0, 0, 0, 0};  // edge draws by mode: 3, 7, 9, 12
-#endif
-  // A DIRECT launch (round 6): a phase of at most 64 draws has no list -- k_bin_draws was not launched for the frame --, every strip's
-  // wave makes the entries of its bin itself, lane i the one of the phase's draw i, with the two functions the bin kernel makes them
-  // with.  A frame of a handful of draws (a dialog, the reference's 4-node test scene) is one launch less: its launches are latency,
-  // 4 - 5 us each, not work.
-  // (a build of its own, kDirect: as a run-time branch of every build the entry code cost the bench frame's launch sixteen spilled
-  // scalar registers and 1.6 us of its 26 -- same-box A/B against round 5's library, profiles/r06_ab_r05g.txt)
-  constexpr bool direct = kDirect;
-  const uint32_t cnt = direct ? (uint32_t)P.direct_n : P.counts[bin];
-#if FDH_TIMING
-  T_cnt = FDH_NOW() - T0 + (cnt & 0u);
-#endif
-  if (!kFull && cnt == 0 && P.load_fb) return;  // nothing lands in this bin: the surface already holds the result
-
-  const bool row_ok = py < P.H;
-  const bool vec_ok = row_ok && px0 + 3 < P.W && (P.pitch & 3) == 0;  // whole 16-byte group inside the frame
-  const size_t pix = (size_t)py * P.pitch + px0;
-  F4 F0, F1, F2, F3;
-  F0 = F1 = F2 = F3 = unpack255(P.clear_rgba8);
-  if (!kFull && P.load_fb) {
-    if (vec_ok) {
-      const uint4 q = *reinterpret_cast<const uint4*>(P.fb + pix);
-      F0 = unpack255(q.x); F1 = unpack255(q.y); F2 = unpack255(q.z); F3 = unpack255(q.w);
-    } else if (row_ok) {
-      if (px0 + 0 < P.W) F0 = unpack255(P.fb[pix + 0]);
-      if (px0 + 1 < P.W) F1 = unpack255(P.fb[pix + 1]);
-      if (px0 + 2 < P.W) F2 = unpack255(P.fb[pix + 2]);
-      if (px0 + 3 < P.W) F3 = unpack255(P.fb[pix + 3]);
-    }
-  }
-  float mk0 = 1.0f, mk1 = 1.0f, mk2 = 1.0f, mk3 = 1.0f;  // NfClipContent stack product (1 = maskTexEnabled false)
-  float rm0 = 1.0f, rm1 = 1.0f, rm2 = 1.0f, rm3 = 1.0f;  // fast rect mask (atlas_rect_mask.frag), 1 when none
-  int mask_depth = 0;
-  bool rmask_on = false;  // wave-uniform: rm0..3 may differ from 1
-  bool touched = false;
-  const uint2* __restrict__ list = P.lists + (size_t)bin * P.stride;
-  const float cy = (float)py + 0.5f;
-  const float cx0 = (float)px0 + 0.5f;
-  const float inv255 = 1.0f / 255.0f;
-
-  // ---- deep strips: the ring between the strip's shaders and its blender (every store below is made by all 64 lanes with the same
-  // value: a branch on the lane index would be the draw loop's only divergent one -- tools/lint_isa.py)
-  auto deep_slot = [&](const uint32_t rk) __attribute__((always_inline)) -> uint32_t {  // shader: the slot of source term rk, once the blender has freed it
-    if (rk >= (uint32_t)kDeepSlots) deep_wait_ge(ring.consumed, rk - (uint32_t)kDeepSlots + 1u);
-    return rk % (uint32_t)kDeepSlots;
-  };
-  auto deep_publish = [&](const uint32_t slot, const uint32_t rk, const uint32_t tag, const uint32_t h1, const uint32_t h2, const uint32_t h3, const uint32_t h4, const uint32_t h5) __attribute__((always_inline)) {
-    uint32_t* h = ring.hdr + slot * kDeepHdr;
-    h[0] = tag; h[1] = h1; h[2] = h2; h[3] = h3; h[4] = h4; h[5] = h5;
-    __hip_atomic_store(ring.ready + slot, rk + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-  };
-  auto deep_nop = [&](const uint32_t rk) __attribute__((always_inline)) { deep_publish(deep_slot(rk), rk, DT_NOP, 0u, 0u, 0u, 0u, 0u); };
-  // blender: source term rk out of its slot, blended into the strip
-  auto deep_consume = [&](const uint32_t rk) __attribute__((always_inline)) {
-    const uint32_t slot = rk % (uint32_t)kDeepSlots;
-    const uint32_t* h = ring.hdr + slot * kDeepHdr;
-    const float* v = ring.data + slot * kDeepSlotFloats + lane;
-    // The slot's sequence number, its header and the first four payload floats are read in ONE round trip to LDS, then the number is
-    // looked at: LDS returns a wave's reads in order, so values read after a number that says "published" are the published ones.
-    // (Before: wait for the number, then the header, then the payload -- three dependent round trips per source term on the one wave
-    // whose chain a deep strip's time is.)
-    uint32_t tag, h1, h2, h3, h4, h5;
-    float v0, v1, v2, v3;
-    for (int spins = 0; spins < (1 << 20); spins++) {
-      const uint32_t seq = __hip_atomic_load(ring.ready + slot, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-      tag = h[0]; h1 = h[1]; h2 = h[2]; h3 = h[3]; h4 = h[4]; h5 = h[5];
-      v0 = v[0]; v1 = v[64]; v2 = v[128]; v3 = v[192];
-      asm volatile("" : "+v"(tag), "+v"(h1), "+v"(h2), "+v"(h3), "+v"(h4), "+v"(h5), "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3));  // (read HERE, after the number)
-      if ((int32_t)((uint32_t)__builtin_amdgcn_readfirstlane(seq) - (rk + 1u)) >= 0) break;
-      __builtin_amdgcn_s_sleep(1);
-    }
-    tag = __builtin_amdgcn_readfirstlane(tag);
-    if (tag == DT_PACKED || tag == DT_PACKED_BLACK) {
-      const f2 saa = {v0, v1}, sab = {v2, v3};
-      const f2 Aa = saa * 255.0f, Ab = sab * 255.0f, iaa = 1.0f - saa, iab = 1.0f - sab;
-      if (tag == DT_PACKED_BLACK) {
-        blend_black(F0, Aa.x, iaa.x); blend_black(F1, Aa.y, iaa.y); blend_black(F2, Ab.x, iab.x); blend_black(F3, Ab.y, iab.y);
-      } else {
-        const f2 crg = {__uint_as_float(__builtin_amdgcn_readfirstlane(h1)), __uint_as_float(__builtin_amdgcn_readfirstlane(h2))};
-        const float cb = __uint_as_float(__builtin_amdgcn_readfirstlane(h3));
-        const f2 b1 = {cb, 1.0f};
-        blend_pre(F0, crg * Aa.x, b1 * Aa.x, iaa.x); blend_pre(F1, crg * Aa.y, b1 * Aa.y, iaa.y);
-        blend_pre(F2, crg * Ab.x, b1 * Ab.x, iab.x); blend_pre(F3, crg * Ab.y, b1 * Ab.y, iab.y);
-      }
-    } else if (tag == DT_GENERIC) {
-      blend(F0, v0, v[4 * 64], v[8 * 64], v[12 * 64]); blend(F1, v1, v[5 * 64], v[9 * 64], v[13 * 64]);
-      blend(F2, v2, v[6 * 64], v[10 * 64], v[14 * 64]); blend(F3, v3, v[7 * 64], v[11 * 64], v[15 * 64]);
-    } else if (tag == DT_SELF17) {  // mode 17 over the live surface (blur radius <= 0.5): the source IS the strip's own texel (atlas.frag:381-388)
-      const float k255 = 1.0f / 255.0f;
-      blend(F0, F0.x * k255, F0.y * k255, F0.z * k255, F0.w * k255 * v0); blend(F1, F1.x * k255, F1.y * k255, F1.z * k255, F1.w * k255 * v1);
-      blend(F2, F2.x * k255, F2.y * k255, F2.z * k255, F2.w * k255 * v2); blend(F3, F3.x * k255, F3.y * k255, F3.z * k255, F3.w * k255 * v3);
-    } else if (tag == DT_UNIFORM_PRE) {
-      const f2 c_rg = {__uint_as_float(__builtin_amdgcn_readfirstlane(h1)), __uint_as_float(__builtin_amdgcn_readfirstlane(h2))};
-      const f2 c_ba = {__uint_as_float(__builtin_amdgcn_readfirstlane(h3)), __uint_as_float(__builtin_amdgcn_readfirstlane(h4))};
-      const float ia = __uint_as_float(__builtin_amdgcn_readfirstlane(h5));
-      blend_pre(F0, c_rg, c_ba, ia); blend_pre(F1, c_rg, c_ba, ia); blend_pre(F2, c_rg, c_ba, ia); blend_pre(F3, c_rg, c_ba, ia);
-    }
-    // (the slot is free once its values are in registers: the loads above have landed before the store below is made -- release)
-    __hip_atomic_store(ring.consumed, rk + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-  };
-  for (uint32_t base = 0; base < cnt; base += 64) {
-#if FDH_TIMING
-    const unsigned long long Tc0 = FDH_NOW();
-#endif
-    const uint32_t i = base + lane;
-    // (no branch around the load: lanes past the end read the last entry and drop it)
-    uint2 e;
-    if (direct) {  // (wave-uniform; what is inside compiles to selects)
-      const int by = bin / P.bins_x, bx = bin - by * P.bins_x;
-      BinRec br;
-      uint32_t word = 0, strips = 0;
-      bool hit = bin_entry_head(P.binrec, P.direct_first + (int)min(i, cnt - 1u), bx * kBin, by * kBin, br, word, strips);
-      bin_entry_tail(br, bx * kBin, by * kBin, hit, strips);
-      e = make_uint2(word, hit ? strips : 0u);
-    } else {
-      e = list[min(i, cnt - 1u)];  // {draw index | flags, strips touched | strips inside the saturated core << 16}
-    }
-    const uint32_t idx = e.x;
-    const uint32_t ey = i < cnt ? e.y : 0u;
-    // this strip's state in the entry (fdh_types.h): (1, 0) touched, (1, 1) core, (0, 1) an edge strip wholly inside the draw's quad
-    const uint32_t st = (ey >> sbit) & 0x10001u;
-    unsigned long long m = __ballot(st != 0u);
-    const unsigned long long m_core = __ballot(st == 0x10001u);
-    const unsigned long long m_inq = __ballot(st == 0x10000u);  // every pixel of the strip is covered by the quad: no per-pixel test
-    if (!kMasks || !P.has_masks) {
-      // Occlusion: an opaque fill that covers the whole strip makes every earlier draw of the strip invisible.  (Only in
-      // phases without clip / rect masks: a skipped push or pop would derail the mask stack.)
-      const unsigned long long m_opaque = __ballot(st == 0x10001u && (idx & LE_OPAQUE) != 0u);
-      if (m_opaque != 0) m &= ~((1ull << (63 - __builtin_clzll(m_opaque))) - 1ull);
-    }
-#if FDH_TIMING
-    T_cull += FDH_NOW() - Tc0 + (m & 0ull);
-#endif
-    if (m == 0) continue;
-    // Which straight-line path each surviving entry takes on this strip, decided for all 64 entries at once with vector
-    // compares; the draw loop then tests ONE bit per decision (s_bitcmp1 + s_cbranch_scc) where it used to rebuild the answer per
-    // draw out of four scalar booleans (s_cselect_b64 / s_and_b64 chains on the one scalar unit a CU has).
-    //   m_plainc: the strip lies in the draw's saturated core and the draw has one colour -> a uniform blend, record not fetched
-    //   m_simple: an edge strip of a draw with a packed edge path (list-entry path codes 1..8)
-    // (each is one vector compare on the entry's flag word, combined with the strip masks above on the scalar side)
-    const unsigned long long m_plainc = m_core & __ballot((int32_t)idx < 0);  // LE_PLAIN is the sign bit
-    // (a deep strip's blender: the colours of the batch's one-colour core strips, lane i <-> entry i, in ONE vector load -- fetched draw by
-    // draw through the scalar cache each was a round trip to L2 on the strip's critical wave)
-    u32x4 plain_col = {0u, 0u, 0u, 0u};
-    if (kBlender) plain_col = *reinterpret_cast<const u32x4*>(draws[idx & LE_INDEX].col);
-    const uint32_t code_l = idx & (15u << LE_PATH_SHIFT);
-    const unsigned long long m_simple = m & ~m_core & __ballot((kPaths & 3) == 0 ? code_l != 0u : (code_l - 1u) < (4u << LE_PATH_SHIFT));
-    // sdRoundedBox (atlas.frag:51-69) of the lane's four pixels at height py for half extents (bx, by)
-    auto dist4 = [&](const DrawRec& r, const f2 pxa, const f2 pxb, const float py_, const float bx, const float by, f2& da, f2& db) __attribute__((always_inline)) {
-      const bool top = py_ > 0.0f;
-      const float rR = top ? r.r[0] : r.r[1], rL = top ? r.r[2] : r.r[3];
-      const float ay = __builtin_fabsf(py_) - by;
-      const f2 rra = {pxa.x > 0.0f ? rR : rL, pxa.y > 0.0f ? rR : rL}, rrb = {pxb.x > 0.0f ? rR : rL, pxb.y > 0.0f ? rR : rL};
-      const f2 axa = {__builtin_fabsf(pxa.x), __builtin_fabsf(pxa.y)}, axb = {__builtin_fabsf(pxb.x), __builtin_fabsf(pxb.y)};
-      const f2 qxa = axa - bx + rra, qxb = axb - bx + rrb;
-      const f2 qya = ay + rra, qyb = ay + rrb;
-      // sdRoundedBox: min(max(q.x, q.y), 0) + length(max(q, 0)) - r.  With m = max(q.x, q.y): outside the corner cells (not both
-      // components positive) length(max(q, 0)) = max(m, 0), and min(m, 0) + max(m, 0) = m exactly (one of the two is 0); in a corner
-      // cell both components are positive, so max(q, 0) = q and the first term is 0.  So the distance is (corner ? |q| : m) - r,
-      // bit for bit what the three-term form gives, in seven instructions per pixel instead of thirteen where no lane of the
-      // strip sits in a corner cell (round 4).
-      f2 ma = {__builtin_fmaxf(qxa.x, qya.x), __builtin_fmaxf(qxa.y, qya.y)}, mb = {__builtin_fmaxf(qxb.x, qyb.x), __builtin_fmaxf(qxb.y, qyb.y)};
-      const f2 lowa = {__builtin_fminf(qxa.x, qya.x), __builtin_fminf(qxa.y, qya.y)}, lowb = {__builtin_fminf(qxb.x, qyb.x), __builtin_fminf(qxb.y, qyb.y)};
-      if (__any(lowa.x > 0.0f || lowa.y > 0.0f || lowb.x > 0.0f || lowb.y > 0.0f)) {  // some lane sits in a corner cell
-        const f2 sa2 = qxa * qxa + qya * qya, sb2 = qxb * qxb + qyb * qyb;
-        ma.x = lowa.x > 0.0f ? fsqrt(sa2.x) : ma.x; ma.y = lowa.y > 0.0f ? fsqrt(sa2.y) : ma.y;
-        mb.x = lowb.x > 0.0f ? fsqrt(sb2.x) : mb.x; mb.y = lowb.y > 0.0f ? fsqrt(sb2.y) : mb.y;
-      }
-      da = ma - rra; db = mb - rrb;
-    };
-    // elliptical corners (atlas.frag:96-115): the distance itself comes from the general routine, four pixels
-    // unpacked; coverage and blend below stay packed
-    auto dist4e = [&](const DrawRec& r, const f2 pxa, const f2 pxb, const float py_, const float bx, const float by, f2& oa, f2& ob) __attribute__((always_inline)) {
-      const float px4[4] = {pxa.x, pxa.y, pxb.x, pxb.y};
-      float d4[4];
-      shape_distN<4>(true, px4, py_, bx, by, r.r[0], r.r[1], r.r[2], r.r[3], d4);
-      oa = {d4[0], d4[1]}; ob = {d4[2], d4[3]};
-    };
-    // ---- the common edge strip: ONE colour, nothing clipping, mode fill / drop shadow / inner shadow / AA stroke (list-entry
-    // path codes 1..8, k_bin_draws).  Written on float2 pairs -- pixels (0,1) and (2,3) of the lane side by side; same
-    // formulas, same order of operations as the general path in shade() below.  Two halves: the distance field of the node's
-    // shape at the lane's pixels (edge_geom), and what ONE draw makes of it -- coverage by mode, blend (edge_blend).  A node's
-    // fill, stroke and inner shadows are consecutive draws over the same quad and the same shape
-    // (renderRoundedShapeScaledCorners figrender.nim:806-873, renderInnerShadows :716-744): the draw loop evaluates the field
-    // once for such a run (LE_SHARE) and calls edge_blend per draw with that draw's own few parameters.
-    auto edge_geom = [&](const DrawRec& r, const bool inset, const bool ellip, f2& lxa, f2& lxb, float& pyy, f2& da, f2& db) __attribute__((always_inline)) {
-      const float shx = inset ? r.p0 : r.p2, shy = inset ? r.p1 : r.p3;
-      pyy = local_y_up(r, cy);
-      float lx4[4];
-      local_x4(r, cx0, lx4);
-      lxa = {lx4[0], lx4[1]}; lxb = {lx4[2], lx4[3]};
-      if ((kPaths & 3) == 0 && ellip) dist4e(r, lxa, lxb, pyy, shx, shy, da, db); else dist4(r, lxa, lxb, pyy, shx, shy, da, db);
-    };
-    // r: the run's geometry (quad, radii, AA factor, bounds); m_*: the draw's own sdfParams.zw, sdfFactors and colour
-    // inq (wave-uniform, from the list entry): the strip lies wholly inside the quad's pixel bounds
-    // (rk: a deep strip's shader puts the draw's source alphas into the ring as source term rk instead of blending them -- deep_consume is the rest)
-    auto edge_blend = [&](const DrawRec& r, const uint32_t mode, const bool ellip, const bool inq, const float m_p2, const float m_p3, const float m_f0, const float m_f1,
-                          const u32x4 m_col, const f2 lxa, const f2 lxb, const float pyy, const f2 da, const f2 db, F4& A0, F4& A1, F4& A2, F4& A3, const uint32_t rk) __attribute__((always_inline)) {
-      f2 ala, alb;  // coverage
-      if (mode == 3u) {
-        ala = {cover_aa(da.x, r.aa), cover_aa(da.y, r.aa)}; alb = {cover_aa(db.x, r.aa), cover_aa(db.y, r.aa)};
-      } else if (mode == 12u) {
-        const float h = m_f0 * 0.5f;
-        const f2 ea = da + h, eb = db + h;
-        const f2 ga = {__builtin_fabsf(ea.x), __builtin_fabsf(ea.y)}, gb = {__builtin_fabsf(eb.x), __builtin_fabsf(eb.y)};
-        ala = {cover_aa(ga.x - h, r.aa), cover_aa(ga.y - h, r.aa)}; alb = {cover_aa(gb.x - h, r.aa), cover_aa(gb.y - h, r.aa)};
-        if (__all(ala.x == 0.0f && ala.y == 0.0f && alb.x == 0.0f && alb.y == 0.0f)) {  // inside the stroke: no-op
-          if (kShader) deep_nop(rk);
-          return;
-        }
-      } else if (mode == 9u) {  // atlas.frag:364-380 -- clip alpha of the node's own shape x the falloff inside the offset shape
-        f2 sha, shb;
-        if ((kPaths & 3) == 0 && ellip) dist4e(r, lxa - m_p2, lxb - m_p2, pyy + m_p3, r.p0, r.p1, sha, shb); else dist4(r, lxa - m_p2, lxb - m_p2, pyy + m_p3, r.p0, r.p1, sha, shb);
-        const float spread = m_f1;
-        const f2 sda = sha + spread, sdb = shb + spread;
-        const float rs = frcp(__builtin_fmaxf(0.5f * m_f0, 0.5f));
-        // falloff(sd) = sd < 0 ? min(exp2(-0.7213 z^2), 1) : 1 with z = sd rs, written as exp2(-0.7213 z'^2) with z' = min(sd, 0) rs:
-        // the same operations on the same values where sd < 0; exp2(-0) = 1 where it is not; and v_exp_f32 of a non-positive
-        // input is never above 1 (tools/microbench/exp2_le1.hip tries every such float), so the min never acted
-        const f2 za = f2{__builtin_fminf(sda.x, 0.0f), __builtin_fminf(sda.y, 0.0f)} * rs, zb = f2{__builtin_fminf(sdb.x, 0.0f), __builtin_fminf(sdb.y, 0.0f)} * rs;
-        const f2 ea = -0.72134752044f * za * za, eb = -0.72134752044f * zb * zb;
-        ala = {cover_aa(da.x, r.aa) * fexp2(ea.x), cover_aa(da.y, r.aa) * fexp2(ea.y)};
-        alb = {cover_aa(db.x, r.aa) * fexp2(eb.x), cover_aa(db.y, r.aa) * fexp2(eb.y)};
-      } else {  // 7: atlas.frag:330-343
-        const float spread = m_f1;
-        const f2 sda = da - spread, sdb = db - spread;
-        if (__all(sda.x <= 0.0f && sda.y <= 0.0f && sdb.x <= 0.0f && sdb.y <= 0.0f)) {
-          ala = 1.0f; alb = 1.0f;
-        } else {
-          const float rs = frcp(__builtin_fmaxf(0.5f * m_f0, 0.5f));
-          // (sd > 0 ? min(exp2(..), 1) : 1 as exp2 of max(sd, 0): see the inner shadow above)
-          const f2 za = f2{__builtin_fmaxf(sda.x, 0.0f), __builtin_fmaxf(sda.y, 0.0f)} * rs, zb = f2{__builtin_fmaxf(sdb.x, 0.0f), __builtin_fmaxf(sdb.y, 0.0f)} * rs;
-          const f2 ea = -0.72134752044f * za * za, eb = -0.72134752044f * zb * zb;
-          ala = {fexp2(ea.x), fexp2(ea.y)};
-          alb = {fexp2(eb.x), fexp2(eb.y)};
-        }
-      }
-      const float cw = (float)(m_col.x >> 24) * inv255;  // (m_col: the draw's colour and, as floats, its r, g, b / 255: Context::prepare)
-      f2 saa = ala * cw, sab = alb * cw;
-      FDH_COUNT(inq ? 64 : 65);
-      if ((m_col.y | m_col.z | m_col.w) == 0u) FDH_COUNT(71);
-      if (!inq) {
-        // coverage of the quad: unsigned (x - bx0) < width, width 0 on rows outside it
-        const uint32_t xrel = (uint32_t)(px0 - (int)r.bx0);
-        const uint32_t wcov = (py >= r.by0 && py < r.by1) ? (uint32_t)((int)r.bx1 - (int)r.bx0) : 0u;
-        saa.x = xrel < wcov ? saa.x : 0.0f; saa.y = xrel + 1u < wcov ? saa.y : 0.0f;
-        sab.x = xrel + 2u < wcov ? sab.x : 0.0f; sab.y = xrel + 3u < wcov ? sab.y : 0.0f;
-      }
-      if (kShader) {
-        const uint32_t slot = deep_slot(rk);
-        float* v = ring.data + slot * kDeepSlotFloats + lane;
-        v[0] = saa.x; v[64] = saa.y; v[128] = sab.x; v[192] = sab.y;
-        deep_publish(slot, rk, (m_col.y | m_col.z | m_col.w) == 0u ? DT_PACKED_BLACK : DT_PACKED, m_col.y, m_col.z, m_col.w, 0u, 0u);
-        return;
-      }
-      const f2 Aa = saa * 255.0f, Ab = sab * 255.0f, iaa = 1.0f - saa, iab = 1.0f - sab;
-      if ((m_col.y | m_col.z | m_col.w) == 0u) {
-        // a black source (every drop shadow of the reference's scenes, most strokes): the colour terms are +0 and fma(F, 1 - sa, +0)
-        // is the product F (1 - sa) itself (F >= 0, 1 - sa >= 0): three multiplies per pixel less, the same bits
-        blend_black(A0, Aa.x, iaa.x); blend_black(A1, Aa.y, iaa.y); blend_black(A2, Ab.x, iab.x); blend_black(A3, Ab.y, iab.y);
-        return;
-      }
-      const f2 crg = {__uint_as_float(m_col.y), __uint_as_float(m_col.z)};
-      const float cb = __uint_as_float(m_col.w);
-      { const f2 b1 = {cb, 1.0f}; blend_pre(A0, crg * Aa.x, b1 * Aa.x, iaa.x); blend_pre(A1, crg * Aa.y, b1 * Aa.y, iaa.y);
-        blend_pre(A2, crg * Ab.x, b1 * Ab.x, iab.x); blend_pre(A3, crg * Ab.y, b1 * Ab.y, iab.y); }
-    };
-    // One draw = one lambda call.  The record of the NEXT surviving draw is fetched (scalar loads) before the
-    // current one is shaded, so the ~L2-latency of the fetch overlaps the shading arithmetic.
-    auto shade = [&](const uint32_t d, const DrawRec& r, const bool core, const bool inq, const uint32_t rk) {
-      const uint32_t om = r.op_mode;
-      const uint32_t op = (om >> 12) & 15u;
-      const uint32_t mode = om & 255u;
-      touched = true;
-      FDH_COUNT(0);
-      if (kMasks && op == OP_MASK_POP) {
-        mask_depth--;
-        if (mask_depth > 0) {
-          const uint32_t w = stack_get(mask_depth - 1);
-          mk0 = (float)(w & 255u) * inv255; mk1 = (float)((w >> 8) & 255u) * inv255;
-          mk2 = (float)((w >> 16) & 255u) * inv255; mk3 = (float)(w >> 24) * inv255;
-        } else {
-          mk0 = mk1 = mk2 = mk3 = 1.0f;
-        }
-        return;
-      }
-      if (kMasks && op == OP_RMASK_END) { rm0 = rm1 = rm2 = rm3 = 1.0f; rmask_on = false; return; }
-      if (kMasks && op == OP_RMASK_BEGIN && r.inv_h == 0.0f) {
-        // The fast rect mask under a transform without rotation (matY.x == 0: a row of pixels shares its local y), four pixels
-        // at once: rectMaskAlpha atlas_rect_mask.frag:222-237, operation for operation what rect_mask_alpha() does per pixel.
-        // (Rotated masks keep the one-pixel-slot path; this one lets a phase of rect-masked cells run on the <0> build: the
-        // reference's own clip + rect-mask benchmark went through the 128-VGPR slot build for these alone.)
-        float qx[4], dm[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) qx[k] = ((r.ox * (cx0 + (float)k) + r.oy * cy) + r.inv_w) - r.p0;
-        const float qy = ((r.inv_h * cx0 + r.f0 * cy) + r.f1) - r.p1;
-        shape_distN<4>((om & F_ELLIP) != 0u, qx, -qy, r.p2, r.p3, r.r[0], r.r[1], r.r[2], r.r[3], dm);
-        rm0 = 1.0f - clamp01(r.aa * dm[0] + 0.5f); rm1 = 1.0f - clamp01(r.aa * dm[1] + 0.5f);
-        rm2 = 1.0f - clamp01(r.aa * dm[2] + 0.5f); rm3 = 1.0f - clamp01(r.aa * dm[3] + 0.5f);
-        rmask_on = true;
-        return;
-      }
-      const bool atlas_mode = (mode == 0u) || (mode >= 13u && mode <= 16u);
-      // (builds without the slot path and the atlas path only ever see `fast` draws: the host picks the build per phase from
-      // exactly these properties, Context::submit -- no need to decode them again per draw)
-      const bool fast = (kPaths & 11) == 0 || (!(om & F_GENERAL) && !atlas_mode && mode < 18u && (op == OP_DRAW || (kMasks && op == OP_MASK_PUSH)));
-      // ---- axis-aligned atlas quads (glyphs, images at >= 1:1, MSDF / MTSDF): 4 pixels per lane in lock-step.  All
-      // sixteen bilinear texel fetches of the lane are issued before any of them is used, so the wave pays the atlas
-      // latency once per draw instead of once per pixel slot.  (Minified images, lod > 0, keep the trilinear slot path.)
-      constexpr bool kSlow = (kPaths & 1) != 0, kAtlas = (kPaths & 2) != 0, kRot = (kPaths & 9) != 0;
-      if (kAtlas && atlas_mode && !(om & F_GENERAL) && op == OP_DRAW && !(mode == 0u && r.aux2 > 0.0f && P.atlas.n_levels >= 2)) {
-        const uint32_t fill_mode = (om >> 9) & 7u;
-        const int S = P.atlas.size, msk = S - 1;
-        const float fS = (float)S;
-        const uint32_t* __restrict__ tex = P.atlas.level[0];
-        if (mode == 0u && (om & F_TEXEL_1TO1) != 0u) {
-          // ---- a glyph placed texel on pixel (figrender.nim:456-496): the bilinear fractions are 0 up to float noise (a GL
-          // sampler's fixed-point coordinates snap them to 0), so a pixel IS its texel: the lane's four come in one 16-byte
-          // run (4-byte aligned: the atlas origin of a glyph is arbitrary) instead of sixteen dword gathers and their filter
-          // arithmetic.  Lanes outside the quad read texel (0, 0) and blend with alpha 0.
-          const uint32_t xrel = (uint32_t)(px0 - (int)r.bx0);
-          const bool rowc = py >= r.by0 && py < r.by1;
-          const uint32_t wcov = rowc ? (uint32_t)((int)r.bx1 - (int)r.bx0) : 0u;
-          const bool any_px = rowc & (px0 + 3 >= (int)r.bx0) & (px0 < (int)r.bx1);
-          const int tx = px0 + (int)r.ext, ty = py + (int)r._pad;
-          // (the atlas is a power of two wide: a shift, not a multiply -- an expensive arm would bring a divergent branch back)
-          const uint32_t off_in = ((((uint32_t)ty) << (uint32_t)__builtin_ctz((uint32_t)S)) + (uint32_t)tx) << 2;
-          const uint32_t off = any_px ? off_in : 0u;
-          struct __attribute__((packed, aligned(4))) Run4 { uint32_t v[4]; };
-          const Run4 run = *reinterpret_cast<const Run4*>(reinterpret_cast<const char*>(tex) + off);
-          const F4 c0u = unpack255(r.col[0]);
-          const bool solid = (om & F_SOLID) != 0u, masked = mask_depth > 0 || rmask_on;
-          const bool lane_col = solid || (r.col[0] == r.col[1] && r.col[2] == r.col[3]);  // wave-uniform
-          const float t = (cy - r.oy) * r.inv_h;
-          F4 colL = {c0u.x * inv255, c0u.y * inv255, c0u.z * inv255, c0u.w * inv255};
-          if (!solid && lane_col) {  // a vertical tint: one colour per lane (see the general atlas path below)
-            const F4 br = unpack255(r.col[1]), tr = unpack255(r.col[2]), tl = unpack255(r.col[3]);
-            const float s0 = (cx0 - r.ox) * r.inv_w;
-            colL.x = tri_lerp(tl.x, c0u.x, br.x, tr.x, s0, t) * inv255;
-            colL.y = tri_lerp(tl.y, c0u.y, br.y, tr.y, s0, t) * inv255;
-            colL.z = tri_lerp(tl.z, c0u.z, br.z, tr.z, s0, t) * inv255;
-            colL.w = tri_lerp(tl.w, c0u.w, br.w, tr.w, s0, t) * inv255;
-          }
-          auto texel_px = [&](const int k, F4& F, const float mk, const float rm) __attribute__((always_inline)) {
-            const F4 a = unpack255(run.v[k]);
-            F4 col = colL;
-            if (!lane_col) {  // wave-uniform
-              const F4 br = unpack255(r.col[1]), tr = unpack255(r.col[2]), tl = unpack255(r.col[3]);
-              const float sk = (cx0 + (float)k - r.ox) * r.inv_w;
-              col.x = tri_lerp(tl.x, c0u.x, br.x, tr.x, sk, t) * inv255;
-              col.y = tri_lerp(tl.y, c0u.y, br.y, tr.y, sk, t) * inv255;
-              col.z = tri_lerp(tl.z, c0u.z, br.z, tr.z, sk, t) * inv255;
-              col.w = tri_lerp(tl.w, c0u.w, br.w, tr.w, sk, t) * inv255;
-            }
-            float sa = a.w * inv255 * col.w;
-            if (masked) sa = sa * mk * rm;
-            blend(F, a.x * inv255 * col.x, a.y * inv255 * col.y, a.z * inv255 * col.z, (xrel + (uint32_t)k) < wcov ? sa : 0.0f);
-          };
-          texel_px(0, F0, mk0, rm0); texel_px(1, F1, mk1, rm1); texel_px(2, F2, mk2, rm2); texel_px(3, F3, mk3, rm3);
-          return;
-        }
-        const float uax = r.r[0], uay = r.r[1], utx = r.r[2], uty = r.r[3];
-        const float t = (cy - r.oy) * r.inv_h;
-        const float v = uay + (uty - uay) * t;
-        const float ty_ = v * fS - 0.5f, fy = __builtin_floorf(ty_), ayf = ty_ - fy;
-        const int y0 = (int)fy & msk, y1 = (y0 + 1) & msk;
-        const uint32_t xrel = (uint32_t)(px0 - (int)r.bx0);
-        const uint32_t wcov = (py >= r.by0 && py < r.by1) ? (uint32_t)((int)r.bx1 - (int)r.bx0) : 0u;
-        float ushift = 0.0f;
-        if (mode == 0u && (om & F_SUBPIXEL)) ushift = r.aux * frcp(__builtin_fmaxf(fS, 1.0f));  // wave-uniform
-        float sK[4], uK[4], axK[4];
-        uint32_t q00[4], q01[4], q10[4], q11[4];
-        int fxi[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-          sK[k] = (cx0 + (float)k - r.ox) * r.inv_w;
-          uK[k] = uax + (utx - uax) * sK[k];
-          const float tx_ = (uK[k] - ushift) * fS - 0.5f, fx = __builtin_floorf(tx_);
-          axK[k] = tx_ - fx;
-          fxi[k] = (int)fx;
-        }
-        const int fyi = (int)fy;
-        // The strip's texel window.  The map pixel -> texel is linear, so the texel columns / rows the strip's 32 x 8 pixels touch
-        // lie between those of its first and last pixel (+ 1 for the second bilinear tap).  When the window is small -- a glyph or
-        // an MSDF image drawn at >= 0.5x: at most 64 x 12 texels -- the wave stages it in LDS with 16-byte runs (two or three
-        // loads per lane) and every pixel takes its four taps from there: sixteen dword gathers per lane and draw kept the CU's
-        // one texture-address unit busier than the arithmetic (config 4: a wave lived 13 us for 1.6 us of issue).
-        const int wxa = __builtin_amdgcn_readlane(fxi[0], 0), wxb = __builtin_amdgcn_readlane(fxi[3], 7);
-        const int wya = __builtin_amdgcn_readlane(fyi, 0), wyb = __builtin_amdgcn_readlane(fyi, 56);
-        const int wx0 = min(wxa, wxb), wx1 = max(wxa, wxb) + 1, wy0 = min(wya, wyb), wy1 = max(wya, wyb) + 1;  // inclusive texel bounds
-        const bool windowed = wx1 - wx0 < kWinCols && wy1 - wy0 < kWinRows && wx0 >= 0 && wy0 >= 0 && wx1 + 3 < S && wy1 < S;  // wave-uniform
-        if (windowed) {
-          uint32_t* const win = composite_lds + (P.has_masks ? kMaskDepth * 64 : 256);
-          {  // 16 lanes x 16 bytes per window row, four rows per pass; lanes past the window repeat its last run / row (no branch)
-            const int lr = lane >> 4, lc = (lane & 15) * 4;
-            const int cc = min(lc, (wx1 - wx0) & ~3);
-            struct __attribute__((packed, aligned(4))) Run4 { uint32_t v[4]; };
-#pragma unroll
-            for (int pass = 0; pass < kWinRows / 4; pass++) {
-              const int row = min(pass * 4 + lr, wy1 - wy0);
-              const Run4 run = *reinterpret_cast<const Run4*>(tex + (((uint32_t)(wy0 + row)) << (uint32_t)__builtin_ctz((uint32_t)S)) + (uint32_t)(wx0 + cc));
-              uint4 q4 = {run.v[0], run.v[1], run.v[2], run.v[3]};
-              *reinterpret_cast<uint4*>(win + (pass * 4 + lr) * kWinStride + lc) = q4;
-            }
-          }
-          __builtin_amdgcn_wave_barrier();
-          const int ly = min(max(fyi - wy0, 0), kWinRows - 2);
-#pragma unroll
-          for (int k = 0; k < 4; k++) {
-            const int lx = min(max(fxi[k] - wx0, 0), kWinCols - 2);
-            const uint32_t* w0 = win + ly * kWinStride + lx;
-            q00[k] = w0[0]; q01[k] = w0[1]; q10[k] = w0[kWinStride]; q11[k] = w0[kWinStride + 1];
-          }
-          __builtin_amdgcn_wave_barrier();  // (the next draw of this strip overwrites the window)
-        } else {
-          // texel addresses as 32-bit byte offsets from the (scalar) level pointer: one shift and two adds per column instead of
-          // sign extensions and 64-bit adds (a level is at most 16384^2 x 4 bytes = 1 GiB)
-          const char* __restrict__ texb = reinterpret_cast<const char*>(tex);
-          const uint32_t row0 = ((uint32_t)y0 * (uint32_t)S) << 2, row1 = ((uint32_t)y1 * (uint32_t)S) << 2;
-          auto texel = [&](uint32_t off) __attribute__((always_inline)) { return *reinterpret_cast<const uint32_t*>(texb + off); };
-#pragma unroll
-          for (int k = 0; k < 4; k++) {
-            const uint32_t x0 = (uint32_t)(fxi[k] & msk), x1 = (x0 + 1u) & (uint32_t)msk;
-            q00[k] = texel(row0 + (x0 << 2)); q01[k] = texel(row0 + (x1 << 2));
-            q10[k] = texel(row1 + (x0 << 2)); q11[k] = texel(row1 + (x1 << 2));
-          }
-        }
-        const bool solid = (om & F_SOLID) != 0u;
-        const bool masked = mask_depth > 0 || rmask_on;
-        const bool msdf = mode != 0u;
-        const bool is_mtsdf = (mode == 14u || mode == 16u), is_stroke = (mode == 15u || mode == 16u);
-        float spr = 1.0f;
-        if (msdf) {  // wave-uniform (three v_rcp a coverage glyph has no use for)
-          const float unit = r.f0 * frcp(r.p0);  // pxRange / atlas size (atlas.frag:45-49)
-          const float fw_u = __builtin_fabsf((utx - uax) * r.inv_w), fw_v = __builtin_fabsf((uty - uay) * r.inv_h);
-          spr = __builtin_fmaxf(0.5f * (unit * frcp(fw_u) + unit * frcp(fw_v)), 1.0f);
-        }
-        const F4 c0u = unpack255(r.col[0]);
-        // The vertex-colour term once per lane where it cannot differ between the lane's four pixels: one colour, or a
-        // vertical gradient (BL == BR and TR == TL -- what a text tint is).  With equal colours on both sides, tri_lerp's two
-        // triangle formulas reduce to the same fma(bl - tl, t, tl) whatever s is (the s terms multiply an exact 0), so
-        // this is the value every pixel computed before, bit for bit.
-        const bool lane_col = solid || (r.col[0] == r.col[1] && r.col[2] == r.col[3]);  // wave-uniform
-        F4 colL = {c0u.x * inv255, c0u.y * inv255, c0u.z * inv255, c0u.w * inv255};
-        if (!solid && lane_col) {
-          const F4 br = unpack255(r.col[1]), tr = unpack255(r.col[2]), tl = unpack255(r.col[3]);
-          colL.x = tri_lerp(tl.x, c0u.x, br.x, tr.x, sK[0], t) * inv255;
-          colL.y = tri_lerp(tl.y, c0u.y, br.y, tr.y, sK[0], t) * inv255;
-          colL.z = tri_lerp(tl.z, c0u.z, br.z, tr.z, sK[0], t) * inv255;
-          colL.w = tri_lerp(tl.w, c0u.w, br.w, tr.w, sK[0], t) * inv255;
-        }
-        const bool msdf3 = msdf && !is_mtsdf;  // the distance is the median of r, g, b: the alpha channel is not sampled
-        auto pixel = [&](const int k, F4& F, const float mk, const float rm) __attribute__((always_inline)) {
-          const F4 a = unpack255(q00[k]), b = unpack255(q01[k]), c = unpack255(q10[k]), d = unpack255(q11[k]);
-          const float ax = axK[k];
-          F4 col = colL;
-          if (!lane_col) {  // wave-uniform
-            const F4 br = unpack255(r.col[1]), tr = unpack255(r.col[2]), tl = unpack255(r.col[3]);
-            col.x = tri_lerp(tl.x, c0u.x, br.x, tr.x, sK[k], t) * inv255;
-            col.y = tri_lerp(tl.y, c0u.y, br.y, tr.y, sK[k], t) * inv255;
-            col.z = tri_lerp(tl.z, c0u.z, br.z, tr.z, sK[k], t) * inv255;
-            col.w = tri_lerp(tl.w, c0u.w, br.w, tr.w, sK[k], t) * inv255;
-          }
-          float sr, sg, sb, sa;
-          if (msdf3) {  // wave-uniform.  atlas.frag:296-318; median3(k x, k y, k z) == k median3(x, y, z) exactly for k > 0
-            const float bx_ = mixf(a.x, b.x, ax) * (1.0f - ayf) + mixf(c.x, d.x, ax) * ayf;
-            const float by_ = mixf(a.y, b.y, ax) * (1.0f - ayf) + mixf(c.y, d.y, ax) * ayf;
-            const float bz_ = mixf(a.z, b.z, ax) * (1.0f - ayf) + mixf(c.z, d.z, ax) * ayf;
-            const F4 fc = eval_fill_rec(r, col, fill_mode, uK[k], v);
-            const float sd = median3(bx_, by_, bz_) * inv255;
-            const float spd = spr * (sd - r.f1);
-            const float alpha = is_stroke ? clamp01(__builtin_fmaxf(r.p1, 0.0f) * 0.5f - __builtin_fabsf(spd) + 0.5f) : clamp01(spd + 0.5f);
-            sr = fc.x; sg = fc.y; sb = fc.z; sa = fc.w * alpha;
-          } else {
-            F4 tx;  // GL_LINEAR, 0..1
-            tx.x = (mixf(a.x, b.x, ax) * (1.0f - ayf) + mixf(c.x, d.x, ax) * ayf) * inv255;
-            tx.y = (mixf(a.y, b.y, ax) * (1.0f - ayf) + mixf(c.y, d.y, ax) * ayf) * inv255;
-            tx.z = (mixf(a.z, b.z, ax) * (1.0f - ayf) + mixf(c.z, d.z, ax) * ayf) * inv255;
-            tx.w = (mixf(a.w, b.w, ax) * (1.0f - ayf) + mixf(c.w, d.w, ax) * ayf) * inv255;
-            if (!msdf) {  // atlas.frag:284-295
-              sr = tx.x * col.x; sg = tx.y * col.y; sb = tx.z * col.z; sa = tx.w * col.w;
-            } else {  // atlas.frag:296-318 (MTSDF: the distance is in alpha)
-              const F4 fc = eval_fill_rec(r, col, fill_mode, uK[k], v);
-              const float sd = is_mtsdf ? tx.w : median3(tx.x, tx.y, tx.z);
-              const float spd = spr * (sd - r.f1);
-              const float alpha = is_stroke ? clamp01(__builtin_fmaxf(r.p1, 0.0f) * 0.5f - __builtin_fabsf(spd) + 0.5f) : clamp01(spd + 0.5f);
-              sr = fc.x; sg = fc.y; sb = fc.z; sa = fc.w * alpha;
-            }
-          }
-          if (masked) sa = sa * mk * rm;
-          blend(F, sr, sg, sb, (xrel + (uint32_t)k) < wcov ? sa : 0.0f);
-        };
-        pixel(0, F0, mk0, rm0); pixel(1, F1, mk1, rm1); pixel(2, F2, mk2, rm2); pixel(3, F3, mk3, rm3);
-        return;
-      }
-      // Two-triangle coverage and barycentrics of a rotated / skewed quad for the lane's four pixels (make_frag()'s arithmetic, 32-bit:
-      // F_EDGE32).  The quad is the reference's triangles (3,0,1) = (TL, BL, BR) and (2,3,1) = (TR, TL, BR) over per-vertex ceil'd
-      // corners (glcontext.nim:418-429); a pixel belongs to the first whose three edge functions -- exact integers in half-pixel
-      // units, top-left rule -- admit its centre.  An edge value is a scalar base per strip + two v_mad_i32_i24 per lane + one add per
-      // further pixel; ownership is folded into the base (E - 1 >= 0 <=> E > 0), so a triangle's inside test is one v_or3 and a sign
-      // test.  Out: L0..L2 = the hit triangle's barycentrics (edge value x 1 / (E0 + E1 + E2)), T1 = it is the second triangle.
-      // `exact`: the barycentrics as the ORACLE's rasteriser forms them -- (float)(E x 1 / (E0 + E1 + E2)) in DOUBLE precision -- instead of
-      // float(E) x float(1 / sum).  The two differ in the last bit now and then, which no shading path cares about but one: the
-      // bezier distance's closed-form cubic amplifies a last-bit difference of its input into pixels (see sd_bezierN).
-      auto tri_bary = [&](const QuadExt& q, float (&L0)[4], float (&L1)[4], float (&L2)[4], bool (&T1)[4], bool (&cov)[4], const bool exact) __attribute__((always_inline)) {
-        const int X0 = 2 * tx0 + 1, Y0 = 2 * ty0 + 1;
-        const int dxl = 8 * (lane & 7), dyl = 2 * (lane >> 3);
-        int eb[2][3], a2[2][3], nb[2][3];
-#pragma unroll
-        for (int t = 0; t < 2; t++)
-#pragma unroll
-          for (int k = 0; k < 3; k++) {
-            const int a = q.e[t][k].a, b = q.e[t][k].b;
-            nb[t][k] = (int)(((q.own >> (t * 3 + k)) & 1u) ^ 1u);
-            const int base = a * X0 + b * Y0 + (int)(uint32_t)(uint64_t)q.e[t][k].c - nb[t][k];  // (scalar)
-            eb[t][k] = __mul24(b, dyl) + (__mul24(a, dxl) + base);
-            a2[t][k] = 2 * a;
-          }
-        const bool valid0 = q.inv_sum[0] != 0.0f, valid1 = q.inv_sum[1] != 0.0f;
-        const bool rowc = py >= r.by0 && py < r.by1;
-        // (exact) E0 + E1 + E2 is the same at every point of the plane: one double-precision reciprocal per triangle and lane.  The oracle
-        // divides in pixel units, w = E / 4 and 1 / (sum / 4): powers of two, the same quotient bit for bit.
-        double invd0 = 0.0, invd1 = 0.0;
-        if (exact) {
-          const int s0 = eb[0][0] + eb[0][1] + eb[0][2] + nb[0][0] + nb[0][1] + nb[0][2], s1 = eb[1][0] + eb[1][1] + eb[1][2] + nb[1][0] + nb[1][1] + nb[1][2];
-          invd0 = 1.0 / (double)(valid0 ? s0 : 1);
-          invd1 = 1.0 / (double)(valid1 ? s1 : 1);
-        }
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-          const int e00 = eb[0][0] + k * a2[0][0], e01 = eb[0][1] + k * a2[0][1], e02 = eb[0][2] + k * a2[0][2];
-          const int e10 = eb[1][0] + k * a2[1][0], e11 = eb[1][1] + k * a2[1][1], e12 = eb[1][2] + k * a2[1][2];
-          const bool in0 = valid0 && ((e00 | e01 | e02) >= 0), in1 = valid1 && ((e10 | e11 | e12) >= 0);
-          const bool use1 = !in0 && in1;
-          T1[k] = use1;
-          cov[k] = rowc && px0 + k >= r.bx0 && px0 + k < r.bx1 && (in0 || in1);
-          const int E0 = (use1 ? e10 : e00) + (use1 ? nb[1][0] : nb[0][0]), E1 = (use1 ? e11 : e01) + (use1 ? nb[1][1] : nb[0][1]),
-                    E2 = (use1 ? e12 : e02) + (use1 ? nb[1][2] : nb[0][2]);
-          if (exact) {  // (compile-time at every call site) oracle: w = edge function in pixel units (= E / 4), l = (float)(w / (w0 + w1 + w2))
-            const double inv = use1 ? invd1 : invd0;
-            L0[k] = (float)((double)E0 * inv); L1[k] = (float)((double)E1 * inv); L2[k] = (float)((double)E2 * inv);
-          } else {
-            const float is = use1 ? q.inv_sum[1] : q.inv_sum[0];
-            L0[k] = (float)E0 * is; L1[k] = (float)E1 * is; L2[k] = (float)E2 * is;
-          }
-        }
-      };
-      if (kSlow && (om & F_GENERAL) != 0u && (om & F_EDGE32) != 0u && atlas_mode && op == OP_DRAW) {
-        // ---- rotated / skewed atlas quads (glyphs, images, MSDF under a rotated transform), four pixels per lane: the two-triangle
-        // coverage and barycentrics of the SDF block below, uv interpolated between the quad's atlas corners, then the sampling
-        // and shading shade_one() does per pixel slot (atlas.frag:284-318) -- unrolled, so the lane's sixteen (trilinear: thirty-two)
-        // texel fetches are in flight together.
-        FDH_COUNT(59);
-        const QuadExt& q = exts[r.ext];
-        float L0[4], L1[4], L2[4];
-        bool T1[4], cov[4];
-        tri_bary(q, L0, L1, L2, T1, cov, false);
-        const bool solid = (om & F_SOLID) != 0u;
-        const F4 cBL = unpack255(r.col[0]), cBR = unpack255(r.col[1]), cTR = unpack255(r.col[2]), cTL = unpack255(r.col[3]);
-        const float uax = r.r[0], uay = r.r[1], utx = r.r[2], uty = r.r[3];
-        const uint32_t fill_mode = (om >> 9) & 7u;
-        const bool is_mtsdf = (mode == 14u || mode == 16u), is_stroke = (mode == 15u || mode == 16u);
-        float sr[4], sg[4], sb[4], sa[4];
-        // Round 5.  An MSDF image, or magnified / 1:1 under both triangles (lod <= 0: any glyph row, any image not shrunk): every pixel samples level 0
-        // with GL_LINEAR -- wave-uniform, so no per-lane branch stands between the lane's sixteen texel fetches (atlas_sample() below
-        // decides per pixel, and four dependent round trips per strip-draw made the 10 000-glyph rotated frame 4.5 x the upright one).
-        // And the texels any covered pixel can touch lie in the quad's own atlas rectangle (uv is a convex combination of the corners'):
-        // when that rectangle fits the strip's LDS window -- 64 x 12, 32 x 24 or 16 x 48 texels: every glyph -- the wave stages it with
-        // 16-byte runs and the taps come from LDS, as on the upright path.
-        if (mode != 0u || P.atlas.n_levels < 2 || (!(q.lod[0] > 0.0f) && !(q.lod[1] > 0.0f))) {  // (MSDF: textureLod(.., 0.0), atlas.frag:296-318)
-          const int S = P.atlas.size, msk = S - 1;
-          const float fS = (float)S;
-          const uint32_t* __restrict__ tex = P.atlas.level[0];
-          const bool shifted = mode == 0u && (om & F_SUBPIXEL) != 0u;
-          float ushift = 0.0f;
-          if (shifted) ushift = r.aux * frcp(__builtin_fmaxf(fS, 1.0f));  // (the same expression as the per-pixel form below)
-          float uK[4], vK[4], axK[4], ayK[4];
-          int fxi[4], fyi[4];
-          F4 colK[4];
-#pragma unroll
-          for (int k = 0; k < 4; k++) {
-            const bool use1 = T1[k];
-            const float l0 = L0[k], l1 = L1[k], l2 = L2[k];
-            const float u0 = use1 ? utx : uax, v0 = uay, u1 = uax, v1 = use1 ? uay : uty;
-            uK[k] = l0 * u0 + l1 * u1 + l2 * utx;
-            vK[k] = l0 * v0 + l1 * v1 + l2 * uty;
-            colK[k] = {cBL.x * inv255, cBL.y * inv255, cBL.z * inv255, cBL.w * inv255};
-            if (!solid) {
-              const float c0x = use1 ? cTR.x : cTL.x, c0y = use1 ? cTR.y : cTL.y, c0z = use1 ? cTR.z : cTL.z, c0w = use1 ? cTR.w : cTL.w;
-              const float c1x = use1 ? cTL.x : cBL.x, c1y = use1 ? cTL.y : cBL.y, c1z = use1 ? cTL.z : cBL.z, c1w = use1 ? cTL.w : cBL.w;
-              colK[k].x = (l0 * c0x + l1 * c1x + l2 * cBR.x) * inv255;
-              colK[k].y = (l0 * c0y + l1 * c1y + l2 * cBR.y) * inv255;
-              colK[k].z = (l0 * c0z + l1 * c1z + l2 * cBR.z) * inv255;
-              colK[k].w = (l0 * c0w + l1 * c1w + l2 * cBR.w) * inv255;
-            }
-            float us = uK[k];
-            if (shifted) us -= ushift;
-            const float x = us * fS - 0.5f, y = vK[k] * fS - 0.5f;  // (atlas_sample: u S - 0.5)
-            const float fx = __builtin_floorf(x), fy = __builtin_floorf(y);
-            axK[k] = x - fx; ayK[k] = y - fy;
-            fxi[k] = (int)fx; fyi[k] = (int)fy;
-          }
-          // the quad's atlas rectangle in texels, a texel of slack on every side (the barycentrics sum to 1 only up to rounding)
-          const float ulo = __builtin_fminf(uax, utx) - __builtin_fabsf(ushift), uhi = __builtin_fmaxf(uax, utx) + __builtin_fabsf(ushift);
-          const float vlo = __builtin_fminf(uay, uty), vhi = __builtin_fmaxf(uay, uty);
-          const int wx0 = __builtin_amdgcn_readfirstlane((int)__builtin_floorf(ulo * fS - 0.5f)) - 1, wx1 = __builtin_amdgcn_readfirstlane((int)__builtin_floorf(uhi * fS - 0.5f)) + 2;
-          const int wy0 = __builtin_amdgcn_readfirstlane((int)__builtin_floorf(vlo * fS - 0.5f)) - 1, wy1 = __builtin_amdgcn_readfirstlane((int)__builtin_floorf(vhi * fS - 0.5f)) + 2;
-          const int WW = wx1 - wx0 + 1, WH = wy1 - wy0 + 1;  // texels
-          const int wsh = WW <= 16 ? 4 : WW <= 32 ? 5 : 6;    // log2 of the row stride in dwords: 768 dwords as 48 x 16, 24 x 32 or 12 x 64
-          const bool windowed = WW <= 64 && WH <= (768 >> wsh) && wx0 >= 0 && wy0 >= 0 && wx1 + 3 < S && wy1 < S;  // wave-uniform
-          uint32_t q00[4], q01[4], q10[4], q11[4];
-          if (windowed) {
-            uint32_t* const win = composite_lds + (P.has_masks ? kMaskDepth * 64 : 256);
-            {
-              const int lpr_sh = wsh - 2;  // lanes per window row = stride / 4
-              const int lr = lane >> lpr_sh, lc = (lane & ((1 << lpr_sh) - 1)) * 4, rpp = 64 >> lpr_sh;
-              const int cc = min(lc, (WW - 1) & ~3);
-              struct __attribute__((packed, aligned(4))) Run4 { uint32_t v[4]; };
-              for (int row0 = 0; row0 < WH; row0 += rpp) {  // (wave-uniform trip count: two passes for a 12 x 20 glyph)
-                const int row = min(row0 + lr, WH - 1);
-                const Run4 run = *reinterpret_cast<const Run4*>(tex + (((uint32_t)(wy0 + row)) << (uint32_t)__builtin_ctz((uint32_t)S)) + (uint32_t)(wx0 + cc));
-                uint4 q4 = {run.v[0], run.v[1], run.v[2], run.v[3]};
-                *reinterpret_cast<uint4*>(win + ((row0 + lr) << wsh) + lc) = q4;
-              }
-            }
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int k = 0; k < 4; k++) {  // (a pixel outside the quad may point anywhere: clamped into the window, blended with alpha 0)
-              const int lx = min(max(fxi[k] - wx0, 0), WW - 2), ly = min(max(fyi[k] - wy0, 0), WH - 2);
-              const uint32_t* w0 = win + (ly << wsh) + lx;
-              q00[k] = w0[0]; q01[k] = w0[1]; q10[k] = w0[1 << wsh]; q11[k] = w0[(1 << wsh) + 1];
-            }
-            __builtin_amdgcn_wave_barrier();  // (the next draw of this strip overwrites the window)
-          } else {
-            const char* __restrict__ texb = reinterpret_cast<const char*>(tex);
-            auto texel = [&](uint32_t off) __attribute__((always_inline)) { return *reinterpret_cast<const uint32_t*>(texb + off); };
-#pragma unroll
-            for (int k = 0; k < 4; k++) {  // GL_REPEAT, as atlas_bilinear()
-              const uint32_t x0 = (uint32_t)(fxi[k] & msk), x1 = (x0 + 1u) & (uint32_t)msk, y0 = (uint32_t)(fyi[k] & msk), y1 = (y0 + 1u) & (uint32_t)msk;
-              const uint32_t row0 = (y0 * (uint32_t)S) << 2, row1 = (y1 * (uint32_t)S) << 2;
-              q00[k] = texel(row0 + (x0 << 2)); q01[k] = texel(row0 + (x1 << 2));
-              q10[k] = texel(row1 + (x0 << 2)); q11[k] = texel(row1 + (x1 << 2));
-            }
-          }
-#pragma unroll
-          for (int k = 0; k < 4; k++) {
-            const F4 t = bilinear_of(q00[k], q01[k], q10[k], q11[k], axK[k], ayK[k]);
-            if (mode == 0u) {  // wave-uniform; atlas.frag:284-295
-              sr[k] = t.x * colK[k].x; sg[k] = t.y * colK[k].y; sb[k] = t.z * colK[k].z; sa[k] = t.w * colK[k].w;
-            } else {  // atlas.frag:296-318
-              const bool use1 = T1[k];
-              const float fwu = use1 ? q.fw_u[1] : q.fw_u[0], fwv = use1 ? q.fw_v[1] : q.fw_v[0];
-              const F4 fc = eval_fill_rec(r, colK[k], fill_mode, uK[k], vK[k]);
-              const float sd = is_mtsdf ? t.w : median3(t.x, t.y, t.z);
-              const float unit = r.f0 * frcp(r.p0);  // pxRange / atlas size (atlas.frag:45-49)
-              const float spr = __builtin_fmaxf(0.5f * (unit * frcp(fwu) + unit * frcp(fwv)), 1.0f);
-              const float spd = spr * (sd - r.f1);
-              const float alpha = is_stroke ? clamp01(__builtin_fmaxf(r.p1, 0.0f) * 0.5f - __builtin_fabsf(spd) + 0.5f) : clamp01(spd + 0.5f);
-              sr[k] = fc.x; sg[k] = fc.y; sb[k] = fc.z; sa[k] = fc.w * alpha;
-            }
-          }
-          blend(F0, sr[0], sg[0], sb[0], cov[0] ? sa[0] * mk0 * rm0 : 0.0f);
-          blend(F1, sr[1], sg[1], sb[1], cov[1] ? sa[1] * mk1 * rm1 : 0.0f);
-          blend(F2, sr[2], sg[2], sb[2], cov[2] ? sa[2] * mk2 * rm2 : 0.0f);
-          blend(F3, sr[3], sg[3], sb[3], cov[3] ? sa[3] * mk3 * rm3 : 0.0f);
-          return;
-        }
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-          const bool use1 = T1[k];
-          const float l0 = L0[k], l1 = L1[k], l2 = L2[k];
-          // triangle 0 = (TL, BL, BR), triangle 1 = (TR, TL, BR): make_frag()'s corner table
-          const float u0 = use1 ? utx : uax, v0 = uay, u1 = uax, v1 = use1 ? uay : uty;
-          float u = l0 * u0 + l1 * u1 + l2 * utx;
-          const float v = l0 * v0 + l1 * v1 + l2 * uty;
-          F4 col = {cBL.x * inv255, cBL.y * inv255, cBL.z * inv255, cBL.w * inv255};
-          if (!solid) {
-            const float c0x = use1 ? cTR.x : cTL.x, c0y = use1 ? cTR.y : cTL.y, c0z = use1 ? cTR.z : cTL.z, c0w = use1 ? cTR.w : cTL.w;
-            const float c1x = use1 ? cTL.x : cBL.x, c1y = use1 ? cTL.y : cBL.y, c1z = use1 ? cTL.z : cBL.z, c1w = use1 ? cTL.w : cBL.w;
-            col.x = (l0 * c0x + l1 * c1x + l2 * cBR.x) * inv255;
-            col.y = (l0 * c0y + l1 * c1y + l2 * cBR.y) * inv255;
-            col.z = (l0 * c0z + l1 * c1z + l2 * cBR.z) * inv255;
-            col.w = (l0 * c0w + l1 * c1w + l2 * cBR.w) * inv255;
-          }
-          const float fwu = use1 ? q.fw_u[1] : q.fw_u[0], fwv = use1 ? q.fw_v[1] : q.fw_v[0], lod = use1 ? q.lod[1] : q.lod[0];
-          if (mode == 0u) {  // wave-uniform; atlas.frag:284-295
-            if (om & F_SUBPIXEL) u -= r.aux * frcp(__builtin_fmaxf((float)P.atlas.size, 1.0f));
-            const F4 t = atlas_sample(P.atlas, u, v, lod);
-            sr[k] = t.x * col.x; sg[k] = t.y * col.y; sb[k] = t.z * col.z; sa[k] = t.w * col.w;
-          } else {  // atlas.frag:296-318
-            const F4 fc = eval_fill_rec(r, col, fill_mode, u, v);
-            const F4 t = atlas_sample(P.atlas, u, v, 0.0f);  // textureLod(atlasTex, uv, 0.0)
-            const float sd = is_mtsdf ? t.w : median3(t.x, t.y, t.z);
-            const float unit = r.f0 * frcp(r.p0);  // pxRange / atlas size (atlas.frag:45-49)
-            const float spr = __builtin_fmaxf(0.5f * (unit * frcp(fwu) + unit * frcp(fwv)), 1.0f);
-            const float spd = spr * (sd - r.f1);
-            const float alpha = is_stroke ? clamp01(__builtin_fmaxf(r.p1, 0.0f) * 0.5f - __builtin_fabsf(spd) + 0.5f) : clamp01(spd + 0.5f);
-            sr[k] = fc.x; sg[k] = fc.y; sb[k] = fc.z; sa[k] = fc.w * alpha;
-          }
-        }
-        blend(F0, sr[0], sg[0], sb[0], cov[0] ? sa[0] * mk0 * rm0 : 0.0f);
-        blend(F1, sr[1], sg[1], sb[1], cov[1] ? sa[1] * mk1 * rm1 : 0.0f);
-        blend(F2, sr[2], sg[2], sb[2], cov[2] ? sa[2] * mk2 * rm2 : 0.0f);
-        blend(F3, sr[3], sg[3], sb[3], cov[3] ? sa[3] * mk3 * rm3 : 0.0f);
-        return;
-      }
-      if (kRot && (om & F_GENERAL) != 0u && (om & F_EDGE32) != 0u && !atlas_mode && mode < 18u && (op == OP_DRAW || (kMasks && op == OP_MASK_PUSH))) {
-        // ---- rotated / skewed SDF quads, 4 pixels per lane in lock-step (round 4; before: one pixel slot at a time through
-        // shade_one(), 15x the time of the same tree unrotated).  The quad is the reference's two triangles (3,0,1) / (2,3,1) over
-        // per-vertex ceil'd corners (glcontext.nim:418-429); a pixel belongs to the first whose three edge functions -- exact
-        // integers in half-pixel units, top-left rule -- admit its centre, and its uv / vertex colour are that triangle's
-        // barycentric interpolation, as in make_frag().  F_EDGE32 (Recorder::emit_corners): every edge value any pixel of the frame
-        // can produce fits 32 bits and the coefficients fit 24, so the strip's scalar base + two v_mad_i32_i24 per edge replace the
-        // 64-bit arithmetic; quads beyond that keep the slot path.  Ownership is folded into the base (E - 1 >= 0 <=> E > 0).
-        FDH_COUNT(60);
-        if (core) FDH_COUNT(63);
-        if (core && (mode == 9u || mode == 11u || mode == 12u)) return;
-        const QuadExt& q = exts[r.ext];
-        float L0[4], L1[4], L2[4];
-        bool T1[4], cov[4];
-        tri_bary(q, L0, L1, L2, T1, cov, false);
-        const bool solid = (om & F_SOLID) != 0u;
-        const F4 cBL = unpack255(r.col[0]), cBR = unpack255(r.col[1]), cTR = unpack255(r.col[2]), cTL = unpack255(r.col[3]);
-        const float qhx = r.p0, qhy = r.p1;
-        float u[4], v[4], lx[4], nly[4];
-        F4 col[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-          // tri 0 = (TL, BL, BR): u = l2, v = l1 + l2;  tri 1 = (TR, TL, BR): u = l0 + l2, v = l2   (uv corners are 0 / 1: the
-          // products of make_frag()'s sums are exact)
-          const bool use1 = T1[k];
-          const float la = use1 ? L0[k] : L1[k], lb = L2[k];
-          const float sum = la + lb;
-          u[k] = use1 ? sum : lb;
-          v[k] = use1 ? lb : sum;
-          if (solid) {
-            col[k] = {cBL.x * inv255, cBL.y * inv255, cBL.z * inv255, cBL.w * inv255};
-          } else {
-            const float l0 = L0[k], l1 = L1[k];
-            const float c0x = use1 ? cTR.x : cTL.x, c0y = use1 ? cTR.y : cTL.y, c0z = use1 ? cTR.z : cTL.z, c0w = use1 ? cTR.w : cTL.w;
-            const float c1x = use1 ? cTL.x : cBL.x, c1y = use1 ? cTL.y : cBL.y, c1z = use1 ? cTL.z : cBL.z, c1w = use1 ? cTL.w : cBL.w;
-            col[k].x = (l0 * c0x + l1 * c1x + lb * cBR.x) * inv255;
-            col[k].y = (l0 * c0y + l1 * c1y + lb * cBR.y) * inv255;
-            col[k].z = (l0 * c0z + l1 * c1z + lb * cBR.z) * inv255;
-            col[k].w = (l0 * c0w + l1 * c1w + lb * cBR.w) * inv255;
-          }
-          lx[k] = (u[k] - 0.5f) * 2.0f * qhx;
-          nly[k] = -((v[k] - 0.5f) * 2.0f * qhy);
-        }
-        const bool ellip = (om & F_ELLIP) != 0u;
-        const uint32_t fill_mode = (om >> 9) & 7u;
-        const bool inset = mode == 9u && op == OP_DRAW;
-        const float shx = inset ? qhx : r.p2, shy = inset ? qhy : r.p3;
-        const float spread = fill_mode == 0u ? r.f1 : 0.0f;
-        float dist[4];
-        if (core) { dist[0] = dist[1] = dist[2] = dist[3] = -1.0e30f; }  // (wave-uniform: the coverage term is saturated on this strip, QuadExt::core)
-        else shape_distNy<4, true>(ellip, lx, nly, shx, shy, r.r[0], r.r[1], r.r[2], r.r[3], dist);
-        if (kMasks && op == OP_MASK_PUSH) {  // mask.frag:186-234, as on the axis-aligned path below
-          float mk[4] = {mk0, mk1, mk2, mk3};
-          uint32_t packed = 0;
-#pragma unroll
-          for (int k = 0; k < 4; k++) {
-            float a = (1.0f - clamp01(r.aa * dist[k] + 0.5f)) * col[k].w * mk[k];
-            a = cov[k] ? a : 0.0f;
-            const float qq = __builtin_rintf(a * a * 255.0f);
-            packed |= (uint32_t)qq << (8 * k);
-            mk[k] = qq * inv255;
-          }
-          mk0 = mk[0]; mk1 = mk[1]; mk2 = mk[2]; mk3 = mk[3];
-          stack_put(mask_depth, packed);
-          mask_depth++;
-          return;
-        }
-        float alpha[4];
-        switch (mode) {  // wave-uniform; atlas.frag:337-393, operation for operation what shade_one() does per pixel
-          case 11u: {
-            const float h = r.f0 * 0.5f;
-#pragma unroll
-            for (int k = 0; k < 4; k++) alpha[k] = (__builtin_fabsf(dist[k] + h) - h) < 0.0f ? 1.0f : 0.0f;
-            break;
-          }
-          case 12u: {
-            const float h = r.f0 * 0.5f;
-#pragma unroll
-            for (int k = 0; k < 4; k++) alpha[k] = 1.0f - clamp01(r.aa * (__builtin_fabsf(dist[k] + h) - h) + 0.5f);
-            break;
-          }
-          case 7u: {
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-              const float sd = dist[k] - spread;
-              const float sp = __builtin_fminf(shadow_profile(sd, r.f0), 1.0f);
-              alpha[k] = sd > 0.0f ? sp : 1.0f;
-            }
-            break;
-          }
-          case 8u: {
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-              const float inside = 1.0f - clamp01(r.aa * dist[k] + 0.5f);
-              const float sd = dist[k] - spread;
-              const float sp = __builtin_fminf(shadow_profile(sd, r.f0), 1.0f);
-              alpha[k] = sd >= 0.0f ? sp : inside;
-            }
-            break;
-          }
-          case 9u: {
-            float sx[4], sy[4], shd[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) { sx[k] = lx[k] - r.p2; sy[k] = nly[k] + r.p3; }
-            shape_distNy<4, true>(ellip, sx, sy, qhx, qhy, r.r[0], r.r[1], r.r[2], r.r[3], shd);
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-              const float clip_a = 1.0f - clamp01(r.aa * dist[k] + 0.5f);
-              const float sd = shd[k] + spread;
-              const float sp = __builtin_fminf(shadow_profile(sd, r.f0), 1.0f);
-              const float ia = sd < 0.0f ? sp : 1.0f;
-              alpha[k] = clip_a * ia;
-            }
-            break;
-          }
-          default: {
-#pragma unroll
-            for (int k = 0; k < 4; k++) alpha[k] = 1.0f - clamp01(r.aa * dist[k] + 0.5f);
-            break;
-          }
-        }
-        float sr[4], sg[4], sb[4], sa[4];
-        if (mode == 17u) {  // atlas.frag:381-388: the blurred backdrop at this fragment's own pixel (clamped addresses, no branch)
-          F4 b[4] = {F0, F1, F2, F3};
-          if (!(om & F_SELF_BACKDROP)) {
-            const size_t rowp = (size_t)min(py, P.H - 1) * P.pitch;
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-              const F4 t = unpack255(P.backdrop[rowp + min(px0 + k, P.W - 1)]);
-              const bool in = row_ok && px0 + k < P.W;
-              b[k].x = in ? t.x : b[k].x; b[k].y = in ? t.y : b[k].y; b[k].z = in ? t.z : b[k].z; b[k].w = in ? t.w : b[k].w;
-            }
-          }
-#pragma unroll
-          for (int k = 0; k < 4; k++) { sr[k] = b[k].x * inv255; sg[k] = b[k].y * inv255; sb[k] = b[k].z * inv255; sa[k] = b[k].w * inv255 * alpha[k]; }
-        } else if (fill_mode == 0u) {
-#pragma unroll
-          for (int k = 0; k < 4; k++) { sr[k] = col[k].x; sg[k] = col[k].y; sb[k] = col[k].z; sa[k] = col[k].w * alpha[k]; }
-        } else {
-          const F4 mc = unpack255(r.mid), sc = unpack255(r.stop);
-          const F4 m01 = {mc.x * inv255, mc.y * inv255, mc.z * inv255, mc.w * inv255}, s01 = {sc.x * inv255, sc.y * inv255, sc.z * inv255, sc.w * inv255};
-          const float mid = __builtin_fminf(__builtin_fmaxf(r.f1, 0.01f), 0.99f);
-#pragma unroll
-          for (int k = 0; k < 4; k++) {
-            const F4 fc = eval_fill_nb(col[k], m01, s01, fill_mode, mid, u[k], v[k]);
-            sr[k] = fc.x; sg[k] = fc.y; sb[k] = fc.z; sa[k] = fc.w * alpha[k];
-          }
-        }
-        blend(F0, sr[0], sg[0], sb[0], cov[0] ? sa[0] * mk0 * rm0 : 0.0f);
-        blend(F1, sr[1], sg[1], sb[1], cov[1] ? sa[1] * mk1 * rm1 : 0.0f);
-        blend(F2, sr[2], sg[2], sb[2], cov[2] ? sa[2] * mk2 * rm2 : 0.0f);
-        blend(F3, sr[3], sg[3], sb[3], cov[3] ? sa[3] * mk3 * rm3 : 0.0f);
-        return;
-      }
-      if (kSlow && mode >= 18u && mode <= 20u && ((om & F_GENERAL) == 0u || (om & F_EDGE32) != 0u) && op == OP_DRAW) {
-        // ---- quadratic-bezier strokes on upright quads (drawQuadraticBezierSdf, modes 18 - 20: atlas.frag:121-209, 321-336), four
-        // pixels per lane.  The quad is the span's bounding box; most of it is far from the curve.  The curve lies in the hull of its
-        // control points, inside the box aligned with its chord AC that reaches min(0, b.f) .. max(|AC|, b.f) along it and 0 .. b.g / 2
-        // across (b = B - A): a pixel farther from that box than sqrt 2 (half width + 0.5 / aa) has coverage exactly 0 in every
-        // mode (the square cap of mode 20 reaches that far past an end point), and a strip of such pixels skips the cubic.
-        const float Ax = r.p2, Ay = r.p3, Bx = r.r[0], By = r.r[1], Cx = r.r[2], Cy = r.r[3];
-        const float hw = __builtin_fmaxf(r.f0, 0.0f) * 0.5f;
-        const bool general = (om & F_GENERAL) != 0u;  // wave-uniform: the stroke under a rotated transform (uv from the two-triangle barycentrics)
-        float lx[4], lyv[4], u[4], vv[4];
-        bool cov[4];
-        F4 colv[4];
-        const F4 c0 = unpack255(r.col[0]);
-        if (general) {
-          float L0[4], L1[4], L2[4];
-          bool T1[4];
-          tri_bary(exts[r.ext], L0, L1, L2, T1, cov, true);
-          const F4 cBR = unpack255(r.col[1]), cTR = unpack255(r.col[2]), cTL = unpack255(r.col[3]);
-#pragma unroll
-          for (int k = 0; k < 4; k++) {
-            const bool use1 = T1[k];
-            const float la = use1 ? L0[k] : L1[k], lb = L2[k], sum = la + lb;
-            u[k] = use1 ? sum : lb;
-            vv[k] = use1 ? lb : sum;
-            lx[k] = (u[k] - 0.5f) * 2.0f * r.p0;
-            lyv[k] = (vv[k] - 0.5f) * 2.0f * r.p1;
-            colv[k] = {c0.x * inv255, c0.y * inv255, c0.z * inv255, c0.w * inv255};
-            if (!(om & F_SOLID)) {
-              const float l0 = L0[k], l1 = L1[k];
-              const float c0x = use1 ? cTR.x : cTL.x, c0y = use1 ? cTR.y : cTL.y, c0z = use1 ? cTR.z : cTL.z, c0w = use1 ? cTR.w : cTL.w;
-              const float c1x = use1 ? cTL.x : c0.x, c1y = use1 ? cTL.y : c0.y, c1z = use1 ? cTL.z : c0.z, c1w = use1 ? cTL.w : c0.w;
-              colv[k].x = (l0 * c0x + l1 * c1x + lb * cBR.x) * inv255; colv[k].y = (l0 * c0y + l1 * c1y + lb * cBR.y) * inv255;
-              colv[k].z = (l0 * c0z + l1 * c1z + lb * cBR.z) * inv255; colv[k].w = (l0 * c0w + l1 * c1w + lb * cBR.w) * inv255;
-            }
-          }
-        } else {
-          const bool rowc = py >= r.by0 && py < r.by1;
-          const float t = (cy - r.oy) * r.inv_h;
-          local_x4(r, cx0, lx);
-          const float ly = -local_y_up(r, cy);
-#pragma unroll
-          for (int k = 0; k < 4; k++) {
-            u[k] = (cx0 + (float)k - r.ox) * r.inv_w;
-            vv[k] = t;
-            lyv[k] = ly;
-            cov[k] = rowc && px0 + k >= r.bx0 && px0 + k < r.bx1;
-            colv[k] = {c0.x * inv255, c0.y * inv255, c0.z * inv255, c0.w * inv255};
-            if (!(om & F_SOLID)) {  // wave-uniform
-              const F4 br = unpack255(r.col[1]), tr = unpack255(r.col[2]), tl = unpack255(r.col[3]);
-              colv[k].x = tri_lerp(tl.x, c0.x, br.x, tr.x, u[k], t) * inv255; colv[k].y = tri_lerp(tl.y, c0.y, br.y, tr.y, u[k], t) * inv255;
-              colv[k].z = tri_lerp(tl.z, c0.z, br.z, tr.z, u[k], t) * inv255; colv[k].w = tri_lerp(tl.w, c0.w, br.w, tr.w, u[k], t) * inv255;
-            }
-          }
-        }
-        float fx, fy, sx, sy, ex, ey;  // (wave-uniform: the record's alone)
-        safe_normalize(Cx - Ax, Cy - Ay, 1.0f, 0.0f, fx, fy);
-        {
-          const float bf = (Bx - Ax) * fx + (By - Ay) * fy, bg = (By - Ay) * fx - (Bx - Ax) * fy;
-          const float lac = (Cx - Ax) * fx + (Cy - Ay) * fy;
-          const float x_lo = __builtin_fminf(0.0f, bf), x_hi = __builtin_fmaxf(lac, bf), y_lo = __builtin_fminf(0.0f, 0.5f * bg), y_hi = __builtin_fmaxf(0.0f, 0.5f * bg);
-          const float ocx = 0.5f * (x_lo + x_hi), ohx = 0.5f * (x_hi - x_lo), ocy = 0.5f * (y_lo + y_hi), ohy = 0.5f * (y_hi - y_lo);
-          const float reach = 1.41422f * (hw + 0.5f * frcp(r.aa)) + 0.01f;
-          bool near = false;
-#pragma unroll
-          for (int k = 0; k < 4; k++) {
-            const float rx = lx[k] - Ax, ry = lyv[k] - Ay;
-            const float X = rx * fx + ry * fy, Y = ry * fx - rx * fy;
-            const float db = __builtin_fmaxf(__builtin_fabsf(X - ocx) - ohx, __builtin_fabsf(Y - ocy) - ohy);
-            near = near || (cov[k] && db < reach);
-          }
-          if (!__any(near)) { FDH_COUNT(62); return; }
-        }
-        FDH_COUNT(61);
-        float dist[4];
-        if (general) sd_bezierN<4, true>(lx, lyv, Ax, Ay, Bx, By, Cx, Cy, dist);  // (wave-uniform)
-        else sd_bezierN<4, false>(lx, lyv, Ax, Ay, Bx, By, Cx, Cy, dist);
-        float alpha[4];
-        if (mode == 18u) {
-#pragma unroll
-          for (int k = 0; k < 4; k++) alpha[k] = 1.0f - clamp01(r.aa * (dist[k] - hw) + 0.5f);
-        } else {  // bezierStrokeSd atlas.frag:179-209
-          safe_normalize(Bx - Ax, By - Ay, fx, fy, sx, sy);
-          safe_normalize(Cx - Bx, Cy - By, fx, fy, ex, ey);
-          const float trim = mode == 20u ? hw : 0.0f;
-#pragma unroll
-          for (int k = 0; k < 4; k++) {
-            const float start_proj = (lx[k] - Ax) * sx + (lyv[k] - Ay) * sy, end_proj = (lx[k] - Cx) * ex + (lyv[k] - Cy) * ey;
-            float tube = dist[k];
-            if (mode == 20u) {  // wave-uniform
-              const float ta = __builtin_fminf(tube, __builtin_fabsf((lx[k] - Ax) * sy - (lyv[k] - Ay) * sx));
-              tube = start_proj < 0.0f ? ta : tube;
-              const float tb = __builtin_fminf(tube, __builtin_fabsf((lx[k] - Cx) * ey - (lyv[k] - Cy) * ex));
-              tube = end_proj > 0.0f ? tb : tube;
-            }
-            const float cap = __builtin_fmaxf(-start_proj - trim, end_proj - trim);
-            alpha[k] = 1.0f - clamp01(r.aa * __builtin_fmaxf(tube - hw, cap) + 0.5f);
-          }
-        }
-        const uint32_t fill_mode = (om >> 9) & 7u;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-          const F4 fc = eval_fill_rec(r, colv[k], fill_mode, u[k], vv[k]);
-          const float mkk = k == 0 ? mk0 : k == 1 ? mk1 : k == 2 ? mk2 : mk3, rmk = k == 0 ? rm0 : k == 1 ? rm1 : k == 2 ? rm2 : rm3;
-          F4& F = k == 0 ? F0 : k == 1 ? F1 : k == 2 ? F2 : F3;
-          blend(F, fc.x, fc.y, fc.z, cov[k] ? fc.w * alpha[k] * mkk * rmk : 0.0f);
-        }
-        return;
-      }
-      if (!kSlow && !fast) return;  // unreachable: the host picks kSlow = true for any phase holding such a draw
-      if (kSlow && !fast) {
-        FDH_COUNT(1);
-        // ---- one pixel slot at a time, state rotated so slot 0 is always the live one
-        uint32_t packed = 0;
-#pragma unroll 1
-        for (int k = 0; k < 4; k++) {
-          const int px = px0 + k;
-          if (op == OP_RMASK_BEGIN) {
-            rmask_on = true;
-            rm0 = rect_mask_alpha(draws[d], (float)px + 0.5f, cy);
-          } else {
-            const bool in_frame = row_ok && px < P.W;
-            const Src s = shade_one(draws + d, exts, &P.atlas, P.backdrop, pix + k, in_frame, px, py, F0);
-            if (op == OP_MASK_PUSH) {
-              float a = s.covered ? s.a * mk0 : 0.0f;
-              const float q = __builtin_rintf(a * a * 255.0f);
-              packed |= (uint32_t)q << (8 * k);
-              mk0 = q * inv255;
-            } else {
-              float a = s.a * mk0 * rm0;
-              a = s.covered ? a : 0.0f;
-              blend(F0, s.r, s.g, s.b, a);
-            }
-          }
-          { const F4 t = F0; F0 = F1; F1 = F2; F2 = F3; F3 = t; }
-          { const float t = mk0; mk0 = mk1; mk1 = mk2; mk2 = mk3; mk3 = t; }
-          { const float t = rm0; rm0 = rm1; rm1 = rm2; rm2 = rm3; rm3 = t; }
-        }
-        if (op == OP_MASK_PUSH) { stack_put(mask_depth, packed); mask_depth++; }
-        return;
-      }
-
-      // ---- fast path: axis-aligned SDF draw / clip push, 4 pixels per lane in lock-step
-      const bool ellip = (om & F_ELLIP) != 0u;
-      const uint32_t fill_mode = (om >> 9) & 7u;
-      // `core`: the strip lies in the draw's saturated core (DrawRec::ix0..iy1, decided per strip by k_bin_draws): the
-      // whole strip has coverage alpha 1 (annular strokes, alpha 0 there, never get this far).
-      if (core) {
-        if (mode == 9u || mode == 11u || mode == 12u) { FDH_COUNT(32); if (kShader) deep_nop(rk); return; }
-        if (op == OP_DRAW && (om & F_SOLID) && fill_mode == 0u && mode != 17u) {
-          FDH_COUNT(33);
-          const F4 c0 = unpack255(r.col[0]);
-          const float sa = c0.w * inv255;
-          if (mask_depth == 0 && !rmask_on) {  // one source term for the whole strip
-            const float A = 255.0f * sa, ia = 1.0f - sa;
-            const f2 c_rg = {c0.x * inv255 * A, c0.y * inv255 * A}, c_ba = {c0.z * inv255 * A, A};
-            if (kShader) {
-              deep_publish(deep_slot(rk), rk, DT_UNIFORM_PRE, __float_as_uint(c_rg.x), __float_as_uint(c_rg.y), __float_as_uint(c_ba.x), __float_as_uint(c_ba.y), __float_as_uint(ia));
-              return;
-            }
-            blend_pre(F0, c_rg, c_ba, ia); blend_pre(F1, c_rg, c_ba, ia); blend_pre(F2, c_rg, c_ba, ia); blend_pre(F3, c_rg, c_ba, ia);
-          } else {
-            const float cr = c0.x * inv255, cg = c0.y * inv255, cb = c0.z * inv255;
-            blend(F0, cr, cg, cb, sa * mk0 * rm0); blend(F1, cr, cg, cb, sa * mk1 * rm1);
-            blend(F2, cr, cg, cb, sa * mk2 * rm2); blend(F3, cr, cg, cb, sa * mk3 * rm3);
-          }
-          return;
-        }
-        FDH_COUNT(34);
-      }
-      FDH_COUNT(8 + (mode & 31u));
-      if (ellip) FDH_COUNT(2);
-      if (!(om & F_SOLID)) FDH_COUNT(3);
-      if (fill_mode != 0u) FDH_COUNT(4);
-      const float t = (cy - r.oy) * r.inv_h;  // v of the quad (uv = (0,0)-(1,1) for SDF quads)
-      const bool rowc = py >= r.by0 && py < r.by1;
-      // (wave-uniform) every pixel of the strip is covered by the quad: the strip lies in the draw's saturated core, which lies inside
-      // the quad (set_saturated_core), or k_bin_draws found it inside the quad's pixel bounds (BR_BOX_EXACT)
-      const bool all_cov = core || inq;
-      float u[4];
-      bool cov[4];
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        u[k] = (cx0 + (float)k - r.ox) * r.inv_w;
-        cov[k] = rowc && px0 + k >= r.bx0 && px0 + k < r.bx1;
-      }
-      F4 col[4];
-      {
-        const F4 c0 = unpack255(r.col[0]);
-        if (om & F_SOLID) {
-#pragma unroll
-          for (int k = 0; k < 4; k++) col[k] = {c0.x * inv255, c0.y * inv255, c0.z * inv255, c0.w * inv255};
-        } else {
-          const F4 br = unpack255(r.col[1]), tr = unpack255(r.col[2]), tl = unpack255(r.col[3]);
-          // Which of the quad's two triangles interpolates (s > t: the upper one) is the same for every pixel of most strips -- the
-          // diagonal crosses few of them: then only that triangle's expression is evaluated (two FMAs per channel instead of four and a select)
-          const bool up_all = __all(u[0] > t && u[1] > t && u[2] > t && u[3] > t), low_all = __all(!(u[0] > t) && !(u[1] > t) && !(u[2] > t) && !(u[3] > t));
-          if (up_all) {
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-              col[k].x = tri_upper(tl.x, br.x, tr.x, u[k], t) * inv255; col[k].y = tri_upper(tl.y, br.y, tr.y, u[k], t) * inv255;
-              col[k].z = tri_upper(tl.z, br.z, tr.z, u[k], t) * inv255; col[k].w = tri_upper(tl.w, br.w, tr.w, u[k], t) * inv255;
-            }
-          } else if (low_all) {
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-              col[k].x = tri_lower(tl.x, c0.x, br.x, u[k], t) * inv255; col[k].y = tri_lower(tl.y, c0.y, br.y, u[k], t) * inv255;
-              col[k].z = tri_lower(tl.z, c0.z, br.z, u[k], t) * inv255; col[k].w = tri_lower(tl.w, c0.w, br.w, u[k], t) * inv255;
-            }
-          } else {
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-              col[k].x = tri_lerp(tl.x, c0.x, br.x, tr.x, u[k], t) * inv255;
-              col[k].y = tri_lerp(tl.y, c0.y, br.y, tr.y, u[k], t) * inv255;
-              col[k].z = tri_lerp(tl.z, c0.z, br.z, tr.z, u[k], t) * inv255;
-              col[k].w = tri_lerp(tl.w, c0.w, br.w, tr.w, u[k], t) * inv255;
-            }
-          }
-        }
-      }
-      const float qhx = r.p0, qhy = r.p1;
-      const bool inset = mode == 9u && op == OP_DRAW;
-      const float shx = inset ? qhx : r.p2, shy = inset ? qhy : r.p3;
-      float lx[4], dist[4];
-      local_x4(r, cx0, lx);
-      const float ly = -local_y_up(r, cy);
-      const float spread = fill_mode == 0u ? r.f1 : 0.0f;
-      // Tile classification.  Along a row the rounded-box distance is quasi-convex (its sub-level sets are
-      // intervals), so if the two OUTER pixels of every lane's 4-pixel run give the same saturated alpha, the two
-      // inner ones do too -- exactly, not approximately.  cls 1: alpha == 1 on the whole 32x8 strip (shape interior);
-      // cls 2: alpha == 0 (deep inside a stroke): the draw is a no-op for this strip.
-      int cls = 0;
-      if (core) {
-        cls = 1;
-#pragma unroll
-        for (int k = 0; k < 4; k++) dist[k] = -1.0e30f;
-      } else if (!ellip) {
-        const float lxo[2] = {lx[0], lx[3]};
-        float d2[2];
-        shape_distN<2>(false, lxo, -ly, shx, shy, r.r[0], r.r[1], r.r[2], r.r[3], d2);
-        dist[0] = d2[0];
-        dist[3] = d2[1];
-        const float dm = __builtin_fmaxf(d2[0], d2[1]);
-        bool one = false, zero = false;
-        if (op == OP_MASK_PUSH || mode == 3u || mode == 17u) one = __builtin_fmaf(-dm, r.aa, 0.5f) >= 1.0f;
-        else if (mode == 7u) one = dm - spread <= 0.0f;
-        else if (mode == 12u) { const float h = r.f0 * 0.5f; zero = (dm + h < 0.0f) & (__builtin_fmaf(-(-(dm + h) - h), r.aa, 0.5f) <= 0.0f); }
-        if (__all(one)) cls = 1;
-        else if (__all(zero)) cls = 2;
-        if (cls == 1) FDH_COUNT(5);
-        if (cls == 2) FDH_COUNT(6);
-        if (cls == 1 && r.bx0 <= tx0 && r.bx1 >= tx1 && r.by0 <= ty0 && r.by1 >= ty1) FDH_COUNT(7);
-        if (cls == 1) FDH_COUNT(40 + (mode & 15u));
-        if (cls == 2) { if (kShader) deep_nop(rk); return; }
-        if (cls == 0) {
-          const float lxi[2] = {lx[1], lx[2]};
-          shape_distN<2>(false, lxi, -ly, shx, shy, r.r[0], r.r[1], r.r[2], r.r[3], d2);
-          dist[1] = d2[0];
-          dist[2] = d2[1];
-        } else {
-          dist[1] = dist[2] = dm;
-        }
-      } else {
-        shape_distN<4>(true, lx, -ly, shx, shy, r.r[0], r.r[1], r.r[2], r.r[3], dist);
-      }
-
-      if (kMasks && op == OP_MASK_PUSH) {
-        // mask.frag:186-234 drawn through the blender into a cleared R8 plane: stored = q8(a*a), a = shape*parent
-        float mk[4] = {mk0, mk1, mk2, mk3};
-        uint32_t packed = 0;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-          float a = cover_aa(dist[k], r.aa) * col[k].w * mk[k];
-          a = cov[k] ? a : 0.0f;
-          const float q = __builtin_rintf(a * a * 255.0f);
-          packed |= (uint32_t)q << (8 * k);
-          mk[k] = q * inv255;
-        }
-        mk0 = mk[0]; mk1 = mk[1]; mk2 = mk[2]; mk3 = mk[3];
-        stack_put(mask_depth, packed);
-        mask_depth++;
-        return;
-      }
-
-      // ---- OP_DRAW: atlas.frag main():252-405
-      float alpha[4];
-      if (cls == 1) {  // wave-uniform: saturated coverage
-#pragma unroll
-        for (int k = 0; k < 4; k++) alpha[k] = 1.0f;
-      } else switch (mode) {  // wave-uniform
-        case 11u: {
-          const float h = r.f0 * 0.5f;
-#pragma unroll
-          for (int k = 0; k < 4; k++) alpha[k] = (__builtin_fabsf(dist[k] + h) - h) < 0.0f ? 1.0f : 0.0f;
-          break;
-        }
-        case 12u: {
-          const float h = r.f0 * 0.5f;
-#pragma unroll
-          for (int k = 0; k < 4; k++) alpha[k] = cover_aa(__builtin_fabsf(dist[k] + h) - h, r.aa);
-          break;
-        }
-        case 7u: {
-#pragma unroll
-          for (int k = 0; k < 4; k++) alpha[k] = shadow_profile(__builtin_fmaxf(dist[k] - spread, 0.0f), r.f0);  // (= sd > 0 ? min(profile, 1) : 1: edge_blend)
-          break;
-        }
-        case 8u: {
-#pragma unroll
-          for (int k = 0; k < 4; k++) {
-            const float inside = cover_aa(dist[k], r.aa);
-            const float sd = dist[k] - spread;
-            const float sp = __builtin_fminf(shadow_profile(sd, r.f0), 1.0f);
-            alpha[k] = sd >= 0.0f ? sp : inside;
-          }
-          break;
-        }
-        case 9u: {  // atlas.frag:364-380
-          float sx[4], shd[4];
-#pragma unroll
-          for (int k = 0; k < 4; k++) sx[k] = lx[k] - r.p2;
-          shape_distN<4>(ellip, sx, -ly + r.p3, qhx, qhy, r.r[0], r.r[1], r.r[2], r.r[3], shd);
-#pragma unroll
-          for (int k = 0; k < 4; k++) alpha[k] = cover_aa(dist[k], r.aa) * shadow_profile(__builtin_fminf(shd[k] + spread, 0.0f), r.f0);  // (edge_blend)
-          break;
-        }
-        default: {  // ClipAA / BackdropBlur / others: atlas.frag:389-393
-#pragma unroll
-          for (int k = 0; k < 4; k++) alpha[k] = cover_aa(dist[k], r.aa);
-          break;
-        }
-      }
-      float sr[4], sg[4], sb[4], sa[4];
-      if (mode == 17u) {  // atlas.frag:381-388: the blurred backdrop at this fragment's own pixel
-        F4 b[4] = {F0, F1, F2, F3};
-        if (!(om & F_SELF_BACKDROP)) {
-          if (__all(vec_ok)) {  // (wave-uniform on purpose: see )
-            const uint4 q = *reinterpret_cast<const uint4*>(P.backdrop + pix);
-            b[0] = unpack255(q.x); b[1] = unpack255(q.y); b[2] = unpack255(q.z); b[3] = unpack255(q.w);
-          } else {  // a strip on the frame's right or bottom edge: clamped addresses, no branch
-            int here = 0;  // (opaque: keeps the address arithmetic of this rare branch from being hoisted into every strip's prologue)
-            asm volatile("" : "+s"(here));
-            const size_t rowp = (size_t)min(py + here, P.H - 1) * P.pitch;
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-              const F4 t = unpack255(P.backdrop[rowp + min(px0 + k + here, P.W - 1)]);
-              const bool in = row_ok && px0 + k + here < P.W;
-              b[k].x = in ? t.x : b[k].x; b[k].y = in ? t.y : b[k].y; b[k].z = in ? t.z : b[k].z; b[k].w = in ? t.w : b[k].w;
-            }
-          }
-        }
-#pragma unroll
-        for (int k = 0; k < 4; k++) { sr[k] = b[k].x * inv255; sg[k] = b[k].y * inv255; sb[k] = b[k].z * inv255; sa[k] = b[k].w * inv255 * alpha[k]; }
-      } else if (fill_mode == 0u) {
-#pragma unroll
-        for (int k = 0; k < 4; k++) { sr[k] = col[k].x; sg[k] = col[k].y; sb[k] = col[k].z; sa[k] = col[k].w * alpha[k]; }
-      } else {
-        const F4 mc = unpack255(r.mid), sc = unpack255(r.stop);
-        const F4 m01 = {mc.x * inv255, mc.y * inv255, mc.z * inv255, mc.w * inv255}, s01 = {sc.x * inv255, sc.y * inv255, sc.z * inv255, sc.w * inv255};
-        const float mid = __builtin_fminf(__builtin_fmaxf(r.f1, 0.01f), 0.99f);
-        // evalFillColor (atlas.frag:233-250) picks the stop pair (start, mid) or (mid, end) per pixel by t <= mid.  A 32 x 8 strip
-        // nearly always lies on ONE side of the middle stop: then the pair is the same for the whole strip and the eight selects per
-        // pixel (and the select between the two weights) are not needed -- the operands they would have picked are used as they are
-        float tt[4];
-        bool lo_all = true, lo_none = true;
-#pragma unroll
-        for (int k = 0; k < 4; k++) { tt[k] = fill_t(fill_mode, u[k], t); lo_all = lo_all && tt[k] <= mid; lo_none = lo_none && !(tt[k] <= mid); }
-        FDH_COUNT(__all(lo_all) ? 68 : __all(lo_none) ? 69 : 70);
-        if (__all(lo_all)) {
-          const float rw = frcp(mid);
-#pragma unroll
-          for (int k = 0; k < 4; k++) {
-            const float w = tt[k] * rw;
-            sr[k] = mixf(col[k].x, m01.x, w); sg[k] = mixf(col[k].y, m01.y, w); sb[k] = mixf(col[k].z, m01.z, w); sa[k] = mixf(col[k].w, m01.w, w) * alpha[k];
-          }
-        } else if (__all(lo_none)) {
-          const float rw = frcp(1.0f - mid);
-#pragma unroll
-          for (int k = 0; k < 4; k++) {
-            const float w = (tt[k] - mid) * rw;
-            sr[k] = mixf(m01.x, s01.x, w); sg[k] = mixf(m01.y, s01.y, w); sb[k] = mixf(m01.z, s01.z, w); sa[k] = mixf(m01.w, s01.w, w) * alpha[k];
-          }
-        } else {
-#pragma unroll
-          for (int k = 0; k < 4; k++) {
-            const F4 fc = eval_fill_nb(col[k], m01, s01, fill_mode, mid, u[k], t);
-            sr[k] = fc.x; sg[k] = fc.y; sb[k] = fc.z; sa[k] = fc.w * alpha[k];
-          }
-        }
-      }
-      // mask multiply (atlas.frag:401-404), rect mask (atlas_rect_mask.frag:425); outside the quad alpha is forced
-      // to 0: blending with alpha 0 leaves the integer texel exactly as it is
-      // (the masked alphas are formed BEFORE the uniform branch, for both of its sides: as arms of the selects below they became a
-      // divergent branch around two multiplies in the builds with masks -- tools/lint_isa.py)
-      const float am[4] = {sa[0] * mk0 * rm0, sa[1] * mk1 * rm1, sa[2] * mk2 * rm2, sa[3] * mk3 * rm3};
-      FDH_COUNT(all_cov ? 66 : 67);
-      if (kShader) {  // a deep strip's shader: the source term goes into the ring, the blender does what follows (deep_consume)
-        const uint32_t slot = deep_slot(rk);
-        float* v = ring.data + slot * kDeepSlotFloats + lane;
-        if (mode == 17u && (om & F_SELF_BACKDROP) != 0u) {  // the source is the strip's own texel, which only the blender holds: the coverage goes over
-#pragma unroll
-          for (int k = 0; k < 4; k++) { const float a = alpha[k]; v[64 * k] = all_cov ? a : (cov[k] ? a : 0.0f); }
-          deep_publish(slot, rk, DT_SELF17, 0u, 0u, 0u, 0u, 0u);
-          return;
-        }
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-          v[64 * k] = sr[k]; v[64 * (4 + k)] = sg[k]; v[64 * (8 + k)] = sb[k];
-          v[64 * (12 + k)] = all_cov ? am[k] : (cov[k] ? am[k] : 0.0f);
-        }
-        deep_publish(slot, rk, DT_GENERIC, 0u, 0u, 0u, 0u, 0u);
-        return;
-      }
-      if (all_cov) {
-        blend(F0, sr[0], sg[0], sb[0], am[0]); blend(F1, sr[1], sg[1], sb[1], am[1]);
-        blend(F2, sr[2], sg[2], sb[2], am[2]); blend(F3, sr[3], sg[3], sb[3], am[3]);
-        return;
-      }
-      blend(F0, sr[0], sg[0], sb[0], cov[0] ? am[0] : 0.0f);
-      blend(F1, sr[1], sg[1], sb[1], cov[1] ? am[1] : 0.0f);
-      blend(F2, sr[2], sg[2], sb[2], cov[2] ? am[2] : 0.0f);
-      blend(F3, sr[3], sg[3], sb[3], cov[3] ? am[3] : 0.0f);
-    };
-    while (m != 0) {
-      const int bit = __builtin_ctzll(m);
-      const unsigned long long one = 1ull << bit;  // (one shift serves the removal and every class test below)
-      m &= ~one;
-      const uint32_t word = __builtin_amdgcn_readlane(idx, bit);
-      const uint32_t d = word & LE_INDEX;
-#if FDH_TIMING
-      n_all_t++;
-#endif
-      const bool unclipped = !kMasks || (mask_depth == 0 && !rmask_on);
-      if (unclipped && (m_plainc & one) != 0ull) {
-        if (kShader) continue;  // (a deep strip: the blender's own)
-        // One colour, coverage 1, nothing clipping: the whole strip gets the same source term.  Only the colour is
-        // fetched (4 bytes instead of the 128-byte record) and nothing of the record is decoded.
-        // (col[1..3] of such a record hold c / 255 as floats: Context::prepare)
-        u32x4 c4;
-        if (kBlender) {
-          c4 = u32x4{(uint32_t)__builtin_amdgcn_readlane(plain_col.x, bit), (uint32_t)__builtin_amdgcn_readlane(plain_col.y, bit),
-                     (uint32_t)__builtin_amdgcn_readlane(plain_col.z, bit), (uint32_t)__builtin_amdgcn_readlane(plain_col.w, bit)};
-        } else {
-          c4 = *reinterpret_cast<const u32x4*>(draws[d].col);
-          asm volatile("" : "+s"(c4));
-        }
-        const float sa = (float)(c4.x >> 24) * inv255, A = 255.0f * sa, ia = 1.0f - sa;
-        const f2 c_rg = {__uint_as_float(c4.y) * A, __uint_as_float(c4.z) * A}, c_ba = {__uint_as_float(c4.w) * A, A};
-        blend_pre(F0, c_rg, c_ba, ia); blend_pre(F1, c_rg, c_ba, ia); blend_pre(F2, c_rg, c_ba, ia); blend_pre(F3, c_rg, c_ba, ia);
-        touched = true;
-        FDH_COUNT(35);
-        continue;
-      }
-      if (kBlender) {  // a deep strip's blender: every other draw's source term comes out of the ring, in list order
-        touched = true;
-        deep_consume(rank);
-        rank++;
-        continue;
-      }
-      // the path code rides in the list entry: the branch is taken on a value that is already in an SGPR, and the record
-      // is fetched whole, once, behind it
-      const uint32_t code = (word >> LE_PATH_SHIFT) & 15u;
-      if (unclipped && (m_simple & one) != 0ull) {
-        // (a deep strip's shaders take the shading units -- this draw and the run that shares its field -- in turn; the others' are
-        // walked over on the list words alone, counting their source terms)
-        const bool mine = !kShader || unit % 3u == (uint32_t)shader_id;
-        unit++;
-        if (kShader && !mine) {
-          rank++;
-          uint32_t wcur = word, dcur = d;
-          while ((wcur & LE_SHARE) != 0u && m != 0) {
-            const int nb = __builtin_ctzll(m);
-            const uint32_t w2 = __builtin_amdgcn_readlane(idx, nb);
-            const unsigned long long one2 = 1ull << nb;
-            if ((w2 & LE_INDEX) != dcur + 1u || (m_simple & one2) == 0ull || (((w2 >> LE_PATH_SHIFT) & 15u) > 4u) != (code > 4u)) break;
-            m &= ~one2;
-            dcur++;
-            wcur = w2;
-            rank++;
-          }
-          continue;
-        }
-        const DrawRec r = load_rec_whole(draws + d);
-        const uint32_t c4 = (code - 1u) & 3u;
-        const uint32_t mode = c4 == 0u ? 3u : c4 == 1u ? 7u : c4 == 2u ? 9u : 12u;
-        touched = true;
-        FDH_COUNT(48 + code);
-        {
-          const bool ellip = code > 4u;
-          f2 lxa, lxb, da, db;
-          float pyy;
-          edge_geom(r, mode == 9u, ellip, lxa, lxb, pyy, da, db);
-          const bool inq = (m_inq & one) != 0ull;
-          edge_blend(r, mode, ellip, inq, r.p2, r.p3, r.f0, r.f1, u32x4{r.col[0], r.col[1], r.col[2], r.col[3]}, lxa, lxb, pyy, da, db, F0, F1, F2, F3, rank);
-          rank++;
-          // The draws that follow over the same quad and shape (the node's stroke, its inner shadows: LE_SHARE on the entry of
-          // the draw before them) reuse the field: their entries are taken off the list here.  All conditions are wave-uniform.
-          uint32_t wcur = word, dcur = d;
-          while ((wcur & LE_SHARE) != 0u && m != 0) {
-            const int nb = __builtin_ctzll(m);
-            const uint32_t w2 = __builtin_amdgcn_readlane(idx, nb);
-            const uint32_t code2 = (w2 >> LE_PATH_SHIFT) & 15u;
-            const unsigned long long one2 = 1ull << nb;
-            if ((w2 & LE_INDEX) != dcur + 1u || (m_simple & one2) == 0ull || (code2 > 4u) != ellip) break;
-            m &= ~one2;
-            dcur++;
-            wcur = w2;
-            // the member's own parameters: sdfParams.zw + sdfFactors (16 bytes at offset 32) and its colour (offset 64)
-            const u32x4* __restrict__ mp = reinterpret_cast<const u32x4*>(draws + dcur);
-            u32x4 q = mp[2];
-            u32x4 mcol = mp[4];
-            asm volatile("" : "+s"(q), "+s"(mcol));
-            const uint32_t c42 = (code2 - 1u) & 3u;
-            const uint32_t mode2 = c42 == 0u ? 3u : c42 == 1u ? 7u : c42 == 2u ? 9u : 12u;
-            FDH_COUNT(57);
-            edge_blend(r, mode2, ellip, (m_inq & one2) != 0ull, __uint_as_float(q.x), __uint_as_float(q.y), __uint_as_float(q.z), __uint_as_float(q.w), mcol, lxa, lxb, pyy, da, db, F0, F1, F2, F3, rank);
-            rank++;
-          }
-        }
-        continue;
-      }
-      if (kShader) {  // (a unit of one draw)
-        const bool mine = unit % 3u == (uint32_t)shader_id;
-        unit++;
-        if (!mine) { rank++; continue; }
-      }
-      const DrawRec r = load_rec_whole(draws + d);
-      const bool core = (m_core & one) != 0ull;
-#if FDH_TIMING
-      const unsigned long long Ts0 = FDH_NOW() + (r.op_mode & 0u);
-#endif
-      shade(d, r, core, (m_inq & one) != 0ull, rank);
-      rank++;
-#if FDH_TIMING
-      {
-        const unsigned long long Ts1 = FDH_NOW() + (__builtin_amdgcn_readfirstlane(__float_as_uint(F0.x + F1.x + F2.x + F3.x)) & 0u);
-        const uint32_t md = r.op_mode & 255u;
-        const int slot = md == 3u ? 0 : md == 7u ? 1 : md == 9u ? 2 : 3;
-        if (!core) { T_mode[slot] += Ts1 - Ts0; N_mode[slot]++; }
-        T_shade += Ts1 - Ts0; n_draws_t++;
-      }
-#endif
-    }
-  }
-#if FDH_TIMING
-  if (lane == 0 && blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6) < 65536) {  // (one row per wave: the four of a k_composite_deep workgroup side by side)
-    const unsigned long long T1 = FDH_NOW();
-    unsigned long long* row = g_wave_times + 16 * ((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
-    row[0] = T1 - T0; row[1] = W0 + (T_cnt & 0ull); row[2] = wall_clock64() + (T_cull & 0ull);  // (wall clock, 100 MHz, one counter for the device: tools/wave_timeline.py)
-    row[3] = T_rec; row[4] = T_shade; row[5] = n_all_t; row[6] = 1 + kRole; row[7] = T_cull_core * 1024 + n_core_t;  // (row[5]: list entries walked; row[6]: 1 a strip's one wave, 2 a deep strip's blender, 3 one of its shaders)
-    for (int i = 0; i < 4; i++) { row[8 + i] = T_mode[i]; row[12 + i] = N_mode[i]; }
-  }
-#endif
-  // The store address is derived again from an (opaque) lane index: kept from the prologue it held three VGPRs across
-  // the whole draw loop, the three that stood between the no-clip build and six waves per SIMD.
-  if (kShader) return;  // (a deep strip's shaders hold no texels)
-  int lane_e = threadIdx.x & 63;
-  asm volatile("" : "+v"(lane_e));
-  const int px0e = tx0 + (lane_e & 7) * 4, pye = ty0 + (lane_e >> 3);
-  if (!(touched || kFull || !P.load_fb) || pye < P.row_lo || pye >= P.row_hi) return;
-  const bool row_ok_e = pye < P.H;
-  const size_t pixe = (size_t)pye * P.pitch + px0e;
-  if (row_ok_e && px0e + 3 < P.W && (P.pitch & 3) == 0) {
-    // (a strip of the launch that starts the frame on which nothing landed -- wave-uniform -- is the clear colour as it is: no packing)
-    uint4 o = {P.clear_rgba8, P.clear_rgba8, P.clear_rgba8, P.clear_rgba8};
-    if (!kFull || touched) o = uint4{pack255(F0), pack255(F1), pack255(F2), pack255(F3)};
-    *reinterpret_cast<uint4*>(P.fb + pixe) = o;
-  } else if (row_ok_e) {
-    if (px0e + 0 < P.W) P.fb[pixe + 0] = pack255(F0);
-    if (px0e + 1 < P.W) P.fb[pixe + 1] = pack255(F1);
-    if (px0e + 2 < P.W) P.fb[pixe + 2] = pack255(F2);
-    if (px0e + 3 < P.W) P.fb[pixe + 3] = pack255(F3);
-  }
+#include "k_composite_strip.inc"
 }
 
 #if FDH_TU == 0
