@@ -555,7 +555,7 @@ def main():
             for c in ctxs:
                 c.set_walk_threads(pool_n)
             fn = make_run(cand)
-            fn(args.warmup)
+            fn(max(args.warmup, args.steps))  # (a whole batch untimed first: a candidate's first batches carry its one-offs -- pool threads' first wake-up, staging growth)
             # (five batches: with two, one late wake-up of a pool thread in both 1.3-ms batches of the driver's command once put the
             # run on the slowest candidate -- 116.7 Gpixel/s where the runs before and after it measured 134 - 139.  And their MEDIAN,
             # round 5: a thread per context has the occasional fast batch and a slow typical one -- its best of five beat the single
@@ -567,6 +567,20 @@ def main():
         best = min(calibration, key=lambda k: calibration[k])
         if calibration[best] > 0.98 * calibration[default_key]:
             best = default_key
+        if best != default_key:
+            # a second opinion before leaving the library's default (round 6: one driver-style run measured the default at 4.7 ms per batch
+            # in calibration -- three of its five batches hit by something on the shared host --, took a thread per context and ran at
+            # 146 Gpixel/s where the runs beside it, on the default, read 160 - 163): the default is measured again, and so is the winner
+            for key, (cand, pool_n) in (("1", (1, pool_default)), (best, (int(best.split(",")[0]), 0 if "off" in best else pool_default))):
+                for c in ctxs:
+                    c.set_walk_threads(pool_n)
+                fn = make_run(cand)
+                fn(args.steps)
+                again = sorted(timed(fn, args.steps) for _ in range(5))[2]
+                calibration[key + ", second run"] = round(1e3 * again, 4)
+                calibration[key] = min(calibration[key], round(1e3 * again, 4))
+            if calibration[best] > 0.98 * calibration[default_key]:
+                best = default_key
         T = int(best.split(",")[0])
         pool = 0 if "off" in best else pool_default
     for c in ctxs:
