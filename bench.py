@@ -540,7 +540,7 @@ def main():
     # ... and who walks the trees: the calling thread with the library's walk pool beside it (fdh_set_walk_threads, the default) or
     # the calling thread alone.  The bench frame is GPU-bound either way (host 25 - 30 us against 51 us per frame, GPU ~57): what
     # differs is how the four contexts' kernels interleave -- a host that is only just faster than the GPU keeps the queues short
-    # and the frames staggered -- so the calibration tries both and says which it took (`walk_pool_threads`).
+    # and the frames staggered (docs/HISTORY.md section 4a) -- so the calibration tries both and says which it took (`walk_pool_threads`).
     calibration = None
     pool_default = ctx.walk_stats()[0]
     pool = pool_default
