@@ -109,6 +109,11 @@ size_t vram_store_bytes(int device) {
   for (int k = 0; k < 48; k++) b += g_vram_free[device][k].size() << k;
   return b;
 }
+int vram_contexts_alive(int device) {
+  if (device < 0 || device >= kMaxDevices) return 0;
+  std::lock_guard<std::mutex> lk(g_vram_mu);
+  return g_vram_contexts[device];
+}
 void vram_context_born(int device) {
   if (device < 0 || device >= kMaxDevices) return;
   std::lock_guard<std::mutex> lk(g_vram_mu);
@@ -1258,7 +1263,12 @@ void Context::launch_frame(const LaunchJob& J, bool profile, uint32_t upload_seq
   // Quarter strips for the frame's longest lists (k_composite_tiles, round 6): the sorting waves of earlier full-frame launches left, per
   // class of bins, how many hold at least deep_min draws; that many leading positions of the order (x 8 classes) get four waves per
   // strip.  Whatever value is there serves -- a frame or two stale, 0 before the first launch has run: any count is a correct schedule.
-  static const int deep_min = [] { const char* e = std::getenv("FDH_DEEP_MIN"); return e ? std::atoi(e) : kDeepMinDefault; }();
+  // The threshold goes by who else renders: a deep strip holds four wave slots and its waves mostly wait, which is what a frame that has
+  // the GPU to itself wants (the launch is its longest strips' chain) and what frames of OTHER contexts pay for.  Bench tree through
+  // fdh_render_frame (profiles/r06_deep_in_flight.txt): one context, 1080p, 49.7 us per frame without deep strips, 46.6 with bins of >= 24
+  // draws, 46.4 with >= 40; four contexts in flight 30.3 / 31.1 / 28.9 us -- so 24 for a device's only context, 40 beside others.
+  static const int deep_env = [] { const char* e = std::getenv("FDH_DEEP_MIN"); return e ? std::atoi(e) : -1; }();
+  const int deep_min = deep_env >= 0 ? deep_env : (vram_contexts_alive(device_) > 1 ? kDeepMinInFlight : kDeepMinDefault);
   int deep_k8 = 0;
   if (sorting && deep_min > 0) {
     if (!deep_host_) {

@@ -104,6 +104,7 @@ bool vram_staging(int device);  // large-BAR device and FDH_VRAM_STAGING != 0, d
 void* vram_block_acquire(int device, size_t bytes, size_t* size_class);  // throws Error on failure
 void vram_block_release(int device, void* p, size_t size_class);
 size_t vram_store_bytes(int device);   // bytes the store of a device holds (released blocks)
+int vram_contexts_alive(int device);   // device contexts alive on `device` (the deep strips' threshold goes by it: Context::launch_frame)
 void vram_context_born(int device);    // a device context exists on `device` ...
 void vram_context_gone(int device);    // ... and is gone: with the last one, the device's store is trimmed to kVramStoreKeep
 constexpr size_t kVramStoreKeep = (size_t)16 << 20;

@@ -27,6 +27,7 @@ constexpr int kMaskDepth = 16;                             // per-lane clip stac
 // a bin whose list holds at least this many draws gets quarter-strip waves in the next frames' full-frame launch (k_composite_tiles;
 // FDH_DEEP_MIN overrides, 0 turns the quarter strips off)
 constexpr int kDeepMinDefault = 24;
+constexpr int kDeepMinInFlight = 40;      // ... when the device has other contexts (frames in flight beside this one's): fdh_context.cpp
 constexpr int kDeepStripMinDefault = 16;  // ... and of such a bin's strips, those with at least this many draws to shade (FDH_DEEP_STRIP_MIN)
 constexpr int kMaxMips = 14;
 constexpr int kMaxBlurTaps = 36;
