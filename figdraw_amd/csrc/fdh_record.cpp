@@ -476,7 +476,13 @@ bool Recorder::emit_corners(DrawRec& r, const QuadPx& q, bool count_fragments) {
   // A draw that reaches no pixel the frame will produce leaves no trace (it would never be binned).  Clip pushes stay: their
   // bounds grow to their content's, and a push that is not there would let that content through.
   const bool cullable = ((r.op_mode >> 12) & 15u) == OP_DRAW && culling();
-  if (!q.finite) {
+  // The same for a draw with a NaN or an infinity among its shader parameters (half extents, factors, radii / uv rect, AA factor,
+  // sub-pixel shift, LOD): the kernels are compiled with -fno-honor-nans (csrc/Makefile) on the guarantee that no such value reaches
+  // them, and this is where it is kept -- the reference's shader would produce NaN alphas there, i.e. no defined pixel either.
+  const float fields[] = {r.p0, r.p1, r.p2, r.p3, r.f0, r.f1, r.r[0], r.r[1], r.r[2], r.r[3], r.aa, r.aux, r.aux2};
+  bool params_finite = true;
+  for (const float v : fields) params_finite = params_finite && std::isfinite(v);
+  if (!q.finite || !params_finite) {
     if (cullable) { FDH_CULLED(); return false; }
     r.bx0 = r.by0 = r.bx1 = r.by1 = 0; push_rec(b); return true;
   }

@@ -406,10 +406,52 @@ SWIFTSHADER_SCENES = {
 #     no rule reproduces it and another conformant rasteriser need not agree.  Counted: 26 measured, 28 allowed.
 #   curves: sdBezier's closed-form cubic cancels catastrophically at isolated pixels ("Rotated quads and
 #     curves"): two conformant evaluations of it differ there by anything.
+# (allowances = twice what is measured, not measured + 2: the counts hang on the last bit of float code that another compiler or ROCm
+# release may generate differently -- ADVICE r5 --; what must NOT move is where the outliers are, and the rotated scene's test asserts
+# that: every one within 0.004 px of a quad edge)
 OUTLIER_SCENES = {
-    "rotated_tree": (rotated_tree, 900, 600, 28),  # 26 measured (oracle and HIP alike)
-    "curves": (curves, 640, 420, 3),               # 1 measured
+    "rotated_tree": (rotated_tree, 900, 600, 52),  # 26 measured (oracle and HIP alike)
+    "curves": (curves, 640, 420, 8),               # 1 measured
 }
+
+
+def quads_of_call_stream(calls):
+    """the pixel-grid quads (ceil'd vertices, glcontext.nim:1498-1509) of every draw_rounded_rect_sdf of a recorded BackendContext call stream,
+    under its translate / rotate / scale calls (vmath's rotateZ: x' = cos x + sin y, y' = -sin x + cos y -- the convention
+    tests/expected/render_line_rect.png pins)"""
+    import math
+
+    import numpy as np
+
+    M, stack, out = np.eye(3), [], []
+    for c in calls:
+        if c[0] == "save_transform":
+            stack.append(M.copy())
+        elif c[0] == "restore_transform":
+            M = stack.pop()
+        elif c[0] == "translate":
+            M = M @ np.array([[1, 0, c[1]], [0, 1, c[2]], [0, 0, 1.0]])
+        elif c[0] == "scale":
+            M = M @ np.diag([c[1], c[2] if len(c) > 2 and c[2] is not None else c[1], 1.0])
+        elif c[0] == "rotate":
+            cs, sn = math.cos(c[1]), math.sin(c[1])
+            M = M @ np.array([[cs, sn, 0], [-sn, cs, 0], [0, 0, 1.0]])
+        elif c[0] == "draw_rounded_rect_sdf":
+            x, y, rw, rh = c[1]
+            out.append([tuple(np.ceil((M @ np.array([px, py, 1.0]))[:2])) for px, py in ((x, y + rh), (x + rw, y + rh), (x + rw, y), (x, y))])
+    return out
+
+
+def worst_distance_to_a_quad_edge(pixels, quads):
+    """the largest, over the given (x, y) pixels, of the distance from the pixel's centre to the nearest edge of any quad"""
+    import numpy as np
+
+    def seg(p, a, b):
+        p, a, b = np.array(p), np.array(a), np.array(b)
+        ab = b - a
+        t = np.clip(np.dot(p - a, ab) / max(float(np.dot(ab, ab)), 1e-9), 0.0, 1.0)
+        return float(np.linalg.norm(p - (a + t * ab)))
+    return max((min(seg((x + 0.5, y + 0.5), q[i], q[(i + 1) % 4]) for q in quads for i in range(4)) for x, y in pixels), default=0.0)
 
 
 # ----------------------------------------------------------------------- atlas scenes (need images: see ATLAS_SCENES)

@@ -61,8 +61,21 @@ def test_oracle_matches_reference_shaders_but_for_counted_pixels(name):
     roots of the bezier cubic"""
     fn, w, h, allowed = RS.OUTLIER_SCENES[name]
     img = _render(fn, w, h)
-    mx, n0, n1 = diff_stats(img, load_png(f"ss_{name}.png"))
+    gold = load_png(f"ss_{name}.png")
+    mx, n0, n1 = diff_stats(img, gold)
     assert n1 <= allowed and n0 <= 0.005 * w * h, (name, mx, n0, n1)
+    if name == "rotated_tree":
+        # the property that must not move with a compiler or a ROCm release, whatever the count does: every counted pixel's centre lies ON an
+        # edge of a rotated quad (0.02 px in this float64 restatement of the transforms; 0.004 px with the rasteriser's own vertices)
+        from figdraw_amd.context import HipContext
+
+        ctx = HipContext(record_only=True)
+        ctx.record_begin()
+        ctx.render_frame(fn(float(w), float(h)), w, h)
+        quads = RS.quads_of_call_stream(ctx.record_calls())
+        ctx.close()
+        ys, xs = np.nonzero(np.abs(img.astype(int) - gold.astype(int)).max(axis=2) > 1)
+        assert RS.worst_distance_to_a_quad_edge(zip(xs, ys), quads) < 0.05
 
 
 def test_reference_point_checks():
