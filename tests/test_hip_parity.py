@@ -209,7 +209,8 @@ def test_direct_launches_give_the_same_pixels():
             res[tag] = dict(np.load(path))
             binms[tag] = eval([ln for ln in r.stdout.splitlines() if ln.startswith("BINMS ")][-1][6:])
     assert all(v > 0 for v in binms["bin"].values()), binms
-    assert binms["direct"]["rgb_boxes_sdf"] == 0 and binms["direct"]["nested_clips"] == 0 and binms["direct"]["tree8"] == 0, binms   # no bin launch
+    if os.environ.get("FDH_FORCE_KERNEL_PATHS") not in ("3", "8"):  # (tools/suite_off_defaults.sh: the slot / rotated builds have no direct form)
+        assert binms["direct"]["rgb_boxes_sdf"] == 0 and binms["direct"]["nested_clips"] == 0 and binms["direct"]["tree8"] == 0, binms   # no bin launch
     assert binms["direct"]["tree40"] > 0, binms  # (283 draws in its first phase: over the limit)
     for k in res["bin"]:
         assert np.array_equal(res["bin"][k], res["direct"][k]), (k, int((res["bin"][k] != res["direct"][k]).any(axis=2).sum()))
