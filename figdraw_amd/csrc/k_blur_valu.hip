@@ -197,18 +197,30 @@ __global__ __launch_bounds__(64 * kVWaves) void k_blur_v(BlurParams P, const Dra
 
 // ------------------------------------------------------------------ a small region: both passes in one kernel
 // A 360 x 240 backdrop (the demo's own blur node) took two launches of 5 + 7 us -- latency, not work: < 1 % of the HBM peak -- and
-// a third for the composite behind them.  Here a workgroup produces a 32 x 16 tile of the BLURRED SNAPSHOT: it stages the tile's
-// (32 + 2 reach) x (16 + 2 reach) source window in LDS (clamp-to-edge), filters its 16 + 2 reach rows horizontally into LDS --
+// a third for the composite behind them.  Here a workgroup produces a kSmallTW x kSmallTH tile of the BLURRED SNAPSHOT: it stages the tile's
+// (TW + 2 reach) x (TH + 2 reach) source window in LDS (clamp-to-edge), filters its TH + 2 reach rows horizontally into LDS --
 // rounded to RGBA8 exactly as the horizontal pass stores its intermediate texture (glcontext.nim:1743-1786) -- and filters
 // those vertically.  Same per-output sums in the same order as k_blur_h<2> / k_blur_v<2, .> (fir_outputs<2>): the snapshot is
 // the two-pass one bit for bit.  It goes to the backdrop surface, out of place (a tile's neighbours still read the live surface
 // around it), and the phase's compositor launch samples it for the mode-17 quad like any other draw.
-// 1024 threads per workgroup: the tile's 832 horizontal tasks (radius 18) are ONE fir_outputs per thread and its 256 vertical
-// tasks one more -- with 256 threads a thread ran 3.25 + 1 of them back to back, each a chain of 38 dependent LDS reads (15 us
+// 1024 threads per workgroup: the tile's horizontal tasks (radius 18: 832 for the first, 32 x 16 tile) are ONE fir_outputs per thread and
+// its vertical tasks one more -- with 256 threads a thread ran 3.25 + 1 of them back to back, each a chain of 38 dependent LDS reads (15 us
 // for the 360 x 240 node against 5 + 7 for the two launches).
-constexpr int kSmallTW = 32, kSmallTH = 16, kSmallThreads = 1024;
+// The tile is 16 x 24 (round 6; 32 x 16 before).  Wall clocks of every wave (tools/small_blur_times.py) put the kernel's 7.9 us at 2.0 us
+// until the window is in LDS, then 5.5 us of ONE CU's arithmetic per tile: 832 horizontal tasks of ~560 instructions (a 16-row tile
+// filters 16 + 2 reach = 54 rows: 3.4 x what it keeps) on sixteen waves, then 256 vertical ones.  At 16 x 24 a tile has 496 horizontal
+// tasks (eight waves, two per SIMD) for 384 outputs, the 360 x 240 node is 230 tiles for 256 CUs, and the window's rows are at most 64
+// texels wide, so a wave stages a row with a lane per column (no division on the way to the first load: -0.7 us).  Same sums per output:
+// the frames of every shape tried are equal bit for bit.  Measured (rocprofv3, 300 bench frames, same box): 32 x 16 7.91 us, 16 x 32 7.42,
+// 12 x 32 7.10, 16 x 24 7.05 -- with four horizontal outputs per thread 7.44 --, 16 x 24 staged by rows 6.24, that with one vertical
+// output per thread 6.27 - 6.57.
+constexpr int kSmallTW = 16, kSmallTH = 24, kSmallHOut = 2, kSmallVOut = 2, kSmallThreads = 1024;
 __global__ __launch_bounds__(kSmallThreads) void k_blur_small(BlurParams P) {
   extern __shared__ uint32_t small_lds[];
+#if FDH_TIMING  // tools/small_blur_times.py: wall clocks of every wave (100 MHz, one counter for the device)
+  const unsigned long long W_in = wall_clock64();
+  unsigned long long W_asked = 0, W_staged = 0, W_h = 0, W_hb = 0, W_v = 0;
+#endif
   const int reach = P.taps.reach;
   const int in_w = kSmallTW + 2 * reach, rows = kSmallTH + 2 * reach;
   uint32_t* in = small_lds;                    // [rows][in_w]
@@ -222,42 +234,86 @@ __global__ __launch_bounds__(kSmallThreads) void k_blur_small(BlurParams P) {
   constexpr int kSmallStage = 5;
   const int n_in = rows * in_w;
   uint32_t texel[kSmallStage];
-#pragma unroll
-  for (int k = 0; k < kSmallStage; k++) {
-    const int i = min((int)threadIdx.x + k * kSmallThreads, n_in - 1);
-    const int rr = i / in_w, cc = i - rr * in_w;
-    int y = ys - reach + rr, x = xs - reach + cc;
-    y = y < 0 ? 0 : (y > P.H - 1 ? P.H - 1 : y);  // clamp-to-edge (glcontext.nim:214-215)
+  // (a window row of at most 64 texels -- every filter the 16-wide tile takes: a wave per row, a lane per column, no division by the
+  // window's width on the way to the first load; the general form below spent 1.0 of the kernel's 7 us before its loads were out)
+  const bool by_rows = in_w <= 64 && rows <= kSmallStage * (kSmallThreads / 64);
+  if (by_rows) {
+    const int wv = (int)threadIdx.x >> 6, ln = (int)threadIdx.x & 63;
+    int x = xs - reach + min(ln, in_w - 1);
     x = x < 0 ? 0 : (x > P.W - 1 ? P.W - 1 : x);
-    texel[k] = P.src[(size_t)y * P.pitch + x];
-  }
 #pragma unroll
-  for (int k = 0; k < kSmallStage; k++) {
-    const int i = (int)threadIdx.x + k * kSmallThreads;
-    if (i < n_in) in[i] = texel[k];
+    for (int k = 0; k < kSmallStage; k++) {
+      int y = ys - reach + min(wv + k * (kSmallThreads / 64), rows - 1);
+      y = y < 0 ? 0 : (y > P.H - 1 ? P.H - 1 : y);  // clamp-to-edge (glcontext.nim:214-215)
+      texel[k] = P.src[(size_t)y * P.pitch + x];
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < kSmallStage; k++) {
+      const int i = min((int)threadIdx.x + k * kSmallThreads, n_in - 1);
+      const int rr = i / in_w, cc = i - rr * in_w;
+      int y = ys - reach + rr, x = xs - reach + cc;
+      y = y < 0 ? 0 : (y > P.H - 1 ? P.H - 1 : y);  // clamp-to-edge (glcontext.nim:214-215)
+      x = x < 0 ? 0 : (x > P.W - 1 ? P.W - 1 : x);
+      texel[k] = P.src[(size_t)y * P.pitch + x];
+    }
+  }
+#if FDH_TIMING
+  W_asked = wall_clock64();
+#endif
+  if (by_rows) {
+    const int wv = (int)threadIdx.x >> 6, ln = (int)threadIdx.x & 63;
+#pragma unroll
+    for (int k = 0; k < kSmallStage; k++) {
+      const int rr = wv + k * (kSmallThreads / 64);
+      if (ln < in_w && rr < rows) in[rr * in_w + ln] = texel[k];
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < kSmallStage; k++) {
+      const int i = (int)threadIdx.x + k * kSmallThreads;
+      if (i < n_in) in[i] = texel[k];
+    }
   }
   __syncthreads();
+#if FDH_TIMING
+  W_staged = wall_clock64();
+#endif
   // horizontal: a thread produces two consecutive outputs of one row
-  for (int t = threadIdx.x; t < rows * (kSmallTW / 2); t += kSmallThreads) {
-    const int rr = t / (kSmallTW / 2), c = t - rr * (kSmallTW / 2);
-    f2 rg[2], ba[2];
-    const uint32_t* __restrict__ win = in + rr * in_w + 2 * c;
-    fir_outputs<2, 6>(P.taps.dense, reach, [&](int j) { return win[j]; }, rg, ba);
-    hres[rr * kSmallTW + 2 * c] = pack2(rg[0], ba[0]);
-    hres[rr * kSmallTW + 2 * c + 1] = pack2(rg[1], ba[1]);
+  for (int t = threadIdx.x; t < rows * (kSmallTW / kSmallHOut); t += kSmallThreads) {
+    const int rr = t / (kSmallTW / kSmallHOut), c = t - rr * (kSmallTW / kSmallHOut);
+    f2 rg[kSmallHOut], ba[kSmallHOut];
+    const uint32_t* __restrict__ win = in + rr * in_w + kSmallHOut * c;
+    fir_outputs<kSmallHOut, 6>(P.taps.dense, reach, [&](int j) { return win[j]; }, rg, ba);
+#pragma unroll
+    for (int o = 0; o < kSmallHOut; o++) hres[rr * kSmallTW + kSmallHOut * c + o] = pack2(rg[o], ba[o]);
   }
+#if FDH_TIMING
+  W_h = wall_clock64();
+#endif
   __syncthreads();
-  // vertical: a thread produces two consecutive rows of one column
-  for (int t = threadIdx.x; t < kSmallTW * (kSmallTH / 2); t += kSmallThreads) {
+#if FDH_TIMING
+  W_hb = wall_clock64();
+#endif
+  // vertical: a thread produces kSmallVOut consecutive rows of one column
+  for (int t = threadIdx.x; t < kSmallTW * (kSmallTH / kSmallVOut); t += kSmallThreads) {
     const int pr = t / kSmallTW, c = t - pr * kSmallTW;
-    const int x = xs + c, y = ys + 2 * pr;
+    const int x = xs + c, y = ys + kSmallVOut * pr;
     if (x >= P.x1 || y >= P.y1) continue;
-    f2 rg[2], ba[2];
-    const uint32_t* __restrict__ col = hres + (2 * pr) * kSmallTW + c;
-    fir_outputs<2, 6>(P.taps.dense, reach, [&](int j) { return col[j * kSmallTW]; }, rg, ba);
-    P.dst[(size_t)y * P.pitch + x] = pack2(rg[0], ba[0]);
-    if (y + 1 < P.y1) P.dst[(size_t)(y + 1) * P.pitch + x] = pack2(rg[1], ba[1]);
+    f2 rg[kSmallVOut], ba[kSmallVOut];
+    const uint32_t* __restrict__ col = hres + (kSmallVOut * pr) * kSmallTW + c;
+    fir_outputs<kSmallVOut, 6>(P.taps.dense, reach, [&](int j) { return col[j * kSmallTW]; }, rg, ba);
+#pragma unroll
+    for (int o = 0; o < kSmallVOut; o++)
+      if (y + o < P.y1) P.dst[(size_t)(y + o) * P.pitch + x] = pack2(rg[o], ba[o]);
   }
+#if FDH_TIMING
+  W_v = wall_clock64();
+  if ((threadIdx.x & 63) == 0 && blockIdx.x < 2048) {
+    unsigned long long* row = g_wave_times + 16 * ((size_t)blockIdx.x * 16 + (threadIdx.x >> 6));
+    row[1] = W_in; row[2] = W_asked; row[3] = W_staged; row[4] = W_h; row[5] = W_hb; row[7] = W_v; row[6] = 8;
+  }
+#endif
 }
 
 // small regions: fewer outputs per thread -> more, shorter waves (see NOUT above)
