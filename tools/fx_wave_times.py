@@ -8,7 +8,10 @@ from figdraw_amd import context as ctx_mod
 from figdraw_amd.scenes import make_render_tree_100
 w, h = 3840, 2160
 ctx = ctx_mod.HipContext(device=0); L = ctx_mod.load()
-ctx.render_frame(make_render_tree_100(w, h, frame=0, full_frame_blur=True), w, h); ctx.sync()
+tree = make_render_tree_100(w, h, frame=0, full_frame_blur=True)
+lst = tree.layers[0]  # (without the small blur node and its panel: the launches behind k_blur_fx write their own rows over its)
+lst.nodes = lst.nodes[:-2]; lst.rootIds = list(range(len(lst.nodes)))
+ctx.render_frame(tree, w, h); ctx.sync()
 wt = np.zeros((65536, 16), dtype=np.uint64)
 L.fdh_debug_wave_times(wt.ctypes.data_as(C.c_void_p))  # (reading clears the rows)
 ctx.replay(1); ctx.sync()
