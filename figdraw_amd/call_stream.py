@@ -86,18 +86,22 @@ def pack(calls) -> np.ndarray:
 
 
 def build_player(force: bool = False) -> str:
-    """gcc -std=c99 the C driver against the installed header and library (a few hundred ms)"""
+    """gcc -std=c99 the C driver against the installed header and library (a few hundred ms).  With FIGDRAW_HIP_LIB set (a variant library:
+    A/B runs, instrumented builds) the player is linked against THAT file, under a name of its own -- linked against the product beside a
+    variant's contexts, two libraries with two layouts met in one process."""
     from . import context
 
-    if not force and os.path.exists(PLAYER_LIB) and os.path.getmtime(PLAYER_LIB) >= max(os.path.getmtime(PLAYER_SRC), os.path.getmtime(context.LIB_PATH)):
-        return PLAYER_LIB
-    os.makedirs(os.path.dirname(PLAYER_LIB), exist_ok=True)
-    tmp = f"{PLAYER_LIB}.{os.getpid()}.tmp"  # (several ranks may find it stale at once: each links its own file, the rename is atomic)
+    lib = os.path.abspath(os.environ.get("FIGDRAW_HIP_LIB", context.LIB_PATH))
+    out = PLAYER_LIB if lib == os.path.abspath(context.LIB_PATH) else PLAYER_LIB[:-3] + "_" + os.path.basename(lib)[:-3].replace("libfigdraw_hip_", "") + ".so"
+    if not force and os.path.exists(out) and os.path.getmtime(out) >= max(os.path.getmtime(PLAYER_SRC), os.path.getmtime(lib)):
+        return out
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    tmp = f"{out}.{os.getpid()}.tmp"  # (several ranks may find it stale at once: each links its own file, the rename is atomic)
     subprocess.check_call(["gcc", "-std=c99", "-O2", "-Wall", "-Wextra", "-Werror", "-pedantic", "-D_POSIX_C_SOURCE=200112L", "-pthread", "-fPIC", "-shared",
                            "-I", os.path.join(ROOT, "include"), PLAYER_SRC, "-o", tmp,
-                           "-L", _HERE, "-l:libfigdraw_hip.so", "-Wl,-rpath," + _HERE])
-    os.replace(tmp, PLAYER_LIB)
-    return PLAYER_LIB
+                           "-L", os.path.dirname(lib), "-l:" + os.path.basename(lib), "-Wl,-rpath," + os.path.dirname(lib)])
+    os.replace(tmp, out)
+    return out
 
 
 class Player:

@@ -1135,13 +1135,13 @@ int Context::walk_threads() const { return walk_threads_ >= 0 ? walk_threads_ : 
 // A frame every phase of which holds at most 64 draws, none of them a rotated quad or a curve (their entries need the bin kernel's
 // per-strip tests): no bin launch, the compositor's waves make their entries themselves (k_composite_tiles, "direct").  FDH_DIRECT=0: never.
 static bool direct_frame(const LaunchJob& J) {
-  // (FDH_FORCE_KERNEL_PATHS=3 / 8, the test hook that puts a frame on the builds with the slot path / the rotated-quad path: those two
+  // (FDH_FORCE_KERNEL_PATHS=3 / 19 / 8, the test hook that puts a frame on the builds with the slot path / the rotated-quad path: those
   // have no direct form)
   static const bool on = [] {
     const char* e = std::getenv("FDH_DIRECT");
     const char* f = std::getenv("FDH_FORCE_KERNEL_PATHS");
     const int forced = f ? std::atoi(f) : 0;
-    return (!e || std::atoi(e) != 0) && forced != 3 && forced != 8;
+    return (!e || std::atoi(e) != 0) && forced != 3 && forced != 8 && forced != 19;
   }();
   if (!on || J.phases.empty()) return false;
   for (const Phase& ph : J.phases)
@@ -1365,6 +1365,7 @@ void Context::launch_frame(const LaunchJob& J, bool profile, uint32_t upload_seq
     C.deep_strip_min = deep_strip_min;
     C.deep_out = (full && order_next && deep_min > 0) ? const_cast<uint32_t*>(deep_host_) : nullptr;
     C.has_slow = ph.has_slow ? 1 : 0;
+    C.has_slow_atlas = ph.has_slow_atlas ? 1 : 0;
     C.has_rot = ph.has_rot ? 1 : 0;
     C.has_atlas = ph.has_atlas ? 1 : 0;
     C.has_masks = ph.has_masks ? 1 : 0;

@@ -182,6 +182,7 @@ struct Phase {
   bool has_masks = false; // clip / rect-mask ops present
   bool has_atlas = false; // axis-aligned atlas quads at >= 1:1 present (k_composite_tiles<2> unless has_slow)
   bool has_slow = false;  // some draw needs k_composite_tiles<true> (atlas / rotated quad / bezier / rect-mask setup)
+  bool has_slow_atlas = false;  // ... and one of them is an atlas quad off the 4-wide path (rotated, or minified over mip levels): the 168-register form of that build
   bool has_rot = false;   // rotated / skewed SDF quads whose edge functions fit 32 bits (F_EDGE32): the 4-wide path of builds <8> and <3>
 };
 struct BlurJob {
@@ -235,7 +236,7 @@ struct Lane {
 // what a run of records adds to its phase (kept per parallel chunk by the walk pool's threads, merged by the calling thread)
 struct PhaseSum {
   BBox u{0, 0, 0, 0};  // union of the records' final bounds
-  bool has_masks = false, has_atlas = false, has_slow = false, has_rot = false;
+  bool has_masks = false, has_atlas = false, has_slow = false, has_rot = false, has_slow_atlas = false;
   int deepest = 0;     // deepest clip nesting reached, relative to the run's start
   int64_t frag_mode[4] = {0, 0, 0, 0}, frag_ellip = 0, frag_other = 0;  // covered fragments by SdfMode 3 / 7 / 9 / 12
 };

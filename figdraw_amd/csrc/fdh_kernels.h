@@ -48,6 +48,7 @@ struct CompositeParams {
   const uint32_t* backdrop;  // blurred snapshot sampled by mode 17
   int has_masks;            // the phase holds clip / rect-mask ops (disables per-strip occlusion culling)
   int has_slow;             // the phase holds draws that need the one-pixel-slot path (k_composite_tiles<3>)
+  int has_slow_atlas = 0;   // ... atlas quads among them: k_composite_tiles<19>, the same build at three waves per SIMD (168 registers)
   int has_rot;              // ... or rotated SDF quads the 4-wide path takes (k_composite_tiles<8>, or <3> with the others)
   int has_atlas;            // ... or axis-aligned atlas quads at >= 1:1 (k_composite_tiles<2>)
   uint32_t* mask_spill;     // clip-stack levels beyond kMaskDepth: [level - kMaskDepth][strip][lane] (null when no frame nests that deep)

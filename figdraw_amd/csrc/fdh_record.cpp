@@ -239,7 +239,11 @@ void Recorder::commit_bins(uint32_t idx) {
   if (atlas4) sum_.has_atlas = true;
   // (a rect mask under a rotated transform -- matY.x != 0 -- is set up one pixel slot at a time; an upright one runs 4-wide)
   else if ((op == OP_DRAW || op == OP_MASK_PUSH) && (om & F_GENERAL) && (om & F_EDGE32) && !atlas_mode && mode < 18u) sum_.has_rot = true;
-  else if ((op == OP_RMASK_BEGIN && r.inv_h != 0.0f) || ((op == OP_DRAW || op == OP_MASK_PUSH) && ((om & F_GENERAL) || atlas_mode || mode >= 18u))) sum_.has_slow = true;
+  else if ((op == OP_RMASK_BEGIN && r.inv_h != 0.0f) || ((op == OP_DRAW || op == OP_MASK_PUSH) && ((om & F_GENERAL) || atlas_mode || mode >= 18u))) {
+    sum_.has_slow = true;
+    // (a quad textured with one white texel -- drawRect / drawFilledQuad: uvAt == uvTo -- samples nothing worth registers)
+    if (atlas_mode && !(mode == 0u && r.r[0] == r.r[2] && r.r[1] == r.r[3])) sum_.has_slow_atlas = true;
+  }
   if (op == OP_DRAW && !bbox_empty(b)) {  // covered fragments by mode (counted for phase 0 by the context)
     const int64_t area = (int64_t)(b.x1 - b.x0) * (b.y1 - b.y0);
     if (mode == 3u) sum_.frag_mode[0] += area; else if (mode == 7u) sum_.frag_mode[1] += area; else if (mode == 9u) sum_.frag_mode[2] += area;
@@ -1124,6 +1128,7 @@ void Context::add_sum(const PhaseSum& s, int depth_base) {
   ph.has_masks = ph.has_masks || s.has_masks;
   ph.has_atlas = ph.has_atlas || s.has_atlas;
   ph.has_slow = ph.has_slow || s.has_slow;
+  ph.has_slow_atlas = ph.has_slow_atlas || s.has_slow_atlas;
   ph.has_rot = ph.has_rot || s.has_rot;
   bbox_union(phase_u_, s.u);
   deepest_clip_ = std::max(deepest_clip_, depth_base + s.deepest);
@@ -1437,6 +1442,7 @@ void Context::splice_cached(const RetainedRoot& C) {
   sum_.has_masks = sum_.has_masks || C.sum.has_masks;
   sum_.has_atlas = sum_.has_atlas || C.sum.has_atlas;
   sum_.has_slow = sum_.has_slow || C.sum.has_slow;
+  sum_.has_slow_atlas = sum_.has_slow_atlas || C.sum.has_slow_atlas;
   sum_.has_rot = sum_.has_rot || C.sum.has_rot;
   sum_.deepest = std::max(sum_.deepest, depth_now_ + C.sum.deepest);
   for (int k = 0; k < 4; k++) sum_.frag_mode[k] += C.sum.frag_mode[k];

@@ -305,6 +305,10 @@ __device__ __forceinline__ Src shade_one(const DrawRec* __restrict__ rp, const Q
 constexpr int kFastWaves = 5;
 constexpr int kAtlasWaves = 5;  // waves per SIMD of the atlas build <2>
 constexpr int kSlowWaves = 4;  // waves per SIMD of the build with every path <3>
+// (<19> = <3> at three: a phase with atlas quads off the 4-wide path -- rotated glyph rows, minified images -- holds sixteen to thirty-two
+// texels per lane and spills 47 registers at 128; config 11 243 -> 223 us at 168 registers, while the curves of config 10, all arithmetic,
+// lose 7 % of their waves' overlap there (136 -> 146 us): the phase's content picks the form, fdh_record.cpp's has_slow_atlas)
+constexpr int kSlowAtlasWaves = 3;
 constexpr int kRotWaves = 4;  // waves per SIMD of the rotated-quad build <8>
 constexpr int kUniformWaves = 6;  // waves per SIMD of the no-clip build <4>: 80 VGPRs, no spills
 // the strip's texel window in LDS (builds with the atlas path): up to kWinCols x kWinRows texels, rows kWinStride dwords apart
@@ -378,12 +382,17 @@ __device__ __forceinline__ void composite_strip(const CompositeParams& P, const 
                                                 const int lane, const int shader_id);
 
 template <int kPaths, bool kFull, bool kDirect = false>
-__global__ __launch_bounds__(64, (kPaths & 1) ? kSlowWaves : kPaths == 4 ? kUniformWaves : (kPaths & 2) ? kAtlasWaves : (kPaths & 8) ? kRotWaves : kFastWaves) void k_composite_tiles(
+__global__ __launch_bounds__(64, (kPaths & 16) ? kSlowAtlasWaves : (kPaths & 1) ? kSlowWaves : kPaths == 4 ? kUniformWaves : (kPaths & 2) ? kAtlasWaves : (kPaths & 8) ? kRotWaves : kFastWaves) void k_composite_tiles(
     // the sixteen dwords a wave needs before anything else, as leading scalar arguments: with kernel-argument preloading
     // (-amdgpu-kernarg-preload-count, csrc/Makefile) they arrive in SGPRs with the wave instead of through a first s_load
     const int* __restrict__ a_order, int* __restrict__ a_order_next, const uint32_t* __restrict__ a_counts, const uint2* __restrict__ a_lists,
     int a_bin_x0, int a_bin_y0, int a_bin_nx, int a_bin_ny, int a_bins_x, int a_stride, int a_row_lo, int a_row_hi,
-    const DrawRec* __restrict__ draws, const QuadExt* __restrict__ exts, CompositeParams P) {
+    const DrawRec* __restrict__ draws, const QuadExt* __restrict__ exts, const CompositeParams P_in) {
+  // (a copy, so that the preloaded arguments can take their fields' places -- and the atlas read through the ORIGINAL: a mip level is picked by
+  // a run-time index, and an indexed member of a struct the kernel writes to keeps the WHOLE struct in scratch memory: the <3> build read
+  // every field of its 312-byte copy from there, tools/kernel_regs.py)
+  CompositeParams P = P_in;
+  [[maybe_unused]] const AtlasView& atlas_view = P_in.atlas;
   P.order = kFull ? a_order : nullptr; P.order_next = kFull ? a_order_next : nullptr; P.counts = a_counts; P.lists = a_lists;
   if (kFull) P.load_fb = 0;
   P.bin_x0 = a_bin_x0; P.bin_y0 = a_bin_y0; P.bin_nx = a_bin_nx; P.bin_ny = a_bin_ny;
@@ -407,7 +416,7 @@ __global__ __launch_bounds__(64, (kPaths & 1) ? kSlowWaves : kPaths == 4 ? kUnif
     // One extra wavefront per full-frame launch sorts THIS frame's bin counts for the NEXT frame's launch (any
     // permutation is a correct schedule, and list lengths barely change from frame to frame).  As a kernel of its own the
     // sort was a ~6 us serial step of every frame; here it runs beside 32 000 compositing waves.
-    order_bins_wave(P.counts, P.order_next, P.bin_nx, P.bin_nx * P.bin_ny, &mask_stack[0][0][0], threadIdx.x, (int)blockIdx.x, P.deep_min, P.deep_out);
+    order_bins_wave(P.counts, P.order_next, P.bin_nx, P.bin_nx * P.bin_ny, &mask_stack[0][0][0], threadIdx.x, (int)blockIdx.x, kPaths == 4 ? P.deep_min : 0, kPaths == 4 ? P.deep_out : nullptr);
     return;
   }
   int bin_local = xcd + 8 * (q / kStripsPerBin);
@@ -510,6 +519,7 @@ template <int kPaths, bool kFull, int kRole, bool kDirect>
 __device__ __forceinline__ void composite_strip(const CompositeParams& P, const DrawRec* __restrict__ draws, const QuadExt* __restrict__ exts,
                                                 uint32_t* composite_lds, const int bin, const int sidx, const int sbit, const int tx0, const int ty0,
                                                 const int lane, const int shader_id) {
+  [[maybe_unused]] const AtlasView& atlas_view = P.atlas;
 #include "k_composite_strip.inc"
 }
 
@@ -526,6 +536,7 @@ void launch_composite(hipStream_t s, const DrawRec* draws, const QuadExt* exts, 
   // the same pixels (tests/test_hip_parity.py)
   static const int force = [] { const char* e = std::getenv("FDH_FORCE_KERNEL_PATHS"); return e ? std::atoi(e) : 0; }();
   if (force == 3) P.has_slow = 1;
+  if (force == 19) { P.has_slow = 1; P.has_slow_atlas = 1; }
   if (force == 8) P.has_rot = 1;
   if (force == 2) P.has_atlas = 1;
   if (force == 1) P.has_masks = 1;  // (the build with mask registers and the 4-KB stack, even where no clip is open)
@@ -542,11 +553,11 @@ void launch_composite(hipStream_t s, const DrawRec* draws, const QuadExt* exts, 
   do { if (full) FDH_LAUNCH((k_composite_tiles<paths, true>), dim3(grid), blk, lds, s, P.order, P.order_next, P.counts, P.lists, P.bin_x0, P.bin_y0, P.bin_nx, P.bin_ny, P.bins_x, P.stride, P.row_lo, P.row_hi, draws, exts, P); \
        else FDH_LAUNCH((k_composite_tiles<paths, false>), dim3(grid), blk, lds, s, P.order, P.order_next, P.counts, P.lists, P.bin_x0, P.bin_y0, P.bin_nx, P.bin_ny, P.bins_x, P.stride, P.row_lo, P.row_hi, draws, exts, P); } while (0)
 #if FDH_SPLIT_UNIFORM
-  if (P.has_slow || (P.has_rot && P.has_atlas)) FDH_COMPOSITE(3);
+  if (P.has_slow || (P.has_rot && P.has_atlas)) { if (P.has_slow_atlas) FDH_COMPOSITE(19); else FDH_COMPOSITE(3); }
   else if (P.has_rot) FDH_COMPOSITE(8);
   else { launch_composite_uniform(s, t_prof_start, t_prof_stop, grid, lds, draws, exts, P, P.has_atlas ? 2 : P.has_masks ? 0 : 4); if (t_prof_start) t_prof_used = true; }
 #else
-  if (P.has_slow || (P.has_rot && P.has_atlas)) FDH_COMPOSITE(3);
+  if (P.has_slow || (P.has_rot && P.has_atlas)) { if (P.has_slow_atlas) FDH_COMPOSITE(19); else FDH_COMPOSITE(3); }
   else if (P.has_rot) FDH_COMPOSITE(8);
   else if (P.direct) { if (P.has_atlas) FDH_COMPOSITE_DIRECT(2); else if (!P.has_masks) FDH_COMPOSITE_DIRECT(4); else FDH_COMPOSITE_DIRECT(0); }
   else if (P.has_atlas) FDH_COMPOSITE(2);

@@ -105,12 +105,12 @@ def test_render_is_deterministic_and_replay_is_idempotent(hip):
     assert (a == b).all() and (a == c).all()
 
 
-@pytest.mark.parametrize("paths", [1, 2, 3, 8])
+@pytest.mark.parametrize("paths", [1, 2, 3, 8, 19])
 def test_every_kernel_build_gives_the_same_pixels(hip, paths):
     """k_composite_tiles comes in five builds picked per phase: <4> SDF draws without clip operations, <0> + clip masks,
     <2> + the 4-wide atlas path, <8> + the 4-wide path for rotated SDF quads, <3> + everything incl. the one-pixel-slot path (the
     first three live in the uniform-regions translation unit, the last two in the default one).  Forcing the more general builds
-    (1: <0>, 2: <2>, 8: <8>, 3: <3>) onto scenes that do not need them (a child process with FDH_FORCE_KERNEL_PATHS) must not
+    (1: <0>, 2: <2>, 8: <8>, 3: <3>, 19: <3> at the register budget of phases with atlas quads off the 4-wide path) onto scenes that do not need them (a child process with FDH_FORCE_KERNEL_PATHS) must not
     change a pixel -- the rotated scenes included, whose quads <8> and <3> shade with the same code."""
     import os
     import subprocess
@@ -209,7 +209,7 @@ def test_direct_launches_give_the_same_pixels():
             res[tag] = dict(np.load(path))
             binms[tag] = eval([ln for ln in r.stdout.splitlines() if ln.startswith("BINMS ")][-1][6:])
     assert all(v > 0 for v in binms["bin"].values()), binms
-    if os.environ.get("FDH_FORCE_KERNEL_PATHS") not in ("3", "8"):  # (tools/suite_off_defaults.sh: the slot / rotated builds have no direct form)
+    if os.environ.get("FDH_FORCE_KERNEL_PATHS") not in ("3", "8", "19"):  # (tools/suite_off_defaults.sh: the slot / rotated builds have no direct form)
         assert binms["direct"]["rgb_boxes_sdf"] == 0 and binms["direct"]["nested_clips"] == 0 and binms["direct"]["tree8"] == 0, binms   # no bin launch
     assert binms["direct"]["tree40"] > 0, binms  # (283 draws in its first phase: over the limit)
     for k in res["bin"]:

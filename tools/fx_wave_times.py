@@ -40,3 +40,16 @@ for k in (1, n_seg - 1):
     print(f"segment {k}: per H-block (ns) wait {(r[m_,2]/nb[m_]).mean()*tick:.0f} h-product {(r[m_,3]/nb[m_]).mean()*tick:.0f} rounding + v-product {(r[m_,4]/nb[m_]).mean()*tick:.0f} "
           f"epilogue {(r[m_,5]/nb[m_]).mean()*tick:.0f} stores {(r[m_,7]/nb[m_]).mean()*tick:.0f} prologue {r[m_,1].mean()*tick:.0f}; V blocks {r[m_,10].mean():.1f}")
 print("mean / max life (us) by segment:", " ".join(f"{int(k)}:{life[seg == k].mean():.1f}/{life[seg == k].max():.1f}" for k in np.unique(seg)))
+# edge strip groups (their shared window crosses the frame's left / right edge; their blocks lie on the fused quad's border) against the rest
+def brk(name, m_):
+    print(f"{name}: {int(m_.sum())} waves, life {life[m_].mean():.1f} us; per H-block (ns) wait {(r[m_,2]/nb[m_]).mean()*tick:.0f} h-product {(r[m_,3]/nb[m_]).mean()*tick:.0f} "
+          f"dma issue {(r[m_,12]/nb[m_]).mean()*tick:.0f} rounding + v-product {((r[m_,4]-r[m_,12])/nb[m_]).mean()*tick:.0f} epilogue {(r[m_,5]/nb[m_]).mean()*tick:.0f} "
+          f"stores {(r[m_,7]/nb[m_]).mean()*tick:.0f} prologue {r[m_,1].mean()*tick:.0f}")
+inner_seg = (seg > 0) & (seg < n_seg - 1)
+brk("left edge group, inner segments", (sg == 0) & inner_seg)
+for k in range(4): brk(f"   its wave {k}", (sg == 0) & inner_seg & (wv == k))
+brk("right edge group, inner segments", (sg == n_sg - 1) & inner_seg)
+for k in range(4): brk(f"   its wave {k}", (sg == n_sg - 1) & inner_seg & (wv == k))
+brk("interior groups, inner segments", (sg > 0) & (sg < n_sg - 1) & inner_seg)
+brk("interior groups, first segment", (sg > 0) & (sg < n_sg - 1) & (seg == 0))
+brk("interior groups, last segment", (sg > 0) & (sg < n_sg - 1) & (seg == n_seg - 1))
