@@ -85,9 +85,11 @@ struct Rec {
 };
 }  // namespace
 struct RecPause {  // a backend method that calls other backend methods records only itself
+  // (writes the flag only where it was on -- i.e. on the calling thread while the call recorder runs, when nothing is handed to the walk
+  // pool: written unconditionally, false over false, it was a data race between the pool's threads; ThreadSanitizer, profiles/r06_host_asan.txt)
   bool& on; const bool was;
-  explicit RecPause(bool& o) : on(o), was(o) { on = false; }
-  ~RecPause() { on = was; }
+  explicit RecPause(bool& o) : on(o), was(o) { if (was) on = false; }
+  ~RecPause() { if (was) on = true; }
 };
 // (the recorder only ever runs on the calling thread's recorder: while it is on nothing is handed to the walk pool)
 #define FDH_REC(name) Rec rec_scope_(cx_->rec_, cx_->rec_first_, cx_->rec_on_ && is_main_, name, &cx_->rec_mark_, &cx_->rec_mark_first_); rec_scope_
