@@ -1074,7 +1074,9 @@ void Context::prepare(LaunchJob& J) {
     store_fence();  // (what this thread wrote into device memory is on its way before the launches are)
     // ... and what it and the pool's threads wrote is pushed out of the host data path: without this, frames of fresh contexts on
     // several host threads came out wrong -- or faulted -- in ~5 % of tools/thread_churn.py runs (end of round 4)
-    if (hdp_flush_reg_) { *hdp_flush_reg_ = 1u; store_fence(); }
+    // (a device register every context of the device writes 1 to, from whichever host thread renders it: an atomic store, so that the
+    // language knows too)
+    if (hdp_flush_reg_) { __atomic_store_n(hdp_flush_reg_, 1u, __ATOMIC_RELAXED); store_fence(); }
   }
   const auto t_l0 = std::chrono::steady_clock::now();
   stats_.ms_host_record = host_record_ms_;
