@@ -221,7 +221,10 @@ __global__ __launch_bounds__(64) void k_bin_draws(BinParams P) {
   const int c_last = (last - 1) >> 8;
   for (int c0 = first >> 8; c0 <= c_last && first < last; c0 += 64) {
     const int cl = c0 + lane;
-    unsigned long long live = __ballot(cl <= c_last && binbox_hits(P.chunkbox[min(cl, c_last)], U));
+    // (a phase of at most kAhead chunks -- the bench frame's 707 draws are three -- walks them all: their boxes are fetched together
+    // anyway, and the chunk boxes in front were one more dependent round trip of a launch that is four of them)
+    const bool few = c_last - (first >> 8) < kAhead;  // (wave-uniform)
+    unsigned long long live = few ? __ballot(cl <= c_last) : __ballot(cl <= c_last && binbox_hits(P.chunkbox[min(cl, c_last)], U));
     while (live) {
     int cs[kAhead];
     uint4 qc[kAhead];

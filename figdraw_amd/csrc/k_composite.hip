@@ -535,7 +535,7 @@ void launch_composite(hipStream_t s, const DrawRec* draws, const QuadExt* exts, 
   // FDH_FORCE_KERNEL_PATHS=3 (or 2, or 1): run a more general build than the phase needs -- a test hook: every build must give
   // the same pixels (tests/test_hip_parity.py)
   static const int force = [] { const char* e = std::getenv("FDH_FORCE_KERNEL_PATHS"); return e ? std::atoi(e) : 0; }();
-  if (force == 3) P.has_slow = 1;
+  if (force == 3) { P.has_slow = 1; P.has_slow_atlas = 0; }  // (<3> itself, also where the phase would take its 168-register form)
   if (force == 19) { P.has_slow = 1; P.has_slow_atlas = 1; }
   if (force == 8) P.has_rot = 1;
   if (force == 2) P.has_atlas = 1;

@@ -132,8 +132,16 @@ def test_every_kernel_build_gives_the_same_pixels(hip, paths):
         "ctx.render_frame(sc, 700, 500); out['fuzz'] = ctx.read_pixels()\n"
         "from figdraw_amd.scenes import make_rotated_tree\n"
         "ctx.render_frame(make_rotated_tree(1280, 720, 3, copies=30), 1280, 720); out['rotated'] = ctx.read_pixels()\n"
+        "# glyph rows turned by 2 degrees: atlas quads off the 4-wide path -- by default the slot build's 168-register form <19>, forced 3: <3> itself\n"
+        "from figdraw_amd.scenes import make_glyph_scene, load_glyph_fixture\n"
+        "imgs = load_glyph_fixture(%r)\n"
+        "ctx2 = HipContext(atlas_size=1024, device=0)\n"
+        "sc = make_glyph_scene(900.0, 500.0, imgs, cols=22, rows=22, rotation=2.0)\n"
+        "for k, v in RS.used_images(sc, imgs).items(): ctx2.put_image(k, v)\n"
+        "ctx2.render_frame(sc, 900, 500); out['rotated_glyphs'] = ctx2.read_pixels()\n"
         "np.savez(sys.argv[1], **out)\n"
-    ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)), names)
+    ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)), names,
+         os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "glyphs_ubuntu20.npz"))
     with tempfile.TemporaryDirectory() as td:
         res = {}
         for tag, env in (("default", {}), ("forced", {"FDH_FORCE_KERNEL_PATHS": str(paths)})):
