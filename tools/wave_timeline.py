@@ -51,6 +51,9 @@ for rl, name in ((1, "one-wave strips"), (2, "deep strips' blenders"), (3, "deep
     k = role == rl
     if not k.any():
         continue
+    if rl == 2:  # (columns 11 / 15 of a blender's row: cycles between asking for a slot and having it, polls that found it unpublished)
+        tw, npoll = t[:, 11][keep][k], t[:, 15][keep][k]
+        print(f"   blenders: {100.0 * tw.sum() / cyc[k].sum():.0f} % of their cycles between asking for a slot and having it; {npoll.sum() / max(draws[k].sum(), 1):.2f} polls per list entry found the slot unpublished")
     d_, n_, s_, e_ = dur[k], draws[k], start[k], end[k]
     print(f"-- {name}: {int(k.sum())} waves; duration us p50 {np.percentile(d_, 50):.1f} p90 {np.percentile(d_, 90):.1f} p99 {np.percentile(d_, 99):.1f} max {d_.max():.1f}; list entries walked p50 {np.percentile(n_, 50):.0f} p90 {np.percentile(n_, 90):.0f} max {n_.max():.0f}; start p50 {np.percentile(s_, 50):.1f} max {s_.max():.1f}; end max {e_.max():.1f}")
     for lo, hi in ((0, 0), (1, 4), (5, 9), (10, 19), (20, 29), (30, 39), (40, 59), (60, 999)):
